@@ -1,0 +1,135 @@
+"""ctypes loader for the CPU oracle (oracle/liblc3oracle.so).
+
+Test infrastructure only: the product package never imports this module.
+The library is built on demand with oracle/Makefile (plain gcc)."""
+import ctypes
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liblc3oracle.so")
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+        if not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+            build()
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.lc3o_encoder_new.restype = ctypes.c_void_p
+        _lib.lc3o_decoder_new.restype = ctypes.c_void_p
+        _lib.lc3o_encoder_free.argtypes = [ctypes.c_void_p]
+        _lib.lc3o_decoder_free.argtypes = [ctypes.c_void_p]
+        _lib.lc3o_kat_powf.restype = ctypes.c_float
+        _lib.lc3o_kat_powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    return _lib
+
+
+def P(a):
+    """pointer to a numpy array's data"""
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+_kats = None
+
+
+def kats():
+    global _kats
+    if _kats is None:
+        with open(os.path.join(ROOT, "tests", "golden", "ref_kats.json")) as f:
+            _kats = json.load(f)
+    return _kats
+
+
+def kat(test, name=None, index=None, dtype=None):
+    """Fetch one vector of a reference test: by let-binding name (n-th occurrence) or by position."""
+    entries = kats()[test]
+    if name is not None:
+        sel = [e for e in entries if e["name"] == name]
+        e = sel[index or 0]
+    else:
+        e = entries[index]
+    v = e["values"]
+    return np.array(v, dtype=dtype) if dtype is not None else v
+
+
+class Encoder:
+    """One channel of the oracle encoder (mirrors Lc3Encoder with num_channels = 1)."""
+
+    def __init__(self, fs_hz=48000, frame_us=10000):
+        self.L = lib()
+        self.h = ctypes.c_void_p(self.L.lc3o_encoder_new(fs_hz, frame_us))
+        assert self.h, "unsupported configuration"
+        cfg = np.zeros(7, np.int32)
+        self.L.lc3o_kat_config(fs_hz, frame_us, P(cfg))
+        self.nf = int(cfg[5])
+        self.ne = int(cfg[2])
+
+    def encode_frame(self, pcm, nbytes):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        assert pcm.size == self.nf
+        out = np.zeros(nbytes, np.uint8)
+        self.L.lc3o_encode_frame(self.h, P(pcm), P(out), nbytes)
+        return out
+
+    def __del__(self):
+        try:
+            self.L.lc3o_encoder_free(self.h)
+        except Exception:
+            pass
+
+
+class Decoder:
+    def __init__(self, fs_hz=48000, frame_us=10000):
+        self.L = lib()
+        self.h = ctypes.c_void_p(self.L.lc3o_decoder_new(fs_hz, frame_us))
+        assert self.h, "unsupported configuration"
+        cfg = np.zeros(7, np.int32)
+        self.L.lc3o_kat_config(fs_hz, frame_us, P(cfg))
+        self.nf = int(cfg[5])
+        self.ne = int(cfg[2])
+
+    def decode_frame(self, buf, bits_per_sample=16):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        out = np.zeros(self.nf, np.int16)
+        rc = self.L.lc3o_decode_frame(self.h, bits_per_sample, P(buf), int(buf.size), P(out))
+        return rc, out
+
+    def last_was_plc(self):
+        return bool(self.L.lc3o_decoder_last_plc(self.h))
+
+    def __del__(self):
+        try:
+            self.L.lc3o_decoder_free(self.h)
+        except Exception:
+            pass
+
+
+def encode_batch(pcm, nbytes, fs_hz=48000, frame_us=10000, threads=1):
+    """pcm int16[S][T][nf] -> uint8[S][T][nbytes]; every stream starts from a fresh encoder."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    S, T, nf = pcm.shape
+    out = np.zeros((S, T, nbytes), np.uint8)
+    rc = lib().lc3o_encode_batch(fs_hz, frame_us, nbytes, S, T, P(pcm), P(out), threads)
+    assert rc == 0
+    return out
+
+
+def decode_batch(data, nf, fs_hz=48000, frame_us=10000, threads=1):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    S, T, nbytes = data.shape
+    out = np.zeros((S, T, nf), np.int16)
+    rc = lib().lc3o_decode_batch(fs_hz, frame_us, nbytes, S, T, P(data), P(out), threads)
+    assert rc == 0
+    return out
