@@ -1,0 +1,119 @@
+/* lc3gpu -- C ABI of the MI355X-native batched LC3 codec (liblc3gpu.so).
+ *
+ * Drop-in boundary for the per-frame hot path of ninjasource/lc3-codec v0.2.0:
+ *   Lc3Encoder::{calc_working_buffer_lengths,new,encode_frame}   reference src/encoder/lc3_encoder.rs:117-209
+ *   Lc3Decoder::{calc_working_buffer_lengths,new,decode_frame}   reference src/decoder/lc3_decoder.rs:181-244
+ * A handle owns N independent codec channels ("streams") on one HIP device; each stream is one
+ * reference EncoderChannel / DecoderChannel with its own carried state.  The batch calls process
+ * `n_streams x n_frames` frames per launch: one CDNA4 wavefront per stream, frames of a stream in
+ * time order.  The *_frame calls are the n_streams = 1, n_frames = 1 case with host buffers and
+ * have the reference's argument meaning (slice lengths select the frame size / bitrate).
+ *
+ * Plain C types only (pointers + sizes); no torch / C++ types cross this boundary.
+ * All functions return LC3GPU_OK (0) or a negative LC3GPU_E* code; nothing aborts across the ABI:
+ * where the reference panics (bad channel index, wrong slice length: lc3_encoder.rs:181-190,
+ * encoder/modified_dct.rs:109-111) an error code is returned instead.  Corrupt frames are NOT
+ * errors: as in the reference (lc3_decoder.rs:138-141) they are concealed (PLC) and counted.
+ * Handles are not thread-safe (mirrors `&mut self`); distinct handles may be used concurrently.
+ */
+#ifndef LC3GPU_H_
+#define LC3GPU_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LC3GPU_OK 0
+#define LC3GPU_EINVAL -1        /* bad argument (unsupported fs / duration, null pointer, size mismatch) */
+#define LC3GPU_ECHANNEL -2      /* channel index out of range (reference: panic, lc3_encoder.rs:185-189) */
+#define LC3GPU_ELENGTH -3       /* samples / buffer length mismatch (reference: assert_eq! panic) */
+#define LC3GPU_EBITS -4         /* Lc3DecoderError::Only16BitsPerAudioSampleSupported (lc3_decoder.rs:80-82) */
+#define LC3GPU_EHIP -5          /* HIP runtime error; see lc3gpu_last_hip_error() */
+#define LC3GPU_ENODEVICE -6     /* no usable HIP device */
+#define LC3GPU_EUNSUPPORTED -7  /* configuration the reference cannot run (8 kHz encode: bandwidth_detector.rs:36-37) */
+
+typedef struct lc3gpu_encoder lc3gpu_encoder;
+typedef struct lc3gpu_decoder lc3gpu_decoder;
+
+/* library / device */
+int lc3gpu_version(void);
+const char *lc3gpu_strerror(int code);
+int lc3gpu_last_hip_error(void);
+int lc3gpu_device_count(void);
+
+/* common/config.rs:42-100 -- out[7] = {fs_ind, fs, ne, n_ms_is_10, nb, nf, z} */
+int lc3gpu_config(int frame_us, int fs_hz, int out[7]);
+
+/* Lc3Encoder::calc_working_buffer_lengths (lc3_encoder.rs:194-209): out = {i16_len, f32_len, complex_len}.
+ * Kept for API parity; the GPU engine allocates its own device memory. */
+int lc3gpu_encoder_working_buffer_lengths(int num_channels, int frame_us, int fs_hz, int64_t out[3]);
+/* Lc3Decoder::calc_working_buffer_lengths (lc3_decoder.rs:236-244): out = {f32_len, complex_len} */
+int lc3gpu_decoder_working_buffer_lengths(int num_channels, int frame_us, int fs_hz, int64_t out[2]);
+
+/* ---- encoder ------------------------------------------------------------------------------------ */
+/* Lc3Encoder::new (lc3_encoder.rs:117-173): num_channels fresh channels on the current HIP device. */
+int lc3gpu_encoder_create(lc3gpu_encoder **out, int num_channels, int frame_us, int fs_hz);
+int lc3gpu_encoder_destroy(lc3gpu_encoder *enc);
+/* back to the freshly constructed state (all channels) */
+int lc3gpu_encoder_reset(lc3gpu_encoder *enc);
+
+/* Lc3Encoder::encode_frame (lc3_encoder.rs:175-191), host buffers.
+ * samples_in: n_samples (must be nf) planar i16; buf_out: nbytes (= buf_out.len(), selects the bitrate). */
+int lc3gpu_encode_frame(lc3gpu_encoder *enc, int channel_index, const int16_t *samples_in, int n_samples,
+                        uint8_t *buf_out, int nbytes);
+
+/* Batch: every channel encodes n_frames consecutive frames.  DEVICE pointers, stream-major:
+ *   d_pcm  int16[num_channels][n_frames][nf]      (4-byte aligned)
+ *   d_out  uint8[num_channels][n_frames][nbytes]
+ * Asynchronous on hip_stream (a hipStream_t, may be NULL for the default stream). */
+int lc3gpu_encode(lc3gpu_encoder *enc, const int16_t *d_pcm, uint8_t *d_out, int nbytes, int n_frames,
+                  void *hip_stream);
+/* same, restricted to channels [first_channel, first_channel + n_channels); buffers hold only those channels */
+int lc3gpu_encode_range(lc3gpu_encoder *enc, int first_channel, int n_channels, const int16_t *d_pcm,
+                        uint8_t *d_out, int nbytes, int n_frames, void *hip_stream);
+
+/* per-channel state blobs (checkpoint / CPU cross-checks): size per channel, device->host copy, host->device */
+size_t lc3gpu_encoder_state_size(const lc3gpu_encoder *enc);
+int lc3gpu_encoder_state_save(lc3gpu_encoder *enc, void *host_dst);
+int lc3gpu_encoder_state_load(lc3gpu_encoder *enc, const void *host_src);
+
+/* ---- decoder ------------------------------------------------------------------------------------ */
+/* Lc3Decoder::new (lc3_decoder.rs:181-215) */
+int lc3gpu_decoder_create(lc3gpu_decoder **out, int num_channels, int frame_us, int fs_hz);
+int lc3gpu_decoder_destroy(lc3gpu_decoder *dec);
+int lc3gpu_decoder_reset(lc3gpu_decoder *dec);
+
+/* Lc3Decoder::decode_frame (lc3_decoder.rs:217-234), host buffers.  num_bits_per_audio_sample must be 16. */
+int lc3gpu_decode_frame(lc3gpu_decoder *dec, int num_bits_per_audio_sample, int channel_index,
+                        const uint8_t *buf_in, int nbytes, int16_t *samples_out, int n_samples);
+
+/* Batch decode, DEVICE pointers, stream-major:
+ *   d_in   uint8[num_channels][n_frames][nbytes]
+ *   d_pcm  int16[num_channels][n_frames][nf]      (4-byte aligned)
+ *   d_bad_frame  optional uint8[num_channels][n_frames]: non-zero marks a lost frame -> concealment
+ *                (external bad-frame indicator; NULL = none) */
+int lc3gpu_decode(lc3gpu_decoder *dec, const uint8_t *d_in, const uint8_t *d_bad_frame, int16_t *d_pcm, int nbytes,
+                  int n_frames, void *hip_stream);
+int lc3gpu_decode_range(lc3gpu_decoder *dec, int first_channel, int n_channels, const uint8_t *d_in,
+                        const uint8_t *d_bad_frame, int16_t *d_pcm, int nbytes, int n_frames, void *hip_stream);
+
+size_t lc3gpu_decoder_state_size(const lc3gpu_decoder *dec);
+int lc3gpu_decoder_state_save(lc3gpu_decoder *dec, void *host_dst);
+int lc3gpu_decoder_state_load(lc3gpu_decoder *dec, const void *host_src);
+/* total number of frames concealed so far over all channels (synchronises the device) */
+int lc3gpu_decoder_plc_events(lc3gpu_decoder *dec, uint64_t *out);
+
+/* ---- diagnostics -------------------------------------------------------------------------------- */
+/* encode one frame of channel 0 from host PCM and also return stage dumps:
+ * dbg float[1472] = spectrum after MDCT [0,480), after SNS [480,960), after TNS [960,1440), scalars [1440,1472) */
+int lc3gpu_encode_frame_debug(lc3gpu_encoder *enc, const int16_t *samples_in, int n_samples, uint8_t *buf_out,
+                              int nbytes, float *dbg);
+/* kernel resource report: out = {lds_bytes, vgprs, sgprs, scratch_bytes, max_threads} for 0 = encoder, 1 = decoder */
+int lc3gpu_kernel_info(int which, int out[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LC3GPU_H_ */

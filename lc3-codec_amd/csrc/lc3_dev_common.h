@@ -1,0 +1,545 @@
+// LC3 batched codec for MI355X (gfx950) -- device-side common layer.
+//
+// Execution model: ONE WAVEFRONT (64 lanes) PER STREAM.  A stream is one codec
+// channel (the reference's EncoderChannel / DecoderChannel, encoder/lc3_encoder.rs:42-60,
+// decoder/lc3_decoder.rs:62-69); its frames are processed in time order by the
+// same wave with all working data resident in LDS.  Every routine here takes the
+// caller's lane id and is executed by all 64 lanes of the wave; lane-parallel
+// loops stride by 64, inherently serial recurrences run on lane 0 while the
+// others wait at the next LC3_SYNC().
+//
+// Bit-exactness contract (SURVEY.md section 7 "design rule"): parallelise across
+// OUTPUTS, never inside one of the reference's f32 summations; every f32
+// expression keeps the reference's evaluation order; build with
+// -ffp-contract=off so no mul+add is fused.
+//
+// The including translation unit provides LC3_SYNC() (a workgroup barrier for the
+// one-wave workgroup) and the __device__ / __forceinline__ keywords.
+#pragma once
+#include <stdint.h>
+
+#define LC3_TABLE_QUAL static __device__ const
+#include "../../tables/lc3_tables.h"
+
+#define LC3_WAVE 64
+#define LC3_MAX_NF 480
+#define LC3_MAX_NE 400
+
+struct lc3_cpx {
+    float r, i;
+};
+
+// Per-configuration constants (reference common/config.rs:18-100) plus the derived
+// transform plan.  Passed to kernels by value (wave-uniform -> SGPRs).
+struct lc3_cfg {
+    int fs, fs_ind, nf, ne, nb, z, n_ms_10;
+    // mixed-radix plan of the nf/2-point complex FFT (common/kissfft.rs:47-76)
+    int nfft, n_stages;
+    int radix[6], m[6], fstride[6];
+    // device tables owned by the codec handle
+    const lc3_cpx *fft_tw;  // exp(-2*pi*i*k/nfft), f64 -> f32 (kissfft.rs:19-27)
+    const lc3_cpx *dct_tw;  // exp(-i*pi*(8n+1)/(8*nf)), f64 -> f32 (dct_iv.rs:30-35)
+    const uint16_t *perm;   // leaf gather order of kf_work (kissfft.rs:101-108)
+    // encoder LTPF (encoder/long_term_post_filter.rs:93-127)
+    int len12, len6, delay12, p_up, hist;
+    float resamp_scale;  // p as f32 * resampling_factor
+    // decoder LTPF (decoder/long_term_post_filter.rs:104-134)
+    int l_den, l_num, num_mem_blocks, norm, s25;
+};
+
+__device__ __forceinline__ float lc3_f(const uint32_t *tab, int i) { return __builtin_bit_cast(float, tab[i]); }
+__device__ __forceinline__ float lc3_from_bits(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t lc3_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ double lc3_d_from_bits(uint64_t u) { return __builtin_bit_cast(double, u); }
+
+// f32::max / f32::min: NaN-ignoring (Rust core::f32)
+__device__ __forceinline__ float lc3_maxf(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? b : a)); }
+__device__ __forceinline__ float lc3_minf(float a, float b) { return (a != a) ? b : ((b != b) ? a : (b < a ? b : a)); }
+__device__ __forceinline__ float lc3_absf(float a) { return lc3_from_bits(lc3_bits(a) & 0x7fffffffu); }
+
+// Rust `as` casts are saturating with NaN -> 0
+__device__ __forceinline__ int32_t lc3_f2i32(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return (-2147483647 - 1);
+    return (int32_t)x;
+}
+__device__ __forceinline__ int32_t lc3_f2i16(float x) {
+    if (x != x) return 0;
+    if (x >= 32767.0f) return 32767;
+    if (x <= -32768.0f) return -32768;
+    return (int32_t)x;
+}
+__device__ __forceinline__ int32_t lc3_f2i8(float x) {
+    if (x != x) return 0;
+    if (x >= 127.0f) return 127;
+    if (x <= -128.0f) return -128;
+    return (int32_t)x;
+}
+__device__ __forceinline__ int32_t lc3_f2u16(float x) {
+    if (x != x) return 0;
+    if (x >= 65535.0f) return 65535;
+    if (x <= 0.0f) return 0;
+    return (int32_t)x;
+}
+__device__ __forceinline__ int lc3_ilog2(uint32_t v) { return 31 - __builtin_clz(v | 1u); }
+
+// exact IEEE operations the reference relies on.  With hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt both are correctly rounded.
+__device__ __forceinline__ float lc3_sqrtf(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float lc3_floorf(float x) { return __builtin_floorf(x); }
+__device__ __forceinline__ float lc3_ceilf(float x) { return __builtin_ceilf(x); }
+
+// ------------------------------------------------------------------------------------------
+// Float library.  The reference is no_std: every f32 method resolves through num_traits to the
+// `libm` crate (reference Cargo.toml:17), a port of the FreeBSD msun routines.  These are the same
+// published algorithms written for the GPU: plain f32 (f64 where msun uses double), no FMA.
+// Call sites are cited where they are used.
+// ------------------------------------------------------------------------------------------
+
+// e_powf.c, specialised for the only base the codec uses: x = 10 (interval k = 1, n = 3)
+// and finite y with |y| < 2^27 (encoder/spectral_noise_shaping.rs:218,
+// encoder/spectral_quantization.rs:239, decoder/global_gain.rs:20).
+__device__ __forceinline__ float lc3_pow10f(float y) {
+    const float L1 = lc3_from_bits(0x3f19999au), L2 = lc3_from_bits(0x3edb6db7u), L3 = lc3_from_bits(0x3eaaaaabu);
+    const float L4 = lc3_from_bits(0x3e8ba305u), L5 = lc3_from_bits(0x3e6c3255u), L6 = lc3_from_bits(0x3e53f142u);
+    const float P1 = lc3_from_bits(0x3e2aaaabu), P2 = lc3_from_bits(0xbb360b61u), P3 = lc3_from_bits(0x388ab355u);
+    const float P4 = lc3_from_bits(0xb5ddea0eu), P5 = lc3_from_bits(0x3331bb4cu);
+    const float lg2 = lc3_from_bits(0x3f317218u), lg2_h = lc3_from_bits(0x3f317200u), lg2_l = lc3_from_bits(0x35bfbe8cu);
+    const float ovt = 4.2995665694e-08f;
+    const float cp = lc3_from_bits(0x3f76384fu), cp_h = lc3_from_bits(0x3f764000u), cp_l = lc3_from_bits(0xb8f623c6u);
+    const float dp_h = lc3_from_bits(0x3f15c000u), dp_l = lc3_from_bits(0x35d1cfdcu);
+    const float huge = 1.0e30f, tiny = 1.0e-30f;
+    const float bp = 1.5f;
+    uint32_t hy = lc3_bits(y), iy = hy & 0x7fffffffu;
+    if (iy == 0) return 1.0f;
+    if (iy > 0x7f800000u) return 10.0f + y;
+    if (iy == 0x7f800000u) return (hy >> 31) ? 0.0f : y;
+    if (iy == 0x3f800000u) return (hy >> 31) ? 1.0f / 10.0f : 10.0f;
+    if (hy == 0x40000000u) return 10.0f * 10.0f;
+    if (hy == 0x3f000000u) return lc3_sqrtf(10.0f);
+    float t1, t2;
+    {
+        // ix(10.0f) = 0x41200000: n = 3, j = 0x200000 -> interval k = 1, normalised ax = 1.25
+        const int32_t ix = 0x3fa00000;
+        const float ax = 1.25f;
+        float u = ax - bp;
+        float v = 1.0f / (ax + bp);
+        float s = u * v;
+        float s_h = lc3_from_bits(lc3_bits(s) & 0xfffff000u);
+        uint32_t is = (((uint32_t)ix >> 1) & 0xfffff000u) | 0x20000000u;
+        float t_h = lc3_from_bits(is + 0x00400000u + (1u << 21));
+        float t_l = ax - (t_h - bp);
+        float s_l = v * ((u - s_h * t_h) - s_h * t_l);
+        float s2 = s * s;
+        float r = s2 * s2 * (L1 + s2 * (L2 + s2 * (L3 + s2 * (L4 + s2 * (L5 + s2 * L6)))));
+        r += s_l * (s_h + s);
+        s2 = s_h * s_h;
+        t_h = 3.0f + s2 + r;
+        t_h = lc3_from_bits(lc3_bits(t_h) & 0xfffff000u);
+        t_l = r - ((t_h - 3.0f) - s2);
+        u = s_h * t_h;
+        v = s_l * t_h + t_l * s;
+        float p_h = u + v;
+        p_h = lc3_from_bits(lc3_bits(p_h) & 0xfffff000u);
+        float p_l = v - (p_h - u);
+        float z_h = cp_h * p_h;
+        float z_l = cp_l * p_h + p_l * cp + dp_l;
+        float t = 3.0f;
+        t1 = (((z_h + z_l) + dp_h) + t);
+        t1 = lc3_from_bits(lc3_bits(t1) & 0xfffff000u);
+        t2 = z_l - (((t1 - t) - dp_h) - z_h);
+    }
+    float y1 = lc3_from_bits(hy & 0xfffff000u);
+    float p_l = (y - y1) * t1 + y * t2;
+    float p_h = y1 * t1;
+    float z = p_l + p_h;
+    int32_t j = (int32_t)lc3_bits(z);
+    if (j > 0x43000000) return huge * huge;
+    else if (j == 0x43000000) {
+        if (p_l + ovt > z - p_h) return huge * huge;
+    } else if ((j & 0x7fffffff) > 0x43160000) return tiny * tiny;
+    else if ((uint32_t)j == 0xc3160000u) {
+        if (p_l <= z - p_h) return tiny * tiny;
+    }
+    int32_t i = j & 0x7fffffff;
+    int32_t k = (i >> 23) - 0x7f;
+    int32_t n = 0;
+    if (i > 0x3f000000) {
+        n = j + (0x00800000 >> (k + 1));
+        k = ((n & 0x7fffffff) >> 23) - 0x7f;
+        float t = lc3_from_bits((uint32_t)n & ~(0x007fffffu >> k));
+        n = ((n & 0x007fffff) | 0x00800000) >> (23 - k);
+        if (j < 0) n = -n;
+        p_h -= t;
+    }
+    float t = p_l + p_h;
+    t = lc3_from_bits(lc3_bits(t) & 0xffff8000u);
+    float u = t * lg2_h;
+    float v = (p_l - (t - p_h)) * lg2 + t * lg2_l;
+    z = u + v;
+    float w = v - (z - u);
+    t = z * z;
+    t1 = z - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    float r = (z * t1) / (t1 - 2.0f) - (w + z * w);
+    z = 1.0f - (r - z);
+    j = (int32_t)lc3_bits(z);
+    j += (int32_t)((uint32_t)n << 23);
+    if ((j >> 23) <= 0) {
+        // subnormal result: scalbnf(z, n) -- two exact power-of-two scalings (n in [-150, -126))
+        float s1 = lc3_from_bits((uint32_t)(n + 60 + 127) << 23);
+        z = (z * s1) * lc3_from_bits((uint32_t)(127 - 60) << 23);
+    } else z = lc3_from_bits((uint32_t)j);
+    return z;
+}
+
+// shared reduction of e_log2f.c / e_log10f.c
+struct lc3_logparts {
+    float hi, lo;
+    int k;
+    int special;   // 1: result already final in `hi`
+};
+__device__ __forceinline__ lc3_logparts lc3_log_reduce(float x) {
+    const float Lg1 = lc3_from_bits(0x3f2aaaaau), Lg2 = lc3_from_bits(0x3eccce13u);
+    const float Lg3 = lc3_from_bits(0x3e91e9eeu), Lg4 = lc3_from_bits(0x3e789e26u);
+    lc3_logparts p;
+    p.special = 0;
+    p.lo = 0.0f;
+    uint32_t ix = lc3_bits(x);
+    int k = 0;
+    if (ix < 0x00800000u || (ix >> 31)) {
+        if ((ix << 1) == 0) { p.special = 1; p.hi = -1.0f / (x * x); p.k = 0; return p; }
+        if (ix >> 31) { p.special = 1; p.hi = (x - x) / 0.0f; p.k = 0; return p; }
+        k -= 25;
+        x *= 33554432.0f;
+        ix = lc3_bits(x);
+    } else if (ix >= 0x7f800000u) {
+        p.special = 1; p.hi = x; p.k = 0; return p;
+    } else if (ix == 0x3f800000u) {
+        p.special = 1; p.hi = 0.0f; p.k = 0; return p;
+    }
+    ix += 0x3f800000u - 0x3f3504f3u;
+    k += (int)(ix >> 23) - 0x7f;
+    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+    x = lc3_from_bits(ix);
+    float f = x - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float w = z * z;
+    float t1 = w * (Lg2 + w * Lg4);
+    float t2 = z * (Lg1 + w * Lg3);
+    float R = t2 + t1;
+    float hfsq = 0.5f * f * f;
+    float hi = f - hfsq;
+    hi = lc3_from_bits(lc3_bits(hi) & 0xfffff000u);
+    p.hi = hi;
+    p.lo = (f - hi) - hfsq + s * (hfsq + R);
+    p.k = k;
+    return p;
+}
+// e_log2f.c (encoder/spectral_noise_shaping.rs:232)
+__device__ __forceinline__ float lc3_log2f(float x) {
+    const float ivln2hi = lc3_from_bits(0x3fb8b000u), ivln2lo = lc3_from_bits(0xb9389ad4u);
+    lc3_logparts p = lc3_log_reduce(x);
+    if (p.special) return p.hi;
+    return (p.lo + p.hi) * ivln2lo + p.lo * ivln2hi + p.hi * ivln2hi + (float)p.k;
+}
+// e_log10f.c (encoder/spectral_quantization.rs:218,393)
+__device__ __forceinline__ float lc3_log10f(float x) {
+    const float ivln10hi = lc3_from_bits(0x3ede6000u), ivln10lo = lc3_from_bits(0xb804ead9u);
+    const float log10_2hi = lc3_from_bits(0x3e9a2080u), log10_2lo = lc3_from_bits(0x355427dbu);
+    lc3_logparts p = lc3_log_reduce(x);
+    if (p.special) return p.hi;
+    float dk = (float)p.k;
+    return dk * log10_2lo + (p.lo + p.hi) * ivln10lo + p.lo * ivln10hi + p.hi * ivln10hi + dk * log10_2hi;
+}
+
+// s_exp2f.c, TBLSIZE = 16, f64 polynomial (encoder/spectral_noise_shaping.rs:256)
+__device__ __forceinline__ float lc3_exp2f(float x) {
+    const float redux = lc3_from_bits(0x4b400000u) / 16.0f;
+    const float P1 = lc3_from_bits(0x3f317218u), P2 = lc3_from_bits(0x3e75fdf0u);
+    const float P3 = lc3_from_bits(0x3d6359a4u), P4 = lc3_from_bits(0x3c1d964eu);
+    uint32_t ui = lc3_bits(x), ix = ui & 0x7fffffffu;
+    if (ix > 0x42fc0000u) {
+        if (ix > 0x7f800000u) return x;
+        if (ui >= 0x43000000u && ui < 0x80000000u) return x * lc3_from_bits(0x7f000000u);
+        if (ui >= 0x80000000u) {
+            if (ui >= 0xc3160000u) return 0.0f;
+        }
+    } else if (ix <= 0x33000000u) {
+        return 1.0f + x;
+    }
+    float uf = x + redux;
+    uint32_t i0 = lc3_bits(uf);
+    i0 += 8;
+    uint32_t k = i0 / 16;
+    uint64_t uk = (uint64_t)(0x3ffu + k) << 52;
+    i0 &= 15;
+    uf -= redux;
+    double z = (double)(x - uf);
+    // exp2ft[i] = 2^((i-8)/16)
+    uint64_t tb;
+    switch (i0) {
+    case 0: tb = 0x3fe6a09e667f3bcdull; break;
+    case 1: tb = 0x3fe7a11473eb0187ull; break;
+    case 2: tb = 0x3fe8ace5422aa0dbull; break;
+    case 3: tb = 0x3fe9c49182a3f090ull; break;
+    case 4: tb = 0x3feae89f995ad3adull; break;
+    case 5: tb = 0x3fec199bdd85529cull; break;
+    case 6: tb = 0x3fed5818dcfba487ull; break;
+    case 7: tb = 0x3feea4afa2a490daull; break;
+    case 8: tb = 0x3ff0000000000000ull; break;
+    case 9: tb = 0x3ff0b5586cf9890full; break;
+    case 10: tb = 0x3ff172b83c7d517bull; break;
+    case 11: tb = 0x3ff2387a6e756238ull; break;
+    case 12: tb = 0x3ff306fe0a31b715ull; break;
+    case 13: tb = 0x3ff3dea64c123422ull; break;
+    case 14: tb = 0x3ff4bfdad5362a27ull; break;
+    default: tb = 0x3ff5ab07dd485429ull; break;
+    }
+    double r = lc3_d_from_bits(tb);
+    double t = r * z;
+    r = r + t * ((double)P1 + z * (double)P2) + t * (z * z) * ((double)P3 + z * (double)P4);
+    return (float)(r * lc3_d_from_bits(uk));
+}
+
+// e_asinf.c (encoder/temporal_noise_shaping.rs:272)
+__device__ __forceinline__ float lc3_asinf_R(float z) {
+    const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f;
+    const float qS1 = -7.0662963390e-01f;
+    float p = z * (pS0 + z * (pS1 + z * pS2));
+    float q = 1.0f + z * qS1;
+    return p / q;
+}
+__device__ __forceinline__ float lc3_asinf(float x) {
+    const double pio2 = 1.570796326794896558e+00;
+    uint32_t hx = lc3_bits(x), ix = hx & 0x7fffffffu;
+    if (ix >= 0x3f800000u) {
+        if (ix == 0x3f800000u) return (float)((double)x * pio2 + 7.5231638452626401e-37);
+        return 0.0f / (x - x);
+    }
+    if (ix < 0x3f000000u) {
+        if (ix < 0x39800000u && ix >= 0x00800000u) return x;
+        return x + x * lc3_asinf_R(x * x);
+    }
+    float z = (1.0f - lc3_absf(x)) * 0.5f;
+    double s = __builtin_sqrt((double)z);
+    x = (float)(pio2 - 2.0 * (s + s * (double)lc3_asinf_R(z)));
+    if (hx >> 31) return -x;
+    return x;
+}
+
+// s_sinf.c restricted to |x| <= 3*pi/4 (the codec evaluates sin(k*pi/17), |k| <= 8:
+// encoder/temporal_noise_shaping.rs:273, decoder/temporal_noise_shaping.rs:44)
+__device__ __forceinline__ float lc3_sinf_small(float x) {
+    const double S1 = -0x15555554cbac77.0p-55, S2 = 0x111110896efbb2.0p-59;
+    const double S3 = -0x1a00f9e2cae774.0p-65, S4 = 0x16cd878c3b46a7.0p-71;
+    const double C0 = -0x1ffffffd0c5e81.0p-54, C1 = 0x155553e1053a42.0p-57;
+    const double C2 = -0x16c087e80f1e27.0p-62, C3 = 0x199342e0ee5069.0p-68;
+    const double s1pio2 = 1.5707963267948966;
+    uint32_t ix = lc3_bits(x);
+    int sign = (int)(ix >> 31);
+    ix &= 0x7fffffffu;
+    if (ix <= 0x3f490fdau) {
+        if (ix < 0x39800000u) return x;
+        double xd = (double)x, z = xd * xd, w = z * z, r = S3 + z * S4, s = z * xd;
+        return (float)((xd + s * (S1 + z * S2)) + s * w * r);
+    }
+    double xd = sign ? (double)x + s1pio2 : (double)x - s1pio2;
+    double z = xd * xd, w = z * z, r = C2 + z * C3;
+    float c = (float)(((1.0 + z * C0) + w * C1) + (w * z) * r);
+    return sign ? -c : c;
+}
+
+// fast_math::exp2_raw (fast-math 0.1.1; decoder/spectral_noise_shaping.rs:122)
+__device__ __forceinline__ float lc3_exp2_raw(float x) {
+    const float A = 8388608.0f, E = 1.1920929e-7f;
+    const float C0 = (0.3371894346f * E) * E, C1 = 0.657636276f * E, C2 = 1.00172476f;
+    float a = A * x;
+    int32_t mul = lc3_f2i32(a);
+    uint32_t fl = (uint32_t)mul & 0xff800000u;
+    float frac = (float)(int32_t)((uint32_t)mul - fl);
+    float approx = (C0 * frac + C1) * frac + C2;
+    return lc3_from_bits(lc3_bits(approx) + fl);
+}
+
+// num_traits pow(): square-and-multiply (used as powi; encoder/spectral_noise_shaping.rs:223-224,
+// encoder/temporal_noise_shaping.rs:240)
+__device__ __forceinline__ float lc3_powi(float base, int exp) {
+    unsigned e;
+    if (exp < 0) { base = 1.0f / base; e = (unsigned)(-exp); } else e = (unsigned)exp;
+    if (e == 0) return 1.0f;
+    while ((e & 1u) == 0) { base = base * base; e >>= 1; }
+    if (e == 1) return base;
+    float acc = base;
+    while (e > 1) {
+        e >>= 1;
+        base = base * base;
+        if (e & 1u) acc = acc * base;
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// static tables selected by configuration
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ const uint32_t *lc3_window_bits(const lc3_cfg &c) {
+    if (c.n_ms_10) {
+        switch (c.fs_ind) {
+        case 0: return LC3T_W_N80_10MS_BITS;
+        case 1: return LC3T_W_N160_10MS_BITS;
+        case 2: return LC3T_W_N240_10MS_BITS;
+        case 3: return LC3T_W_N320_10MS_BITS;
+        default: return LC3T_W_N480_10MS_BITS;
+        }
+    }
+    switch (c.fs_ind) {
+    case 0: return LC3T_W_N60_7P5MS_BITS;
+    case 1: return LC3T_W_N120_7P5MS_BITS;
+    case 2: return LC3T_W_N180_7P5MS_BITS;
+    case 3: return LC3T_W_N240_7P5MS_BITS;
+    default: return LC3T_W_N360_7P5MS_BITS;
+    }
+}
+__device__ __forceinline__ const uint16_t *lc3_band_index(const lc3_cfg &c) {
+    if (c.n_ms_10) {
+        switch (c.fs_ind) {
+        case 0: return LC3T_I_8000_10MS;
+        case 1: return LC3T_I_16000_10MS;
+        case 2: return LC3T_I_24000_10MS;
+        case 3: return LC3T_I_32000_10MS;
+        default: return LC3T_I_48000_10MS;
+        }
+    }
+    switch (c.fs_ind) {
+    case 0: return LC3T_I_8000_7P5MS;
+    case 1: return LC3T_I_16000_7P5MS;
+    case 2: return LC3T_I_24000_7P5MS;
+    case 3: return LC3T_I_32000_7P5MS;
+    default: return LC3T_I_48000_7P5MS;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Complex FFT (common/kissfft.rs) and DCT-IV (common/dct_iv.rs), wave-parallel over butterflies.
+// The reference's recursion kf_work (:86-131) is a decimation-in-time plan: a strided gather at
+// the leaves (perm[]) followed by the butterfly stages innermost-first.  Butterflies of one
+// stage touch disjoint elements, so one lane per butterfly is exact; the butterfly expression
+// trees (:133-256) are kept verbatim.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ lc3_cpx lc3_cmul(lc3_cpx a, lc3_cpx b) {  // common/complex.rs:16-24
+    lc3_cpx r;
+    r.r = a.r * b.r - a.i * b.i;
+    r.i = a.r * b.i + a.i * b.r;
+    return r;
+}
+__device__ __forceinline__ lc3_cpx lc3_cadd(lc3_cpx a, lc3_cpx b) { lc3_cpx r; r.r = a.r + b.r; r.i = a.i + b.i; return r; }
+__device__ __forceinline__ lc3_cpx lc3_csub(lc3_cpx a, lc3_cpx b) { lc3_cpx r; r.r = a.r - b.r; r.i = a.i - b.i; return r; }
+
+// one butterfly of radix p at element i of the sub-transform based at f[0]
+__device__ __forceinline__ void lc3_bfly(lc3_cpx *f, const lc3_cpx *tw, int p, int fstride, int m, int i) {
+    if (p == 4) {  // kissfft.rs:143-175
+        int m2 = 2 * m, m3 = 3 * m;
+        lc3_cpx s0 = lc3_cmul(f[i + m], tw[i * fstride]);
+        lc3_cpx s1 = lc3_cmul(f[i + m2], tw[i * fstride * 2]);
+        lc3_cpx s2 = lc3_cmul(f[i + m3], tw[i * fstride * 3]);
+        lc3_cpx f0 = f[i];
+        lc3_cpx s5 = lc3_csub(f0, s1);
+        f0 = lc3_cadd(f0, s1);
+        lc3_cpx s3 = lc3_cadd(s0, s2);
+        lc3_cpx s4 = lc3_csub(s0, s2);
+        f[i + m2] = lc3_csub(f0, s3);
+        f[i] = lc3_cadd(f0, s3);
+        lc3_cpx a, b;
+        a.r = s5.r + s4.i;
+        a.i = s5.i - s4.r;
+        b.r = s5.r - s4.i;
+        b.i = s5.i + s4.r;
+        f[i + m] = a;
+        f[i + m3] = b;
+    } else if (p == 2) {  // :133-141
+        lc3_cpx t = lc3_cmul(f[m + i], tw[i * fstride]);
+        lc3_cpx f0 = f[i];
+        f[m + i] = lc3_csub(f0, t);
+        f[i] = lc3_cadd(f0, t);
+    } else if (p == 3) {  // :177-205
+        int m2 = 2 * m;
+        lc3_cpx epi3 = tw[fstride * m];
+        lc3_cpx s1 = lc3_cmul(f[i + m], tw[i * fstride]);
+        lc3_cpx s2 = lc3_cmul(f[i + m2], tw[i * fstride * 2]);
+        lc3_cpx s3 = lc3_cadd(s1, s2);
+        lc3_cpx s0 = lc3_csub(s1, s2);
+        lc3_cpx fi = f[i];
+        lc3_cpx fm;
+        fm.r = fi.r - (s3.r * 0.5f);
+        fm.i = fi.i - (s3.i * 0.5f);
+        s0.r *= epi3.i;
+        s0.i *= epi3.i;
+        f[i] = lc3_cadd(fi, s3);
+        lc3_cpx a, b;
+        a.r = fm.r + s0.i;
+        a.i = fm.i - s0.r;
+        b.r = fm.r - s0.i;
+        b.i = fm.i + s0.r;
+        f[i + m2] = a;
+        f[i + m] = b;
+    } else {  // p == 5, :207-256
+        lc3_cpx ya = tw[fstride * m], yb = tw[fstride * 2 * m];
+        int m2 = 2 * m, m3 = 3 * m, m4 = 4 * m;
+        lc3_cpx s0 = f[i];
+        lc3_cpx s1 = lc3_cmul(f[i + m], tw[i * fstride]);
+        lc3_cpx s2 = lc3_cmul(f[i + m2], tw[i * 2 * fstride]);
+        lc3_cpx s3 = lc3_cmul(f[i + m3], tw[i * 3 * fstride]);
+        lc3_cpx s4 = lc3_cmul(f[i + m4], tw[i * 4 * fstride]);
+        lc3_cpx s7 = lc3_cadd(s1, s4), s10 = lc3_csub(s1, s4), s8 = lc3_cadd(s2, s3), s9 = lc3_csub(s2, s3);
+        lc3_cpx o0, s5, s6, s11, s12;
+        o0.r = s0.r + (s7.r + s8.r);
+        o0.i = s0.i + (s7.i + s8.i);
+        f[i] = o0;
+        s5.r = s0.r + (s7.r * ya.r) + (s8.r * yb.r);
+        s5.i = s0.i + (s7.i * ya.r) + (s8.i * yb.r);
+        s6.r = (s10.i * ya.i) + (s9.i * yb.i);
+        s6.i = -(s10.r * ya.i) - (s9.r * yb.i);
+        f[i + m] = lc3_csub(s5, s6);
+        f[i + m4] = lc3_cadd(s5, s6);
+        s11.r = s0.r + (s7.r * yb.r) + (s8.r * ya.r);
+        s11.i = s0.i + (s7.i * yb.r) + (s8.i * ya.r);
+        s12.r = -(s10.i * yb.i) + (s9.i * ya.i);
+        s12.i = (s10.r * yb.i) - (s9.r * ya.i);
+        f[i + m2] = lc3_cadd(s11, s12);
+        f[i + m3] = lc3_csub(s11, s12);
+    }
+}
+
+// DiscreteCosTransformIv::run (common/dct_iv.rs:49-67) on buf[0..nf) (LDS), scratch fa/fb (LDS, nf/2 each)
+__device__ __forceinline__ void lc3_dct4_wave(const lc3_cfg &c, int lane, float *buf, lc3_cpx *fa, lc3_cpx *fb) {
+    const int nf = c.nf, cnt = c.nfft;
+    // pre-twiddle :53-56
+    for (int n = lane; n < cnt; n += LC3_WAVE) {
+        lc3_cpx x;
+        x.r = buf[2 * n];
+        x.i = buf[nf - 2 * n - 1];
+        fa[n] = lc3_cmul(c.dct_tw[n], x);
+    }
+    LC3_SYNC();
+    // leaf gather of kf_work (kissfft.rs:101-108)
+    for (int o = lane; o < cnt; o += LC3_WAVE) fb[o] = fa[c.perm[o]];
+    LC3_SYNC();
+    // butterfly stages, innermost first
+    for (int s = c.n_stages - 1; s >= 0; s--) {
+        const int p = c.radix[s], m = c.m[s], fstride = c.fstride[s];
+        const int nb = cnt / p;
+        for (int u = lane; u < nb; u += LC3_WAVE) {
+            int blk = u / m, i = u - blk * m;
+            lc3_bfly(fb + blk * p * m, c.fft_tw, p, fstride, m, i);
+        }
+        LC3_SYNC();
+    }
+    // post-twiddle :62-66
+    for (int n = lane; n < cnt; n += LC3_WAVE) {
+        lc3_cpx y = lc3_cmul(c.dct_tw[n], fb[n]);
+        buf[2 * n] = y.r * 2.0f;
+        buf[nf - 2 * n - 1] = -y.i * 2.0f;
+    }
+    LC3_SYNC();
+}

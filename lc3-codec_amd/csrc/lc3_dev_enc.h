@@ -1,0 +1,1556 @@
+// LC3 batched encoder for MI355X -- device-side stages (one wavefront per stream).
+// Mirrors EncoderChannel::encode (reference encoder/lc3_encoder.rs:63-112) stage by stage.
+// See lc3_dev_common.h for the execution model and the bit-exactness contract.
+#pragma once
+#include "lc3_dev_common.h"
+
+// ------------------------------------------------------------------------------------------
+// Persistent per-stream encoder state as it lives in HBM between launches.
+// Word-aligned blob, one per stream, loaded/stored by the owning wave with coalesced accesses.
+// ------------------------------------------------------------------------------------------
+struct lc3_enc_state {
+    float x12[384];          // LTPF 12.8 kHz ring (encoder/long_term_post_filter.rs:114,227); 10 ms uses all 384
+    float x6[180];           // LTPF 6.4 kHz ring, 178 used (:116,228)
+    int16_t hist[304];       // MDCT time-buffer history t[0 .. nf-z) (encoder/modified_dct.rs:126-138); also
+                             // supplies the LTPF resampler's 240/P history samples (long_term_post_filter.rs:217-224)
+    // attack detector (encoder/attack_detector.rs:17-21)
+    float att_energy_last, att_max_energy_last;
+    int att_pos_last, att_ds_tm1, att_ds_tm2;
+    // LTPF (encoder/long_term_post_filter.rs:32-41)
+    int t_prev;
+    float mem_pitch;
+    int mem_ltpf_active;
+    float mem_nc, mem_mem_nc, h50_m1, h50_m2;
+    // quantiser (encoder/spectral_quantization.rs:56-61); nbits_spec_old stays 0
+    int reset_offset_old;
+    float nbits_offset_old;
+    int nbits_est_old;
+    int pad;
+};
+#define LC3_ENC_STATE_WORDS ((int)(sizeof(lc3_enc_state) / 4))
+
+// LDS working set of one encoder wave (~12 KB)
+struct lc3_enc_lds {
+    lc3_enc_state st;        // resident copy of the stream state (x12/x6/hist are worked on in place)
+    float spec[LC3_MAX_NF];  // MDCT output -> SNS -> TNS spectrum (mdct_out / spec_lines)
+    lc3_cpx fa[LC3_MAX_NF / 2];  // FFT input; afterwards scratch
+    lc3_cpx fb[LC3_MAX_NF / 2];  // FFT work buffer; afterwards scratch
+    float eb[64];            // band energies
+    int16_t t[2 * LC3_MAX_NF];   // MDCT time buffer (ModDiscreteCosTrans::freq)
+    int16_t xq[LC3_MAX_NE];  // quantised spectrum
+    uint8_t out[LC3_MAX_NE]; // frame bytes staging
+    uint8_t res_bits[LC3_MAX_NE];
+    float sm[160];           // small scratch (per-stage)
+    int ism[64];
+};
+
+struct lc3_sns_res { int ind_lf, ind_hf, shape_j, gind, ls_inda, ls_indb; uint32_t index_joint_j; };
+struct lc3_tns_res { int nbits_tns, lpc_weighting, num_tns_filters; int rc_order[2]; };  // rc_i / rc_q live in LDS
+struct lc3_ltpf_res { int pitch_index, pitch_present, ltpf_active, nbits_ltpf; };
+struct lc3_quant_res { int gg_ind, nbits_spec, nbits_lsb, nbits_trunc, lsb_mode, rate_flag, lastnz_trunc; float gg; };
+
+// ------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------
+// broadcast an int / float computed by lane 0 through LDS slot `slot` of L.ism
+#define LC3_BCAST_I(L, slot, val) ((L).ism[slot])
+
+__device__ __forceinline__ void lc3_enc_state_init(lc3_enc_lds &L, int lane) {
+    // fresh channel (Lc3Encoder::new: zeroed working buffers; attack_detector.rs:31-43;
+    // long_term_post_filter.rs:74-90 t_prev = K_MIN)
+    int *w = (int *)&L.st;
+    for (int i = lane; i < LC3_ENC_STATE_WORDS; i += LC3_WAVE) w[i] = 0;
+    LC3_SYNC();
+    if (lane == 0) {
+        L.st.att_pos_last = -1;
+        L.st.t_prev = 17;
+    }
+    LC3_SYNC();
+}
+__device__ __forceinline__ void lc3_enc_state_load(lc3_enc_lds &L, int lane, const lc3_enc_state *g) {
+    const int *src = (const int *)g;
+    int *w = (int *)&L.st;
+    for (int i = lane; i < LC3_ENC_STATE_WORDS; i += LC3_WAVE) w[i] = src[i];
+    LC3_SYNC();
+}
+__device__ __forceinline__ void lc3_enc_state_store(lc3_enc_lds &L, int lane, lc3_enc_state *g) {
+    int *dst = (int *)g;
+    const int *w = (const int *)&L.st;
+    LC3_SYNC();
+    for (int i = lane; i < LC3_ENC_STATE_WORDS; i += LC3_WAVE) dst[i] = w[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// E1-E6: MDCT analysis (encoder/modified_dct.rs:108-177)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lc3_enc_mdct(const lc3_cfg &c, lc3_enc_lds &L, int lane, const int16_t *pcm) {
+    const int nf = c.nf, z = c.z, h = nf / 2, mid = 3 * h;
+    const uint32_t *w = lc3_window_bits(c);
+    const uint16_t *ifs = lc3_band_index(c);
+    // update_time_buffer :126-138: t[0..nf-z) <- history, t[nf-z..2nf-z) <- new frame, tail stays 0.
+    // The frame is fetched from HBM as 32-bit words (two samples per lane per load, coalesced).
+    for (int i = lane; i < nf - z; i += LC3_WAVE) L.t[i] = L.st.hist[i];
+    {
+        const uint32_t *p32 = (const uint32_t *)pcm;
+        for (int i = lane; i < nf / 2; i += LC3_WAVE) {
+            uint32_t v = p32[i];
+            L.t[nf - z + 2 * i] = (int16_t)(v & 0xffffu);
+            L.t[nf - z + 2 * i + 1] = (int16_t)(v >> 16);
+        }
+    }
+    for (int i = 2 * nf - z + lane; i < 2 * nf; i += LC3_WAVE) L.t[i] = 0;
+    LC3_SYNC();
+    // apply_mdct :73-105 (window / fold)
+    for (int k = lane; k < h; k += LC3_WAVE) {
+        L.spec[k] = -((float)L.t[mid - 1 - k] * lc3_f(w, mid - 1 - k)) - ((float)L.t[mid + k] * lc3_f(w, mid + k));
+        L.spec[h + k] = ((float)L.t[k] * lc3_f(w, k)) - ((float)L.t[nf - 1 - k] * lc3_f(w, nf - 1 - k));
+    }
+    LC3_SYNC();
+    lc3_dct4_wave(c, lane, L.spec, L.fa, L.fb);
+    {
+        const float gain = 1.0f / lc3_sqrtf(2.0f * (float)nf);
+        for (int k = lane; k < nf; k += LC3_WAVE) L.spec[k] *= gain;
+    }
+    // next frame's history = t[nf .. 2nf-z)
+    for (int i = lane; i < nf - z; i += LC3_WAVE) L.st.hist[i] = L.t[nf + i];
+    LC3_SYNC();
+    // apply_energy_estimation :140-152 -- one lane per band, terms accumulated in order
+    for (int b = lane; b < c.nb; b += LC3_WAVE) {
+        int from = ifs[b], to = ifs[b + 1];
+        float width = (float)(to - from), acc = 0.0f;
+        for (int k = from; k < to; k++) acc += L.spec[k] * L.spec[k] / width;
+        L.eb[b] = acc;
+    }
+    LC3_SYNC();
+    // is_near_nyquist :154-177
+    int nn = 0;
+    if (c.fs <= 32000) {
+        if (lane == 0) {
+            int nn_idx = c.n_ms_10 ? c.nb - 2 : c.nb - 4;
+            float lower = 0.0f, upper = 0.0f;
+            for (int b = 0; b < c.nb; b++) {
+                if (b < nn_idx) lower += L.eb[b];
+                else upper += L.eb[b];
+            }
+            L.ism[0] = upper > 30.0f * lower;
+        }
+        LC3_SYNC();
+        nn = L.ism[0];
+        LC3_SYNC();
+    }
+    return nn;
+}
+
+// ------------------------------------------------------------------------------------------
+// E7: bandwidth detector (encoder/bandwidth_detector.rs:64-127), lane 0
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lc3_enc_bandwidth(const lc3_cfg &c, lc3_enc_lds &L, int lane, int *nbits_bw) {
+    const int NBITS_BW[5] = {0, 1, 2, 2, 3};
+    *nbits_bw = NBITS_BW[c.fs_ind];
+    if (c.fs_ind == 0) return 0;  // :66-71 (the reference cannot construct an 8 kHz encoder)
+    if (lane == 0) {
+        const int START10[4][4] = {{53, 0, 0, 0}, {47, 59, 0, 0}, {44, 54, 60, 0}, {41, 51, 57, 61}};
+        const int STOP10[4][4] = {{63, 0, 0, 0}, {56, 63, 0, 0}, {52, 59, 63, 0}, {49, 55, 60, 63}};
+        const int START75[4][4] = {{51, 0, 0, 0}, {45, 58, 0, 0}, {42, 53, 60, 0}, {40, 51, 57, 61}};
+        const int STOP75[4][4] = {{63, 0, 0, 0}, {55, 63, 0, 0}, {51, 58, 63, 0}, {48, 55, 60, 63}};
+        const int TQ[4] = {20, 10, 10, 10};
+        const int TC[4] = {15, 23, 20, 20};
+        const int L10[4] = {4, 4, 3, 1};
+        const int L75[4] = {4, 4, 3, 2};
+        const int fsi = c.fs_ind;
+        int bw = 0;
+        for (int k = fsi - 1; k >= 0; k--) {
+            int start = c.n_ms_10 ? START10[fsi - 1][k] : START75[fsi - 1][k];
+            int stop = c.n_ms_10 ? STOP10[fsi - 1][k] : STOP75[fsi - 1][k];
+            float width = (float)(stop + 1 - start), quiet = 0.0f;
+            for (int n = start; n <= stop; n++) quiet += L.eb[n] / width;
+            if (quiet >= (float)TQ[k]) {
+                bw = k + 1;
+                break;
+            }
+        }
+        int result = bw;
+        if (fsi != bw) {
+            float cutoff_max = 0.0f;
+            int l_bw = c.n_ms_10 ? L10[bw] : L75[bw];
+            int start_bw = c.n_ms_10 ? START10[fsi - 1][bw] : START75[fsi - 1][bw];
+            for (int n = start_bw + 1 - l_bw; n < start_bw; n++) {
+                float cutoff = L.eb[n - l_bw] / L.eb[n];  // raw ratio, no dB
+                cutoff_max = lc3_maxf(cutoff, cutoff_max);
+            }
+            result = cutoff_max > (float)TC[bw] ? bw : fsi;
+        }
+        L.ism[0] = result;
+    }
+    LC3_SYNC();
+    int r = L.ism[0];
+    LC3_SYNC();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// E8: attack detector (encoder/attack_detector.rs:45-128)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lc3_enc_attack(const lc3_cfg &c, lc3_enc_lds &L, int lane, int nbytes) {
+    const int num_ds = c.n_ms_10 ? 160 : 120, num_blocks = c.n_ms_10 ? 4 : 3, limit = c.n_ms_10 ? 2 : 1;
+    int active;
+    if (c.fs < 32000) active = 0;
+    else if (!c.n_ms_10)
+        active = (c.fs == 32000 && nbytes >= 61 && nbytes < 150) || (c.fs >= 44100 && nbytes >= 75 && nbytes < 150);
+    else active = (c.fs == 32000 && nbytes > 80) || (c.fs >= 41000 && nbytes >= 100);
+    if (!active) {
+        if (lane == 0) {
+            L.st.att_energy_last = 0.0f;
+            L.st.att_max_energy_last = 0.0f;
+            L.st.att_pos_last = -1;
+        }
+        LC3_SYNC();
+        return 0;
+    }
+    const int block_len = c.nf / num_ds;
+    const int16_t *x_s = L.t + (c.nf - c.z);  // the current frame inside the time buffer
+    int *ds = (int *)L.fa;                    // 160 ints
+    float *hp = (float *)L.fb;                // 160 floats
+    float *en = L.sm;                         // 4 block energies
+    for (int n = lane; n < num_ds; n += LC3_WAVE) {
+        int acc = 0;
+        for (int j = 0; j < block_len; j++) acc += (int)x_s[block_len * n + j];
+        ds[n] = acc;
+    }
+    LC3_SYNC();
+    for (int n = lane; n < num_ds; n += LC3_WAVE) {  // filter :118-128
+        float x0 = (float)ds[n];
+        float x1 = n >= 1 ? (float)ds[n - 1] : (float)L.st.att_ds_tm1;
+        float x2 = n >= 2 ? (float)ds[n - 2] : (n == 1 ? (float)L.st.att_ds_tm1 : (float)L.st.att_ds_tm2);
+        hp[n] = 0.375f * x0 - 0.5f * x1 + 0.125f * x2;
+    }
+    LC3_SYNC();
+    if (lane < num_blocks) {  // block energies, 40 terms each in order
+        float e = 0.0f;
+        for (int j = 40 * lane; j < 40 * lane + 40; j++) e += hp[j] * hp[j];
+        en[lane] = e;
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        int attack_position = -1;
+        float e_last = L.st.att_energy_last, m_last = L.st.att_max_energy_last;
+        for (int n = 0; n < num_blocks; n++) {
+            float energy = en[n];
+            float max_energy = lc3_maxf(0.25f * m_last, e_last);
+            if (energy > 8.5f * max_energy) attack_position = n;
+            e_last = energy;
+            m_last = max_energy;
+        }
+        L.ism[0] = attack_position >= 0 || L.st.att_pos_last >= limit;
+        L.st.att_energy_last = e_last;
+        L.st.att_max_energy_last = m_last;
+        L.st.att_pos_last = attack_position;
+        L.st.att_ds_tm1 = ds[num_ds - 1];
+        L.st.att_ds_tm2 = ds[num_ds - 2];
+    }
+    LC3_SYNC();
+    int r = L.ism[0];
+    LC3_SYNC();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// E9/E10: spectral noise shaping (encoder/spectral_noise_shaping.rs:203-648)
+// ------------------------------------------------------------------------------------------
+// add_unit_pulse :285-316 (corr_xy / energy_y written through on every probe: SURVEY A2)
+__device__ __forceinline__ void lc3_add_unit_pulse(const float *abs_x, int n_max, int k, int k_max, int *cand,
+                                                   float &corr_xy, float &energy_y) {
+    float corr_last = corr_xy, en_last = energy_y;
+    for (int it = k; it < k_max; it++) {
+        int n_best = 0;
+        corr_xy = corr_last + abs_x[0];
+        float best_corr_sq = corr_xy * corr_xy;
+        float best_en = en_last + 2.0f * (float)cand[0] + 1.0f;
+        for (int n_c = 1; n_c < n_max; n_c++) {
+            corr_xy = corr_last + abs_x[n_c];
+            energy_y = en_last + 2.0f * (float)cand[n_c] + 1.0f;
+            if (corr_xy * corr_xy * best_en > best_corr_sq * energy_y) {
+                n_best = n_c;
+                best_corr_sq = corr_xy * corr_xy;
+                best_en = energy_y;
+            }
+        }
+        corr_last += abs_x[n_best];
+        en_last += 2.0f * (float)cand[n_best] + 1.0f;
+        cand[n_best] += 1;
+    }
+}
+__device__ __forceinline__ void lc3_normalize_candidate(const int *y, float *xq, int n_max) {  // :632-648
+    float norm = 0.0f;
+    for (int n = 0; n < n_max; n++)
+        if (y[n] != 0) norm += (float)y[n] * (float)y[n];
+    norm = lc3_sqrtf(norm);
+    for (int n = 0; n < n_max; n++) {
+        float v = (float)y[n];
+        if (y[n] != 0) v /= norm;
+        xq[n] = v;
+    }
+    for (int n = n_max; n < 16; n++) xq[n] = 0.0f;
+}
+__device__ __forceinline__ void lc3_mvpq_enum(uint32_t &index, int &lead_sign_ind, int dim_in, const int *vec_in) {
+    // :584-629
+    int next_sign_ind = (-2147483647 - 1);
+    int k_val_acc = 0, n = 0;
+    uint32_t tmp_h_row = LC3T_MPVQ_OFFSETS[0][0];
+    index = 0;
+    for (int pos = dim_in - 1; pos >= 0; pos--) {
+        int tmp_val = (int)(int8_t)vec_in[pos];
+        if (next_sign_ind >= 0 && tmp_val != 0) index = 2 * index + (uint32_t)next_sign_ind;
+        if (tmp_val < 0) next_sign_ind = 1;
+        else if (tmp_val > 0) next_sign_ind = 0;
+        index += tmp_h_row;
+        k_val_acc += tmp_val < 0 ? -tmp_val : tmp_val;
+        if (pos != 0) n += 1;
+        tmp_h_row = k_val_acc >= 11 ? LC3T_MPVQ_OFFSETS[n + 1][k_val_acc % 11] : LC3T_MPVQ_OFFSETS[n][k_val_acc];
+    }
+    lead_sign_ind = next_sign_ind;
+}
+
+// scratch map inside L.fa/L.fb (floats): all disjoint
+//   sE[64] smoothed/log energies, sP[64] padded, sDS[16], sSCF[16], sSCFQ[16], sINT[64],
+//   sST1[16], sR1[16], sT2[16], sABS[16], sXQ[4][16], sDM[64] (stage-1 distortions), iY[4][16]
+__device__ __forceinline__ lc3_sns_res lc3_enc_sns(const lc3_cfg &c, lc3_enc_lds &L, int lane, int attack) {
+    float *S = (float *)L.fa;
+    float *sE = S, *sP = S + 64, *sDS = S + 128, *sSCF = S + 144, *sSCFQ = S + 160, *sINT = S + 176;
+    float *sST1 = S + 240, *sR1 = S + 256, *sT2 = S + 272, *sABS = S + 288, *sXQ = S + 304, *sDM = S + 368;
+    int *iY = (int *)(S + 432);  // 4*16 ints -> ends at 496 floats < 960
+    const uint16_t *ifs = lc3_band_index(c);
+    const int G_TILT[5] = {14, 18, 22, 26, 30};
+    const int diff = 64 - c.nb;
+    lc3_sns_res res;
+
+    // padding :75-90
+    if (diff > 0) {
+        if (lane == 0) {
+            for (int b = 0; b < diff; b++) {
+                sP[2 * b] = L.eb[b];
+                sP[2 * b + 1] = L.eb[b];
+            }
+            for (int b = 0; b < c.nb && 2 * diff + b < 64; b++) sP[2 * diff + b] = L.eb[diff + b];
+        }
+    } else {
+        sP[lane] = L.eb[lane];
+    }
+    LC3_SYNC();
+    // smoothing :92-98, pre-emphasis :214-219 -- one lane per band
+    {
+        const int b = lane;
+        float v;
+        if (b == 0) v = 0.75f * sP[0] + 0.25f * sP[1];
+        else if (b == 63) v = 0.25f * sP[62] + 0.75f * sP[63];
+        else v = 0.25f * sP[b - 1] + 0.5f * sP[b] + 0.25f * sP[b + 1];
+        const float exponent = (float)G_TILT[c.fs_ind] / 630.0f;
+        v *= lc3_pow10f((float)b * exponent);
+        sE[b] = v;
+    }
+    LC3_SYNC();
+    // noise floor :221-228 -- 64-term sequential sum on lane 0
+    if (lane == 0) {
+        float total = 0.0f;
+        for (int b = 0; b < 64; b++) total += sE[b];
+        total = (total / 64.0f) * lc3_powi(10.0f, -4);
+        L.sm[0] = lc3_maxf(lc3_powi(2.0f, -32), total);
+    }
+    LC3_SYNC();
+    {
+        float v = lc3_maxf(sE[lane], L.sm[0]);
+        sE[lane] = lc3_log2f(1.1920929e-7f + v) / 2.0f;  // :230-233
+    }
+    LC3_SYNC();
+    // band energy grouping :100-124 -- one lane per scale
+    if (lane < 16) {
+        const float W[6] = {1.0f / 12.0f, 2.0f / 12.0f, 3.0f / 12.0f, 3.0f / 12.0f, 2.0f / 12.0f, 1.0f / 12.0f};
+        float d;
+        if (lane == 0) {
+            d = W[0] * sE[0];
+            for (int k = 1; k < 6; k++) d += W[k] * sE[k - 1];
+        } else if (lane == 15) {
+            d = W[5] * sE[63];
+            for (int k = 0; k < 5; k++) d += W[k] * sE[60 + k - 1];
+        } else {
+            d = 0.0f;
+            for (int k = 0; k < 6; k++) d += W[k] * sE[4 * lane - 1 + k];
+        }
+        sDS[lane] = d;
+    }
+    LC3_SYNC();
+    // mean removal :126-132, attack handling :134-161, and the whole vector quantiser on lane 0
+    if (lane == 0) {
+        float total = 0.0f;
+        for (int n = 0; n < 16; n++) total += sDS[n];
+        float avg = total / 16.0f;
+        for (int n = 0; n < 16; n++) sDS[n] = 0.85f * (sDS[n] - avg);
+        if (attack) {
+            sSCF[0] = (sDS[0] + sDS[1] + sDS[2]) / 3.0f;
+            sSCF[1] = (sDS[0] + sDS[1] + sDS[2] + sDS[3]) / 4.0f;
+            for (int n = 2; n < 14; n++) {
+                float wt = 0.0f;
+                for (int k = n - 2; k < n + 3; k++) wt += sDS[k];
+                sSCF[n] = wt / 5.0f;
+            }
+            sSCF[14] = (sDS[12] + sDS[13] + sDS[14] + sDS[15]) / 4.0f;
+            sSCF[15] = (sDS[13] + sDS[14] + sDS[15]) / 3.0f;
+            total = 0.0f;
+            for (int n = 0; n < 16; n++) total += sSCF[n];
+            avg = total / 16.0f;
+            const float att = c.n_ms_10 ? 0.5f : 0.3f;
+            for (int n = 0; n < 16; n++) sSCF[n] = att * (sSCF[n] - avg);
+        } else {
+            for (int n = 0; n < 16; n++) sSCF[n] = sDS[n];
+        }
+    }
+    LC3_SYNC();
+    // stage 1 :318-361 -- lanes 0..31: LF codebook entry, lanes 32..63: HF codebook entry
+    {
+        const int i = lane & 31, hf = lane >> 5;
+        const uint32_t *cb = hf ? &LC3T_HFCB_BITS[i][0] : &LC3T_LFCB_BITS[i][0];
+        const float *s = sSCF + 8 * hf;
+        float d = 0.0f;
+        for (int n = 0; n < 8; n++) d += (s[n] - lc3_f(cb, n)) * (s[n] - lc3_f(cb, n));
+        sDM[lane] = d;
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        float lf_min = __builtin_inff(), hf_min = __builtin_inff();
+        int ind_lf = 0, ind_hf = 0;
+        for (int i = 0; i < 32; i++) {
+            if (sDM[i] < lf_min) { ind_lf = i; lf_min = sDM[i]; }
+            if (sDM[32 + i] < hf_min) { ind_hf = i; hf_min = sDM[32 + i]; }
+        }
+        for (int n = 0; n < 8; n++) {
+            sST1[n] = lc3_f(&LC3T_LFCB_BITS[ind_lf][0], n);
+            sST1[8 + n] = lc3_f(&LC3T_HFCB_BITS[ind_hf][0], n);
+        }
+        for (int n = 0; n < 16; n++) sR1[n] = sSCF[n] - sST1[n];
+        L.ism[0] = ind_lf;
+        L.ism[1] = ind_hf;
+    }
+    LC3_SYNC();
+    // stage 2 target: t2rot = r1 * D, row-by-row accumulation order (:378-384) -- one lane per column
+    if (lane < 16) {
+        float acc = 0.0f;
+        for (int i = 0; i < 16; i++) acc += sR1[i] * lc3_f(&LC3T_D_BITS[i][0], lane);
+        sT2[lane] = acc;
+        sABS[lane] = lc3_absf(acc);
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        int *y0 = iY, *y1 = iY + 16, *y2 = iY + 32, *y3 = iY + 48;
+        int k = 0;
+        float abs_sum = 0.0f, corr_xy = 0.0f, energy_y = 0.0f;
+        for (int n = 0; n < 16; n++) abs_sum += sABS[n];
+        const float proj = (6.0f - 1.0f) / abs_sum;
+        for (int n = 0; n < 16; n++) {
+            int v = lc3_f2i32(lc3_floorf(sABS[n] * proj));
+            y3[n] = v;
+            if (v != 0) {
+                k += v;
+                corr_xy += (float)v * sABS[n];
+                energy_y += (float)v * (float)v;
+            }
+        }
+        lc3_add_unit_pulse(sABS, 16, k, 6, y3, corr_xy, energy_y);
+        for (int n = 0; n < 16; n++) y2[n] = y3[n];
+        lc3_add_unit_pulse(sABS, 16, 6, 8, y2, corr_xy, energy_y);
+        for (int n = 0; n < 10; n++) y1[n] = y2[n];
+        for (int n = 10; n < 16; n++) y1[n] = 0;
+        int ks = 8;
+        for (int n = 10; n < 16; n++) {
+            if (y2[n] != 0) {
+                ks -= y2[n];
+                corr_xy -= (float)y2[n] * sABS[n];
+                energy_y -= (float)y2[n] * (float)y2[n];
+            }
+        }
+        lc3_add_unit_pulse(sABS, 10, ks, 10, y1, corr_xy, energy_y);
+        {
+            float max_abs = 0.0f;
+            int n_best = 0;
+            for (int n = 0; n < 10; n++) y0[n] = y1[n];
+            for (int n = 10; n < 16; n++) {
+                y0[n] = 0;
+                if (sABS[n] > max_abs) {
+                    max_abs = sABS[n];
+                    n_best = n;
+                }
+            }
+            y0[n_best] = 1;
+        }
+        for (int n = 0; n < 10; n++)
+            if (sT2[n] < 0.0f) { y0[n] = -y0[n]; y1[n] = -y1[n]; y2[n] = -y2[n]; y3[n] = -y3[n]; }
+        for (int n = 10; n < 16; n++)
+            if (sT2[n] < 0.0f) { y0[n] = -y0[n]; y2[n] = -y2[n]; y3[n] = -y3[n]; }
+        lc3_normalize_candidate(y0, sXQ, 16);
+        lc3_normalize_candidate(y1, sXQ + 16, 10);
+        lc3_normalize_candidate(y2, sXQ + 32, 16);
+        lc3_normalize_candidate(y3, sXQ + 48, 16);
+        // shape/gain search; the last gain of every shape is never tried
+        const int g_maxind[4] = {1, 3, 3, 7};
+        int shape_j = 0, gind = 0;
+        float g_sel = 0.0f, d_min = __builtin_inff();
+        for (int j = 0; j < 4; j++) {
+            const uint32_t *gains = j == 0 ? LC3T_SNS_VQ_REG_ADJ_GAINS_BITS
+                                    : j == 1 ? LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS
+                                    : j == 2 ? LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS : LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS;
+            for (int i = 0; i < g_maxind[j]; i++) {
+                float g = lc3_f(gains, i), d = 0.0f;
+                for (int n = 0; n < 16; n++) {
+                    float df = sT2[n] - g * sXQ[16 * j + n];
+                    d += df * df;
+                }
+                if (d < d_min) { shape_j = j; gind = i; d_min = d; g_sel = g; }
+            }
+        }
+        uint32_t idxa = 0, idxb = 0, joint;
+        int ls_inda = 0, ls_indb = 0;
+        const int lsb_gain = gind & 1;
+        if (shape_j == 0) {
+            lc3_mvpq_enum(idxa, ls_inda, 10, y0);
+            lc3_mvpq_enum(idxb, ls_indb, 6, y0 + 10);
+            joint = (2u * idxb + (uint32_t)ls_indb + 2u) * 2390004u + idxa;
+        } else if (shape_j == 1) {
+            lc3_mvpq_enum(idxa, ls_inda, 10, y1);
+            joint = (uint32_t)lsb_gain * 2390004u + idxa;
+        } else if (shape_j == 2) {
+            lc3_mvpq_enum(idxa, ls_inda, 16, y2);
+            joint = idxa;
+        } else {
+            lc3_mvpq_enum(idxa, ls_inda, 16, y3);
+            joint = 15158272u + (uint32_t)lsb_gain + (2u * idxa);
+        }
+        L.ism[2] = shape_j;
+        L.ism[3] = gind;
+        L.ism[4] = ls_inda;
+        L.ism[5] = ls_indb;
+        L.ism[6] = (int)joint;
+        L.sm[1] = g_sel;
+    }
+    LC3_SYNC();
+    // synthesis :552-559 -- one lane per scale factor
+    if (lane < 16) {
+        const float *xq_sel = sXQ + 16 * L.ism[2];
+        float factor = 0.0f;
+        for (int col = 0; col < 16; col++) factor += xq_sel[col] * lc3_f(&LC3T_D_BITS[lane][0], col);
+        sSCFQ[lane] = sST1[lane] + L.sm[1] * factor;
+    }
+    LC3_SYNC();
+    // interpolation :163-183 -- one lane per band
+    {
+        const int b = lane;
+        float v;
+        if (b < 2) v = sSCFQ[0];
+        else if (b >= 62) v = sSCFQ[15] + ((b == 62 ? 0.125f : 0.375f) * (sSCFQ[15] - sSCFQ[14]));
+        else {
+            int n = (b - 2) >> 2, r = (b - 2) & 3;
+            float in0 = sSCFQ[n], d = sSCFQ[n + 1] - sSCFQ[n];
+            float w = r == 0 ? 0.125f : (r == 1 ? 0.375f : (r == 2 ? 0.625f : 0.875f));
+            v = in0 + (w * d);
+        }
+        sINT[b] = v;
+    }
+    LC3_SYNC();
+    if (diff > 0) {  // :185-201
+        if (lane == 0) {
+            for (int b = 0; b < diff; b++) sINT[b] = (sINT[2 * b] + sINT[2 * b + 1]) / 2.0f;
+            for (int b = diff; b < c.nb; b++) sINT[b] = sINT[diff + 1];
+        }
+        LC3_SYNC();
+    }
+    sINT[lane] = lc3_exp2f(-sINT[lane]);  // :254-257
+    LC3_SYNC();
+    // spectral shaping :264-268 -- one lane per band (bands are 1..25 lines wide)
+    if (lane < c.nb) {
+        const float g = sINT[lane];
+        for (int k = ifs[lane]; k < ifs[lane + 1]; k++) L.spec[k] *= g;
+    }
+    res.ind_lf = L.ism[0];
+    res.ind_hf = L.ism[1];
+    res.shape_j = L.ism[2];
+    res.gind = L.ism[3];
+    res.ls_inda = L.ism[4];
+    res.ls_indb = L.ism[5];
+    res.index_joint_j = (uint32_t)L.ism[6];
+    LC3_SYNC();
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------
+// E11: temporal noise shaping (encoder/temporal_noise_shaping.rs:40-349)
+// rc_i[16] -> L.ism[16..32), rc_q[16] -> L.sm[16..32)
+// ------------------------------------------------------------------------------------------
+struct lc3_tns_params { int num, start[2], stop[2], sub_start[2][3], sub_stop[2][3]; };
+__device__ __forceinline__ lc3_tns_params lc3_tns_get_params(int n_ms_10, int p_bw) {
+    // :117-202 (10 ms p_bw = 2 keeps stop_freq = 200: SURVEY A5)
+    const lc3_tns_params T10[5] = {
+        {1, {12, 160}, {80, 0}, {{12, 34, 57}, {0, 0, 0}}, {{34, 57, 80}, {0, 0, 0}}},
+        {1, {12, 160}, {160, 0}, {{12, 61, 110}, {0, 0, 0}}, {{61, 110, 160}, {0, 0, 0}}},
+        {1, {12, 160}, {200, 0}, {{12, 88, 164}, {0, 0, 0}}, {{88, 164, 240}, {0, 0, 0}}},
+        {2, {12, 160}, {160, 320}, {{12, 61, 110}, {160, 213, 266}}, {{61, 110, 160}, {213, 266, 320}}},
+        {2, {12, 200}, {200, 400}, {{12, 74, 137}, {200, 266, 333}}, {{74, 137, 200}, {266, 333, 400}}},
+    };
+    const lc3_tns_params T75[5] = {
+        {1, {9, 120}, {60, 0}, {{9, 26, 43}, {0, 0, 0}}, {{26, 43, 60}, {0, 0, 0}}},
+        {1, {9, 120}, {120, 0}, {{9, 46, 83}, {0, 0, 0}}, {{46, 83, 120}, {0, 0, 0}}},
+        {1, {9, 120}, {180, 0}, {{9, 66, 123}, {0, 0, 0}}, {{66, 123, 180}, {0, 0, 0}}},
+        {2, {9, 120}, {120, 240}, {{9, 46, 82}, {120, 159, 200}}, {{46, 82, 120}, {159, 200, 240}}},
+        {2, {9, 150}, {150, 300}, {{9, 56, 103}, {150, 200, 250}}, {{56, 103, 150}, {200, 250, 300}}},
+    };
+    return n_ms_10 ? T10[p_bw] : T75[p_bw];
+}
+
+__device__ __forceinline__ lc3_tns_res lc3_enc_tns(const lc3_cfg &c, lc3_enc_lds &L, int lane, int p_bw, int nbits,
+                                                  int near_nyquist) {
+    const lc3_tns_params tp = lc3_tns_get_params(c.n_ms_10, p_bw);
+    float *S = (float *)L.fa;
+    float *sAC = S;        // [2][9][3] partial autocorrelations
+    float *sES = S + 64;   // [2][3] sub-block energies
+    int *rc_i = L.ism + 16;
+    float *rc_q = L.sm + 16;
+    float *x = L.spec;
+    const int ne = c.ne;
+    lc3_tns_res res;
+    res.num_tns_filters = tp.num;
+    res.lpc_weighting = c.n_ms_10 ? (nbits < 480) : (nbits < 360);
+
+    // compute_normalized_autocorrelation :80-115 -- one lane per (filter, lag, sub-block) partial sum and
+    // one lane per sub-block energy; every sum runs in the reference's order.
+    if (lane < 54) {
+        const int f = lane / 27, r = lane - 27 * f, k = r / 3, s = r - 3 * k;
+        float ac = 0.0f;
+        if (f < tp.num) {
+            const int start = tp.sub_start[f][s], stop = tp.sub_stop[f][s], k_from = start + k;
+            if (k_from < ne && k_from < stop)
+                for (int n = 0; k_from + n < stop; n++) ac += x[start + n] * x[k_from + n];
+        }
+        sAC[lane] = ac;
+    } else if (lane < 60) {
+        const int q = lane - 54, f = q / 3, s = q - 3 * f;
+        float es = 0.0f;
+        if (f < tp.num)
+            for (int n = tp.sub_start[f][s]; n < tp.sub_stop[f][s]; n++) es += x[n] * x[n];
+        sES[q] = es;
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        const float LAGW[9] = {1.0f, 0.9980280260203829f, 0.9921354055113971f, 0.9823915844707989f,
+                               0.9689107911912967f, 0.9518498073692735f, 0.9314049334023056f,
+                               0.9078082299969592f, 0.8813231366694713f};
+        const float step = (float)3.14159265358979323846 / 17.0f;  // PI as f32 / 17.0 :268
+        for (int f = 0; f < tp.num; f++) {
+            float *r = S + 96, *a0 = S + 112, *a1 = S + 128;  // LDS (dynamic indexing)
+            for (int k = 0; k < 9; k++) {
+                float r0 = k == 0 ? 3.0f : 0.0f, rk = 0.0f, e_prod = 1.0f;
+                for (int s = 0; s < 3; s++) {
+                    float es = sES[f * 3 + s];
+                    e_prod *= es;
+                    rk += sAC[f * 27 + k * 3 + s] / es;
+                }
+                r[k] = (e_prod == 0.0f ? r0 : rk) * LAGW[k];
+            }
+            // Levinson-Durbin :204-232
+            float *a = a0, *a_last = a1;
+            for (int n = 0; n < 9; n++) { a0[n] = 0.0f; a1[n] = 0.0f; }
+            float e = r[0];
+            a[0] = 1.0f;
+            for (int k = 1; k < 9; k++) {
+                float *tmp = a_last;
+                a_last = a;
+                a = tmp;
+                float rc = 0.0f;
+                for (int n = 0; n < k; n++) rc -= a_last[n] * r[k - n];
+                if (e != 0.0f) rc /= e;
+                a[0] = 1.0f;
+                for (int n = 1; n < k; n++) a[n] = a_last[n] + rc * a_last[k - n];
+                a[k] = rc;
+                e *= 1.0f - rc * rc;
+            }
+            const float pred_gain = e == 0.0f ? r[0] : r[0] / e;
+            if (pred_gain > 1.5f && !near_nyquist) {
+                float gamma = 1.0f;
+                if (res.lpc_weighting > 0 && pred_gain < 2.0f)
+                    gamma -= (1.0f - 0.85f) * (2.0f - pred_gain) / (2.0f - 1.5f);
+                for (int k = 0; k < 9; k++) a[k] *= lc3_powi(gamma, k);
+                float *a_k = a, *a_km1 = a_last;
+                for (int k = 8; k >= 1; k--) {
+                    float rck = a_k[k];
+                    rc_q[f * 8 + k - 1] = rck;
+                    float ee = 1.0f - rck * rck;
+                    for (int n = 1; n < k; n++) {
+                        float v = a_k[n] - rck * a_k[k - n];
+                        a_km1[n] = v / ee;
+                    }
+                    float *tmp = a_k;
+                    a_k = a_km1;
+                    a_km1 = tmp;
+                }
+            } else {
+                for (int k = 0; k < 8; k++) rc_q[f * 8 + k] = 0.0f;
+            }
+        }
+        // apply_quantization :267-292
+        for (int f = 0; f < tp.num; f++) {
+            for (int k = 0; k < 8; k++) {
+                float q = lc3_asinf(rc_q[f * 8 + k]) / step;
+                int ri = (q >= 0.0f ? lc3_f2i8(q + 0.5f) : lc3_f2i8(-(-q + 0.5f))) + 8;
+                rc_i[f * 8 + k] = ri;
+                rc_q[f * 8 + k] = lc3_sinf_small(step * ((float)ri - 8.0f));
+            }
+            int k = 7;
+            while (k >= 0 && rc_i[f * 8 + k] == 8) k--;
+            L.ism[8 + f] = k + 1;
+        }
+        for (int f = tp.num; f < 2; f++) {
+            for (int k = 0; k < 8; k++) {
+                rc_i[f * 8 + k] = 8;
+                rc_q[f * 8 + k] = 0.0f;
+            }
+            L.ism[8 + f] = 0;
+        }
+        // calc_bit_budget :294-311
+        int nbits_tns = 0;
+        for (int f = 0; f < tp.num; f++) {
+            int order = L.ism[8 + f];
+            int order_bits = order != 0 ? LC3T_AC_TNS_ORDER_BITS[res.lpc_weighting][order - 1] : 0;
+            int coef_bits = 0;
+            for (int k = 0; k < order; k++) {
+                int ri = rc_i[f * 8 + k];
+                ri = ri < 0 ? 0 : (ri > 16 ? 16 : ri);
+                coef_bits += LC3T_AC_TNS_COEF_BITS[k][ri];
+            }
+            nbits_tns += (int)lc3_ceilf((2048.0f + (float)order_bits + (float)coef_bits) / 2048.0f);
+        }
+        L.ism[10] = nbits_tns;
+        // apply_filtering :313-340 -- serial MA lattice, state shared across filters
+        float st[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int f = 0; f < tp.num; f++) {
+            const int order = L.ism[8 + f];
+            if (order != 0) {
+                float rq[8];
+                for (int k = 0; k < 8; k++) rq[k] = rc_q[f * 8 + k];
+                for (int n = tp.start[f]; n < tp.stop[f]; n++) {
+                    float t = x[n], st_save = t;
+#pragma unroll
+                    for (int k = 0; k < 7; k++) {
+                        if (k < order - 1) {
+                            float st_tmp = rq[k] * t + st[k];
+                            t += rq[k] * st[k];
+                            st[k] = st_save;
+                            st_save = st_tmp;
+                        }
+                    }
+                    // t += rc_q[prev_order] * st[prev_order]; st[prev_order] = st_save
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (k == order - 1) {
+                            t += rq[k] * st[k];
+                            st[k] = st_save;
+                        }
+                    }
+                    x[n] = t;
+                }
+            }
+        }
+    }
+    LC3_SYNC();
+    res.rc_order[0] = L.ism[8];
+    res.rc_order[1] = L.ism[9];
+    res.nbits_tns = L.ism[10];
+    LC3_SYNC();
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------
+// E12-E16: long-term post-filter analysis (encoder/long_term_post_filter.rs:139-469)
+// ------------------------------------------------------------------------------------------
+#define LC3_NMEM 232
+#define LC3_KMIN 17
+#define LC3_KMAX 114
+
+__device__ __forceinline__ float lc3_ltpf_interp(const float *r, int rel, int d) {  // :457-469
+    float acc = 0.0f;
+    for (int m = -4; m <= 4; m++) {
+        int n = 4 * m - d;
+        if (n > -16 && n < 16) acc += r[rel + m] * lc3_f(LC3T_TAB_LTPF_INTERP_R_BITS, n + 15);
+    }
+    return acc;
+}
+__device__ __forceinline__ float lc3_ltpf_dot(const float *x12, int n, int d) {  // :412-424
+    float acc = 0.0f;
+    for (int k = -2; k <= 2; k++) {
+        int h = 4 * k - d;
+        if (h > -8 && h < 8) acc += x12[LC3_NMEM + n - k] * lc3_f(LC3T_TAB_LTPF_INTERP_X12K8_BITS, h + 7);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(const lc3_cfg &c, lc3_enc_lds &L, int lane, int near_nyquist,
+                                                    int nbits) {
+    const int len12 = c.len12, len6 = c.len6, p = c.p_up;
+    const int x12_len = len12 + c.delay12 + LC3_NMEM;
+    float *x12 = L.st.x12, *x6 = L.st.x6;
+    float *S = (float *)L.fa;
+    float *r6 = S, *rw6 = S + 128, *r12 = S + 256, *dA = S + 512, *dB = S + 640;  // dA/dB: 128 each
+    int t_nbits = nbits;
+    if (!c.n_ms_10) {
+        double v = (double)nbits * 10.0 / 7.5;  // .round(): half away from zero (:143)
+        t_nbits = (int)(v + 0.5);
+    }
+    const int gain_ltpf_on = t_nbits < 560 + c.fs_ind * 80;
+    lc3_ltpf_res res;
+
+    // shift_out_old_samples :217-229.  Each lane first reads its elements, then all write (in-place shift).
+    {
+        float v[7];
+        int cnt = 0;
+        for (int i = lane; i < x12_len - len12; i += LC3_WAVE) v[cnt++] = x12[i + len12];
+        LC3_SYNC();
+        cnt = 0;
+        for (int i = lane; i < x12_len - len12; i += LC3_WAVE) x12[i] = v[cnt++];
+        cnt = 0;
+        for (int i = lane; i < 178 - len6; i += LC3_WAVE) v[cnt++] = x6[i + len6];
+        LC3_SYNC();
+        cnt = 0;
+        for (int i = lane; i < 178 - len6; i += LC3_WAVE) x6[i] = v[cnt++];
+        LC3_SYNC();
+    }
+    // resampling :152-166 -- one lane per 12.8 kHz output, taps accumulated in order.
+    // x_s_extended[i] == time buffer t[(nf - z) - hist + i]
+    {
+        const int16_t *xs = L.t + (c.nf - c.z) - c.hist;
+        const int lim = 120 / p;
+        float *o12 = x12 + c.delay12 + LC3_NMEM;
+        for (int n = lane; n < len12; n += LC3_WAVE) {
+            float acc = 0.0f;
+            const int base = (15 * n) / p - lim, ph = (15 * n) % p;
+            for (int k = -lim; k <= lim; k++) {
+                int index_h = p * k - ph;
+                if (index_h > -120 && index_h < 120)
+                    acc += (float)xs[c.hist + base + k] * lc3_f(LC3T_TAB_RESAMP_FILTER_BITS, 119 + index_h);
+            }
+            o12[n] = acc * c.resamp_scale;
+        }
+    }
+    LC3_SYNC();
+    // 50 Hz high-pass :168-177 -- recursive across samples and frames: lane 0
+    if (lane == 0) {
+        float *o12 = x12 + c.delay12 + LC3_NMEM;
+        float m1 = L.st.h50_m1, m2 = L.st.h50_m2;
+        for (int n = 0; n < len12; n++) {
+            float h50 = o12[n] - -1.9652933726226904f * m1 - 0.9658854605688177f * m2;
+            o12[n] = 0.9827947082978771f * h50 + -1.965589416595754f * m1 + 0.9827947082978771f * m2;
+            m2 = m1;
+            m1 = h50;
+        }
+        L.st.h50_m1 = m1;
+        L.st.h50_m2 = m2;
+    }
+    LC3_SYNC();
+    // pitch_detection :232-290
+    for (int n = lane; n < len6; n += LC3_WAVE) {
+        const float *s = x12 + LC3_NMEM - 3 + 2 * n;
+        x6[LC3_KMAX + n] = 0.1236796411180537f * s[0] + 0.2353512128364889f * s[1] + 0.2819382920909148f * s[2] +
+                           0.2353512128364889f * s[3] + 0.1236796411180537f * s[4];
+    }
+    LC3_SYNC();
+    for (int k = lane; k < LC3_KMAX + 1 - LC3_KMIN; k += LC3_WAVE) {  // 98 lags, 64-term sums in order
+        const int from_k = LC3_KMAX - LC3_KMIN - k;
+        float acc = 0.0f;
+        for (int n = 0; n < len6; n++) acc += x6[LC3_KMAX + n] * x6[from_k + n];
+        r6[k] = acc;
+        float weight = 1.0f - 0.5f * (float)k / (float)(LC3_KMAX - LC3_KMIN);
+        rw6[k] = weight * acc;
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        const int NL = LC3_KMAX + 1 - LC3_KMIN;
+        int idx = 0;
+        float mx = rw6[0];
+        for (int i = 0; i < NL; i++)
+            if (rw6[i] > mx) { idx = i; mx = rw6[i]; }
+        const int lag_t1 = idx + LC3_KMIN;
+        const int t_prev = L.st.t_prev;
+        const int k_from = (t_prev - 4 > LC3_KMIN ? t_prev - 4 : LC3_KMIN) - LC3_KMIN;
+        const int k_to = (t_prev + 4 < LC3_KMAX ? t_prev + 4 : LC3_KMAX) - LC3_KMIN + 1;
+        idx = 0;
+        if (k_to > k_from) {
+            mx = r6[k_from];
+            for (int i = 0; i < k_to - k_from; i++)
+                if (r6[k_from + i] > mx) { idx = i; mx = r6[k_from + i]; }
+        }
+        L.ism[0] = lag_t1;
+        L.ism[1] = idx + k_from + LC3_KMIN;
+    }
+    LC3_SYNC();
+    // compute_normalized_value :445-455 for lag 0, lag_t1, lag_t2 -- three lanes
+    if (lane < 3) {
+        const int lag = lane == 0 ? 0 : L.ism[lane - 1];
+        const int from = LC3_KMAX - lag;
+        float v = 0.0f;
+        for (int n = from; n < from + len6; n++) v += x6[n] * x6[n];
+        L.sm[lane] = v;
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        const int lag_t1 = L.ism[0], lag_t2 = L.ism[1];
+        const float nv0 = L.sm[0], nv1 = L.sm[1], nv2 = L.sm[2];
+        float normcorr1 = lc3_maxf(0.0f, r6[lag_t1 - LC3_KMIN] / lc3_sqrtf(nv0 * nv1));
+        float normcorr2 = lag_t1 == lag_t2 ? normcorr1 : lc3_maxf(0.0f, r6[lag_t2 - LC3_KMIN] / lc3_sqrtf(nv0 * nv2));
+        int t_current, pitch_present;
+        if (normcorr2 > 0.85f * normcorr1) {
+            t_current = lag_t2;
+            pitch_present = normcorr2 > 0.6f;
+        } else {
+            t_current = lag_t1;
+            pitch_present = normcorr1 > 0.6f;
+        }
+        L.ism[2] = t_current;
+        L.ism[3] = pitch_present;
+    }
+    LC3_SYNC();
+    // pitch_lag_parameter :292-363
+    const int t_current = L.ism[2];
+    const int k_min = 2 * t_current - 4 > 32 ? 2 * t_current - 4 : 32;
+    const int k_max = 2 * t_current + 4 < 228 ? 2 * t_current + 4 : 228;
+    {
+        const int nk = (k_max + 4) - (k_min - 4) + 1;  // <= 17
+        if (lane < nk) {
+            const int k = k_min - 4 + lane;
+            float acc = 0.0f;
+            for (int n = 0; n < len12; n++) acc += x12[LC3_NMEM + n] * x12[LC3_NMEM - k + n];
+            r12[lane] = acc;
+        }
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        float max_corr = 0.0f;
+        int pitch_int = k_min, pitch_fr = 0;
+        for (int k = k_min - 4; k <= k_max + 4; k++) {
+            float v = r12[k - (k_min - 4)];
+            if (v > max_corr && k >= k_min && k <= k_max) {
+                max_corr = v;
+                pitch_int = k;
+            }
+        }
+        const int rel = pitch_int - (k_min - 4);
+        if (pitch_int == 32) {
+            float mx = 0.0f;
+            for (int d = 0; d <= 3; d++) {
+                float v = lc3_ltpf_interp(r12, rel, d);
+                if (v > mx) { mx = v; pitch_fr = d; }
+            }
+        } else if (pitch_int < 127 && pitch_int > 32) {
+            float mx = 0.0f;
+            for (int d = -3; d <= 3; d++) {
+                float v = lc3_ltpf_interp(r12, rel, d);
+                if (v > mx) { mx = v; pitch_fr = d; }
+            }
+        } else if (pitch_int >= 127 && pitch_int < 157) {
+            float mx = 0.0f;
+            for (int d = -2; d <= 2; d += 2) {
+                float v = lc3_ltpf_interp(r12, rel, d);
+                if (v > mx) { mx = v; pitch_fr = d; }
+            }
+        }
+        if (pitch_fr < 0) {
+            pitch_int -= 1;
+            pitch_fr += 4;
+        }
+        int pitch_index;
+        if (pitch_int < 127) pitch_index = 4 * pitch_int + pitch_fr - 128;
+        else if (pitch_int < 157) pitch_index = 2 * pitch_int + pitch_fr / 2 - 126;
+        else pitch_index = pitch_int + 283;
+        L.ism[4] = pitch_int;
+        L.ism[5] = pitch_fr;
+        L.ism[6] = pitch_index;
+    }
+    LC3_SYNC();
+    // activation_bit :365-409 -- interpolated signals in parallel, the three 128-term sums on three lanes
+    {
+        const int pitch_int = L.ism[4], pitch_fr = L.ism[5];
+        for (int n = lane; n < len12; n += LC3_WAVE) {
+            dA[n] = lc3_ltpf_dot(x12, n, 0);
+            dB[n] = lc3_ltpf_dot(x12, n - pitch_int, pitch_fr);
+        }
+    }
+    LC3_SYNC();
+    if (lane < 3) {
+        float acc = 0.0f;
+        for (int n = 0; n < len12; n++) {
+            float a = dA[n], b = dB[n];
+            acc += lane == 0 ? a * b : (lane == 1 ? a * a : b * b);
+        }
+        L.sm[lane] = acc;
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        const int pitch_int = L.ism[4], pitch_fr = L.ism[5], pitch_present = L.ism[3];
+        int pitch_index = L.ism[6];
+        const float num = L.sm[0], nd = L.sm[1], sh = L.sm[2];
+        const float den = lc3_sqrtf(nd * sh);
+        float nc = den > 0.0f ? num / den : 0.0f;
+        const float pitch = (float)pitch_int + (float)pitch_fr / 4.0f;
+        int ltpf_active = 0;
+        if (gain_ltpf_on && !near_nyquist) {
+            const int ma = L.st.mem_ltpf_active;
+            ltpf_active = (!ma && (c.n_ms_10 || L.st.mem_mem_nc > 0.94f) && L.st.mem_nc > 0.94f && nc > 0.94f) ||
+                          (ma && nc > 0.9f) ||
+                          (ma && lc3_absf(pitch - L.st.mem_pitch) < 2.0f && (nc - L.st.mem_nc) > -0.1f && nc > 0.84f);
+        }
+        if (!pitch_present) {  // :184-214
+            pitch_index = 0;
+            nc = 0.0f;
+        }
+        L.st.t_prev = t_current;
+        L.st.mem_mem_nc = L.st.mem_nc;
+        if (pitch_present) {
+            L.st.mem_pitch = pitch;
+            L.st.mem_ltpf_active = ltpf_active;
+            L.st.mem_nc = nc;
+        } else {
+            L.st.mem_pitch = 0.0f;
+            L.st.mem_ltpf_active = 0;
+            L.st.mem_nc = 0.0f;
+        }
+        L.ism[6] = pitch_index;
+        L.ism[7] = ltpf_active;
+    }
+    LC3_SYNC();
+    res.pitch_index = L.ism[6];
+    res.pitch_present = L.ism[3];
+    res.ltpf_active = L.ism[7];
+    res.nbits_ltpf = res.pitch_present ? 11 : 1;
+    LC3_SYNC();
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------
+// E17: spectral quantisation (encoder/spectral_quantization.rs:75-395)
+// ------------------------------------------------------------------------------------------
+struct lc3_bitcons { int rate_flag, lastnz, nbits_lsb, lastnz_trunc, nbits_est, nbits_trunc, mode_flag; };
+
+// quantize_spectrum :230-263 + compute_bit_consumption :265-348.
+// Quantisation is lane-parallel; the context-adaptive bit estimate walks tuples in order on lane 0.
+__device__ __forceinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_enc_lds &L, int lane, int nbits,
+                                                            int gg_off, int gg_ind, int nbits_spec, float *gg_out,
+                                                            int *lsb_mode) {
+    const int ne = c.ne;
+    const float gg = lc3_pow10f(((float)gg_ind + (float)gg_off) / 28.0f);
+    for (int n = lane; n < ne; n += LC3_WAVE) {
+        float x = L.spec[n];
+        L.xq[n] = (int16_t)(x >= 0.0f ? lc3_f2i16(x / gg + 0.375f) : lc3_f2i16(x / gg - 0.375f));
+    }
+    LC3_SYNC();
+    const int rate_flag = nbits > (160 + c.fs_ind * 160) ? 512 : 0;
+    const int mode_flag = nbits >= (480 + c.fs_ind * 160);
+    if (lane == 0) {
+        int lastnz = ne;
+        while (lastnz > 2 && L.xq[lastnz - 1] == 0 && L.xq[lastnz - 2] == 0) lastnz -= 2;
+        uint32_t est = 0, trunc = 0;
+        int nbits_lsb = 0, lastnz_trunc = 2, cctx = 0;
+        for (int n = 0; n < lastnz; n += 2) {
+            int t = cctx + rate_flag, lev = 0;
+            const int q0 = L.xq[n], q1 = L.xq[n + 1];
+            unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
+            unsigned a_lsb = a, b_lsb = b;
+            if (n > ne / 2) t += 256;
+            while ((a > b ? a : b) >= 4) {
+                int pki = LC3T_AC_SPEC_LOOKUP[t + lev * 1024];
+                est += LC3T_AC_SPEC_BITS[pki][16];
+                if (lev == 0 && mode_flag) nbits_lsb += 2;
+                else est += 2 * 2048;
+                a >>= 1;
+                b >>= 1;
+                lev = lev + 1 < 3 ? lev + 1 : 3;
+            }
+            int pki = LC3T_AC_SPEC_LOOKUP[t + lev * 1024];
+            est += LC3T_AC_SPEC_BITS[pki][a + 4 * b];
+            if (a_lsb > 0) est += 2048;
+            if (b_lsb > 0) est += 2048;
+            if (lev > 0 && mode_flag) {
+                a_lsb >>= 1;
+                b_lsb >>= 1;
+                if (a_lsb == 0 && q0 != 0) nbits_lsb += 1;
+                if (b_lsb == 0 && q1 != 0) nbits_lsb += 1;
+            }
+            if ((q0 != 0 || q1 != 0) && (int)lc3_ceilf((float)est / 2048.0f) <= nbits_spec) {
+                lastnz_trunc = n + 2;
+                trunc = est;
+            }
+            t = lev <= 1 ? 1 + (int)(a + b) * (lev + 1) : 12 + lev;
+            cctx = (cctx & 15) * 16 + t;
+        }
+        L.ism[0] = lastnz;
+        L.ism[1] = lastnz_trunc;
+        L.ism[2] = (int)lc3_ceilf((float)est / 2048.0f) + nbits_lsb;
+        L.ism[3] = (int)lc3_ceilf((float)trunc / 2048.0f);
+        L.ism[4] = nbits_lsb;
+    }
+    LC3_SYNC();
+    lc3_bitcons bc;
+    bc.rate_flag = rate_flag;
+    bc.mode_flag = mode_flag;
+    bc.lastnz = L.ism[0];
+    bc.lastnz_trunc = L.ism[1];
+    bc.nbits_est = L.ism[2];
+    bc.nbits_trunc = L.ism[3];
+    bc.nbits_lsb = L.ism[4];
+    LC3_SYNC();
+    for (int n = bc.lastnz_trunc + lane; n < bc.lastnz; n += LC3_WAVE) L.xq[n] = 0;  // truncation :249-252
+    LC3_SYNC();
+    *lsb_mode = bc.mode_flag && bc.nbits_est > nbits_spec;
+    *gg_out = gg;
+    return bc;
+}
+
+__device__ __forceinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_lds &L, int lane, int nbits, int nbits_bw,
+                                                      int nbits_tns, int nbits_ltpf) {
+    const int ne = c.ne, ne4 = ne / 4;
+    float *e = (float *)L.fa;  // 100 group energies
+    float *xm = e + 128;       // 64 per-lane maxima
+    lc3_quant_res res;
+    // calc_bit_budget :122-134: ceil(log2(ne/2)) + {3,4,5}
+    int nbits_ari = 0;
+    while ((1 << nbits_ari) < ne / 2) nbits_ari++;
+    nbits_ari += nbits <= 1280 ? 3 : (nbits <= 2560 ? 4 : 5);
+    const int nbits_spec = nbits - (nbits_bw + nbits_tns + nbits_ltpf + 38 + 8 + 3 + nbits_ari);
+    // get_global_gain_estimation_parameter :156-172
+    float nbits_offset;
+    if (L.st.reset_offset_old) nbits_offset = 0.0f;
+    else {
+        float prev = L.st.nbits_offset_old + 0.0f - (float)L.st.nbits_est_old;
+        nbits_offset = 0.8f * L.st.nbits_offset_old + 0.2f * lc3_minf(40.0f, lc3_maxf(-40.0f, prev));
+    }
+    const int nbits_spec_adj = lc3_f2u16((float)nbits_spec + nbits_offset + 0.5f);
+    int gg_off;
+    {
+        int q = (int)(int16_t)nbits / (10 * (c.fs_ind + 1));
+        gg_off = -(q < 115 ? q : 115) - 105 - 5 * (c.fs_ind + 1);
+    }
+    // compute_spectral_energy :390-395 -- one lane per 4-line group
+    for (int n = lane; n < ne4; n += LC3_WAVE) {
+        const float *x = L.spec + 4 * n;
+        float total = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+        e[n] = 10.0f * lc3_log10f(1.1920929e-7f + total);
+    }
+    // global_gain_limitation's max |x| :214-217 (max is order-independent)
+    {
+        float m = 0.0f;
+        for (int n = lane; n < ne; n += LC3_WAVE) m = lc3_maxf(m, lc3_absf(L.spec[n]));
+        xm[lane] = m;
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        // global_gain_estimation :174-209 -- 8-step bisection, sequential f32 accumulation
+        int fac = 256, gg_ind = 255;
+        for (int it = 0; it < 8; it++) {
+            float tmp = 0.0f;
+            int is_zero = 1;
+            fac >>= 1;
+            gg_ind -= fac;
+            const float g = (float)gg_ind + (float)gg_off;
+            for (int n = ne4 - 1; n >= 0; n--) {
+                const float ei = e[n];
+                if (ei * 28.0f / 20.0f < g) {
+                    if (!is_zero) tmp += 2.7f * 28.0f / 20.0f;
+                } else {
+                    if (g < (ei * 28.0f / 20.0f - 43.0f * 28.0f / 20.0f))
+                        tmp += 2.0f * ei * 28.0f / 20.0f - 2.0f * g - 36.0f * 28.0f / 20.0f;
+                    else tmp += ei * 28.0f / 20.0f - g + 7.0f * 28.0f / 20.0f;
+                    is_zero = 0;
+                }
+            }
+            if ((tmp > (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f) && !is_zero) gg_ind += fac;
+        }
+        // global_gain_limitation :212-228
+        float x_f_max = 0.0f;
+        for (int i = 0; i < LC3_WAVE; i++) x_f_max = lc3_maxf(x_f_max, xm[i]);
+        int gg_min = 0;
+        if (x_f_max > 0.0f) gg_min = lc3_f2i16(lc3_ceilf(28.0f * lc3_log10f(x_f_max / (32768.0f - 0.375f)))) - gg_off;
+        int reset_offset = 0;
+        if (gg_ind < gg_min || x_f_max == 0.0f) {
+            reset_offset = 1;
+            gg_ind = gg_min;
+        }
+        L.ism[8] = gg_ind;
+        L.ism[9] = gg_min;
+        L.ism[10] = reset_offset;
+    }
+    LC3_SYNC();
+    int gg_ind = L.ism[8];
+    const int gg_min = L.ism[9], reset_offset = L.ism[10];
+    LC3_SYNC();
+    float gg;
+    int lsb_mode;
+    lc3_bitcons bc = lc3_quantize_spectrum(c, L, lane, nbits, gg_off, gg_ind, nbits_spec, &gg, &lsb_mode);
+    // save state after the FIRST pass :97-100
+    if (lane == 0) {
+        L.st.nbits_offset_old = nbits_offset;
+        L.st.nbits_est_old = bc.nbits_est;
+        L.st.reset_offset_old = reset_offset;
+    }
+    // global_gain_adjustment :350-388 (wave-uniform scalar code)
+    {
+        const int T1[5] = {80, 230, 380, 530, 680};
+        const int T2[5] = {500, 1025, 1550, 2075, 2600};
+        const int T3[5] = {850, 1700, 2550, 3400, 4250};
+        const int t1 = T1[c.fs_ind], t2 = T2[c.fs_ind], t3 = T3[c.fs_ind], est = bc.nbits_est, origin = gg_ind;
+        float delta;
+        if (est < t1) delta = ((float)est + 48.0f) / 16.0f;
+        else if (est < t2) {
+            float tmp1 = (float)t1 / 16.0f + 3.0f, tmp2 = (float)t2 / 48.0f;
+            delta = ((float)est - (float)t1) * (tmp2 - tmp1) / ((float)t2 - (float)t1) + tmp1;
+        } else if (est < t3) delta = (float)est / 48.0f;
+        else delta = (float)t3 / 48.0f;
+        delta = lc3_floorf(delta + 0.5f);
+        const float delta2 = delta + 2.0f;
+        if ((gg_ind < 255 && est > nbits_spec) || (gg_ind > 0 && (float)est < ((float)nbits_spec - delta2))) {
+            if ((float)est < ((float)nbits_spec - delta2)) gg_ind -= 1;
+            else if (gg_ind == 254 || (float)est < ((float)nbits_spec + delta)) gg_ind += 1;
+            else gg_ind += 2;
+            if (gg_ind < gg_min) gg_ind = gg_min;
+        }
+        if (origin != gg_ind) bc = lc3_quantize_spectrum(c, L, lane, nbits, gg_off, gg_ind, nbits_spec, &gg, &lsb_mode);
+    }
+    res.gg_ind = gg_ind;
+    res.nbits_spec = nbits_spec;
+    res.nbits_lsb = bc.nbits_lsb;
+    res.lsb_mode = lsb_mode;
+    res.nbits_trunc = bc.nbits_trunc;
+    res.rate_flag = bc.rate_flag;
+    res.lastnz_trunc = bc.lastnz_trunc;
+    res.gg = gg;
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------
+// E18 residual bits (encoder/residual_spectrum.rs:33-62), E19 noise level
+// (encoder/noise_level_estimation.rs:21-55).  Returns n_res via L.ism[0], noise factor via L.ism[1].
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lc3_enc_residual_noise(const lc3_cfg &c, lc3_enc_lds &L, int lane,
+                                                       const lc3_quant_res &q, int bw_ind) {
+    const int BW10[5] = {80, 160, 240, 320, 400};
+    const int BW75[5] = {60, 120, 180, 240, 300};
+    const int ne = c.ne;
+    float *nz = (float *)L.fa;  // |x|/gg where relevant
+    uint8_t *rel = (uint8_t *)L.fb;
+    const int bw_stop = c.n_ms_10 ? BW10[bw_ind] : BW75[bw_ind];
+    const int nf_start = c.n_ms_10 ? 24 : 18, nf_width = c.n_ms_10 ? 3 : 2;
+    const int nf_stop = ne < bw_stop ? ne : bw_stop;
+    // relevance flags + per-line contributions in parallel
+    for (int k = nf_start + lane; k < nf_stop; k += LC3_WAVE) {
+        int from = k - nf_width, to = bw_stop < k + nf_width + 1 ? bw_stop : k + nf_width + 1, r = 1;
+        for (int j = from; j < to; j++)
+            if (L.xq[j] != 0) r = 0;
+        rel[k] = (uint8_t)r;
+        nz[k] = lc3_absf(L.spec[k]) / q.gg;
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        // residual bits
+        int mx = q.nbits_spec - q.nbits_trunc + 4, n = 0;
+        if (mx < 0) mx = 0;
+        if (mx > 0) {
+            for (int k = 0; k < ne; k++) {
+                if (n >= mx) break;
+                int v = L.xq[k];
+                if (v != 0) L.res_bits[n++] = (uint8_t)(L.spec[k] >= (float)v * q.gg);
+            }
+        }
+        L.ism[0] = n;
+    } else if (lane == 1) {
+        // noise factor: sequential sum over relevant lines
+        float sum = 0.0f;
+        int count = 0;
+        for (int k = nf_start; k < nf_stop; k++)
+            if (rel[k]) {
+                sum += nz[k];
+                count++;
+            }
+        float level = count > 0 ? sum / (float)count : 0.0f;
+        float diff = 8.0f - 16.0f * level;
+        int nfac = 0;
+        if (diff >= 0.0f) {
+            int v = lc3_f2i32(diff + 0.5f);
+            nfac = v < 7 ? v : 7;
+        }
+        L.ism[1] = nfac;
+    }
+    LC3_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// E20/E21: bitstream (encoder/bitstream_encoding.rs:77-429, encoder/buffer_writer.rs:11-67), lane 0
+// ------------------------------------------------------------------------------------------
+struct lc3_bitwriter {
+    uint8_t *buf;
+    int nbytes, nbits, bp, bp_side, mask_side;
+    uint32_t low, range;
+    int cache, carry, carry_count;
+};
+__device__ __forceinline__ void lc3_bw_bool_backward(lc3_bitwriter &w, int bit) {  // buffer_writer.rs:27-40
+    if (w.bp_side >= 0 && w.bp_side < w.nbytes) {
+        if (!bit) w.buf[w.bp_side] &= (uint8_t)~w.mask_side;
+        else w.buf[w.bp_side] |= (uint8_t)w.mask_side;
+    }
+    if (w.mask_side == 0x80) {
+        w.mask_side = 1;
+        w.bp_side -= 1;
+    } else w.mask_side <<= 1;
+}
+__device__ __forceinline__ void lc3_bw_uint_backward(lc3_bitwriter &w, uint32_t val, int nbits) {  // :19-25
+    for (int i = 0; i < nbits; i++) {
+        lc3_bw_bool_backward(w, (int)(val & 1u));
+        val >>= 1;
+    }
+}
+__device__ __forceinline__ void lc3_bw_byte_forward(lc3_bitwriter &w, int val) {  // :55-58
+    if (w.bp >= 0 && w.bp < w.nbytes) w.buf[w.bp] = (uint8_t)val;
+    w.bp += 1;
+}
+__device__ __forceinline__ void lc3_bw_uint_forward(lc3_bitwriter &w, unsigned val, int nbits) {  // :42-53
+    unsigned mask = 0x80;
+    for (int i = 0; i < nbits; i++) {
+        if (w.bp >= 0 && w.bp < w.nbytes) {
+            if (((val & 0xff) & mask) == 0) w.buf[w.bp] &= (uint8_t)~mask;
+            else w.buf[w.bp] |= (uint8_t)mask;
+        }
+        mask >>= 1;
+    }
+}
+__device__ __forceinline__ void lc3_ac_shift(lc3_bitwriter &w) {  // bitstream_encoding.rs:397-415
+    if (w.low < 0x00ff0000u || w.carry == 1) {
+        if (w.cache >= 0) lc3_bw_byte_forward(w, (w.cache + w.carry) & 0xff);
+        while (w.carry_count > 0) {
+            lc3_bw_byte_forward(w, (w.carry + 0xff) & 0xff);
+            w.carry_count -= 1;
+        }
+        w.cache = (int)(w.low >> 16);
+        w.carry = 0;
+    } else w.carry_count += 1;
+    w.low <<= 8;
+    w.low &= 0x00ffffffu;
+}
+__device__ __forceinline__ void lc3_ac_encode(lc3_bitwriter &w, int cum_freq, int sym_freq) {  // :417-429
+    uint32_t r = w.range >> 10;
+    w.low += r * (uint32_t)cum_freq;
+    if ((w.low >> 24) != 0) w.carry = 1;
+    w.low &= 0x00ffffffu;
+    w.range = r * (uint32_t)sym_freq;
+    while (w.range < 0x10000u) {
+        w.range <<= 8;
+        lc3_ac_shift(w);
+    }
+}
+
+__device__ __forceinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L, int lane, int bw_ind, int nbits_bw,
+                                                  const lc3_sns_res &sns, const lc3_tns_res &tns,
+                                                  const lc3_ltpf_res &ltpf, const lc3_quant_res &spec, int n_res_bits,
+                                                  int noise_factor, int nbytes) {
+    // init :138-144: the frame is zero-filled first (lane-parallel)
+    for (int i = lane; i < nbytes; i += LC3_WAVE) L.out[i] = 0;
+    LC3_SYNC();
+    if (lane == 0) {
+        const int ne = c.ne;
+        const int *rc_i = L.ism + 16;
+        uint8_t *lsbs = (uint8_t *)L.fa;  // LSB list for lsb_mode (<= 3840 entries used in practice << 1920*2 bytes)
+        const int lsbs_cap = (int)(sizeof(L.fa) + sizeof(L.fb));
+        int nlsbs = 0;
+        lc3_bitwriter w;
+        w.buf = L.out;
+        w.nbytes = nbytes;
+        w.nbits = nbytes * 8;
+        w.bp = 0;
+        w.bp_side = nbytes - 1;
+        w.mask_side = 1;
+        // side information :92-112 (layout: SURVEY App. E)
+        if (nbits_bw > 0) lc3_bw_uint_backward(w, (uint32_t)bw_ind, nbits_bw);
+        {
+            int nb = 0;
+            while ((1 << nb) < ne / 2) nb++;
+            lc3_bw_uint_backward(w, (uint32_t)((spec.lastnz_trunc >> 1) - 1), nb);
+        }
+        lc3_bw_bool_backward(w, spec.lsb_mode);
+        lc3_bw_uint_backward(w, (uint32_t)spec.gg_ind, 8);
+        for (int f = 0; f < tns.num_tns_filters; f++) lc3_bw_bool_backward(w, tns.rc_order[f] != 0);
+        lc3_bw_bool_backward(w, ltpf.pitch_present);
+        lc3_bw_uint_backward(w, (uint32_t)sns.ind_lf, 5);
+        lc3_bw_uint_backward(w, (uint32_t)sns.ind_hf, 5);
+        {
+            const int submode_msb = (sns.shape_j >> 1) != 0;
+            lc3_bw_bool_backward(w, submode_msb);
+            lc3_bw_uint_backward(w, (uint32_t)(sns.gind >> LC3T_SNS_GAIN_LSB_BITS[sns.shape_j]),
+                                 LC3T_SNS_GAIN_MSB_BITS[sns.shape_j]);
+            lc3_bw_bool_backward(w, sns.ls_inda != 0);
+            if (!submode_msb) {
+                lc3_bw_uint_backward(w, sns.index_joint_j, 13);
+                lc3_bw_uint_backward(w, sns.index_joint_j >> 13, 12);
+            } else {
+                lc3_bw_uint_backward(w, sns.index_joint_j, 12);
+                lc3_bw_uint_backward(w, sns.index_joint_j >> 12, 12);
+            }
+        }
+        if (ltpf.pitch_present) {
+            lc3_bw_bool_backward(w, ltpf.ltpf_active);
+            lc3_bw_uint_backward(w, (uint32_t)ltpf.pitch_index, 9);
+        }
+        lc3_bw_uint_backward(w, (uint32_t)noise_factor, 3);
+        // ac_enc_init :216-222
+        w.low = 0;
+        w.range = 0x00ffffffu;
+        w.cache = -1;
+        w.carry = 0;
+        w.carry_count = 0;
+        // tns_data :224-244
+        for (int f = 0; f < tns.num_tns_filters; f++) {
+            if (tns.rc_order[f] > 0) {
+                lc3_ac_encode(w, LC3T_AC_TNS_ORDER_CUMFREQ[tns.lpc_weighting][tns.rc_order[f] - 1],
+                              LC3T_AC_TNS_ORDER_FREQ[tns.lpc_weighting][tns.rc_order[f] - 1]);
+                for (int k = 0; k < tns.rc_order[f]; k++) {
+                    int ri = rc_i[k + 8 * f];
+                    ri = ri < 0 ? 0 : (ri > 16 ? 16 : ri);
+                    lc3_ac_encode(w, LC3T_AC_TNS_COEF_CUMFREQ[k][ri], LC3T_AC_TNS_COEF_FREQ[k][ri]);
+                }
+            }
+        }
+        // spectral_data :246-326
+        {
+            int cctx = 0;
+            for (int k = 0; k < spec.lastnz_trunc; k += 2) {
+                int t = cctx + spec.rate_flag + (k > ne / 2 ? 256 : 0), lev = 0;
+                const int q0 = L.xq[k], q1 = L.xq[k + 1];
+                unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
+                unsigned a_lsb = a, b_lsb = b;
+                int lsb0 = 0, lsb1 = 0;
+                while ((a > b ? a : b) >= 4) {
+                    int pki = LC3T_AC_SPEC_LOOKUP[t + (lev < 3 ? lev : 3) * 1024];
+                    lc3_ac_encode(w, LC3T_AC_SPEC_CUMFREQ[pki][16], LC3T_AC_SPEC_FREQ[pki][16]);
+                    if (spec.lsb_mode && lev == 0) {
+                        lsb0 = (int)(a & 1u);
+                        lsb1 = (int)(b & 1u);
+                    } else {
+                        lc3_bw_bool_backward(w, (a & 1u) == 1u);
+                        lc3_bw_bool_backward(w, (b & 1u) == 1u);
+                    }
+                    a >>= 1;
+                    b >>= 1;
+                    lev += 1;
+                }
+                int pki = LC3T_AC_SPEC_LOOKUP[t + (lev < 3 ? lev : 3) * 1024];
+                int sym = (int)(a + 4 * b);
+                lc3_ac_encode(w, LC3T_AC_SPEC_CUMFREQ[pki][sym], LC3T_AC_SPEC_FREQ[pki][sym]);
+                if (spec.lsb_mode && lev > 0) {
+                    a_lsb >>= 1;
+                    b_lsb >>= 1;
+                    if (nlsbs < lsbs_cap) lsbs[nlsbs] = (uint8_t)lsb0;
+                    nlsbs++;
+                    if (a_lsb == 0 && q0 != 0) {
+                        if (nlsbs < lsbs_cap) lsbs[nlsbs] = q0 > 0 ? 0 : 1;
+                        nlsbs++;
+                    }
+                    if (nlsbs < lsbs_cap) lsbs[nlsbs] = (uint8_t)lsb1;
+                    nlsbs++;
+                    if (b_lsb == 0 && q1 != 0) {
+                        if (nlsbs < lsbs_cap) lsbs[nlsbs] = q1 > 0 ? 0 : 1;
+                        nlsbs++;
+                    }
+                }
+                if (a_lsb > 0) lc3_bw_bool_backward(w, q0 <= 0);
+                if (b_lsb > 0) lc3_bw_bool_backward(w, q1 <= 0);
+                lev = lev < 3 ? lev : 3;
+                t = lev <= 1 ? 1 + (int)(a + b) * (lev + 1) : 12 + lev;
+                cctx = (cctx & 15) * 16 + t;
+            }
+        }
+        // residual_data_and_finalization :328-352
+        {
+            int nbits_side = w.nbits - (8 * w.bp_side + 8 - lc3_ilog2((uint32_t)w.mask_side));
+            int nbits_ari = w.bp * 8 + 25 - lc3_ilog2(w.range);  // nbits_side_forcast :64-75
+            if (w.carry >= 0) nbits_ari += 8;
+            if (w.carry_count > 0) nbits_ari += w.carry_count * 8;
+            int n_enc = w.nbits - (nbits_side + nbits_ari);
+            if (n_enc < 0) n_enc = 0;
+            if (!spec.lsb_mode) {
+                for (int k = 0; k < n_enc && k < n_res_bits; k++) lc3_bw_bool_backward(w, L.res_bits[k]);
+            } else {
+                if (n_enc > nlsbs) n_enc = nlsbs;
+                for (int k = 0; k < n_enc; k++) lc3_bw_bool_backward(w, lsbs[k] == 1);
+            }
+        }
+        // ac_enc_finish :354-395
+        {
+            int bits = 1;
+            while ((w.range >> (24 - bits)) == 0) bits++;
+            uint32_t mask = 0x00ffffffu >> bits;
+            uint32_t val = w.low + mask;
+            uint32_t over1 = val >> 24;
+            uint32_t high = w.low + w.range;
+            uint32_t over2 = high >> 24;
+            val &= 0x00ffffffu & ~mask;
+            if (over1 == over2) {
+                if ((val + mask) >= high) {
+                    bits += 1;
+                    mask >>= 1;
+                    val = ((w.low + mask) & 0x00ffffffu) & ~mask;
+                }
+                if (val < w.low) w.carry = 1;
+            }
+            w.low = val;
+            while (bits > 0) {
+                lc3_ac_shift(w);
+                bits -= 8;
+            }
+            bits += 8;
+            if (w.carry_count > 0) {
+                lc3_bw_byte_forward(w, w.cache & 0xff);
+                while (w.carry_count > 1) {
+                    lc3_bw_byte_forward(w, 0xff);
+                    w.carry_count -= 1;
+                }
+                lc3_bw_uint_forward(w, 0xffu >> (8 - bits), bits);
+            } else {
+                lc3_bw_uint_forward(w, (unsigned)w.cache, bits);
+            }
+        }
+    }
+    LC3_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// EncoderChannel::encode (encoder/lc3_encoder.rs:63-112): one frame of one stream on one wave.
+// pcm: nf samples in HBM (4-byte aligned); out: nbytes in HBM.  dbg (optional): float[3*480] stage dumps.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lc3_encode_frame_wave(const lc3_cfg &c, lc3_enc_lds &L, int lane, const int16_t *pcm,
+                                                      uint8_t *out, int nbytes, float *dbg) {
+    const int nbits = nbytes * 8;
+    const int near_nyquist = lc3_enc_mdct(c, L, lane, pcm);
+    if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[i] = L.spec[i];
+    int nbits_bw;
+    const int bw_ind = lc3_enc_bandwidth(c, L, lane, &nbits_bw);
+    const int attack = lc3_enc_attack(c, L, lane, nbytes);
+    const lc3_sns_res sns = lc3_enc_sns(c, L, lane, attack);
+    if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[480 + i] = L.spec[i];
+    const lc3_tns_res tns = lc3_enc_tns(c, L, lane, bw_ind, nbits, near_nyquist);
+    if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[960 + i] = L.spec[i];
+    const lc3_ltpf_res pf = lc3_enc_ltpf(c, L, lane, near_nyquist, nbits);
+    const lc3_quant_res spec = lc3_enc_quant(c, L, lane, nbits, nbits_bw, tns.nbits_tns, pf.nbits_ltpf);
+    lc3_enc_residual_noise(c, L, lane, spec, bw_ind);
+    const int n_res = L.ism[0], noise_factor = L.ism[1];
+    LC3_SYNC();
+    if (dbg && lane == 0) {
+        float *d = dbg + 1440;
+        d[0] = (float)bw_ind; d[1] = (float)attack; d[2] = (float)sns.ind_lf; d[3] = (float)sns.ind_hf;
+        d[4] = (float)sns.shape_j; d[5] = (float)sns.gind; d[6] = (float)tns.rc_order[0]; d[7] = (float)tns.rc_order[1];
+        d[8] = (float)tns.nbits_tns; d[9] = (float)pf.pitch_index; d[10] = (float)pf.pitch_present;
+        d[11] = (float)pf.ltpf_active; d[12] = (float)spec.gg_ind; d[13] = (float)spec.lastnz_trunc;
+        d[14] = (float)spec.nbits_lsb; d[15] = (float)spec.lsb_mode; d[16] = (float)n_res; d[17] = (float)noise_factor;
+        d[18] = spec.gg; d[19] = (float)spec.nbits_spec; d[20] = (float)spec.nbits_trunc; d[21] = (float)near_nyquist;
+    }
+    lc3_enc_bitstream(c, L, lane, bw_ind, nbits_bw, sns, tns, pf, spec, n_res, noise_factor, nbytes);
+    for (int i = lane; i < nbytes; i += LC3_WAVE) out[i] = L.out[i];
+    LC3_SYNC();
+}

@@ -1,0 +1,453 @@
+// lc3gpu -- kernels and C ABI of the MI355X-native batched LC3 codec.  gfx950 only.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.build()).
+//
+// Launch geometry: one workgroup = one wavefront (64 threads) = one stream.  A launch covers
+// `n_channels` streams x `n_frames` frames; the wave loads its stream state from HBM into LDS once,
+// runs the frames in time order and writes the state back.  blockIdx -> stream is the identity:
+// streams share nothing but the read-only tables, so XCD placement only affects table L2 hits.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/lc3gpu.h"
+
+#define LC3_SYNC() __syncthreads()
+#include "lc3_dev_dec.h"
+#include "lc3_dev_enc.h"
+#include "lc3_host_plan.h"
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void lc3_encode_kernel(lc3_cfg cfg, lc3_enc_state *states, int first_channel,
+                                                       const int16_t *pcm, uint8_t *out, int nbytes, int n_frames,
+                                                       int fresh, float *dbg) {
+    __shared__ lc3_enc_lds L;
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x;  // stream index inside this launch
+    lc3_enc_state *gst = states + (size_t)(first_channel + s);
+    if (fresh) lc3_enc_state_init(L, lane);
+    else lc3_enc_state_load(L, lane, gst);
+    for (int t = 0; t < n_frames; t++) {
+        const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
+        lc3_encode_frame_wave(cfg, L, lane, pcm + f * (size_t)cfg.nf, out + f * (size_t)nbytes, nbytes, dbg);
+    }
+    lc3_enc_state_store(L, lane, gst);
+}
+
+__global__ __launch_bounds__(64) void lc3_decode_kernel(lc3_cfg cfg, lc3_dec_state *states, int first_channel,
+                                                       const uint8_t *in, const uint8_t *bad, int16_t *pcm, int nbytes,
+                                                       int n_frames, int fresh) {
+    __shared__ lc3_dec_lds L;
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x;
+    lc3_dec_state *gst = states + (size_t)(first_channel + s);
+    if (fresh) lc3_dec_state_init(L, lane);
+    else lc3_dec_state_load(L, lane, gst);
+    for (int t = 0; t < n_frames; t++) {
+        const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
+        const int force_plc = bad ? (int)bad[f] : 0;
+        lc3_decode_frame_wave(cfg, L, lane, in + f * (size_t)nbytes, nbytes, pcm + f * (size_t)cfg.nf, force_plc);
+    }
+    lc3_dec_state_store(L, lane, gst);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+thread_local int g_last_hip = 0;
+
+#define HIP_TRY(expr)                       \
+    do {                                    \
+        hipError_t e_ = (expr);             \
+        if (e_ != hipSuccess) {             \
+            g_last_hip = (int)e_;           \
+            return LC3GPU_EHIP;             \
+        }                                   \
+    } while (0)
+
+struct HostCfg {
+    lc3_cfg c;
+    void *d_tables = nullptr;  // fft_tw | dct_tw | perm in one allocation
+};
+
+int make_config(lc3_cfg &c, int frame_us, int fs_hz) {
+    return lc3_make_config(c, frame_us, fs_hz) ? LC3GPU_EINVAL : LC3GPU_OK;
+}
+
+// build the plan on the host (lc3_host_plan.h) and upload its three tables in one allocation
+int build_tables(HostCfg &h) {
+    lc3_cfg &c = h.c;
+    lc3_host_plan pl;
+    if (lc3_make_plan(c, pl)) return LC3GPU_EINVAL;
+    const int nfft = c.nfft;
+    const size_t bytes_tw = sizeof(lc3_cpx) * (size_t)nfft;
+    const size_t bytes = 2 * bytes_tw + sizeof(uint16_t) * (size_t)nfft;
+    HIP_TRY(hipMalloc(&h.d_tables, bytes));
+    char *base = (char *)h.d_tables;
+    HIP_TRY(hipMemcpy(base, pl.fft_tw.data(), bytes_tw, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + bytes_tw, pl.dct_tw.data(), bytes_tw, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + 2 * bytes_tw, pl.perm.data(), sizeof(uint16_t) * (size_t)nfft, hipMemcpyHostToDevice));
+    c.fft_tw = (const lc3_cpx *)base;
+    c.dct_tw = (const lc3_cpx *)(base + bytes_tw);
+    c.perm = (const uint16_t *)(base + 2 * bytes_tw);
+    return LC3GPU_OK;
+}
+
+}  // namespace
+
+struct lc3gpu_encoder {
+    HostCfg h;
+    int num_channels = 0;
+    lc3_enc_state *d_states = nullptr;
+    bool fresh = true;  // states not yet materialised in HBM: kernels initialise in LDS
+    // staging for the single-frame host API
+    int16_t *d_pcm1 = nullptr;
+    uint8_t *d_out1 = nullptr;
+    float *d_dbg = nullptr;
+    std::vector<uint8_t> fresh_mask;  // per channel: 1 = still fresh
+};
+
+struct lc3gpu_decoder {
+    HostCfg h;
+    int num_channels = 0;
+    lc3_dec_state *d_states = nullptr;
+    uint8_t *d_in1 = nullptr;
+    int16_t *d_pcm1 = nullptr;
+};
+
+extern "C" {
+
+int lc3gpu_version(void) { return 100; }
+
+const char *lc3gpu_strerror(int code) {
+    switch (code) {
+    case LC3GPU_OK: return "ok";
+    case LC3GPU_EINVAL: return "invalid argument";
+    case LC3GPU_ECHANNEL: return "channel index out of range";
+    case LC3GPU_ELENGTH: return "buffer length does not match the configuration";
+    case LC3GPU_EBITS: return "only 16 bits per audio sample supported";
+    case LC3GPU_EHIP: return "HIP runtime error";
+    case LC3GPU_ENODEVICE: return "no HIP device";
+    case LC3GPU_EUNSUPPORTED: return "configuration not supported by the reference";
+    default: return "unknown error";
+    }
+}
+
+int lc3gpu_last_hip_error(void) { return g_last_hip; }
+
+int lc3gpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lc3gpu_config(int frame_us, int fs_hz, int out[7]) {
+    lc3_cfg c;
+    if (!out) return LC3GPU_EINVAL;
+    int rc = make_config(c, frame_us, fs_hz);
+    if (rc) return rc;
+    out[0] = c.fs_ind; out[1] = c.fs; out[2] = c.ne; out[3] = c.n_ms_10; out[4] = c.nb; out[5] = c.nf; out[6] = c.z;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_encoder_working_buffer_lengths(int num_channels, int frame_us, int fs_hz, int64_t out[3]) {
+    lc3_cfg c;
+    if (!out || num_channels < 0) return LC3GPU_EINVAL;
+    int rc = make_config(c, frame_us, fs_hz);
+    if (rc) return rc;
+    // lc3_encoder.rs:194-209, modified_dct.rs:67-71, long_term_post_filter.rs:93-137, dct_iv.rs:69-71
+    const int64_t integer_len = 2 * c.nf + (c.hist + c.nf) + c.ne;
+    const int64_t scaler_len = (c.len12 + c.delay12 + 232) + (64 + 114) + c.nf + c.nb;
+    const int64_t complex_len = c.nf / 2 * 4;
+    out[0] = integer_len * num_channels;
+    out[1] = scaler_len * num_channels;
+    out[2] = complex_len * num_channels;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_decoder_working_buffer_lengths(int num_channels, int frame_us, int fs_hz, int64_t out[2]) {
+    lc3_cfg c;
+    if (!out || num_channels < 0) return LC3GPU_EINVAL;
+    int rc = make_config(c, frame_us, fs_hz);
+    if (rc) return rc;
+    // lc3_decoder.rs:155-162, modified_dct.rs:153-166, long_term_post_filter.rs:104-140
+    const int64_t dct = c.nf / 2 + (c.nf - c.ne) + (c.nf - c.z) + 2 * c.nf + c.nf;
+    const int64_t c_num = c.l_num + 1, c_den = c.l_den + 1, scratch = c.l_num + c.norm;
+    const int64_t ltpf = c_den * 3 + c_num * 2 + 2 * (int64_t)c.nf * c.num_mem_blocks + scratch;
+    out[0] = (c.ne + c.ne + dct + ltpf) * num_channels;
+    out[1] = (int64_t)(c.nf / 2 * 4) * num_channels;
+    return LC3GPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int lc3gpu_encoder_create(lc3gpu_encoder **out, int num_channels, int frame_us, int fs_hz) {
+    if (!out || num_channels <= 0) return LC3GPU_EINVAL;
+    *out = nullptr;
+    lc3_cfg c;
+    int rc = make_config(c, frame_us, fs_hz);
+    if (rc) return rc;
+    // the reference cannot construct an 8 kHz encoder (encoder/bandwidth_detector.rs:36-37 indexes [fs_ind - 1])
+    if (c.fs_ind == 0) return LC3GPU_EUNSUPPORTED;
+    if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
+    lc3gpu_encoder *e = new (std::nothrow) lc3gpu_encoder();
+    if (!e) return LC3GPU_EINVAL;
+    e->h.c = c;
+    e->num_channels = num_channels;
+    rc = build_tables(e->h);
+    if (rc) { lc3gpu_encoder_destroy(e); return rc; }
+    if (hipMalloc((void **)&e->d_states, sizeof(lc3_enc_state) * (size_t)num_channels) != hipSuccess ||
+        hipMalloc((void **)&e->d_pcm1, sizeof(int16_t) * LC3_MAX_NF) != hipSuccess ||
+        hipMalloc((void **)&e->d_out1, LC3_MAX_NE) != hipSuccess ||
+        hipMalloc((void **)&e->d_dbg, sizeof(float) * 1472) != hipSuccess) {
+        lc3gpu_encoder_destroy(e);
+        return LC3GPU_EHIP;
+    }
+    e->fresh = true;
+    e->fresh_mask.assign((size_t)num_channels, 1);
+    *out = e;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_encoder_destroy(lc3gpu_encoder *e) {
+    if (!e) return LC3GPU_OK;
+    if (e->d_states) (void)hipFree(e->d_states);
+    if (e->d_pcm1) (void)hipFree(e->d_pcm1);
+    if (e->d_out1) (void)hipFree(e->d_out1);
+    if (e->d_dbg) (void)hipFree(e->d_dbg);
+    if (e->h.d_tables) (void)hipFree(e->h.d_tables);
+    delete e;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_encoder_reset(lc3gpu_encoder *e) {
+    if (!e) return LC3GPU_EINVAL;
+    e->fresh = true;
+    e->fresh_mask.assign((size_t)e->num_channels, 1);
+    return LC3GPU_OK;
+}
+
+static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_pcm, uint8_t *d_out, int nbytes,
+                         int n_frames, hipStream_t stream, float *dbg) {
+    if (!e || !d_pcm || !d_out) return LC3GPU_EINVAL;
+    if (first < 0 || n <= 0 || first + n > e->num_channels) return LC3GPU_ECHANNEL;
+    if (nbytes < 20 || nbytes > LC3_MAX_NE || n_frames <= 0) return LC3GPU_ELENGTH;
+    if (((uintptr_t)d_pcm & 3u) != 0) return LC3GPU_EINVAL;
+    // a range is launched "fresh" only if every channel in it is still fresh
+    int fresh = 1;
+    for (int i = first; i < first + n; i++) fresh &= e->fresh_mask[(size_t)i];
+    if (!fresh) {
+        // materialise any still-fresh channel of the range with a zero-frame launch of the init path
+        for (int i = first; i < first + n; i++) {
+            if (e->fresh_mask[(size_t)i]) {
+                hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64), 0, stream, e->h.c, e->d_states, i, d_pcm,
+                                   d_out, nbytes, 0, 1, (float *)nullptr);
+                e->fresh_mask[(size_t)i] = 0;
+            }
+        }
+    }
+    hipLaunchKernelGGL(lc3_encode_kernel, dim3((unsigned)n), dim3(64), 0, stream, e->h.c, e->d_states, first, d_pcm,
+                       d_out, nbytes, n_frames, fresh, dbg);
+    HIP_TRY(hipGetLastError());
+    for (int i = first; i < first + n; i++) e->fresh_mask[(size_t)i] = 0;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_encode(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out, int nbytes, int n_frames, void *stream) {
+    if (!e) return LC3GPU_EINVAL;
+    return encode_launch(e, 0, e->num_channels, d_pcm, d_out, nbytes, n_frames, (hipStream_t)stream, nullptr);
+}
+
+int lc3gpu_encode_range(lc3gpu_encoder *e, int first_channel, int n_channels, const int16_t *d_pcm, uint8_t *d_out,
+                        int nbytes, int n_frames, void *stream) {
+    return encode_launch(e, first_channel, n_channels, d_pcm, d_out, nbytes, n_frames, (hipStream_t)stream, nullptr);
+}
+
+static int encode_frame_host(lc3gpu_encoder *e, int channel_index, const int16_t *samples_in, int n_samples,
+                             uint8_t *buf_out, int nbytes, float *dbg) {
+    if (!e || !samples_in || !buf_out) return LC3GPU_EINVAL;
+    if (channel_index < 0 || channel_index >= e->num_channels) return LC3GPU_ECHANNEL;
+    if (n_samples != e->h.c.nf) return LC3GPU_ELENGTH;
+    if (nbytes < 20 || nbytes > LC3_MAX_NE) return LC3GPU_ELENGTH;
+    HIP_TRY(hipMemcpy(e->d_pcm1, samples_in, sizeof(int16_t) * (size_t)n_samples, hipMemcpyHostToDevice));
+    int rc = encode_launch(e, channel_index, 1, e->d_pcm1, e->d_out1, nbytes, 1, nullptr, dbg ? e->d_dbg : nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(buf_out, e->d_out1, (size_t)nbytes, hipMemcpyDeviceToHost));
+    if (dbg) HIP_TRY(hipMemcpy(dbg, e->d_dbg, sizeof(float) * 1472, hipMemcpyDeviceToHost));
+    return LC3GPU_OK;
+}
+
+int lc3gpu_encode_frame(lc3gpu_encoder *e, int channel_index, const int16_t *samples_in, int n_samples,
+                        uint8_t *buf_out, int nbytes) {
+    return encode_frame_host(e, channel_index, samples_in, n_samples, buf_out, nbytes, nullptr);
+}
+
+int lc3gpu_encode_frame_debug(lc3gpu_encoder *e, const int16_t *samples_in, int n_samples, uint8_t *buf_out, int nbytes,
+                              float *dbg) {
+    if (!dbg) return LC3GPU_EINVAL;
+    return encode_frame_host(e, 0, samples_in, n_samples, buf_out, nbytes, dbg);
+}
+
+size_t lc3gpu_encoder_state_size(const lc3gpu_encoder *e) { return e ? sizeof(lc3_enc_state) : 0; }
+
+int lc3gpu_encoder_state_save(lc3gpu_encoder *e, void *host_dst) {
+    if (!e || !host_dst) return LC3GPU_EINVAL;
+    // materialise fresh channels first
+    for (int i = 0; i < e->num_channels; i++) {
+        if (e->fresh_mask[(size_t)i]) {
+            hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64), 0, nullptr, e->h.c, e->d_states, i, e->d_pcm1,
+                               e->d_out1, 20, 0, 1, (float *)nullptr);
+            e->fresh_mask[(size_t)i] = 0;
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_dst, e->d_states, sizeof(lc3_enc_state) * (size_t)e->num_channels, hipMemcpyDeviceToHost));
+    return LC3GPU_OK;
+}
+
+int lc3gpu_encoder_state_load(lc3gpu_encoder *e, const void *host_src) {
+    if (!e || !host_src) return LC3GPU_EINVAL;
+    HIP_TRY(hipMemcpy(e->d_states, host_src, sizeof(lc3_enc_state) * (size_t)e->num_channels, hipMemcpyHostToDevice));
+    e->fresh_mask.assign((size_t)e->num_channels, 0);
+    return LC3GPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int decoder_init_states(lc3gpu_decoder *d) {
+    // decoder state is materialised eagerly (fresh = 1, zero frames): PLC counters must survive range launches
+    uint8_t *dummy = d->d_in1;
+    hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)d->num_channels), dim3(64), 0, nullptr, d->h.c, d->d_states, 0,
+                       dummy, (const uint8_t *)nullptr, d->d_pcm1, 20, 0, 1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return LC3GPU_OK;
+}
+
+int lc3gpu_decoder_create(lc3gpu_decoder **out, int num_channels, int frame_us, int fs_hz) {
+    if (!out || num_channels <= 0) return LC3GPU_EINVAL;
+    *out = nullptr;
+    lc3_cfg c;
+    int rc = make_config(c, frame_us, fs_hz);
+    if (rc) return rc;
+    if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
+    lc3gpu_decoder *d = new (std::nothrow) lc3gpu_decoder();
+    if (!d) return LC3GPU_EINVAL;
+    d->h.c = c;
+    d->num_channels = num_channels;
+    rc = build_tables(d->h);
+    if (rc) { lc3gpu_decoder_destroy(d); return rc; }
+    if (hipMalloc((void **)&d->d_states, sizeof(lc3_dec_state) * (size_t)num_channels) != hipSuccess ||
+        hipMalloc((void **)&d->d_in1, LC3_MAX_NE) != hipSuccess ||
+        hipMalloc((void **)&d->d_pcm1, sizeof(int16_t) * LC3_MAX_NF) != hipSuccess) {
+        lc3gpu_decoder_destroy(d);
+        return LC3GPU_EHIP;
+    }
+    rc = decoder_init_states(d);
+    if (rc) { lc3gpu_decoder_destroy(d); return rc; }
+    *out = d;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_decoder_destroy(lc3gpu_decoder *d) {
+    if (!d) return LC3GPU_OK;
+    if (d->d_states) (void)hipFree(d->d_states);
+    if (d->d_in1) (void)hipFree(d->d_in1);
+    if (d->d_pcm1) (void)hipFree(d->d_pcm1);
+    if (d->h.d_tables) (void)hipFree(d->h.d_tables);
+    delete d;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_decoder_reset(lc3gpu_decoder *d) {
+    if (!d) return LC3GPU_EINVAL;
+    return decoder_init_states(d);
+}
+
+static int decode_launch(lc3gpu_decoder *d, int first, int n, const uint8_t *d_in, const uint8_t *d_bad, int16_t *d_pcm,
+                         int nbytes, int n_frames, hipStream_t stream) {
+    if (!d || !d_in || !d_pcm) return LC3GPU_EINVAL;
+    if (first < 0 || n <= 0 || first + n > d->num_channels) return LC3GPU_ECHANNEL;
+    if (nbytes < 1 || nbytes > LC3_MAX_NE || n_frames <= 0) return LC3GPU_ELENGTH;
+    if (((uintptr_t)d_pcm & 3u) != 0) return LC3GPU_EINVAL;
+    hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)n), dim3(64), 0, stream, d->h.c, d->d_states, first, d_in,
+                       d_bad, d_pcm, nbytes, n_frames, 0);
+    HIP_TRY(hipGetLastError());
+    return LC3GPU_OK;
+}
+
+int lc3gpu_decode(lc3gpu_decoder *d, const uint8_t *d_in, const uint8_t *d_bad, int16_t *d_pcm, int nbytes, int n_frames,
+                  void *stream) {
+    if (!d) return LC3GPU_EINVAL;
+    return decode_launch(d, 0, d->num_channels, d_in, d_bad, d_pcm, nbytes, n_frames, (hipStream_t)stream);
+}
+
+int lc3gpu_decode_range(lc3gpu_decoder *d, int first_channel, int n_channels, const uint8_t *d_in, const uint8_t *d_bad,
+                        int16_t *d_pcm, int nbytes, int n_frames, void *stream) {
+    return decode_launch(d, first_channel, n_channels, d_in, d_bad, d_pcm, nbytes, n_frames, (hipStream_t)stream);
+}
+
+int lc3gpu_decode_frame(lc3gpu_decoder *d, int num_bits_per_audio_sample, int channel_index, const uint8_t *buf_in,
+                        int nbytes, int16_t *samples_out, int n_samples) {
+    if (!d || !buf_in || !samples_out) return LC3GPU_EINVAL;
+    if (num_bits_per_audio_sample != 16) return LC3GPU_EBITS;  // checked first, as in lc3_decoder.rs:80-82
+    if (channel_index < 0 || channel_index >= d->num_channels) return LC3GPU_ECHANNEL;
+    if (n_samples != d->h.c.nf) return LC3GPU_ELENGTH;
+    if (nbytes < 1 || nbytes > LC3_MAX_NE) return LC3GPU_ELENGTH;
+    HIP_TRY(hipMemcpy(d->d_in1, buf_in, (size_t)nbytes, hipMemcpyHostToDevice));
+    int rc = decode_launch(d, channel_index, 1, d->d_in1, nullptr, d->d_pcm1, nbytes, 1, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(samples_out, d->d_pcm1, sizeof(int16_t) * (size_t)n_samples, hipMemcpyDeviceToHost));
+    return LC3GPU_OK;
+}
+
+size_t lc3gpu_decoder_state_size(const lc3gpu_decoder *d) { return d ? sizeof(lc3_dec_state) : 0; }
+
+int lc3gpu_decoder_state_save(lc3gpu_decoder *d, void *host_dst) {
+    if (!d || !host_dst) return LC3GPU_EINVAL;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_dst, d->d_states, sizeof(lc3_dec_state) * (size_t)d->num_channels, hipMemcpyDeviceToHost));
+    return LC3GPU_OK;
+}
+
+int lc3gpu_decoder_state_load(lc3gpu_decoder *d, const void *host_src) {
+    if (!d || !host_src) return LC3GPU_EINVAL;
+    HIP_TRY(hipMemcpy(d->d_states, host_src, sizeof(lc3_dec_state) * (size_t)d->num_channels, hipMemcpyHostToDevice));
+    return LC3GPU_OK;
+}
+
+int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
+    if (!d || !out) return LC3GPU_EINVAL;
+    std::vector<lc3_dec_state> st((size_t)d->num_channels);
+    int rc = lc3gpu_decoder_state_save(d, st.data());
+    if (rc) return rc;
+    uint64_t total = 0;
+    for (const auto &s : st) total += (uint64_t)s.plc_events;
+    *out = total;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_kernel_info(int which, int out[5]) {
+    if (!out) return LC3GPU_EINVAL;
+    hipFuncAttributes a;
+    hipError_t e = which == 0 ? hipFuncGetAttributes(&a, (const void *)lc3_encode_kernel)
+                              : hipFuncGetAttributes(&a, (const void *)lc3_decode_kernel);
+    if (e != hipSuccess) {
+        g_last_hip = (int)e;
+        return LC3GPU_EHIP;
+    }
+    out[0] = (int)a.sharedSizeBytes;
+    out[1] = a.numRegs;
+    out[2] = 0;
+    out[3] = (int)a.localSizeBytes;
+    out[4] = a.maxThreadsPerBlock;
+    return LC3GPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+"""Deterministic synthetic PCM for parity tests and bench.py.
+
+Host-side, numpy only: the same int16 arrays feed the CPU oracle and the GPU engine.
+Per stream: a harmonic tone (f0 ~ logU[80, 400] Hz, partials 1, 1/2, 1/3 with random phases;
+exercises pitch search / LTPF), level ~U[-18, -3] dBFS, additive uniform white noise at
+U[-45, -20] dBFS, and with probability 1/16 per frame a 2 ms exponentially decaying click at
++6 dB (attack detector / TNS).  5 % of the streams are all-zero (zero-frame paths) and 5 % are
+full-scale white noise (clipping, high global gain).  Computed in float64, rounded to nearest,
+clipped to int16.  Layout int16[S][T][nf] (stream-major, planar)."""
+import numpy as np
+
+SEED = 0x4C43335F  # "LC3_"
+
+
+def make_pcm(n_streams, n_frames, nf, fs_hz, seed=SEED, first_stream=0):
+    """Streams are generated independently from (seed, stream index) so that shards of a larger
+    batch (multi-GPU ranks) see exactly the streams a single-process run would."""
+    out = np.zeros((n_streams, n_frames, nf), np.int16)
+    n = n_frames * nf
+    t = np.arange(n, dtype=np.float64) / float(fs_hz)
+    for i in range(n_streams):
+        sid = first_stream + i
+        rng = np.random.default_rng([seed, sid])
+        kind = rng.random()
+        if kind < 0.05:
+            continue  # silent stream
+        if kind < 0.10:
+            x = rng.uniform(-1.0, 1.0, n) * 40000.0  # clips
+        else:
+            f0 = float(np.exp(rng.uniform(np.log(80.0), np.log(400.0))))
+            level = 10.0 ** (rng.uniform(-18.0, -3.0) / 20.0) * 32767.0
+            noise = 10.0 ** (rng.uniform(-45.0, -20.0) / 20.0) * 32767.0
+            ph = rng.uniform(0.0, 2.0 * np.pi, 3)
+            x = np.zeros(n)
+            for h, amp in enumerate((1.0, 0.5, 1.0 / 3.0)):
+                x += amp * np.sin(2.0 * np.pi * f0 * (h + 1) * t + ph[h])
+            x *= level / 1.6
+            x += rng.uniform(-1.0, 1.0, n) * noise
+            clicks = rng.random(n_frames) < (1.0 / 16.0)
+            tau = 0.002 * fs_hz / 4.0
+            for fr in np.flatnonzero(clicks):
+                start = fr * nf + int(rng.integers(0, nf))
+                ln = min(n - start, int(0.002 * fs_hz) * 3)
+                env = np.exp(-np.arange(ln) / tau)
+                x[start:start + ln] += 2.0 * level * env * rng.choice([-1.0, 1.0])
+        out[i] = np.clip(np.rint(x), -32768, 32767).astype(np.int16).reshape(n_frames, nf)
+    return out

@@ -1,0 +1,142 @@
+// TEST INFRASTRUCTURE -- CPU wave emulator for the HIP device code.
+//
+// Compiles the product's device headers (lc3-codec_amd/csrc/lc3_dev_*.h) UNCHANGED with g++ and runs
+// one "wavefront" as 64 host threads that meet at a pthread barrier wherever the kernel has a
+// workgroup barrier.  It exists so that the lane-parallel decomposition (indexing, barrier
+// placement, LDS aliasing) can be checked against the oracle in this GPU-less container before
+// GPU minutes are spent; it is never shipped or timed.  Build: tests/emu_lib.py.
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#define __device__
+#define __forceinline__ inline __attribute__((always_inline))
+
+static pthread_barrier_t g_bar;
+#define LC3_SYNC() pthread_barrier_wait(&g_bar)
+
+#include "../../lc3-codec_amd/csrc/lc3_dev_dec.h"
+#include "../../lc3-codec_amd/csrc/lc3_dev_enc.h"
+#include "../../lc3-codec_amd/csrc/lc3_host_plan.h"
+
+namespace {
+struct Job {
+    lc3_cfg cfg;
+    int lane;
+    int encode;
+    int n_frames, nbytes, fresh;
+    lc3_enc_lds *EL;
+    lc3_dec_lds *DL;
+    lc3_enc_state *est;
+    lc3_dec_state *dst;
+    const int16_t *pcm_in;
+    uint8_t *bytes_out;
+    const uint8_t *bytes_in;
+    const uint8_t *bad;
+    int16_t *pcm_out;
+    float *dbg;
+};
+
+void *lane_main(void *arg) {
+    Job *j = (Job *)arg;
+    const int lane = j->lane;
+    if (j->encode) {
+        lc3_enc_lds &L = *j->EL;
+        if (j->fresh) lc3_enc_state_init(L, lane);
+        else lc3_enc_state_load(L, lane, j->est);
+        for (int t = 0; t < j->n_frames; t++)
+            lc3_encode_frame_wave(j->cfg, L, lane, j->pcm_in + (size_t)t * j->cfg.nf, j->bytes_out + (size_t)t * j->nbytes,
+                                  j->nbytes, j->dbg);
+        lc3_enc_state_store(L, lane, j->est);
+    } else {
+        lc3_dec_lds &L = *j->DL;
+        if (j->fresh) lc3_dec_state_init(L, lane);
+        else lc3_dec_state_load(L, lane, j->dst);
+        for (int t = 0; t < j->n_frames; t++)
+            lc3_decode_frame_wave(j->cfg, L, lane, j->bytes_in + (size_t)t * j->nbytes, j->nbytes,
+                                  j->pcm_out + (size_t)t * j->cfg.nf, j->bad ? j->bad[t] : 0);
+        lc3_dec_state_store(L, lane, j->dst);
+    }
+    return 0;
+}
+
+void run_wave(Job proto) {
+    pthread_t th[LC3_WAVE];
+    Job jobs[LC3_WAVE];
+    pthread_barrier_init(&g_bar, 0, LC3_WAVE);
+    for (int i = 0; i < LC3_WAVE; i++) {
+        jobs[i] = proto;
+        jobs[i].lane = i;
+        pthread_create(&th[i], 0, lane_main, &jobs[i]);
+    }
+    for (int i = 0; i < LC3_WAVE; i++) pthread_join(th[i], 0);
+    pthread_barrier_destroy(&g_bar);
+}
+}  // namespace
+
+extern "C" {
+// pcm int16[S][T][nf] -> bytes uint8[S][T][nbytes]; every stream starts fresh; dbg optional float[1472] (last frame)
+int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16_t *pcm, uint8_t *bytes, float *dbg) {
+    Job j;
+    memset(&j, 0, sizeof(j));
+    lc3_host_plan pl;
+    if (lc3_make_config(j.cfg, frame_us, fs_hz) || lc3_make_plan(j.cfg, pl)) return -1;
+    j.cfg.fft_tw = pl.fft_tw.data();
+    j.cfg.dct_tw = pl.dct_tw.data();
+    j.cfg.perm = pl.perm.data();
+    j.encode = 1;
+    j.n_frames = T;
+    j.nbytes = nbytes;
+    j.fresh = 1;
+    j.dbg = dbg;
+    lc3_enc_lds *L = (lc3_enc_lds *)calloc(1, sizeof(lc3_enc_lds));
+    lc3_enc_state *st = (lc3_enc_state *)calloc(1, sizeof(lc3_enc_state));
+    j.EL = L;
+    j.est = st;
+    for (int s = 0; s < S; s++) {
+        j.pcm_in = pcm + (size_t)s * T * j.cfg.nf;
+        j.bytes_out = bytes + (size_t)s * T * nbytes;
+        run_wave(j);
+    }
+    free(L);
+    free(st);
+    return 0;
+}
+int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8_t *bytes, const uint8_t *bad,
+                  int16_t *pcm) {
+    Job j;
+    memset(&j, 0, sizeof(j));
+    lc3_host_plan pl;
+    if (lc3_make_config(j.cfg, frame_us, fs_hz) || lc3_make_plan(j.cfg, pl)) return -1;
+    j.cfg.fft_tw = pl.fft_tw.data();
+    j.cfg.dct_tw = pl.dct_tw.data();
+    j.cfg.perm = pl.perm.data();
+    j.encode = 0;
+    j.n_frames = T;
+    j.nbytes = nbytes;
+    j.fresh = 1;
+    lc3_dec_lds *L = (lc3_dec_lds *)calloc(1, sizeof(lc3_dec_lds));
+    lc3_dec_state *st = (lc3_dec_state *)calloc(1, sizeof(lc3_dec_state));
+    j.DL = L;
+    j.dst = st;
+    for (int s = 0; s < S; s++) {
+        j.bytes_in = bytes + (size_t)s * T * nbytes;
+        j.bad = bad ? bad + (size_t)s * T : 0;
+        j.pcm_out = pcm + (size_t)s * T * j.cfg.nf;
+        run_wave(j);
+    }
+    free(L);
+    free(st);
+    return 0;
+}
+float lc3emu_pow10f(float y) { return lc3_pow10f(y); }
+float lc3emu_log2f(float x) { return lc3_log2f(x); }
+float lc3emu_log10f(float x) { return lc3_log10f(x); }
+float lc3emu_exp2f(float x) { return lc3_exp2f(x); }
+float lc3emu_asinf(float x) { return lc3_asinf(x); }
+float lc3emu_sinf_small(float x) { return lc3_sinf_small(x); }
+float lc3emu_exp2_raw(float x) { return lc3_exp2_raw(x); }
+}
