@@ -1,0 +1,338 @@
+"""ctypes binding of liblc3gpu.so and the Python mirror of the reference API.
+
+Names, argument meaning and error behaviour follow the reference:
+  Lc3Encoder.calc_working_buffer_lengths / new / encode_frame   (encoder/lc3_encoder.rs:117-209)
+  Lc3Decoder.calc_working_buffer_lengths / new / decode_frame   (decoder/lc3_decoder.rs:181-244)
+plus the batch entry points (`encode` / `decode`) that take DEVICE pointers
+(e.g. torch tensors' data_ptr()) and a HIP stream.  No torch types cross the ABI.
+"""
+import ctypes
+import enum
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_LIB = os.path.join(_HERE, "lib", "liblc3gpu.so")
+_SRC = os.path.join(_HERE, "csrc", "lc3gpu.hip")
+
+class Lc3GpuError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        msg = _strerror(code)
+        super().__init__(f"lc3gpu error {code} ({msg}){': ' + what if what else ''}")
+
+
+class Lc3EncoderError(Lc3GpuError):
+    """The reference's Lc3EncoderError is an empty enum (lc3_encoder.rs:29-30): encode never returns Err.
+    Raised here only where the reference panics (bad channel index / slice length)."""
+
+
+class Lc3DecoderError(Lc3GpuError):
+    """Lc3DecoderError::Only16BitsPerAudioSampleSupported (lc3_decoder.rs:36-42,80-82) and the panics."""
+
+
+class SamplingFrequency(enum.IntEnum):  # common/config.rs:1-9
+    Hz8000 = 8000
+    Hz16000 = 16000
+    Hz24000 = 24000
+    Hz32000 = 32000
+    Hz44100 = 44100
+    Hz48000 = 48000
+
+
+class FrameDuration(enum.IntEnum):  # common/config.rs:11-15 (microseconds)
+    SevenPointFiveMs = 7500
+    TenMs = 10000
+
+
+_lib = None
+
+
+def library_path():
+    return _LIB
+
+
+def build_native(force=False, verbose=False):
+    """Compile csrc/lc3gpu.hip for gfx950 into lib/liblc3gpu.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs += [os.path.join(_ROOT, "include", "lc3gpu.h"), os.path.join(_ROOT, "tables", "lc3_tables.h")]
+    if not force and os.path.exists(_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(_LIB) for s in srcs):
+        return _LIB
+    os.makedirs(os.path.dirname(_LIB), exist_ok=True)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-fno-fast-math", "-Wno-unused-function", "-Wno-missing-braces", "-o", _LIB, _SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _LIB
+
+
+def load_library():
+    """Load liblc3gpu.so; fails loudly if the native extension is missing (there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise ImportError(f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the LC3 engine has no non-native path)")
+    L = ctypes.CDLL(_LIB)
+    vp, i, pi64 = ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)
+    L.lc3gpu_strerror.restype = ctypes.c_char_p
+    L.lc3gpu_strerror.argtypes = [i]
+    L.lc3gpu_config.argtypes = [i, i, vp]
+    L.lc3gpu_encoder_working_buffer_lengths.argtypes = [i, i, i, pi64]
+    L.lc3gpu_decoder_working_buffer_lengths.argtypes = [i, i, i, pi64]
+    L.lc3gpu_encoder_create.argtypes = [ctypes.POINTER(vp), i, i, i]
+    L.lc3gpu_encoder_destroy.argtypes = [vp]
+    L.lc3gpu_encoder_reset.argtypes = [vp]
+    L.lc3gpu_encode_frame.argtypes = [vp, i, vp, i, vp, i]
+    L.lc3gpu_encode_frame_debug.argtypes = [vp, vp, i, vp, i, vp]
+    L.lc3gpu_encode.argtypes = [vp, vp, vp, i, i, vp]
+    L.lc3gpu_encode_range.argtypes = [vp, i, i, vp, vp, i, i, vp]
+    L.lc3gpu_encoder_state_size.restype = ctypes.c_size_t
+    L.lc3gpu_encoder_state_size.argtypes = [vp]
+    L.lc3gpu_encoder_state_save.argtypes = [vp, vp]
+    L.lc3gpu_encoder_state_load.argtypes = [vp, vp]
+    L.lc3gpu_decoder_create.argtypes = [ctypes.POINTER(vp), i, i, i]
+    L.lc3gpu_decoder_destroy.argtypes = [vp]
+    L.lc3gpu_decoder_reset.argtypes = [vp]
+    L.lc3gpu_decode_frame.argtypes = [vp, i, i, vp, i, vp, i]
+    L.lc3gpu_decode.argtypes = [vp, vp, vp, vp, i, i, vp]
+    L.lc3gpu_decode_range.argtypes = [vp, i, i, vp, vp, vp, i, i, vp]
+    L.lc3gpu_decoder_state_size.restype = ctypes.c_size_t
+    L.lc3gpu_decoder_state_size.argtypes = [vp]
+    L.lc3gpu_decoder_state_save.argtypes = [vp, vp]
+    L.lc3gpu_decoder_state_load.argtypes = [vp, vp]
+    L.lc3gpu_decoder_plc_events.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.lc3gpu_kernel_info.argtypes = [i, vp]
+    _lib = L
+    return L
+
+
+# every symbol include/lc3gpu.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "lc3gpu_version", "lc3gpu_strerror", "lc3gpu_last_hip_error", "lc3gpu_device_count", "lc3gpu_config",
+    "lc3gpu_encoder_working_buffer_lengths", "lc3gpu_decoder_working_buffer_lengths", "lc3gpu_encoder_create",
+    "lc3gpu_encoder_destroy", "lc3gpu_encoder_reset", "lc3gpu_encode_frame", "lc3gpu_encode", "lc3gpu_encode_range",
+    "lc3gpu_encoder_state_size", "lc3gpu_encoder_state_save", "lc3gpu_encoder_state_load", "lc3gpu_decoder_create",
+    "lc3gpu_decoder_destroy", "lc3gpu_decoder_reset", "lc3gpu_decode_frame", "lc3gpu_decode", "lc3gpu_decode_range",
+    "lc3gpu_decoder_state_size", "lc3gpu_decoder_state_save", "lc3gpu_decoder_state_load",
+    "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info",
+]
+
+
+def _strerror(code):
+    try:
+        return load_library().lc3gpu_strerror(int(code)).decode()
+    except Exception:
+        return "?"
+
+
+def device_count():
+    return int(load_library().lc3gpu_device_count())
+
+
+def _ptr(x):
+    """device pointer (int) or host numpy array -> c_void_p"""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data_as(ctypes.c_void_p)
+    if hasattr(x, "data_ptr"):
+        return ctypes.c_void_p(x.data_ptr())
+    return ctypes.c_void_p(int(x))
+
+
+class Lc3Config:
+    """common/config.rs:18-100"""
+
+    def __init__(self, sampling_frequency, frame_duration):
+        out = (ctypes.c_int * 7)()
+        rc = load_library().lc3gpu_config(int(frame_duration), int(sampling_frequency), out)
+        if rc:
+            raise Lc3GpuError(rc, "Lc3Config")
+        self.fs_ind, self.fs, self.ne, n10, self.nb, self.nf, self.z = list(out)
+        self.n_ms = FrameDuration.TenMs if n10 else FrameDuration.SevenPointFiveMs
+
+
+class Lc3Encoder:
+    """`num_channels` independent encoder channels resident on the current HIP device."""
+
+    @staticmethod
+    def calc_working_buffer_lengths(num_channels, frame_duration, sampling_frequency):
+        """-> (integer_len, scaler_len, complex_len), lc3_encoder.rs:194-209"""
+        out = (ctypes.c_int64 * 3)()
+        rc = load_library().lc3gpu_encoder_working_buffer_lengths(num_channels, int(frame_duration),
+                                                                  int(sampling_frequency), out)
+        if rc:
+            raise Lc3EncoderError(rc)
+        return tuple(int(v) for v in out)
+
+    def __init__(self, num_channels, frame_duration, sampling_frequency):
+        self._L = load_library()
+        self.config = Lc3Config(sampling_frequency, frame_duration)
+        self.num_channels = int(num_channels)
+        h = ctypes.c_void_p()
+        rc = self._L.lc3gpu_encoder_create(ctypes.byref(h), self.num_channels, int(frame_duration),
+                                           int(sampling_frequency))
+        if rc:
+            raise Lc3EncoderError(rc, "Lc3Encoder::new")
+        self._h = h
+
+    new = classmethod(lambda cls, *a, **k: cls(*a, **k))
+
+    def encode_frame(self, channel_index, samples_in, buf_out):
+        """encode one frame of one channel; len(buf_out) selects the bitrate (lc3_encoder.rs:65,175-191)"""
+        samples_in = np.ascontiguousarray(samples_in, dtype=np.int16)
+        if not (isinstance(buf_out, np.ndarray) and buf_out.dtype == np.uint8 and buf_out.flags.c_contiguous):
+            raise TypeError("buf_out must be a contiguous uint8 numpy array")
+        rc = self._L.lc3gpu_encode_frame(self._h, int(channel_index), _ptr(samples_in), int(samples_in.size),
+                                         _ptr(buf_out), int(buf_out.size))
+        if rc:
+            raise Lc3EncoderError(rc, "encode_frame")
+
+    def encode_frame_debug(self, samples_in, nbytes):
+        samples_in = np.ascontiguousarray(samples_in, dtype=np.int16)
+        out = np.zeros(nbytes, np.uint8)
+        dbg = np.zeros(1472, np.float32)
+        rc = self._L.lc3gpu_encode_frame_debug(self._h, _ptr(samples_in), int(samples_in.size), _ptr(out), nbytes,
+                                               _ptr(dbg))
+        if rc:
+            raise Lc3EncoderError(rc, "encode_frame_debug")
+        return out, dbg
+
+    def encode(self, d_pcm, d_out, nbytes, n_frames, stream=None, first_channel=None, n_channels=None):
+        """batch: DEVICE int16[S][T][nf] -> DEVICE uint8[S][T][nbytes], asynchronous on `stream`"""
+        if first_channel is None:
+            rc = self._L.lc3gpu_encode(self._h, _ptr(d_pcm), _ptr(d_out), int(nbytes), int(n_frames), _ptr(stream))
+        else:
+            rc = self._L.lc3gpu_encode_range(self._h, int(first_channel), int(n_channels), _ptr(d_pcm), _ptr(d_out),
+                                             int(nbytes), int(n_frames), _ptr(stream))
+        if rc:
+            raise Lc3EncoderError(rc, "encode")
+
+    def reset(self):
+        rc = self._L.lc3gpu_encoder_reset(self._h)
+        if rc:
+            raise Lc3EncoderError(rc, "reset")
+
+    def state_save(self):
+        n = self._L.lc3gpu_encoder_state_size(self._h) * self.num_channels
+        buf = np.zeros(n, np.uint8)
+        rc = self._L.lc3gpu_encoder_state_save(self._h, _ptr(buf))
+        if rc:
+            raise Lc3EncoderError(rc, "state_save")
+        return buf
+
+    def state_load(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        assert buf.size == self._L.lc3gpu_encoder_state_size(self._h) * self.num_channels
+        rc = self._L.lc3gpu_encoder_state_load(self._h, _ptr(buf))
+        if rc:
+            raise Lc3EncoderError(rc, "state_load")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lc3gpu_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Lc3Decoder:
+    @staticmethod
+    def calc_working_buffer_lengths(num_channels, frame_duration, sampling_frequency):
+        """-> (scaler_len, complex_len), lc3_decoder.rs:236-244"""
+        out = (ctypes.c_int64 * 2)()
+        rc = load_library().lc3gpu_decoder_working_buffer_lengths(num_channels, int(frame_duration),
+                                                                  int(sampling_frequency), out)
+        if rc:
+            raise Lc3DecoderError(rc)
+        return tuple(int(v) for v in out)
+
+    def __init__(self, num_channels, frame_duration, sampling_frequency):
+        self._L = load_library()
+        self.config = Lc3Config(sampling_frequency, frame_duration)
+        self.num_channels = int(num_channels)
+        h = ctypes.c_void_p()
+        rc = self._L.lc3gpu_decoder_create(ctypes.byref(h), self.num_channels, int(frame_duration),
+                                           int(sampling_frequency))
+        if rc:
+            raise Lc3DecoderError(rc, "Lc3Decoder::new")
+        self._h = h
+
+    new = classmethod(lambda cls, *a, **k: cls(*a, **k))
+
+    def decode_frame(self, num_bits_per_audio_sample, channel_index, buf_in, samples_out):
+        """lc3_decoder.rs:217-234; corrupt frames are concealed, not reported (":138-141")"""
+        buf_in = np.ascontiguousarray(buf_in, dtype=np.uint8)
+        if not (isinstance(samples_out, np.ndarray) and samples_out.dtype == np.int16 and samples_out.flags.c_contiguous):
+            raise TypeError("samples_out must be a contiguous int16 numpy array")
+        rc = self._L.lc3gpu_decode_frame(self._h, int(num_bits_per_audio_sample), int(channel_index), _ptr(buf_in),
+                                         int(buf_in.size), _ptr(samples_out), int(samples_out.size))
+        if rc:
+            raise Lc3DecoderError(rc, "decode_frame")
+
+    def decode(self, d_in, d_pcm, nbytes, n_frames, stream=None, d_bad_frame=None, first_channel=None,
+               n_channels=None):
+        """batch: DEVICE uint8[S][T][nbytes] -> DEVICE int16[S][T][nf], asynchronous on `stream`"""
+        if first_channel is None:
+            rc = self._L.lc3gpu_decode(self._h, _ptr(d_in), _ptr(d_bad_frame), _ptr(d_pcm), int(nbytes), int(n_frames),
+                                       _ptr(stream))
+        else:
+            rc = self._L.lc3gpu_decode_range(self._h, int(first_channel), int(n_channels), _ptr(d_in),
+                                             _ptr(d_bad_frame), _ptr(d_pcm), int(nbytes), int(n_frames), _ptr(stream))
+        if rc:
+            raise Lc3DecoderError(rc, "decode")
+
+    def reset(self):
+        rc = self._L.lc3gpu_decoder_reset(self._h)
+        if rc:
+            raise Lc3DecoderError(rc, "reset")
+
+    def plc_events(self):
+        v = ctypes.c_uint64()
+        rc = self._L.lc3gpu_decoder_plc_events(self._h, ctypes.byref(v))
+        if rc:
+            raise Lc3DecoderError(rc, "plc_events")
+        return int(v.value)
+
+    def state_save(self):
+        n = self._L.lc3gpu_decoder_state_size(self._h) * self.num_channels
+        buf = np.zeros(n, np.uint8)
+        rc = self._L.lc3gpu_decoder_state_save(self._h, _ptr(buf))
+        if rc:
+            raise Lc3DecoderError(rc, "state_save")
+        return buf
+
+    def state_load(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        rc = self._L.lc3gpu_decoder_state_load(self._h, _ptr(buf))
+        if rc:
+            raise Lc3DecoderError(rc, "state_load")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lc3gpu_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def kernel_info(which):
+    out = (ctypes.c_int * 5)()
+    rc = load_library().lc3gpu_kernel_info(int(which), out)
+    if rc:
+        raise Lc3GpuError(rc, "kernel_info")
+    return dict(zip(["lds_bytes", "vgprs", "sgprs", "scratch_bytes", "max_threads"], list(out)))

@@ -1,0 +1,92 @@
+"""CPU-side checks of the drop-in boundary: the C ABI library builds, loads and exports every symbol
+include/lc3gpu.h declares; host logic that needs no GPU (config, working-buffer lengths, error strings)."""
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pkg = importlib.import_module("lc3-codec_amd")
+api = importlib.import_module("lc3-codec_amd.api")
+
+
+@pytest.fixture(scope="module")
+def L():
+    pkg.build_native()
+    return pkg.load_library()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "lc3gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lc3gpu_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(L):
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(L, s), f"liblc3gpu.so does not export {s}"
+    assert sorted(api.ABI_SYMBOLS) == syms
+
+
+def test_signatures_are_plain_c():
+    text = open(os.path.join(ROOT, "include", "lc3gpu.h")).read()
+    assert "torch" not in text.lower().replace("no torch", "")
+    assert "std::" not in text and "hipStream_t" not in text.replace("(a hipStream_t", "")
+
+
+def test_config_matches_reference_table(L):  # common/config.rs:57-88, test :109-119
+    c = pkg.Lc3Config(pkg.SamplingFrequency.Hz48000, pkg.FrameDuration.TenMs)
+    assert (c.fs, c.fs_ind, c.z, c.nf, c.nb, c.ne) == (48000, 4, 180, 480, 64, 400)
+    c = pkg.Lc3Config(8000, 7500)
+    assert (c.nf, c.ne, c.nb, c.z) == (60, 60, 60, 14)
+    c = pkg.Lc3Config(44100, 7500)
+    assert (c.fs_ind, c.nf, c.ne) == (4, 360, 300)
+    with pytest.raises(pkg.Lc3GpuError):
+        pkg.Lc3Config(48000, 5000)
+
+
+def test_working_buffer_lengths(L):  # lc3_encoder.rs:194-209, lc3_decoder.rs:236-244, README.md:130
+    assert pkg.Lc3Encoder.calc_working_buffer_lengths(1, 10000, 48000) == (1900, 1106, 960)
+    assert pkg.Lc3Encoder.calc_working_buffer_lengths(2, 10000, 48000) == (3800, 2212, 1920)
+    assert pkg.Lc3Decoder.calc_working_buffer_lengths(1, 10000, 48000) == (4971, 960)
+    import oracle_lib as O
+
+    for fs in (8000, 16000, 24000, 32000, 44100, 48000):
+        for us in (7500, 10000):
+            e = np.zeros(3, np.int64)
+            d = np.zeros(2, np.int64)
+            O.lib().lc3o_encoder_working_buffer_lengths(3, fs, us, O.P(e))
+            O.lib().lc3o_decoder_working_buffer_lengths(3, fs, us, O.P(d))
+            assert pkg.Lc3Encoder.calc_working_buffer_lengths(3, us, fs) == tuple(e.tolist())
+            assert pkg.Lc3Decoder.calc_working_buffer_lengths(3, us, fs) == tuple(d.tolist())
+
+
+def test_error_strings_and_no_fallback(L):
+    assert L.lc3gpu_strerror(0) == b"ok"
+    assert b"16 bits" in L.lc3gpu_strerror(-4)
+    assert L.lc3gpu_version() >= 100
+    if pkg.device_count() == 0:
+        # no GPU here: constructing a codec must fail loudly, never fall back to a CPU path
+        with pytest.raises(pkg.Lc3EncoderError) as e:
+            pkg.Lc3Encoder(1, 10000, 48000)
+        assert e.value.code == -6
+        with pytest.raises(pkg.Lc3DecoderError):
+            pkg.Lc3Decoder(1, 10000, 48000)
+
+
+def test_product_does_not_touch_the_oracle():
+    """the shipped package must not import, link or execute anything under oracle/ or tests/"""
+    pdir = os.path.join(ROOT, "lc3-codec_amd")
+    for dirpath, _, files in os.walk(pdir):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in src.replace("CPU oracle", "").replace("the oracle", "").lower() or f == "synth.py", \
+                    f"{f} mentions the oracle"
+    out = os.popen(f"ldd {pkg.library_path()}").read()
+    assert "oracle" not in out

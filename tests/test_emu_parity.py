@@ -1,0 +1,84 @@
+"""The HIP device code (lc3-codec_amd/csrc/lc3_dev_*.h) run under the CPU wave emulator vs the oracle.
+Checks the lane-parallel decomposition and barrier placement in this GPU-less container; the -m gpu
+tests repeat the same comparisons on the real hardware through the C ABI."""
+import importlib
+
+import numpy as np
+import pytest
+
+import emu_lib as E
+import oracle_lib as O
+
+synth = importlib.import_module("lc3-codec_amd.synth")
+
+
+def test_emu_kats():
+    t = "encoder/lc3_encoder.rs::lc3_encode_channel"
+    out = E.encode(O.kat(t, "samples_in", 0, np.int16).reshape(1, 1, 480), 150)
+    assert out[0, 0].tolist() == O.kat(t, "buf_out_expected")
+    t = "decoder/lc3_decoder.rs::lc3_decode_channel"
+    pcm = E.decode(np.array(O.kat(t, "buf_in"), np.uint8).reshape(1, 1, 150), 480)
+    assert pcm[0, 0].tolist() == O.kat(t, "samples_out_expected")
+
+
+@pytest.mark.parametrize("fs,us,nbytes", [
+    (48000, 10000, 150), (48000, 10000, 60), (48000, 10000, 400), (48000, 7500, 113), (44100, 10000, 110),
+    (32000, 10000, 80), (32000, 7500, 61), (24000, 10000, 60), (24000, 7500, 45), (16000, 10000, 40),
+    (16000, 7500, 30), (48000, 10000, 40),
+])
+def test_emu_matches_oracle(fs, us, nbytes):
+    cfg = np.zeros(7, np.int32)
+    O.lib().lc3o_kat_config(fs, us, O.P(cfg))
+    nf = int(cfg[5])
+    pcm = synth.make_pcm(4, 6, nf, fs)
+    ref = O.encode_batch(pcm, nbytes, fs, us)
+    assert np.array_equal(E.encode(pcm, nbytes, fs, us), ref)
+    assert np.array_equal(E.decode(ref, nf, fs, us), O.decode_batch(ref, nf, fs, us))
+
+
+def test_emu_decode_8khz_and_corrupt():
+    pcm = synth.make_pcm(3, 5, 80, 8000)
+    data = O.encode_batch(pcm, 30, 8000, 10000)
+    assert np.array_equal(E.decode(data, 80, 8000, 10000), O.decode_batch(data, 80, 8000, 10000))
+    pcm = synth.make_pcm(3, 8, 480, 48000, seed=3)
+    data = O.encode_batch(pcm, 150).copy()
+    data[0, 2, -1] |= 7
+    data[0, 3, -1] |= 7
+    data[1, 4] = np.random.default_rng(1).integers(0, 256, 150, dtype=np.uint8)
+    assert np.array_equal(E.decode(data, 480), O.decode_batch(data, 480))
+    bad = np.zeros((3, 8), np.uint8)
+    bad[2, 1] = 1
+    corrupt = O.encode_batch(pcm, 150).copy()
+    corrupt[2, 1, -1] |= 7
+    assert np.array_equal(E.decode(O.encode_batch(pcm, 150), 480, bad=bad), O.decode_batch(corrupt, 480))
+
+
+def test_device_math_matches_oracle_math():
+    """the GPU float library (lc3_dev_common.h) against the oracle's restatement of the same msun routines"""
+    import ctypes
+
+    L, M = E.lib(), O.lib()
+    for n in ("lc3m_log2f", "lc3m_log10f", "lc3m_exp2f", "lc3m_asinf", "lc3m_sinf", "lc3m_exp2_raw"):
+        getattr(M, n).restype = ctypes.c_float
+        getattr(M, n).argtypes = [ctypes.c_float]
+    rng = np.random.default_rng(0)
+    for k in range(-260, 261):
+        y = float(np.float32(k) / np.float32(28))
+        assert L.lc3emu_pow10f(y) == M.lc3o_kat_powf(10.0, y), k
+    for b in range(64):
+        for g in (14, 18, 22, 26, 30):
+            y = float(np.float32(b) * (np.float32(g) / np.float32(630)))
+            assert L.lc3emu_pow10f(y) == M.lc3o_kat_powf(10.0, y)
+    xs = np.exp(rng.uniform(-30, 40, 4000)).astype(np.float32)
+    for x in xs:
+        assert L.lc3emu_log2f(float(x)) == M.lc3m_log2f(float(x))
+        assert L.lc3emu_log10f(float(x)) == M.lc3m_log10f(float(x))
+    for x in rng.uniform(-40, 40, 4000).astype(np.float32):
+        assert L.lc3emu_exp2f(float(x)) == M.lc3m_exp2f(float(x))
+        assert L.lc3emu_exp2_raw(float(x)) == M.lc3m_exp2_raw(float(x))
+    for x in rng.uniform(-1, 1, 4000).astype(np.float32):
+        assert L.lc3emu_asinf(float(x)) == M.lc3m_asinf(float(x))
+    step = np.float32(np.float32(np.pi) / np.float32(17.0))
+    for i in range(17):
+        x = float(np.float32(step * np.float32(i - 8)))
+        assert L.lc3emu_sinf_small(x) == M.lc3m_sinf(x)

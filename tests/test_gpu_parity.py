@@ -1,0 +1,286 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI,
+against the CPU oracle and the reference's end-to-end known-answer vectors.
+
+Bar (BASELINE.json north_star): arithmetic-coded bitstream BYTE-EXACT; decoded i16 PCM within
++-1 LSB (PCM_TOL below; the engine is expected to be exact, max|diff| is asserted == 0 where the
+oracle and the engine share every arithmetic step)."""
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+PCM_TOL = 1  # LSB, the tolerance the north star states for decode
+
+pkg = importlib.import_module("lc3-codec_amd")
+synth = importlib.import_module("lc3-codec_amd.synth")
+FS, US = pkg.SamplingFrequency.Hz48000, pkg.FrameDuration.TenMs
+
+
+def torch_mod():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU test needs a HIP device"
+    return torch
+
+
+def gpu_encode(pcm, nbytes, fs=48000, us=10000, enc=None):
+    torch = torch_mod()
+    S, T, nf = pcm.shape
+    enc = enc or pkg.Lc3Encoder(S, us, fs)
+    d_pcm = torch.from_numpy(np.ascontiguousarray(pcm)).cuda()
+    d_out = torch.zeros((S, T, nbytes), dtype=torch.uint8, device="cuda")
+    enc.encode(d_pcm, d_out, nbytes, T, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy()
+
+
+def gpu_decode(data, nf, fs=48000, us=10000, dec=None, bad=None):
+    torch = torch_mod()
+    S, T, nbytes = data.shape
+    dec = dec or pkg.Lc3Decoder(S, us, fs)
+    d_in = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    d_pcm = torch.zeros((S, T, nf), dtype=torch.int16, device="cuda")
+    d_bad = torch.from_numpy(np.ascontiguousarray(bad)).cuda() if bad is not None else None
+    dec.decode(d_in, d_pcm, nbytes, T, stream=torch.cuda.current_stream().cuda_stream, d_bad_frame=d_bad)
+    torch.cuda.synchronize()
+    return d_pcm.cpu().numpy()
+
+
+# ---------------------------------------------------------------- reference KATs through the drop-in API
+def test_kat_encode_frame():  # encoder/lc3_encoder.rs:314-369
+    t = "encoder/lc3_encoder.rs::lc3_encode_channel"
+    enc = pkg.Lc3Encoder(1, US, FS)
+    buf = np.zeros(150, np.uint8)
+    enc.encode_frame(0, O.kat(t, "samples_in", 0, np.int16), buf)
+    assert buf.tolist() == O.kat(t, "buf_out_expected")
+
+
+def test_kat_decode_frame():  # decoder/lc3_decoder.rs:374-425
+    t = "decoder/lc3_decoder.rs::lc3_decode_channel"
+    dec = pkg.Lc3Decoder(1, US, FS)
+    pcm = np.zeros(480, np.int16)
+    dec.decode_frame(16, 0, np.array(O.kat(t, "buf_in"), np.uint8), pcm)
+    assert pcm.tolist() == O.kat(t, "samples_out_expected")
+
+
+def test_kat_stage_dumps():
+    """stage-level localisation: spectrum after MDCT / SNS / TNS of the KAT frame vs the reference's stage goldens"""
+    t = "encoder/lc3_encoder.rs::lc3_encode_channel"
+    enc = pkg.Lc3Encoder(1, US, FS)
+    out, dbg = enc.encode_frame_debug(O.kat(t, "samples_in", 0, np.int16), 150)
+    sns_in = O.kat("encoder/spectral_noise_shaping.rs::sns_run", "x", 0, np.float32)
+    sns_out = O.kat("encoder/spectral_noise_shaping.rs::sns_run", "x_s_expected", 0, np.float32)
+    tns_out = O.kat("encoder/temporal_noise_shaping.rs::temporal_noise_shaping_run", "x_f_expected", 0, np.float32)
+    assert np.array_equal(dbg[0:400], sns_in), "MDCT spectrum"
+    assert np.array_equal(dbg[480:880], sns_out), "SNS-shaped spectrum"
+    assert np.array_equal(dbg[960:1360], tns_out), "TNS-filtered spectrum"
+    assert dbg[1452] == 193 and dbg[1453] == 350 and dbg[1454] == 107  # gg_ind, lastnz_trunc, nbits_lsb
+    assert out.tolist() == O.kat(t, "buf_out_expected")
+
+
+# ---------------------------------------------------------------- batch parity vs the oracle
+def _roundtrip_check(fs, us, nbytes, S, T, seed=synth.SEED):
+    cfg = pkg.Lc3Config(fs, us)
+    pcm = synth.make_pcm(S, T, cfg.nf, fs, seed=seed)
+    ref_bytes = O.encode_batch(pcm, nbytes, fs, us, threads=8)
+    got_bytes = gpu_encode(pcm, nbytes, fs, us)
+    bad = np.argwhere((got_bytes != ref_bytes).any(axis=2))
+    assert len(bad) == 0, f"{len(bad)} frames differ, first (stream, frame) = {bad[0].tolist()}"
+    ref_pcm = O.decode_batch(ref_bytes, cfg.nf, fs, us, threads=8)
+    got_pcm = gpu_decode(ref_bytes, cfg.nf, fs, us)
+    diff = np.abs(got_pcm.astype(np.int32) - ref_pcm.astype(np.int32)).max()
+    assert diff <= PCM_TOL, f"PCM max |diff| = {diff}"
+    assert diff == 0, f"PCM not exact: max |diff| = {diff}"
+
+
+def test_batch_48k_10ms_150B():  # BASELINE config shape, 2048 frames with carried state
+    _roundtrip_check(48000, 10000, 150, 256, 8)
+
+
+@pytest.mark.parametrize("fs,us,nbytes", [
+    (48000, 10000, 60), (48000, 10000, 300), (48000, 10000, 400), (48000, 10000, 40), (48000, 7500, 113),
+    (48000, 7500, 40), (44100, 10000, 110), (32000, 10000, 80), (32000, 10000, 120), (32000, 7500, 61),
+    (24000, 10000, 60), (24000, 7500, 45), (16000, 10000, 40), (16000, 7500, 30), (16000, 10000, 20),
+])
+def test_batch_other_configs(fs, us, nbytes):  # BASELINE config 4's rate/duration matrix (8 kHz encode: no reference)
+    _roundtrip_check(fs, us, nbytes, 24, 6)
+
+
+@pytest.mark.parametrize("us,nbytes", [(10000, 30), (7500, 23)])
+def test_decode_8khz(us, nbytes):
+    """8 kHz has no reference encoder (bandwidth_detector.rs:36-37 panics); decode-only parity on a
+    stream produced by the oracle's early-return encoder path."""
+    cfg = pkg.Lc3Config(8000, us)
+    pcm = synth.make_pcm(8, 6, cfg.nf, 8000)
+    data = O.encode_batch(pcm, nbytes, 8000, us)
+    ref = O.decode_batch(data, cfg.nf, 8000, us)
+    got = gpu_decode(data, cfg.nf, 8000, us)
+    assert np.array_equal(got, ref)
+    with pytest.raises(pkg.Lc3EncoderError) as ei:
+        pkg.Lc3Encoder(1, us, 8000)
+    assert ei.value.code == -7
+
+
+def test_cold_start_many_streams():  # Mode A: every frame from a fresh encoder/decoder
+    pcm = synth.make_pcm(1024, 1, 480, 48000, seed=7)
+    ref = O.encode_batch(pcm, 150, threads=8)
+    got = gpu_encode(pcm, 150)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(gpu_decode(ref, 480), O.decode_batch(ref, 480, threads=8))
+
+
+def test_state_carry_across_launches():
+    """T frames in one launch == the same frames split over several launches (state round-trips through HBM),
+    and == frame-by-frame encode_frame / decode_frame."""
+    S, T = 8, 6
+    pcm = synth.make_pcm(S, T, 480, 48000, seed=11)
+    ref = O.encode_batch(pcm, 150)
+    enc = pkg.Lc3Encoder(S, US, FS)
+    a = gpu_encode(pcm[:, :2], 150, enc=enc)
+    b = gpu_encode(pcm[:, 2:], 150, enc=enc)
+    assert np.array_equal(np.concatenate([a, b], axis=1), ref)
+    ref_pcm = O.decode_batch(ref, 480)
+    dec = pkg.Lc3Decoder(S, US, FS)
+    pa = gpu_decode(ref[:, :3], 480, dec=dec)
+    pb = gpu_decode(ref[:, 3:], 480, dec=dec)
+    assert np.array_equal(np.concatenate([pa, pb], axis=1), ref_pcm)
+    # frame API on one channel while the others idle
+    enc2 = pkg.Lc3Encoder(3, US, FS)
+    dec2 = pkg.Lc3Decoder(3, US, FS)
+    for t in range(T):
+        buf = np.zeros(150, np.uint8)
+        enc2.encode_frame(1, pcm[5, t], buf)
+        assert np.array_equal(buf, ref[5, t])
+        out = np.zeros(480, np.int16)
+        dec2.decode_frame(16, 2, buf, out)
+        assert np.array_equal(out, ref_pcm[5, t])
+
+
+def test_state_save_load_and_reset():
+    S, T = 4, 4
+    pcm = synth.make_pcm(S, T, 480, 48000, seed=13)
+    ref = O.encode_batch(pcm, 150)
+    enc = pkg.Lc3Encoder(S, US, FS)
+    gpu_encode(pcm[:, :2], 150, enc=enc)
+    blob = enc.state_save()
+    enc_b = pkg.Lc3Encoder(S, US, FS)
+    enc_b.state_load(blob)
+    assert np.array_equal(gpu_encode(pcm[:, 2:], 150, enc=enc_b), ref[:, 2:])
+    enc.reset()
+    assert np.array_equal(gpu_encode(pcm, 150, enc=enc), ref)
+    dec = pkg.Lc3Decoder(S, US, FS)
+    ref_pcm = O.decode_batch(ref, 480)
+    gpu_decode(ref[:, :2], 480, dec=dec)
+    dblob = dec.state_save()
+    dec_b = pkg.Lc3Decoder(S, US, FS)
+    dec_b.state_load(dblob)
+    assert np.array_equal(gpu_decode(ref[:, 2:], 480, dec=dec_b), ref_pcm[:, 2:])
+    dec.reset()
+    assert np.array_equal(gpu_decode(ref, 480, dec=dec), ref_pcm)
+
+
+def test_variable_bitrate_per_call():  # nbits = 8 * buf_out.len() may change per call (lc3_encoder.rs:65)
+    pcm = synth.make_pcm(1, 6, 480, 48000, seed=17)[0]
+    sizes = [150, 100, 60, 300, 150, 40]
+    oe, od = O.Encoder(), O.Decoder()
+    enc, dec = pkg.Lc3Encoder(1, US, FS), pkg.Lc3Decoder(1, US, FS)
+    for t, nb in enumerate(sizes):
+        want = oe.encode_frame(pcm[t], nb)
+        got = np.zeros(nb, np.uint8)
+        enc.encode_frame(0, pcm[t], got)
+        assert np.array_equal(got, want), f"frame {t} ({nb} bytes)"
+        _, wp = od.decode_frame(want)
+        gp = np.zeros(480, np.int16)
+        dec.decode_frame(16, 0, want, gp)
+        assert np.array_equal(gp, wp), f"frame {t} pcm"
+
+
+# ---------------------------------------------------------------- corrupt frames / PLC
+def test_corrupt_frames_are_concealed_like_the_reference():  # lc3_decoder.rs:138-141, packet_loss_concealment.rs
+    S, T = 6, 12
+    pcm = synth.make_pcm(S, T, 480, 48000, seed=19)
+    data = O.encode_batch(pcm, 150).copy()
+    rng = np.random.default_rng(5)
+    # invalid bandwidth index (P_BW = 7 > fs_ind) -> SideInfoError::BandwidthIdxOutOfRange -> PLC
+    for s, t in [(0, 3), (0, 4), (1, 0), (2, 5), (2, 6), (2, 7), (2, 8), (2, 9), (2, 10), (3, 11)]:
+        data[s, t, -1] |= 7
+    # random garbage frames: whatever the parser makes of them must match the oracle
+    for s, t in [(4, 2), (4, 7), (5, 1), (5, 2)]:
+        data[s, t] = rng.integers(0, 256, 150, dtype=np.uint8)
+    ref = O.decode_batch(data, 480)
+    dec = pkg.Lc3Decoder(S, US, FS)
+    got = gpu_decode(data, 480, dec=dec)
+    assert np.array_equal(got, ref)
+    assert dec.plc_events() >= 10
+
+
+def test_random_garbage_streams():
+    rng = np.random.default_rng(23)
+    for nbytes in (20, 40, 150, 400):
+        data = rng.integers(0, 256, (32, 4, nbytes), dtype=np.uint8)
+        assert np.array_equal(gpu_decode(data, 480), O.decode_batch(data, 480)), nbytes
+
+
+def test_bad_frame_flag_forces_concealment():
+    S, T = 2, 6
+    pcm = synth.make_pcm(S, T, 480, 48000, seed=29)
+    data = O.encode_batch(pcm, 150)
+    bad = np.zeros((S, T), np.uint8)
+    bad[0, 2] = bad[0, 3] = bad[1, 5] = 1
+    corrupt = data.copy()
+    corrupt[bad.astype(bool), -1] |= 7  # same effect in the oracle: unparsable side info
+    ref = O.decode_batch(corrupt, 480)
+    got = gpu_decode(data, 480, bad=bad)
+    assert np.array_equal(got, ref)
+
+
+# ---------------------------------------------------------------- API error behaviour
+def test_error_codes():
+    enc = pkg.Lc3Encoder(2, US, FS)
+    dec = pkg.Lc3Decoder(2, US, FS)
+    buf = np.zeros(150, np.uint8)
+    with pytest.raises(pkg.Lc3EncoderError) as e:  # reference: panic "Cannot decode channel index"
+        enc.encode_frame(2, np.zeros(480, np.int16), buf)
+    assert e.value.code == -2
+    with pytest.raises(pkg.Lc3EncoderError) as e:  # reference: assert_eq!(input.len(), nf) panic
+        enc.encode_frame(0, np.zeros(479, np.int16), buf)
+    assert e.value.code == -3
+    with pytest.raises(pkg.Lc3DecoderError) as e:  # Only16BitsPerAudioSampleSupported
+        dec.decode_frame(24, 0, buf, np.zeros(480, np.int16))
+    assert e.value.code == -4
+    with pytest.raises(pkg.Lc3DecoderError) as e:
+        dec.decode_frame(16, 5, buf, np.zeros(480, np.int16))
+    assert e.value.code == -2
+    with pytest.raises(pkg.Lc3GpuError):
+        pkg.Lc3Config(22050, 10000)
+
+
+# ---------------------------------------------------------------- full-size batch (BASELINE configs[1])
+def test_full_size_batch_properties():
+    """65 536 frames (16 384 streams x 4 frames) on one GPU: determinism, sampled oracle parity,
+    and a size-independent round-trip property (decode(encode(x)) tracks x)."""
+    S, T, NB = 16384, 4, 150
+    torch = torch_mod()
+    pcm = synth.make_pcm(512, T, 480, 48000, seed=31)
+    big = np.tile(pcm, (S // 512, 1, 1))  # 512 distinct streams repeated: identical streams must agree
+    a = gpu_encode(big, NB)
+    b = gpu_encode(big, NB)
+    assert np.array_equal(a, b), "encode is not deterministic"
+    assert np.array_equal(a[:512], a[512:1024]) and np.array_equal(a[:512], a[-512:])
+    assert np.array_equal(a[:512], O.encode_batch(pcm, NB, threads=8))
+    p = gpu_decode(a, 480)
+    assert np.array_equal(p[:512], p[-512:])
+    assert np.array_equal(p[:512], O.decode_batch(a[:512], 480, threads=8))
+    # round trip: codec delay is z + ... = 2.5 ms + LTPF-free path: compare energy of the error on tonal streams
+    x = big[:512, :-1].astype(np.float64).reshape(512, -1)
+    y = p[:512].astype(np.float64).reshape(512, -1)
+    delay = 480 - 180  # nf - z samples of algorithmic delay (decoder/modified_dct.rs:138-151)
+    xs, ys = x[:, : x.shape[1] - delay], y[:, delay: delay + x.shape[1] - delay]
+    live = xs.std(axis=1) > 100
+    err = ((xs[live] - ys[live]) ** 2).sum(axis=1)
+    snr = 10 * np.log10((xs[live] ** 2).sum(axis=1) / np.maximum(err, 1e-9))
+    assert np.median(snr) > 15.0, f"median round-trip SNR {np.median(snr):.1f} dB"
+    del torch
