@@ -75,6 +75,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64
+    # under torch/lib.  If the system runtime (/opt/rocm) is mapped first through this library, a later
+    # `import torch` binds to the wrong runtime and torch.cuda reports no device.  When torch is installed
+    # (it is only used by callers for device memory / streams), let it bring in its runtime first.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional for the C ABI
+        pass
     if not os.path.exists(_LIB):
         raise ImportError(f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(the LC3 engine has no non-native path)")

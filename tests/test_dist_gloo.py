@@ -1,0 +1,95 @@
+"""N > 1 path on CPU: world_size-2 gloo job that shards streams exactly as bench.py does on GPUs
+(contiguous stream ranges, no data-path collective, counters reduced at the end).  The per-rank
+"engine" here is the CPU wave emulator of the device code (tests only)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total_streams, T, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    import emu_lib as E
+
+    synth = importlib.import_module("lc3-codec_amd.synth")
+    D = importlib.import_module("lc3-codec_amd.dist")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = D.shard_range(total_streams, world, rank)
+    pcm = synth.make_pcm(hi - lo, T, 480, 48000, first_stream=lo)
+    data = E.encode(pcm, 150)
+    out = E.decode(data, 480)
+    dist.barrier()
+    elapsed, frames, mism, plc = D.reduce_report(dist, "cpu", 1.0 + rank, (hi - lo) * T, mismatches=rank, plc_events=0)
+    # gather the shards' bitstreams to rank 0 for comparison with the single-process result
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, data, out))
+    if rank == 0:
+        q.put((elapsed, frames, mism, plc, gathered))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process():
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    synth = importlib.import_module("lc3-codec_amd.synth")
+    total, T, world = 6, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    elapsed, frames, mism, plc, gathered = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert elapsed == 2.0 and frames == total * T and mism == 1 and plc == 0  # MAX time, SUM counters
+    pcm = synth.make_pcm(total, T, 480, 48000)
+    ref = O.encode_batch(pcm, 150)
+    ref_pcm = O.decode_batch(ref, 480)
+    covered = np.zeros(total, bool)
+    for lo, hi, data, out in gathered:
+        assert np.array_equal(data, ref[lo:hi])
+        assert np.array_equal(out, ref_pcm[lo:hi])
+        covered[lo:hi] = True
+    assert covered.all()
+
+
+def test_shard_range_partitions():
+    D = importlib.import_module("lc3-codec_amd.dist")
+    for total in (1, 7, 8, 65536, 1048576):
+        for world in (1, 2, 4, 8):
+            spans = [D.shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def test_synth_shards_are_consistent():
+    synth = importlib.import_module("lc3-codec_amd.synth")
+    a = synth.make_pcm(8, 2, 480, 48000)
+    b = synth.make_pcm(4, 2, 480, 48000, first_stream=4)
+    assert np.array_equal(a[4:], b)
+    assert np.array_equal(a, synth.make_pcm(8, 2, 480, 48000))
+    assert a.dtype == np.int16 and np.abs(a).max() > 1000
