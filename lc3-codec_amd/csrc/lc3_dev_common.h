@@ -381,6 +381,52 @@ __device__ __forceinline__ float lc3_powi(float base, int exp) {
 }
 
 // ------------------------------------------------------------------------------------------
+// small constant tables of the reference's stage modules (kept in device constant data, not on
+// the per-lane stack)
+// ------------------------------------------------------------------------------------------
+static __device__ const int LC3C_NBITS_BW[5] = {0, 1, 2, 2, 3};  // bandwidth_detector.rs:10, side_info_reader.rs:11
+// encoder/bandwidth_detector.rs:5-18
+static __device__ const int LC3C_BW_START10[4][4] = {{53, 0, 0, 0}, {47, 59, 0, 0}, {44, 54, 60, 0}, {41, 51, 57, 61}};
+static __device__ const int LC3C_BW_STOP10[4][4] = {{63, 0, 0, 0}, {56, 63, 0, 0}, {52, 59, 63, 0}, {49, 55, 60, 63}};
+static __device__ const int LC3C_BW_START75[4][4] = {{51, 0, 0, 0}, {45, 58, 0, 0}, {42, 53, 60, 0}, {40, 51, 57, 61}};
+static __device__ const int LC3C_BW_STOP75[4][4] = {{63, 0, 0, 0}, {55, 63, 0, 0}, {51, 58, 63, 0}, {48, 55, 60, 63}};
+static __device__ const int LC3C_BW_TQ[4] = {20, 10, 10, 10};
+static __device__ const int LC3C_BW_TC[4] = {15, 23, 20, 20};
+static __device__ const int LC3C_BW_L10[4] = {4, 4, 3, 1};
+static __device__ const int LC3C_BW_L75[4] = {4, 4, 3, 2};
+static __device__ const int LC3C_G_TILT[5] = {14, 18, 22, 26, 30};  // spectral_noise_shaping.rs:51-57
+static __device__ const int LC3C_BWSTOP10[5] = {80, 160, 240, 320, 400};  // noise_level_estimation.rs:22-23, noise_filling.rs:28-29
+static __device__ const int LC3C_BWSTOP75[5] = {60, 120, 180, 240, 300};
+// encoder/spectral_quantization.rs:351-353
+static __device__ const int LC3C_GGA_T1[5] = {80, 230, 380, 530, 680};
+static __device__ const int LC3C_GGA_T2[5] = {500, 1025, 1550, 2075, 2600};
+static __device__ const int LC3C_GGA_T3[5] = {850, 1700, 2550, 3400, 4250};
+// encoder/temporal_noise_shaping.rs:81-84 (f32 literals)
+static __device__ const float LC3C_TNS_LAGW[9] = {1.0f, 0.9980280260203829f, 0.9921354055113971f, 0.9823915844707989f,
+                                                  0.9689107911912967f, 0.9518498073692735f, 0.9314049334023056f,
+                                                  0.9078082299969592f, 0.8813231366694713f};
+// TNS parameter sets: {num_filters, start0, start1, stop0, stop1, sub_start[2][3], sub_stop[2][3]}
+// encoder/temporal_noise_shaping.rs:117-202 (10 ms p_bw = 2 keeps stop_freq = 200: SURVEY A5)
+struct lc3_tns_params { int num, start[2], stop[2], sub_start[2][3], sub_stop[2][3]; };
+static __device__ const lc3_tns_params LC3C_TNS10[5] = {
+    {1, {12, 160}, {80, 0}, {{12, 34, 57}, {0, 0, 0}}, {{34, 57, 80}, {0, 0, 0}}},
+    {1, {12, 160}, {160, 0}, {{12, 61, 110}, {0, 0, 0}}, {{61, 110, 160}, {0, 0, 0}}},
+    {1, {12, 160}, {200, 0}, {{12, 88, 164}, {0, 0, 0}}, {{88, 164, 240}, {0, 0, 0}}},
+    {2, {12, 160}, {160, 320}, {{12, 61, 110}, {160, 213, 266}}, {{61, 110, 160}, {213, 266, 320}}},
+    {2, {12, 200}, {200, 400}, {{12, 74, 137}, {200, 266, 333}}, {{74, 137, 200}, {266, 333, 400}}},
+};
+static __device__ const lc3_tns_params LC3C_TNS75[5] = {
+    {1, {9, 120}, {60, 0}, {{9, 26, 43}, {0, 0, 0}}, {{26, 43, 60}, {0, 0, 0}}},
+    {1, {9, 120}, {120, 0}, {{9, 46, 83}, {0, 0, 0}}, {{46, 83, 120}, {0, 0, 0}}},
+    {1, {9, 120}, {180, 0}, {{9, 66, 123}, {0, 0, 0}}, {{66, 123, 180}, {0, 0, 0}}},
+    {2, {9, 120}, {120, 240}, {{9, 46, 82}, {120, 159, 200}}, {{46, 82, 120}, {159, 200, 240}}},
+    {2, {9, 150}, {150, 300}, {{9, 56, 103}, {150, 200, 250}}, {{56, 103, 150}, {200, 250, 300}}},
+};
+// decoder/temporal_noise_shaping.rs:84-137: filter bands {lo0, hi0, lo1, hi1} per bandwidth
+static __device__ const int LC3C_TNSDEC10[5][4] = {{12, 80, 0, 0}, {12, 160, 0, 0}, {12, 240, 0, 0}, {12, 160, 160, 320}, {12, 200, 200, 400}};
+static __device__ const int LC3C_TNSDEC75[5][4] = {{9, 60, 0, 0}, {9, 120, 0, 0}, {9, 180, 0, 0}, {9, 120, 120, 240}, {9, 150, 150, 300}};
+
+// ------------------------------------------------------------------------------------------
 // static tables selected by configuration
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ const uint32_t *lc3_window_bits(const lc3_cfg &c) {

@@ -4,12 +4,13 @@
 #pragma once
 #include "lc3_dev_common.h"
 
-// Persistent per-stream decoder state in HBM
-struct lc3_dec_state {
+// Persistent per-stream decoder state.  `core` is what a wave keeps resident in LDS while it
+// works on the stream; plc_last_good stays in HBM (written once per good frame, read only when concealing).
+struct lc3_dec_core {
     float mem_ola[304];            // IMDCT overlap memory, nf - z used (decoder/modified_dct.rs:30,149)
-    float x_hat_mem[1080];         // LTPF input ring, num_mem_blocks * nf (decoder/long_term_post_filter.rs:127-128)
-    float x_hat_ltpf_mem[1080];    // LTPF output ring
-    float plc_last_good[LC3_MAX_NE];  // decoder/packet_loss_concealment.rs:7-22
+    float x_hat_ltpf_mem[1080];    // LTPF output ring, num_mem_blocks * nf (decoder/long_term_post_filter.rs:127-128)
+    float x_tail[12];              // last l_num samples of the previous LTPF input frame: the only part of the
+                                   // reference's x_hat_mem ring that is ever read back (:380-387, k <= l_num)
     float c_num[12], c_den[14];    // current LTPF coefficients (:20-27); the *_mem copies are per-frame temporaries
     int ltpf_active_prev, block_start_index, p_int_mem, p_fr_mem;
     int plc_num_lost;
@@ -17,23 +18,28 @@ struct lc3_dec_state {
     uint32_t plc_seed;
     int plc_events;                // counter: frames concealed so far (not in the reference; reporting only)
 };
-#define LC3_DEC_STATE_WORDS ((int)(sizeof(lc3_dec_state) / 4))
+struct lc3_dec_state {
+    lc3_dec_core core;
+    float plc_last_good[LC3_MAX_NE];  // decoder/packet_loss_concealment.rs:7-22
+};
+#define LC3_DEC_CORE_WORDS ((int)(sizeof(lc3_dec_core) / 4))
 
+// LDS working set of one decoder wave (~13 KB -> 12 waves per CU)
 struct lc3_dec_lds {
-    lc3_dec_state st;
+    lc3_dec_core st;
     float spec[LC3_MAX_NF];        // spec_lines, then freq_samples
-    lc3_cpx fa[LC3_MAX_NF / 2];    // FFT in   | t_hat_mdct[0 .. nf)
-    lc3_cpx fb[LC3_MAX_NF / 2];    // FFT work | t_hat_mdct[nf .. 2nf)   (fa and fb are contiguous)
-    int32_t xi[LC3_MAX_NE];        // decoded integer spectrum
+    lc3_cpx fa[LC3_MAX_NF / 2];    // save_lev during parsing | FFT in   | t_hat_mdct[0 .. nf)
+    lc3_cpx fb[LC3_MAX_NF / 2];    // integer spectrum xi     | FFT work | t_hat_mdct[nf .. 2nf)  (contiguous with fa)
     uint8_t in[LC3_MAX_NE];        // frame bytes
     uint8_t res_bits[480];
     float sm[192];
     int ism[64];
 };
 
-__device__ __forceinline__ void lc3_dec_state_init(lc3_dec_lds &L, int lane) {
+__device__ __forceinline__ void lc3_dec_state_init(lc3_dec_lds &L, int lane, lc3_dec_state *g) {
+    for (int i = lane; i < LC3_MAX_NE; i += LC3_WAVE) g->plc_last_good[i] = 0.0f;
     int *w = (int *)&L.st;
-    for (int i = lane; i < LC3_DEC_STATE_WORDS; i += LC3_WAVE) w[i] = 0;
+    for (int i = lane; i < LC3_DEC_CORE_WORDS; i += LC3_WAVE) w[i] = 0;
     LC3_SYNC();
     if (lane == 0) {
         L.st.plc_seed = 24607;  // packet_loss_concealment.rs:31
@@ -42,16 +48,16 @@ __device__ __forceinline__ void lc3_dec_state_init(lc3_dec_lds &L, int lane) {
     LC3_SYNC();
 }
 __device__ __forceinline__ void lc3_dec_state_load(lc3_dec_lds &L, int lane, const lc3_dec_state *g) {
-    const int *src = (const int *)g;
+    const int *src = (const int *)&g->core;
     int *w = (int *)&L.st;
-    for (int i = lane; i < LC3_DEC_STATE_WORDS; i += LC3_WAVE) w[i] = src[i];
+    for (int i = lane; i < LC3_DEC_CORE_WORDS; i += LC3_WAVE) w[i] = src[i];
     LC3_SYNC();
 }
 __device__ __forceinline__ void lc3_dec_state_store(lc3_dec_lds &L, int lane, lc3_dec_state *g) {
-    int *dst = (int *)g;
+    int *dst = (int *)&g->core;
     const int *w = (const int *)&L.st;
     LC3_SYNC();
-    for (int i = lane; i < LC3_DEC_STATE_WORDS; i += LC3_WAVE) dst[i] = w[i];
+    for (int i = lane; i < LC3_DEC_CORE_WORDS; i += LC3_WAVE) dst[i] = w[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -103,10 +109,9 @@ enum {
 
 // D2: side_info_reader::read (decoder/side_info_reader.rs:29-200), lane 0
 __device__ __forceinline__ int lc3_dec_side_info(lc3_reader &r, int fs_ind, int ne, int *si) {
-    const int NBITS_BW[5] = {0, 1, 2, 2, 3};
     uint32_t v;
     int b, p_bw = 0, lastnz_bits = 0;
-    const int nbits_bw = NBITS_BW[fs_ind];
+    const int nbits_bw = LC3C_NBITS_BW[fs_ind];
     if (nbits_bw > 0) {
         LC3_RD(nbits_bw, v);
         if (fs_ind < (int)v) return -2;
@@ -377,7 +382,7 @@ __device__ __forceinline__ void lc3_mpvq_deenum(int dim_in, int k_val_in, int ls
 // ------------------------------------------------------------------------------------------
 // D10: IMDCT + window + overlap-add (decoder/modified_dct.rs:76-151); spec -> time samples in spec
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lc3_dec_imdct(const lc3_cfg &c, lc3_dec_lds &L, int lane) {
+__device__ __noinline__ void lc3_dec_imdct(const lc3_cfg &c, lc3_dec_lds &L, int lane) {
     const int nf = c.nf, ne = c.ne, z = c.z, h = nf / 2;
     const uint32_t *w = lc3_window_bits(c);
     float *freq = L.spec;
@@ -411,16 +416,21 @@ __device__ __forceinline__ void lc3_dec_imdct(const lc3_cfg &c, lc3_dec_lds &L, 
 __device__ __forceinline__ int lc3_wrap_neg(const lc3_cfg &c, int idx) {  // :244-250
     return idx < 0 ? idx + c.num_mem_blocks * c.nf : idx;
 }
-__device__ __forceinline__ float lc3_ltpf_filter(const lc3_cfg &c, const lc3_dec_state &st, const float *cn,
-                                                 const float *cd, int start, int pitch_int) {  // :380-415
+// compute_filter / compute_filter_mem (:380-415).  The reference's x_hat_mem ring is only ever read at
+// start - k, k <= l_num: the current input frame (freq_in) or the last l_num samples of the previous one.
+__device__ __forceinline__ float lc3_ltpf_filter(const lc3_cfg &c, const lc3_dec_core &st, const float *freq_in,
+                                                 const float *cn, const float *cd, int blk, int n, int pitch_int) {
     float acc = 0.0f;
-    for (int k = 0; k <= c.l_num; k++) acc += cn[k] * st.x_hat_mem[lc3_wrap_neg(c, start - k)];
-    const int sden = start - pitch_int + c.l_den / 2;
+    for (int k = 0; k <= c.l_num; k++) {
+        const int j = n - k;
+        acc += cn[k] * (j >= 0 ? freq_in[j] : st.x_tail[c.l_num + j]);
+    }
+    const int sden = blk + n - pitch_int + c.l_den / 2;
     for (int k = 0; k <= c.l_den; k++) acc -= cd[k] * st.x_hat_ltpf_mem[lc3_wrap_neg(c, sden - k)];
     return acc;
 }
 
-__device__ __forceinline__ void lc3_dec_ltpf(const lc3_cfg &c, lc3_dec_lds &L, int lane, int is_active, int pitch_index,
+__device__ __noinline__ void lc3_dec_ltpf(const lc3_cfg &c, lc3_dec_lds &L, int lane, int is_active, int pitch_index,
                                              int nbits) {
     const int nf = c.nf, blk = L.st.block_start_index, s25 = c.s25;
     const int ncn = c.l_num + 1, ncd = c.l_den + 1;
@@ -483,36 +493,35 @@ __device__ __forceinline__ void lc3_dec_ltpf(const lc3_cfg &c, lc3_dec_lds &L, i
             for (int k = 0; k < ncd && k < td; k++) L.st.c_den[k] = gain * lc3_f(tden, k);
         }
     }
-    for (int n = lane; n < nf; n += LC3_WAVE) L.st.x_hat_mem[blk + n] = freq[n];
     LC3_SYNC();
     if (trans == 1) {
         // inactive -> inactive: plain copy (lane-parallel)
         for (int n = lane; n < nf; n += LC3_WAVE) L.st.x_hat_ltpf_mem[blk + n] = freq[n];
     } else if (lane == 0) {
         // the IIR recursion over the output ring is serial in n
-        lc3_dec_state &st = L.st;
+        lc3_dec_core &st = L.st;
         if (trans == 2) {
             for (int n = 0; n < nf; n++) {
-                st.x_hat_ltpf_mem[blk + n] = st.x_hat_mem[blk + n];
-                float fo = lc3_ltpf_filter(c, st, st.c_num, st.c_den, blk + n, pitch_int);
+                st.x_hat_ltpf_mem[blk + n] = freq[n];
+                float fo = lc3_ltpf_filter(c, st, freq, st.c_num, st.c_den, blk, n, pitch_int);
                 if (n < s25) fo *= (float)n / (float)c.norm;
                 st.x_hat_ltpf_mem[blk + n] -= fo;
             }
         } else if (trans == 4) {
             for (int n = 0; n < nf; n++) {
-                st.x_hat_ltpf_mem[blk + n] = st.x_hat_mem[blk + n];
-                st.x_hat_ltpf_mem[blk + n] -= lc3_ltpf_filter(c, st, st.c_num, st.c_den, blk + n, pitch_int);
+                st.x_hat_ltpf_mem[blk + n] = freq[n];
+                st.x_hat_ltpf_mem[blk + n] -= lc3_ltpf_filter(c, st, freq, st.c_num, st.c_den, blk, n, pitch_int);
             }
         } else {
             // deactive_first_2p5ms :417-424
             for (int n = 0; n < s25; n++) {
-                st.x_hat_ltpf_mem[blk + n] = st.x_hat_mem[blk + n];
-                float fo = lc3_ltpf_filter(c, st, cnm, cdm, blk + n, p_int_mem);
+                st.x_hat_ltpf_mem[blk + n] = freq[n];
+                float fo = lc3_ltpf_filter(c, st, freq, cnm, cdm, blk, n, p_int_mem);
                 fo *= 1.0f - ((float)n / (float)c.norm);
                 st.x_hat_ltpf_mem[blk + n] -= fo;
             }
             if (trans == 3) {
-                for (int n = s25; n < nf; n++) st.x_hat_ltpf_mem[blk + n] = st.x_hat_mem[blk + n];
+                for (int n = s25; n < nf; n++) st.x_hat_ltpf_mem[blk + n] = freq[n];
             } else {
                 // activate_first_2p5ms_from_mem :345-378
                 const int l_num = c.l_num;
@@ -534,12 +543,14 @@ __device__ __forceinline__ void lc3_dec_ltpf(const lc3_cfg &c, lc3_dec_lds &L, i
                     st.x_hat_ltpf_mem[blk + n] -= fo;
                 }
                 for (int n = s25; n < nf; n++) {
-                    st.x_hat_ltpf_mem[blk + n] = st.x_hat_mem[blk + n];
-                    st.x_hat_ltpf_mem[blk + n] -= lc3_ltpf_filter(c, st, st.c_num, st.c_den, blk + n, pitch_int);
+                    st.x_hat_ltpf_mem[blk + n] = freq[n];
+                    st.x_hat_ltpf_mem[blk + n] -= lc3_ltpf_filter(c, st, freq, st.c_num, st.c_den, blk, n, pitch_int);
                 }
             }
         }
     }
+    LC3_SYNC();
+    if (lane < c.l_num) L.st.x_tail[lane] = freq[nf - c.l_num + lane];  // input history for the next frame
     LC3_SYNC();
     if (trans != 1)
         for (int n = lane; n < nf; n += LC3_WAVE) freq[n] = L.st.x_hat_ltpf_mem[blk + n];
@@ -555,196 +566,234 @@ __device__ __forceinline__ void lc3_dec_ltpf(const lc3_cfg &c, lc3_dec_lds &L, i
 }
 
 // ------------------------------------------------------------------------------------------
-// DecoderChannel::decode (decoder/lc3_decoder.rs:73-154): one frame of one stream on one wave.
-// in: nbytes in HBM; pcm_out: nf samples in HBM (4-byte aligned).
+// D0/D2/D3: read_frame (decoder/lc3_decoder.rs:165-177).  The range decoder is a serial state machine: lane 0.
+// Returns 1 when the frame parsed (side info in L.ism, integer spectrum in xi), 0 -> conceal.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lc3_decode_frame_wave(const lc3_cfg &c, lc3_dec_lds &L, int lane, const uint8_t *in,
-                                                      int nbytes, int16_t *pcm_out, int force_plc) {
-    const int ne = c.ne, nf = c.nf, nbits = nbytes * 8;
+__device__ __noinline__ int lc3_dec_read_frame(const lc3_cfg &c, lc3_dec_lds &L, int lane, const uint8_t *in, int nbytes,
+                                               int force_plc) {
     int *si = L.ism;
     int32_t *save_lev = (int32_t *)L.fa;  // 400 ints, free until the IMDCT
+    int32_t *xi = (int32_t *)L.fb;        // 400 ints
     for (int i = lane; i < nbytes; i += LC3_WAVE) L.in[i] = in[i];
     for (int i = lane; i < LC3_MAX_NE; i += LC3_WAVE) {
-        L.xi[i] = 0;
+        xi[i] = 0;
         save_lev[i] = 0;
     }
     LC3_SYNC();
-    // read_frame :165-177 -- the range decoder is a serial state machine: lane 0
     if (lane == 0) {
         lc3_reader r;
         r.buf = L.in;
         r.len = nbytes;
         r.head = 0;
         r.tail = 0;
-        int rc = force_plc ? -100 : lc3_dec_side_info(r, c.fs_ind, ne, si);
-        if (rc == 0) rc = lc3_dec_arith(r, c, si, L.xi, save_lev, L.res_bits);
+        int rc = force_plc ? -100 : lc3_dec_side_info(r, c.fs_ind, c.ne, si);
+        if (rc == 0) rc = lc3_dec_arith(r, c, si, xi, save_lev, L.res_bits);
         si[AD_OK] = rc == 0;
     }
     LC3_SYNC();
-    const int ok = si[AD_OK];
+    return si[AD_OK];
+}
+
+// ------------------------------------------------------------------------------------------
+// D4-D8: residual refinement, noise filling, global gain, TNS synthesis, SNS (decoder/lc3_decoder.rs:93-131)
+// ------------------------------------------------------------------------------------------
+__device__ __noinline__ void lc3_dec_spectrum(const lc3_cfg &c, lc3_dec_lds &L, int lane, int nbits) {
+    const int ne = c.ne;
+    int *si = L.ism;
+    const int32_t *xi = (const int32_t *)L.fb;
+    for (int k = lane; k < ne; k += LC3_WAVE) L.spec[k] = (float)xi[k];
+    LC3_SYNC();
+    if (lane == 0) {
+        // residual_spectrum::decode (decoder/residual_spectrum.rs:13-39)
+        if (!si[SI_LSB_MODE]) {
+            const int nres = si[AD_NRES];
+            int n = 0;
+            for (int k = 0; k < ne; k++) {
+                float v = L.spec[k];
+                if (v != 0.0f) {
+                    if (n >= nres) break;
+                    if (L.res_bits[n]) v += v > 0.0f ? 0.3125f : 0.1875f;
+                    else v -= v > 0.0f ? 0.1875f : 0.3125f;
+                    L.spec[k] = v;
+                    n++;
+                }
+            }
+        }
+        // noise_filling::apply_noise_filling (decoder/noise_filling.rs:18-56)
+        if (!si[AD_ZERO]) {
+            const int bw_stop = c.n_ms_10 ? LC3C_BWSTOP10[si[SI_BW]] : LC3C_BWSTOP75[si[SI_BW]];
+            const int nf_start = c.n_ms_10 ? 24 : 18, nf_width = c.n_ms_10 ? 3 : 2;
+            const float level = (8.0f - (float)si[SI_NF]) / 16.0f;
+            const int lim = bw_stop < ne ? bw_stop : ne;
+            int nfill = si[AD_SEED];
+            for (int k = nf_start; k < lim; k++) {
+                const int from = k - nf_width, to = (bw_stop - 1) < (k + nf_width) ? (bw_stop - 1) : (k + nf_width);
+                int all0 = 1;
+                for (int j = from; j <= to; j++)
+                    if (xi[j] != 0) { all0 = 0; break; }
+                if (all0) {
+                    nfill = (13849 + nfill * 31821) & 0xFFFF;
+                    L.spec[k] = nfill < 0x8000 ? level : -level;
+                }
+            }
+        }
+    }
+    LC3_SYNC();
+    // global_gain::apply_global_gain (decoder/global_gain.rs:15-25)
+    {
+        const int fs = c.fs_ind + 1, q = nbits / (10 * fs);
+        const int gg_off = -(q < 115 ? q : 115) - 105 - (5 * fs);
+        const float gg = lc3_pow10f(((float)si[SI_GG] + (float)gg_off) / 28.0f);
+        for (int k = lane; k < ne; k += LC3_WAVE) L.spec[k] *= gg;
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        // temporal_noise_shaping::apply_temporal_noise_shaping (decoder/temporal_noise_shaping.rs:24-137):
+        // all-pole lattice, recursive in n -> serial; state shared across both filters
+        const int bw = si[SI_BW];
+        const int nbands = bw < 3 ? 1 : 2;
+        const float step = (float)(3.14159265358979323846 / 17.0);  // (PI / 17.0) as f32 :41
+        float st[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int f = 0; f < nbands && f < si[SI_NUM_TNS]; f++) {
+            const int order = si[AD_ORD0 + f];
+            if (order > 0) {
+                float rq[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int ri = si[AD_RCI + f * 8 + k];
+                    rq[k] = ri != 0 ? lc3_sinf_small(step * (float)(ri - 8)) : 0.0f;
+                }
+                const int lo = c.n_ms_10 ? LC3C_TNSDEC10[bw][2 * f] : LC3C_TNSDEC75[bw][2 * f];
+                const int hi = c.n_ms_10 ? LC3C_TNSDEC10[bw][2 * f + 1] : LC3C_TNSDEC75[bw][2 * f + 1];
+                for (int n = lo; n < hi; n++) {
+                    float t = L.spec[n];
+                    // t = x - rc[order-1]*st[order-1]; then k = order-2 .. 0
+#pragma unroll
+                    for (int k = 7; k >= 0; k--) {
+                        if (k == order - 1) t -= rq[k] * st[k];
+                        else if (k < order - 1) {
+                            t -= rq[k] * st[k];
+                            st[k + 1] = rq[k] * t + st[k];
+                        }
+                    }
+                    L.spec[n] = t;
+                    st[0] = t;
+                }
+            }
+        }
+        // spectral_noise_shaping::decode (decoder/spectral_noise_shaping.rs:21-151): scale factors
+        int *y = (int *)(L.sm + 96), *zv = y + 16;
+        float *scf = L.sm, *sfi = L.sm + 16;  // 16 + 64
+        const int shape_j = (si[SI_SUB_MSB] << 1) + si[SI_SUB_LSB];
+        for (int n = 0; n < 16; n++) { y[n] = 0; zv[n] = 0; }
+        if (shape_j == 0) {
+            lc3_mpvq_deenum(10, 10, si[SI_LS_A], (uint32_t)si[SI_IDX_A], y);
+            lc3_mpvq_deenum(6, 1, si[SI_LS_B], (uint32_t)si[SI_IDX_B], zv);
+            for (int n = 0; n < 6; n++) y[10 + n] = zv[n];
+        } else if (shape_j == 1) {
+            lc3_mpvq_deenum(10, 10, si[SI_LS_A], (uint32_t)si[SI_IDX_A], y);
+            for (int n = 10; n < 16; n++) y[n] = 0;
+        } else if (shape_j == 2) lc3_mpvq_deenum(16, 8, si[SI_LS_A], (uint32_t)si[SI_IDX_A], y);
+        else lc3_mpvq_deenum(16, 6, si[SI_LS_A], (uint32_t)si[SI_IDX_A], y);
+        float y_norm = 0.0f;
+        for (int n = 0; n < 16; n++) y_norm += (float)y[n] * (float)y[n];
+        y_norm = lc3_sqrtf(y_norm);
+        float gain;
+        const int gi = si[SI_G_IND];
+        if (shape_j == 0) gain = lc3_f(LC3T_SNS_VQ_REG_ADJ_GAINS_BITS, gi & 1);
+        else if (shape_j == 1) gain = lc3_f(LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS, gi & 3);
+        else if (shape_j == 2) gain = lc3_f(LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS, gi & 3);
+        else gain = lc3_f(LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS, gi & 7);
+        if (y_norm != 0.0f) gain /= y_norm;
+        for (int n = 0; n < 16; n++) {
+            float factor = 0.0f;
+            for (int col = 0; col < 16; col++) factor += (float)y[col] * lc3_f(&LC3T_D_BITS[n][0], col);
+            const float st1 = n < 8 ? lc3_f(&LC3T_LFCB_BITS[si[SI_IND_LF]][0], n) : lc3_f(&LC3T_HFCB_BITS[si[SI_IND_HF]][0], n - 8);
+            scf[n] = st1 + gain * factor;
+        }
+        sfi[0] = scf[0];
+        sfi[1] = scf[0];
+        for (int n = 0; n <= 14; n++) {
+            const float fn = scf[n], d = scf[n + 1] - fn;
+            sfi[4 * n + 2] = fn + (1.0f / 8.0f * d);
+            sfi[4 * n + 3] = fn + (3.0f / 8.0f * d);
+            sfi[4 * n + 4] = fn + (5.0f / 8.0f * d);
+            sfi[4 * n + 5] = fn + (7.0f / 8.0f * d);
+        }
+        sfi[62] = scf[15] + 1.0f / 8.0f * (scf[15] - scf[14]);
+        sfi[63] = scf[15] + 3.0f / 8.0f * (scf[15] - scf[14]);
+        const int n2 = 64 - c.nb;
+        if (n2 != 0) {  // :100-111 (decoder form)
+            for (int b = 0; b < n2; b++) sfi[b] = (sfi[2 * b] + sfi[2 * b + 1]) / 2.0f;
+            for (int b = n2; b < c.nb; b++) sfi[b] = sfi[b + n2];
+        }
+    }
+    LC3_SYNC();
+    // band gains via fast_math::exp2_raw and spectral shaping -- one lane per band
+    if (lane < c.nb) {
+        const uint16_t *ifs = lc3_band_index(c);
+        const float g = lc3_exp2_raw(L.sm[16 + lane]);
+        for (int k = ifs[lane]; k < ifs[lane + 1]; k++) L.spec[k] *= g;
+    }
+    LC3_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// D9: packet loss concealment (decoder/packet_loss_concealment.rs:49-85).  plc_last_good lives in HBM.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lc3_dec_plc_save(const lc3_cfg &c, lc3_dec_lds &L, int lane, lc3_dec_state *g) {
+    for (int k = lane; k < c.ne; k += LC3_WAVE) g->plc_last_good[k] = L.spec[k];
+    if (lane == 0) {
+        L.st.plc_num_lost = 0;
+        L.st.plc_alpha = 1.0f;
+    }
+}
+__device__ __noinline__ void lc3_dec_plc_load(const lc3_cfg &c, lc3_dec_lds &L, int lane, const lc3_dec_state *g) {
+    // The sign-scrambling LCG seed_k = (16831 + seed_{k-1} * 12821) & 0xFFFF is affine mod 2^16, so lane l can
+    // jump straight to its elements k = l, l + 64, ...: seed_{k+64} = A64 * seed_k + C64 (integer, exact).
+    const int ne = c.ne;
+    const uint32_t seed0 = L.st.plc_seed;
+    const int num_lost = L.st.plc_num_lost;
+    float alpha = L.st.plc_alpha;
+    if (num_lost >= 4) alpha *= num_lost < 8 ? 0.9f : 0.85f;
+    LC3_SYNC();
+    uint32_t a64 = 1, c64 = 0;
+    for (int i = 0; i < 64; i++) {
+        c64 = (16831u + c64 * 12821u) & 0xFFFFu;
+        a64 = (a64 * 12821u) & 0xFFFFu;
+    }
+    uint32_t seed = seed0;
+    for (int i = 0; i <= lane; i++) seed = (16831u + seed * 12821u) & 0xFFFFu;  // seed_{lane}
+    for (int k = lane; k < ne; k += LC3_WAVE) {
+        const float lg = g->plc_last_good[k];
+        L.spec[k] = seed < 0x8000u ? lg * alpha : lg * -alpha;
+        if (k == ne - 1) {
+            L.st.plc_seed = seed;  // the reference leaves the seed after ne steps
+            L.st.plc_alpha = alpha;
+            L.st.plc_num_lost = num_lost + 1;
+            L.st.plc_events += 1;
+        }
+        seed = (a64 * seed + c64) & 0xFFFFu;
+    }
+    LC3_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// DecoderChannel::decode (decoder/lc3_decoder.rs:73-154): one frame of one stream on one wave.
+// in: nbytes in HBM; pcm_out: nf samples in HBM (4-byte aligned); g: the stream's state blob in HBM.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lc3_decode_frame_wave(const lc3_cfg &c, lc3_dec_lds &L, int lane, const uint8_t *in,
+                                                      int nbytes, int16_t *pcm_out, int force_plc, lc3_dec_state *g) {
+    const int nf = c.nf, nbits = nbytes * 8;
+    const int ok = lc3_dec_read_frame(c, L, lane, in, nbytes, force_plc);
     int ltpf_active = 0, pitch_index = 0;
     if (ok) {
-        ltpf_active = si[SI_LTPF_ACTIVE];
-        pitch_index = si[SI_PITCH_INDEX];
-        for (int k = lane; k < ne; k += LC3_WAVE) L.spec[k] = (float)L.xi[k];
-        LC3_SYNC();
-        if (lane == 0) {
-            // residual_spectrum::decode (decoder/residual_spectrum.rs:13-39)
-            if (!si[SI_LSB_MODE]) {
-                const int nres = si[AD_NRES];
-                int n = 0;
-                for (int k = 0; k < ne; k++) {
-                    float v = L.spec[k];
-                    if (v != 0.0f) {
-                        if (n >= nres) break;
-                        if (L.res_bits[n]) v += v > 0.0f ? 0.3125f : 0.1875f;
-                        else v -= v > 0.0f ? 0.1875f : 0.3125f;
-                        L.spec[k] = v;
-                        n++;
-                    }
-                }
-            }
-            // noise_filling::apply_noise_filling (decoder/noise_filling.rs:18-56)
-            if (!si[AD_ZERO]) {
-                const int BW75[5] = {60, 120, 180, 240, 300};
-                const int BW10[5] = {80, 160, 240, 320, 400};
-                const int bw_stop = c.n_ms_10 ? BW10[si[SI_BW]] : BW75[si[SI_BW]];
-                const int nf_start = c.n_ms_10 ? 24 : 18, nf_width = c.n_ms_10 ? 3 : 2;
-                const float level = (8.0f - (float)si[SI_NF]) / 16.0f;
-                const int lim = bw_stop < ne ? bw_stop : ne;
-                int nfill = si[AD_SEED];
-                for (int k = nf_start; k < lim; k++) {
-                    const int from = k - nf_width, to = (bw_stop - 1) < (k + nf_width) ? (bw_stop - 1) : (k + nf_width);
-                    int all0 = 1;
-                    for (int j = from; j <= to; j++)
-                        if (L.xi[j] != 0) { all0 = 0; break; }
-                    if (all0) {
-                        nfill = (13849 + nfill * 31821) & 0xFFFF;
-                        L.spec[k] = nfill < 0x8000 ? level : -level;
-                    }
-                }
-            }
-        }
-        LC3_SYNC();
-        // global_gain::apply_global_gain (decoder/global_gain.rs:15-25)
-        {
-            const int fs = c.fs_ind + 1, q = nbits / (10 * fs);
-            const int gg_off = -(q < 115 ? q : 115) - 105 - (5 * fs);
-            const float gg = lc3_pow10f(((float)si[SI_GG] + (float)gg_off) / 28.0f);
-            for (int k = lane; k < ne; k += LC3_WAVE) L.spec[k] *= gg;
-        }
-        LC3_SYNC();
-        if (lane == 0) {
-            // temporal_noise_shaping::apply_temporal_noise_shaping (decoder/temporal_noise_shaping.rs:24-137)
-            const int B10[5][4] = {{12, 80, 0, 0}, {12, 160, 0, 0}, {12, 240, 0, 0}, {12, 160, 160, 320}, {12, 200, 200, 400}};
-            const int B75[5][4] = {{9, 60, 0, 0}, {9, 120, 0, 0}, {9, 180, 0, 0}, {9, 120, 120, 240}, {9, 150, 150, 300}};
-            const int bw = si[SI_BW];
-            const int nbands = bw < 3 ? 1 : 2;
-            const float step = (float)(3.14159265358979323846 / 17.0);  // (PI / 17.0) as f32 :41
-            float st[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            for (int f = 0; f < nbands && f < si[SI_NUM_TNS]; f++) {
-                const int order = si[AD_ORD0 + f];
-                if (order > 0) {
-                    float rq[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int ri = si[AD_RCI + f * 8 + k];
-                        rq[k] = ri != 0 ? lc3_sinf_small(step * (float)(ri - 8)) : 0.0f;
-                    }
-                    const int lo = c.n_ms_10 ? B10[bw][2 * f] : B75[bw][2 * f];
-                    const int hi = c.n_ms_10 ? B10[bw][2 * f + 1] : B75[bw][2 * f + 1];
-                    for (int n = lo; n < hi; n++) {
-                        float t = L.spec[n];
-                        // t = x - rc[order-1]*st[order-1]; then k = order-2 .. 0
-#pragma unroll
-                        for (int k = 7; k >= 0; k--) {
-                            if (k == order - 1) t -= rq[k] * st[k];
-                            else if (k < order - 1) {
-                                t -= rq[k] * st[k];
-                                st[k + 1] = rq[k] * t + st[k];
-                            }
-                        }
-                        L.spec[n] = t;
-                        st[0] = t;
-                    }
-                }
-            }
-            // spectral_noise_shaping::decode (decoder/spectral_noise_shaping.rs:21-151): scale factors
-            int *y = (int *)L.fb, *zv = y + 16;
-            float *scf = L.sm, *sfi = L.sm + 16;  // 16 + 64
-            const int shape_j = (si[SI_SUB_MSB] << 1) + si[SI_SUB_LSB];
-            for (int n = 0; n < 16; n++) { y[n] = 0; zv[n] = 0; }
-            if (shape_j == 0) {
-                lc3_mpvq_deenum(10, 10, si[SI_LS_A], (uint32_t)si[SI_IDX_A], y);
-                lc3_mpvq_deenum(6, 1, si[SI_LS_B], (uint32_t)si[SI_IDX_B], zv);
-                for (int n = 0; n < 6; n++) y[10 + n] = zv[n];
-            } else if (shape_j == 1) {
-                lc3_mpvq_deenum(10, 10, si[SI_LS_A], (uint32_t)si[SI_IDX_A], y);
-                for (int n = 10; n < 16; n++) y[n] = 0;
-            } else if (shape_j == 2) lc3_mpvq_deenum(16, 8, si[SI_LS_A], (uint32_t)si[SI_IDX_A], y);
-            else lc3_mpvq_deenum(16, 6, si[SI_LS_A], (uint32_t)si[SI_IDX_A], y);
-            float y_norm = 0.0f;
-            for (int n = 0; n < 16; n++) y_norm += (float)y[n] * (float)y[n];
-            y_norm = lc3_sqrtf(y_norm);
-            float gain;
-            const int gi = si[SI_G_IND];
-            if (shape_j == 0) gain = lc3_f(LC3T_SNS_VQ_REG_ADJ_GAINS_BITS, gi & 1);
-            else if (shape_j == 1) gain = lc3_f(LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS, gi & 3);
-            else if (shape_j == 2) gain = lc3_f(LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS, gi & 3);
-            else gain = lc3_f(LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS, gi & 7);
-            if (y_norm != 0.0f) gain /= y_norm;
-            for (int n = 0; n < 16; n++) {
-                float factor = 0.0f;
-                for (int col = 0; col < 16; col++) factor += (float)y[col] * lc3_f(&LC3T_D_BITS[n][0], col);
-                const float st1 = n < 8 ? lc3_f(&LC3T_LFCB_BITS[si[SI_IND_LF]][0], n) : lc3_f(&LC3T_HFCB_BITS[si[SI_IND_HF]][0], n - 8);
-                scf[n] = st1 + gain * factor;
-            }
-            sfi[0] = scf[0];
-            sfi[1] = scf[0];
-            for (int n = 0; n <= 14; n++) {
-                const float fn = scf[n], d = scf[n + 1] - fn;
-                sfi[4 * n + 2] = fn + (1.0f / 8.0f * d);
-                sfi[4 * n + 3] = fn + (3.0f / 8.0f * d);
-                sfi[4 * n + 4] = fn + (5.0f / 8.0f * d);
-                sfi[4 * n + 5] = fn + (7.0f / 8.0f * d);
-            }
-            sfi[62] = scf[15] + 1.0f / 8.0f * (scf[15] - scf[14]);
-            sfi[63] = scf[15] + 3.0f / 8.0f * (scf[15] - scf[14]);
-            const int n2 = 64 - c.nb;
-            if (n2 != 0) {  // :100-111 (decoder form)
-                for (int b = 0; b < n2; b++) sfi[b] = (sfi[2 * b] + sfi[2 * b + 1]) / 2.0f;
-                for (int b = n2; b < c.nb; b++) sfi[b] = sfi[b + n2];
-            }
-        }
-        LC3_SYNC();
-        // band gains via fast_math::exp2_raw and spectral shaping -- one lane per band
-        if (lane < c.nb) {
-            const uint16_t *ifs = lc3_band_index(c);
-            const float g = lc3_exp2_raw(L.sm[16 + lane]);
-            for (int k = ifs[lane]; k < ifs[lane + 1]; k++) L.spec[k] *= g;
-        }
-        LC3_SYNC();
-        // packet_loss.save (decoder/packet_loss_concealment.rs:49-53)
-        for (int k = lane; k < ne; k += LC3_WAVE) L.st.plc_last_good[k] = L.spec[k];
-        if (lane == 0) {
-            L.st.plc_num_lost = 0;
-            L.st.plc_alpha = 1.0f;
-        }
+        ltpf_active = L.ism[SI_LTPF_ACTIVE];
+        pitch_index = L.ism[SI_PITCH_INDEX];
+        lc3_dec_spectrum(c, L, lane, nbits);
+        lc3_dec_plc_save(c, L, lane, g);
     } else {
-        // packet_loss.load_into (:63-85): serial LCG over the spectrum
-        if (lane == 0) {
-            lc3_dec_state &st = L.st;
-            if (st.plc_num_lost >= 4) st.plc_alpha *= st.plc_num_lost < 8 ? 0.9f : 0.85f;
-            st.plc_num_lost += 1;
-            st.plc_events += 1;
-            uint32_t seed = st.plc_seed;
-            const float alpha = st.plc_alpha;
-            for (int k = 0; k < ne; k++) {
-                seed = (16831u + seed * 12821u) & 0xFFFFu;
-                L.spec[k] = seed < 0x8000u ? st.plc_last_good[k] * alpha : st.plc_last_good[k] * -alpha;
-            }
-            st.plc_seed = seed;
-        }
+        lc3_dec_plc_load(c, L, lane, g);
     }
     LC3_SYNC();
     lc3_dec_imdct(c, L, lane);

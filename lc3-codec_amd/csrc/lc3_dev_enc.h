@@ -83,7 +83,7 @@ __device__ __forceinline__ void lc3_enc_state_store(lc3_enc_lds &L, int lane, lc
 // ------------------------------------------------------------------------------------------
 // E1-E6: MDCT analysis (encoder/modified_dct.rs:108-177)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lc3_enc_mdct(const lc3_cfg &c, lc3_enc_lds &L, int lane, const int16_t *pcm) {
+__device__ __noinline__ int lc3_enc_mdct(const lc3_cfg &c, lc3_enc_lds &L, int lane, const int16_t *pcm) {
     const int nf = c.nf, z = c.z, h = nf / 2, mid = 3 * h;
     const uint32_t *w = lc3_window_bits(c);
     const uint16_t *ifs = lc3_band_index(c);
@@ -144,27 +144,18 @@ __device__ __forceinline__ int lc3_enc_mdct(const lc3_cfg &c, lc3_enc_lds &L, in
 // ------------------------------------------------------------------------------------------
 // E7: bandwidth detector (encoder/bandwidth_detector.rs:64-127), lane 0
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lc3_enc_bandwidth(const lc3_cfg &c, lc3_enc_lds &L, int lane, int *nbits_bw) {
-    const int NBITS_BW[5] = {0, 1, 2, 2, 3};
-    *nbits_bw = NBITS_BW[c.fs_ind];
+__device__ __noinline__ int lc3_enc_bandwidth(const lc3_cfg &c, lc3_enc_lds &L, int lane, int *nbits_bw) {
+    *nbits_bw = LC3C_NBITS_BW[c.fs_ind];
     if (c.fs_ind == 0) return 0;  // :66-71 (the reference cannot construct an 8 kHz encoder)
     if (lane == 0) {
-        const int START10[4][4] = {{53, 0, 0, 0}, {47, 59, 0, 0}, {44, 54, 60, 0}, {41, 51, 57, 61}};
-        const int STOP10[4][4] = {{63, 0, 0, 0}, {56, 63, 0, 0}, {52, 59, 63, 0}, {49, 55, 60, 63}};
-        const int START75[4][4] = {{51, 0, 0, 0}, {45, 58, 0, 0}, {42, 53, 60, 0}, {40, 51, 57, 61}};
-        const int STOP75[4][4] = {{63, 0, 0, 0}, {55, 63, 0, 0}, {51, 58, 63, 0}, {48, 55, 60, 63}};
-        const int TQ[4] = {20, 10, 10, 10};
-        const int TC[4] = {15, 23, 20, 20};
-        const int L10[4] = {4, 4, 3, 1};
-        const int L75[4] = {4, 4, 3, 2};
         const int fsi = c.fs_ind;
         int bw = 0;
         for (int k = fsi - 1; k >= 0; k--) {
-            int start = c.n_ms_10 ? START10[fsi - 1][k] : START75[fsi - 1][k];
-            int stop = c.n_ms_10 ? STOP10[fsi - 1][k] : STOP75[fsi - 1][k];
+            int start = c.n_ms_10 ? LC3C_BW_START10[fsi - 1][k] : LC3C_BW_START75[fsi - 1][k];
+            int stop = c.n_ms_10 ? LC3C_BW_STOP10[fsi - 1][k] : LC3C_BW_STOP75[fsi - 1][k];
             float width = (float)(stop + 1 - start), quiet = 0.0f;
             for (int n = start; n <= stop; n++) quiet += L.eb[n] / width;
-            if (quiet >= (float)TQ[k]) {
+            if (quiet >= (float)LC3C_BW_TQ[k]) {
                 bw = k + 1;
                 break;
             }
@@ -172,13 +163,13 @@ __device__ __forceinline__ int lc3_enc_bandwidth(const lc3_cfg &c, lc3_enc_lds &
         int result = bw;
         if (fsi != bw) {
             float cutoff_max = 0.0f;
-            int l_bw = c.n_ms_10 ? L10[bw] : L75[bw];
-            int start_bw = c.n_ms_10 ? START10[fsi - 1][bw] : START75[fsi - 1][bw];
+            int l_bw = c.n_ms_10 ? LC3C_BW_L10[bw] : LC3C_BW_L75[bw];
+            int start_bw = c.n_ms_10 ? LC3C_BW_START10[fsi - 1][bw] : LC3C_BW_START75[fsi - 1][bw];
             for (int n = start_bw + 1 - l_bw; n < start_bw; n++) {
                 float cutoff = L.eb[n - l_bw] / L.eb[n];  // raw ratio, no dB
                 cutoff_max = lc3_maxf(cutoff, cutoff_max);
             }
-            result = cutoff_max > (float)TC[bw] ? bw : fsi;
+            result = cutoff_max > (float)LC3C_BW_TC[bw] ? bw : fsi;
         }
         L.ism[0] = result;
     }
@@ -191,7 +182,7 @@ __device__ __forceinline__ int lc3_enc_bandwidth(const lc3_cfg &c, lc3_enc_lds &
 // ------------------------------------------------------------------------------------------
 // E8: attack detector (encoder/attack_detector.rs:45-128)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lc3_enc_attack(const lc3_cfg &c, lc3_enc_lds &L, int lane, int nbytes) {
+__device__ __noinline__ int lc3_enc_attack(const lc3_cfg &c, lc3_enc_lds &L, int lane, int nbytes) {
     const int num_ds = c.n_ms_10 ? 160 : 120, num_blocks = c.n_ms_10 ? 4 : 3, limit = c.n_ms_10 ? 2 : 1;
     int active;
     if (c.fs < 32000) active = 0;
@@ -314,13 +305,12 @@ __device__ __forceinline__ void lc3_mvpq_enum(uint32_t &index, int &lead_sign_in
 // scratch map inside L.fa/L.fb (floats): all disjoint
 //   sE[64] smoothed/log energies, sP[64] padded, sDS[16], sSCF[16], sSCFQ[16], sINT[64],
 //   sST1[16], sR1[16], sT2[16], sABS[16], sXQ[4][16], sDM[64] (stage-1 distortions), iY[4][16]
-__device__ __forceinline__ lc3_sns_res lc3_enc_sns(const lc3_cfg &c, lc3_enc_lds &L, int lane, int attack) {
+__device__ __noinline__ lc3_sns_res lc3_enc_sns(const lc3_cfg &c, lc3_enc_lds &L, int lane, int attack) {
     float *S = (float *)L.fa;
     float *sE = S, *sP = S + 64, *sDS = S + 128, *sSCF = S + 144, *sSCFQ = S + 160, *sINT = S + 176;
     float *sST1 = S + 240, *sR1 = S + 256, *sT2 = S + 272, *sABS = S + 288, *sXQ = S + 304, *sDM = S + 368;
     int *iY = (int *)(S + 432);  // 4*16 ints -> ends at 496 floats < 960
     const uint16_t *ifs = lc3_band_index(c);
-    const int G_TILT[5] = {14, 18, 22, 26, 30};
     const int diff = 64 - c.nb;
     lc3_sns_res res;
 
@@ -344,7 +334,7 @@ __device__ __forceinline__ lc3_sns_res lc3_enc_sns(const lc3_cfg &c, lc3_enc_lds
         if (b == 0) v = 0.75f * sP[0] + 0.25f * sP[1];
         else if (b == 63) v = 0.25f * sP[62] + 0.75f * sP[63];
         else v = 0.25f * sP[b - 1] + 0.5f * sP[b] + 0.25f * sP[b + 1];
-        const float exponent = (float)G_TILT[c.fs_ind] / 630.0f;
+        const float exponent = (float)LC3C_G_TILT[c.fs_ind] / 630.0f;
         v *= lc3_pow10f((float)b * exponent);
         sE[b] = v;
     }
@@ -583,29 +573,9 @@ __device__ __forceinline__ lc3_sns_res lc3_enc_sns(const lc3_cfg &c, lc3_enc_lds
 // E11: temporal noise shaping (encoder/temporal_noise_shaping.rs:40-349)
 // rc_i[16] -> L.ism[16..32), rc_q[16] -> L.sm[16..32)
 // ------------------------------------------------------------------------------------------
-struct lc3_tns_params { int num, start[2], stop[2], sub_start[2][3], sub_stop[2][3]; };
-__device__ __forceinline__ lc3_tns_params lc3_tns_get_params(int n_ms_10, int p_bw) {
-    // :117-202 (10 ms p_bw = 2 keeps stop_freq = 200: SURVEY A5)
-    const lc3_tns_params T10[5] = {
-        {1, {12, 160}, {80, 0}, {{12, 34, 57}, {0, 0, 0}}, {{34, 57, 80}, {0, 0, 0}}},
-        {1, {12, 160}, {160, 0}, {{12, 61, 110}, {0, 0, 0}}, {{61, 110, 160}, {0, 0, 0}}},
-        {1, {12, 160}, {200, 0}, {{12, 88, 164}, {0, 0, 0}}, {{88, 164, 240}, {0, 0, 0}}},
-        {2, {12, 160}, {160, 320}, {{12, 61, 110}, {160, 213, 266}}, {{61, 110, 160}, {213, 266, 320}}},
-        {2, {12, 200}, {200, 400}, {{12, 74, 137}, {200, 266, 333}}, {{74, 137, 200}, {266, 333, 400}}},
-    };
-    const lc3_tns_params T75[5] = {
-        {1, {9, 120}, {60, 0}, {{9, 26, 43}, {0, 0, 0}}, {{26, 43, 60}, {0, 0, 0}}},
-        {1, {9, 120}, {120, 0}, {{9, 46, 83}, {0, 0, 0}}, {{46, 83, 120}, {0, 0, 0}}},
-        {1, {9, 120}, {180, 0}, {{9, 66, 123}, {0, 0, 0}}, {{66, 123, 180}, {0, 0, 0}}},
-        {2, {9, 120}, {120, 240}, {{9, 46, 82}, {120, 159, 200}}, {{46, 82, 120}, {159, 200, 240}}},
-        {2, {9, 150}, {150, 300}, {{9, 56, 103}, {150, 200, 250}}, {{56, 103, 150}, {200, 250, 300}}},
-    };
-    return n_ms_10 ? T10[p_bw] : T75[p_bw];
-}
-
-__device__ __forceinline__ lc3_tns_res lc3_enc_tns(const lc3_cfg &c, lc3_enc_lds &L, int lane, int p_bw, int nbits,
+__device__ __noinline__ lc3_tns_res lc3_enc_tns(const lc3_cfg &c, lc3_enc_lds &L, int lane, int p_bw, int nbits,
                                                   int near_nyquist) {
-    const lc3_tns_params tp = lc3_tns_get_params(c.n_ms_10, p_bw);
+    const lc3_tns_params &tp = c.n_ms_10 ? LC3C_TNS10[p_bw] : LC3C_TNS75[p_bw];
     float *S = (float *)L.fa;
     float *sAC = S;        // [2][9][3] partial autocorrelations
     float *sES = S + 64;   // [2][3] sub-block energies
@@ -637,9 +607,6 @@ __device__ __forceinline__ lc3_tns_res lc3_enc_tns(const lc3_cfg &c, lc3_enc_lds
     }
     LC3_SYNC();
     if (lane == 0) {
-        const float LAGW[9] = {1.0f, 0.9980280260203829f, 0.9921354055113971f, 0.9823915844707989f,
-                               0.9689107911912967f, 0.9518498073692735f, 0.9314049334023056f,
-                               0.9078082299969592f, 0.8813231366694713f};
         const float step = (float)3.14159265358979323846 / 17.0f;  // PI as f32 / 17.0 :268
         for (int f = 0; f < tp.num; f++) {
             float *r = S + 96, *a0 = S + 112, *a1 = S + 128;  // LDS (dynamic indexing)
@@ -650,7 +617,7 @@ __device__ __forceinline__ lc3_tns_res lc3_enc_tns(const lc3_cfg &c, lc3_enc_lds
                     e_prod *= es;
                     rk += sAC[f * 27 + k * 3 + s] / es;
                 }
-                r[k] = (e_prod == 0.0f ? r0 : rk) * LAGW[k];
+                r[k] = (e_prod == 0.0f ? r0 : rk) * LC3C_TNS_LAGW[k];
             }
             // Levinson-Durbin :204-232
             float *a = a0, *a_last = a1;
@@ -788,7 +755,7 @@ __device__ __forceinline__ float lc3_ltpf_dot(const float *x12, int n, int d) { 
     return acc;
 }
 
-__device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(const lc3_cfg &c, lc3_enc_lds &L, int lane, int near_nyquist,
+__device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(const lc3_cfg &c, lc3_enc_lds &L, int lane, int near_nyquist,
                                                     int nbits) {
     const int len12 = c.len12, len6 = c.len6, p = c.p_up;
     const int x12_len = len12 + c.delay12 + LC3_NMEM;
@@ -1035,7 +1002,7 @@ struct lc3_bitcons { int rate_flag, lastnz, nbits_lsb, lastnz_trunc, nbits_est, 
 
 // quantize_spectrum :230-263 + compute_bit_consumption :265-348.
 // Quantisation is lane-parallel; the context-adaptive bit estimate walks tuples in order on lane 0.
-__device__ __forceinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_enc_lds &L, int lane, int nbits,
+__device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_enc_lds &L, int lane, int nbits,
                                                             int gg_off, int gg_ind, int nbits_spec, float *gg_out,
                                                             int *lsb_mode) {
     const int ne = c.ne;
@@ -1107,7 +1074,7 @@ __device__ __forceinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, l
     return bc;
 }
 
-__device__ __forceinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_lds &L, int lane, int nbits, int nbits_bw,
+__device__ __noinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_lds &L, int lane, int nbits, int nbits_bw,
                                                       int nbits_tns, int nbits_ltpf) {
     const int ne = c.ne, ne4 = ne / 4;
     float *e = (float *)L.fa;  // 100 group energies
@@ -1195,10 +1162,7 @@ __device__ __forceinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc
     }
     // global_gain_adjustment :350-388 (wave-uniform scalar code)
     {
-        const int T1[5] = {80, 230, 380, 530, 680};
-        const int T2[5] = {500, 1025, 1550, 2075, 2600};
-        const int T3[5] = {850, 1700, 2550, 3400, 4250};
-        const int t1 = T1[c.fs_ind], t2 = T2[c.fs_ind], t3 = T3[c.fs_ind], est = bc.nbits_est, origin = gg_ind;
+        const int t1 = LC3C_GGA_T1[c.fs_ind], t2 = LC3C_GGA_T2[c.fs_ind], t3 = LC3C_GGA_T3[c.fs_ind], est = bc.nbits_est, origin = gg_ind;
         float delta;
         if (est < t1) delta = ((float)est + 48.0f) / 16.0f;
         else if (est < t2) {
@@ -1231,14 +1195,12 @@ __device__ __forceinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc
 // E18 residual bits (encoder/residual_spectrum.rs:33-62), E19 noise level
 // (encoder/noise_level_estimation.rs:21-55).  Returns n_res via L.ism[0], noise factor via L.ism[1].
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lc3_enc_residual_noise(const lc3_cfg &c, lc3_enc_lds &L, int lane,
+__device__ __noinline__ void lc3_enc_residual_noise(const lc3_cfg &c, lc3_enc_lds &L, int lane,
                                                        const lc3_quant_res &q, int bw_ind) {
-    const int BW10[5] = {80, 160, 240, 320, 400};
-    const int BW75[5] = {60, 120, 180, 240, 300};
     const int ne = c.ne;
     float *nz = (float *)L.fa;  // |x|/gg where relevant
     uint8_t *rel = (uint8_t *)L.fb;
-    const int bw_stop = c.n_ms_10 ? BW10[bw_ind] : BW75[bw_ind];
+    const int bw_stop = c.n_ms_10 ? LC3C_BWSTOP10[bw_ind] : LC3C_BWSTOP75[bw_ind];
     const int nf_start = c.n_ms_10 ? 24 : 18, nf_width = c.n_ms_10 ? 3 : 2;
     const int nf_stop = ne < bw_stop ? ne : bw_stop;
     // relevance flags + per-line contributions in parallel
@@ -1347,7 +1309,7 @@ __device__ __forceinline__ void lc3_ac_encode(lc3_bitwriter &w, int cum_freq, in
     }
 }
 
-__device__ __forceinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L, int lane, int bw_ind, int nbits_bw,
+__device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L, int lane, int bw_ind, int nbits_bw,
                                                   const lc3_sns_res &sns, const lc3_tns_res &tns,
                                                   const lc3_ltpf_res &ltpf, const lc3_quant_res &spec, int n_res_bits,
                                                   int noise_factor, int nbytes) {

@@ -24,7 +24,7 @@
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void lc3_encode_kernel(lc3_cfg cfg, lc3_enc_state *states, int first_channel,
+__global__ __launch_bounds__(64, 3) void lc3_encode_kernel(lc3_cfg cfg, lc3_enc_state *states, int first_channel,
                                                        const int16_t *pcm, uint8_t *out, int nbytes, int n_frames,
                                                        int fresh, float *dbg) {
     __shared__ lc3_enc_lds L;
@@ -40,19 +40,19 @@ __global__ __launch_bounds__(64) void lc3_encode_kernel(lc3_cfg cfg, lc3_enc_sta
     lc3_enc_state_store(L, lane, gst);
 }
 
-__global__ __launch_bounds__(64) void lc3_decode_kernel(lc3_cfg cfg, lc3_dec_state *states, int first_channel,
+__global__ __launch_bounds__(64, 3) void lc3_decode_kernel(lc3_cfg cfg, lc3_dec_state *states, int first_channel,
                                                        const uint8_t *in, const uint8_t *bad, int16_t *pcm, int nbytes,
                                                        int n_frames, int fresh) {
     __shared__ lc3_dec_lds L;
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
     lc3_dec_state *gst = states + (size_t)(first_channel + s);
-    if (fresh) lc3_dec_state_init(L, lane);
+    if (fresh) lc3_dec_state_init(L, lane, gst);
     else lc3_dec_state_load(L, lane, gst);
     for (int t = 0; t < n_frames; t++) {
         const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
         const int force_plc = bad ? (int)bad[f] : 0;
-        lc3_decode_frame_wave(cfg, L, lane, in + f * (size_t)nbytes, nbytes, pcm + f * (size_t)cfg.nf, force_plc);
+        lc3_decode_frame_wave(cfg, L, lane, in + f * (size_t)nbytes, nbytes, pcm + f * (size_t)cfg.nf, force_plc, gst);
     }
     lc3_dec_state_store(L, lane, gst);
 }
@@ -428,7 +428,7 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
     int rc = lc3gpu_decoder_state_save(d, st.data());
     if (rc) return rc;
     uint64_t total = 0;
-    for (const auto &s : st) total += (uint64_t)s.plc_events;
+    for (const auto &s : st) total += (uint64_t)s.core.plc_events;
     *out = total;
     return LC3GPU_OK;
 }

@@ -14,6 +14,7 @@
 
 #define __device__
 #define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
 
 static pthread_barrier_t g_bar;
 #define LC3_SYNC() pthread_barrier_wait(&g_bar)
@@ -53,11 +54,11 @@ void *lane_main(void *arg) {
         lc3_enc_state_store(L, lane, j->est);
     } else {
         lc3_dec_lds &L = *j->DL;
-        if (j->fresh) lc3_dec_state_init(L, lane);
+        if (j->fresh) lc3_dec_state_init(L, lane, j->dst);
         else lc3_dec_state_load(L, lane, j->dst);
         for (int t = 0; t < j->n_frames; t++)
             lc3_decode_frame_wave(j->cfg, L, lane, j->bytes_in + (size_t)t * j->nbytes, j->nbytes,
-                                  j->pcm_out + (size_t)t * j->cfg.nf, j->bad ? j->bad[t] : 0);
+                                  j->pcm_out + (size_t)t * j->cfg.nf, j->bad ? j->bad[t] : 0, j->dst);
         lc3_dec_state_store(L, lane, j->dst);
     }
     return 0;

