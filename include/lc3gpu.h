@@ -110,6 +110,10 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *dec, uint64_t *out);
  * dbg float[1472] = spectrum after MDCT [0,480), after SNS [480,960), after TNS [960,1440), scalars [1440,1472) */
 int lc3gpu_encode_frame_debug(lc3gpu_encoder *enc, const int16_t *samples_in, int n_samples, uint8_t *buf_out,
                               int nbytes, float *dbg);
+/* diagnostic build (liblc3gpu_prof.so, -DLC3_PROFILE) only: per-stage shader-clock cycle sums since the last call.
+ * slots 1..9 = encoder stages (mdct, bw+attack, sns, tns, ltpf, quant, residual+noise, bitstream, store),
+ * slots 17..21 = decoder (read_frame, spectrum/plc, imdct, ltpf, output).  LC3GPU_EUNSUPPORTED in the normal build. */
+int lc3gpu_prof_read(unsigned long long out[32]);
 /* kernel resource report: out = {lds_bytes, vgprs, sgprs, scratch_bytes, max_threads} for 0 = encoder, 1 = decoder */
 int lc3gpu_kernel_info(int which, int out[5]);
 

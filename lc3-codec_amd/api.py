@@ -15,7 +15,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_LIB = os.path.join(_HERE, "lib", "liblc3gpu.so")
+# LC3GPU_PROFILE=1 selects the diagnostic build with in-kernel stage stamps (never used for timing claims)
+_PROFILE = os.environ.get("LC3GPU_PROFILE", "0") == "1"
+_LIB = os.path.join(_HERE, "lib", "liblc3gpu_prof.so" if _PROFILE else "liblc3gpu.so")
 _SRC = os.path.join(_HERE, "csrc", "lc3gpu.hip")
 
 class Lc3GpuError(RuntimeError):
@@ -64,6 +66,8 @@ def build_native(force=False, verbose=False):
     os.makedirs(os.path.dirname(_LIB), exist_ok=True)
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-fno-fast-math", "-Wno-unused-function", "-Wno-missing-braces", "-o", _LIB, _SRC]
+    if _PROFILE:
+        cmd.insert(1, "-DLC3_PROFILE")
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -128,7 +132,7 @@ ABI_SYMBOLS = [
     "lc3gpu_encoder_state_size", "lc3gpu_encoder_state_save", "lc3gpu_encoder_state_load", "lc3gpu_decoder_create",
     "lc3gpu_decoder_destroy", "lc3gpu_decoder_reset", "lc3gpu_decode_frame", "lc3gpu_decode", "lc3gpu_decode_range",
     "lc3gpu_decoder_state_size", "lc3gpu_decoder_state_save", "lc3gpu_decoder_state_load",
-    "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info",
+    "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info", "lc3gpu_prof_read",
 ]
 
 
@@ -336,6 +340,15 @@ class Lc3Decoder:
             self.close()
         except Exception:
             pass
+
+
+def prof_read():
+    """diagnostic build only: per-slot cycles accumulated since the previous call"""
+    out = (ctypes.c_ulonglong * 32)()
+    rc = load_library().lc3gpu_prof_read(out)
+    if rc:
+        raise Lc3GpuError(rc, "prof_read")
+    return list(out)
 
 
 def kernel_info(which):

@@ -21,6 +21,12 @@
 #define LC3_TABLE_QUAL static __device__ const
 #include "../../tables/lc3_tables.h"
 
+// Optional in-kernel stage stamps (diagnostic build only, -DLC3_PROFILE; see lc3gpu.hip).  The production
+// build compiles them away.
+#ifndef LC3_STAMP
+#define LC3_STAMP(L, lane, id)
+#endif
+
 #define LC3_WAVE 64
 #define LC3_MAX_NF 480
 #define LC3_MAX_NE 400

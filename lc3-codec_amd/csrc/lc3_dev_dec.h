@@ -34,6 +34,7 @@ struct lc3_dec_lds {
     uint8_t res_bits[480];
     float sm[192];
     int ism[64];
+    unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
 };
 
 __device__ __forceinline__ void lc3_dec_state_init(lc3_dec_lds &L, int lane, lc3_dec_state *g) {
@@ -785,7 +786,9 @@ __device__ __noinline__ void lc3_dec_plc_load(const lc3_cfg &c, lc3_dec_lds &L, 
 __device__ __forceinline__ void lc3_decode_frame_wave(const lc3_cfg &c, lc3_dec_lds &L, int lane, const uint8_t *in,
                                                       int nbytes, int16_t *pcm_out, int force_plc, lc3_dec_state *g) {
     const int nf = c.nf, nbits = nbytes * 8;
+    LC3_STAMP(L, lane, 16);
     const int ok = lc3_dec_read_frame(c, L, lane, in, nbytes, force_plc);
+    LC3_STAMP(L, lane, 17);
     int ltpf_active = 0, pitch_index = 0;
     if (ok) {
         ltpf_active = L.ism[SI_LTPF_ACTIVE];
@@ -796,8 +799,11 @@ __device__ __forceinline__ void lc3_decode_frame_wave(const lc3_cfg &c, lc3_dec_
         lc3_dec_plc_load(c, L, lane, g);
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 18);
     lc3_dec_imdct(c, L, lane);
+    LC3_STAMP(L, lane, 19);
     lc3_dec_ltpf(c, L, lane, ltpf_active, pitch_index, nbits);
+    LC3_STAMP(L, lane, 20);
     // output_scaling::scale_and_round (decoder/output_scaling.rs:13-25); two samples per 32-bit store
     {
         uint32_t *o32 = (uint32_t *)pcm_out;
@@ -814,4 +820,5 @@ __device__ __forceinline__ void lc3_decode_frame_wave(const lc3_cfg &c, lc3_dec_
         }
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 21);
 }

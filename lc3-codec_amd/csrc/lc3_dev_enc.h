@@ -42,6 +42,7 @@ struct lc3_enc_lds {
     uint8_t res_bits[LC3_MAX_NE];
     float sm[160];           // small scratch (per-stage)
     int ism[64];
+    unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
 };
 
 struct lc3_sns_res { int ind_lf, ind_hf, shape_j, gind, ls_inda, ls_indb; uint32_t index_joint_j; };
@@ -692,34 +693,61 @@ __device__ __noinline__ lc3_tns_res lc3_enc_tns(const lc3_cfg &c, lc3_enc_lds &L
             nbits_tns += (int)lc3_ceilf((2048.0f + (float)order_bits + (float)coef_bits) / 2048.0f);
         }
         L.ism[10] = nbits_tns;
-        // apply_filtering :313-340 -- serial MA lattice, state shared across filters
-        float st[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    LC3_SYNC();
+    // apply_filtering :313-340.  The reference walks the samples serially through an order-8 MA lattice
+    //   B_{k+1}[n] = rc_k * F_k[n] + B_k[n-1],   F_{k+1}[n] = F_k[n] + rc_k * B_k[n-1],   F_0 = B_0 = x,
+    // where st[k] holds B_k[n-1].  A stage only needs the previous stage at n and n-1, so each stage is computed
+    // for all samples at once (one lane per sample, identical f32 operations per element => bit-exact), 8 stages
+    // instead of ~200 x 8 dependent steps.  The lattice state is shared across the two filters exactly as in the
+    // reference (st[k] = B_k at the last sample of the previous filter, untouched for k >= its order).
+    {
+        float *sF = S + 160, *sB = S + 384, *sST = S + 608;  // 200 + 200 + 8 floats of stage scratch
+        if (lane < 8) sST[lane] = 0.0f;
+        LC3_SYNC();
         for (int f = 0; f < tp.num; f++) {
             const int order = L.ism[8 + f];
-            if (order != 0) {
-                float rq[8];
-                for (int k = 0; k < 8; k++) rq[k] = rc_q[f * 8 + k];
-                for (int n = tp.start[f]; n < tp.stop[f]; n++) {
-                    float t = x[n], st_save = t;
+            if (order == 0) continue;
+            const int start = tp.start[f], len = tp.stop[f] - tp.start[f];
 #pragma unroll
-                    for (int k = 0; k < 7; k++) {
-                        if (k < order - 1) {
-                            float st_tmp = rq[k] * t + st[k];
-                            t += rq[k] * st[k];
-                            st[k] = st_save;
-                            st_save = st_tmp;
-                        }
-                    }
-                    // t += rc_q[prev_order] * st[prev_order]; st[prev_order] = st_save
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        if (k == order - 1) {
-                            t += rq[k] * st[k];
-                            st[k] = st_save;
-                        }
-                    }
-                    x[n] = t;
+            for (int j = 0; j < 4; j++) {
+                const int i = lane + LC3_WAVE * j;
+                if (i < len) {
+                    const float v = x[start + i];
+                    sF[i] = v;
+                    sB[i] = v;
                 }
+            }
+            LC3_SYNC();
+            for (int k = 0; k < order; k++) {
+                const float rc = rc_q[f * 8 + k];
+                const int last_stage = k == order - 1;
+                float nb[4], nfv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int i = lane + LC3_WAVE * j;
+                    if (i < len) {
+                        const float bprev = i == 0 ? sST[k] : sB[i - 1];
+                        const float fv = sF[i];
+                        nb[j] = rc * fv + bprev;   // st_tmp = rcq * t + st
+                        nfv[j] = fv + rc * bprev;  // t += rcq * st
+                    }
+                }
+                const float b_last = sB[len - 1];  // B_k at the filter's last sample -> next st[k]
+                LC3_SYNC();
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int i = lane + LC3_WAVE * j;
+                    if (i < len) {
+                        if (last_stage) x[start + i] = nfv[j];
+                        else {
+                            sB[i] = nb[j];
+                            sF[i] = nfv[j];
+                        }
+                    }
+                }
+                if (lane == 0) sST[k] = b_last;
+                LC3_SYNC();
             }
         }
     }
@@ -1489,18 +1517,26 @@ __device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L,
 __device__ __forceinline__ void lc3_encode_frame_wave(const lc3_cfg &c, lc3_enc_lds &L, int lane, const int16_t *pcm,
                                                       uint8_t *out, int nbytes, float *dbg) {
     const int nbits = nbytes * 8;
+    LC3_STAMP(L, lane, 0);
     const int near_nyquist = lc3_enc_mdct(c, L, lane, pcm);
+    LC3_STAMP(L, lane, 1);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[i] = L.spec[i];
     int nbits_bw;
     const int bw_ind = lc3_enc_bandwidth(c, L, lane, &nbits_bw);
     const int attack = lc3_enc_attack(c, L, lane, nbytes);
+    LC3_STAMP(L, lane, 2);
     const lc3_sns_res sns = lc3_enc_sns(c, L, lane, attack);
+    LC3_STAMP(L, lane, 3);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[480 + i] = L.spec[i];
     const lc3_tns_res tns = lc3_enc_tns(c, L, lane, bw_ind, nbits, near_nyquist);
+    LC3_STAMP(L, lane, 4);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[960 + i] = L.spec[i];
     const lc3_ltpf_res pf = lc3_enc_ltpf(c, L, lane, near_nyquist, nbits);
+    LC3_STAMP(L, lane, 5);
     const lc3_quant_res spec = lc3_enc_quant(c, L, lane, nbits, nbits_bw, tns.nbits_tns, pf.nbits_ltpf);
+    LC3_STAMP(L, lane, 6);
     lc3_enc_residual_noise(c, L, lane, spec, bw_ind);
+    LC3_STAMP(L, lane, 7);
     const int n_res = L.ism[0], noise_factor = L.ism[1];
     LC3_SYNC();
     if (dbg && lane == 0) {
@@ -1513,6 +1549,8 @@ __device__ __forceinline__ void lc3_encode_frame_wave(const lc3_cfg &c, lc3_enc_
         d[18] = spec.gg; d[19] = (float)spec.nbits_spec; d[20] = (float)spec.nbits_trunc; d[21] = (float)near_nyquist;
     }
     lc3_enc_bitstream(c, L, lane, bw_ind, nbits_bw, sns, tns, pf, spec, n_res, noise_factor, nbytes);
+    LC3_STAMP(L, lane, 8);
     for (int i = lane; i < nbytes; i += LC3_WAVE) out[i] = L.out[i];
     LC3_SYNC();
+    LC3_STAMP(L, lane, 9);
 }

@@ -17,6 +17,20 @@
 #include "../../include/lc3gpu.h"
 
 #define LC3_SYNC() __syncthreads()
+#ifdef LC3_PROFILE
+// Diagnostic build (liblc3gpu_prof.so): lane 0 of every wave adds the shader-clock cycles between consecutive
+// stage stamps into a global table.  Stamp i accumulates the time since the previous stamp into slot i.
+// Never timed as a whole; read its SHARES (cdna_hip_programming.md section 7, in-kernel stamps).
+__device__ unsigned long long lc3_prof_acc[32];
+#define LC3_STAMP(L, lane, id)                                                                \
+    do {                                                                                      \
+        if ((lane) == 0) {                                                                    \
+            unsigned long long t_ = clock64();                                                \
+            if ((id) != 0 && (id) != 16) atomicAdd(&lc3_prof_acc[(id)], t_ - (L).prof_last);  \
+            (L).prof_last = t_;                                                               \
+        }                                                                                     \
+    } while (0)
+#endif
 #include "lc3_dev_dec.h"
 #include "lc3_dev_enc.h"
 #include "lc3_host_plan.h"
@@ -431,6 +445,21 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
     for (const auto &s : st) total += (uint64_t)s.core.plc_events;
     *out = total;
     return LC3GPU_OK;
+}
+
+// diagnostic build only: copy (and clear) the per-stage cycle accumulators; LC3GPU_EUNSUPPORTED otherwise
+int lc3gpu_prof_read(unsigned long long out[32]) {
+#ifdef LC3_PROFILE
+    if (!out) return LC3GPU_EINVAL;
+    unsigned long long zero[32] = {0};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(lc3_prof_acc), sizeof(zero)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lc3_prof_acc), zero, sizeof(zero)));
+    return LC3GPU_OK;
+#else
+    (void)out;
+    return LC3GPU_EUNSUPPORTED;
+#endif
 }
 
 int lc3gpu_kernel_info(int which, int out[5]) {
