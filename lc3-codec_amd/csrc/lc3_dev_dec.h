@@ -62,8 +62,14 @@ __device__ __forceinline__ void lc3_dec_state_store(lc3_dec_lds &L, int lane, lc
 }
 
 // ------------------------------------------------------------------------------------------
-// D1: BufferReader (decoder/buffer_reader.rs:11-116)
+// Frame parsing runs in "uniform-scalar" style: the whole wave executes the serial bitstream state
+// machine with identical (wave-uniform) values, so on the GPU the state lives in SGPRs and the integer
+// work issues on the scalar unit instead of a 1-of-64-lanes vector stream.  LDS reads are made uniform
+// with LC3_U() (v_readfirstlane), LDS writes go through LC3_UST() (lane 0 stores), and the 17-way
+// symbol search of the range decoder is done by 17 lanes at once (lc3_sym_search: ballot + readlane).
+// The including translation unit defines LC3_UNIFORM_LEADER / LC3_U / LC3_UST / lc3_sym_search.
 // ------------------------------------------------------------------------------------------
+// D1: BufferReader (decoder/buffer_reader.rs:11-116)
 struct lc3_reader {
     const uint8_t *buf;
     int len, head, tail;
@@ -77,7 +83,7 @@ __device__ __forceinline__ int lc3_rd_tail(lc3_reader &r, int num_bits, uint32_t
     const int from = r.len - byte_index - num_bytes;
     uint32_t value = 0;
     if (num_bytes <= 4)
-        for (int i = 0; i < num_bytes; i++) value = (value << 8) | r.buf[from + i];
+        for (int i = 0; i < num_bytes; i++) value = (value << 8) | (uint32_t)LC3_U(r.buf[from + i]);
     const int shift_by = 32 - num_bits - bit_index;
     value <<= shift_by;
     value >>= shift_by + bit_index;
@@ -90,7 +96,7 @@ __device__ __forceinline__ int lc3_rd_bool(lc3_reader &r, int &bit) {  // read_t
     if (r.len - r.head - byte_index + 2 < 0) return -1;
     const int from = r.len - byte_index - 1;
     if (from < 0) return -1;  // the reference would panic here; treated as a read error (-> PLC)
-    uint32_t byte = r.buf[from];
+    uint32_t byte = (uint32_t)LC3_U(r.buf[from]);
     byte = (byte << (7 - bit_index)) & 0xffu;
     byte >>= 7;
     r.tail += 1;
@@ -98,18 +104,19 @@ __device__ __forceinline__ int lc3_rd_bool(lc3_reader &r, int &bit) {  // read_t
     return 0;
 }
 
-// decoded side information, kept in L.ism[] by lane 0:
+// decoded side information, kept in L.ism[]:
 enum {
     SI_BW = 0, SI_LASTNZ, SI_LSB_MODE, SI_GG, SI_NUM_TNS, SI_ORD0, SI_ORD1, SI_IND_LF, SI_IND_HF, SI_LS_A, SI_LS_B,
     SI_IDX_A, SI_IDX_B, SI_SUB_LSB, SI_SUB_MSB, SI_G_IND, SI_PITCH_PRESENT, SI_LTPF_ACTIVE, SI_PITCH_INDEX, SI_NF,
-    AD_ORD0, AD_ORD1, AD_NRES, AD_SEED, AD_ZERO, AD_OK, AD_RCI /* 16 entries */
+    AD_ORD0, AD_ORD1, AD_NRES, AD_SEED, AD_ZERO, AD_OK, AD_RCI /* 16 entries */, AD_TAIL0 = AD_RCI + 16, AD_NRES_MAX,
+    AD_HEAD
 };
 
 #define LC3_RD(nb, dst) do { if (lc3_rd_tail(r, (nb), (dst))) return -1; } while (0)
 #define LC3_RDB(dst) do { if (lc3_rd_bool(r, (dst))) return -1; } while (0)
 
-// D2: side_info_reader::read (decoder/side_info_reader.rs:29-200), lane 0
-__device__ __forceinline__ int lc3_dec_side_info(lc3_reader &r, int fs_ind, int ne, int *si) {
+// D2: side_info_reader::read (decoder/side_info_reader.rs:29-200)
+__device__ __forceinline__ int lc3_dec_side_info(lc3_reader &r, int fs_ind, int ne, int *si, int lane) {
     uint32_t v;
     int b, p_bw = 0, lastnz_bits = 0;
     const int nbits_bw = LC3C_NBITS_BW[fs_ind];
@@ -120,33 +127,36 @@ __device__ __forceinline__ int lc3_dec_side_info(lc3_reader &r, int fs_ind, int 
     }
     while ((1 << lastnz_bits) < ne / 2) lastnz_bits++;
     LC3_RD(lastnz_bits, v);
-    si[SI_LASTNZ] = (int)((v + 1) << 1);
-    if (si[SI_LASTNZ] > ne) return -3;
+    const int lastnz = (int)((v + 1) << 1);
+    LC3_UST(si[SI_LASTNZ], lastnz);
+    if (lastnz > ne) return -3;
     LC3_RDB(b);
-    si[SI_LSB_MODE] = b;
+    LC3_UST(si[SI_LSB_MODE], b);
     LC3_RD(8, v);
-    si[SI_GG] = (int)v;
-    si[SI_NUM_TNS] = p_bw < 3 ? 1 : 2;
-    si[SI_ORD0] = 0;
-    si[SI_ORD1] = 0;
-    for (int f = 0; f < si[SI_NUM_TNS]; f++) {
+    LC3_UST(si[SI_GG], (int)v);
+    const int num_tns = p_bw < 3 ? 1 : 2;
+    LC3_UST(si[SI_NUM_TNS], num_tns);
+    LC3_UST(si[SI_ORD0], 0);
+    LC3_UST(si[SI_ORD1], 0);
+    for (int f = 0; f < num_tns; f++) {
         LC3_RDB(b);
-        si[SI_ORD0 + f] = b;
+        LC3_UST(si[SI_ORD0 + f], b);
     }
     LC3_RDB(b);
-    si[SI_PITCH_PRESENT] = b;
+    const int pitch_present = b;
+    LC3_UST(si[SI_PITCH_PRESENT], b);
     // read_sns_vq :131-200
     LC3_RD(5, v);
-    si[SI_IND_LF] = (int)v;
+    LC3_UST(si[SI_IND_LF], (int)v);
     LC3_RD(5, v);
-    si[SI_IND_HF] = (int)v;
+    LC3_UST(si[SI_IND_HF], (int)v);
     LC3_RDB(b);
     const int submode_msb = b;
     if (submode_msb == 0) LC3_RD(1, v);
     else LC3_RD(2, v);
     int g_ind = (int)v;
     LC3_RDB(b);
-    si[SI_LS_A] = b;
+    LC3_UST(si[SI_LS_A], b);
     int submode_lsb = 0, ls_indb = 0;
     uint32_t idx_a, idx_b = 0;
     if (submode_msb == 0) {
@@ -174,100 +184,108 @@ __device__ __forceinline__ int lc3_dec_side_info(lc3_reader &r, int fs_ind, int 
             idx_a = tmp >> 1;
         } else idx_a = tmp;
     }
-    si[SI_LS_B] = ls_indb;
-    si[SI_IDX_A] = (int)idx_a;
-    si[SI_IDX_B] = (int)idx_b;
-    si[SI_SUB_LSB] = submode_lsb;
-    si[SI_SUB_MSB] = submode_msb;
-    si[SI_G_IND] = g_ind;
+    LC3_UST(si[SI_LS_B], ls_indb);
+    LC3_UST(si[SI_IDX_A], (int)idx_a);
+    LC3_UST(si[SI_IDX_B], (int)idx_b);
+    LC3_UST(si[SI_SUB_LSB], submode_lsb);
+    LC3_UST(si[SI_SUB_MSB], submode_msb);
+    LC3_UST(si[SI_G_IND], g_ind);
     // read_long_term_post_filter_info :106-129
-    si[SI_LTPF_ACTIVE] = 0;
-    si[SI_PITCH_INDEX] = 0;
-    if (si[SI_PITCH_PRESENT]) {
+    int ltpf_active = 0, pitch_index = 0;
+    if (pitch_present) {
         LC3_RDB(b);
-        si[SI_LTPF_ACTIVE] = b;
+        ltpf_active = b;
         LC3_RD(9, v);
-        si[SI_PITCH_INDEX] = (int)v;
+        pitch_index = (int)v;
     }
+    LC3_UST(si[SI_LTPF_ACTIVE], ltpf_active);
+    LC3_UST(si[SI_PITCH_INDEX], pitch_index);
     LC3_RD(3, v);
-    si[SI_NF] = (int)v;
-    si[SI_BW] = p_bw;
+    LC3_UST(si[SI_NF], (int)v);
+    LC3_UST(si[SI_BW], p_bw);
     return 0;
 }
 
-// D3: arithmetic decoder (decoder/arithmetic_codec.rs:57-405), lane 0
+// D3: arithmetic decoder (decoder/arithmetic_codec.rs:57-405)
 struct lc3_acdec { uint32_t low, range; };
+// ac_decode :67-97.  The reference searches the symbol linearly from the top (`while low < tmp * cum[val]`);
+// here lane i evaluates symbol i and the highest lane whose test holds is the answer (same integer compare).
 __device__ __forceinline__ int lc3_ac_decode(lc3_reader &r, lc3_acdec &st, const int16_t *cum, const int16_t *freq,
-                                             int nsym, int &sym) {  // :67-97
+                                             int nsym, int lane, int &sym) {
     const uint32_t tmp = st.range >> 10, limit = tmp << 10;
     if (st.low >= limit) return -1;
-    int val = nsym - 1;
-    while (st.low < tmp * (uint32_t)cum[val]) val--;
-    st.low -= tmp * (uint32_t)cum[val];
-    st.range = tmp * (uint32_t)freq[val];
+    uint32_t cval, fval;
+    const int val = lc3_sym_search(cum, freq, nsym, st.low, tmp, lane, cval, fval);
+    st.low -= tmp * cval;
+    st.range = tmp * fval;
     while (st.range < 0x10000u) {
         st.low <<= 8;
         st.low &= 0x00ffffffu;
         if (r.head >= r.len) return -1;  // read_head_byte :42-50
-        st.low += r.buf[r.head++];
+        st.low += (uint32_t)LC3_U(r.buf[r.head]);
+        r.head += 1;
         st.range <<= 8;
     }
     sym = val;
     return 0;
 }
-__device__ __forceinline__ int lc3_read_res_bit(int32_t *x, lc3_reader &r, int idx, int &nbits_res, int &cont) {
+__device__ __forceinline__ int lc3_read_res_bit(int32_t *x, lc3_reader &r, int idx, int &nbits_res, int &cont, int lane) {
     // :339-383
     int bit;
     if (nbits_res == 0) { cont = 0; return 0; }
     if (lc3_rd_bool(r, bit)) return -1;
     nbits_res -= 1;
     if (bit) {
-        if (x[idx] > 0) x[idx] += 1;
-        else if (x[idx] < 0) x[idx] -= 1;
+        const int xv = LC3_U(x[idx]);
+        if (xv > 0) LC3_UST(x[idx], xv + 1);
+        else if (xv < 0) LC3_UST(x[idx], xv - 1);
         else {
             if (nbits_res == 0) { cont = 0; return 0; }
             if (lc3_rd_bool(r, bit)) return -1;
             nbits_res -= 1;
-            x[idx] = bit ? -1 : 1;
+            LC3_UST(x[idx], bit ? -1 : 1);
         }
     }
     cont = 1;
     return 0;
 }
 
-// save_lev lives in `save_lev` (LDS, ne ints, zeroed by the caller)
-__device__ __forceinline__ int lc3_dec_arith(lc3_reader &r, const lc3_cfg &c, int *si, int32_t *x, int32_t *save_lev,
-                                             uint8_t *res_bits) {
-    const int nbits = r.len * 8, ne = c.ne;
+// arithmetic_codec::decode :109-158 up to (not including) the non-lsb residual bits and the noise seed, which
+// the caller does lane-parallel.  x and save_lev are zero on entry.
+__device__ __forceinline__ int lc3_dec_arith(lc3_reader &r, int ne, int fs_ind, int n_ms_10, int *si, int32_t *x,
+                                             int32_t *save_lev, int lane) {
+    const int nbits = r.len * 8;
+    const int num_tns = LC3_U(si[SI_NUM_TNS]), lastnz = LC3_U(si[SI_LASTNZ]), lsb_mode = LC3_U(si[SI_LSB_MODE]);
     lc3_acdec st;
     int sym = 0;
     // ac_dec_init :57-65
     if (!(r.head + 2 < r.len)) return -1;
-    st.low = ((uint32_t)r.buf[r.head] << 16) | ((uint32_t)r.buf[r.head + 1] << 8) | r.buf[r.head + 2];
+    st.low = ((uint32_t)LC3_U(r.buf[r.head]) << 16) | ((uint32_t)LC3_U(r.buf[r.head + 1]) << 8) |
+             (uint32_t)LC3_U(r.buf[r.head + 2]);
     r.head += 3;
     st.range = 0x00ffffffu;
     // decode_tns_data :304-337
     {
-        const int wt = nbits < (c.n_ms_10 ? 480 : 360);
-        si[AD_ORD0] = si[SI_ORD0];
-        si[AD_ORD1] = si[SI_ORD1];
-        for (int k = 0; k < 16; k++) si[AD_RCI + k] = 0;
-        for (int f = 0; f < si[SI_NUM_TNS]; f++) {
-            if (si[AD_ORD0 + f] > 0) {
-                if (lc3_ac_decode(r, st, LC3T_AC_TNS_ORDER_CUMFREQ[wt], LC3T_AC_TNS_ORDER_FREQ[wt], 8, sym)) return -2;
-                si[AD_ORD0 + f] = sym + 1;
-                for (int k = 0; k < sym + 1; k++) {
+        const int wt = nbits < (n_ms_10 ? 480 : 360);
+        for (int k = 0; k < 16; k++) LC3_UST(si[AD_RCI + k], 0);
+        for (int f = 0; f < 2; f++) {
+            int order = LC3_U(si[SI_ORD0 + f]);
+            if (f < num_tns && order > 0) {
+                if (lc3_ac_decode(r, st, LC3T_AC_TNS_ORDER_CUMFREQ[wt], LC3T_AC_TNS_ORDER_FREQ[wt], 8, lane, sym)) return -2;
+                order = sym + 1;
+                for (int k = 0; k < order; k++) {
                     int s2;
-                    if (lc3_ac_decode(r, st, LC3T_AC_TNS_COEF_CUMFREQ[k], LC3T_AC_TNS_COEF_FREQ[k], 17, s2)) return -3;
-                    si[AD_RCI + f * 8 + k] = s2;
+                    if (lc3_ac_decode(r, st, LC3T_AC_TNS_COEF_CUMFREQ[k], LC3T_AC_TNS_COEF_FREQ[k], 17, lane, s2)) return -3;
+                    LC3_UST(si[AD_RCI + f * 8 + k], s2);
                 }
             }
+            LC3_UST(si[AD_ORD0 + f], order);
         }
     }
     // decode_spectral_data :211-302
     {
-        const int rate_flag = nbits > (160 + c.fs_ind * 160) ? 512 : 0, lsb_mode = si[SI_LSB_MODE];
-        const int ntup = si[SI_LASTNZ] / 2;
+        const int rate_flag = nbits > (160 + fs_ind * 160) ? 512 : 0;
+        const int ntup = lastnz / 2;
         int cctx = 0;
         for (int tup = 0; tup < ntup; tup++) {
             int t = cctx + rate_flag + ((tup * 2) > (ne / 2) ? 256 : 0), lev = 0, bit;
@@ -275,7 +293,7 @@ __device__ __forceinline__ int lc3_dec_arith(lc3_reader &r, const lc3_cfg &c, in
             sym = 0;
             while (lev < 14) {
                 const int pki = LC3T_AC_SPEC_LOOKUP[t + (lev < 3 ? lev : 3) * 1024];
-                if (lc3_ac_decode(r, st, LC3T_AC_SPEC_CUMFREQ[pki], LC3T_AC_SPEC_FREQ[pki], 17, sym)) return -4;
+                if (lc3_ac_decode(r, st, LC3T_AC_SPEC_CUMFREQ[pki], LC3T_AC_SPEC_FREQ[pki], 17, lane, sym)) return -4;
                 if (sym < 16) break;
                 if (!lsb_mode || lev > 0) {
                     if (lc3_rd_bool(r, bit)) return -5;
@@ -285,7 +303,7 @@ __device__ __forceinline__ int lc3_dec_arith(lc3_reader &r, const lc3_cfg &c, in
                 }
                 lev += 1;
             }
-            if (lsb_mode) save_lev[tup] = lev;  // written by TUPLE index, read back by LINE index (:184-195)
+            if (lsb_mode) LC3_UST(save_lev[tup], lev);  // written by TUPLE index, read back by LINE index (:184-195)
             const int a = sym & 3, b = sym >> 2;
             xk += (int32_t)((uint32_t)a << lev);
             xk1 += (int32_t)((uint32_t)b << lev);
@@ -297,53 +315,33 @@ __device__ __forceinline__ int lc3_dec_arith(lc3_reader &r, const lc3_cfg &c, in
                 if (lc3_rd_bool(r, bit)) return -5;
                 if (bit) xk1 = -xk1;
             }
-            x[2 * tup] = xk;
-            x[2 * tup + 1] = xk1;
+            LC3_UST(x[2 * tup], xk);
+            LC3_UST(x[2 * tup + 1], xk1);
             lev = lev < 3 ? lev : 3;
             t = lev <= 1 ? 1 + (a + b) * (lev + 1) : 12 + lev;
             cctx = (cctx & 15) * 16 + t;
         }
     }
-    for (int k = si[SI_LASTNZ]; k < LC3_MAX_NE; k++) x[k] = 0;  // :131-133
-    // decode_residual_bits :160-208, calc_num_residual_bits :385-405
-    int n_res = 0;
+    // x[lastnz ..] stays 0 (:131-133).  calc_num_residual_bits :385-405
     {
         const int nbits_side = r.tail - 8;
         const int nbits_ari = (r.head + 1 - 3) * 8 + 25 - lc3_ilog2(st.range);
         if (nbits < nbits_side + nbits_ari) return -6;
-        int nres = nbits - nbits_side - nbits_ari, bit, cont;
-        if (!si[SI_LSB_MODE]) {
-            for (int k = 0; k < ne; k++) {
-                if (x[k] != 0) {
-                    if (n_res == nres) break;
-                    if (lc3_rd_bool(r, bit)) return -7;
-                    if (n_res >= 480) return -8;
-                    res_bits[n_res++] = (uint8_t)bit;
-                }
-            }
-        } else {
-            for (int k = 0; k < si[SI_LASTNZ]; k += 2) {
-                if (save_lev[k] > 0) {
-                    if (lc3_read_res_bit(x, r, k, nres, cont)) return -7;
+        int nres = nbits - nbits_side - nbits_ari, cont;
+        LC3_UST(si[AD_TAIL0], r.tail);
+        LC3_UST(si[AD_NRES_MAX], nres);
+        LC3_UST(si[AD_HEAD], r.head);
+        if (lsb_mode) {  // decode_residual_bits :184-206, lsb mode refines the integers in place (serial)
+            for (int k = 0; k < lastnz; k += 2) {
+                if (LC3_U(save_lev[k]) > 0) {
+                    if (lc3_read_res_bit(x, r, k, nres, cont, lane)) return -7;
                     if (!cont) break;
-                    if (lc3_read_res_bit(x, r, k + 1, nres, cont)) return -7;
+                    if (lc3_read_res_bit(x, r, k + 1, nres, cont, lane)) return -7;
                     if (!cont) break;
                 }
             }
         }
     }
-    si[AD_NRES] = n_res;
-    // noise filling seed :140-145 (wrapping sum)
-    {
-        uint32_t seed = 0;
-        for (int k = 0; k < ne; k++) {
-            int32_t v = x[k];
-            uint32_t a = (uint32_t)(v < 0 ? -v : v);
-            seed += a * (uint32_t)k;
-        }
-        si[AD_SEED] = (int)(seed & 0xFFFFu);
-    }
-    si[AD_ZERO] = si[SI_LASTNZ] == 2 && x[0] == 0 && x[1] == 0 && si[SI_GG] == 0;
     return 0;
 }
 
@@ -570,29 +568,76 @@ __device__ __noinline__ void lc3_dec_ltpf(const lc3_cfg &c, lc3_dec_lds &L, int 
 // D0/D2/D3: read_frame (decoder/lc3_decoder.rs:165-177).  The range decoder is a serial state machine: lane 0.
 // Returns 1 when the frame parsed (side info in L.ism, integer spectrum in xi), 0 -> conceal.
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_dec_read_frame(const lc3_cfg &c, lc3_dec_lds &L, int lane, const uint8_t *in, int nbytes,
-                                               int force_plc) {
+__device__ __noinline__ int lc3_dec_read_frame(const lc3_cfg &c, lc3_dec_lds &L, int lane, const uint8_t *in,
+                                               int nbytes_in, int force_plc_in) {
+    // arguments of a non-inlined device function arrive in vector registers: re-establish wave-uniformity so that
+    // the serial parser below is scalarised
+    const int nbytes = LC3_U(nbytes_in), force_plc = LC3_U(force_plc_in);
+    const int u_ne = LC3_U(c.ne), u_fs_ind = LC3_U(c.fs_ind), u_n_ms_10 = LC3_U(c.n_ms_10);
     int *si = L.ism;
     int32_t *save_lev = (int32_t *)L.fa;  // 400 ints, free until the IMDCT
     int32_t *xi = (int32_t *)L.fb;        // 400 ints
+    const int ne = c.ne;
     for (int i = lane; i < nbytes; i += LC3_WAVE) L.in[i] = in[i];
     for (int i = lane; i < LC3_MAX_NE; i += LC3_WAVE) {
         xi[i] = 0;
         save_lev[i] = 0;
     }
     LC3_SYNC();
-    if (lane == 0) {
+    if (LC3_UNIFORM_LEADER(lane)) {
+        // uniform-scalar region: on the GPU every lane runs the same state machine with identical values
         lc3_reader r;
         r.buf = L.in;
         r.len = nbytes;
         r.head = 0;
         r.tail = 0;
-        int rc = force_plc ? -100 : lc3_dec_side_info(r, c.fs_ind, c.ne, si);
-        if (rc == 0) rc = lc3_dec_arith(r, c, si, xi, save_lev, L.res_bits);
-        si[AD_OK] = rc == 0;
+        int rc = force_plc ? -100 : lc3_dec_side_info(r, u_fs_ind, u_ne, si, lane);
+        if (rc == 0) rc = lc3_dec_arith(r, u_ne, u_fs_ind, u_n_ms_10, si, xi, save_lev, lane);
+        LC3_UST(si[AD_OK], rc == 0);
     }
     LC3_SYNC();
-    return si[AD_OK];
+    if (!si[AD_OK]) return 0;
+    // Lane-parallel epilogue (integer work, order-free): number of non-zero lines, the residual-bit count and its
+    // bounds check, the noise-filling seed  sum |x_k| * k  (:140-145, wrapping) and the zero-frame flag.
+    uint32_t *part = (uint32_t *)L.sm;  // [0,64) nnz per lane, [64,128) seed partial sums
+    {
+        uint32_t nnz = 0, seed = 0;
+        for (int k = lane; k < ne; k += LC3_WAVE) {
+            const int32_t v = xi[k];
+            nnz += v != 0;
+            seed += (uint32_t)(v < 0 ? -v : v) * (uint32_t)k;
+        }
+        part[lane] = nnz;
+        part[64 + lane] = seed;
+    }
+    LC3_SYNC();
+    uint32_t nnz = 0, seed = 0;
+    for (int i = 0; i < LC3_WAVE; i++) {
+        nnz += part[i];
+        seed += part[64 + i];
+    }
+    const int lsb_mode = si[SI_LSB_MODE], tail0 = si[AD_TAIL0], nres_max = si[AD_NRES_MAX];
+    int n_res = 0, ok = 1;
+    if (!lsb_mode) {
+        // decode_residual_bits :168-183: one tail bit per non-zero line, at most nres_max.  Every read_tail_bool
+        // bound check is monotone in the bit position, so checking the last position covers all of them.
+        n_res = (int)nnz < nres_max ? (int)nnz : nres_max;
+        if (n_res > 480) ok = 0;  // ResidualBoolDataOverflow (Vec<bool, 480>)
+        if (n_res > 0) {
+            const int last_byte = (tail0 + n_res - 1) / 8;
+            if (nbytes - si[AD_HEAD] - last_byte + 2 < 0) ok = 0;
+            if (nbytes - last_byte - 1 < 0) ok = 0;
+        }
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        si[AD_NRES] = n_res;
+        si[AD_SEED] = (int)(seed & 0xFFFFu);
+        si[AD_ZERO] = si[SI_LASTNZ] == 2 && xi[0] == 0 && xi[1] == 0 && si[SI_GG] == 0;
+        si[AD_OK] = ok;
+    }
+    LC3_SYNC();
+    return ok;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -604,37 +649,76 @@ __device__ __noinline__ void lc3_dec_spectrum(const lc3_cfg &c, lc3_dec_lds &L, 
     const int32_t *xi = (const int32_t *)L.fb;
     for (int k = lane; k < ne; k += LC3_WAVE) L.spec[k] = (float)xi[k];
     LC3_SYNC();
-    if (lane == 0) {
-        // residual_spectrum::decode (decoder/residual_spectrum.rs:13-39)
-        if (!si[SI_LSB_MODE]) {
-            const int nres = si[AD_NRES];
-            int n = 0;
-            for (int k = 0; k < ne; k++) {
-                float v = L.spec[k];
-                if (v != 0.0f) {
-                    if (n >= nres) break;
-                    if (L.res_bits[n]) v += v > 0.0f ? 0.3125f : 0.1875f;
-                    else v -= v > 0.0f ? 0.1875f : 0.3125f;
-                    L.spec[k] = v;
-                    n++;
+    // residual_spectrum::decode (decoder/residual_spectrum.rs:13-39): the j-th non-zero line takes residual bit j
+    // (tail bit AD_TAIL0 + j, read_tail_bool: bit (pos % 8) of byte len - 1 - pos / 8), for j < AD_NRES.
+    // noise_filling::apply_noise_filling (decoder/noise_filling.rs:18-56): the j-th line whose +-width neighbourhood
+    // is all zero takes state j + 1 of the LCG s <- (13849 + 31821 s) & 0xFFFF.  Both ranks are prefix counts, and
+    // the LCG is affine mod 2^16, so each lane owns 7 consecutive lines and jumps straight to its first state.
+    {
+        uint32_t *part = (uint32_t *)L.sm;  // [0,64) non-zero counts, [64,128) fill counts
+        const int k0 = 7 * lane;
+        const int n_res = si[SI_LSB_MODE] ? 0 : si[AD_NRES];
+        const int do_fill = !si[AD_ZERO];
+        const int bw_stop = c.n_ms_10 ? LC3C_BWSTOP10[si[SI_BW]] : LC3C_BWSTOP75[si[SI_BW]];
+        const int nf_start = c.n_ms_10 ? 24 : 18, nf_width = c.n_ms_10 ? 3 : 2;
+        const int lim = bw_stop < ne ? bw_stop : ne;
+        uint32_t nzmask = 0, fillmask = 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const int k = k0 + j;
+            if (k < ne) {
+                if (xi[k] != 0) nzmask |= 1u << j;
+                if (do_fill && k >= nf_start && k < lim) {
+                    const int from = k - nf_width, to = (bw_stop - 1) < (k + nf_width) ? (bw_stop - 1) : (k + nf_width);
+                    int all0 = 1;
+                    for (int q = from; q <= to; q++)
+                        if (xi[q] != 0) all0 = 0;
+                    if (all0) fillmask |= 1u << j;
                 }
             }
         }
-        // noise_filling::apply_noise_filling (decoder/noise_filling.rs:18-56)
-        if (!si[AD_ZERO]) {
-            const int bw_stop = c.n_ms_10 ? LC3C_BWSTOP10[si[SI_BW]] : LC3C_BWSTOP75[si[SI_BW]];
-            const int nf_start = c.n_ms_10 ? 24 : 18, nf_width = c.n_ms_10 ? 3 : 2;
-            const float level = (8.0f - (float)si[SI_NF]) / 16.0f;
-            const int lim = bw_stop < ne ? bw_stop : ne;
-            int nfill = si[AD_SEED];
-            for (int k = nf_start; k < lim; k++) {
-                const int from = k - nf_width, to = (bw_stop - 1) < (k + nf_width) ? (bw_stop - 1) : (k + nf_width);
-                int all0 = 1;
-                for (int j = from; j <= to; j++)
-                    if (xi[j] != 0) { all0 = 0; break; }
-                if (all0) {
-                    nfill = (13849 + nfill * 31821) & 0xFFFF;
-                    L.spec[k] = nfill < 0x8000 ? level : -level;
+        part[lane] = (uint32_t)__builtin_popcount(nzmask);
+        part[64 + lane] = (uint32_t)__builtin_popcount(fillmask);
+        LC3_SYNC();
+        int rank_nz = 0, rank_fill = 0;
+        for (int i = 0; i < lane; i++) {
+            rank_nz += (int)part[i];
+            rank_fill += (int)part[64 + i];
+        }
+        // LCG state after rank_fill steps: compose the affine map with itself by binary exponentiation
+        uint32_t lcg = (uint32_t)si[AD_SEED];
+        {
+            uint32_t ra = 1, rcst = 0, ba = 31821u, bc = 13849u;
+            for (int n = rank_fill; n > 0; n >>= 1) {
+                if (n & 1) {
+                    rcst = (ba * rcst + bc) & 0xFFFFu;
+                    ra = (ba * ra) & 0xFFFFu;
+                }
+                bc = (ba * bc + bc) & 0xFFFFu;
+                ba = (ba * ba) & 0xFFFFu;
+            }
+            lcg = (ra * lcg + rcst) & 0xFFFFu;
+        }
+        const float level = (8.0f - (float)si[SI_NF]) / 16.0f;
+        const int tail0 = si[AD_TAIL0], nbytes = nbits / 8;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const int k = k0 + j;
+            if (k < ne) {
+                if (nzmask & (1u << j)) {
+                    if (rank_nz < n_res) {
+                        const int pos = tail0 + rank_nz;
+                        const int bit = (L.in[nbytes - 1 - pos / 8] >> (pos % 8)) & 1;
+                        float v = L.spec[k];
+                        if (bit) v += v > 0.0f ? 0.3125f : 0.1875f;
+                        else v -= v > 0.0f ? 0.1875f : 0.3125f;
+                        L.spec[k] = v;
+                    }
+                    rank_nz++;
+                }
+                if (fillmask & (1u << j)) {
+                    lcg = (13849u + lcg * 31821u) & 0xFFFFu;
+                    L.spec[k] = lcg < 0x8000u ? level : -level;
                 }
             }
         }

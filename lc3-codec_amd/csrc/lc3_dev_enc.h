@@ -1276,14 +1276,16 @@ __device__ __noinline__ void lc3_enc_residual_noise(const lc3_cfg &c, lc3_enc_ld
 // ------------------------------------------------------------------------------------------
 // E20/E21: bitstream (encoder/bitstream_encoding.rs:77-429, encoder/buffer_writer.rs:11-67), lane 0
 // ------------------------------------------------------------------------------------------
+// All of this runs in "uniform-scalar" style (see lc3_dev_dec.h): the writer state is wave-uniform (SGPRs on the
+// GPU), lane 0 performs the byte updates in LDS.
 struct lc3_bitwriter {
     uint8_t *buf;
-    int nbytes, nbits, bp, bp_side, mask_side;
+    int nbytes, nbits, bp, bp_side, mask_side, lane;
     uint32_t low, range;
     int cache, carry, carry_count;
 };
 __device__ __forceinline__ void lc3_bw_bool_backward(lc3_bitwriter &w, int bit) {  // buffer_writer.rs:27-40
-    if (w.bp_side >= 0 && w.bp_side < w.nbytes) {
+    if (w.lane == 0 && w.bp_side >= 0 && w.bp_side < w.nbytes) {
         if (!bit) w.buf[w.bp_side] &= (uint8_t)~w.mask_side;
         else w.buf[w.bp_side] |= (uint8_t)w.mask_side;
     }
@@ -1299,13 +1301,13 @@ __device__ __forceinline__ void lc3_bw_uint_backward(lc3_bitwriter &w, uint32_t 
     }
 }
 __device__ __forceinline__ void lc3_bw_byte_forward(lc3_bitwriter &w, int val) {  // :55-58
-    if (w.bp >= 0 && w.bp < w.nbytes) w.buf[w.bp] = (uint8_t)val;
+    if (w.lane == 0 && w.bp >= 0 && w.bp < w.nbytes) w.buf[w.bp] = (uint8_t)val;
     w.bp += 1;
 }
 __device__ __forceinline__ void lc3_bw_uint_forward(lc3_bitwriter &w, unsigned val, int nbits) {  // :42-53
     unsigned mask = 0x80;
     for (int i = 0; i < nbits; i++) {
-        if (w.bp >= 0 && w.bp < w.nbytes) {
+        if (w.lane == 0 && w.bp >= 0 && w.bp < w.nbytes) {
             if (((val & 0xff) & mask) == 0) w.buf[w.bp] &= (uint8_t)~mask;
             else w.buf[w.bp] |= (uint8_t)mask;
         }
@@ -1337,20 +1339,41 @@ __device__ __forceinline__ void lc3_ac_encode(lc3_bitwriter &w, int cum_freq, in
     }
 }
 
-__device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L, int lane, int bw_ind, int nbits_bw,
-                                                  const lc3_sns_res &sns, const lc3_tns_res &tns,
-                                                  const lc3_ltpf_res &ltpf, const lc3_quant_res &spec, int n_res_bits,
-                                                  int noise_factor, int nbytes) {
+__device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L, int lane, int bw_ind_in, int nbits_bw_in,
+                                                  const lc3_sns_res &sns_in, const lc3_tns_res &tns_in,
+                                                  const lc3_ltpf_res &ltpf_in, const lc3_quant_res &spec_in,
+                                                  int n_res_bits_in, int noise_factor_in, int nbytes_in) {
+    // arguments of a non-inlined device function arrive in vector registers: re-establish wave-uniformity so that
+    // the serial coder below is scalarised
+    const int nbytes = LC3_U(nbytes_in);
     // init :138-144: the frame is zero-filled first (lane-parallel)
     for (int i = lane; i < nbytes; i += LC3_WAVE) L.out[i] = 0;
     LC3_SYNC();
-    if (lane == 0) {
-        const int ne = c.ne;
+    if (LC3_UNIFORM_LEADER(lane)) {
+        const int ne = LC3_U(c.ne);
+        const int bw_ind = LC3_U(bw_ind_in), nbits_bw = LC3_U(nbits_bw_in), n_res_bits = LC3_U(n_res_bits_in);
+        const int noise_factor = LC3_U(noise_factor_in);
+        lc3_sns_res sns;
+        sns.ind_lf = LC3_U(sns_in.ind_lf); sns.ind_hf = LC3_U(sns_in.ind_hf); sns.shape_j = LC3_U(sns_in.shape_j);
+        sns.gind = LC3_U(sns_in.gind); sns.ls_inda = LC3_U(sns_in.ls_inda); sns.ls_indb = LC3_U(sns_in.ls_indb);
+        sns.index_joint_j = (uint32_t)LC3_U(sns_in.index_joint_j);
+        lc3_tns_res tns;
+        tns.nbits_tns = 0; tns.lpc_weighting = LC3_U(tns_in.lpc_weighting);
+        tns.num_tns_filters = LC3_U(tns_in.num_tns_filters);
+        tns.rc_order[0] = LC3_U(tns_in.rc_order[0]); tns.rc_order[1] = LC3_U(tns_in.rc_order[1]);
+        lc3_ltpf_res ltpf;
+        ltpf.pitch_index = LC3_U(ltpf_in.pitch_index); ltpf.pitch_present = LC3_U(ltpf_in.pitch_present);
+        ltpf.ltpf_active = LC3_U(ltpf_in.ltpf_active); ltpf.nbits_ltpf = 0;
+        lc3_quant_res spec;
+        spec.gg_ind = LC3_U(spec_in.gg_ind); spec.lsb_mode = LC3_U(spec_in.lsb_mode);
+        spec.rate_flag = LC3_U(spec_in.rate_flag); spec.lastnz_trunc = LC3_U(spec_in.lastnz_trunc);
+        spec.nbits_spec = 0; spec.nbits_lsb = 0; spec.nbits_trunc = 0; spec.gg = 0.0f;
         const int *rc_i = L.ism + 16;
         uint8_t *lsbs = (uint8_t *)L.fa;  // LSB list for lsb_mode (<= 3840 entries used in practice << 1920*2 bytes)
         const int lsbs_cap = (int)(sizeof(L.fa) + sizeof(L.fb));
         int nlsbs = 0;
         lc3_bitwriter w;
+        w.lane = lane;
         w.buf = L.out;
         w.nbytes = nbytes;
         w.nbits = nbytes * 8;
@@ -1401,7 +1424,7 @@ __device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L,
                 lc3_ac_encode(w, LC3T_AC_TNS_ORDER_CUMFREQ[tns.lpc_weighting][tns.rc_order[f] - 1],
                               LC3T_AC_TNS_ORDER_FREQ[tns.lpc_weighting][tns.rc_order[f] - 1]);
                 for (int k = 0; k < tns.rc_order[f]; k++) {
-                    int ri = rc_i[k + 8 * f];
+                    int ri = LC3_U(rc_i[k + 8 * f]);
                     ri = ri < 0 ? 0 : (ri > 16 ? 16 : ri);
                     lc3_ac_encode(w, LC3T_AC_TNS_COEF_CUMFREQ[k][ri], LC3T_AC_TNS_COEF_FREQ[k][ri]);
                 }
@@ -1412,7 +1435,7 @@ __device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L,
             int cctx = 0;
             for (int k = 0; k < spec.lastnz_trunc; k += 2) {
                 int t = cctx + spec.rate_flag + (k > ne / 2 ? 256 : 0), lev = 0;
-                const int q0 = L.xq[k], q1 = L.xq[k + 1];
+                const int q0 = (int)(int16_t)LC3_U(L.xq[k]), q1 = (int)(int16_t)LC3_U(L.xq[k + 1]);
                 unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
                 unsigned a_lsb = a, b_lsb = b;
                 int lsb0 = 0, lsb1 = 0;
@@ -1436,16 +1459,16 @@ __device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L,
                 if (spec.lsb_mode && lev > 0) {
                     a_lsb >>= 1;
                     b_lsb >>= 1;
-                    if (nlsbs < lsbs_cap) lsbs[nlsbs] = (uint8_t)lsb0;
+                    if (nlsbs < lsbs_cap) LC3_UST(lsbs[nlsbs], (uint8_t)lsb0);
                     nlsbs++;
                     if (a_lsb == 0 && q0 != 0) {
-                        if (nlsbs < lsbs_cap) lsbs[nlsbs] = q0 > 0 ? 0 : 1;
+                        if (nlsbs < lsbs_cap) LC3_UST(lsbs[nlsbs], (uint8_t)(q0 > 0 ? 0 : 1));
                         nlsbs++;
                     }
-                    if (nlsbs < lsbs_cap) lsbs[nlsbs] = (uint8_t)lsb1;
+                    if (nlsbs < lsbs_cap) LC3_UST(lsbs[nlsbs], (uint8_t)lsb1);
                     nlsbs++;
                     if (b_lsb == 0 && q1 != 0) {
-                        if (nlsbs < lsbs_cap) lsbs[nlsbs] = q1 > 0 ? 0 : 1;
+                        if (nlsbs < lsbs_cap) LC3_UST(lsbs[nlsbs], (uint8_t)(q1 > 0 ? 0 : 1));
                         nlsbs++;
                     }
                 }
@@ -1465,10 +1488,10 @@ __device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L,
             int n_enc = w.nbits - (nbits_side + nbits_ari);
             if (n_enc < 0) n_enc = 0;
             if (!spec.lsb_mode) {
-                for (int k = 0; k < n_enc && k < n_res_bits; k++) lc3_bw_bool_backward(w, L.res_bits[k]);
+                for (int k = 0; k < n_enc && k < n_res_bits; k++) lc3_bw_bool_backward(w, LC3_U(L.res_bits[k]));
             } else {
                 if (n_enc > nlsbs) n_enc = nlsbs;
-                for (int k = 0; k < n_enc; k++) lc3_bw_bool_backward(w, lsbs[k] == 1);
+                for (int k = 0; k < n_enc; k++) lc3_bw_bool_backward(w, LC3_U(lsbs[k]) == 1);
             }
         }
         // ac_enc_finish :354-395

@@ -17,6 +17,23 @@
 #include "../../include/lc3gpu.h"
 
 #define LC3_SYNC() __syncthreads()
+// wave-uniform primitives of the "uniform-scalar" serial sections (see lc3_dev_dec.h): all 64 lanes execute the
+// section with identical values, LDS reads are broadcast into SGPRs, one lane performs the LDS writes.
+#define LC3_UNIFORM_LEADER(lane) (true)
+#define LC3_U(x) ((int)__builtin_amdgcn_readfirstlane((int)(x)))
+#define LC3_UST(lv, v) do { if (lane == 0) (lv) = (v); } while (0)
+// symbol search of the range decoder: lane i tests symbol i, the highest passing lane is the symbol
+// (reference: linear search from the top, decoder/arithmetic_codec.rs:81-84)
+__device__ __forceinline__ int lc3_sym_search(const int16_t *cum, const int16_t *freq, int nsym, uint32_t low,
+                                              uint32_t tmp, int lane, uint32_t &cval, uint32_t &fval) {
+    const int i = lane < nsym ? lane : nsym - 1;
+    const uint32_t cv = (uint32_t)(int)cum[i], fv = (uint32_t)(int)freq[i];
+    const unsigned long long m = __ballot(lane < nsym && low >= tmp * cv);
+    const int val = m ? 63 - __builtin_clzll(m) : 0;
+    cval = (uint32_t)__builtin_amdgcn_readlane((int)cv, val);
+    fval = (uint32_t)__builtin_amdgcn_readlane((int)fv, val);
+    return val;
+}
 #ifdef LC3_PROFILE
 // Diagnostic build (liblc3gpu_prof.so): lane 0 of every wave adds the shader-clock cycles between consecutive
 // stage stamps into a global table.  Stamp i accumulates the time since the previous stamp into slot i.

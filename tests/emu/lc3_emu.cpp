@@ -18,6 +18,20 @@
 
 static pthread_barrier_t g_bar;
 #define LC3_SYNC() pthread_barrier_wait(&g_bar)
+// "uniform-scalar" sections: on the GPU all lanes run them redundantly; the emulator runs them on lane 0 only
+#define LC3_UNIFORM_LEADER(lane) ((lane) == 0)
+#define LC3_U(x) ((int)(x))
+#define LC3_UST(lv, v) ((lv) = (v))
+static inline int lc3_sym_search(const int16_t *cum, const int16_t *freq, int nsym, uint32_t low, uint32_t tmp, int lane,
+                                 uint32_t &cval, uint32_t &fval) {
+    (void)lane;
+    int val = 0;
+    for (int i = 0; i < nsym; i++)  // highest symbol whose test holds (what ballot + clz computes on the GPU)
+        if (low >= tmp * (uint32_t)(int)cum[i]) val = i;
+    cval = (uint32_t)(int)cum[val];
+    fval = (uint32_t)(int)freq[val];
+    return val;
+}
 
 #include "../../lc3-codec_amd/csrc/lc3_dev_dec.h"
 #include "../../lc3-codec_amd/csrc/lc3_dev_enc.h"
