@@ -25,7 +25,7 @@ struct lc3_enc_state {
     int reset_offset_old;
     float nbits_offset_old;
     int nbits_est_old;
-    int pad;
+    int bitstream_fallbacks;  // diagnostic counter: frames written by the serial bitstream path (not in the reference)
 };
 #define LC3_ENC_STATE_WORDS ((int)(sizeof(lc3_enc_state) / 4))
 
@@ -33,14 +33,14 @@ struct lc3_enc_state {
 struct lc3_enc_lds {
     lc3_enc_state st;        // resident copy of the stream state (x12/x6/hist are worked on in place)
     float spec[LC3_MAX_NF];  // MDCT output -> SNS -> TNS spectrum (mdct_out / spec_lines)
-    lc3_cpx fa[LC3_MAX_NF / 2];  // FFT input; afterwards scratch
+    lc3_cpx fa[LC3_MAX_NF / 2];  // FFT input; afterwards scratch (must directly follow spec: symbol list spans both)
     lc3_cpx fb[LC3_MAX_NF / 2];  // FFT work buffer; afterwards scratch
     float eb[64];            // band energies
     int16_t t[2 * LC3_MAX_NF];   // MDCT time buffer (ModDiscreteCosTrans::freq)
     int16_t xq[LC3_MAX_NE];  // quantised spectrum
-    uint8_t out[LC3_MAX_NE]; // frame bytes staging
+    alignas(16) uint8_t out[LC3_MAX_NE]; // frame bytes staging (32-bit LDS atomics on it)
     uint8_t res_bits[LC3_MAX_NE];
-    float sm[160];           // small scratch (per-stage)
+    float sm[192];           // small scratch (per-stage)
     int ism[64];
     unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
 };
@@ -1042,48 +1042,118 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_
     LC3_SYNC();
     const int rate_flag = nbits > (160 + c.fs_ind * 160) ? 512 : 0;
     const int mode_flag = nbits >= (480 + c.fs_ind * 160);
-    if (lane == 0) {
-        int lastnz = ne;
-        while (lastnz > 2 && L.xq[lastnz - 1] == 0 && L.xq[lastnz - 2] == 0) lastnz -= 2;
-        uint32_t est = 0, trunc = 0;
-        int nbits_lsb = 0, lastnz_trunc = 2, cctx = 0;
-        for (int n = 0; n < lastnz; n += 2) {
-            int t = cctx + rate_flag, lev = 0;
-            const int q0 = L.xq[n], q1 = L.xq[n + 1];
-            unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
-            unsigned a_lsb = a, b_lsb = b;
-            if (n > ne / 2) t += 256;
-            while ((a > b ? a : b) >= 4) {
-                int pki = LC3T_AC_SPEC_LOOKUP[t + lev * 1024];
-                est += LC3T_AC_SPEC_BITS[pki][16];
-                if (lev == 0 && mode_flag) nbits_lsb += 2;
-                else est += 2 * 2048;
-                a >>= 1;
-                b >>= 1;
-                lev = lev + 1 < 3 ? lev + 1 : 3;
+    // compute_bit_consumption :265-348, lane-parallel.  Everything here is integer arithmetic, so any evaluation
+    // order is exact.  The context of tuple k only depends on the (a, b, level) class tt of tuples k-1 and k-2:
+    //   c_k = (c_{k-1} & 15) * 16 + tt_{k-1}  ==  16 * tt_{k-2} + tt_{k-1}          (tt <= 15)
+    // so all contexts are known after one pass over the quantised pairs.  Lane l owns tuples 4l .. 4l+3; the running
+    // bit estimate a tuple sees is (sum over lower lanes) + (running sum inside the lane).
+    {
+        uint8_t *ttab = (uint8_t *)L.fb + 256;         // tt per tuple (<= 200 bytes)
+        uint32_t *tinfo = (uint32_t *)((uint8_t *)L.fb + 1024);  // packed tuple info, reused by the bitstream writer
+        uint32_t *part = (uint32_t *)L.sm;             // [0,64) est sums, [64,128) lsb sums, [128,192) hi nz / cand
+        const int ntup_all = ne / 2, k0 = 4 * lane;
+        uint32_t loc[4];   // a | b << 8 | n_esc << 16 | nonzero << 24 for the lane's tuples
+        int hi_nz = -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
+            loc[j] = 0;
+            if (k < ntup_all) {
+                const int q0 = L.xq[2 * k], q1 = L.xq[2 * k + 1];
+                const unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
+                const unsigned m = a > b ? a : b;
+                const int n_esc = m >= 4 ? (32 - __builtin_clz(m)) - 2 : 0;
+                const unsigned af = a >> n_esc, bf = b >> n_esc;
+                const int lev = n_esc < 3 ? n_esc : 3;
+                ttab[k] = (uint8_t)(lev <= 1 ? 1 + (int)(af + bf) * (lev + 1) : 12 + lev);
+                const int nz = q0 != 0 || q1 != 0;
+                if (nz) hi_nz = k;
+                loc[j] = af | (bf << 8) | ((uint32_t)n_esc << 16) | ((uint32_t)nz << 24) | ((uint32_t)(a == 1) << 25) |
+                         ((uint32_t)(b == 1) << 26) | ((uint32_t)(a != 0) << 27) | ((uint32_t)(b != 0) << 28);
             }
-            int pki = LC3T_AC_SPEC_LOOKUP[t + lev * 1024];
-            est += LC3T_AC_SPEC_BITS[pki][a + 4 * b];
-            if (a_lsb > 0) est += 2048;
-            if (b_lsb > 0) est += 2048;
-            if (lev > 0 && mode_flag) {
-                a_lsb >>= 1;
-                b_lsb >>= 1;
-                if (a_lsb == 0 && q0 != 0) nbits_lsb += 1;
-                if (b_lsb == 0 && q1 != 0) nbits_lsb += 1;
-            }
-            if ((q0 != 0 || q1 != 0) && (int)lc3_ceilf((float)est / 2048.0f) <= nbits_spec) {
-                lastnz_trunc = n + 2;
-                trunc = est;
-            }
-            t = lev <= 1 ? 1 + (int)(a + b) * (lev + 1) : 12 + lev;
-            cctx = (cctx & 15) * 16 + t;
         }
-        L.ism[0] = lastnz;
-        L.ism[1] = lastnz_trunc;
-        L.ism[2] = (int)lc3_ceilf((float)est / 2048.0f) + nbits_lsb;
-        L.ism[3] = (int)lc3_ceilf((float)trunc / 2048.0f);
-        L.ism[4] = nbits_lsb;
+        part[128 + lane] = (uint32_t)(hi_nz + 1);
+        LC3_SYNC();
+        int hi_all = 0;  // 1 + index of the last non-zero tuple
+        for (int i = 0; i < LC3_WAVE; i++) {
+            const int v = (int)part[128 + i];
+            hi_all = v > hi_all ? v : hi_all;
+        }
+        const int lastnz = hi_all < 1 ? 2 : 2 * hi_all;  // `while lastnz > 2 && last pair == 0` (:270-273)
+        const int ntup = lastnz / 2;
+        uint32_t est4[4], run = 0, lsb_sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
+            est4[j] = 0;
+            if (k < ntup) {
+                const uint32_t v = loc[j];
+                const unsigned af = v & 0xff, bf = (v >> 8) & 0xff;
+                const int n_esc = (int)((v >> 16) & 0xff);
+                const int cctx = k == 0 ? 0 : (k == 1 ? (int)ttab[0] : 16 * (int)ttab[k - 2] + (int)ttab[k - 1]);
+                const int t = cctx + rate_flag + ((2 * k) > ne / 2 ? 256 : 0);
+                uint32_t est = 0;
+                for (int i = 0; i < n_esc; i++) {
+                    const int pki = LC3T_AC_SPEC_LOOKUP[t + (i < 3 ? i : 3) * 1024];
+                    est += LC3T_AC_SPEC_BITS[pki][16];
+                    if (!(i == 0 && mode_flag)) est += 2 * 2048;
+                }
+                const int levf = n_esc < 3 ? n_esc : 3;
+                const int pki = LC3T_AC_SPEC_LOOKUP[t + levf * 1024];
+                est += LC3T_AC_SPEC_BITS[pki][af + 4 * bf];
+                if (v & (1u << 27)) est += 2048;
+                if (v & (1u << 28)) est += 2048;
+                if (n_esc > 0 && mode_flag) lsb_sum += 2 + ((v >> 25) & 1) + ((v >> 26) & 1);
+                est4[j] = est;
+                run += est;
+                tinfo[k] = (uint32_t)t | ((uint32_t)n_esc << 12) | (af << 16) | (bf << 18);
+            }
+        }
+        part[lane] = run;
+        part[64 + lane] = lsb_sum;
+        LC3_SYNC();
+        uint32_t base = 0, est_total = 0, lsb_total = 0;
+        for (int i = 0; i < LC3_WAVE; i++) {
+            const uint32_t e = part[i];
+            if (i < lane) base += e;
+            est_total += e;
+            lsb_total += part[64 + i];
+        }
+        // lastnz_trunc / nbits_trunc: the last non-zero tuple whose running estimate still fits nbits_spec (:327-330)
+        int cand_k = -1;
+        uint32_t cand_est = 0, acc = base;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
+            if (k < ntup) {
+                acc += est4[j];
+                if ((loc[j] & (1u << 24)) && (int)lc3_ceilf((float)acc / 2048.0f) <= nbits_spec) {
+                    cand_k = k;
+                    cand_est = acc;
+                }
+            }
+        }
+        LC3_SYNC();
+        part[128 + lane] = (uint32_t)(cand_k + 1);
+        part[lane] = cand_est;
+        LC3_SYNC();
+        int best_k = -1;
+        uint32_t best_est = 0;
+        for (int i = 0; i < LC3_WAVE; i++) {
+            const int v = (int)part[128 + i] - 1;
+            if (v > best_k) {
+                best_k = v;
+                best_est = part[i];
+            }
+        }
+        LC3_SYNC();
+        if (lane == 0) {
+            L.ism[0] = lastnz;
+            L.ism[1] = best_k < 0 ? 2 : 2 * best_k + 2;
+            L.ism[2] = (int)lc3_ceilf((float)est_total / 2048.0f) + (int)lsb_total;
+            L.ism[3] = (int)lc3_ceilf((float)best_est / 2048.0f);
+            L.ism[4] = (int)lsb_total;
+        }
     }
     LC3_SYNC();
     lc3_bitcons bc;
@@ -1139,41 +1209,59 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_ld
         xm[lane] = m;
     }
     LC3_SYNC();
-    if (lane == 0) {
-        // global_gain_estimation :174-209 -- 8-step bisection, sequential f32 accumulation
+    // global_gain_estimation :174-209 -- 8-step bisection.  Per step the reference walks the group energies from the
+    // top: a group below the gain adds a constant only once a group at/above the gain has been seen ("is_zero"), the
+    // others add a linear term; tmp is a sequential f32 sum.  The terms are computed one lane per group (the first
+    // group at/above the gain is a max-reduction), the f32 accumulation stays sequential on lane 0.
+    {
+        float *term = e + 256;                  // 100 per-group contributions
+        int *hi_part = (int *)(e + 384);        // 64 per-lane maxima
         int fac = 256, gg_ind = 255;
         for (int it = 0; it < 8; it++) {
-            float tmp = 0.0f;
-            int is_zero = 1;
             fac >>= 1;
             gg_ind -= fac;
             const float g = (float)gg_ind + (float)gg_off;
-            for (int n = ne4 - 1; n >= 0; n--) {
+            int hi = -1;
+            for (int n = lane; n < ne4; n += LC3_WAVE)
+                if (!(e[n] * 28.0f / 20.0f < g)) hi = n;
+            hi_part[lane] = hi;
+            LC3_SYNC();
+            hi = -1;
+            for (int i = 0; i < LC3_WAVE; i++) hi = hi_part[i] > hi ? hi_part[i] : hi;
+            for (int n = lane; n < ne4; n += LC3_WAVE) {
                 const float ei = e[n];
-                if (ei * 28.0f / 20.0f < g) {
-                    if (!is_zero) tmp += 2.7f * 28.0f / 20.0f;
-                } else {
-                    if (g < (ei * 28.0f / 20.0f - 43.0f * 28.0f / 20.0f))
-                        tmp += 2.0f * ei * 28.0f / 20.0f - 2.0f * g - 36.0f * 28.0f / 20.0f;
-                    else tmp += ei * 28.0f / 20.0f - g + 7.0f * 28.0f / 20.0f;
-                    is_zero = 0;
-                }
+                float tv;
+                if (ei * 28.0f / 20.0f < g) tv = n < hi ? 2.7f * 28.0f / 20.0f : 0.0f;
+                else if (g < (ei * 28.0f / 20.0f - 43.0f * 28.0f / 20.0f))
+                    tv = 2.0f * ei * 28.0f / 20.0f - 2.0f * g - 36.0f * 28.0f / 20.0f;
+                else tv = ei * 28.0f / 20.0f - g + 7.0f * 28.0f / 20.0f;
+                term[n] = tv;
             }
-            if ((tmp > (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f) && !is_zero) gg_ind += fac;
+            LC3_SYNC();
+            if (lane == 0) {
+                float tmp = 0.0f;
+                for (int n = ne4 - 1; n >= 0; n--) tmp += term[n];
+                L.ism[11] = (tmp > (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f) && hi >= 0;
+            }
+            LC3_SYNC();
+            if (L.ism[11]) gg_ind += fac;
+            LC3_SYNC();
         }
-        // global_gain_limitation :212-228
-        float x_f_max = 0.0f;
-        for (int i = 0; i < LC3_WAVE; i++) x_f_max = lc3_maxf(x_f_max, xm[i]);
-        int gg_min = 0;
-        if (x_f_max > 0.0f) gg_min = lc3_f2i16(lc3_ceilf(28.0f * lc3_log10f(x_f_max / (32768.0f - 0.375f)))) - gg_off;
-        int reset_offset = 0;
-        if (gg_ind < gg_min || x_f_max == 0.0f) {
-            reset_offset = 1;
-            gg_ind = gg_min;
+        if (lane == 0) {
+            // global_gain_limitation :212-228
+            float x_f_max = 0.0f;
+            for (int i = 0; i < LC3_WAVE; i++) x_f_max = lc3_maxf(x_f_max, xm[i]);
+            int gg_min = 0;
+            if (x_f_max > 0.0f) gg_min = lc3_f2i16(lc3_ceilf(28.0f * lc3_log10f(x_f_max / (32768.0f - 0.375f)))) - gg_off;
+            int reset_offset = 0;
+            if (gg_ind < gg_min || x_f_max == 0.0f) {
+                reset_offset = 1;
+                gg_ind = gg_min;
+            }
+            L.ism[8] = gg_ind;
+            L.ism[9] = gg_min;
+            L.ism[10] = reset_offset;
         }
-        L.ism[8] = gg_ind;
-        L.ism[9] = gg_min;
-        L.ism[10] = reset_offset;
     }
     LC3_SYNC();
     int gg_ind = L.ism[8];
@@ -1224,48 +1312,68 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_ld
 // (encoder/noise_level_estimation.rs:21-55).  Returns n_res via L.ism[0], noise factor via L.ism[1].
 // ------------------------------------------------------------------------------------------
 __device__ __noinline__ void lc3_enc_residual_noise(const lc3_cfg &c, lc3_enc_lds &L, int lane,
-                                                       const lc3_quant_res &q, int bw_ind) {
+                                                    const lc3_quant_res &q, int bw_ind) {
+    // Both loops of the reference walk the spectrum in order and act on a SUBSET of the lines (non-zero lines for
+    // the residual bits, lines with an all-zero neighbourhood for the noise level); the position of a line inside
+    // its subset is a prefix count.  Lane l owns lines 7l .. 7l+6: it counts, the counts are prefix-summed, and
+    //  - residual bit j (j < nbits_residual_max) is written by the owner of the j-th non-zero line,
+    //  - the noise contributions |x|/gg are compacted in order so that lane 0 can add them up sequentially
+    //    (the f32 sum keeps the reference's order).
     const int ne = c.ne;
-    float *nz = (float *)L.fa;  // |x|/gg where relevant
-    uint8_t *rel = (uint8_t *)L.fb;
+    float *compact = (float *)L.fa;          // relevant |x| / gg values, in line order (<= 376)
+    uint32_t *part = (uint32_t *)L.sm;       // [0,64) non-zero counts, [64,128) relevant counts
     const int bw_stop = c.n_ms_10 ? LC3C_BWSTOP10[bw_ind] : LC3C_BWSTOP75[bw_ind];
     const int nf_start = c.n_ms_10 ? 24 : 18, nf_width = c.n_ms_10 ? 3 : 2;
     const int nf_stop = ne < bw_stop ? ne : bw_stop;
-    // relevance flags + per-line contributions in parallel
-    for (int k = nf_start + lane; k < nf_stop; k += LC3_WAVE) {
-        int from = k - nf_width, to = bw_stop < k + nf_width + 1 ? bw_stop : k + nf_width + 1, r = 1;
-        for (int j = from; j < to; j++)
-            if (L.xq[j] != 0) r = 0;
-        rel[k] = (uint8_t)r;
-        nz[k] = lc3_absf(L.spec[k]) / q.gg;
+    int mx = q.nbits_spec - q.nbits_trunc + 4;  // nbits_residual_max (encoder/residual_spectrum.rs:42-43)
+    if (mx < 0) mx = 0;
+    const int k0 = 7 * lane;
+    uint32_t nzmask = 0, relmask = 0;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        const int k = k0 + j;
+        if (k < ne) {
+            if (L.xq[k] != 0) nzmask |= 1u << j;
+            if (k >= nf_start && k < nf_stop) {  // encoder/noise_level_estimation.rs:35-42
+                const int from = k - nf_width, to = bw_stop < k + nf_width + 1 ? bw_stop : k + nf_width + 1;
+                int r = 1;
+                for (int i = from; i < to; i++)
+                    if (L.xq[i] != 0) r = 0;
+                if (r) relmask |= 1u << j;
+            }
+        }
+    }
+    part[lane] = (uint32_t)__builtin_popcount(nzmask);
+    part[64 + lane] = (uint32_t)__builtin_popcount(relmask);
+    LC3_SYNC();
+    int rank_nz = 0, rank_rel = 0, tot_nz = 0, tot_rel = 0;
+    for (int i = 0; i < LC3_WAVE; i++) {
+        const int a = (int)part[i], b = (int)part[64 + i];
+        if (i < lane) { rank_nz += a; rank_rel += b; }
+        tot_nz += a;
+        tot_rel += b;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        const int k = k0 + j;
+        if (k < ne) {
+            if (nzmask & (1u << j)) {
+                if (rank_nz < mx) L.res_bits[rank_nz] = (uint8_t)(L.spec[k] >= (float)L.xq[k] * q.gg);  // :50-55
+                rank_nz++;
+            }
+            if (relmask & (1u << j)) compact[rank_rel++] = lc3_absf(L.spec[k]) / q.gg;
+        }
     }
     LC3_SYNC();
     if (lane == 0) {
-        // residual bits
-        int mx = q.nbits_spec - q.nbits_trunc + 4, n = 0;
-        if (mx < 0) mx = 0;
-        if (mx > 0) {
-            for (int k = 0; k < ne; k++) {
-                if (n >= mx) break;
-                int v = L.xq[k];
-                if (v != 0) L.res_bits[n++] = (uint8_t)(L.spec[k] >= (float)v * q.gg);
-            }
-        }
-        L.ism[0] = n;
-    } else if (lane == 1) {
-        // noise factor: sequential sum over relevant lines
+        L.ism[0] = tot_nz < mx ? tot_nz : mx;
         float sum = 0.0f;
-        int count = 0;
-        for (int k = nf_start; k < nf_stop; k++)
-            if (rel[k]) {
-                sum += nz[k];
-                count++;
-            }
-        float level = count > 0 ? sum / (float)count : 0.0f;
-        float diff = 8.0f - 16.0f * level;
+        for (int i = 0; i < tot_rel; i++) sum += compact[i];
+        const float level = tot_rel > 0 ? sum / (float)tot_rel : 0.0f;
+        const float diff = 8.0f - 16.0f * level;
         int nfac = 0;
         if (diff >= 0.0f) {
-            int v = lc3_f2i32(diff + 0.5f);
+            const int v = lc3_f2i32(diff + 0.5f);
             nfac = v < 7 ? v : 7;
         }
         L.ism[1] = nfac;
@@ -1274,7 +1382,7 @@ __device__ __noinline__ void lc3_enc_residual_noise(const lc3_cfg &c, lc3_enc_ld
 }
 
 // ------------------------------------------------------------------------------------------
-// E20/E21: bitstream (encoder/bitstream_encoding.rs:77-429, encoder/buffer_writer.rs:11-67), lane 0
+// E20/E21: bitstream (encoder/bitstream_encoding.rs:77-429, encoder/buffer_writer.rs:11-67)
 // ------------------------------------------------------------------------------------------
 // All of this runs in "uniform-scalar" style (see lc3_dev_dec.h): the writer state is wave-uniform (SGPRs on the
 // GPU), lane 0 performs the byte updates in LDS.
@@ -1339,7 +1447,7 @@ __device__ __forceinline__ void lc3_ac_encode(lc3_bitwriter &w, int cum_freq, in
     }
 }
 
-__device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L, int lane, int bw_ind_in, int nbits_bw_in,
+__device__ __noinline__ void lc3_enc_bitstream_serial(const lc3_cfg &c, lc3_enc_lds &L, int lane, int bw_ind_in, int nbits_bw_in,
                                                   const lc3_sns_res &sns_in, const lc3_tns_res &tns_in,
                                                   const lc3_ltpf_res &ltpf_in, const lc3_quant_res &spec_in,
                                                   int n_res_bits_in, int noise_factor_in, int nbytes_in) {
@@ -1531,6 +1639,293 @@ __device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L,
         }
     }
     LC3_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// Fast path of the bitstream writer.  The reference interleaves, tuple by tuple, range-coder symbols (bytes
+// growing forward from byte 0) with sign / LSB bits (growing backward from the tail).  The two regions are
+// disjoint in a frame that respects its bit budget, so their writes commute:
+//   1. side information (serial, ~75 bits);
+//   2. one lane per group of 4 tuples: the (cum, freq) pair of every symbol from the context tables -> a symbol
+//      list in LDS (the table walks, which dominate the serial cost, now overlap across 64 lanes), every backward
+//      bit OR-ed straight into its final position (prefix sums give each tuple its offsets), LSB list for lsb_mode;
+//   3. the range coder proper walks the symbol list serially (pure 24-bit integer state, wave-uniform);
+//   4. residual bits + termination as in the reference.
+// If the forward and backward regions would meet (only possible when the bit estimate was violated) or the symbol
+// list does not fit, the frame is redone by lc3_enc_bitstream_serial, so the result is always the reference's.
+// ------------------------------------------------------------------------------------------
+__device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L, int lane, int bw_ind_in, int nbits_bw_in,
+                                               const lc3_sns_res &sns_in, const lc3_tns_res &tns_in,
+                                               const lc3_ltpf_res &ltpf_in, const lc3_quant_res &spec_in,
+                                               int n_res_bits_in, int noise_factor_in, int nbytes_in) {
+    const int nbytes = LC3_U(nbytes_in), ne = LC3_U(c.ne);
+    const int lsb_mode = LC3_U(spec_in.lsb_mode), lastnz_trunc = LC3_U(spec_in.lastnz_trunc);
+    const int n_res_bits = LC3_U(n_res_bits_in);
+    uint32_t *symlist = (uint32_t *)L.spec;                        // cum | freq << 16; spec and fa are contiguous and
+                                                                   // dead by now: capacity 960 symbols
+    uint8_t *lsbs = (uint8_t *)L.fb;                               // lsb_mode LSB/sign list, capacity 1024
+    const uint32_t *tinfo = (const uint32_t *)((uint8_t *)L.fb + 1024);  // from lc3_quantize_spectrum
+    uint32_t *part = (uint32_t *)L.sm;                             // 3 x 64 per-lane counts
+    int *bs = L.ism + 40;                                          // cross-phase scalars
+    const int SYM_CAP = 960, LSB_CAP = 1024;
+    for (int i = lane; i < nbytes; i += LC3_WAVE) L.out[i] = 0;    // init :138-144
+    LC3_SYNC();
+    // ---- phase 1: side information (uniform serial), App. E layout
+    if (LC3_UNIFORM_LEADER(lane)) {
+        lc3_bitwriter w;
+        w.lane = lane;
+        w.buf = L.out;
+        w.nbytes = nbytes;
+        w.nbits = nbytes * 8;
+        w.bp = 0;
+        w.bp_side = nbytes - 1;
+        w.mask_side = 1;
+        const int nbits_bw = LC3_U(nbits_bw_in);
+        if (nbits_bw > 0) lc3_bw_uint_backward(w, (uint32_t)LC3_U(bw_ind_in), nbits_bw);
+        {
+            int nb = 0;
+            while ((1 << nb) < ne / 2) nb++;
+            lc3_bw_uint_backward(w, (uint32_t)((lastnz_trunc >> 1) - 1), nb);
+        }
+        lc3_bw_bool_backward(w, lsb_mode);
+        lc3_bw_uint_backward(w, (uint32_t)LC3_U(spec_in.gg_ind), 8);
+        const int num_tns = LC3_U(tns_in.num_tns_filters);
+        for (int f = 0; f < num_tns; f++) lc3_bw_bool_backward(w, LC3_U(tns_in.rc_order[f]) != 0);
+        const int pitch_present = LC3_U(ltpf_in.pitch_present);
+        lc3_bw_bool_backward(w, pitch_present);
+        lc3_bw_uint_backward(w, (uint32_t)LC3_U(sns_in.ind_lf), 5);
+        lc3_bw_uint_backward(w, (uint32_t)LC3_U(sns_in.ind_hf), 5);
+        {
+            const int shape_j = LC3_U(sns_in.shape_j);
+            const uint32_t joint = (uint32_t)LC3_U(sns_in.index_joint_j);
+            const int submode_msb = (shape_j >> 1) != 0;
+            lc3_bw_bool_backward(w, submode_msb);
+            lc3_bw_uint_backward(w, (uint32_t)(LC3_U(sns_in.gind) >> LC3T_SNS_GAIN_LSB_BITS[shape_j]),
+                                 LC3T_SNS_GAIN_MSB_BITS[shape_j]);
+            lc3_bw_bool_backward(w, LC3_U(sns_in.ls_inda) != 0);
+            if (!submode_msb) {
+                lc3_bw_uint_backward(w, joint, 13);
+                lc3_bw_uint_backward(w, joint >> 13, 12);
+            } else {
+                lc3_bw_uint_backward(w, joint, 12);
+                lc3_bw_uint_backward(w, joint >> 12, 12);
+            }
+        }
+        if (pitch_present) {
+            lc3_bw_bool_backward(w, LC3_U(ltpf_in.ltpf_active));
+            lc3_bw_uint_backward(w, (uint32_t)LC3_U(ltpf_in.pitch_index), 9);
+        }
+        lc3_bw_uint_backward(w, (uint32_t)LC3_U(noise_factor_in), 3);
+        // number of backward bits so far == nbits_side_written()
+        LC3_UST(bs[0], w.nbits - (8 * w.bp_side + 8 - lc3_ilog2((uint32_t)w.mask_side)));
+    }
+    LC3_SYNC();
+    const int side_bits = bs[0];
+    // ---- phase 2: per-tuple symbols and backward bits, lane l owns tuples 4l .. 4l+3
+    const int ntup = lastnz_trunc / 2, k0 = 4 * lane;
+    {
+        uint32_t ns = 0, nb = 0, nl = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
+            if (k < ntup) {
+                const uint32_t ti = tinfo[k];
+                const int n_esc = (int)((ti >> 12) & 15);
+                const int q0 = L.xq[2 * k], q1 = L.xq[2 * k + 1];
+                unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
+                ns += (uint32_t)n_esc + 1;
+                const int lsb_tuple = lsb_mode && n_esc > 0;
+                nb += 2u * (uint32_t)(n_esc - (lsb_tuple ? 1 : 0));
+                if (lsb_tuple) {
+                    nl += 2u + (uint32_t)((a >> 1) == 0 && q0 != 0) + (uint32_t)((b >> 1) == 0 && q1 != 0);
+                    a >>= 1;
+                    b >>= 1;
+                }
+                nb += (uint32_t)(a > 0) + (uint32_t)(b > 0);
+            }
+        }
+        part[lane] = ns;
+        part[64 + lane] = nb;
+        part[128 + lane] = nl;
+    }
+    LC3_SYNC();
+    uint32_t soff = 0, boff = 0, loff = 0, stot = 0, btot = 0, ltot = 0;
+    for (int i = 0; i < LC3_WAVE; i++) {
+        const uint32_t a = part[i], b = part[64 + i], l = part[128 + i];
+        if (i < lane) { soff += a; boff += b; loff += l; }
+        stot += a; btot += b; ltot += l;
+    }
+#ifdef LC3_FORCE_SERIAL_BITSTREAM
+    const int fits = 0;  // test hook: always take the reference-order serial writer
+#else
+    const int fits = (int)stot <= SYM_CAP && (int)ltot <= LSB_CAP && side_bits + (int)btot <= nbytes * 8;
+#endif
+    LC3_SYNC();
+    if (fits) {
+        uint32_t gpos = (uint32_t)side_bits + boff;  // next backward bit position (0 = bit 0 of the last byte)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
+            if (k < ntup) {
+                const uint32_t ti = tinfo[k];
+                const int t = (int)(ti & 0xfff), n_esc = (int)((ti >> 12) & 15);
+                const unsigned af = (ti >> 16) & 3, bf = (ti >> 18) & 3;
+                const int q0 = L.xq[2 * k], q1 = L.xq[2 * k + 1];
+                unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
+                unsigned a_lsb = a, b_lsb = b;
+                for (int i = 0; i < n_esc; i++) {
+                    const int pki = LC3T_AC_SPEC_LOOKUP[t + (i < 3 ? i : 3) * 1024];
+                    symlist[soff++] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[pki][16] |
+                                      ((uint32_t)(int)LC3T_AC_SPEC_FREQ[pki][16] << 16);
+                    if (!(lsb_mode && i == 0)) {
+                        unsigned bits2[2] = {(a >> i) & 1u, (b >> i) & 1u};
+                        for (int q = 0; q < 2; q++) {
+                            if (bits2[q]) {
+                                const uint32_t byte = (uint32_t)nbytes - 1u - (gpos >> 3);
+                                LC3_LDS_OR32((uint32_t *)L.out + (byte >> 2), 1u << (8u * (byte & 3u) + (gpos & 7u)));
+                            }
+                            gpos++;
+                        }
+                    }
+                }
+                {
+                    const int pki = LC3T_AC_SPEC_LOOKUP[t + (n_esc < 3 ? n_esc : 3) * 1024];
+                    const int sym = (int)(af + 4 * bf);
+                    symlist[soff++] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[pki][sym] |
+                                      ((uint32_t)(int)LC3T_AC_SPEC_FREQ[pki][sym] << 16);
+                }
+                if (lsb_mode && n_esc > 0) {  // :298-312
+                    a_lsb >>= 1;
+                    b_lsb >>= 1;
+                    lsbs[loff++] = (uint8_t)(a & 1u);
+                    if (a_lsb == 0 && q0 != 0) lsbs[loff++] = (uint8_t)(q0 > 0 ? 0 : 1);
+                    lsbs[loff++] = (uint8_t)(b & 1u);
+                    if (b_lsb == 0 && q1 != 0) lsbs[loff++] = (uint8_t)(q1 > 0 ? 0 : 1);
+                }
+                if (a_lsb > 0) {  // sign bits :313-318
+                    if (q0 <= 0) {
+                        const uint32_t byte = (uint32_t)nbytes - 1u - (gpos >> 3);
+                        LC3_LDS_OR32((uint32_t *)L.out + (byte >> 2), 1u << (8u * (byte & 3u) + (gpos & 7u)));
+                    }
+                    gpos++;
+                }
+                if (b_lsb > 0) {
+                    if (q1 <= 0) {
+                        const uint32_t byte = (uint32_t)nbytes - 1u - (gpos >> 3);
+                        LC3_LDS_OR32((uint32_t *)L.out + (byte >> 2), 1u << (8u * (byte & 3u) + (gpos & 7u)));
+                    }
+                    gpos++;
+                }
+            }
+        }
+    }
+    LC3_SYNC();
+    // ---- phase 3/4: range coder over the symbol list, residual bits, termination (uniform serial)
+    if (LC3_UNIFORM_LEADER(lane)) {
+        int collided = !fits;
+        if (fits) {
+            const int *rc_i = L.ism + 16;
+            lc3_bitwriter w;
+            w.lane = lane;
+            w.buf = L.out;
+            w.nbytes = nbytes;
+            w.nbits = nbytes * 8;
+            w.bp = 0;
+            {
+                const int gtot = side_bits + (int)btot;  // all backward bits written so far
+                w.bp_side = nbytes - 1 - (gtot >> 3);
+                w.mask_side = 1 << (gtot & 7);
+            }
+            w.low = 0;
+            w.range = 0x00ffffffu;
+            w.cache = -1;
+            w.carry = 0;
+            w.carry_count = 0;
+            // tns_data :224-244
+            const int num_tns = LC3_U(tns_in.num_tns_filters), wt = LC3_U(tns_in.lpc_weighting);
+            for (int f = 0; f < num_tns; f++) {
+                const int order = LC3_U(tns_in.rc_order[f]);
+                if (order > 0) {
+                    lc3_ac_encode(w, LC3T_AC_TNS_ORDER_CUMFREQ[wt][order - 1], LC3T_AC_TNS_ORDER_FREQ[wt][order - 1]);
+                    for (int k = 0; k < order; k++) {
+                        int ri = LC3_U(rc_i[k + 8 * f]);
+                        ri = ri < 0 ? 0 : (ri > 16 ? 16 : ri);
+                        lc3_ac_encode(w, LC3T_AC_TNS_COEF_CUMFREQ[k][ri], LC3T_AC_TNS_COEF_FREQ[k][ri]);
+                    }
+                }
+            }
+            // spectral_data :246-326, symbols only
+            for (int i = 0; i < (int)stot; i++) {
+                const uint32_t sv = (uint32_t)LC3_U(symlist[i]);
+                lc3_ac_encode(w, (int)(sv & 0xffffu), (int)(sv >> 16));
+            }
+            // residual_data_and_finalization :328-352
+            {
+                int nbits_side = w.nbits - (8 * w.bp_side + 8 - lc3_ilog2((uint32_t)w.mask_side));
+                int nbits_ari = w.bp * 8 + 25 - lc3_ilog2(w.range);
+                if (w.carry >= 0) nbits_ari += 8;
+                if (w.carry_count > 0) nbits_ari += w.carry_count * 8;
+                int n_enc = w.nbits - (nbits_side + nbits_ari);
+                if (n_enc < 0) n_enc = 0;
+                if (!lsb_mode) {
+                    for (int k = 0; k < n_enc && k < n_res_bits; k++) lc3_bw_bool_backward(w, LC3_U(L.res_bits[k]));
+                } else {
+                    if (n_enc > (int)ltot) n_enc = (int)ltot;
+                    for (int k = 0; k < n_enc; k++) lc3_bw_bool_backward(w, LC3_U(lsbs[k]) == 1);
+                }
+            }
+            // ac_enc_finish :354-395
+            int bits = 1;
+            while ((w.range >> (24 - bits)) == 0) bits++;
+            uint32_t mask = 0x00ffffffu >> bits;
+            uint32_t val = w.low + mask;
+            const uint32_t over1 = val >> 24;
+            const uint32_t high = w.low + w.range;
+            const uint32_t over2 = high >> 24;
+            val &= 0x00ffffffu & ~mask;
+            if (over1 == over2) {
+                if ((val + mask) >= high) {
+                    bits += 1;
+                    mask >>= 1;
+                    val = ((w.low + mask) & 0x00ffffffu) & ~mask;
+                }
+                if (val < w.low) w.carry = 1;
+            }
+            w.low = val;
+            while (bits > 0) {
+                lc3_ac_shift(w);
+                bits -= 8;
+            }
+            bits += 8;
+            // The forward region ends with `bits` bits in byte w.bp (+ carry bytes); it must stay clear of every
+            // backward bit, otherwise the reference's write ORDER matters and the serial path decides.
+            {
+                const int last_fwd_byte = w.bp + (w.carry_count > 0 ? w.carry_count : 0);
+                const int used_back = lc3_ilog2((uint32_t)w.mask_side);  // bits already taken in byte bp_side
+                if (last_fwd_byte > w.bp_side || (last_fwd_byte == w.bp_side && (8 - bits) < used_back)) collided = 1;
+            }
+            if (!collided) {
+                if (w.carry_count > 0) {
+                    lc3_bw_byte_forward(w, w.cache & 0xff);
+                    while (w.carry_count > 1) {
+                        lc3_bw_byte_forward(w, 0xff);
+                        w.carry_count -= 1;
+                    }
+                    lc3_bw_uint_forward(w, 0xffu >> (8 - bits), bits);
+                } else {
+                    lc3_bw_uint_forward(w, (unsigned)w.cache, bits);
+                }
+            }
+        }
+        LC3_UST(bs[1], collided);
+    }
+    LC3_SYNC();
+    if (bs[1]) {
+        if (lane == 0) L.st.bitstream_fallbacks += 1;
+        LC3_SYNC();
+        lc3_enc_bitstream_serial(c, L, lane, bw_ind_in, nbits_bw_in, sns_in, tns_in, ltpf_in, spec_in, n_res_bits_in,
+                                 noise_factor_in, nbytes_in);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -22,6 +22,7 @@
 #define LC3_UNIFORM_LEADER(lane) (true)
 #define LC3_U(x) ((int)__builtin_amdgcn_readfirstlane((int)(x)))
 #define LC3_UST(lv, v) do { if (lane == 0) (lv) = (v); } while (0)
+#define LC3_LDS_OR32(p, v) atomicOr((p), (v))
 // symbol search of the range decoder: lane i tests symbol i, the highest passing lane is the symbol
 // (reference: linear search from the top, decoder/arithmetic_codec.rs:81-84)
 __device__ __forceinline__ int lc3_sym_search(const int16_t *cum, const int16_t *freq, int nsym, uint32_t low,

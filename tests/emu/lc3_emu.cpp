@@ -22,6 +22,7 @@ static pthread_barrier_t g_bar;
 #define LC3_UNIFORM_LEADER(lane) ((lane) == 0)
 #define LC3_U(x) ((int)(x))
 #define LC3_UST(lv, v) ((lv) = (v))
+#define LC3_LDS_OR32(p, v) __atomic_fetch_or((p), (v), __ATOMIC_RELAXED)
 static inline int lc3_sym_search(const int16_t *cum, const int16_t *freq, int nsym, uint32_t low, uint32_t tmp, int lane,
                                  uint32_t &cval, uint32_t &fval) {
     (void)lane;
@@ -92,6 +93,7 @@ void run_wave(Job proto) {
 }
 }  // namespace
 
+static int g_fallbacks = 0;
 extern "C" {
 // pcm int16[S][T][nf] -> bytes uint8[S][T][nbytes]; every stream starts fresh; dbg optional float[1472] (last frame)
 int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16_t *pcm, uint8_t *bytes, float *dbg) {
@@ -111,15 +113,18 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
     lc3_enc_state *st = (lc3_enc_state *)calloc(1, sizeof(lc3_enc_state));
     j.EL = L;
     j.est = st;
+    g_fallbacks = 0;
     for (int s = 0; s < S; s++) {
         j.pcm_in = pcm + (size_t)s * T * j.cfg.nf;
         j.bytes_out = bytes + (size_t)s * T * nbytes;
         run_wave(j);
+        g_fallbacks += st->bitstream_fallbacks;
     }
     free(L);
     free(st);
     return 0;
 }
+int lc3emu_last_fallbacks(void) { return g_fallbacks; }
 int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8_t *bytes, const uint8_t *bad,
                   int16_t *pcm) {
     Job j;
