@@ -30,8 +30,7 @@ struct lc3_dec_lds {
     float spec[LC3_MAX_NF];        // spec_lines, then freq_samples
     lc3_cpx fa[LC3_MAX_NF / 2];    // save_lev during parsing | FFT in   | t_hat_mdct[0 .. nf)
     lc3_cpx fb[LC3_MAX_NF / 2];    // integer spectrum xi     | FFT work | t_hat_mdct[nf .. 2nf)  (contiguous with fa)
-    uint8_t in[LC3_MAX_NE];        // frame bytes
-    uint8_t res_bits[480];
+    alignas(16) uint8_t in[LC3_MAX_NE + 112];  // frame bytes (padded to 512: read as 128 dwords by the parser)
     float sm[192];
     int ism[64];
     unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
@@ -70,10 +69,6 @@ __device__ __forceinline__ void lc3_dec_state_store(lc3_dec_lds &L, int lane, lc
 // The including translation unit defines LC3_UNIFORM_LEADER / LC3_U / LC3_UST / lc3_sym_search.
 // ------------------------------------------------------------------------------------------
 // D1: BufferReader (decoder/buffer_reader.rs:11-116)
-struct lc3_reader {
-    const uint8_t *buf;
-    int len, head, tail;
-};
 __device__ __forceinline__ int lc3_rd_tail(lc3_reader &r, int num_bits, uint32_t &val) {  // read_tail_usize :63-98
     const int byte_index = r.tail / 8, bit_index = r.tail % 8;
     const int bits_left = 8 - bit_index;
@@ -83,7 +78,7 @@ __device__ __forceinline__ int lc3_rd_tail(lc3_reader &r, int num_bits, uint32_t
     const int from = r.len - byte_index - num_bytes;
     uint32_t value = 0;
     if (num_bytes <= 4)
-        for (int i = 0; i < num_bytes; i++) value = (value << 8) | (uint32_t)LC3_U(r.buf[from + i]);
+        for (int i = 0; i < num_bytes; i++) value = (value << 8) | (uint32_t)LC3_FRAME_BYTE(r, from + i);
     const int shift_by = 32 - num_bits - bit_index;
     value <<= shift_by;
     value >>= shift_by + bit_index;
@@ -96,7 +91,7 @@ __device__ __forceinline__ int lc3_rd_bool(lc3_reader &r, int &bit) {  // read_t
     if (r.len - r.head - byte_index + 2 < 0) return -1;
     const int from = r.len - byte_index - 1;
     if (from < 0) return -1;  // the reference would panic here; treated as a read error (-> PLC)
-    uint32_t byte = (uint32_t)LC3_U(r.buf[from]);
+    uint32_t byte = (uint32_t)LC3_FRAME_BYTE(r, from);
     byte = (byte << (7 - bit_index)) & 0xffu;
     byte >>= 7;
     r.tail += 1;
@@ -207,7 +202,6 @@ __device__ __forceinline__ int lc3_dec_side_info(lc3_reader &r, int fs_ind, int 
 }
 
 // D3: arithmetic decoder (decoder/arithmetic_codec.rs:57-405)
-struct lc3_acdec { uint32_t low, range; };
 // ac_decode :67-97.  The reference searches the symbol linearly from the top (`while low < tmp * cum[val]`);
 // here lane i evaluates symbol i and the highest lane whose test holds is the answer (same integer compare).
 __device__ __forceinline__ int lc3_ac_decode(lc3_reader &r, lc3_acdec &st, const int16_t *cum, const int16_t *freq,
@@ -222,7 +216,28 @@ __device__ __forceinline__ int lc3_ac_decode(lc3_reader &r, lc3_acdec &st, const
         st.low <<= 8;
         st.low &= 0x00ffffffu;
         if (r.head >= r.len) return -1;  // read_head_byte :42-50
-        st.low += (uint32_t)LC3_U(r.buf[r.head]);
+        st.low += (uint32_t)LC3_FRAME_BYTE(r, r.head);
+        r.head += 1;
+        st.range <<= 8;
+    }
+    sym = val;
+    return 0;
+}
+// Spectral symbols: the 64 x 17 (cum, freq) model and the 4096-entry context lookup are held in vector registers
+// for the duration of the parse (lc3_dec_tabs, filled by the translation unit's lc3_dec_tabs_load) and read with
+// v_readlane, so a symbol costs a handful of scalar compares instead of two dependent trips to memory.
+__device__ __forceinline__ int lc3_ac_decode_spec(lc3_reader &r, lc3_acdec &st, const lc3_dec_tabs &T, int pki, int &sym) {
+    const uint32_t tmp = st.range >> 10, limit = tmp << 10;
+    if (st.low >= limit) return -1;
+    uint32_t sv;
+    const int val = lc3_tab_search(T, pki, st.low, tmp, sv);  // largest j with low >= tmp * cum[j]; sv = cum | freq << 16
+    st.low -= tmp * (sv & 0xffffu);
+    st.range = tmp * (sv >> 16);
+    while (st.range < 0x10000u) {
+        st.low <<= 8;
+        st.low &= 0x00ffffffu;
+        if (r.head >= r.len) return -1;
+        st.low += (uint32_t)LC3_FRAME_BYTE(r, r.head);
         r.head += 1;
         st.range <<= 8;
     }
@@ -252,16 +267,16 @@ __device__ __forceinline__ int lc3_read_res_bit(int32_t *x, lc3_reader &r, int i
 
 // arithmetic_codec::decode :109-158 up to (not including) the non-lsb residual bits and the noise seed, which
 // the caller does lane-parallel.  x and save_lev are zero on entry.
-__device__ __forceinline__ int lc3_dec_arith(lc3_reader &r, int ne, int fs_ind, int n_ms_10, int *si, int32_t *x,
-                                             int32_t *save_lev, int lane) {
+__device__ __forceinline__ int lc3_dec_arith(lc3_reader &r, const lc3_dec_tabs &T, int ne, int fs_ind, int n_ms_10, int *si,
+                                             int32_t *x, int32_t *save_lev, int lane) {
     const int nbits = r.len * 8;
     const int num_tns = LC3_U(si[SI_NUM_TNS]), lastnz = LC3_U(si[SI_LASTNZ]), lsb_mode = LC3_U(si[SI_LSB_MODE]);
     lc3_acdec st;
     int sym = 0;
     // ac_dec_init :57-65
     if (!(r.head + 2 < r.len)) return -1;
-    st.low = ((uint32_t)LC3_U(r.buf[r.head]) << 16) | ((uint32_t)LC3_U(r.buf[r.head + 1]) << 8) |
-             (uint32_t)LC3_U(r.buf[r.head + 2]);
+    st.low = ((uint32_t)LC3_FRAME_BYTE(r, r.head) << 16) | ((uint32_t)LC3_FRAME_BYTE(r, r.head + 1) << 8) |
+             (uint32_t)LC3_FRAME_BYTE(r, r.head + 2);
     r.head += 3;
     st.range = 0x00ffffffu;
     // decode_tns_data :304-337
@@ -292,8 +307,8 @@ __device__ __forceinline__ int lc3_dec_arith(lc3_reader &r, int ne, int fs_ind, 
             int32_t xk = 0, xk1 = 0;
             sym = 0;
             while (lev < 14) {
-                const int pki = LC3T_AC_SPEC_LOOKUP[t + (lev < 3 ? lev : 3) * 1024];
-                if (lc3_ac_decode(r, st, LC3T_AC_SPEC_CUMFREQ[pki], LC3T_AC_SPEC_FREQ[pki], 17, lane, sym)) return -4;
+                const int pki = lc3_tab_lookup(T, t + (lev < 3 ? lev : 3) * 1024);
+                if (lc3_ac_decode_spec(r, st, T, pki, sym)) return -4;
                 if (sym < 16) break;
                 if (!lsb_mode || lev > 0) {
                     if (lc3_rd_bool(r, bit)) return -5;
@@ -591,8 +606,10 @@ __device__ __noinline__ int lc3_dec_read_frame(const lc3_cfg &c, lc3_dec_lds &L,
         r.len = nbytes;
         r.head = 0;
         r.tail = 0;
+        lc3_dec_tabs T;
+        lc3_dec_tabs_load(T, r, lane);
         int rc = force_plc ? -100 : lc3_dec_side_info(r, u_fs_ind, u_ne, si, lane);
-        if (rc == 0) rc = lc3_dec_arith(r, u_ne, u_fs_ind, u_n_ms_10, si, xi, save_lev, lane);
+        if (rc == 0) rc = lc3_dec_arith(r, T, u_ne, u_fs_ind, u_n_ms_10, si, xi, save_lev, lane);
         LC3_UST(si[AD_OK], rc == 0);
     }
     LC3_SYNC();
@@ -612,7 +629,7 @@ __device__ __noinline__ int lc3_dec_read_frame(const lc3_cfg &c, lc3_dec_lds &L,
     }
     LC3_SYNC();
     uint32_t nnz = 0, seed = 0;
-    for (int i = 0; i < LC3_WAVE; i++) {
+    _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) {
         nnz += part[i];
         seed += part[64 + i];
     }
@@ -681,7 +698,7 @@ __device__ __noinline__ void lc3_dec_spectrum(const lc3_cfg &c, lc3_dec_lds &L, 
         part[64 + lane] = (uint32_t)__builtin_popcount(fillmask);
         LC3_SYNC();
         int rank_nz = 0, rank_fill = 0;
-        for (int i = 0; i < lane; i++) {
+        _Pragma("nounroll") for (int i = 0; i < lane; i++) {
             rank_nz += (int)part[i];
             rank_fill += (int)part[64 + i];
         }

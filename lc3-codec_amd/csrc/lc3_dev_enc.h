@@ -1075,7 +1075,7 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_
         part[128 + lane] = (uint32_t)(hi_nz + 1);
         LC3_SYNC();
         int hi_all = 0;  // 1 + index of the last non-zero tuple
-        for (int i = 0; i < LC3_WAVE; i++) {
+        _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) {
             const int v = (int)part[128 + i];
             hi_all = v > hi_all ? v : hi_all;
         }
@@ -1113,7 +1113,7 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_
         part[64 + lane] = lsb_sum;
         LC3_SYNC();
         uint32_t base = 0, est_total = 0, lsb_total = 0;
-        for (int i = 0; i < LC3_WAVE; i++) {
+        _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) {
             const uint32_t e = part[i];
             if (i < lane) base += e;
             est_total += e;
@@ -1139,7 +1139,7 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_
         LC3_SYNC();
         int best_k = -1;
         uint32_t best_est = 0;
-        for (int i = 0; i < LC3_WAVE; i++) {
+        _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) {
             const int v = (int)part[128 + i] - 1;
             if (v > best_k) {
                 best_k = v;
@@ -1227,7 +1227,7 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_ld
             hi_part[lane] = hi;
             LC3_SYNC();
             hi = -1;
-            for (int i = 0; i < LC3_WAVE; i++) hi = hi_part[i] > hi ? hi_part[i] : hi;
+            _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) hi = hi_part[i] > hi ? hi_part[i] : hi;
             for (int n = lane; n < ne4; n += LC3_WAVE) {
                 const float ei = e[n];
                 float tv;
@@ -1250,7 +1250,7 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_ld
         if (lane == 0) {
             // global_gain_limitation :212-228
             float x_f_max = 0.0f;
-            for (int i = 0; i < LC3_WAVE; i++) x_f_max = lc3_maxf(x_f_max, xm[i]);
+            _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) x_f_max = lc3_maxf(x_f_max, xm[i]);
             int gg_min = 0;
             if (x_f_max > 0.0f) gg_min = lc3_f2i16(lc3_ceilf(28.0f * lc3_log10f(x_f_max / (32768.0f - 0.375f)))) - gg_off;
             int reset_offset = 0;
@@ -1347,7 +1347,7 @@ __device__ __noinline__ void lc3_enc_residual_noise(const lc3_cfg &c, lc3_enc_ld
     part[64 + lane] = (uint32_t)__builtin_popcount(relmask);
     LC3_SYNC();
     int rank_nz = 0, rank_rel = 0, tot_nz = 0, tot_rel = 0;
-    for (int i = 0; i < LC3_WAVE; i++) {
+    _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) {
         const int a = (int)part[i], b = (int)part[64 + i];
         if (i < lane) { rank_nz += a; rank_rel += b; }
         tot_nz += a;
@@ -1725,7 +1725,6 @@ __device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L,
     const int ntup = lastnz_trunc / 2, k0 = 4 * lane;
     {
         uint32_t ns = 0, nb = 0, nl = 0;
-#pragma unroll
         for (int j = 0; j < 4; j++) {
             const int k = k0 + j;
             if (k < ntup) {
@@ -1750,7 +1749,7 @@ __device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L,
     }
     LC3_SYNC();
     uint32_t soff = 0, boff = 0, loff = 0, stot = 0, btot = 0, ltot = 0;
-    for (int i = 0; i < LC3_WAVE; i++) {
+    _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) {
         const uint32_t a = part[i], b = part[64 + i], l = part[128 + i];
         if (i < lane) { soff += a; boff += b; loff += l; }
         stot += a; btot += b; ltot += l;
@@ -1763,7 +1762,6 @@ __device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L,
     LC3_SYNC();
     if (fits) {
         uint32_t gpos = (uint32_t)side_bits + boff;  // next backward bit position (0 = bit 0 of the last byte)
-#pragma unroll
         for (int j = 0; j < 4; j++) {
             const int k = k0 + j;
             if (k < ntup) {
@@ -1778,14 +1776,16 @@ __device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L,
                     symlist[soff++] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[pki][16] |
                                       ((uint32_t)(int)LC3T_AC_SPEC_FREQ[pki][16] << 16);
                     if (!(lsb_mode && i == 0)) {
-                        unsigned bits2[2] = {(a >> i) & 1u, (b >> i) & 1u};
-                        for (int q = 0; q < 2; q++) {
-                            if (bits2[q]) {
-                                const uint32_t byte = (uint32_t)nbytes - 1u - (gpos >> 3);
-                                LC3_LDS_OR32((uint32_t *)L.out + (byte >> 2), 1u << (8u * (byte & 3u) + (gpos & 7u)));
-                            }
-                            gpos++;
+                        if ((a >> i) & 1u) {
+                            const uint32_t byte = (uint32_t)nbytes - 1u - (gpos >> 3);
+                            LC3_LDS_OR32((uint32_t *)L.out + (byte >> 2), 1u << (8u * (byte & 3u) + (gpos & 7u)));
                         }
+                        gpos++;
+                        if ((b >> i) & 1u) {
+                            const uint32_t byte = (uint32_t)nbytes - 1u - (gpos >> 3);
+                            LC3_LDS_OR32((uint32_t *)L.out + (byte >> 2), 1u << (8u * (byte & 3u) + (gpos & 7u)));
+                        }
+                        gpos++;
                     }
                 }
                 {

@@ -17,6 +17,7 @@
 #include "../../include/lc3gpu.h"
 
 #define LC3_SYNC() __syncthreads()
+#include "lc3_dev_common.h"
 // wave-uniform primitives of the "uniform-scalar" serial sections (see lc3_dev_dec.h): all 64 lanes execute the
 // section with identical values, LDS reads are broadcast into SGPRs, one lane performs the LDS writes.
 #define LC3_UNIFORM_LEADER(lane) (true)
@@ -35,6 +36,58 @@ __device__ __forceinline__ int lc3_sym_search(const int16_t *cum, const int16_t 
     fval = (uint32_t)__builtin_amdgcn_readlane((int)fv, val);
     return val;
 }
+// ---- register-resident tables of the decoder's frame parser ------------------------------------------------
+// Lane p keeps distribution p of the spectral model (17 x (cum | freq << 16)), the 4096-byte context lookup is
+// spread as 1024 dwords over 16 registers x 64 lanes, and the frame itself sits in two registers.  All reads are
+// v_readlane with a wave-uniform lane select; uniform register selection is resolved by small decision trees.
+struct lc3_dec_tabs {
+    uint32_t row[17];
+    uint32_t lk[16];
+};
+__device__ __forceinline__ void lc3_dec_tabs_load(lc3_dec_tabs &T, lc3_reader &r, int lane) {
+#pragma unroll
+    for (int j = 0; j < 17; j++)
+        T.row[j] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[lane][j] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[lane][j] << 16);
+    const uint32_t *lk32 = (const uint32_t *)LC3T_AC_SPEC_LOOKUP;
+#pragma unroll
+    for (int q = 0; q < 16; q++) T.lk[q] = lk32[q * 64 + lane];
+    const uint32_t *f32 = (const uint32_t *)r.buf;  // LDS buffer, padded to 512 bytes
+    r.fr0 = f32[lane];
+    r.fr1 = f32[64 + lane];
+}
+#define LC3_FRAME_BYTE(r, i) \
+    ((((uint32_t)__builtin_amdgcn_readlane((int)(((i) >> 8) ? (r).fr1 : (r).fr0), ((i) >> 2) & 63)) >> (8 * ((i) & 3))) & 0xffu)
+template <int LO, int HI>
+__device__ __forceinline__ uint32_t lc3_pick_reg(const uint32_t (&a)[16], int q, int l) {
+    if constexpr (LO == HI) return (uint32_t)__builtin_amdgcn_readlane((int)a[LO], l);
+    else {
+        constexpr int MID = (LO + HI) / 2;
+        return q <= MID ? lc3_pick_reg<LO, MID>(a, q, l) : lc3_pick_reg<MID + 1, HI>(a, q, l);
+    }
+}
+__device__ __forceinline__ int lc3_tab_lookup(const lc3_dec_tabs &T, int idx) {
+    const int d = idx >> 2;
+    const uint32_t w = lc3_pick_reg<0, 15>(T.lk, d >> 6, d & 63);
+    return (int)((w >> (8 * (idx & 3))) & 0xffu);
+}
+// largest j in [LO, HI] with low >= tmp * cum[j] (cum is non-decreasing, cum[0] == 0): the symbol the reference's
+// top-down linear search returns (decoder/arithmetic_codec.rs:81-84)
+template <int LO, int HI>
+__device__ __forceinline__ int lc3_search_sym(const uint32_t (&row)[17], int pki, uint32_t low, uint32_t tmp, uint32_t &sv) {
+    if constexpr (LO == HI) {
+        sv = (uint32_t)__builtin_amdgcn_readlane((int)row[LO], pki);
+        return LO;
+    } else {
+        constexpr int MID = (LO + HI + 1) / 2;
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)row[MID], pki);
+        if (low >= tmp * (s & 0xffffu)) return lc3_search_sym<MID, HI>(row, pki, low, tmp, sv);
+        return lc3_search_sym<LO, MID - 1>(row, pki, low, tmp, sv);
+    }
+}
+__device__ __forceinline__ int lc3_tab_search(const lc3_dec_tabs &T, int pki, uint32_t low, uint32_t tmp, uint32_t &sv) {
+    return lc3_search_sym<0, 16>(T.row, pki, low, tmp, sv);
+}
+
 #ifdef LC3_PROFILE
 // Diagnostic build (liblc3gpu_prof.so): lane 0 of every wave adds the shader-clock cycles between consecutive
 // stage stamps into a global table.  Stamp i accumulates the time since the previous stamp into slot i.

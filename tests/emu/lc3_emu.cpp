@@ -18,6 +18,7 @@
 
 static pthread_barrier_t g_bar;
 #define LC3_SYNC() pthread_barrier_wait(&g_bar)
+#include "../../lc3-codec_amd/csrc/lc3_dev_common.h"
 // "uniform-scalar" sections: on the GPU all lanes run them redundantly; the emulator runs them on lane 0 only
 #define LC3_UNIFORM_LEADER(lane) ((lane) == 0)
 #define LC3_U(x) ((int)(x))
@@ -31,6 +32,18 @@ static inline int lc3_sym_search(const int16_t *cum, const int16_t *freq, int ns
         if (low >= tmp * (uint32_t)(int)cum[i]) val = i;
     cval = (uint32_t)(int)cum[val];
     fval = (uint32_t)(int)freq[val];
+    return val;
+}
+
+// decoder parser tables: the GPU keeps them in vector registers; the emulator reads the tables directly
+struct lc3_dec_tabs { int unused; };
+static inline void lc3_dec_tabs_load(lc3_dec_tabs &, lc3_reader &, int) {}
+#define LC3_FRAME_BYTE(r, i) ((uint32_t)(r).buf[(i)])
+static inline int lc3_tab_lookup(const lc3_dec_tabs &, int idx) { return LC3T_AC_SPEC_LOOKUP[idx]; }
+static inline int lc3_tab_search(const lc3_dec_tabs &, int pki, uint32_t low, uint32_t tmp, uint32_t &sv) {
+    int val = 16;
+    while (low < tmp * (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[pki][val]) val--;  // reference order (arithmetic_codec.rs:81-84)
+    sv = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[pki][val] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[pki][val] << 16);
     return val;
 }
 

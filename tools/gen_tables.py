@@ -148,7 +148,7 @@ def emit_table(name, base, dims, flat_tokens, out):
     dimstr = "".join(f"[{d}]" for d in dims)
     if base == "Scaler":
         bits = [parse_float_token(t) for t in flat_tokens]
-        out.append(f"/* f32 bit patterns */\nLC3_TABLE_QUAL uint32_t LC3T_{name}_BITS{dimstr} = {{")
+        out.append(f"/* f32 bit patterns */\nLC3_TABLE_QUAL uint32_t LC3T_{name}_BITS{dimstr} LC3_TABLE_ALIGN = {{")
         vals = [f"0x{b:08x}u" for b in bits]
         per = 8
     else:
@@ -163,7 +163,7 @@ def emit_table(name, base, dims, flat_tokens, out):
         else:  # usize
             cty = "uint16_t" if hi < 65536 else "uint32_t"
             assert lo >= 0
-        out.append(f"LC3_TABLE_QUAL {cty} LC3T_{name}{dimstr} = {{")
+        out.append(f"LC3_TABLE_QUAL {cty} LC3T_{name}{dimstr} LC3_TABLE_ALIGN = {{")
         vals = [str(v) for v in ints]
         per = 16
     # nested braces are optional in C for multi-dim arrays; emit flat rows
@@ -185,6 +185,8 @@ def main():
     out.append(" * Define LC3_TABLE_QUAL before including (e.g. `static const` or `__device__ const`). */")
     out.append("#ifndef LC3_TABLES_H_\n#define LC3_TABLES_H_\n#include <stdint.h>\n")
     out.append("#ifndef LC3_TABLE_QUAL\n#define LC3_TABLE_QUAL static const\n#endif\n")
+    out.append("/* every table is 16-byte aligned so that byte/short tables can also be fetched as 32-bit words */")
+    out.append("#define LC3_TABLE_ALIGN __attribute__((aligned(16)))\n")
     files = [
         "mdct_windows.rs",
         "band_index_tables.rs",
