@@ -96,14 +96,7 @@ __device__ __forceinline__ float lc3_sqrtf(float x) { return __builtin_sqrtf(x);
 __device__ __forceinline__ float lc3_floorf(float x) { return __builtin_floorf(x); }
 __device__ __forceinline__ float lc3_ceilf(float x) { return __builtin_ceilf(x); }
 
-// bitstream reader / range decoder state of the decoder's frame parser (decoder/buffer_reader.rs:11-15,
-// decoder/arithmetic_codec.rs:22-26); declared here because the translation unit's table accessors use them
-struct lc3_reader {
-    const uint8_t *buf;   // frame bytes in LDS
-    uint32_t fr0, fr1;    // GPU build: the same bytes held in two vector registers (dword 64 r + lane), read with
-                          // v_readlane so that the serial parser never waits on memory (LC3_FRAME_BYTE)
-    int len, head, tail;
-};
+// range decoder state (decoder/arithmetic_codec.rs:22-26)
 struct lc3_acdec { uint32_t low, range; };
 
 // ------------------------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 // See lc3_dev_common.h for the execution model and the bit-exactness contract.
 #pragma once
 #include "lc3_dev_common.h"
+#include "lc3_dev_dec_parse.h"
 
 // Persistent per-stream decoder state.  `core` is what a wave keeps resident in LDS while it
 // works on the stream; plc_last_good stays in HBM (written once per good frame, read only when concealing).
@@ -28,9 +29,9 @@ struct lc3_dec_state {
 struct lc3_dec_lds {
     lc3_dec_core st;
     float spec[LC3_MAX_NF];        // spec_lines, then freq_samples
-    lc3_cpx fa[LC3_MAX_NF / 2];    // save_lev during parsing | FFT in   | t_hat_mdct[0 .. nf)
+    lc3_cpx fa[LC3_MAX_NF / 2];    // FFT in   | t_hat_mdct[0 .. nf)
     lc3_cpx fb[LC3_MAX_NF / 2];    // integer spectrum xi     | FFT work | t_hat_mdct[nf .. 2nf)  (contiguous with fa)
-    alignas(16) uint8_t in[LC3_MAX_NE + 112];  // frame bytes (padded to 512: read as 128 dwords by the parser)
+    uint8_t in[LC3_MAX_NE];        // frame bytes (residual bits are read from them)
     float sm[192];
     int ism[64];
     unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
@@ -58,306 +59,6 @@ __device__ __forceinline__ void lc3_dec_state_store(lc3_dec_lds &L, int lane, lc
     const int *w = (const int *)&L.st;
     LC3_SYNC();
     for (int i = lane; i < LC3_DEC_CORE_WORDS; i += LC3_WAVE) dst[i] = w[i];
-}
-
-// ------------------------------------------------------------------------------------------
-// Frame parsing runs in "uniform-scalar" style: the whole wave executes the serial bitstream state
-// machine with identical (wave-uniform) values, so on the GPU the state lives in SGPRs and the integer
-// work issues on the scalar unit instead of a 1-of-64-lanes vector stream.  LDS reads are made uniform
-// with LC3_U() (v_readfirstlane), LDS writes go through LC3_UST() (lane 0 stores), and the 17-way
-// symbol search of the range decoder is done by 17 lanes at once (lc3_sym_search: ballot + readlane).
-// The including translation unit defines LC3_UNIFORM_LEADER / LC3_U / LC3_UST / lc3_sym_search.
-// ------------------------------------------------------------------------------------------
-// D1: BufferReader (decoder/buffer_reader.rs:11-116)
-__device__ __forceinline__ int lc3_rd_tail(lc3_reader &r, int num_bits, uint32_t &val) {  // read_tail_usize :63-98
-    const int byte_index = r.tail / 8, bit_index = r.tail % 8;
-    const int bits_left = 8 - bit_index;
-    const int add_bytes = (num_bits > bits_left && num_bits < 8) ? 2 : 1;
-    const int num_bytes = num_bits / 8 + add_bytes;
-    if (r.len - r.head - byte_index - num_bytes < 0) return -1;
-    const int from = r.len - byte_index - num_bytes;
-    uint32_t value = 0;
-    if (num_bytes <= 4)
-        for (int i = 0; i < num_bytes; i++) value = (value << 8) | (uint32_t)LC3_FRAME_BYTE(r, from + i);
-    const int shift_by = 32 - num_bits - bit_index;
-    value <<= shift_by;
-    value >>= shift_by + bit_index;
-    r.tail += num_bits;
-    val = value;
-    return 0;
-}
-__device__ __forceinline__ int lc3_rd_bool(lc3_reader &r, int &bit) {  // read_tail_bool :100-116
-    const int byte_index = r.tail / 8, bit_index = r.tail % 8;
-    if (r.len - r.head - byte_index + 2 < 0) return -1;
-    const int from = r.len - byte_index - 1;
-    if (from < 0) return -1;  // the reference would panic here; treated as a read error (-> PLC)
-    uint32_t byte = (uint32_t)LC3_FRAME_BYTE(r, from);
-    byte = (byte << (7 - bit_index)) & 0xffu;
-    byte >>= 7;
-    r.tail += 1;
-    bit = byte == 1;
-    return 0;
-}
-
-// decoded side information, kept in L.ism[]:
-enum {
-    SI_BW = 0, SI_LASTNZ, SI_LSB_MODE, SI_GG, SI_NUM_TNS, SI_ORD0, SI_ORD1, SI_IND_LF, SI_IND_HF, SI_LS_A, SI_LS_B,
-    SI_IDX_A, SI_IDX_B, SI_SUB_LSB, SI_SUB_MSB, SI_G_IND, SI_PITCH_PRESENT, SI_LTPF_ACTIVE, SI_PITCH_INDEX, SI_NF,
-    AD_ORD0, AD_ORD1, AD_NRES, AD_SEED, AD_ZERO, AD_OK, AD_RCI /* 16 entries */, AD_TAIL0 = AD_RCI + 16, AD_NRES_MAX,
-    AD_HEAD
-};
-
-#define LC3_RD(nb, dst) do { if (lc3_rd_tail(r, (nb), (dst))) return -1; } while (0)
-#define LC3_RDB(dst) do { if (lc3_rd_bool(r, (dst))) return -1; } while (0)
-
-// D2: side_info_reader::read (decoder/side_info_reader.rs:29-200)
-__device__ __forceinline__ int lc3_dec_side_info(lc3_reader &r, int fs_ind, int ne, int *si, int lane) {
-    uint32_t v;
-    int b, p_bw = 0, lastnz_bits = 0;
-    const int nbits_bw = LC3C_NBITS_BW[fs_ind];
-    if (nbits_bw > 0) {
-        LC3_RD(nbits_bw, v);
-        if (fs_ind < (int)v) return -2;
-        p_bw = (int)v;
-    }
-    while ((1 << lastnz_bits) < ne / 2) lastnz_bits++;
-    LC3_RD(lastnz_bits, v);
-    const int lastnz = (int)((v + 1) << 1);
-    LC3_UST(si[SI_LASTNZ], lastnz);
-    if (lastnz > ne) return -3;
-    LC3_RDB(b);
-    LC3_UST(si[SI_LSB_MODE], b);
-    LC3_RD(8, v);
-    LC3_UST(si[SI_GG], (int)v);
-    const int num_tns = p_bw < 3 ? 1 : 2;
-    LC3_UST(si[SI_NUM_TNS], num_tns);
-    LC3_UST(si[SI_ORD0], 0);
-    LC3_UST(si[SI_ORD1], 0);
-    for (int f = 0; f < num_tns; f++) {
-        LC3_RDB(b);
-        LC3_UST(si[SI_ORD0 + f], b);
-    }
-    LC3_RDB(b);
-    const int pitch_present = b;
-    LC3_UST(si[SI_PITCH_PRESENT], b);
-    // read_sns_vq :131-200
-    LC3_RD(5, v);
-    LC3_UST(si[SI_IND_LF], (int)v);
-    LC3_RD(5, v);
-    LC3_UST(si[SI_IND_HF], (int)v);
-    LC3_RDB(b);
-    const int submode_msb = b;
-    if (submode_msb == 0) LC3_RD(1, v);
-    else LC3_RD(2, v);
-    int g_ind = (int)v;
-    LC3_RDB(b);
-    LC3_UST(si[SI_LS_A], b);
-    int submode_lsb = 0, ls_indb = 0;
-    uint32_t idx_a, idx_b = 0;
-    if (submode_msb == 0) {
-        uint32_t tmp;
-        LC3_RD(25, tmp);
-        if (tmp >= 33460056u) return -4;
-        const uint32_t idx_bor = tmp / 2390004u;
-        idx_a = tmp - idx_bor * 2390004u;
-        int s = (int)idx_bor - 2;
-        if (s < 0) submode_lsb = 1;
-        s = s + submode_lsb * 2;
-        if (submode_lsb != 0) g_ind = (g_ind << 1) + s;
-        else {
-            idx_b = (uint32_t)s >> 1;
-            ls_indb = s & 1;
-        }
-    } else {
-        uint32_t tmp;
-        LC3_RD(24, tmp);
-        if (tmp >= 16708096u) return -5;
-        if (tmp >= 15158272u) {
-            tmp -= 15158272u;
-            submode_lsb = 1;
-            g_ind = (g_ind << 1) + (int)(tmp & 1u);
-            idx_a = tmp >> 1;
-        } else idx_a = tmp;
-    }
-    LC3_UST(si[SI_LS_B], ls_indb);
-    LC3_UST(si[SI_IDX_A], (int)idx_a);
-    LC3_UST(si[SI_IDX_B], (int)idx_b);
-    LC3_UST(si[SI_SUB_LSB], submode_lsb);
-    LC3_UST(si[SI_SUB_MSB], submode_msb);
-    LC3_UST(si[SI_G_IND], g_ind);
-    // read_long_term_post_filter_info :106-129
-    int ltpf_active = 0, pitch_index = 0;
-    if (pitch_present) {
-        LC3_RDB(b);
-        ltpf_active = b;
-        LC3_RD(9, v);
-        pitch_index = (int)v;
-    }
-    LC3_UST(si[SI_LTPF_ACTIVE], ltpf_active);
-    LC3_UST(si[SI_PITCH_INDEX], pitch_index);
-    LC3_RD(3, v);
-    LC3_UST(si[SI_NF], (int)v);
-    LC3_UST(si[SI_BW], p_bw);
-    return 0;
-}
-
-// D3: arithmetic decoder (decoder/arithmetic_codec.rs:57-405)
-// ac_decode :67-97.  The reference searches the symbol linearly from the top (`while low < tmp * cum[val]`);
-// here lane i evaluates symbol i and the highest lane whose test holds is the answer (same integer compare).
-__device__ __forceinline__ int lc3_ac_decode(lc3_reader &r, lc3_acdec &st, const int16_t *cum, const int16_t *freq,
-                                             int nsym, int lane, int &sym) {
-    const uint32_t tmp = st.range >> 10, limit = tmp << 10;
-    if (st.low >= limit) return -1;
-    uint32_t cval, fval;
-    const int val = lc3_sym_search(cum, freq, nsym, st.low, tmp, lane, cval, fval);
-    st.low -= tmp * cval;
-    st.range = tmp * fval;
-    while (st.range < 0x10000u) {
-        st.low <<= 8;
-        st.low &= 0x00ffffffu;
-        if (r.head >= r.len) return -1;  // read_head_byte :42-50
-        st.low += (uint32_t)LC3_FRAME_BYTE(r, r.head);
-        r.head += 1;
-        st.range <<= 8;
-    }
-    sym = val;
-    return 0;
-}
-// Spectral symbols: the 64 x 17 (cum, freq) model and the 4096-entry context lookup are held in vector registers
-// for the duration of the parse (lc3_dec_tabs, filled by the translation unit's lc3_dec_tabs_load) and read with
-// v_readlane, so a symbol costs a handful of scalar compares instead of two dependent trips to memory.
-__device__ __forceinline__ int lc3_ac_decode_spec(lc3_reader &r, lc3_acdec &st, const lc3_dec_tabs &T, int pki, int &sym) {
-    const uint32_t tmp = st.range >> 10, limit = tmp << 10;
-    if (st.low >= limit) return -1;
-    uint32_t sv;
-    const int val = lc3_tab_search(T, pki, st.low, tmp, sv);  // largest j with low >= tmp * cum[j]; sv = cum | freq << 16
-    st.low -= tmp * (sv & 0xffffu);
-    st.range = tmp * (sv >> 16);
-    while (st.range < 0x10000u) {
-        st.low <<= 8;
-        st.low &= 0x00ffffffu;
-        if (r.head >= r.len) return -1;
-        st.low += (uint32_t)LC3_FRAME_BYTE(r, r.head);
-        r.head += 1;
-        st.range <<= 8;
-    }
-    sym = val;
-    return 0;
-}
-__device__ __forceinline__ int lc3_read_res_bit(int32_t *x, lc3_reader &r, int idx, int &nbits_res, int &cont, int lane) {
-    // :339-383
-    int bit;
-    if (nbits_res == 0) { cont = 0; return 0; }
-    if (lc3_rd_bool(r, bit)) return -1;
-    nbits_res -= 1;
-    if (bit) {
-        const int xv = LC3_U(x[idx]);
-        if (xv > 0) LC3_UST(x[idx], xv + 1);
-        else if (xv < 0) LC3_UST(x[idx], xv - 1);
-        else {
-            if (nbits_res == 0) { cont = 0; return 0; }
-            if (lc3_rd_bool(r, bit)) return -1;
-            nbits_res -= 1;
-            LC3_UST(x[idx], bit ? -1 : 1);
-        }
-    }
-    cont = 1;
-    return 0;
-}
-
-// arithmetic_codec::decode :109-158 up to (not including) the non-lsb residual bits and the noise seed, which
-// the caller does lane-parallel.  x and save_lev are zero on entry.
-__device__ __forceinline__ int lc3_dec_arith(lc3_reader &r, const lc3_dec_tabs &T, int ne, int fs_ind, int n_ms_10, int *si,
-                                             int32_t *x, int32_t *save_lev, int lane) {
-    const int nbits = r.len * 8;
-    const int num_tns = LC3_U(si[SI_NUM_TNS]), lastnz = LC3_U(si[SI_LASTNZ]), lsb_mode = LC3_U(si[SI_LSB_MODE]);
-    lc3_acdec st;
-    int sym = 0;
-    // ac_dec_init :57-65
-    if (!(r.head + 2 < r.len)) return -1;
-    st.low = ((uint32_t)LC3_FRAME_BYTE(r, r.head) << 16) | ((uint32_t)LC3_FRAME_BYTE(r, r.head + 1) << 8) |
-             (uint32_t)LC3_FRAME_BYTE(r, r.head + 2);
-    r.head += 3;
-    st.range = 0x00ffffffu;
-    // decode_tns_data :304-337
-    {
-        const int wt = nbits < (n_ms_10 ? 480 : 360);
-        for (int k = 0; k < 16; k++) LC3_UST(si[AD_RCI + k], 0);
-        for (int f = 0; f < 2; f++) {
-            int order = LC3_U(si[SI_ORD0 + f]);
-            if (f < num_tns && order > 0) {
-                if (lc3_ac_decode(r, st, LC3T_AC_TNS_ORDER_CUMFREQ[wt], LC3T_AC_TNS_ORDER_FREQ[wt], 8, lane, sym)) return -2;
-                order = sym + 1;
-                for (int k = 0; k < order; k++) {
-                    int s2;
-                    if (lc3_ac_decode(r, st, LC3T_AC_TNS_COEF_CUMFREQ[k], LC3T_AC_TNS_COEF_FREQ[k], 17, lane, s2)) return -3;
-                    LC3_UST(si[AD_RCI + f * 8 + k], s2);
-                }
-            }
-            LC3_UST(si[AD_ORD0 + f], order);
-        }
-    }
-    // decode_spectral_data :211-302
-    {
-        const int rate_flag = nbits > (160 + fs_ind * 160) ? 512 : 0;
-        const int ntup = lastnz / 2;
-        int cctx = 0;
-        for (int tup = 0; tup < ntup; tup++) {
-            int t = cctx + rate_flag + ((tup * 2) > (ne / 2) ? 256 : 0), lev = 0, bit;
-            int32_t xk = 0, xk1 = 0;
-            sym = 0;
-            while (lev < 14) {
-                const int pki = lc3_tab_lookup(T, t + (lev < 3 ? lev : 3) * 1024);
-                if (lc3_ac_decode_spec(r, st, T, pki, sym)) return -4;
-                if (sym < 16) break;
-                if (!lsb_mode || lev > 0) {
-                    if (lc3_rd_bool(r, bit)) return -5;
-                    xk += (int32_t)((uint32_t)bit << lev);
-                    if (lc3_rd_bool(r, bit)) return -5;
-                    xk1 += (int32_t)((uint32_t)bit << lev);
-                }
-                lev += 1;
-            }
-            if (lsb_mode) LC3_UST(save_lev[tup], lev);  // written by TUPLE index, read back by LINE index (:184-195)
-            const int a = sym & 3, b = sym >> 2;
-            xk += (int32_t)((uint32_t)a << lev);
-            xk1 += (int32_t)((uint32_t)b << lev);
-            if (xk > 0) {
-                if (lc3_rd_bool(r, bit)) return -5;
-                if (bit) xk = -xk;
-            }
-            if (xk1 > 0) {
-                if (lc3_rd_bool(r, bit)) return -5;
-                if (bit) xk1 = -xk1;
-            }
-            LC3_UST(x[2 * tup], xk);
-            LC3_UST(x[2 * tup + 1], xk1);
-            lev = lev < 3 ? lev : 3;
-            t = lev <= 1 ? 1 + (a + b) * (lev + 1) : 12 + lev;
-            cctx = (cctx & 15) * 16 + t;
-        }
-    }
-    // x[lastnz ..] stays 0 (:131-133).  calc_num_residual_bits :385-405
-    {
-        const int nbits_side = r.tail - 8;
-        const int nbits_ari = (r.head + 1 - 3) * 8 + 25 - lc3_ilog2(st.range);
-        if (nbits < nbits_side + nbits_ari) return -6;
-        int nres = nbits - nbits_side - nbits_ari, cont;
-        LC3_UST(si[AD_TAIL0], r.tail);
-        LC3_UST(si[AD_NRES_MAX], nres);
-        LC3_UST(si[AD_HEAD], r.head);
-        if (lsb_mode) {  // decode_residual_bits :184-206, lsb mode refines the integers in place (serial)
-            for (int k = 0; k < lastnz; k += 2) {
-                if (LC3_U(save_lev[k]) > 0) {
-                    if (lc3_read_res_bit(x, r, k, nres, cont, lane)) return -7;
-                    if (!cont) break;
-                    if (lc3_read_res_bit(x, r, k + 1, nres, cont, lane)) return -7;
-                    if (!cont) break;
-                }
-            }
-        }
-    }
-    return 0;
 }
 
 // D8 helper: mpvq_deenum (decoder/spectral_noise_shaping.rs:155-235)
@@ -580,42 +281,22 @@ __device__ __noinline__ void lc3_dec_ltpf(const lc3_cfg &c, lc3_dec_lds &L, int 
 }
 
 // ------------------------------------------------------------------------------------------
-// D0/D2/D3: read_frame (decoder/lc3_decoder.rs:165-177).  The range decoder is a serial state machine: lane 0.
-// Returns 1 when the frame parsed (side info in L.ism, integer spectrum in xi), 0 -> conceal.
+// D0: pick up one parsed frame (lc3_dev_dec_parse.h) from its HBM plane column: side information -> L.ism,
+// integer spectrum -> xi, frame bytes -> L.in (the residual bits are still read from them).  Then the order-free
+// integer epilogue of arithmetic_codec::decode, lane-parallel: residual-bit count and its bounds check, the
+// noise-filling seed  sum |x_k| * k  (:140-145, wrapping) and the zero-frame flag.
+// Returns 1 when the frame parsed, 0 -> conceal.
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_dec_read_frame(const lc3_cfg &c, lc3_dec_lds &L, int lane, const uint8_t *in,
-                                               int nbytes_in, int force_plc_in) {
-    // arguments of a non-inlined device function arrive in vector registers: re-establish wave-uniformity so that
-    // the serial parser below is scalarised
-    const int nbytes = LC3_U(nbytes_in), force_plc = LC3_U(force_plc_in);
-    const int u_ne = LC3_U(c.ne), u_fs_ind = LC3_U(c.fs_ind), u_n_ms_10 = LC3_U(c.n_ms_10);
+__device__ __noinline__ int lc3_dec_load_frame(const lc3_cfg &c, lc3_dec_lds &L, int lane, const uint8_t *in, int nbytes,
+                                               const int32_t *plane, int stride) {
     int *si = L.ism;
-    int32_t *save_lev = (int32_t *)L.fa;  // 400 ints, free until the IMDCT
-    int32_t *xi = (int32_t *)L.fb;        // 400 ints
+    int32_t *xi = (int32_t *)L.fb;  // 400 ints
     const int ne = c.ne;
     for (int i = lane; i < nbytes; i += LC3_WAVE) L.in[i] = in[i];
-    for (int i = lane; i < LC3_MAX_NE; i += LC3_WAVE) {
-        xi[i] = 0;
-        save_lev[i] = 0;
-    }
-    LC3_SYNC();
-    if (LC3_UNIFORM_LEADER(lane)) {
-        // uniform-scalar region: on the GPU every lane runs the same state machine with identical values
-        lc3_reader r;
-        r.buf = L.in;
-        r.len = nbytes;
-        r.head = 0;
-        r.tail = 0;
-        lc3_dec_tabs T;
-        lc3_dec_tabs_load(T, r, lane);
-        int rc = force_plc ? -100 : lc3_dec_side_info(r, u_fs_ind, u_ne, si, lane);
-        if (rc == 0) rc = lc3_dec_arith(r, T, u_ne, u_fs_ind, u_n_ms_10, si, xi, save_lev, lane);
-        LC3_UST(si[AD_OK], rc == 0);
-    }
+    if (lane < SI_WORDS) si[lane] = plane[(LC3_PLANE_SI + lane) * stride];
+    for (int k = lane; k < ne; k += LC3_WAVE) xi[k] = plane[(LC3_PLANE_X + k) * stride];
     LC3_SYNC();
     if (!si[AD_OK]) return 0;
-    // Lane-parallel epilogue (integer work, order-free): number of non-zero lines, the residual-bit count and its
-    // bounds check, the noise-filling seed  sum |x_k| * k  (:140-145, wrapping) and the zero-frame flag.
     uint32_t *part = (uint32_t *)L.sm;  // [0,64) nnz per lane, [64,128) seed partial sums
     {
         uint32_t nnz = 0, seed = 0;
@@ -882,13 +563,15 @@ __device__ __noinline__ void lc3_dec_plc_load(const lc3_cfg &c, lc3_dec_lds &L, 
 
 // ------------------------------------------------------------------------------------------
 // DecoderChannel::decode (decoder/lc3_decoder.rs:73-154): one frame of one stream on one wave.
-// in: nbytes in HBM; pcm_out: nf samples in HBM (4-byte aligned); g: the stream's state blob in HBM.
+// in: nbytes in HBM; pcm_out: nf samples in HBM (4-byte aligned); plane/stride: the frame's parsed column
+// (lc3_dev_dec_parse.h); g: the stream's state blob in HBM.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lc3_decode_frame_wave(const lc3_cfg &c, lc3_dec_lds &L, int lane, const uint8_t *in,
-                                                      int nbytes, int16_t *pcm_out, int force_plc, lc3_dec_state *g) {
+                                                      int nbytes, int16_t *pcm_out, const int32_t *plane, int stride,
+                                                      lc3_dec_state *g) {
     const int nf = c.nf, nbits = nbytes * 8;
     LC3_STAMP(L, lane, 16);
-    const int ok = lc3_dec_read_frame(c, L, lane, in, nbytes, force_plc);
+    const int ok = lc3_dec_load_frame(c, L, lane, in, nbytes, plane, stride);
     LC3_STAMP(L, lane, 17);
     int ltpf_active = 0, pitch_index = 0;
     if (ok) {

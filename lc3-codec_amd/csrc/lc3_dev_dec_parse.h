@@ -1,0 +1,333 @@
+// LC3 batched decoder for MI355X -- frame parser, ONE LANE PER FRAME.
+//
+// Parsing an LC3 frame (side information + range decoder, reference decoder/lc3_decoder.rs:165-177,
+// decoder/side_info_reader.rs:29-200, decoder/arithmetic_codec.rs:57-405) is a serial integer state machine with
+// no floating point and no dependence on earlier frames.  One wavefront per frame leaves 63 lanes idle and is
+// bound by the scalar-issue rate (measured: ~41 k SALU instructions per frame, profiles/r01_pmc_*.csv), so this
+// stage is run with the opposite mapping: every lane parses its own frame and a wave advances 64 frames per
+// instruction.  The context/cumulative-frequency tables and the frame bytes sit in LDS; the results go to HBM
+// "planes" laid out [block of 64 frames][word][lane] so that the 64 lanes of a wave store to consecutive
+// addresses.  The wave-per-stream synthesis kernel (lc3_dev_dec.h) picks the planes up.
+//
+// Plane words of one frame (int32):  [0, 48) side info (enum below)   [48, 448) integer spectrum x[k]
+//                                    [448, 648) save_lev per tuple (lsb_mode only)
+#pragma once
+#include "lc3_dev_common.h"
+
+#define LC3_PLANE_SI 0
+#define LC3_PLANE_X 48
+#define LC3_PLANE_LEV 448
+#define LC3_PLANE_WORDS 648
+
+// decoded side information
+enum {
+    SI_BW = 0, SI_LASTNZ, SI_LSB_MODE, SI_GG, SI_NUM_TNS, SI_ORD0, SI_ORD1, SI_IND_LF, SI_IND_HF, SI_LS_A, SI_LS_B,
+    SI_IDX_A, SI_IDX_B, SI_SUB_LSB, SI_SUB_MSB, SI_G_IND, SI_PITCH_PRESENT, SI_LTPF_ACTIVE, SI_PITCH_INDEX, SI_NF,
+    AD_ORD0, AD_ORD1, AD_NRES, AD_SEED, AD_ZERO, AD_OK, AD_RCI /* 16 entries */, AD_TAIL0 = AD_RCI + 16, AD_NRES_MAX,
+    AD_HEAD, SI_WORDS
+};
+
+struct lc3_parse_ctx {
+    const uint8_t *bytes;    // this frame's bytes
+    int len;
+    const uint8_t *lookup;   // AC_SPEC_LOOKUP[4096]
+    const uint32_t *cf;      // [64][17] cum | freq << 16 of the spectral model
+    int32_t *plane;          // this frame's plane column: word w at plane[w * stride]
+    int stride;
+    int head, tail;          // BufferReader cursors (decoder/buffer_reader.rs:11-15)
+};
+
+__device__ __forceinline__ void lc3_px_set(lc3_parse_ctx &c, int word, int32_t v) { c.plane[word * c.stride] = v; }
+__device__ __forceinline__ int32_t lc3_px_get(const lc3_parse_ctx &c, int word) { return c.plane[word * c.stride]; }
+
+// read_tail_usize (decoder/buffer_reader.rs:63-98)
+__device__ __forceinline__ int lc3_p_tail(lc3_parse_ctx &c, int num_bits, uint32_t &val) {
+    const int byte_index = c.tail >> 3, bit_index = c.tail & 7;
+    const int bits_left = 8 - bit_index;
+    const int add_bytes = (num_bits > bits_left && num_bits < 8) ? 2 : 1;
+    const int num_bytes = (num_bits >> 3) + add_bytes;
+    if (c.len - c.head - byte_index - num_bytes < 0) return -1;
+    const int from = c.len - byte_index - num_bytes;
+    uint32_t value = 0;
+    if (num_bytes <= 4)
+        for (int i = 0; i < num_bytes; i++) value = (value << 8) | (uint32_t)c.bytes[from + i];
+    const int shift_by = 32 - num_bits - bit_index;
+    value <<= shift_by;
+    value >>= shift_by + bit_index;
+    c.tail += num_bits;
+    val = value;
+    return 0;
+}
+// read_tail_bool (:100-116)
+__device__ __forceinline__ int lc3_p_bool(lc3_parse_ctx &c, int &bit) {
+    const int byte_index = c.tail >> 3, bit_index = c.tail & 7;
+    if (c.len - c.head - byte_index + 2 < 0) return -1;
+    const int from = c.len - byte_index - 1;
+    if (from < 0) return -1;  // the reference would panic on this index; treated as a read error (-> PLC)
+    bit = ((uint32_t)c.bytes[from] >> bit_index) & 1u;
+    c.tail += 1;
+    return 0;
+}
+
+#define LC3_PT(nb, dst) do { if (lc3_p_tail(c, (nb), (dst))) return -1; } while (0)
+#define LC3_PB(dst) do { if (lc3_p_bool(c, (dst))) return -1; } while (0)
+
+// side_info_reader::read (decoder/side_info_reader.rs:29-200)
+__device__ __forceinline__ int lc3_parse_side_info(lc3_parse_ctx &c, int fs_ind, int ne, int &lastnz_out, int &lsb_mode_out,
+                                                   int &num_tns_out, int ord[2]) {
+    uint32_t v;
+    int b, p_bw = 0, lastnz_bits = 0;
+    const int nbits_bw = LC3C_NBITS_BW[fs_ind];
+    if (nbits_bw > 0) {
+        LC3_PT(nbits_bw, v);
+        if (fs_ind < (int)v) return -2;  // BandwidthIdxOutOfRange
+        p_bw = (int)v;
+    }
+    while ((1 << lastnz_bits) < ne / 2) lastnz_bits++;
+    LC3_PT(lastnz_bits, v);
+    const int lastnz = (int)((v + 1) << 1);
+    lc3_px_set(c, SI_LASTNZ, lastnz);
+    if (lastnz > ne) return -3;
+    LC3_PB(b);
+    lc3_px_set(c, SI_LSB_MODE, b);
+    lsb_mode_out = b;
+    LC3_PT(8, v);
+    lc3_px_set(c, SI_GG, (int)v);
+    const int num_tns = p_bw < 3 ? 1 : 2;
+    lc3_px_set(c, SI_NUM_TNS, num_tns);
+    ord[0] = 0;
+    ord[1] = 0;
+    for (int f = 0; f < num_tns; f++) {
+        LC3_PB(b);
+        ord[f] = b;
+    }
+    lc3_px_set(c, SI_ORD0, ord[0]);
+    lc3_px_set(c, SI_ORD1, ord[1]);
+    LC3_PB(b);
+    const int pitch_present = b;
+    lc3_px_set(c, SI_PITCH_PRESENT, b);
+    // read_sns_vq :131-200
+    LC3_PT(5, v);
+    lc3_px_set(c, SI_IND_LF, (int)v);
+    LC3_PT(5, v);
+    lc3_px_set(c, SI_IND_HF, (int)v);
+    LC3_PB(b);
+    const int submode_msb = b;
+    if (submode_msb == 0) LC3_PT(1, v);
+    else LC3_PT(2, v);
+    int g_ind = (int)v;
+    LC3_PB(b);
+    lc3_px_set(c, SI_LS_A, b);
+    int submode_lsb = 0, ls_indb = 0;
+    uint32_t idx_a, idx_b = 0;
+    if (submode_msb == 0) {
+        uint32_t tmp;
+        LC3_PT(25, tmp);
+        if (tmp >= 33460056u) return -4;  // PlcTriggerSns1OutOfRange
+        const uint32_t idx_bor = tmp / 2390004u;
+        idx_a = tmp - idx_bor * 2390004u;
+        int s = (int)idx_bor - 2;
+        if (s < 0) submode_lsb = 1;
+        s = s + submode_lsb * 2;
+        if (submode_lsb != 0) g_ind = (g_ind << 1) + s;
+        else {
+            idx_b = (uint32_t)s >> 1;
+            ls_indb = s & 1;
+        }
+    } else {
+        uint32_t tmp;
+        LC3_PT(24, tmp);
+        if (tmp >= 16708096u) return -5;  // PlcTriggerSns2OutOfRange
+        if (tmp >= 15158272u) {
+            tmp -= 15158272u;
+            submode_lsb = 1;
+            g_ind = (g_ind << 1) + (int)(tmp & 1u);
+            idx_a = tmp >> 1;
+        } else idx_a = tmp;
+    }
+    lc3_px_set(c, SI_LS_B, ls_indb);
+    lc3_px_set(c, SI_IDX_A, (int)idx_a);
+    lc3_px_set(c, SI_IDX_B, (int)idx_b);
+    lc3_px_set(c, SI_SUB_LSB, submode_lsb);
+    lc3_px_set(c, SI_SUB_MSB, submode_msb);
+    lc3_px_set(c, SI_G_IND, g_ind);
+    // read_long_term_post_filter_info :106-129
+    int ltpf_active = 0, pitch_index = 0;
+    if (pitch_present) {
+        LC3_PB(b);
+        ltpf_active = b;
+        LC3_PT(9, v);
+        pitch_index = (int)v;
+    }
+    lc3_px_set(c, SI_LTPF_ACTIVE, ltpf_active);
+    lc3_px_set(c, SI_PITCH_INDEX, pitch_index);
+    LC3_PT(3, v);
+    lc3_px_set(c, SI_NF, (int)v);
+    lc3_px_set(c, SI_BW, p_bw);
+    lastnz_out = lastnz;
+    num_tns_out = num_tns;
+    return 0;
+}
+
+// ac_decode (decoder/arithmetic_codec.rs:67-97) over a cumulative-frequency row of `nsym` int16 entries
+__device__ __forceinline__ int lc3_p_ac_decode16(lc3_parse_ctx &c, lc3_acdec &st, const int16_t *cum, const int16_t *freq,
+                                                 int nsym, int &sym) {
+    const uint32_t tmp = st.range >> 10, limit = tmp << 10;
+    if (st.low >= limit) return -1;
+    int val = nsym - 1;
+    while (st.low < tmp * (uint32_t)(int)cum[val]) val--;
+    st.low -= tmp * (uint32_t)(int)cum[val];
+    st.range = tmp * (uint32_t)(int)freq[val];
+    while (st.range < 0x10000u) {
+        st.low = (st.low << 8) & 0x00ffffffu;
+        if (c.head >= c.len) return -1;  // read_head_byte :42-50
+        st.low += (uint32_t)c.bytes[c.head++];
+        st.range <<= 8;
+    }
+    sym = val;
+    return 0;
+}
+// the same over a packed (cum | freq << 16) row of the 17-symbol spectral model; binary search for the largest j with
+// low >= tmp * cum[j] (cum is non-decreasing, cum[0] = 0) = the symbol the reference's top-down scan returns
+__device__ __forceinline__ int lc3_p_ac_decode_spec(lc3_parse_ctx &c, lc3_acdec &st, const uint32_t *row, int &sym) {
+    const uint32_t tmp = st.range >> 10, limit = tmp << 10;
+    if (st.low >= limit) return -1;
+    int lo = 0, hi = 16;
+#pragma unroll
+    for (int it = 0; it < 5; it++) {
+        const int mid = (lo + hi + 1) >> 1;
+        const int ge = st.low >= tmp * (row[mid] & 0xffffu);
+        lo = ge ? mid : lo;
+        hi = ge ? hi : mid - 1;
+    }
+    const uint32_t sv = row[lo];
+    st.low -= tmp * (sv & 0xffffu);
+    st.range = tmp * (sv >> 16);
+    while (st.range < 0x10000u) {
+        st.low = (st.low << 8) & 0x00ffffffu;
+        if (c.head >= c.len) return -1;
+        st.low += (uint32_t)c.bytes[c.head++];
+        st.range <<= 8;
+    }
+    sym = lo;
+    return 0;
+}
+
+// read_res_bit (decoder/arithmetic_codec.rs:339-383)
+__device__ __forceinline__ int lc3_p_res_bit(lc3_parse_ctx &c, int idx, int &nbits_res, int &cont) {
+    int bit;
+    if (nbits_res == 0) { cont = 0; return 0; }
+    if (lc3_p_bool(c, bit)) return -1;
+    nbits_res -= 1;
+    if (bit) {
+        const int32_t xv = lc3_px_get(c, LC3_PLANE_X + idx);
+        if (xv > 0) lc3_px_set(c, LC3_PLANE_X + idx, xv + 1);
+        else if (xv < 0) lc3_px_set(c, LC3_PLANE_X + idx, xv - 1);
+        else {
+            if (nbits_res == 0) { cont = 0; return 0; }
+            if (lc3_p_bool(c, bit)) return -1;
+            nbits_res -= 1;
+            lc3_px_set(c, LC3_PLANE_X + idx, bit ? -1 : 1);
+        }
+    }
+    cont = 1;
+    return 0;
+}
+
+// read_frame: side info + arithmetic_codec::decode up to (not including) the non-lsb residual bits, the noise seed
+// and the zero-frame flag, which the synthesis kernel derives lane-parallel from x.  Returns 0 when the frame parsed.
+__device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_ind, int n_ms_10) {
+    int lastnz = 0, lsb_mode = 0, num_tns = 0, ord[2];
+    int rc = lc3_parse_side_info(c, fs_ind, ne, lastnz, lsb_mode, num_tns, ord);
+    if (rc) return rc;
+    const int nbits = c.len * 8;
+    lc3_acdec st;
+    int sym = 0;
+    // ac_dec_init :57-65
+    if (!(c.head + 2 < c.len)) return -1;
+    st.low = ((uint32_t)c.bytes[c.head] << 16) | ((uint32_t)c.bytes[c.head + 1] << 8) | (uint32_t)c.bytes[c.head + 2];
+    c.head += 3;
+    st.range = 0x00ffffffu;
+    // decode_tns_data :304-337
+    {
+        const int wt = nbits < (n_ms_10 ? 480 : 360);
+        for (int k = 0; k < 16; k++) lc3_px_set(c, AD_RCI + k, 0);
+        for (int f = 0; f < 2; f++) {
+            int order = ord[f];
+            if (f < num_tns && order > 0) {
+                if (lc3_p_ac_decode16(c, st, LC3T_AC_TNS_ORDER_CUMFREQ[wt], LC3T_AC_TNS_ORDER_FREQ[wt], 8, sym)) return -2;
+                order = sym + 1;
+                for (int k = 0; k < order; k++) {
+                    int s2;
+                    if (lc3_p_ac_decode16(c, st, LC3T_AC_TNS_COEF_CUMFREQ[k], LC3T_AC_TNS_COEF_FREQ[k], 17, s2)) return -3;
+                    lc3_px_set(c, AD_RCI + f * 8 + k, s2);
+                }
+            }
+            lc3_px_set(c, AD_ORD0 + f, order);
+        }
+    }
+    // decode_spectral_data :211-302
+    const int ntup = lastnz / 2;
+    {
+        const int rate_flag = nbits > (160 + fs_ind * 160) ? 512 : 0;
+        int cctx = 0;
+        for (int tup = 0; tup < ntup; tup++) {
+            int t = cctx + rate_flag + ((tup * 2) > (ne / 2) ? 256 : 0), lev = 0, bit;
+            int32_t xk = 0, xk1 = 0;
+            sym = 0;
+            while (lev < 14) {
+                const int pki = c.lookup[t + (lev < 3 ? lev : 3) * 1024];
+                if (lc3_p_ac_decode_spec(c, st, c.cf + pki * 17, sym)) return -4;
+                if (sym < 16) break;
+                if (!lsb_mode || lev > 0) {
+                    if (lc3_p_bool(c, bit)) return -5;
+                    xk += (int32_t)((uint32_t)bit << lev);
+                    if (lc3_p_bool(c, bit)) return -5;
+                    xk1 += (int32_t)((uint32_t)bit << lev);
+                }
+                lev += 1;
+            }
+            if (lsb_mode) lc3_px_set(c, LC3_PLANE_LEV + tup, lev);  // written by TUPLE index, read by LINE index (:184-195)
+            const int a = sym & 3, b = sym >> 2;
+            xk += (int32_t)((uint32_t)a << lev);
+            xk1 += (int32_t)((uint32_t)b << lev);
+            if (xk > 0) {
+                if (lc3_p_bool(c, bit)) return -5;
+                if (bit) xk = -xk;
+            }
+            if (xk1 > 0) {
+                if (lc3_p_bool(c, bit)) return -5;
+                if (bit) xk1 = -xk1;
+            }
+            lc3_px_set(c, LC3_PLANE_X + 2 * tup, xk);
+            lc3_px_set(c, LC3_PLANE_X + 2 * tup + 1, xk1);
+            lev = lev < 3 ? lev : 3;
+            t = lev <= 1 ? 1 + (a + b) * (lev + 1) : 12 + lev;
+            cctx = (cctx & 15) * 16 + t;
+        }
+    }
+    for (int k = lastnz; k < ne; k++) lc3_px_set(c, LC3_PLANE_X + k, 0);  // :131-133
+    // calc_num_residual_bits :385-405
+    {
+        const int nbits_side = c.tail - 8;
+        const int nbits_ari = (c.head + 1 - 3) * 8 + 25 - lc3_ilog2(st.range);
+        if (nbits < nbits_side + nbits_ari) return -6;  // NegativeResidualNumBits
+        int nres = nbits - nbits_side - nbits_ari, cont;
+        lc3_px_set(c, AD_TAIL0, c.tail);
+        lc3_px_set(c, AD_NRES_MAX, nres);
+        lc3_px_set(c, AD_HEAD, c.head);
+        if (lsb_mode) {  // decode_residual_bits :184-206: refines the integers in place
+            for (int k = 0; k < lastnz; k += 2) {
+                // save_lev[k]: entries at or beyond the number of tuples were never written (zero in the reference)
+                const int lv = k < ntup ? lc3_px_get(c, LC3_PLANE_LEV + k) : 0;
+                if (lv > 0) {
+                    if (lc3_p_res_bit(c, k, nres, cont)) return -7;
+                    if (!cont) break;
+                    if (lc3_p_res_bit(c, k + 1, nres, cont)) return -7;
+                    if (!cont) break;
+                }
+            }
+        }
+    }
+    return 0;
+}

@@ -24,6 +24,7 @@
 #define LC3_U(x) ((int)__builtin_amdgcn_readfirstlane((int)(x)))
 #define LC3_UST(lv, v) do { if (lane == 0) (lv) = (v); } while (0)
 #define LC3_LDS_OR32(p, v) atomicOr((p), (v))
+#define LC3_LDS_OR32(p, v) atomicOr((p), (v))
 // symbol search of the range decoder: lane i tests symbol i, the highest passing lane is the symbol
 // (reference: linear search from the top, decoder/arithmetic_codec.rs:81-84)
 __device__ __forceinline__ int lc3_sym_search(const int16_t *cum, const int16_t *freq, int nsym, uint32_t low,
@@ -36,58 +37,6 @@ __device__ __forceinline__ int lc3_sym_search(const int16_t *cum, const int16_t 
     fval = (uint32_t)__builtin_amdgcn_readlane((int)fv, val);
     return val;
 }
-// ---- register-resident tables of the decoder's frame parser ------------------------------------------------
-// Lane p keeps distribution p of the spectral model (17 x (cum | freq << 16)), the 4096-byte context lookup is
-// spread as 1024 dwords over 16 registers x 64 lanes, and the frame itself sits in two registers.  All reads are
-// v_readlane with a wave-uniform lane select; uniform register selection is resolved by small decision trees.
-struct lc3_dec_tabs {
-    uint32_t row[17];
-    uint32_t lk[16];
-};
-__device__ __forceinline__ void lc3_dec_tabs_load(lc3_dec_tabs &T, lc3_reader &r, int lane) {
-#pragma unroll
-    for (int j = 0; j < 17; j++)
-        T.row[j] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[lane][j] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[lane][j] << 16);
-    const uint32_t *lk32 = (const uint32_t *)LC3T_AC_SPEC_LOOKUP;
-#pragma unroll
-    for (int q = 0; q < 16; q++) T.lk[q] = lk32[q * 64 + lane];
-    const uint32_t *f32 = (const uint32_t *)r.buf;  // LDS buffer, padded to 512 bytes
-    r.fr0 = f32[lane];
-    r.fr1 = f32[64 + lane];
-}
-#define LC3_FRAME_BYTE(r, i) \
-    ((((uint32_t)__builtin_amdgcn_readlane((int)(((i) >> 8) ? (r).fr1 : (r).fr0), ((i) >> 2) & 63)) >> (8 * ((i) & 3))) & 0xffu)
-template <int LO, int HI>
-__device__ __forceinline__ uint32_t lc3_pick_reg(const uint32_t (&a)[16], int q, int l) {
-    if constexpr (LO == HI) return (uint32_t)__builtin_amdgcn_readlane((int)a[LO], l);
-    else {
-        constexpr int MID = (LO + HI) / 2;
-        return q <= MID ? lc3_pick_reg<LO, MID>(a, q, l) : lc3_pick_reg<MID + 1, HI>(a, q, l);
-    }
-}
-__device__ __forceinline__ int lc3_tab_lookup(const lc3_dec_tabs &T, int idx) {
-    const int d = idx >> 2;
-    const uint32_t w = lc3_pick_reg<0, 15>(T.lk, d >> 6, d & 63);
-    return (int)((w >> (8 * (idx & 3))) & 0xffu);
-}
-// largest j in [LO, HI] with low >= tmp * cum[j] (cum is non-decreasing, cum[0] == 0): the symbol the reference's
-// top-down linear search returns (decoder/arithmetic_codec.rs:81-84)
-template <int LO, int HI>
-__device__ __forceinline__ int lc3_search_sym(const uint32_t (&row)[17], int pki, uint32_t low, uint32_t tmp, uint32_t &sv) {
-    if constexpr (LO == HI) {
-        sv = (uint32_t)__builtin_amdgcn_readlane((int)row[LO], pki);
-        return LO;
-    } else {
-        constexpr int MID = (LO + HI + 1) / 2;
-        const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)row[MID], pki);
-        if (low >= tmp * (s & 0xffffu)) return lc3_search_sym<MID, HI>(row, pki, low, tmp, sv);
-        return lc3_search_sym<LO, MID - 1>(row, pki, low, tmp, sv);
-    }
-}
-__device__ __forceinline__ int lc3_tab_search(const lc3_dec_tabs &T, int pki, uint32_t low, uint32_t tmp, uint32_t &sv) {
-    return lc3_search_sym<0, 16>(T.row, pki, low, tmp, sv);
-}
-
 #ifdef LC3_PROFILE
 // Diagnostic build (liblc3gpu_prof.so): lane 0 of every wave adds the shader-clock cycles between consecutive
 // stage stamps into a global table.  Stamp i accumulates the time since the previous stamp into slot i.
@@ -125,9 +74,59 @@ __global__ __launch_bounds__(64, 3) void lc3_encode_kernel(lc3_cfg cfg, lc3_enc_
     lc3_enc_state_store(L, lane, gst);
 }
 
+// Frame parser, one LANE per frame (lc3_dev_dec_parse.h).  256 frames per workgroup; the context lookup, the packed
+// (cum | freq) spectral model and the frames' bytes are staged in LDS with coalesced loads.  blockDim.x frames per
+// workgroup (256, or 128 for frames above 220 bytes so that the staging fits 64 KB of dynamic LDS):
+// 4096 + 64*17*4 + blockDim.x*nbytes bytes.
+__global__ __launch_bounds__(256) void lc3_parse_kernel(int ne, int fs_ind, int n_ms_10, const uint8_t *in,
+                                                        const uint8_t *bad, int32_t *planes, int nbytes, int n_frames) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *s_lookup = smem;
+    uint32_t *s_cf = (uint32_t *)(smem + 4096);
+    uint8_t *s_bytes = smem + 4096 + 64 * 17 * 4;
+    const int tid = threadIdx.x, fpb = blockDim.x;
+    const size_t f0 = (size_t)blockIdx.x * (size_t)fpb;
+    {
+        const uint32_t *lk32 = (const uint32_t *)LC3T_AC_SPEC_LOOKUP;
+        uint32_t *d32 = (uint32_t *)s_lookup;
+        for (int i = tid; i < 1024; i += fpb) d32[i] = lk32[i];
+        for (int i = tid; i < 64 * 17; i += fpb) {
+            const int p = i / 17, j = i - 17 * p;
+            s_cf[i] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[p][j] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[p][j] << 16);
+        }
+        const size_t remaining = (size_t)n_frames - f0;
+        const int nfr = remaining < (size_t)fpb ? (int)remaining : fpb;
+        const int total = nfr * nbytes;
+        const uint8_t *src = in + f0 * (size_t)nbytes;
+        if ((((uintptr_t)src) & 3u) == 0) {
+            const uint32_t *s32 = (const uint32_t *)src;
+            uint32_t *b32 = (uint32_t *)s_bytes;
+            for (int i = tid; i < total / 4; i += fpb) b32[i] = s32[i];
+            for (int i = (total & ~3) + tid; i < total; i += fpb) s_bytes[i] = src[i];
+        } else {
+            for (int i = tid; i < total; i += fpb) s_bytes[i] = src[i];
+        }
+    }
+    __syncthreads();
+    const size_t f = f0 + (size_t)tid;
+    if (f < (size_t)n_frames) {
+        lc3_parse_ctx c;
+        c.bytes = s_bytes + tid * nbytes;
+        c.len = nbytes;
+        c.lookup = s_lookup;
+        c.cf = s_cf;
+        c.plane = planes + (f >> 6) * (size_t)(LC3_PLANE_WORDS * 64) + (f & 63);
+        c.stride = 64;
+        c.head = 0;
+        c.tail = 0;
+        int rc = (bad && bad[f]) ? -100 : lc3_parse_frame(c, ne, fs_ind, n_ms_10);
+        lc3_px_set(c, AD_OK, rc == 0);
+    }
+}
+
 __global__ __launch_bounds__(64, 3) void lc3_decode_kernel(lc3_cfg cfg, lc3_dec_state *states, int first_channel,
-                                                       const uint8_t *in, const uint8_t *bad, int16_t *pcm, int nbytes,
-                                                       int n_frames, int fresh) {
+                                                          const uint8_t *in, const int32_t *planes, int16_t *pcm,
+                                                          int nbytes, int n_frames, int fresh) {
     __shared__ lc3_dec_lds L;
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
@@ -136,8 +135,8 @@ __global__ __launch_bounds__(64, 3) void lc3_decode_kernel(lc3_cfg cfg, lc3_dec_
     else lc3_dec_state_load(L, lane, gst);
     for (int t = 0; t < n_frames; t++) {
         const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
-        const int force_plc = bad ? (int)bad[f] : 0;
-        lc3_decode_frame_wave(cfg, L, lane, in + f * (size_t)nbytes, nbytes, pcm + f * (size_t)cfg.nf, force_plc, gst);
+        const int32_t *plane = planes + (f >> 6) * (size_t)(LC3_PLANE_WORDS * 64) + (f & 63);
+        lc3_decode_frame_wave(cfg, L, lane, in + f * (size_t)nbytes, nbytes, pcm + f * (size_t)cfg.nf, plane, 64, gst);
     }
     lc3_dec_state_store(L, lane, gst);
 }
@@ -206,6 +205,8 @@ struct lc3gpu_decoder {
     lc3_dec_state *d_states = nullptr;
     uint8_t *d_in1 = nullptr;
     int16_t *d_pcm1 = nullptr;
+    int32_t *d_planes = nullptr;   // parsed-frame planes [blocks of 64 frames][LC3_PLANE_WORDS][64]
+    size_t planes_frames = 0;      // capacity in frames (multiple of 64)
 };
 
 extern "C" {
@@ -405,11 +406,23 @@ int lc3gpu_encoder_state_load(lc3gpu_encoder *e, const void *host_src) {
 }
 
 // ---------------------------------------------------------------------------------------------
+static int decoder_reserve_planes(lc3gpu_decoder *d, size_t frames) {
+    const size_t need = (frames + 63) / 64 * 64;
+    if (need <= d->planes_frames) return LC3GPU_OK;
+    // growing synchronises: earlier launches may still read the old buffer
+    HIP_TRY(hipDeviceSynchronize());
+    if (d->d_planes) (void)hipFree(d->d_planes);
+    d->d_planes = nullptr;
+    d->planes_frames = 0;
+    HIP_TRY(hipMalloc((void **)&d->d_planes, need * (size_t)LC3_PLANE_WORDS * sizeof(int32_t)));
+    d->planes_frames = need;
+    return LC3GPU_OK;
+}
+
 static int decoder_init_states(lc3gpu_decoder *d) {
     // decoder state is materialised eagerly (fresh = 1, zero frames): PLC counters must survive range launches
-    uint8_t *dummy = d->d_in1;
     hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)d->num_channels), dim3(64), 0, nullptr, d->h.c, d->d_states, 0,
-                       dummy, (const uint8_t *)nullptr, d->d_pcm1, 20, 0, 1);
+                       (const uint8_t *)d->d_in1, (const int32_t *)d->d_planes, d->d_pcm1, 20, 0, 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return LC3GPU_OK;
@@ -434,7 +447,8 @@ int lc3gpu_decoder_create(lc3gpu_decoder **out, int num_channels, int frame_us, 
         lc3gpu_decoder_destroy(d);
         return LC3GPU_EHIP;
     }
-    rc = decoder_init_states(d);
+    rc = decoder_reserve_planes(d, (size_t)num_channels);
+    if (rc == LC3GPU_OK) rc = decoder_init_states(d);
     if (rc) { lc3gpu_decoder_destroy(d); return rc; }
     *out = d;
     return LC3GPU_OK;
@@ -445,6 +459,7 @@ int lc3gpu_decoder_destroy(lc3gpu_decoder *d) {
     if (d->d_states) (void)hipFree(d->d_states);
     if (d->d_in1) (void)hipFree(d->d_in1);
     if (d->d_pcm1) (void)hipFree(d->d_pcm1);
+    if (d->d_planes) (void)hipFree(d->d_planes);
     if (d->h.d_tables) (void)hipFree(d->h.d_tables);
     delete d;
     return LC3GPU_OK;
@@ -461,8 +476,17 @@ static int decode_launch(lc3gpu_decoder *d, int first, int n, const uint8_t *d_i
     if (first < 0 || n <= 0 || first + n > d->num_channels) return LC3GPU_ECHANNEL;
     if (nbytes < 1 || nbytes > LC3_MAX_NE || n_frames <= 0) return LC3GPU_ELENGTH;
     if (((uintptr_t)d_pcm & 3u) != 0) return LC3GPU_EINVAL;
+    // stage 1: parse all n * n_frames frames, one lane each (stateless); stage 2: synthesis, one wave per stream
+    const size_t frames = (size_t)n * (size_t)n_frames;
+    int rc = decoder_reserve_planes(d, frames);
+    if (rc) return rc;
+    const unsigned fpb = nbytes <= 220 ? 256u : 128u;
+    const size_t lds = 4096 + 64 * 17 * 4 + (size_t)fpb * (size_t)nbytes;
+    hipLaunchKernelGGL(lc3_parse_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, d->h.c.ne,
+                       d->h.c.fs_ind, d->h.c.n_ms_10, d_in, d_bad, d->d_planes, nbytes, (int)frames);
+    HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)n), dim3(64), 0, stream, d->h.c, d->d_states, first, d_in,
-                       d_bad, d_pcm, nbytes, n_frames, 0);
+                       (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0);
     HIP_TRY(hipGetLastError());
     return LC3GPU_OK;
 }

@@ -24,29 +24,6 @@ static pthread_barrier_t g_bar;
 #define LC3_U(x) ((int)(x))
 #define LC3_UST(lv, v) ((lv) = (v))
 #define LC3_LDS_OR32(p, v) __atomic_fetch_or((p), (v), __ATOMIC_RELAXED)
-static inline int lc3_sym_search(const int16_t *cum, const int16_t *freq, int nsym, uint32_t low, uint32_t tmp, int lane,
-                                 uint32_t &cval, uint32_t &fval) {
-    (void)lane;
-    int val = 0;
-    for (int i = 0; i < nsym; i++)  // highest symbol whose test holds (what ballot + clz computes on the GPU)
-        if (low >= tmp * (uint32_t)(int)cum[i]) val = i;
-    cval = (uint32_t)(int)cum[val];
-    fval = (uint32_t)(int)freq[val];
-    return val;
-}
-
-// decoder parser tables: the GPU keeps them in vector registers; the emulator reads the tables directly
-struct lc3_dec_tabs { int unused; };
-static inline void lc3_dec_tabs_load(lc3_dec_tabs &, lc3_reader &, int) {}
-#define LC3_FRAME_BYTE(r, i) ((uint32_t)(r).buf[(i)])
-static inline int lc3_tab_lookup(const lc3_dec_tabs &, int idx) { return LC3T_AC_SPEC_LOOKUP[idx]; }
-static inline int lc3_tab_search(const lc3_dec_tabs &, int pki, uint32_t low, uint32_t tmp, uint32_t &sv) {
-    int val = 16;
-    while (low < tmp * (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[pki][val]) val--;  // reference order (arithmetic_codec.rs:81-84)
-    sv = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[pki][val] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[pki][val] << 16);
-    return val;
-}
-
 #include "../../lc3-codec_amd/csrc/lc3_dev_dec.h"
 #include "../../lc3-codec_amd/csrc/lc3_dev_enc.h"
 #include "../../lc3-codec_amd/csrc/lc3_host_plan.h"
@@ -64,7 +41,8 @@ struct Job {
     const int16_t *pcm_in;
     uint8_t *bytes_out;
     const uint8_t *bytes_in;
-    const uint8_t *bad;
+    const int32_t *planes;  // parsed frames of this stream: frame t at column index (frame0 + t)
+    size_t frame0;
     int16_t *pcm_out;
     float *dbg;
 };
@@ -85,8 +63,12 @@ void *lane_main(void *arg) {
         if (j->fresh) lc3_dec_state_init(L, lane, j->dst);
         else lc3_dec_state_load(L, lane, j->dst);
         for (int t = 0; t < j->n_frames; t++)
+        {
+            const size_t f = j->frame0 + (size_t)t;
+            const int32_t *plane = j->planes + (f >> 6) * (size_t)(LC3_PLANE_WORDS * 64) + (f & 63);
             lc3_decode_frame_wave(j->cfg, L, lane, j->bytes_in + (size_t)t * j->nbytes, j->nbytes,
-                                  j->pcm_out + (size_t)t * j->cfg.nf, j->bad ? j->bad[t] : 0, j->dst);
+                                  j->pcm_out + (size_t)t * j->cfg.nf, plane, 64, j->dst);
+        }
         lc3_dec_state_store(L, lane, j->dst);
     }
     return 0;
@@ -151,13 +133,35 @@ int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8
     j.n_frames = T;
     j.nbytes = nbytes;
     j.fresh = 1;
+    // stage 1: the lane-per-frame parser (lc3_dev_dec_parse.h) -- on the GPU 64 frames per wave, here a plain loop
+    const size_t frames = (size_t)S * (size_t)T;
+    std::vector<int32_t> planes(((frames + 63) / 64) * 64 * LC3_PLANE_WORDS, 0);
+    std::vector<uint32_t> cf(64 * 17);
+    for (int p = 0; p < 64; p++)
+        for (int q = 0; q < 17; q++)
+            cf[(size_t)p * 17 + q] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[p][q] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[p][q] << 16);
+    for (size_t f = 0; f < frames; f++) {
+        lc3_parse_ctx c;
+        c.bytes = bytes + f * (size_t)nbytes;
+        c.len = nbytes;
+        c.lookup = LC3T_AC_SPEC_LOOKUP;
+        c.cf = cf.data();
+        c.plane = planes.data() + (f >> 6) * (size_t)(LC3_PLANE_WORDS * 64) + (f & 63);
+        c.stride = 64;
+        c.head = 0;
+        c.tail = 0;
+        int rc = (bad && bad[f]) ? -100 : lc3_parse_frame(c, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10);
+        lc3_px_set(c, AD_OK, rc == 0);
+    }
+    // stage 2: synthesis, one emulated wave per stream
     lc3_dec_lds *L = (lc3_dec_lds *)calloc(1, sizeof(lc3_dec_lds));
     lc3_dec_state *st = (lc3_dec_state *)calloc(1, sizeof(lc3_dec_state));
     j.DL = L;
     j.dst = st;
+    j.planes = planes.data();
     for (int s = 0; s < S; s++) {
         j.bytes_in = bytes + (size_t)s * T * nbytes;
-        j.bad = bad ? bad + (size_t)s * T : 0;
+        j.frame0 = (size_t)s * T;
         j.pcm_out = pcm + (size_t)s * T * j.cfg.nf;
         run_wave(j);
     }
