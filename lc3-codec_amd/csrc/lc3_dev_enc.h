@@ -3,6 +3,7 @@
 // See lc3_dev_common.h for the execution model and the bit-exactness contract.
 #pragma once
 #include "lc3_dev_common.h"
+#include "lc3_dev_enc_pack.h"
 
 // ------------------------------------------------------------------------------------------
 // Persistent per-stream encoder state as it lives in HBM between launches.
@@ -25,7 +26,7 @@ struct lc3_enc_state {
     int reset_offset_old;
     float nbits_offset_old;
     int nbits_est_old;
-    int bitstream_fallbacks;  // diagnostic counter: frames written by the serial bitstream path (not in the reference)
+    int pad;
 };
 #define LC3_ENC_STATE_WORDS ((int)(sizeof(lc3_enc_state) / 4))
 
@@ -38,7 +39,6 @@ struct lc3_enc_lds {
     float eb[64];            // band energies
     int16_t t[2 * LC3_MAX_NF];   // MDCT time buffer (ModDiscreteCosTrans::freq)
     int16_t xq[LC3_MAX_NE];  // quantised spectrum
-    alignas(16) uint8_t out[LC3_MAX_NE]; // frame bytes staging (32-bit LDS atomics on it)
     uint8_t res_bits[LC3_MAX_NE];
     float sm[192];           // small scratch (per-stage)
     int ism[64];
@@ -1049,7 +1049,6 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_
     // bit estimate a tuple sees is (sum over lower lanes) + (running sum inside the lane).
     {
         uint8_t *ttab = (uint8_t *)L.fb + 256;         // tt per tuple (<= 200 bytes)
-        uint32_t *tinfo = (uint32_t *)((uint8_t *)L.fb + 1024);  // packed tuple info, reused by the bitstream writer
         uint32_t *part = (uint32_t *)L.sm;             // [0,64) est sums, [64,128) lsb sums, [128,192) hi nz / cand
         const int ntup_all = ne / 2, k0 = 4 * lane;
         uint32_t loc[4];   // a | b << 8 | n_esc << 16 | nonzero << 24 for the lane's tuples
@@ -1106,7 +1105,6 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_
                 if (n_esc > 0 && mode_flag) lsb_sum += 2 + ((v >> 25) & 1) + ((v >> 26) & 1);
                 est4[j] = est;
                 run += est;
-                tinfo[k] = (uint32_t)t | ((uint32_t)n_esc << 12) | (af << 16) | (bf << 18);
             }
         }
         part[lane] = run;
@@ -1382,558 +1380,12 @@ __device__ __noinline__ void lc3_enc_residual_noise(const lc3_cfg &c, lc3_enc_ld
 }
 
 // ------------------------------------------------------------------------------------------
-// E20/E21: bitstream (encoder/bitstream_encoding.rs:77-429, encoder/buffer_writer.rs:11-67)
-// ------------------------------------------------------------------------------------------
-// All of this runs in "uniform-scalar" style (see lc3_dev_dec.h): the writer state is wave-uniform (SGPRs on the
-// GPU), lane 0 performs the byte updates in LDS.
-struct lc3_bitwriter {
-    uint8_t *buf;
-    int nbytes, nbits, bp, bp_side, mask_side, lane;
-    uint32_t low, range;
-    int cache, carry, carry_count;
-};
-__device__ __forceinline__ void lc3_bw_bool_backward(lc3_bitwriter &w, int bit) {  // buffer_writer.rs:27-40
-    if (w.lane == 0 && w.bp_side >= 0 && w.bp_side < w.nbytes) {
-        if (!bit) w.buf[w.bp_side] &= (uint8_t)~w.mask_side;
-        else w.buf[w.bp_side] |= (uint8_t)w.mask_side;
-    }
-    if (w.mask_side == 0x80) {
-        w.mask_side = 1;
-        w.bp_side -= 1;
-    } else w.mask_side <<= 1;
-}
-__device__ __forceinline__ void lc3_bw_uint_backward(lc3_bitwriter &w, uint32_t val, int nbits) {  // :19-25
-    for (int i = 0; i < nbits; i++) {
-        lc3_bw_bool_backward(w, (int)(val & 1u));
-        val >>= 1;
-    }
-}
-__device__ __forceinline__ void lc3_bw_byte_forward(lc3_bitwriter &w, int val) {  // :55-58
-    if (w.lane == 0 && w.bp >= 0 && w.bp < w.nbytes) w.buf[w.bp] = (uint8_t)val;
-    w.bp += 1;
-}
-__device__ __forceinline__ void lc3_bw_uint_forward(lc3_bitwriter &w, unsigned val, int nbits) {  // :42-53
-    unsigned mask = 0x80;
-    for (int i = 0; i < nbits; i++) {
-        if (w.lane == 0 && w.bp >= 0 && w.bp < w.nbytes) {
-            if (((val & 0xff) & mask) == 0) w.buf[w.bp] &= (uint8_t)~mask;
-            else w.buf[w.bp] |= (uint8_t)mask;
-        }
-        mask >>= 1;
-    }
-}
-__device__ __forceinline__ void lc3_ac_shift(lc3_bitwriter &w) {  // bitstream_encoding.rs:397-415
-    if (w.low < 0x00ff0000u || w.carry == 1) {
-        if (w.cache >= 0) lc3_bw_byte_forward(w, (w.cache + w.carry) & 0xff);
-        while (w.carry_count > 0) {
-            lc3_bw_byte_forward(w, (w.carry + 0xff) & 0xff);
-            w.carry_count -= 1;
-        }
-        w.cache = (int)(w.low >> 16);
-        w.carry = 0;
-    } else w.carry_count += 1;
-    w.low <<= 8;
-    w.low &= 0x00ffffffu;
-}
-__device__ __forceinline__ void lc3_ac_encode(lc3_bitwriter &w, int cum_freq, int sym_freq) {  // :417-429
-    uint32_t r = w.range >> 10;
-    w.low += r * (uint32_t)cum_freq;
-    if ((w.low >> 24) != 0) w.carry = 1;
-    w.low &= 0x00ffffffu;
-    w.range = r * (uint32_t)sym_freq;
-    while (w.range < 0x10000u) {
-        w.range <<= 8;
-        lc3_ac_shift(w);
-    }
-}
-
-__device__ __noinline__ void lc3_enc_bitstream_serial(const lc3_cfg &c, lc3_enc_lds &L, int lane, int bw_ind_in, int nbits_bw_in,
-                                                  const lc3_sns_res &sns_in, const lc3_tns_res &tns_in,
-                                                  const lc3_ltpf_res &ltpf_in, const lc3_quant_res &spec_in,
-                                                  int n_res_bits_in, int noise_factor_in, int nbytes_in) {
-    // arguments of a non-inlined device function arrive in vector registers: re-establish wave-uniformity so that
-    // the serial coder below is scalarised
-    const int nbytes = LC3_U(nbytes_in);
-    // init :138-144: the frame is zero-filled first (lane-parallel)
-    for (int i = lane; i < nbytes; i += LC3_WAVE) L.out[i] = 0;
-    LC3_SYNC();
-    if (LC3_UNIFORM_LEADER(lane)) {
-        const int ne = LC3_U(c.ne);
-        const int bw_ind = LC3_U(bw_ind_in), nbits_bw = LC3_U(nbits_bw_in), n_res_bits = LC3_U(n_res_bits_in);
-        const int noise_factor = LC3_U(noise_factor_in);
-        lc3_sns_res sns;
-        sns.ind_lf = LC3_U(sns_in.ind_lf); sns.ind_hf = LC3_U(sns_in.ind_hf); sns.shape_j = LC3_U(sns_in.shape_j);
-        sns.gind = LC3_U(sns_in.gind); sns.ls_inda = LC3_U(sns_in.ls_inda); sns.ls_indb = LC3_U(sns_in.ls_indb);
-        sns.index_joint_j = (uint32_t)LC3_U(sns_in.index_joint_j);
-        lc3_tns_res tns;
-        tns.nbits_tns = 0; tns.lpc_weighting = LC3_U(tns_in.lpc_weighting);
-        tns.num_tns_filters = LC3_U(tns_in.num_tns_filters);
-        tns.rc_order[0] = LC3_U(tns_in.rc_order[0]); tns.rc_order[1] = LC3_U(tns_in.rc_order[1]);
-        lc3_ltpf_res ltpf;
-        ltpf.pitch_index = LC3_U(ltpf_in.pitch_index); ltpf.pitch_present = LC3_U(ltpf_in.pitch_present);
-        ltpf.ltpf_active = LC3_U(ltpf_in.ltpf_active); ltpf.nbits_ltpf = 0;
-        lc3_quant_res spec;
-        spec.gg_ind = LC3_U(spec_in.gg_ind); spec.lsb_mode = LC3_U(spec_in.lsb_mode);
-        spec.rate_flag = LC3_U(spec_in.rate_flag); spec.lastnz_trunc = LC3_U(spec_in.lastnz_trunc);
-        spec.nbits_spec = 0; spec.nbits_lsb = 0; spec.nbits_trunc = 0; spec.gg = 0.0f;
-        const int *rc_i = L.ism + 16;
-        uint8_t *lsbs = (uint8_t *)L.fa;  // LSB list for lsb_mode (<= 3840 entries used in practice << 1920*2 bytes)
-        const int lsbs_cap = (int)(sizeof(L.fa) + sizeof(L.fb));
-        int nlsbs = 0;
-        lc3_bitwriter w;
-        w.lane = lane;
-        w.buf = L.out;
-        w.nbytes = nbytes;
-        w.nbits = nbytes * 8;
-        w.bp = 0;
-        w.bp_side = nbytes - 1;
-        w.mask_side = 1;
-        // side information :92-112 (layout: SURVEY App. E)
-        if (nbits_bw > 0) lc3_bw_uint_backward(w, (uint32_t)bw_ind, nbits_bw);
-        {
-            int nb = 0;
-            while ((1 << nb) < ne / 2) nb++;
-            lc3_bw_uint_backward(w, (uint32_t)((spec.lastnz_trunc >> 1) - 1), nb);
-        }
-        lc3_bw_bool_backward(w, spec.lsb_mode);
-        lc3_bw_uint_backward(w, (uint32_t)spec.gg_ind, 8);
-        for (int f = 0; f < tns.num_tns_filters; f++) lc3_bw_bool_backward(w, tns.rc_order[f] != 0);
-        lc3_bw_bool_backward(w, ltpf.pitch_present);
-        lc3_bw_uint_backward(w, (uint32_t)sns.ind_lf, 5);
-        lc3_bw_uint_backward(w, (uint32_t)sns.ind_hf, 5);
-        {
-            const int submode_msb = (sns.shape_j >> 1) != 0;
-            lc3_bw_bool_backward(w, submode_msb);
-            lc3_bw_uint_backward(w, (uint32_t)(sns.gind >> LC3T_SNS_GAIN_LSB_BITS[sns.shape_j]),
-                                 LC3T_SNS_GAIN_MSB_BITS[sns.shape_j]);
-            lc3_bw_bool_backward(w, sns.ls_inda != 0);
-            if (!submode_msb) {
-                lc3_bw_uint_backward(w, sns.index_joint_j, 13);
-                lc3_bw_uint_backward(w, sns.index_joint_j >> 13, 12);
-            } else {
-                lc3_bw_uint_backward(w, sns.index_joint_j, 12);
-                lc3_bw_uint_backward(w, sns.index_joint_j >> 12, 12);
-            }
-        }
-        if (ltpf.pitch_present) {
-            lc3_bw_bool_backward(w, ltpf.ltpf_active);
-            lc3_bw_uint_backward(w, (uint32_t)ltpf.pitch_index, 9);
-        }
-        lc3_bw_uint_backward(w, (uint32_t)noise_factor, 3);
-        // ac_enc_init :216-222
-        w.low = 0;
-        w.range = 0x00ffffffu;
-        w.cache = -1;
-        w.carry = 0;
-        w.carry_count = 0;
-        // tns_data :224-244
-        for (int f = 0; f < tns.num_tns_filters; f++) {
-            if (tns.rc_order[f] > 0) {
-                lc3_ac_encode(w, LC3T_AC_TNS_ORDER_CUMFREQ[tns.lpc_weighting][tns.rc_order[f] - 1],
-                              LC3T_AC_TNS_ORDER_FREQ[tns.lpc_weighting][tns.rc_order[f] - 1]);
-                for (int k = 0; k < tns.rc_order[f]; k++) {
-                    int ri = LC3_U(rc_i[k + 8 * f]);
-                    ri = ri < 0 ? 0 : (ri > 16 ? 16 : ri);
-                    lc3_ac_encode(w, LC3T_AC_TNS_COEF_CUMFREQ[k][ri], LC3T_AC_TNS_COEF_FREQ[k][ri]);
-                }
-            }
-        }
-        // spectral_data :246-326
-        {
-            int cctx = 0;
-            for (int k = 0; k < spec.lastnz_trunc; k += 2) {
-                int t = cctx + spec.rate_flag + (k > ne / 2 ? 256 : 0), lev = 0;
-                const int q0 = (int)(int16_t)LC3_U(L.xq[k]), q1 = (int)(int16_t)LC3_U(L.xq[k + 1]);
-                unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
-                unsigned a_lsb = a, b_lsb = b;
-                int lsb0 = 0, lsb1 = 0;
-                while ((a > b ? a : b) >= 4) {
-                    int pki = LC3T_AC_SPEC_LOOKUP[t + (lev < 3 ? lev : 3) * 1024];
-                    lc3_ac_encode(w, LC3T_AC_SPEC_CUMFREQ[pki][16], LC3T_AC_SPEC_FREQ[pki][16]);
-                    if (spec.lsb_mode && lev == 0) {
-                        lsb0 = (int)(a & 1u);
-                        lsb1 = (int)(b & 1u);
-                    } else {
-                        lc3_bw_bool_backward(w, (a & 1u) == 1u);
-                        lc3_bw_bool_backward(w, (b & 1u) == 1u);
-                    }
-                    a >>= 1;
-                    b >>= 1;
-                    lev += 1;
-                }
-                int pki = LC3T_AC_SPEC_LOOKUP[t + (lev < 3 ? lev : 3) * 1024];
-                int sym = (int)(a + 4 * b);
-                lc3_ac_encode(w, LC3T_AC_SPEC_CUMFREQ[pki][sym], LC3T_AC_SPEC_FREQ[pki][sym]);
-                if (spec.lsb_mode && lev > 0) {
-                    a_lsb >>= 1;
-                    b_lsb >>= 1;
-                    if (nlsbs < lsbs_cap) LC3_UST(lsbs[nlsbs], (uint8_t)lsb0);
-                    nlsbs++;
-                    if (a_lsb == 0 && q0 != 0) {
-                        if (nlsbs < lsbs_cap) LC3_UST(lsbs[nlsbs], (uint8_t)(q0 > 0 ? 0 : 1));
-                        nlsbs++;
-                    }
-                    if (nlsbs < lsbs_cap) LC3_UST(lsbs[nlsbs], (uint8_t)lsb1);
-                    nlsbs++;
-                    if (b_lsb == 0 && q1 != 0) {
-                        if (nlsbs < lsbs_cap) LC3_UST(lsbs[nlsbs], (uint8_t)(q1 > 0 ? 0 : 1));
-                        nlsbs++;
-                    }
-                }
-                if (a_lsb > 0) lc3_bw_bool_backward(w, q0 <= 0);
-                if (b_lsb > 0) lc3_bw_bool_backward(w, q1 <= 0);
-                lev = lev < 3 ? lev : 3;
-                t = lev <= 1 ? 1 + (int)(a + b) * (lev + 1) : 12 + lev;
-                cctx = (cctx & 15) * 16 + t;
-            }
-        }
-        // residual_data_and_finalization :328-352
-        {
-            int nbits_side = w.nbits - (8 * w.bp_side + 8 - lc3_ilog2((uint32_t)w.mask_side));
-            int nbits_ari = w.bp * 8 + 25 - lc3_ilog2(w.range);  // nbits_side_forcast :64-75
-            if (w.carry >= 0) nbits_ari += 8;
-            if (w.carry_count > 0) nbits_ari += w.carry_count * 8;
-            int n_enc = w.nbits - (nbits_side + nbits_ari);
-            if (n_enc < 0) n_enc = 0;
-            if (!spec.lsb_mode) {
-                for (int k = 0; k < n_enc && k < n_res_bits; k++) lc3_bw_bool_backward(w, LC3_U(L.res_bits[k]));
-            } else {
-                if (n_enc > nlsbs) n_enc = nlsbs;
-                for (int k = 0; k < n_enc; k++) lc3_bw_bool_backward(w, LC3_U(lsbs[k]) == 1);
-            }
-        }
-        // ac_enc_finish :354-395
-        {
-            int bits = 1;
-            while ((w.range >> (24 - bits)) == 0) bits++;
-            uint32_t mask = 0x00ffffffu >> bits;
-            uint32_t val = w.low + mask;
-            uint32_t over1 = val >> 24;
-            uint32_t high = w.low + w.range;
-            uint32_t over2 = high >> 24;
-            val &= 0x00ffffffu & ~mask;
-            if (over1 == over2) {
-                if ((val + mask) >= high) {
-                    bits += 1;
-                    mask >>= 1;
-                    val = ((w.low + mask) & 0x00ffffffu) & ~mask;
-                }
-                if (val < w.low) w.carry = 1;
-            }
-            w.low = val;
-            while (bits > 0) {
-                lc3_ac_shift(w);
-                bits -= 8;
-            }
-            bits += 8;
-            if (w.carry_count > 0) {
-                lc3_bw_byte_forward(w, w.cache & 0xff);
-                while (w.carry_count > 1) {
-                    lc3_bw_byte_forward(w, 0xff);
-                    w.carry_count -= 1;
-                }
-                lc3_bw_uint_forward(w, 0xffu >> (8 - bits), bits);
-            } else {
-                lc3_bw_uint_forward(w, (unsigned)w.cache, bits);
-            }
-        }
-    }
-    LC3_SYNC();
-}
-
-// ------------------------------------------------------------------------------------------
-// Fast path of the bitstream writer.  The reference interleaves, tuple by tuple, range-coder symbols (bytes
-// growing forward from byte 0) with sign / LSB bits (growing backward from the tail).  The two regions are
-// disjoint in a frame that respects its bit budget, so their writes commute:
-//   1. side information (serial, ~75 bits);
-//   2. one lane per group of 4 tuples: the (cum, freq) pair of every symbol from the context tables -> a symbol
-//      list in LDS (the table walks, which dominate the serial cost, now overlap across 64 lanes), every backward
-//      bit OR-ed straight into its final position (prefix sums give each tuple its offsets), LSB list for lsb_mode;
-//   3. the range coder proper walks the symbol list serially (pure 24-bit integer state, wave-uniform);
-//   4. residual bits + termination as in the reference.
-// If the forward and backward regions would meet (only possible when the bit estimate was violated) or the symbol
-// list does not fit, the frame is redone by lc3_enc_bitstream_serial, so the result is always the reference's.
-// ------------------------------------------------------------------------------------------
-__device__ __noinline__ void lc3_enc_bitstream(const lc3_cfg &c, lc3_enc_lds &L, int lane, int bw_ind_in, int nbits_bw_in,
-                                               const lc3_sns_res &sns_in, const lc3_tns_res &tns_in,
-                                               const lc3_ltpf_res &ltpf_in, const lc3_quant_res &spec_in,
-                                               int n_res_bits_in, int noise_factor_in, int nbytes_in) {
-    const int nbytes = LC3_U(nbytes_in), ne = LC3_U(c.ne);
-    const int lsb_mode = LC3_U(spec_in.lsb_mode), lastnz_trunc = LC3_U(spec_in.lastnz_trunc);
-    const int n_res_bits = LC3_U(n_res_bits_in);
-    uint32_t *symlist = (uint32_t *)L.spec;                        // cum | freq << 16; spec and fa are contiguous and
-                                                                   // dead by now: capacity 960 symbols
-    uint8_t *lsbs = (uint8_t *)L.fb;                               // lsb_mode LSB/sign list, capacity 1024
-    const uint32_t *tinfo = (const uint32_t *)((uint8_t *)L.fb + 1024);  // from lc3_quantize_spectrum
-    uint32_t *part = (uint32_t *)L.sm;                             // 3 x 64 per-lane counts
-    int *bs = L.ism + 40;                                          // cross-phase scalars
-    const int SYM_CAP = 960, LSB_CAP = 1024;
-    for (int i = lane; i < nbytes; i += LC3_WAVE) L.out[i] = 0;    // init :138-144
-    LC3_SYNC();
-    // ---- phase 1: side information (uniform serial), App. E layout
-    if (LC3_UNIFORM_LEADER(lane)) {
-        lc3_bitwriter w;
-        w.lane = lane;
-        w.buf = L.out;
-        w.nbytes = nbytes;
-        w.nbits = nbytes * 8;
-        w.bp = 0;
-        w.bp_side = nbytes - 1;
-        w.mask_side = 1;
-        const int nbits_bw = LC3_U(nbits_bw_in);
-        if (nbits_bw > 0) lc3_bw_uint_backward(w, (uint32_t)LC3_U(bw_ind_in), nbits_bw);
-        {
-            int nb = 0;
-            while ((1 << nb) < ne / 2) nb++;
-            lc3_bw_uint_backward(w, (uint32_t)((lastnz_trunc >> 1) - 1), nb);
-        }
-        lc3_bw_bool_backward(w, lsb_mode);
-        lc3_bw_uint_backward(w, (uint32_t)LC3_U(spec_in.gg_ind), 8);
-        const int num_tns = LC3_U(tns_in.num_tns_filters);
-        for (int f = 0; f < num_tns; f++) lc3_bw_bool_backward(w, LC3_U(tns_in.rc_order[f]) != 0);
-        const int pitch_present = LC3_U(ltpf_in.pitch_present);
-        lc3_bw_bool_backward(w, pitch_present);
-        lc3_bw_uint_backward(w, (uint32_t)LC3_U(sns_in.ind_lf), 5);
-        lc3_bw_uint_backward(w, (uint32_t)LC3_U(sns_in.ind_hf), 5);
-        {
-            const int shape_j = LC3_U(sns_in.shape_j);
-            const uint32_t joint = (uint32_t)LC3_U(sns_in.index_joint_j);
-            const int submode_msb = (shape_j >> 1) != 0;
-            lc3_bw_bool_backward(w, submode_msb);
-            lc3_bw_uint_backward(w, (uint32_t)(LC3_U(sns_in.gind) >> LC3T_SNS_GAIN_LSB_BITS[shape_j]),
-                                 LC3T_SNS_GAIN_MSB_BITS[shape_j]);
-            lc3_bw_bool_backward(w, LC3_U(sns_in.ls_inda) != 0);
-            if (!submode_msb) {
-                lc3_bw_uint_backward(w, joint, 13);
-                lc3_bw_uint_backward(w, joint >> 13, 12);
-            } else {
-                lc3_bw_uint_backward(w, joint, 12);
-                lc3_bw_uint_backward(w, joint >> 12, 12);
-            }
-        }
-        if (pitch_present) {
-            lc3_bw_bool_backward(w, LC3_U(ltpf_in.ltpf_active));
-            lc3_bw_uint_backward(w, (uint32_t)LC3_U(ltpf_in.pitch_index), 9);
-        }
-        lc3_bw_uint_backward(w, (uint32_t)LC3_U(noise_factor_in), 3);
-        // number of backward bits so far == nbits_side_written()
-        LC3_UST(bs[0], w.nbits - (8 * w.bp_side + 8 - lc3_ilog2((uint32_t)w.mask_side)));
-    }
-    LC3_SYNC();
-    const int side_bits = bs[0];
-    // ---- phase 2: per-tuple symbols and backward bits, lane l owns tuples 4l .. 4l+3
-    const int ntup = lastnz_trunc / 2, k0 = 4 * lane;
-    {
-        uint32_t ns = 0, nb = 0, nl = 0;
-        for (int j = 0; j < 4; j++) {
-            const int k = k0 + j;
-            if (k < ntup) {
-                const uint32_t ti = tinfo[k];
-                const int n_esc = (int)((ti >> 12) & 15);
-                const int q0 = L.xq[2 * k], q1 = L.xq[2 * k + 1];
-                unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
-                ns += (uint32_t)n_esc + 1;
-                const int lsb_tuple = lsb_mode && n_esc > 0;
-                nb += 2u * (uint32_t)(n_esc - (lsb_tuple ? 1 : 0));
-                if (lsb_tuple) {
-                    nl += 2u + (uint32_t)((a >> 1) == 0 && q0 != 0) + (uint32_t)((b >> 1) == 0 && q1 != 0);
-                    a >>= 1;
-                    b >>= 1;
-                }
-                nb += (uint32_t)(a > 0) + (uint32_t)(b > 0);
-            }
-        }
-        part[lane] = ns;
-        part[64 + lane] = nb;
-        part[128 + lane] = nl;
-    }
-    LC3_SYNC();
-    uint32_t soff = 0, boff = 0, loff = 0, stot = 0, btot = 0, ltot = 0;
-    _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) {
-        const uint32_t a = part[i], b = part[64 + i], l = part[128 + i];
-        if (i < lane) { soff += a; boff += b; loff += l; }
-        stot += a; btot += b; ltot += l;
-    }
-#ifdef LC3_FORCE_SERIAL_BITSTREAM
-    const int fits = 0;  // test hook: always take the reference-order serial writer
-#else
-    const int fits = (int)stot <= SYM_CAP && (int)ltot <= LSB_CAP && side_bits + (int)btot <= nbytes * 8;
-#endif
-    LC3_SYNC();
-    if (fits) {
-        uint32_t gpos = (uint32_t)side_bits + boff;  // next backward bit position (0 = bit 0 of the last byte)
-        for (int j = 0; j < 4; j++) {
-            const int k = k0 + j;
-            if (k < ntup) {
-                const uint32_t ti = tinfo[k];
-                const int t = (int)(ti & 0xfff), n_esc = (int)((ti >> 12) & 15);
-                const unsigned af = (ti >> 16) & 3, bf = (ti >> 18) & 3;
-                const int q0 = L.xq[2 * k], q1 = L.xq[2 * k + 1];
-                unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
-                unsigned a_lsb = a, b_lsb = b;
-                for (int i = 0; i < n_esc; i++) {
-                    const int pki = LC3T_AC_SPEC_LOOKUP[t + (i < 3 ? i : 3) * 1024];
-                    symlist[soff++] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[pki][16] |
-                                      ((uint32_t)(int)LC3T_AC_SPEC_FREQ[pki][16] << 16);
-                    if (!(lsb_mode && i == 0)) {
-                        if ((a >> i) & 1u) {
-                            const uint32_t byte = (uint32_t)nbytes - 1u - (gpos >> 3);
-                            LC3_LDS_OR32((uint32_t *)L.out + (byte >> 2), 1u << (8u * (byte & 3u) + (gpos & 7u)));
-                        }
-                        gpos++;
-                        if ((b >> i) & 1u) {
-                            const uint32_t byte = (uint32_t)nbytes - 1u - (gpos >> 3);
-                            LC3_LDS_OR32((uint32_t *)L.out + (byte >> 2), 1u << (8u * (byte & 3u) + (gpos & 7u)));
-                        }
-                        gpos++;
-                    }
-                }
-                {
-                    const int pki = LC3T_AC_SPEC_LOOKUP[t + (n_esc < 3 ? n_esc : 3) * 1024];
-                    const int sym = (int)(af + 4 * bf);
-                    symlist[soff++] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[pki][sym] |
-                                      ((uint32_t)(int)LC3T_AC_SPEC_FREQ[pki][sym] << 16);
-                }
-                if (lsb_mode && n_esc > 0) {  // :298-312
-                    a_lsb >>= 1;
-                    b_lsb >>= 1;
-                    lsbs[loff++] = (uint8_t)(a & 1u);
-                    if (a_lsb == 0 && q0 != 0) lsbs[loff++] = (uint8_t)(q0 > 0 ? 0 : 1);
-                    lsbs[loff++] = (uint8_t)(b & 1u);
-                    if (b_lsb == 0 && q1 != 0) lsbs[loff++] = (uint8_t)(q1 > 0 ? 0 : 1);
-                }
-                if (a_lsb > 0) {  // sign bits :313-318
-                    if (q0 <= 0) {
-                        const uint32_t byte = (uint32_t)nbytes - 1u - (gpos >> 3);
-                        LC3_LDS_OR32((uint32_t *)L.out + (byte >> 2), 1u << (8u * (byte & 3u) + (gpos & 7u)));
-                    }
-                    gpos++;
-                }
-                if (b_lsb > 0) {
-                    if (q1 <= 0) {
-                        const uint32_t byte = (uint32_t)nbytes - 1u - (gpos >> 3);
-                        LC3_LDS_OR32((uint32_t *)L.out + (byte >> 2), 1u << (8u * (byte & 3u) + (gpos & 7u)));
-                    }
-                    gpos++;
-                }
-            }
-        }
-    }
-    LC3_SYNC();
-    // ---- phase 3/4: range coder over the symbol list, residual bits, termination (uniform serial)
-    if (LC3_UNIFORM_LEADER(lane)) {
-        int collided = !fits;
-        if (fits) {
-            const int *rc_i = L.ism + 16;
-            lc3_bitwriter w;
-            w.lane = lane;
-            w.buf = L.out;
-            w.nbytes = nbytes;
-            w.nbits = nbytes * 8;
-            w.bp = 0;
-            {
-                const int gtot = side_bits + (int)btot;  // all backward bits written so far
-                w.bp_side = nbytes - 1 - (gtot >> 3);
-                w.mask_side = 1 << (gtot & 7);
-            }
-            w.low = 0;
-            w.range = 0x00ffffffu;
-            w.cache = -1;
-            w.carry = 0;
-            w.carry_count = 0;
-            // tns_data :224-244
-            const int num_tns = LC3_U(tns_in.num_tns_filters), wt = LC3_U(tns_in.lpc_weighting);
-            for (int f = 0; f < num_tns; f++) {
-                const int order = LC3_U(tns_in.rc_order[f]);
-                if (order > 0) {
-                    lc3_ac_encode(w, LC3T_AC_TNS_ORDER_CUMFREQ[wt][order - 1], LC3T_AC_TNS_ORDER_FREQ[wt][order - 1]);
-                    for (int k = 0; k < order; k++) {
-                        int ri = LC3_U(rc_i[k + 8 * f]);
-                        ri = ri < 0 ? 0 : (ri > 16 ? 16 : ri);
-                        lc3_ac_encode(w, LC3T_AC_TNS_COEF_CUMFREQ[k][ri], LC3T_AC_TNS_COEF_FREQ[k][ri]);
-                    }
-                }
-            }
-            // spectral_data :246-326, symbols only
-            for (int i = 0; i < (int)stot; i++) {
-                const uint32_t sv = (uint32_t)LC3_U(symlist[i]);
-                lc3_ac_encode(w, (int)(sv & 0xffffu), (int)(sv >> 16));
-            }
-            // residual_data_and_finalization :328-352
-            {
-                int nbits_side = w.nbits - (8 * w.bp_side + 8 - lc3_ilog2((uint32_t)w.mask_side));
-                int nbits_ari = w.bp * 8 + 25 - lc3_ilog2(w.range);
-                if (w.carry >= 0) nbits_ari += 8;
-                if (w.carry_count > 0) nbits_ari += w.carry_count * 8;
-                int n_enc = w.nbits - (nbits_side + nbits_ari);
-                if (n_enc < 0) n_enc = 0;
-                if (!lsb_mode) {
-                    for (int k = 0; k < n_enc && k < n_res_bits; k++) lc3_bw_bool_backward(w, LC3_U(L.res_bits[k]));
-                } else {
-                    if (n_enc > (int)ltot) n_enc = (int)ltot;
-                    for (int k = 0; k < n_enc; k++) lc3_bw_bool_backward(w, LC3_U(lsbs[k]) == 1);
-                }
-            }
-            // ac_enc_finish :354-395
-            int bits = 1;
-            while ((w.range >> (24 - bits)) == 0) bits++;
-            uint32_t mask = 0x00ffffffu >> bits;
-            uint32_t val = w.low + mask;
-            const uint32_t over1 = val >> 24;
-            const uint32_t high = w.low + w.range;
-            const uint32_t over2 = high >> 24;
-            val &= 0x00ffffffu & ~mask;
-            if (over1 == over2) {
-                if ((val + mask) >= high) {
-                    bits += 1;
-                    mask >>= 1;
-                    val = ((w.low + mask) & 0x00ffffffu) & ~mask;
-                }
-                if (val < w.low) w.carry = 1;
-            }
-            w.low = val;
-            while (bits > 0) {
-                lc3_ac_shift(w);
-                bits -= 8;
-            }
-            bits += 8;
-            // The forward region ends with `bits` bits in byte w.bp (+ carry bytes); it must stay clear of every
-            // backward bit, otherwise the reference's write ORDER matters and the serial path decides.
-            {
-                const int last_fwd_byte = w.bp + (w.carry_count > 0 ? w.carry_count : 0);
-                const int used_back = lc3_ilog2((uint32_t)w.mask_side);  // bits already taken in byte bp_side
-                if (last_fwd_byte > w.bp_side || (last_fwd_byte == w.bp_side && (8 - bits) < used_back)) collided = 1;
-            }
-            if (!collided) {
-                if (w.carry_count > 0) {
-                    lc3_bw_byte_forward(w, w.cache & 0xff);
-                    while (w.carry_count > 1) {
-                        lc3_bw_byte_forward(w, 0xff);
-                        w.carry_count -= 1;
-                    }
-                    lc3_bw_uint_forward(w, 0xffu >> (8 - bits), bits);
-                } else {
-                    lc3_bw_uint_forward(w, (unsigned)w.cache, bits);
-                }
-            }
-        }
-        LC3_UST(bs[1], collided);
-    }
-    LC3_SYNC();
-    if (bs[1]) {
-        if (lane == 0) L.st.bitstream_fallbacks += 1;
-        LC3_SYNC();
-        lc3_enc_bitstream_serial(c, L, lane, bw_ind_in, nbits_bw_in, sns_in, tns_in, ltpf_in, spec_in, n_res_bits_in,
-                                 noise_factor_in, nbytes_in);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // EncoderChannel::encode (encoder/lc3_encoder.rs:63-112): one frame of one stream on one wave.
-// pcm: nf samples in HBM (4-byte aligned); out: nbytes in HBM.  dbg (optional): float[3*480] stage dumps.
+// pcm: nf samples in HBM (4-byte aligned); plane/plane_stride: this frame's column of the packer planes
+// (lc3_dev_enc_pack.h); nbytes selects the bitrate.  dbg (optional): float[3*480] stage dumps.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lc3_encode_frame_wave(const lc3_cfg &c, lc3_enc_lds &L, int lane, const int16_t *pcm,
-                                                      uint8_t *out, int nbytes, float *dbg) {
+                                                      int32_t *plane, int plane_stride, int nbytes, float *dbg) {
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
     const int near_nyquist = lc3_enc_mdct(c, L, lane, pcm);
@@ -1966,9 +1418,44 @@ __device__ __forceinline__ void lc3_encode_frame_wave(const lc3_cfg &c, lc3_enc_
         d[14] = (float)spec.nbits_lsb; d[15] = (float)spec.lsb_mode; d[16] = (float)n_res; d[17] = (float)noise_factor;
         d[18] = spec.gg; d[19] = (float)spec.nbits_spec; d[20] = (float)spec.nbits_trunc; d[21] = (float)near_nyquist;
     }
-    lc3_enc_bitstream(c, L, lane, bw_ind, nbits_bw, sns, tns, pf, spec, n_res, noise_factor, nbytes);
-    LC3_STAMP(L, lane, 8);
-    for (int i = lane; i < nbytes; i += LC3_WAVE) out[i] = L.out[i];
+    // E20/E21 run as a separate lane-per-frame stage (lc3_dev_enc_pack.h): leave this frame's plane column in HBM
+    {
+        const int st = plane_stride;
+        if (lane == 0) {
+            plane[EP_BW * st] = bw_ind;
+            plane[EP_NBITS_BW * st] = nbits_bw;
+            plane[EP_LASTNZ_TRUNC * st] = spec.lastnz_trunc;
+            plane[EP_LSB_MODE * st] = spec.lsb_mode;
+            plane[EP_GG_IND * st] = spec.gg_ind;
+            plane[EP_NUM_TNS * st] = tns.num_tns_filters;
+            plane[EP_ORD0 * st] = tns.rc_order[0];
+            plane[EP_ORD1 * st] = tns.rc_order[1];
+            plane[EP_LPC_W * st] = tns.lpc_weighting;
+            plane[EP_PITCH_PRESENT * st] = pf.pitch_present;
+            plane[EP_LTPF_ACTIVE * st] = pf.ltpf_active;
+            plane[EP_PITCH_INDEX * st] = pf.pitch_index;
+            plane[EP_IND_LF * st] = sns.ind_lf;
+            plane[EP_IND_HF * st] = sns.ind_hf;
+            plane[EP_SHAPE_J * st] = sns.shape_j;
+            plane[EP_GIND * st] = sns.gind;
+            plane[EP_LS_INDA * st] = sns.ls_inda;
+            plane[EP_JOINT * st] = (int32_t)sns.index_joint_j;
+            plane[EP_NOISE * st] = noise_factor;
+            plane[EP_RATE_FLAG * st] = spec.rate_flag;
+            plane[EP_N_RES * st] = n_res;
+        }
+        if (lane < 16) plane[(EP_RCI + lane) * st] = L.ism[16 + lane];
+        if (lane < 13) {  // residual bits as a bit mask
+            uint32_t m = 0;
+            for (int j = 0; j < 32; j++) {
+                const int i = 32 * lane + j;
+                if (i < n_res && L.res_bits[i]) m |= 1u << j;
+            }
+            plane[(EP_RES + lane) * st] = (int32_t)m;
+        }
+        for (int k = lane; k < c.ne / 2; k += LC3_WAVE)
+            plane[(EP_XQ + k) * st] = (int32_t)(((uint32_t)(uint16_t)L.xq[2 * k]) | ((uint32_t)(uint16_t)L.xq[2 * k + 1] << 16));
+    }
     LC3_SYNC();
-    LC3_STAMP(L, lane, 9);
+    LC3_STAMP(L, lane, 8);
 }

@@ -1,0 +1,283 @@
+// LC3 batched encoder for MI355X -- bitstream writer, ONE LANE PER FRAME.
+//
+// BitstreamEncoding::encode (reference encoder/bitstream_encoding.rs:77-429) with its BufferWriter
+// (encoder/buffer_writer.rs:11-67) is a serial integer state machine: side information, a 24-bit range coder
+// growing forward, sign/LSB/residual bits growing backward.  It needs nothing but integers the analysis stages
+// produced, so -- like the decoder's parser (lc3_dev_dec_parse.h) -- it runs with every lane writing its own frame
+// in the reference's exact operation order.  The wave-per-stream analysis kernel (lc3_dev_enc.h) leaves one
+// "plane" column per frame in HBM, laid out [block of 64 frames][word][lane]; this stage reads it and produces the
+// frame bytes in an LDS staging area that the workgroup then copies out with coalesced stores.
+#pragma once
+#include "lc3_dev_common.h"
+
+// plane words of one frame (int32)
+enum {
+    EP_BW = 0, EP_NBITS_BW, EP_LASTNZ_TRUNC, EP_LSB_MODE, EP_GG_IND, EP_NUM_TNS, EP_ORD0, EP_ORD1, EP_LPC_W,
+    EP_PITCH_PRESENT, EP_LTPF_ACTIVE, EP_PITCH_INDEX, EP_IND_LF, EP_IND_HF, EP_SHAPE_J, EP_GIND, EP_LS_INDA,
+    EP_JOINT, EP_NOISE, EP_RATE_FLAG, EP_N_RES,
+    EP_RCI,                    // 16 words: TNS coefficient indices
+    EP_RES = EP_RCI + 16,      // 13 words: residual bits, bit j of word j / 32
+    EP_XQ = EP_RES + 13,       // 200 words: quantised spectrum, x_q[2k] | x_q[2k+1] << 16
+    EP_WORDS = EP_XQ + 200
+};
+
+struct lc3_pack_ctx {
+    uint8_t *buf;            // this frame's nbytes output bytes (LDS staging)
+    int nbytes, nbits;
+    const uint8_t *lookup;   // AC_SPEC_LOOKUP[4096]
+    const uint32_t *cf;      // [64][17] cum | freq << 16
+    const int32_t *plane;    // word w at plane[w * stride]
+    int stride;
+    // BufferWriter (buffer_writer.rs:5-9) + ArithmeticEncoderState (bitstream_encoding.rs:27-34)
+    int bp, bp_side, mask_side;
+    uint32_t low, range;
+    int cache, carry, carry_count;
+};
+
+__device__ __forceinline__ int32_t lc3_ep_get(const lc3_pack_ctx &c, int word) { return c.plane[word * c.stride]; }
+
+__device__ __forceinline__ void lc3_pk_bool_backward(lc3_pack_ctx &w, int bit) {  // buffer_writer.rs:27-40
+    if (w.bp_side >= 0 && w.bp_side < w.nbytes) {
+        if (!bit) w.buf[w.bp_side] &= (uint8_t)~w.mask_side;
+        else w.buf[w.bp_side] |= (uint8_t)w.mask_side;
+    }
+    if (w.mask_side == 0x80) {
+        w.mask_side = 1;
+        w.bp_side -= 1;
+    } else w.mask_side <<= 1;
+}
+__device__ __forceinline__ void lc3_pk_uint_backward(lc3_pack_ctx &w, uint32_t val, int nbits) {  // :19-25
+    for (int i = 0; i < nbits; i++) {
+        lc3_pk_bool_backward(w, (int)(val & 1u));
+        val >>= 1;
+    }
+}
+__device__ __forceinline__ void lc3_pk_byte_forward(lc3_pack_ctx &w, int val) {  // :55-58
+    if (w.bp >= 0 && w.bp < w.nbytes) w.buf[w.bp] = (uint8_t)val;
+    w.bp += 1;
+}
+__device__ __forceinline__ void lc3_pk_uint_forward(lc3_pack_ctx &w, unsigned val, int nbits) {  // :42-53
+    unsigned mask = 0x80;
+    for (int i = 0; i < nbits; i++) {
+        if (w.bp >= 0 && w.bp < w.nbytes) {
+            if (((val & 0xff) & mask) == 0) w.buf[w.bp] &= (uint8_t)~mask;
+            else w.buf[w.bp] |= (uint8_t)mask;
+        }
+        mask >>= 1;
+    }
+}
+__device__ __forceinline__ void lc3_pk_ac_shift(lc3_pack_ctx &w) {  // bitstream_encoding.rs:397-415
+    if (w.low < 0x00ff0000u || w.carry == 1) {
+        if (w.cache >= 0) lc3_pk_byte_forward(w, (w.cache + w.carry) & 0xff);
+        while (w.carry_count > 0) {
+            lc3_pk_byte_forward(w, (w.carry + 0xff) & 0xff);
+            w.carry_count -= 1;
+        }
+        w.cache = (int)(w.low >> 16);
+        w.carry = 0;
+    } else w.carry_count += 1;
+    w.low <<= 8;
+    w.low &= 0x00ffffffu;
+}
+__device__ __forceinline__ void lc3_pk_ac_encode(lc3_pack_ctx &w, uint32_t cum_freq, uint32_t sym_freq) {  // :417-429
+    const uint32_t r = w.range >> 10;
+    w.low += r * cum_freq;
+    if ((w.low >> 24) != 0) w.carry = 1;
+    w.low &= 0x00ffffffu;
+    w.range = r * sym_freq;
+    while (w.range < 0x10000u) {
+        w.range <<= 8;
+        lc3_pk_ac_shift(w);
+    }
+}
+
+// one (x_q[k], x_q[k+1]) pair of the plane
+__device__ __forceinline__ void lc3_ep_pair(const lc3_pack_ctx &c, int tup, int &q0, int &q1) {
+    const uint32_t v = (uint32_t)lc3_ep_get(c, EP_XQ + tup);
+    q0 = (int)(int16_t)(v & 0xffffu);
+    q1 = (int)(int16_t)(v >> 16);
+}
+
+// BitstreamEncoding::encode :77-136; the buffer must be zero-filled (init :138-144)
+__device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
+    w.nbits = w.nbytes * 8;
+    w.bp = 0;
+    w.bp_side = w.nbytes - 1;
+    w.mask_side = 1;
+    const int lsb_mode = lc3_ep_get(w, EP_LSB_MODE), lastnz_trunc = lc3_ep_get(w, EP_LASTNZ_TRUNC);
+    const int num_tns = lc3_ep_get(w, EP_NUM_TNS), rate_flag = lc3_ep_get(w, EP_RATE_FLAG);
+    const int ord0 = lc3_ep_get(w, EP_ORD0), ord1 = lc3_ep_get(w, EP_ORD1);
+    // side information :92-112 (layout: SURVEY App. E)
+    {
+        const int nbits_bw = lc3_ep_get(w, EP_NBITS_BW);
+        if (nbits_bw > 0) lc3_pk_uint_backward(w, (uint32_t)lc3_ep_get(w, EP_BW), nbits_bw);
+        int nb = 0;
+        while ((1 << nb) < ne / 2) nb++;
+        lc3_pk_uint_backward(w, (uint32_t)((lastnz_trunc >> 1) - 1), nb);
+        lc3_pk_bool_backward(w, lsb_mode);
+        lc3_pk_uint_backward(w, (uint32_t)lc3_ep_get(w, EP_GG_IND), 8);
+        if (num_tns > 0) lc3_pk_bool_backward(w, ord0 != 0);
+        if (num_tns > 1) lc3_pk_bool_backward(w, ord1 != 0);
+        const int pitch_present = lc3_ep_get(w, EP_PITCH_PRESENT);
+        lc3_pk_bool_backward(w, pitch_present);
+        lc3_pk_uint_backward(w, (uint32_t)lc3_ep_get(w, EP_IND_LF), 5);
+        lc3_pk_uint_backward(w, (uint32_t)lc3_ep_get(w, EP_IND_HF), 5);
+        const int shape_j = lc3_ep_get(w, EP_SHAPE_J);
+        const uint32_t joint = (uint32_t)lc3_ep_get(w, EP_JOINT);
+        const int submode_msb = (shape_j >> 1) != 0;
+        lc3_pk_bool_backward(w, submode_msb);
+        lc3_pk_uint_backward(w, (uint32_t)(lc3_ep_get(w, EP_GIND) >> LC3T_SNS_GAIN_LSB_BITS[shape_j]),
+                             LC3T_SNS_GAIN_MSB_BITS[shape_j]);
+        lc3_pk_bool_backward(w, lc3_ep_get(w, EP_LS_INDA) != 0);
+        if (!submode_msb) {
+            lc3_pk_uint_backward(w, joint, 13);
+            lc3_pk_uint_backward(w, joint >> 13, 12);
+        } else {
+            lc3_pk_uint_backward(w, joint, 12);
+            lc3_pk_uint_backward(w, joint >> 12, 12);
+        }
+        if (pitch_present) {
+            lc3_pk_bool_backward(w, lc3_ep_get(w, EP_LTPF_ACTIVE));
+            lc3_pk_uint_backward(w, (uint32_t)lc3_ep_get(w, EP_PITCH_INDEX), 9);
+        }
+        lc3_pk_uint_backward(w, (uint32_t)lc3_ep_get(w, EP_NOISE), 3);
+    }
+    // ac_enc_init :216-222
+    w.low = 0;
+    w.range = 0x00ffffffu;
+    w.cache = -1;
+    w.carry = 0;
+    w.carry_count = 0;
+    // tns_data :224-244
+    {
+        const int wt = lc3_ep_get(w, EP_LPC_W);
+        for (int f = 0; f < num_tns; f++) {
+            const int order = f == 0 ? ord0 : ord1;
+            if (order > 0) {
+                lc3_pk_ac_encode(w, (uint32_t)(int)LC3T_AC_TNS_ORDER_CUMFREQ[wt][order - 1],
+                                 (uint32_t)(int)LC3T_AC_TNS_ORDER_FREQ[wt][order - 1]);
+                for (int k = 0; k < order; k++) {
+                    int ri = lc3_ep_get(w, EP_RCI + k + 8 * f);
+                    ri = ri < 0 ? 0 : (ri > 16 ? 16 : ri);
+                    lc3_pk_ac_encode(w, (uint32_t)(int)LC3T_AC_TNS_COEF_CUMFREQ[k][ri],
+                                     (uint32_t)(int)LC3T_AC_TNS_COEF_FREQ[k][ri]);
+                }
+            }
+        }
+    }
+    // spectral_data :246-326
+    int nlsbs = 0;
+    {
+        int cctx = 0;
+        const int ntup = lastnz_trunc / 2;
+        for (int tup = 0; tup < ntup; tup++) {
+            const int k = 2 * tup;
+            int t = cctx + rate_flag + (k > ne / 2 ? 256 : 0), lev = 0, q0, q1;
+            lc3_ep_pair(w, tup, q0, q1);
+            unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
+            unsigned a_lsb = a, b_lsb = b;
+            while ((a > b ? a : b) >= 4) {
+                const uint32_t sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + 16];
+                lc3_pk_ac_encode(w, sv & 0xffffu, sv >> 16);
+                if (!(lsb_mode && lev == 0)) {
+                    lc3_pk_bool_backward(w, (a & 1u) == 1u);
+                    lc3_pk_bool_backward(w, (b & 1u) == 1u);
+                }
+                a >>= 1;
+                b >>= 1;
+                lev += 1;
+            }
+            {
+                const uint32_t sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + (int)(a + 4 * b)];
+                lc3_pk_ac_encode(w, sv & 0xffffu, sv >> 16);
+            }
+            if (lsb_mode && lev > 0) {  // the LSB list itself is regenerated below when it is written
+                a_lsb >>= 1;
+                b_lsb >>= 1;
+                nlsbs += 2 + (a_lsb == 0 && q0 != 0) + (b_lsb == 0 && q1 != 0);
+            }
+            if (a_lsb > 0) lc3_pk_bool_backward(w, q0 <= 0);
+            if (b_lsb > 0) lc3_pk_bool_backward(w, q1 <= 0);
+            lev = lev < 3 ? lev : 3;
+            t = lev <= 1 ? 1 + (int)(a + b) * (lev + 1) : 12 + lev;
+            cctx = (cctx & 15) * 16 + t;
+        }
+    }
+    // residual_data_and_finalization :328-352
+    {
+        const int nbits_side = w.nbits - (8 * w.bp_side + 8 - lc3_ilog2((uint32_t)w.mask_side));
+        int nbits_ari = w.bp * 8 + 25 - lc3_ilog2(w.range);  // nbits_side_forcast :64-75
+        if (w.carry >= 0) nbits_ari += 8;
+        if (w.carry_count > 0) nbits_ari += w.carry_count * 8;
+        int n_enc = w.nbits - (nbits_side + nbits_ari);
+        if (n_enc < 0) n_enc = 0;
+        if (!lsb_mode) {
+            const int n_res = lc3_ep_get(w, EP_N_RES);
+            if (n_enc > n_res) n_enc = n_res;
+            for (int k = 0; k < n_enc; k += 32) {
+                uint32_t bits = (uint32_t)lc3_ep_get(w, EP_RES + (k >> 5));
+                const int m = n_enc - k < 32 ? n_enc - k : 32;
+                for (int j = 0; j < m; j++) {
+                    lc3_pk_bool_backward(w, (int)(bits & 1u));
+                    bits >>= 1;
+                }
+            }
+        } else {
+            // lsbs[0 .. nlsbs) in the order spectral_data pushed them (:298-312), regenerated on the fly
+            if (n_enc > nlsbs) n_enc = nlsbs;
+            int written = 0;
+            const int ntup = lastnz_trunc / 2;
+            for (int tup = 0; tup < ntup && written < n_enc; tup++) {
+                int q0, q1;
+                lc3_ep_pair(w, tup, q0, q1);
+                const unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
+                if ((a > b ? a : b) >= 4) {
+                    int e[4], ne_ = 0;
+                    e[ne_++] = (int)(a & 1u);
+                    if ((a >> 1) == 0 && q0 != 0) e[ne_++] = q0 > 0 ? 0 : 1;
+                    e[ne_++] = (int)(b & 1u);
+                    if ((b >> 1) == 0 && q1 != 0) e[ne_++] = q1 > 0 ? 0 : 1;
+                    for (int j = 0; j < ne_ && written < n_enc; j++) {
+                        lc3_pk_bool_backward(w, e[j] == 1);
+                        written++;
+                    }
+                }
+            }
+        }
+    }
+    // ac_enc_finish :354-395
+    {
+        int bits = 1;
+        while ((w.range >> (24 - bits)) == 0) bits++;
+        uint32_t mask = 0x00ffffffu >> bits;
+        uint32_t val = w.low + mask;
+        const uint32_t over1 = val >> 24;
+        const uint32_t high = w.low + w.range;
+        const uint32_t over2 = high >> 24;
+        val &= 0x00ffffffu & ~mask;
+        if (over1 == over2) {
+            if ((val + mask) >= high) {
+                bits += 1;
+                mask >>= 1;
+                val = ((w.low + mask) & 0x00ffffffu) & ~mask;
+            }
+            if (val < w.low) w.carry = 1;
+        }
+        w.low = val;
+        while (bits > 0) {
+            lc3_pk_ac_shift(w);
+            bits -= 8;
+        }
+        bits += 8;
+        if (w.carry_count > 0) {
+            lc3_pk_byte_forward(w, w.cache & 0xff);
+            while (w.carry_count > 1) {
+                lc3_pk_byte_forward(w, 0xff);
+                w.carry_count -= 1;
+            }
+            lc3_pk_uint_forward(w, 0xffu >> (8 - bits), bits);
+        } else {
+            lc3_pk_uint_forward(w, (unsigned)w.cache, bits);
+        }
+    }
+}

@@ -18,25 +18,6 @@
 
 #define LC3_SYNC() __syncthreads()
 #include "lc3_dev_common.h"
-// wave-uniform primitives of the "uniform-scalar" serial sections (see lc3_dev_dec.h): all 64 lanes execute the
-// section with identical values, LDS reads are broadcast into SGPRs, one lane performs the LDS writes.
-#define LC3_UNIFORM_LEADER(lane) (true)
-#define LC3_U(x) ((int)__builtin_amdgcn_readfirstlane((int)(x)))
-#define LC3_UST(lv, v) do { if (lane == 0) (lv) = (v); } while (0)
-#define LC3_LDS_OR32(p, v) atomicOr((p), (v))
-#define LC3_LDS_OR32(p, v) atomicOr((p), (v))
-// symbol search of the range decoder: lane i tests symbol i, the highest passing lane is the symbol
-// (reference: linear search from the top, decoder/arithmetic_codec.rs:81-84)
-__device__ __forceinline__ int lc3_sym_search(const int16_t *cum, const int16_t *freq, int nsym, uint32_t low,
-                                              uint32_t tmp, int lane, uint32_t &cval, uint32_t &fval) {
-    const int i = lane < nsym ? lane : nsym - 1;
-    const uint32_t cv = (uint32_t)(int)cum[i], fv = (uint32_t)(int)freq[i];
-    const unsigned long long m = __ballot(lane < nsym && low >= tmp * cv);
-    const int val = m ? 63 - __builtin_clzll(m) : 0;
-    cval = (uint32_t)__builtin_amdgcn_readlane((int)cv, val);
-    fval = (uint32_t)__builtin_amdgcn_readlane((int)fv, val);
-    return val;
-}
 #ifdef LC3_PROFILE
 // Diagnostic build (liblc3gpu_prof.so): lane 0 of every wave adds the shader-clock cycles between consecutive
 // stage stamps into a global table.  Stamp i accumulates the time since the previous stamp into slot i.
@@ -58,9 +39,10 @@ __device__ unsigned long long lc3_prof_acc[32];
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
+// Analysis kernel: one wave per stream, MDCT ... quantisation, leaves one packer plane column per frame.
 __global__ __launch_bounds__(64, 3) void lc3_encode_kernel(lc3_cfg cfg, lc3_enc_state *states, int first_channel,
-                                                       const int16_t *pcm, uint8_t *out, int nbytes, int n_frames,
-                                                       int fresh, float *dbg) {
+                                                          const int16_t *pcm, int32_t *planes, int nbytes, int n_frames,
+                                                          int fresh, float *dbg) {
     __shared__ lc3_enc_lds L;
     const int lane = threadIdx.x;
     const int s = blockIdx.x;  // stream index inside this launch
@@ -69,9 +51,59 @@ __global__ __launch_bounds__(64, 3) void lc3_encode_kernel(lc3_cfg cfg, lc3_enc_
     else lc3_enc_state_load(L, lane, gst);
     for (int t = 0; t < n_frames; t++) {
         const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
-        lc3_encode_frame_wave(cfg, L, lane, pcm + f * (size_t)cfg.nf, out + f * (size_t)nbytes, nbytes, dbg);
+        int32_t *plane = planes + (f >> 6) * (size_t)(EP_WORDS * 64) + (f & 63);
+        lc3_encode_frame_wave(cfg, L, lane, pcm + f * (size_t)cfg.nf, plane, 64, nbytes, dbg);
     }
     lc3_enc_state_store(L, lane, gst);
+}
+
+// Bitstream packer, one LANE per frame (lc3_dev_enc_pack.h).  blockDim.x frames per workgroup; context lookup and the
+// packed spectral model in LDS, every lane builds its frame in an LDS staging slot, then the workgroup copies the
+// frames out with coalesced stores.  Dynamic LDS: 4096 + 64*17*4 + blockDim.x * nbytes (rounded up to 4).
+__global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *planes, uint8_t *out, int nbytes,
+                                                       int n_frames) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *s_lookup = smem;
+    uint32_t *s_cf = (uint32_t *)(smem + 4096);
+    uint8_t *s_bytes = smem + 4096 + 64 * 17 * 4;
+    const int tid = threadIdx.x, fpb = blockDim.x;
+    const size_t f0 = (size_t)blockIdx.x * (size_t)fpb;
+    const size_t remaining = (size_t)n_frames - f0;
+    const int nfr = remaining < (size_t)fpb ? (int)remaining : fpb;
+    const int total = nfr * nbytes;
+    {
+        const uint32_t *lk32 = (const uint32_t *)LC3T_AC_SPEC_LOOKUP;
+        uint32_t *d32 = (uint32_t *)s_lookup;
+        for (int i = tid; i < 1024; i += fpb) d32[i] = lk32[i];
+        for (int i = tid; i < 64 * 17; i += fpb) {
+            const int p = i / 17, j = i - 17 * p;
+            s_cf[i] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[p][j] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[p][j] << 16);
+        }
+        uint32_t *b32 = (uint32_t *)s_bytes;  // init :138-144: frames start zero-filled
+        for (int i = tid; i < (total + 3) / 4; i += fpb) b32[i] = 0;
+    }
+    __syncthreads();
+    const size_t f = f0 + (size_t)tid;
+    if (f < (size_t)n_frames) {
+        lc3_pack_ctx c;
+        c.buf = s_bytes + tid * nbytes;
+        c.nbytes = nbytes;
+        c.lookup = s_lookup;
+        c.cf = s_cf;
+        c.plane = planes + (f >> 6) * (size_t)(EP_WORDS * 64) + (f & 63);
+        c.stride = 64;
+        lc3_pack_frame(c, ne);
+    }
+    __syncthreads();
+    uint8_t *dst = out + f0 * (size_t)nbytes;
+    if ((((uintptr_t)dst) & 3u) == 0) {
+        const uint32_t *b32 = (const uint32_t *)s_bytes;
+        uint32_t *d32 = (uint32_t *)dst;
+        for (int i = tid; i < total / 4; i += fpb) d32[i] = b32[i];
+        for (int i = (total & ~3) + tid; i < total; i += fpb) dst[i] = s_bytes[i];
+    } else {
+        for (int i = tid; i < total; i += fpb) dst[i] = s_bytes[i];
+    }
 }
 
 // Frame parser, one LANE per frame (lc3_dev_dec_parse.h).  256 frames per workgroup; the context lookup, the packed
@@ -197,6 +229,8 @@ struct lc3gpu_encoder {
     uint8_t *d_out1 = nullptr;
     float *d_dbg = nullptr;
     std::vector<uint8_t> fresh_mask;  // per channel: 1 = still fresh
+    int32_t *d_planes = nullptr;      // packer planes [blocks of 64 frames][EP_WORDS][64]
+    size_t planes_frames = 0;
 };
 
 struct lc3gpu_decoder {
@@ -208,6 +242,9 @@ struct lc3gpu_decoder {
     int32_t *d_planes = nullptr;   // parsed-frame planes [blocks of 64 frames][LC3_PLANE_WORDS][64]
     size_t planes_frames = 0;      // capacity in frames (multiple of 64)
 };
+
+static int encoder_reserve_planes(lc3gpu_encoder *e, size_t frames);
+static int decoder_reserve_planes(lc3gpu_decoder *d, size_t frames);
 
 extern "C" {
 
@@ -298,6 +335,8 @@ int lc3gpu_encoder_create(lc3gpu_encoder **out, int num_channels, int frame_us, 
     }
     e->fresh = true;
     e->fresh_mask.assign((size_t)num_channels, 1);
+    rc = encoder_reserve_planes(e, (size_t)num_channels);
+    if (rc) { lc3gpu_encoder_destroy(e); return rc; }
     *out = e;
     return LC3GPU_OK;
 }
@@ -308,6 +347,7 @@ int lc3gpu_encoder_destroy(lc3gpu_encoder *e) {
     if (e->d_pcm1) (void)hipFree(e->d_pcm1);
     if (e->d_out1) (void)hipFree(e->d_out1);
     if (e->d_dbg) (void)hipFree(e->d_dbg);
+    if (e->d_planes) (void)hipFree(e->d_planes);
     if (e->h.d_tables) (void)hipFree(e->h.d_tables);
     delete e;
     return LC3GPU_OK;
@@ -320,12 +360,27 @@ int lc3gpu_encoder_reset(lc3gpu_encoder *e) {
     return LC3GPU_OK;
 }
 
+static int encoder_reserve_planes(lc3gpu_encoder *e, size_t frames) {
+    const size_t need = (frames + 63) / 64 * 64;
+    if (need <= e->planes_frames) return LC3GPU_OK;
+    HIP_TRY(hipDeviceSynchronize());  // growing: earlier launches may still use the old buffer
+    if (e->d_planes) (void)hipFree(e->d_planes);
+    e->d_planes = nullptr;
+    e->planes_frames = 0;
+    HIP_TRY(hipMalloc((void **)&e->d_planes, need * (size_t)EP_WORDS * sizeof(int32_t)));
+    e->planes_frames = need;
+    return LC3GPU_OK;
+}
+
 static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_pcm, uint8_t *d_out, int nbytes,
                          int n_frames, hipStream_t stream, float *dbg) {
     if (!e || !d_pcm || !d_out) return LC3GPU_EINVAL;
     if (first < 0 || n <= 0 || first + n > e->num_channels) return LC3GPU_ECHANNEL;
     if (nbytes < 20 || nbytes > LC3_MAX_NE || n_frames <= 0) return LC3GPU_ELENGTH;
     if (((uintptr_t)d_pcm & 3u) != 0) return LC3GPU_EINVAL;
+    const size_t frames = (size_t)n * (size_t)n_frames;
+    int rc = encoder_reserve_planes(e, frames);
+    if (rc) return rc;
     // a range is launched "fresh" only if every channel in it is still fresh
     int fresh = 1;
     for (int i = first; i < first + n; i++) fresh &= e->fresh_mask[(size_t)i];
@@ -334,13 +389,19 @@ static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_p
         for (int i = first; i < first + n; i++) {
             if (e->fresh_mask[(size_t)i]) {
                 hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64), 0, stream, e->h.c, e->d_states, i, d_pcm,
-                                   d_out, nbytes, 0, 1, (float *)nullptr);
+                                   e->d_planes, nbytes, 0, 1, (float *)nullptr);
                 e->fresh_mask[(size_t)i] = 0;
             }
         }
     }
+    // stage 1: analysis, one wave per stream; stage 2: bitstream packing, one lane per frame
     hipLaunchKernelGGL(lc3_encode_kernel, dim3((unsigned)n), dim3(64), 0, stream, e->h.c, e->d_states, first, d_pcm,
-                       d_out, nbytes, n_frames, fresh, dbg);
+                       e->d_planes, nbytes, n_frames, fresh, dbg);
+    HIP_TRY(hipGetLastError());
+    const unsigned fpb = nbytes <= 220 ? 256u : 128u;
+    const size_t lds = 4096 + 64 * 17 * 4 + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3);
+    hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, e->h.c.ne,
+                       (const int32_t *)e->d_planes, d_out, nbytes, (int)frames);
     HIP_TRY(hipGetLastError());
     for (int i = first; i < first + n; i++) e->fresh_mask[(size_t)i] = 0;
     return LC3GPU_OK;
@@ -389,7 +450,7 @@ int lc3gpu_encoder_state_save(lc3gpu_encoder *e, void *host_dst) {
     for (int i = 0; i < e->num_channels; i++) {
         if (e->fresh_mask[(size_t)i]) {
             hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64), 0, nullptr, e->h.c, e->d_states, i, e->d_pcm1,
-                               e->d_out1, 20, 0, 1, (float *)nullptr);
+                               e->d_planes, 20, 0, 1, (float *)nullptr);
             e->fresh_mask[(size_t)i] = 0;
         }
     }

@@ -19,11 +19,6 @@
 static pthread_barrier_t g_bar;
 #define LC3_SYNC() pthread_barrier_wait(&g_bar)
 #include "../../lc3-codec_amd/csrc/lc3_dev_common.h"
-// "uniform-scalar" sections: on the GPU all lanes run them redundantly; the emulator runs them on lane 0 only
-#define LC3_UNIFORM_LEADER(lane) ((lane) == 0)
-#define LC3_U(x) ((int)(x))
-#define LC3_UST(lv, v) ((lv) = (v))
-#define LC3_LDS_OR32(p, v) __atomic_fetch_or((p), (v), __ATOMIC_RELAXED)
 #include "../../lc3-codec_amd/csrc/lc3_dev_dec.h"
 #include "../../lc3-codec_amd/csrc/lc3_dev_enc.h"
 #include "../../lc3-codec_amd/csrc/lc3_host_plan.h"
@@ -39,7 +34,7 @@ struct Job {
     lc3_enc_state *est;
     lc3_dec_state *dst;
     const int16_t *pcm_in;
-    uint8_t *bytes_out;
+    int32_t *enc_planes;  // packer planes of this stream: frame t at column (frame0 + t)
     const uint8_t *bytes_in;
     const int32_t *planes;  // parsed frames of this stream: frame t at column index (frame0 + t)
     size_t frame0;
@@ -54,9 +49,11 @@ void *lane_main(void *arg) {
         lc3_enc_lds &L = *j->EL;
         if (j->fresh) lc3_enc_state_init(L, lane);
         else lc3_enc_state_load(L, lane, j->est);
-        for (int t = 0; t < j->n_frames; t++)
-            lc3_encode_frame_wave(j->cfg, L, lane, j->pcm_in + (size_t)t * j->cfg.nf, j->bytes_out + (size_t)t * j->nbytes,
-                                  j->nbytes, j->dbg);
+        for (int t = 0; t < j->n_frames; t++) {
+            const size_t f = j->frame0 + (size_t)t;
+            int32_t *plane = j->enc_planes + (f >> 6) * (size_t)(EP_WORDS * 64) + (f & 63);
+            lc3_encode_frame_wave(j->cfg, L, lane, j->pcm_in + (size_t)t * j->cfg.nf, plane, 64, j->nbytes, j->dbg);
+        }
         lc3_enc_state_store(L, lane, j->est);
     } else {
         lc3_dec_lds &L = *j->DL;
@@ -88,7 +85,6 @@ void run_wave(Job proto) {
 }
 }  // namespace
 
-static int g_fallbacks = 0;
 extern "C" {
 // pcm int16[S][T][nf] -> bytes uint8[S][T][nbytes]; every stream starts fresh; dbg optional float[1472] (last frame)
 int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16_t *pcm, uint8_t *bytes, float *dbg) {
@@ -104,22 +100,39 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
     j.nbytes = nbytes;
     j.fresh = 1;
     j.dbg = dbg;
+    // stage 1: analysis, one emulated wave per stream, leaves the packer planes
+    const size_t frames = (size_t)S * (size_t)T;
+    std::vector<int32_t> planes(((frames + 63) / 64) * 64 * EP_WORDS, 0);
     lc3_enc_lds *L = (lc3_enc_lds *)calloc(1, sizeof(lc3_enc_lds));
     lc3_enc_state *st = (lc3_enc_state *)calloc(1, sizeof(lc3_enc_state));
     j.EL = L;
     j.est = st;
-    g_fallbacks = 0;
+    j.enc_planes = planes.data();
     for (int s = 0; s < S; s++) {
         j.pcm_in = pcm + (size_t)s * T * j.cfg.nf;
-        j.bytes_out = bytes + (size_t)s * T * nbytes;
+        j.frame0 = (size_t)s * T;
         run_wave(j);
-        g_fallbacks += st->bitstream_fallbacks;
     }
     free(L);
     free(st);
+    // stage 2: the lane-per-frame bitstream packer (lc3_dev_enc_pack.h) -- on the GPU 64 frames per wave
+    std::vector<uint32_t> cf(64 * 17);
+    for (int p = 0; p < 64; p++)
+        for (int q = 0; q < 17; q++)
+            cf[(size_t)p * 17 + q] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[p][q] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[p][q] << 16);
+    memset(bytes, 0, frames * (size_t)nbytes);
+    for (size_t f = 0; f < frames; f++) {
+        lc3_pack_ctx c;
+        c.buf = bytes + f * (size_t)nbytes;
+        c.nbytes = nbytes;
+        c.lookup = LC3T_AC_SPEC_LOOKUP;
+        c.cf = cf.data();
+        c.plane = planes.data() + (f >> 6) * (size_t)(EP_WORDS * 64) + (f & 63);
+        c.stride = 64;
+        lc3_pack_frame(c, j.cfg.ne);
+    }
     return 0;
 }
-int lc3emu_last_fallbacks(void) { return g_fallbacks; }
 int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8_t *bytes, const uint8_t *bad,
                   int16_t *pcm) {
     Job j;

@@ -9,29 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 LIB = os.path.join(EMU_DIR, "liblc3emu.so")
-LIB_SERIAL = os.path.join(EMU_DIR, "liblc3emu_serialbs.so")  # variant that forces the serial bitstream writer
 _lib = None
-_lib_serial = None
-
-
-def build_variant(path, extra):
-    deps = [os.path.join(EMU_DIR, "lc3_emu.cpp"), os.path.join(ROOT, "tables", "lc3_tables.h")]
-    csrc = os.path.join(ROOT, "lc3-codec_amd", "csrc")
-    deps += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
-    if os.path.exists(path) and all(os.path.getmtime(d) <= os.path.getmtime(path) for d in deps):
-        return path
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
-                           "-fno-strict-aliasing", "-Wno-unknown-pragmas", "-Wno-attributes"] + extra +
-                          ["-o", path, os.path.join(EMU_DIR, "lc3_emu.cpp"), "-lpthread"])
-    return path
-
-
-def lib_serial():
-    """emulator built with -DLC3_FORCE_SERIAL_BITSTREAM: every frame takes the fallback writer"""
-    global _lib_serial
-    if _lib_serial is None:
-        _lib_serial = ctypes.CDLL(build_variant(LIB_SERIAL, ["-DLC3_FORCE_SERIAL_BITSTREAM"]))
-    return _lib_serial
 
 
 def build():
@@ -62,14 +40,12 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 
 
-def encode(pcm, nbytes, fs_hz=48000, frame_us=10000, dbg=None, force_serial_bitstream=False):
+def encode(pcm, nbytes, fs_hz=48000, frame_us=10000, dbg=None):
     pcm = np.ascontiguousarray(pcm, np.int16)
     S, T, _ = pcm.shape
     out = np.zeros((S, T, nbytes), np.uint8)
-    L = lib_serial() if force_serial_bitstream else lib()
-    rc = L.lc3emu_encode(fs_hz, frame_us, nbytes, S, T, _p(pcm), _p(out), _p(dbg))
+    rc = lib().lc3emu_encode(fs_hz, frame_us, nbytes, S, T, _p(pcm), _p(out), _p(dbg))
     assert rc == 0
-    encode.last_fallbacks = int(L.lc3emu_last_fallbacks())
     return out
 
 

@@ -36,21 +36,6 @@ def test_emu_matches_oracle(fs, us, nbytes):
     assert np.array_equal(E.decode(ref, nf, fs, us), O.decode_batch(ref, nf, fs, us))
 
 
-def test_bitstream_fast_path_and_serial_fallback_agree():
-    """the parallel-precompute bitstream writer must never need its fallback on in-budget frames, and the fallback
-    (reference write order) must produce the same bytes"""
-    for fs, us, nbytes in [(48000, 10000, 150), (48000, 10000, 400), (32000, 7500, 61), (16000, 10000, 20)]:
-        cfg = np.zeros(7, np.int32)
-        O.lib().lc3o_kat_config(fs, us, O.P(cfg))
-        pcm = synth.make_pcm(6, 4, int(cfg[5]), fs, seed=77)
-        ref = O.encode_batch(pcm, nbytes, fs, us)
-        fast = E.encode(pcm, nbytes, fs, us)
-        assert E.encode.last_fallbacks == 0
-        slow = E.encode(pcm, nbytes, fs, us, force_serial_bitstream=True)
-        assert E.encode.last_fallbacks == pcm.shape[0] * pcm.shape[1]
-        assert np.array_equal(fast, ref) and np.array_equal(slow, ref)
-
-
 def test_emu_decode_8khz_and_corrupt():
     pcm = synth.make_pcm(3, 5, 80, 8000)
     data = O.encode_batch(pcm, 30, 8000, 10000)

@@ -38,10 +38,10 @@ for _ in range(5):
 torch.cuda.synchronize()
 acc = api.prof_read()
 names = {1: "enc mdct+energy", 2: "enc bandwidth+attack", 3: "enc sns", 4: "enc tns", 5: "enc ltpf", 6: "enc quant",
-         7: "enc residual+noise", 8: "enc bitstream", 9: "enc store", 17: "dec load parsed frame (planes) + epilogue",
+         7: "enc residual+noise", 8: "enc plane store", 17: "dec load parsed frame (planes) + epilogue",
          18: "dec spectrum (residual,noise,gain,tns,sns,plc)", 19: "dec imdct", 20: "dec ltpf", 21: "dec output"}
 frames = 5 * S * T
-for lo, hi, label in ((1, 10, "encoder"), (17, 22, "decoder")):
+for lo, hi, label in ((1, 9, "encoder analysis kernel"), (17, 22, "decoder synthesis kernel")):
     tot = sum(acc[lo:hi])
     print(f"{label}: {tot / frames:.0f} wave-cycles per frame (sum over stages, S={S} T={T})")
     for i in range(lo, hi):
