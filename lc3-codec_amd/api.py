@@ -120,6 +120,8 @@ def load_library():
     L.lc3gpu_decoder_state_load.argtypes = [vp, vp]
     L.lc3gpu_decoder_plc_events.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.lc3gpu_kernel_info.argtypes = [i, vp]
+    L.lc3gpu_encoder_timing.argtypes = [vp, i, vp]
+    L.lc3gpu_decoder_timing.argtypes = [vp, i, vp]
     _lib = L
     return L
 
@@ -132,7 +134,7 @@ ABI_SYMBOLS = [
     "lc3gpu_encoder_state_size", "lc3gpu_encoder_state_save", "lc3gpu_encoder_state_load", "lc3gpu_decoder_create",
     "lc3gpu_decoder_destroy", "lc3gpu_decoder_reset", "lc3gpu_decode_frame", "lc3gpu_decode", "lc3gpu_decode_range",
     "lc3gpu_decoder_state_size", "lc3gpu_decoder_state_save", "lc3gpu_decoder_state_load",
-    "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info", "lc3gpu_prof_read",
+    "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info", "lc3gpu_prof_read", "lc3gpu_encoder_timing", "lc3gpu_decoder_timing",
 ]
 
 
@@ -226,6 +228,14 @@ class Lc3Encoder:
         if rc:
             raise Lc3EncoderError(rc, "encode")
 
+    def timing(self, enable=True):
+        """-> (analysis-kernel ms, pack-kernel ms, batch calls) since the last call; (re)arms recording"""
+        out = (ctypes.c_double * 3)()
+        rc = self._L.lc3gpu_encoder_timing(self._h, int(bool(enable)), out)
+        if rc:
+            raise Lc3EncoderError(rc, "timing")
+        return float(out[0]), float(out[1]), int(out[2])
+
     def reset(self):
         rc = self._L.lc3gpu_encoder_reset(self._h)
         if rc:
@@ -303,6 +313,14 @@ class Lc3Decoder:
                                              _ptr(d_bad_frame), _ptr(d_pcm), int(nbytes), int(n_frames), _ptr(stream))
         if rc:
             raise Lc3DecoderError(rc, "decode")
+
+    def timing(self, enable=True):
+        """-> (parse-kernel ms, synthesis-kernel ms, batch calls) since the last call; (re)arms recording"""
+        out = (ctypes.c_double * 3)()
+        rc = self._L.lc3gpu_decoder_timing(self._h, int(bool(enable)), out)
+        if rc:
+            raise Lc3DecoderError(rc, "timing")
+        return float(out[0]), float(out[1]), int(out[2])
 
     def reset(self):
         rc = self._L.lc3gpu_decoder_reset(self._h)

@@ -219,7 +219,38 @@ int build_tables(HostCfg &h) {
 
 }  // namespace
 
+// optional per-kernel timing with HIP events recorded on the launch stream (bench.py roofline)
+struct KernelTimer {
+    bool enabled = false;
+    std::vector<hipEvent_t> ev;   // triples: before stage 1, between, after stage 2
+    double ms[2] = {0.0, 0.0};
+    long launches = 0;
+    void mark(hipStream_t s) {
+        if (!enabled) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, s);
+        ev.push_back(e);
+    }
+    // synchronises; folds the recorded triples into ms[] and clears them
+    void collect() {
+        for (size_t i = 0; i + 2 < ev.size(); i += 3) {
+            float a = 0.f, b = 0.f;
+            (void)hipEventSynchronize(ev[i + 2]);
+            if (hipEventElapsedTime(&a, ev[i], ev[i + 1]) == hipSuccess &&
+                hipEventElapsedTime(&b, ev[i + 1], ev[i + 2]) == hipSuccess) {
+                ms[0] += a;
+                ms[1] += b;
+                launches += 1;
+            }
+        }
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+    }
+};
+
 struct lc3gpu_encoder {
+    KernelTimer timer;
     HostCfg h;
     int num_channels = 0;
     lc3_enc_state *d_states = nullptr;
@@ -234,6 +265,7 @@ struct lc3gpu_encoder {
 };
 
 struct lc3gpu_decoder {
+    KernelTimer timer;
     HostCfg h;
     int num_channels = 0;
     lc3_dec_state *d_states = nullptr;
@@ -395,14 +427,17 @@ static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_p
         }
     }
     // stage 1: analysis, one wave per stream; stage 2: bitstream packing, one lane per frame
+    e->timer.mark(stream);
     hipLaunchKernelGGL(lc3_encode_kernel, dim3((unsigned)n), dim3(64), 0, stream, e->h.c, e->d_states, first, d_pcm,
                        e->d_planes, nbytes, n_frames, fresh, dbg);
     HIP_TRY(hipGetLastError());
+    e->timer.mark(stream);
     const unsigned fpb = nbytes <= 220 ? 256u : 128u;
     const size_t lds = 4096 + 64 * 17 * 4 + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3);
     hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, e->h.c.ne,
                        (const int32_t *)e->d_planes, d_out, nbytes, (int)frames);
     HIP_TRY(hipGetLastError());
+    e->timer.mark(stream);
     for (int i = first; i < first + n; i++) e->fresh_mask[(size_t)i] = 0;
     return LC3GPU_OK;
 }
@@ -543,12 +578,15 @@ static int decode_launch(lc3gpu_decoder *d, int first, int n, const uint8_t *d_i
     if (rc) return rc;
     const unsigned fpb = nbytes <= 220 ? 256u : 128u;
     const size_t lds = 4096 + 64 * 17 * 4 + (size_t)fpb * (size_t)nbytes;
+    d->timer.mark(stream);
     hipLaunchKernelGGL(lc3_parse_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, d->h.c.ne,
                        d->h.c.fs_ind, d->h.c.n_ms_10, d_in, d_bad, d->d_planes, nbytes, (int)frames);
     HIP_TRY(hipGetLastError());
+    d->timer.mark(stream);
     hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)n), dim3(64), 0, stream, d->h.c, d->d_states, first, d_in,
                        (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0);
     HIP_TRY(hipGetLastError());
+    d->timer.mark(stream);
     return LC3GPU_OK;
 }
 
@@ -600,6 +638,27 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
     uint64_t total = 0;
     for (const auto &s : st) total += (uint64_t)s.core.plc_events;
     *out = total;
+    return LC3GPU_OK;
+}
+
+// per-kernel timing (HIP events on the launch stream).  enable = 1 starts recording every batch launch, reading
+// synchronises and returns {stage-1 ms total, stage-2 ms total, launches} since the last read.
+int lc3gpu_encoder_timing(lc3gpu_encoder *e, int enable, double out[3]) {
+    if (!e) return LC3GPU_EINVAL;
+    e->timer.collect();
+    if (out) { out[0] = e->timer.ms[0]; out[1] = e->timer.ms[1]; out[2] = (double)e->timer.launches; }
+    e->timer.ms[0] = e->timer.ms[1] = 0.0;
+    e->timer.launches = 0;
+    e->timer.enabled = enable != 0;
+    return LC3GPU_OK;
+}
+int lc3gpu_decoder_timing(lc3gpu_decoder *d, int enable, double out[3]) {
+    if (!d) return LC3GPU_EINVAL;
+    d->timer.collect();
+    if (out) { out[0] = d->timer.ms[0]; out[1] = d->timer.ms[1]; out[2] = (double)d->timer.launches; }
+    d->timer.ms[0] = d->timer.ms[1] = 0.0;
+    d->timer.launches = 0;
+    d->timer.enabled = enable != 0;
     return LC3GPU_OK;
 }
 
