@@ -28,6 +28,22 @@
 #endif
 
 #define LC3_WAVE 64
+
+// HBM "planes" hand frames between the wave-per-stream and the lane-per-frame kernels.  Frame-major: a frame's
+// words are contiguous, so the wave side moves them with coalesced 256-byte accesses and the lane side walks its
+// own frame sequentially (sectors are merged / re-served by L2).  The lane-major alternative
+// ([block of 64 frames][word][lane]) coalesces the lane side instead but costs a 64-byte sector per 4-byte word on
+// the wave side (measured: 15 KB written + 33 KB fetched per frame, profiles/r01_v3_hbm_traffic.csv).
+#ifndef LC3_PLANE_FRAME_MAJOR
+#define LC3_PLANE_FRAME_MAJOR 1
+#endif
+#if LC3_PLANE_FRAME_MAJOR
+#define LC3_PLANE_COL(base, f, words) ((base) + (size_t)(f) * (size_t)(words))
+#define LC3_PLANE_STRIDE 1
+#else
+#define LC3_PLANE_COL(base, f, words) ((base) + ((size_t)(f) >> 6) * (size_t)((words) * 64) + ((size_t)(f) & 63))
+#define LC3_PLANE_STRIDE 64
+#endif
 #define LC3_MAX_NF 480
 #define LC3_MAX_NE 400
 

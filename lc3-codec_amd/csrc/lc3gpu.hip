@@ -51,8 +51,8 @@ __global__ __launch_bounds__(64, 3) void lc3_encode_kernel(lc3_cfg cfg, lc3_enc_
     else lc3_enc_state_load(L, lane, gst);
     for (int t = 0; t < n_frames; t++) {
         const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
-        int32_t *plane = planes + (f >> 6) * (size_t)(EP_WORDS * 64) + (f & 63);
-        lc3_encode_frame_wave(cfg, L, lane, pcm + f * (size_t)cfg.nf, plane, 64, nbytes, dbg);
+        int32_t *plane = LC3_PLANE_COL(planes, f, EP_WORDS);
+        lc3_encode_frame_wave(cfg, L, lane, pcm + f * (size_t)cfg.nf, plane, LC3_PLANE_STRIDE, nbytes, dbg);
     }
     lc3_enc_state_store(L, lane, gst);
 }
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *pl
         c.nbytes = nbytes;
         c.lookup = s_lookup;
         c.cf = s_cf;
-        c.plane = planes + (f >> 6) * (size_t)(EP_WORDS * 64) + (f & 63);
-        c.stride = 64;
+        c.plane = LC3_PLANE_COL(planes, f, EP_WORDS);
+        c.stride = LC3_PLANE_STRIDE;
         lc3_pack_frame(c, ne);
     }
     __syncthreads();
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(int ne, int fs_ind, int 
         c.len = nbytes;
         c.lookup = s_lookup;
         c.cf = s_cf;
-        c.plane = planes + (f >> 6) * (size_t)(LC3_PLANE_WORDS * 64) + (f & 63);
-        c.stride = 64;
+        c.plane = LC3_PLANE_COL(planes, f, LC3_PLANE_WORDS);
+        c.stride = LC3_PLANE_STRIDE;
         c.head = 0;
         c.tail = 0;
         int rc = (bad && bad[f]) ? -100 : lc3_parse_frame(c, ne, fs_ind, n_ms_10);
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(64, 3) void lc3_decode_kernel(lc3_cfg cfg, lc3_dec_
     else lc3_dec_state_load(L, lane, gst);
     for (int t = 0; t < n_frames; t++) {
         const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
-        const int32_t *plane = planes + (f >> 6) * (size_t)(LC3_PLANE_WORDS * 64) + (f & 63);
-        lc3_decode_frame_wave(cfg, L, lane, in + f * (size_t)nbytes, nbytes, pcm + f * (size_t)cfg.nf, plane, 64, gst);
+        const int32_t *plane = LC3_PLANE_COL(planes, f, LC3_PLANE_WORDS);
+        lc3_decode_frame_wave(cfg, L, lane, in + f * (size_t)nbytes, nbytes, pcm + f * (size_t)cfg.nf, plane, LC3_PLANE_STRIDE, gst);
     }
     lc3_dec_state_store(L, lane, gst);
 }

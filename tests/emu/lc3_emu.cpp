@@ -51,8 +51,8 @@ void *lane_main(void *arg) {
         else lc3_enc_state_load(L, lane, j->est);
         for (int t = 0; t < j->n_frames; t++) {
             const size_t f = j->frame0 + (size_t)t;
-            int32_t *plane = j->enc_planes + (f >> 6) * (size_t)(EP_WORDS * 64) + (f & 63);
-            lc3_encode_frame_wave(j->cfg, L, lane, j->pcm_in + (size_t)t * j->cfg.nf, plane, 64, j->nbytes, j->dbg);
+            int32_t *plane = LC3_PLANE_COL(j->enc_planes, f, EP_WORDS);
+            lc3_encode_frame_wave(j->cfg, L, lane, j->pcm_in + (size_t)t * j->cfg.nf, plane, LC3_PLANE_STRIDE, j->nbytes, j->dbg);
         }
         lc3_enc_state_store(L, lane, j->est);
     } else {
@@ -62,9 +62,9 @@ void *lane_main(void *arg) {
         for (int t = 0; t < j->n_frames; t++)
         {
             const size_t f = j->frame0 + (size_t)t;
-            const int32_t *plane = j->planes + (f >> 6) * (size_t)(LC3_PLANE_WORDS * 64) + (f & 63);
+            const int32_t *plane = LC3_PLANE_COL(j->planes, f, LC3_PLANE_WORDS);
             lc3_decode_frame_wave(j->cfg, L, lane, j->bytes_in + (size_t)t * j->nbytes, j->nbytes,
-                                  j->pcm_out + (size_t)t * j->cfg.nf, plane, 64, j->dst);
+                                  j->pcm_out + (size_t)t * j->cfg.nf, plane, LC3_PLANE_STRIDE, j->dst);
         }
         lc3_dec_state_store(L, lane, j->dst);
     }
@@ -127,8 +127,8 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
         c.nbytes = nbytes;
         c.lookup = LC3T_AC_SPEC_LOOKUP;
         c.cf = cf.data();
-        c.plane = planes.data() + (f >> 6) * (size_t)(EP_WORDS * 64) + (f & 63);
-        c.stride = 64;
+        c.plane = LC3_PLANE_COL(planes.data(), f, EP_WORDS);
+        c.stride = LC3_PLANE_STRIDE;
         lc3_pack_frame(c, j.cfg.ne);
     }
     return 0;
@@ -159,8 +159,8 @@ int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8
         c.len = nbytes;
         c.lookup = LC3T_AC_SPEC_LOOKUP;
         c.cf = cf.data();
-        c.plane = planes.data() + (f >> 6) * (size_t)(LC3_PLANE_WORDS * 64) + (f & 63);
-        c.stride = 64;
+        c.plane = LC3_PLANE_COL(planes.data(), f, LC3_PLANE_WORDS);
+        c.stride = LC3_PLANE_STRIDE;
         c.head = 0;
         c.tail = 0;
         int rc = (bad && bad[f]) ? -100 : lc3_parse_frame(c, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10);
