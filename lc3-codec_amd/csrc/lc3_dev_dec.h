@@ -297,23 +297,14 @@ __device__ __noinline__ int lc3_dec_load_frame(const lc3_cfg &c, lc3_dec_lds &L,
     for (int k = lane; k < ne; k += LC3_WAVE) xi[k] = plane[(LC3_PLANE_X + k) * stride];
     LC3_SYNC();
     if (!si[AD_OK]) return 0;
-    uint32_t *part = (uint32_t *)L.sm;  // [0,64) nnz per lane, [64,128) seed partial sums
-    {
-        uint32_t nnz = 0, seed = 0;
-        for (int k = lane; k < ne; k += LC3_WAVE) {
-            const int32_t v = xi[k];
-            nnz += v != 0;
-            seed += (uint32_t)(v < 0 ? -v : v) * (uint32_t)k;
-        }
-        part[lane] = nnz;
-        part[64 + lane] = seed;
-    }
-    LC3_SYNC();
     uint32_t nnz = 0, seed = 0;
-    _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) {
-        nnz += part[i];
-        seed += part[64 + i];
+    for (int k = lane; k < ne; k += LC3_WAVE) {
+        const int32_t v = xi[k];
+        nnz += v != 0;
+        seed += (uint32_t)(v < 0 ? -v : v) * (uint32_t)k;
     }
+    nnz = lc3_wave_sum_u32(nnz, lane);
+    seed = lc3_wave_sum_u32(seed, lane);
     const int lsb_mode = si[SI_LSB_MODE], tail0 = si[AD_TAIL0], nres_max = si[AD_NRES_MAX];
     int n_res = 0, ok = 1;
     if (!lsb_mode) {
@@ -353,7 +344,6 @@ __device__ __noinline__ void lc3_dec_spectrum(const lc3_cfg &c, lc3_dec_lds &L, 
     // is all zero takes state j + 1 of the LCG s <- (13849 + 31821 s) & 0xFFFF.  Both ranks are prefix counts, and
     // the LCG is affine mod 2^16, so each lane owns 7 consecutive lines and jumps straight to its first state.
     {
-        uint32_t *part = (uint32_t *)L.sm;  // [0,64) non-zero counts, [64,128) fill counts
         const int k0 = 7 * lane;
         const int n_res = si[SI_LSB_MODE] ? 0 : si[AD_NRES];
         const int do_fill = !si[AD_ZERO];
@@ -375,14 +365,8 @@ __device__ __noinline__ void lc3_dec_spectrum(const lc3_cfg &c, lc3_dec_lds &L, 
                 }
             }
         }
-        part[lane] = (uint32_t)__builtin_popcount(nzmask);
-        part[64 + lane] = (uint32_t)__builtin_popcount(fillmask);
-        LC3_SYNC();
-        int rank_nz = 0, rank_fill = 0;
-        _Pragma("nounroll") for (int i = 0; i < lane; i++) {
-            rank_nz += (int)part[i];
-            rank_fill += (int)part[64 + i];
-        }
+        int rank_nz = (int)lc3_wave_exscan_u32((uint32_t)__builtin_popcount(nzmask), lane);
+        const int rank_fill = (int)lc3_wave_exscan_u32((uint32_t)__builtin_popcount(fillmask), lane);
         // LCG state after rank_fill steps: compose the affine map with itself by binary exponentiation
         uint32_t lcg = (uint32_t)si[AD_SEED];
         {

@@ -1071,13 +1071,7 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_
                          ((uint32_t)(b == 1) << 26) | ((uint32_t)(a != 0) << 27) | ((uint32_t)(b != 0) << 28);
             }
         }
-        part[128 + lane] = (uint32_t)(hi_nz + 1);
-        LC3_SYNC();
-        int hi_all = 0;  // 1 + index of the last non-zero tuple
-        _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) {
-            const int v = (int)part[128 + i];
-            hi_all = v > hi_all ? v : hi_all;
-        }
+        const int hi_all = lc3_wave_max_i32(hi_nz + 1, lane);  // 1 + index of the last non-zero tuple
         const int lastnz = hi_all < 1 ? 2 : 2 * hi_all;  // `while lastnz > 2 && last pair == 0` (:270-273)
         const int ntup = lastnz / 2;
         uint32_t est4[4], run = 0, lsb_sum = 0;
@@ -1107,16 +1101,8 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_
                 run += est;
             }
         }
-        part[lane] = run;
-        part[64 + lane] = lsb_sum;
-        LC3_SYNC();
-        uint32_t base = 0, est_total = 0, lsb_total = 0;
-        _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) {
-            const uint32_t e = part[i];
-            if (i < lane) base += e;
-            est_total += e;
-            lsb_total += part[64 + i];
-        }
+        const uint32_t base = lc3_wave_exscan_u32(run, lane);
+        const uint32_t est_total = lc3_wave_sum_u32(run, lane), lsb_total = lc3_wave_sum_u32(lsb_sum, lane);
         // lastnz_trunc / nbits_trunc: the last non-zero tuple whose running estimate still fits nbits_spec (:327-330)
         int cand_k = -1;
         uint32_t cand_est = 0, acc = base;
@@ -1131,19 +1117,12 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_
                 }
             }
         }
+        // the owner of the highest qualifying tuple publishes its running estimate
+        const int best_k = lc3_wave_max_i32(cand_k, lane);
         LC3_SYNC();
-        part[128 + lane] = (uint32_t)(cand_k + 1);
-        part[lane] = cand_est;
+        if (cand_k == best_k && best_k >= 0) part[0] = cand_est;
         LC3_SYNC();
-        int best_k = -1;
-        uint32_t best_est = 0;
-        _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) {
-            const int v = (int)part[128 + i] - 1;
-            if (v > best_k) {
-                best_k = v;
-                best_est = part[i];
-            }
-        }
+        const uint32_t best_est = best_k >= 0 ? part[0] : 0u;
         LC3_SYNC();
         if (lane == 0) {
             L.ism[0] = lastnz;
@@ -1212,8 +1191,6 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_ld
     // others add a linear term; tmp is a sequential f32 sum.  The terms are computed one lane per group (the first
     // group at/above the gain is a max-reduction), the f32 accumulation stays sequential on lane 0.
     {
-        float *term = e + 256;                  // 100 per-group contributions
-        int *hi_part = (int *)(e + 384);        // 64 per-lane maxima
         int fac = 256, gg_ind = 255;
         for (int it = 0; it < 8; it++) {
             fac >>= 1;
@@ -1222,28 +1199,22 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_ld
             int hi = -1;
             for (int n = lane; n < ne4; n += LC3_WAVE)
                 if (!(e[n] * 28.0f / 20.0f < g)) hi = n;
-            hi_part[lane] = hi;
-            LC3_SYNC();
-            hi = -1;
-            _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) hi = hi_part[i] > hi ? hi_part[i] : hi;
-            for (int n = lane; n < ne4; n += LC3_WAVE) {
-                const float ei = e[n];
-                float tv;
-                if (ei * 28.0f / 20.0f < g) tv = n < hi ? 2.7f * 28.0f / 20.0f : 0.0f;
-                else if (g < (ei * 28.0f / 20.0f - 43.0f * 28.0f / 20.0f))
-                    tv = 2.0f * ei * 28.0f / 20.0f - 2.0f * g - 36.0f * 28.0f / 20.0f;
-                else tv = ei * 28.0f / 20.0f - g + 7.0f * 28.0f / 20.0f;
-                term[n] = tv;
+            hi = lc3_wave_max_i32(hi, lane);
+            float tv[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int n = lane + LC3_WAVE * q;
+                if (n < ne4) {
+                    const float ei = e[n];
+                    if (ei * 28.0f / 20.0f < g) tv[q] = n < hi ? 2.7f * 28.0f / 20.0f : 0.0f;
+                    else if (g < (ei * 28.0f / 20.0f - 43.0f * 28.0f / 20.0f))
+                        tv[q] = 2.0f * ei * 28.0f / 20.0f - 2.0f * g - 36.0f * 28.0f / 20.0f;
+                    else tv[q] = ei * 28.0f / 20.0f - g + 7.0f * 28.0f / 20.0f;
+                }
             }
-            LC3_SYNC();
-            if (lane == 0) {
-                float tmp = 0.0f;
-                for (int n = ne4 - 1; n >= 0; n--) tmp += term[n];
-                L.ism[11] = (tmp > (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f) && hi >= 0;
-            }
-            LC3_SYNC();
-            if (L.ism[11]) gg_ind += fac;
-            LC3_SYNC();
+            // tmp: sequential f32 sum in the reference's order (groups from the top down)
+            const float tmp = lc3_wave_seqsum2(tv[0], tv[1], ne4, 1, lane);
+            if ((tmp > (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f) && hi >= 0) gg_ind += fac;
         }
         if (lane == 0) {
             // global_gain_limitation :212-228
@@ -1341,16 +1312,9 @@ __device__ __noinline__ void lc3_enc_residual_noise(const lc3_cfg &c, lc3_enc_ld
             }
         }
     }
-    part[lane] = (uint32_t)__builtin_popcount(nzmask);
-    part[64 + lane] = (uint32_t)__builtin_popcount(relmask);
-    LC3_SYNC();
-    int rank_nz = 0, rank_rel = 0, tot_nz = 0, tot_rel = 0;
-    _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) {
-        const int a = (int)part[i], b = (int)part[64 + i];
-        if (i < lane) { rank_nz += a; rank_rel += b; }
-        tot_nz += a;
-        tot_rel += b;
-    }
+    const uint32_t cnt_nz = (uint32_t)__builtin_popcount(nzmask), cnt_rel = (uint32_t)__builtin_popcount(relmask);
+    int rank_nz = (int)lc3_wave_exscan_u32(cnt_nz, lane), rank_rel = (int)lc3_wave_exscan_u32(cnt_rel, lane);
+    const int tot_nz = (int)lc3_wave_sum_u32(cnt_nz, lane), tot_rel = (int)lc3_wave_sum_u32(cnt_rel, lane);
 #pragma unroll
     for (int j = 0; j < 7; j++) {
         const int k = k0 + j;

@@ -18,6 +18,50 @@
 
 #define LC3_SYNC() __syncthreads()
 #include "lc3_dev_common.h"
+// ---- wave-level primitives used by the stage code (64 lanes, results wave-uniform unless noted) -----------------
+// integer max / sum over the wave and exclusive prefix sum: butterfly / Hillis-Steele over cross-lane shuffles
+__device__ __forceinline__ int lc3_wave_max_i32(int v, int lane) {
+    (void)lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t lc3_wave_sum_u32(uint32_t v, int lane) {
+    (void)lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+// returns the sum over lanes < lane (per lane)
+__device__ __forceinline__ uint32_t lc3_wave_exscan_u32(uint32_t v, int lane) {
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t w = (uint32_t)__shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += w;
+    }
+    return inc - v;
+}
+// sequential f32 sum  ((0 + a[first]) + a[first+step]) + ...  over n elements held one per lane in registers:
+// element i lives in lane (i & 63) of (i < 64 ? r0 : r1).  descending = 1 walks i = n-1 .. 0.  The additions run
+// in the given order on wave-uniform values (v_readlane), so the result is bit-identical to the serial loop.
+__device__ __forceinline__ float lc3_wave_seqsum2(float r0, float r1, int n, int descending, int lane) {
+    (void)lane;
+    float acc = 0.0f;
+    const int b0 = __builtin_bit_cast(int, r0), b1 = __builtin_bit_cast(int, r1);
+    if (descending) {
+        for (int i = n - 1; i >= 64; i--) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(b1, i - 64));
+        for (int i = (n < 64 ? n : 64) - 1; i >= 0; i--) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(b0, i));
+    } else {
+        for (int i = 0; i < (n < 64 ? n : 64); i++) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(b0, i));
+        for (int i = 64; i < n; i++) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(b1, i - 64));
+    }
+    return acc;
+}
+
 #ifdef LC3_PROFILE
 // Diagnostic build (liblc3gpu_prof.so): lane 0 of every wave adds the shader-clock cycles between consecutive
 // stage stamps into a global table.  Stamp i accumulates the time since the previous stamp into slot i.
