@@ -16,6 +16,7 @@
 // The including translation unit provides LC3_SYNC() (a workgroup barrier for the
 // one-wave workgroup) and the __device__ / __forceinline__ keywords.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #define LC3_TABLE_QUAL static __device__ const
@@ -25,6 +26,20 @@
 // build compiles them away.
 #ifndef LC3_STAMP
 #define LC3_STAMP(L, lane, id)
+#endif
+
+// How the stage functions receive the codec configuration.  Default: by reference.  The HIP translation unit passes
+// a slot number into a __constant__ table instead (lc3gpu.hip), so that the fields are scalar loads.
+#ifndef LC3_CFG_PARAM
+#define LC3_CFG_PARAM const lc3_cfg &c
+#define LC3_CFG_BIND
+#define LC3_CFG_PASS c
+#endif
+
+// Pointer to read-only HBM data handed to a stage function: the HIP translation unit marks the address space so that
+// the loads are global_load rather than flat_load.
+#ifndef LC3_HBM_CONST
+#define LC3_HBM_CONST(T) const T *
 #endif
 
 #define LC3_WAVE 64
@@ -47,6 +62,9 @@
 #define LC3_MAX_NF 480
 #define LC3_MAX_NE 400
 
+// four consecutive floats at a 16-byte aligned address (one ds_read_b128 / global_load_dwordx4)
+struct __attribute__((aligned(16))) lc3_f4 { float x, y, z, w; };
+
 struct lc3_cpx {
     float r, i;
 };
@@ -65,6 +83,10 @@ struct lc3_cfg {
     // encoder LTPF (encoder/long_term_post_filter.rs:93-127)
     int len12, len6, delay12, p_up, hist;
     float resamp_scale;  // p as f32 * resampling_factor
+    // polyphase layout of the resampling low-pass: row ph (0..p_up-1) holds taps k = -lim..lim of phase ph, zero padded
+    // to resamp_nt (multiple of 4) taps, rows resamp_stride floats apart (lc3_resamp_poly_value)
+    int resamp_lim, resamp_nt, resamp_stride;
+    const float *resamp_poly;
     // decoder LTPF (decoder/long_term_post_filter.rs:104-134)
     int l_den, l_num, num_mem_blocks, norm, s25;
 };
@@ -454,6 +476,17 @@ static __device__ const int LC3C_TNSDEC75[5][4] = {{9, 60, 0, 0}, {9, 120, 0, 0}
 // ------------------------------------------------------------------------------------------
 // static tables selected by configuration
 // ------------------------------------------------------------------------------------------
+// Element i of the polyphase resampler table (encoder/long_term_post_filter.rs:152-166): row ph = i / stride,
+// tap j = i % stride stands for k = j - lim of the reference loop, i.e. tab_resamp_filter[119 + p*k - ph] while
+// that index lies strictly inside (-120, 120) and k <= lim; zero elsewhere.  A zero tap adds x * 0 = +-0 to the
+// running f32 sum, which leaves it unchanged, so the padded sum equals the reference's guarded one bit for bit.
+__device__ __forceinline__ float lc3_resamp_poly_value(int p, int lim, int stride, int i) {
+    const int ph = i / stride, j = i - ph * stride;
+    const int index_h = p * (j - lim) - ph;
+    if (j > 2 * lim || index_h <= -120 || index_h >= 120) return 0.0f;
+    return lc3_f(LC3T_TAB_RESAMP_FILTER_BITS, 119 + index_h);
+}
+
 __device__ __forceinline__ const uint32_t *lc3_window_bits(const lc3_cfg &c) {
     if (c.n_ms_10) {
         switch (c.fs_ind) {

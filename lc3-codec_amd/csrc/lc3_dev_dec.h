@@ -35,6 +35,9 @@ struct lc3_dec_lds {
     float sm[192];
     int ism[64];
     unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
+#ifdef LC3_PROFILE
+    unsigned long long prof_acc[32];  // diagnostic build: per-wave stage totals, flushed once per launch
+#endif
 };
 
 __device__ __forceinline__ void lc3_dec_state_init(lc3_dec_lds &L, int lane, lc3_dec_state *g) {
@@ -97,7 +100,8 @@ __device__ __forceinline__ void lc3_mpvq_deenum(int dim_in, int k_val_in, int ls
 // ------------------------------------------------------------------------------------------
 // D10: IMDCT + window + overlap-add (decoder/modified_dct.rs:76-151); spec -> time samples in spec
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ void lc3_dec_imdct(const lc3_cfg &c, lc3_dec_lds &L, int lane) {
+__device__ __noinline__ void lc3_dec_imdct(LC3_CFG_PARAM, lc3_dec_lds &L, int lane) {
+    LC3_CFG_BIND;
     const int nf = c.nf, ne = c.ne, z = c.z, h = nf / 2;
     const uint32_t *w = lc3_window_bits(c);
     float *freq = L.spec;
@@ -105,6 +109,7 @@ __device__ __noinline__ void lc3_dec_imdct(const lc3_cfg &c, lc3_dec_lds &L, int
     for (int n = ne + lane; n < nf; n += LC3_WAVE) freq[n] = 0.0f;
     LC3_SYNC();
     lc3_dct4_wave(c, lane, freq, L.fa, L.fb);
+    LC3_STAMP(L, lane, 25);
     // unfold :97-136, gain, reversed window :89-91 -- values are staged in registers because t aliases fa/fb
     const float gain = 1.0f / lc3_sqrtf(2.0f * (float)nf);
     for (int n = lane; n < h; n += LC3_WAVE) {
@@ -145,8 +150,9 @@ __device__ __forceinline__ float lc3_ltpf_filter(const lc3_cfg &c, const lc3_dec
     return acc;
 }
 
-__device__ __noinline__ void lc3_dec_ltpf(const lc3_cfg &c, lc3_dec_lds &L, int lane, int is_active, int pitch_index,
+__device__ __noinline__ void lc3_dec_ltpf(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int is_active, int pitch_index,
                                              int nbits) {
+    LC3_CFG_BIND;
     const int nf = c.nf, blk = L.st.block_start_index, s25 = c.s25;
     const int ncn = c.l_num + 1, ncd = c.l_den + 1;
     float *freq = L.spec;
@@ -287,14 +293,17 @@ __device__ __noinline__ void lc3_dec_ltpf(const lc3_cfg &c, lc3_dec_lds &L, int 
 // noise-filling seed  sum |x_k| * k  (:140-145, wrapping) and the zero-frame flag.
 // Returns 1 when the frame parsed, 0 -> conceal.
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_dec_load_frame(const lc3_cfg &c, lc3_dec_lds &L, int lane, const uint8_t *in, int nbytes,
+__device__ __noinline__ int lc3_dec_load_frame(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, const uint8_t *in, int nbytes,
                                                const int32_t *plane, int stride) {
+    LC3_CFG_BIND;
     int *si = L.ism;
     int32_t *xi = (int32_t *)L.fb;  // 400 ints
     const int ne = c.ne;
-    for (int i = lane; i < nbytes; i += LC3_WAVE) L.in[i] = in[i];
-    if (lane < SI_WORDS) si[lane] = plane[(LC3_PLANE_SI + lane) * stride];
-    for (int k = lane; k < ne; k += LC3_WAVE) xi[k] = plane[(LC3_PLANE_X + k) * stride];
+    LC3_HBM_CONST(uint8_t) gin = (LC3_HBM_CONST(uint8_t))in;
+    LC3_HBM_CONST(int32_t) gplane = (LC3_HBM_CONST(int32_t))plane;
+    for (int i = lane; i < nbytes; i += LC3_WAVE) L.in[i] = gin[i];
+    if (lane < SI_WORDS) si[lane] = gplane[(LC3_PLANE_SI + lane) * stride];
+    for (int k = lane; k < ne; k += LC3_WAVE) xi[k] = gplane[(LC3_PLANE_X + k) * stride];
     LC3_SYNC();
     if (!si[AD_OK]) return 0;
     uint32_t nnz = 0, seed = 0;
@@ -332,7 +341,8 @@ __device__ __noinline__ int lc3_dec_load_frame(const lc3_cfg &c, lc3_dec_lds &L,
 // ------------------------------------------------------------------------------------------
 // D4-D8: residual refinement, noise filling, global gain, TNS synthesis, SNS (decoder/lc3_decoder.rs:93-131)
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ void lc3_dec_spectrum(const lc3_cfg &c, lc3_dec_lds &L, int lane, int nbits) {
+__device__ __noinline__ void lc3_dec_spectrum(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbits) {
+    LC3_CFG_BIND;
     const int ne = c.ne;
     int *si = L.ism;
     const int32_t *xi = (const int32_t *)L.fb;
@@ -406,6 +416,7 @@ __device__ __noinline__ void lc3_dec_spectrum(const lc3_cfg &c, lc3_dec_lds &L, 
         }
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 22);
     // global_gain::apply_global_gain (decoder/global_gain.rs:15-25)
     {
         const int fs = c.fs_ind + 1, q = nbits / (10 * fs);
@@ -448,6 +459,7 @@ __device__ __noinline__ void lc3_dec_spectrum(const lc3_cfg &c, lc3_dec_lds &L, 
                 }
             }
         }
+        LC3_STAMP(L, lane, 23);
         // spectral_noise_shaping::decode (decoder/spectral_noise_shaping.rs:21-151): scale factors
         int *y = (int *)(L.sm + 96), *zv = y + 16;
         float *scf = L.sm, *sfi = L.sm + 16;  // 16 + 64
@@ -496,6 +508,7 @@ __device__ __noinline__ void lc3_dec_spectrum(const lc3_cfg &c, lc3_dec_lds &L, 
         }
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 24);
     // band gains via fast_math::exp2_raw and spectral shaping -- one lane per band
     if (lane < c.nb) {
         const uint16_t *ifs = lc3_band_index(c);
@@ -515,7 +528,8 @@ __device__ __forceinline__ void lc3_dec_plc_save(const lc3_cfg &c, lc3_dec_lds &
         L.st.plc_alpha = 1.0f;
     }
 }
-__device__ __noinline__ void lc3_dec_plc_load(const lc3_cfg &c, lc3_dec_lds &L, int lane, const lc3_dec_state *g) {
+__device__ __noinline__ void lc3_dec_plc_load(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, const lc3_dec_state *g) {
+    LC3_CFG_BIND;
     // The sign-scrambling LCG seed_k = (16831 + seed_{k-1} * 12821) & 0xFFFF is affine mod 2^16, so lane l can
     // jump straight to its elements k = l, l + 64, ...: seed_{k+64} = A64 * seed_k + C64 (integer, exact).
     const int ne = c.ne;
@@ -550,27 +564,28 @@ __device__ __noinline__ void lc3_dec_plc_load(const lc3_cfg &c, lc3_dec_lds &L, 
 // in: nbytes in HBM; pcm_out: nf samples in HBM (4-byte aligned); plane/stride: the frame's parsed column
 // (lc3_dev_dec_parse.h); g: the stream's state blob in HBM.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lc3_decode_frame_wave(const lc3_cfg &c, lc3_dec_lds &L, int lane, const uint8_t *in,
+__device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, const uint8_t *in,
                                                       int nbytes, int16_t *pcm_out, const int32_t *plane, int stride,
                                                       lc3_dec_state *g) {
+    LC3_CFG_BIND;
     const int nf = c.nf, nbits = nbytes * 8;
     LC3_STAMP(L, lane, 16);
-    const int ok = lc3_dec_load_frame(c, L, lane, in, nbytes, plane, stride);
+    const int ok = lc3_dec_load_frame(LC3_CFG_PASS, L, lane, in, nbytes, plane, stride);
     LC3_STAMP(L, lane, 17);
     int ltpf_active = 0, pitch_index = 0;
     if (ok) {
         ltpf_active = L.ism[SI_LTPF_ACTIVE];
         pitch_index = L.ism[SI_PITCH_INDEX];
-        lc3_dec_spectrum(c, L, lane, nbits);
+        lc3_dec_spectrum(LC3_CFG_PASS, L, lane, nbits);
         lc3_dec_plc_save(c, L, lane, g);
     } else {
-        lc3_dec_plc_load(c, L, lane, g);
+        lc3_dec_plc_load(LC3_CFG_PASS, L, lane, g);
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 18);
-    lc3_dec_imdct(c, L, lane);
+    lc3_dec_imdct(LC3_CFG_PASS, L, lane);
     LC3_STAMP(L, lane, 19);
-    lc3_dec_ltpf(c, L, lane, ltpf_active, pitch_index, nbits);
+    lc3_dec_ltpf(LC3_CFG_PASS, L, lane, ltpf_active, pitch_index, nbits);
     LC3_STAMP(L, lane, 20);
     // output_scaling::scale_and_round (decoder/output_scaling.rs:13-25); two samples per 32-bit store
     {

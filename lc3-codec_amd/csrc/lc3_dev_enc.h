@@ -26,12 +26,13 @@ struct lc3_enc_state {
     int reset_offset_old;
     float nbits_offset_old;
     int nbits_est_old;
-    int pad;
+    int pad;                 // keeps the blob (and the LDS arrays behind it) a multiple of 16 bytes
 };
+static_assert(sizeof(lc3_enc_state) % 16 == 0, "encoder state blob must keep 16-byte alignment of the LDS arrays");
 #define LC3_ENC_STATE_WORDS ((int)(sizeof(lc3_enc_state) / 4))
 
 // LDS working set of one encoder wave (~12 KB)
-struct lc3_enc_lds {
+struct __attribute__((aligned(16))) lc3_enc_lds {
     lc3_enc_state st;        // resident copy of the stream state (x12/x6/hist are worked on in place)
     float spec[LC3_MAX_NF];  // MDCT output -> SNS -> TNS spectrum (mdct_out / spec_lines)
     lc3_cpx fa[LC3_MAX_NF / 2];  // FFT input; afterwards scratch (must directly follow spec: symbol list spans both)
@@ -43,7 +44,12 @@ struct lc3_enc_lds {
     float sm[192];           // small scratch (per-stage)
     int ism[64];
     unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
+#ifdef LC3_PROFILE
+    unsigned long long prof_acc[32];  // diagnostic build: per-wave stage totals, flushed once per launch
+#endif
 };
+
+static_assert(offsetof(lc3_enc_lds, fa) % 16 == 0 && offsetof(lc3_enc_lds, spec) % 16 == 0, "128-bit LDS reads need aligned buffers");
 
 struct lc3_sns_res { int ind_lf, ind_hf, shape_j, gind, ls_inda, ls_indb; uint32_t index_joint_j; };
 struct lc3_tns_res { int nbits_tns, lpc_weighting, num_tns_filters; int rc_order[2]; };  // rc_i / rc_q live in LDS
@@ -84,7 +90,8 @@ __device__ __forceinline__ void lc3_enc_state_store(lc3_enc_lds &L, int lane, lc
 // ------------------------------------------------------------------------------------------
 // E1-E6: MDCT analysis (encoder/modified_dct.rs:108-177)
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_enc_mdct(const lc3_cfg &c, lc3_enc_lds &L, int lane, const int16_t *pcm) {
+__device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const int16_t *pcm) {
+    LC3_CFG_BIND;
     const int nf = c.nf, z = c.z, h = nf / 2, mid = 3 * h;
     const uint32_t *w = lc3_window_bits(c);
     const uint16_t *ifs = lc3_band_index(c);
@@ -92,7 +99,7 @@ __device__ __noinline__ int lc3_enc_mdct(const lc3_cfg &c, lc3_enc_lds &L, int l
     // The frame is fetched from HBM as 32-bit words (two samples per lane per load, coalesced).
     for (int i = lane; i < nf - z; i += LC3_WAVE) L.t[i] = L.st.hist[i];
     {
-        const uint32_t *p32 = (const uint32_t *)pcm;
+        LC3_HBM_CONST(uint32_t) p32 = (LC3_HBM_CONST(uint32_t))pcm;
         for (int i = lane; i < nf / 2; i += LC3_WAVE) {
             uint32_t v = p32[i];
             L.t[nf - z + 2 * i] = (int16_t)(v & 0xffffu);
@@ -145,7 +152,8 @@ __device__ __noinline__ int lc3_enc_mdct(const lc3_cfg &c, lc3_enc_lds &L, int l
 // ------------------------------------------------------------------------------------------
 // E7: bandwidth detector (encoder/bandwidth_detector.rs:64-127), lane 0
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_enc_bandwidth(const lc3_cfg &c, lc3_enc_lds &L, int lane, int *nbits_bw) {
+__device__ __noinline__ int lc3_enc_bandwidth(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int *nbits_bw) {
+    LC3_CFG_BIND;
     *nbits_bw = LC3C_NBITS_BW[c.fs_ind];
     if (c.fs_ind == 0) return 0;  // :66-71 (the reference cannot construct an 8 kHz encoder)
     if (lane == 0) {
@@ -183,7 +191,8 @@ __device__ __noinline__ int lc3_enc_bandwidth(const lc3_cfg &c, lc3_enc_lds &L, 
 // ------------------------------------------------------------------------------------------
 // E8: attack detector (encoder/attack_detector.rs:45-128)
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_enc_attack(const lc3_cfg &c, lc3_enc_lds &L, int lane, int nbytes) {
+__device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int nbytes) {
+    LC3_CFG_BIND;
     const int num_ds = c.n_ms_10 ? 160 : 120, num_blocks = c.n_ms_10 ? 4 : 3, limit = c.n_ms_10 ? 2 : 1;
     int active;
     if (c.fs < 32000) active = 0;
@@ -306,7 +315,8 @@ __device__ __forceinline__ void lc3_mvpq_enum(uint32_t &index, int &lead_sign_in
 // scratch map inside L.fa/L.fb (floats): all disjoint
 //   sE[64] smoothed/log energies, sP[64] padded, sDS[16], sSCF[16], sSCFQ[16], sINT[64],
 //   sST1[16], sR1[16], sT2[16], sABS[16], sXQ[4][16], sDM[64] (stage-1 distortions), iY[4][16]
-__device__ __noinline__ lc3_sns_res lc3_enc_sns(const lc3_cfg &c, lc3_enc_lds &L, int lane, int attack) {
+__device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int attack) {
+    LC3_CFG_BIND;
     float *S = (float *)L.fa;
     float *sE = S, *sP = S + 64, *sDS = S + 128, *sSCF = S + 144, *sSCFQ = S + 160, *sINT = S + 176;
     float *sST1 = S + 240, *sR1 = S + 256, *sT2 = S + 272, *sABS = S + 288, *sXQ = S + 304, *sDM = S + 368;
@@ -574,8 +584,9 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(const lc3_cfg &c, lc3_enc_lds &L
 // E11: temporal noise shaping (encoder/temporal_noise_shaping.rs:40-349)
 // rc_i[16] -> L.ism[16..32), rc_q[16] -> L.sm[16..32)
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ lc3_tns_res lc3_enc_tns(const lc3_cfg &c, lc3_enc_lds &L, int lane, int p_bw, int nbits,
+__device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int p_bw, int nbits,
                                                   int near_nyquist) {
+    LC3_CFG_BIND;
     const lc3_tns_params &tp = c.n_ms_10 ? LC3C_TNS10[p_bw] : LC3C_TNS75[p_bw];
     float *S = (float *)L.fa;
     float *sAC = S;        // [2][9][3] partial autocorrelations
@@ -783,8 +794,9 @@ __device__ __forceinline__ float lc3_ltpf_dot(const float *x12, int n, int d) { 
     return acc;
 }
 
-__device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(const lc3_cfg &c, lc3_enc_lds &L, int lane, int near_nyquist,
+__device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int near_nyquist,
                                                     int nbits) {
+    LC3_CFG_BIND;
     const int len12 = c.len12, len6 = c.len6, p = c.p_up;
     const int x12_len = len12 + c.delay12 + LC3_NMEM;
     float *x12 = L.st.x12, *x6 = L.st.x6;
@@ -800,37 +812,64 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(const lc3_cfg &c, lc3_enc_lds 
 
     // shift_out_old_samples :217-229.  Each lane first reads its elements, then all write (in-place shift).
     {
-        float v[7];
-        int cnt = 0;
-        for (int i = lane; i < x12_len - len12; i += LC3_WAVE) v[cnt++] = x12[i + len12];
+        const int keep12 = x12_len - len12, keep6 = 178 - len6;  // <= 276, <= 130
+        float v[5], w[3];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int i = lane + LC3_WAVE * j;
+            v[j] = i < keep12 ? x12[i + len12] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = lane + LC3_WAVE * j;
+            w[j] = i < keep6 ? x6[i + len6] : 0.0f;
+        }
         LC3_SYNC();
-        cnt = 0;
-        for (int i = lane; i < x12_len - len12; i += LC3_WAVE) x12[i] = v[cnt++];
-        cnt = 0;
-        for (int i = lane; i < 178 - len6; i += LC3_WAVE) v[cnt++] = x6[i + len6];
-        LC3_SYNC();
-        cnt = 0;
-        for (int i = lane; i < 178 - len6; i += LC3_WAVE) x6[i] = v[cnt++];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int i = lane + LC3_WAVE * j;
+            if (i < keep12) x12[i] = v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = lane + LC3_WAVE * j;
+            if (i < keep6) x6[i] = w[j];
+        }
         LC3_SYNC();
     }
-    // resampling :152-166 -- one lane per 12.8 kHz output, taps accumulated in order.
+    // resampling :152-166 -- one lane per 12.8 kHz output, taps accumulated in the reference's order (k ascending).
+    // The low-pass is applied in polyphase form: the configuration's table (lc3_resamp_poly_value: one zero-padded
+    // row of taps per phase) is staged in LDS, so a lane streams its row with 128-bit reads next to the samples.
     // x_s_extended[i] == time buffer t[(nf - z) - hist + i]
     {
+        const int p_rows = p * c.resamp_stride, nt = c.resamp_nt, lim = c.resamp_lim;
+        for (int i = lane; i < p_rows; i += LC3_WAVE) S[i] = c.resamp_poly[i];
+        LC3_SYNC();
         const int16_t *xs = L.t + (c.nf - c.z) - c.hist;
-        const int lim = 120 / p;
         float *o12 = x12 + c.delay12 + LC3_NMEM;
-        for (int n = lane; n < len12; n += LC3_WAVE) {
-            float acc = 0.0f;
-            const int base = (15 * n) / p - lim, ph = (15 * n) % p;
-            for (int k = -lim; k <= lim; k++) {
-                int index_h = p * k - ph;
-                if (index_h > -120 && index_h < 120)
-                    acc += (float)xs[c.hist + base + k] * lc3_f(LC3T_TAB_RESAMP_FILTER_BITS, 119 + index_h);
-            }
-            o12[n] = acc * c.resamp_scale;
+        const int n0 = lane, has1 = lane + LC3_WAVE < len12;
+        const int n1 = has1 ? lane + LC3_WAVE : lane;
+        const int16_t *xa = xs + c.hist + (15 * n0) / p - 2 * lim;  // tap j <-> k = j - lim
+        const int16_t *xb = xs + c.hist + (15 * n1) / p - 2 * lim;
+        const float *ha = S + ((15 * n0) % p) * c.resamp_stride, *hb = S + ((15 * n1) % p) * c.resamp_stride;
+        float acc0 = 0.0f, acc1 = 0.0f;
+        for (int j = 0; j < nt; j += 4) {
+            const lc3_f4 a = *(const lc3_f4 *)(ha + j), b = *(const lc3_f4 *)(hb + j);
+            acc0 += (float)xa[j] * a.x;
+            acc1 += (float)xb[j] * b.x;
+            acc0 += (float)xa[j + 1] * a.y;
+            acc1 += (float)xb[j + 1] * b.y;
+            acc0 += (float)xa[j + 2] * a.z;
+            acc1 += (float)xb[j + 2] * b.z;
+            acc0 += (float)xa[j + 3] * a.w;
+            acc1 += (float)xb[j + 3] * b.w;
         }
+        LC3_SYNC();
+        if (n0 < len12) o12[n0] = acc0 * c.resamp_scale;
+        if (has1) o12[n1] = acc1 * c.resamp_scale;
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 12);
     // 50 Hz high-pass :168-177 -- recursive across samples and frames: lane 0
     if (lane == 0) {
         float *o12 = x12 + c.delay12 + LC3_NMEM;
@@ -845,6 +884,7 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(const lc3_cfg &c, lc3_enc_lds 
         L.st.h50_m2 = m2;
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 13);
     // pitch_detection :232-290
     for (int n = lane; n < len6; n += LC3_WAVE) {
         const float *s = x12 + LC3_NMEM - 3 + 2 * n;
@@ -907,6 +947,7 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(const lc3_cfg &c, lc3_enc_lds 
         L.ism[3] = pitch_present;
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 14);
     // pitch_lag_parameter :292-363
     const int t_current = L.ism[2];
     const int k_min = 2 * t_current - 4 > 32 ? 2 * t_current - 4 : 32;
@@ -964,6 +1005,7 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(const lc3_cfg &c, lc3_enc_lds 
         L.ism[6] = pitch_index;
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 15);
     // activation_bit :365-409 -- interpolated signals in parallel, the three 128-term sums on three lanes
     {
         const int pitch_int = L.ism[4], pitch_fr = L.ism[5];
@@ -1026,13 +1068,13 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(const lc3_cfg &c, lc3_enc_lds 
 // ------------------------------------------------------------------------------------------
 // E17: spectral quantisation (encoder/spectral_quantization.rs:75-395)
 // ------------------------------------------------------------------------------------------
-struct lc3_bitcons { int rate_flag, lastnz, nbits_lsb, lastnz_trunc, nbits_est, nbits_trunc, mode_flag; };
+struct lc3_bitcons { int rate_flag, lastnz, nbits_lsb, lastnz_trunc, nbits_est, nbits_trunc, mode_flag, lsb_mode; float gg; };
 
 // quantize_spectrum :230-263 + compute_bit_consumption :265-348.
 // Quantisation is lane-parallel; the context-adaptive bit estimate walks tuples in order on lane 0.
-__device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_enc_lds &L, int lane, int nbits,
-                                                            int gg_off, int gg_ind, int nbits_spec, float *gg_out,
-                                                            int *lsb_mode) {
+__device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int nbits,
+                                                            int gg_off, int gg_ind, int nbits_spec) {
+    LC3_CFG_BIND;
     const int ne = c.ne;
     const float gg = lc3_pow10f(((float)gg_ind + (float)gg_off) / 28.0f);
     for (int n = lane; n < ne; n += LC3_WAVE) {
@@ -1144,13 +1186,14 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(const lc3_cfg &c, lc3_
     LC3_SYNC();
     for (int n = bc.lastnz_trunc + lane; n < bc.lastnz; n += LC3_WAVE) L.xq[n] = 0;  // truncation :249-252
     LC3_SYNC();
-    *lsb_mode = bc.mode_flag && bc.nbits_est > nbits_spec;
-    *gg_out = gg;
+    bc.lsb_mode = bc.mode_flag && bc.nbits_est > nbits_spec;
+    bc.gg = gg;
     return bc;
 }
 
-__device__ __noinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_lds &L, int lane, int nbits, int nbits_bw,
+__device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int nbits, int nbits_bw,
                                                       int nbits_tns, int nbits_ltpf) {
+    LC3_CFG_BIND;
     const int ne = c.ne, ne4 = ne / 4;
     float *e = (float *)L.fa;  // 100 group energies
     float *xm = e + 128;       // 64 per-lane maxima
@@ -1186,34 +1229,72 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_ld
         xm[lane] = m;
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 9);
     // global_gain_estimation :174-209 -- 8-step bisection.  Per step the reference walks the group energies from the
     // top: a group below the gain adds a constant only once a group at/above the gain has been seen ("is_zero"), the
     // others add a linear term; tmp is a sequential f32 sum.  The terms are computed one lane per group (the first
     // group at/above the gain is a max-reduction), the f32 accumulation stays sequential on lane 0.
     {
         int fac = 256, gg_ind = 255;
+        float *tvb = xm + 64;  // ne4p floats of per-group terms (+ 20 readable floats behind them)
+        const int ne4p = ((ne4 + 19) / 20) * 20;
+        // the lane's two groups: energy terms that do not depend on the gain are formed once
+        float e14[2], e28[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int n = lane + LC3_WAVE * q;
+            const float ei = n < ne4 ? e[n] : 0.0f;
+            e14[q] = ei * 28.0f / 20.0f;
+            e28[q] = 2.0f * ei * 28.0f / 20.0f;
+        }
         for (int it = 0; it < 8; it++) {
             fac >>= 1;
             gg_ind -= fac;
             const float g = (float)gg_ind + (float)gg_off;
             int hi = -1;
-            for (int n = lane; n < ne4; n += LC3_WAVE)
-                if (!(e[n] * 28.0f / 20.0f < g)) hi = n;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int n = lane + LC3_WAVE * q;
+                if (n < ne4 && !(e14[q] < g)) hi = n;
+            }
             hi = lc3_wave_max_i32(hi, lane);
-            float tv[2] = {0.0f, 0.0f};
+            // terms in the reference's order (groups from the top down) at tvb[ne4 - 1 - n], zero padded to a multiple
+            // of twenty (adding +0 at the end of the sum does not change it)
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const int n = lane + LC3_WAVE * q;
                 if (n < ne4) {
-                    const float ei = e[n];
-                    if (ei * 28.0f / 20.0f < g) tv[q] = n < hi ? 2.7f * 28.0f / 20.0f : 0.0f;
-                    else if (g < (ei * 28.0f / 20.0f - 43.0f * 28.0f / 20.0f))
-                        tv[q] = 2.0f * ei * 28.0f / 20.0f - 2.0f * g - 36.0f * 28.0f / 20.0f;
-                    else tv[q] = ei * 28.0f / 20.0f - g + 7.0f * 28.0f / 20.0f;
+                    float tv;
+                    if (e14[q] < g) tv = n < hi ? 2.7f * 28.0f / 20.0f : 0.0f;
+                    else if (g < (e14[q] - 43.0f * 28.0f / 20.0f)) tv = e28[q] - 2.0f * g - 36.0f * 28.0f / 20.0f;
+                    else tv = e14[q] - g + 7.0f * 28.0f / 20.0f;
+                    tvb[ne4 - 1 - n] = tv;
+                } else if (n < ne4p) tvb[n] = 0.0f;
+            }
+            LC3_SYNC();
+            // tmp: sequential f32 sum, evaluated by every lane on the same (broadcast) LDS reads; the terms are fetched
+            // 20 at a time, one chunk ahead of the additions
+            float tmp = 0.0f;
+            {
+                const lc3_f4 *tv4 = (const lc3_f4 *)tvb;
+                lc3_f4 cur[5], nxt[5];
+#pragma unroll
+                for (int u = 0; u < 5; u++) cur[u] = tv4[u];
+                for (int i = 0; i < ne4p; i += 20) {
+#pragma unroll
+                    for (int u = 0; u < 5; u++) nxt[u] = tv4[i / 4 + 5 + u];  // one chunk past the end is scratch space
+#pragma unroll
+                    for (int u = 0; u < 5; u++) {
+                        tmp += cur[u].x;
+                        tmp += cur[u].y;
+                        tmp += cur[u].z;
+                        tmp += cur[u].w;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 5; u++) cur[u] = nxt[u];
                 }
             }
-            // tmp: sequential f32 sum in the reference's order (groups from the top down)
-            const float tmp = lc3_wave_seqsum2(tv[0], tv[1], ne4, 1, lane);
+            LC3_SYNC();
             if ((tmp > (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f) && hi >= 0) gg_ind += fac;
         }
         if (lane == 0) {
@@ -1236,9 +1317,9 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_ld
     int gg_ind = L.ism[8];
     const int gg_min = L.ism[9], reset_offset = L.ism[10];
     LC3_SYNC();
-    float gg;
-    int lsb_mode;
-    lc3_bitcons bc = lc3_quantize_spectrum(c, L, lane, nbits, gg_off, gg_ind, nbits_spec, &gg, &lsb_mode);
+    LC3_STAMP(L, lane, 10);
+    lc3_bitcons bc = lc3_quantize_spectrum(LC3_CFG_PASS, L, lane, nbits, gg_off, gg_ind, nbits_spec);
+    LC3_STAMP(L, lane, 11);
     // save state after the FIRST pass :97-100
     if (lane == 0) {
         L.st.nbits_offset_old = nbits_offset;
@@ -1263,16 +1344,16 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_ld
             else gg_ind += 2;
             if (gg_ind < gg_min) gg_ind = gg_min;
         }
-        if (origin != gg_ind) bc = lc3_quantize_spectrum(c, L, lane, nbits, gg_off, gg_ind, nbits_spec, &gg, &lsb_mode);
+        if (origin != gg_ind) bc = lc3_quantize_spectrum(LC3_CFG_PASS, L, lane, nbits, gg_off, gg_ind, nbits_spec);
     }
     res.gg_ind = gg_ind;
     res.nbits_spec = nbits_spec;
     res.nbits_lsb = bc.nbits_lsb;
-    res.lsb_mode = lsb_mode;
+    res.lsb_mode = bc.lsb_mode;
     res.nbits_trunc = bc.nbits_trunc;
     res.rate_flag = bc.rate_flag;
     res.lastnz_trunc = bc.lastnz_trunc;
-    res.gg = gg;
+    res.gg = bc.gg;
     return res;
 }
 
@@ -1280,8 +1361,9 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(const lc3_cfg &c, lc3_enc_ld
 // E18 residual bits (encoder/residual_spectrum.rs:33-62), E19 noise level
 // (encoder/noise_level_estimation.rs:21-55).  Returns n_res via L.ism[0], noise factor via L.ism[1].
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ void lc3_enc_residual_noise(const lc3_cfg &c, lc3_enc_lds &L, int lane,
-                                                    const lc3_quant_res &q, int bw_ind) {
+__device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, lc3_enc_lds &L, int lane,
+                                                    const lc3_quant_res q, int bw_ind) {
+    LC3_CFG_BIND;
     // Both loops of the reference walk the spectrum in order and act on a SUBSET of the lines (non-zero lines for
     // the residual bits, lines with an all-zero neighbourhood for the noise level); the position of a line inside
     // its subset is a prefix count.  Lane l owns lines 7l .. 7l+6: it counts, the counts are prefix-summed, and
@@ -1348,28 +1430,29 @@ __device__ __noinline__ void lc3_enc_residual_noise(const lc3_cfg &c, lc3_enc_ld
 // pcm: nf samples in HBM (4-byte aligned); plane/plane_stride: this frame's column of the packer planes
 // (lc3_dev_enc_pack.h); nbytes selects the bitrate.  dbg (optional): float[3*480] stage dumps.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lc3_encode_frame_wave(const lc3_cfg &c, lc3_enc_lds &L, int lane, const int16_t *pcm,
+__device__ __forceinline__ void lc3_encode_frame_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const int16_t *pcm,
                                                       int32_t *plane, int plane_stride, int nbytes, float *dbg) {
+    LC3_CFG_BIND;
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
-    const int near_nyquist = lc3_enc_mdct(c, L, lane, pcm);
+    const int near_nyquist = lc3_enc_mdct(LC3_CFG_PASS, L, lane, pcm);
     LC3_STAMP(L, lane, 1);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[i] = L.spec[i];
     int nbits_bw;
-    const int bw_ind = lc3_enc_bandwidth(c, L, lane, &nbits_bw);
-    const int attack = lc3_enc_attack(c, L, lane, nbytes);
+    const int bw_ind = lc3_enc_bandwidth(LC3_CFG_PASS, L, lane, &nbits_bw);
+    const int attack = lc3_enc_attack(LC3_CFG_PASS, L, lane, nbytes);
     LC3_STAMP(L, lane, 2);
-    const lc3_sns_res sns = lc3_enc_sns(c, L, lane, attack);
+    const lc3_sns_res sns = lc3_enc_sns(LC3_CFG_PASS, L, lane, attack);
     LC3_STAMP(L, lane, 3);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[480 + i] = L.spec[i];
-    const lc3_tns_res tns = lc3_enc_tns(c, L, lane, bw_ind, nbits, near_nyquist);
+    const lc3_tns_res tns = lc3_enc_tns(LC3_CFG_PASS, L, lane, bw_ind, nbits, near_nyquist);
     LC3_STAMP(L, lane, 4);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[960 + i] = L.spec[i];
-    const lc3_ltpf_res pf = lc3_enc_ltpf(c, L, lane, near_nyquist, nbits);
+    const lc3_ltpf_res pf = lc3_enc_ltpf(LC3_CFG_PASS, L, lane, near_nyquist, nbits);
     LC3_STAMP(L, lane, 5);
-    const lc3_quant_res spec = lc3_enc_quant(c, L, lane, nbits, nbits_bw, tns.nbits_tns, pf.nbits_ltpf);
+    const lc3_quant_res spec = lc3_enc_quant(LC3_CFG_PASS, L, lane, nbits, nbits_bw, tns.nbits_tns, pf.nbits_ltpf);
     LC3_STAMP(L, lane, 6);
-    lc3_enc_residual_noise(c, L, lane, spec, bw_ind);
+    lc3_enc_residual_noise(LC3_CFG_PASS, L, lane, spec, bw_ind);
     LC3_STAMP(L, lane, 7);
     const int n_res = L.ism[0], noise_factor = L.ism[1];
     LC3_SYNC();

@@ -51,6 +51,9 @@ static inline int lc3_make_config(lc3_cfg &c, int frame_us, int fs_hz) {
     default: c.p_up = 4; break;
     }
     c.hist = 240 / c.p_up;
+    c.resamp_lim = 120 / c.p_up;
+    c.resamp_nt = (2 * c.resamp_lim + 1 + 3) & ~3;
+    c.resamp_stride = c.resamp_nt + 4;  // row pitch: keeps the p rows on different LDS banks
     c.resamp_scale = (float)c.p_up * rf;
     // decoder LTPF constants (decoder/long_term_post_filter.rs:104-134)
     switch (fs_hz) {

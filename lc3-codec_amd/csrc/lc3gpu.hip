@@ -11,70 +11,98 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
 #include "../../include/lc3gpu.h"
 
 #define LC3_SYNC() __syncthreads()
+#define LC3_HBM_CONST(T) const __attribute__((address_space(1))) T *
 #include "lc3_dev_common.h"
+// ---- configuration slots ----------------------------------------------------------------------------------------
+// Every (sampling rate, frame duration) pair owns one slot of a __constant__ table; handles register their
+// configuration there (cfg_acquire below) and the kernels pass the slot number down to the stage functions, which
+// bind `c` to the slot through a wave-uniform index: every field is then a scalar (s_load) read that no LDS or HBM
+// store can alias, instead of a load from a by-value copy of the struct in scratch.
+#define LC3_CFG_SLOTS 12
+__constant__ lc3_cfg lc3_cfg_table[LC3_CFG_SLOTS];
+struct lc3_cfg_slot { int id; };
+#undef LC3_CFG_PARAM
+#undef LC3_CFG_BIND
+#undef LC3_CFG_PASS
+#define LC3_CFG_PARAM lc3_cfg_slot cslot
+#define LC3_CFG_BIND const lc3_cfg &c = lc3_cfg_table[__builtin_amdgcn_readfirstlane(cslot.id)]
+#define LC3_CFG_PASS cslot
+
 // ---- wave-level primitives used by the stage code (64 lanes, results wave-uniform unless noted) -----------------
-// integer max / sum over the wave and exclusive prefix sum: butterfly / Hillis-Steele over cross-lane shuffles
+// Integer max / sum over the wave and exclusive prefix sum (any evaluation order is exact for integers).  Built on
+// DPP lane permutes (no LDS crossbar round trips): four steps reduce/scan inside each row of 16 lanes, the four rows
+// are then combined through v_readlane (reductions) or row broadcasts (scan).
+#define LC3_DPP(old, src, ctrl, row_mask, bound) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (row_mask), 0xf, (bound))
+#define LC3_DPP_QUAD_1032 0xB1
+#define LC3_DPP_QUAD_2301 0x4E
+#define LC3_DPP_ROW_HALF_MIRROR 0x141
+#define LC3_DPP_ROW_MIRROR 0x140
+#define LC3_DPP_ROW_SHR(n) (0x110 + (n))
+#define LC3_DPP_ROW_BCAST15 0x142
+#define LC3_DPP_ROW_BCAST31 0x143
 __device__ __forceinline__ int lc3_wave_max_i32(int v, int lane) {
     (void)lane;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
+    int w;
+    w = LC3_DPP(v, v, LC3_DPP_QUAD_1032, 0xf, false); v = w > v ? w : v;
+    w = LC3_DPP(v, v, LC3_DPP_QUAD_2301, 0xf, false); v = w > v ? w : v;
+    w = LC3_DPP(v, v, LC3_DPP_ROW_HALF_MIRROR, 0xf, false); v = w > v ? w : v;
+    w = LC3_DPP(v, v, LC3_DPP_ROW_MIRROR, 0xf, false); v = w > v ? w : v;
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    const int a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+    return a > b ? a : b;
 }
-__device__ __forceinline__ uint32_t lc3_wave_sum_u32(uint32_t v, int lane) {
+__device__ __forceinline__ uint32_t lc3_wave_sum_u32(uint32_t u, int lane) {
     (void)lane;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-    return v;
+    int v = (int)u;
+    v += LC3_DPP(v, v, LC3_DPP_QUAD_1032, 0xf, false);
+    v += LC3_DPP(v, v, LC3_DPP_QUAD_2301, 0xf, false);
+    v += LC3_DPP(v, v, LC3_DPP_ROW_HALF_MIRROR, 0xf, false);
+    v += LC3_DPP(v, v, LC3_DPP_ROW_MIRROR, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane(v, 0) + (uint32_t)__builtin_amdgcn_readlane(v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane(v, 32) + (uint32_t)__builtin_amdgcn_readlane(v, 48);
 }
 // returns the sum over lanes < lane (per lane)
-__device__ __forceinline__ uint32_t lc3_wave_exscan_u32(uint32_t v, int lane) {
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t w = (uint32_t)__shfl_up((int)inc, o, 64);
-        if (lane >= o) inc += w;
-    }
-    return inc - v;
-}
-// sequential f32 sum  ((0 + a[first]) + a[first+step]) + ...  over n elements held one per lane in registers:
-// element i lives in lane (i & 63) of (i < 64 ? r0 : r1).  descending = 1 walks i = n-1 .. 0.  The additions run
-// in the given order on wave-uniform values (v_readlane), so the result is bit-identical to the serial loop.
-__device__ __forceinline__ float lc3_wave_seqsum2(float r0, float r1, int n, int descending, int lane) {
+__device__ __forceinline__ uint32_t lc3_wave_exscan_u32(uint32_t u, int lane) {
     (void)lane;
-    float acc = 0.0f;
-    const int b0 = __builtin_bit_cast(int, r0), b1 = __builtin_bit_cast(int, r1);
-    if (descending) {
-        for (int i = n - 1; i >= 64; i--) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(b1, i - 64));
-        for (int i = (n < 64 ? n : 64) - 1; i >= 0; i--) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(b0, i));
-    } else {
-        for (int i = 0; i < (n < 64 ? n : 64); i++) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(b0, i));
-        for (int i = 64; i < n; i++) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(b1, i - 64));
-    }
-    return acc;
+    int inc = (int)u;
+    inc += LC3_DPP(0, inc, LC3_DPP_ROW_SHR(1), 0xf, true);  // lanes shifted in from outside the row read 0
+    inc += LC3_DPP(0, inc, LC3_DPP_ROW_SHR(2), 0xf, true);
+    inc += LC3_DPP(0, inc, LC3_DPP_ROW_SHR(4), 0xf, true);
+    inc += LC3_DPP(0, inc, LC3_DPP_ROW_SHR(8), 0xf, true);
+    inc += LC3_DPP(0, inc, LC3_DPP_ROW_BCAST15, 0xa, false);  // rows 1,3 += total of rows 0,2
+    inc += LC3_DPP(0, inc, LC3_DPP_ROW_BCAST31, 0xc, false);  // rows 2,3 += total of rows 0..1
+    return (uint32_t)inc - u;
 }
 
 #ifdef LC3_PROFILE
 // Diagnostic build (liblc3gpu_prof.so): lane 0 of every wave adds the shader-clock cycles between consecutive
-// stage stamps into a global table.  Stamp i accumulates the time since the previous stamp into slot i.
-// Never timed as a whole; read its SHARES (cdna_hip_programming.md section 7, in-kernel stamps).
+// stage stamps into a per-wave table in LDS (stamp i accumulates the time since the previous stamp into slot i);
+// the table is flushed to a global one with one atomic per slot at the end of the launch, so the stamps do not put
+// memory traffic inside the stages.  Never timed as a whole; read its SHARES (cdna_hip_programming.md section 7).
 __device__ unsigned long long lc3_prof_acc[32];
-#define LC3_STAMP(L, lane, id)                                                                \
-    do {                                                                                      \
-        if ((lane) == 0) {                                                                    \
-            unsigned long long t_ = clock64();                                                \
-            if ((id) != 0 && (id) != 16) atomicAdd(&lc3_prof_acc[(id)], t_ - (L).prof_last);  \
-            (L).prof_last = t_;                                                               \
-        }                                                                                     \
+#undef LC3_STAMP
+#define LC3_STAMP(L, lane, id)                                                     \
+    do {                                                                           \
+        if ((lane) == 0) {                                                         \
+            unsigned long long t_ = clock64();                                     \
+            if ((id) != 0 && (id) != 16) (L).prof_acc[(id)] += t_ - (L).prof_last; \
+            (L).prof_last = t_;                                                    \
+        }                                                                          \
     } while (0)
+#define LC3_PROF_BEGIN(L, lane) do { if ((lane) < 32) (L).prof_acc[(lane)] = 0; __syncthreads(); } while (0)
+#define LC3_PROF_END(L, lane) \
+    do { __syncthreads(); if ((lane) < 32 && (L).prof_acc[(lane)]) atomicAdd(&lc3_prof_acc[(lane)], (L).prof_acc[(lane)]); } while (0)
+#else
+#define LC3_PROF_BEGIN(L, lane)
+#define LC3_PROF_END(L, lane)
 #endif
 #include "lc3_dev_dec.h"
 #include "lc3_dev_enc.h"
@@ -84,21 +112,24 @@ __device__ unsigned long long lc3_prof_acc[32];
 // kernels
 // ---------------------------------------------------------------------------------------------
 // Analysis kernel: one wave per stream, MDCT ... quantisation, leaves one packer plane column per frame.
-__global__ __launch_bounds__(64, 3) void lc3_encode_kernel(lc3_cfg cfg, lc3_enc_state *states, int first_channel,
+__global__ __launch_bounds__(64, 3) void lc3_encode_kernel(lc3_cfg_slot cfg, lc3_enc_state *states, int first_channel,
                                                           const int16_t *pcm, int32_t *planes, int nbytes, int n_frames,
                                                           int fresh, float *dbg) {
     __shared__ lc3_enc_lds L;
     const int lane = threadIdx.x;
     const int s = blockIdx.x;  // stream index inside this launch
+    const int nf = lc3_cfg_table[cfg.id].nf;
     lc3_enc_state *gst = states + (size_t)(first_channel + s);
+    LC3_PROF_BEGIN(L, lane);
     if (fresh) lc3_enc_state_init(L, lane);
     else lc3_enc_state_load(L, lane, gst);
     for (int t = 0; t < n_frames; t++) {
         const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
         int32_t *plane = LC3_PLANE_COL(planes, f, EP_WORDS);
-        lc3_encode_frame_wave(cfg, L, lane, pcm + f * (size_t)cfg.nf, plane, LC3_PLANE_STRIDE, nbytes, dbg);
+        lc3_encode_frame_wave(cfg, L, lane, pcm + f * (size_t)nf, plane, LC3_PLANE_STRIDE, nbytes, dbg);
     }
     lc3_enc_state_store(L, lane, gst);
+    LC3_PROF_END(L, lane);
 }
 
 // Bitstream packer, one LANE per frame (lc3_dev_enc_pack.h).  blockDim.x frames per workgroup; context lookup and the
@@ -200,21 +231,24 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(int ne, int fs_ind, int 
     }
 }
 
-__global__ __launch_bounds__(64, 3) void lc3_decode_kernel(lc3_cfg cfg, lc3_dec_state *states, int first_channel,
+__global__ __launch_bounds__(64, 3) void lc3_decode_kernel(lc3_cfg_slot cfg, lc3_dec_state *states, int first_channel,
                                                           const uint8_t *in, const int32_t *planes, int16_t *pcm,
                                                           int nbytes, int n_frames, int fresh) {
     __shared__ lc3_dec_lds L;
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
+    const int nf = lc3_cfg_table[cfg.id].nf;
     lc3_dec_state *gst = states + (size_t)(first_channel + s);
+    LC3_PROF_BEGIN(L, lane);
     if (fresh) lc3_dec_state_init(L, lane, gst);
     else lc3_dec_state_load(L, lane, gst);
     for (int t = 0; t < n_frames; t++) {
         const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
         const int32_t *plane = LC3_PLANE_COL(planes, f, LC3_PLANE_WORDS);
-        lc3_decode_frame_wave(cfg, L, lane, in + f * (size_t)nbytes, nbytes, pcm + f * (size_t)cfg.nf, plane, LC3_PLANE_STRIDE, gst);
+        lc3_decode_frame_wave(cfg, L, lane, in + f * (size_t)nbytes, nbytes, pcm + f * (size_t)nf, plane, LC3_PLANE_STRIDE, gst);
     }
     lc3_dec_state_store(L, lane, gst);
+    LC3_PROF_END(L, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -234,30 +268,68 @@ thread_local int g_last_hip = 0;
     } while (0)
 
 struct HostCfg {
-    lc3_cfg c;
-    void *d_tables = nullptr;  // fft_tw | dct_tw | perm in one allocation
+    lc3_cfg c;          // host copy (device pointers inside are valid on the device it was registered on)
+    lc3_cfg_slot slot;  // its slot in lc3_cfg_table
 };
 
 int make_config(lc3_cfg &c, int frame_us, int fs_hz) {
     return lc3_make_config(c, frame_us, fs_hz) ? LC3GPU_EINVAL : LC3GPU_OK;
 }
 
-// build the plan on the host (lc3_host_plan.h) and upload its three tables in one allocation
-int build_tables(HostCfg &h) {
-    lc3_cfg &c = h.c;
-    lc3_host_plan pl;
-    if (lc3_make_plan(c, pl)) return LC3GPU_EINVAL;
-    const int nfft = c.nfft;
-    const size_t bytes_tw = sizeof(lc3_cpx) * (size_t)nfft;
-    const size_t bytes = 2 * bytes_tw + sizeof(uint16_t) * (size_t)nfft;
-    HIP_TRY(hipMalloc(&h.d_tables, bytes));
-    char *base = (char *)h.d_tables;
-    HIP_TRY(hipMemcpy(base, pl.fft_tw.data(), bytes_tw, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(base + bytes_tw, pl.dct_tw.data(), bytes_tw, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(base + 2 * bytes_tw, pl.perm.data(), sizeof(uint16_t) * (size_t)nfft, hipMemcpyHostToDevice));
-    c.fft_tw = (const lc3_cpx *)base;
-    c.dct_tw = (const lc3_cpx *)(base + bytes_tw);
-    c.perm = (const uint16_t *)(base + 2 * bytes_tw);
+// fills the polyphase resampler table of a configuration on the device (lc3_resamp_poly_value)
+__global__ void lc3_resamp_poly_kernel(float *out, int p, int lim, int stride) {
+    const int n = p * stride;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = lc3_resamp_poly_value(p, lim, stride, i);
+}
+
+// Process-wide registry of configuration slots, per device: the plan (lc3_host_plan.h) is built on the host once per
+// (device, rate, duration), its tables are uploaded in one allocation that lives as long as the process, and the
+// filled lc3_cfg is published in the device's lc3_cfg_table.  Encoders and decoders of equal configuration share it.
+#define LC3_MAX_DEVICES 64
+struct CfgRegistry {
+    std::mutex mu;
+    bool ready[LC3_MAX_DEVICES][LC3_CFG_SLOTS] = {};
+    lc3_cfg cfg[LC3_MAX_DEVICES][LC3_CFG_SLOTS];
+};
+CfgRegistry g_cfgs;
+
+int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
+    static const int fs_tab[6] = {8000, 16000, 24000, 32000, 44100, 48000};
+    int k = -1;
+    for (int i = 0; i < 6; i++)
+        if (fs_tab[i] == fs_hz) k = i;
+    if (k < 0 || (frame_us != 7500 && frame_us != 10000)) return LC3GPU_EINVAL;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= LC3_MAX_DEVICES) return LC3GPU_EINVAL;
+    const int slot = 2 * k + (frame_us == 10000);
+    std::lock_guard<std::mutex> lock(g_cfgs.mu);
+    if (!g_cfgs.ready[dev][slot]) {
+        lc3_cfg c;
+        lc3_host_plan pl;
+        if (lc3_make_config(c, frame_us, fs_hz) || lc3_make_plan(c, pl)) return LC3GPU_EINVAL;
+        const size_t bytes_tw = sizeof(lc3_cpx) * (size_t)c.nfft;
+        const size_t bytes_perm = (sizeof(uint16_t) * (size_t)c.nfft + 15) & ~(size_t)15;
+        const size_t bytes_poly = sizeof(float) * (size_t)c.p_up * (size_t)c.resamp_stride;
+        char *base = nullptr;
+        HIP_TRY(hipMalloc((void **)&base, 2 * bytes_tw + bytes_perm + bytes_poly));
+        HIP_TRY(hipMemcpy(base, pl.fft_tw.data(), bytes_tw, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(base + bytes_tw, pl.dct_tw.data(), bytes_tw, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(base + 2 * bytes_tw, pl.perm.data(), sizeof(uint16_t) * (size_t)c.nfft, hipMemcpyHostToDevice));
+        float *poly = (float *)(base + 2 * bytes_tw + bytes_perm);
+        hipLaunchKernelGGL(lc3_resamp_poly_kernel, dim3(1), dim3(256), 0, nullptr, poly, c.p_up, c.resamp_lim, c.resamp_stride);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        c.fft_tw = (const lc3_cpx *)base;
+        c.dct_tw = (const lc3_cpx *)(base + bytes_tw);
+        c.perm = (const uint16_t *)(base + 2 * bytes_tw);
+        c.resamp_poly = poly;
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lc3_cfg_table), &c, sizeof(c), sizeof(c) * (size_t)slot, hipMemcpyHostToDevice));
+        g_cfgs.cfg[dev][slot] = c;
+        g_cfgs.ready[dev][slot] = true;
+    }
+    h.c = g_cfgs.cfg[dev][slot];
+    h.slot.id = slot;
     return LC3GPU_OK;
 }
 
@@ -398,9 +470,8 @@ int lc3gpu_encoder_create(lc3gpu_encoder **out, int num_channels, int frame_us, 
     if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
     lc3gpu_encoder *e = new (std::nothrow) lc3gpu_encoder();
     if (!e) return LC3GPU_EINVAL;
-    e->h.c = c;
     e->num_channels = num_channels;
-    rc = build_tables(e->h);
+    rc = cfg_acquire(e->h, frame_us, fs_hz);
     if (rc) { lc3gpu_encoder_destroy(e); return rc; }
     if (hipMalloc((void **)&e->d_states, sizeof(lc3_enc_state) * (size_t)num_channels) != hipSuccess ||
         hipMalloc((void **)&e->d_pcm1, sizeof(int16_t) * LC3_MAX_NF) != hipSuccess ||
@@ -424,7 +495,6 @@ int lc3gpu_encoder_destroy(lc3gpu_encoder *e) {
     if (e->d_out1) (void)hipFree(e->d_out1);
     if (e->d_dbg) (void)hipFree(e->d_dbg);
     if (e->d_planes) (void)hipFree(e->d_planes);
-    if (e->h.d_tables) (void)hipFree(e->h.d_tables);
     delete e;
     return LC3GPU_OK;
 }
@@ -464,7 +534,7 @@ static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_p
         // materialise any still-fresh channel of the range with a zero-frame launch of the init path
         for (int i = first; i < first + n; i++) {
             if (e->fresh_mask[(size_t)i]) {
-                hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64), 0, stream, e->h.c, e->d_states, i, d_pcm,
+                hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64), 0, stream, e->h.slot, e->d_states, i, d_pcm,
                                    e->d_planes, nbytes, 0, 1, (float *)nullptr);
                 e->fresh_mask[(size_t)i] = 0;
             }
@@ -472,7 +542,7 @@ static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_p
     }
     // stage 1: analysis, one wave per stream; stage 2: bitstream packing, one lane per frame
     e->timer.mark(stream);
-    hipLaunchKernelGGL(lc3_encode_kernel, dim3((unsigned)n), dim3(64), 0, stream, e->h.c, e->d_states, first, d_pcm,
+    hipLaunchKernelGGL(lc3_encode_kernel, dim3((unsigned)n), dim3(64), 0, stream, e->h.slot, e->d_states, first, d_pcm,
                        e->d_planes, nbytes, n_frames, fresh, dbg);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
@@ -528,7 +598,7 @@ int lc3gpu_encoder_state_save(lc3gpu_encoder *e, void *host_dst) {
     // materialise fresh channels first
     for (int i = 0; i < e->num_channels; i++) {
         if (e->fresh_mask[(size_t)i]) {
-            hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64), 0, nullptr, e->h.c, e->d_states, i, e->d_pcm1,
+            hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64), 0, nullptr, e->h.slot, e->d_states, i, e->d_pcm1,
                                e->d_planes, 20, 0, 1, (float *)nullptr);
             e->fresh_mask[(size_t)i] = 0;
         }
@@ -561,7 +631,7 @@ static int decoder_reserve_planes(lc3gpu_decoder *d, size_t frames) {
 
 static int decoder_init_states(lc3gpu_decoder *d) {
     // decoder state is materialised eagerly (fresh = 1, zero frames): PLC counters must survive range launches
-    hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)d->num_channels), dim3(64), 0, nullptr, d->h.c, d->d_states, 0,
+    hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)d->num_channels), dim3(64), 0, nullptr, d->h.slot, d->d_states, 0,
                        (const uint8_t *)d->d_in1, (const int32_t *)d->d_planes, d->d_pcm1, 20, 0, 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -577,9 +647,8 @@ int lc3gpu_decoder_create(lc3gpu_decoder **out, int num_channels, int frame_us, 
     if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
     lc3gpu_decoder *d = new (std::nothrow) lc3gpu_decoder();
     if (!d) return LC3GPU_EINVAL;
-    d->h.c = c;
     d->num_channels = num_channels;
-    rc = build_tables(d->h);
+    rc = cfg_acquire(d->h, frame_us, fs_hz);
     if (rc) { lc3gpu_decoder_destroy(d); return rc; }
     if (hipMalloc((void **)&d->d_states, sizeof(lc3_dec_state) * (size_t)num_channels) != hipSuccess ||
         hipMalloc((void **)&d->d_in1, LC3_MAX_NE) != hipSuccess ||
@@ -600,7 +669,6 @@ int lc3gpu_decoder_destroy(lc3gpu_decoder *d) {
     if (d->d_in1) (void)hipFree(d->d_in1);
     if (d->d_pcm1) (void)hipFree(d->d_pcm1);
     if (d->d_planes) (void)hipFree(d->d_planes);
-    if (d->h.d_tables) (void)hipFree(d->h.d_tables);
     delete d;
     return LC3GPU_OK;
 }
@@ -627,7 +695,7 @@ static int decode_launch(lc3gpu_decoder *d, int first, int n, const uint8_t *d_i
                        d->h.c.fs_ind, d->h.c.n_ms_10, d_in, d_bad, d->d_planes, nbytes, (int)frames);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream);
-    hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)n), dim3(64), 0, stream, d->h.c, d->d_states, first, d_in,
+    hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)n), dim3(64), 0, stream, d->h.slot, d->d_states, first, d_in,
                        (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream);

@@ -137,6 +137,10 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
     j.cfg.fft_tw = pl.fft_tw.data();
     j.cfg.dct_tw = pl.dct_tw.data();
     j.cfg.perm = pl.perm.data();
+    std::vector<float> poly((size_t)j.cfg.p_up * (size_t)j.cfg.resamp_stride);
+    for (size_t i = 0; i < poly.size(); i++)
+        poly[i] = lc3_resamp_poly_value(j.cfg.p_up, j.cfg.resamp_lim, j.cfg.resamp_stride, (int)i);
+    j.cfg.resamp_poly = poly.data();
     j.encode = 1;
     j.n_frames = T;
     j.nbytes = nbytes;

@@ -37,12 +37,16 @@ for _ in range(5):
     dec.decode(d_b, d_o, 150, T, stream=st)
 torch.cuda.synchronize()
 acc = api.prof_read()
-names = {1: "enc mdct+energy", 2: "enc bandwidth+attack", 3: "enc sns", 4: "enc tns", 5: "enc ltpf", 6: "enc quant",
+names = {9: "enc quant: energies+max", 10: "enc quant: gain bisection", 11: "enc quant: first quantise+bit count",
+         12: "enc ltpf: shift+resample", 13: "enc ltpf: 50 Hz high-pass", 14: "enc ltpf: pitch detection",
+         15: "enc ltpf: lag refinement", 22: "dec spectrum: residual+noise fill", 23: "dec spectrum: gain+tns",
+         24: "dec spectrum: sns scale factors", 25: "dec imdct: dct-iv",
+         1: "enc mdct+energy", 2: "enc bandwidth+attack", 3: "enc sns", 4: "enc tns", 5: "enc ltpf (rest: activation)", 6: "enc quant (rest: adjust + 2nd pass)",
          7: "enc residual+noise", 8: "enc plane store", 17: "dec load parsed frame (planes) + epilogue",
-         18: "dec spectrum (residual,noise,gain,tns,sns,plc)", 19: "dec imdct", 20: "dec ltpf", 21: "dec output"}
+         18: "dec spectrum (rest: band scaling, plc save)", 19: "dec imdct (rest: window+ola)", 20: "dec ltpf", 21: "dec output"}
 frames = 5 * S * T
-for lo, hi, label in ((1, 9, "encoder analysis kernel"), (17, 22, "decoder synthesis kernel")):
+for lo, hi, label in ((1, 16, "encoder analysis kernel"), (17, 26, "decoder synthesis kernel")):
     tot = sum(acc[lo:hi])
     print(f"{label}: {tot / frames:.0f} wave-cycles per frame (sum over stages, S={S} T={T})")
     for i in range(lo, hi):
-        print(f"  {names[i]:48s} {acc[i] / frames:10.0f} cyc/frame  {100.0 * acc[i] / max(tot, 1):5.1f} %")
+        if i in names: print(f"  {names[i]:48s} {acc[i] / frames:10.0f} cyc/frame  {100.0 * acc[i] / max(tot, 1):5.1f} %")
