@@ -258,56 +258,49 @@ __device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, lc3_enc_lds &L, int la
 // ------------------------------------------------------------------------------------------
 // E9/E10: spectral noise shaping (encoder/spectral_noise_shaping.rs:203-648)
 // ------------------------------------------------------------------------------------------
-// add_unit_pulse :285-316 (corr_xy / energy_y written through on every probe: SURVEY A2)
-__device__ __forceinline__ void lc3_add_unit_pulse(const float *abs_x, int n_max, int k, int k_max, int *cand,
-                                                   float &corr_xy, float &energy_y) {
+// add_unit_pulse :285-316 (corr_xy / energy_y written through on every probe: SURVEY A2).  Magnitudes and pulse
+// counts are register arrays (N = 16 or 10 candidates, fully unrolled).
+template <int N>
+__device__ __forceinline__ void lc3_add_unit_pulse_r(const float (&abs_x)[16], int (&cand)[16], int k, int k_max,
+                                                     float &corr_xy, float &energy_y) {
     float corr_last = corr_xy, en_last = energy_y;
     for (int it = k; it < k_max; it++) {
         int n_best = 0;
         corr_xy = corr_last + abs_x[0];
         float best_corr_sq = corr_xy * corr_xy;
         float best_en = en_last + 2.0f * (float)cand[0] + 1.0f;
-        for (int n_c = 1; n_c < n_max; n_c++) {
+        float best_abs = abs_x[0];
+        int best_cand = cand[0];
+#pragma unroll
+        for (int n_c = 1; n_c < N; n_c++) {
             corr_xy = corr_last + abs_x[n_c];
             energy_y = en_last + 2.0f * (float)cand[n_c] + 1.0f;
             if (corr_xy * corr_xy * best_en > best_corr_sq * energy_y) {
                 n_best = n_c;
                 best_corr_sq = corr_xy * corr_xy;
                 best_en = energy_y;
+                best_abs = abs_x[n_c];
+                best_cand = cand[n_c];
             }
         }
-        corr_last += abs_x[n_best];
-        en_last += 2.0f * (float)cand[n_best] + 1.0f;
-        cand[n_best] += 1;
+        corr_last += best_abs;
+        en_last += 2.0f * (float)best_cand + 1.0f;
+#pragma unroll
+        for (int n = 0; n < N; n++) cand[n] += n == n_best;
     }
 }
-__device__ __forceinline__ void lc3_normalize_candidate(const int *y, float *xq, int n_max) {  // :632-648
-    float norm = 0.0f;
-    for (int n = 0; n < n_max; n++)
-        if (y[n] != 0) norm += (float)y[n] * (float)y[n];
-    norm = lc3_sqrtf(norm);
-    for (int n = 0; n < n_max; n++) {
-        float v = (float)y[n];
-        if (y[n] != 0) v /= norm;
-        xq[n] = v;
-    }
-    for (int n = n_max; n < 16; n++) xq[n] = 0.0f;
-}
-__device__ __forceinline__ void lc3_mvpq_enum(uint32_t &index, int &lead_sign_ind, int dim_in, const int *vec_in) {
-    // :584-629
+// mvpq_enum :584-629 with the per-position offset rows already looked up (h[pos] is the row value the reference adds
+// while visiting pos): folds sign bits and offsets from the last position down to the first.
+__device__ __forceinline__ void lc3_mvpq_fold(uint32_t &index, int &lead_sign_ind, int dim_in, const int *vec_in,
+                                              const int *h) {
     int next_sign_ind = (-2147483647 - 1);
-    int k_val_acc = 0, n = 0;
-    uint32_t tmp_h_row = LC3T_MPVQ_OFFSETS[0][0];
     index = 0;
     for (int pos = dim_in - 1; pos >= 0; pos--) {
-        int tmp_val = (int)(int8_t)vec_in[pos];
+        const int tmp_val = (int)(int8_t)vec_in[pos];
         if (next_sign_ind >= 0 && tmp_val != 0) index = 2 * index + (uint32_t)next_sign_ind;
         if (tmp_val < 0) next_sign_ind = 1;
         else if (tmp_val > 0) next_sign_ind = 0;
-        index += tmp_h_row;
-        k_val_acc += tmp_val < 0 ? -tmp_val : tmp_val;
-        if (pos != 0) n += 1;
-        tmp_h_row = k_val_acc >= 11 ? LC3T_MPVQ_OFFSETS[n + 1][k_val_acc % 11] : LC3T_MPVQ_OFFSETS[n][k_val_acc];
+        index += (uint32_t)h[pos];
     }
     lead_sign_ind = next_sign_ind;
 }
@@ -440,96 +433,159 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, lc3_enc_lds &L, i
         sABS[lane] = lc3_absf(acc);
     }
     LC3_SYNC();
+    // Pulse search :285-316, :386-470 on lane 0 with the 16 magnitudes and pulse counts in registers; the signs of
+    // the target only enter when a finished candidate is stored (y0 | y1 | y2 | y3 at iY + 0 | 16 | 32 | 48).
     if (lane == 0) {
-        int *y0 = iY, *y1 = iY + 16, *y2 = iY + 32, *y3 = iY + 48;
+        float ax[16];
+        int cand[16];
+        uint32_t neg = 0;
+#pragma unroll
+        for (int n = 0; n < 16; n++) {
+            ax[n] = sABS[n];
+            if (sT2[n] < 0.0f) neg |= 1u << n;
+        }
         int k = 0;
         float abs_sum = 0.0f, corr_xy = 0.0f, energy_y = 0.0f;
-        for (int n = 0; n < 16; n++) abs_sum += sABS[n];
+#pragma unroll
+        for (int n = 0; n < 16; n++) abs_sum += ax[n];
         const float proj = (6.0f - 1.0f) / abs_sum;
+#pragma unroll
         for (int n = 0; n < 16; n++) {
-            int v = lc3_f2i32(lc3_floorf(sABS[n] * proj));
-            y3[n] = v;
+            const int v = lc3_f2i32(lc3_floorf(ax[n] * proj));
+            cand[n] = v;
             if (v != 0) {
                 k += v;
-                corr_xy += (float)v * sABS[n];
+                corr_xy += (float)v * ax[n];
                 energy_y += (float)v * (float)v;
             }
         }
-        lc3_add_unit_pulse(sABS, 16, k, 6, y3, corr_xy, energy_y);
-        for (int n = 0; n < 16; n++) y2[n] = y3[n];
-        lc3_add_unit_pulse(sABS, 16, 6, 8, y2, corr_xy, energy_y);
-        for (int n = 0; n < 10; n++) y1[n] = y2[n];
-        for (int n = 10; n < 16; n++) y1[n] = 0;
+        lc3_add_unit_pulse_r<16>(ax, cand, k, 6, corr_xy, energy_y);
+#pragma unroll
+        for (int n = 0; n < 16; n++) iY[48 + n] = (neg >> n) & 1u ? -cand[n] : cand[n];
+        lc3_add_unit_pulse_r<16>(ax, cand, 6, 8, corr_xy, energy_y);
+#pragma unroll
+        for (int n = 0; n < 16; n++) iY[32 + n] = (neg >> n) & 1u ? -cand[n] : cand[n];
         int ks = 8;
+#pragma unroll
         for (int n = 10; n < 16; n++) {
-            if (y2[n] != 0) {
-                ks -= y2[n];
-                corr_xy -= (float)y2[n] * sABS[n];
-                energy_y -= (float)y2[n] * (float)y2[n];
+            if (cand[n] != 0) {
+                ks -= cand[n];
+                corr_xy -= (float)cand[n] * ax[n];
+                energy_y -= (float)cand[n] * (float)cand[n];
+            }
+            cand[n] = 0;
+        }
+        lc3_add_unit_pulse_r<10>(ax, cand, ks, 10, corr_xy, energy_y);
+        float max_abs = 0.0f;
+        int n_best = 0;
+#pragma unroll
+        for (int n = 10; n < 16; n++) {
+            if (ax[n] > max_abs) {
+                max_abs = ax[n];
+                n_best = n;
             }
         }
-        lc3_add_unit_pulse(sABS, 10, ks, 10, y1, corr_xy, energy_y);
-        {
-            float max_abs = 0.0f;
-            int n_best = 0;
-            for (int n = 0; n < 10; n++) y0[n] = y1[n];
-            for (int n = 10; n < 16; n++) {
-                y0[n] = 0;
-                if (sABS[n] > max_abs) {
-                    max_abs = sABS[n];
-                    n_best = n;
-                }
-            }
-            y0[n_best] = 1;
+#pragma unroll
+        for (int n = 0; n < 16; n++) {
+            const int y1 = n < 10 ? ((neg >> n) & 1u ? -cand[n] : cand[n]) : 0;
+            int y0 = y1;
+            if (n >= 10 && n == n_best) y0 = (neg >> n) & 1u ? -1 : 1;
+            iY[16 + n] = y1;
+            iY[n] = y0;
         }
-        for (int n = 0; n < 10; n++)
-            if (sT2[n] < 0.0f) { y0[n] = -y0[n]; y1[n] = -y1[n]; y2[n] = -y2[n]; y3[n] = -y3[n]; }
-        for (int n = 10; n < 16; n++)
-            if (sT2[n] < 0.0f) { y0[n] = -y0[n]; y2[n] = -y2[n]; y3[n] = -y3[n]; }
-        lc3_normalize_candidate(y0, sXQ, 16);
-        lc3_normalize_candidate(y1, sXQ + 16, 10);
-        lc3_normalize_candidate(y2, sXQ + 32, 16);
-        lc3_normalize_candidate(y3, sXQ + 48, 16);
-        // shape/gain search; the last gain of every shape is never tried
-        const int g_maxind[4] = {1, 3, 3, 7};
-        int shape_j = 0, gind = 0;
-        float g_sel = 0.0f, d_min = __builtin_inff();
-        for (int j = 0; j < 4; j++) {
-            const uint32_t *gains = j == 0 ? LC3T_SNS_VQ_REG_ADJ_GAINS_BITS
-                                    : j == 1 ? LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS
-                                    : j == 2 ? LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS : LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS;
-            for (int i = 0; i < g_maxind[j]; i++) {
-                float g = lc3_f(gains, i), d = 0.0f;
-                for (int n = 0; n < 16; n++) {
-                    float df = sT2[n] - g * sXQ[16 * j + n];
-                    d += df * df;
-                }
-                if (d < d_min) { shape_j = j; gind = i; d_min = d; g_sel = g; }
-            }
+        // no positive magnitude in 10..15: the reference's pulse lands on line 0 and takes that line's sign
+        if (n_best == 0) iY[0] = neg & 1u ? -1 : 1;
+    }
+    LC3_SYNC();
+    // normalize_candidate :632-648 -- the four norms on four lanes (16-term sums in order), the divisions on all lanes
+    if (lane < 4) {
+        const int n_max = lane == 1 ? 10 : 16;
+        float norm = 0.0f;
+        for (int n = 0; n < n_max; n++) {
+            const int y = iY[16 * lane + n];
+            if (y != 0) norm += (float)y * (float)y;
         }
-        uint32_t idxa = 0, idxb = 0, joint;
-        int ls_inda = 0, ls_indb = 0;
-        const int lsb_gain = gind & 1;
-        if (shape_j == 0) {
-            lc3_mvpq_enum(idxa, ls_inda, 10, y0);
-            lc3_mvpq_enum(idxb, ls_indb, 6, y0 + 10);
-            joint = (2u * idxb + (uint32_t)ls_indb + 2u) * 2390004u + idxa;
-        } else if (shape_j == 1) {
-            lc3_mvpq_enum(idxa, ls_inda, 10, y1);
-            joint = (uint32_t)lsb_gain * 2390004u + idxa;
-        } else if (shape_j == 2) {
-            lc3_mvpq_enum(idxa, ls_inda, 16, y2);
-            joint = idxa;
-        } else {
-            lc3_mvpq_enum(idxa, ls_inda, 16, y3);
-            joint = 15158272u + (uint32_t)lsb_gain + (2u * idxa);
+        L.sm[4 + lane] = lc3_sqrtf(norm);
+    }
+    LC3_SYNC();
+    {
+        const int j = lane >> 4, n = lane & 15, y = iY[lane];
+        float v = (float)y;
+        if (y != 0) v /= L.sm[4 + j];
+        sXQ[lane] = (j == 1 && n >= 10) ? 0.0f : v;
+    }
+    LC3_SYNC();
+    // shape/gain search :472-521; the last gain of every shape is never tried.  One lane per
+    // (shape, gain) pair computes its distortion, lane 0 then walks the 14 results in the reference's order.
+    if (lane < 14) {
+        const int j = lane < 1 ? 0 : (lane < 4 ? 1 : (lane < 7 ? 2 : 3));
+        const int i = lane - (j == 0 ? 0 : (j == 1 ? 1 : (j == 2 ? 4 : 7)));
+        const uint32_t *gains = j == 0 ? LC3T_SNS_VQ_REG_ADJ_GAINS_BITS
+                                : j == 1 ? LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS
+                                : j == 2 ? LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS : LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS;
+        const float g = lc3_f(gains, i);
+        float d = 0.0f;
+        for (int n = 0; n < 16; n++) {
+            const float df = sT2[n] - g * sXQ[16 * j + n];
+            d += df * df;
         }
+        sDM[lane] = d;
+        sDM[16 + lane] = g;
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        int best = 0;
+        float d_min = __builtin_inff();
+        for (int q = 0; q < 14; q++) {
+            const float d = sDM[q];
+            if (d < d_min) { best = q; d_min = d; }
+        }
+        const int shape_j = best < 1 ? 0 : (best < 4 ? 1 : (best < 7 ? 2 : 3));
         L.ism[2] = shape_j;
-        L.ism[3] = gind;
-        L.ism[4] = ls_inda;
-        L.ism[5] = ls_indb;
-        L.ism[6] = (int)joint;
-        L.sm[1] = g_sel;
+        L.ism[3] = best - (shape_j == 0 ? 0 : (shape_j == 1 ? 1 : (shape_j == 2 ? 4 : 7)));
+        L.sm[1] = d_min < __builtin_inff() ? sDM[16 + best] : 0.0f;
+    }
+    LC3_SYNC();
+    // mvpq_enum :584-629 of the selected shape.  The offset row a position adds depends only on the pulse count above
+    // it, so the table lookups run one lane per position; lane 0 then folds the positions (integer arithmetic).
+    {
+        const int shape_j = L.ism[2];
+        const int *ysel = iY + 16 * shape_j;
+        int *eH = (int *)sDM + 32;  // [16] offsets per position
+        if (lane < 16) {
+            // enumeration A covers positions [0, dimA), enumeration B (shape 0 only) positions [10, 16)
+            const int dimA = shape_j <= 1 ? 10 : 16;
+            const int lo = lane < dimA ? 0 : 10, hi = lane < dimA ? dimA : 16;  // this position's vector is [lo, hi)
+            uint32_t h = LC3T_MPVQ_OFFSETS[0][0];
+            if (lane < hi - 1) {
+                int kacc = 0;
+                for (int p2 = lane + 1; p2 < hi; p2++) {
+                    const int v = (int)(int8_t)ysel[p2];
+                    kacc += v < 0 ? -v : v;
+                }
+                const int nrow = hi - 1 - lane;
+                h = kacc >= 11 ? LC3T_MPVQ_OFFSETS[nrow + 1][kacc % 11] : LC3T_MPVQ_OFFSETS[nrow][kacc];
+            }
+            (void)lo;
+            eH[lane] = (int)h;
+        }
+        LC3_SYNC();
+        if (lane == 0) {
+            uint32_t idxa = 0, idxb = 0, joint;
+            int ls_inda = 0, ls_indb = 0;
+            const int lsb_gain = L.ism[3] & 1;
+            const int dimA = shape_j <= 1 ? 10 : 16;
+            lc3_mvpq_fold(idxa, ls_inda, dimA, ysel, eH);
+            if (shape_j == 0) {
+                lc3_mvpq_fold(idxb, ls_indb, 6, ysel + 10, eH + 10);
+                joint = (2u * idxb + (uint32_t)ls_indb + 2u) * 2390004u + idxa;
+            } else if (shape_j == 1) joint = (uint32_t)lsb_gain * 2390004u + idxa;
+            else if (shape_j == 2) joint = idxa;
+            else joint = 15158272u + (uint32_t)lsb_gain + (2u * idxa);
+            L.ism[4] = ls_inda;
+            L.ism[5] = ls_indb;
+            L.ism[6] = (int)joint;
+        }
     }
     LC3_SYNC();
     // synthesis :552-559 -- one lane per scale factor
@@ -618,77 +674,83 @@ __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, lc3_enc_lds &L, i
         sES[q] = es;
     }
     LC3_SYNC();
-    if (lane == 0) {
-        const float step = (float)3.14159265358979323846 / 17.0f;  // PI as f32 / 17.0 :268
-        for (int f = 0; f < tp.num; f++) {
-            float *r = S + 96, *a0 = S + 112, *a1 = S + 128;  // LDS (dynamic indexing)
-            for (int k = 0; k < 9; k++) {
-                float r0 = k == 0 ? 3.0f : 0.0f, rk = 0.0f, e_prod = 1.0f;
-                for (int s = 0; s < 3; s++) {
-                    float es = sES[f * 3 + s];
-                    e_prod *= es;
-                    rk += sAC[f * 27 + k * 3 + s] / es;
-                }
-                r[k] = (e_prod == 0.0f ? r0 : rk) * LC3C_TNS_LAGW[k];
+    // Levinson-Durbin :204-232 and the LPC -> reflection conversion :234-265: one lane per filter, the order-8
+    // recursions fully unrolled on register arrays.
+    if (lane < 2 && lane < tp.num) {
+        const int f = lane;
+        float r[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            float r0 = k == 0 ? 3.0f : 0.0f, rk = 0.0f, e_prod = 1.0f;
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                float es = sES[f * 3 + s];
+                e_prod *= es;
+                rk += sAC[f * 27 + k * 3 + s] / es;
             }
-            // Levinson-Durbin :204-232
-            float *a = a0, *a_last = a1;
-            for (int n = 0; n < 9; n++) { a0[n] = 0.0f; a1[n] = 0.0f; }
-            float e = r[0];
-            a[0] = 1.0f;
-            for (int k = 1; k < 9; k++) {
-                float *tmp = a_last;
-                a_last = a;
-                a = tmp;
-                float rc = 0.0f;
-                for (int n = 0; n < k; n++) rc -= a_last[n] * r[k - n];
-                if (e != 0.0f) rc /= e;
-                a[0] = 1.0f;
-                for (int n = 1; n < k; n++) a[n] = a_last[n] + rc * a_last[k - n];
-                a[k] = rc;
-                e *= 1.0f - rc * rc;
-            }
-            const float pred_gain = e == 0.0f ? r[0] : r[0] / e;
-            if (pred_gain > 1.5f && !near_nyquist) {
-                float gamma = 1.0f;
-                if (res.lpc_weighting > 0 && pred_gain < 2.0f)
-                    gamma -= (1.0f - 0.85f) * (2.0f - pred_gain) / (2.0f - 1.5f);
-                for (int k = 0; k < 9; k++) a[k] *= lc3_powi(gamma, k);
-                float *a_k = a, *a_km1 = a_last;
-                for (int k = 8; k >= 1; k--) {
-                    float rck = a_k[k];
-                    rc_q[f * 8 + k - 1] = rck;
-                    float ee = 1.0f - rck * rck;
-                    for (int n = 1; n < k; n++) {
-                        float v = a_k[n] - rck * a_k[k - n];
-                        a_km1[n] = v / ee;
-                    }
-                    float *tmp = a_k;
-                    a_k = a_km1;
-                    a_km1 = tmp;
-                }
-            } else {
-                for (int k = 0; k < 8; k++) rc_q[f * 8 + k] = 0.0f;
-            }
+            r[k] = (e_prod == 0.0f ? r0 : rk) * LC3C_TNS_LAGW[k];
         }
-        // apply_quantization :267-292
-        for (int f = 0; f < tp.num; f++) {
-            for (int k = 0; k < 8; k++) {
-                float q = lc3_asinf(rc_q[f * 8 + k]) / step;
-                int ri = (q >= 0.0f ? lc3_f2i8(q + 0.5f) : lc3_f2i8(-(-q + 0.5f))) + 8;
-                rc_i[f * 8 + k] = ri;
-                rc_q[f * 8 + k] = lc3_sinf_small(step * ((float)ri - 8.0f));
+        float a[9], al[9];
+#pragma unroll
+        for (int n = 0; n < 9; n++) a[n] = 0.0f;
+        float e = r[0];
+        a[0] = 1.0f;
+#pragma unroll
+        for (int k = 1; k < 9; k++) {
+#pragma unroll
+            for (int n = 0; n < 9; n++) al[n] = a[n];
+            float rc = 0.0f;
+#pragma unroll
+            for (int n = 0; n < k; n++) rc -= al[n] * r[k - n];
+            if (e != 0.0f) rc /= e;
+            a[0] = 1.0f;
+#pragma unroll
+            for (int n = 1; n < k; n++) a[n] = al[n] + rc * al[k - n];
+            a[k] = rc;
+            e *= 1.0f - rc * rc;
+        }
+        const float pred_gain = e == 0.0f ? r[0] : r[0] / e;
+        if (pred_gain > 1.5f && !near_nyquist) {
+            float gamma = 1.0f;
+            if (res.lpc_weighting > 0 && pred_gain < 2.0f)
+                gamma -= (1.0f - 0.85f) * (2.0f - pred_gain) / (2.0f - 1.5f);
+#pragma unroll
+            for (int k = 0; k < 9; k++) a[k] *= lc3_powi(gamma, k);
+#pragma unroll
+            for (int k = 8; k >= 1; k--) {
+                const float rck = a[k];
+                rc_q[f * 8 + k - 1] = rck;
+                const float ee = 1.0f - rck * rck;
+#pragma unroll
+                for (int n = 1; n < k; n++) al[n] = (a[n] - rck * a[k - n]) / ee;
+#pragma unroll
+                for (int n = 1; n < k; n++) a[n] = al[n];
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) rc_q[f * 8 + k] = 0.0f;
+        }
+    }
+    LC3_SYNC();
+    // apply_quantization :267-292 -- one lane per coefficient
+    if (lane < 16) {
+        const float step = (float)3.14159265358979323846 / 17.0f;  // PI as f32 / 17.0 :268
+        if ((lane >> 3) < tp.num) {
+            float q = lc3_asinf(rc_q[lane]) / step;
+            int ri = (q >= 0.0f ? lc3_f2i8(q + 0.5f) : lc3_f2i8(-(-q + 0.5f))) + 8;
+            rc_i[lane] = ri;
+            rc_q[lane] = lc3_sinf_small(step * ((float)ri - 8.0f));
+        } else {
+            rc_i[lane] = 8;
+            rc_q[lane] = 0.0f;
+        }
+    }
+    LC3_SYNC();
+    if (lane == 0) {
+        for (int f = 0; f < 2; f++) {
             int k = 7;
             while (k >= 0 && rc_i[f * 8 + k] == 8) k--;
-            L.ism[8 + f] = k + 1;
-        }
-        for (int f = tp.num; f < 2; f++) {
-            for (int k = 0; k < 8; k++) {
-                rc_i[f * 8 + k] = 8;
-                rc_q[f * 8 + k] = 0.0f;
-            }
-            L.ism[8 + f] = 0;
+            L.ism[8 + f] = f < tp.num ? k + 1 : 0;
         }
         // calc_bit_budget :294-311
         int nbits_tns = 0;
@@ -892,13 +954,31 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, lc3_enc_lds &L,
                            0.2353512128364889f * s[3] + 0.1236796411180537f * s[4];
     }
     LC3_SYNC();
-    for (int k = lane; k < LC3_KMAX + 1 - LC3_KMIN; k += LC3_WAVE) {  // 98 lags, 64-term sums in order
-        const int from_k = LC3_KMAX - LC3_KMIN - k;
-        float acc = 0.0f;
-        for (int n = 0; n < len6; n++) acc += x6[LC3_KMAX + n] * x6[from_k + n];
-        r6[k] = acc;
-        float weight = 1.0f - 0.5f * (float)k / (float)(LC3_KMAX - LC3_KMIN);
-        rw6[k] = weight * acc;
+    {   // 98 lags, len6-term sums in order; a lane runs its two lags (lane, lane + 64) side by side, 8 terms per batch
+        const int NL = LC3_KMAX + 1 - LC3_KMIN;
+        const int k0 = lane, has1 = lane + LC3_WAVE < NL, k1 = has1 ? lane + LC3_WAVE : lane;
+        const float *pa = x6 + LC3_KMAX, *pb0 = x6 + (LC3_KMAX - LC3_KMIN - k0), *pb1 = x6 + (LC3_KMAX - LC3_KMIN - k1);
+        float acc0 = 0.0f, acc1 = 0.0f;
+        for (int n = 0; n < len6; n += 8) {
+            float a[8], b0[8], b1[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                a[u] = pa[n + u];
+                b0[u] = pb0[n + u];
+                b1[u] = pb1[n + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                acc0 += a[u] * b0[u];
+                acc1 += a[u] * b1[u];
+            }
+        }
+        r6[k0] = acc0;
+        rw6[k0] = (1.0f - 0.5f * (float)k0 / (float)(LC3_KMAX - LC3_KMIN)) * acc0;
+        if (has1) {
+            r6[k1] = acc1;
+            rw6[k1] = (1.0f - 0.5f * (float)k1 / (float)(LC3_KMAX - LC3_KMIN)) * acc1;
+        }
     }
     LC3_SYNC();
     if (lane == 0) {
@@ -926,7 +1006,13 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, lc3_enc_lds &L,
         const int lag = lane == 0 ? 0 : L.ism[lane - 1];
         const int from = LC3_KMAX - lag;
         float v = 0.0f;
-        for (int n = from; n < from + len6; n++) v += x6[n] * x6[n];
+        for (int n = from; n < from + len6; n += 8) {
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = x6[n + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v += a[u] * a[u];
+        }
         L.sm[lane] = v;
     }
     LC3_SYNC();
@@ -957,7 +1043,17 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, lc3_enc_lds &L,
         if (lane < nk) {
             const int k = k_min - 4 + lane;
             float acc = 0.0f;
-            for (int n = 0; n < len12; n++) acc += x12[LC3_NMEM + n] * x12[LC3_NMEM - k + n];
+            const float *pa = x12 + LC3_NMEM, *pb = x12 + LC3_NMEM - k;
+            for (int n = 0; n < len12; n += 8) {
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    a[u] = pa[n + u];
+                    b[u] = pb[n + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += a[u] * b[u];
+            }
             r12[lane] = acc;
         }
     }
@@ -1016,10 +1112,18 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, lc3_enc_lds &L,
     }
     LC3_SYNC();
     if (lane < 3) {
+        // lane 0: sum dA*dB, lane 1: sum dA*dA, lane 2: sum dB*dB
+        const float *pa = lane == 2 ? dB : dA, *pb = lane == 1 ? dA : dB;
         float acc = 0.0f;
-        for (int n = 0; n < len12; n++) {
-            float a = dA[n], b = dB[n];
-            acc += lane == 0 ? a * b : (lane == 1 ? a * a : b * b);
+        for (int n = 0; n < len12; n += 8) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                a[u] = pa[n + u];
+                b[u] = pb[n + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += a[u] * b[u];
         }
         L.sm[lane] = acc;
     }
