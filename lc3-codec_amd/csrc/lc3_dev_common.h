@@ -36,6 +36,34 @@
 #define LC3_CFG_PASS c
 #endif
 
+// How the stage functions reach their stream's LDS working set.  Default: a reference parameter.  The HIP translation
+// unit keeps the working sets of a workgroup in a file-scope __shared__ array (declared by LC3_LDS_DECL right after the
+// struct) and binds `L` to the calling wave's element inside every function, so that the compiler addresses LDS
+// directly (ds_read / ds_write) instead of through generic pointers.
+#ifndef LC3_LDS_PARAM
+#define LC3_LDS_DECL(T, arr)
+#define LC3_LDS_PARAM(T) T &L,
+#define LC3_LDS_PASS L,
+#define LC3_LDS_BIND(T, arr)
+#endif
+
+// Code that is serial per stream sits between LC3_SERIAL_BEGIN(T, L, lane, phase, K) and LC3_SERIAL_END: K lanes
+// (`sub` = 0..K-1) run it per stream with `L` bound to the stream's working set of type T.  The translation unit decides
+// who runs it: by default lanes 0..K-1 of the stream's own wave; the HIP kernels gather the streams of a workgroup on
+// one wave (lc3gpu.hip).  Such a block may only use L, launch-uniform values and what it declares itself.
+#ifndef LC3_SERIAL_BEGIN
+#define LC3_SERIAL_BEGIN(T, L, lane, phase, K) \
+    {                                          \
+        LC3_SYNC();                            \
+        if ((lane) < (K)) {                    \
+            const int sub = (lane);            \
+            (void)sub;
+#define LC3_SERIAL_END \
+        }              \
+        LC3_SYNC();    \
+    }
+#endif
+
 // Pointer to read-only HBM data handed to a stage function: the HIP translation unit marks the address space so that
 // the loads are global_load rather than flat_load.
 #ifndef LC3_HBM_CONST
@@ -476,6 +504,46 @@ static __device__ const int LC3C_TNSDEC75[5][4] = {{9, 60, 0, 0}, {9, 120, 0, 0}
 // ------------------------------------------------------------------------------------------
 // static tables selected by configuration
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Coalesced block copies between HBM and a wave's LDS working set.  n4 = number of 16-byte units; both sides 16-byte
+// aligned.  All of a batch's loads are issued before the first use, so a copy costs one memory latency per 8 KB.
+// ------------------------------------------------------------------------------------------
+typedef int lc3_i4 __attribute__((vector_size(16)));  // builtin vector: assignable across address spaces
+__device__ __forceinline__ void lc3_wave_copy_in16(void *lds_dst, const void *hbm_src, int n4, int lane) {
+    lc3_i4 *d = (lc3_i4 *)lds_dst;
+    LC3_HBM_CONST(lc3_i4) s = (LC3_HBM_CONST(lc3_i4))hbm_src;
+    for (int i0 = 0; i0 < n4; i0 += 8 * LC3_WAVE) {
+        lc3_i4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + LC3_WAVE * u + lane;
+            if (i < n4) v[u] = s[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + LC3_WAVE * u + lane;
+            if (i < n4) d[i] = v[u];
+        }
+    }
+}
+__device__ __forceinline__ void lc3_wave_copy_out16(void *hbm_dst, const void *lds_src, int n4, int lane) {
+    lc3_i4 *d = (lc3_i4 *)hbm_dst;
+    const lc3_i4 *s = (const lc3_i4 *)lds_src;
+    for (int i0 = 0; i0 < n4; i0 += 8 * LC3_WAVE) {
+        lc3_i4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + LC3_WAVE * u + lane;
+            if (i < n4) v[u] = s[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + LC3_WAVE * u + lane;
+            if (i < n4) d[i] = v[u];
+        }
+    }
+}
+
 // Element i of the polyphase resampler table (encoder/long_term_post_filter.rs:152-166): row ph = i / stride,
 // tap j = i % stride stands for k = j - lim of the reference loop, i.e. tab_resamp_filter[119 + p*k - ph] while
 // that index lies strictly inside (-120, 120) and k <= lim; zero elsewhere.  A zero tap adds x * 0 = +-0 to the

@@ -18,7 +18,9 @@ struct lc3_dec_core {
     float plc_alpha;
     uint32_t plc_seed;
     int plc_events;                // counter: frames concealed so far (not in the reference; reporting only)
+    int pad[2];                    // keeps the blob a multiple of 16 bytes (128-bit copies, aligned LDS arrays)
 };
+static_assert(sizeof(lc3_dec_core) % 16 == 0, "decoder state blob must stay a multiple of 16 bytes");
 struct lc3_dec_state {
     lc3_dec_core core;
     float plc_last_good[LC3_MAX_NE];  // decoder/packet_loss_concealment.rs:7-22
@@ -26,7 +28,7 @@ struct lc3_dec_state {
 #define LC3_DEC_CORE_WORDS ((int)(sizeof(lc3_dec_core) / 4))
 
 // LDS working set of one decoder wave (~13 KB -> 12 waves per CU)
-struct lc3_dec_lds {
+struct __attribute__((aligned(16))) lc3_dec_lds {
     lc3_dec_core st;
     float spec[LC3_MAX_NF];        // spec_lines, then freq_samples
     lc3_cpx fa[LC3_MAX_NF / 2];    // FFT in   | t_hat_mdct[0 .. nf)
@@ -39,9 +41,11 @@ struct lc3_dec_lds {
     unsigned long long prof_acc[32];  // diagnostic build: per-wave stage totals, flushed once per launch
 #endif
 };
+LC3_LDS_DECL(lc3_dec_lds, lc3_dec_wg)
 
-__device__ __forceinline__ void lc3_dec_state_init(lc3_dec_lds &L, int lane, lc3_dec_state *g) {
-    for (int i = lane; i < LC3_MAX_NE; i += LC3_WAVE) g->plc_last_good[i] = 0.0f;
+__device__ __forceinline__ void lc3_dec_state_init(lc3_dec_lds &L, int lane, lc3_dec_state *g, int valid) {
+    if (valid)
+        for (int i = lane; i < LC3_MAX_NE; i += LC3_WAVE) g->plc_last_good[i] = 0.0f;
     int *w = (int *)&L.st;
     for (int i = lane; i < LC3_DEC_CORE_WORDS; i += LC3_WAVE) w[i] = 0;
     LC3_SYNC();
@@ -52,16 +56,12 @@ __device__ __forceinline__ void lc3_dec_state_init(lc3_dec_lds &L, int lane, lc3
     LC3_SYNC();
 }
 __device__ __forceinline__ void lc3_dec_state_load(lc3_dec_lds &L, int lane, const lc3_dec_state *g) {
-    const int *src = (const int *)&g->core;
-    int *w = (int *)&L.st;
-    for (int i = lane; i < LC3_DEC_CORE_WORDS; i += LC3_WAVE) w[i] = src[i];
+    lc3_wave_copy_in16(&L.st, &g->core, (int)(sizeof(lc3_dec_core) / 16), lane);
     LC3_SYNC();
 }
 __device__ __forceinline__ void lc3_dec_state_store(lc3_dec_lds &L, int lane, lc3_dec_state *g) {
-    int *dst = (int *)&g->core;
-    const int *w = (const int *)&L.st;
     LC3_SYNC();
-    for (int i = lane; i < LC3_DEC_CORE_WORDS; i += LC3_WAVE) dst[i] = w[i];
+    lc3_wave_copy_out16(&g->core, &L.st, (int)(sizeof(lc3_dec_core) / 16), lane);
 }
 
 // D8 helper: mpvq_deenum (decoder/spectral_noise_shaping.rs:155-235)
@@ -100,8 +100,9 @@ __device__ __forceinline__ void lc3_mpvq_deenum(int dim_in, int k_val_in, int ls
 // ------------------------------------------------------------------------------------------
 // D10: IMDCT + window + overlap-add (decoder/modified_dct.rs:76-151); spec -> time samples in spec
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ void lc3_dec_imdct(LC3_CFG_PARAM, lc3_dec_lds &L, int lane) {
+__device__ __noinline__ void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     const int nf = c.nf, ne = c.ne, z = c.z, h = nf / 2;
     const uint32_t *w = lc3_window_bits(c);
     float *freq = L.spec;
@@ -133,26 +134,47 @@ __device__ __noinline__ void lc3_dec_imdct(LC3_CFG_PARAM, lc3_dec_lds &L, int la
 // ------------------------------------------------------------------------------------------
 // D11: long-term post-filter synthesis (decoder/long_term_post_filter.rs:142-424)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lc3_wrap_neg(const lc3_cfg &c, int idx) {  // :244-250
-    return idx < 0 ? idx + c.num_mem_blocks * c.nf : idx;
-}
-// compute_filter / compute_filter_mem (:380-415).  The reference's x_hat_mem ring is only ever read at
-// start - k, k <= l_num: the current input frame (freq_in) or the last l_num samples of the previous one.
-__device__ __forceinline__ float lc3_ltpf_filter(const lc3_cfg &c, const lc3_dec_core &st, const float *freq_in,
-                                                 const float *cn, const float *cd, int blk, int n, int pitch_int) {
-    float acc = 0.0f;
-    for (int k = 0; k <= c.l_num; k++) {
-        const int j = n - k;
-        acc += cn[k] * (j >= 0 ? freq_in[j] : st.x_tail[c.l_num + j]);
+// compute_filter / compute_filter_mem (:380-415) over the samples [n_begin, n_end) of the current frame:
+//   x_hat[blk + n] = input(n) - ramp(n) * ( sum_k cn[k] * input(n - k)  -  sum_k cd[k] * x_hat[blk + n - pitch_int + l_den/2 - k] )
+// with input(j) = inp[j] for j >= 0 and hist[l_num + j] for the l_num samples before the frame (the reference's
+// x_hat_mem ring is only ever read there), ramp: 0 none, 1 fade-in n / norm for n < s25, 2 fade-out 1 - n / norm.
+// Samples are computed in blocks of min(64, pitch_int - l_den/2): inside a block no output depends on another.
+__device__ __forceinline__ void lc3_ltpf_run(const lc3_cfg &c, lc3_dec_lds &L, int lane, int n_begin, int n_end,
+                                             const float *inp, const float *hist, const float *cn, const float *cd,
+                                             int pitch_int, int ramp) {
+    const int blk = L.st.block_start_index, l_num = c.l_num, l_den = c.l_den, ring = c.num_mem_blocks * c.nf;
+    int bsz = pitch_int - l_den / 2;
+    bsz = bsz < 1 ? 1 : (bsz > LC3_WAVE ? LC3_WAVE : bsz);
+    float *xh = L.st.x_hat_ltpf_mem;
+    for (int n0 = n_begin; n0 < n_end; n0 += bsz) {
+        const int n = n0 + lane;
+        if (lane < bsz && n < n_end) {
+            float acc = 0.0f;
+            for (int k = 0; k <= l_num; k++) {
+                const int j = n - k;
+                acc += cn[k] * (j >= 0 ? inp[j] : hist[l_num + j]);
+            }
+            const int sden = blk + n - pitch_int + l_den / 2;
+            for (int k = 0; k <= l_den; k++) {
+                int idx = sden - k;
+                idx = idx < 0 ? idx + ring : idx;  // :244-250
+                acc -= cd[k] * xh[idx];
+            }
+            if (ramp == 1) {
+                if (n < c.s25) acc *= (float)n / (float)c.norm;
+            } else if (ramp == 2) {
+                acc *= 1.0f - ((float)n / (float)c.norm);
+            }
+            xh[blk + n] = inp[n] - acc;
+        }
+        LC3_SYNC();
     }
-    const int sden = blk + n - pitch_int + c.l_den / 2;
-    for (int k = 0; k <= c.l_den; k++) acc -= cd[k] * st.x_hat_ltpf_mem[lc3_wrap_neg(c, sden - k)];
-    return acc;
 }
 
-__device__ __noinline__ void lc3_dec_ltpf(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int is_active, int pitch_index,
+__device__ __noinline__ void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int is_active, int pitch_index,
                                              int nbits) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     const int nf = c.nf, blk = L.st.block_start_index, s25 = c.s25;
     const int ncn = c.l_num + 1, ncd = c.l_den + 1;
     float *freq = L.spec;
@@ -215,59 +237,33 @@ __device__ __noinline__ void lc3_dec_ltpf(LC3_CFG_PARAM, lc3_dec_lds &L, int lan
         }
     }
     LC3_SYNC();
+    // The IIR recursion feeds back x_hat delayed by at least pitch_int - l_den/2 samples, so that many consecutive
+    // outputs are independent: they are computed one per lane (lc3_ltpf_run), each with the reference's tap order.
     if (trans == 1) {
-        // inactive -> inactive: plain copy (lane-parallel)
+        // inactive -> inactive: plain copy
         for (int n = lane; n < nf; n += LC3_WAVE) L.st.x_hat_ltpf_mem[blk + n] = freq[n];
-    } else if (lane == 0) {
-        // the IIR recursion over the output ring is serial in n
-        lc3_dec_core &st = L.st;
-        if (trans == 2) {
-            for (int n = 0; n < nf; n++) {
-                st.x_hat_ltpf_mem[blk + n] = freq[n];
-                float fo = lc3_ltpf_filter(c, st, freq, st.c_num, st.c_den, blk, n, pitch_int);
-                if (n < s25) fo *= (float)n / (float)c.norm;
-                st.x_hat_ltpf_mem[blk + n] -= fo;
-            }
-        } else if (trans == 4) {
-            for (int n = 0; n < nf; n++) {
-                st.x_hat_ltpf_mem[blk + n] = freq[n];
-                st.x_hat_ltpf_mem[blk + n] -= lc3_ltpf_filter(c, st, freq, st.c_num, st.c_den, blk, n, pitch_int);
-            }
+    } else if (trans == 2) {
+        lc3_ltpf_run(c, L, lane, 0, nf, freq, L.st.x_tail, L.st.c_num, L.st.c_den, pitch_int, 1);
+    } else if (trans == 4) {
+        lc3_ltpf_run(c, L, lane, 0, nf, freq, L.st.x_tail, L.st.c_num, L.st.c_den, pitch_int, 0);
+    } else {
+        // deactive_first_2p5ms :417-424
+        lc3_ltpf_run(c, L, lane, 0, s25, freq, L.st.x_tail, cnm, cdm, p_int_mem, 2);
+        if (trans == 3) {
+            for (int n = s25 + lane; n < nf; n += LC3_WAVE) L.st.x_hat_ltpf_mem[blk + n] = freq[n];
         } else {
-            // deactive_first_2p5ms :417-424
-            for (int n = 0; n < s25; n++) {
-                st.x_hat_ltpf_mem[blk + n] = freq[n];
-                float fo = lc3_ltpf_filter(c, st, freq, cnm, cdm, blk, n, p_int_mem);
-                fo *= 1.0f - ((float)n / (float)c.norm);
-                st.x_hat_ltpf_mem[blk + n] -= fo;
+            // activate_first_2p5ms_from_mem :345-378; cnm/cdm are no longer needed: scratch may overlap them
+            const int l_num = c.l_num;
+            LC3_SYNC();
+            for (int i = lane; i < l_num + c.norm; i += LC3_WAVE) {
+                int src;
+                if (blk < l_num) src = i < l_num ? c.num_mem_blocks * nf - l_num + i : i - l_num;
+                else src = blk - l_num + i;
+                scratch[i] = L.st.x_hat_ltpf_mem[src];
             }
-            if (trans == 3) {
-                for (int n = s25; n < nf; n++) st.x_hat_ltpf_mem[blk + n] = freq[n];
-            } else {
-                // activate_first_2p5ms_from_mem :345-378
-                const int l_num = c.l_num;
-                // cnm/cdm are no longer needed: scratch may overlap them
-                if (blk < l_num) {
-                    const int from = c.num_mem_blocks * nf - l_num;
-                    for (int i = 0; i < l_num; i++) scratch[i] = st.x_hat_ltpf_mem[from + i];
-                    for (int i = 0; i < c.norm; i++) scratch[l_num + i] = st.x_hat_ltpf_mem[i];
-                } else {
-                    for (int i = 0; i < l_num + c.norm; i++) scratch[i] = st.x_hat_ltpf_mem[blk - l_num + i];
-                }
-                for (int n = 0; n < s25; n++) {
-                    float fo = 0.0f;
-                    st.x_hat_ltpf_mem[blk + n] = scratch[n + l_num];
-                    for (int k = 0; k <= l_num; k++) fo += st.c_num[k] * scratch[l_num + n - k];
-                    const int sden = (blk + n) - pitch_int + c.l_den / 2;
-                    for (int k = 0; k <= c.l_den; k++) fo -= st.c_den[k] * st.x_hat_ltpf_mem[lc3_wrap_neg(c, sden - k)];
-                    fo *= (float)n / (float)c.norm;
-                    st.x_hat_ltpf_mem[blk + n] -= fo;
-                }
-                for (int n = s25; n < nf; n++) {
-                    st.x_hat_ltpf_mem[blk + n] = freq[n];
-                    st.x_hat_ltpf_mem[blk + n] -= lc3_ltpf_filter(c, st, freq, st.c_num, st.c_den, blk, n, pitch_int);
-                }
-            }
+            LC3_SYNC();
+            lc3_ltpf_run(c, L, lane, 0, s25, scratch + l_num, scratch, L.st.c_num, L.st.c_den, pitch_int, 1);
+            lc3_ltpf_run(c, L, lane, s25, nf, freq, L.st.x_tail, L.st.c_num, L.st.c_den, pitch_int, 0);
         }
     }
     LC3_SYNC();
@@ -293,17 +289,45 @@ __device__ __noinline__ void lc3_dec_ltpf(LC3_CFG_PARAM, lc3_dec_lds &L, int lan
 // noise-filling seed  sum |x_k| * k  (:140-145, wrapping) and the zero-frame flag.
 // Returns 1 when the frame parsed, 0 -> conceal.
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_dec_load_frame(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, const uint8_t *in, int nbytes,
+__device__ __noinline__ int lc3_dec_load_frame(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const uint8_t *in, int nbytes,
                                                const int32_t *plane, int stride) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     int *si = L.ism;
     int32_t *xi = (int32_t *)L.fb;  // 400 ints
     const int ne = c.ne;
     LC3_HBM_CONST(uint8_t) gin = (LC3_HBM_CONST(uint8_t))in;
     LC3_HBM_CONST(int32_t) gplane = (LC3_HBM_CONST(int32_t))plane;
-    for (int i = lane; i < nbytes; i += LC3_WAVE) L.in[i] = gin[i];
-    if (lane < SI_WORDS) si[lane] = gplane[(LC3_PLANE_SI + lane) * stride];
-    for (int k = lane; k < ne; k += LC3_WAVE) xi[k] = gplane[(LC3_PLANE_X + k) * stride];
+    (void)stride;  // frame-major planes: the column is contiguous
+    {
+        // frame bytes (<= 400: seven per lane) and the plane column (side information + integer spectrum, contiguous
+        // 16-byte units: two per lane), every load issued before the first LDS store
+        uint8_t bv[7];
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int i = lane + LC3_WAVE * u;
+            bv[u] = i < nbytes ? gin[i] : (uint8_t)0;
+        }
+        LC3_HBM_CONST(lc3_i4) p4 = (LC3_HBM_CONST(lc3_i4))(gplane + LC3_PLANE_SI);
+        const int n_si4 = (LC3_PLANE_X - LC3_PLANE_SI) / 4, n4 = n_si4 + ne / 4;
+        lc3_i4 pv[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int i = lane + LC3_WAVE * u;
+            if (i < n4) pv[u] = p4[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int i = lane + LC3_WAVE * u;
+            if (i < nbytes) L.in[i] = bv[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int i = lane + LC3_WAVE * u;
+            if (i < n_si4) ((lc3_i4 *)si)[i] = pv[u];
+            else if (i < n4) ((lc3_i4 *)xi)[i - n_si4] = pv[u];
+        }
+    }
     LC3_SYNC();
     if (!si[AD_OK]) return 0;
     uint32_t nnz = 0, seed = 0;
@@ -341,8 +365,9 @@ __device__ __noinline__ int lc3_dec_load_frame(LC3_CFG_PARAM, lc3_dec_lds &L, in
 // ------------------------------------------------------------------------------------------
 // D4-D8: residual refinement, noise filling, global gain, TNS synthesis, SNS (decoder/lc3_decoder.rs:93-131)
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ void lc3_dec_spectrum(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbits) {
+__device__ __noinline__ void lc3_dec_spectrum(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int nbits) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     const int ne = c.ne;
     int *si = L.ism;
     const int32_t *xi = (const int32_t *)L.fb;
@@ -528,8 +553,9 @@ __device__ __forceinline__ void lc3_dec_plc_save(const lc3_cfg &c, lc3_dec_lds &
         L.st.plc_alpha = 1.0f;
     }
 }
-__device__ __noinline__ void lc3_dec_plc_load(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, const lc3_dec_state *g) {
+__device__ __noinline__ void lc3_dec_plc_load(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_dec_state *g) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     // The sign-scrambling LCG seed_k = (16831 + seed_{k-1} * 12821) & 0xFFFF is affine mod 2^16, so lane l can
     // jump straight to its elements k = l, l + 64, ...: seed_{k+64} = A64 * seed_k + C64 (integer, exact).
     const int ne = c.ne;
@@ -566,31 +592,31 @@ __device__ __noinline__ void lc3_dec_plc_load(LC3_CFG_PARAM, lc3_dec_lds &L, int
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, const uint8_t *in,
                                                       int nbytes, int16_t *pcm_out, const int32_t *plane, int stride,
-                                                      lc3_dec_state *g) {
+                                                      lc3_dec_state *g, int valid) {
     LC3_CFG_BIND;
     const int nf = c.nf, nbits = nbytes * 8;
     LC3_STAMP(L, lane, 16);
-    const int ok = lc3_dec_load_frame(LC3_CFG_PASS, L, lane, in, nbytes, plane, stride);
+    const int ok = lc3_dec_load_frame(LC3_CFG_PASS, LC3_LDS_PASS lane, in, nbytes, plane, stride);
     LC3_STAMP(L, lane, 17);
     int ltpf_active = 0, pitch_index = 0;
     if (ok) {
         ltpf_active = L.ism[SI_LTPF_ACTIVE];
         pitch_index = L.ism[SI_PITCH_INDEX];
-        lc3_dec_spectrum(LC3_CFG_PASS, L, lane, nbits);
-        lc3_dec_plc_save(c, L, lane, g);
+        lc3_dec_spectrum(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits);
+        if (valid) lc3_dec_plc_save(c, L, lane, g);
     } else {
-        lc3_dec_plc_load(LC3_CFG_PASS, L, lane, g);
+        lc3_dec_plc_load(LC3_CFG_PASS, LC3_LDS_PASS lane, g);
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 18);
-    lc3_dec_imdct(LC3_CFG_PASS, L, lane);
+    lc3_dec_imdct(LC3_CFG_PASS, LC3_LDS_PASS lane);
     LC3_STAMP(L, lane, 19);
-    lc3_dec_ltpf(LC3_CFG_PASS, L, lane, ltpf_active, pitch_index, nbits);
+    lc3_dec_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, ltpf_active, pitch_index, nbits);
     LC3_STAMP(L, lane, 20);
     // output_scaling::scale_and_round (decoder/output_scaling.rs:13-25); two samples per 32-bit store
     {
         uint32_t *o32 = (uint32_t *)pcm_out;
-        for (int i = lane; i < nf / 2; i += LC3_WAVE) {
+        for (int i = lane; valid && i < nf / 2; i += LC3_WAVE) {
             int32_t v[2];
             for (int j = 0; j < 2; j++) {
                 const float x = L.spec[2 * i + j];

@@ -49,6 +49,7 @@ struct __attribute__((aligned(16))) lc3_enc_lds {
 #endif
 };
 
+LC3_LDS_DECL(lc3_enc_lds, lc3_enc_wg)
 static_assert(offsetof(lc3_enc_lds, fa) % 16 == 0 && offsetof(lc3_enc_lds, spec) % 16 == 0, "128-bit LDS reads need aligned buffers");
 
 struct lc3_sns_res { int ind_lf, ind_hf, shape_j, gind, ls_inda, ls_indb; uint32_t index_joint_j; };
@@ -75,23 +76,20 @@ __device__ __forceinline__ void lc3_enc_state_init(lc3_enc_lds &L, int lane) {
     LC3_SYNC();
 }
 __device__ __forceinline__ void lc3_enc_state_load(lc3_enc_lds &L, int lane, const lc3_enc_state *g) {
-    const int *src = (const int *)g;
-    int *w = (int *)&L.st;
-    for (int i = lane; i < LC3_ENC_STATE_WORDS; i += LC3_WAVE) w[i] = src[i];
+    lc3_wave_copy_in16(&L.st, g, (int)(sizeof(lc3_enc_state) / 16), lane);
     LC3_SYNC();
 }
 __device__ __forceinline__ void lc3_enc_state_store(lc3_enc_lds &L, int lane, lc3_enc_state *g) {
-    int *dst = (int *)g;
-    const int *w = (const int *)&L.st;
     LC3_SYNC();
-    for (int i = lane; i < LC3_ENC_STATE_WORDS; i += LC3_WAVE) dst[i] = w[i];
+    lc3_wave_copy_out16(g, &L.st, (int)(sizeof(lc3_enc_state) / 16), lane);
 }
 
 // ------------------------------------------------------------------------------------------
 // E1-E6: MDCT analysis (encoder/modified_dct.rs:108-177)
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const int16_t *pcm) {
+__device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const int16_t *pcm) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int nf = c.nf, z = c.z, h = nf / 2, mid = 3 * h;
     const uint32_t *w = lc3_window_bits(c);
     const uint16_t *ifs = lc3_band_index(c);
@@ -100,10 +98,19 @@ __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, lc3_enc_lds &L, int lane
     for (int i = lane; i < nf - z; i += LC3_WAVE) L.t[i] = L.st.hist[i];
     {
         LC3_HBM_CONST(uint32_t) p32 = (LC3_HBM_CONST(uint32_t))pcm;
-        for (int i = lane; i < nf / 2; i += LC3_WAVE) {
-            uint32_t v = p32[i];
-            L.t[nf - z + 2 * i] = (int16_t)(v & 0xffffu);
-            L.t[nf - z + 2 * i + 1] = (int16_t)(v >> 16);
+        uint32_t v[4];  // nf / 2 <= 240 words: four per lane, all in flight together
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = lane + LC3_WAVE * u;
+            v[u] = i < nf / 2 ? p32[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = lane + LC3_WAVE * u;
+            if (i < nf / 2) {
+                L.t[nf - z + 2 * i] = (int16_t)(v[u] & 0xffffu);
+                L.t[nf - z + 2 * i + 1] = (int16_t)(v[u] >> 16);
+            }
         }
     }
     for (int i = 2 * nf - z + lane; i < 2 * nf; i += LC3_WAVE) L.t[i] = 0;
@@ -152,8 +159,9 @@ __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, lc3_enc_lds &L, int lane
 // ------------------------------------------------------------------------------------------
 // E7: bandwidth detector (encoder/bandwidth_detector.rs:64-127), lane 0
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_enc_bandwidth(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int *nbits_bw) {
+__device__ __noinline__ int lc3_enc_bandwidth(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int *nbits_bw) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     *nbits_bw = LC3C_NBITS_BW[c.fs_ind];
     if (c.fs_ind == 0) return 0;  // :66-71 (the reference cannot construct an 8 kHz encoder)
     if (lane == 0) {
@@ -191,8 +199,9 @@ __device__ __noinline__ int lc3_enc_bandwidth(LC3_CFG_PARAM, lc3_enc_lds &L, int
 // ------------------------------------------------------------------------------------------
 // E8: attack detector (encoder/attack_detector.rs:45-128)
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int nbytes) {
+__device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int nbytes) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int num_ds = c.n_ms_10 ? 160 : 120, num_blocks = c.n_ms_10 ? 4 : 3, limit = c.n_ms_10 ? 2 : 1;
     int active;
     if (c.fs < 32000) active = 0;
@@ -308,8 +317,9 @@ __device__ __forceinline__ void lc3_mvpq_fold(uint32_t &index, int &lead_sign_in
 // scratch map inside L.fa/L.fb (floats): all disjoint
 //   sE[64] smoothed/log energies, sP[64] padded, sDS[16], sSCF[16], sSCFQ[16], sINT[64],
 //   sST1[16], sR1[16], sT2[16], sABS[16], sXQ[4][16], sDM[64] (stage-1 distortions), iY[4][16]
-__device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int attack) {
+__device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int attack) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     float *S = (float *)L.fa;
     float *sE = S, *sP = S + 64, *sDS = S + 128, *sSCF = S + 144, *sSCFQ = S + 160, *sINT = S + 176;
     float *sST1 = S + 240, *sR1 = S + 256, *sT2 = S + 272, *sABS = S + 288, *sXQ = S + 304, *sDM = S + 368;
@@ -356,6 +366,7 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, lc3_enc_lds &L, i
         sE[lane] = lc3_log2f(1.1920929e-7f + v) / 2.0f;  // :230-233
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 26);
     // band energy grouping :100-124 -- one lane per scale
     if (lane < 16) {
         const float W[6] = {1.0f / 12.0f, 2.0f / 12.0f, 3.0f / 12.0f, 3.0f / 12.0f, 2.0f / 12.0f, 1.0f / 12.0f};
@@ -399,6 +410,7 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, lc3_enc_lds &L, i
         }
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 27);
     // stage 1 :318-361 -- lanes 0..31: LF codebook entry, lanes 32..63: HF codebook entry
     {
         const int i = lane & 31, hf = lane >> 5;
@@ -425,6 +437,7 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, lc3_enc_lds &L, i
         L.ism[1] = ind_hf;
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 28);
     // stage 2 target: t2rot = r1 * D, row-by-row accumulation order (:378-384) -- one lane per column
     if (lane < 16) {
         float acc = 0.0f;
@@ -433,6 +446,7 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, lc3_enc_lds &L, i
         sABS[lane] = lc3_absf(acc);
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 29);
     // Pulse search :285-316, :386-470 on lane 0 with the 16 magnitudes and pulse counts in registers; the signs of
     // the target only enter when a finished candidate is stored (y0 | y1 | y2 | y3 at iY + 0 | 16 | 32 | 48).
     if (lane == 0) {
@@ -497,6 +511,7 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, lc3_enc_lds &L, i
         if (n_best == 0) iY[0] = neg & 1u ? -1 : 1;
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 30);
     // normalize_candidate :632-648 -- the four norms on four lanes (16-term sums in order), the divisions on all lanes
     if (lane < 4) {
         const int n_max = lane == 1 ? 10 : 16;
@@ -588,6 +603,7 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, lc3_enc_lds &L, i
         }
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 31);
     // synthesis :552-559 -- one lane per scale factor
     if (lane < 16) {
         const float *xq_sel = sXQ + 16 * L.ism[2];
@@ -640,9 +656,10 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, lc3_enc_lds &L, i
 // E11: temporal noise shaping (encoder/temporal_noise_shaping.rs:40-349)
 // rc_i[16] -> L.ism[16..32), rc_q[16] -> L.sm[16..32)
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int p_bw, int nbits,
+__device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int p_bw, int nbits,
                                                   int near_nyquist) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const lc3_tns_params &tp = c.n_ms_10 ? LC3C_TNS10[p_bw] : LC3C_TNS75[p_bw];
     float *S = (float *)L.fa;
     float *sAC = S;        // [2][9][3] partial autocorrelations
@@ -856,9 +873,10 @@ __device__ __forceinline__ float lc3_ltpf_dot(const float *x12, int n, int d) { 
     return acc;
 }
 
-__device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int near_nyquist,
+__device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int near_nyquist,
                                                     int nbits) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int len12 = c.len12, len6 = c.len6, p = c.p_up;
     const int x12_len = len12 + c.delay12 + LC3_NMEM;
     float *x12 = L.st.x12, *x6 = L.st.x6;
@@ -1176,9 +1194,10 @@ struct lc3_bitcons { int rate_flag, lastnz, nbits_lsb, lastnz_trunc, nbits_est, 
 
 // quantize_spectrum :230-263 + compute_bit_consumption :265-348.
 // Quantisation is lane-parallel; the context-adaptive bit estimate walks tuples in order on lane 0.
-__device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int nbits,
+__device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int nbits,
                                                             int gg_off, int gg_ind, int nbits_spec) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int ne = c.ne;
     const float gg = lc3_pow10f(((float)gg_ind + (float)gg_off) / 28.0f);
     for (int n = lane; n < ne; n += LC3_WAVE) {
@@ -1295,9 +1314,10 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, lc3_enc
     return bc;
 }
 
-__device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int nbits, int nbits_bw,
+__device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int nbits, int nbits_bw,
                                                       int nbits_tns, int nbits_ltpf) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int ne = c.ne, ne4 = ne / 4;
     float *e = (float *)L.fa;  // 100 group energies
     float *xm = e + 128;       // 64 per-lane maxima
@@ -1422,7 +1442,7 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, lc3_enc_lds &
     const int gg_min = L.ism[9], reset_offset = L.ism[10];
     LC3_SYNC();
     LC3_STAMP(L, lane, 10);
-    lc3_bitcons bc = lc3_quantize_spectrum(LC3_CFG_PASS, L, lane, nbits, gg_off, gg_ind, nbits_spec);
+    lc3_bitcons bc = lc3_quantize_spectrum(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, gg_off, gg_ind, nbits_spec);
     LC3_STAMP(L, lane, 11);
     // save state after the FIRST pass :97-100
     if (lane == 0) {
@@ -1448,7 +1468,7 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, lc3_enc_lds &
             else gg_ind += 2;
             if (gg_ind < gg_min) gg_ind = gg_min;
         }
-        if (origin != gg_ind) bc = lc3_quantize_spectrum(LC3_CFG_PASS, L, lane, nbits, gg_off, gg_ind, nbits_spec);
+        if (origin != gg_ind) bc = lc3_quantize_spectrum(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, gg_off, gg_ind, nbits_spec);
     }
     res.gg_ind = gg_ind;
     res.nbits_spec = nbits_spec;
@@ -1465,9 +1485,10 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, lc3_enc_lds &
 // E18 residual bits (encoder/residual_spectrum.rs:33-62), E19 noise level
 // (encoder/noise_level_estimation.rs:21-55).  Returns n_res via L.ism[0], noise factor via L.ism[1].
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, lc3_enc_lds &L, int lane,
+__device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane,
                                                     const lc3_quant_res q, int bw_ind) {
     LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     // Both loops of the reference walk the spectrum in order and act on a SUBSET of the lines (non-zero lines for
     // the residual bits, lines with an all-zero neighbourhood for the noise level); the position of a line inside
     // its subset is a prefix count.  Lane l owns lines 7l .. 7l+6: it counts, the counts are prefix-summed, and
@@ -1539,24 +1560,24 @@ __device__ __forceinline__ void lc3_encode_frame_wave(LC3_CFG_PARAM, lc3_enc_lds
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
-    const int near_nyquist = lc3_enc_mdct(LC3_CFG_PASS, L, lane, pcm);
+    const int near_nyquist = lc3_enc_mdct(LC3_CFG_PASS, LC3_LDS_PASS lane, pcm);
     LC3_STAMP(L, lane, 1);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[i] = L.spec[i];
     int nbits_bw;
-    const int bw_ind = lc3_enc_bandwidth(LC3_CFG_PASS, L, lane, &nbits_bw);
-    const int attack = lc3_enc_attack(LC3_CFG_PASS, L, lane, nbytes);
+    const int bw_ind = lc3_enc_bandwidth(LC3_CFG_PASS, LC3_LDS_PASS lane, &nbits_bw);
+    const int attack = lc3_enc_attack(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes);
     LC3_STAMP(L, lane, 2);
-    const lc3_sns_res sns = lc3_enc_sns(LC3_CFG_PASS, L, lane, attack);
+    const lc3_sns_res sns = lc3_enc_sns(LC3_CFG_PASS, LC3_LDS_PASS lane, attack);
     LC3_STAMP(L, lane, 3);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[480 + i] = L.spec[i];
-    const lc3_tns_res tns = lc3_enc_tns(LC3_CFG_PASS, L, lane, bw_ind, nbits, near_nyquist);
+    const lc3_tns_res tns = lc3_enc_tns(LC3_CFG_PASS, LC3_LDS_PASS lane, bw_ind, nbits, near_nyquist);
     LC3_STAMP(L, lane, 4);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[960 + i] = L.spec[i];
-    const lc3_ltpf_res pf = lc3_enc_ltpf(LC3_CFG_PASS, L, lane, near_nyquist, nbits);
+    const lc3_ltpf_res pf = lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits);
     LC3_STAMP(L, lane, 5);
-    const lc3_quant_res spec = lc3_enc_quant(LC3_CFG_PASS, L, lane, nbits, nbits_bw, tns.nbits_tns, pf.nbits_ltpf);
+    const lc3_quant_res spec = lc3_enc_quant(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, nbits_bw, tns.nbits_tns, pf.nbits_ltpf);
     LC3_STAMP(L, lane, 6);
-    lc3_enc_residual_noise(LC3_CFG_PASS, L, lane, spec, bw_ind);
+    lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
     LC3_STAMP(L, lane, 7);
     const int n_res = L.ism[0], noise_factor = L.ism[1];
     LC3_SYNC();
@@ -1570,7 +1591,7 @@ __device__ __forceinline__ void lc3_encode_frame_wave(LC3_CFG_PARAM, lc3_enc_lds
         d[18] = spec.gg; d[19] = (float)spec.nbits_spec; d[20] = (float)spec.nbits_trunc; d[21] = (float)near_nyquist;
     }
     // E20/E21 run as a separate lane-per-frame stage (lc3_dev_enc_pack.h): leave this frame's plane column in HBM
-    {
+    if (plane) {
         const int st = plane_stride;
         if (lane == 0) {
             plane[EP_BW * st] = bw_ind;

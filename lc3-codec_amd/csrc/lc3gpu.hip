@@ -17,7 +17,37 @@
 
 #include "../../include/lc3gpu.h"
 
-#define LC3_SYNC() __syncthreads()
+// A workgroup is LC3_WG_WAVES wavefronts, one stream each.  LC3_SYNC orders the LDS traffic of ONE wave (its lanes
+// exchange data through the stream's LDS working set): the hardware executes a wave's LDS instructions in order, so
+// only the compiler has to be kept from moving accesses across the point.  LC3_SERIAL_BEGIN/END bracket code that is
+// serial per stream: the workgroup meets at a barrier, one wave (rotating with `phase`, so that every SIMD gets its
+// share) runs the block for all streams of the workgroup at once -- lane q*K+sub works on stream q with `L` rebound
+// to that stream's working set -- and a second barrier releases the others.  Everything such a block reads or writes
+// therefore lives in LDS (or is a launch-uniform value); per-stream register values must be staged through L first.
+#define LC3_WG_WAVES 4
+#define LC3_SYNC()                                            \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+#define LC3_WAVE_ID() ((int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))
+#define LC3_LDS_DECL(T, arr) __shared__ T arr[LC3_WG_WAVES];
+#define LC3_LDS_PARAM(T)
+#define LC3_LDS_PASS
+#define LC3_LDS_BIND(T, arr) T &L = arr[LC3_WAVE_ID()]
+#define LC3_SERIAL_BEGIN(T, L, lane, phase, K)                                               \
+    {                                                                                        \
+        T *lc3_wg_base_ = &(L) - LC3_WAVE_ID();                                              \
+        __syncthreads();                                                                     \
+        if (LC3_WAVE_ID() == ((phase) % LC3_WG_WAVES) && (lane) < LC3_WG_WAVES * (K)) {      \
+            T &L = lc3_wg_base_[(lane) / (K)];                                               \
+            const int sub = (lane) % (K);                                                    \
+            (void)sub;
+#define LC3_SERIAL_END \
+        }              \
+        __syncthreads(); \
+    }
 #define LC3_HBM_CONST(T) const __attribute__((address_space(1))) T *
 #include "lc3_dev_common.h"
 // ---- configuration slots ----------------------------------------------------------------------------------------
@@ -87,7 +117,7 @@ __device__ __forceinline__ uint32_t lc3_wave_exscan_u32(uint32_t u, int lane) {
 // stage stamps into a per-wave table in LDS (stamp i accumulates the time since the previous stamp into slot i);
 // the table is flushed to a global one with one atomic per slot at the end of the launch, so the stamps do not put
 // memory traffic inside the stages.  Never timed as a whole; read its SHARES (cdna_hip_programming.md section 7).
-__device__ unsigned long long lc3_prof_acc[32];
+__device__ unsigned long long lc3_prof_acc[40];  // 0..31 stage sums; 32/33/34 enc wave time sum/max/count, 35/36/37 dec
 #undef LC3_STAMP
 #define LC3_STAMP(L, lane, id)                                                     \
     do {                                                                           \
@@ -97,12 +127,35 @@ __device__ unsigned long long lc3_prof_acc[32];
             (L).prof_last = t_;                                                    \
         }                                                                          \
     } while (0)
-#define LC3_PROF_BEGIN(L, lane) do { if ((lane) < 32) (L).prof_acc[(lane)] = 0; __syncthreads(); } while (0)
-#define LC3_PROF_END(L, lane) \
-    do { __syncthreads(); if ((lane) < 32 && (L).prof_acc[(lane)]) atomicAdd(&lc3_prof_acc[(lane)], (L).prof_acc[(lane)]); } while (0)
+#define LC3_PROF_BEGIN(L, lane)                                   \
+    do {                                                          \
+        if ((lane) < 32) (L).prof_acc[(lane)] = 0;                \
+        if ((lane) == 0) (L).prof_acc[0] = clock64();             \
+        __syncthreads();                                          \
+    } while (0)
+#define LC3_PROF_MARK(L, lane, slot)                                                    \
+    do {                                                                                \
+        if ((lane) == 0) {                                                              \
+            const unsigned long long t_ = clock64();                                    \
+            atomicAdd(&lc3_prof_acc[(slot)], t_ - ((L).prof_acc[1] ? (L).prof_acc[1] : (L).prof_acc[0])); \
+            (L).prof_acc[1] = t_;                                                       \
+        }                                                                               \
+    } while (0)
+#define LC3_PROF_END(L, lane, base)                                                                     \
+    do {                                                                                                \
+        __syncthreads();                                                                                \
+        if ((lane) == 0) {                                                                              \
+            const unsigned long long d_ = clock64() - (L).prof_acc[0];                                  \
+            atomicAdd(&lc3_prof_acc[(base)], d_);                                                       \
+            atomicMax(&lc3_prof_acc[(base) + 1], d_);                                                   \
+            atomicAdd(&lc3_prof_acc[(base) + 2], 1ull);                                                 \
+        } else if ((lane) < 32 && (L).prof_acc[(lane)])                                                 \
+            atomicAdd(&lc3_prof_acc[(lane)], (L).prof_acc[(lane)]);                                     \
+    } while (0)
 #else
 #define LC3_PROF_BEGIN(L, lane)
-#define LC3_PROF_END(L, lane)
+#define LC3_PROF_END(L, lane, base)
+#define LC3_PROF_MARK(L, lane, slot)
 #endif
 #include "lc3_dev_dec.h"
 #include "lc3_dev_enc.h"
@@ -112,12 +165,17 @@ __device__ unsigned long long lc3_prof_acc[32];
 // kernels
 // ---------------------------------------------------------------------------------------------
 // Analysis kernel: one wave per stream, MDCT ... quantisation, leaves one packer plane column per frame.
-__global__ __launch_bounds__(64, 3) void lc3_encode_kernel(lc3_cfg_slot cfg, lc3_enc_state *states, int first_channel,
-                                                          const int16_t *pcm, int32_t *planes, int nbytes, int n_frames,
-                                                          int fresh, float *dbg) {
-    __shared__ lc3_enc_lds L;
-    const int lane = threadIdx.x;
-    const int s = blockIdx.x;  // stream index inside this launch
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 3) void lc3_encode_kernel(lc3_cfg_slot cfg, lc3_enc_state *states,
+                                                                          int first_channel, int n_streams,
+                                                                          const int16_t *pcm, int32_t *planes, int nbytes,
+                                                                          int n_frames, int fresh, float *dbg) {
+    const int lane = threadIdx.x & 63, wave = LC3_WAVE_ID();
+    lc3_enc_lds &L = lc3_enc_wg[wave];
+    // stream index inside this launch; the waves past the end of the launch shadow the last stream (they take part in
+    // the workgroup barriers) and store nothing
+    const int s_raw = blockIdx.x * LC3_WG_WAVES + wave;
+    const int valid = s_raw < n_streams;
+    const int s = valid ? s_raw : n_streams - 1;
     const int nf = lc3_cfg_table[cfg.id].nf;
     lc3_enc_state *gst = states + (size_t)(first_channel + s);
     LC3_PROF_BEGIN(L, lane);
@@ -125,11 +183,11 @@ __global__ __launch_bounds__(64, 3) void lc3_encode_kernel(lc3_cfg_slot cfg, lc3
     else lc3_enc_state_load(L, lane, gst);
     for (int t = 0; t < n_frames; t++) {
         const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
-        int32_t *plane = LC3_PLANE_COL(planes, f, EP_WORDS);
-        lc3_encode_frame_wave(cfg, L, lane, pcm + f * (size_t)nf, plane, LC3_PLANE_STRIDE, nbytes, dbg);
+        int32_t *plane = valid ? LC3_PLANE_COL(planes, f, EP_WORDS) : nullptr;
+        lc3_encode_frame_wave(cfg, L, lane, pcm + f * (size_t)nf, plane, LC3_PLANE_STRIDE, nbytes, valid ? dbg : nullptr);
     }
-    lc3_enc_state_store(L, lane, gst);
-    LC3_PROF_END(L, lane);
+    if (valid) lc3_enc_state_store(L, lane, gst);
+    LC3_PROF_END(L, lane, 32);
 }
 
 // Bitstream packer, one LANE per frame (lc3_dev_enc_pack.h).  blockDim.x frames per workgroup; context lookup and the
@@ -231,24 +289,30 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(int ne, int fs_ind, int 
     }
 }
 
-__global__ __launch_bounds__(64, 3) void lc3_decode_kernel(lc3_cfg_slot cfg, lc3_dec_state *states, int first_channel,
-                                                          const uint8_t *in, const int32_t *planes, int16_t *pcm,
-                                                          int nbytes, int n_frames, int fresh) {
-    __shared__ lc3_dec_lds L;
-    const int lane = threadIdx.x;
-    const int s = blockIdx.x;
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 3) void lc3_decode_kernel(lc3_cfg_slot cfg, lc3_dec_state *states,
+                                                                          int first_channel, int n_streams,
+                                                                          const uint8_t *in, const int32_t *planes,
+                                                                          int16_t *pcm, int nbytes, int n_frames, int fresh) {
+    const int lane = threadIdx.x & 63, wave = LC3_WAVE_ID();
+    lc3_dec_lds &L = lc3_dec_wg[wave];
+    const int s_raw = blockIdx.x * LC3_WG_WAVES + wave;
+    const int valid = s_raw < n_streams;
+    const int s = valid ? s_raw : n_streams - 1;  // see lc3_encode_kernel
     const int nf = lc3_cfg_table[cfg.id].nf;
     lc3_dec_state *gst = states + (size_t)(first_channel + s);
     LC3_PROF_BEGIN(L, lane);
-    if (fresh) lc3_dec_state_init(L, lane, gst);
+    if (fresh) lc3_dec_state_init(L, lane, gst, valid);
     else lc3_dec_state_load(L, lane, gst);
+    LC3_PROF_MARK(L, lane, 38);  // state load
     for (int t = 0; t < n_frames; t++) {
         const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
         const int32_t *plane = LC3_PLANE_COL(planes, f, LC3_PLANE_WORDS);
-        lc3_decode_frame_wave(cfg, L, lane, in + f * (size_t)nbytes, nbytes, pcm + f * (size_t)nf, plane, LC3_PLANE_STRIDE, gst);
+        lc3_decode_frame_wave(cfg, L, lane, in + f * (size_t)nbytes, nbytes, pcm + f * (size_t)nf, plane, LC3_PLANE_STRIDE, gst,
+                              valid);
     }
-    lc3_dec_state_store(L, lane, gst);
-    LC3_PROF_END(L, lane);
+    LC3_PROF_MARK(L, lane, 39);  // frames (incl. everything between the stage stamps)
+    if (valid) lc3_dec_state_store(L, lane, gst);
+    LC3_PROF_END(L, lane, 35);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -534,7 +598,7 @@ static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_p
         // materialise any still-fresh channel of the range with a zero-frame launch of the init path
         for (int i = first; i < first + n; i++) {
             if (e->fresh_mask[(size_t)i]) {
-                hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64), 0, stream, e->h.slot, e->d_states, i, d_pcm,
+                hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64 * LC3_WG_WAVES), 0, stream, e->h.slot, e->d_states, i, 1, d_pcm,
                                    e->d_planes, nbytes, 0, 1, (float *)nullptr);
                 e->fresh_mask[(size_t)i] = 0;
             }
@@ -542,7 +606,8 @@ static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_p
     }
     // stage 1: analysis, one wave per stream; stage 2: bitstream packing, one lane per frame
     e->timer.mark(stream);
-    hipLaunchKernelGGL(lc3_encode_kernel, dim3((unsigned)n), dim3(64), 0, stream, e->h.slot, e->d_states, first, d_pcm,
+    hipLaunchKernelGGL(lc3_encode_kernel, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0, stream,
+                       e->h.slot, e->d_states, first, n, d_pcm,
                        e->d_planes, nbytes, n_frames, fresh, dbg);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
@@ -598,7 +663,7 @@ int lc3gpu_encoder_state_save(lc3gpu_encoder *e, void *host_dst) {
     // materialise fresh channels first
     for (int i = 0; i < e->num_channels; i++) {
         if (e->fresh_mask[(size_t)i]) {
-            hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64), 0, nullptr, e->h.slot, e->d_states, i, e->d_pcm1,
+            hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64 * LC3_WG_WAVES), 0, nullptr, e->h.slot, e->d_states, i, 1, e->d_pcm1,
                                e->d_planes, 20, 0, 1, (float *)nullptr);
             e->fresh_mask[(size_t)i] = 0;
         }
@@ -631,7 +696,8 @@ static int decoder_reserve_planes(lc3gpu_decoder *d, size_t frames) {
 
 static int decoder_init_states(lc3gpu_decoder *d) {
     // decoder state is materialised eagerly (fresh = 1, zero frames): PLC counters must survive range launches
-    hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)d->num_channels), dim3(64), 0, nullptr, d->h.slot, d->d_states, 0,
+    hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)((d->num_channels + LC3_WG_WAVES - 1) / LC3_WG_WAVES)),
+                       dim3(64 * LC3_WG_WAVES), 0, nullptr, d->h.slot, d->d_states, 0, d->num_channels,
                        (const uint8_t *)d->d_in1, (const int32_t *)d->d_planes, d->d_pcm1, 20, 0, 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -695,7 +761,8 @@ static int decode_launch(lc3gpu_decoder *d, int first, int n, const uint8_t *d_i
                        d->h.c.fs_ind, d->h.c.n_ms_10, d_in, d_bad, d->d_planes, nbytes, (int)frames);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream);
-    hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)n), dim3(64), 0, stream, d->h.slot, d->d_states, first, d_in,
+    hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0, stream,
+                       d->h.slot, d->d_states, first, n, d_in,
                        (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream);
@@ -775,10 +842,10 @@ int lc3gpu_decoder_timing(lc3gpu_decoder *d, int enable, double out[3]) {
 }
 
 // diagnostic build only: copy (and clear) the per-stage cycle accumulators; LC3GPU_EUNSUPPORTED otherwise
-int lc3gpu_prof_read(unsigned long long out[32]) {
+int lc3gpu_prof_read(unsigned long long out[40]) {
 #ifdef LC3_PROFILE
     if (!out) return LC3GPU_EINVAL;
-    unsigned long long zero[32] = {0};
+    unsigned long long zero[40] = {0};
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(lc3_prof_acc), sizeof(zero)));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lc3_prof_acc), zero, sizeof(zero)));

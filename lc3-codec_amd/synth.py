@@ -45,3 +45,21 @@ def make_pcm(n_streams, n_frames, nf, fs_hz, seed=SEED, first_stream=0):
                 x[start:start + ln] += 2.0 * level * env * rng.choice([-1.0, 1.0])
         out[i] = np.clip(np.rint(x), -32768, 32767).astype(np.int16).reshape(n_frames, nf)
     return out
+
+
+def make_ltpf_pcm(nf, fs_hz, n_frames=14):
+    """Three streams that walk the decoder's long-term post-filter through all five of its frame-to-frame transition
+    cases (decoder/long_term_post_filter.rs:142-160): a tone whose pitch glides (filter stays on while its lag changes),
+    a tone that is interrupted by noise (filter switches off and on again) and a steady tone (unchanged filter)."""
+    n = n_frames * nf
+    t = np.arange(n, dtype=np.float64) / float(fs_hz)
+    x = np.zeros((3, n))
+    f = 180.0 + 60.0 * np.clip((t - 0.04) / 0.06, 0.0, 1.0)
+    ph = 2.0 * np.pi * np.cumsum(f) / float(fs_hz)
+    x[0] = 9000.0 * np.sin(ph) + 3000.0 * np.sin(2.0 * ph)
+    tone = 9000.0 * np.sin(2.0 * np.pi * 220.0 * t) + 4000.0 * np.sin(2.0 * np.pi * 440.0 * t + 1.0)
+    gate = ((t < 0.05) | (t > 0.09)).astype(np.float64)
+    rng = np.random.default_rng([SEED, 5])
+    x[1] = tone * gate + rng.uniform(-1.0, 1.0, n) * 3000.0 * (1.0 - gate)
+    x[2] = 12000.0 * np.sin(2.0 * np.pi * 150.0 * t) + 5000.0 * np.sin(2.0 * np.pi * 300.0 * t + 0.3)
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16).reshape(3, n_frames, nf)

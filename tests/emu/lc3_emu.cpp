@@ -16,49 +16,55 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __noinline__ __attribute__((noinline))
 
-static pthread_barrier_t g_bar;
-#define LC3_SYNC() pthread_barrier_wait(&g_bar)
+// One emulated workgroup = LC3_WG_WAVES wavefronts of 64 host threads, one stream per wave -- the same shape as the
+// HIP kernels (lc3gpu.hip).  LC3_SYNC is the wave-level barrier; the serial phases (LC3_SERIAL_BEGIN/END) meet at the
+// workgroup barrier and run on the phase's leader wave with `L` rebound per stream, exactly as on the GPU, so a block
+// that wrongly reads a per-stream value from a register (instead of LDS) reads the wrong stream's value here too.
+#define LC3_WG_WAVES 4
+static pthread_barrier_t g_wave_bar[LC3_WG_WAVES], g_wg_bar;
+static thread_local int tl_wave = 0;
+#define LC3_SYNC() pthread_barrier_wait(&g_wave_bar[tl_wave])
+#define LC3_SERIAL_BEGIN(T, L, lane, phase, K)                                   \
+    {                                                                            \
+        T *lc3_wg_base_ = &(L) - tl_wave;                                        \
+        pthread_barrier_wait(&g_wg_bar);                                         \
+        if (tl_wave == ((phase) % LC3_WG_WAVES) && (lane) < LC3_WG_WAVES * (K)) { \
+            T &L = lc3_wg_base_[(lane) / (K)];                                   \
+            const int sub = (lane) % (K);                                        \
+            (void)sub;
+#define LC3_SERIAL_END                   \
+        }                                \
+        pthread_barrier_wait(&g_wg_bar); \
+    }
 #include "../../lc3-codec_amd/csrc/lc3_dev_common.h"
-// wave-level primitives: the GPU uses cross-lane shuffles / v_readlane; the emulator exchanges through memory
-static int g_xi[64];
-static float g_xf0[64], g_xf1[64];
+// wave-level primitives: the GPU uses DPP / v_readlane; the emulator exchanges through memory
+static int g_xi[LC3_WG_WAVES][64];
 static inline int lc3_wave_max_i32(int v, int lane) {
-    pthread_barrier_wait(&g_bar);
-    g_xi[lane] = v;
-    pthread_barrier_wait(&g_bar);
-    int m = g_xi[0];
-    for (int i = 1; i < 64; i++) m = g_xi[i] > m ? g_xi[i] : m;
-    pthread_barrier_wait(&g_bar);
+    LC3_SYNC();
+    g_xi[tl_wave][lane] = v;
+    LC3_SYNC();
+    int m = g_xi[tl_wave][0];
+    for (int i = 1; i < 64; i++) m = g_xi[tl_wave][i] > m ? g_xi[tl_wave][i] : m;
+    LC3_SYNC();
     return m;
 }
 static inline uint32_t lc3_wave_sum_u32(uint32_t v, int lane) {
-    pthread_barrier_wait(&g_bar);
-    g_xi[lane] = (int)v;
-    pthread_barrier_wait(&g_bar);
+    LC3_SYNC();
+    g_xi[tl_wave][lane] = (int)v;
+    LC3_SYNC();
     uint32_t m = 0;
-    for (int i = 0; i < 64; i++) m += (uint32_t)g_xi[i];
-    pthread_barrier_wait(&g_bar);
+    for (int i = 0; i < 64; i++) m += (uint32_t)g_xi[tl_wave][i];
+    LC3_SYNC();
     return m;
 }
 static inline uint32_t lc3_wave_exscan_u32(uint32_t v, int lane) {
-    pthread_barrier_wait(&g_bar);
-    g_xi[lane] = (int)v;
-    pthread_barrier_wait(&g_bar);
+    LC3_SYNC();
+    g_xi[tl_wave][lane] = (int)v;
+    LC3_SYNC();
     uint32_t m = 0;
-    for (int i = 0; i < lane; i++) m += (uint32_t)g_xi[i];
-    pthread_barrier_wait(&g_bar);
+    for (int i = 0; i < lane; i++) m += (uint32_t)g_xi[tl_wave][i];
+    LC3_SYNC();
     return m;
-}
-static inline float lc3_wave_seqsum2(float r0, float r1, int n, int descending, int lane) {
-    pthread_barrier_wait(&g_bar);
-    g_xf0[lane] = r0;
-    g_xf1[lane] = r1;
-    pthread_barrier_wait(&g_bar);
-    float acc = 0.0f;
-    if (descending) for (int i = n - 1; i >= 0; i--) acc += i < 64 ? g_xf0[i] : g_xf1[i - 64];
-    else for (int i = 0; i < n; i++) acc += i < 64 ? g_xf0[i] : g_xf1[i - 64];
-    pthread_barrier_wait(&g_bar);
-    return acc;
 }
 
 #include "../../lc3-codec_amd/csrc/lc3_dev_dec.h"
@@ -68,62 +74,70 @@ static inline float lc3_wave_seqsum2(float r0, float r1, int n, int descending, 
 namespace {
 struct Job {
     lc3_cfg cfg;
-    int lane;
+    int lane, wave, valid;
     int encode;
     int n_frames, nbytes, fresh;
-    lc3_enc_lds *EL;
+    lc3_enc_lds *EL;  // the workgroup's array of working sets
     lc3_dec_lds *DL;
-    lc3_enc_state *est;
+    lc3_enc_state *est;   // this stream's state blob
     lc3_dec_state *dst;
     const int16_t *pcm_in;
-    int32_t *enc_planes;  // packer planes of this stream: frame t at column (frame0 + t)
+    int32_t *enc_planes;  // packer planes of the whole batch: frame t of this stream at column (frame0 + t)
     const uint8_t *bytes_in;
-    const int32_t *planes;  // parsed frames of this stream: frame t at column index (frame0 + t)
+    const int32_t *planes;  // parsed frames of the whole batch
     size_t frame0;
     int16_t *pcm_out;
     float *dbg;
 };
 
+// body of lc3_encode_kernel / lc3_decode_kernel (lc3gpu.hip) for one lane
 void *lane_main(void *arg) {
     Job *j = (Job *)arg;
     const int lane = j->lane;
+    tl_wave = j->wave;
     if (j->encode) {
-        lc3_enc_lds &L = *j->EL;
+        lc3_enc_lds &L = j->EL[j->wave];
         if (j->fresh) lc3_enc_state_init(L, lane);
         else lc3_enc_state_load(L, lane, j->est);
         for (int t = 0; t < j->n_frames; t++) {
             const size_t f = j->frame0 + (size_t)t;
-            int32_t *plane = LC3_PLANE_COL(j->enc_planes, f, EP_WORDS);
-            lc3_encode_frame_wave(j->cfg, L, lane, j->pcm_in + (size_t)t * j->cfg.nf, plane, LC3_PLANE_STRIDE, j->nbytes, j->dbg);
+            int32_t *plane = j->valid ? LC3_PLANE_COL(j->enc_planes, f, EP_WORDS) : nullptr;
+            lc3_encode_frame_wave(j->cfg, L, lane, j->pcm_in + (size_t)t * j->cfg.nf, plane, LC3_PLANE_STRIDE, j->nbytes,
+                                  j->valid ? j->dbg : nullptr);
         }
-        lc3_enc_state_store(L, lane, j->est);
+        if (j->valid) lc3_enc_state_store(L, lane, j->est);
     } else {
-        lc3_dec_lds &L = *j->DL;
-        if (j->fresh) lc3_dec_state_init(L, lane, j->dst);
+        lc3_dec_lds &L = j->DL[j->wave];
+        if (j->fresh) lc3_dec_state_init(L, lane, j->dst, j->valid);
         else lc3_dec_state_load(L, lane, j->dst);
-        for (int t = 0; t < j->n_frames; t++)
-        {
+        for (int t = 0; t < j->n_frames; t++) {
             const size_t f = j->frame0 + (size_t)t;
             const int32_t *plane = LC3_PLANE_COL(j->planes, f, LC3_PLANE_WORDS);
             lc3_decode_frame_wave(j->cfg, L, lane, j->bytes_in + (size_t)t * j->nbytes, j->nbytes,
-                                  j->pcm_out + (size_t)t * j->cfg.nf, plane, LC3_PLANE_STRIDE, j->dst);
+                                  j->pcm_out + (size_t)t * j->cfg.nf, plane, LC3_PLANE_STRIDE, j->dst, j->valid);
         }
-        lc3_dec_state_store(L, lane, j->dst);
+        if (j->valid) lc3_dec_state_store(L, lane, j->dst);
     }
     return 0;
 }
 
-void run_wave(Job proto) {
-    pthread_t th[LC3_WAVE];
-    Job jobs[LC3_WAVE];
-    pthread_barrier_init(&g_bar, 0, LC3_WAVE);
-    for (int i = 0; i < LC3_WAVE; i++) {
-        jobs[i] = proto;
-        jobs[i].lane = i;
-        pthread_create(&th[i], 0, lane_main, &jobs[i]);
-    }
-    for (int i = 0; i < LC3_WAVE; i++) pthread_join(th[i], 0);
-    pthread_barrier_destroy(&g_bar);
+// runs one workgroup: wave w works on protos[w]
+void run_wg(const Job *protos) {
+    static pthread_t th[LC3_WG_WAVES * LC3_WAVE];
+    static Job jobs[LC3_WG_WAVES * LC3_WAVE];
+    for (int w = 0; w < LC3_WG_WAVES; w++) pthread_barrier_init(&g_wave_bar[w], 0, LC3_WAVE);
+    pthread_barrier_init(&g_wg_bar, 0, LC3_WG_WAVES * LC3_WAVE);
+    for (int w = 0; w < LC3_WG_WAVES; w++)
+        for (int i = 0; i < LC3_WAVE; i++) {
+            Job &q = jobs[w * LC3_WAVE + i];
+            q = protos[w];
+            q.lane = i;
+            q.wave = w;
+            pthread_create(&th[w * LC3_WAVE + i], 0, lane_main, &q);
+        }
+    for (int i = 0; i < LC3_WG_WAVES * LC3_WAVE; i++) pthread_join(th[i], 0);
+    for (int w = 0; w < LC3_WG_WAVES; w++) pthread_barrier_destroy(&g_wave_bar[w]);
+    pthread_barrier_destroy(&g_wg_bar);
 }
 }  // namespace
 
@@ -149,15 +163,24 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
     // stage 1: analysis, one emulated wave per stream, leaves the packer planes
     const size_t frames = (size_t)S * (size_t)T;
     std::vector<int32_t> planes(((frames + 63) / 64) * 64 * EP_WORDS, 0);
-    lc3_enc_lds *L = (lc3_enc_lds *)calloc(1, sizeof(lc3_enc_lds));
-    lc3_enc_state *st = (lc3_enc_state *)calloc(1, sizeof(lc3_enc_state));
+    lc3_enc_lds *L = (lc3_enc_lds *)aligned_alloc(16, LC3_WG_WAVES * sizeof(lc3_enc_lds));
+    lc3_enc_state *st = (lc3_enc_state *)aligned_alloc(16, LC3_WG_WAVES * sizeof(lc3_enc_state));
     j.EL = L;
-    j.est = st;
     j.enc_planes = planes.data();
-    for (int s = 0; s < S; s++) {
-        j.pcm_in = pcm + (size_t)s * T * j.cfg.nf;
-        j.frame0 = (size_t)s * T;
-        run_wave(j);
+    for (int s0 = 0; s0 < S; s0 += LC3_WG_WAVES) {
+        Job protos[LC3_WG_WAVES];
+        memset(L, 0, LC3_WG_WAVES * sizeof(lc3_enc_lds));
+        memset(st, 0, LC3_WG_WAVES * sizeof(lc3_enc_state));
+        for (int w = 0; w < LC3_WG_WAVES; w++) {
+            // waves past the end of the batch shadow the last stream and store nothing (as in lc3_encode_kernel)
+            const int valid = s0 + w < S, s = valid ? s0 + w : S - 1;
+            protos[w] = j;
+            protos[w].valid = valid;
+            protos[w].est = st + w;
+            protos[w].pcm_in = pcm + (size_t)s * T * j.cfg.nf;
+            protos[w].frame0 = (size_t)s * T;
+        }
+        run_wg(protos);
     }
     free(L);
     free(st);
@@ -213,16 +236,24 @@ int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8
         lc3_px_set(c, AD_OK, rc == 0);
     }
     // stage 2: synthesis, one emulated wave per stream
-    lc3_dec_lds *L = (lc3_dec_lds *)calloc(1, sizeof(lc3_dec_lds));
-    lc3_dec_state *st = (lc3_dec_state *)calloc(1, sizeof(lc3_dec_state));
+    lc3_dec_lds *L = (lc3_dec_lds *)aligned_alloc(16, LC3_WG_WAVES * sizeof(lc3_dec_lds));
+    lc3_dec_state *st = (lc3_dec_state *)aligned_alloc(16, LC3_WG_WAVES * sizeof(lc3_dec_state));
     j.DL = L;
-    j.dst = st;
     j.planes = planes.data();
-    for (int s = 0; s < S; s++) {
-        j.bytes_in = bytes + (size_t)s * T * nbytes;
-        j.frame0 = (size_t)s * T;
-        j.pcm_out = pcm + (size_t)s * T * j.cfg.nf;
-        run_wave(j);
+    for (int s0 = 0; s0 < S; s0 += LC3_WG_WAVES) {
+        Job protos[LC3_WG_WAVES];
+        memset(L, 0, LC3_WG_WAVES * sizeof(lc3_dec_lds));
+        memset(st, 0, LC3_WG_WAVES * sizeof(lc3_dec_state));
+        for (int w = 0; w < LC3_WG_WAVES; w++) {
+            const int valid = s0 + w < S, s = valid ? s0 + w : S - 1;
+            protos[w] = j;
+            protos[w].valid = valid;
+            protos[w].dst = st + w;
+            protos[w].bytes_in = bytes + (size_t)s * T * nbytes;
+            protos[w].frame0 = (size_t)s * T;
+            protos[w].pcm_out = pcm + (size_t)s * T * j.cfg.nf;
+        }
+        run_wg(protos);
     }
     free(L);
     free(st);

@@ -133,3 +133,14 @@ def decode_batch(data, nf, fs_hz=48000, frame_us=10000, threads=1):
     rc = lib().lc3o_decode_batch(fs_hz, frame_us, nbytes, S, T, P(data), P(out), threads)
     assert rc == 0
     return out
+
+
+def ltpf_transition_counts(reset=False):
+    """How often each decoder LTPF transition case (index 1..5) ran inside the oracle since the last reset."""
+    import ctypes
+    cnt = (ctypes.c_long * 6).in_dll(lib(), "lc3o_ltpf_trans_count")
+    out = [int(v) for v in cnt]
+    if reset:
+        for i in range(6):
+            cnt[i] = 0
+    return out

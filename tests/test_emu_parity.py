@@ -82,3 +82,19 @@ def test_device_math_matches_oracle_math():
     for i in range(17):
         x = float(np.float32(step * np.float32(i - 8)))
         assert L.lc3emu_sinf_small(x) == M.lc3m_sinf(x)
+
+
+@pytest.mark.parametrize("fs,us,nbytes", [(48000, 10000, 60), (16000, 7500, 30)])
+def test_emu_ltpf_transitions(fs, us, nbytes):
+    """Decoder LTPF synthesis through all five transition cases (off->off, off->on, on->off, same lag, new lag)."""
+    cfg = np.zeros(7, np.int32)
+    O.lib().lc3o_kat_config(fs, us, O.P(cfg))
+    nf = int(cfg[5])
+    pcm = synth.make_ltpf_pcm(nf, fs)
+    ref = O.encode_batch(pcm, nbytes, fs, us)
+    O.ltpf_transition_counts(reset=True)
+    ref_pcm = O.decode_batch(ref, nf, fs, us)
+    counts = O.ltpf_transition_counts()
+    assert all(c > 0 for c in counts[1:]), counts
+    assert np.array_equal(E.encode(pcm, nbytes, fs, us), ref)
+    assert np.array_equal(E.decode(ref, nf, fs, us), ref_pcm)

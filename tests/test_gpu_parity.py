@@ -290,3 +290,18 @@ def test_full_size_batch_properties():
             best, best_lag = snr, lag
     assert best > 15.0, f"median round-trip SNR {best:.1f} dB at lag {best_lag}"
     del torch
+
+
+@pytest.mark.parametrize("fs,us,nbytes", [(48000, 10000, 60), (32000, 10000, 40), (16000, 7500, 30), (48000, 7500, 60)])
+def test_ltpf_transitions(fs, us, nbytes):
+    """Decoder LTPF synthesis (block-parallel on the GPU) through all five transition cases of
+    decoder/long_term_post_filter.rs:142-160; the oracle's counters prove the inputs reach every case."""
+    nf = {48000: 480, 32000: 320, 16000: 160}[fs] * us // 10000
+    pcm = synth.make_ltpf_pcm(nf, fs)
+    ref = O.encode_batch(pcm, nbytes, fs, us)
+    O.ltpf_transition_counts(reset=True)
+    ref_pcm = O.decode_batch(ref, nf, fs, us)
+    counts = O.ltpf_transition_counts()
+    assert all(c > 0 for c in counts[1:]), counts
+    assert np.array_equal(gpu_encode(pcm, nbytes, fs, us), ref)
+    assert np.array_equal(gpu_decode(ref, nf, fs, us), ref_pcm)
