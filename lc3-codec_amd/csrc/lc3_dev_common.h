@@ -64,6 +64,20 @@
     }
 #endif
 
+// The same bracket without the gathering: lanes 0..K-1 of the stream's own wave run the block (for serial work whose
+// duration differs a lot from stream to stream, where waiting for the slowest stream of the workgroup costs more than
+// the issue slots the gathering saves).
+#define LC3_LOCAL_BEGIN(lane, K)    \
+    {                               \
+        LC3_SYNC();                 \
+        if ((lane) < (K)) {         \
+            const int sub = (lane); \
+            (void)sub;
+#define LC3_LOCAL_END \
+        }             \
+        LC3_SYNC();   \
+    }
+
 // Pointer to read-only HBM data handed to a stage function: the HIP translation unit marks the address space so that
 // the loads are global_load rather than flat_load.
 #ifndef LC3_HBM_CONST

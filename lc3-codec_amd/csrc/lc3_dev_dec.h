@@ -365,12 +365,15 @@ __device__ __noinline__ int lc3_dec_load_frame(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_
 // ------------------------------------------------------------------------------------------
 // D4-D8: residual refinement, noise filling, global gain, TNS synthesis, SNS (decoder/lc3_decoder.rs:93-131)
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ void lc3_dec_spectrum(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int nbits) {
+// Every wave of the workgroup calls this (it contains a serial phase); `ok` = the frame parsed (L.ism[AD_OK]), a
+// stream whose frame did not parse skips the work and conceals afterwards.
+__device__ __noinline__ void lc3_dec_spectrum(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int nbits, int ok) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     const int ne = c.ne;
     int *si = L.ism;
     const int32_t *xi = (const int32_t *)L.fb;
+    if (ok) {
     for (int k = lane; k < ne; k += LC3_WAVE) L.spec[k] = (float)xi[k];
     LC3_SYNC();
     // residual_spectrum::decode (decoder/residual_spectrum.rs:13-39): the j-th non-zero line takes residual bit j
@@ -449,10 +452,16 @@ __device__ __noinline__ void lc3_dec_spectrum(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_d
         const float gg = lc3_pow10f(((float)si[SI_GG] + (float)gg_off) / 28.0f);
         for (int k = lane; k < ne; k += LC3_WAVE) L.spec[k] *= gg;
     }
-    LC3_SYNC();
-    if (lane == 0) {
-        // temporal_noise_shaping::apply_temporal_noise_shaping (decoder/temporal_noise_shaping.rs:24-137):
-        // all-pole lattice, recursive in n -> serial; state shared across both filters
+    }  // if (ok)
+    // Sixteen lanes.  Lane 0: the TNS synthesis lattice (decoder/temporal_noise_shaping.rs:24-137, recursive in n,
+    // state shared across both filters) and the pulse de-enumeration of the SNS shape; then the sixteen together: scale
+    // factors (decoder/spectral_noise_shaping.rs:21-151).  Kept on the stream's own wave: the lattice takes anything
+    // from nothing to ~100 k cycles depending on the frame's TNS orders (measured: gathering the workgroup's four
+    // streams on one wave made every stream wait for the slowest, profiles/r01_v6_notes.txt).
+    LC3_LOCAL_BEGIN(lane, LC3_WAVE)  // the whole wave enters (it syncs inside); lanes 16.. only keep step
+    int *y = (int *)(L.sm + 96);          // [16] pulses
+    float *scf = L.sm, *sfi = L.sm + 16;  // 16 + 64
+    if (sub == 0 && ok) {
         const int bw = si[SI_BW];
         const int nbands = bw < 3 ? 1 : 2;
         const float step = (float)(3.14159265358979323846 / 17.0);  // (PI / 17.0) as f32 :41
@@ -484,10 +493,7 @@ __device__ __noinline__ void lc3_dec_spectrum(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_d
                 }
             }
         }
-        LC3_STAMP(L, lane, 23);
-        // spectral_noise_shaping::decode (decoder/spectral_noise_shaping.rs:21-151): scale factors
-        int *y = (int *)(L.sm + 96), *zv = y + 16;
-        float *scf = L.sm, *sfi = L.sm + 16;  // 16 + 64
+        int *zv = y + 16;
         const int shape_j = (si[SI_SUB_MSB] << 1) + si[SI_SUB_LSB];
         for (int n = 0; n < 16; n++) { y[n] = 0; zv[n] = 0; }
         if (shape_j == 0) {
@@ -509,30 +515,46 @@ __device__ __noinline__ void lc3_dec_spectrum(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_d
         else if (shape_j == 2) gain = lc3_f(LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS, gi & 3);
         else gain = lc3_f(LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS, gi & 7);
         if (y_norm != 0.0f) gain /= y_norm;
-        for (int n = 0; n < 16; n++) {
-            float factor = 0.0f;
-            for (int col = 0; col < 16; col++) factor += (float)y[col] * lc3_f(&LC3T_D_BITS[n][0], col);
-            const float st1 = n < 8 ? lc3_f(&LC3T_LFCB_BITS[si[SI_IND_LF]][0], n) : lc3_f(&LC3T_HFCB_BITS[si[SI_IND_HF]][0], n - 8);
-            scf[n] = st1 + gain * factor;
+        L.sm[128] = gain;
+    }
+    LC3_SYNC();
+    if (ok && sub < 16) {
+        // scale factor sub = codebook entry + gain * (y . D[sub][:]), 16-term sum in order
+        const int n = sub;
+        const float gain = L.sm[128];
+        float factor = 0.0f;
+        for (int col = 0; col < 16; col++) factor += (float)y[col] * lc3_f(&LC3T_D_BITS[n][0], col);
+        const float st1 = n < 8 ? lc3_f(&LC3T_LFCB_BITS[si[SI_IND_LF]][0], n) : lc3_f(&LC3T_HFCB_BITS[si[SI_IND_HF]][0], n - 8);
+        scf[n] = st1 + gain * factor;
+    }
+    LC3_SYNC();
+    if (ok && sub < 16) {
+        // interpolation :75-98 -- four of the 64 values per lane
+        const int n = sub;
+        if (n == 0) {
+            sfi[0] = scf[0];
+            sfi[1] = scf[0];
+            sfi[62] = scf[15] + 1.0f / 8.0f * (scf[15] - scf[14]);
+            sfi[63] = scf[15] + 3.0f / 8.0f * (scf[15] - scf[14]);
         }
-        sfi[0] = scf[0];
-        sfi[1] = scf[0];
-        for (int n = 0; n <= 14; n++) {
+        if (n <= 14) {
             const float fn = scf[n], d = scf[n + 1] - fn;
             sfi[4 * n + 2] = fn + (1.0f / 8.0f * d);
             sfi[4 * n + 3] = fn + (3.0f / 8.0f * d);
             sfi[4 * n + 4] = fn + (5.0f / 8.0f * d);
             sfi[4 * n + 5] = fn + (7.0f / 8.0f * d);
         }
-        sfi[62] = scf[15] + 1.0f / 8.0f * (scf[15] - scf[14]);
-        sfi[63] = scf[15] + 3.0f / 8.0f * (scf[15] - scf[14]);
+    }
+    LC3_SYNC();
+    if (ok && sub == 0) {
         const int n2 = 64 - c.nb;
         if (n2 != 0) {  // :100-111 (decoder form)
             for (int b = 0; b < n2; b++) sfi[b] = (sfi[2 * b] + sfi[2 * b + 1]) / 2.0f;
             for (int b = n2; b < c.nb; b++) sfi[b] = sfi[b + n2];
         }
     }
-    LC3_SYNC();
+    LC3_LOCAL_END
+    if (ok) {
     LC3_STAMP(L, lane, 24);
     // band gains via fast_math::exp2_raw and spectral shaping -- one lane per band
     if (lane < c.nb) {
@@ -540,6 +562,7 @@ __device__ __noinline__ void lc3_dec_spectrum(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_d
         const float g = lc3_exp2_raw(L.sm[16 + lane]);
         for (int k = ifs[lane]; k < ifs[lane + 1]; k++) L.spec[k] *= g;
     }
+    }  // if (ok)
     LC3_SYNC();
 }
 
@@ -599,10 +622,10 @@ __device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds
     const int ok = lc3_dec_load_frame(LC3_CFG_PASS, LC3_LDS_PASS lane, in, nbytes, plane, stride);
     LC3_STAMP(L, lane, 17);
     int ltpf_active = 0, pitch_index = 0;
+    lc3_dec_spectrum(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, ok);
     if (ok) {
         ltpf_active = L.ism[SI_LTPF_ACTIVE];
         pitch_index = L.ism[SI_PITCH_INDEX];
-        lc3_dec_spectrum(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits);
         if (valid) lc3_dec_plc_save(c, L, lane, g);
     } else {
         lc3_dec_plc_load(LC3_CFG_PASS, LC3_LDS_PASS lane, g);

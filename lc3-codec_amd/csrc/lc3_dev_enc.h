@@ -447,9 +447,14 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 29);
-    // Pulse search :285-316, :386-470 on lane 0 with the 16 magnitudes and pulse counts in registers; the signs of
-    // the target only enter when a finished candidate is stored (y0 | y1 | y2 | y3 at iY + 0 | 16 | 32 | 48).
-    if (lane == 0) {
+    // Pulse search :285-316, :386-470, serial per stream, with the 16 magnitudes and pulse counts in registers; the
+    // signs of the target only enter when a finished candidate is stored (y0 | y1 | y2 | y3 at iY + 0 | 16 | 32 | 48).
+    // (Gathering the workgroup's four streams on one wave -- LC3_SERIAL_BEGIN -- cut 1.2 k VALU instructions per frame
+    // but not the kernel time: profiles/r01_v6_notes.txt.)
+    LC3_LOCAL_BEGIN(lane, 1)
+    {
+        const float *sABS = (const float *)L.fa + 288, *sT2 = (const float *)L.fa + 272;
+        int *iY = (int *)((float *)L.fa + 432);
         float ax[16];
         int cand[16];
         uint32_t neg = 0;
@@ -510,7 +515,7 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3
         // no positive magnitude in 10..15: the reference's pulse lands on line 0 and takes that line's sign
         if (n_best == 0) iY[0] = neg & 1u ? -1 : 1;
     }
-    LC3_SYNC();
+    LC3_LOCAL_END
     LC3_STAMP(L, lane, 30);
     // normalize_candidate :632-648 -- the four norms on four lanes (16-term sums in order), the divisions on all lanes
     if (lane < 4) {

@@ -137,8 +137,8 @@ __device__ unsigned long long lc3_prof_acc[40];  // 0..31 stage sums; 32/33/34 e
     do {                                                                                \
         if ((lane) == 0) {                                                              \
             const unsigned long long t_ = clock64();                                    \
-            atomicAdd(&lc3_prof_acc[(slot)], t_ - ((L).prof_acc[1] ? (L).prof_acc[1] : (L).prof_acc[0])); \
-            (L).prof_acc[1] = t_;                                                       \
+            atomicAdd(&lc3_prof_acc[(slot)], t_ - ((L).prof_acc[16] ? (L).prof_acc[16] : (L).prof_acc[0])); \
+            (L).prof_acc[16] = t_;                                                      \
         }                                                                               \
     } while (0)
 #define LC3_PROF_END(L, lane, base)                                                                     \

@@ -41,8 +41,7 @@ names = {26: "enc sns: pad, smooth, pre-emph, floor, log2", 27: "enc sns: groupi
          29: "enc sns: stage-2 target", 30: "enc sns: pulse search", 31: "enc sns: normalise, gain search, enumeration",
          9: "enc quant: energies+max", 10: "enc quant: gain bisection", 11: "enc quant: first quantise+bit count",
          12: "enc ltpf: shift+resample", 13: "enc ltpf: 50 Hz high-pass", 14: "enc ltpf: pitch detection",
-         15: "enc ltpf: lag refinement", 22: "dec spectrum: residual+noise fill", 23: "dec spectrum: gain+tns",
-         24: "dec spectrum: sns scale factors", 25: "dec imdct: dct-iv",
+         15: "enc ltpf: lag refinement", 22: "dec spectrum: residual+noise fill", 24: "dec spectrum: gain, serial phase (tns lattice, sns scale factors)", 25: "dec imdct: dct-iv",
          1: "enc mdct+energy", 2: "enc bandwidth+attack", 3: "enc sns (rest: synthesis, interpolation, shaping)", 4: "enc tns", 5: "enc ltpf (rest: activation)", 6: "enc quant (rest: adjust + 2nd pass)",
          7: "enc residual+noise", 8: "enc plane store", 17: "dec load parsed frame (planes) + epilogue",
          18: "dec spectrum (rest: band scaling, plc save)", 19: "dec imdct (rest: window+ola)", 20: "dec ltpf", 21: "dec output"}
