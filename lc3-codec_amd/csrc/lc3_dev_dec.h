@@ -32,8 +32,7 @@ struct __attribute__((aligned(16))) lc3_dec_lds {
     lc3_dec_core st;
     float spec[LC3_MAX_NF];        // spec_lines, then freq_samples
     lc3_cpx fa[LC3_MAX_NF / 2];    // FFT in   | t_hat_mdct[0 .. nf)
-    lc3_cpx fb[LC3_MAX_NF / 2];    // integer spectrum xi     | FFT work | t_hat_mdct[nf .. 2nf)  (contiguous with fa)
-    uint8_t in[LC3_MAX_NE];        // frame bytes (residual bits are read from them)
+    lc3_cpx fb[LC3_MAX_NF / 2];    // FFT work | t_hat_mdct[nf .. 2nf)  (contiguous with fa)
     float sm[192];
     int ism[64];
     unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
@@ -42,6 +41,8 @@ struct __attribute__((aligned(16))) lc3_dec_lds {
 #endif
 };
 LC3_LDS_DECL(lc3_dec_lds, lc3_dec_wg)
+static_assert(offsetof(lc3_dec_lds, spec) % 16 == 0 && offsetof(lc3_dec_lds, fa) % 16 == 0 && offsetof(lc3_dec_lds, ism) % 16 == 0,
+              "128-bit LDS accesses need aligned buffers");
 
 __device__ __forceinline__ void lc3_dec_state_init(lc3_dec_lds &L, int lane, lc3_dec_state *g, int valid) {
     if (valid)
@@ -62,39 +63,6 @@ __device__ __forceinline__ void lc3_dec_state_load(lc3_dec_lds &L, int lane, con
 __device__ __forceinline__ void lc3_dec_state_store(lc3_dec_lds &L, int lane, lc3_dec_state *g) {
     LC3_SYNC();
     lc3_wave_copy_out16(&g->core, &L.st, (int)(sizeof(lc3_dec_core) / 16), lane);
-}
-
-// D8 helper: mpvq_deenum (decoder/spectral_noise_shaping.rs:155-235)
-__device__ __forceinline__ void lc3_mpvq_deenum(int dim_in, int k_val_in, int ls_ind, uint32_t mpvq_ind, int *vec_out) {
-    int leading_sign = ls_ind == 0 ? 1 : -1, k_max_local = k_val_in;
-    uint32_t ind = mpvq_ind;
-    for (int pos = 0; pos < dim_in; pos++) vec_out[pos] = 0;
-    for (int pos = 0; pos < dim_in; pos++) {
-        const uint32_t *h_row = LC3T_MPVQ_OFFSETS[dim_in - 1 - pos];
-        int k_delta;
-        if (ind != 0) {
-            int k_acc = k_max_local;
-            uint32_t ul_diff = 0;
-            int wrap = ind < h_row[k_acc];
-            if (!wrap) ul_diff = ind - h_row[k_acc];
-            while (wrap) {
-                k_acc -= 1;
-                wrap = ind < h_row[k_acc];
-                if (!wrap) ul_diff = ind - h_row[k_acc];
-            }
-            ind = ul_diff;
-            k_delta = k_max_local - k_acc;
-        } else {
-            vec_out[pos] = leading_sign < 0 ? -k_max_local : k_max_local;
-            break;
-        }
-        if (k_delta != 0) {
-            vec_out[pos] = leading_sign < 0 ? -k_delta : k_delta;
-            leading_sign = (ind & 1u) ? -1 : 1;
-            ind >>= 1;
-            k_max_local -= k_delta;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -283,287 +251,31 @@ __device__ __noinline__ void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_l
 }
 
 // ------------------------------------------------------------------------------------------
-// D0: pick up one parsed frame (lc3_dev_dec_parse.h) from its HBM plane column: side information -> L.ism,
-// integer spectrum -> xi, frame bytes -> L.in (the residual bits are still read from them).  Then the order-free
-// integer epilogue of arithmetic_codec::decode, lane-parallel: residual-bit count and its bounds check, the
-// noise-filling seed  sum |x_k| * k  (:140-145, wrapping) and the zero-frame flag.
-// Returns 1 when the frame parsed, 0 -> conceal.
+// D0: pick up one frame as the lane-per-frame stage (lc3_dev_dec_parse.h) left it in its HBM plane column: side
+// information words -> L.ism, reconstructed spectrum (f32, D4-D8 applied) -> L.spec.  One 16-byte unit per lane and load,
+// both loads in flight together.  Returns 1 when the frame is usable, 0 -> conceal.
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_dec_load_frame(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const uint8_t *in, int nbytes,
-                                               const int32_t *plane, int stride) {
+__device__ __noinline__ int lc3_dec_load_frame(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const int32_t *plane) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
-    int *si = L.ism;
-    int32_t *xi = (int32_t *)L.fb;  // 400 ints
-    const int ne = c.ne;
-    LC3_HBM_CONST(uint8_t) gin = (LC3_HBM_CONST(uint8_t))in;
-    LC3_HBM_CONST(int32_t) gplane = (LC3_HBM_CONST(int32_t))plane;
-    (void)stride;  // frame-major planes: the column is contiguous
-    {
-        // frame bytes (<= 400: seven per lane) and the plane column (side information + integer spectrum, contiguous
-        // 16-byte units: two per lane), every load issued before the first LDS store
-        uint8_t bv[7];
+    LC3_HBM_CONST(lc3_i4) p4 = (LC3_HBM_CONST(lc3_i4))((LC3_HBM_CONST(int32_t))plane + LC3_PLANE_SI);
+    const int n_si4 = (LC3_PLANE_X - LC3_PLANE_SI) / 4, n4 = n_si4 + c.ne / 4;
+    lc3_i4 pv[2];
 #pragma unroll
-        for (int u = 0; u < 7; u++) {
-            const int i = lane + LC3_WAVE * u;
-            bv[u] = i < nbytes ? gin[i] : (uint8_t)0;
-        }
-        LC3_HBM_CONST(lc3_i4) p4 = (LC3_HBM_CONST(lc3_i4))(gplane + LC3_PLANE_SI);
-        const int n_si4 = (LC3_PLANE_X - LC3_PLANE_SI) / 4, n4 = n_si4 + ne / 4;
-        lc3_i4 pv[2];
+    for (int u = 0; u < 2; u++) {
+        const int i = lane + LC3_WAVE * u;
+        if (i < n4) pv[u] = p4[i];
+    }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int i = lane + LC3_WAVE * u;
-            if (i < n4) pv[u] = p4[i];
-        }
-#pragma unroll
-        for (int u = 0; u < 7; u++) {
-            const int i = lane + LC3_WAVE * u;
-            if (i < nbytes) L.in[i] = bv[u];
-        }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int i = lane + LC3_WAVE * u;
-            if (i < n_si4) ((lc3_i4 *)si)[i] = pv[u];
-            else if (i < n4) ((lc3_i4 *)xi)[i - n_si4] = pv[u];
-        }
+    for (int u = 0; u < 2; u++) {
+        const int i = lane + LC3_WAVE * u;
+        if (i < n_si4) ((lc3_i4 *)L.ism)[i] = pv[u];
+        else if (i < n4) ((lc3_i4 *)L.spec)[i - n_si4] = pv[u];
     }
     LC3_SYNC();
-    if (!si[AD_OK]) return 0;
-    uint32_t nnz = 0, seed = 0;
-    for (int k = lane; k < ne; k += LC3_WAVE) {
-        const int32_t v = xi[k];
-        nnz += v != 0;
-        seed += (uint32_t)(v < 0 ? -v : v) * (uint32_t)k;
-    }
-    nnz = lc3_wave_sum_u32(nnz, lane);
-    seed = lc3_wave_sum_u32(seed, lane);
-    const int lsb_mode = si[SI_LSB_MODE], tail0 = si[AD_TAIL0], nres_max = si[AD_NRES_MAX];
-    int n_res = 0, ok = 1;
-    if (!lsb_mode) {
-        // decode_residual_bits :168-183: one tail bit per non-zero line, at most nres_max.  Every read_tail_bool
-        // bound check is monotone in the bit position, so checking the last position covers all of them.
-        n_res = (int)nnz < nres_max ? (int)nnz : nres_max;
-        if (n_res > 480) ok = 0;  // ResidualBoolDataOverflow (Vec<bool, 480>)
-        if (n_res > 0) {
-            const int last_byte = (tail0 + n_res - 1) / 8;
-            if (nbytes - si[AD_HEAD] - last_byte + 2 < 0) ok = 0;
-            if (nbytes - last_byte - 1 < 0) ok = 0;
-        }
-    }
-    LC3_SYNC();
-    if (lane == 0) {
-        si[AD_NRES] = n_res;
-        si[AD_SEED] = (int)(seed & 0xFFFFu);
-        si[AD_ZERO] = si[SI_LASTNZ] == 2 && xi[0] == 0 && xi[1] == 0 && si[SI_GG] == 0;
-        si[AD_OK] = ok;
-    }
+    const int ok = L.ism[AD_OK];
     LC3_SYNC();
     return ok;
-}
-
-// ------------------------------------------------------------------------------------------
-// D4-D8: residual refinement, noise filling, global gain, TNS synthesis, SNS (decoder/lc3_decoder.rs:93-131)
-// ------------------------------------------------------------------------------------------
-// Every wave of the workgroup calls this (it contains a serial phase); `ok` = the frame parsed (L.ism[AD_OK]), a
-// stream whose frame did not parse skips the work and conceals afterwards.
-__device__ __noinline__ void lc3_dec_spectrum(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int nbits, int ok) {
-    LC3_CFG_BIND;
-    LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
-    const int ne = c.ne;
-    int *si = L.ism;
-    const int32_t *xi = (const int32_t *)L.fb;
-    if (ok) {
-    for (int k = lane; k < ne; k += LC3_WAVE) L.spec[k] = (float)xi[k];
-    LC3_SYNC();
-    // residual_spectrum::decode (decoder/residual_spectrum.rs:13-39): the j-th non-zero line takes residual bit j
-    // (tail bit AD_TAIL0 + j, read_tail_bool: bit (pos % 8) of byte len - 1 - pos / 8), for j < AD_NRES.
-    // noise_filling::apply_noise_filling (decoder/noise_filling.rs:18-56): the j-th line whose +-width neighbourhood
-    // is all zero takes state j + 1 of the LCG s <- (13849 + 31821 s) & 0xFFFF.  Both ranks are prefix counts, and
-    // the LCG is affine mod 2^16, so each lane owns 7 consecutive lines and jumps straight to its first state.
-    {
-        const int k0 = 7 * lane;
-        const int n_res = si[SI_LSB_MODE] ? 0 : si[AD_NRES];
-        const int do_fill = !si[AD_ZERO];
-        const int bw_stop = c.n_ms_10 ? LC3C_BWSTOP10[si[SI_BW]] : LC3C_BWSTOP75[si[SI_BW]];
-        const int nf_start = c.n_ms_10 ? 24 : 18, nf_width = c.n_ms_10 ? 3 : 2;
-        const int lim = bw_stop < ne ? bw_stop : ne;
-        uint32_t nzmask = 0, fillmask = 0;
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const int k = k0 + j;
-            if (k < ne) {
-                if (xi[k] != 0) nzmask |= 1u << j;
-                if (do_fill && k >= nf_start && k < lim) {
-                    const int from = k - nf_width, to = (bw_stop - 1) < (k + nf_width) ? (bw_stop - 1) : (k + nf_width);
-                    int all0 = 1;
-                    for (int q = from; q <= to; q++)
-                        if (xi[q] != 0) all0 = 0;
-                    if (all0) fillmask |= 1u << j;
-                }
-            }
-        }
-        int rank_nz = (int)lc3_wave_exscan_u32((uint32_t)__builtin_popcount(nzmask), lane);
-        const int rank_fill = (int)lc3_wave_exscan_u32((uint32_t)__builtin_popcount(fillmask), lane);
-        // LCG state after rank_fill steps: compose the affine map with itself by binary exponentiation
-        uint32_t lcg = (uint32_t)si[AD_SEED];
-        {
-            uint32_t ra = 1, rcst = 0, ba = 31821u, bc = 13849u;
-            for (int n = rank_fill; n > 0; n >>= 1) {
-                if (n & 1) {
-                    rcst = (ba * rcst + bc) & 0xFFFFu;
-                    ra = (ba * ra) & 0xFFFFu;
-                }
-                bc = (ba * bc + bc) & 0xFFFFu;
-                ba = (ba * ba) & 0xFFFFu;
-            }
-            lcg = (ra * lcg + rcst) & 0xFFFFu;
-        }
-        const float level = (8.0f - (float)si[SI_NF]) / 16.0f;
-        const int tail0 = si[AD_TAIL0], nbytes = nbits / 8;
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const int k = k0 + j;
-            if (k < ne) {
-                if (nzmask & (1u << j)) {
-                    if (rank_nz < n_res) {
-                        const int pos = tail0 + rank_nz;
-                        const int bit = (L.in[nbytes - 1 - pos / 8] >> (pos % 8)) & 1;
-                        float v = L.spec[k];
-                        if (bit) v += v > 0.0f ? 0.3125f : 0.1875f;
-                        else v -= v > 0.0f ? 0.1875f : 0.3125f;
-                        L.spec[k] = v;
-                    }
-                    rank_nz++;
-                }
-                if (fillmask & (1u << j)) {
-                    lcg = (13849u + lcg * 31821u) & 0xFFFFu;
-                    L.spec[k] = lcg < 0x8000u ? level : -level;
-                }
-            }
-        }
-    }
-    LC3_SYNC();
-    LC3_STAMP(L, lane, 22);
-    // global_gain::apply_global_gain (decoder/global_gain.rs:15-25)
-    {
-        const int fs = c.fs_ind + 1, q = nbits / (10 * fs);
-        const int gg_off = -(q < 115 ? q : 115) - 105 - (5 * fs);
-        const float gg = lc3_pow10f(((float)si[SI_GG] + (float)gg_off) / 28.0f);
-        for (int k = lane; k < ne; k += LC3_WAVE) L.spec[k] *= gg;
-    }
-    }  // if (ok)
-    // Sixteen lanes.  Lane 0: the TNS synthesis lattice (decoder/temporal_noise_shaping.rs:24-137, recursive in n,
-    // state shared across both filters) and the pulse de-enumeration of the SNS shape; then the sixteen together: scale
-    // factors (decoder/spectral_noise_shaping.rs:21-151).  Kept on the stream's own wave: the lattice takes anything
-    // from nothing to ~100 k cycles depending on the frame's TNS orders (measured: gathering the workgroup's four
-    // streams on one wave made every stream wait for the slowest, profiles/r01_v6_notes.txt).
-    LC3_LOCAL_BEGIN(lane, LC3_WAVE)  // the whole wave enters (it syncs inside); lanes 16.. only keep step
-    int *y = (int *)(L.sm + 96);          // [16] pulses
-    float *scf = L.sm, *sfi = L.sm + 16;  // 16 + 64
-    if (sub == 0 && ok) {
-        const int bw = si[SI_BW];
-        const int nbands = bw < 3 ? 1 : 2;
-        const float step = (float)(3.14159265358979323846 / 17.0);  // (PI / 17.0) as f32 :41
-        float st[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        for (int f = 0; f < nbands && f < si[SI_NUM_TNS]; f++) {
-            const int order = si[AD_ORD0 + f];
-            if (order > 0) {
-                float rq[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int ri = si[AD_RCI + f * 8 + k];
-                    rq[k] = ri != 0 ? lc3_sinf_small(step * (float)(ri - 8)) : 0.0f;
-                }
-                const int lo = c.n_ms_10 ? LC3C_TNSDEC10[bw][2 * f] : LC3C_TNSDEC75[bw][2 * f];
-                const int hi = c.n_ms_10 ? LC3C_TNSDEC10[bw][2 * f + 1] : LC3C_TNSDEC75[bw][2 * f + 1];
-                for (int n = lo; n < hi; n++) {
-                    float t = L.spec[n];
-                    // t = x - rc[order-1]*st[order-1]; then k = order-2 .. 0
-#pragma unroll
-                    for (int k = 7; k >= 0; k--) {
-                        if (k == order - 1) t -= rq[k] * st[k];
-                        else if (k < order - 1) {
-                            t -= rq[k] * st[k];
-                            st[k + 1] = rq[k] * t + st[k];
-                        }
-                    }
-                    L.spec[n] = t;
-                    st[0] = t;
-                }
-            }
-        }
-        int *zv = y + 16;
-        const int shape_j = (si[SI_SUB_MSB] << 1) + si[SI_SUB_LSB];
-        for (int n = 0; n < 16; n++) { y[n] = 0; zv[n] = 0; }
-        if (shape_j == 0) {
-            lc3_mpvq_deenum(10, 10, si[SI_LS_A], (uint32_t)si[SI_IDX_A], y);
-            lc3_mpvq_deenum(6, 1, si[SI_LS_B], (uint32_t)si[SI_IDX_B], zv);
-            for (int n = 0; n < 6; n++) y[10 + n] = zv[n];
-        } else if (shape_j == 1) {
-            lc3_mpvq_deenum(10, 10, si[SI_LS_A], (uint32_t)si[SI_IDX_A], y);
-            for (int n = 10; n < 16; n++) y[n] = 0;
-        } else if (shape_j == 2) lc3_mpvq_deenum(16, 8, si[SI_LS_A], (uint32_t)si[SI_IDX_A], y);
-        else lc3_mpvq_deenum(16, 6, si[SI_LS_A], (uint32_t)si[SI_IDX_A], y);
-        float y_norm = 0.0f;
-        for (int n = 0; n < 16; n++) y_norm += (float)y[n] * (float)y[n];
-        y_norm = lc3_sqrtf(y_norm);
-        float gain;
-        const int gi = si[SI_G_IND];
-        if (shape_j == 0) gain = lc3_f(LC3T_SNS_VQ_REG_ADJ_GAINS_BITS, gi & 1);
-        else if (shape_j == 1) gain = lc3_f(LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS, gi & 3);
-        else if (shape_j == 2) gain = lc3_f(LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS, gi & 3);
-        else gain = lc3_f(LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS, gi & 7);
-        if (y_norm != 0.0f) gain /= y_norm;
-        L.sm[128] = gain;
-    }
-    LC3_SYNC();
-    if (ok && sub < 16) {
-        // scale factor sub = codebook entry + gain * (y . D[sub][:]), 16-term sum in order
-        const int n = sub;
-        const float gain = L.sm[128];
-        float factor = 0.0f;
-        for (int col = 0; col < 16; col++) factor += (float)y[col] * lc3_f(&LC3T_D_BITS[n][0], col);
-        const float st1 = n < 8 ? lc3_f(&LC3T_LFCB_BITS[si[SI_IND_LF]][0], n) : lc3_f(&LC3T_HFCB_BITS[si[SI_IND_HF]][0], n - 8);
-        scf[n] = st1 + gain * factor;
-    }
-    LC3_SYNC();
-    if (ok && sub < 16) {
-        // interpolation :75-98 -- four of the 64 values per lane
-        const int n = sub;
-        if (n == 0) {
-            sfi[0] = scf[0];
-            sfi[1] = scf[0];
-            sfi[62] = scf[15] + 1.0f / 8.0f * (scf[15] - scf[14]);
-            sfi[63] = scf[15] + 3.0f / 8.0f * (scf[15] - scf[14]);
-        }
-        if (n <= 14) {
-            const float fn = scf[n], d = scf[n + 1] - fn;
-            sfi[4 * n + 2] = fn + (1.0f / 8.0f * d);
-            sfi[4 * n + 3] = fn + (3.0f / 8.0f * d);
-            sfi[4 * n + 4] = fn + (5.0f / 8.0f * d);
-            sfi[4 * n + 5] = fn + (7.0f / 8.0f * d);
-        }
-    }
-    LC3_SYNC();
-    if (ok && sub == 0) {
-        const int n2 = 64 - c.nb;
-        if (n2 != 0) {  // :100-111 (decoder form)
-            for (int b = 0; b < n2; b++) sfi[b] = (sfi[2 * b] + sfi[2 * b + 1]) / 2.0f;
-            for (int b = n2; b < c.nb; b++) sfi[b] = sfi[b + n2];
-        }
-    }
-    LC3_LOCAL_END
-    if (ok) {
-    LC3_STAMP(L, lane, 24);
-    // band gains via fast_math::exp2_raw and spectral shaping -- one lane per band
-    if (lane < c.nb) {
-        const uint16_t *ifs = lc3_band_index(c);
-        const float g = lc3_exp2_raw(L.sm[16 + lane]);
-        for (int k = ifs[lane]; k < ifs[lane + 1]; k++) L.spec[k] *= g;
-    }
-    }  // if (ok)
-    LC3_SYNC();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -619,10 +331,9 @@ __device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds
     LC3_CFG_BIND;
     const int nf = c.nf, nbits = nbytes * 8;
     LC3_STAMP(L, lane, 16);
-    const int ok = lc3_dec_load_frame(LC3_CFG_PASS, LC3_LDS_PASS lane, in, nbytes, plane, stride);
+    const int ok = lc3_dec_load_frame(LC3_CFG_PASS, LC3_LDS_PASS lane, plane);
     LC3_STAMP(L, lane, 17);
     int ltpf_active = 0, pitch_index = 0;
-    lc3_dec_spectrum(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, ok);
     if (ok) {
         ltpf_active = L.ism[SI_LTPF_ACTIVE];
         pitch_index = L.ism[SI_PITCH_INDEX];

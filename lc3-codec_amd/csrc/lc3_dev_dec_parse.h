@@ -6,10 +6,13 @@
 // bound by the scalar-issue rate (measured: ~41 k SALU instructions per frame, profiles/r01_pmc_*.csv), so this
 // stage is run with the opposite mapping: every lane parses its own frame and a wave advances 64 frames per
 // instruction.  The context/cumulative-frequency tables and the frame bytes sit in LDS; the results go to HBM
-// "planes" laid out [block of 64 frames][word][lane] so that the 64 lanes of a wave store to consecutive
-// addresses.  The wave-per-stream synthesis kernel (lc3_dev_dec.h) picks the planes up.
+// "planes" (one column of LC3_PLANE_WORDS words per frame).  The same lane then rebuilds the frame's spectrum from
+// the integers (lc3_reconstruct_frame: residual refinement, noise filling, global gain, TNS synthesis, SNS -- all of
+// them recursions or prefix-dependent walks over the lines, D4-D8 of the reference) and leaves it as f32 in the plane;
+// the wave-per-stream synthesis kernel (lc3_dev_dec.h) picks it up for concealment, IMDCT and LTPF.
 //
-// Plane words of one frame (int32):  [0, 48) side info (enum below)   [48, 448) integer spectrum x[k]
+// Plane words of one frame (int32):  [0, 48) side info (enum below)   [48, 448) spectrum x[k]: integers while
+//                                    parsing, f32 bit patterns once reconstructed
 //                                    [448, 648) save_lev per tuple (lsb_mode only)
 #pragma once
 #include "lc3_dev_common.h"
@@ -35,6 +38,7 @@ struct lc3_parse_ctx {
     int32_t *plane;          // this frame's plane column: word w at plane[w * stride]
     int stride;
     int head, tail;          // BufferReader cursors (decoder/buffer_reader.rs:11-15)
+    uint32_t nnz, seed;      // running count of non-zero lines and sum |x_k| * k (noise-filling seed :140-145, wrapping)
 };
 
 __device__ __forceinline__ void lc3_px_set(lc3_parse_ctx &c, int word, int32_t v) { c.plane[word * c.stride] = v; }
@@ -228,7 +232,9 @@ __device__ __forceinline__ int lc3_p_res_bit(lc3_parse_ctx &c, int idx, int &nbi
             if (lc3_p_bool(c, bit)) return -1;
             nbits_res -= 1;
             lc3_px_set(c, LC3_PLANE_X + idx, bit ? -1 : 1);
+            c.nnz += 1;
         }
+        c.seed += (uint32_t)idx;  // |x| grew by one
     }
     cont = 1;
     return 0;
@@ -238,6 +244,8 @@ __device__ __forceinline__ int lc3_p_res_bit(lc3_parse_ctx &c, int idx, int &nbi
 // and the zero-frame flag, which the synthesis kernel derives lane-parallel from x.  Returns 0 when the frame parsed.
 __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_ind, int n_ms_10) {
     int lastnz = 0, lsb_mode = 0, num_tns = 0, ord[2];
+    c.nnz = 0;
+    c.seed = 0;
     int rc = lc3_parse_side_info(c, fs_ind, ne, lastnz, lsb_mode, num_tns, ord);
     if (rc) return rc;
     const int nbits = c.len * 8;
@@ -301,6 +309,8 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             }
             lc3_px_set(c, LC3_PLANE_X + 2 * tup, xk);
             lc3_px_set(c, LC3_PLANE_X + 2 * tup + 1, xk1);
+            c.nnz += (uint32_t)(xk != 0) + (uint32_t)(xk1 != 0);
+            c.seed += (uint32_t)(xk < 0 ? -xk : xk) * (uint32_t)(2 * tup) + (uint32_t)(xk1 < 0 ? -xk1 : xk1) * (uint32_t)(2 * tup + 1);
             lev = lev < 3 ? lev : 3;
             t = lev <= 1 ? 1 + (a + b) * (lev + 1) : 12 + lev;
             cctx = (cctx & 15) * 16 + t;
@@ -330,4 +340,233 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
         }
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// D4-D8 of a parsed frame on the same lane: what is left of arithmetic_codec::decode (residual-bit count and bounds,
+// noise seed, zero-frame flag; decoder/arithmetic_codec.rs:134-183), residual_spectrum::decode
+// (decoder/residual_spectrum.rs:13-39), noise_filling::apply_noise_filling (decoder/noise_filling.rs:18-56),
+// global_gain::apply_global_gain (decoder/global_gain.rs:15-25), temporal_noise_shaping::apply_temporal_noise_shaping
+// (decoder/temporal_noise_shaping.rs:24-137) and spectral_noise_shaping::decode
+// (decoder/spectral_noise_shaping.rs:21-151).  Every one of them walks the lines in order carrying state (bit rank, LCG,
+// lattice memory, band pointer), and every line is touched by them in this order, so ONE pass over k = 0..ne-1 applies
+// them all: int -> f32, residual or noise value, gain, lattice, band gain, store.  The f32 operations on a line are the
+// reference's, in the reference's order.
+// Returns 1 (and sets AD_OK) when the frame is usable, 0 -> the synthesis kernel conceals it.
+// ------------------------------------------------------------------------------------------------------------------
+struct lc3_recon_ctx {
+    float *scf;            // 16 scale factors of this lane, element n at scf[n * sstride] (LDS, dynamically indexed)
+    int sstride;
+    const uint32_t *mpvq;  // MPVQ_OFFSETS[16][11] (LDS copy)
+};
+
+// mpvq_deenum (decoder/spectral_noise_shaping.rs:155-235) writing the pulses into scf slots as floats is not possible
+// (they are needed as integers first), so the pulses live in a 16-entry register array filled by static unrolling.
+__device__ __forceinline__ void lc3_r_deenum(const lc3_recon_ctx &r, int dim_in, int k_val_in, int ls_ind, uint32_t mpvq_ind,
+                                             int (&vec)[16], int base) {
+    int leading_sign = ls_ind == 0 ? 1 : -1, k_max_local = k_val_in, done = 0;
+    uint32_t ind = mpvq_ind;
+#pragma unroll
+    for (int pos = 0; pos < 16; pos++) {
+        if (pos < dim_in && !done) {
+            const uint32_t *h_row = r.mpvq + (dim_in - 1 - pos) * 11;
+            if (ind != 0) {
+                int k_acc = k_max_local;
+                uint32_t ul_diff = 0;
+                int wrap = ind < h_row[k_acc];
+                if (!wrap) ul_diff = ind - h_row[k_acc];
+                while (wrap) {
+                    k_acc -= 1;
+                    wrap = ind < h_row[k_acc];
+                    if (!wrap) ul_diff = ind - h_row[k_acc];
+                }
+                ind = ul_diff;
+                const int k_delta = k_max_local - k_acc;
+                if (k_delta != 0) {
+                    vec[base + pos] = leading_sign < 0 ? -k_delta : k_delta;
+                    leading_sign = (ind & 1u) ? -1 : 1;
+                    ind >>= 1;
+                    k_max_local -= k_delta;
+                }
+            } else {
+                vec[base + pos] = leading_sign < 0 ? -k_max_local : k_max_local;
+                done = 1;
+            }
+        }
+    }
+}
+
+// interpolated scale factor of band slot b (0..63) before the nb < 64 folding (:75-98)
+__device__ __forceinline__ float lc3_r_sfi(const lc3_recon_ctx &r, int b) {
+    if (b < 2) return r.scf[0];
+    if (b >= 62) {
+        const float s15 = r.scf[15 * r.sstride], s14 = r.scf[14 * r.sstride];
+        return s15 + (b == 62 ? 1.0f / 8.0f : 3.0f / 8.0f) * (s15 - s14);
+    }
+    const int n = (b - 2) >> 2, q = (b - 2) & 3;
+    const float fn = r.scf[n * r.sstride], d = r.scf[(n + 1) * r.sstride] - fn;
+    const float w = q == 0 ? 1.0f / 8.0f : (q == 1 ? 3.0f / 8.0f : (q == 2 ? 5.0f / 8.0f : 7.0f / 8.0f));
+    return fn + (w * d);
+}
+// gain of band bi (0..nb-1): exp2_raw of the scale factor after the decoder's nb < 64 folding (:100-111)
+__device__ __forceinline__ float lc3_r_band_gain(const lc3_recon_ctx &r, int bi, int nb) {
+    const int n2 = 64 - nb;
+    float sf;
+    if (n2 == 0) sf = lc3_r_sfi(r, bi);
+    else if (bi < n2) sf = (lc3_r_sfi(r, 2 * bi) + lc3_r_sfi(r, 2 * bi + 1)) / 2.0f;
+    else sf = lc3_r_sfi(r, bi + n2);
+    return lc3_exp2_raw(sf);
+}
+
+__device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3_recon_ctx &r, const lc3_cfg &cfg) {
+    const int ne = cfg.ne, nbytes = c.len, nbits = nbytes * 8;
+    const int lsb_mode = lc3_px_get(c, SI_LSB_MODE), lastnz = lc3_px_get(c, SI_LASTNZ), gg_ind = lc3_px_get(c, SI_GG);
+    const int tail0 = lc3_px_get(c, AD_TAIL0), nres_max = lc3_px_get(c, AD_NRES_MAX), head = lc3_px_get(c, AD_HEAD);
+    const int bw = lc3_px_get(c, SI_BW);
+    // decode_residual_bits :168-183: one tail bit per non-zero line, at most nres_max.  Every read_tail_bool bound check
+    // is monotone in the bit position, so checking the last position covers all of them.
+    int n_res = 0;
+    if (!lsb_mode) {
+        n_res = (int)c.nnz < nres_max ? (int)c.nnz : nres_max;
+        if (n_res > 480) return 0;  // ResidualBoolDataOverflow (Vec<bool, 480>)
+        if (n_res > 0) {
+            const int last_byte = (tail0 + n_res - 1) / 8;
+            if (nbytes - head - last_byte + 2 < 0) return 0;
+            if (nbytes - last_byte - 1 < 0) return 0;
+        }
+    }
+    const int x0 = lc3_px_get(c, LC3_PLANE_X), x1 = lc3_px_get(c, LC3_PLANE_X + 1);
+    const int do_fill = !(lastnz == 2 && x0 == 0 && x1 == 0 && gg_ind == 0);  // zero frame :147-151
+    uint32_t lcg = c.seed & 0xFFFFu;
+    // spectral_noise_shaping::decode: scale factors scf[16] = codebook + gain * (y . D) (:21-73)
+    {
+        int y[16];
+#pragma unroll
+        for (int n = 0; n < 16; n++) y[n] = 0;
+        const int shape_j = (lc3_px_get(c, SI_SUB_MSB) << 1) + lc3_px_get(c, SI_SUB_LSB);
+        const int ls_a = lc3_px_get(c, SI_LS_A);
+        const uint32_t idx_a = (uint32_t)lc3_px_get(c, SI_IDX_A);
+        if (shape_j == 0) {
+            lc3_r_deenum(r, 10, 10, ls_a, idx_a, y, 0);
+            lc3_r_deenum(r, 6, 1, lc3_px_get(c, SI_LS_B), (uint32_t)lc3_px_get(c, SI_IDX_B), y, 10);
+        } else if (shape_j == 1) lc3_r_deenum(r, 10, 10, ls_a, idx_a, y, 0);
+        else if (shape_j == 2) lc3_r_deenum(r, 16, 8, ls_a, idx_a, y, 0);
+        else lc3_r_deenum(r, 16, 6, ls_a, idx_a, y, 0);
+        float y_norm = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 16; n++) y_norm += (float)y[n] * (float)y[n];
+        y_norm = lc3_sqrtf(y_norm);
+        float gain;
+        const int gi = lc3_px_get(c, SI_G_IND);
+        if (shape_j == 0) gain = lc3_f(LC3T_SNS_VQ_REG_ADJ_GAINS_BITS, gi & 1);
+        else if (shape_j == 1) gain = lc3_f(LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS, gi & 3);
+        else if (shape_j == 2) gain = lc3_f(LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS, gi & 3);
+        else gain = lc3_f(LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS, gi & 7);
+        if (y_norm != 0.0f) gain /= y_norm;
+        const int ind_lf = lc3_px_get(c, SI_IND_LF), ind_hf = lc3_px_get(c, SI_IND_HF);
+        for (int n = 0; n < 16; n++) {
+            float factor = 0.0f;
+#pragma unroll
+            for (int col = 0; col < 16; col++) factor += (float)y[col] * lc3_f(&LC3T_D_BITS[n][0], col);
+            const float st1 = n < 8 ? lc3_f(&LC3T_LFCB_BITS[ind_lf][0], n) : lc3_f(&LC3T_HFCB_BITS[ind_hf][0], n - 8);
+            r.scf[n * r.sstride] = st1 + gain * factor;
+        }
+    }
+    // global gain :15-25
+    float gg;
+    {
+        const int fs = cfg.fs_ind + 1, q = nbits / (10 * fs);
+        const int gg_off = -(q < 115 ? q : 115) - 105 - (5 * fs);
+        gg = lc3_pow10f(((float)gg_ind + (float)gg_off) / 28.0f);
+    }
+    // TNS :24-137: all-pole lattice, state shared across both filters
+    const int nbands = bw < 3 ? 1 : 2, num_tns = lc3_px_get(c, SI_NUM_TNS);
+    const int ord0 = (0 < nbands && 0 < num_tns) ? lc3_px_get(c, AD_ORD0) : 0;
+    const int ord1 = (1 < nbands && 1 < num_tns) ? lc3_px_get(c, AD_ORD0 + 1) : 0;
+    const int lo0 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][0] : LC3C_TNSDEC75[bw][0];
+    const int hi0 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][1] : LC3C_TNSDEC75[bw][1];
+    const int lo1 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][2] : LC3C_TNSDEC75[bw][2];
+    const int hi1 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][3] : LC3C_TNSDEC75[bw][3];
+    const float step = (float)(3.14159265358979323846 / 17.0);  // (PI / 17.0) as f32 :41
+    float st[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, rq[8];
+    int order = ord0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int ri = lc3_px_get(c, AD_RCI + k);
+        rq[k] = ri != 0 ? lc3_sinf_small(step * (float)(ri - 8)) : 0.0f;
+    }
+    // noise filling :18-56
+    const int bw_stop = cfg.n_ms_10 ? LC3C_BWSTOP10[bw] : LC3C_BWSTOP75[bw];
+    const int nf_start = cfg.n_ms_10 ? 24 : 18, nf_width = cfg.n_ms_10 ? 3 : 2;
+    const int lim = bw_stop < ne ? bw_stop : ne;
+    const float level = (8.0f - (float)lc3_px_get(c, SI_NF)) / 16.0f;
+    // window of non-zero flags: bit (j + 3) <-> line k + j, j = -3 .. 3, lines at or beyond bw_stop count as zero; the
+    // integers of lines k .. k + 3 ride along in xq[0..3]
+    uint32_t nzwin = 0;
+    int32_t xq[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        xq[j] = j < ne ? lc3_px_get(c, LC3_PLANE_X + j) : 0;
+        if (xq[j] != 0 && j < bw_stop) nzwin |= 1u << (j + 3);
+    }
+    const uint32_t winmask = nf_width == 3 ? 0x7Fu : 0x3Eu;  // lines k-3..k+3 or k-2..k+2
+    const uint16_t *ifs = lc3_band_index(cfg);
+    int bi = 0, rank_nz = 0;
+    float g_band = lc3_r_band_gain(r, 0, cfg.nb);
+    for (int k = 0; k < ne; k++) {
+        const int32_t xi = xq[0];
+        float v = (float)xi;
+        if (xi != 0) {
+            if (rank_nz < n_res) {  // residual_spectrum::decode: the j-th non-zero line takes tail bit tail0 + j
+                const int pos = tail0 + rank_nz;
+                const int bit = (c.bytes[nbytes - 1 - pos / 8] >> (pos % 8)) & 1;
+                if (bit) v += v > 0.0f ? 0.3125f : 0.1875f;
+                else v -= v > 0.0f ? 0.1875f : 0.3125f;
+            }
+            rank_nz++;
+        }
+        if (do_fill && k >= nf_start && k < lim && (nzwin & winmask) == 0) {
+            lcg = (13849u + lcg * 31821u) & 0xFFFFu;
+            v = lcg < 0x8000u ? level : -level;
+        }
+        v *= gg;
+        if (k == lo1 && nbands == 2) {  // second filter: its coefficients, the lattice memory carries over
+            order = ord1;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int ri = lc3_px_get(c, AD_RCI + 8 + q);
+                rq[q] = ri != 0 ? lc3_sinf_small(step * (float)(ri - 8)) : 0.0f;
+            }
+        }
+        if (order > 0 && ((k >= lo0 && k < hi0) || (nbands == 2 && k >= lo1 && k < hi1))) {
+            float t = v;
+            // t = x - rc[order-1]*st[order-1]; then k = order-2 .. 0
+#pragma unroll
+            for (int q = 7; q >= 0; q--) {
+                if (q == order - 1) t -= rq[q] * st[q];
+                else if (q < order - 1) {
+                    t -= rq[q] * st[q];
+                    st[q + 1] = rq[q] * t + st[q];
+                }
+            }
+            v = t;
+            st[0] = t;
+        }
+        while (k >= (int)ifs[bi + 1]) {  // band of line k (bands are contiguous and non-empty below ne)
+            bi++;
+            g_band = lc3_r_band_gain(r, bi, cfg.nb);
+        }
+        v *= g_band;
+        lc3_px_set(c, LC3_PLANE_X + k, (int32_t)lc3_bits(v));
+        // slide the window: drop line k - 3, bring in line k + 4
+        const int kn = k + 4;
+        const int32_t xn = kn < ne ? lc3_px_get(c, LC3_PLANE_X + kn) : 0;
+        nzwin >>= 1;
+        if (xn != 0 && kn < bw_stop) nzwin |= 1u << 6;
+        xq[0] = xq[1];
+        xq[1] = xq[2];
+        xq[2] = xq[3];
+        xq[3] = xn;
+    }
+    return 1;
 }

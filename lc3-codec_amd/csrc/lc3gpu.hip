@@ -243,15 +243,23 @@ __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *pl
 // (cum | freq) spectral model and the frames' bytes are staged in LDS with coalesced loads.  blockDim.x frames per
 // workgroup (256, or 128 for frames above 220 bytes so that the staging fits 64 KB of dynamic LDS):
 // 4096 + 64*17*4 + blockDim.x*nbytes bytes.
-__global__ __launch_bounds__(256) void lc3_parse_kernel(int ne, int fs_ind, int n_ms_10, const uint8_t *in,
-                                                        const uint8_t *bad, int32_t *planes, int nbytes, int n_frames) {
+// Dynamic LDS: 4096 (context lookup) + 64*17*4 (spectral model) + 16*11*4 (MPVQ offsets) + 16*4*blockDim.x (scale
+// factors, [n][lane]) + blockDim.x * nbytes (frame bytes).
+#define LC3_PARSE_LDS_FIXED (4096 + 64 * 17 * 4 + 16 * 11 * 4)
+__global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot cfg, const uint8_t *in, const uint8_t *bad,
+                                                        int32_t *planes, int nbytes, int n_frames) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const lc3_cfg &c0 = lc3_cfg_table[cfg.id];
+    const int ne = c0.ne, fs_ind = c0.fs_ind, n_ms_10 = c0.n_ms_10;
+    const int tid = threadIdx.x, fpb = blockDim.x;
     uint8_t *s_lookup = smem;
     uint32_t *s_cf = (uint32_t *)(smem + 4096);
-    uint8_t *s_bytes = smem + 4096 + 64 * 17 * 4;
-    const int tid = threadIdx.x, fpb = blockDim.x;
+    uint32_t *s_mpvq = (uint32_t *)(smem + 4096 + 64 * 17 * 4);
+    float *s_scf = (float *)(smem + LC3_PARSE_LDS_FIXED);
+    uint8_t *s_bytes = smem + LC3_PARSE_LDS_FIXED + 16 * 4 * fpb;
     const size_t f0 = (size_t)blockIdx.x * (size_t)fpb;
     {
+        for (int i = tid; i < 16 * 11; i += fpb) s_mpvq[i] = LC3T_MPVQ_OFFSETS[i / 11][i % 11];
         const uint32_t *lk32 = (const uint32_t *)LC3T_AC_SPEC_LOOKUP;
         uint32_t *d32 = (uint32_t *)s_lookup;
         for (int i = tid; i < 1024; i += fpb) d32[i] = lk32[i];
@@ -284,8 +292,16 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(int ne, int fs_ind, int 
         c.stride = LC3_PLANE_STRIDE;
         c.head = 0;
         c.tail = 0;
-        int rc = (bad && bad[f]) ? -100 : lc3_parse_frame(c, ne, fs_ind, n_ms_10);
-        lc3_px_set(c, AD_OK, rc == 0);
+        const int rc = (bad && bad[f]) ? -100 : lc3_parse_frame(c, ne, fs_ind, n_ms_10);
+        int ok = rc == 0;
+        if (ok) {
+            lc3_recon_ctx r;
+            r.scf = s_scf + tid;
+            r.sstride = fpb;
+            r.mpvq = s_mpvq;
+            ok = lc3_reconstruct_frame(c, r, c0);
+        }
+        lc3_px_set(c, AD_OK, ok);
     }
 }
 
@@ -754,11 +770,14 @@ static int decode_launch(lc3gpu_decoder *d, int first, int n, const uint8_t *d_i
     const size_t frames = (size_t)n * (size_t)n_frames;
     int rc = decoder_reserve_planes(d, frames);
     if (rc) return rc;
-    const unsigned fpb = nbytes <= 220 ? 256u : 128u;
-    const size_t lds = 4096 + 64 * 17 * 4 + (size_t)fpb * (size_t)nbytes;
+    // frames per workgroup: as many as fit the default 64 KB of dynamic LDS (tables + 64 B of scale factors and nbytes of
+    // frame data per frame)
+    unsigned fpb = 256u;
+    while (fpb > 64u && LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes) > 65536u) fpb >>= 1;
+    const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes);
     d->timer.mark(stream);
-    hipLaunchKernelGGL(lc3_parse_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, d->h.c.ne,
-                       d->h.c.fs_ind, d->h.c.n_ms_10, d_in, d_bad, d->d_planes, nbytes, (int)frames);
+    hipLaunchKernelGGL(lc3_parse_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, d->h.slot,
+                       d_in, d_bad, d->d_planes, nbytes, (int)frames);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream);
     hipLaunchKernelGGL(lc3_decode_kernel, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0, stream,

@@ -233,7 +233,16 @@ int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8
         c.head = 0;
         c.tail = 0;
         int rc = (bad && bad[f]) ? -100 : lc3_parse_frame(c, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10);
-        lc3_px_set(c, AD_OK, rc == 0);
+        int ok = rc == 0;
+        if (ok) {  // the same lane rebuilds the spectrum (lc3_parse_kernel)
+            float scf[16];
+            lc3_recon_ctx r;
+            r.scf = scf;
+            r.sstride = 1;
+            r.mpvq = &LC3T_MPVQ_OFFSETS[0][0];
+            ok = lc3_reconstruct_frame(c, r, j.cfg);
+        }
+        lc3_px_set(c, AD_OK, ok);
     }
     // stage 2: synthesis, one emulated wave per stream
     lc3_dec_lds *L = (lc3_dec_lds *)aligned_alloc(16, LC3_WG_WAVES * sizeof(lc3_dec_lds));
