@@ -6,14 +6,11 @@
 #include "lc3_dev_enc_pack.h"
 
 // ------------------------------------------------------------------------------------------
-// Persistent per-stream encoder state as it lives in HBM between launches.
-// Word-aligned blob, one per stream, loaded/stored by the owning wave with coalesced accesses.
+// Persistent per-stream encoder state as it lives in HBM between launches: the two LTPF sample rings
+// and the MDCT history stay in HBM for good (the stages that use them stage them through scratch LDS, once per frame);
+// the 16 scalar words ride along in the wave's LDS working set during a launch.
 // ------------------------------------------------------------------------------------------
-struct lc3_enc_state {
-    float x12[384];          // LTPF 12.8 kHz ring (encoder/long_term_post_filter.rs:114,227); 10 ms uses all 384
-    float x6[180];           // LTPF 6.4 kHz ring, 178 used (:116,228)
-    int16_t hist[304];       // MDCT time-buffer history t[0 .. nf-z) (encoder/modified_dct.rs:126-138); also
-                             // supplies the LTPF resampler's 240/P history samples (long_term_post_filter.rs:217-224)
+struct lc3_enc_scalars {
     // attack detector (encoder/attack_detector.rs:17-21)
     float att_energy_last, att_max_energy_last;
     int att_pos_last, att_ds_tm1, att_ds_tm2;
@@ -26,31 +23,44 @@ struct lc3_enc_state {
     int reset_offset_old;
     float nbits_offset_old;
     int nbits_est_old;
-    int pad;                 // keeps the blob (and the LDS arrays behind it) a multiple of 16 bytes
+    int pad;
 };
-static_assert(sizeof(lc3_enc_state) % 16 == 0, "encoder state blob must keep 16-byte alignment of the LDS arrays");
-#define LC3_ENC_STATE_WORDS ((int)(sizeof(lc3_enc_state) / 4))
+struct lc3_enc_state {
+    float x12[384];          // LTPF 12.8 kHz ring (encoder/long_term_post_filter.rs:114,227); 10 ms uses all 384
+    float x6[180];           // LTPF 6.4 kHz ring, 178 used (:116,228)
+    int16_t hist[304];       // MDCT time-buffer history t[0 .. nf-z) (encoder/modified_dct.rs:126-138) = the last nf - z
+                             // samples of the previous frame
+    lc3_enc_scalars sc;
+};
+static_assert(sizeof(lc3_enc_scalars) == 64 && sizeof(lc3_enc_state) % 16 == 0 && offsetof(lc3_enc_state, sc) % 16 == 0,
+              "encoder state blob: 16-byte units");
 
-// LDS working set of one encoder wave (~12 KB)
+// LDS working set of one encoder wave: 8 KB -> five workgroups of four streams per CU.  Buffers are reused as their
+// contents die: `t` holds the MDCT time buffer until the LTPF resampler has read it, then the 6.4 kHz ring (LTPF) and
+// finally the quantised spectrum and the residual bits; fa/fb are the FFT buffers and every later stage's scratch.
 struct __attribute__((aligned(16))) lc3_enc_lds {
-    lc3_enc_state st;        // resident copy of the stream state (x12/x6/hist are worked on in place)
+    lc3_enc_scalars st;      // scalar part of the stream state
     float spec[LC3_MAX_NF];  // MDCT output -> SNS -> TNS spectrum (mdct_out / spec_lines)
     lc3_cpx fa[LC3_MAX_NF / 2];  // FFT input; afterwards scratch (must directly follow spec: symbol list spans both)
     lc3_cpx fb[LC3_MAX_NF / 2];  // FFT work buffer; afterwards scratch
-    float eb[64];            // band energies
-    int16_t t[2 * LC3_MAX_NF];   // MDCT time buffer (ModDiscreteCosTrans::freq)
-    int16_t xq[LC3_MAX_NE];  // quantised spectrum
-    uint8_t res_bits[LC3_MAX_NE];
-    float sm[192];           // small scratch (per-stage)
+    int16_t t[2 * LC3_MAX_NF];   // MDCT time buffer (ModDiscreteCosTrans::freq); later x6 | xq + residual bits
+    float sm[32];            // small scratch (per-stage)
     int ism[64];
     unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
 #ifdef LC3_PROFILE
     unsigned long long prof_acc[32];  // diagnostic build: per-wave stage totals, flushed once per launch
 #endif
 };
+#define LC3_EB(L) ((float *)(L).fa + 512)                    // [64] band energies: MDCT stage -> bandwidth, SNS
+#define LC3_XQ(L) ((L).t)                                    // int16[ne] quantised spectrum (from the quantiser on)
+#define LC3_RESB(L) ((uint8_t *)(L).t + 2 * LC3_MAX_NE)      // uint8[ne] residual bits
 
 LC3_LDS_DECL(lc3_enc_lds, lc3_enc_wg)
-static_assert(offsetof(lc3_enc_lds, fa) % 16 == 0 && offsetof(lc3_enc_lds, spec) % 16 == 0, "128-bit LDS reads need aligned buffers");
+static_assert(offsetof(lc3_enc_lds, fa) % 16 == 0 && offsetof(lc3_enc_lds, spec) % 16 == 0 && offsetof(lc3_enc_lds, t) % 16 == 0,
+              "128-bit LDS reads need aligned buffers");
+#ifndef LC3_PROFILE
+static_assert(sizeof(lc3_enc_lds) <= 8192, "encoder working set must stay within 8 KB (20 waves per CU)");
+#endif
 
 struct lc3_sns_res { int ind_lf, ind_hf, shape_j, gind, ls_inda, ls_indb; uint32_t index_joint_j; };
 struct lc3_tns_res { int nbits_tns, lpc_weighting, num_tns_filters; int rc_order[2]; };  // rc_i / rc_q live in LDS
@@ -63,31 +73,62 @@ struct lc3_quant_res { int gg_ind, nbits_spec, nbits_lsb, nbits_trunc, lsb_mode,
 // broadcast an int / float computed by lane 0 through LDS slot `slot` of L.ism
 #define LC3_BCAST_I(L, slot, val) ((L).ism[slot])
 
-__device__ __forceinline__ void lc3_enc_state_init(lc3_enc_lds &L, int lane) {
+// order global-memory traffic of the wave's lanes among themselves (state rings written by some lanes, read by others)
+#ifndef LC3_HBM_FENCE
+#define LC3_HBM_FENCE() LC3_SYNC()
+#endif
+
+__device__ __forceinline__ void lc3_enc_state_init(lc3_enc_lds &L, int lane, lc3_enc_state *g, int valid) {
     // fresh channel (Lc3Encoder::new: zeroed working buffers; attack_detector.rs:31-43;
     // long_term_post_filter.rs:74-90 t_prev = K_MIN)
     int *w = (int *)&L.st;
-    for (int i = lane; i < LC3_ENC_STATE_WORDS; i += LC3_WAVE) w[i] = 0;
+    if (lane < 16) w[lane] = 0;
+    if (valid) {  // rings and history in HBM
+        int *gw = (int *)g;
+        for (int i = lane; i < (int)(offsetof(lc3_enc_state, sc) / 4); i += LC3_WAVE) gw[i] = 0;
+    }
     LC3_SYNC();
     if (lane == 0) {
         L.st.att_pos_last = -1;
         L.st.t_prev = 17;
     }
     LC3_SYNC();
+    LC3_HBM_FENCE();
 }
 __device__ __forceinline__ void lc3_enc_state_load(lc3_enc_lds &L, int lane, const lc3_enc_state *g) {
-    lc3_wave_copy_in16(&L.st, g, (int)(sizeof(lc3_enc_state) / 16), lane);
+    lc3_wave_copy_in16(&L.st, &g->sc, (int)(sizeof(lc3_enc_scalars) / 16), lane);
     LC3_SYNC();
 }
-__device__ __forceinline__ void lc3_enc_state_store(lc3_enc_lds &L, int lane, lc3_enc_state *g) {
+// scalars back to HBM; the MDCT history of the next launch = samples [z, nf) of the last frame of this one
+__device__ __forceinline__ void lc3_enc_state_store(const lc3_cfg &c, lc3_enc_lds &L, int lane, lc3_enc_state *g,
+                                                    const int16_t *last_frame) {
     LC3_SYNC();
-    lc3_wave_copy_out16(g, &L.st, (int)(sizeof(lc3_enc_state) / 16), lane);
+    lc3_wave_copy_out16(&g->sc, &L.st, (int)(sizeof(lc3_enc_scalars) / 16), lane);
+    if (last_frame) {
+        LC3_HBM_CONST(uint32_t) src = (LC3_HBM_CONST(uint32_t))(last_frame + c.z);
+        uint32_t *dst = (uint32_t *)g->hist;
+        const int nw = (c.nf - c.z) / 2;  // <= 150 words
+        uint32_t v[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int i = lane + LC3_WAVE * u;
+            v[u] = i < nw ? src[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int i = lane + LC3_WAVE * u;
+            if (i < nw) dst[i] = v[u];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // E1-E6: MDCT analysis (encoder/modified_dct.rs:108-177)
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const int16_t *pcm) {
+// hist: the nf - z samples before this frame (previous frame's tail in the PCM input, or the state blob's copy for the
+// first frame of a launch), 4-byte aligned; nullptr = silence (fresh stream)
+__device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const int16_t *pcm,
+                                         const int16_t *hist) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int nf = c.nf, z = c.z, h = nf / 2, mid = 3 * h;
@@ -95,14 +136,27 @@ __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_ld
     const uint16_t *ifs = lc3_band_index(c);
     // update_time_buffer :126-138: t[0..nf-z) <- history, t[nf-z..2nf-z) <- new frame, tail stays 0.
     // The frame is fetched from HBM as 32-bit words (two samples per lane per load, coalesced).
-    for (int i = lane; i < nf - z; i += LC3_WAVE) L.t[i] = L.st.hist[i];
     {
         LC3_HBM_CONST(uint32_t) p32 = (LC3_HBM_CONST(uint32_t))pcm;
-        uint32_t v[4];  // nf / 2 <= 240 words: four per lane, all in flight together
+        LC3_HBM_CONST(uint32_t) h32 = (LC3_HBM_CONST(uint32_t))hist;
+        uint32_t v[4], hv[3];  // nf / 2 <= 240 and (nf - z) / 2 <= 150 words, all in flight together
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = lane + LC3_WAVE * u;
             v[u] = i < nf / 2 ? p32[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int i = lane + LC3_WAVE * u;
+            hv[u] = (hist && i < (nf - z) / 2) ? h32[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int i = lane + LC3_WAVE * u;
+            if (i < (nf - z) / 2) {
+                L.t[2 * i] = (int16_t)(hv[u] & 0xffffu);
+                L.t[2 * i + 1] = (int16_t)(hv[u] >> 16);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -126,15 +180,13 @@ __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_ld
         const float gain = 1.0f / lc3_sqrtf(2.0f * (float)nf);
         for (int k = lane; k < nf; k += LC3_WAVE) L.spec[k] *= gain;
     }
-    // next frame's history = t[nf .. 2nf-z)
-    for (int i = lane; i < nf - z; i += LC3_WAVE) L.st.hist[i] = L.t[nf + i];
     LC3_SYNC();
     // apply_energy_estimation :140-152 -- one lane per band, terms accumulated in order
     for (int b = lane; b < c.nb; b += LC3_WAVE) {
         int from = ifs[b], to = ifs[b + 1];
         float width = (float)(to - from), acc = 0.0f;
         for (int k = from; k < to; k++) acc += L.spec[k] * L.spec[k] / width;
-        L.eb[b] = acc;
+        LC3_EB(L)[b] = acc;
     }
     LC3_SYNC();
     // is_near_nyquist :154-177
@@ -144,8 +196,8 @@ __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_ld
             int nn_idx = c.n_ms_10 ? c.nb - 2 : c.nb - 4;
             float lower = 0.0f, upper = 0.0f;
             for (int b = 0; b < c.nb; b++) {
-                if (b < nn_idx) lower += L.eb[b];
-                else upper += L.eb[b];
+                if (b < nn_idx) lower += LC3_EB(L)[b];
+                else upper += LC3_EB(L)[b];
             }
             L.ism[0] = upper > 30.0f * lower;
         }
@@ -171,7 +223,7 @@ __device__ __noinline__ int lc3_enc_bandwidth(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_e
             int start = c.n_ms_10 ? LC3C_BW_START10[fsi - 1][k] : LC3C_BW_START75[fsi - 1][k];
             int stop = c.n_ms_10 ? LC3C_BW_STOP10[fsi - 1][k] : LC3C_BW_STOP75[fsi - 1][k];
             float width = (float)(stop + 1 - start), quiet = 0.0f;
-            for (int n = start; n <= stop; n++) quiet += L.eb[n] / width;
+            for (int n = start; n <= stop; n++) quiet += LC3_EB(L)[n] / width;
             if (quiet >= (float)LC3C_BW_TQ[k]) {
                 bw = k + 1;
                 break;
@@ -183,7 +235,7 @@ __device__ __noinline__ int lc3_enc_bandwidth(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_e
             int l_bw = c.n_ms_10 ? LC3C_BW_L10[bw] : LC3C_BW_L75[bw];
             int start_bw = c.n_ms_10 ? LC3C_BW_START10[fsi - 1][bw] : LC3C_BW_START75[fsi - 1][bw];
             for (int n = start_bw + 1 - l_bw; n < start_bw; n++) {
-                float cutoff = L.eb[n - l_bw] / L.eb[n];  // raw ratio, no dB
+                float cutoff = LC3_EB(L)[n - l_bw] / LC3_EB(L)[n];  // raw ratio, no dB
                 cutoff_max = lc3_maxf(cutoff, cutoff_max);
             }
             result = cutoff_max > (float)LC3C_BW_TC[bw] ? bw : fsi;
@@ -220,7 +272,7 @@ __device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_
     const int block_len = c.nf / num_ds;
     const int16_t *x_s = L.t + (c.nf - c.z);  // the current frame inside the time buffer
     int *ds = (int *)L.fa;                    // 160 ints
-    float *hp = (float *)L.fb;                // 160 floats
+    float *hp = (float *)L.fa + 160;          // 160 floats (the band energies sit at fa + 512: LC3_EB)
     float *en = L.sm;                         // 4 block energies
     for (int n = lane; n < num_ds; n += LC3_WAVE) {
         int acc = 0;
@@ -332,13 +384,13 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3
     if (diff > 0) {
         if (lane == 0) {
             for (int b = 0; b < diff; b++) {
-                sP[2 * b] = L.eb[b];
-                sP[2 * b + 1] = L.eb[b];
+                sP[2 * b] = LC3_EB(L)[b];
+                sP[2 * b + 1] = LC3_EB(L)[b];
             }
-            for (int b = 0; b < c.nb && 2 * diff + b < 64; b++) sP[2 * diff + b] = L.eb[diff + b];
+            for (int b = 0; b < c.nb && 2 * diff + b < 64; b++) sP[2 * diff + b] = LC3_EB(L)[diff + b];
         }
     } else {
-        sP[lane] = L.eb[lane];
+        sP[lane] = LC3_EB(L)[lane];
     }
     LC3_SYNC();
     // smoothing :92-98, pre-emphasis :214-219 -- one lane per band
@@ -878,15 +930,18 @@ __device__ __forceinline__ float lc3_ltpf_dot(const float *x12, int n, int d) { 
     return acc;
 }
 
+// g: the stream's state blob in HBM, owner of the two sample rings (x12 at 12.8 kHz, x6 at 6.4 kHz); `store` = 0 for
+// the shadow waves of a partial workgroup.  Staging: x12 lives in fa for the duration of the stage, the resampler's
+// polyphase table and later the correlation scratch in fb, x6 in `t` once the resampler has consumed the time buffer.
 __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int near_nyquist,
-                                                    int nbits) {
+                                                    int nbits, lc3_enc_state *g, int store) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int len12 = c.len12, len6 = c.len6, p = c.p_up;
     const int x12_len = len12 + c.delay12 + LC3_NMEM;
-    float *x12 = L.st.x12, *x6 = L.st.x6;
-    float *S = (float *)L.fa;
-    float *r6 = S, *rw6 = S + 128, *r12 = S + 256, *dA = S + 512, *dB = S + 640;  // dA/dB: 128 each
+    float *x12 = (float *)L.fa, *x6 = (float *)L.t;
+    float *S = (float *)L.fb;
+    float *r6 = S, *rw6 = S + 100, *r12 = S + 200, *dA = S + 224, *dB = S + 352;  // 98 | 98 | 17 | 128 | 128 floats
     int t_nbits = nbits;
     if (!c.n_ms_10) {
         double v = (double)nbits * 10.0 / 7.5;  // .round(): half away from zero (:143)
@@ -895,30 +950,24 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(l
     const int gain_ltpf_on = t_nbits < 560 + c.fs_ind * 80;
     lc3_ltpf_res res;
 
-    // shift_out_old_samples :217-229.  Each lane first reads its elements, then all write (in-place shift).
+    // shift_out_old_samples :217-229 happens while the ring is fetched: element i of the staged ring = element i + len12
+    // of the stored one.  The polyphase table rides along.
+    const int keep12 = x12_len - len12, keep6 = 178 - len6;  // <= 276, <= 130
+    LC3_HBM_FENCE();
     {
-        const int keep12 = x12_len - len12, keep6 = 178 - len6;  // <= 276, <= 130
-        float v[5], w[3];
+        LC3_HBM_CONST(float) g12 = (LC3_HBM_CONST(float))g->x12;
+        float v[5];
 #pragma unroll
         for (int j = 0; j < 5; j++) {
             const int i = lane + LC3_WAVE * j;
-            v[j] = i < keep12 ? x12[i + len12] : 0.0f;
+            v[j] = i < keep12 ? g12[i + len12] : 0.0f;
         }
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int i = lane + LC3_WAVE * j;
-            w[j] = i < keep6 ? x6[i + len6] : 0.0f;
-        }
-        LC3_SYNC();
+        const int p_rows = p * c.resamp_stride;
+        for (int i = lane; i < p_rows; i += LC3_WAVE) S[i] = c.resamp_poly[i];
 #pragma unroll
         for (int j = 0; j < 5; j++) {
             const int i = lane + LC3_WAVE * j;
             if (i < keep12) x12[i] = v[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int i = lane + LC3_WAVE * j;
-            if (i < keep6) x6[i] = w[j];
         }
         LC3_SYNC();
     }
@@ -927,9 +976,7 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(l
     // row of taps per phase) is staged in LDS, so a lane streams its row with 128-bit reads next to the samples.
     // x_s_extended[i] == time buffer t[(nf - z) - hist + i]
     {
-        const int p_rows = p * c.resamp_stride, nt = c.resamp_nt, lim = c.resamp_lim;
-        for (int i = lane; i < p_rows; i += LC3_WAVE) S[i] = c.resamp_poly[i];
-        LC3_SYNC();
+        const int nt = c.resamp_nt, lim = c.resamp_lim;
         const int16_t *xs = L.t + (c.nf - c.z) - c.hist;
         float *o12 = x12 + c.delay12 + LC3_NMEM;
         const int n0 = lane, has1 = lane + LC3_WAVE < len12;
@@ -952,6 +999,13 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(l
         LC3_SYNC();
         if (n0 < len12) o12[n0] = acc0 * c.resamp_scale;
         if (has1) o12[n1] = acc1 * c.resamp_scale;
+        // the time buffer is consumed: stage the 6.4 kHz ring in its place (shifted by len6 on the way in)
+        LC3_HBM_CONST(float) g6 = (LC3_HBM_CONST(float))g->x6;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = lane + LC3_WAVE * j;
+            if (i < keep6) x6[i] = g6[i + len6];
+        }
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 12);
@@ -1188,6 +1242,20 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(l
     res.pitch_present = L.ism[3];
     res.ltpf_active = L.ism[7];
     res.nbits_ltpf = res.pitch_present ? 11 : 1;
+    // the rings go back to the state blob
+    if (store) {
+        float *g12 = g->x12, *g6 = g->x6;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const int i = lane + LC3_WAVE * j;
+            if (i < x12_len) g12[i] = x12[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = lane + LC3_WAVE * j;
+            if (i < 178) g6[i] = x6[i];
+        }
+    }
     LC3_SYNC();
     return res;
 }
@@ -1207,7 +1275,7 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, LC3_LDS
     const float gg = lc3_pow10f(((float)gg_ind + (float)gg_off) / 28.0f);
     for (int n = lane; n < ne; n += LC3_WAVE) {
         float x = L.spec[n];
-        L.xq[n] = (int16_t)(x >= 0.0f ? lc3_f2i16(x / gg + 0.375f) : lc3_f2i16(x / gg - 0.375f));
+        LC3_XQ(L)[n] = (int16_t)(x >= 0.0f ? lc3_f2i16(x / gg + 0.375f) : lc3_f2i16(x / gg - 0.375f));
     }
     LC3_SYNC();
     const int rate_flag = nbits > (160 + c.fs_ind * 160) ? 512 : 0;
@@ -1228,7 +1296,7 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, LC3_LDS
             const int k = k0 + j;
             loc[j] = 0;
             if (k < ntup_all) {
-                const int q0 = L.xq[2 * k], q1 = L.xq[2 * k + 1];
+                const int q0 = LC3_XQ(L)[2 * k], q1 = LC3_XQ(L)[2 * k + 1];
                 const unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
                 const unsigned m = a > b ? a : b;
                 const int n_esc = m >= 4 ? (32 - __builtin_clz(m)) - 2 : 0;
@@ -1312,7 +1380,7 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, LC3_LDS
     bc.nbits_trunc = L.ism[3];
     bc.nbits_lsb = L.ism[4];
     LC3_SYNC();
-    for (int n = bc.lastnz_trunc + lane; n < bc.lastnz; n += LC3_WAVE) L.xq[n] = 0;  // truncation :249-252
+    for (int n = bc.lastnz_trunc + lane; n < bc.lastnz; n += LC3_WAVE) LC3_XQ(L)[n] = 0;  // truncation :249-252
     LC3_SYNC();
     bc.lsb_mode = bc.mode_flag && bc.nbits_est > nbits_spec;
     bc.gg = gg;
@@ -1514,12 +1582,12 @@ __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM
     for (int j = 0; j < 7; j++) {
         const int k = k0 + j;
         if (k < ne) {
-            if (L.xq[k] != 0) nzmask |= 1u << j;
+            if (LC3_XQ(L)[k] != 0) nzmask |= 1u << j;
             if (k >= nf_start && k < nf_stop) {  // encoder/noise_level_estimation.rs:35-42
                 const int from = k - nf_width, to = bw_stop < k + nf_width + 1 ? bw_stop : k + nf_width + 1;
                 int r = 1;
                 for (int i = from; i < to; i++)
-                    if (L.xq[i] != 0) r = 0;
+                    if (LC3_XQ(L)[i] != 0) r = 0;
                 if (r) relmask |= 1u << j;
             }
         }
@@ -1532,7 +1600,7 @@ __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM
         const int k = k0 + j;
         if (k < ne) {
             if (nzmask & (1u << j)) {
-                if (rank_nz < mx) L.res_bits[rank_nz] = (uint8_t)(L.spec[k] >= (float)L.xq[k] * q.gg);  // :50-55
+                if (rank_nz < mx) LC3_RESB(L)[rank_nz] = (uint8_t)(L.spec[k] >= (float)LC3_XQ(L)[k] * q.gg);  // :50-55
                 rank_nz++;
             }
             if (relmask & (1u << j)) compact[rank_rel++] = lc3_absf(L.spec[k]) / q.gg;
@@ -1560,12 +1628,14 @@ __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM
 // pcm: nf samples in HBM (4-byte aligned); plane/plane_stride: this frame's column of the packer planes
 // (lc3_dev_enc_pack.h); nbytes selects the bitrate.  dbg (optional): float[3*480] stage dumps.
 // ------------------------------------------------------------------------------------------
+// hist: see lc3_enc_mdct; g: the stream's state blob (LTPF rings); plane == nullptr marks a shadow wave that stores nothing
 __device__ __forceinline__ void lc3_encode_frame_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const int16_t *pcm,
-                                                      int32_t *plane, int plane_stride, int nbytes, float *dbg) {
+                                                      const int16_t *hist, lc3_enc_state *g, int32_t *plane,
+                                                      int plane_stride, int nbytes, float *dbg) {
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
-    const int near_nyquist = lc3_enc_mdct(LC3_CFG_PASS, LC3_LDS_PASS lane, pcm);
+    const int near_nyquist = lc3_enc_mdct(LC3_CFG_PASS, LC3_LDS_PASS lane, pcm, hist);
     LC3_STAMP(L, lane, 1);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[i] = L.spec[i];
     int nbits_bw;
@@ -1578,7 +1648,7 @@ __device__ __forceinline__ void lc3_encode_frame_wave(LC3_CFG_PARAM, lc3_enc_lds
     const lc3_tns_res tns = lc3_enc_tns(LC3_CFG_PASS, LC3_LDS_PASS lane, bw_ind, nbits, near_nyquist);
     LC3_STAMP(L, lane, 4);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[960 + i] = L.spec[i];
-    const lc3_ltpf_res pf = lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits);
+    const lc3_ltpf_res pf = lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, plane != nullptr);
     LC3_STAMP(L, lane, 5);
     const lc3_quant_res spec = lc3_enc_quant(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, nbits_bw, tns.nbits_tns, pf.nbits_ltpf);
     LC3_STAMP(L, lane, 6);
@@ -1626,12 +1696,12 @@ __device__ __forceinline__ void lc3_encode_frame_wave(LC3_CFG_PARAM, lc3_enc_lds
             uint32_t m = 0;
             for (int j = 0; j < 32; j++) {
                 const int i = 32 * lane + j;
-                if (i < n_res && L.res_bits[i]) m |= 1u << j;
+                if (i < n_res && LC3_RESB(L)[i]) m |= 1u << j;
             }
             plane[(EP_RES + lane) * st] = (int32_t)m;
         }
         for (int k = lane; k < c.ne / 2; k += LC3_WAVE)
-            plane[(EP_XQ + k) * st] = (int32_t)(((uint32_t)(uint16_t)L.xq[2 * k]) | ((uint32_t)(uint16_t)L.xq[2 * k + 1] << 16));
+            plane[(EP_XQ + k) * st] = (int32_t)(((uint32_t)(uint16_t)LC3_XQ(L)[2 * k]) | ((uint32_t)(uint16_t)LC3_XQ(L)[2 * k + 1] << 16));
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 8);

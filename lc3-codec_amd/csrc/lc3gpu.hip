@@ -32,6 +32,14 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 #define LC3_WAVE_ID() ((int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))
+// lanes of a wave exchanging data through HBM (state rings): wait for the wave's outstanding stores/loads; the CU's
+// vector L1 serves all lanes of the wave, so no cache maintenance is needed
+#define LC3_HBM_FENCE()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+    } while (0)
 #define LC3_LDS_DECL(T, arr) __shared__ T arr[LC3_WG_WAVES];
 #define LC3_LDS_PARAM(T)
 #define LC3_LDS_PASS
@@ -165,7 +173,7 @@ __device__ unsigned long long lc3_prof_acc[40];  // 0..31 stage sums; 32/33/34 e
 // kernels
 // ---------------------------------------------------------------------------------------------
 // Analysis kernel: one wave per stream, MDCT ... quantisation, leaves one packer plane column per frame.
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 3) void lc3_encode_kernel(lc3_cfg_slot cfg, lc3_enc_state *states,
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 5) void lc3_encode_kernel(lc3_cfg_slot cfg, lc3_enc_state *states,
                                                                           int first_channel, int n_streams,
                                                                           const int16_t *pcm, int32_t *planes, int nbytes,
                                                                           int n_frames, int fresh, float *dbg) {
@@ -179,14 +187,20 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 3) void lc3_encode_kernel(lc3_cf
     const int nf = lc3_cfg_table[cfg.id].nf;
     lc3_enc_state *gst = states + (size_t)(first_channel + s);
     LC3_PROF_BEGIN(L, lane);
-    if (fresh) lc3_enc_state_init(L, lane);
+    if (fresh) lc3_enc_state_init(L, lane, gst, valid);
     else lc3_enc_state_load(L, lane, gst);
+    const int z = lc3_cfg_table[cfg.id].z;
     for (int t = 0; t < n_frames; t++) {
         const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
         int32_t *plane = valid ? LC3_PLANE_COL(planes, f, EP_WORDS) : nullptr;
-        lc3_encode_frame_wave(cfg, L, lane, pcm + f * (size_t)nf, plane, LC3_PLANE_STRIDE, nbytes, valid ? dbg : nullptr);
+        const int16_t *frame = pcm + f * (size_t)nf;
+        // MDCT history: the tail of the previous frame of this launch, else the state blob's copy (silence when fresh)
+        const int16_t *hist = t > 0 ? frame - nf + z : (fresh ? nullptr : gst->hist);
+        lc3_encode_frame_wave(cfg, L, lane, frame, hist, gst, plane, LC3_PLANE_STRIDE, nbytes, valid ? dbg : nullptr);
     }
-    if (valid) lc3_enc_state_store(L, lane, gst);
+    if (valid)
+        lc3_enc_state_store(lc3_cfg_table[cfg.id], L, lane, gst,
+                            n_frames > 0 ? pcm + ((size_t)s * (size_t)n_frames + (size_t)(n_frames - 1)) * (size_t)nf : nullptr);
     LC3_PROF_END(L, lane, 32);
 }
 

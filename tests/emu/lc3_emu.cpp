@@ -97,15 +97,18 @@ void *lane_main(void *arg) {
     tl_wave = j->wave;
     if (j->encode) {
         lc3_enc_lds &L = j->EL[j->wave];
-        if (j->fresh) lc3_enc_state_init(L, lane);
+        if (j->fresh) lc3_enc_state_init(L, lane, j->est, j->valid);
         else lc3_enc_state_load(L, lane, j->est);
         for (int t = 0; t < j->n_frames; t++) {
             const size_t f = j->frame0 + (size_t)t;
             int32_t *plane = j->valid ? LC3_PLANE_COL(j->enc_planes, f, EP_WORDS) : nullptr;
-            lc3_encode_frame_wave(j->cfg, L, lane, j->pcm_in + (size_t)t * j->cfg.nf, plane, LC3_PLANE_STRIDE, j->nbytes,
+            const int16_t *frame = j->pcm_in + (size_t)t * j->cfg.nf;
+            const int16_t *hist = t > 0 ? frame - j->cfg.nf + j->cfg.z : (j->fresh ? nullptr : j->est->hist);
+            lc3_encode_frame_wave(j->cfg, L, lane, frame, hist, j->est, plane, LC3_PLANE_STRIDE, j->nbytes,
                                   j->valid ? j->dbg : nullptr);
         }
-        if (j->valid) lc3_enc_state_store(L, lane, j->est);
+        if (j->valid)
+            lc3_enc_state_store(j->cfg, L, lane, j->est, j->n_frames > 0 ? j->pcm_in + (size_t)(j->n_frames - 1) * j->cfg.nf : nullptr);
     } else {
         lc3_dec_lds &L = j->DL[j->wave];
         if (j->fresh) lc3_dec_state_init(L, lane, j->dst, j->valid);
