@@ -500,73 +500,79 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     const int nf_start = cfg.n_ms_10 ? 24 : 18, nf_width = cfg.n_ms_10 ? 3 : 2;
     const int lim = bw_stop < ne ? bw_stop : ne;
     const float level = (8.0f - (float)lc3_px_get(c, SI_NF)) / 16.0f;
-    // window of non-zero flags: bit (j + 3) <-> line k + j, j = -3 .. 3, lines at or beyond bw_stop count as zero; the
-    // integers of lines k .. k + 3 ride along in xq[0..3]
+    // window of non-zero flags: bit (j + 3) <-> line k + j, j = -3 .. 3, lines at or beyond bw_stop count as zero.
+    // The integers are fetched from the plane four lines at a time, two groups ahead of their use (xw holds lines
+    // k0 .. k0+11 of the current group of four), so that the loads of a group have a whole group's work to land.
     uint32_t nzwin = 0;
-    int32_t xq[4];
+    int32_t xw[12];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        xq[j] = j < ne ? lc3_px_get(c, LC3_PLANE_X + j) : 0;
-        if (xq[j] != 0 && j < bw_stop) nzwin |= 1u << (j + 3);
-    }
+    for (int j = 0; j < 12; j++) xw[j] = j < ne ? lc3_px_get(c, LC3_PLANE_X + j) : 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (xw[j] != 0 && j < bw_stop) nzwin |= 1u << (j + 3);
     const uint32_t winmask = nf_width == 3 ? 0x7Fu : 0x3Eu;  // lines k-3..k+3 or k-2..k+2
     const uint16_t *ifs = lc3_band_index(cfg);
     int bi = 0, rank_nz = 0;
     float g_band = lc3_r_band_gain(r, 0, cfg.nb);
-    for (int k = 0; k < ne; k++) {
-        const int32_t xi = xq[0];
-        float v = (float)xi;
-        if (xi != 0) {
-            if (rank_nz < n_res) {  // residual_spectrum::decode: the j-th non-zero line takes tail bit tail0 + j
-                const int pos = tail0 + rank_nz;
-                const int bit = (c.bytes[nbytes - 1 - pos / 8] >> (pos % 8)) & 1;
-                if (bit) v += v > 0.0f ? 0.3125f : 0.1875f;
-                else v -= v > 0.0f ? 0.1875f : 0.3125f;
-            }
-            rank_nz++;
-        }
-        if (do_fill && k >= nf_start && k < lim && (nzwin & winmask) == 0) {
-            lcg = (13849u + lcg * 31821u) & 0xFFFFu;
-            v = lcg < 0x8000u ? level : -level;
-        }
-        v *= gg;
-        if (k == lo1 && nbands == 2) {  // second filter: its coefficients, the lattice memory carries over
-            order = ord1;
+    for (int k0 = 0; k0 < ne; k0 += 4) {  // ne is a multiple of 4
+        int32_t xnext[4];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int ri = lc3_px_get(c, AD_RCI + 8 + q);
-                rq[q] = ri != 0 ? lc3_sinf_small(step * (float)(ri - 8)) : 0.0f;
-            }
-        }
-        if (order > 0 && ((k >= lo0 && k < hi0) || (nbands == 2 && k >= lo1 && k < hi1))) {
-            float t = v;
-            // t = x - rc[order-1]*st[order-1]; then k = order-2 .. 0
+        for (int j = 0; j < 4; j++) xnext[j] = k0 + 12 + j < ne ? lc3_px_get(c, LC3_PLANE_X + k0 + 12 + j) : 0;
 #pragma unroll
-            for (int q = 7; q >= 0; q--) {
-                if (q == order - 1) t -= rq[q] * st[q];
-                else if (q < order - 1) {
-                    t -= rq[q] * st[q];
-                    st[q + 1] = rq[q] * t + st[q];
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
+            const int32_t xi = xw[j];
+            float v = (float)xi;
+            if (xi != 0) {
+                if (rank_nz < n_res) {  // residual_spectrum::decode: the j-th non-zero line takes tail bit tail0 + j
+                    const int pos = tail0 + rank_nz;
+                    const int bit = (c.bytes[nbytes - 1 - pos / 8] >> (pos % 8)) & 1;
+                    if (bit) v += v > 0.0f ? 0.3125f : 0.1875f;
+                    else v -= v > 0.0f ? 0.1875f : 0.3125f;
+                }
+                rank_nz++;
+            }
+            if (do_fill && k >= nf_start && k < lim && (nzwin & winmask) == 0) {
+                lcg = (13849u + lcg * 31821u) & 0xFFFFu;
+                v = lcg < 0x8000u ? level : -level;
+            }
+            v *= gg;
+            if (k == lo1 && nbands == 2) {  // second filter: its coefficients, the lattice memory carries over
+                order = ord1;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int ri = lc3_px_get(c, AD_RCI + 8 + q);
+                    rq[q] = ri != 0 ? lc3_sinf_small(step * (float)(ri - 8)) : 0.0f;
                 }
             }
-            v = t;
-            st[0] = t;
+            if (order > 0 && ((k >= lo0 && k < hi0) || (nbands == 2 && k >= lo1 && k < hi1))) {
+                float t = v;
+                // t = x - rc[order-1]*st[order-1]; then k = order-2 .. 0
+#pragma unroll
+                for (int q = 7; q >= 0; q--) {
+                    if (q == order - 1) t -= rq[q] * st[q];
+                    else if (q < order - 1) {
+                        t -= rq[q] * st[q];
+                        st[q + 1] = rq[q] * t + st[q];
+                    }
+                }
+                v = t;
+                st[0] = t;
+            }
+            while (k >= (int)ifs[bi + 1]) {  // band of line k (bands are contiguous and non-empty below ne)
+                bi++;
+                g_band = lc3_r_band_gain(r, bi, cfg.nb);
+            }
+            v *= g_band;
+            lc3_px_set(c, LC3_PLANE_X + k, (int32_t)lc3_bits(v));
+            // slide the window: drop line k - 3, bring in line k + 4
+            nzwin >>= 1;
+            if (xw[j + 4] != 0 && k + 4 < bw_stop) nzwin |= 1u << 6;
         }
-        while (k >= (int)ifs[bi + 1]) {  // band of line k (bands are contiguous and non-empty below ne)
-            bi++;
-            g_band = lc3_r_band_gain(r, bi, cfg.nb);
-        }
-        v *= g_band;
-        lc3_px_set(c, LC3_PLANE_X + k, (int32_t)lc3_bits(v));
-        // slide the window: drop line k - 3, bring in line k + 4
-        const int kn = k + 4;
-        const int32_t xn = kn < ne ? lc3_px_get(c, LC3_PLANE_X + kn) : 0;
-        nzwin >>= 1;
-        if (xn != 0 && kn < bw_stop) nzwin |= 1u << 6;
-        xq[0] = xq[1];
-        xq[1] = xq[2];
-        xq[2] = xq[3];
-        xq[3] = xn;
+#pragma unroll
+        for (int j = 0; j < 8; j++) xw[j] = xw[j + 4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) xw[8 + j] = xnext[j];
     }
     return 1;
 }
