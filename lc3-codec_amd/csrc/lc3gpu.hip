@@ -173,7 +173,7 @@ __device__ unsigned long long lc3_prof_acc[40];  // 0..31 stage sums; 32/33/34 e
 // kernels
 // ---------------------------------------------------------------------------------------------
 // Analysis kernel: one wave per stream, MDCT ... quantisation, leaves one packer plane column per frame.
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 5) void lc3_encode_kernel(lc3_cfg_slot cfg, lc3_enc_state *states,
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_encode_kernel(lc3_cfg_slot cfg, lc3_enc_state *states,
                                                                           int first_channel, int n_streams,
                                                                           const int16_t *pcm, int32_t *planes, int nbytes,
                                                                           int n_frames, int fresh, float *dbg) {
