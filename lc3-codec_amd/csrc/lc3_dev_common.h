@@ -558,6 +558,78 @@ __device__ __forceinline__ void lc3_wave_copy_out16(void *hbm_dst, const void *l
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Sequential f32 sums over LDS arrays.  The additions run in index order (the reference's order); the operands are
+// fetched eight at a time so that a sum costs one LDS latency per eight terms instead of one per term.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lc3_sum_seq(const float *a, int n, float acc) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = a[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += x[u];
+    }
+    for (; i < n; i++) acc += a[i];
+    return acc;
+}
+__device__ __forceinline__ float lc3_dot_seq(const float *a, const float *b, int n, float acc) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        float x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            x[u] = a[i + u];
+            y[u] = b[i + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += x[u] * y[u];
+    }
+    for (; i < n; i++) acc += a[i] * b[i];
+    return acc;
+}
+
+// first index of the maximum / minimum of a[0..n) under the reference's scan  `if (a[i] > best) { best = a[i]; idx = i; }`
+// (strict comparison, starting from `best`/`idx`), operands fetched eight at a time
+__device__ __forceinline__ void lc3_argmax_seq(const float *a, int n, float &best, int &idx) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = a[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (x[u] > best) { best = x[u]; idx = i + u; }
+    }
+    for (; i < n; i++)
+        if (a[i] > best) { best = a[i]; idx = i; }
+}
+__device__ __forceinline__ void lc3_argmin_seq(const float *a, int n, float &best, int &idx) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = a[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (x[u] < best) { best = x[u]; idx = i + u; }
+    }
+    for (; i < n; i++)
+        if (a[i] < best) { best = a[i]; idx = i; }
+}
+// a[from..to) *= g, four lines per round trip
+__device__ __forceinline__ void lc3_scale_run(float *a, int from, int to, float g) {
+    for (int k = from; k < to; k += 4) {
+        float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = k + u < to ? a[k + u] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (k + u < to) a[k + u] = x[u] * g;
+    }
+}
+
 // Element i of the polyphase resampler table (encoder/long_term_post_filter.rs:152-166): row ph = i / stride,
 // tap j = i % stride stands for k = j - lim of the reference loop, i.e. tab_resamp_filter[119 + p*k - ph] while
 // that index lies strictly inside (-120, 120) and k <= lim; zero elsewhere.  A zero tap adds x * 0 = +-0 to the

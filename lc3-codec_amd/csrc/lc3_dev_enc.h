@@ -185,7 +185,14 @@ __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_ld
     for (int b = lane; b < c.nb; b += LC3_WAVE) {
         int from = ifs[b], to = ifs[b + 1];
         float width = (float)(to - from), acc = 0.0f;
-        for (int k = from; k < to; k++) acc += L.spec[k] * L.spec[k] / width;
+        for (int k = from; k < to; k += 4) {  // four lines per LDS round trip
+            float x[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) x[u] = k + u < to ? L.spec[k + u] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (k + u < to) acc += x[u] * x[u] / width;
+        }
         LC3_EB(L)[b] = acc;
     }
     LC3_SYNC();
@@ -288,9 +295,7 @@ __device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_
     }
     LC3_SYNC();
     if (lane < num_blocks) {  // block energies, 40 terms each in order
-        float e = 0.0f;
-        for (int j = 40 * lane; j < 40 * lane + 40; j++) e += hp[j] * hp[j];
-        en[lane] = e;
+        en[lane] = lc3_dot_seq(hp + 40 * lane, hp + 40 * lane, 40, 0.0f);
     }
     LC3_SYNC();
     if (lane == 0) {
@@ -407,8 +412,7 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3
     LC3_SYNC();
     // noise floor :221-228 -- 64-term sequential sum on lane 0
     if (lane == 0) {
-        float total = 0.0f;
-        for (int b = 0; b < 64; b++) total += sE[b];
+        float total = lc3_sum_seq(sE, 64, 0.0f);
         total = (total / 64.0f) * lc3_powi(10.0f, -4);
         L.sm[0] = lc3_maxf(lc3_powi(2.0f, -32), total);
     }
@@ -476,10 +480,8 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3
     if (lane == 0) {
         float lf_min = __builtin_inff(), hf_min = __builtin_inff();
         int ind_lf = 0, ind_hf = 0;
-        for (int i = 0; i < 32; i++) {
-            if (sDM[i] < lf_min) { ind_lf = i; lf_min = sDM[i]; }
-            if (sDM[32 + i] < hf_min) { ind_hf = i; hf_min = sDM[32 + i]; }
-        }
+        lc3_argmin_seq(sDM, 32, lf_min, ind_lf);
+        lc3_argmin_seq(sDM + 32, 32, hf_min, ind_hf);
         for (int n = 0; n < 8; n++) {
             sST1[n] = lc3_f(&LC3T_LFCB_BITS[ind_lf][0], n);
             sST1[8 + n] = lc3_f(&LC3T_HFCB_BITS[ind_hf][0], n);
@@ -695,8 +697,7 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3
     LC3_SYNC();
     // spectral shaping :264-268 -- one lane per band (bands are 1..25 lines wide)
     if (lane < c.nb) {
-        const float g = sINT[lane];
-        for (int k = ifs[lane]; k < ifs[lane + 1]; k++) L.spec[k] *= g;
+        lc3_scale_run(L.spec, ifs[lane], ifs[lane + 1], sINT[lane]);
     }
     res.ind_lf = L.ism[0];
     res.ind_hf = L.ism[1];
@@ -736,15 +737,13 @@ __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3
         float ac = 0.0f;
         if (f < tp.num) {
             const int start = tp.sub_start[f][s], stop = tp.sub_stop[f][s], k_from = start + k;
-            if (k_from < ne && k_from < stop)
-                for (int n = 0; k_from + n < stop; n++) ac += x[start + n] * x[k_from + n];
+            if (k_from < ne && k_from < stop) ac = lc3_dot_seq(x + start, x + k_from, stop - k_from, 0.0f);
         }
         sAC[lane] = ac;
     } else if (lane < 60) {
         const int q = lane - 54, f = q / 3, s = q - 3 * f;
         float es = 0.0f;
-        if (f < tp.num)
-            for (int n = tp.sub_start[f][s]; n < tp.sub_stop[f][s]; n++) es += x[n] * x[n];
+        if (f < tp.num) es = lc3_dot_seq(x + tp.sub_start[f][s], x + tp.sub_start[f][s], tp.sub_stop[f][s] - tp.sub_start[f][s], 0.0f);
         sES[q] = es;
     }
     LC3_SYNC();
@@ -1013,11 +1012,19 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(l
     if (lane == 0) {
         float *o12 = x12 + c.delay12 + LC3_NMEM;
         float m1 = L.st.h50_m1, m2 = L.st.h50_m2;
-        for (int n = 0; n < len12; n++) {
-            float h50 = o12[n] - -1.9652933726226904f * m1 - 0.9658854605688177f * m2;
-            o12[n] = 0.9827947082978771f * h50 + -1.965589416595754f * m1 + 0.9827947082978771f * m2;
-            m2 = m1;
-            m1 = h50;
+        for (int n0 = 0; n0 < len12; n0 += 8) {  // len12 is a multiple of 8; eight samples per LDS round trip
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = o12[n0 + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                float h50 = x[u] - -1.9652933726226904f * m1 - 0.9658854605688177f * m2;
+                x[u] = 0.9827947082978771f * h50 + -1.965589416595754f * m1 + 0.9827947082978771f * m2;
+                m2 = m1;
+                m1 = h50;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) o12[n0 + u] = x[u];
         }
         L.st.h50_m1 = m1;
         L.st.h50_m2 = m2;
@@ -1062,8 +1069,7 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(l
         const int NL = LC3_KMAX + 1 - LC3_KMIN;
         int idx = 0;
         float mx = rw6[0];
-        for (int i = 0; i < NL; i++)
-            if (rw6[i] > mx) { idx = i; mx = rw6[i]; }
+        lc3_argmax_seq(rw6, NL, mx, idx);
         const int lag_t1 = idx + LC3_KMIN;
         const int t_prev = L.st.t_prev;
         const int k_from = (t_prev - 4 > LC3_KMIN ? t_prev - 4 : LC3_KMIN) - LC3_KMIN;
@@ -1071,8 +1077,7 @@ __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(l
         idx = 0;
         if (k_to > k_from) {
             mx = r6[k_from];
-            for (int i = 0; i < k_to - k_from; i++)
-                if (r6[k_from + i] > mx) { idx = i; mx = r6[k_from + i]; }
+            lc3_argmax_seq(r6 + k_from, k_to - k_from, mx, idx);
         }
         L.ism[0] = lag_t1;
         L.ism[1] = idx + k_from + LC3_KMIN;
@@ -1471,13 +1476,16 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, LC3_LDS_PARAM
             LC3_SYNC();
             // tmp: sequential f32 sum, evaluated by every lane on the same (broadcast) LDS reads; the terms are fetched
             // 20 at a time, one chunk ahead of the additions
+            // Every term is >= 0 (3.78, 0, >= 9.8, > 70), so the running f32 sum never decreases: once it exceeds the
+            // threshold the comparison below is decided and the rest of the walk can be skipped.
+            const float thr = (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f;
             float tmp = 0.0f;
             {
                 const lc3_f4 *tv4 = (const lc3_f4 *)tvb;
                 lc3_f4 cur[5], nxt[5];
 #pragma unroll
                 for (int u = 0; u < 5; u++) cur[u] = tv4[u];
-                for (int i = 0; i < ne4p; i += 20) {
+                for (int i = 0; i < ne4p && !(tmp > thr); i += 20) {
 #pragma unroll
                     for (int u = 0; u < 5; u++) nxt[u] = tv4[i / 4 + 5 + u];  // one chunk past the end is scratch space
 #pragma unroll
@@ -1492,7 +1500,7 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, LC3_LDS_PARAM
                 }
             }
             LC3_SYNC();
-            if ((tmp > (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f) && hi >= 0) gg_ind += fac;
+            if ((tmp > thr) && hi >= 0) gg_ind += fac;
         }
         if (lane == 0) {
             // global_gain_limitation :212-228
@@ -1609,8 +1617,7 @@ __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM
     LC3_SYNC();
     if (lane == 0) {
         L.ism[0] = tot_nz < mx ? tot_nz : mx;
-        float sum = 0.0f;
-        for (int i = 0; i < tot_rel; i++) sum += compact[i];
+        const float sum = lc3_sum_seq(compact, tot_rel, 0.0f);
         const float level = tot_rel > 0 ? sum / (float)tot_rel : 0.0f;
         const float diff = 8.0f - 16.0f * level;
         int nfac = 0;
