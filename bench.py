@@ -175,6 +175,16 @@ def main():
         dom_ms, alg = kernel_ms[dom], alg_bytes[dom]
         value = total_frames / elapsed
         achieved = frames_per_step * alg / (dom_ms * 1e-3) / 1e9
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside this
+        # process); scaled to this run's frames per launch
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")) as f:
+                tj = json.load(f)
+            kk = tj["kernels"][dom]
+            traffic = (kk["fetch_size_kb_per_launch"] + kk["write_size_kb_per_launch"]) * 1024.0 * frames_per_step / tj["frames_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         line = {
             "metric": "LC3 frames/sec (encode+decode) @48kHz/10ms",
             "value": value,
@@ -205,12 +215,13 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_frame": alg,
                 "roundtrip_algorithmic_bytes_per_frame": ALG_BYTES_ENC + ALG_BYTES_DEC,
                 "roundtrip_achieved_GBs": value * (ALG_BYTES_ENC + ALG_BYTES_DEC) / 1e9 / world,
-                "note": "instruction-issue-bound, not HBM-bound (SURVEY 8d honesty note): ~60-90 flop per algorithmic "
-                        "byte; PMC traffic and instruction mix in profiles/",
+                "note": "instruction/latency-bound, not HBM-bound (SURVEY 8d honesty note): ~60 flop per algorithmic byte; "
+                        "traffic = FETCH_SIZE + WRITE_SIZE of this kernel from profiles/hbm_traffic_latest.json (bytes per "
+                        "launch); instruction mix and wait counters in profiles/r01_v7_pmc_summary.csv, DESIGN.md section 5",
             },
             "cpu_baseline": cpu,
             "parity": parity,
