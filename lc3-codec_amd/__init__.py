@@ -17,7 +17,9 @@ from .api import (  # noqa: F401
     Lc3GpuError,
     SamplingFrequency,
     build_native,
+    build_tool,
     device_count,
     library_path,
     load_library,
+    tool_path,
 )

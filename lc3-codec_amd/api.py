@@ -74,6 +74,26 @@ def build_native(force=False, verbose=False):
     return _LIB
 
 
+def tool_path():
+    return os.path.join(os.path.dirname(_LIB), "lc3gpu-tool")
+
+
+def build_tool(force=False, verbose=False):
+    """Compile the file-driver command line tool (host/lc3_files.cpp, host/lc3gpu_tool.cpp) against liblc3gpu.so."""
+    host = os.path.join(_HERE, "host")
+    srcs = [os.path.join(host, f) for f in ("lc3_files.cpp", "lc3gpu_tool.cpp")]
+    deps = srcs + [os.path.join(host, "lc3_files.hpp"), os.path.join(_ROOT, "include", "lc3gpu.h"), _LIB]
+    out = tool_path()
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    cmd = ["hipcc", "-O2", "-std=c++17", "-Wno-unused-result", "-o", out] + srcs + [
+        "-L" + os.path.dirname(_LIB), "-llc3gpu", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def load_library():
     """Load liblc3gpu.so; fails loudly if the native extension is missing (there is no fallback)."""
     global _lib
