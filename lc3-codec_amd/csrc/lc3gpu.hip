@@ -485,6 +485,16 @@ struct lc3gpu_decoder {
     size_t planes_frames = 0;      // capacity in frames (multiple of 64)
 };
 
+// frames per workgroup of the lane-per-frame kernels (= threads per workgroup).  LC3GPU_FPB overrides (tuning aid).
+static unsigned lc3_frame_block(unsigned dflt) {
+    static int env = -1;
+    if (env < 0) {
+        const char *v = std::getenv("LC3GPU_FPB");
+        env = v ? std::atoi(v) : 0;
+    }
+    return (env == 64 || env == 128 || env == 256) ? (unsigned)env : dflt;
+}
+
 static int encoder_reserve_planes(lc3gpu_encoder *e, size_t frames);
 static int decoder_reserve_planes(lc3gpu_decoder *d, size_t frames);
 
@@ -641,7 +651,7 @@ static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_p
                        e->d_planes, nbytes, n_frames, fresh, dbg);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
-    const unsigned fpb = nbytes <= 220 ? 256u : 128u;
+    const unsigned fpb = lc3_frame_block(nbytes <= 220 ? 256u : 128u);
     const size_t lds = 4096 + 64 * 17 * 4 + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3);
     hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, e->h.c.ne,
                        (const int32_t *)e->d_planes, d_out, nbytes, (int)frames);
@@ -786,7 +796,7 @@ static int decode_launch(lc3gpu_decoder *d, int first, int n, const uint8_t *d_i
     if (rc) return rc;
     // frames per workgroup: as many as fit the default 64 KB of dynamic LDS (tables + 64 B of scale factors and nbytes of
     // frame data per frame)
-    unsigned fpb = 256u;
+    unsigned fpb = lc3_frame_block(256u);
     while (fpb > 64u && LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes) > 65536u) fpb >>= 1;
     const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes);
     d->timer.mark(stream);
