@@ -1,20 +1,21 @@
 // LC3 batched codec for MI355X (gfx950) -- device-side common layer.
 //
-// Execution model: ONE WAVEFRONT (64 lanes) PER STREAM.  A stream is one codec
-// channel (the reference's EncoderChannel / DecoderChannel, encoder/lc3_encoder.rs:42-60,
-// decoder/lc3_decoder.rs:62-69); its frames are processed in time order by the
-// same wave with all working data resident in LDS.  Every routine here takes the
-// caller's lane id and is executed by all 64 lanes of the wave; lane-parallel
-// loops stride by 64, inherently serial recurrences run on lane 0 while the
-// others wait at the next LC3_SYNC().
+// Execution model of the stream kernels: ONE WAVEFRONT (64 lanes) PER STREAM, four streams per workgroup.  A
+// stream is one codec channel (the reference's EncoderChannel / DecoderChannel, encoder/lc3_encoder.rs:42-60,
+// decoder/lc3_decoder.rs:62-69); its frames are processed in time order by the same wave with the working data in
+// LDS.  Every stage routine takes the caller's lane id and is executed by all 64 lanes of the wave; lane-parallel
+// loops stride by 64, inherently serial recurrences run on lane 0 (or a few lanes) while the others wait at the next
+// LC3_SYNC().  Stages that are serial per frame AND stateless across frames do not live here at all: they run one
+// lane per frame in lc3_dev_enc_pack.h / lc3_dev_dec_parse.h.
 //
 // Bit-exactness contract (SURVEY.md section 7 "design rule"): parallelise across
 // OUTPUTS, never inside one of the reference's f32 summations; every f32
 // expression keeps the reference's evaluation order; build with
 // -ffp-contract=off so no mul+add is fused.
 //
-// The including translation unit provides LC3_SYNC() (a workgroup barrier for the
-// one-wave workgroup) and the __device__ / __forceinline__ keywords.
+// The including translation unit provides LC3_SYNC() (orders one wave's LDS traffic), the wave primitives
+// (lc3_wave_max_i32, lc3_wave_sum_u32, lc3_wave_exscan_u32) and the __device__ / __forceinline__ keywords: lc3gpu.hip
+// for the GPU, tests/emu/lc3_emu.cpp for the CPU wave emulator of the tests.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>

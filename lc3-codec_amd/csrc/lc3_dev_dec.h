@@ -1,5 +1,6 @@
-// LC3 batched decoder for MI355X -- device-side stages (one wavefront per stream).
-// Mirrors DecoderChannel::decode (reference decoder/lc3_decoder.rs:73-154) stage by stage.
+// LC3 batched decoder for MI355X -- synthesis stages (one wavefront per stream): concealment, IMDCT, LTPF, output.
+// The first half of DecoderChannel::decode (reference decoder/lc3_decoder.rs:73-154: parsing and the spectrum
+// reconstruction D1-D8) runs one lane per frame in lc3_dev_dec_parse.h; this file is the stateful second half.
 // See lc3_dev_common.h for the execution model and the bit-exactness contract.
 #pragma once
 #include "lc3_dev_common.h"
@@ -27,7 +28,7 @@ struct lc3_dec_state {
 };
 #define LC3_DEC_CORE_WORDS ((int)(sizeof(lc3_dec_core) / 4))
 
-// LDS working set of one decoder wave (~13 KB -> 12 waves per CU)
+// LDS working set of one decoder wave (12.5 KB; the synthesis kernel is 9 % of a step, its occupancy is not tuned)
 struct __attribute__((aligned(16))) lc3_dec_lds {
     lc3_dec_core st;
     float spec[LC3_MAX_NF];        // spec_lines, then freq_samples

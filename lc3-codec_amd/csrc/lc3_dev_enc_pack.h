@@ -5,7 +5,7 @@
 // growing forward, sign/LSB/residual bits growing backward.  It needs nothing but integers the analysis stages
 // produced, so -- like the decoder's parser (lc3_dev_dec_parse.h) -- it runs with every lane writing its own frame
 // in the reference's exact operation order.  The wave-per-stream analysis kernel (lc3_dev_enc.h) leaves one
-// "plane" column per frame in HBM, laid out [block of 64 frames][word][lane]; this stage reads it and produces the
+// "plane" column per frame in HBM (EP_WORDS contiguous words, lc3_dev_common.h); this stage reads it and produces the
 // frame bytes in an LDS staging area that the workgroup then copies out with coalesced stores.
 #pragma once
 #include "lc3_dev_common.h"
