@@ -305,3 +305,44 @@ def test_ltpf_transitions(fs, us, nbytes):
     assert all(c > 0 for c in counts[1:]), counts
     assert np.array_equal(gpu_encode(pcm, nbytes, fs, us), ref)
     assert np.array_equal(gpu_decode(ref, nf, fs, us), ref_pcm)
+
+
+@pytest.mark.parametrize("nbytes", [20, 25, 50, 79, 80, 81, 99, 100, 139, 140, 141, 160, 200, 260, 320, 399])
+def test_bitrate_sweep_48k(nbytes):
+    """Bitrate boundaries at 48 kHz / 10 ms: rate_flag (nbits > 800), lsb mode (nbits >= 1120), attack detector on
+    (>= 100 bytes), LTPF gain classes (nbits < 880), bit-budget steps (nbits <= 1280 / 2560)."""
+    _roundtrip_check(48000, 10000, nbytes, 12, 5, seed=nbytes)
+
+
+@pytest.mark.parametrize("S", [1, 2, 3, 5, 7])
+def test_stream_counts_not_multiple_of_workgroup(S):  # workgroups hold four streams: partial last workgroup
+    _roundtrip_check(48000, 10000, 150, S, 3, seed=100 + S)
+
+
+def test_long_stream_state_carry():  # 6 s of two streams in ONE launch: state carried over 600 frames inside the kernel
+    _roundtrip_check(48000, 10000, 150, 2, 600, seed=11)
+
+
+def test_channel_ranges_on_separate_hip_streams():
+    """lc3gpu_encode_range / lc3gpu_decode_range on sub-ranges of one handle's channels, different T per call."""
+    t = torch_mod()
+    S, T, nf, nb = 12, 6, 480, 150
+    pcm = synth.make_pcm(S, T, nf, 48000, seed=21)
+    ref_b = O.encode_batch(pcm, nb)
+    ref_p = O.decode_batch(ref_b, nf)
+    enc = pkg.Lc3Encoder(S, 10000, 48000)
+    dec = pkg.Lc3Decoder(S, 10000, 48000)
+    out_b = np.zeros((S, T, nb), np.uint8)
+    out_p = np.zeros((S, T, nf), np.int16)
+    for first, n in ((0, 5), (5, 4), (9, 3)):
+        for t0, tn in ((0, 2), (2, 4)):  # two launches per range: 2 frames, then 4
+            d_pcm = t.from_numpy(np.ascontiguousarray(pcm[first:first + n, t0:t0 + tn])).cuda()
+            d_b = t.zeros((n, tn, nb), dtype=t.uint8, device="cuda")
+            d_p = t.zeros((n, tn, nf), dtype=t.int16, device="cuda")
+            enc.encode(d_pcm, d_b, nb, tn, first_channel=first, n_channels=n)
+            dec.decode(d_b, d_p, nb, tn, first_channel=first, n_channels=n)
+            t.cuda.synchronize()
+            out_b[first:first + n, t0:t0 + tn] = d_b.cpu().numpy()
+            out_p[first:first + n, t0:t0 + tn] = d_p.cpu().numpy()
+    assert np.array_equal(out_b, ref_b)
+    assert np.array_equal(out_p, ref_p)
