@@ -932,7 +932,7 @@ __device__ __forceinline__ float lc3_ltpf_dot(const float *x12, int n, int d) { 
 // g: the stream's state blob in HBM, owner of the two sample rings (x12 at 12.8 kHz, x6 at 6.4 kHz); `store` = 0 for
 // the shadow waves of a partial workgroup.  Staging: x12 lives in fa for the duration of the stage, the resampler's
 // polyphase table and later the correlation scratch in fb, x6 in `t` once the resampler has consumed the time buffer.
-__device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int near_nyquist,
+__device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int near_nyquist,
                                                     int nbits, lc3_enc_state *g, int store) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
