@@ -48,6 +48,14 @@
 #define LC3_LDS_BIND(T, arr)
 #endif
 
+// The spectral-model tables of the quantiser's bit estimate (AC_SPEC_LOOKUP[4096], AC_SPEC_BITS[64][17]): read
+// straight from the constant tables by default; the HIP kernels keep a per-workgroup copy in LDS (data-dependent
+// gathers, two dependent lookups per tuple).
+#ifndef LC3_SPEC_LOOKUP
+#define LC3_SPEC_LOOKUP(i) ((int)LC3T_AC_SPEC_LOOKUP[(i)])
+#define LC3_SPEC_BITS(p, j) ((uint32_t)LC3T_AC_SPEC_BITS[(p)][(j)])
+#endif
+
 // Code that is serial per stream sits between LC3_SERIAL_BEGIN(T, L, lane, phase, K) and LC3_SERIAL_END: K lanes
 // (`sub` = 0..K-1) run it per stream with `L` bound to the stream's working set of type T.  The translation unit decides
 // who runs it: by default lanes 0..K-1 of the stream's own wave; the HIP kernels gather the streams of a workgroup on

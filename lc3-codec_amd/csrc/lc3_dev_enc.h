@@ -1318,31 +1318,43 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, LC3_LDS
         const int lastnz = hi_all < 1 ? 2 : 2 * hi_all;  // `while lastnz > 2 && last pair == 0` (:270-273)
         const int ntup = lastnz / 2;
         uint32_t est4[4], run = 0, lsb_sum = 0;
+        int tctx[4];
+        // main symbols first: four independent lookup -> bits chains per lane, straight-line so that they overlap
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int k = k0 + j;
             est4[j] = 0;
+            tctx[j] = 0;
             if (k < ntup) {
                 const uint32_t v = loc[j];
                 const unsigned af = v & 0xff, bf = (v >> 8) & 0xff;
                 const int n_esc = (int)((v >> 16) & 0xff);
                 const int cctx = k == 0 ? 0 : (k == 1 ? (int)ttab[0] : 16 * (int)ttab[k - 2] + (int)ttab[k - 1]);
                 const int t = cctx + rate_flag + ((2 * k) > ne / 2 ? 256 : 0);
-                uint32_t est = 0;
-                for (int i = 0; i < n_esc; i++) {
-                    const int pki = LC3T_AC_SPEC_LOOKUP[t + (i < 3 ? i : 3) * 1024];
-                    est += LC3T_AC_SPEC_BITS[pki][16];
-                    if (!(i == 0 && mode_flag)) est += 2 * 2048;
-                }
+                tctx[j] = t;
                 const int levf = n_esc < 3 ? n_esc : 3;
-                const int pki = LC3T_AC_SPEC_LOOKUP[t + levf * 1024];
-                est += LC3T_AC_SPEC_BITS[pki][af + 4 * bf];
+                const int pki = LC3_SPEC_LOOKUP(t + levf * 1024);
+                uint32_t est = LC3_SPEC_BITS(pki, af + 4 * bf);
                 if (v & (1u << 27)) est += 2048;
                 if (v & (1u << 28)) est += 2048;
                 if (n_esc > 0 && mode_flag) lsb_sum += 2 + ((v >> 25) & 1) + ((v >> 26) & 1);
                 est4[j] = est;
-                run += est;
             }
+        }
+        // escape symbols (magnitudes >= 4 only): one per dropped bit plane (integer sums: any order is exact)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int n_esc = (int)((loc[j] >> 16) & 0xff);
+            if (k0 + j < ntup && n_esc > 0) {
+                uint32_t est = 0;
+                for (int i = 0; i < n_esc; i++) {
+                    const int pki = LC3_SPEC_LOOKUP(tctx[j] + (i < 3 ? i : 3) * 1024);
+                    est += LC3_SPEC_BITS(pki, 16);
+                    if (!(i == 0 && mode_flag)) est += 2 * 2048;
+                }
+                est4[j] += est;
+            }
+            run += est4[j];
         }
         const uint32_t base = lc3_wave_exscan_u32(run, lane);
         const uint32_t est_total = lc3_wave_sum_u32(run, lane), lsb_total = lc3_wave_sum_u32(lsb_sum, lane);

@@ -40,6 +40,14 @@
         __builtin_amdgcn_wave_barrier();                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
     } while (0)
+// per-workgroup LDS copy of the spectral-model tables used by the analysis kernel's bit estimate (6.1 KB)
+struct lc3_spec_tables {
+    uint8_t lookup[4096];
+    uint16_t bits[64 * 17];
+};
+__shared__ lc3_spec_tables lc3_spec_tab;
+#define LC3_SPEC_LOOKUP(i) ((int)lc3_spec_tab.lookup[(i)])
+#define LC3_SPEC_BITS(p, j) ((uint32_t)lc3_spec_tab.bits[(p) * 17 + (j)])
 #define LC3_LDS_DECL(T, arr) __shared__ T arr[LC3_WG_WAVES];
 #define LC3_LDS_PARAM(T)
 #define LC3_LDS_PASS
@@ -186,6 +194,13 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_encode_kernel(lc3_cf
     const int s = valid ? s_raw : n_streams - 1;
     const int nf = lc3_cfg_table[cfg.id].nf;
     lc3_enc_state *gst = states + (size_t)(first_channel + s);
+    {   // spectral-model tables -> LDS, once per workgroup
+        const uint32_t *lk = (const uint32_t *)LC3T_AC_SPEC_LOOKUP, *bt = (const uint32_t *)&LC3T_AC_SPEC_BITS[0][0];
+        uint32_t *dl = (uint32_t *)lc3_spec_tab.lookup, *db = (uint32_t *)lc3_spec_tab.bits;
+        for (int i = threadIdx.x; i < 1024; i += 64 * LC3_WG_WAVES) dl[i] = lk[i];
+        for (int i = threadIdx.x; i < 64 * 17 / 2; i += 64 * LC3_WG_WAVES) db[i] = bt[i];
+        __syncthreads();
+    }
     LC3_PROF_BEGIN(L, lane);
     if (fresh) lc3_enc_state_init(L, lane, gst, valid);
     else lc3_enc_state_load(L, lane, gst);
