@@ -1278,9 +1278,22 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, LC3_LDS
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int ne = c.ne;
     const float gg = lc3_pow10f(((float)gg_ind + (float)gg_off) / 28.0f);
-    for (int n = lane; n < ne; n += LC3_WAVE) {
-        float x = L.spec[n];
-        LC3_XQ(L)[n] = (int16_t)(x >= 0.0f ? lc3_f2i16(x / gg + 0.375f) : lc3_f2i16(x / gg - 0.375f));
+    {   // ne <= 400: seven lines per lane, loaded together, divided as seven independent chains, stored together
+        float x[7];
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int n = lane + LC3_WAVE * u;
+            x[u] = n < ne ? L.spec[n] : 0.0f;
+        }
+        int16_t q[7];
+#pragma unroll
+        for (int u = 0; u < 7; u++)
+            q[u] = (int16_t)(x[u] >= 0.0f ? lc3_f2i16(x[u] / gg + 0.375f) : lc3_f2i16(x[u] / gg - 0.375f));
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int n = lane + LC3_WAVE * u;
+            if (n < ne) LC3_XQ(L)[n] = q[u];
+        }
     }
     LC3_SYNC();
     const int rate_flag = nbits > (160 + c.fs_ind * 160) ? 512 : 0;
