@@ -110,11 +110,13 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *dec, uint64_t *out);
  * dbg float[1472] = spectrum after MDCT [0,480), after SNS [480,960), after TNS [960,1440), scalars [1440,1472) */
 int lc3gpu_encode_frame_debug(lc3gpu_encoder *enc, const int16_t *samples_in, int n_samples, uint8_t *buf_out,
                               int nbytes, float *dbg);
-/* per-kernel timing of the batch calls with HIP events recorded on the launch stream.  A batch call runs two
- * kernels: encoder = {analysis (wave per stream), bitstream packing (lane per frame)}, decoder = {frame parsing
- * (lane per frame), synthesis (wave per stream)}.  `enable` switches recording on/off; the call synchronises and
- * returns in out[3] = {stage-1 ms, stage-2 ms, number of batch calls} accumulated since the previous call. */
-int lc3gpu_encoder_timing(lc3gpu_encoder *enc, int enable, double out[3]);
+/* per-kernel timing of the batch calls with HIP events recorded on the launch stream.  An encoder batch call runs four
+ * kernels: analysis front half (wave per stream), SNS vector quantiser (lane per frame), analysis back half (wave per
+ * stream), bitstream packing (lane per frame); a decoder batch call two: frame parsing + spectrum reconstruction (lane
+ * per frame), synthesis (wave per stream).  `enable` switches recording on/off; the call synchronises and returns the
+ * per-kernel milliseconds accumulated since the previous call followed by the number of batch calls:
+ * encoder out[5] = {front, vq, back, pack, calls}, decoder out[3] = {parse, synthesis, calls}. */
+int lc3gpu_encoder_timing(lc3gpu_encoder *enc, int enable, double out[5]);
 int lc3gpu_decoder_timing(lc3gpu_decoder *dec, int enable, double out[3]);
 /* diagnostic build (liblc3gpu_prof.so, -DLC3_PROFILE) only: per-stage shader-clock cycle sums since the last call.
  * slots 1..9 = encoder stages (mdct, bw+attack, sns, tns, ltpf, quant, residual+noise, bitstream, store),

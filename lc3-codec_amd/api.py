@@ -249,12 +249,12 @@ class Lc3Encoder:
             raise Lc3EncoderError(rc, "encode")
 
     def timing(self, enable=True):
-        """-> (analysis-kernel ms, pack-kernel ms, batch calls) since the last call; (re)arms recording"""
-        out = (ctypes.c_double * 3)()
+        """-> (front ms, vector-quantiser ms, back ms, pack ms, batch calls) since the last call; (re)arms recording"""
+        out = (ctypes.c_double * 5)()
         rc = self._L.lc3gpu_encoder_timing(self._h, int(bool(enable)), out)
         if rc:
             raise Lc3EncoderError(rc, "timing")
-        return float(out[0]), float(out[1]), int(out[2])
+        return float(out[0]), float(out[1]), float(out[2]), float(out[3]), int(out[4])
 
     def reset(self):
         rc = self._L.lc3gpu_encoder_reset(self._h)

@@ -4,6 +4,7 @@
 #pragma once
 #include "lc3_dev_common.h"
 #include "lc3_dev_enc_pack.h"
+#include "lc3_dev_enc_vq.h"
 
 // ------------------------------------------------------------------------------------------
 // Persistent per-stream encoder state as it lives in HBM between launches: the two LTPF sample rings
@@ -52,6 +53,7 @@ struct __attribute__((aligned(16))) lc3_enc_lds {
 #endif
 };
 #define LC3_EB(L) ((float *)(L).fa + 512)                    // [64] band energies: MDCT stage -> bandwidth, SNS
+#define LC3_SCF(L) ((float *)(L).fa + 144)                   // [16] SNS target scale factors (lc3_enc_sns_front)
 #define LC3_XQ(L) ((L).t)                                    // int16[ne] quantised spectrum (from the quantiser on)
 #define LC3_RESB(L) ((uint8_t *)(L).t + 2 * LC3_MAX_NE)      // uint8[ne] residual bits
 
@@ -324,66 +326,15 @@ __device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_
 // ------------------------------------------------------------------------------------------
 // E9/E10: spectral noise shaping (encoder/spectral_noise_shaping.rs:203-648)
 // ------------------------------------------------------------------------------------------
-// add_unit_pulse :285-316 (corr_xy / energy_y written through on every probe: SURVEY A2).  Magnitudes and pulse
-// counts are register arrays (N = 16 or 10 candidates, fully unrolled).
-template <int N>
-__device__ __forceinline__ void lc3_add_unit_pulse_r(const float (&abs_x)[16], int (&cand)[16], int k, int k_max,
-                                                     float &corr_xy, float &energy_y) {
-    float corr_last = corr_xy, en_last = energy_y;
-    for (int it = k; it < k_max; it++) {
-        int n_best = 0;
-        corr_xy = corr_last + abs_x[0];
-        float best_corr_sq = corr_xy * corr_xy;
-        float best_en = en_last + 2.0f * (float)cand[0] + 1.0f;
-        float best_abs = abs_x[0];
-        int best_cand = cand[0];
-#pragma unroll
-        for (int n_c = 1; n_c < N; n_c++) {
-            corr_xy = corr_last + abs_x[n_c];
-            energy_y = en_last + 2.0f * (float)cand[n_c] + 1.0f;
-            if (corr_xy * corr_xy * best_en > best_corr_sq * energy_y) {
-                n_best = n_c;
-                best_corr_sq = corr_xy * corr_xy;
-                best_en = energy_y;
-                best_abs = abs_x[n_c];
-                best_cand = cand[n_c];
-            }
-        }
-        corr_last += best_abs;
-        en_last += 2.0f * (float)best_cand + 1.0f;
-#pragma unroll
-        for (int n = 0; n < N; n++) cand[n] += n == n_best;
-    }
-}
-// mvpq_enum :584-629 with the per-position offset rows already looked up (h[pos] is the row value the reference adds
-// while visiting pos): folds sign bits and offsets from the last position down to the first.
-__device__ __forceinline__ void lc3_mvpq_fold(uint32_t &index, int &lead_sign_ind, int dim_in, const int *vec_in,
-                                              const int *h) {
-    int next_sign_ind = (-2147483647 - 1);
-    index = 0;
-    for (int pos = dim_in - 1; pos >= 0; pos--) {
-        const int tmp_val = (int)(int8_t)vec_in[pos];
-        if (next_sign_ind >= 0 && tmp_val != 0) index = 2 * index + (uint32_t)next_sign_ind;
-        if (tmp_val < 0) next_sign_ind = 1;
-        else if (tmp_val > 0) next_sign_ind = 0;
-        index += (uint32_t)h[pos];
-    }
-    lead_sign_ind = next_sign_ind;
-}
-
-// scratch map inside L.fa/L.fb (floats): all disjoint
-//   sE[64] smoothed/log energies, sP[64] padded, sDS[16], sSCF[16], sSCFQ[16], sINT[64],
-//   sST1[16], sR1[16], sT2[16], sABS[16], sXQ[4][16], sDM[64] (stage-1 distortions), iY[4][16]
-__device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int attack) {
+// E9 front half (encoder/spectral_noise_shaping.rs:75-161, 203-233): band energies -> 16 target scale factors, left in
+// LDS at S[144..160) (sSCF) for the caller to hand to the vector quantiser (lc3_dev_enc_vq.h).
+// scratch map inside L.fa (floats): sE[64] smoothed/log energies, sP[64] padded, sDS[16], sSCF[16]
+__device__ __noinline__ void lc3_enc_sns_front(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int attack) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     float *S = (float *)L.fa;
-    float *sE = S, *sP = S + 64, *sDS = S + 128, *sSCF = S + 144, *sSCFQ = S + 160, *sINT = S + 176;
-    float *sST1 = S + 240, *sR1 = S + 256, *sT2 = S + 272, *sABS = S + 288, *sXQ = S + 304, *sDM = S + 368;
-    int *iY = (int *)(S + 432);  // 4*16 ints -> ends at 496 floats < 960
-    const uint16_t *ifs = lc3_band_index(c);
+    float *sE = S, *sP = S + 64, *sDS = S + 128, *sSCF = S + 144;
     const int diff = 64 - c.nb;
-    lc3_sns_res res;
 
     // padding :75-90
     if (diff > 0) {
@@ -467,247 +418,19 @@ __device__ __noinline__ lc3_sns_res lc3_enc_sns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 27);
-    // stage 1 :318-361 -- lanes 0..31: LF codebook entry, lanes 32..63: HF codebook entry
-    {
-        const int i = lane & 31, hf = lane >> 5;
-        const uint32_t *cb = hf ? &LC3T_HFCB_BITS[i][0] : &LC3T_LFCB_BITS[i][0];
-        const float *s = sSCF + 8 * hf;
-        float d = 0.0f;
-        for (int n = 0; n < 8; n++) d += (s[n] - lc3_f(cb, n)) * (s[n] - lc3_f(cb, n));
-        sDM[lane] = d;
-    }
-    LC3_SYNC();
-    if (lane == 0) {
-        float lf_min = __builtin_inff(), hf_min = __builtin_inff();
-        int ind_lf = 0, ind_hf = 0;
-        lc3_argmin_seq(sDM, 32, lf_min, ind_lf);
-        lc3_argmin_seq(sDM + 32, 32, hf_min, ind_hf);
-        for (int n = 0; n < 8; n++) {
-            sST1[n] = lc3_f(&LC3T_LFCB_BITS[ind_lf][0], n);
-            sST1[8 + n] = lc3_f(&LC3T_HFCB_BITS[ind_hf][0], n);
-        }
-        for (int n = 0; n < 16; n++) sR1[n] = sSCF[n] - sST1[n];
-        L.ism[0] = ind_lf;
-        L.ism[1] = ind_hf;
-    }
-    LC3_SYNC();
-    LC3_STAMP(L, lane, 28);
-    // stage 2 target: t2rot = r1 * D, row-by-row accumulation order (:378-384) -- one lane per column
-    if (lane < 16) {
-        float acc = 0.0f;
-        for (int i = 0; i < 16; i++) acc += sR1[i] * lc3_f(&LC3T_D_BITS[i][0], lane);
-        sT2[lane] = acc;
-        sABS[lane] = lc3_absf(acc);
-    }
-    LC3_SYNC();
-    LC3_STAMP(L, lane, 29);
-    // Pulse search :285-316, :386-470, serial per stream, with the 16 magnitudes and pulse counts in registers; the
-    // signs of the target only enter when a finished candidate is stored (y0 | y1 | y2 | y3 at iY + 0 | 16 | 32 | 48).
-    // (Gathering the workgroup's four streams on one wave -- LC3_SERIAL_BEGIN -- cut 1.2 k VALU instructions per frame
-    // but not the kernel time: profiles/r01_v6_notes.txt.)
-    LC3_LOCAL_BEGIN(lane, 1)
-    {
-        const float *sABS = (const float *)L.fa + 288, *sT2 = (const float *)L.fa + 272;
-        int *iY = (int *)((float *)L.fa + 432);
-        float ax[16];
-        int cand[16];
-        uint32_t neg = 0;
-#pragma unroll
-        for (int n = 0; n < 16; n++) {
-            ax[n] = sABS[n];
-            if (sT2[n] < 0.0f) neg |= 1u << n;
-        }
-        int k = 0;
-        float abs_sum = 0.0f, corr_xy = 0.0f, energy_y = 0.0f;
-#pragma unroll
-        for (int n = 0; n < 16; n++) abs_sum += ax[n];
-        const float proj = (6.0f - 1.0f) / abs_sum;
-#pragma unroll
-        for (int n = 0; n < 16; n++) {
-            const int v = lc3_f2i32(lc3_floorf(ax[n] * proj));
-            cand[n] = v;
-            if (v != 0) {
-                k += v;
-                corr_xy += (float)v * ax[n];
-                energy_y += (float)v * (float)v;
-            }
-        }
-        lc3_add_unit_pulse_r<16>(ax, cand, k, 6, corr_xy, energy_y);
-#pragma unroll
-        for (int n = 0; n < 16; n++) iY[48 + n] = (neg >> n) & 1u ? -cand[n] : cand[n];
-        lc3_add_unit_pulse_r<16>(ax, cand, 6, 8, corr_xy, energy_y);
-#pragma unroll
-        for (int n = 0; n < 16; n++) iY[32 + n] = (neg >> n) & 1u ? -cand[n] : cand[n];
-        int ks = 8;
-#pragma unroll
-        for (int n = 10; n < 16; n++) {
-            if (cand[n] != 0) {
-                ks -= cand[n];
-                corr_xy -= (float)cand[n] * ax[n];
-                energy_y -= (float)cand[n] * (float)cand[n];
-            }
-            cand[n] = 0;
-        }
-        lc3_add_unit_pulse_r<10>(ax, cand, ks, 10, corr_xy, energy_y);
-        float max_abs = 0.0f;
-        int n_best = 0;
-#pragma unroll
-        for (int n = 10; n < 16; n++) {
-            if (ax[n] > max_abs) {
-                max_abs = ax[n];
-                n_best = n;
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < 16; n++) {
-            const int y1 = n < 10 ? ((neg >> n) & 1u ? -cand[n] : cand[n]) : 0;
-            int y0 = y1;
-            if (n >= 10 && n == n_best) y0 = (neg >> n) & 1u ? -1 : 1;
-            iY[16 + n] = y1;
-            iY[n] = y0;
-        }
-        // no positive magnitude in 10..15: the reference's pulse lands on line 0 and takes that line's sign
-        if (n_best == 0) iY[0] = neg & 1u ? -1 : 1;
-    }
-    LC3_LOCAL_END
-    LC3_STAMP(L, lane, 30);
-    // normalize_candidate :632-648 -- the four norms on four lanes (16-term sums in order), the divisions on all lanes
-    if (lane < 4) {
-        const int n_max = lane == 1 ? 10 : 16;
-        float norm = 0.0f;
-        for (int n = 0; n < n_max; n++) {
-            const int y = iY[16 * lane + n];
-            if (y != 0) norm += (float)y * (float)y;
-        }
-        L.sm[4 + lane] = lc3_sqrtf(norm);
-    }
-    LC3_SYNC();
-    {
-        const int j = lane >> 4, n = lane & 15, y = iY[lane];
-        float v = (float)y;
-        if (y != 0) v /= L.sm[4 + j];
-        sXQ[lane] = (j == 1 && n >= 10) ? 0.0f : v;
-    }
-    LC3_SYNC();
-    // shape/gain search :472-521; the last gain of every shape is never tried.  One lane per
-    // (shape, gain) pair computes its distortion, lane 0 then walks the 14 results in the reference's order.
-    if (lane < 14) {
-        const int j = lane < 1 ? 0 : (lane < 4 ? 1 : (lane < 7 ? 2 : 3));
-        const int i = lane - (j == 0 ? 0 : (j == 1 ? 1 : (j == 2 ? 4 : 7)));
-        const uint32_t *gains = j == 0 ? LC3T_SNS_VQ_REG_ADJ_GAINS_BITS
-                                : j == 1 ? LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS
-                                : j == 2 ? LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS : LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS;
-        const float g = lc3_f(gains, i);
-        float d = 0.0f;
-        for (int n = 0; n < 16; n++) {
-            const float df = sT2[n] - g * sXQ[16 * j + n];
-            d += df * df;
-        }
-        sDM[lane] = d;
-        sDM[16 + lane] = g;
-    }
-    LC3_SYNC();
-    if (lane == 0) {
-        int best = 0;
-        float d_min = __builtin_inff();
-        for (int q = 0; q < 14; q++) {
-            const float d = sDM[q];
-            if (d < d_min) { best = q; d_min = d; }
-        }
-        const int shape_j = best < 1 ? 0 : (best < 4 ? 1 : (best < 7 ? 2 : 3));
-        L.ism[2] = shape_j;
-        L.ism[3] = best - (shape_j == 0 ? 0 : (shape_j == 1 ? 1 : (shape_j == 2 ? 4 : 7)));
-        L.sm[1] = d_min < __builtin_inff() ? sDM[16 + best] : 0.0f;
-    }
-    LC3_SYNC();
-    // mvpq_enum :584-629 of the selected shape.  The offset row a position adds depends only on the pulse count above
-    // it, so the table lookups run one lane per position; lane 0 then folds the positions (integer arithmetic).
-    {
-        const int shape_j = L.ism[2];
-        const int *ysel = iY + 16 * shape_j;
-        int *eH = (int *)sDM + 32;  // [16] offsets per position
-        if (lane < 16) {
-            // enumeration A covers positions [0, dimA), enumeration B (shape 0 only) positions [10, 16)
-            const int dimA = shape_j <= 1 ? 10 : 16;
-            const int lo = lane < dimA ? 0 : 10, hi = lane < dimA ? dimA : 16;  // this position's vector is [lo, hi)
-            uint32_t h = LC3T_MPVQ_OFFSETS[0][0];
-            if (lane < hi - 1) {
-                int kacc = 0;
-                for (int p2 = lane + 1; p2 < hi; p2++) {
-                    const int v = (int)(int8_t)ysel[p2];
-                    kacc += v < 0 ? -v : v;
-                }
-                const int nrow = hi - 1 - lane;
-                h = kacc >= 11 ? LC3T_MPVQ_OFFSETS[nrow + 1][kacc % 11] : LC3T_MPVQ_OFFSETS[nrow][kacc];
-            }
-            (void)lo;
-            eH[lane] = (int)h;
-        }
-        LC3_SYNC();
-        if (lane == 0) {
-            uint32_t idxa = 0, idxb = 0, joint;
-            int ls_inda = 0, ls_indb = 0;
-            const int lsb_gain = L.ism[3] & 1;
-            const int dimA = shape_j <= 1 ? 10 : 16;
-            lc3_mvpq_fold(idxa, ls_inda, dimA, ysel, eH);
-            if (shape_j == 0) {
-                lc3_mvpq_fold(idxb, ls_indb, 6, ysel + 10, eH + 10);
-                joint = (2u * idxb + (uint32_t)ls_indb + 2u) * 2390004u + idxa;
-            } else if (shape_j == 1) joint = (uint32_t)lsb_gain * 2390004u + idxa;
-            else if (shape_j == 2) joint = idxa;
-            else joint = 15158272u + (uint32_t)lsb_gain + (2u * idxa);
-            L.ism[4] = ls_inda;
-            L.ism[5] = ls_indb;
-            L.ism[6] = (int)joint;
-        }
-    }
-    LC3_SYNC();
-    LC3_STAMP(L, lane, 31);
-    // synthesis :552-559 -- one lane per scale factor
-    if (lane < 16) {
-        const float *xq_sel = sXQ + 16 * L.ism[2];
-        float factor = 0.0f;
-        for (int col = 0; col < 16; col++) factor += xq_sel[col] * lc3_f(&LC3T_D_BITS[lane][0], col);
-        sSCFQ[lane] = sST1[lane] + L.sm[1] * factor;
-    }
-    LC3_SYNC();
-    // interpolation :163-183 -- one lane per band
-    {
-        const int b = lane;
-        float v;
-        if (b < 2) v = sSCFQ[0];
-        else if (b >= 62) v = sSCFQ[15] + ((b == 62 ? 0.125f : 0.375f) * (sSCFQ[15] - sSCFQ[14]));
-        else {
-            int n = (b - 2) >> 2, r = (b - 2) & 3;
-            float in0 = sSCFQ[n], d = sSCFQ[n + 1] - sSCFQ[n];
-            float w = r == 0 ? 0.125f : (r == 1 ? 0.375f : (r == 2 ? 0.625f : 0.875f));
-            v = in0 + (w * d);
-        }
-        sINT[b] = v;
-    }
-    LC3_SYNC();
-    if (diff > 0) {  // :185-201
-        if (lane == 0) {
-            for (int b = 0; b < diff; b++) sINT[b] = (sINT[2 * b] + sINT[2 * b + 1]) / 2.0f;
-            for (int b = diff; b < c.nb; b++) sINT[b] = sINT[diff + 1];
-        }
-        LC3_SYNC();
-    }
-    sINT[lane] = lc3_exp2f(-sINT[lane]);  // :254-257
-    LC3_SYNC();
-    // spectral shaping :264-268 -- one lane per band (bands are 1..25 lines wide)
+}
+
+// E9 back half: spectral shaping :264-268 with the band gains the vector quantiser stage produced (HBM, 64 f32) --
+// one lane per band (bands are 1..25 lines wide)
+__device__ __noinline__ void lc3_enc_sns_apply(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const float *gains) {
+    LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
+    const uint16_t *ifs = lc3_band_index(c);
     if (lane < c.nb) {
-        lc3_scale_run(L.spec, ifs[lane], ifs[lane + 1], sINT[lane]);
+        LC3_HBM_CONST(float) g = (LC3_HBM_CONST(float))gains;
+        lc3_scale_run(L.spec, ifs[lane], ifs[lane + 1], g[lane]);
     }
-    res.ind_lf = L.ism[0];
-    res.ind_hf = L.ism[1];
-    res.shape_j = L.ism[2];
-    res.gind = L.ism[3];
-    res.ls_inda = L.ism[4];
-    res.ls_indb = L.ism[5];
-    res.index_joint_j = (uint32_t)L.ism[6];
     LC3_SYNC();
-    return res;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1660,9 +1383,16 @@ __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM
 // pcm: nf samples in HBM (4-byte aligned); plane/plane_stride: this frame's column of the packer planes
 // (lc3_dev_enc_pack.h); nbytes selects the bitrate.  dbg (optional): float[3*480] stage dumps.
 // ------------------------------------------------------------------------------------------
-// hist: see lc3_enc_mdct; g: the stream's state blob (LTPF rings); plane == nullptr marks a shadow wave that stores nothing
-__device__ __forceinline__ void lc3_encode_frame_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const int16_t *pcm,
-                                                      const int16_t *hist, lc3_enc_state *g, int32_t *plane,
+// The analysis of one frame runs in two wave-per-stream halves with the lane-per-frame SNS vector quantiser
+// (lc3_dev_enc_vq.h) between them:
+//   front: E1-E9a, E12-E16  MDCT, band energies, bandwidth, attack, SNS target scale factors, LTPF analysis
+//          -> "mid" plane column (MP_*: spectrum, targets, flags) + the packer-plane words it already knows
+//   back : E9b, E11, E17-E19  spectral shaping with the quantised gains, TNS, quantiser, residual bits, noise level
+//          -> the rest of the packer plane column
+// hist: see lc3_enc_mdct; g: the stream's state blob (LTPF rings); mid/plane == nullptr marks a shadow wave that
+// stores nothing.  dbg (optional): float[1472] stage dumps.
+__device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const int16_t *pcm,
+                                                      const int16_t *hist, lc3_enc_state *g, float *mid, int32_t *plane,
                                                       int plane_stride, int nbytes, float *dbg) {
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
@@ -1674,15 +1404,53 @@ __device__ __forceinline__ void lc3_encode_frame_wave(LC3_CFG_PARAM, lc3_enc_lds
     const int bw_ind = lc3_enc_bandwidth(LC3_CFG_PASS, LC3_LDS_PASS lane, &nbits_bw);
     const int attack = lc3_enc_attack(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes);
     LC3_STAMP(L, lane, 2);
-    const lc3_sns_res sns = lc3_enc_sns(LC3_CFG_PASS, LC3_LDS_PASS lane, attack);
+    lc3_enc_sns_front(LC3_CFG_PASS, LC3_LDS_PASS lane, attack);
+    if (mid) {  // targets and spectrum leave LDS before the LTPF stage reuses fa/fb
+        if (lane < 16) mid[MP_SCF + lane] = LC3_SCF(L)[lane];
+        lc3_wave_copy_out16(mid + MP_SPEC, L.spec, c.nf / 4, lane);
+    }
+    LC3_SYNC();
     LC3_STAMP(L, lane, 3);
+    const lc3_ltpf_res pf = lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, plane != nullptr);
+    LC3_STAMP(L, lane, 5);
+    if (dbg && lane == 0) {
+        float *d = dbg + 1440;
+        d[0] = (float)bw_ind; d[1] = (float)attack; d[9] = (float)pf.pitch_index; d[10] = (float)pf.pitch_present;
+        d[11] = (float)pf.ltpf_active; d[21] = (float)near_nyquist;
+    }
+    if (plane && mid && lane == 0) {
+        const int st = plane_stride;
+        int32_t *mf = (int32_t *)mid + MP_FLAGS;
+        mf[MPF_BW] = bw_ind;
+        mf[MPF_NBITS_BW] = nbits_bw;
+        mf[MPF_NEAR_NYQUIST] = near_nyquist;
+        mf[MPF_NBITS_LTPF] = pf.nbits_ltpf;
+        plane[EP_BW * st] = bw_ind;
+        plane[EP_NBITS_BW * st] = nbits_bw;
+        plane[EP_PITCH_PRESENT * st] = pf.pitch_present;
+        plane[EP_LTPF_ACTIVE * st] = pf.ltpf_active;
+        plane[EP_PITCH_INDEX * st] = pf.pitch_index;
+    }
+    LC3_SYNC();
+}
+
+__device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const float *mid,
+                                                     int32_t *plane, int plane_stride, int nbytes, int store, float *dbg) {
+    LC3_CFG_BIND;
+    const int nbits = nbytes * 8;
+    // pick up the frame: spectrum -> LDS (16-byte units), flags
+    lc3_wave_copy_in16(L.spec, mid + MP_SPEC, c.nf / 4, lane);
+    if (lane < 4) L.ism[lane] = ((LC3_HBM_CONST(int32_t))mid)[MP_FLAGS + lane];
+    LC3_SYNC();
+    const int bw_ind = L.ism[MPF_BW], nbits_bw = L.ism[MPF_NBITS_BW], near_nyquist = L.ism[MPF_NEAR_NYQUIST];
+    const int nbits_ltpf = L.ism[MPF_NBITS_LTPF];
+    LC3_SYNC();
+    lc3_enc_sns_apply(LC3_CFG_PASS, LC3_LDS_PASS lane, mid + MP_G);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[480 + i] = L.spec[i];
     const lc3_tns_res tns = lc3_enc_tns(LC3_CFG_PASS, LC3_LDS_PASS lane, bw_ind, nbits, near_nyquist);
     LC3_STAMP(L, lane, 4);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[960 + i] = L.spec[i];
-    const lc3_ltpf_res pf = lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, plane != nullptr);
-    LC3_STAMP(L, lane, 5);
-    const lc3_quant_res spec = lc3_enc_quant(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, nbits_bw, tns.nbits_tns, pf.nbits_ltpf);
+    const lc3_quant_res spec = lc3_enc_quant(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, nbits_bw, tns.nbits_tns, nbits_ltpf);
     LC3_STAMP(L, lane, 6);
     lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
     LC3_STAMP(L, lane, 7);
@@ -1690,19 +1458,18 @@ __device__ __forceinline__ void lc3_encode_frame_wave(LC3_CFG_PARAM, lc3_enc_lds
     LC3_SYNC();
     if (dbg && lane == 0) {
         float *d = dbg + 1440;
-        d[0] = (float)bw_ind; d[1] = (float)attack; d[2] = (float)sns.ind_lf; d[3] = (float)sns.ind_hf;
-        d[4] = (float)sns.shape_j; d[5] = (float)sns.gind; d[6] = (float)tns.rc_order[0]; d[7] = (float)tns.rc_order[1];
-        d[8] = (float)tns.nbits_tns; d[9] = (float)pf.pitch_index; d[10] = (float)pf.pitch_present;
-        d[11] = (float)pf.ltpf_active; d[12] = (float)spec.gg_ind; d[13] = (float)spec.lastnz_trunc;
+        const int st = plane_stride;
+        d[2] = (float)plane[EP_IND_LF * st]; d[3] = (float)plane[EP_IND_HF * st];
+        d[4] = (float)plane[EP_SHAPE_J * st]; d[5] = (float)plane[EP_GIND * st];
+        d[6] = (float)tns.rc_order[0]; d[7] = (float)tns.rc_order[1]; d[8] = (float)tns.nbits_tns;
+        d[12] = (float)spec.gg_ind; d[13] = (float)spec.lastnz_trunc;
         d[14] = (float)spec.nbits_lsb; d[15] = (float)spec.lsb_mode; d[16] = (float)n_res; d[17] = (float)noise_factor;
-        d[18] = spec.gg; d[19] = (float)spec.nbits_spec; d[20] = (float)spec.nbits_trunc; d[21] = (float)near_nyquist;
+        d[18] = spec.gg; d[19] = (float)spec.nbits_spec; d[20] = (float)spec.nbits_trunc;
     }
     // E20/E21 run as a separate lane-per-frame stage (lc3_dev_enc_pack.h): leave this frame's plane column in HBM
-    if (plane) {
+    if (store) {
         const int st = plane_stride;
         if (lane == 0) {
-            plane[EP_BW * st] = bw_ind;
-            plane[EP_NBITS_BW * st] = nbits_bw;
             plane[EP_LASTNZ_TRUNC * st] = spec.lastnz_trunc;
             plane[EP_LSB_MODE * st] = spec.lsb_mode;
             plane[EP_GG_IND * st] = spec.gg_ind;
@@ -1710,15 +1477,6 @@ __device__ __forceinline__ void lc3_encode_frame_wave(LC3_CFG_PARAM, lc3_enc_lds
             plane[EP_ORD0 * st] = tns.rc_order[0];
             plane[EP_ORD1 * st] = tns.rc_order[1];
             plane[EP_LPC_W * st] = tns.lpc_weighting;
-            plane[EP_PITCH_PRESENT * st] = pf.pitch_present;
-            plane[EP_LTPF_ACTIVE * st] = pf.ltpf_active;
-            plane[EP_PITCH_INDEX * st] = pf.pitch_index;
-            plane[EP_IND_LF * st] = sns.ind_lf;
-            plane[EP_IND_HF * st] = sns.ind_hf;
-            plane[EP_SHAPE_J * st] = sns.shape_j;
-            plane[EP_GIND * st] = sns.gind;
-            plane[EP_LS_INDA * st] = sns.ls_inda;
-            plane[EP_JOINT * st] = (int32_t)sns.index_joint_j;
             plane[EP_NOISE * st] = noise_factor;
             plane[EP_RATE_FLAG * st] = spec.rate_flag;
             plane[EP_N_RES * st] = n_res;

@@ -180,19 +180,67 @@ __device__ unsigned long long lc3_prof_acc[40];  // 0..31 stage sums; 32/33/34 e
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-// Analysis kernel: one wave per stream, MDCT ... quantisation, leaves one packer plane column per frame.
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_encode_kernel(lc3_cfg_slot cfg, lc3_enc_state *states,
-                                                                          int first_channel, int n_streams,
-                                                                          const int16_t *pcm, int32_t *planes, int nbytes,
-                                                                          int n_frames, int fresh, float *dbg) {
+// Analysis, front half: one wave per stream (four streams per workgroup): MDCT, band energies, bandwidth, attack,
+// SNS targets, LTPF analysis.  Leaves the mid-plane column (spectrum, targets, flags) and the first packer-plane words.
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_kernel(lc3_cfg_slot cfg, lc3_enc_state *states,
+                                                                             int first_channel, int n_streams,
+                                                                             const int16_t *pcm, float *mid, int32_t *planes,
+                                                                             int nbytes, int n_frames, int fresh, float *dbg) {
     const int lane = threadIdx.x & 63, wave = LC3_WAVE_ID();
     lc3_enc_lds &L = lc3_enc_wg[wave];
-    // stream index inside this launch; the waves past the end of the launch shadow the last stream (they take part in
-    // the workgroup barriers) and store nothing
+    // stream index inside this launch; the waves past the end of the launch shadow the last stream and store nothing
     const int s_raw = blockIdx.x * LC3_WG_WAVES + wave;
     const int valid = s_raw < n_streams;
     const int s = valid ? s_raw : n_streams - 1;
-    const int nf = lc3_cfg_table[cfg.id].nf;
+    const int nf = lc3_cfg_table[cfg.id].nf, z = lc3_cfg_table[cfg.id].z;
+    lc3_enc_state *gst = states + (size_t)(first_channel + s);
+    LC3_PROF_BEGIN(L, lane);
+    if (fresh) lc3_enc_state_init(L, lane, gst, valid);
+    else lc3_enc_state_load(L, lane, gst);
+    for (int t = 0; t < n_frames; t++) {
+        const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
+        int32_t *plane = valid ? LC3_PLANE_COL(planes, f, EP_WORDS) : nullptr;
+        float *mcol = valid ? mid + f * (size_t)MP_WORDS : nullptr;
+        const int16_t *frame = pcm + f * (size_t)nf;
+        // MDCT history: the tail of the previous frame of this launch, else the state blob's copy (silence when fresh)
+        const int16_t *hist = t > 0 ? frame - nf + z : (fresh ? nullptr : gst->hist);
+        lc3_encode_front_wave(cfg, L, lane, frame, hist, gst, mcol, plane, LC3_PLANE_STRIDE, nbytes, valid ? dbg : nullptr);
+    }
+    if (valid)
+        lc3_enc_state_store(lc3_cfg_table[cfg.id], L, lane, gst,
+                            n_frames > 0 ? pcm + ((size_t)s * (size_t)n_frames + (size_t)(n_frames - 1)) * (size_t)nf : nullptr);
+    LC3_PROF_END(L, lane, 32);
+}
+
+// SNS vector quantiser, one LANE per frame (lc3_dev_enc_vq.h): 16 targets -> indices (packer plane) + 64 band gains.
+__global__ __launch_bounds__(256) void lc3_sns_vq_kernel(int nb, float *mid, int32_t *planes, int n_frames) {
+    __shared__ uint32_t s_mpvq[16 * 11];
+    for (int i = threadIdx.x; i < 16 * 11; i += blockDim.x) s_mpvq[i] = LC3T_MPVQ_OFFSETS[i / 11][i % 11];
+    __syncthreads();
+    const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < (size_t)n_frames) {
+        lc3_vq_ctx v;
+        v.mid = mid + f * (size_t)MP_WORDS;
+        v.gains = mid + f * (size_t)MP_WORDS + MP_G;
+        v.plane = LC3_PLANE_COL(planes, f, EP_WORDS);
+        v.stride = LC3_PLANE_STRIDE;
+        v.mpvq = s_mpvq;
+        v.nb = nb;
+        lc3_sns_vq_frame(v);
+    }
+}
+
+// Analysis, back half: one wave per stream: spectral shaping with the quantised gains, TNS, quantiser (stateful),
+// residual bits, noise level.  Completes the packer plane column.
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_back_kernel(lc3_cfg_slot cfg, lc3_enc_state *states,
+                                                                            int first_channel, int n_streams,
+                                                                            const float *mid, int32_t *planes, int nbytes,
+                                                                            int n_frames, float *dbg) {
+    const int lane = threadIdx.x & 63, wave = LC3_WAVE_ID();
+    lc3_enc_lds &L = lc3_enc_wg[wave];
+    const int s_raw = blockIdx.x * LC3_WG_WAVES + wave;
+    const int valid = s_raw < n_streams;
+    const int s = valid ? s_raw : n_streams - 1;
     lc3_enc_state *gst = states + (size_t)(first_channel + s);
     {   // spectral-model tables -> LDS, once per workgroup
         const uint32_t *lk = (const uint32_t *)LC3T_AC_SPEC_LOOKUP, *bt = (const uint32_t *)&LC3T_AC_SPEC_BITS[0][0];
@@ -202,20 +250,13 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_encode_kernel(lc3_cf
         __syncthreads();
     }
     LC3_PROF_BEGIN(L, lane);
-    if (fresh) lc3_enc_state_init(L, lane, gst, valid);
-    else lc3_enc_state_load(L, lane, gst);
-    const int z = lc3_cfg_table[cfg.id].z;
+    lc3_enc_state_load(L, lane, gst);  // the front half has stored (or initialised) the scalars
     for (int t = 0; t < n_frames; t++) {
         const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
-        int32_t *plane = valid ? LC3_PLANE_COL(planes, f, EP_WORDS) : nullptr;
-        const int16_t *frame = pcm + f * (size_t)nf;
-        // MDCT history: the tail of the previous frame of this launch, else the state blob's copy (silence when fresh)
-        const int16_t *hist = t > 0 ? frame - nf + z : (fresh ? nullptr : gst->hist);
-        lc3_encode_frame_wave(cfg, L, lane, frame, hist, gst, plane, LC3_PLANE_STRIDE, nbytes, valid ? dbg : nullptr);
+        lc3_encode_back_wave(cfg, L, lane, mid + f * (size_t)MP_WORDS, LC3_PLANE_COL(planes, f, EP_WORDS), LC3_PLANE_STRIDE, nbytes,
+                             valid, valid ? dbg : nullptr);
     }
-    if (valid)
-        lc3_enc_state_store(lc3_cfg_table[cfg.id], L, lane, gst,
-                            n_frames > 0 ? pcm + ((size_t)s * (size_t)n_frames + (size_t)(n_frames - 1)) * (size_t)nf : nullptr);
+    if (valid) lc3_enc_state_store(lc3_cfg_table[cfg.id], L, lane, gst, nullptr);
     LC3_PROF_END(L, lane, 32);
 }
 
@@ -342,7 +383,7 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 3) void lc3_decode_kernel(lc3_cf
     lc3_dec_lds &L = lc3_dec_wg[wave];
     const int s_raw = blockIdx.x * LC3_WG_WAVES + wave;
     const int valid = s_raw < n_streams;
-    const int s = valid ? s_raw : n_streams - 1;  // see lc3_encode_kernel
+    const int s = valid ? s_raw : n_streams - 1;  // see lc3_enc_front_kernel
     const int nf = lc3_cfg_table[cfg.id].nf;
     lc3_dec_state *gst = states + (size_t)(first_channel + s);
     LC3_PROF_BEGIN(L, lane);
@@ -447,8 +488,9 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
 // optional per-kernel timing with HIP events recorded on the launch stream (bench.py roofline)
 struct KernelTimer {
     bool enabled = false;
-    std::vector<hipEvent_t> ev;   // triples: before stage 1, between, after stage 2
-    double ms[2] = {0.0, 0.0};
+    int stages = 2;               // kernels per batch call: stages + 1 events per call
+    std::vector<hipEvent_t> ev;
+    double ms[4] = {0.0, 0.0, 0.0, 0.0};
     long launches = 0;
     void mark(hipStream_t s) {
         if (!enabled) return;
@@ -457,15 +499,16 @@ struct KernelTimer {
         (void)hipEventRecord(e, s);
         ev.push_back(e);
     }
-    // synchronises; folds the recorded triples into ms[] and clears them
+    // synchronises; folds the recorded event groups into ms[] and clears them
     void collect() {
-        for (size_t i = 0; i + 2 < ev.size(); i += 3) {
-            float a = 0.f, b = 0.f;
-            (void)hipEventSynchronize(ev[i + 2]);
-            if (hipEventElapsedTime(&a, ev[i], ev[i + 1]) == hipSuccess &&
-                hipEventElapsedTime(&b, ev[i + 1], ev[i + 2]) == hipSuccess) {
-                ms[0] += a;
-                ms[1] += b;
+        const size_t grp = (size_t)stages + 1;
+        for (size_t i = 0; i + grp <= ev.size(); i += grp) {
+            (void)hipEventSynchronize(ev[i + grp - 1]);
+            float d[4] = {0.f, 0.f, 0.f, 0.f};
+            bool ok = true;
+            for (int k = 0; k < stages; k++) ok = ok && hipEventElapsedTime(&d[k], ev[i + k], ev[i + k + 1]) == hipSuccess;
+            if (ok) {
+                for (int k = 0; k < stages; k++) ms[k] += d[k];
                 launches += 1;
             }
         }
@@ -485,7 +528,8 @@ struct lc3gpu_encoder {
     uint8_t *d_out1 = nullptr;
     float *d_dbg = nullptr;
     std::vector<uint8_t> fresh_mask;  // per channel: 1 = still fresh
-    int32_t *d_planes = nullptr;      // packer planes [blocks of 64 frames][EP_WORDS][64]
+    int32_t *d_planes = nullptr;      // packer planes, EP_WORDS words per frame
+    float *d_mid = nullptr;           // mid planes (front half -> vector quantiser -> back half), MP_WORDS words per frame
     size_t planes_frames = 0;
 };
 
@@ -614,6 +658,7 @@ int lc3gpu_encoder_destroy(lc3gpu_encoder *e) {
     if (e->d_out1) (void)hipFree(e->d_out1);
     if (e->d_dbg) (void)hipFree(e->d_dbg);
     if (e->d_planes) (void)hipFree(e->d_planes);
+    if (e->d_mid) (void)hipFree(e->d_mid);
     delete e;
     return LC3GPU_OK;
 }
@@ -630,9 +675,12 @@ static int encoder_reserve_planes(lc3gpu_encoder *e, size_t frames) {
     if (need <= e->planes_frames) return LC3GPU_OK;
     HIP_TRY(hipDeviceSynchronize());  // growing: earlier launches may still use the old buffer
     if (e->d_planes) (void)hipFree(e->d_planes);
+    if (e->d_mid) (void)hipFree(e->d_mid);
     e->d_planes = nullptr;
+    e->d_mid = nullptr;
     e->planes_frames = 0;
     HIP_TRY(hipMalloc((void **)&e->d_planes, need * (size_t)EP_WORDS * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&e->d_mid, need * (size_t)MP_WORDS * sizeof(float)));
     e->planes_frames = need;
     return LC3GPU_OK;
 }
@@ -653,17 +701,26 @@ static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_p
         // materialise any still-fresh channel of the range with a zero-frame launch of the init path
         for (int i = first; i < first + n; i++) {
             if (e->fresh_mask[(size_t)i]) {
-                hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64 * LC3_WG_WAVES), 0, stream, e->h.slot, e->d_states, i, 1, d_pcm,
-                                   e->d_planes, nbytes, 0, 1, (float *)nullptr);
+                hipLaunchKernelGGL(lc3_enc_front_kernel, dim3(1), dim3(64 * LC3_WG_WAVES), 0, stream, e->h.slot, e->d_states, i, 1,
+                                   d_pcm, e->d_mid, e->d_planes, nbytes, 0, 1, (float *)nullptr);
                 e->fresh_mask[(size_t)i] = 0;
             }
         }
     }
-    // stage 1: analysis, one wave per stream; stage 2: bitstream packing, one lane per frame
+    // analysis front half (wave per stream) -> SNS vector quantiser (lane per frame) -> back half (wave per stream) ->
+    // bitstream packing (lane per frame)
+    const dim3 wg_grid((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), wg_block(64 * LC3_WG_WAVES);
     e->timer.mark(stream);
-    hipLaunchKernelGGL(lc3_encode_kernel, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0, stream,
-                       e->h.slot, e->d_states, first, n, d_pcm,
+    hipLaunchKernelGGL(lc3_enc_front_kernel, wg_grid, wg_block, 0, stream, e->h.slot, e->d_states, first, n, d_pcm, e->d_mid,
                        e->d_planes, nbytes, n_frames, fresh, dbg);
+    HIP_TRY(hipGetLastError());
+    e->timer.mark(stream);
+    hipLaunchKernelGGL(lc3_sns_vq_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, stream, e->h.c.nb, e->d_mid,
+                       e->d_planes, (int)frames);
+    HIP_TRY(hipGetLastError());
+    e->timer.mark(stream);
+    hipLaunchKernelGGL(lc3_enc_back_kernel, wg_grid, wg_block, 0, stream, e->h.slot, e->d_states, first, n,
+                       (const float *)e->d_mid, e->d_planes, nbytes, n_frames, dbg);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
     const unsigned fpb = lc3_frame_block(nbytes <= 220 ? 256u : 128u);
@@ -718,8 +775,8 @@ int lc3gpu_encoder_state_save(lc3gpu_encoder *e, void *host_dst) {
     // materialise fresh channels first
     for (int i = 0; i < e->num_channels; i++) {
         if (e->fresh_mask[(size_t)i]) {
-            hipLaunchKernelGGL(lc3_encode_kernel, dim3(1), dim3(64 * LC3_WG_WAVES), 0, nullptr, e->h.slot, e->d_states, i, 1, e->d_pcm1,
-                               e->d_planes, 20, 0, 1, (float *)nullptr);
+            hipLaunchKernelGGL(lc3_enc_front_kernel, dim3(1), dim3(64 * LC3_WG_WAVES), 0, nullptr, e->h.slot, e->d_states, i, 1,
+                               e->d_pcm1, e->d_mid, e->d_planes, 20, 0, 1, (float *)nullptr);
             e->fresh_mask[(size_t)i] = 0;
         }
     }
@@ -879,16 +936,22 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
 }
 
 // per-kernel timing (HIP events on the launch stream).  enable = 1 starts recording every batch launch, reading
-// synchronises and returns {stage-1 ms total, stage-2 ms total, launches} since the last read.
-int lc3gpu_encoder_timing(lc3gpu_encoder *e, int enable, double out[3]) {
+// synchronises and returns the per-kernel totals since the last read.
+// encoder: out[5] = {front ms, vector-quantiser ms, back ms, pack ms, launches}
+int lc3gpu_encoder_timing(lc3gpu_encoder *e, int enable, double out[5]) {
     if (!e) return LC3GPU_EINVAL;
+    e->timer.stages = 4;
     e->timer.collect();
-    if (out) { out[0] = e->timer.ms[0]; out[1] = e->timer.ms[1]; out[2] = (double)e->timer.launches; }
-    e->timer.ms[0] = e->timer.ms[1] = 0.0;
+    if (out) {
+        for (int k = 0; k < 4; k++) out[k] = e->timer.ms[k];
+        out[4] = (double)e->timer.launches;
+    }
+    for (int k = 0; k < 4; k++) e->timer.ms[k] = 0.0;
     e->timer.launches = 0;
     e->timer.enabled = enable != 0;
     return LC3GPU_OK;
 }
+// decoder: out[3] = {parse+reconstruct ms, synthesis ms, launches}
 int lc3gpu_decoder_timing(lc3gpu_decoder *d, int enable, double out[3]) {
     if (!d) return LC3GPU_EINVAL;
     d->timer.collect();
@@ -917,7 +980,7 @@ int lc3gpu_prof_read(unsigned long long out[40]) {
 int lc3gpu_kernel_info(int which, int out[5]) {
     if (!out) return LC3GPU_EINVAL;
     hipFuncAttributes a;
-    hipError_t e = which == 0 ? hipFuncGetAttributes(&a, (const void *)lc3_encode_kernel)
+    hipError_t e = which == 0 ? hipFuncGetAttributes(&a, (const void *)lc3_enc_back_kernel)
                               : hipFuncGetAttributes(&a, (const void *)lc3_decode_kernel);
     if (e != hipSuccess) {
         g_last_hip = (int)e;

@@ -75,7 +75,8 @@ namespace {
 struct Job {
     lc3_cfg cfg;
     int lane, wave, valid;
-    int encode;
+    int encode;   // 0 decode, 1 encoder front half, 2 encoder back half
+    float *mid;   // mid planes of the whole batch (encoder)
     int n_frames, nbytes, fresh;
     lc3_enc_lds *EL;  // the workgroup's array of working sets
     lc3_dec_lds *DL;
@@ -95,20 +96,30 @@ void *lane_main(void *arg) {
     Job *j = (Job *)arg;
     const int lane = j->lane;
     tl_wave = j->wave;
-    if (j->encode) {
+    if (j->encode == 1) {  // body of lc3_enc_front_kernel
         lc3_enc_lds &L = j->EL[j->wave];
         if (j->fresh) lc3_enc_state_init(L, lane, j->est, j->valid);
         else lc3_enc_state_load(L, lane, j->est);
         for (int t = 0; t < j->n_frames; t++) {
             const size_t f = j->frame0 + (size_t)t;
             int32_t *plane = j->valid ? LC3_PLANE_COL(j->enc_planes, f, EP_WORDS) : nullptr;
+            float *mcol = j->valid ? j->mid + f * (size_t)MP_WORDS : nullptr;
             const int16_t *frame = j->pcm_in + (size_t)t * j->cfg.nf;
             const int16_t *hist = t > 0 ? frame - j->cfg.nf + j->cfg.z : (j->fresh ? nullptr : j->est->hist);
-            lc3_encode_frame_wave(j->cfg, L, lane, frame, hist, j->est, plane, LC3_PLANE_STRIDE, j->nbytes,
+            lc3_encode_front_wave(j->cfg, L, lane, frame, hist, j->est, mcol, plane, LC3_PLANE_STRIDE, j->nbytes,
                                   j->valid ? j->dbg : nullptr);
         }
         if (j->valid)
             lc3_enc_state_store(j->cfg, L, lane, j->est, j->n_frames > 0 ? j->pcm_in + (size_t)(j->n_frames - 1) * j->cfg.nf : nullptr);
+    } else if (j->encode == 2) {  // body of lc3_enc_back_kernel
+        lc3_enc_lds &L = j->EL[j->wave];
+        lc3_enc_state_load(L, lane, j->est);
+        for (int t = 0; t < j->n_frames; t++) {
+            const size_t f = j->frame0 + (size_t)t;
+            lc3_encode_back_wave(j->cfg, L, lane, j->mid + f * (size_t)MP_WORDS, LC3_PLANE_COL(j->enc_planes, f, EP_WORDS),
+                                 LC3_PLANE_STRIDE, j->nbytes, j->valid, j->valid ? j->dbg : nullptr);
+        }
+        if (j->valid) lc3_enc_state_store(j->cfg, L, lane, j->est, nullptr);
     } else {
         lc3_dec_lds &L = j->DL[j->wave];
         if (j->fresh) lc3_dec_state_init(L, lane, j->dst, j->valid);
@@ -167,26 +178,46 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
     const size_t frames = (size_t)S * (size_t)T;
     std::vector<int32_t> planes(((frames + 63) / 64) * 64 * EP_WORDS, 0);
     lc3_enc_lds *L = (lc3_enc_lds *)aligned_alloc(16, LC3_WG_WAVES * sizeof(lc3_enc_lds));
-    lc3_enc_state *st = (lc3_enc_state *)aligned_alloc(16, LC3_WG_WAVES * sizeof(lc3_enc_state));
+    lc3_enc_state *st = (lc3_enc_state *)aligned_alloc(16, (size_t)S * sizeof(lc3_enc_state));  // one blob per stream
+    float *mid = (float *)aligned_alloc(16, frames * (size_t)MP_WORDS * sizeof(float));
+    memset(st, 0, (size_t)S * sizeof(lc3_enc_state));
+    memset(mid, 0, frames * (size_t)MP_WORDS * sizeof(float));
     j.EL = L;
     j.enc_planes = planes.data();
-    for (int s0 = 0; s0 < S; s0 += LC3_WG_WAVES) {
-        Job protos[LC3_WG_WAVES];
-        memset(L, 0, LC3_WG_WAVES * sizeof(lc3_enc_lds));
-        memset(st, 0, LC3_WG_WAVES * sizeof(lc3_enc_state));
-        for (int w = 0; w < LC3_WG_WAVES; w++) {
-            // waves past the end of the batch shadow the last stream and store nothing (as in lc3_encode_kernel)
-            const int valid = s0 + w < S, s = valid ? s0 + w : S - 1;
-            protos[w] = j;
-            protos[w].valid = valid;
-            protos[w].est = st + w;
-            protos[w].pcm_in = pcm + (size_t)s * T * j.cfg.nf;
-            protos[w].frame0 = (size_t)s * T;
+    j.mid = mid;
+    for (int phase = 1; phase <= 2; phase++) {
+        // phase 1: front halves of every workgroup; then the lane-per-frame vector quantiser; phase 2: back halves
+        for (int s0 = 0; s0 < S; s0 += LC3_WG_WAVES) {
+            Job protos[LC3_WG_WAVES];
+            memset(L, 0, LC3_WG_WAVES * sizeof(lc3_enc_lds));
+            for (int w = 0; w < LC3_WG_WAVES; w++) {
+                // waves past the end of the batch shadow the last stream and store nothing (as in the kernels)
+                const int valid = s0 + w < S, s = valid ? s0 + w : S - 1;
+                protos[w] = j;
+                protos[w].encode = phase;
+                protos[w].valid = valid;
+                protos[w].est = st + s;
+                protos[w].pcm_in = pcm + (size_t)s * T * j.cfg.nf;
+                protos[w].frame0 = (size_t)s * T;
+            }
+            run_wg(protos);
         }
-        run_wg(protos);
+        if (phase == 1) {
+            for (size_t f = 0; f < frames; f++) {  // lc3_sns_vq_kernel
+                lc3_vq_ctx v;
+                v.mid = mid + f * (size_t)MP_WORDS;
+                v.gains = mid + f * (size_t)MP_WORDS + MP_G;
+                v.plane = LC3_PLANE_COL(planes.data(), f, EP_WORDS);
+                v.stride = LC3_PLANE_STRIDE;
+                v.mpvq = &LC3T_MPVQ_OFFSETS[0][0];
+                v.nb = j.cfg.nb;
+                lc3_sns_vq_frame(v);
+            }
+        }
     }
     free(L);
     free(st);
+    free(mid);
     // stage 2: the lane-per-frame bitstream packer (lc3_dev_enc_pack.h) -- on the GPU 64 frames per wave
     std::vector<uint32_t> cf(64 * 17);
     for (int p = 0; p < 64; p++)

@@ -37,21 +37,24 @@ for _ in range(5):
     dec.decode(d_b, d_o, 150, T, stream=st)
 torch.cuda.synchronize()
 acc = api.prof_read()
-names = {26: "enc sns: pad, smooth, pre-emph, floor, log2", 27: "enc sns: grouping, mean, attack", 28: "enc sns: stage-1 codebooks",
-         29: "enc sns: stage-2 target", 30: "enc sns: pulse search", 31: "enc sns: normalise, gain search, enumeration",
-         9: "enc quant: energies+max", 10: "enc quant: gain bisection", 11: "enc quant: first quantise+bit count",
-         12: "enc ltpf: shift+resample", 13: "enc ltpf: 50 Hz high-pass", 14: "enc ltpf: pitch detection",
-         15: "enc ltpf: lag refinement", 22: "dec spectrum: residual+noise fill", 24: "dec spectrum: gain, serial phase (tns lattice, sns scale factors)", 25: "dec imdct: dct-iv",
-         1: "enc mdct+energy", 2: "enc bandwidth+attack", 3: "enc sns (rest: synthesis, interpolation, shaping)", 4: "enc tns", 5: "enc ltpf (rest: activation)", 6: "enc quant (rest: adjust + 2nd pass)",
-         7: "enc residual+noise", 8: "enc plane store", 17: "dec load parsed frame (planes) + epilogue",
-         18: "dec spectrum (rest: band scaling, plc save)", 19: "dec imdct (rest: window+ola)", 20: "dec ltpf", 21: "dec output"}
+names = {1: "front: mdct+energy", 2: "front: bandwidth+attack", 26: "front: sns pad, smooth, pre-emph, floor, log2",
+         27: "front: sns grouping, mean, attack smoothing", 3: "front: targets + spectrum -> mid plane",
+         12: "front: ltpf shift+resample", 13: "front: ltpf 50 Hz high-pass", 14: "front: ltpf pitch detection",
+         15: "front: ltpf lag refinement", 5: "front: ltpf activation, ring store",
+         4: "back: load mid plane, shaping, tns", 9: "back: quant energies+max", 10: "back: quant gain bisection",
+         11: "back: quant first quantise+bit count", 6: "back: quant adjust + 2nd pass", 7: "back: residual+noise",
+         8: "back: plane store",
+         17: "dec load reconstructed frame (plane)", 18: "dec plc save/load", 25: "dec imdct: dct-iv",
+         19: "dec imdct: window+ola", 20: "dec ltpf", 21: "dec output"}
 frames = 5 * S * T
-for lo, hi, label in ((1, 16, "encoder analysis kernel"), (26, 32, "  (encoder, continued)"), (17, 26, "decoder synthesis kernel")):
-    tot = sum(acc[lo:hi])
+enc_ids = [1, 2, 26, 27, 3, 12, 13, 14, 15, 5, 4, 9, 10, 11, 6, 7, 8]
+dec_ids = [17, 18, 25, 19, 20, 21]
+for ids, label in ((enc_ids, "encoder analysis kernels (front + back)"), (dec_ids, "decoder synthesis kernel")):
+    tot = sum(acc[i] for i in ids)
     print(f"{label}: {tot / frames:.0f} wave-cycles per frame (sum over stages, S={S} T={T})")
-    for i in range(lo, hi):
-        if i in names: print(f"  {names[i]:48s} {acc[i] / frames:10.0f} cyc/frame  {100.0 * acc[i] / max(tot, 1):5.1f} %")
-for base, label in ((32, "encoder"), (35, "decoder")):
+    for i in ids:
+        print(f"  {names[i]:48s} {acc[i] / frames:10.0f} cyc/frame  {100.0 * acc[i] / max(tot, 1):5.1f} %")
+for base, label in ((32, "encoder front+back"), (35, "decoder")):
     tot, mx, n = acc[base], acc[base + 1], max(acc[base + 2], 1)
     print(f"{label} waves: {n} launches-waves, mean whole-wave time {tot / n:.0f} cyc ({tot / n / T:.0f} per frame), max {mx} cyc "
           f"(x{mx / (tot / n):.2f} of the mean)")
