@@ -194,18 +194,26 @@ def main():
         # the vector quantiser and the back half touch no algorithmic bytes (their traffic is the planes between kernels)
         alg_bytes = {"lc3_enc_front_kernel": 2 * NF, "lc3_sns_vq_kernel": 0, "lc3_enc_back_kernel": 0, "lc3_pack_kernel": NBYTES,
                      "lc3_parse_kernel": NBYTES, "lc3_decode_kernel": 2 * NF}
-        dom = max(kernel_ms, key=kernel_ms.get)
-        dom_ms, alg = kernel_ms[dom], alg_bytes[dom]
+        # The analysis of a frame is three kernels since the SNS vector quantiser moved to its own lane-per-frame stage
+        # (front half, quantiser, back half): they are reported as ONE unit for the roofline, with the frame's PCM as its
+        # algorithmic bytes -- otherwise the longest single kernel (the back half) would have no algorithmic bytes at all.
+        groups = {"analysis (lc3_enc_front_kernel + lc3_sns_vq_kernel + lc3_enc_back_kernel)":
+                  ["lc3_enc_front_kernel", "lc3_sns_vq_kernel", "lc3_enc_back_kernel"],
+                  "lc3_pack_kernel": ["lc3_pack_kernel"], "lc3_parse_kernel": ["lc3_parse_kernel"],
+                  "lc3_decode_kernel": ["lc3_decode_kernel"]}
+        group_ms = {g: sum(kernel_ms[k] for k in ks) for g, ks in groups.items()}
+        dom = max(group_ms, key=group_ms.get)
+        dom_ms, alg = group_ms[dom], sum(alg_bytes[k] for k in groups[dom])
         value = total_frames / elapsed
         achieved = frames_per_step * alg / (dom_ms * 1e-3) / 1e9
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside this
+        # HBM bytes per launch of the dominant unit from the committed PMC passes (rocprofv3 cannot run inside this
         # process); scaled to this run's frames per launch
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")) as f:
                 tj = json.load(f)
-            kk = tj["kernels"][dom]
-            traffic = (kk["fetch_size_kb_per_launch"] + kk["write_size_kb_per_launch"]) * 1024.0 * frames_per_step / tj["frames_per_launch"]
+            traffic = sum(tj["kernels"][k]["fetch_size_kb_per_launch"] + tj["kernels"][k]["write_size_kb_per_launch"]
+                          for k in groups[dom]) * 1024.0 * frames_per_step / tj["frames_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
         line = {
@@ -245,7 +253,7 @@ def main():
                 "roundtrip_achieved_GBs": value * (ALG_BYTES_ENC + ALG_BYTES_DEC) / 1e9 / world,
                 "note": "instruction/latency-bound, not HBM-bound (SURVEY 8d honesty note): ~60 flop per algorithmic byte; "
                         "traffic = FETCH_SIZE + WRITE_SIZE of this kernel from profiles/hbm_traffic_latest.json (bytes per "
-                        "launch); instruction mix and wait counters in profiles/r01_v7_pmc_summary.csv, DESIGN.md section 5",
+                        "launch); instruction mix and wait counters in profiles/r01_v9_pmc_summary.csv, DESIGN.md section 5",
             },
             "cpu_baseline": cpu,
             "parity": parity,

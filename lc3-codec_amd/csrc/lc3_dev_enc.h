@@ -1438,6 +1438,7 @@ __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PARAM, lc3_enc_lds 
                                                      int32_t *plane, int plane_stride, int nbytes, int store, float *dbg) {
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
+    LC3_STAMP(L, lane, 0);
     // pick up the frame: spectrum -> LDS (16-byte units), flags
     lc3_wave_copy_in16(L.spec, mid + MP_SPEC, c.nf / 4, lane);
     if (lane < 4) L.ism[lane] = ((LC3_HBM_CONST(int32_t))mid)[MP_FLAGS + lane];

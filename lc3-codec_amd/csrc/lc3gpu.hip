@@ -40,6 +40,13 @@
         __builtin_amdgcn_wave_barrier();                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
     } while (0)
+#ifndef LC3_BACK_WAVES
+#define LC3_BACK_WAVES 4
+#endif
+#ifndef LC3_SPEC_IN_LDS
+#define LC3_SPEC_IN_LDS 1
+#endif
+#if LC3_SPEC_IN_LDS
 // per-workgroup LDS copy of the spectral-model tables used by the analysis kernel's bit estimate (6.1 KB)
 struct lc3_spec_tables {
     uint8_t lookup[4096];
@@ -48,6 +55,7 @@ struct lc3_spec_tables {
 __shared__ lc3_spec_tables lc3_spec_tab;
 #define LC3_SPEC_LOOKUP(i) ((int)lc3_spec_tab.lookup[(i)])
 #define LC3_SPEC_BITS(p, j) ((uint32_t)lc3_spec_tab.bits[(p) * 17 + (j)])
+#endif
 #define LC3_LDS_DECL(T, arr) __shared__ T arr[LC3_WG_WAVES];
 #define LC3_LDS_PARAM(T)
 #define LC3_LDS_PASS
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(256) void lc3_sns_vq_kernel(int nb, float *mid, int
 
 // Analysis, back half: one wave per stream: spectral shaping with the quantised gains, TNS, quantiser (stateful),
 // residual bits, noise level.  Completes the packer plane column.
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_back_kernel(lc3_cfg_slot cfg, lc3_enc_state *states,
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_back_kernel(lc3_cfg_slot cfg, lc3_enc_state *states,
                                                                             int first_channel, int n_streams,
                                                                             const float *mid, int32_t *planes, int nbytes,
                                                                             int n_frames, float *dbg) {
@@ -242,6 +250,7 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_back_kernel(lc3_
     const int valid = s_raw < n_streams;
     const int s = valid ? s_raw : n_streams - 1;
     lc3_enc_state *gst = states + (size_t)(first_channel + s);
+#if LC3_SPEC_IN_LDS
     {   // spectral-model tables -> LDS, once per workgroup
         const uint32_t *lk = (const uint32_t *)LC3T_AC_SPEC_LOOKUP, *bt = (const uint32_t *)&LC3T_AC_SPEC_BITS[0][0];
         uint32_t *dl = (uint32_t *)lc3_spec_tab.lookup, *db = (uint32_t *)lc3_spec_tab.bits;
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_back_kernel(lc3_
         for (int i = threadIdx.x; i < 64 * 17 / 2; i += 64 * LC3_WG_WAVES) db[i] = bt[i];
         __syncthreads();
     }
+#endif
     LC3_PROF_BEGIN(L, lane);
     lc3_enc_state_load(L, lane, gst);  // the front half has stored (or initialised) the scalars
     for (int t = 0; t < n_frames; t++) {
