@@ -127,6 +127,7 @@ struct lc3_cfg {
     // mixed-radix plan of the nf/2-point complex FFT (common/kissfft.rs:47-76)
     int nfft, n_stages;
     int radix[6], m[6], fstride[6];
+    int inv_m[6];  // ceil(2^16 / m[s]): u / m[s] == (u * inv_m[s]) >> 16 for every butterfly index u < nfft (host plan checks)
     // device tables owned by the codec handle
     const lc3_cpx *fft_tw;  // exp(-2*pi*i*k/nfft), f64 -> f32 (kissfft.rs:19-27)
     const lc3_cpx *dct_tw;  // exp(-i*pi*(8n+1)/(8*nf)), f64 -> f32 (dct_iv.rs:30-35)
@@ -137,6 +138,7 @@ struct lc3_cfg {
     // polyphase layout of the resampling low-pass: row ph (0..p_up-1) holds taps k = -lim..lim of phase ph, zero padded
     // to resamp_nt (multiple of 4) taps, rows resamp_stride floats apart (lc3_resamp_poly_value)
     int resamp_lim, resamp_nt, resamp_stride;
+    int inv_p;     // ceil(2^16 / p_up): x / p_up == (x * inv_p) >> 16 for x = 15 n, n < len12
     const float *resamp_poly;
     // decoder LTPF (decoder/long_term_post_filter.rs:104-134)
     int l_den, l_num, num_mem_blocks, norm, s25;
@@ -797,7 +799,7 @@ __device__ __forceinline__ void lc3_dct4_wave(const lc3_cfg &c, int lane, float 
         const int p = c.radix[s], m = c.m[s], fstride = c.fstride[s];
         const int nb = cnt / p;
         for (int u = lane; u < nb; u += LC3_WAVE) {
-            int blk = u / m, i = u - blk * m;
+            const int blk = (u * c.inv_m[s]) >> 16, i = u - blk * m;  // u / m without an integer division
             lc3_bfly(fb + blk * p * m, c.fft_tw, p, fstride, m, i);
         }
         LC3_SYNC();

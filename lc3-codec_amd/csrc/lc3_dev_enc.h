@@ -703,9 +703,10 @@ __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARA
         float *o12 = x12 + c.delay12 + LC3_NMEM;
         const int n0 = lane, has1 = lane + LC3_WAVE < len12;
         const int n1 = has1 ? lane + LC3_WAVE : lane;
-        const int16_t *xa = xs + c.hist + (15 * n0) / p - 2 * lim;  // tap j <-> k = j - lim
-        const int16_t *xb = xs + c.hist + (15 * n1) / p - 2 * lim;
-        const float *ha = S + ((15 * n0) % p) * c.resamp_stride, *hb = S + ((15 * n1) % p) * c.resamp_stride;
+        const int q0 = (15 * n0 * c.inv_p) >> 16, q1 = (15 * n1 * c.inv_p) >> 16;  // 15 n / p without integer divisions
+        const int16_t *xa = xs + c.hist + q0 - 2 * lim;  // tap j <-> k = j - lim
+        const int16_t *xb = xs + c.hist + q1 - 2 * lim;
+        const float *ha = S + (15 * n0 - q0 * p) * c.resamp_stride, *hb = S + (15 * n1 - q1 * p) * c.resamp_stride;
         float acc0 = 0.0f, acc1 = 0.0f;
         for (int j = 0; j < nt; j += 4) {
             const lc3_f4 a = *(const lc3_f4 *)(ha + j), b = *(const lc3_f4 *)(hb + j);

@@ -51,6 +51,9 @@ static inline int lc3_make_config(lc3_cfg &c, int frame_us, int fs_hz) {
     default: c.p_up = 4; break;
     }
     c.hist = 240 / c.p_up;
+    c.inv_p = (65536 + c.p_up - 1) / c.p_up;
+    for (int x = 0; x < 15 * 128; x++)
+        if (((x * c.inv_p) >> 16) != x / c.p_up) return -1;
     c.resamp_lim = 120 / c.p_up;
     c.resamp_nt = (2 * c.resamp_lim + 1 + 3) & ~3;
     c.resamp_stride = c.resamp_nt + 4;  // row pitch: keeps the p rows on different LDS banks
@@ -96,6 +99,11 @@ static inline int lc3_make_plan(lc3_cfg &c, lc3_host_plan &pl) {
             if (n <= 1) break;
         }
         c.n_stages = i;
+        for (int s2 = 0; s2 < i; s2++) {
+            c.inv_m[s2] = (65536 + c.m[s2] - 1) / c.m[s2];
+            for (int u = 0; u < nfft; u++)
+                if (((u * c.inv_m[s2]) >> 16) != u / c.m[s2]) return -1;
+        }
     }
     pl.fft_tw.resize((size_t)nfft);
     pl.dct_tw.resize((size_t)nfft);
