@@ -36,7 +36,8 @@ struct lc3_enc_state {
 static_assert(sizeof(lc3_enc_scalars) == 64 && sizeof(lc3_enc_state) % 16 == 0 && offsetof(lc3_enc_state, sc) % 16 == 0,
               "encoder state blob: 16-byte units");
 
-// LDS working set of one encoder wave: 8 KB -> five workgroups of four streams per CU.  Buffers are reused as their
+// LDS working set of one encoder wave: 8 KB (room for five workgroups of four streams per CU; the kernels run four,
+// bound by registers).  Buffers are reused as their
 // contents die: `t` holds the MDCT time buffer until the LTPF resampler has read it, then the 6.4 kHz ring (LTPF) and
 // finally the quantised spectrum and the residual bits; fa/fb are the FFT buffers and every later stage's scratch.
 struct __attribute__((aligned(16))) lc3_enc_lds {
@@ -61,19 +62,12 @@ LC3_LDS_DECL(lc3_enc_lds, lc3_enc_wg)
 static_assert(offsetof(lc3_enc_lds, fa) % 16 == 0 && offsetof(lc3_enc_lds, spec) % 16 == 0 && offsetof(lc3_enc_lds, t) % 16 == 0,
               "128-bit LDS reads need aligned buffers");
 #ifndef LC3_PROFILE
-static_assert(sizeof(lc3_enc_lds) <= 8192, "encoder working set must stay within 8 KB (20 waves per CU)");
+static_assert(sizeof(lc3_enc_lds) <= 8192, "encoder working set: 8 KB per stream (the kernels run 16 waves per CU, register-bound)");
 #endif
 
-struct lc3_sns_res { int ind_lf, ind_hf, shape_j, gind, ls_inda, ls_indb; uint32_t index_joint_j; };
 struct lc3_tns_res { int nbits_tns, lpc_weighting, num_tns_filters; int rc_order[2]; };  // rc_i / rc_q live in LDS
 struct lc3_ltpf_res { int pitch_index, pitch_present, ltpf_active, nbits_ltpf; };
 struct lc3_quant_res { int gg_ind, nbits_spec, nbits_lsb, nbits_trunc, lsb_mode, rate_flag, lastnz_trunc; float gg; };
-
-// ------------------------------------------------------------------------------------------
-// wave helpers
-// ------------------------------------------------------------------------------------------
-// broadcast an int / float computed by lane 0 through LDS slot `slot` of L.ism
-#define LC3_BCAST_I(L, slot, val) ((L).ism[slot])
 
 // order global-memory traffic of the wave's lanes among themselves (state rings written by some lanes, read by others)
 #ifndef LC3_HBM_FENCE

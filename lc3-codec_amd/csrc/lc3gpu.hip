@@ -1,10 +1,12 @@
 // lc3gpu -- kernels and C ABI of the MI355X-native batched LC3 codec.  gfx950 only.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.build()).
 //
-// Launch geometry: one workgroup = one wavefront (64 threads) = one stream.  A launch covers
-// `n_channels` streams x `n_frames` frames; the wave loads its stream state from HBM into LDS once,
-// runs the frames in time order and writes the state back.  blockIdx -> stream is the identity:
-// streams share nothing but the read-only tables, so XCD placement only affects table L2 hits.
+// Six kernels.  Stream kernels (lc3_enc_front_kernel, lc3_enc_back_kernel, lc3_decode_kernel): one workgroup = four
+// wavefronts = four streams; a launch covers `n_streams` streams x `n_frames` frames, each wave loads its stream's
+// state scalars from HBM into LDS once, runs the frames in time order and writes the state back.  Frame kernels
+// (lc3_sns_vq_kernel, lc3_pack_kernel, lc3_parse_kernel): one LANE per frame for the serial, frame-local stages.
+// Stages meet in HBM "planes" (one contiguous column of words per frame).  blockIdx -> stream / frame is the identity:
+// streams share nothing but read-only tables, so XCD placement only affects table L2 hits.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
