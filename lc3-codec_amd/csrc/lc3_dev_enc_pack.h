@@ -104,31 +104,37 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
     w.bp = 0;
     w.bp_side = w.nbytes - 1;
     w.mask_side = 1;
-    const int lsb_mode = lc3_ep_get(w, EP_LSB_MODE), lastnz_trunc = lc3_ep_get(w, EP_LASTNZ_TRUNC);
-    const int num_tns = lc3_ep_get(w, EP_NUM_TNS), rate_flag = lc3_ep_get(w, EP_RATE_FLAG);
-    const int ord0 = lc3_ep_get(w, EP_ORD0), ord1 = lc3_ep_get(w, EP_ORD1);
+    // the 21 scalar words and the 16 TNS indices of the column: one batch of independent loads (a lane of this kernel
+    // is latency-bound; every plane word fetched at its point of use would cost a full memory round trip)
+    int32_t sw[EP_RES];
+#pragma unroll
+    for (int i = 0; i < EP_RES; i++) sw[i] = lc3_ep_get(w, i);
+#define LC3_EPW(word) sw[word]
+    const int lsb_mode = LC3_EPW(EP_LSB_MODE), lastnz_trunc = LC3_EPW(EP_LASTNZ_TRUNC);
+    const int num_tns = LC3_EPW(EP_NUM_TNS), rate_flag = LC3_EPW(EP_RATE_FLAG);
+    const int ord0 = LC3_EPW(EP_ORD0), ord1 = LC3_EPW(EP_ORD1);
     // side information :92-112 (layout: SURVEY App. E)
     {
-        const int nbits_bw = lc3_ep_get(w, EP_NBITS_BW);
-        if (nbits_bw > 0) lc3_pk_uint_backward(w, (uint32_t)lc3_ep_get(w, EP_BW), nbits_bw);
+        const int nbits_bw = LC3_EPW(EP_NBITS_BW);
+        if (nbits_bw > 0) lc3_pk_uint_backward(w, (uint32_t)LC3_EPW(EP_BW), nbits_bw);
         int nb = 0;
         while ((1 << nb) < ne / 2) nb++;
         lc3_pk_uint_backward(w, (uint32_t)((lastnz_trunc >> 1) - 1), nb);
         lc3_pk_bool_backward(w, lsb_mode);
-        lc3_pk_uint_backward(w, (uint32_t)lc3_ep_get(w, EP_GG_IND), 8);
+        lc3_pk_uint_backward(w, (uint32_t)LC3_EPW(EP_GG_IND), 8);
         if (num_tns > 0) lc3_pk_bool_backward(w, ord0 != 0);
         if (num_tns > 1) lc3_pk_bool_backward(w, ord1 != 0);
-        const int pitch_present = lc3_ep_get(w, EP_PITCH_PRESENT);
+        const int pitch_present = LC3_EPW(EP_PITCH_PRESENT);
         lc3_pk_bool_backward(w, pitch_present);
-        lc3_pk_uint_backward(w, (uint32_t)lc3_ep_get(w, EP_IND_LF), 5);
-        lc3_pk_uint_backward(w, (uint32_t)lc3_ep_get(w, EP_IND_HF), 5);
-        const int shape_j = lc3_ep_get(w, EP_SHAPE_J);
-        const uint32_t joint = (uint32_t)lc3_ep_get(w, EP_JOINT);
+        lc3_pk_uint_backward(w, (uint32_t)LC3_EPW(EP_IND_LF), 5);
+        lc3_pk_uint_backward(w, (uint32_t)LC3_EPW(EP_IND_HF), 5);
+        const int shape_j = LC3_EPW(EP_SHAPE_J);
+        const uint32_t joint = (uint32_t)LC3_EPW(EP_JOINT);
         const int submode_msb = (shape_j >> 1) != 0;
         lc3_pk_bool_backward(w, submode_msb);
-        lc3_pk_uint_backward(w, (uint32_t)(lc3_ep_get(w, EP_GIND) >> LC3T_SNS_GAIN_LSB_BITS[shape_j]),
+        lc3_pk_uint_backward(w, (uint32_t)(LC3_EPW(EP_GIND) >> LC3T_SNS_GAIN_LSB_BITS[shape_j]),
                              LC3T_SNS_GAIN_MSB_BITS[shape_j]);
-        lc3_pk_bool_backward(w, lc3_ep_get(w, EP_LS_INDA) != 0);
+        lc3_pk_bool_backward(w, LC3_EPW(EP_LS_INDA) != 0);
         if (!submode_msb) {
             lc3_pk_uint_backward(w, joint, 13);
             lc3_pk_uint_backward(w, joint >> 13, 12);
@@ -137,10 +143,10 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
             lc3_pk_uint_backward(w, joint >> 12, 12);
         }
         if (pitch_present) {
-            lc3_pk_bool_backward(w, lc3_ep_get(w, EP_LTPF_ACTIVE));
-            lc3_pk_uint_backward(w, (uint32_t)lc3_ep_get(w, EP_PITCH_INDEX), 9);
+            lc3_pk_bool_backward(w, LC3_EPW(EP_LTPF_ACTIVE));
+            lc3_pk_uint_backward(w, (uint32_t)LC3_EPW(EP_PITCH_INDEX), 9);
         }
-        lc3_pk_uint_backward(w, (uint32_t)lc3_ep_get(w, EP_NOISE), 3);
+        lc3_pk_uint_backward(w, (uint32_t)LC3_EPW(EP_NOISE), 3);
     }
     // ac_enc_init :216-222
     w.low = 0;
@@ -150,14 +156,17 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
     w.carry_count = 0;
     // tns_data :224-244
     {
-        const int wt = lc3_ep_get(w, EP_LPC_W);
+        const int wt = LC3_EPW(EP_LPC_W);
         for (int f = 0; f < num_tns; f++) {
             const int order = f == 0 ? ord0 : ord1;
             if (order > 0) {
                 lc3_pk_ac_encode(w, (uint32_t)(int)LC3T_AC_TNS_ORDER_CUMFREQ[wt][order - 1],
                                  (uint32_t)(int)LC3T_AC_TNS_ORDER_FREQ[wt][order - 1]);
                 for (int k = 0; k < order; k++) {
-                    int ri = lc3_ep_get(w, EP_RCI + k + 8 * f);
+                    int ri = 0;
+#pragma unroll
+                    for (int q = 0; q < 16; q++)
+                        if (q == k + 8 * f) ri = sw[EP_RCI + q];
                     ri = ri < 0 ? 0 : (ri > 16 ? 16 : ri);
                     lc3_pk_ac_encode(w, (uint32_t)(int)LC3T_AC_TNS_COEF_CUMFREQ[k][ri],
                                      (uint32_t)(int)LC3T_AC_TNS_COEF_FREQ[k][ri]);
@@ -170,37 +179,51 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
     {
         int cctx = 0;
         const int ntup = lastnz_trunc / 2;
-        for (int tup = 0; tup < ntup; tup++) {
-            const int k = 2 * tup;
-            int t = cctx + rate_flag + (k > ne / 2 ? 256 : 0), lev = 0, q0, q1;
-            lc3_ep_pair(w, tup, q0, q1);
-            unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
-            unsigned a_lsb = a, b_lsb = b;
-            while ((a > b ? a : b) >= 4) {
-                const uint32_t sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + 16];
-                lc3_pk_ac_encode(w, sv & 0xffffu, sv >> 16);
-                if (!(lsb_mode && lev == 0)) {
-                    lc3_pk_bool_backward(w, (a & 1u) == 1u);
-                    lc3_pk_bool_backward(w, (b & 1u) == 1u);
+        // the quantised pairs are fetched eight tuples at a time, one group ahead of their use
+        uint32_t xcur[8], xnext[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) xcur[j] = j < ne / 2 ? (uint32_t)lc3_ep_get(w, EP_XQ + j) : 0u;
+        for (int tup0 = 0; tup0 < ntup; tup0 += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) xnext[j] = tup0 + 8 + j < ne / 2 ? (uint32_t)lc3_ep_get(w, EP_XQ + tup0 + 8 + j) : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int tup = tup0 + j;
+                if (tup < ntup) {
+                    const int k = 2 * tup;
+                    int t = cctx + rate_flag + (k > ne / 2 ? 256 : 0), lev = 0;
+                    const int q0 = (int)(int16_t)(xcur[j] & 0xffffu), q1 = (int)(int16_t)(xcur[j] >> 16);
+                    unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
+                    unsigned a_lsb = a, b_lsb = b;
+                    while ((a > b ? a : b) >= 4) {
+                        const uint32_t sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + 16];
+                        lc3_pk_ac_encode(w, sv & 0xffffu, sv >> 16);
+                        if (!(lsb_mode && lev == 0)) {
+                            lc3_pk_bool_backward(w, (a & 1u) == 1u);
+                            lc3_pk_bool_backward(w, (b & 1u) == 1u);
+                        }
+                        a >>= 1;
+                        b >>= 1;
+                        lev += 1;
+                    }
+                    {
+                        const uint32_t sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + (int)(a + 4 * b)];
+                        lc3_pk_ac_encode(w, sv & 0xffffu, sv >> 16);
+                    }
+                    if (lsb_mode && lev > 0) {  // the LSB list itself is regenerated below when it is written
+                        a_lsb >>= 1;
+                        b_lsb >>= 1;
+                        nlsbs += 2 + (a_lsb == 0 && q0 != 0) + (b_lsb == 0 && q1 != 0);
+                    }
+                    if (a_lsb > 0) lc3_pk_bool_backward(w, q0 <= 0);
+                    if (b_lsb > 0) lc3_pk_bool_backward(w, q1 <= 0);
+                    lev = lev < 3 ? lev : 3;
+                    t = lev <= 1 ? 1 + (int)(a + b) * (lev + 1) : 12 + lev;
+                    cctx = (cctx & 15) * 16 + t;
                 }
-                a >>= 1;
-                b >>= 1;
-                lev += 1;
             }
-            {
-                const uint32_t sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + (int)(a + 4 * b)];
-                lc3_pk_ac_encode(w, sv & 0xffffu, sv >> 16);
-            }
-            if (lsb_mode && lev > 0) {  // the LSB list itself is regenerated below when it is written
-                a_lsb >>= 1;
-                b_lsb >>= 1;
-                nlsbs += 2 + (a_lsb == 0 && q0 != 0) + (b_lsb == 0 && q1 != 0);
-            }
-            if (a_lsb > 0) lc3_pk_bool_backward(w, q0 <= 0);
-            if (b_lsb > 0) lc3_pk_bool_backward(w, q1 <= 0);
-            lev = lev < 3 ? lev : 3;
-            t = lev <= 1 ? 1 + (int)(a + b) * (lev + 1) : 12 + lev;
-            cctx = (cctx & 15) * 16 + t;
+#pragma unroll
+            for (int j = 0; j < 8; j++) xcur[j] = xnext[j];
         }
     }
     // residual_data_and_finalization :328-352
@@ -212,7 +235,7 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
         int n_enc = w.nbits - (nbits_side + nbits_ari);
         if (n_enc < 0) n_enc = 0;
         if (!lsb_mode) {
-            const int n_res = lc3_ep_get(w, EP_N_RES);
+            const int n_res = LC3_EPW(EP_N_RES);
             if (n_enc > n_res) n_enc = n_res;
             for (int k = 0; k < n_enc; k += 32) {
                 uint32_t bits = (uint32_t)lc3_ep_get(w, EP_RES + (k >> 5));
@@ -280,4 +303,5 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
             lc3_pk_uint_forward(w, (unsigned)w.cache, bits);
         }
     }
+#undef LC3_EPW
 }
