@@ -420,9 +420,15 @@ __device__ __forceinline__ float lc3_r_band_gain(const lc3_recon_ctx &r, int bi,
 
 __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3_recon_ctx &r, const lc3_cfg &cfg) {
     const int ne = cfg.ne, nbytes = c.len, nbits = nbytes * 8;
-    const int lsb_mode = lc3_px_get(c, SI_LSB_MODE), lastnz = lc3_px_get(c, SI_LASTNZ), gg_ind = lc3_px_get(c, SI_GG);
-    const int tail0 = lc3_px_get(c, AD_TAIL0), nres_max = lc3_px_get(c, AD_NRES_MAX), head = lc3_px_get(c, AD_HEAD);
-    const int bw = lc3_px_get(c, SI_BW);
+    // the side-information words of the column in one batch of independent loads (a lane of this kernel is
+    // latency-bound: a word fetched at its point of use costs a full memory round trip)
+    int32_t siw[SI_WORDS];
+#pragma unroll
+    for (int i = 0; i < SI_WORDS; i++) siw[i] = lc3_px_get(c, i);
+#define LC3_SIW(word) siw[word]
+    const int lsb_mode = LC3_SIW(SI_LSB_MODE), lastnz = LC3_SIW(SI_LASTNZ), gg_ind = LC3_SIW(SI_GG);
+    const int tail0 = LC3_SIW(AD_TAIL0), nres_max = LC3_SIW(AD_NRES_MAX), head = LC3_SIW(AD_HEAD);
+    const int bw = LC3_SIW(SI_BW);
     // decode_residual_bits :168-183: one tail bit per non-zero line, at most nres_max.  Every read_tail_bool bound check
     // is monotone in the bit position, so checking the last position covers all of them.
     int n_res = 0;
@@ -443,12 +449,12 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
         int y[16];
 #pragma unroll
         for (int n = 0; n < 16; n++) y[n] = 0;
-        const int shape_j = (lc3_px_get(c, SI_SUB_MSB) << 1) + lc3_px_get(c, SI_SUB_LSB);
-        const int ls_a = lc3_px_get(c, SI_LS_A);
-        const uint32_t idx_a = (uint32_t)lc3_px_get(c, SI_IDX_A);
+        const int shape_j = (LC3_SIW(SI_SUB_MSB) << 1) + LC3_SIW(SI_SUB_LSB);
+        const int ls_a = LC3_SIW(SI_LS_A);
+        const uint32_t idx_a = (uint32_t)LC3_SIW(SI_IDX_A);
         if (shape_j == 0) {
             lc3_r_deenum(r, 10, 10, ls_a, idx_a, y, 0);
-            lc3_r_deenum(r, 6, 1, lc3_px_get(c, SI_LS_B), (uint32_t)lc3_px_get(c, SI_IDX_B), y, 10);
+            lc3_r_deenum(r, 6, 1, LC3_SIW(SI_LS_B), (uint32_t)LC3_SIW(SI_IDX_B), y, 10);
         } else if (shape_j == 1) lc3_r_deenum(r, 10, 10, ls_a, idx_a, y, 0);
         else if (shape_j == 2) lc3_r_deenum(r, 16, 8, ls_a, idx_a, y, 0);
         else lc3_r_deenum(r, 16, 6, ls_a, idx_a, y, 0);
@@ -457,13 +463,13 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
         for (int n = 0; n < 16; n++) y_norm += (float)y[n] * (float)y[n];
         y_norm = lc3_sqrtf(y_norm);
         float gain;
-        const int gi = lc3_px_get(c, SI_G_IND);
+        const int gi = LC3_SIW(SI_G_IND);
         if (shape_j == 0) gain = lc3_f(LC3T_SNS_VQ_REG_ADJ_GAINS_BITS, gi & 1);
         else if (shape_j == 1) gain = lc3_f(LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS, gi & 3);
         else if (shape_j == 2) gain = lc3_f(LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS, gi & 3);
         else gain = lc3_f(LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS, gi & 7);
         if (y_norm != 0.0f) gain /= y_norm;
-        const int ind_lf = lc3_px_get(c, SI_IND_LF), ind_hf = lc3_px_get(c, SI_IND_HF);
+        const int ind_lf = LC3_SIW(SI_IND_LF), ind_hf = LC3_SIW(SI_IND_HF);
         for (int n = 0; n < 16; n++) {
             float factor = 0.0f;
 #pragma unroll
@@ -480,9 +486,9 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
         gg = lc3_pow10f(((float)gg_ind + (float)gg_off) / 28.0f);
     }
     // TNS :24-137: all-pole lattice, state shared across both filters
-    const int nbands = bw < 3 ? 1 : 2, num_tns = lc3_px_get(c, SI_NUM_TNS);
-    const int ord0 = (0 < nbands && 0 < num_tns) ? lc3_px_get(c, AD_ORD0) : 0;
-    const int ord1 = (1 < nbands && 1 < num_tns) ? lc3_px_get(c, AD_ORD0 + 1) : 0;
+    const int nbands = bw < 3 ? 1 : 2, num_tns = LC3_SIW(SI_NUM_TNS);
+    const int ord0 = (0 < nbands && 0 < num_tns) ? LC3_SIW(AD_ORD0) : 0;
+    const int ord1 = (1 < nbands && 1 < num_tns) ? LC3_SIW(AD_ORD0 + 1) : 0;
     const int lo0 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][0] : LC3C_TNSDEC75[bw][0];
     const int hi0 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][1] : LC3C_TNSDEC75[bw][1];
     const int lo1 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][2] : LC3C_TNSDEC75[bw][2];
@@ -492,14 +498,14 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     int order = ord0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const int ri = lc3_px_get(c, AD_RCI + k);
+        const int ri = LC3_SIW(AD_RCI + k);
         rq[k] = ri != 0 ? lc3_sinf_small(step * (float)(ri - 8)) : 0.0f;
     }
     // noise filling :18-56
     const int bw_stop = cfg.n_ms_10 ? LC3C_BWSTOP10[bw] : LC3C_BWSTOP75[bw];
     const int nf_start = cfg.n_ms_10 ? 24 : 18, nf_width = cfg.n_ms_10 ? 3 : 2;
     const int lim = bw_stop < ne ? bw_stop : ne;
-    const float level = (8.0f - (float)lc3_px_get(c, SI_NF)) / 16.0f;
+    const float level = (8.0f - (float)LC3_SIW(SI_NF)) / 16.0f;
     // window of non-zero flags: bit (j + 3) <-> line k + j, j = -3 .. 3, lines at or beyond bw_stop count as zero.
     // The integers are fetched from the plane four lines at a time, two groups ahead of their use (xw holds lines
     // k0 .. k0+11 of the current group of four), so that the loads of a group have a whole group's work to land.
@@ -541,7 +547,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
                 order = ord1;
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    const int ri = lc3_px_get(c, AD_RCI + 8 + q);
+                    const int ri = LC3_SIW(AD_RCI + 8 + q);
                     rq[q] = ri != 0 ? lc3_sinf_small(step * (float)(ri - 8)) : 0.0f;
                 }
             }
@@ -574,5 +580,6 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
 #pragma unroll
         for (int j = 0; j < 4; j++) xw[8 + j] = xnext[j];
     }
+#undef LC3_SIW
     return 1;
 }
