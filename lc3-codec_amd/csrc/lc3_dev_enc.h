@@ -1321,26 +1321,35 @@ __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM
     //    (the f32 sum keeps the reference's order).
     const int ne = c.ne;
     float *compact = (float *)L.fa;          // relevant |x| / gg values, in line order (<= 376)
-    uint32_t *part = (uint32_t *)L.sm;       // [0,64) non-zero counts, [64,128) relevant counts
     const int bw_stop = c.n_ms_10 ? LC3C_BWSTOP10[bw_ind] : LC3C_BWSTOP75[bw_ind];
     const int nf_start = c.n_ms_10 ? 24 : 18, nf_width = c.n_ms_10 ? 3 : 2;
     const int nf_stop = ne < bw_stop ? ne : bw_stop;
     int mx = q.nbits_spec - q.nbits_trunc + 4;  // nbits_residual_max (encoder/residual_spectrum.rs:42-43)
     if (mx < 0) mx = 0;
     const int k0 = 7 * lane;
+    // the lane's seven lines and three neighbours on either side: thirteen quantised values and spectrum lines fetched
+    // once; bit i of nz13 <-> line k0 - 3 + i is non-zero (lines outside [0, bw_stop) count as zero: the reference's
+    // window is clipped at bw_stop and never reaches below line 0)
+    int16_t xv[13];
+    float sv[7];
+    uint32_t nz13 = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const int k = k0 - 3 + i;
+        xv[i] = (k >= 0 && k < ne) ? LC3_XQ(L)[k] : (int16_t)0;
+        if (xv[i] != 0 && k < bw_stop) nz13 |= 1u << i;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; j++) sv[j] = k0 + j < ne ? L.spec[k0 + j] : 0.0f;
     uint32_t nzmask = 0, relmask = 0;
+    const uint32_t win = nf_width == 3 ? 0x7Fu : 0x3Eu;  // lines k-3..k+3 or k-2..k+2 relative to bit j
 #pragma unroll
     for (int j = 0; j < 7; j++) {
         const int k = k0 + j;
         if (k < ne) {
-            if (LC3_XQ(L)[k] != 0) nzmask |= 1u << j;
-            if (k >= nf_start && k < nf_stop) {  // encoder/noise_level_estimation.rs:35-42
-                const int from = k - nf_width, to = bw_stop < k + nf_width + 1 ? bw_stop : k + nf_width + 1;
-                int r = 1;
-                for (int i = from; i < to; i++)
-                    if (LC3_XQ(L)[i] != 0) r = 0;
-                if (r) relmask |= 1u << j;
-            }
+            if (xv[j + 3] != 0) nzmask |= 1u << j;
+            // encoder/noise_level_estimation.rs:35-42: x_q[k - w .. min(bw_stop, k + w + 1)) all zero
+            if (k >= nf_start && k < nf_stop && ((nz13 >> j) & win) == 0) relmask |= 1u << j;
         }
     }
     const uint32_t cnt_nz = (uint32_t)__builtin_popcount(nzmask), cnt_rel = (uint32_t)__builtin_popcount(relmask);
@@ -1351,10 +1360,10 @@ __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM
         const int k = k0 + j;
         if (k < ne) {
             if (nzmask & (1u << j)) {
-                if (rank_nz < mx) LC3_RESB(L)[rank_nz] = (uint8_t)(L.spec[k] >= (float)LC3_XQ(L)[k] * q.gg);  // :50-55
+                if (rank_nz < mx) LC3_RESB(L)[rank_nz] = (uint8_t)(sv[j] >= (float)xv[j + 3] * q.gg);  // :50-55
                 rank_nz++;
             }
-            if (relmask & (1u << j)) compact[rank_rel++] = lc3_absf(L.spec[k]) / q.gg;
+            if (relmask & (1u << j)) compact[rank_rel++] = lc3_absf(sv[j]) / q.gg;
         }
     }
     LC3_SYNC();
@@ -1429,14 +1438,40 @@ __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_PARAM, lc3_enc_lds
     LC3_SYNC();
 }
 
+// A frame's mid-plane words in flight: the back half issues the loads of frame t + 1 before it works on frame t and
+// keeps them in registers (two 16-byte units of spectrum per lane, one flag word on lanes 0..3)
+struct lc3_mid_fetch {
+    lc3_i4 u[2];
+    int32_t flag;
+};
+__device__ __forceinline__ void lc3_mid_issue(const lc3_cfg &c, int lane, const float *mid, lc3_mid_fetch &m) {
+    LC3_HBM_CONST(lc3_i4) s4 = (LC3_HBM_CONST(lc3_i4))(mid + MP_SPEC);
+    const int n4 = c.nf / 4;  // <= 120
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int i = lane + LC3_WAVE * j;
+        if (i < n4) m.u[j] = s4[i];
+    }
+    m.flag = lane < 4 ? ((LC3_HBM_CONST(int32_t))mid)[MP_FLAGS + lane] : 0;
+}
+
+// m: this frame's mid-plane words, fetched by lc3_mid_issue
 __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const float *mid,
-                                                     int32_t *plane, int plane_stride, int nbytes, int store, float *dbg) {
+                                                     const lc3_mid_fetch &m, int32_t *plane, int plane_stride, int nbytes,
+                                                     int store, float *dbg) {
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
     // pick up the frame: spectrum -> LDS (16-byte units), flags
-    lc3_wave_copy_in16(L.spec, mid + MP_SPEC, c.nf / 4, lane);
-    if (lane < 4) L.ism[lane] = ((LC3_HBM_CONST(int32_t))mid)[MP_FLAGS + lane];
+    {
+        const int n4 = c.nf / 4;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int i = lane + LC3_WAVE * j;
+            if (i < n4) ((lc3_i4 *)L.spec)[i] = m.u[j];
+        }
+        if (lane < 4) L.ism[lane] = m.flag;
+    }
     LC3_SYNC();
     const int bw_ind = L.ism[MPF_BW], nbits_bw = L.ism[MPF_NBITS_BW], near_nyquist = L.ism[MPF_NEAR_NYQUIST];
     const int nbits_ltpf = L.ism[MPF_NBITS_LTPF];

@@ -263,10 +263,16 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_bac
 #endif
     LC3_PROF_BEGIN(L, lane);
     lc3_enc_state_load(L, lane, gst);  // the front half has stored (or initialised) the scalars
+    const lc3_cfg &c0 = lc3_cfg_table[cfg.id];
+    const size_t fbase = (size_t)s * (size_t)n_frames;
+    lc3_mid_fetch cur, nxt;
+    if (n_frames > 0) lc3_mid_issue(c0, lane, mid + fbase * (size_t)MP_WORDS, cur);
     for (int t = 0; t < n_frames; t++) {
-        const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
-        lc3_encode_back_wave(cfg, L, lane, mid + f * (size_t)MP_WORDS, LC3_PLANE_COL(planes, f, EP_WORDS), LC3_PLANE_STRIDE, nbytes,
-                             valid, valid ? dbg : nullptr);
+        const size_t f = fbase + (size_t)t;
+        if (t + 1 < n_frames) lc3_mid_issue(c0, lane, mid + (f + 1) * (size_t)MP_WORDS, nxt);  // lands while frame t is worked on
+        lc3_encode_back_wave(cfg, L, lane, mid + f * (size_t)MP_WORDS, cur, LC3_PLANE_COL(planes, f, EP_WORDS), LC3_PLANE_STRIDE,
+                             nbytes, valid, valid ? dbg : nullptr);
+        cur = nxt;
     }
     if (valid) lc3_enc_state_store(lc3_cfg_table[cfg.id], L, lane, gst, nullptr);
     LC3_PROF_END(L, lane, 32);

@@ -114,10 +114,16 @@ void *lane_main(void *arg) {
     } else if (j->encode == 2) {  // body of lc3_enc_back_kernel
         lc3_enc_lds &L = j->EL[j->wave];
         lc3_enc_state_load(L, lane, j->est);
+        lc3_mid_fetch cur, nxt;
+        memset(&cur, 0, sizeof(cur));
+        memset(&nxt, 0, sizeof(nxt));
+        if (j->n_frames > 0) lc3_mid_issue(j->cfg, lane, j->mid + j->frame0 * (size_t)MP_WORDS, cur);
         for (int t = 0; t < j->n_frames; t++) {
             const size_t f = j->frame0 + (size_t)t;
-            lc3_encode_back_wave(j->cfg, L, lane, j->mid + f * (size_t)MP_WORDS, LC3_PLANE_COL(j->enc_planes, f, EP_WORDS),
+            if (t + 1 < j->n_frames) lc3_mid_issue(j->cfg, lane, j->mid + (f + 1) * (size_t)MP_WORDS, nxt);
+            lc3_encode_back_wave(j->cfg, L, lane, j->mid + f * (size_t)MP_WORDS, cur, LC3_PLANE_COL(j->enc_planes, f, EP_WORDS),
                                  LC3_PLANE_STRIDE, j->nbytes, j->valid, j->valid ? j->dbg : nullptr);
+            cur = nxt;
         }
         if (j->valid) lc3_enc_state_store(j->cfg, L, lane, j->est, nullptr);
     } else {
