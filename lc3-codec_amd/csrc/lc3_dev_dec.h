@@ -256,22 +256,25 @@ __device__ __noinline__ void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_l
 // information words -> L.ism, reconstructed spectrum (f32, D4-D8 applied) -> L.spec.  One 16-byte unit per lane and load,
 // both loads in flight together.  Returns 1 when the frame is usable, 0 -> conceal.
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_dec_load_frame(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const int32_t *plane) {
-    LC3_CFG_BIND;
-    LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
+// The plane words of a frame in flight (two 16-byte units per lane): the kernel issues the loads of frame t + 1 before
+// it works on frame t, so the memory latency hides behind a frame's worth of work.
+struct lc3_plane_fetch { lc3_i4 u[2]; };
+__device__ __forceinline__ void lc3_dec_issue_frame(const lc3_cfg &c, int lane, const int32_t *plane, lc3_plane_fetch &m) {
     LC3_HBM_CONST(lc3_i4) p4 = (LC3_HBM_CONST(lc3_i4))((LC3_HBM_CONST(int32_t))plane + LC3_PLANE_SI);
-    const int n_si4 = (LC3_PLANE_X - LC3_PLANE_SI) / 4, n4 = n_si4 + c.ne / 4;
-    lc3_i4 pv[2];
+    const int n4 = (LC3_PLANE_X - LC3_PLANE_SI) / 4 + c.ne / 4;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int i = lane + LC3_WAVE * u;
-        if (i < n4) pv[u] = p4[i];
+        if (i < n4) m.u[u] = p4[i];
     }
+}
+__device__ __forceinline__ int lc3_dec_load_frame(const lc3_cfg &c, lc3_dec_lds &L, int lane, const lc3_plane_fetch &m) {
+    const int n_si4 = (LC3_PLANE_X - LC3_PLANE_SI) / 4, n4 = n_si4 + c.ne / 4;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int i = lane + LC3_WAVE * u;
-        if (i < n_si4) ((lc3_i4 *)L.ism)[i] = pv[u];
-        else if (i < n4) ((lc3_i4 *)L.spec)[i - n_si4] = pv[u];
+        if (i < n_si4) ((lc3_i4 *)L.ism)[i] = m.u[u];
+        else if (i < n4) ((lc3_i4 *)L.spec)[i - n_si4] = m.u[u];
     }
     LC3_SYNC();
     const int ok = L.ism[AD_OK];
@@ -326,13 +329,13 @@ __device__ __noinline__ void lc3_dec_plc_load(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_d
 // in: nbytes in HBM; pcm_out: nf samples in HBM (4-byte aligned); plane/stride: the frame's parsed column
 // (lc3_dev_dec_parse.h); g: the stream's state blob in HBM.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, const uint8_t *in,
-                                                      int nbytes, int16_t *pcm_out, const int32_t *plane, int stride,
-                                                      lc3_dec_state *g, int valid) {
+__device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes,
+                                                      int16_t *pcm_out, const lc3_plane_fetch &fetched, lc3_dec_state *g,
+                                                      int valid) {
     LC3_CFG_BIND;
     const int nf = c.nf, nbits = nbytes * 8;
     LC3_STAMP(L, lane, 16);
-    const int ok = lc3_dec_load_frame(LC3_CFG_PASS, LC3_LDS_PASS lane, plane);
+    const int ok = lc3_dec_load_frame(c, L, lane, fetched);
     LC3_STAMP(L, lane, 17);
     int ltpf_active = 0, pitch_index = 0;
     if (ok) {

@@ -408,11 +408,16 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 3) void lc3_decode_kernel(lc3_cf
     if (fresh) lc3_dec_state_init(L, lane, gst, valid);
     else lc3_dec_state_load(L, lane, gst);
     LC3_PROF_MARK(L, lane, 38);  // state load
+    (void)in;  // the frame bytes were consumed by the lane-per-frame stage
+    const lc3_cfg &c0 = lc3_cfg_table[cfg.id];
+    const size_t fbase = (size_t)s * (size_t)n_frames;
+    lc3_plane_fetch cur, nxt;
+    if (n_frames > 0) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, fbase, LC3_PLANE_WORDS), cur);
     for (int t = 0; t < n_frames; t++) {
-        const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
-        const int32_t *plane = LC3_PLANE_COL(planes, f, LC3_PLANE_WORDS);
-        lc3_decode_frame_wave(cfg, L, lane, in + f * (size_t)nbytes, nbytes, pcm + f * (size_t)nf, plane, LC3_PLANE_STRIDE, gst,
-                              valid);
+        const size_t f = fbase + (size_t)t;
+        if (t + 1 < n_frames) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, f + 1, LC3_PLANE_WORDS), nxt);
+        lc3_decode_frame_wave(cfg, L, lane, nbytes, pcm + f * (size_t)nf, cur, gst, valid);
+        cur = nxt;
     }
     LC3_PROF_MARK(L, lane, 39);  // frames (incl. everything between the stage stamps)
     if (valid) lc3_dec_state_store(L, lane, gst);

@@ -130,11 +130,15 @@ void *lane_main(void *arg) {
         lc3_dec_lds &L = j->DL[j->wave];
         if (j->fresh) lc3_dec_state_init(L, lane, j->dst, j->valid);
         else lc3_dec_state_load(L, lane, j->dst);
+        lc3_plane_fetch cur, nxt;
+        memset(&cur, 0, sizeof(cur));
+        memset(&nxt, 0, sizeof(nxt));
+        if (j->n_frames > 0) lc3_dec_issue_frame(j->cfg, lane, LC3_PLANE_COL(j->planes, j->frame0, LC3_PLANE_WORDS), cur);
         for (int t = 0; t < j->n_frames; t++) {
             const size_t f = j->frame0 + (size_t)t;
-            const int32_t *plane = LC3_PLANE_COL(j->planes, f, LC3_PLANE_WORDS);
-            lc3_decode_frame_wave(j->cfg, L, lane, j->bytes_in + (size_t)t * j->nbytes, j->nbytes,
-                                  j->pcm_out + (size_t)t * j->cfg.nf, plane, LC3_PLANE_STRIDE, j->dst, j->valid);
+            if (t + 1 < j->n_frames) lc3_dec_issue_frame(j->cfg, lane, LC3_PLANE_COL(j->planes, f + 1, LC3_PLANE_WORDS), nxt);
+            lc3_decode_frame_wave(j->cfg, L, lane, j->nbytes, j->pcm_out + (size_t)t * j->cfg.nf, cur, j->dst, j->valid);
+            cur = nxt;
         }
         if (j->valid) lc3_dec_state_store(L, lane, j->dst);
     }
