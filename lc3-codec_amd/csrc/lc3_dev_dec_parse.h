@@ -39,7 +39,13 @@ struct lc3_parse_ctx {
     int stride;
     int head, tail;          // BufferReader cursors (decoder/buffer_reader.rs:11-15)
     uint32_t nnz, seed;      // running count of non-zero lines and sum |x_k| * k (noise-filling seed :140-145, wrapping)
+#ifdef LC3_PROFILE
+    unsigned long long plast, pt[8];  // diagnostic build: section stamps
+#endif
 };
+#ifndef LC3_PSTAMP
+#define LC3_PSTAMP(c, id)
+#endif
 
 __device__ __forceinline__ void lc3_px_set(lc3_parse_ctx &c, int word, int32_t v) { c.plane[word * c.stride] = v; }
 __device__ __forceinline__ int32_t lc3_px_get(const lc3_parse_ctx &c, int word) { return c.plane[word * c.stride]; }
@@ -248,6 +254,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
     c.seed = 0;
     int rc = lc3_parse_side_info(c, fs_ind, ne, lastnz, lsb_mode, num_tns, ord);
     if (rc) return rc;
+    LC3_PSTAMP(c, 0);
     const int nbits = c.len * 8;
     lc3_acdec st;
     int sym = 0;
@@ -274,6 +281,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             lc3_px_set(c, AD_ORD0 + f, order);
         }
     }
+    LC3_PSTAMP(c, 1);
     // decode_spectral_data :211-302
     const int ntup = lastnz / 2;
     {
@@ -316,6 +324,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             cctx = (cctx & 15) * 16 + t;
         }
     }
+    LC3_PSTAMP(c, 2);
     for (int k = lastnz; k < ne; k++) lc3_px_set(c, LC3_PLANE_X + k, 0);  // :131-133
     // calc_num_residual_bits :385-405
     {
@@ -339,6 +348,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             }
         }
     }
+    LC3_PSTAMP(c, 3);
     return 0;
 }
 
@@ -506,6 +516,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     const int nf_start = cfg.n_ms_10 ? 24 : 18, nf_width = cfg.n_ms_10 ? 3 : 2;
     const int lim = bw_stop < ne ? bw_stop : ne;
     const float level = (8.0f - (float)LC3_SIW(SI_NF)) / 16.0f;
+    LC3_PSTAMP(c, 4);
     // window of non-zero flags: bit (j + 3) <-> line k + j, j = -3 .. 3, lines at or beyond bw_stop count as zero.
     // The integers are fetched from the plane four lines at a time, two groups ahead of their use (xw holds lines
     // k0 .. k0+11 of the current group of four), so that the loads of a group have a whole group's work to land.
@@ -519,6 +530,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     const uint32_t winmask = nf_width == 3 ? 0x7Fu : 0x3Eu;  // lines k-3..k+3 or k-2..k+2
     const uint16_t *ifs = lc3_band_index(cfg);
     int bi = 0, rank_nz = 0;
+    int band_end = (int)ifs[1];  // first line of the next band (kept in a register: one table read per band, not per line)
     float g_band = lc3_r_band_gain(r, 0, cfg.nb);
     for (int k0 = 0; k0 < ne; k0 += 4) {  // ne is a multiple of 4
         int32_t xnext[4];
@@ -565,8 +577,9 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
                 v = t;
                 st[0] = t;
             }
-            while (k >= (int)ifs[bi + 1]) {  // band of line k (bands are contiguous and non-empty below ne)
+            while (k >= band_end) {  // band of line k (bands are contiguous and non-empty below ne)
                 bi++;
+                band_end = (int)ifs[bi + 1];
                 g_band = lc3_r_band_gain(r, bi, cfg.nb);
             }
             v *= g_band;
@@ -580,6 +593,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
 #pragma unroll
         for (int j = 0; j < 4; j++) xw[8 + j] = xnext[j];
     }
+    LC3_PSTAMP(c, 5);
 #undef LC3_SIW
     return 1;
 }

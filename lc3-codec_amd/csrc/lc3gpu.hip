@@ -143,7 +143,7 @@ __device__ __forceinline__ uint32_t lc3_wave_exscan_u32(uint32_t u, int lane) {
 // stage stamps into a per-wave table in LDS (stamp i accumulates the time since the previous stamp into slot i);
 // the table is flushed to a global one with one atomic per slot at the end of the launch, so the stamps do not put
 // memory traffic inside the stages.  Never timed as a whole; read its SHARES (cdna_hip_programming.md section 7).
-__device__ unsigned long long lc3_prof_acc[40];  // 0..31 stage sums; 32/33/34 enc wave time sum/max/count, 35/36/37 dec
+__device__ unsigned long long lc3_prof_acc[48];  // 0..31 stage sums; 32/33/34 enc wave time sum/max/count, 35/36/37 dec; 40..47 parse kernel
 #undef LC3_STAMP
 #define LC3_STAMP(L, lane, id)                                                     \
     do {                                                                           \
@@ -152,6 +152,13 @@ __device__ unsigned long long lc3_prof_acc[40];  // 0..31 stage sums; 32/33/34 e
             if ((id) != 0 && (id) != 16) (L).prof_acc[(id)] += t_ - (L).prof_last; \
             (L).prof_last = t_;                                                    \
         }                                                                          \
+    } while (0)
+// lane-per-frame parse kernel: wave-level sections (lane 0 of each wave reports), slots 40..47
+#define LC3_PSTAMP(c, id)                                              \
+    do {                                                               \
+        const unsigned long long t_ = clock64();                       \
+        if ((id) >= 0) (c).pt[(id)] += t_ - (c).plast;                 \
+        (c).plast = t_;                                                \
     } while (0)
 #define LC3_PROF_BEGIN(L, lane)                                   \
     do {                                                          \
@@ -380,6 +387,10 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot cfg, const 
         c.stride = LC3_PLANE_STRIDE;
         c.head = 0;
         c.tail = 0;
+#ifdef LC3_PROFILE
+        for (int i = 0; i < 8; i++) c.pt[i] = 0;
+        c.plast = clock64();
+#endif
         const int rc = (bad && bad[f]) ? -100 : lc3_parse_frame(c, ne, fs_ind, n_ms_10);
         int ok = rc == 0;
         if (ok) {
@@ -390,6 +401,11 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot cfg, const 
             ok = lc3_reconstruct_frame(c, r, c0);
         }
         lc3_px_set(c, AD_OK, ok);
+#ifdef LC3_PROFILE
+        LC3_PSTAMP(c, 6);
+        if ((tid & 63) == 0)
+            for (int i = 0; i < 8; i++) atomicAdd(&lc3_prof_acc[40 + i], c.pt[i]);
+#endif
     }
 }
 
@@ -986,10 +1002,10 @@ int lc3gpu_decoder_timing(lc3gpu_decoder *d, int enable, double out[3]) {
 }
 
 // diagnostic build only: copy (and clear) the per-stage cycle accumulators; LC3GPU_EUNSUPPORTED otherwise
-int lc3gpu_prof_read(unsigned long long out[40]) {
+int lc3gpu_prof_read(unsigned long long out[48]) {
 #ifdef LC3_PROFILE
     if (!out) return LC3GPU_EINVAL;
-    unsigned long long zero[40] = {0};
+    unsigned long long zero[48] = {0};
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(lc3_prof_acc), sizeof(zero)));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lc3_prof_acc), zero, sizeof(zero)));

@@ -59,3 +59,10 @@ for base, label in ((32, "encoder front+back"), (35, "decoder")):
     print(f"{label} waves: {n} launches-waves, mean whole-wave time {tot / n:.0f} cyc ({tot / n / T:.0f} per frame), max {mx} cyc "
           f"(x{mx / (tot / n):.2f} of the mean)")
 print(f"decoder: state load {acc[38] / max(acc[37], 1):.0f} cyc per wave, frame loop {acc[39] / max(acc[37], 1):.0f} cyc per wave")
+pn = ["side information", "TNS data", "spectral data (range decoder)", "zero fill, LSB refinement", "reconstruction set-up (SNS scale factors, gain, TNS coefficients)",
+      "reconstruction pass over the lines", "rest"]
+waves = 5 * S * T / 64
+ptot = sum(acc[40:47])
+print(f"parse kernel: {ptot / waves:.0f} cycles per wave of 64 frames")
+for i, nme in enumerate(pn):
+    print(f"  {nme:70s} {acc[40 + i] / waves:10.0f} cyc/wave  {100.0 * acc[40 + i] / max(ptot, 1):5.1f} %")
