@@ -536,23 +536,28 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
         int32_t xnext[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) xnext[j] = k0 + 12 + j < ne ? lc3_px_get(c, LC3_PLANE_X + k0 + 12 + j) : 0;
+        // The per-line work is written with selects, not branches: the conditions differ from lane to lane (each lane is
+        // another frame), and a divergent branch costs more scalar bookkeeping than the few operations it would skip.
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int k = k0 + j;
             const int32_t xi = xw[j];
             float v = (float)xi;
-            if (xi != 0) {
-                if (rank_nz < n_res) {  // residual_spectrum::decode: the j-th non-zero line takes tail bit tail0 + j
-                    const int pos = tail0 + rank_nz;
-                    const int bit = (c.bytes[nbytes - 1 - pos / 8] >> (pos % 8)) & 1;
-                    if (bit) v += v > 0.0f ? 0.3125f : 0.1875f;
-                    else v -= v > 0.0f ? 0.1875f : 0.3125f;
-                }
-                rank_nz++;
+            {   // residual_spectrum::decode: the j-th non-zero line takes tail bit tail0 + j while j < n_res
+                const int nz = xi != 0, take = nz && rank_nz < n_res;
+                const int pos = tail0 + rank_nz;
+                const int bidx = take ? nbytes - 1 - (pos >> 3) : 0;
+                const int bit = (c.bytes[bidx] >> (pos & 7)) & 1;
+                const float up = v > 0.0f ? 0.3125f : 0.1875f, dn = v > 0.0f ? 0.1875f : 0.3125f;
+                const float v_adj = bit ? v + up : v - dn;
+                v = take ? v_adj : v;
+                rank_nz += nz;
             }
-            if (do_fill && k >= nf_start && k < lim && (nzwin & winmask) == 0) {
-                lcg = (13849u + lcg * 31821u) & 0xFFFFu;
-                v = lcg < 0x8000u ? level : -level;
+            {   // noise filling: next LCG state and a +-level line where the neighbourhood is empty
+                const int fill = do_fill && k >= nf_start && k < lim && (nzwin & winmask) == 0;
+                const uint32_t lcg_n = (13849u + lcg * 31821u) & 0xFFFFu;
+                lcg = fill ? lcg_n : lcg;
+                v = fill ? (lcg_n < 0x8000u ? level : -level) : v;
             }
             v *= gg;
             if (k == lo1 && nbands == 2) {  // second filter: its coefficients, the lattice memory carries over
@@ -563,19 +568,22 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
                     rq[q] = ri != 0 ? lc3_sinf_small(step * (float)(ri - 8)) : 0.0f;
                 }
             }
-            if (order > 0 && ((k >= lo0 && k < hi0) || (nbands == 2 && k >= lo1 && k < hi1))) {
+            {   // TNS synthesis lattice: stages q < ord_eff are live on this lane for this line.
+                // t = x - rc[order-1]*st[order-1]; then q = order-2 .. 0: t -= rc[q]*st[q]; st[q+1] = rc[q]*t + st[q]
+                const int in_range = (k >= lo0 && k < hi0) || (nbands == 2 && k >= lo1 && k < hi1);
+                const int ord_eff = in_range ? order : 0;
                 float t = v;
-                // t = x - rc[order-1]*st[order-1]; then k = order-2 .. 0
 #pragma unroll
                 for (int q = 7; q >= 0; q--) {
-                    if (q == order - 1) t -= rq[q] * st[q];
-                    else if (q < order - 1) {
-                        t -= rq[q] * st[q];
-                        st[q + 1] = rq[q] * t + st[q];
+                    const float t2 = t - rq[q] * st[q];
+                    t = q < ord_eff ? t2 : t;
+                    if (q < 7) {
+                        const float sn = rq[q] * t + st[q];
+                        st[q + 1] = q + 1 < ord_eff ? sn : st[q + 1];
                     }
                 }
                 v = t;
-                st[0] = t;
+                st[0] = ord_eff > 0 ? t : st[0];
             }
             while (k >= band_end) {  // band of line k (bands are contiguous and non-empty below ne)
                 bi++;
@@ -585,8 +593,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
             v *= g_band;
             lc3_px_set(c, LC3_PLANE_X + k, (int32_t)lc3_bits(v));
             // slide the window: drop line k - 3, bring in line k + 4
-            nzwin >>= 1;
-            if (xw[j + 4] != 0 && k + 4 < bw_stop) nzwin |= 1u << 6;
+            nzwin = (nzwin >> 1) | ((xw[j + 4] != 0 && k + 4 < bw_stop) ? 64u : 0u);
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) xw[j] = xw[j + 4];
