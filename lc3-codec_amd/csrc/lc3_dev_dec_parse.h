@@ -223,6 +223,50 @@ __device__ __forceinline__ int lc3_p_ac_decode_spec(lc3_parse_ctx &c, lc3_acdec 
     return 0;
 }
 
+// ---- select-based variants for the spectral loop.  Every lane is another frame, so a branch on frame data diverges
+// and costs more scalar bookkeeping than the operations it skips.  These never return early: a failed bound check sets
+// the sticky `err` (the frame is concealed, exactly as when the reference returns Err at that point), reads fall back to
+// a safe index, and the caller tests `err` once after the loop.
+// read_tail_bool (:100-116) when `want`; returns the bit (0 when not wanted) and advances the cursor by `want`
+__device__ __forceinline__ int lc3_p_bool_sel(lc3_parse_ctx &c, int want, int &err) {
+    const int byte_index = c.tail >> 3, bit_index = c.tail & 7;
+    const int from = c.len - byte_index - 1;
+    const int bad = (c.len - c.head - byte_index + 2 < 0) | (from < 0);
+    err |= want & bad;
+    const int idx = from < 0 ? 0 : from;
+    const int bit = (int)(((uint32_t)c.bytes[idx] >> bit_index) & 1u);
+    c.tail += want;
+    return want ? bit : 0;
+}
+// ac_decode over a packed spectral-model row, see lc3_p_ac_decode_spec.  After range = tmp * freq the range is at least
+// 64 (tmp >= 64 because range >= 2^16 on entry, freq >= 1), so the reference's renormalisation loop runs at most twice.
+__device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_acdec &st, const uint32_t *row, int &err) {
+    const uint32_t tmp = st.range >> 10, limit = tmp << 10;
+    err |= st.low >= limit;
+    int lo = 0, hi = 16;
+#pragma unroll
+    for (int it = 0; it < 5; it++) {
+        const int mid = (lo + hi + 1) >> 1;
+        const int ge = st.low >= tmp * (row[mid] & 0xffffu);
+        lo = ge ? mid : lo;
+        hi = ge ? hi : mid - 1;
+    }
+    const uint32_t sv = row[lo];
+    st.low -= tmp * (sv & 0xffffu);
+    st.range = tmp * (sv >> 16);
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int need = st.range < 0x10000u;
+        err |= need & (c.head >= c.len);  // read_head_byte :42-50
+        const int idx = c.head < c.len ? c.head : c.len - 1;
+        const uint32_t byte = (uint32_t)c.bytes[idx];
+        st.low = need ? ((st.low << 8) & 0x00ffffffu) + byte : st.low;
+        st.range = need ? st.range << 8 : st.range;
+        c.head += need;
+    }
+    return lo;
+}
+
 // read_res_bit (decoder/arithmetic_codec.rs:339-383)
 __device__ __forceinline__ int lc3_p_res_bit(lc3_parse_ctx &c, int idx, int &nbits_res, int &cont) {
     int bit;
@@ -286,46 +330,41 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
     const int ntup = lastnz / 2;
     {
         const int rate_flag = nbits > (160 + fs_ind * 160) ? 512 : 0;
-        int cctx = 0;
+        int cctx = 0, err = 0;
         for (int tup = 0; tup < ntup; tup++) {
-            int t = cctx + rate_flag + ((tup * 2) > (ne / 2) ? 256 : 0), lev = 0, bit;
+            const int t = cctx + rate_flag + ((tup * 2) > (ne / 2) ? 256 : 0);
+            int lev = 0;
             int32_t xk = 0, xk1 = 0;
-            sym = 0;
-            while (lev < 14) {
-                const int pki = c.lookup[t + (lev < 3 ? lev : 3) * 1024];
-                if (lc3_p_ac_decode_spec(c, st, c.cf + pki * 17, sym)) return -4;
-                if (sym < 16) break;
-                if (!lsb_mode || lev > 0) {
-                    if (lc3_p_bool(c, bit)) return -5;
-                    xk += (int32_t)((uint32_t)bit << lev);
-                    if (lc3_p_bool(c, bit)) return -5;
-                    xk1 += (int32_t)((uint32_t)bit << lev);
-                }
+            sym = lc3_p_ac_decode_spec_sel(c, st, c.cf + (int)c.lookup[t] * 17, err);
+            // escape symbols (magnitudes >= 4, the rarer case): one more bit plane and one more symbol per round.
+            // Reference loop: `while lev < 14 { decode; if sym < 16 break; [two LSBs]; lev += 1 }`
+            while (sym >= 16 && lev < 14) {
+                const int want = !lsb_mode || lev > 0;
+                xk += (int32_t)((uint32_t)lc3_p_bool_sel(c, want, err) << lev);
+                xk1 += (int32_t)((uint32_t)lc3_p_bool_sel(c, want, err) << lev);
                 lev += 1;
+                if (lev < 14) sym = lc3_p_ac_decode_spec_sel(c, st, c.cf + (int)c.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17, err);
             }
             if (lsb_mode) lc3_px_set(c, LC3_PLANE_LEV + tup, lev);  // written by TUPLE index, read by LINE index (:184-195)
             const int a = sym & 3, b = sym >> 2;
             xk += (int32_t)((uint32_t)a << lev);
             xk1 += (int32_t)((uint32_t)b << lev);
-            if (xk > 0) {
-                if (lc3_p_bool(c, bit)) return -5;
-                if (bit) xk = -xk;
-            }
-            if (xk1 > 0) {
-                if (lc3_p_bool(c, bit)) return -5;
-                if (bit) xk1 = -xk1;
+            {
+                const int w0 = xk > 0, s0 = lc3_p_bool_sel(c, w0, err);
+                xk = s0 ? -xk : xk;
+                const int w1 = xk1 > 0, s1 = lc3_p_bool_sel(c, w1, err);
+                xk1 = s1 ? -xk1 : xk1;
             }
             lc3_px_set(c, LC3_PLANE_X + 2 * tup, xk);
             lc3_px_set(c, LC3_PLANE_X + 2 * tup + 1, xk1);
             c.nnz += (uint32_t)(xk != 0) + (uint32_t)(xk1 != 0);
             c.seed += (uint32_t)(xk < 0 ? -xk : xk) * (uint32_t)(2 * tup) + (uint32_t)(xk1 < 0 ? -xk1 : xk1) * (uint32_t)(2 * tup + 1);
-            lev = lev < 3 ? lev : 3;
-            t = lev <= 1 ? 1 + (a + b) * (lev + 1) : 12 + lev;
-            cctx = (cctx & 15) * 16 + t;
+            const int lv = lev < 3 ? lev : 3;
+            cctx = (cctx & 15) * 16 + (lv <= 1 ? 1 + (a + b) * (lv + 1) : 12 + lv);
         }
+        if (err) return -4;
     }
-    LC3_PSTAMP(c, 2);
-    for (int k = lastnz; k < ne; k++) lc3_px_set(c, LC3_PLANE_X + k, 0);  // :131-133
+    // lines lastnz .. ne-1 are zero (:131-133): not stored, lc3_reconstruct_frame substitutes zeros when it reads them
     // calc_num_residual_bits :385-405
     {
         const int nbits_side = c.tail - 8;
@@ -451,7 +490,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
             if (nbytes - last_byte - 1 < 0) return 0;
         }
     }
-    const int x0 = lc3_px_get(c, LC3_PLANE_X), x1 = lc3_px_get(c, LC3_PLANE_X + 1);
+    const int x0 = lc3_px_get(c, LC3_PLANE_X), x1 = lc3_px_get(c, LC3_PLANE_X + 1);  // lastnz >= 2: both were stored
     const int do_fill = !(lastnz == 2 && x0 == 0 && x1 == 0 && gg_ind == 0);  // zero frame :147-151
     uint32_t lcg = c.seed & 0xFFFFu;
     // spectral_noise_shaping::decode: scale factors scf[16] = codebook + gain * (y . D) (:21-73)
@@ -523,7 +562,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     uint32_t nzwin = 0;
     int32_t xw[12];
 #pragma unroll
-    for (int j = 0; j < 12; j++) xw[j] = j < ne ? lc3_px_get(c, LC3_PLANE_X + j) : 0;
+    for (int j = 0; j < 12; j++) xw[j] = j < lastnz ? lc3_px_get(c, LC3_PLANE_X + j) : 0;  // lastnz <= ne
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if (xw[j] != 0 && j < bw_stop) nzwin |= 1u << (j + 3);
@@ -535,7 +574,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     for (int k0 = 0; k0 < ne; k0 += 4) {  // ne is a multiple of 4
         int32_t xnext[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) xnext[j] = k0 + 12 + j < ne ? lc3_px_get(c, LC3_PLANE_X + k0 + 12 + j) : 0;
+        for (int j = 0; j < 4; j++) xnext[j] = k0 + 12 + j < lastnz ? lc3_px_get(c, LC3_PLANE_X + k0 + 12 + j) : 0;
         // The per-line work is written with selects, not branches: the conditions differ from lane to lane (each lane is
         // another frame), and a divergent branch costs more scalar bookkeeping than the few operations it would skip.
 #pragma unroll
