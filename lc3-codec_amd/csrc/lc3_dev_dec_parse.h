@@ -35,6 +35,7 @@ struct lc3_parse_ctx {
     int len;
     const uint8_t *lookup;   // AC_SPEC_LOOKUP[4096]
     const uint32_t *cf;      // [64][17] cum | freq << 16 of the spectral model
+    const uint32_t *tns;     // [2][8] TNS order models then [8][17] TNS coefficient models, packed the same way
     int32_t *plane;          // this frame's plane column: word w at plane[w * stride]
     int stride;
     int head, tail;          // BufferReader cursors (decoder/buffer_reader.rs:11-15)
@@ -179,51 +180,7 @@ __device__ __forceinline__ int lc3_parse_side_info(lc3_parse_ctx &c, int fs_ind,
     return 0;
 }
 
-// ac_decode (decoder/arithmetic_codec.rs:67-97) over a cumulative-frequency row of `nsym` int16 entries
-__device__ __forceinline__ int lc3_p_ac_decode16(lc3_parse_ctx &c, lc3_acdec &st, const int16_t *cum, const int16_t *freq,
-                                                 int nsym, int &sym) {
-    const uint32_t tmp = st.range >> 10, limit = tmp << 10;
-    if (st.low >= limit) return -1;
-    int val = nsym - 1;
-    while (st.low < tmp * (uint32_t)(int)cum[val]) val--;
-    st.low -= tmp * (uint32_t)(int)cum[val];
-    st.range = tmp * (uint32_t)(int)freq[val];
-    while (st.range < 0x10000u) {
-        st.low = (st.low << 8) & 0x00ffffffu;
-        if (c.head >= c.len) return -1;  // read_head_byte :42-50
-        st.low += (uint32_t)c.bytes[c.head++];
-        st.range <<= 8;
-    }
-    sym = val;
-    return 0;
-}
-// the same over a packed (cum | freq << 16) row of the 17-symbol spectral model; binary search for the largest j with
-// low >= tmp * cum[j] (cum is non-decreasing, cum[0] = 0) = the symbol the reference's top-down scan returns
-__device__ __forceinline__ int lc3_p_ac_decode_spec(lc3_parse_ctx &c, lc3_acdec &st, const uint32_t *row, int &sym) {
-    const uint32_t tmp = st.range >> 10, limit = tmp << 10;
-    if (st.low >= limit) return -1;
-    int lo = 0, hi = 16;
-#pragma unroll
-    for (int it = 0; it < 5; it++) {
-        const int mid = (lo + hi + 1) >> 1;
-        const int ge = st.low >= tmp * (row[mid] & 0xffffu);
-        lo = ge ? mid : lo;
-        hi = ge ? hi : mid - 1;
-    }
-    const uint32_t sv = row[lo];
-    st.low -= tmp * (sv & 0xffffu);
-    st.range = tmp * (sv >> 16);
-    while (st.range < 0x10000u) {
-        st.low = (st.low << 8) & 0x00ffffffu;
-        if (c.head >= c.len) return -1;
-        st.low += (uint32_t)c.bytes[c.head++];
-        st.range <<= 8;
-    }
-    sym = lo;
-    return 0;
-}
-
-// ---- select-based variants for the spectral loop.  Every lane is another frame, so a branch on frame data diverges
+// ---- range decoder and bit reader, written with selects.  Every lane is another frame, so a branch on frame data diverges
 // and costs more scalar bookkeeping than the operations it skips.  These never return early: a failed bound check sets
 // the sticky `err` (the frame is concealed, exactly as when the reference returns Err at that point), reads fall back to
 // a safe index, and the caller tests `err` once after the loop.
@@ -238,14 +195,17 @@ __device__ __forceinline__ int lc3_p_bool_sel(lc3_parse_ctx &c, int want, int &e
     c.tail += want;
     return want ? bit : 0;
 }
-// ac_decode over a packed spectral-model row, see lc3_p_ac_decode_spec.  After range = tmp * freq the range is at least
-// 64 (tmp >= 64 because range >= 2^16 on entry, freq >= 1), so the reference's renormalisation loop runs at most twice.
-__device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_acdec &st, const uint32_t *row, int &err) {
+// ac_decode (decoder/arithmetic_codec.rs:67-97) over a packed (cum | freq << 16) model row with symbols 0..HI: the
+// reference scans from the top for the largest j with low >= tmp * cum[j] (:81-84; cum is non-decreasing, cum[0] = 0),
+// here a STEPS-step binary search.  After range = tmp * freq the range is at least 64 (tmp >= 64 because range >= 2^16
+// on entry, freq >= 1), so the reference's renormalisation loop runs at most twice.
+template <int HI, int STEPS>
+__device__ __forceinline__ int lc3_p_ac_decode_sel(lc3_parse_ctx &c, lc3_acdec &st, const uint32_t *row, int &err) {
     const uint32_t tmp = st.range >> 10, limit = tmp << 10;
     err |= st.low >= limit;
-    int lo = 0, hi = 16;
+    int lo = 0, hi = HI;
 #pragma unroll
-    for (int it = 0; it < 5; it++) {
+    for (int it = 0; it < STEPS; it++) {
         const int mid = (lo + hi + 1) >> 1;
         const int ge = st.low >= tmp * (row[mid] & 0xffffu);
         lo = ge ? mid : lo;
@@ -265,6 +225,17 @@ __device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_ac
         c.head += need;
     }
     return lo;
+}
+__device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_acdec &st, const uint32_t *row, int &err) {
+    return lc3_p_ac_decode_sel<16, 5>(c, st, row, err);
+}
+
+// element i (0 .. LC3_TNS_MODEL_WORDS-1) of the packed TNS models: [2][8] order models, then [8][17] coefficient models
+#define LC3_TNS_MODEL_WORDS (2 * 8 + 8 * 17)
+__device__ __forceinline__ uint32_t lc3_tns_model_word(int i) {
+    if (i < 16) return (uint32_t)(int)LC3T_AC_TNS_ORDER_CUMFREQ[i / 8][i % 8] | ((uint32_t)(int)LC3T_AC_TNS_ORDER_FREQ[i / 8][i % 8] << 16);
+    const int k = (i - 16) / 17, j = (i - 16) % 17;
+    return (uint32_t)(int)LC3T_AC_TNS_COEF_CUMFREQ[k][j] | ((uint32_t)(int)LC3T_AC_TNS_COEF_FREQ[k][j] << 16);
 }
 
 // read_res_bit (decoder/arithmetic_codec.rs:339-383)
@@ -314,13 +285,11 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
         for (int f = 0; f < 2; f++) {
             int order = ord[f];
             if (f < num_tns && order > 0) {
-                if (lc3_p_ac_decode16(c, st, LC3T_AC_TNS_ORDER_CUMFREQ[wt], LC3T_AC_TNS_ORDER_FREQ[wt], 8, sym)) return -2;
-                order = sym + 1;
-                for (int k = 0; k < order; k++) {
-                    int s2;
-                    if (lc3_p_ac_decode16(c, st, LC3T_AC_TNS_COEF_CUMFREQ[k], LC3T_AC_TNS_COEF_FREQ[k], 17, s2)) return -3;
-                    lc3_px_set(c, AD_RCI + f * 8 + k, s2);
-                }
+                int err = 0;
+                order = lc3_p_ac_decode_sel<7, 3>(c, st, c.tns + wt * 8, err) + 1;
+                for (int k = 0; k < order; k++)
+                    lc3_px_set(c, AD_RCI + f * 8 + k, lc3_p_ac_decode_sel<16, 5>(c, st, c.tns + 16 + k * 17, err));
+                if (err) return -2;
             }
             lc3_px_set(c, AD_ORD0 + f, order);
         }
@@ -364,6 +333,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
         }
         if (err) return -4;
     }
+    LC3_PSTAMP(c, 2);
     // lines lastnz .. ne-1 are zero (:131-133): not stored, lc3_reconstruct_frame substitutes zeros when it reads them
     // calc_num_residual_bits :385-405
     {
@@ -375,14 +345,25 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
         lc3_px_set(c, AD_NRES_MAX, nres);
         lc3_px_set(c, AD_HEAD, c.head);
         if (lsb_mode) {  // decode_residual_bits :184-206: refines the integers in place
-            for (int k = 0; k < lastnz; k += 2) {
-                // save_lev[k]: entries at or beyond the number of tuples were never written (zero in the reference)
-                const int lv = k < ntup ? lc3_px_get(c, LC3_PLANE_LEV + k) : 0;
-                if (lv > 0) {
-                    if (lc3_p_res_bit(c, k, nres, cont)) return -7;
-                    if (!cont) break;
-                    if (lc3_p_res_bit(c, k + 1, nres, cont)) return -7;
-                    if (!cont) break;
+            // save_lev is read by LINE index k = 0, 2, 4 .. but was written by TUPLE index: entries at or beyond the
+            // number of tuples were never written (zero in the reference), so the walk ends at ntup.  The levels are
+            // fetched eight at a time.
+            int stop = 0;
+            for (int k0 = 0; k0 < ntup && !stop; k0 += 16) {
+                int lv[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) lv[j] = k0 + 2 * j < ntup ? lc3_px_get(c, LC3_PLANE_LEV + k0 + 2 * j) : 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (!stop && lv[j] > 0) {
+                        const int k = k0 + 2 * j;
+                        if (lc3_p_res_bit(c, k, nres, cont)) return -7;
+                        if (!cont) stop = 1;
+                        else {
+                            if (lc3_p_res_bit(c, k + 1, nres, cont)) return -7;
+                            if (!cont) stop = 1;
+                        }
+                    }
                 }
             }
         }

@@ -338,9 +338,9 @@ __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *pl
 // (cum | freq) spectral model and the frames' bytes are staged in LDS with coalesced loads.  blockDim.x frames per
 // workgroup (256, or 128 for frames above 220 bytes so that the staging fits 64 KB of dynamic LDS):
 // 4096 + 64*17*4 + blockDim.x*nbytes bytes.
-// Dynamic LDS: 4096 (context lookup) + 64*17*4 (spectral model) + 16*11*4 (MPVQ offsets) + 16*4*blockDim.x (scale
+// Dynamic LDS: 4096 (context lookup) + 64*17*4 (spectral model) + 16*11*4 (MPVQ offsets) + 152*4 (TNS models) + 16*4*blockDim.x (scale
 // factors, [n][lane]) + blockDim.x * nbytes (frame bytes).
-#define LC3_PARSE_LDS_FIXED (4096 + 64 * 17 * 4 + 16 * 11 * 4)
+#define LC3_PARSE_LDS_FIXED (4096 + 64 * 17 * 4 + 16 * 11 * 4 + 4 * 152)
 __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot cfg, const uint8_t *in, const uint8_t *bad,
                                                         int32_t *planes, int nbytes, int n_frames) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -350,11 +350,13 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot cfg, const 
     uint8_t *s_lookup = smem;
     uint32_t *s_cf = (uint32_t *)(smem + 4096);
     uint32_t *s_mpvq = (uint32_t *)(smem + 4096 + 64 * 17 * 4);
+    uint32_t *s_tns = (uint32_t *)(smem + 4096 + 64 * 17 * 4 + 16 * 11 * 4);
     float *s_scf = (float *)(smem + LC3_PARSE_LDS_FIXED);
     uint8_t *s_bytes = smem + LC3_PARSE_LDS_FIXED + 16 * 4 * fpb;
     const size_t f0 = (size_t)blockIdx.x * (size_t)fpb;
     {
         for (int i = tid; i < 16 * 11; i += fpb) s_mpvq[i] = LC3T_MPVQ_OFFSETS[i / 11][i % 11];
+        for (int i = tid; i < LC3_TNS_MODEL_WORDS; i += fpb) s_tns[i] = lc3_tns_model_word(i);
         const uint32_t *lk32 = (const uint32_t *)LC3T_AC_SPEC_LOOKUP;
         uint32_t *d32 = (uint32_t *)s_lookup;
         for (int i = tid; i < 1024; i += fpb) d32[i] = lk32[i];
@@ -383,6 +385,7 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot cfg, const 
         c.len = nbytes;
         c.lookup = s_lookup;
         c.cf = s_cf;
+        c.tns = s_tns;
         c.plane = LC3_PLANE_COL(planes, f, LC3_PLANE_WORDS);
         c.stride = LC3_PLANE_STRIDE;
         c.head = 0;

@@ -266,8 +266,11 @@ int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8
     for (int p = 0; p < 64; p++)
         for (int q = 0; q < 17; q++)
             cf[(size_t)p * 17 + q] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[p][q] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[p][q] << 16);
+    std::vector<uint32_t> tns(LC3_TNS_MODEL_WORDS);
+    for (int i = 0; i < LC3_TNS_MODEL_WORDS; i++) tns[(size_t)i] = lc3_tns_model_word(i);
     for (size_t f = 0; f < frames; f++) {
         lc3_parse_ctx c;
+        c.tns = tns.data();
         c.bytes = bytes + f * (size_t)nbytes;
         c.len = nbytes;
         c.lookup = LC3T_AC_SPEC_LOOKUP;
