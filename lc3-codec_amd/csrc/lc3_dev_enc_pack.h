@@ -91,6 +91,50 @@ __device__ __forceinline__ void lc3_pk_ac_encode(lc3_pack_ctx &w, uint32_t cum_f
     }
 }
 
+// ---- select-based variants for the spectral loop: every lane is another frame, a branch on frame data diverges and
+// costs more scalar bookkeeping than the few operations it skips.
+// write_bool_backward (buffer_writer.rs:27-40) when `want`
+__device__ __forceinline__ void lc3_pk_bool_backward_sel(lc3_pack_ctx &w, int want, int bit) {
+    const int in = (w.bp_side >= 0) & (w.bp_side < w.nbytes);
+    const int idx = in ? w.bp_side : 0;
+    const uint32_t old = w.buf[idx], m = (uint32_t)w.mask_side;
+    const uint32_t nw = bit ? (old | m) : (old & ~m);
+    w.buf[idx] = (uint8_t)((want & in) ? nw : old);
+    const int wrap = w.mask_side == 0x80;
+    w.mask_side = want ? (wrap ? 1 : w.mask_side << 1) : w.mask_side;
+    w.bp_side -= want & wrap;
+}
+// ac_shift (bitstream_encoding.rs:397-415) when `need`
+__device__ __forceinline__ void lc3_pk_ac_shift_sel(lc3_pack_ctx &w, int need) {
+    const int flush = need & ((w.low < 0x00ff0000u) | (w.carry == 1));
+    if (flush) {
+        if (w.cache >= 0) lc3_pk_byte_forward(w, (w.cache + w.carry) & 0xff);
+        while (w.carry_count > 0) {
+            lc3_pk_byte_forward(w, (w.carry + 0xff) & 0xff);
+            w.carry_count -= 1;
+        }
+        w.cache = (int)(w.low >> 16);
+        w.carry = 0;
+    }
+    w.carry_count += need & !flush;
+    w.low = need ? (w.low << 8) & 0x00ffffffu : w.low;
+}
+// ac_encode (:417-429).  After range = r * sym_freq the range is at least 64 (r >= 64 because range >= 2^16 on entry,
+// sym_freq >= 1), so the reference's renormalisation loop runs at most twice.
+__device__ __forceinline__ void lc3_pk_ac_encode_sel(lc3_pack_ctx &w, uint32_t cum_freq, uint32_t sym_freq) {
+    const uint32_t r = w.range >> 10;
+    w.low += r * cum_freq;
+    w.carry = (w.low >> 24) != 0 ? 1 : w.carry;
+    w.low &= 0x00ffffffu;
+    w.range = r * sym_freq;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int need = w.range < 0x10000u;
+        w.range = need ? w.range << 8 : w.range;
+        lc3_pk_ac_shift_sel(w, need);
+    }
+}
+
 // one (x_q[k], x_q[k+1]) pair of the plane
 __device__ __forceinline__ void lc3_ep_pair(const lc3_pack_ctx &c, int tup, int &q0, int &q1) {
     const uint32_t v = (uint32_t)lc3_ep_get(c, EP_XQ + tup);
@@ -195,28 +239,28 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
                     const int q0 = (int)(int16_t)(xcur[j] & 0xffffu), q1 = (int)(int16_t)(xcur[j] >> 16);
                     unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
                     unsigned a_lsb = a, b_lsb = b;
-                    while ((a > b ? a : b) >= 4) {
+                    while ((a > b ? a : b) >= 4) {  // escape symbols: the rarer case
                         const uint32_t sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + 16];
-                        lc3_pk_ac_encode(w, sv & 0xffffu, sv >> 16);
-                        if (!(lsb_mode && lev == 0)) {
-                            lc3_pk_bool_backward(w, (a & 1u) == 1u);
-                            lc3_pk_bool_backward(w, (b & 1u) == 1u);
-                        }
+                        lc3_pk_ac_encode_sel(w, sv & 0xffffu, sv >> 16);
+                        const int want = !(lsb_mode && lev == 0);
+                        lc3_pk_bool_backward_sel(w, want, (a & 1u) == 1u);
+                        lc3_pk_bool_backward_sel(w, want, (b & 1u) == 1u);
                         a >>= 1;
                         b >>= 1;
                         lev += 1;
                     }
                     {
                         const uint32_t sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + (int)(a + 4 * b)];
-                        lc3_pk_ac_encode(w, sv & 0xffffu, sv >> 16);
+                        lc3_pk_ac_encode_sel(w, sv & 0xffffu, sv >> 16);
                     }
-                    if (lsb_mode && lev > 0) {  // the LSB list itself is regenerated below when it is written
-                        a_lsb >>= 1;
-                        b_lsb >>= 1;
-                        nlsbs += 2 + (a_lsb == 0 && q0 != 0) + (b_lsb == 0 && q1 != 0);
+                    {   // the LSB list itself is regenerated below when it is written
+                        const int lsb_here = lsb_mode && lev > 0;
+                        a_lsb = lsb_here ? a_lsb >> 1 : a_lsb;
+                        b_lsb = lsb_here ? b_lsb >> 1 : b_lsb;
+                        nlsbs += lsb_here ? 2 + (a_lsb == 0 && q0 != 0) + (b_lsb == 0 && q1 != 0) : 0;
                     }
-                    if (a_lsb > 0) lc3_pk_bool_backward(w, q0 <= 0);
-                    if (b_lsb > 0) lc3_pk_bool_backward(w, q1 <= 0);
+                    lc3_pk_bool_backward_sel(w, a_lsb > 0, q0 <= 0);
+                    lc3_pk_bool_backward_sel(w, b_lsb > 0, q1 <= 0);
                     lev = lev < 3 ? lev : 3;
                     t = lev <= 1 ? 1 + (int)(a + b) * (lev + 1) : 12 + lev;
                     cctx = (cctx & 15) * 16 + t;
