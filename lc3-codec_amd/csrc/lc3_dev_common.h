@@ -14,7 +14,7 @@
 // -ffp-contract=off so no mul+add is fused.
 //
 // The including translation unit provides LC3_SYNC() (orders one wave's LDS traffic), the wave primitives
-// (lc3_wave_max_i32, lc3_wave_sum_u32, lc3_wave_exscan_u32) and the __device__ / __forceinline__ keywords: lc3gpu.hip
+// (lc3_wave_max_i32, lc3_wave_sum_u32, lc3_wave_exscan_u32, lc3_wave_ballot) and the __device__ / __forceinline__ keywords: lc3gpu.hip
 // for the GPU, tests/emu/lc3_emu.cpp for the CPU wave emulator of the tests.
 #pragma once
 #include <stddef.h>

@@ -1140,8 +1140,6 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, LC3_LDS_PARAM
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int ne = c.ne, ne4 = ne / 4;
-    float *e = (float *)L.fa;  // 100 group energies
-    float *xm = e + 128;       // 64 per-lane maxima
     lc3_quant_res res;
     // calc_bit_budget :122-134: ceil(log2(ne/2)) + {3,4,5}
     int nbits_ari = 0;
@@ -1161,74 +1159,95 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, LC3_LDS_PARAM
         int q = (int)(int16_t)nbits / (10 * (c.fs_ind + 1));
         gg_off = -(q < 115 ? q : 115) - 105 - 5 * (c.fs_ind + 1);
     }
-    // compute_spectral_energy :390-395 -- one lane per 4-line group
-    for (int n = lane; n < ne4; n += LC3_WAVE) {
-        const float *x = L.spec + 4 * n;
-        float total = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
-        e[n] = 10.0f * lc3_log10f(1.1920929e-7f + total);
+    // compute_spectral_energy :390-395 -- one lane per 4-line group (two groups per lane, kept in registers together
+    // with the two products of the energy that the gain search needs)
+    float e14[2], e28[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int n = lane + LC3_WAVE * q;
+        float ei = 0.0f;
+        if (n < ne4) {
+            const lc3_f4 x = *(const lc3_f4 *)(L.spec + 4 * n);
+            const float total = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+            ei = 10.0f * lc3_log10f(1.1920929e-7f + total);
+        }
+        e14[q] = ei * 28.0f / 20.0f;
+        e28[q] = 2.0f * ei * 28.0f / 20.0f;
     }
-    // global_gain_limitation's max |x| :214-217 (max is order-independent)
+    // global_gain_limitation's max |x| :214-217 (the maximum is order-independent; non-negative floats order like
+    // their bit patterns, so the wave maximum is an integer reduction)
+    float x_f_max;
     {
         float m = 0.0f;
         for (int n = lane; n < ne; n += LC3_WAVE) m = lc3_maxf(m, lc3_absf(L.spec[n]));
-        xm[lane] = m;
+        x_f_max = lc3_from_bits((uint32_t)lc3_wave_max_i32((int)lc3_bits(m), lane));
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 9);
-    // global_gain_estimation :174-209 -- 8-step bisection.  Per step the reference walks the group energies from the
-    // top: a group below the gain adds a constant only once a group at/above the gain has been seen ("is_zero"), the
-    // others add a linear term; tmp is a sequential f32 sum.  The terms are computed one lane per group (the first
-    // group at/above the gain is a max-reduction), the f32 accumulation stays sequential on lane 0.
+    // global_gain_estimation :174-209 -- 8-step bisection on gg_ind.  Per step the reference walks the group energies
+    // from the top: a group below the gain adds a constant only once a group at/above the gain has been seen
+    // ("is_zero"), the others add a linear term; tmp is a sequential f32 sum of ~100 terms, so a step is a chain of ~100
+    // dependent additions that every lane would execute redundantly.  Instead, three levels of the bisection are
+    // evaluated per round: the 1 + 2 + 4 gains the next three steps can possibly visit are known in advance, lane c
+    // sums the terms of candidate c (each sum in the reference's order), and the three decisions are then read off.
+    // Rounds of 3, 3 and 2 levels replace 8 dependent chains by 3.
     {
         int fac = 256, gg_ind = 255;
-        float *tvb = xm + 64;  // ne4p floats of per-group terms (+ 20 readable floats behind them)
-        const int ne4p = ((ne4 + 19) / 20) * 20;
-        // the lane's two groups: energy terms that do not depend on the gain are formed once
-        float e14[2], e28[2];
+        float *tvb = (float *)L.fa;  // 7 candidate term arrays of LC3_TVB floats (840 of the 960 floats of fa/fb)
+#define LC3_TVB 120
+        const int ne4p = ((ne4 + 19) / 20) * 20;  // <= 100; the sum loop reads one 20-float chunk beyond it
+        const float thr = (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f;
+        for (int level = 0; level < 8;) {
+            const int depth = 8 - level >= 3 ? 3 : 8 - level, nc = (1 << depth) - 1;
+            const int f1 = fac >> 1, f2 = fac >> 2, f3 = fac >> 3;
+            // candidate c: the gain visited at depth d after the decisions encoded in its index (see the walk below)
+            int cand[7];
+            cand[0] = gg_ind - f1;
+            cand[1] = gg_ind - f1 - f2;
+            cand[2] = gg_ind - f2;
+            cand[3] = gg_ind - f1 - f2 - f3;
+            cand[4] = gg_ind - f1 - f3;
+            cand[5] = gg_ind - f2 - f3;
+            cand[6] = gg_ind - f3;
+            int hi[7];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int n = lane + LC3_WAVE * q;
-            const float ei = n < ne4 ? e[n] : 0.0f;
-            e14[q] = ei * 28.0f / 20.0f;
-            e28[q] = 2.0f * ei * 28.0f / 20.0f;
-        }
-        for (int it = 0; it < 8; it++) {
-            fac >>= 1;
-            gg_ind -= fac;
-            const float g = (float)gg_ind + (float)gg_off;
-            int hi = -1;
+            for (int cidx = 0; cidx < 7; cidx++) {
+                hi[cidx] = -1;
+                if (cidx < nc) {
+                    const float g = (float)cand[cidx] + (float)gg_off;
+                    // highest group at/above the gain: two ballots (groups 0..63, 64..127)
+                    const unsigned long long m0 = lc3_wave_ballot(lane < ne4 && !(e14[0] < g), lane);
+                    const unsigned long long m1 = lc3_wave_ballot(lane + LC3_WAVE < ne4 && !(e14[1] < g), lane);
+                    const int h = m1 ? 64 + (63 - __builtin_clzll(m1)) : (m0 ? 63 - __builtin_clzll(m0) : -1);
+                    hi[cidx] = h;
+                    float *tv_c = tvb + cidx * LC3_TVB;
+                    // terms in the reference's order (groups from the top down) at tv_c[ne4 - 1 - n], zero padded to a
+                    // multiple of twenty (adding +0 at the end of the sum does not change it)
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int n = lane + LC3_WAVE * q;
-                if (n < ne4 && !(e14[q] < g)) hi = n;
-            }
-            hi = lc3_wave_max_i32(hi, lane);
-            // terms in the reference's order (groups from the top down) at tvb[ne4 - 1 - n], zero padded to a multiple
-            // of twenty (adding +0 at the end of the sum does not change it)
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int n = lane + LC3_WAVE * q;
-                if (n < ne4) {
-                    float tv;
-                    if (e14[q] < g) tv = n < hi ? 2.7f * 28.0f / 20.0f : 0.0f;
-                    else if (g < (e14[q] - 43.0f * 28.0f / 20.0f)) tv = e28[q] - 2.0f * g - 36.0f * 28.0f / 20.0f;
-                    else tv = e14[q] - g + 7.0f * 28.0f / 20.0f;
-                    tvb[ne4 - 1 - n] = tv;
-                } else if (n < ne4p) tvb[n] = 0.0f;
+                    for (int q = 0; q < 2; q++) {
+                        const int n = lane + LC3_WAVE * q;
+                        if (n < ne4) {
+                            float tv;
+                            if (e14[q] < g) tv = n < h ? 2.7f * 28.0f / 20.0f : 0.0f;
+                            else if (g < (e14[q] - 43.0f * 28.0f / 20.0f)) tv = e28[q] - 2.0f * g - 36.0f * 28.0f / 20.0f;
+                            else tv = e14[q] - g + 7.0f * 28.0f / 20.0f;
+                            tv_c[ne4 - 1 - n] = tv;
+                        } else if (n < ne4p) tv_c[n] = 0.0f;
+                    }
+                }
             }
             LC3_SYNC();
-            // tmp: sequential f32 sum, evaluated by every lane on the same (broadcast) LDS reads; the terms are fetched
-            // 20 at a time, one chunk ahead of the additions
-            // Every term is >= 0 (3.78, 0, >= 9.8, > 70), so the running f32 sum never decreases: once it exceeds the
-            // threshold the comparison below is decided and the rest of the walk can be skipped.
-            const float thr = (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f;
+            // lane c < nc: tmp = sequential f32 sum of candidate c's terms (the other lanes shadow candidate 0); the
+            // terms are fetched 20 at a time, one chunk ahead of the additions.  Every term is >= 0 (3.78, 0, >= 9.8,
+            // > 70), so a running sum never decreases: a lane is decided once it exceeds the threshold, and the walk
+            // stops when every candidate is decided.
             float tmp = 0.0f;
             {
-                const lc3_f4 *tv4 = (const lc3_f4 *)tvb;
+                const lc3_f4 *tv4 = (const lc3_f4 *)(tvb + (lane < nc ? lane : 0) * LC3_TVB);
                 lc3_f4 cur[5], nxt[5];
 #pragma unroll
                 for (int u = 0; u < 5; u++) cur[u] = tv4[u];
-                for (int i = 0; i < ne4p && !(tmp > thr); i += 20) {
+                for (int i = 0; i < ne4p && lc3_wave_ballot(lane < nc && !(tmp > thr), lane) != 0ull; i += 20) {
 #pragma unroll
                     for (int u = 0; u < 5; u++) nxt[u] = tv4[i / 4 + 5 + u];  // one chunk past the end is scratch space
 #pragma unroll
@@ -1242,13 +1261,29 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, LC3_LDS_PARAM
                     for (int u = 0; u < 5; u++) cur[u] = nxt[u];
                 }
             }
+            const unsigned long long over = lc3_wave_ballot(tmp > thr, lane);  // bit c: candidate c's sum exceeds thr
             LC3_SYNC();
-            if ((tmp > thr) && hi >= 0) gg_ind += fac;
+            // the walk: `fac >>= 1; gg_ind -= fac; if tmp > thr && hi >= 0 { gg_ind += fac }` per level; the candidate
+            // visited at depth 2 is 1 + P1, at depth 3 it is 3 + 2 P1 + P2
+            int idx = 0, path = 0;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                if (d < depth) {
+                    int h = 0;
+#pragma unroll
+                    for (int cidx = 0; cidx < 7; cidx++) h = cidx == idx ? hi[cidx] : h;
+                    const int P = (int)((over >> idx) & 1ull) && h >= 0;
+                    fac >>= 1;
+                    gg_ind -= P ? 0 : fac;
+                    path = 2 * path + P;
+                    idx = (2 << d) - 1 + path;
+                }
+            }
+            level += depth;
         }
+#undef LC3_TVB
         if (lane == 0) {
             // global_gain_limitation :212-228
-            float x_f_max = 0.0f;
-            _Pragma("nounroll") for (int i = 0; i < LC3_WAVE; i++) x_f_max = lc3_maxf(x_f_max, xm[i]);
             int gg_min = 0;
             if (x_f_max > 0.0f) gg_min = lc3_f2i16(lc3_ceilf(28.0f * lc3_log10f(x_f_max / (32768.0f - 0.375f)))) - gg_off;
             int reset_offset = 0;

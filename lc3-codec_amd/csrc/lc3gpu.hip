@@ -125,6 +125,11 @@ __device__ __forceinline__ uint32_t lc3_wave_sum_u32(uint32_t u, int lane) {
     return (uint32_t)__builtin_amdgcn_readlane(v, 0) + (uint32_t)__builtin_amdgcn_readlane(v, 16) +
            (uint32_t)__builtin_amdgcn_readlane(v, 32) + (uint32_t)__builtin_amdgcn_readlane(v, 48);
 }
+// bit l of the result = lane l's predicate (wave-uniform)
+__device__ __forceinline__ unsigned long long lc3_wave_ballot(int pred, int lane) {
+    (void)lane;
+    return __ballot(pred);
+}
 // returns the sum over lanes < lane (per lane)
 __device__ __forceinline__ uint32_t lc3_wave_exscan_u32(uint32_t u, int lane) {
     (void)lane;

@@ -57,6 +57,15 @@ static inline uint32_t lc3_wave_sum_u32(uint32_t v, int lane) {
     LC3_SYNC();
     return m;
 }
+static inline unsigned long long lc3_wave_ballot(int pred, int lane) {
+    LC3_SYNC();
+    g_xi[tl_wave][lane] = pred != 0;
+    LC3_SYNC();
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; i++) m |= (unsigned long long)(g_xi[tl_wave][i] != 0) << i;
+    LC3_SYNC();
+    return m;
+}
 static inline uint32_t lc3_wave_exscan_u32(uint32_t v, int lane) {
     LC3_SYNC();
     g_xi[tl_wave][lane] = (int)v;
