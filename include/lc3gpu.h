@@ -122,8 +122,10 @@ int lc3gpu_decoder_timing(lc3gpu_decoder *dec, int enable, double out[3]);
  * slots 1..9 = encoder stages (mdct, bw+attack, sns, tns, ltpf, quant, residual+noise, bitstream, store),
  * slots 17..25 = decoder stages (names in tools/stage_profile.py); 32/33/34 = encoder whole-wave time sum / max / waves,
  * 35/36/37 the same for the decoder, 40..46 = sections of the parse kernel (side info, TNS data, spectral data,
- * zero fill + residual bits, reconstruction set-up, reconstruction pass, rest).  LC3GPU_EUNSUPPORTED in the normal build. */
-int lc3gpu_prof_read(unsigned long long out[48]);
+ * zero fill + residual bits, reconstruction set-up, reconstruction pass, rest), 48..54 = sections of the pack kernel
+ * (staging, side info, TNS data, spectral data, residual bits, finish, barrier wait + copy-out), 55 = its waves.
+ * LC3GPU_EUNSUPPORTED in the normal build. */
+int lc3gpu_prof_read(unsigned long long out[64]);
 /* kernel resource report: out = {lds_bytes, vgprs, sgprs, scratch_bytes, max_threads} for 0 = encoder, 1 = decoder */
 int lc3gpu_kernel_info(int which, int out[5]);
 

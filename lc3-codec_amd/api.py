@@ -382,7 +382,7 @@ class Lc3Decoder:
 
 def prof_read():
     """diagnostic build only: per-slot cycles accumulated since the previous call"""
-    out = (ctypes.c_ulonglong * 48)()
+    out = (ctypes.c_ulonglong * 64)()
     rc = load_library().lc3gpu_prof_read(out)
     if rc:
         raise Lc3GpuError(rc, "prof_read")

@@ -179,6 +179,10 @@ __device__ __forceinline__ int32_t lc3_f2u16(float x) {
     if (x <= 0.0f) return 0;
     return (int32_t)x;
 }
+// a * b for a, b < 2^24 (the device build maps it to the 24-bit multiplier)
+#ifndef LC3_MUL24
+#define LC3_MUL24(a, b) ((uint32_t)(a) * (uint32_t)(b))
+#endif
 __device__ __forceinline__ int lc3_ilog2(uint32_t v) { return 31 - __builtin_clz(v | 1u); }
 
 // exact IEEE operations the reference relies on.  With hipcc's default

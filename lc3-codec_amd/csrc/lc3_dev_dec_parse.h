@@ -34,11 +34,14 @@ struct lc3_parse_ctx {
     const uint8_t *bytes;    // this frame's bytes
     int len;
     const uint8_t *lookup;   // AC_SPEC_LOOKUP[4096]
-    const uint32_t *cf;      // [64][17] cum | freq << 16 of the spectral model
+    const uint32_t *cf;      // [64][LC3_DCF_ROW_WORDS] cum | freq << 16 of the spectral model (lc3_dcf_word), 16-byte aligned
     const uint32_t *tns;     // [2][8] TNS order models then [8][17] TNS coefficient models, packed the same way
     int32_t *plane;          // this frame's plane column: word w at plane[w * stride]
     int stride;
     int head, tail;          // BufferReader cursors (decoder/buffer_reader.rs:11-15)
+    // the spectral loop keeps the bytes its next reads will need in registers (lc3_p_prime): bytes[head], bytes[head + 1]
+    // and the byte under the tail cursor plus the one after it, each fetched one step before its use
+    uint32_t hb0, hb1, tcur, tnext;
     uint32_t nnz, seed;      // running count of non-zero lines and sum |x_k| * k (noise-filling seed :140-145, wrapping)
 #ifdef LC3_PROFILE
     unsigned long long plast, pt[8];  // diagnostic build: section stamps
@@ -184,16 +187,49 @@ __device__ __forceinline__ int lc3_parse_side_info(lc3_parse_ctx &c, int fs_ind,
 // and costs more scalar bookkeeping than the operations it skips.  These never return early: a failed bound check sets
 // the sticky `err` (the frame is concealed, exactly as when the reference returns Err at that point), reads fall back to
 // a safe index, and the caller tests `err` once after the loop.
+// Register copies of the bytes the next reads need.  A lane of this kernel is latency-bound: a byte fetched from LDS at
+// its point of use costs a full LDS round trip per bit / per renormalisation.  Here every read consumes a byte that was
+// requested one step earlier and requests the one the following step may need.
+__device__ __forceinline__ uint32_t lc3_p_head_byte(const lc3_parse_ctx &c, int at) {
+    return (uint32_t)c.bytes[at < c.len ? at : c.len - 1];
+}
+__device__ __forceinline__ uint32_t lc3_p_tail_byte(const lc3_parse_ctx &c, int byte_index) {
+    const int from = c.len - byte_index - 1;
+    return (uint32_t)c.bytes[from < 0 ? 0 : from];
+}
+__device__ __forceinline__ void lc3_p_prime(lc3_parse_ctx &c) {
+    c.hb0 = lc3_p_head_byte(c, c.head);
+    c.hb1 = lc3_p_head_byte(c, c.head + 1);
+    c.tcur = lc3_p_tail_byte(c, c.tail >> 3);
+    c.tnext = lc3_p_tail_byte(c, (c.tail >> 3) + 1);
+}
 // read_tail_bool (:100-116) when `want`; returns the bit (0 when not wanted) and advances the cursor by `want`
 __device__ __forceinline__ int lc3_p_bool_sel(lc3_parse_ctx &c, int want, int &err) {
     const int byte_index = c.tail >> 3, bit_index = c.tail & 7;
     const int from = c.len - byte_index - 1;
     const int bad = (c.len - c.head - byte_index + 2 < 0) | (from < 0);
     err |= want & bad;
-    const int idx = from < 0 ? 0 : from;
-    const int bit = (int)(((uint32_t)c.bytes[idx] >> bit_index) & 1u);
+    const int bit = (int)((c.tcur >> bit_index) & 1u);
     c.tail += want;
+    const int wrap = want & (bit_index == 7);
+    c.tcur = wrap ? c.tnext : c.tcur;
+    c.tnext = lc3_p_tail_byte(c, (c.tail >> 3) + 1);  // consumed at the next wrap, not here
     return want ? bit : 0;
+}
+// the two renormalisation steps of ac_decode (:88-95) from the head bytes held in registers
+__device__ __forceinline__ void lc3_p_ac_renorm_sel(lc3_parse_ctx &c, lc3_acdec &st, int &err) {
+    const int need0 = st.range < 0x10000u;
+    err |= need0 & (c.head >= c.len);  // read_head_byte :42-50
+    st.low = need0 ? ((st.low << 8) & 0x00ffffffu) + c.hb0 : st.low;
+    st.range = need0 ? st.range << 8 : st.range;
+    c.head += need0;
+    const int need1 = st.range < 0x10000u;
+    err |= need1 & (c.head >= c.len);
+    st.low = need1 ? ((st.low << 8) & 0x00ffffffu) + c.hb1 : st.low;
+    st.range = need1 ? st.range << 8 : st.range;
+    c.head += need1;
+    c.hb0 = lc3_p_head_byte(c, c.head);
+    c.hb1 = lc3_p_head_byte(c, c.head + 1);
 }
 // ac_decode (decoder/arithmetic_codec.rs:67-97) over a packed (cum | freq << 16) model row with symbols 0..HI: the
 // reference scans from the top for the largest j with low >= tmp * cum[j] (:81-84; cum is non-decreasing, cum[0] = 0),
@@ -207,27 +243,43 @@ __device__ __forceinline__ int lc3_p_ac_decode_sel(lc3_parse_ctx &c, lc3_acdec &
 #pragma unroll
     for (int it = 0; it < STEPS; it++) {
         const int mid = (lo + hi + 1) >> 1;
-        const int ge = st.low >= tmp * (row[mid] & 0xffffu);
+        const int ge = st.low >= LC3_MUL24(tmp, row[mid] & 0xffffu);
         lo = ge ? mid : lo;
         hi = ge ? hi : mid - 1;
     }
     const uint32_t sv = row[lo];
-    st.low -= tmp * (sv & 0xffffu);
-    st.range = tmp * (sv >> 16);
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int need = st.range < 0x10000u;
-        err |= need & (c.head >= c.len);  // read_head_byte :42-50
-        const int idx = c.head < c.len ? c.head : c.len - 1;
-        const uint32_t byte = (uint32_t)c.bytes[idx];
-        st.low = need ? ((st.low << 8) & 0x00ffffffu) + byte : st.low;
-        st.range = need ? st.range << 8 : st.range;
-        c.head += need;
-    }
+    st.low -= LC3_MUL24(tmp, sv & 0xffffu);
+    st.range = LC3_MUL24(tmp, sv >> 16);
+    lc3_p_ac_renorm_sel(c, st, err);
     return lo;
 }
+// The spectral model rows for the decoder: LC3_DCF_ROW_WORDS = 20 words per context, words 0..16 the symbols' (cum | freq
+// << 16), words 17..19 copies of symbols 4, 8 and 12.  One aligned 16-byte read of words 16..19 decides "escape" and which
+// group of four symbols holds the answer, a second one fetches that group: two dependent LDS reads per symbol instead of
+// the binary search's six.
+#define LC3_DCF_ROW_WORDS 20
+__device__ __forceinline__ uint32_t lc3_dcf_word(int i) {
+    const int p = i / LC3_DCF_ROW_WORDS, w = i % LC3_DCF_ROW_WORDS;
+    const int j = w < 17 ? w : 4 * (w - 16);
+    return (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[p][j] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[p][j] << 16);
+}
 __device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_acdec &st, const uint32_t *row, int &err) {
-    return lc3_p_ac_decode_sel<16, 5>(c, st, row, err);
+    const uint32_t tmp = st.range >> 10, limit = tmp << 10;
+    err |= st.low >= limit;
+    const lc3_i4 pv = ((const lc3_i4 *)row)[4];  // symbols 16, 4, 8, 12
+    const int ge16 = st.low >= LC3_MUL24(tmp, (uint32_t)pv[0] & 0xffffu);
+    const int g = (int)(st.low >= LC3_MUL24(tmp, (uint32_t)pv[1] & 0xffffu)) + (int)(st.low >= LC3_MUL24(tmp, (uint32_t)pv[2] & 0xffffu)) +
+                  (int)(st.low >= LC3_MUL24(tmp, (uint32_t)pv[3] & 0xffffu));
+    const lc3_i4 q = ((const lc3_i4 *)row)[g];   // symbols 4g .. 4g + 3; symbol 4g is known to satisfy the test
+    const int n = (int)(st.low >= LC3_MUL24(tmp, (uint32_t)q[1] & 0xffffu)) + (int)(st.low >= LC3_MUL24(tmp, (uint32_t)q[2] & 0xffffu)) +
+                  (int)(st.low >= LC3_MUL24(tmp, (uint32_t)q[3] & 0xffffu));
+    uint32_t sv = n == 0 ? (uint32_t)q[0] : (n == 1 ? (uint32_t)q[1] : (n == 2 ? (uint32_t)q[2] : (uint32_t)q[3]));
+    sv = ge16 ? (uint32_t)pv[0] : sv;
+    const int lo = ge16 ? 16 : 4 * g + n;
+    st.low -= LC3_MUL24(tmp, sv & 0xffffu);
+    st.range = LC3_MUL24(tmp, sv >> 16);
+    lc3_p_ac_renorm_sel(c, st, err);
+    return lo;
 }
 
 // element i (0 .. LC3_TNS_MODEL_WORDS-1) of the packed TNS models: [2][8] order models, then [8][17] coefficient models
@@ -278,6 +330,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
     st.low = ((uint32_t)c.bytes[c.head] << 16) | ((uint32_t)c.bytes[c.head + 1] << 8) | (uint32_t)c.bytes[c.head + 2];
     c.head += 3;
     st.range = 0x00ffffffu;
+    lc3_p_prime(c);  // from here to the end of the spectral data the readers run on the register copies
     // decode_tns_data :304-337
     {
         const int wt = nbits < (n_ms_10 ? 480 : 360);
@@ -304,7 +357,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             const int t = cctx + rate_flag + ((tup * 2) > (ne / 2) ? 256 : 0);
             int lev = 0;
             int32_t xk = 0, xk1 = 0;
-            sym = lc3_p_ac_decode_spec_sel(c, st, c.cf + (int)c.lookup[t] * 17, err);
+            sym = lc3_p_ac_decode_spec_sel(c, st, c.cf + (int)c.lookup[t] * LC3_DCF_ROW_WORDS, err);
             // escape symbols (magnitudes >= 4, the rarer case): one more bit plane and one more symbol per round.
             // Reference loop: `while lev < 14 { decode; if sym < 16 break; [two LSBs]; lev += 1 }`
             while (sym >= 16 && lev < 14) {
@@ -312,7 +365,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
                 xk += (int32_t)((uint32_t)lc3_p_bool_sel(c, want, err) << lev);
                 xk1 += (int32_t)((uint32_t)lc3_p_bool_sel(c, want, err) << lev);
                 lev += 1;
-                if (lev < 14) sym = lc3_p_ac_decode_spec_sel(c, st, c.cf + (int)c.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17, err);
+                if (lev < 14) sym = lc3_p_ac_decode_spec_sel(c, st, c.cf + (int)c.lookup[t + (lev < 3 ? lev : 3) * 1024] * LC3_DCF_ROW_WORDS, err);
             }
             if (lsb_mode) lc3_px_set(c, LC3_PLANE_LEV + tup, lev);  // written by TUPLE index, read by LINE index (:184-195)
             const int a = sym & 3, b = sym >> 2;

@@ -21,8 +21,13 @@ enum {
     EP_WORDS = EP_XQ + 200
 };
 
+#ifndef LC3_PACK_BATCH_SV
+#define LC3_PACK_BATCH_SV 1
+#endif
+
 struct lc3_pack_ctx {
     uint8_t *buf;            // this frame's nbytes output bytes (LDS staging)
+    uint8_t *sink;           // a byte nobody reads: where the stores of out-of-range writes go (keeps the writers branch-free)
     int nbytes, nbits;
     const uint8_t *lookup;   // AC_SPEC_LOOKUP[4096]
     const uint32_t *cf;      // [64][17] cum | freq << 16
@@ -30,30 +35,60 @@ struct lc3_pack_ctx {
     int stride;
     // BufferWriter (buffer_writer.rs:5-9) + ArithmeticEncoderState (bitstream_encoding.rs:27-34)
     int bp, bp_side, mask_side;
+    uint32_t side_acc;       // register mirror of buf[bp_side] (written through): backward bits never read LDS
     uint32_t low, range;
     int cache, carry, carry_count;
+#ifdef LC3_PROFILE
+    unsigned long long plast, pt[8];  // diagnostic build: section stamps
+#endif
 };
+#ifndef LC3_PSTAMP
+#define LC3_PSTAMP(c, id)
+#endif
 
 __device__ __forceinline__ int32_t lc3_ep_get(const lc3_pack_ctx &c, int word) { return c.plane[word * c.stride]; }
 
-__device__ __forceinline__ void lc3_pk_bool_backward(lc3_pack_ctx &w, int bit) {  // buffer_writer.rs:27-40
-    if (w.bp_side >= 0 && w.bp_side < w.nbytes) {
-        if (!bit) w.buf[w.bp_side] &= (uint8_t)~w.mask_side;
-        else w.buf[w.bp_side] |= (uint8_t)w.mask_side;
-    }
-    if (w.mask_side == 0x80) {
-        w.mask_side = 1;
-        w.bp_side -= 1;
-    } else w.mask_side <<= 1;
+// The byte the backward writer is filling is mirrored in w.side_acc and written through to LDS on every bit, so a bit
+// costs no LDS read (a read-modify-write per bit was half of this kernel's time in memory waits).  The mirror stays exact:
+// the staging buffer starts zero-filled, a byte the backward writer moves on to is still zero unless the forward writer
+// has already passed it (then it is loaded), and a forward byte landing on the mirrored byte updates the mirror too.
+// write_bool_backward (buffer_writer.rs:27-40) when `want`
+__device__ __forceinline__ void lc3_pk_bool_backward_sel(lc3_pack_ctx &w, int want, int bit) {
+    const int in = (w.bp_side >= 0) & (w.bp_side < w.nbytes);
+    const uint32_t m = (uint32_t)w.mask_side;
+    const uint32_t nw = bit ? (w.side_acc | m) : (w.side_acc & ~m);
+    w.side_acc = want ? nw : w.side_acc;
+    *(in ? w.buf + w.bp_side : w.sink) = (uint8_t)w.side_acc;  // without `want` this rewrites the byte with its own value
+    const int wrap = want & (w.mask_side == 0x80);
+    w.mask_side = want ? (wrap ? 1 : w.mask_side << 1) : w.mask_side;
+    w.bp_side -= wrap;
+    w.side_acc = wrap ? 0u : w.side_acc;
+    if (wrap && w.bp > w.bp_side && w.bp_side >= 0 && w.bp_side < w.nbytes) w.side_acc = w.buf[w.bp_side];  // rare: the writers crossed
 }
-__device__ __forceinline__ void lc3_pk_uint_backward(lc3_pack_ctx &w, uint32_t val, int nbits) {  // :19-25
-    for (int i = 0; i < nbits; i++) {
-        lc3_pk_bool_backward(w, (int)(val & 1u));
-        val >>= 1;
+__device__ __forceinline__ void lc3_pk_bool_backward(lc3_pack_ctx &w, int bit) { lc3_pk_bool_backward_sel(w, 1, bit); }
+// write_uint_backward (:19-25): nbits (<= 32) bits of val, least significant first -- the reference's bit-by-bit loop done a
+// byte at a time: the bits that land in the mirrored byte replace its field (set or cleared, as write_bool_backward does),
+// the byte is written through, and a completed byte moves the cursor on.
+__device__ __forceinline__ void lc3_pk_uint_backward(lc3_pack_ctx &w, uint32_t val, int nbits) {
+    while (nbits > 0) {
+        const int o = lc3_ilog2((uint32_t)w.mask_side);
+        const int take = nbits < 8 - o ? nbits : 8 - o;
+        const uint32_t field = ((1u << take) - 1u) << o;
+        w.side_acc = (w.side_acc & ~field) | ((val << o) & field);
+        const int in = (w.bp_side >= 0) & (w.bp_side < w.nbytes);
+        *(in ? w.buf + w.bp_side : w.sink) = (uint8_t)w.side_acc;
+        const int wrap = o + take == 8;
+        w.mask_side = wrap ? 1 : w.mask_side << take;
+        w.bp_side -= wrap;
+        w.side_acc = wrap ? 0u : w.side_acc;
+        if (wrap && w.bp > w.bp_side && w.bp_side >= 0 && w.bp_side < w.nbytes) w.side_acc = w.buf[w.bp_side];  // rare: the writers crossed
+        val >>= take;
+        nbits -= take;
     }
 }
 __device__ __forceinline__ void lc3_pk_byte_forward(lc3_pack_ctx &w, int val) {  // :55-58
-    if (w.bp >= 0 && w.bp < w.nbytes) w.buf[w.bp] = (uint8_t)val;
+    *((w.bp >= 0) & (w.bp < w.nbytes) ? w.buf + w.bp : w.sink) = (uint8_t)val;
+    w.side_acc = w.bp == w.bp_side ? (uint32_t)(val & 0xff) : w.side_acc;
     w.bp += 1;
 }
 __device__ __forceinline__ void lc3_pk_uint_forward(lc3_pack_ctx &w, unsigned val, int nbits) {  // :42-53
@@ -81,10 +116,10 @@ __device__ __forceinline__ void lc3_pk_ac_shift(lc3_pack_ctx &w) {  // bitstream
 }
 __device__ __forceinline__ void lc3_pk_ac_encode(lc3_pack_ctx &w, uint32_t cum_freq, uint32_t sym_freq) {  // :417-429
     const uint32_t r = w.range >> 10;
-    w.low += r * cum_freq;
+    w.low += LC3_MUL24(r, cum_freq);  // r < 2^14, frequencies <= 2^10
     if ((w.low >> 24) != 0) w.carry = 1;
     w.low &= 0x00ffffffu;
-    w.range = r * sym_freq;
+    w.range = LC3_MUL24(r, sym_freq);
     while (w.range < 0x10000u) {
         w.range <<= 8;
         lc3_pk_ac_shift(w);
@@ -93,29 +128,21 @@ __device__ __forceinline__ void lc3_pk_ac_encode(lc3_pack_ctx &w, uint32_t cum_f
 
 // ---- select-based variants for the spectral loop: every lane is another frame, a branch on frame data diverges and
 // costs more scalar bookkeeping than the few operations it skips.
-// write_bool_backward (buffer_writer.rs:27-40) when `want`
-__device__ __forceinline__ void lc3_pk_bool_backward_sel(lc3_pack_ctx &w, int want, int bit) {
-    const int in = (w.bp_side >= 0) & (w.bp_side < w.nbytes);
-    const int idx = in ? w.bp_side : 0;
-    const uint32_t old = w.buf[idx], m = (uint32_t)w.mask_side;
-    const uint32_t nw = bit ? (old | m) : (old & ~m);
-    w.buf[idx] = (uint8_t)((want & in) ? nw : old);
-    const int wrap = w.mask_side == 0x80;
-    w.mask_side = want ? (wrap ? 1 : w.mask_side << 1) : w.mask_side;
-    w.bp_side -= want & wrap;
-}
 // ac_shift (bitstream_encoding.rs:397-415) when `need`
 __device__ __forceinline__ void lc3_pk_ac_shift_sel(lc3_pack_ctx &w, int need) {
     const int flush = need & ((w.low < 0x00ff0000u) | (w.carry == 1));
-    if (flush) {
-        if (w.cache >= 0) lc3_pk_byte_forward(w, (w.cache + w.carry) & 0xff);
-        while (w.carry_count > 0) {
-            lc3_pk_byte_forward(w, (w.carry + 0xff) & 0xff);
-            w.carry_count -= 1;
-        }
-        w.cache = (int)(w.low >> 16);
-        w.carry = 0;
+    {   // the cached byte goes out (to the sink when there is nothing to write)
+        const int put = flush & (w.cache >= 0);
+        *(put & (w.bp >= 0) & (w.bp < w.nbytes) ? w.buf + w.bp : w.sink) = (uint8_t)(w.cache + w.carry);
+        w.side_acc = (put & (w.bp == w.bp_side)) ? (uint32_t)((w.cache + w.carry) & 0xff) : w.side_acc;
+        w.bp += put;
     }
+    while (flush && w.carry_count > 0) {  // rare: a run of 0xff bytes was waiting for the carry
+        lc3_pk_byte_forward(w, (w.carry + 0xff) & 0xff);
+        w.carry_count -= 1;
+    }
+    w.cache = flush ? (int)(w.low >> 16) : w.cache;
+    w.carry = flush ? 0 : w.carry;
     w.carry_count += need & !flush;
     w.low = need ? (w.low << 8) & 0x00ffffffu : w.low;
 }
@@ -123,10 +150,10 @@ __device__ __forceinline__ void lc3_pk_ac_shift_sel(lc3_pack_ctx &w, int need) {
 // sym_freq >= 1), so the reference's renormalisation loop runs at most twice.
 __device__ __forceinline__ void lc3_pk_ac_encode_sel(lc3_pack_ctx &w, uint32_t cum_freq, uint32_t sym_freq) {
     const uint32_t r = w.range >> 10;
-    w.low += r * cum_freq;
+    w.low += LC3_MUL24(r, cum_freq);
     w.carry = (w.low >> 24) != 0 ? 1 : w.carry;
     w.low &= 0x00ffffffu;
-    w.range = r * sym_freq;
+    w.range = LC3_MUL24(r, sym_freq);
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int need = w.range < 0x10000u;
@@ -148,6 +175,7 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
     w.bp = 0;
     w.bp_side = w.nbytes - 1;
     w.mask_side = 1;
+    w.side_acc = 0;
     // the 21 scalar words and the 16 TNS indices of the column: one batch of independent loads (a lane of this kernel
     // is latency-bound; every plane word fetched at its point of use would cost a full memory round trip)
     int32_t sw[EP_RES];
@@ -192,6 +220,7 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
         }
         lc3_pk_uint_backward(w, (uint32_t)LC3_EPW(EP_NOISE), 3);
     }
+    LC3_PSTAMP(w, 1);
     // ac_enc_init :216-222
     w.low = 0;
     w.range = 0x00ffffffu;
@@ -218,6 +247,7 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
             }
         }
     }
+    LC3_PSTAMP(w, 2);
     // spectral_data :246-326
     int nlsbs = 0;
     {
@@ -230,17 +260,46 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
         for (int tup0 = 0; tup0 < ntup; tup0 += 8) {
 #pragma unroll
             for (int j = 0; j < 8; j++) xnext[j] = tup0 + 8 + j < ne / 2 ? (uint32_t)lc3_ep_get(w, EP_XQ + tup0 + 8 + j) : 0u;
+            // The contexts depend on the quantised values only, not on the coder's state (:262-296): the group's
+            // contexts follow in closed form, and the model words of its eight main symbols are fetched as one batch of
+            // independent LDS reads instead of two dependent reads inside every pair's coding step.
+            int tcx[8];
+            uint32_t svm[8], sve[8];  // model words of the main symbols and of the first escape symbols
+            {
+                uint32_t row[8], row0[8], sym[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = 2 * (tup0 + j);
+                    const int q0 = (int)(int16_t)(xcur[j] & 0xffffu), q1 = (int)(int16_t)(xcur[j] >> 16);
+                    const unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
+                    const unsigned m = a > b ? a : b;
+                    const int lev = m < 4u ? 0 : lc3_ilog2(m) - 1;  // escape rounds of the pair
+                    const int lv = lev < 3 ? lev : 3;
+                    const unsigned af = a >> lev, bf = b >> lev;
+                    tcx[j] = cctx + rate_flag + (k > ne / 2 ? 256 : 0);
+                    row0[j] = (uint32_t)w.lookup[tcx[j]];
+                    row[j] = (uint32_t)w.lookup[tcx[j] + lv * 1024];
+                    sym[j] = af + 4u * bf;
+                    cctx = (cctx & 15) * 16 + (lv <= 1 ? 1 + (int)(af + bf) * (lv + 1) : 12 + lv);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    svm[j] = w.cf[(int)row[j] * 17 + (int)sym[j]];
+                    sve[j] = w.cf[(int)row0[j] * 17 + 16];
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int tup = tup0 + j;
                 if (tup < ntup) {
-                    const int k = 2 * tup;
-                    int t = cctx + rate_flag + (k > ne / 2 ? 256 : 0), lev = 0;
+                    const int t = tcx[j];
+                    int lev = 0;
                     const int q0 = (int)(int16_t)(xcur[j] & 0xffffu), q1 = (int)(int16_t)(xcur[j] >> 16);
                     unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
                     unsigned a_lsb = a, b_lsb = b;
                     while ((a > b ? a : b) >= 4) {  // escape symbols: the rarer case
-                        const uint32_t sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + 16];
+                        uint32_t sv = sve[j];  // level 0 was fetched with the group
+                        if (lev > 0) sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + 16];
                         lc3_pk_ac_encode_sel(w, sv & 0xffffu, sv >> 16);
                         const int want = !(lsb_mode && lev == 0);
                         lc3_pk_bool_backward_sel(w, want, (a & 1u) == 1u);
@@ -249,10 +308,14 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
                         b >>= 1;
                         lev += 1;
                     }
+#if LC3_PACK_BATCH_SV
+                    lc3_pk_ac_encode_sel(w, svm[j] & 0xffffu, svm[j] >> 16);
+#else
                     {
                         const uint32_t sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + (int)(a + 4 * b)];
                         lc3_pk_ac_encode_sel(w, sv & 0xffffu, sv >> 16);
                     }
+#endif
                     {   // the LSB list itself is regenerated below when it is written
                         const int lsb_here = lsb_mode && lev > 0;
                         a_lsb = lsb_here ? a_lsb >> 1 : a_lsb;
@@ -261,15 +324,13 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
                     }
                     lc3_pk_bool_backward_sel(w, a_lsb > 0, q0 <= 0);
                     lc3_pk_bool_backward_sel(w, b_lsb > 0, q1 <= 0);
-                    lev = lev < 3 ? lev : 3;
-                    t = lev <= 1 ? 1 + (int)(a + b) * (lev + 1) : 12 + lev;
-                    cctx = (cctx & 15) * 16 + t;
                 }
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) xcur[j] = xnext[j];
         }
     }
+    LC3_PSTAMP(w, 3);
     // residual_data_and_finalization :328-352
     {
         const int nbits_side = w.nbits - (8 * w.bp_side + 8 - lc3_ilog2((uint32_t)w.mask_side));
@@ -282,12 +343,8 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
             const int n_res = LC3_EPW(EP_N_RES);
             if (n_enc > n_res) n_enc = n_res;
             for (int k = 0; k < n_enc; k += 32) {
-                uint32_t bits = (uint32_t)lc3_ep_get(w, EP_RES + (k >> 5));
-                const int m = n_enc - k < 32 ? n_enc - k : 32;
-                for (int j = 0; j < m; j++) {
-                    lc3_pk_bool_backward(w, (int)(bits & 1u));
-                    bits >>= 1;
-                }
+                const uint32_t bits = (uint32_t)lc3_ep_get(w, EP_RES + (k >> 5));
+                lc3_pk_uint_backward(w, bits, n_enc - k < 32 ? n_enc - k : 32);
             }
         } else {
             // lsbs[0 .. nlsbs) in the order spectral_data pushed them (:298-312), regenerated on the fly
@@ -312,6 +369,7 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
             }
         }
     }
+    LC3_PSTAMP(w, 4);
     // ac_enc_finish :354-395
     {
         int bits = 1;
@@ -347,5 +405,6 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
             lc3_pk_uint_forward(w, (unsigned)w.cache, bits);
         }
     }
+    LC3_PSTAMP(w, 5);
 #undef LC3_EPW
 }

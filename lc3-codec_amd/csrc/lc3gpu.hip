@@ -75,6 +75,8 @@ __shared__ lc3_spec_tables lc3_spec_tab;
         __syncthreads(); \
     }
 #define LC3_HBM_CONST(T) const __attribute__((address_space(1))) T *
+// product of two values below 2^24 (range-coder steps): the full-rate 24-bit multiplier instead of the quarter-rate v_mul_lo_u32
+#define LC3_MUL24(a, b) __umul24((a), (b))
 #include "lc3_dev_common.h"
 // ---- configuration slots ----------------------------------------------------------------------------------------
 // Every (sampling rate, frame duration) pair owns one slot of a __constant__ table; handles register their
@@ -148,7 +150,7 @@ __device__ __forceinline__ uint32_t lc3_wave_exscan_u32(uint32_t u, int lane) {
 // stage stamps into a per-wave table in LDS (stamp i accumulates the time since the previous stamp into slot i);
 // the table is flushed to a global one with one atomic per slot at the end of the launch, so the stamps do not put
 // memory traffic inside the stages.  Never timed as a whole; read its SHARES (cdna_hip_programming.md section 7).
-__device__ unsigned long long lc3_prof_acc[48];  // 0..31 stage sums; 32/33/34 enc wave time sum/max/count, 35/36/37 dec; 40..47 parse kernel
+__device__ unsigned long long lc3_prof_acc[64];  // 0..31 stage sums; 32/33/34 enc wave time sum/max/count, 35/36/37 dec; 40..47 parse kernel; 48..55 pack kernel
 #undef LC3_STAMP
 #define LC3_STAMP(L, lane, id)                                                     \
     do {                                                                           \
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_bac
 
 // Bitstream packer, one LANE per frame (lc3_dev_enc_pack.h).  blockDim.x frames per workgroup; context lookup and the
 // packed spectral model in LDS, every lane builds its frame in an LDS staging slot, then the workgroup copies the
-// frames out with coalesced stores.  Dynamic LDS: 4096 + 64*17*4 + blockDim.x * nbytes (rounded up to 4).
+// frames out with coalesced stores.  Dynamic LDS: 4096 + 64*17*4 + blockDim.x * nbytes (rounded up to 4) + 4 (sink).
 __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *planes, uint8_t *out, int nbytes,
                                                        int n_frames) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -304,6 +306,10 @@ __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *pl
     const size_t remaining = (size_t)n_frames - f0;
     const int nfr = remaining < (size_t)fpb ? (int)remaining : fpb;
     const int total = nfr * nbytes;
+#ifdef LC3_PROFILE
+    const unsigned long long pk_t0 = clock64();
+    unsigned long long pk_t1 = 0, pk_t2 = 0, pk_pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     {
         const uint32_t *lk32 = (const uint32_t *)LC3T_AC_SPEC_LOOKUP;
         uint32_t *d32 = (uint32_t *)s_lookup;
@@ -320,13 +326,25 @@ __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *pl
     if (f < (size_t)n_frames) {
         lc3_pack_ctx c;
         c.buf = s_bytes + tid * nbytes;
+        c.sink = s_bytes + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3);
         c.nbytes = nbytes;
         c.lookup = s_lookup;
         c.cf = s_cf;
         c.plane = LC3_PLANE_COL(planes, f, EP_WORDS);
         c.stride = LC3_PLANE_STRIDE;
+#ifdef LC3_PROFILE
+        for (int i = 0; i < 8; i++) c.pt[i] = 0;
+        c.plast = clock64();
+        pk_t1 = c.plast;
+#endif
         lc3_pack_frame(c, ne);
+#ifdef LC3_PROFILE
+        for (int i = 0; i < 8; i++) pk_pt[i] = c.pt[i];
+#endif
     }
+#ifdef LC3_PROFILE
+    pk_t2 = clock64();
+#endif
     __syncthreads();
     uint8_t *dst = out + f0 * (size_t)nbytes;
     if ((((uintptr_t)dst) & 3u) == 0) {
@@ -337,15 +355,24 @@ __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *pl
     } else {
         for (int i = tid; i < total; i += fpb) dst[i] = s_bytes[i];
     }
+#ifdef LC3_PROFILE
+    if ((tid & 63) == 0 && pk_t1) {  // 48: staging; 49..53: sections of lc3_pack_frame; 54: barrier wait + copy-out; 55: waves
+        const unsigned long long t3 = clock64();
+        atomicAdd(&lc3_prof_acc[48], pk_t1 - pk_t0);
+        for (int i = 1; i <= 5; i++) atomicAdd(&lc3_prof_acc[48 + i], pk_pt[i]);
+        atomicAdd(&lc3_prof_acc[54], t3 - pk_t2);
+        atomicAdd(&lc3_prof_acc[55], 1ull);
+    }
+#endif
 }
 
 // Frame parser, one LANE per frame (lc3_dev_dec_parse.h).  256 frames per workgroup; the context lookup, the packed
 // (cum | freq) spectral model and the frames' bytes are staged in LDS with coalesced loads.  blockDim.x frames per
 // workgroup (256, or 128 for frames above 220 bytes so that the staging fits 64 KB of dynamic LDS):
 // 4096 + 64*17*4 + blockDim.x*nbytes bytes.
-// Dynamic LDS: 4096 (context lookup) + 64*17*4 (spectral model) + 16*11*4 (MPVQ offsets) + 152*4 (TNS models) + 16*4*blockDim.x (scale
+// Dynamic LDS: 4096 (context lookup) + 64*20*4 (spectral model, lc3_dcf_word) + 16*11*4 (MPVQ offsets) + 152*4 (TNS models) + 16*4*blockDim.x (scale
 // factors, [n][lane]) + blockDim.x * nbytes (frame bytes).
-#define LC3_PARSE_LDS_FIXED (4096 + 64 * 17 * 4 + 16 * 11 * 4 + 4 * 152)
+#define LC3_PARSE_LDS_FIXED (4096 + 64 * LC3_DCF_ROW_WORDS * 4 + 16 * 11 * 4 + 4 * 152)
 __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot cfg, const uint8_t *in, const uint8_t *bad,
                                                         int32_t *planes, int nbytes, int n_frames) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -354,8 +381,8 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot cfg, const 
     const int tid = threadIdx.x, fpb = blockDim.x;
     uint8_t *s_lookup = smem;
     uint32_t *s_cf = (uint32_t *)(smem + 4096);
-    uint32_t *s_mpvq = (uint32_t *)(smem + 4096 + 64 * 17 * 4);
-    uint32_t *s_tns = (uint32_t *)(smem + 4096 + 64 * 17 * 4 + 16 * 11 * 4);
+    uint32_t *s_mpvq = (uint32_t *)(smem + 4096 + 64 * LC3_DCF_ROW_WORDS * 4);
+    uint32_t *s_tns = (uint32_t *)(smem + 4096 + 64 * LC3_DCF_ROW_WORDS * 4 + 16 * 11 * 4);
     float *s_scf = (float *)(smem + LC3_PARSE_LDS_FIXED);
     uint8_t *s_bytes = smem + LC3_PARSE_LDS_FIXED + 16 * 4 * fpb;
     const size_t f0 = (size_t)blockIdx.x * (size_t)fpb;
@@ -365,10 +392,7 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot cfg, const 
         const uint32_t *lk32 = (const uint32_t *)LC3T_AC_SPEC_LOOKUP;
         uint32_t *d32 = (uint32_t *)s_lookup;
         for (int i = tid; i < 1024; i += fpb) d32[i] = lk32[i];
-        for (int i = tid; i < 64 * 17; i += fpb) {
-            const int p = i / 17, j = i - 17 * p;
-            s_cf[i] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[p][j] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[p][j] << 16);
-        }
+        for (int i = tid; i < 64 * LC3_DCF_ROW_WORDS; i += fpb) s_cf[i] = lc3_dcf_word(i);
         const size_t remaining = (size_t)n_frames - f0;
         const int nfr = remaining < (size_t)fpb ? (int)remaining : fpb;
         const int total = nfr * nbytes;
@@ -771,7 +795,7 @@ static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_p
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
     const unsigned fpb = lc3_frame_block(nbytes <= 220 ? 256u : 128u);
-    const size_t lds = 4096 + 64 * 17 * 4 + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3);
+    const size_t lds = 4096 + 64 * 17 * 4 + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3) + 4;  // + the packer's sink byte
     hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, e->h.c.ne,
                        (const int32_t *)e->d_planes, d_out, nbytes, (int)frames);
     HIP_TRY(hipGetLastError());
@@ -1010,10 +1034,10 @@ int lc3gpu_decoder_timing(lc3gpu_decoder *d, int enable, double out[3]) {
 }
 
 // diagnostic build only: copy (and clear) the per-stage cycle accumulators; LC3GPU_EUNSUPPORTED otherwise
-int lc3gpu_prof_read(unsigned long long out[48]) {
+int lc3gpu_prof_read(unsigned long long out[64]) {
 #ifdef LC3_PROFILE
     if (!out) return LC3GPU_EINVAL;
-    unsigned long long zero[48] = {0};
+    unsigned long long zero[64] = {0};
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(lc3_prof_acc), sizeof(zero)));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lc3_prof_acc), zero, sizeof(zero)));

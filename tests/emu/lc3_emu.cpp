@@ -245,7 +245,9 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
     memset(bytes, 0, frames * (size_t)nbytes);
     for (size_t f = 0; f < frames; f++) {
         lc3_pack_ctx c;
+        uint8_t sink = 0;
         c.buf = bytes + f * (size_t)nbytes;
+        c.sink = &sink;
         c.nbytes = nbytes;
         c.lookup = LC3T_AC_SPEC_LOOKUP;
         c.cf = cf.data();
@@ -271,10 +273,8 @@ int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8
     // stage 1: the lane-per-frame parser (lc3_dev_dec_parse.h) -- on the GPU 64 frames per wave, here a plain loop
     const size_t frames = (size_t)S * (size_t)T;
     std::vector<int32_t> planes(((frames + 63) / 64) * 64 * LC3_PLANE_WORDS, 0);
-    std::vector<uint32_t> cf(64 * 17);
-    for (int p = 0; p < 64; p++)
-        for (int q = 0; q < 17; q++)
-            cf[(size_t)p * 17 + q] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[p][q] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[p][q] << 16);
+    alignas(16) static uint32_t cf[64 * LC3_DCF_ROW_WORDS];
+    for (int i = 0; i < 64 * LC3_DCF_ROW_WORDS; i++) cf[i] = lc3_dcf_word(i);
     std::vector<uint32_t> tns(LC3_TNS_MODEL_WORDS);
     for (int i = 0; i < LC3_TNS_MODEL_WORDS; i++) tns[(size_t)i] = lc3_tns_model_word(i);
     for (size_t f = 0; f < frames; f++) {
@@ -283,7 +283,7 @@ int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8
         c.bytes = bytes + f * (size_t)nbytes;
         c.len = nbytes;
         c.lookup = LC3T_AC_SPEC_LOOKUP;
-        c.cf = cf.data();
+        c.cf = cf;
         c.plane = LC3_PLANE_COL(planes.data(), f, LC3_PLANE_WORDS);
         c.stride = LC3_PLANE_STRIDE;
         c.head = 0;

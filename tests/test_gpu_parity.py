@@ -346,3 +346,45 @@ def test_channel_ranges_on_separate_hip_streams():
             out_p[first:first + n, t0:t0 + tn] = d_p.cpu().numpy()
     assert np.array_equal(out_b, ref_b)
     assert np.array_equal(out_p, ref_p)
+
+
+MIXED = [  # BASELINE config 4: (fs, frame_us, bytes per frame); 8 kHz is decode-only (no reference encoder)
+    (16000, 10000, 40), (24000, 10000, 60), (32000, 10000, 80), (44100, 10000, 110), (48000, 10000, 150),
+    (16000, 7500, 30), (24000, 7500, 45), (32000, 7500, 60), (44100, 7500, 83), (48000, 7500, 113),
+    (8000, 10000, 30), (8000, 7500, 23),
+]
+
+
+def test_mixed_configuration_batch():
+    """All twelve (rate, duration) configurations in flight at once: one handle pair per configuration, each on its
+    own HIP stream, everything queued before the first synchronisation (the configurations share the kernels and the
+    constant configuration table, nothing else).  Two calls per handle so that the state is carried."""
+    t = torch_mod()
+    S, T = 40, 3
+    jobs = []
+    for fs, us, nb in MIXED:
+        cfg = pkg.Lc3Config(fs, us)
+        pcm = synth.make_pcm(S, 2 * T, cfg.nf, fs, seed=41)
+        ref_b = O.encode_batch(pcm, nb, fs, us)
+        ref_p = O.decode_batch(ref_b, cfg.nf, fs, us)
+        jobs.append(dict(fs=fs, us=us, nb=nb, nf=cfg.nf, pcm=pcm, ref_b=ref_b, ref_p=ref_p, st=t.cuda.Stream(),
+                         enc=pkg.Lc3Encoder(S, us, fs) if fs != 8000 else None, dec=pkg.Lc3Decoder(S, us, fs), out=[]))
+    t.cuda.synchronize()
+    for t0 in (0, T):
+        for j in jobs:
+            with t.cuda.stream(j["st"]):
+                d_b = t.zeros((S, T, j["nb"]), dtype=t.uint8, device="cuda")
+                d_p = t.zeros((S, T, j["nf"]), dtype=t.int16, device="cuda")
+                if j["enc"] is not None:
+                    d_pcm = t.from_numpy(np.ascontiguousarray(j["pcm"][:, t0:t0 + T])).cuda()
+                    j["enc"].encode(d_pcm, d_b, j["nb"], T, stream=j["st"].cuda_stream)
+                else:
+                    d_b.copy_(t.from_numpy(np.ascontiguousarray(j["ref_b"][:, t0:t0 + T])))
+                j["dec"].decode(d_b, d_p, j["nb"], T, stream=j["st"].cuda_stream)
+                j["out"].append((d_b, d_p))
+    t.cuda.synchronize()
+    for j in jobs:
+        got_b = np.concatenate([b.cpu().numpy() for b, _ in j["out"]], axis=1)
+        got_p = np.concatenate([p.cpu().numpy() for _, p in j["out"]], axis=1)
+        assert np.array_equal(got_b, j["ref_b"]), (j["fs"], j["us"])
+        assert np.array_equal(got_p, j["ref_p"]), (j["fs"], j["us"])

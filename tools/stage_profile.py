@@ -66,3 +66,10 @@ ptot = sum(acc[40:47])
 print(f"parse kernel: {ptot / waves:.0f} cycles per wave of 64 frames")
 for i, nme in enumerate(pn):
     print(f"  {nme:70s} {acc[40 + i] / waves:10.0f} cyc/wave  {100.0 * acc[40 + i] / max(ptot, 1):5.1f} %")
+kn = ["table + frame staging (to the first barrier)", "side information", "TNS data", "spectral data (range coder)", "residual bits / LSBs",
+      "range coder finish", "wait for the workgroup's slowest wave + copy-out"]
+kw = max(acc[55], 1)
+ktot = sum(acc[48:55])
+print(f"pack kernel: {ktot / kw:.0f} cycles per wave of 64 frames")
+for i, nme in enumerate(kn):
+    print(f"  {nme:70s} {acc[48 + i] / kw:10.0f} cyc/wave  {100.0 * acc[48 + i] / max(ktot, 1):5.1f} %")
