@@ -223,11 +223,12 @@ __device__ __forceinline__ void lc3_p_ac_renorm_sel(lc3_parse_ctx &c, lc3_acdec 
     st.low = need0 ? ((st.low << 8) & 0x00ffffffu) + c.hb0 : st.low;
     st.range = need0 ? st.range << 8 : st.range;
     c.head += need0;
-    const int need1 = st.range < 0x10000u;
-    err |= need1 & (c.head >= c.len);
-    st.low = need1 ? ((st.low << 8) & 0x00ffffffu) + c.hb1 : st.low;
-    st.range = need1 ? st.range << 8 : st.range;
-    c.head += need1;
+    if (st.range < 0x10000u) {  // a second byte only after a symbol of probability below 2^-8: usually no lane of the wave
+        err |= c.head >= c.len;
+        st.low = ((st.low << 8) & 0x00ffffffu) + c.hb1;
+        st.range <<= 8;
+        c.head += 1;
+    }
     c.hb0 = lc3_p_head_byte(c, c.head);
     c.hb1 = lc3_p_head_byte(c, c.head + 1);
 }

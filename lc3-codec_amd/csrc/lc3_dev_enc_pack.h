@@ -54,16 +54,16 @@ __device__ __forceinline__ int32_t lc3_ep_get(const lc3_pack_ctx &c, int word) {
 // has already passed it (then it is loaded), and a forward byte landing on the mirrored byte updates the mirror too.
 // write_bool_backward (buffer_writer.rs:27-40) when `want`
 __device__ __forceinline__ void lc3_pk_bool_backward_sel(lc3_pack_ctx &w, int want, int bit) {
-    const int in = (w.bp_side >= 0) & (w.bp_side < w.nbytes);
+    // bp_side starts at nbytes - 1 and only decreases: in range means not negative
     const uint32_t m = (uint32_t)w.mask_side;
     const uint32_t nw = bit ? (w.side_acc | m) : (w.side_acc & ~m);
     w.side_acc = want ? nw : w.side_acc;
-    *(in ? w.buf + w.bp_side : w.sink) = (uint8_t)w.side_acc;  // without `want` this rewrites the byte with its own value
+    *(w.bp_side >= 0 ? w.buf + w.bp_side : w.sink) = (uint8_t)w.side_acc;  // without `want` this rewrites the byte with its own value
     const int wrap = want & (w.mask_side == 0x80);
     w.mask_side = want ? (wrap ? 1 : w.mask_side << 1) : w.mask_side;
     w.bp_side -= wrap;
     w.side_acc = wrap ? 0u : w.side_acc;
-    if (wrap && w.bp > w.bp_side && w.bp_side >= 0 && w.bp_side < w.nbytes) w.side_acc = w.buf[w.bp_side];  // rare: the writers crossed
+    if (wrap & (w.bp > w.bp_side)) w.side_acc = w.bp_side >= 0 ? (uint32_t)w.buf[w.bp_side] : 0u;  // rare: the writers crossed
 }
 __device__ __forceinline__ void lc3_pk_bool_backward(lc3_pack_ctx &w, int bit) { lc3_pk_bool_backward_sel(w, 1, bit); }
 // write_uint_backward (:19-25): nbits (<= 32) bits of val, least significant first -- the reference's bit-by-bit loop done a
@@ -75,19 +75,18 @@ __device__ __forceinline__ void lc3_pk_uint_backward(lc3_pack_ctx &w, uint32_t v
         const int take = nbits < 8 - o ? nbits : 8 - o;
         const uint32_t field = ((1u << take) - 1u) << o;
         w.side_acc = (w.side_acc & ~field) | ((val << o) & field);
-        const int in = (w.bp_side >= 0) & (w.bp_side < w.nbytes);
-        *(in ? w.buf + w.bp_side : w.sink) = (uint8_t)w.side_acc;
+        *(w.bp_side >= 0 ? w.buf + w.bp_side : w.sink) = (uint8_t)w.side_acc;
         const int wrap = o + take == 8;
         w.mask_side = wrap ? 1 : w.mask_side << take;
         w.bp_side -= wrap;
         w.side_acc = wrap ? 0u : w.side_acc;
-        if (wrap && w.bp > w.bp_side && w.bp_side >= 0 && w.bp_side < w.nbytes) w.side_acc = w.buf[w.bp_side];  // rare: the writers crossed
+        if (wrap & (w.bp > w.bp_side)) w.side_acc = w.bp_side >= 0 ? (uint32_t)w.buf[w.bp_side] : 0u;  // rare: the writers crossed
         val >>= take;
         nbits -= take;
     }
 }
 __device__ __forceinline__ void lc3_pk_byte_forward(lc3_pack_ctx &w, int val) {  // :55-58
-    *((w.bp >= 0) & (w.bp < w.nbytes) ? w.buf + w.bp : w.sink) = (uint8_t)val;
+    *(w.bp < w.nbytes ? w.buf + w.bp : w.sink) = (uint8_t)val;  // bp starts at 0 and only grows
     w.side_acc = w.bp == w.bp_side ? (uint32_t)(val & 0xff) : w.side_acc;
     w.bp += 1;
 }
@@ -133,7 +132,7 @@ __device__ __forceinline__ void lc3_pk_ac_shift_sel(lc3_pack_ctx &w, int need) {
     const int flush = need & ((w.low < 0x00ff0000u) | (w.carry == 1));
     {   // the cached byte goes out (to the sink when there is nothing to write)
         const int put = flush & (w.cache >= 0);
-        *(put & (w.bp >= 0) & (w.bp < w.nbytes) ? w.buf + w.bp : w.sink) = (uint8_t)(w.cache + w.carry);
+        *(put & (w.bp < w.nbytes) ? w.buf + w.bp : w.sink) = (uint8_t)(w.cache + w.carry);
         w.side_acc = (put & (w.bp == w.bp_side)) ? (uint32_t)((w.cache + w.carry) & 0xff) : w.side_acc;
         w.bp += put;
     }
@@ -154,11 +153,14 @@ __device__ __forceinline__ void lc3_pk_ac_encode_sel(lc3_pack_ctx &w, uint32_t c
     w.carry = (w.low >> 24) != 0 ? 1 : w.carry;
     w.low &= 0x00ffffffu;
     w.range = LC3_MUL24(r, sym_freq);
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
+    {
         const int need = w.range < 0x10000u;
         w.range = need ? w.range << 8 : w.range;
         lc3_pk_ac_shift_sel(w, need);
+    }
+    if (w.range < 0x10000u) {  // a second byte only after a symbol of probability below 2^-8: usually no lane of the wave
+        w.range <<= 8;
+        lc3_pk_ac_shift_sel(w, 1);
     }
 }
 
