@@ -94,4 +94,27 @@ private:
     lc3gpu_decoder *h_ = nullptr;
 };
 
+// ---- the reference's no_std / no-alloc API shape (lc3_encoder.rs:37-40,212-303, lc3_decoder.rs:56-60,247-310): the
+// number of channels is a compile-time constant instead of a constructor argument (`Lc3Encoder::<NUM_CH>::new(duration,
+// frequency, ..)`, `Lc3Encoder::<NUM_CH>::calc_working_buffer_lengths(duration, frequency)`; default 2 as in the
+// reference).  Same engine underneath; the caller-lent working buffers of the reference have no counterpart here.
+template <size_t NUM_CHANNELS = 2>
+class Lc3EncoderStatic : public Lc3Encoder {
+public:
+    static constexpr size_t num_channels = NUM_CHANNELS;
+    static std::tuple<size_t, size_t, size_t> calc_working_buffer_lengths(FrameDuration d, SamplingFrequency f) {
+        return Lc3Encoder::calc_working_buffer_lengths(NUM_CHANNELS, d, f);
+    }
+    Lc3EncoderStatic(FrameDuration d, SamplingFrequency f) : Lc3Encoder(NUM_CHANNELS, d, f) {}
+};
+template <size_t NUM_CHANNELS = 2>
+class Lc3DecoderStatic : public Lc3Decoder {
+public:
+    static constexpr size_t num_channels = NUM_CHANNELS;
+    static std::tuple<size_t, size_t> calc_working_buffer_lengths(FrameDuration d, SamplingFrequency f) {
+        return Lc3Decoder::calc_working_buffer_lengths(NUM_CHANNELS, d, f);
+    }
+    Lc3DecoderStatic(FrameDuration d, SamplingFrequency f) : Lc3Decoder(NUM_CHANNELS, d, f) {}
+};
+
 }  // namespace lc3gpu

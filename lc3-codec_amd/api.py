@@ -82,7 +82,8 @@ def build_tool(force=False, verbose=False):
     """Compile the file-driver command line tool (host/lc3_files.cpp, host/lc3gpu_tool.cpp) against liblc3gpu.so."""
     host = os.path.join(_HERE, "host")
     srcs = [os.path.join(host, f) for f in ("lc3_files.cpp", "lc3gpu_tool.cpp")]
-    deps = srcs + [os.path.join(host, "lc3_files.hpp"), os.path.join(_ROOT, "include", "lc3gpu.h"), _LIB]
+    deps = srcs + [os.path.join(host, "lc3_files.hpp"), os.path.join(_ROOT, "include", "lc3gpu.h"),
+                   os.path.join(_ROOT, "include", "lc3gpu.hpp"), _LIB]
     out = tool_path()
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out

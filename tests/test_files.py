@@ -128,3 +128,25 @@ def test_file_round_trip_matches_oracle(tool, tmp_path, fs, us, channels, nbytes
     full = O.decode_batch(ref, nf, fs, us)
     assert struct.unpack("<I", out[40:44])[0] == n_frames * nf * channels * 2 and out[32:34] == struct.pack("<H", channels * 2)
     assert out[44:] == np.ascontiguousarray(full.reshape(channels, n_frames * nf).T).astype("<i2").tobytes()
+
+
+def test_static_channel_api_buffer_lengths(tool):
+    """The no_std API shape (channel count as a template argument, lc3_encoder.rs:286-303, lc3_decoder.rs:296-310) through
+    the C++ facade: the reference's numbers for 48 kHz / 10 ms (1900/1106/960 and 4971/960 per channel), twice
+    that for the default two channels.  No device needed."""
+    r1 = run(tool, "buffer-lengths", 1, 48000, 10000)
+    r2 = run(tool, "buffer-lengths", 2, 48000, 10000)
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr
+    one = list(map(int, r1.stdout.split()))
+    assert one == [1900, 1106, 960, 4971, 960]
+    assert list(map(int, r2.stdout.split())) == [2 * v for v in one]
+    assert run(tool, "buffer-lengths", 1, 12345, 10000).returncode == 1  # unsupported rate: an error, not an abort
+
+
+@pytest.mark.gpu
+def test_single_frame_timing_harness(tool):
+    """examples/arm/src/main.rs:39-112 shape: one channel, one encode_frame and one decode_frame call, host-timed."""
+    r = run(tool, "frame-timing", 48000, 10000, 150, 20)
+    assert r.returncode == 0, r.stderr
+    assert "Encoded in" in r.stdout and "Decoded in" in r.stdout
+    assert "(1900, 1106, 960)" in r.stdout

@@ -7,4 +7,4 @@ for grp in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "SQ_IFETCH SQ_WAVE
   i=$((i+1))
   rocprofv3 --pmc $grp -d $out/pass$i --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $out/pass$i.log 2>&1 || echo "pass $i ($grp) failed: $(tail -2 $out/pass$i.log)"
 done
-python3 tools/pmc_summary.py $out | grep "encode\|counter"
+python3 tools/pmc_summary.py $out 
