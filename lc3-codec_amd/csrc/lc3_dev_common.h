@@ -140,6 +140,8 @@ struct lc3_cfg {
     int resamp_lim, resamp_nt, resamp_stride;
     int inv_p;     // ceil(2^16 / p_up): x / p_up == (x * inv_p) >> 16 for x = 15 n, n < len12
     const float *resamp_poly;
+    // width (in lines, as f32) of the band each spectral line belongs to, ne entries (lc3_line_width_value)
+    const float *line_width;
     // decoder LTPF (decoder/long_term_post_filter.rs:104-134)
     int l_den, l_num, num_mem_blocks, norm, s25;
 };
@@ -692,6 +694,13 @@ __device__ __forceinline__ const uint16_t *lc3_band_index(const lc3_cfg &c) {
     default: return LC3T_I_48000_7P5MS;
     }
 }
+// band width of spectral line k (the divisor of apply_energy_estimation, encoder/modified_dct.rs:140-152); fills c.line_width
+__device__ __forceinline__ float lc3_line_width_value(const lc3_cfg &c, int k) {
+    const uint16_t *ifs = lc3_band_index(c);
+    int b = 0;
+    while (b + 1 < c.nb && (int)ifs[b + 1] <= k) b++;
+    return (float)((int)ifs[b + 1] - (int)ifs[b]);
+}
 
 // ------------------------------------------------------------------------------------------
 // Complex FFT (common/kissfft.rs) and DCT-IV (common/dct_iv.rs), wave-parallel over butterflies.
@@ -813,6 +822,36 @@ __device__ __forceinline__ void lc3_dct4_wave(const lc3_cfg &c, int lane, float 
         lc3_cpx y = lc3_cmul(c.dct_tw[n], fb[n]);
         buf[2 * n] = y.r * 2.0f;
         buf[nf - 2 * n - 1] = -y.i * 2.0f;
+    }
+    LC3_SYNC();
+}
+// The same transform with two buffers instead of three: a[0..nf) -> b[0..nf), a is destroyed (it serves as the complex work
+// array once the pre-twiddle has consumed it).  Same operations in the same order as lc3_dct4_wave.
+__device__ __forceinline__ void lc3_dct4_wave_ab(const lc3_cfg &c, int lane, float *a, float *b) {
+    const int nf = c.nf, cnt = c.nfft;
+    lc3_cpx *ca = (lc3_cpx *)a, *cb = (lc3_cpx *)b;
+    for (int n = lane; n < cnt; n += LC3_WAVE) {  // pre-twiddle :53-56
+        lc3_cpx x;
+        x.r = a[2 * n];
+        x.i = a[nf - 2 * n - 1];
+        cb[n] = lc3_cmul(c.dct_tw[n], x);
+    }
+    LC3_SYNC();
+    for (int o = lane; o < cnt; o += LC3_WAVE) ca[o] = cb[c.perm[o]];  // leaf gather of kf_work (kissfft.rs:101-108)
+    LC3_SYNC();
+    for (int s = c.n_stages - 1; s >= 0; s--) {  // butterfly stages, innermost first
+        const int p = c.radix[s], m = c.m[s], fstride = c.fstride[s];
+        const int nb = cnt / p;
+        for (int u = lane; u < nb; u += LC3_WAVE) {
+            const int blk = (u * c.inv_m[s]) >> 16, i = u - blk * m;
+            lc3_bfly(ca + blk * p * m, c.fft_tw, p, fstride, m, i);
+        }
+        LC3_SYNC();
+    }
+    for (int n = lane; n < cnt; n += LC3_WAVE) {  // post-twiddle :62-66
+        lc3_cpx y = lc3_cmul(c.dct_tw[n], ca[n]);
+        b[2 * n] = y.r * 2.0f;
+        b[nf - 2 * n - 1] = -y.i * 2.0f;
     }
     LC3_SYNC();
 }

@@ -7,9 +7,9 @@
 #include "lc3_dev_dec_parse.h"
 
 // Persistent per-stream decoder state.  `core` is what a wave keeps resident in LDS while it
-// works on the stream; plc_last_good stays in HBM (written once per good frame, read only when concealing).
+// works on the stream; the IMDCT overlap memory (read once and written once per frame, element n by the same lane) and
+// plc_last_good (written once per good frame, read only when concealing) stay in HBM.
 struct lc3_dec_core {
-    float mem_ola[304];            // IMDCT overlap memory, nf - z used (decoder/modified_dct.rs:30,149)
     float x_hat_ltpf_mem[1080];    // LTPF output ring, num_mem_blocks * nf (decoder/long_term_post_filter.rs:127-128)
     float x_tail[12];              // last l_num samples of the previous LTPF input frame: the only part of the
                                    // reference's x_hat_mem ring that is ever read back (:380-387, k <= l_num)
@@ -24,16 +24,16 @@ struct lc3_dec_core {
 static_assert(sizeof(lc3_dec_core) % 16 == 0, "decoder state blob must stay a multiple of 16 bytes");
 struct lc3_dec_state {
     lc3_dec_core core;
+    float mem_ola[304];               // IMDCT overlap memory, nf - z used (decoder/modified_dct.rs:30,149)
     float plc_last_good[LC3_MAX_NE];  // decoder/packet_loss_concealment.rs:7-22
 };
 #define LC3_DEC_CORE_WORDS ((int)(sizeof(lc3_dec_core) / 4))
 
-// LDS working set of one decoder wave (12.5 KB; the synthesis kernel is 9 % of a step, its occupancy is not tuned)
+// LDS working set of one decoder wave: 9.2 KB, four workgroups (16 streams) per CU
 struct __attribute__((aligned(16))) lc3_dec_lds {
     lc3_dec_core st;
-    float spec[LC3_MAX_NF];        // spec_lines, then freq_samples
-    lc3_cpx fa[LC3_MAX_NF / 2];    // FFT in   | t_hat_mdct[0 .. nf)
-    lc3_cpx fb[LC3_MAX_NF / 2];    // FFT work | t_hat_mdct[nf .. 2nf)  (contiguous with fa)
+    float spec[LC3_MAX_NF];        // spec_lines -> FFT work array -> time samples
+    lc3_cpx fa[LC3_MAX_NF / 2];    // pre-twiddled FFT input -> DCT-IV output
     float sm[192];
     int ism[64];
     unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
@@ -46,8 +46,10 @@ static_assert(offsetof(lc3_dec_lds, spec) % 16 == 0 && offsetof(lc3_dec_lds, fa)
               "128-bit LDS accesses need aligned buffers");
 
 __device__ __forceinline__ void lc3_dec_state_init(lc3_dec_lds &L, int lane, lc3_dec_state *g, int valid) {
-    if (valid)
+    if (valid) {
         for (int i = lane; i < LC3_MAX_NE; i += LC3_WAVE) g->plc_last_good[i] = 0.0f;
+        for (int i = lane; i < 304; i += LC3_WAVE) g->mem_ola[i] = 0.0f;
+    }
     int *w = (int *)&L.st;
     for (int i = lane; i < LC3_DEC_CORE_WORDS; i += LC3_WAVE) w[i] = 0;
     LC3_SYNC();
@@ -69,34 +71,42 @@ __device__ __forceinline__ void lc3_dec_state_store(lc3_dec_lds &L, int lane, lc
 // ------------------------------------------------------------------------------------------
 // D10: IMDCT + window + overlap-add (decoder/modified_dct.rs:76-151); spec -> time samples in spec
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane) {
+__device__ __noinline__ void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, lc3_dec_state *g, int valid) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     const int nf = c.nf, ne = c.ne, z = c.z, h = nf / 2;
     const uint32_t *w = lc3_window_bits(c);
     float *freq = L.spec;
-    float *t = (float *)L.fa;  // t_hat_mdct[2*nf] aliases the FFT buffers (free once the DCT-IV has finished)
+    float *u = (float *)L.fa;  // DCT-IV output
+    // the overlap memory of the previous frame: requested now, used after the transform (element n belongs to lane n % 64
+    // in every frame, so a lane reads back what it stored itself)
+    float mo[5];  // nf - z <= 300
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int n = lane + LC3_WAVE * r;
+        mo[r] = n < nf - z ? g->mem_ola[n] : 0.0f;
+    }
     for (int n = ne + lane; n < nf; n += LC3_WAVE) freq[n] = 0.0f;
     LC3_SYNC();
-    lc3_dct4_wave(c, lane, freq, L.fa, L.fb);
+    lc3_dct4_wave_ab(c, lane, freq, u);
     LC3_STAMP(L, lane, 25);
-    // unfold :97-136, gain, reversed window :89-91 -- values are staged in registers because t aliases fa/fb
+    // unfold :97-136, gain, reversed window :89-91 and overlap_add :138-151 in one pass: the reference's
+    // t_hat_mdct[i] = unfolded(i) * gain * w[2nf - 1 - i] is evaluated where it is consumed (each element is used once)
     const float gain = 1.0f / lc3_sqrtf(2.0f * (float)nf);
-    for (int n = lane; n < h; n += LC3_WAVE) {
-        float v0 = freq[h + n], v1 = -freq[nf - 1 - n], v2 = -freq[h - 1 - n], v3 = -freq[n];
-        v0 *= gain; v1 *= gain; v2 *= gain; v3 *= gain;
-        t[n] = v0 * lc3_f(w, 2 * nf - 1 - n);
-        t[h + n] = v1 * lc3_f(w, 2 * nf - 1 - (h + n));
-        t[nf + n] = v2 * lc3_f(w, 2 * nf - 1 - (nf + n));
-        t[3 * h + n] = v3 * lc3_f(w, 2 * nf - 1 - (3 * h + n));
+#define LC3_THAT(i)                                                                                                   \
+    ((((i) < h ? u[h + (i)] : ((i) < nf ? -u[nf - 1 - ((i) - h)] : ((i) < 3 * h ? -u[h - 1 - ((i) - nf)] : -u[(i) - 3 * h]))) * gain) * \
+     lc3_f(w, 2 * nf - 1 - (i)))
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int n = lane + LC3_WAVE * r;
+        if (n < nf - z) {
+            freq[n] = mo[r] + LC3_THAT(z + n);
+            const float keep = LC3_THAT(nf + z + n);
+            if (valid) g->mem_ola[n] = keep;
+        }
     }
-    LC3_SYNC();
-    // overlap_add :138-151
-    for (int n = lane; n < nf - z; n += LC3_WAVE) {
-        freq[n] = L.st.mem_ola[n] + t[z + n];
-        L.st.mem_ola[n] = t[nf + z + n];
-    }
-    for (int n = lane; n < z; n += LC3_WAVE) freq[nf - z + n] = t[nf + n];
+    for (int n = lane; n < z; n += LC3_WAVE) freq[nf - z + n] = LC3_THAT(nf + n);
+#undef LC3_THAT
     LC3_SYNC();
 }
 
@@ -347,7 +357,7 @@ __device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 18);
-    lc3_dec_imdct(LC3_CFG_PASS, LC3_LDS_PASS lane);
+    lc3_dec_imdct(LC3_CFG_PASS, LC3_LDS_PASS lane, g, valid);
     LC3_STAMP(L, lane, 19);
     lc3_dec_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, ltpf_active, pitch_index, nbits);
     LC3_STAMP(L, lane, 20);

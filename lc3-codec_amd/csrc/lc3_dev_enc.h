@@ -177,19 +177,29 @@ __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_ld
         for (int k = lane; k < nf; k += LC3_WAVE) L.spec[k] *= gain;
     }
     LC3_SYNC();
-    // apply_energy_estimation :140-152 -- one lane per band, terms accumulated in order
-    for (int b = lane; b < c.nb; b += LC3_WAVE) {
-        int from = ifs[b], to = ifs[b + 1];
-        float width = (float)(to - from), acc = 0.0f;
-        for (int k = from; k < to; k += 4) {  // four lines per LDS round trip
-            float x[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) x[u] = k + u < to ? L.spec[k + u] : 0.0f;
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (k + u < to) acc += x[u] * x[u] / width;
+    // apply_energy_estimation :140-152: E_b = sum over the band's lines of (X_k * X_k / width), the division inside the
+    // sum.  The terms are independent: one line per lane (seven rounds instead of up to 25 divisions in a row
+    // on the lanes of the widest bands); then one lane per band adds its terms in the reference's order.
+    {
+        float *e = (float *)L.fa;  // fa is free after the transform; the band energies live at fa + 512 floats
+        for (int k = lane; k < c.ne; k += LC3_WAVE) {
+            const float x = L.spec[k];
+            e[k] = x * x / c.line_width[k];
         }
-        LC3_EB(L)[b] = acc;
+        LC3_SYNC();
+        for (int b = lane; b < c.nb; b += LC3_WAVE) {
+            const int from = ifs[b], to = ifs[b + 1];
+            float acc = 0.0f;
+            for (int k = from; k < to; k += 4) {  // four terms per LDS round trip
+                float x[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) x[u] = k + u < to ? e[k + u] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (k + u < to) acc += x[u];
+            }
+            LC3_EB(L)[b] = acc;
+        }
     }
     LC3_SYNC();
     // is_near_nyquist :154-177

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot cfg, const 
     }
 }
 
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 3) void lc3_decode_kernel(lc3_cfg_slot cfg, lc3_dec_state *states,
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_kernel(lc3_cfg_slot cfg, lc3_dec_state *states,
                                                                           int first_channel, int n_streams,
                                                                           const uint8_t *in, const int32_t *planes,
                                                                           int16_t *pcm, int nbytes, int n_frames, int fresh) {
@@ -497,6 +497,10 @@ int make_config(lc3_cfg &c, int frame_us, int fs_hz) {
     return lc3_make_config(c, frame_us, fs_hz) ? LC3GPU_EINVAL : LC3GPU_OK;
 }
 
+// fills the line -> band width table of a configuration on the device (lc3_line_width_value)
+__global__ void lc3_line_width_kernel(float *out, lc3_cfg c) {
+    for (int k = threadIdx.x; k < c.ne; k += blockDim.x) out[k] = lc3_line_width_value(c, k);
+}
 // fills the polyphase resampler table of a configuration on the device (lc3_resamp_poly_value)
 __global__ void lc3_resamp_poly_kernel(float *out, int p, int lim, int stride) {
     const int n = p * stride;
@@ -532,19 +536,24 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
         const size_t bytes_tw = sizeof(lc3_cpx) * (size_t)c.nfft;
         const size_t bytes_perm = (sizeof(uint16_t) * (size_t)c.nfft + 15) & ~(size_t)15;
         const size_t bytes_poly = sizeof(float) * (size_t)c.p_up * (size_t)c.resamp_stride;
+        const size_t bytes_lw = sizeof(float) * (size_t)c.ne;
         char *base = nullptr;
-        HIP_TRY(hipMalloc((void **)&base, 2 * bytes_tw + bytes_perm + bytes_poly));
+        HIP_TRY(hipMalloc((void **)&base, 2 * bytes_tw + bytes_perm + bytes_poly + bytes_lw));
         HIP_TRY(hipMemcpy(base, pl.fft_tw.data(), bytes_tw, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(base + bytes_tw, pl.dct_tw.data(), bytes_tw, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(base + 2 * bytes_tw, pl.perm.data(), sizeof(uint16_t) * (size_t)c.nfft, hipMemcpyHostToDevice));
         float *poly = (float *)(base + 2 * bytes_tw + bytes_perm);
+        float *lw = (float *)(base + 2 * bytes_tw + bytes_perm + bytes_poly);
         hipLaunchKernelGGL(lc3_resamp_poly_kernel, dim3(1), dim3(256), 0, nullptr, poly, c.p_up, c.resamp_lim, c.resamp_stride);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(lc3_line_width_kernel, dim3(1), dim3(256), 0, nullptr, lw, c);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(nullptr));
         c.fft_tw = (const lc3_cpx *)base;
         c.dct_tw = (const lc3_cpx *)(base + bytes_tw);
         c.perm = (const uint16_t *)(base + 2 * bytes_tw);
         c.resamp_poly = poly;
+        c.line_width = lw;
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lc3_cfg_table), &c, sizeof(c), sizeof(c) * (size_t)slot, hipMemcpyHostToDevice));
         g_cfgs.cfg[dev][slot] = c;
         g_cfgs.ready[dev][slot] = true;

@@ -188,6 +188,9 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
     for (size_t i = 0; i < poly.size(); i++)
         poly[i] = lc3_resamp_poly_value(j.cfg.p_up, j.cfg.resamp_lim, j.cfg.resamp_stride, (int)i);
     j.cfg.resamp_poly = poly.data();
+    std::vector<float> lw((size_t)j.cfg.ne);
+    for (int k = 0; k < j.cfg.ne; k++) lw[(size_t)k] = lc3_line_width_value(j.cfg, k);
+    j.cfg.line_width = lw.data();
     j.encode = 1;
     j.n_frames = T;
     j.nbytes = nbytes;
