@@ -181,6 +181,34 @@ __device__ __forceinline__ int32_t lc3_f2u16(float x) {
     if (x <= 0.0f) return 0;
     return (int32_t)x;
 }
+// The transform tables of the configuration (FFT twiddles, DCT-IV twiddles, leaf gather order).  The device build can
+// redirect them to a copy staged in LDS (lc3gpu.hip: lc3_fft_tab); the default reads the configuration's HBM tables.
+#ifdef LC3_FFT_TABLES_IN_LDS
+struct lc3_fft_tables {
+    lc3_cpx fft_tw[LC3_MAX_NF / 2], dct_tw[LC3_MAX_NF / 2];
+    uint16_t perm[LC3_MAX_NF / 2];
+};
+__shared__ lc3_fft_tables lc3_fft_tab;  // one copy per workgroup (4.2 KB), filled by lc3_fft_tables_stage
+#define LC3_FFT_TW(c) (lc3_fft_tab.fft_tw)
+#define LC3_DCT_TW(c) (lc3_fft_tab.dct_tw)
+#define LC3_FFT_PERM(c) (lc3_fft_tab.perm)
+// all threads of the workgroup; ends with a workgroup barrier
+__device__ __forceinline__ void lc3_fft_tables_stage(const lc3_cfg &c) {
+    const int n = c.nfft;  // complex elements are copied as two 32-bit words, the gather order as 16-bit words
+    const uint32_t *ft = (const uint32_t *)c.fft_tw, *dt = (const uint32_t *)c.dct_tw;
+    uint32_t *lf = (uint32_t *)lc3_fft_tab.fft_tw, *ld = (uint32_t *)lc3_fft_tab.dct_tw;
+    for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) {
+        lf[i] = ft[i];
+        ld[i] = dt[i];
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lc3_fft_tab.perm[i] = c.perm[i];
+    __syncthreads();
+}
+#else
+#define LC3_FFT_TW(c) ((c).fft_tw)
+#define LC3_DCT_TW(c) ((c).dct_tw)
+#define LC3_FFT_PERM(c) ((c).perm)
+#endif
 // a * b for a, b < 2^24 (the device build maps it to the 24-bit multiplier)
 #ifndef LC3_MUL24
 #define LC3_MUL24(a, b) ((uint32_t)(a) * (uint32_t)(b))
@@ -801,11 +829,11 @@ __device__ __forceinline__ void lc3_dct4_wave(const lc3_cfg &c, int lane, float 
         lc3_cpx x;
         x.r = buf[2 * n];
         x.i = buf[nf - 2 * n - 1];
-        fa[n] = lc3_cmul(c.dct_tw[n], x);
+        fa[n] = lc3_cmul(LC3_DCT_TW(c)[n], x);
     }
     LC3_SYNC();
     // leaf gather of kf_work (kissfft.rs:101-108)
-    for (int o = lane; o < cnt; o += LC3_WAVE) fb[o] = fa[c.perm[o]];
+    for (int o = lane; o < cnt; o += LC3_WAVE) fb[o] = fa[LC3_FFT_PERM(c)[o]];
     LC3_SYNC();
     // butterfly stages, innermost first
     for (int s = c.n_stages - 1; s >= 0; s--) {
@@ -813,13 +841,13 @@ __device__ __forceinline__ void lc3_dct4_wave(const lc3_cfg &c, int lane, float 
         const int nb = cnt / p;
         for (int u = lane; u < nb; u += LC3_WAVE) {
             const int blk = (u * c.inv_m[s]) >> 16, i = u - blk * m;  // u / m without an integer division
-            lc3_bfly(fb + blk * p * m, c.fft_tw, p, fstride, m, i);
+            lc3_bfly(fb + blk * p * m, LC3_FFT_TW(c), p, fstride, m, i);
         }
         LC3_SYNC();
     }
     // post-twiddle :62-66
     for (int n = lane; n < cnt; n += LC3_WAVE) {
-        lc3_cpx y = lc3_cmul(c.dct_tw[n], fb[n]);
+        lc3_cpx y = lc3_cmul(LC3_DCT_TW(c)[n], fb[n]);
         buf[2 * n] = y.r * 2.0f;
         buf[nf - 2 * n - 1] = -y.i * 2.0f;
     }
@@ -834,22 +862,22 @@ __device__ __forceinline__ void lc3_dct4_wave_ab(const lc3_cfg &c, int lane, flo
         lc3_cpx x;
         x.r = a[2 * n];
         x.i = a[nf - 2 * n - 1];
-        cb[n] = lc3_cmul(c.dct_tw[n], x);
+        cb[n] = lc3_cmul(LC3_DCT_TW(c)[n], x);
     }
     LC3_SYNC();
-    for (int o = lane; o < cnt; o += LC3_WAVE) ca[o] = cb[c.perm[o]];  // leaf gather of kf_work (kissfft.rs:101-108)
+    for (int o = lane; o < cnt; o += LC3_WAVE) ca[o] = cb[LC3_FFT_PERM(c)[o]];  // leaf gather of kf_work (kissfft.rs:101-108)
     LC3_SYNC();
     for (int s = c.n_stages - 1; s >= 0; s--) {  // butterfly stages, innermost first
         const int p = c.radix[s], m = c.m[s], fstride = c.fstride[s];
         const int nb = cnt / p;
         for (int u = lane; u < nb; u += LC3_WAVE) {
             const int blk = (u * c.inv_m[s]) >> 16, i = u - blk * m;
-            lc3_bfly(ca + blk * p * m, c.fft_tw, p, fstride, m, i);
+            lc3_bfly(ca + blk * p * m, LC3_FFT_TW(c), p, fstride, m, i);
         }
         LC3_SYNC();
     }
     for (int n = lane; n < cnt; n += LC3_WAVE) {  // post-twiddle :62-66
-        lc3_cpx y = lc3_cmul(c.dct_tw[n], ca[n]);
+        lc3_cpx y = lc3_cmul(LC3_DCT_TW(c)[n], ca[n]);
         b[2 * n] = y.r * 2.0f;
         b[nf - 2 * n - 1] = -y.i * 2.0f;
     }

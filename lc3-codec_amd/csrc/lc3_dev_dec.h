@@ -29,12 +29,12 @@ struct lc3_dec_state {
 };
 #define LC3_DEC_CORE_WORDS ((int)(sizeof(lc3_dec_core) / 4))
 
-// LDS working set of one decoder wave: 9.2 KB, four workgroups (16 streams) per CU
+// LDS working set of one decoder wave: 8.5 KB; with the workgroup's transform tables four workgroups (16 streams) per CU
 struct __attribute__((aligned(16))) lc3_dec_lds {
     lc3_dec_core st;
     float spec[LC3_MAX_NF];        // spec_lines -> FFT work array -> time samples
     lc3_cpx fa[LC3_MAX_NF / 2];    // pre-twiddled FFT input -> DCT-IV output
-    float sm[192];
+    float sm[32];                  // LTPF: the previous frame's coefficients
     int ism[64];
     unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
 #ifdef LC3_PROFILE
@@ -157,8 +157,8 @@ __device__ __noinline__ void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_l
     const int nf = c.nf, blk = L.st.block_start_index, s25 = c.s25;
     const int ncn = c.l_num + 1, ncd = c.l_den + 1;
     float *freq = L.spec;
-    float *cnm = L.sm + 64, *cdm = L.sm + 80;  // c_num_mem / c_den_mem
-    float *scratch = L.sm;                      // activate_first_2p5ms scratch, l_num + norm <= 130 floats
+    float *cnm = L.sm, *cdm = L.sm + 16;  // c_num_mem / c_den_mem
+    float *scratch = (float *)L.fa;       // activate_first_2p5ms scratch, l_num + norm <= 130 floats (the transform output is dead)
     int pitch_int = 0, pitch_frac = 0;
     // compute_filter_parameters :164-189 (f64)
     if (is_active) {
@@ -231,7 +231,7 @@ __device__ __noinline__ void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_l
         if (trans == 3) {
             for (int n = s25 + lane; n < nf; n += LC3_WAVE) L.st.x_hat_ltpf_mem[blk + n] = freq[n];
         } else {
-            // activate_first_2p5ms_from_mem :345-378; cnm/cdm are no longer needed: scratch may overlap them
+            // activate_first_2p5ms_from_mem :345-378
             const int l_num = c.l_num;
             LC3_SYNC();
             for (int i = lane; i < l_num + c.norm; i += LC3_WAVE) {

@@ -58,6 +58,8 @@ __shared__ lc3_spec_tables lc3_spec_tab;
 #define LC3_SPEC_LOOKUP(i) ((int)lc3_spec_tab.lookup[(i)])
 #define LC3_SPEC_BITS(p, j) ((uint32_t)lc3_spec_tab.bits[(p) * 17 + (j)])
 #endif
+// FFT / DCT-IV twiddles and the gather order: one LDS copy per workgroup instead of HBM table reads inside every stage
+#define LC3_FFT_TABLES_IN_LDS 1
 #define LC3_LDS_DECL(T, arr) __shared__ T arr[LC3_WG_WAVES];
 #define LC3_LDS_PARAM(T)
 #define LC3_LDS_PASS
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_kernel(lc3
     const int s = valid ? s_raw : n_streams - 1;
     const int nf = lc3_cfg_table[cfg.id].nf, z = lc3_cfg_table[cfg.id].z;
     lc3_enc_state *gst = states + (size_t)(first_channel + s);
+    lc3_fft_tables_stage(lc3_cfg_table[cfg.id]);
     LC3_PROF_BEGIN(L, lane);
     if (fresh) lc3_enc_state_init(L, lane, gst, valid);
     else lc3_enc_state_load(L, lane, gst);
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_kernel(lc3_cf
     const int s = valid ? s_raw : n_streams - 1;  // see lc3_enc_front_kernel
     const int nf = lc3_cfg_table[cfg.id].nf;
     lc3_dec_state *gst = states + (size_t)(first_channel + s);
+    lc3_fft_tables_stage(lc3_cfg_table[cfg.id]);
     LC3_PROF_BEGIN(L, lane);
     if (fresh) lc3_dec_state_init(L, lane, gst, valid);
     else lc3_dec_state_load(L, lane, gst);
