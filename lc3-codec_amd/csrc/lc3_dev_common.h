@@ -91,6 +91,7 @@
 // the loads are global_load rather than flat_load.
 #ifndef LC3_HBM_CONST
 #define LC3_HBM_CONST(T) const T *
+#define LC3_HBM(T) T *
 #endif
 
 #define LC3_WAVE 64

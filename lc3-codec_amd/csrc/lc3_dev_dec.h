@@ -78,13 +78,22 @@ __device__ __noinline__ void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_
     const uint32_t *w = lc3_window_bits(c);
     float *freq = L.spec;
     float *u = (float *)L.fa;  // DCT-IV output
-    // the overlap memory of the previous frame: requested now, used after the transform (element n belongs to lane n % 64
-    // in every frame, so a lane reads back what it stored itself)
-    float mo[5];  // nf - z <= 300
+    // The overlap memory of the previous frame (HBM; element n belongs to lane n % 64 in every frame, so a lane reads back what
+    // it stored itself) and the window coefficients this lane will need are requested now, as one batch of independent
+    // loads, and used after the transform.
+    LC3_HBM(float) ola = (LC3_HBM(float))g->mem_ola;
+    float mo[5], wa[5], wb[5], wc[3];  // nf - z <= 300, z <= 180
 #pragma unroll
     for (int r = 0; r < 5; r++) {
+        const int n = lane + LC3_WAVE * r, in = n < nf - z;
+        mo[r] = in ? ola[n] : 0.0f;
+        wa[r] = in ? lc3_f(w, 2 * nf - 1 - (z + n)) : 0.0f;
+        wb[r] = in ? lc3_f(w, 2 * nf - 1 - (nf + z + n)) : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
         const int n = lane + LC3_WAVE * r;
-        mo[r] = n < nf - z ? g->mem_ola[n] : 0.0f;
+        wc[r] = n < z ? lc3_f(w, 2 * nf - 1 - (nf + n)) : 0.0f;
     }
     for (int n = ne + lane; n < nf; n += LC3_WAVE) freq[n] = 0.0f;
     LC3_SYNC();
@@ -93,20 +102,22 @@ __device__ __noinline__ void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_
     // unfold :97-136, gain, reversed window :89-91 and overlap_add :138-151 in one pass: the reference's
     // t_hat_mdct[i] = unfolded(i) * gain * w[2nf - 1 - i] is evaluated where it is consumed (each element is used once)
     const float gain = 1.0f / lc3_sqrtf(2.0f * (float)nf);
-#define LC3_THAT(i)                                                                                                   \
-    ((((i) < h ? u[h + (i)] : ((i) < nf ? -u[nf - 1 - ((i) - h)] : ((i) < 3 * h ? -u[h - 1 - ((i) - nf)] : -u[(i) - 3 * h]))) * gain) * \
-     lc3_f(w, 2 * nf - 1 - (i)))
+#define LC3_UNFOLD(i) ((i) < h ? u[h + (i)] : ((i) < nf ? -u[nf - 1 - ((i) - h)] : ((i) < 3 * h ? -u[h - 1 - ((i) - nf)] : -u[(i) - 3 * h])))
 #pragma unroll
     for (int r = 0; r < 5; r++) {
         const int n = lane + LC3_WAVE * r;
         if (n < nf - z) {
-            freq[n] = mo[r] + LC3_THAT(z + n);
-            const float keep = LC3_THAT(nf + z + n);
-            if (valid) g->mem_ola[n] = keep;
+            freq[n] = mo[r] + (LC3_UNFOLD(z + n) * gain) * wa[r];
+            const float keep = (LC3_UNFOLD(nf + z + n) * gain) * wb[r];
+            if (valid) ola[n] = keep;
         }
     }
-    for (int n = lane; n < z; n += LC3_WAVE) freq[nf - z + n] = LC3_THAT(nf + n);
-#undef LC3_THAT
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int n = lane + LC3_WAVE * r;
+        if (n < z) freq[nf - z + n] = (LC3_UNFOLD(nf + n) * gain) * wc[r];
+    }
+#undef LC3_UNFOLD
     LC3_SYNC();
 }
 
