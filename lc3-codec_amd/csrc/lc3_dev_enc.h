@@ -132,10 +132,19 @@ __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_ld
     const uint16_t *ifs = lc3_band_index(c);
     // update_time_buffer :126-138: t[0..nf-z) <- history, t[nf-z..2nf-z) <- new frame, tail stays 0.
     // The frame is fetched from HBM as 32-bit words (two samples per lane per load, coalesced).
+    float wv[4][4];
     {
         LC3_HBM_CONST(uint32_t) p32 = (LC3_HBM_CONST(uint32_t))pcm;
         LC3_HBM_CONST(uint32_t) h32 = (LC3_HBM_CONST(uint32_t))hist;
         uint32_t v[4], hv[3];  // nf / 2 <= 240 and (nf - z) / 2 <= 150 words, all in flight together
+#pragma unroll
+        for (int r = 0; r < 4; r++) {  // the window coefficients of this lane's fold outputs (h <= 240): same batch of loads
+            const int k = lane + LC3_WAVE * r, in = k < h;
+            wv[r][0] = in ? lc3_f(w, mid - 1 - k) : 0.0f;
+            wv[r][1] = in ? lc3_f(w, mid + k) : 0.0f;
+            wv[r][2] = in ? lc3_f(w, k) : 0.0f;
+            wv[r][3] = in ? lc3_f(w, nf - 1 - k) : 0.0f;
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = lane + LC3_WAVE * u;
@@ -165,10 +174,14 @@ __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_ld
     }
     for (int i = 2 * nf - z + lane; i < 2 * nf; i += LC3_WAVE) L.t[i] = 0;
     LC3_SYNC();
-    // apply_mdct :73-105 (window / fold)
-    for (int k = lane; k < h; k += LC3_WAVE) {
-        L.spec[k] = -((float)L.t[mid - 1 - k] * lc3_f(w, mid - 1 - k)) - ((float)L.t[mid + k] * lc3_f(w, mid + k));
-        L.spec[h + k] = ((float)L.t[k] * lc3_f(w, k)) - ((float)L.t[nf - 1 - k] * lc3_f(w, nf - 1 - k));
+    // apply_mdct :73-105 (window / fold); the window coefficients were requested with the frame (wv)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int k = lane + LC3_WAVE * r;
+        if (k < h) {
+            L.spec[k] = -((float)L.t[mid - 1 - k] * wv[r][0]) - ((float)L.t[mid + k] * wv[r][1]);
+            L.spec[h + k] = ((float)L.t[k] * wv[r][2]) - ((float)L.t[nf - 1 - k] * wv[r][3]);
+        }
     }
     LC3_SYNC();
     lc3_dct4_wave(c, lane, L.spec, L.fa, L.fb);
