@@ -89,6 +89,10 @@
 
 // Pointer to read-only HBM data handed to a stage function: the HIP translation unit marks the address space so that
 // the loads are global_load rather than flat_load.
+// a value the caller knows to be the same on every lane of the wave (the device build moves it to a scalar register)
+#ifndef LC3_UNIFORM_I32
+#define LC3_UNIFORM_I32(x) (x)
+#endif
 #ifndef LC3_HBM_CONST
 #define LC3_HBM_CONST(T) const T *
 #define LC3_HBM(T) T *

@@ -6,6 +6,14 @@
 #include "lc3_dev_common.h"
 #include "lc3_dev_dec_parse.h"
 
+// The decoder's stage functions are real calls (inlined, the kernel needs 128 VGPRs plus spills and runs 1.5x slower).
+// A call has a price the code is arranged around: the callee waits for every outstanding load and store at its entry and
+// before its return, so stores are issued where a long stretch without a call follows (the output stage), not at the end
+// of a stage function.
+#ifndef LC3_DEC_STAGE
+#define LC3_DEC_STAGE __noinline__
+#endif
+
 // Persistent per-stream decoder state.  `core` is what a wave keeps resident in LDS while it
 // works on the stream; the IMDCT overlap memory (read once and written once per frame, element n by the same lane) and
 // plc_last_good (written once per good frame, read only when concealing) stay in HBM.
@@ -71,7 +79,7 @@ __device__ __forceinline__ void lc3_dec_state_store(lc3_dec_lds &L, int lane, lc
 // ------------------------------------------------------------------------------------------
 // D10: IMDCT + window + overlap-add (decoder/modified_dct.rs:76-151); spec -> time samples in spec
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, lc3_dec_state *g, int valid) {
+__device__ LC3_DEC_STAGE void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_dec_state *g) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     const int nf = c.nf, ne = c.ne, z = c.z, h = nf / 2;
@@ -81,7 +89,7 @@ __device__ __noinline__ void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_
     // The overlap memory of the previous frame (HBM; element n belongs to lane n % 64 in every frame, so a lane reads back what
     // it stored itself) and the window coefficients this lane will need are requested now, as one batch of independent
     // loads, and used after the transform.
-    LC3_HBM(float) ola = (LC3_HBM(float))g->mem_ola;
+    LC3_HBM_CONST(float) ola = (LC3_HBM_CONST(float))g->mem_ola;
     float mo[5], wa[5], wb[5], wc[3];  // nf - z <= 300, z <= 180
 #pragma unroll
     for (int r = 0; r < 5; r++) {
@@ -103,13 +111,15 @@ __device__ __noinline__ void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_
     // t_hat_mdct[i] = unfolded(i) * gain * w[2nf - 1 - i] is evaluated where it is consumed (each element is used once)
     const float gain = 1.0f / lc3_sqrtf(2.0f * (float)nf);
 #define LC3_UNFOLD(i) ((i) < h ? u[h + (i)] : ((i) < nf ? -u[nf - 1 - ((i) - h)] : ((i) < 3 * h ? -u[h - 1 - ((i) - nf)] : -u[(i) - 3 * h])))
+    float keep[5];  // the new overlap memory; it replaces the transform output in LDS (u is dead once every lane has read it)
+                    // and goes out to HBM with the PCM in the output stage (lc3_dec_ola_store)
 #pragma unroll
     for (int r = 0; r < 5; r++) {
         const int n = lane + LC3_WAVE * r;
+        keep[r] = 0.0f;
         if (n < nf - z) {
             freq[n] = mo[r] + (LC3_UNFOLD(z + n) * gain) * wa[r];
-            const float keep = (LC3_UNFOLD(nf + z + n) * gain) * wb[r];
-            if (valid) ola[n] = keep;
+            keep[r] = (LC3_UNFOLD(nf + z + n) * gain) * wb[r];
         }
     }
 #pragma unroll
@@ -119,6 +129,28 @@ __device__ __noinline__ void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_
     }
 #undef LC3_UNFOLD
     LC3_SYNC();
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int n = lane + LC3_WAVE * r;
+        if (n < nf - z) u[n] = keep[r];
+    }
+    LC3_SYNC();
+}
+// the overlap memory left in LDS by lc3_dec_imdct -> the state blob; whole rounds of 64 under a wave-uniform condition,
+// one base address with constant offsets
+__device__ __forceinline__ void lc3_dec_ola_store(const lc3_cfg &c, lc3_dec_lds &L, int lane, lc3_dec_state *g, int valid) {
+    const float *u = (const float *)L.fa;
+    const int nv = LC3_UNIFORM_I32(valid) ? c.nf - c.z : 0;
+    LC3_HBM(float) ob = (LC3_HBM(float))g->mem_ola + lane;
+    float keep[5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) keep[r] = lane < nv - LC3_WAVE * r ? u[lane + LC3_WAVE * r] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int rem = nv - LC3_WAVE * r;
+        if (rem >= LC3_WAVE) ob[LC3_WAVE * r] = keep[r];
+        else if (lane < rem) ob[LC3_WAVE * r] = keep[r];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -161,7 +193,7 @@ __device__ __forceinline__ void lc3_ltpf_run(const lc3_cfg &c, lc3_dec_lds &L, i
     }
 }
 
-__device__ __noinline__ void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int is_active, int pitch_index,
+__device__ LC3_DEC_STAGE void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int is_active, int pitch_index,
                                              int nbits) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
@@ -169,7 +201,7 @@ __device__ __noinline__ void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_l
     const int ncn = c.l_num + 1, ncd = c.l_den + 1;
     float *freq = L.spec;
     float *cnm = L.sm, *cdm = L.sm + 16;  // c_num_mem / c_den_mem
-    float *scratch = (float *)L.fa;       // activate_first_2p5ms scratch, l_num + norm <= 130 floats (the transform output is dead)
+    float *scratch = (float *)L.fa + 304;  // activate_first_2p5ms scratch, l_num + norm <= 130 floats (fa[0..304) holds the new overlap memory)
     int pitch_int = 0, pitch_frac = 0;
     // compute_filter_parameters :164-189 (f64)
     if (is_active) {
@@ -313,7 +345,7 @@ __device__ __forceinline__ void lc3_dec_plc_save(const lc3_cfg &c, lc3_dec_lds &
         L.st.plc_alpha = 1.0f;
     }
 }
-__device__ __noinline__ void lc3_dec_plc_load(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_dec_state *g) {
+__device__ LC3_DEC_STAGE void lc3_dec_plc_load(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_dec_state *g) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     // The sign-scrambling LCG seed_k = (16831 + seed_{k-1} * 12821) & 0xFFFF is affine mod 2^16, so lane l can
@@ -368,23 +400,37 @@ __device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 18);
-    lc3_dec_imdct(LC3_CFG_PASS, LC3_LDS_PASS lane, g, valid);
+    lc3_dec_imdct(LC3_CFG_PASS, LC3_LDS_PASS lane, g);
     LC3_STAMP(L, lane, 19);
     lc3_dec_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, ltpf_active, pitch_index, nbits);
     LC3_STAMP(L, lane, 20);
     // output_scaling::scale_and_round (decoder/output_scaling.rs:13-25); two samples per 32-bit store
+    lc3_dec_ola_store(c, L, lane, g, valid);
     {
-        uint32_t *o32 = (uint32_t *)pcm_out;
-        for (int i = lane; valid && i < nf / 2; i += LC3_WAVE) {
-            int32_t v[2];
-            for (int j = 0; j < 2; j++) {
-                const float x = L.spec[2 * i + j];
-                int32_t tmp = x > 0.0f ? lc3_f2i32(x + 0.5f) : lc3_f2i32(x - 0.5f);
-                tmp = tmp > 32767 ? 32767 : tmp;
-                tmp = tmp < -32768 ? -32768 : tmp;
-                v[j] = tmp;
+        LC3_HBM(uint32_t) o32 = (LC3_HBM(uint32_t))pcm_out;
+        uint32_t ow[4];  // nf / 2 <= 240 words: all four computed, then stored together
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = lane + LC3_WAVE * r;
+            int32_t v[2] = {0, 0};
+            if (i < nf / 2) {
+                for (int j = 0; j < 2; j++) {
+                    const float x = L.spec[2 * i + j];
+                    int32_t tmp = x > 0.0f ? lc3_f2i32(x + 0.5f) : lc3_f2i32(x - 0.5f);
+                    tmp = tmp > 32767 ? 32767 : tmp;
+                    tmp = tmp < -32768 ? -32768 : tmp;
+                    v[j] = tmp;
+                }
             }
-            o32[i] = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
+            ow[r] = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
+        }
+        const int nv = LC3_UNIFORM_I32(valid) ? nf / 2 : 0;
+        LC3_HBM(uint32_t) ob = o32 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int rem = nv - LC3_WAVE * r;
+            if (rem >= LC3_WAVE) ob[LC3_WAVE * r] = ow[r];
+            else if (lane < rem) ob[LC3_WAVE * r] = ow[r];
         }
     }
     LC3_SYNC();
