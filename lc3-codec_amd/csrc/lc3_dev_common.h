@@ -30,8 +30,12 @@
 #endif
 
 // How the stage functions receive the codec configuration.  Default: by reference.  The HIP translation unit passes
-// a slot number into a __constant__ table instead (lc3gpu.hip), so that the fields are scalar loads.
+// a slot number into a __constant__ table instead (lc3gpu.hip), so that the fields are scalar loads, and makes the stage
+// functions templates over a "configuration view" (LC3_CFG_TEMPLATE): the run-time view reads the table, the view of the
+// headline configuration (48 kHz / 10 ms) has its integers as compile-time constants.  Helpers that take the
+// configuration as an argument are templates over its type for the same reason.
 #ifndef LC3_CFG_PARAM
+#define LC3_CFG_TEMPLATE
 #define LC3_CFG_PARAM const lc3_cfg &c
 #define LC3_CFG_BIND
 #define LC3_CFG_PASS c
@@ -198,7 +202,8 @@ __shared__ lc3_fft_tables lc3_fft_tab;  // one copy per workgroup (4.2 KB), fill
 #define LC3_DCT_TW(c) (lc3_fft_tab.dct_tw)
 #define LC3_FFT_PERM(c) (lc3_fft_tab.perm)
 // all threads of the workgroup; ends with a workgroup barrier
-__device__ __forceinline__ void lc3_fft_tables_stage(const lc3_cfg &c) {
+template <class CC>
+__device__ __forceinline__ void lc3_fft_tables_stage(const CC &c) {
     const int n = c.nfft;  // complex elements are copied as two 32-bit words, the gather order as 16-bit words
     const uint32_t *ft = (const uint32_t *)c.fft_tw, *dt = (const uint32_t *)c.dct_tw;
     uint32_t *lf = (uint32_t *)lc3_fft_tab.fft_tw, *ld = (uint32_t *)lc3_fft_tab.dct_tw;
@@ -691,7 +696,8 @@ __device__ __forceinline__ float lc3_resamp_poly_value(int p, int lim, int strid
     return lc3_f(LC3T_TAB_RESAMP_FILTER_BITS, 119 + index_h);
 }
 
-__device__ __forceinline__ const uint32_t *lc3_window_bits(const lc3_cfg &c) {
+template <class CC>
+__device__ __forceinline__ const uint32_t *lc3_window_bits(const CC &c) {
     if (c.n_ms_10) {
         switch (c.fs_ind) {
         case 0: return LC3T_W_N80_10MS_BITS;
@@ -709,7 +715,8 @@ __device__ __forceinline__ const uint32_t *lc3_window_bits(const lc3_cfg &c) {
     default: return LC3T_W_N360_7P5MS_BITS;
     }
 }
-__device__ __forceinline__ const uint16_t *lc3_band_index(const lc3_cfg &c) {
+template <class CC>
+__device__ __forceinline__ const uint16_t *lc3_band_index(const CC &c) {
     if (c.n_ms_10) {
         switch (c.fs_ind) {
         case 0: return LC3T_I_8000_10MS;
@@ -728,7 +735,8 @@ __device__ __forceinline__ const uint16_t *lc3_band_index(const lc3_cfg &c) {
     }
 }
 // band width of spectral line k (the divisor of apply_energy_estimation, encoder/modified_dct.rs:140-152); fills c.line_width
-__device__ __forceinline__ float lc3_line_width_value(const lc3_cfg &c, int k) {
+template <class CC>
+__device__ __forceinline__ float lc3_line_width_value(const CC &c, int k) {
     const uint16_t *ifs = lc3_band_index(c);
     int b = 0;
     while (b + 1 < c.nb && (int)ifs[b + 1] <= k) b++;
@@ -827,7 +835,8 @@ __device__ __forceinline__ void lc3_bfly(lc3_cpx *f, const lc3_cpx *tw, int p, i
 }
 
 // DiscreteCosTransformIv::run (common/dct_iv.rs:49-67) on buf[0..nf) (LDS), scratch fa/fb (LDS, nf/2 each)
-__device__ __forceinline__ void lc3_dct4_wave(const lc3_cfg &c, int lane, float *buf, lc3_cpx *fa, lc3_cpx *fb) {
+template <class CC>
+__device__ __forceinline__ void lc3_dct4_wave(const CC &c, int lane, float *buf, lc3_cpx *fa, lc3_cpx *fb) {
     const int nf = c.nf, cnt = c.nfft;
     // pre-twiddle :53-56
     for (int n = lane; n < cnt; n += LC3_WAVE) {
@@ -860,7 +869,8 @@ __device__ __forceinline__ void lc3_dct4_wave(const lc3_cfg &c, int lane, float 
 }
 // The same transform with two buffers instead of three: a[0..nf) -> b[0..nf), a is destroyed (it serves as the complex work
 // array once the pre-twiddle has consumed it).  Same operations in the same order as lc3_dct4_wave.
-__device__ __forceinline__ void lc3_dct4_wave_ab(const lc3_cfg &c, int lane, float *a, float *b) {
+template <class CC>
+__device__ __forceinline__ void lc3_dct4_wave_ab(const CC &c, int lane, float *a, float *b) {
     const int nf = c.nf, cnt = c.nfft;
     lc3_cpx *ca = (lc3_cpx *)a, *cb = (lc3_cpx *)b;
     for (int n = lane; n < cnt; n += LC3_WAVE) {  // pre-twiddle :53-56

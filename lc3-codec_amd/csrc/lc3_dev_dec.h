@@ -79,7 +79,7 @@ __device__ __forceinline__ void lc3_dec_state_store(lc3_dec_lds &L, int lane, lc
 // ------------------------------------------------------------------------------------------
 // D10: IMDCT + window + overlap-add (decoder/modified_dct.rs:76-151); spec -> time samples in spec
 // ------------------------------------------------------------------------------------------
-__device__ LC3_DEC_STAGE void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_dec_state *g) {
+LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_dec_state *g) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     const int nf = c.nf, ne = c.ne, z = c.z, h = nf / 2;
@@ -138,7 +138,8 @@ __device__ LC3_DEC_STAGE void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec
 }
 // the overlap memory left in LDS by lc3_dec_imdct -> the state blob; whole rounds of 64 under a wave-uniform condition,
 // one base address with constant offsets
-__device__ __forceinline__ void lc3_dec_ola_store(const lc3_cfg &c, lc3_dec_lds &L, int lane, lc3_dec_state *g, int valid) {
+template <class CC>
+__device__ __forceinline__ void lc3_dec_ola_store(const CC &c, lc3_dec_lds &L, int lane, lc3_dec_state *g, int valid) {
     const float *u = (const float *)L.fa;
     const int nv = LC3_UNIFORM_I32(valid) ? c.nf - c.z : 0;
     LC3_HBM(float) ob = (LC3_HBM(float))g->mem_ola + lane;
@@ -161,7 +162,8 @@ __device__ __forceinline__ void lc3_dec_ola_store(const lc3_cfg &c, lc3_dec_lds 
 // with input(j) = inp[j] for j >= 0 and hist[l_num + j] for the l_num samples before the frame (the reference's
 // x_hat_mem ring is only ever read there), ramp: 0 none, 1 fade-in n / norm for n < s25, 2 fade-out 1 - n / norm.
 // Samples are computed in blocks of min(64, pitch_int - l_den/2): inside a block no output depends on another.
-__device__ __forceinline__ void lc3_ltpf_run(const lc3_cfg &c, lc3_dec_lds &L, int lane, int n_begin, int n_end,
+template <class CC>
+__device__ __forceinline__ void lc3_ltpf_run(const CC &c, lc3_dec_lds &L, int lane, int n_begin, int n_end,
                                              const float *inp, const float *hist, const float *cn, const float *cd,
                                              int pitch_int, int ramp) {
     const int blk = L.st.block_start_index, l_num = c.l_num, l_den = c.l_den, ring = c.num_mem_blocks * c.nf;
@@ -193,7 +195,7 @@ __device__ __forceinline__ void lc3_ltpf_run(const lc3_cfg &c, lc3_dec_lds &L, i
     }
 }
 
-__device__ LC3_DEC_STAGE void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int is_active, int pitch_index,
+LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int is_active, int pitch_index,
                                              int nbits) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
@@ -312,7 +314,8 @@ __device__ LC3_DEC_STAGE void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_
 // The plane words of a frame in flight (two 16-byte units per lane): the kernel issues the loads of frame t + 1 before
 // it works on frame t, so the memory latency hides behind a frame's worth of work.
 struct lc3_plane_fetch { lc3_i4 u[2]; };
-__device__ __forceinline__ void lc3_dec_issue_frame(const lc3_cfg &c, int lane, const int32_t *plane, lc3_plane_fetch &m) {
+template <class CC>
+__device__ __forceinline__ void lc3_dec_issue_frame(const CC &c, int lane, const int32_t *plane, lc3_plane_fetch &m) {
     LC3_HBM_CONST(lc3_i4) p4 = (LC3_HBM_CONST(lc3_i4))((LC3_HBM_CONST(int32_t))plane + LC3_PLANE_SI);
     const int n4 = (LC3_PLANE_X - LC3_PLANE_SI) / 4 + c.ne / 4;
 #pragma unroll
@@ -321,7 +324,8 @@ __device__ __forceinline__ void lc3_dec_issue_frame(const lc3_cfg &c, int lane, 
         if (i < n4) m.u[u] = p4[i];
     }
 }
-__device__ __forceinline__ int lc3_dec_load_frame(const lc3_cfg &c, lc3_dec_lds &L, int lane, const lc3_plane_fetch &m) {
+template <class CC>
+__device__ __forceinline__ int lc3_dec_load_frame(const CC &c, lc3_dec_lds &L, int lane, const lc3_plane_fetch &m) {
     const int n_si4 = (LC3_PLANE_X - LC3_PLANE_SI) / 4, n4 = n_si4 + c.ne / 4;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -338,14 +342,15 @@ __device__ __forceinline__ int lc3_dec_load_frame(const lc3_cfg &c, lc3_dec_lds 
 // ------------------------------------------------------------------------------------------
 // D9: packet loss concealment (decoder/packet_loss_concealment.rs:49-85).  plc_last_good lives in HBM.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lc3_dec_plc_save(const lc3_cfg &c, lc3_dec_lds &L, int lane, lc3_dec_state *g) {
+template <class CC>
+__device__ __forceinline__ void lc3_dec_plc_save(const CC &c, lc3_dec_lds &L, int lane, lc3_dec_state *g) {
     for (int k = lane; k < c.ne; k += LC3_WAVE) g->plc_last_good[k] = L.spec[k];
     if (lane == 0) {
         L.st.plc_num_lost = 0;
         L.st.plc_alpha = 1.0f;
     }
 }
-__device__ LC3_DEC_STAGE void lc3_dec_plc_load(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_dec_state *g) {
+LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_plc_load(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_dec_state *g) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     // The sign-scrambling LCG seed_k = (16831 + seed_{k-1} * 12821) & 0xFFFF is affine mod 2^16, so lane l can
@@ -382,7 +387,7 @@ __device__ LC3_DEC_STAGE void lc3_dec_plc_load(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_
 // in: nbytes in HBM; pcm_out: nf samples in HBM (4-byte aligned); plane/stride: the frame's parsed column
 // (lc3_dev_dec_parse.h); g: the stream's state blob in HBM.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes,
+LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes,
                                                       int16_t *pcm_out, const lc3_plane_fetch &fetched, lc3_dec_state *g,
                                                       int valid) {
     LC3_CFG_BIND;

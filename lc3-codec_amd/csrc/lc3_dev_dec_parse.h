@@ -502,7 +502,8 @@ __device__ __forceinline__ float lc3_r_band_gain(const lc3_recon_ctx &r, int bi,
     return lc3_exp2_raw(sf);
 }
 
-__device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3_recon_ctx &r, const lc3_cfg &cfg) {
+template <class CC>
+__device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3_recon_ctx &r, const CC &cfg) {
     const int ne = cfg.ne, nbytes = c.len, nbits = nbytes * 8;
     // the side-information words of the column in one batch of independent loads (a lane of this kernel is
     // latency-bound: a word fetched at its point of use costs a full memory round trip)

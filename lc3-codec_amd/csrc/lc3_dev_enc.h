@@ -96,7 +96,8 @@ __device__ __forceinline__ void lc3_enc_state_load(lc3_enc_lds &L, int lane, con
     LC3_SYNC();
 }
 // scalars back to HBM; the MDCT history of the next launch = samples [z, nf) of the last frame of this one
-__device__ __forceinline__ void lc3_enc_state_store(const lc3_cfg &c, lc3_enc_lds &L, int lane, lc3_enc_state *g,
+template <class CC>
+__device__ __forceinline__ void lc3_enc_state_store(const CC &c, lc3_enc_lds &L, int lane, lc3_enc_state *g,
                                                     const int16_t *last_frame) {
     LC3_SYNC();
     lc3_wave_copy_out16(&g->sc, &L.st, (int)(sizeof(lc3_enc_scalars) / 16), lane);
@@ -123,7 +124,7 @@ __device__ __forceinline__ void lc3_enc_state_store(const lc3_cfg &c, lc3_enc_ld
 // ------------------------------------------------------------------------------------------
 // hist: the nf - z samples before this frame (previous frame's tail in the PCM input, or the state blob's copy for the
 // first frame of a launch), 4-byte aligned; nullptr = silence (fresh stream)
-__device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const int16_t *pcm,
+LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const int16_t *pcm,
                                          const int16_t *hist) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
@@ -237,7 +238,7 @@ __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_ld
 // ------------------------------------------------------------------------------------------
 // E7: bandwidth detector (encoder/bandwidth_detector.rs:64-127), lane 0
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_enc_bandwidth(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int *nbits_bw) {
+LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_bandwidth(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int *nbits_bw) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     *nbits_bw = LC3C_NBITS_BW[c.fs_ind];
@@ -277,7 +278,7 @@ __device__ __noinline__ int lc3_enc_bandwidth(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_e
 // ------------------------------------------------------------------------------------------
 // E8: attack detector (encoder/attack_detector.rs:45-128)
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int nbytes) {
+LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int nbytes) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int num_ds = c.n_ms_10 ? 160 : 120, num_blocks = c.n_ms_10 ? 4 : 3, limit = c.n_ms_10 ? 2 : 1;
@@ -346,7 +347,7 @@ __device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_
 // E9 front half (encoder/spectral_noise_shaping.rs:75-161, 203-233): band energies -> 16 target scale factors, left in
 // LDS at S[144..160) (sSCF) for the caller to hand to the vector quantiser (lc3_dev_enc_vq.h).
 // scratch map inside L.fa (floats): sE[64] smoothed/log energies, sP[64] padded, sDS[16], sSCF[16]
-__device__ __noinline__ void lc3_enc_sns_front(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int attack) {
+LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_sns_front(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int attack) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     float *S = (float *)L.fa;
@@ -439,7 +440,7 @@ __device__ __noinline__ void lc3_enc_sns_front(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_
 
 // E9 back half: spectral shaping :264-268 with the band gains the vector quantiser stage produced (HBM, 64 f32) --
 // one lane per band (bands are 1..25 lines wide)
-__device__ __noinline__ void lc3_enc_sns_apply(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const float *gains) {
+LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_sns_apply(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const float *gains) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const uint16_t *ifs = lc3_band_index(c);
@@ -454,7 +455,7 @@ __device__ __noinline__ void lc3_enc_sns_apply(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_
 // E11: temporal noise shaping (encoder/temporal_noise_shaping.rs:40-349)
 // rc_i[16] -> L.ism[16..32), rc_q[16] -> L.sm[16..32)
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int p_bw, int nbits,
+LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int p_bw, int nbits,
                                                   int near_nyquist) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
@@ -672,7 +673,7 @@ __device__ __forceinline__ float lc3_ltpf_dot(const float *x12, int n, int d) { 
 // g: the stream's state blob in HBM, owner of the two sample rings (x12 at 12.8 kHz, x6 at 6.4 kHz); `store` = 0 for
 // the shadow waves of a partial workgroup.  Staging: x12 lives in fa for the duration of the stage, the resampler's
 // polyphase table and later the correlation scratch in fb, x6 in `t` once the resampler has consumed the time buffer.
-__device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int near_nyquist,
+LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int near_nyquist,
                                                     int nbits, lc3_enc_state *g, int store) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
@@ -1013,7 +1014,7 @@ struct lc3_bitcons { int rate_flag, lastnz, nbits_lsb, lastnz_trunc, nbits_est, 
 
 // quantize_spectrum :230-263 + compute_bit_consumption :265-348.
 // Quantisation is lane-parallel; the context-adaptive bit estimate walks tuples in order on lane 0.
-__device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int nbits,
+LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int nbits,
                                                             int gg_off, int gg_ind, int nbits_spec) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
@@ -1158,7 +1159,7 @@ __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, LC3_LDS
     return bc;
 }
 
-__device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int nbits, int nbits_bw,
+LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int nbits, int nbits_bw,
                                                       int nbits_tns, int nbits_ltpf) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
@@ -1367,7 +1368,7 @@ __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PARAM, LC3_LDS_PARAM
 // E18 residual bits (encoder/residual_spectrum.rs:33-62), E19 noise level
 // (encoder/noise_level_estimation.rs:21-55).  Returns n_res via L.ism[0], noise factor via L.ism[1].
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane,
+LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane,
                                                     const lc3_quant_res q, int bw_ind) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
@@ -1453,7 +1454,7 @@ __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM
 //          -> the rest of the packer plane column
 // hist: see lc3_enc_mdct; g: the stream's state blob (LTPF rings); mid/plane == nullptr marks a shadow wave that
 // stores nothing.  dbg (optional): float[1472] stage dumps.
-__device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const int16_t *pcm,
+LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const int16_t *pcm,
                                                       const int16_t *hist, lc3_enc_state *g, float *mid, int32_t *plane,
                                                       int plane_stride, int nbytes, float *dbg) {
     LC3_CFG_BIND;
@@ -1502,7 +1503,8 @@ struct lc3_mid_fetch {
     lc3_i4 u[2];
     int32_t flag;
 };
-__device__ __forceinline__ void lc3_mid_issue(const lc3_cfg &c, int lane, const float *mid, lc3_mid_fetch &m) {
+template <class CC>
+__device__ __forceinline__ void lc3_mid_issue(const CC &c, int lane, const float *mid, lc3_mid_fetch &m) {
     LC3_HBM_CONST(lc3_i4) s4 = (LC3_HBM_CONST(lc3_i4))(mid + MP_SPEC);
     const int n4 = c.nf / 4;  // <= 120
 #pragma unroll
@@ -1514,7 +1516,7 @@ __device__ __forceinline__ void lc3_mid_issue(const lc3_cfg &c, int lane, const 
 }
 
 // m: this frame's mid-plane words, fetched by lc3_mid_issue
-__device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const float *mid,
+LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const float *mid,
                                                      const lc3_mid_fetch &m, int32_t *plane, int plane_stride, int nbytes,
                                                      int store, float *dbg) {
     LC3_CFG_BIND;

@@ -132,7 +132,7 @@ __device__ __forceinline__ void lc3_pk_ac_shift_sel(lc3_pack_ctx &w, int need) {
     const int flush = need & ((w.low < 0x00ff0000u) | (w.carry == 1));
     {   // the cached byte goes out (to the sink when there is nothing to write)
         const int put = flush & (w.cache >= 0);
-        *(put & (w.bp < w.nbytes) ? w.buf + w.bp : w.sink) = (uint8_t)(w.cache + w.carry);
+        *((put & (w.bp < w.nbytes)) ? w.buf + w.bp : w.sink) = (uint8_t)(w.cache + w.carry);
         w.side_acc = (put & (w.bp == w.bp_side)) ? (uint32_t)((w.cache + w.carry) & 0xff) : w.side_acc;
         w.bp += put;
     }

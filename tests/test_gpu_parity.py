@@ -388,3 +388,26 @@ def test_mixed_configuration_batch():
         got_p = np.concatenate([p.cpu().numpy() for _, p in j["out"]], axis=1)
         assert np.array_equal(got_b, j["ref_b"]), (j["fs"], j["us"])
         assert np.array_equal(got_p, j["ref_p"]), (j["fs"], j["us"])
+
+
+def test_runtime_configuration_view_of_the_headline_configuration():
+    """48 kHz / 10 ms normally runs the kernels instantiated with the configuration as compile-time constants
+    (lc3_cfg_48k10); LC3GPU_GENERIC=1 keeps it on the run-time view every other configuration uses.  Both must give the
+    oracle's bytes and PCM (a fresh process: the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, 'tests')\n"
+        "import test_gpu_parity as t\n"
+        "for nb in (150, 60, 300):\n"
+        "    t._roundtrip_check(48000, 10000, nb, 96, 6, seed=61)\n"
+        "t.test_corrupt_frames_are_concealed_like_the_reference()\n"
+        "t.test_ltpf_transitions(48000, 10000, 40)\n"
+        "print('generic ok')\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LC3GPU_GENERIC="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "generic ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
