@@ -754,6 +754,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     if (lane == 0) {
         float *o12 = x12 + c.delay12 + LC3_NMEM;
         float m1 = L.st.h50_m1, m2 = L.st.h50_m2;
+        #pragma unroll 1
         for (int n0 = 0; n0 < len12; n0 += 8) {  // len12 is a multiple of 8; eight samples per LDS round trip
             float x[8];
 #pragma unroll
@@ -785,6 +786,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         const int k0 = lane, has1 = lane + LC3_WAVE < NL, k1 = has1 ? lane + LC3_WAVE : lane;
         const float *pa = x6 + LC3_KMAX, *pb0 = x6 + (LC3_KMAX - LC3_KMIN - k0), *pb1 = x6 + (LC3_KMAX - LC3_KMIN - k1);
         float acc0 = 0.0f, acc1 = 0.0f;
+        #pragma unroll 1
         for (int n = 0; n < len6; n += 8) {
             float a[8], b0[8], b1[8];
 #pragma unroll
@@ -830,6 +832,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         const int lag = lane == 0 ? 0 : L.ism[lane - 1];
         const int from = LC3_KMAX - lag;
         float v = 0.0f;
+        #pragma unroll 1
         for (int n = from; n < from + len6; n += 8) {
             float a[8];
 #pragma unroll
@@ -868,6 +871,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
             const int k = k_min - 4 + lane;
             float acc = 0.0f;
             const float *pa = x12 + LC3_NMEM, *pb = x12 + LC3_NMEM - k;
+            #pragma unroll 1
             for (int n = 0; n < len12; n += 8) {
                 float a[8], b[8];
 #pragma unroll
@@ -939,6 +943,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         // lane 0: sum dA*dB, lane 1: sum dA*dA, lane 2: sum dB*dB
         const float *pa = lane == 2 ? dB : dA, *pb = lane == 1 ? dA : dB;
         float acc = 0.0f;
+        #pragma unroll 1
         for (int n = 0; n < len12; n += 8) {
             float a[8], b[8];
 #pragma unroll

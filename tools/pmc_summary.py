@@ -14,6 +14,8 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             name = row["Kernel_Name"].split("(")[0]
+            if name.startswith("void "):  # template instantiations: "void kernel<view>(...)"; the view stays in the name
+                name = name[5:]
             if not name.startswith("lc3_"):
                 continue
             acc[(name, row["Counter_Name"], int(row["Grid_Size"]))].append(float(row["Counter_Value"]))

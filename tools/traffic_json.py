@@ -15,7 +15,7 @@ def main():
         for row in csv.DictReader(f):
             key = {"FETCH_SIZE": "fetch_size_kb_per_launch", "WRITE_SIZE": "write_size_kb_per_launch"}.get(row["counter"])
             if key:
-                kernels.setdefault(row["kernel"], {})[key] = float(row["mean_per_launch"])
+                kernels.setdefault(row["kernel"].split("<")[0], {})[key] = float(row["mean_per_launch"])  # drop the <view>
     out = {
         "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB per launch of 65536 "
                   "frames; raw, FETCH_SIZE not doubled: the accesses are not wide streaming reads, "
