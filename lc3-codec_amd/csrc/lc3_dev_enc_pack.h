@@ -21,9 +21,6 @@ enum {
     EP_WORDS = EP_XQ + 200
 };
 
-#ifndef LC3_PACK_BATCH_SV
-#define LC3_PACK_BATCH_SV 1
-#endif
 
 struct lc3_pack_ctx {
     uint8_t *buf;            // this frame's nbytes output bytes (LDS staging)
@@ -253,71 +250,59 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
     // spectral_data :246-326
     int nlsbs = 0;
     {
-        int cctx = 0;
-        const int ntup = lastnz_trunc / 2;
-        // the quantised pairs are fetched eight tuples at a time, one group ahead of their use
-        uint32_t xcur[8], xnext[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) xcur[j] = j < ne / 2 ? (uint32_t)lc3_ep_get(w, EP_XQ + j) : 0u;
-        for (int tup0 = 0; tup0 < ntup; tup0 += 8) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) xnext[j] = tup0 + 8 + j < ne / 2 ? (uint32_t)lc3_ep_get(w, EP_XQ + tup0 + 8 + j) : 0u;
-            // The contexts depend on the quantised values only, not on the coder's state (:262-296): the group's
-            // contexts follow in closed form, and the model words of its eight main symbols are fetched as one batch of
-            // independent LDS reads instead of two dependent reads inside every pair's coding step.
-            int tcx[8];
-            uint32_t svm[8], sve[8];  // model words of the main symbols and of the first escape symbols
-            {
-                uint32_t row[8], row0[8], sym[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int k = 2 * (tup0 + j);
-                    const int q0 = (int)(int16_t)(xcur[j] & 0xffffu), q1 = (int)(int16_t)(xcur[j] >> 16);
-                    const unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
-                    const unsigned m = a > b ? a : b;
-                    const int lev = m < 4u ? 0 : lc3_ilog2(m) - 1;  // escape rounds of the pair
-                    const int lv = lev < 3 ? lev : 3;
-                    const unsigned af = a >> lev, bf = b >> lev;
-                    tcx[j] = cctx + rate_flag + (k > ne / 2 ? 256 : 0);
-                    row0[j] = (uint32_t)w.lookup[tcx[j]];
-                    row[j] = (uint32_t)w.lookup[tcx[j] + lv * 1024];
-                    sym[j] = af + 4u * bf;
-                    cctx = (cctx & 15) * 16 + (lv <= 1 ? 1 + (int)(af + bf) * (lv + 1) : 12 + lv);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    svm[j] = w.cf[(int)row[j] * 17 + (int)sym[j]];
-                    sve[j] = w.cf[(int)row0[j] * 17 + 16];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int tup = tup0 + j;
-                if (tup < ntup) {
-                    const int t = tcx[j];
-                    int lev = 0;
-                    const int q0 = (int)(int16_t)(xcur[j] & 0xffffu), q1 = (int)(int16_t)(xcur[j] >> 16);
-                    unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
-                    unsigned a_lsb = a, b_lsb = b;
-                    while ((a > b ? a : b) >= 4) {  // escape symbols: the rarer case
-                        uint32_t sv = sve[j];  // level 0 was fetched with the group
-                        if (lev > 0) sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + 16];
-                        lc3_pk_ac_encode_sel(w, sv & 0xffffu, sv >> 16);
-                        const int want = !(lsb_mode && lev == 0);
-                        lc3_pk_bool_backward_sel(w, want, (a & 1u) == 1u);
-                        lc3_pk_bool_backward_sel(w, want, (b & 1u) == 1u);
-                        a >>= 1;
-                        b >>= 1;
-                        lev += 1;
-                    }
-#if LC3_PACK_BATCH_SV
-                    lc3_pk_ac_encode_sel(w, svm[j] & 0xffffu, svm[j] >> 16);
-#else
-                    {
-                        const uint32_t sv = w.cf[(int)w.lookup[t + (lev < 3 ? lev : 3) * 1024] * 17 + (int)(a + 4 * b)];
-                        lc3_pk_ac_encode_sel(w, sv & 0xffffu, sv >> 16);
-                    }
-#endif
+        // One symbol per iteration and lane: every lane walks its own frame's symbol sequence (escape symbols of a pair,
+        // then its main symbol) and moves on to its next pair by itself.  With a common pair index the wave spends
+        // sum over pairs of (1 + deepest escape level of any lane) iterations, here max over lanes of (sum over pairs of
+        // 1 + level): 1.45x fewer on the benchmark's frames.  The pair after next-but-one is requested every iteration.
+        const int ntup = lastnz_trunc / 2, last = ne / 2 - 1;
+        int tup = 0, lev = 0, cctx = 0;
+        uint32_t xw = (uint32_t)lc3_ep_get(w, EP_XQ), x1 = (uint32_t)lc3_ep_get(w, EP_XQ + (1 < last ? 1 : last)),
+                 x2 = (uint32_t)lc3_ep_get(w, EP_XQ + (2 < last ? 2 : last)), x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (3 < last ? 3 : last));
+        // the model word of the symbol the coming iteration encodes is fetched during the iteration before it (the
+        // symbols depend on the quantised values only, not on the coder's state :262-296)
+#define LC3_PK_SYMBOL(XW, LEV, CCTX, TUP, A, B, ESC, LV, IDX)                                             \
+    const int q0##A = (int)(int16_t)((XW) & 0xffffu), q1##A = (int)(int16_t)((XW) >> 16);                 \
+    const unsigned a0##A = (unsigned)(q0##A < 0 ? -q0##A : q0##A), b0##A = (unsigned)(q1##A < 0 ? -q1##A : q1##A); \
+    const unsigned A = a0##A >> (LEV), B = b0##A >> (LEV);                                                \
+    const int ESC = (A > B ? A : B) >= 4u;                                                                \
+    const int LV = (LEV) < 3 ? (LEV) : 3;                                                                 \
+    const int IDX = (CCTX) + rate_flag + (2 * (TUP) > ne / 2 ? 256 : 0) + LV * 1024
+        uint32_t sv;
+        {
+            LC3_PK_SYMBOL(xw, 0, 0, 0, af, bf, escf, lvf, idxf);
+            sv = w.cf[(int)w.lookup[idxf] * 17 + (escf ? 16 : (int)(af + 4u * bf))];
+        }
+        while (tup < ntup) {
+            LC3_PK_SYMBOL(xw, lev, cctx, tup, a, b, esc, lv, idx);  // an escape symbol (and two LSBs), or the pair's main symbol (and its signs)
+            (void)idx;
+            // where the lane will be after this symbol, and that symbol's model row
+            const int adv = !esc;
+            const int n_cctx = adv ? (cctx & 15) * 16 + (lv <= 1 ? 1 + (int)(a + b) * (lv + 1) : 12 + lv) : cctx;
+            const int n_lev = adv ? 0 : lev + 1, n_tup = tup + adv;
+            const uint32_t n_xw = adv ? x1 : xw;
+            LC3_PK_SYMBOL(n_xw, n_lev, n_cctx, n_tup, an, bn, escn, lvn, idxn);
+            (void)lvn;
+            const int rown = (int)w.lookup[idxn];
+            // this symbol
+            lc3_pk_ac_encode_sel(w, sv & 0xffffu, sv >> 16);
+            const int lsb_here = lsb_mode && lev > 0;
+            const unsigned a_l = lsb_here ? a0a >> 1 : a0a, b_l = lsb_here ? b0a >> 1 : b0a;
+            const int want_e = !(lsb_mode && lev == 0);
+            lc3_pk_bool_backward_sel(w, esc ? want_e : a_l > 0u, esc ? (a & 1u) == 1u : q0a <= 0);
+            lc3_pk_bool_backward_sel(w, esc ? want_e : b_l > 0u, esc ? (b & 1u) == 1u : q1a <= 0);
+            // the LSB list itself is regenerated below when it is written
+            nlsbs += (!esc && lsb_here) ? 2 + (a_l == 0u && q0a != 0) + (b_l == 0u && q1a != 0) : 0;
+            sv = w.cf[rown * 17 + (escn ? 16 : (int)(an + 4u * bn))];
+            cctx = n_cctx;
+            lev = n_lev;
+            tup = n_tup;
+            xw = n_xw;
+            x1 = adv ? x2 : x1;
+            x2 = adv ? x3 : x2;
+            x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (tup + 3 < last ? tup + 3 : last));  // the same word again unless the lane advanced
+        }
+#undef LC3_PK_SYMBOL
+    }
                     {   // the LSB list itself is regenerated below when it is written
                         const int lsb_here = lsb_mode && lev > 0;
                         a_lsb = lsb_here ? a_lsb >> 1 : a_lsb;
@@ -332,6 +317,7 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
             for (int j = 0; j < 8; j++) xcur[j] = xnext[j];
         }
     }
+#endif
     LC3_PSTAMP(w, 3);
     // residual_data_and_finalization :328-352
     {
