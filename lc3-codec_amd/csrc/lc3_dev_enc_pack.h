@@ -303,21 +303,6 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
         }
 #undef LC3_PK_SYMBOL
     }
-                    {   // the LSB list itself is regenerated below when it is written
-                        const int lsb_here = lsb_mode && lev > 0;
-                        a_lsb = lsb_here ? a_lsb >> 1 : a_lsb;
-                        b_lsb = lsb_here ? b_lsb >> 1 : b_lsb;
-                        nlsbs += lsb_here ? 2 + (a_lsb == 0 && q0 != 0) + (b_lsb == 0 && q1 != 0) : 0;
-                    }
-                    lc3_pk_bool_backward_sel(w, a_lsb > 0, q0 <= 0);
-                    lc3_pk_bool_backward_sel(w, b_lsb > 0, q1 <= 0);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) xcur[j] = xnext[j];
-        }
-    }
-#endif
     LC3_PSTAMP(w, 3);
     // residual_data_and_finalization :328-352
     {
