@@ -353,37 +353,38 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
     const int ntup = lastnz / 2;
     {
         const int rate_flag = nbits > (160 + fs_ind * 160) ? 512 : 0;
-        int cctx = 0, err = 0;
-        for (int tup = 0; tup < ntup; tup++) {
+        // One symbol per iteration and lane: a lane decodes the escape symbols of its pair (each followed by the pair's next
+        // bit plane) and then the main symbol (followed by the signs), and moves on to its next pair by itself.  With a pair
+        // index common to the wave the iterations add up to sum over pairs of (1 + deepest escape level of any lane); here
+        // to max over lanes of (sum over pairs of 1 + level), 1.45x fewer on the benchmark's frames.
+        // Reference loop per pair: `while lev < 14 { decode; if sym < 16 break; [two LSBs]; lev += 1 }` -- a pair that reaches
+        // level 14 ends without another symbol and keeps the escape symbol (16).
+        int cctx = 0, err = 0, tup = 0, lev = 0;
+        int32_t xk = 0, xk1 = 0;
+        while (tup < ntup) {
             const int t = cctx + rate_flag + ((tup * 2) > (ne / 2) ? 256 : 0);
-            int lev = 0;
-            int32_t xk = 0, xk1 = 0;
-            sym = lc3_p_ac_decode_spec_sel(c, st, c.cf + (int)c.lookup[t] * LC3_DCF_ROW_WORDS, err);
-            // escape symbols (magnitudes >= 4, the rarer case): one more bit plane and one more symbol per round.
-            // Reference loop: `while lev < 14 { decode; if sym < 16 break; [two LSBs]; lev += 1 }`
-            while (sym >= 16 && lev < 14) {
-                const int want = !lsb_mode || lev > 0;
-                xk += (int32_t)((uint32_t)lc3_p_bool_sel(c, want, err) << lev);
-                xk1 += (int32_t)((uint32_t)lc3_p_bool_sel(c, want, err) << lev);
-                lev += 1;
-                if (lev < 14) sym = lc3_p_ac_decode_spec_sel(c, st, c.cf + (int)c.lookup[t + (lev < 3 ? lev : 3) * 1024] * LC3_DCF_ROW_WORDS, err);
-            }
-            if (lsb_mode) lc3_px_set(c, LC3_PLANE_LEV + tup, lev);  // written by TUPLE index, read by LINE index (:184-195)
-            const int a = sym & 3, b = sym >> 2;
-            xk += (int32_t)((uint32_t)a << lev);
-            xk1 += (int32_t)((uint32_t)b << lev);
-            {
-                const int w0 = xk > 0, s0 = lc3_p_bool_sel(c, w0, err);
-                xk = s0 ? -xk : xk;
-                const int w1 = xk1 > 0, s1 = lc3_p_bool_sel(c, w1, err);
-                xk1 = s1 ? -xk1 : xk1;
-            }
-            lc3_px_set(c, LC3_PLANE_X + 2 * tup, xk);
-            lc3_px_set(c, LC3_PLANE_X + 2 * tup + 1, xk1);
-            c.nnz += (uint32_t)(xk != 0) + (uint32_t)(xk1 != 0);
-            c.seed += (uint32_t)(xk < 0 ? -xk : xk) * (uint32_t)(2 * tup) + (uint32_t)(xk1 < 0 ? -xk1 : xk1) * (uint32_t)(2 * tup + 1);
             const int lv = lev < 3 ? lev : 3;
-            cctx = (cctx & 15) * 16 + (lv <= 1 ? 1 + (a + b) * (lv + 1) : 12 + lv);
+            if (lev < 14) sym = lc3_p_ac_decode_spec_sel(c, st, c.cf + (int)c.lookup[t + lv * 1024] * LC3_DCF_ROW_WORDS, err);
+            const int esc = sym >= 16 && lev < 14;
+            const int a = sym & 3, b = sym >> 2;
+            const int32_t m0 = xk + (int32_t)((uint32_t)a << lev), m1 = xk1 + (int32_t)((uint32_t)b << lev);  // if this is the main symbol
+            // two tail bits: after an escape symbol the pair's next bit plane (when it is transmitted), after the main symbol
+            // the signs of the non-zero values
+            const int want_e = !lsb_mode || lev > 0;
+            const int bit0 = lc3_p_bool_sel(c, esc ? want_e : m0 > 0, err);
+            const int bit1 = lc3_p_bool_sel(c, esc ? want_e : m1 > 0, err);
+            const int32_t v0 = bit0 ? -m0 : m0, v1 = bit1 ? -m1 : m1;
+            // (an escape step stores its partial values too: the pair's main step overwrites them)
+            lc3_px_set(c, LC3_PLANE_X + 2 * tup, v0);
+            lc3_px_set(c, LC3_PLANE_X + 2 * tup + 1, v1);
+            if (lsb_mode && !esc) lc3_px_set(c, LC3_PLANE_LEV + tup, lev);  // written by TUPLE index, read by LINE index (:184-195)
+            c.nnz += esc ? 0u : (uint32_t)(m0 != 0) + (uint32_t)(m1 != 0);
+            c.seed += esc ? 0u : (uint32_t)m0 * (uint32_t)(2 * tup) + (uint32_t)m1 * (uint32_t)(2 * tup + 1);
+            cctx = esc ? cctx : (cctx & 15) * 16 + (lv <= 1 ? 1 + (a + b) * (lv + 1) : 12 + lv);
+            xk = esc ? xk + (int32_t)((uint32_t)bit0 << lev) : 0;
+            xk1 = esc ? xk1 + (int32_t)((uint32_t)bit1 << lev) : 0;
+            tup += !esc;
+            lev = esc ? lev + 1 : 0;
         }
         if (err) return -4;
     }
