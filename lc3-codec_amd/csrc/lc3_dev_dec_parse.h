@@ -443,6 +443,8 @@ struct lc3_recon_ctx {
     float *scf;            // 16 scale factors of this lane, element n at scf[n * sstride] (LDS, dynamically indexed)
     int sstride;
     const uint32_t *mpvq;  // MPVQ_OFFSETS[16][11] (LDS copy)
+    const uint16_t *ifs;   // band index table of the configuration, nb + 1 entries (LDS copy: read at every band boundary of
+                           // the line loop, and a table word fetched from HBM there waits for every outstanding plane access)
 };
 
 // mpvq_deenum (decoder/spectral_noise_shaping.rs:155-235) writing the pulses into scf slots as floats is not possible
@@ -604,7 +606,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     for (int j = 0; j < 4; j++)
         if (xw[j] != 0 && j < bw_stop) nzwin |= 1u << (j + 3);
     const uint32_t winmask = nf_width == 3 ? 0x7Fu : 0x3Eu;  // lines k-3..k+3 or k-2..k+2
-    const uint16_t *ifs = lc3_band_index(cfg);
+    const uint16_t *ifs = r.ifs;
     int bi = 0, rank_nz = 0;
     int band_end = (int)ifs[1];  // first line of the next band (kept in a register: one table read per band, not per line)
     float g_band = lc3_r_band_gain(r, 0, cfg.nb);

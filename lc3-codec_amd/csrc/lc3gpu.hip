@@ -416,9 +416,9 @@ __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *pl
 // (cum | freq) spectral model and the frames' bytes are staged in LDS with coalesced loads.  blockDim.x frames per
 // workgroup (256, or 128 for frames above 220 bytes so that the staging fits 64 KB of dynamic LDS):
 // 4096 + 64*17*4 + blockDim.x*nbytes bytes.
-// Dynamic LDS: 4096 (context lookup) + 64*20*4 (spectral model, lc3_dcf_word) + 16*11*4 (MPVQ offsets) + 152*4 (TNS models) + 16*4*blockDim.x (scale
+// Dynamic LDS: 4096 (context lookup) + 64*20*4 (spectral model, lc3_dcf_word) + 16*11*4 (MPVQ offsets) + 152*4 (TNS models) + 144 (band index table) + 16*4*blockDim.x (scale
 // factors, [n][lane]) + blockDim.x * nbytes (frame bytes).
-#define LC3_PARSE_LDS_FIXED (4096 + 64 * LC3_DCF_ROW_WORDS * 4 + 16 * 11 * 4 + 4 * 152)
+#define LC3_PARSE_LDS_FIXED (4096 + 64 * LC3_DCF_ROW_WORDS * 4 + 16 * 11 * 4 + 4 * 152 + 144)
 template <class CV>
 __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot<CV> cfg, const uint8_t *in, const uint8_t *bad,
                                                         int32_t *planes, int nbytes, int n_frames) {
@@ -430,12 +430,14 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot<CV> cfg, co
     uint32_t *s_cf = (uint32_t *)(smem + 4096);
     uint32_t *s_mpvq = (uint32_t *)(smem + 4096 + 64 * LC3_DCF_ROW_WORDS * 4);
     uint32_t *s_tns = (uint32_t *)(smem + 4096 + 64 * LC3_DCF_ROW_WORDS * 4 + 16 * 11 * 4);
+    uint16_t *s_ifs = (uint16_t *)(smem + 4096 + 64 * LC3_DCF_ROW_WORDS * 4 + 16 * 11 * 4 + 4 * 152);  // 65 entries, 144 bytes reserved
     float *s_scf = (float *)(smem + LC3_PARSE_LDS_FIXED);
     uint8_t *s_bytes = smem + LC3_PARSE_LDS_FIXED + 16 * 4 * fpb;
     const size_t f0 = (size_t)blockIdx.x * (size_t)fpb;
     {
         for (int i = tid; i < 16 * 11; i += fpb) s_mpvq[i] = LC3T_MPVQ_OFFSETS[i / 11][i % 11];
         for (int i = tid; i < LC3_TNS_MODEL_WORDS; i += fpb) s_tns[i] = lc3_tns_model_word(i);
+        for (int i = tid; i <= c0.nb; i += fpb) s_ifs[i] = lc3_band_index(c0)[i];
         const uint32_t *lk32 = (const uint32_t *)LC3T_AC_SPEC_LOOKUP;
         uint32_t *d32 = (uint32_t *)s_lookup;
         for (int i = tid; i < 1024; i += fpb) d32[i] = lk32[i];
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot<CV> cfg, co
             r.scf = s_scf + tid;
             r.sstride = fpb;
             r.mpvq = s_mpvq;
+            r.ifs = s_ifs;
             ok = lc3_reconstruct_frame(c, r, c0);
         }
         lc3_px_set(c, AD_OK, ok);

@@ -299,6 +299,7 @@ int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8
             r.scf = scf;
             r.sstride = 1;
             r.mpvq = &LC3T_MPVQ_OFFSETS[0][0];
+            r.ifs = lc3_band_index(j.cfg);
             ok = lc3_reconstruct_frame(c, r, j.cfg);
         }
         lc3_px_set(c, AD_OK, ok);
