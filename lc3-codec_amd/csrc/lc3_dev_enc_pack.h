@@ -161,13 +161,6 @@ __device__ __forceinline__ void lc3_pk_ac_encode_sel(lc3_pack_ctx &w, uint32_t c
     }
 }
 
-// one (x_q[k], x_q[k+1]) pair of the plane
-__device__ __forceinline__ void lc3_ep_pair(const lc3_pack_ctx &c, int tup, int &q0, int &q1) {
-    const uint32_t v = (uint32_t)lc3_ep_get(c, EP_XQ + tup);
-    q0 = (int)(int16_t)(v & 0xffffu);
-    q1 = (int)(int16_t)(v >> 16);
-}
-
 // BitstreamEncoding::encode :77-136; the buffer must be zero-filled (init :138-144)
 __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
     w.nbits = w.nbytes * 8;
@@ -178,8 +171,11 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
     // the 21 scalar words and the 16 TNS indices of the column: one batch of independent loads (a lane of this kernel
     // is latency-bound; every plane word fetched at its point of use would cost a full memory round trip)
     int32_t sw[EP_RES];
+    uint32_t rw[13];  // residual bit words (used when the frame is not in LSB mode)
 #pragma unroll
     for (int i = 0; i < EP_RES; i++) sw[i] = lc3_ep_get(w, i);
+#pragma unroll
+    for (int i = 0; i < 13; i++) rw[i] = (uint32_t)lc3_ep_get(w, EP_RES + i);
 #define LC3_EPW(word) sw[word]
     const int lsb_mode = LC3_EPW(EP_LSB_MODE), lastnz_trunc = LC3_EPW(EP_LASTNZ_TRUNC);
     const int num_tns = LC3_EPW(EP_NUM_TNS), rate_flag = LC3_EPW(EP_RATE_FLAG);
@@ -315,28 +311,36 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
         if (!lsb_mode) {
             const int n_res = LC3_EPW(EP_N_RES);
             if (n_enc > n_res) n_enc = n_res;
-            for (int k = 0; k < n_enc; k += 32) {
-                const uint32_t bits = (uint32_t)lc3_ep_get(w, EP_RES + (k >> 5));
-                lc3_pk_uint_backward(w, bits, n_enc - k < 32 ? n_enc - k : 32);
+#pragma unroll
+            for (int i = 0; i < 13; i++) {  // the words were fetched with the column's scalars
+                const int k = 32 * i;
+                if (k < n_enc) lc3_pk_uint_backward(w, rw[i], n_enc - k < 32 ? n_enc - k : 32);
             }
         } else {
-            // lsbs[0 .. nlsbs) in the order spectral_data pushed them (:298-312), regenerated on the fly
+            // lsbs[0 .. nlsbs) in the order spectral_data pushed them (:298-312), regenerated on the fly; the pairs are
+            // fetched eight at a time, and a pair's two to four bits (LSB, sign of a value that became 0 >> 1, LSB, sign) go
+            // out as one backward write
             if (n_enc > nlsbs) n_enc = nlsbs;
             int written = 0;
             const int ntup = lastnz_trunc / 2;
-            for (int tup = 0; tup < ntup && written < n_enc; tup++) {
-                int q0, q1;
-                lc3_ep_pair(w, tup, q0, q1);
-                const unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
-                if ((a > b ? a : b) >= 4) {
-                    int e[4], ne_ = 0;
-                    e[ne_++] = (int)(a & 1u);
-                    if ((a >> 1) == 0 && q0 != 0) e[ne_++] = q0 > 0 ? 0 : 1;
-                    e[ne_++] = (int)(b & 1u);
-                    if ((b >> 1) == 0 && q1 != 0) e[ne_++] = q1 > 0 ? 0 : 1;
-                    for (int j = 0; j < ne_ && written < n_enc; j++) {
-                        lc3_pk_bool_backward(w, e[j] == 1);
-                        written++;
+            for (int tup0 = 0; tup0 < ntup && written < n_enc; tup0 += 8) {
+                uint32_t xq8[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) xq8[j] = tup0 + j < ne / 2 ? (uint32_t)lc3_ep_get(w, EP_XQ + tup0 + j) : 0u;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int q0 = (int)(int16_t)(xq8[j] & 0xffffu), q1 = (int)(int16_t)(xq8[j] >> 16);
+                    const unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
+                    if (tup0 + j < ntup && written < n_enc && (a > b ? a : b) >= 4) {
+                        uint32_t ev = a & 1u;
+                        int ne_ = 1;
+                        if ((a >> 1) == 0 && q0 != 0) { ev |= (q0 > 0 ? 0u : 1u) << ne_; ne_++; }
+                        ev |= (b & 1u) << ne_;
+                        ne_++;
+                        if ((b >> 1) == 0 && q1 != 0) { ev |= (q1 > 0 ? 0u : 1u) << ne_; ne_++; }
+                        const int m = ne_ < n_enc - written ? ne_ : n_enc - written;
+                        lc3_pk_uint_backward(w, ev, m);
+                        written += m;
                     }
                 }
             }
