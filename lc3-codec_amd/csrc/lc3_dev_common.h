@@ -234,6 +234,14 @@ __device__ __forceinline__ float lc3_ceilf(float x) { return __builtin_ceilf(x);
 // range decoder state (decoder/arithmetic_codec.rs:22-26)
 struct lc3_acdec { uint32_t low, range; };
 
+// element i (0 .. LC3_TNS_MODEL_WORDS-1) of the packed TNS models (range coder and decoder keep them in LDS): [2][8] order models, then [8][17] coefficient models
+#define LC3_TNS_MODEL_WORDS (2 * 8 + 8 * 17)
+__device__ __forceinline__ uint32_t lc3_tns_model_word(int i) {
+    if (i < 16) return (uint32_t)(int)LC3T_AC_TNS_ORDER_CUMFREQ[i / 8][i % 8] | ((uint32_t)(int)LC3T_AC_TNS_ORDER_FREQ[i / 8][i % 8] << 16);
+    const int k = (i - 16) / 17, j = (i - 16) % 17;
+    return (uint32_t)(int)LC3T_AC_TNS_COEF_CUMFREQ[k][j] | ((uint32_t)(int)LC3T_AC_TNS_COEF_FREQ[k][j] << 16);
+}
+
 // ------------------------------------------------------------------------------------------
 // Float library.  The reference is no_std: every f32 method resolves through num_traits to the
 // `libm` crate (reference Cargo.toml:17), a port of the FreeBSD msun routines.  These are the same

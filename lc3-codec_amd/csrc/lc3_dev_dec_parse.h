@@ -283,14 +283,6 @@ __device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_ac
     return lo;
 }
 
-// element i (0 .. LC3_TNS_MODEL_WORDS-1) of the packed TNS models: [2][8] order models, then [8][17] coefficient models
-#define LC3_TNS_MODEL_WORDS (2 * 8 + 8 * 17)
-__device__ __forceinline__ uint32_t lc3_tns_model_word(int i) {
-    if (i < 16) return (uint32_t)(int)LC3T_AC_TNS_ORDER_CUMFREQ[i / 8][i % 8] | ((uint32_t)(int)LC3T_AC_TNS_ORDER_FREQ[i / 8][i % 8] << 16);
-    const int k = (i - 16) / 17, j = (i - 16) % 17;
-    return (uint32_t)(int)LC3T_AC_TNS_COEF_CUMFREQ[k][j] | ((uint32_t)(int)LC3T_AC_TNS_COEF_FREQ[k][j] << 16);
-}
-
 // read_res_bit (decoder/arithmetic_codec.rs:339-383)
 __device__ __forceinline__ int lc3_p_res_bit(lc3_parse_ctx &c, int idx, int &nbits_res, int &cont) {
     int bit;

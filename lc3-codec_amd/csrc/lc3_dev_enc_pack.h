@@ -28,6 +28,7 @@ struct lc3_pack_ctx {
     int nbytes, nbits;
     const uint8_t *lookup;   // AC_SPEC_LOOKUP[4096]
     const uint32_t *cf;      // [64][17] cum | freq << 16
+    const uint32_t *tns;     // packed TNS models (lc3_tns_model_word): [2][8] order models, then [8][17] coefficient models
     const int32_t *plane;    // word w at plane[w * stride]
     int stride;
     // BufferWriter (buffer_writer.rs:5-9) + ArithmeticEncoderState (bitstream_encoding.rs:27-34)
@@ -228,16 +229,16 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
         for (int f = 0; f < num_tns; f++) {
             const int order = f == 0 ? ord0 : ord1;
             if (order > 0) {
-                lc3_pk_ac_encode(w, (uint32_t)(int)LC3T_AC_TNS_ORDER_CUMFREQ[wt][order - 1],
-                                 (uint32_t)(int)LC3T_AC_TNS_ORDER_FREQ[wt][order - 1]);
+                const uint32_t so = w.tns[wt * 8 + order - 1];
+                lc3_pk_ac_encode(w, so & 0xffffu, so >> 16);
                 for (int k = 0; k < order; k++) {
                     int ri = 0;
 #pragma unroll
                     for (int q = 0; q < 16; q++)
                         if (q == k + 8 * f) ri = sw[EP_RCI + q];
                     ri = ri < 0 ? 0 : (ri > 16 ? 16 : ri);
-                    lc3_pk_ac_encode(w, (uint32_t)(int)LC3T_AC_TNS_COEF_CUMFREQ[k][ri],
-                                     (uint32_t)(int)LC3T_AC_TNS_COEF_FREQ[k][ri]);
+                    const uint32_t sc = w.tns[16 + k * 17 + ri];
+                    lc3_pk_ac_encode(w, sc & 0xffffu, sc >> 16);
                 }
             }
         }

@@ -340,13 +340,14 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_bac
 
 // Bitstream packer, one LANE per frame (lc3_dev_enc_pack.h).  blockDim.x frames per workgroup; context lookup and the
 // packed spectral model in LDS, every lane builds its frame in an LDS staging slot, then the workgroup copies the
-// frames out with coalesced stores.  Dynamic LDS: 4096 + 64*17*4 + blockDim.x * nbytes (rounded up to 4) + 4 (sink).
+// frames out with coalesced stores.  Dynamic LDS: 4096 + 64*17*4 + 152*4 (TNS models) + blockDim.x * nbytes (rounded up to 4) + 4 (sink).
 __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *planes, uint8_t *out, int nbytes,
                                                        int n_frames) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_lookup = smem;
     uint32_t *s_cf = (uint32_t *)(smem + 4096);
-    uint8_t *s_bytes = smem + 4096 + 64 * 17 * 4;
+    uint32_t *s_tns = (uint32_t *)(smem + 4096 + 64 * 17 * 4);
+    uint8_t *s_bytes = smem + 4096 + 64 * 17 * 4 + LC3_TNS_MODEL_WORDS * 4;
     const int tid = threadIdx.x, fpb = blockDim.x;
     const size_t f0 = (size_t)blockIdx.x * (size_t)fpb;
     const size_t remaining = (size_t)n_frames - f0;
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *pl
             const int p = i / 17, j = i - 17 * p;
             s_cf[i] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[p][j] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[p][j] << 16);
         }
+        for (int i = tid; i < LC3_TNS_MODEL_WORDS; i += fpb) s_tns[i] = lc3_tns_model_word(i);
         uint32_t *b32 = (uint32_t *)s_bytes;  // init :138-144: frames start zero-filled
         for (int i = tid; i < (total + 3) / 4; i += fpb) b32[i] = 0;
     }
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *pl
         c.nbytes = nbytes;
         c.lookup = s_lookup;
         c.cf = s_cf;
+        c.tns = s_tns;
         c.plane = LC3_PLANE_COL(planes, f, EP_WORDS);
         c.stride = LC3_PLANE_STRIDE;
 #ifdef LC3_PROFILE
@@ -868,7 +871,7 @@ static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_p
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
     const unsigned fpb = lc3_frame_block(nbytes <= 220 ? 256u : 128u);
-    const size_t lds = 4096 + 64 * 17 * 4 + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3) + 4;  // + the packer's sink byte
+    const size_t lds = 4096 + 64 * 17 * 4 + LC3_TNS_MODEL_WORDS * 4 + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3) + 4;  // + the packer's sink byte
     hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, e->h.c.ne,
                        (const int32_t *)e->d_planes, d_out, nbytes, (int)frames);
     HIP_TRY(hipGetLastError());

@@ -245,12 +245,15 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
     for (int p = 0; p < 64; p++)
         for (int q = 0; q < 17; q++)
             cf[(size_t)p * 17 + q] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[p][q] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[p][q] << 16);
+    static uint32_t tns_models[LC3_TNS_MODEL_WORDS];
+    for (int i = 0; i < LC3_TNS_MODEL_WORDS; i++) tns_models[i] = lc3_tns_model_word(i);
     memset(bytes, 0, frames * (size_t)nbytes);
     for (size_t f = 0; f < frames; f++) {
         lc3_pack_ctx c;
         uint8_t sink = 0;
         c.buf = bytes + f * (size_t)nbytes;
         c.sink = &sink;
+        c.tns = tns_models;
         c.nbytes = nbytes;
         c.lookup = LC3T_AC_SPEC_LOOKUP;
         c.cf = cf.data();
