@@ -162,6 +162,29 @@ __device__ __forceinline__ void lc3_pk_ac_encode_sel(lc3_pack_ctx &w, uint32_t c
     }
 }
 
+// one symbol of spectral_data (:262-296) as a function of the quantised pair and the lane's position in it
+struct lc3_pk_sym {
+    int q0, q1;       // the pair
+    unsigned a0, b0;  // its magnitudes
+    unsigned a, b;    // ... at the current escape level
+    int esc;          // the symbol is an escape (magnitudes >= 4 at this level)
+    int lv;           // min(level, 3)
+    int idx;          // index of the symbol's context in the lookup table
+};
+__device__ __forceinline__ lc3_pk_sym lc3_pk_symbol(uint32_t xw, int lev, int cctx, int tup, int rate_flag, int ne) {
+    lc3_pk_sym s;
+    s.q0 = (int)(int16_t)(xw & 0xffffu);
+    s.q1 = (int)(int16_t)(xw >> 16);
+    s.a0 = (unsigned)(s.q0 < 0 ? -s.q0 : s.q0);
+    s.b0 = (unsigned)(s.q1 < 0 ? -s.q1 : s.q1);
+    s.a = s.a0 >> lev;
+    s.b = s.b0 >> lev;
+    s.esc = (s.a > s.b ? s.a : s.b) >= 4u;
+    s.lv = lev < 3 ? lev : 3;
+    s.idx = cctx + rate_flag + (2 * tup > ne / 2 ? 256 : 0) + s.lv * 1024;
+    return s;
+}
+
 // BitstreamEncoding::encode :77-136; the buffer must be zero-filled (init :138-144)
 __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
     w.nbits = w.nbytes * 8;
@@ -255,41 +278,30 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
         int tup = 0, lev = 0, cctx = 0;
         uint32_t xw = (uint32_t)lc3_ep_get(w, EP_XQ), x1 = (uint32_t)lc3_ep_get(w, EP_XQ + (1 < last ? 1 : last)),
                  x2 = (uint32_t)lc3_ep_get(w, EP_XQ + (2 < last ? 2 : last)), x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (3 < last ? 3 : last));
-        // the model word of the symbol the coming iteration encodes is fetched during the iteration before it (the
-        // symbols depend on the quantised values only, not on the coder's state :262-296)
-#define LC3_PK_SYMBOL(XW, LEV, CCTX, TUP, A, B, ESC, LV, IDX)                                             \
-    const int q0##A = (int)(int16_t)((XW) & 0xffffu), q1##A = (int)(int16_t)((XW) >> 16);                 \
-    const unsigned a0##A = (unsigned)(q0##A < 0 ? -q0##A : q0##A), b0##A = (unsigned)(q1##A < 0 ? -q1##A : q1##A); \
-    const unsigned A = a0##A >> (LEV), B = b0##A >> (LEV);                                                \
-    const int ESC = (A > B ? A : B) >= 4u;                                                                \
-    const int LV = (LEV) < 3 ? (LEV) : 3;                                                                 \
-    const int IDX = (CCTX) + rate_flag + (2 * (TUP) > ne / 2 ? 256 : 0) + LV * 1024
-        uint32_t sv;
-        {
-            LC3_PK_SYMBOL(xw, 0, 0, 0, af, bf, escf, lvf, idxf);
-            sv = w.cf[(int)w.lookup[idxf] * 17 + (escf ? 16 : (int)(af + 4u * bf))];
-        }
+        // The symbols depend on the quantised values only, not on the coder's state (:262-296): what the coming iteration
+        // encodes (and its model word) is worked out during the iteration before it and carried over.
+        lc3_pk_sym cur = lc3_pk_symbol(xw, 0, 0, 0, rate_flag, ne);
+        uint32_t sv = w.cf[(int)w.lookup[cur.idx] * 17 + (cur.esc ? 16 : (int)(cur.a + 4u * cur.b))];
         while (tup < ntup) {
-            LC3_PK_SYMBOL(xw, lev, cctx, tup, a, b, esc, lv, idx);  // an escape symbol (and two LSBs), or the pair's main symbol (and its signs)
-            (void)idx;
-            // where the lane will be after this symbol, and that symbol's model row
-            const int adv = !esc;
-            const int n_cctx = adv ? (cctx & 15) * 16 + (lv <= 1 ? 1 + (int)(a + b) * (lv + 1) : 12 + lv) : cctx;
+            // `cur`: an escape symbol (and two LSBs), or the pair's main symbol (and its signs).  Where the lane will be
+            // after it, and that symbol's model row:
+            const int adv = !cur.esc;
+            const int n_cctx = adv ? (cctx & 15) * 16 + (cur.lv <= 1 ? 1 + (int)(cur.a + cur.b) * (cur.lv + 1) : 12 + cur.lv) : cctx;
             const int n_lev = adv ? 0 : lev + 1, n_tup = tup + adv;
             const uint32_t n_xw = adv ? x1 : xw;
-            LC3_PK_SYMBOL(n_xw, n_lev, n_cctx, n_tup, an, bn, escn, lvn, idxn);
-            (void)lvn;
-            const int rown = (int)w.lookup[idxn];
+            const lc3_pk_sym nxt = lc3_pk_symbol(n_xw, n_lev, n_cctx, n_tup, rate_flag, ne);
+            const int rown = (int)w.lookup[nxt.idx];
             // this symbol
             lc3_pk_ac_encode_sel(w, sv & 0xffffu, sv >> 16);
             const int lsb_here = lsb_mode && lev > 0;
-            const unsigned a_l = lsb_here ? a0a >> 1 : a0a, b_l = lsb_here ? b0a >> 1 : b0a;
+            const unsigned a_l = lsb_here ? cur.a0 >> 1 : cur.a0, b_l = lsb_here ? cur.b0 >> 1 : cur.b0;
             const int want_e = !(lsb_mode && lev == 0);
-            lc3_pk_bool_backward_sel(w, esc ? want_e : a_l > 0u, esc ? (a & 1u) == 1u : q0a <= 0);
-            lc3_pk_bool_backward_sel(w, esc ? want_e : b_l > 0u, esc ? (b & 1u) == 1u : q1a <= 0);
+            lc3_pk_bool_backward_sel(w, cur.esc ? want_e : a_l > 0u, cur.esc ? (cur.a & 1u) == 1u : cur.q0 <= 0);
+            lc3_pk_bool_backward_sel(w, cur.esc ? want_e : b_l > 0u, cur.esc ? (cur.b & 1u) == 1u : cur.q1 <= 0);
             // the LSB list itself is regenerated below when it is written
-            nlsbs += (!esc && lsb_here) ? 2 + (a_l == 0u && q0a != 0) + (b_l == 0u && q1a != 0) : 0;
-            sv = w.cf[rown * 17 + (escn ? 16 : (int)(an + 4u * bn))];
+            nlsbs += (!cur.esc && lsb_here) ? 2 + (a_l == 0u && cur.q0 != 0) + (b_l == 0u && cur.q1 != 0) : 0;
+            sv = w.cf[rown * 17 + (nxt.esc ? 16 : (int)(nxt.a + 4u * nxt.b))];
+            cur = nxt;
             cctx = n_cctx;
             lev = n_lev;
             tup = n_tup;
@@ -298,7 +310,6 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
             x2 = adv ? x3 : x2;
             x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (tup + 3 < last ? tup + 3 : last));  // the same word again unless the lane advanced
         }
-#undef LC3_PK_SYMBOL
     }
     LC3_PSTAMP(w, 3);
     // residual_data_and_finalization :328-352
