@@ -102,6 +102,7 @@ __device__ __forceinline__ void lc3_pk_ac_shift(lc3_pack_ctx &w) {  // bitstream
     if (w.low < 0x00ff0000u || w.carry == 1) {
         if (w.cache >= 0) lc3_pk_byte_forward(w, (w.cache + w.carry) & 0xff);
         while (w.carry_count > 0) {
+            asm volatile("" ::: "memory");  // a plain loop, not a vectorised one (see lc3_pk_ac_shift_sel)
             lc3_pk_byte_forward(w, (w.carry + 0xff) & 0xff);
             w.carry_count -= 1;
         }
@@ -135,6 +136,7 @@ __device__ __forceinline__ void lc3_pk_ac_shift_sel(lc3_pack_ctx &w, int need) {
         w.bp += put;
     }
     while (flush && w.carry_count > 0) {  // rare: a run of 0xff bytes was waiting for the carry
+        asm volatile("" ::: "memory");    // keeps this a plain loop (vectorised and unrolled it was a quarter of the loop's code)
         lc3_pk_byte_forward(w, (w.carry + 0xff) & 0xff);
         w.carry_count -= 1;
     }
