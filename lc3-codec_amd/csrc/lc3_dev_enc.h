@@ -1107,7 +1107,8 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
             const int n_esc = (int)((loc[j] >> 16) & 0xff);
             if (k0 + j < ntup && n_esc > 0) {
                 uint32_t est = 0;
-                for (int i = 0; i < n_esc; i++) {
+#pragma clang loop vectorize(disable)
+                for (int i = 0; i < n_esc; i++) {  // one to a few trips: a vectorised form only adds its set-up
                     const int pki = LC3_SPEC_LOOKUP(tctx[j] + (i < 3 ? i : 3) * 1024);
                     est += LC3_SPEC_BITS(pki, 16);
                     if (!(i == 0 && mode_flag)) est += 2 * 2048;
