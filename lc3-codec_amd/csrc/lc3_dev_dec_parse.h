@@ -274,7 +274,9 @@ __device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_ac
     const lc3_i4 q = ((const lc3_i4 *)row)[g];   // symbols 4g .. 4g + 3; symbol 4g is known to satisfy the test
     const int n = (int)(st.low >= LC3_MUL24(tmp, (uint32_t)q[1] & 0xffffu)) + (int)(st.low >= LC3_MUL24(tmp, (uint32_t)q[2] & 0xffffu)) +
                   (int)(st.low >= LC3_MUL24(tmp, (uint32_t)q[3] & 0xffffu));
-    uint32_t sv = n == 0 ? (uint32_t)q[0] : (n == 1 ? (uint32_t)q[1] : (n == 2 ? (uint32_t)q[2] : (uint32_t)q[3]));
+    // q[n] as a two-level select on the bits of n (a chain of comparisons came out as nested branches)
+    const uint32_t q01 = (n & 1) ? (uint32_t)q[1] : (uint32_t)q[0], q23 = (n & 1) ? (uint32_t)q[3] : (uint32_t)q[2];
+    uint32_t sv = (n & 2) ? q23 : q01;
     sv = ge16 ? (uint32_t)pv[0] : sv;
     const int lo = ge16 ? 16 : 4 * g + n;
     st.low -= LC3_MUL24(tmp, sv & 0xffffu);
