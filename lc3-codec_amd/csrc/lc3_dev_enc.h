@@ -588,54 +588,49 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
     // for all samples at once (one lane per sample, identical f32 operations per element => bit-exact), 8 stages
     // instead of ~200 x 8 dependent steps.  The lattice state is shared across the two filters exactly as in the
     // reference (st[k] = B_k at the last sample of the previous filter, untouched for k >= its order).
+    // Here the stages run on registers: lane l holds samples l, l + 64, ... of the filter's range, B_k[n-1] comes from the
+    // neighbouring lane (one DPP move; lane 0 takes the previous round's lane 63, or st[k] at the first sample).
     {
-        float *sF = S + 160, *sB = S + 384, *sST = S + 608;  // 200 + 200 + 8 floats of stage scratch
-        if (lane < 8) sST[lane] = 0.0f;
-        LC3_SYNC();
+        float stv[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // the lattice state, the same on every lane
         for (int f = 0; f < tp.num; f++) {
             const int order = L.ism[8 + f];
             if (order == 0) continue;
-            const int start = tp.start[f], len = tp.stop[f] - tp.start[f];
+            const int start = tp.start[f], len = tp.stop[f] - tp.start[f];  // len <= 256
+            const int lastl = (len - 1) & 63, lastj = (len - 1) >> 6;
+            float fv[4], bv[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int i = lane + LC3_WAVE * j;
-                if (i < len) {
-                    const float v = x[start + i];
-                    sF[i] = v;
-                    sB[i] = v;
+                fv[j] = bv[j] = i < len ? x[start + i] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k < order) {
+                    const float rc = rc_q[f * 8 + k];
+                    // B_k at the filter's last sample (before this stage replaces it) -> next st[k]
+                    const float b_last = lc3_wave_read_f32(lastj == 0 ? bv[0] : (lastj == 1 ? bv[1] : (lastj == 2 ? bv[2] : bv[3])), lastl, lane);
+                    float carry = stv[k];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int i = lane + LC3_WAVE * j;
+                        const float from_left = lc3_wave_shr1_f32(bv[j], lane);
+                        const float bprev = lane > 0 ? from_left : carry;
+                        carry = lc3_wave_read_f32(bv[j], 63, lane);  // B_k[64 j + 63] for the next round's lane 0
+                        const float nb = rc * fv[j] + bprev;         // st_tmp = rcq * t + st
+                        const float nfv = fv[j] + rc * bprev;        // t += rcq * st
+                        bv[j] = i < len ? nb : bv[j];
+                        fv[j] = i < len ? nfv : fv[j];
+                    }
+                    stv[k] = b_last;
                 }
             }
             LC3_SYNC();
-            for (int k = 0; k < order; k++) {
-                const float rc = rc_q[f * 8 + k];
-                const int last_stage = k == order - 1;
-                float nb[4], nfv[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int i = lane + LC3_WAVE * j;
-                    if (i < len) {
-                        const float bprev = i == 0 ? sST[k] : sB[i - 1];
-                        const float fv = sF[i];
-                        nb[j] = rc * fv + bprev;   // st_tmp = rcq * t + st
-                        nfv[j] = fv + rc * bprev;  // t += rcq * st
-                    }
-                }
-                const float b_last = sB[len - 1];  // B_k at the filter's last sample -> next st[k]
-                LC3_SYNC();
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int i = lane + LC3_WAVE * j;
-                    if (i < len) {
-                        if (last_stage) x[start + i] = nfv[j];
-                        else {
-                            sB[i] = nb[j];
-                            sF[i] = nfv[j];
-                        }
-                    }
-                }
-                if (lane == 0) sST[k] = b_last;
-                LC3_SYNC();
+            for (int j = 0; j < 4; j++) {
+                const int i = lane + LC3_WAVE * j;
+                if (i < len) x[start + i] = fv[j];
             }
+            LC3_SYNC();
         }
     }
     LC3_SYNC();

@@ -170,6 +170,17 @@ __device__ __forceinline__ uint32_t lc3_wave_sum_u32(uint32_t u, int lane) {
            (uint32_t)__builtin_amdgcn_readlane(v, 32) + (uint32_t)__builtin_amdgcn_readlane(v, 48);
 }
 // bit l of the result = lane l's predicate (wave-uniform)
+// the value lane - 1 holds (lane 0: unspecified); one DPP move across the whole wave
+__device__ __forceinline__ float lc3_wave_shr1_f32(float v, int lane) {
+    (void)lane;
+    const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, r);
+}
+// the value lane `src` holds (src the same on every lane), on every lane
+__device__ __forceinline__ float lc3_wave_read_f32(float v, int src, int lane) {
+    (void)lane;
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane(src)));
+}
 __device__ __forceinline__ unsigned long long lc3_wave_ballot(int pred, int lane) {
     (void)lane;
     return __ballot(pred);

@@ -57,6 +57,23 @@ static inline uint32_t lc3_wave_sum_u32(uint32_t v, int lane) {
     LC3_SYNC();
     return m;
 }
+static float g_xf[LC3_WG_WAVES][64];
+static inline float lc3_wave_shr1_f32(float v, int lane) {
+    LC3_SYNC();
+    g_xf[tl_wave][lane] = v;
+    LC3_SYNC();
+    const float r = lane > 0 ? g_xf[tl_wave][lane - 1] : v;
+    LC3_SYNC();
+    return r;
+}
+static inline float lc3_wave_read_f32(float v, int src, int lane) {
+    LC3_SYNC();
+    g_xf[tl_wave][lane] = v;
+    LC3_SYNC();
+    const float r = g_xf[tl_wave][src & 63];
+    LC3_SYNC();
+    return r;
+}
 static inline unsigned long long lc3_wave_ballot(int pred, int lane) {
     LC3_SYNC();
     g_xi[tl_wave][lane] = pred != 0;
