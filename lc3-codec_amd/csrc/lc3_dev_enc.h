@@ -674,7 +674,10 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int len12 = c.len12, len6 = c.len6, p = c.p_up;
     const int x12_len = len12 + c.delay12 + LC3_NMEM;
-    float *x12 = (float *)L.fa, *x6 = (float *)L.t;
+    // x12 starts 64 floats into fa: the float copy of the resampler's input window (hist + nf <= 540 floats) begins in
+    // spec -- dead once the mid column has left -- and runs over into fa's first 64 floats
+    float *x12 = (float *)L.fa + 64, *x6 = (float *)L.t;
+    float *W = (float *)L.spec;
     float *S = (float *)L.fb;
     float *r6 = S, *rw6 = S + 100, *r12 = S + 200, *dA = S + 224, *dB = S + 352;  // 98 | 98 | 17 | 128 | 128 floats
     int t_nbits = nbits;
@@ -704,33 +707,36 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
             const int i = lane + LC3_WAVE * j;
             if (i < keep12) x12[i] = v[j];
         }
+        // x_s_extended as f32, converted once (every sample is a tap operand of several outputs)
+        const int16_t *xs16 = L.t + (c.nf - c.z) - c.hist;
+        // (the zero-padded taps of a row may reach up to three samples past the window: those operands must be finite)
+        for (int i = lane; i < c.hist + c.nf + 4; i += LC3_WAVE) W[i] = i < c.hist + c.nf ? (float)xs16[i] : 0.0f;
         LC3_SYNC();
     }
     // resampling :152-166 -- one lane per 12.8 kHz output, taps accumulated in the reference's order (k ascending).
     // The low-pass is applied in polyphase form: the configuration's table (lc3_resamp_poly_value: one zero-padded
     // row of taps per phase) is staged in LDS, so a lane streams its row with 128-bit reads next to the samples.
-    // x_s_extended[i] == time buffer t[(nf - z) - hist + i]
+    // x_s_extended[i] == time buffer t[(nf - z) - hist + i] == W[i]
     {
         const int nt = c.resamp_nt, lim = c.resamp_lim;
-        const int16_t *xs = L.t + (c.nf - c.z) - c.hist;
         float *o12 = x12 + c.delay12 + LC3_NMEM;
         const int n0 = lane, has1 = lane + LC3_WAVE < len12;
         const int n1 = has1 ? lane + LC3_WAVE : lane;
         const int q0 = (15 * n0 * c.inv_p) >> 16, q1 = (15 * n1 * c.inv_p) >> 16;  // 15 n / p without integer divisions
-        const int16_t *xa = xs + c.hist + q0 - 2 * lim;  // tap j <-> k = j - lim
-        const int16_t *xb = xs + c.hist + q1 - 2 * lim;
+        const float *xa = W + c.hist + q0 - 2 * lim;  // tap j <-> k = j - lim
+        const float *xb = W + c.hist + q1 - 2 * lim;
         const float *ha = S + (15 * n0 - q0 * p) * c.resamp_stride, *hb = S + (15 * n1 - q1 * p) * c.resamp_stride;
         float acc0 = 0.0f, acc1 = 0.0f;
         for (int j = 0; j < nt; j += 4) {
             const lc3_f4 a = *(const lc3_f4 *)(ha + j), b = *(const lc3_f4 *)(hb + j);
-            acc0 += (float)xa[j] * a.x;
-            acc1 += (float)xb[j] * b.x;
-            acc0 += (float)xa[j + 1] * a.y;
-            acc1 += (float)xb[j + 1] * b.y;
-            acc0 += (float)xa[j + 2] * a.z;
-            acc1 += (float)xb[j + 2] * b.z;
-            acc0 += (float)xa[j + 3] * a.w;
-            acc1 += (float)xb[j + 3] * b.w;
+            acc0 += xa[j] * a.x;
+            acc1 += xb[j] * b.x;
+            acc0 += xa[j + 1] * a.y;
+            acc1 += xb[j + 1] * b.y;
+            acc0 += xa[j + 2] * a.z;
+            acc1 += xb[j + 2] * b.z;
+            acc0 += xa[j + 3] * a.w;
+            acc1 += xb[j + 3] * b.w;
         }
         LC3_SYNC();
         if (n0 < len12) o12[n0] = acc0 * c.resamp_scale;

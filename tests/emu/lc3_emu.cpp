@@ -228,7 +228,7 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
         // phase 1: front halves of every workgroup; then the lane-per-frame vector quantiser; phase 2: back halves
         for (int s0 = 0; s0 < S; s0 += LC3_WG_WAVES) {
             Job protos[LC3_WG_WAVES];
-            memset(L, 0, LC3_WG_WAVES * sizeof(lc3_enc_lds));
+            memset(L, 0xFF, LC3_WG_WAVES * sizeof(lc3_enc_lds));  // LDS is not zeroed on the GPU: NaN floats / -1 integers expose reads of stale words
             for (int w = 0; w < LC3_WG_WAVES; w++) {
                 // waves past the end of the batch shadow the last stream and store nothing (as in the kernels)
                 const int valid = s0 + w < S, s = valid ? s0 + w : S - 1;
@@ -331,7 +331,7 @@ int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8
     j.planes = planes.data();
     for (int s0 = 0; s0 < S; s0 += LC3_WG_WAVES) {
         Job protos[LC3_WG_WAVES];
-        memset(L, 0, LC3_WG_WAVES * sizeof(lc3_dec_lds));
+        memset(L, 0xFF, LC3_WG_WAVES * sizeof(lc3_dec_lds));  // (see lc3emu_encode)
         memset(st, 0, LC3_WG_WAVES * sizeof(lc3_dec_state));
         for (int w = 0; w < LC3_WG_WAVES; w++) {
             const int valid = s0 + w < S, s = valid ? s0 + w : S - 1;
