@@ -679,7 +679,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     float *x12 = (float *)L.fa + 64, *x6 = (float *)L.t;
     float *W = (float *)L.spec;
     float *S = (float *)L.fb;
-    float *r6 = S, *rw6 = S + 100, *r12 = S + 200, *dA = S + 224, *dB = S + 352;  // 98 | 98 | 17 | 128 | 128 floats
+    float *r6 = S, *rw6 = S + 100, *r12 = S + 200;  // 98 | 98 | 17 floats (the activation stage reuses S for 3 x 128 products)
     int t_nbits = nbits;
     if (!c.n_ms_10) {
         double v = (double)nbits * 10.0 / 7.5;  // .round(): half away from zero (:143)
@@ -828,7 +828,14 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         L.ism[1] = idx + k_from + LC3_KMIN;
     }
     LC3_SYNC();
-    // compute_normalized_value :445-455 for lag 0, lag_t1, lag_t2 -- three lanes
+    // compute_normalized_value :445-455 for lag 0, lag_t1, lag_t2: the squares once, one sample per lane, then three lanes
+    // add 64 of them each in the reference's order
+    float *sq = S + 224;  // 178 floats
+    for (int n = lane; n < LC3_KMAX + len6; n += LC3_WAVE) {
+        const float v = x6[n];
+        sq[n] = v * v;
+    }
+    LC3_SYNC();
     if (lane < 3) {
         const int lag = lane == 0 ? 0 : L.ism[lane - 1];
         const int from = LC3_KMAX - lag;
@@ -837,9 +844,9 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         for (int n = from; n < from + len6; n += 8) {
             float a[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) a[u] = x6[n + u];
+            for (int u = 0; u < 8; u++) a[u] = sq[n + u];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v += a[u] * a[u];
+            for (int u = 0; u < 8; u++) v += a[u];
         }
         L.sm[lane] = v;
     }
@@ -934,26 +941,28 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     // activation_bit :365-409 -- interpolated signals in parallel, the three 128-term sums on three lanes
     {
         const int pitch_int = L.ism[4], pitch_fr = L.ism[5];
+        // the products of the three sums are formed here, one sample per lane (a product is the same f32 operation wherever
+        // it runs); the three lanes below only add them up in the reference's order
         for (int n = lane; n < len12; n += LC3_WAVE) {
-            dA[n] = lc3_ltpf_dot(x12, n, 0);
-            dB[n] = lc3_ltpf_dot(x12, n - pitch_int, pitch_fr);
+            const float a = lc3_ltpf_dot(x12, n, 0);
+            const float b = lc3_ltpf_dot(x12, n - pitch_int, pitch_fr);
+            S[n] = a * b;
+            S[128 + n] = a * a;
+            S[256 + n] = b * b;
         }
     }
     LC3_SYNC();
     if (lane < 3) {
         // lane 0: sum dA*dB, lane 1: sum dA*dA, lane 2: sum dB*dB
-        const float *pa = lane == 2 ? dB : dA, *pb = lane == 1 ? dA : dB;
+        const float *pp = S + 128 * lane;
         float acc = 0.0f;
         #pragma unroll 1
         for (int n = 0; n < len12; n += 8) {
-            float a[8], b[8];
+            float a[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                a[u] = pa[n + u];
-                b[u] = pb[n + u];
-            }
+            for (int u = 0; u < 8; u++) a[u] = pp[n + u];
 #pragma unroll
-            for (int u = 0; u < 8; u++) acc += a[u] * b[u];
+            for (int u = 0; u < 8; u++) acc += a[u];
         }
         L.sm[lane] = acc;
     }
