@@ -299,7 +299,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, LC3_L
     const int block_len = c.nf / num_ds;
     const int16_t *x_s = L.t + (c.nf - c.z);  // the current frame inside the time buffer
     int *ds = (int *)L.fa;                    // 160 ints
-    float *hp = (float *)L.fa + 160;          // 160 floats (the band energies sit at fa + 512: LC3_EB)
+    float *hp = (float *)L.fa + 160;          // 160 floats: the high-passed samples squared (the band energies sit at fa + 512: LC3_EB)
     float *en = L.sm;                         // 4 block energies
     for (int n = lane; n < num_ds; n += LC3_WAVE) {
         int acc = 0;
@@ -311,11 +311,12 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, LC3_L
         float x0 = (float)ds[n];
         float x1 = n >= 1 ? (float)ds[n - 1] : (float)L.st.att_ds_tm1;
         float x2 = n >= 2 ? (float)ds[n - 2] : (n == 1 ? (float)L.st.att_ds_tm1 : (float)L.st.att_ds_tm2);
-        hp[n] = 0.375f * x0 - 0.5f * x1 + 0.125f * x2;
+        const float v = 0.375f * x0 - 0.5f * x1 + 0.125f * x2;
+        hp[n] = v * v;  // only the squares are needed; the block lanes below just add them
     }
     LC3_SYNC();
     if (lane < num_blocks) {  // block energies, 40 terms each in order
-        en[lane] = lc3_dot_seq(hp + 40 * lane, hp + 40 * lane, 40, 0.0f);
+        en[lane] = lc3_sum_seq(hp + 40 * lane, 40, 0.0f);
     }
     LC3_SYNC();
     if (lane == 0) {
