@@ -489,20 +489,23 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
         sES[q] = es;
     }
     LC3_SYNC();
+    // the 54 quotients ac_s(k) / e_s (:97-104) on the lanes that hold the partial sums: the Levinson lanes below only add
+    // three of them per lag (0 + q0 + q1 + q2 in the reference's order)
+    if (lane < 54) {
+        const int f = lane / 27, r = lane - 27 * f, s3 = r - 3 * (r / 3);
+        sAC[lane] = sAC[lane] / sES[f * 3 + s3];
+    }
+    LC3_SYNC();
     // Levinson-Durbin :204-232 and the LPC -> reflection conversion :234-265: one lane per filter, the order-8
     // recursions fully unrolled on register arrays.
     if (lane < 2 && lane < tp.num) {
         const int f = lane;
         float r[9];
+        const float e_prod = (1.0f * sES[f * 3] * sES[f * 3 + 1]) * sES[f * 3 + 2];
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            float r0 = k == 0 ? 3.0f : 0.0f, rk = 0.0f, e_prod = 1.0f;
-#pragma unroll
-            for (int s = 0; s < 3; s++) {
-                float es = sES[f * 3 + s];
-                e_prod *= es;
-                rk += sAC[f * 27 + k * 3 + s] / es;
-            }
+            const float r0 = k == 0 ? 3.0f : 0.0f;
+            const float rk = ((0.0f + sAC[f * 27 + k * 3]) + sAC[f * 27 + k * 3 + 1]) + sAC[f * 27 + k * 3 + 2];
             r[k] = (e_prod == 0.0f ? r0 : rk) * LC3C_TNS_LAGW[k];
         }
         float a[9], al[9];
