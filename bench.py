@@ -286,7 +286,7 @@ def main():
                 "roundtrip_achieved_GBs": value * (ALG_BYTES_ENC + ALG_BYTES_DEC) / 1e9 / world,
                 "note": "instruction/latency-bound, not HBM-bound (SURVEY 8d honesty note): ~60 flop per algorithmic byte; "
                         "traffic = FETCH_SIZE + WRITE_SIZE of this kernel from profiles/hbm_traffic_latest.json (bytes per "
-                        "launch); instruction mix and wait counters in profiles/r01_v19_pmc_summary.csv, DESIGN.md section 5",
+                        "launch); instruction mix and wait counters in profiles/r01_v20_pmc_summary.csv, DESIGN.md section 5",
             },
             "cpu_baseline": cpu,
             "overlapped": overlapped,
