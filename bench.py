@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- LC3 frames/sec (encode+decode) @ 48 kHz / 10 ms on 1..8 MI355X (BASELINE.json metric).
+"""bench.py -- LC3 frames/sec @ 48 kHz / 10 ms on 1..8 MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch of synthetic PCM already resident in HBM:
-encode S streams x T frames (150-byte frames) and decode the bitstream that was just produced,
-S*T = 65 536 frames per GPU (BASELINE.json configs[1]).  Stream state carries from step to step
-(streaming operation).  With --gpus N each rank owns its own S streams (weak scaling: frames are
-independent across streams, no data-path collective); torch.distributed (RCCL) is used only for the
-barrier and the final max-time / frame-count reduction.
+One "step" = one pass of the hot path over one batch of synthetic PCM already resident in HBM.
 
-Prints ONE JSON line on rank 0 (see README/DESIGN.md section "Measurement").
-PyTorch is used for device memory, the HIP stream, events and torch.distributed only; the codec is
-liblc3gpu.so (hand-written HIP) called through its C ABI.
+  --mode roundtrip (default, BASELINE configs[1]): encode S streams x T frames (150-byte frames) and decode the
+      bitstream that was just produced; S*T = 65 536 frames per GPU, stream state carried from step to step.
+      With --gpus N every rank owns its own S streams ("scaling": "weak").
+  --mode encode --frames-total 1048576 (BASELINE configs[2]): encode-only; the batch's streams are sharded
+      contiguously over the ranks (lc3-codec_amd/dist.py::shard_range), "scaling": "strong".
+
+Multi-GPU: `python bench.py --gpus N` starts N ranks itself (one process per GPU: RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set per child, rendezvous on 127.0.0.1) BEFORE anything touches the GPU -- the parent never imports torch,
+relays rank 0's JSON line and exits non-zero if a rank fails.  Launched under torch.distributed.run (WORLD_SIZE
+already set) it is simply one rank.  Frames are independent across streams: there is no data-path collective;
+torch.distributed (RCCL) carries the barrier and one all_reduce of {max elapsed, frames, parity mismatches}.
+
+Prints ONE JSON line on rank 0 (DESIGN.md section "Measurement").  PyTorch is used for device memory, the HIP
+stream, events and torch.distributed only; the codec is liblc3gpu.so (hand-written HIP) called through its C ABI.
+`--engine emu` (tests only) swaps the GPU engine for the CPU wave emulator of the device code and RCCL for gloo, so
+that the launcher and the sharding / reduction path run in a GPU-less container (tests/test_dist_gloo.py).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,172 +37,224 @@ FS, US, NBYTES, NF = 48000, 10000, 150, 480
 ALG_BYTES_ENC = 2 * NF + NBYTES   # i16 PCM read + frame bytes written   
 ALG_BYTES_DEC = NBYTES + 2 * NF   # frame bytes read + i16 PCM written
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CLOCK_MHZ = 2400.0                # max shader clock (MI355X_MICROARCH.md, chip-level parameters)
+N_SIMD = 1024                     # 256 CUs x 4 SIMDs
 
 
-def cpu_baseline(pcm_sample, budget_s=12.0):
-    """Time the CPU oracle (a C port of the reference; the reference itself is Rust and cannot be built on the box)
-    on a bounded sample of the same workload, one oracle channel per stream, spread over every host core."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-
-    cores = os.cpu_count() or 1
-    S, T, _ = pcm_sample.shape
-    n_streams = min(S, max(4 * cores, 1024))
-    sample = pcm_sample[:n_streams]
-    done, t0 = 0, time.perf_counter()
-    while True:  # repeat the sample until ~budget_s of wall time has been spent
-        b = O.encode_batch(sample, NBYTES, FS, US, threads=cores)
-        O.decode_batch(b, NF, FS, US, threads=cores)
-        done += n_streams * T
-        dt = time.perf_counter() - t0
-        if dt >= budget_s:
-            break
-    return {
-        "value": done / dt,
-        "unit": "frames/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"{done} frames ({n_streams} streams x {T} frames, repeated) of the bench workload, encode+decode, "
-                  f"{cores} host threads, {dt:.1f} s",
-    }
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=16384, help="streams per GPU")
-    ap.add_argument("--frames", type=int, default=4, help="consecutive frames per stream per step")
+    ap.add_argument("--mode", choices=("roundtrip", "encode"), default="roundtrip")
+    ap.add_argument("--streams", type=int, default=None, help="streams per GPU (roundtrip; default 16384)")
+    ap.add_argument("--frames", type=int, default=None, help="consecutive frames per stream per step (default 4; 16 in encode mode)")
+    ap.add_argument("--frames-total", type=int, default=None,
+                    help="encode mode: frames per step over ALL ranks (default 1048576 = BASELINE configs[2])")
     ap.add_argument("--hip-streams", type=int, default=1,
-                    help="split the rank's streams over this many codec handle pairs, each on its own HIP stream, so that "
-                         "the low-occupancy lane-per-frame kernels of one part overlap the wave kernels of another "
+                    help="split the rank's streams over this many codec handle pairs, each on its own HIP stream "
                          "(default 1: one stream, clean per-kernel timing)")
-    ap.add_argument("--no-overlap-probe", action="store_true",
-                    help="skip the extra, untimed-for-`value` leg that repeats the steps with the batch split over four handle "
-                         "pairs on four HIP streams (reported as `overlapped`)")
+    ap.add_argument("--overlap-probe", action="store_true",
+                    help="add an informational leg that repeats the steps with the batch split over four handle pairs on four "
+                         "HIP streams (reported as `overlapped`, never `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--engine", choices=("gpu", "emu"), default="gpu", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
-    import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: N ranks as child processes, started before any GPU call
+# ---------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+def launch_ranks(n, argv):
+    """Start n ranks of this script (one per GPU), relay rank 0's JSON line; -> process exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LC3_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120.0
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()  # exactly the child we started
+            p.wait()
+        rc = rc or p.returncode
+    line = None
+    for ln in out.decode(errors="replace").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line is None:
+        rc = rc or 1
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
     else:
-        dist = None
-        torch.cuda.set_device(0)
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (the engine has no CPU path)"
+        print(line, flush=True)
+    return int(rc != 0)
 
-    pkg = importlib.import_module("lc3-codec_amd")
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle, test infrastructure): 1 thread and all host cores, persistent codec objects
+# ---------------------------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(mode, budget_1t=6.0, budget_all=12.0):
+    """Time the CPU oracle (a C port of the reference; the reference itself is Rust and cannot be built on the box) on a
+    bounded sample of the bench workload: every stream keeps ONE encoder / decoder object for all its frames (init
+    amortised over 512 frames), one stream per thread at a time.  Two legs: 1 thread, and every host core."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
     synth = importlib.import_module("lc3-codec_amd.synth")
-    S, T = args.streams, args.frames
-    frames_per_step = S * T
+    cores = os.cpu_count() or 1
+    T = 512
+    base = synth.make_pcm(64, 8, NF, FS)                 # 64 distinct streams of the bench generator ...
+    pcm64 = np.tile(base, (1, T // 8, 1))                # ... 512 consecutive frames each
 
-    # synthetic input: 1024 distinct streams per rank, tiled to S (generation is host-side numpy)
-    n_distinct = min(S, 1024)
-    base = synth.make_pcm(n_distinct, T, NF, FS, first_stream=rank * S)
-    pcm_host = np.tile(base, ((S + n_distinct - 1) // n_distinct, 1, 1))[:S]
-    d_pcm = torch.from_numpy(pcm_host).cuda()
-    d_bytes = torch.zeros((S, T, NBYTES), dtype=torch.uint8, device="cuda")
-    d_out = torch.zeros((S, T, NF), dtype=torch.int16, device="cuda")
-    # one encoder/decoder handle pair per HIP stream (handles are independent; a handle's launches are ordered)
-    NP = max(1, args.hip_streams)
-    assert S % NP == 0, "--streams must be a multiple of --hip-streams"
-    SP = S // NP
-    encs = [pkg.Lc3Encoder(SP, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(NP)]
-    decs = [pkg.Lc3Decoder(SP, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(NP)]
-    hip_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(NP - 1)]
-    enc, dec = encs[0], decs[0]
+    def leg(threads, budget):
+        S = max(threads, 2) if threads > 1 else 2
+        sample = np.ascontiguousarray(np.tile(pcm64, ((S + 63) // 64, 1, 1))[:S])
+        done, t0 = 0, time.perf_counter()
+        while True:
+            b = O.encode_batch(sample, NBYTES, FS, US, threads=threads)
+            if mode == "roundtrip":
+                O.decode_batch(b, NF, FS, US, threads=threads)
+            done += S * T
+            dt = time.perf_counter() - t0
+            if dt >= budget:
+                return done / dt, done, dt, S
 
-    def step():
-        for p in range(NP):
-            st = hip_streams[p].cuda_stream
-            lo, hi = p * SP, (p + 1) * SP
-            encs[p].encode(d_pcm[lo:hi], d_bytes[lo:hi], NBYTES, T, stream=st)
-            decs[p].decode(d_bytes[lo:hi], d_out[lo:hi], NBYTES, T, stream=st)
-
-    # parity gate on the first step (fresh state): GPU bitstream / PCM vs the CPU oracle on a sample
-    parity = None
-    cpu = None
-    if rank == 0 and not args.no_parity:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
-
-        step()
-        torch.cuda.synchronize()
-        k = min(n_distinct, 256)
-        ref_b = O.encode_batch(pcm_host[:k], NBYTES, FS, US, threads=os.cpu_count() or 1)
-        ref_p = O.decode_batch(ref_b, NF, FS, US, threads=os.cpu_count() or 1)
-        got_b = d_bytes[:k].cpu().numpy()
-        got_p = d_out[:k].cpu().numpy()
-        parity = {
-            "frames_checked": int(k * T),
-            "bitstream_exact": bool(np.array_equal(got_b, ref_b)),
-            "pcm_max_abs_diff": int(np.abs(got_p.astype(np.int32) - ref_p.astype(np.int32)).max()),
-        }
-        for h in encs + decs:
-            h.reset()
-    elif not args.no_parity:
-        step()
-        torch.cuda.synchronize()
-        for h in encs + decs:
-            h.reset()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-
-    # timed region: exactly K steps; per-kernel durations from events on the launch stream
-    # the C ABI records HIP events around each of its kernels on the launch stream
-    for h in encs + decs:
-        h.timing(True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-
-    ef = ev = eb = ep = en = dp = ds = dn = 0.0
-    for h in encs:
-        a, v, b, p_, n = h.timing(False)
-        ef, ev, eb, ep, en = ef + a, ev + v, eb + b, ep + p_, en + n
-    for h in decs:
-        a, b, n = h.timing(False)
-        dp, ds, dn = dp + a, ds + b, dn + n
-    # launches per step = NP per kernel; scale to "per step" so that the numbers stay comparable across --hip-streams
-    en, dn = en / NP, dn / NP
-    kernel_ms = {
-        "lc3_enc_front_kernel": ef / max(en, 1),  # analysis front half, wave per stream
-        "lc3_sns_vq_kernel": ev / max(en, 1),     # SNS vector quantiser, lane per frame
-        "lc3_enc_back_kernel": eb / max(en, 1),   # analysis back half, wave per stream
-        "lc3_pack_kernel": ep / max(en, 1),       # bitstream packing, lane per frame
-        "lc3_parse_kernel": dp / max(dn, 1),      # frame parsing + spectrum reconstruction, lane per frame
-        "lc3_decode_kernel": ds / max(dn, 1),     # synthesis, wave per stream
+    v1, n1, d1, s1 = leg(1, budget_1t)
+    va, na, da, sa = leg(cores, budget_all)
+    what = "encode+decode" if mode == "roundtrip" else "encode"
+    return {
+        "value": va, "unit": "frames/s", "cores": cores, "kind": "port",
+        "threads_1": {"value": v1, "unit": "frames/s", "cores": 1,
+                      "sample": f"{n1} frames ({s1} streams x {T} consecutive frames, repeated), {what}, {d1:.1f} s"},
+        "nproc": cores, "cpu_model": _cpu_model(),
+        "sample": f"{na} frames ({sa} streams x {T} consecutive frames per pass, one persistent codec object per stream, "
+                  f"repeated) of the bench generator's PCM, {what}, {cores} host threads, {da:.1f} s",
     }
 
-    # max time over ranks, frames summed over ranks (the only collective of the job)
-    D = importlib.import_module("lc3-codec_amd.dist")
-    elapsed, total_frames, _, _ = D.reduce_report(dist, "cuda", elapsed, frames_per_step * args.steps)
 
-    # Informational leg, outside the timed region and not part of `value`: the same batch split over four handle pairs, each
-    # on its own HIP stream, so that one pair's lane-per-frame kernels (one wave per SIMD) run under another pair's
-    # wave-per-stream kernels.  What a caller who pipelines independent batches gets; per-kernel event timings are not taken
-    # here (under overlap every launch's duration includes the others').
-    overlapped = None
-    if world == 1 and NP == 1 and not args.no_overlap_probe and S % 4 == 0:
+# ---------------------------------------------------------------------------------------------------------------
+# committed PMC summary (rocprofv3 cannot run inside this process): only trusted for the kernel sources it measured
+# ---------------------------------------------------------------------------------------------------------------
+def kernel_source_sha():
+    """sha256 over the device code (csrc/*, tables): stamps profiles/pmc_latest.json (tools/pmc_json.py)"""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "lc3-codec_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip"))) + [os.path.join(ROOT, "tables", "lc3_tables.h")]
+    for p in files:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def load_pmc():
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            pj = json.load(f)
+    except (OSError, ValueError):
+        return None, "profiles/pmc_latest.json missing"
+    if pj.get("kernel_source_sha256") != kernel_source_sha():
+        return None, "profiles/pmc_latest.json was measured on other kernel sources (sha mismatch): counters withheld"
+    return pj, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# engines
+# ---------------------------------------------------------------------------------------------------------------
+class GpuEngine:
+    """liblc3gpu.so through its C ABI; torch owns device memory and the HIP streams"""
+
+    def __init__(self, args, pcm_host, S, T, mode, local_rank):
+        import torch
+
+        self.torch = torch
+        torch.cuda.set_device(local_rank)
+        assert torch.cuda.is_available(), "bench.py needs a HIP device (the engine has no CPU path)"
+        pkg = importlib.import_module("lc3-codec_amd")
+        self.pkg, self.S, self.T, self.mode = pkg, S, T, mode
+        self.d_pcm = torch.from_numpy(pcm_host).cuda()
+        self.d_bytes = torch.zeros((S, T, NBYTES), dtype=torch.uint8, device="cuda")
+        self.d_out = torch.zeros((S, T, NF), dtype=torch.int16, device="cuda") if mode == "roundtrip" else None
+        NP = max(1, args.hip_streams)
+        assert S % NP == 0, "--streams must be a multiple of --hip-streams"
+        self.NP, self.SP = NP, S // NP
+        mk = lambda cls: [cls(self.SP, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(NP)]
+        self.encs = mk(pkg.Lc3Encoder)
+        self.decs = mk(pkg.Lc3Decoder) if mode == "roundtrip" else []
+        self.hs = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(NP - 1)]
+
+    device = "cuda"
+
+    def step(self):
+        for p in range(self.NP):
+            st = self.hs[p].cuda_stream
+            lo, hi = p * self.SP, (p + 1) * self.SP
+            self.encs[p].encode(self.d_pcm[lo:hi], self.d_bytes[lo:hi], NBYTES, self.T, stream=st)
+            if self.decs:
+                self.decs[p].decode(self.d_bytes[lo:hi], self.d_out[lo:hi], NBYTES, self.T, stream=st)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def reset(self):
+        for h in self.encs + self.decs:
+            h.reset()
+
+    def results(self, k):
+        return (self.d_bytes[:k].cpu().numpy(), self.d_out[:k].cpu().numpy() if self.d_out is not None else None)
+
+    def timing_start(self):
+        for h in self.encs + self.decs:
+            h.timing(True)
+
+    def timing_stop(self):
+        ef = ev = eb = ep = en = dp = ds = dn = 0.0
+        for h in self.encs:
+            a, v, b, p_, n = h.timing(False)
+            ef, ev, eb, ep, en = ef + a, ev + v, eb + b, ep + p_, en + n
+        for h in self.decs:
+            a, b, n = h.timing(False)
+            dp, ds, dn = dp + a, ds + b, dn + n
+        en, dn = en / self.NP, dn / self.NP  # launches per step = NP per kernel: scale to "per step"
+        km = {"lc3_enc_front_kernel": ef / max(en, 1), "lc3_sns_vq_kernel": ev / max(en, 1),
+              "lc3_enc_back_kernel": eb / max(en, 1), "lc3_pack_kernel": ep / max(en, 1)}
+        if self.decs:
+            km.update({"lc3_parse_kernel": dp / max(dn, 1), "lc3_decode_kernel": ds / max(dn, 1)})
+        return km
+
+    def overlap_probe(self, steps, warmup):
+        torch, pkg, S, T = self.torch, self.pkg, self.S, self.T
+        if self.NP != 1 or S % 4 or self.mode != "roundtrip":
+            return None
         Q, SQ = 4, S // 4
         qe = [pkg.Lc3Encoder(SQ, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(Q)]
         qd = [pkg.Lc3Decoder(SQ, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(Q)]
@@ -202,99 +263,230 @@ def main():
         def qstep():
             for p in range(Q):
                 lo, hi = p * SQ, (p + 1) * SQ
-                qe[p].encode(d_pcm[lo:hi], d_bytes[lo:hi], NBYTES, T, stream=qs[p].cuda_stream)
-                qd[p].decode(d_bytes[lo:hi], d_out[lo:hi], NBYTES, T, stream=qs[p].cuda_stream)
+                qe[p].encode(self.d_pcm[lo:hi], self.d_bytes[lo:hi], NBYTES, T, stream=qs[p].cuda_stream)
+                qd[p].decode(self.d_bytes[lo:hi], self.d_out[lo:hi], NBYTES, T, stream=qs[p].cuda_stream)
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             qstep()
         torch.cuda.synchronize()
         q0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             qstep()
         torch.cuda.synchronize()
         qel = time.perf_counter() - q0
-        overlapped = {"hip_streams": Q, "value": frames_per_step * args.steps / qel, "unit": "frames/s",
-                      "ms_per_step": qel / args.steps * 1e3,
-                      "note": "same batch as four independent quarter batches on four HIP streams; informational, not `value`"}
-        del qe, qd
+        return {"hip_streams": Q, "value": S * T * steps / qel, "unit": "frames/s", "ms_per_step": qel / steps * 1e3,
+                "note": "same batch as four independent quarter batches on four HIP streams; informational, not `value`"}
+
+
+class EmuEngine:
+    """tests only: the device headers under the CPU wave emulator (tests/emu), host arrays, fresh state every step"""
+
+    device = "cpu"
+
+    def __init__(self, args, pcm_host, S, T, mode, local_rank):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import emu_lib
+
+        self.E, self.pcm, self.mode = emu_lib, pcm_host, mode
+        self.bytes = self.out = None
+
+    def step(self):
+        self.bytes = self.E.encode(self.pcm, NBYTES)
+        if self.mode == "roundtrip":
+            self.out = self.E.decode(self.bytes, NF)
+
+    def sync(self):
+        pass
+
+    def reset(self):
+        pass
+
+    def results(self, k):
+        return self.bytes[:k], (self.out[:k] if self.out is not None else None)
+
+    def timing_start(self):
+        pass
+
+    def timing_stop(self):
+        return None
+
+    def overlap_probe(self, steps, warmup):
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def run_rank(args):
+    import numpy as np
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    emu = args.engine == "emu"
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        if emu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    synth = importlib.import_module("lc3-codec_amd.synth")
+    D = importlib.import_module("lc3-codec_amd.dist")
+    mode = args.mode
+    if mode == "roundtrip":
+        S = args.streams if args.streams is not None else (4 if emu else 16384)
+        T = args.frames if args.frames is not None else (2 if emu else 4)
+        first_stream, total_streams, scaling = rank * S, S * world, "weak"
+    else:
+        T = args.frames if args.frames is not None else (2 if emu else 16)
+        total = args.frames_total if args.frames_total is not None else (16 if emu else 1048576)
+        assert total % T == 0, "--frames-total must be a multiple of --frames"
+        total_streams = total // T
+        lo, hi = D.shard_range(total_streams, world, rank)
+        S, first_stream, scaling = hi - lo, lo, "strong"
+    frames_per_step = S * T
+
+    # synthetic input: up to 1024 distinct streams per rank (the generator is host-side numpy), tiled to S streams
+    n_distinct = min(S, 1024)
+    base = synth.make_pcm(n_distinct, T, NF, FS, first_stream=first_stream)
+    pcm_host = np.ascontiguousarray(np.tile(base, ((S + n_distinct - 1) // n_distinct, 1, 1))[:S])
+    eng = (EmuEngine if emu else GpuEngine)(args, pcm_host, S, T, mode, local_rank)
+
+    # parity gate on the first step (fresh state): engine bitstream / PCM vs the CPU oracle on a sample, every rank
+    parity, mismatches = None, 0
+    if not args.no_parity:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+
+        eng.step()
+        eng.sync()
+        k = min(n_distinct, 256 if rank == 0 else 32)
+        thr = os.cpu_count() or 1
+        ref_b = O.encode_batch(pcm_host[:k], NBYTES, FS, US, threads=thr)
+        got_b, got_p = eng.results(k)
+        bad_b = int((got_b != ref_b).any(axis=2).sum())
+        parity = {"frames_checked": int(k * T), "bitstream_exact": bad_b == 0}
+        mismatches = bad_b
+        if mode == "roundtrip":
+            ref_p = O.decode_batch(ref_b, NF, FS, US, threads=thr)
+            diff = np.abs(got_p.astype(np.int32) - ref_p.astype(np.int32))
+            parity["pcm_max_abs_diff"] = int(diff.max())
+            mismatches += int((diff.max(axis=2) > 1).sum())
+        eng.reset()
+
+    for _ in range(args.warmup):
+        eng.step()
+    eng.sync()
+    if dist is not None:
+        dist.barrier()
+    eng.sync()
+
+    # timed region: exactly K steps; per-kernel durations from HIP events the C ABI records on the launch stream
+    eng.timing_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    eng.sync()
+    if dist is not None:
+        dist.barrier()
+    eng.sync()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = eng.timing_stop()
+
+    # max time over ranks, counters summed over ranks (the only collective of the job)
+    elapsed, total_frames, total_mismatches, _ = D.reduce_report(dist, eng.device, elapsed, frames_per_step * args.steps,
+                                                                  mismatches=mismatches)
+    overlapped = eng.overlap_probe(args.steps, args.warmup) if (args.overlap_probe and world == 1) else None
 
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(pcm_host)
-        # roofline of the dominant kernel of a step.  Algorithmic bytes per frame: the analysis kernel
-        # reads 2*nf of PCM, the packer writes nbytes, the parser reads nbytes, the synthesis kernel writes 2*nf.
-        # front half reads 2*nf of PCM, the packer writes nbytes, the parser reads nbytes, the synthesis kernel writes 2*nf;
-        # the vector quantiser and the back half touch no algorithmic bytes (their traffic is the planes between kernels)
-        alg_bytes = {"lc3_enc_front_kernel": 2 * NF, "lc3_sns_vq_kernel": 0, "lc3_enc_back_kernel": 0, "lc3_pack_kernel": NBYTES,
-                     "lc3_parse_kernel": NBYTES, "lc3_decode_kernel": 2 * NF}
-        # The analysis of a frame is three kernels since the SNS vector quantiser moved to its own lane-per-frame stage
-        # (front half, quantiser, back half): they are reported as ONE unit for the roofline, with the frame's PCM as its
-        # algorithmic bytes -- otherwise the longest single kernel (the back half) would have no algorithmic bytes at all.
-        groups = {"analysis (lc3_enc_front_kernel + lc3_sns_vq_kernel + lc3_enc_back_kernel)":
-                  ["lc3_enc_front_kernel", "lc3_sns_vq_kernel", "lc3_enc_back_kernel"],
-                  "lc3_pack_kernel": ["lc3_pack_kernel"], "lc3_parse_kernel": ["lc3_parse_kernel"],
-                  "lc3_decode_kernel": ["lc3_decode_kernel"]}
-        group_ms = {g: sum(kernel_ms[k] for k in ks) for g, ks in groups.items()}
-        dom = max(group_ms, key=group_ms.get)
-        dom_ms, alg = group_ms[dom], sum(alg_bytes[k] for k in groups[dom])
+        cpu = None
+        if not args.no_cpu_baseline and world == 1 and not emu:
+            cpu = cpu_baseline(mode)
         value = total_frames / elapsed
-        achieved = frames_per_step * alg / (dom_ms * 1e-3) / 1e9
-        # HBM bytes per launch of the dominant unit from the committed PMC passes (rocprofv3 cannot run inside this
-        # process); scaled to this run's frames per launch
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")) as f:
-                tj = json.load(f)
-            traffic = sum(tj["kernels"][k]["fetch_size_kb_per_launch"] + tj["kernels"][k]["write_size_kb_per_launch"]
-                          for k in groups[dom]) * 1024.0 * frames_per_step / tj["frames_per_launch"]
-        except (OSError, KeyError, ValueError):
-            traffic = None
-        line = {
-            "metric": "LC3 frames/sec (encode+decode) @48kHz/10ms",
-            "value": value,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "65536-frame batch mono 48 kHz / 10 ms / 150-byte frames, encode+decode (BASELINE configs[1])",
-                "streams_per_gpu": S,
-                "frames_per_stream_per_step": T,
-                "frames_per_step_per_gpu": frames_per_step,
-                "nbytes": NBYTES,
-                "state": "carried across steps (streaming)",
-                "parallelism": f"streams sharded over {world} GPU(s), no data-path collective",
-                "hip_streams": NP,
-            },
-            "kernel_ms": kernel_ms,
-            "roofline": {
-                "bound": "hbm",
-                "kernel": dom,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+        roof = None
+        if kernel_ms:
+            # Algorithmic bytes per frame (SURVEY 8d): the front half reads 2*nf of PCM, the packer writes nbytes, the
+            # parser reads nbytes, the synthesis kernel writes 2*nf; the vector quantiser and the back half touch no
+            # algorithmic bytes (their traffic is the planes between kernels).  The analysis of a frame is three kernels
+            # (front half, quantiser, back half): ONE unit for the roofline, with the frame's PCM as its algorithmic bytes.
+            alg_bytes = {"lc3_enc_front_kernel": 2 * NF, "lc3_sns_vq_kernel": 0, "lc3_enc_back_kernel": 0,
+                         "lc3_pack_kernel": NBYTES, "lc3_parse_kernel": NBYTES, "lc3_decode_kernel": 2 * NF}
+            groups = {"analysis (lc3_enc_front_kernel + lc3_sns_vq_kernel + lc3_enc_back_kernel)":
+                      ["lc3_enc_front_kernel", "lc3_sns_vq_kernel", "lc3_enc_back_kernel"]}
+            for k in kernel_ms:
+                if k not in groups[next(iter(groups))]:
+                    groups[k] = [k]
+            group_ms = {g: sum(kernel_ms[k] for k in ks) for g, ks in groups.items()}
+            dom = max(group_ms, key=group_ms.get)
+            dom_ms, alg = group_ms[dom], sum(alg_bytes[k] for k in groups[dom])
+            achieved = frames_per_step * alg / (dom_ms * 1e-3) / 1e9
+            # counters of the committed PMC passes, scaled to this run's frames per launch; withheld (null) unless the file
+            # was measured on exactly these kernel sources
+            pj, pmc_note = load_pmc()
+            traffic = valu_issue = valu_pipe = lane_frac = None
+            if pj is not None:
+                scale = frames_per_step / pj["frames_per_launch"]
+                kk = pj["kernels"]
+                traffic = sum(kk[k]["fetch_size_kb"] + kk[k]["write_size_kb"] for k in groups[dom]) * 1024.0 * scale
+                insts = sum(kk[k]["sq_insts_valu"] for k in kernel_ms) * scale
+                thread_cyc = sum(kk[k]["sq_thread_cycles_valu"] for k in kernel_ms) * scale
+                cycles = sum(kernel_ms.values()) * 1e-3 * CLOCK_MHZ * 1e6
+                valu_issue = insts * 4.0 / (N_SIMD * cycles)   # one wave's issue cost: 4 cycles per VALU instruction
+                valu_pipe = insts * 2.0 / (N_SIMD * cycles)    # SIMD-32 pipe: 2 cycles per wave64 VALU instruction
+                lane_frac = thread_cyc / (insts * 64.0)
+                pmc_note = pj.get("source")
+            roof = {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_frame": alg,
-                "roundtrip_algorithmic_bytes_per_frame": ALG_BYTES_ENC + ALG_BYTES_DEC,
-                "roundtrip_achieved_GBs": value * (ALG_BYTES_ENC + ALG_BYTES_DEC) / 1e9 / world,
-                "note": "instruction/latency-bound, not HBM-bound (SURVEY 8d honesty note): ~60 flop per algorithmic byte; "
-                        "traffic = FETCH_SIZE + WRITE_SIZE of this kernel from profiles/hbm_traffic_latest.json (bytes per "
-                        "launch); instruction mix and wait counters in profiles/r01_v20_pmc_summary.csv, DESIGN.md section 5",
+                "roundtrip_algorithmic_bytes_per_frame": ALG_BYTES_ENC + (ALG_BYTES_DEC if mode == "roundtrip" else 0),
+                "roundtrip_achieved_GBs": value * (ALG_BYTES_ENC + (ALG_BYTES_DEC if mode == "roundtrip" else 0)) / 1e9 / world,
+                "valu_issue_frac": valu_issue, "valu_pipe_frac": valu_pipe, "active_lane_frac": lane_frac,
+                "pmc": pmc_note,
+                "note": "instruction/latency-bound, not HBM-bound (SURVEY 8d honesty note): ~60 flop per algorithmic byte. "
+                        "traffic = FETCH_SIZE + WRITE_SIZE of the dominant unit per launch; valu_issue_frac = sum SQ_INSTS_VALU x 4 / "
+                        "(1024 SIMDs x cycles of the step's kernels at 2.4 GHz), valu_pipe_frac the same at the SIMD-32 rate of 2 "
+                        "cycles per instruction; active_lane_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU); all from the "
+                        "committed rocprofv3 PMC passes (profiles/pmc_latest.json), null when they were taken on other sources",
+            }
+        if mode == "roundtrip":
+            workload = (f"{frames_per_step}-frame batch mono 48 kHz / 10 ms / 150-byte frames, encode+decode (BASELINE configs[1]); "
+                        f"{n_distinct} distinct synthetic streams tiled to {S}")
+            metric = "LC3 frames/sec (encode+decode) @48kHz/10ms"
+        else:
+            workload = (f"{total_streams * T}-frame batch mono 48 kHz / 10 ms / 150-byte frames, encode only, streams sharded over "
+                        f"{world} GPU(s) (BASELINE configs[2]); {n_distinct} distinct synthetic streams per rank tiled to {S}")
+            metric = "LC3 frames/sec (encode) @48kHz/10ms"
+        line = {
+            "metric": metric, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": workload, "mode": mode, "streams_per_gpu": S, "frames_per_stream_per_step": T,
+                "frames_per_step_per_gpu": frames_per_step, "nbytes": NBYTES, "state": "carried across steps (streaming)",
+                "parallelism": f"streams sharded over {world} GPU(s), no data-path collective; "
+                               + (f"torch.distributed world size {dist.get_world_size()} ({dist.get_backend()})" if dist is not None
+                                  else "single process"),
+                "hip_streams": max(1, args.hip_streams), "engine": args.engine,
             },
-            "cpu_baseline": cpu,
-            "overlapped": overlapped,
-            "parity": parity,
+            "kernel_ms": kernel_ms, "roofline": roof, "cpu_baseline": cpu, "overlapped": overlapped,
+            "parity": parity, "parity_mismatches_all_ranks": total_mismatches,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the parent only launches: no torch import, no HIP call in this process
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -93,3 +93,40 @@ def test_synth_shards_are_consistent():
     assert np.array_equal(a[4:], b)
     assert np.array_equal(a, synth.make_pcm(8, 2, 480, 48000))
     assert a.dtype == np.int16 and np.abs(a).max() > 1000
+
+
+def _run_bench(*extra):
+    import json
+    import subprocess
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--engine", "emu", "--steps", "1", "--warmup", "0",
+                        *extra], capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launcher_starts_two_ranks():
+    """`bench.py --gpus 2` itself starts the ranks (the driver's invocation): the same launcher, sharding and reduction path
+    as on the GPU box, with CPU ranks (wave emulator of the device code, gloo)."""
+    rc, line = _run_bench("--gpus", "2")
+    assert rc == 0 and line is not None
+    assert line["n_gpus"] == 2 and "world size 2 (gloo)" in line["config"]["parallelism"]
+    assert line["scaling"] == "weak" and line["config"]["frames_per_step_per_gpu"] == 8
+    assert line["parity"]["bitstream_exact"] and line["parity"]["pcm_max_abs_diff"] == 0
+    assert line["parity_mismatches_all_ranks"] == 0
+    # value = frames of ALL ranks / max elapsed
+    assert abs(line["value"] - 2 * 8 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+
+
+def test_bench_encode_mode_shards_the_batch():
+    """BASELINE configs[2] shape (encode only, the batch's streams sharded over the ranks: strong scaling), tiny on CPU"""
+    rc, line = _run_bench("--gpus", "2", "--mode", "encode", "--frames-total", "12", "--frames", "2")
+    assert rc == 0 and line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["streams_per_gpu"] == 3 and line["config"]["mode"] == "encode"
+    assert line["parity"]["bitstream_exact"] and line["parity_mismatches_all_ranks"] == 0
+    assert abs(line["value"] - 12 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    rc, line = _run_bench("--gpus", "2", "--mode", "encode", "--frames-total", "3", "--frames", "2")
+    assert rc != 0 and line is None

@@ -292,6 +292,31 @@ def test_full_size_batch_properties():
     del torch
 
 
+# ---------------------------------------------------------------- 1 M-frame encode batch (BASELINE configs[2], one GPU's worth of it)
+@pytest.mark.parametrize("S,T", [(65536, 16), (1048576, 1)])
+def test_one_million_frame_encode_batch(S, T):
+    """1 048 576 frames through ONE lc3gpu_encode call on one GPU (the reference's caller loop, examples/encode.rs:97-115,
+    over a million channel frames): mode B = 65 536 streams x 16 frames with carried state, mode A = 1 048 576 fresh streams x
+    1 frame.  Parity: the distinct streams against the oracle, replicas of a stream against each other (every frame of the
+    batch is compared with something), and a checksum of the whole bitstream against the one the replication implies."""
+    torch = torch_mod()
+    NB, D = 150, 1024
+    pcm = synth.make_pcm(D, T, 480, 48000, seed=53)
+    ref = O.encode_batch(pcm, NB, threads=8)
+    d_small = torch.from_numpy(pcm).cuda()
+    d_pcm = d_small.repeat(S // D, 1, 1).contiguous()  # replica r of stream i sits at r * D + i
+    assert d_pcm.shape == (S, T, 480)
+    d_out = torch.zeros((S, T, NB), dtype=torch.uint8, device="cuda")
+    enc = pkg.Lc3Encoder(S, US, FS)
+    enc.encode(d_pcm, d_out, NB, T, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    d_ref = torch.from_numpy(ref).cuda()
+    view = d_out.view(S // D, D, T, NB)
+    assert bool((view == d_ref.unsqueeze(0)).all()), "a frame of the 1 M batch differs from the oracle's bitstream"
+    assert int(d_out.to(torch.int64).sum().item()) == int(ref.astype(np.int64).sum()) * (S // D)
+    enc.close()
+
+
 @pytest.mark.parametrize("fs,us,nbytes", [(48000, 10000, 60), (32000, 10000, 40), (16000, 7500, 30), (48000, 7500, 60)])
 def test_ltpf_transitions(fs, us, nbytes):
     """Decoder LTPF synthesis (block-parallel on the GPU) through all five transition cases of
