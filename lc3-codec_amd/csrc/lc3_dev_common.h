@@ -151,6 +151,8 @@ struct lc3_cfg {
     const float *resamp_poly;
     // width (in lines, as f32) of the band each spectral line belongs to, ne entries (lc3_line_width_value)
     const float *line_width;
+    // band (0..nb-1) each spectral line belongs to, 255 for lines >= ne; nf entries, read four at a time (lc3_line_band_value)
+    const uint8_t *line_band;
     // decoder LTPF (decoder/long_term_post_filter.rs:104-134)
     int l_den, l_num, num_mem_blocks, norm, s25;
 };
@@ -214,7 +216,27 @@ __device__ __forceinline__ void lc3_fft_tables_stage(const CC &c) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) lc3_fft_tab.perm[i] = c.perm[i];
     __syncthreads();
 }
+// Tables only the analysis front half reads, per workgroup: the band width of every spectral line (divisor of the band
+// energies) and the fractional-lag interpolation filter of the LTPF analysis -- every frame re-read them from L2 otherwise
+struct lc3_front_tables {
+    float line_width[LC3_MAX_NE];
+    float interp_r[32];
+    float resamp_poly[336];  // polyphase rows of the LTPF resampler (lc3_resamp_poly_value), <= 12 rows x 28 floats for an encoder
+};
+__shared__ __attribute__((aligned(16))) lc3_front_tables lc3_front_tab;  // 3.2 KB, filled by lc3_front_tables_stage
+#define LC3_LINE_WIDTH(c, k) (lc3_front_tab.line_width[(k)])
+#define LC3_LTPF_INTERP_R(i) (lc3_front_tab.interp_r[(i)])
+#define LC3_RESAMP_POLY_IN_LDS 1
+template <class CC>
+__device__ __forceinline__ void lc3_front_tables_stage(const CC &c) {  // all threads of the workgroup, before a workgroup barrier
+    for (int i = threadIdx.x; i < c.ne; i += blockDim.x) lc3_front_tab.line_width[i] = c.line_width[i];
+    for (int i = threadIdx.x; i < 31; i += blockDim.x) lc3_front_tab.interp_r[i] = lc3_f(LC3T_TAB_LTPF_INTERP_R_BITS, i);
+    const int p_rows = c.p_up * c.resamp_stride;
+    for (int i = threadIdx.x; i < p_rows && i < 336; i += blockDim.x) lc3_front_tab.resamp_poly[i] = c.resamp_poly[i];
+}
 #else
+#define LC3_LINE_WIDTH(c, k) ((c).line_width[(k)])
+#define LC3_LTPF_INTERP_R(i) (lc3_f(LC3T_TAB_LTPF_INTERP_R_BITS, (i)))
 #define LC3_FFT_TW(c) ((c).fft_tw)
 #define LC3_DCT_TW(c) ((c).dct_tw)
 #define LC3_FFT_PERM(c) ((c).perm)
@@ -626,30 +648,54 @@ __device__ __forceinline__ void lc3_wave_copy_out16(void *hbm_dst, const void *l
 // fetched eight at a time so that a sum costs one LDS latency per eight terms instead of one per term.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lc3_sum_seq(const float *a, int n, float acc) {
-    int i = 0;
-    for (; i + 8 <= n; i += 8) {
-        float x[8];
+    // software-pipelined: the next eight operands are requested before the current eight are added (the additions are one
+    // dependent chain; their operands' LDS latency is then hidden behind it)
+    float x[8], xn[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const int nb = n & ~7;
+    if (nb > 0) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) x[u] = a[i + u];
+        for (int u = 0; u < 8; u++) x[u] = a[u];
+    }
+    for (int i = 0; i < nb; i += 8) {
+        if (i + 8 < nb) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) xn[u] = a[i + 8 + u];
+        }
 #pragma unroll
         for (int u = 0; u < 8; u++) acc += x[u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = xn[u];
     }
-    for (; i < n; i++) acc += a[i];
+    for (int i = nb; i < n; i++) acc += a[i];
     return acc;
 }
 __device__ __forceinline__ float lc3_dot_seq(const float *a, const float *b, int n, float acc) {
-    int i = 0;
-    for (; i + 8 <= n; i += 8) {
-        float x[8], y[8];
+    float x[8], y[8], xn[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, yn[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const int nb = n & ~7;
+    if (nb > 0) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            x[u] = a[i + u];
-            y[u] = b[i + u];
+            x[u] = a[u];
+            y[u] = b[u];
+        }
+    }
+    for (int i = 0; i < nb; i += 8) {
+        if (i + 8 < nb) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                xn[u] = a[i + 8 + u];
+                yn[u] = b[i + 8 + u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) acc += x[u] * y[u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            x[u] = xn[u];
+            y[u] = yn[u];
+        }
     }
-    for (; i < n; i++) acc += a[i] * b[i];
+    for (int i = nb; i < n; i++) acc += a[i] * b[i];
     return acc;
 }
 
@@ -749,6 +795,16 @@ __device__ __forceinline__ float lc3_line_width_value(const CC &c, int k) {
     int b = 0;
     while (b + 1 < c.nb && (int)ifs[b + 1] <= k) b++;
     return (float)((int)ifs[b + 1] - (int)ifs[b]);
+}
+
+// band of spectral line k (0..nb-1), 255 beyond the coded bandwidth; fills c.line_band
+template <class CC>
+__device__ __forceinline__ int lc3_line_band_value(const CC &c, int k) {
+    if (k >= c.ne) return 255;
+    const uint16_t *ifs = lc3_band_index(c);
+    int b = 0;
+    while (b + 1 < c.nb && (int)ifs[b + 1] <= k) b++;
+    return b;
 }
 
 // ------------------------------------------------------------------------------------------

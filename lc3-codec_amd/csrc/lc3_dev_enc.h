@@ -56,7 +56,7 @@ struct __attribute__((aligned(16))) lc3_enc_lds {
 #define LC3_EB(L) ((float *)(L).fa + 512)                    // [64] band energies: MDCT stage -> bandwidth, SNS
 #define LC3_SCF(L) ((float *)(L).fa + 144)                   // [16] SNS target scale factors (lc3_enc_sns_front)
 #define LC3_XQ(L) ((L).t)                                    // int16[ne] quantised spectrum (from the quantiser on)
-#define LC3_RESB(L) ((uint8_t *)(L).t + 2 * LC3_MAX_NE)      // uint8[ne] residual bits
+#define LC3_RESW(L) ((uint32_t *)((uint8_t *)(L).t + 2 * LC3_MAX_NE))  // uint32[13] residual bits, bit j of word j / 32
 
 LC3_LDS_DECL(lc3_enc_lds, lc3_enc_wg)
 static_assert(offsetof(lc3_enc_lds, fa) % 16 == 0 && offsetof(lc3_enc_lds, spec) % 16 == 0 && offsetof(lc3_enc_lds, t) % 16 == 0,
@@ -185,12 +185,15 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS
         }
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 22);
     lc3_dct4_wave(c, lane, L.spec, L.fa, L.fb);
+    LC3_STAMP(L, lane, 23);
     {
         const float gain = 1.0f / lc3_sqrtf(2.0f * (float)nf);
         for (int k = lane; k < nf; k += LC3_WAVE) L.spec[k] *= gain;
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 20);
     // apply_energy_estimation :140-152: E_b = sum over the band's lines of (X_k * X_k / width), the division inside the
     // sum.  The terms are independent: one line per lane (seven rounds instead of up to 25 divisions in a row
     // on the lanes of the widest bands); then one lane per band adds its terms in the reference's order.
@@ -198,9 +201,10 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS
         float *e = (float *)L.fa;  // fa is free after the transform; the band energies live at fa + 512 floats
         for (int k = lane; k < c.ne; k += LC3_WAVE) {
             const float x = L.spec[k];
-            e[k] = x * x / c.line_width[k];
+            e[k] = x * x / LC3_LINE_WIDTH(c, k);
         }
         LC3_SYNC();
+        LC3_STAMP(L, lane, 21);
         for (int b = lane; b < c.nb; b += LC3_WAVE) {
             const int from = ifs[b], to = ifs[b + 1];
             float acc = 0.0f;
@@ -439,19 +443,6 @@ LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_sns_front(LC3_CFG_PARAM, L
     LC3_STAMP(L, lane, 27);
 }
 
-// E9 back half: spectral shaping :264-268 with the band gains the vector quantiser stage produced (HBM, 64 f32) --
-// one lane per band (bands are 1..25 lines wide)
-LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_sns_apply(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const float *gains) {
-    LC3_CFG_BIND;
-    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
-    const uint16_t *ifs = lc3_band_index(c);
-    if (lane < c.nb) {
-        LC3_HBM_CONST(float) g = (LC3_HBM_CONST(float))gains;
-        lc3_scale_run(L.spec, ifs[lane], ifs[lane + 1], g[lane]);
-    }
-    LC3_SYNC();
-}
-
 // ------------------------------------------------------------------------------------------
 // E11: temporal noise shaping (encoder/temporal_noise_shaping.rs:40-349)
 // rc_i[16] -> L.ism[16..32), rc_q[16] -> L.sm[16..32)
@@ -472,21 +463,39 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
     res.num_tns_filters = tp.num;
     res.lpc_weighting = c.n_ms_10 ? (nbits < 480) : (nbits < 360);
 
-    // compute_normalized_autocorrelation :80-115 -- one lane per (filter, lag, sub-block) partial sum and
-    // one lane per sub-block energy; every sum runs in the reference's order.
+    // compute_normalized_autocorrelation :80-115 -- one lane per (filter, lag, sub-block) partial sum, every sum in the
+    // reference's order.  The sub-block energy e_s (:88-93) is the lag-0 sum of its sub-block -- the same products added in the
+    // same order -- so the lag-0 lanes supply it.  A lane's sum has 50..70 terms: blocks of eight, the last one masked.
     if (lane < 54) {
         const int f = lane / 27, r = lane - 27 * f, k = r / 3, s = r - 3 * k;
         float ac = 0.0f;
         if (f < tp.num) {
             const int start = tp.sub_start[f][s], stop = tp.sub_stop[f][s], k_from = start + k;
-            if (k_from < ne && k_from < stop) ac = lc3_dot_seq(x + start, x + k_from, stop - k_from, 0.0f);
+            if (k_from < ne && k_from < stop) {
+                const float *pa = x + start, *pb = x + k_from;  // reads run at most seven lines past `stop` (<= 400 + 7 < nf)
+                const int n = stop - k_from;
+                for (int i = 0; i < n; i += 8) {
+                    float xa[8], xb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        xa[u] = pa[i + u];
+                        xb[u] = pb[i + u];
+                    }
+                    if (i + 8 <= n) {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) ac += xa[u] * xb[u];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const float p = xa[u] * xb[u];
+                            ac = i + u < n ? ac + p : ac;
+                        }
+                    }
+                }
+            }
         }
         sAC[lane] = ac;
-    } else if (lane < 60) {
-        const int q = lane - 54, f = q / 3, s = q - 3 * f;
-        float es = 0.0f;
-        if (f < tp.num) es = lc3_dot_seq(x + tp.sub_start[f][s], x + tp.sub_start[f][s], tp.sub_stop[f][s] - tp.sub_start[f][s], 0.0f);
-        sES[q] = es;
+        if (k == 0) sES[f * 3 + s] = ac;
     }
     LC3_SYNC();
     // the 54 quotients ac_s(k) / e_s (:97-104) on the lanes that hold the partial sums: the Levinson lanes below only add
@@ -496,6 +505,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
         sAC[lane] = sAC[lane] / sES[f * 3 + s3];
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 28);
     // Levinson-Durbin :204-232 and the LPC -> reflection conversion :234-265: one lane per filter, the order-8
     // recursions fully unrolled on register arrays.
     if (lane < 2 && lane < tp.num) {
@@ -550,6 +560,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
         }
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 29);
     // apply_quantization :267-292 -- one lane per coefficient
     if (lane < 16) {
         const float step = (float)3.14159265358979323846 / 17.0f;  // PI as f32 / 17.0 :268
@@ -586,6 +597,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
         L.ism[10] = nbits_tns;
     }
     LC3_SYNC();
+    LC3_STAMP(L, lane, 30);
     // apply_filtering :313-340.  The reference walks the samples serially through an order-8 MA lattice
     //   B_{k+1}[n] = rc_k * F_k[n] + B_k[n-1],   F_{k+1}[n] = F_k[n] + rc_k * B_k[n-1],   F_0 = B_0 = x,
     // where st[k] holds B_k[n-1].  A stage only needs the previous stage at n and n-1, so each stage is computed
@@ -652,6 +664,23 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
 #define LC3_KMIN 17
 #define LC3_KMAX 114
 
+// Wave-parallel form of the reference's first-maximum scan  `best = a[first]; idx = first; for i: if (a[i] > best) { best = a[i]; idx = i; }`
+// over elements held in registers: lane l owns elements l (v0) and l + 64 (v1); in0 / in1 mark the ones inside the scan.  Without
+// NaNs the scan returns the lowest index that holds the maximum (-0.0 and +0.0 compare equal): the floats are mapped to integers
+// of the same order, the maximum is an integer wave reduction and a ballot finds its first holder.  `any_nan` (wave-uniform) tells
+// the caller that a NaN is inside the scan, where the sequential form must be used instead.  Returns -1 for an empty scan.
+__device__ __forceinline__ int lc3_float_order_key(float v) {
+    const uint32_t b = lc3_bits(v + 0.0f);  // -0.0 + 0.0 = +0.0
+    return (int)(b ^ ((uint32_t)((int32_t)b >> 31) & 0x7fffffffu));
+}
+__device__ __forceinline__ int lc3_wave_argmax_first(float v0, int in0, float v1, int in1, int lane, int *any_nan) {
+    const int lowest = -2147483647 - 1;
+    const int k0 = in0 ? lc3_float_order_key(v0) : lowest, k1 = in1 ? lc3_float_order_key(v1) : lowest;
+    *any_nan = lc3_wave_ballot((in0 && v0 != v0) || (in1 && v1 != v1), lane) != 0ull;
+    const int m = lc3_wave_max_i32(k0 > k1 ? k0 : k1, lane);
+    const unsigned long long b0 = lc3_wave_ballot(in0 && k0 == m, lane), b1 = lc3_wave_ballot(in1 && k1 == m, lane);
+    return b0 ? __builtin_ctzll(b0) : (b1 ? 64 + __builtin_ctzll(b1) : -1);
+}
 __device__ __forceinline__ float lc3_ltpf_interp(const float *r, int rel, int d) {  // :457-469
     float acc = 0.0f;
     for (int m = -4; m <= 4; m++) {
@@ -704,8 +733,10 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
             const int i = lane + LC3_WAVE * j;
             v[j] = i < keep12 ? g12[i + len12] : 0.0f;
         }
+#ifndef LC3_RESAMP_POLY_IN_LDS
         const int p_rows = p * c.resamp_stride;
         for (int i = lane; i < p_rows; i += LC3_WAVE) S[i] = c.resamp_poly[i];
+#endif
 #pragma unroll
         for (int j = 0; j < 5; j++) {
             const int i = lane + LC3_WAVE * j;
@@ -729,7 +760,12 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         const int q0 = (15 * n0 * c.inv_p) >> 16, q1 = (15 * n1 * c.inv_p) >> 16;  // 15 n / p without integer divisions
         const float *xa = W + c.hist + q0 - 2 * lim;  // tap j <-> k = j - lim
         const float *xb = W + c.hist + q1 - 2 * lim;
-        const float *ha = S + (15 * n0 - q0 * p) * c.resamp_stride, *hb = S + (15 * n1 - q1 * p) * c.resamp_stride;
+#ifdef LC3_RESAMP_POLY_IN_LDS
+        const float *poly = lc3_front_tab.resamp_poly;  // staged once per workgroup
+#else
+        const float *poly = S;
+#endif
+        const float *ha = poly + (15 * n0 - q0 * p) * c.resamp_stride, *hb = poly + (15 * n1 - q1 * p) * c.resamp_stride;
         float acc0 = 0.0f, acc1 = 0.0f;
         for (int j = 0; j < nt; j += 4) {
             const lc3_f4 a = *(const lc3_f4 *)(ha + j), b = *(const lc3_f4 *)(hb + j);
@@ -753,12 +789,18 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
             if (i < keep6) x6[i] = g6[i + len6];
         }
     }
+    // the high-pass memories h[-1], h[-2] as every lane needs them below (read before lane 0 moves them on)
+    const float hp_m1 = L.st.h50_m1, hp_m2 = L.st.h50_m2;
     LC3_SYNC();
     LC3_STAMP(L, lane, 12);
-    // 50 Hz high-pass :168-177 -- recursive across samples and frames: lane 0
+    // 50 Hz high-pass :168-177.  The reference's loop does two things per sample: the recursion
+    //   h[n] = x[n] - a1 * h[n-1] - a2 * h[n-2]
+    // and the output y[n] = b0 * h[n] + b1 * h[n-1] + b2 * h[n-2].  Only the recursion is serial (and runs across frames):
+    // lane 0 walks it, four operations per sample, and leaves h in place of x; the three-tap output is then formed one
+    // sample per lane from the stored h -- the same f32 operations in the same order as in the single loop.
     if (lane == 0) {
         float *o12 = x12 + c.delay12 + LC3_NMEM;
-        float m1 = L.st.h50_m1, m2 = L.st.h50_m2;
+        float m1 = hp_m1, m2 = hp_m2;
         #pragma unroll 1
         for (int n0 = 0; n0 < len12; n0 += 8) {  // len12 is a multiple of 8; eight samples per LDS round trip
             float x[8];
@@ -766,8 +808,8 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
             for (int u = 0; u < 8; u++) x[u] = o12[n0 + u];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                float h50 = x[u] - -1.9652933726226904f * m1 - 0.9658854605688177f * m2;
-                x[u] = 0.9827947082978771f * h50 + -1.965589416595754f * m1 + 0.9827947082978771f * m2;
+                const float h50 = x[u] - -1.9652933726226904f * m1 - 0.9658854605688177f * m2;
+                x[u] = h50;
                 m2 = m1;
                 m1 = h50;
             }
@@ -778,6 +820,27 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         L.st.h50_m2 = m2;
     }
     LC3_SYNC();
+    {
+        float *o12 = x12 + c.delay12 + LC3_NMEM;
+        float h0[2], h1[2], h2[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int n = lane + LC3_WAVE * q;
+            h0[q] = h1[q] = h2[q] = 0.0f;
+            if (n < len12) {
+                h0[q] = o12[n];
+                h1[q] = n >= 1 ? o12[n - 1] : hp_m1;
+                h2[q] = n >= 2 ? o12[n - 2] : (n == 1 ? hp_m1 : hp_m2);
+            }
+        }
+        LC3_SYNC();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int n = lane + LC3_WAVE * q;
+            if (n < len12) o12[n] = 0.9827947082978771f * h0[q] + -1.965589416595754f * h1[q] + 0.9827947082978771f * h2[q];
+        }
+    }
+    LC3_SYNC();
     LC3_STAMP(L, lane, 13);
     // pitch_detection :232-290
     for (int n = lane; n < len6; n += LC3_WAVE) {
@@ -786,50 +849,82 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
                            0.2353512128364889f * s[3] + 0.1236796411180537f * s[4];
     }
     LC3_SYNC();
+    int lag_t1, lag_t2;
     {   // 98 lags, len6-term sums in order; a lane runs its two lags (lane, lane + 64) side by side, 8 terms per batch
         const int NL = LC3_KMAX + 1 - LC3_KMIN;
         const int k0 = lane, has1 = lane + LC3_WAVE < NL, k1 = has1 ? lane + LC3_WAVE : lane;
         const float *pa = x6 + LC3_KMAX, *pb0 = x6 + (LC3_KMAX - LC3_KMIN - k0), *pb1 = x6 + (LC3_KMAX - LC3_KMIN - k1);
         float acc0 = 0.0f, acc1 = 0.0f;
-        #pragma unroll 1
-        for (int n = 0; n < len6; n += 8) {
-            float a[8], b0[8], b1[8];
+        {   // the next eight operands of each array are requested before the current eight products are added
+            float a[8], b0[8], b1[8], an[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, b0n[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f},
+                  b1n[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                a[u] = pa[n + u];
-                b0[u] = pb0[n + u];
-                b1[u] = pb1[n + u];
+                a[u] = pa[u];
+                b0[u] = pb0[u];
+                b1[u] = pb1[u];
             }
+            #pragma unroll 1
+            for (int n = 0; n < len6; n += 8) {
+                if (n + 8 < len6) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                acc0 += a[u] * b0[u];
-                acc1 += a[u] * b1[u];
+                    for (int u = 0; u < 8; u++) {
+                        an[u] = pa[n + 8 + u];
+                        b0n[u] = pb0[n + 8 + u];
+                        b1n[u] = pb1[n + 8 + u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    acc0 += a[u] * b0[u];
+                    acc1 += a[u] * b1[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    a[u] = an[u];
+                    b0[u] = b0n[u];
+                    b1[u] = b1n[u];
+                }
             }
         }
         r6[k0] = acc0;
-        rw6[k0] = (1.0f - 0.5f * (float)k0 / (float)(LC3_KMAX - LC3_KMIN)) * acc0;
-        if (has1) {
-            r6[k1] = acc1;
-            rw6[k1] = (1.0f - 0.5f * (float)k1 / (float)(LC3_KMAX - LC3_KMIN)) * acc1;
-        }
-    }
-    LC3_SYNC();
-    if (lane == 0) {
-        const int NL = LC3_KMAX + 1 - LC3_KMIN;
-        int idx = 0;
-        float mx = rw6[0];
-        lc3_argmax_seq(rw6, NL, mx, idx);
-        const int lag_t1 = idx + LC3_KMIN;
+        if (has1) r6[k1] = acc1;
+        // index_of_max_value :427-443 twice: over the weighted correlations of all lags (T1) and over the plain ones of the
+        // lags around the previous frame's (T2).  The values are still in registers: wave-parallel first-maximum scans
+        // (lc3_wave_argmax_first) instead of 98 + 9 compare steps on one lane.
+        const float w0 = (1.0f - 0.5f * (float)k0 / (float)(LC3_KMAX - LC3_KMIN)) * acc0;
+        const float w1 = (1.0f - 0.5f * (float)k1 / (float)(LC3_KMAX - LC3_KMIN)) * acc1;
         const int t_prev = L.st.t_prev;
         const int k_from = (t_prev - 4 > LC3_KMIN ? t_prev - 4 : LC3_KMIN) - LC3_KMIN;
         const int k_to = (t_prev + 4 < LC3_KMAX ? t_prev + 4 : LC3_KMAX) - LC3_KMIN + 1;
-        idx = 0;
-        if (k_to > k_from) {
-            mx = r6[k_from];
-            lc3_argmax_seq(r6 + k_from, k_to - k_from, mx, idx);
+        int nan1, nan2;
+        int i1 = lc3_wave_argmax_first(w0, 1, w1, has1, lane, &nan1);
+        int i2 = lc3_wave_argmax_first(acc0, k0 >= k_from && k0 < k_to, acc1, has1 && k1 >= k_from && k1 < k_to, lane, &nan2);
+        i2 = i2 < 0 ? 0 : i2 - k_from;
+        if (nan1 | nan2) {  // a NaN inside a scan (never with finite PCM): the reference's sequential scans, on lane 0
+            LC3_SYNC();
+            if (lane == 0) {
+                int idx = 0;
+                float mx = (1.0f - 0.5f * 0.0f / (float)(LC3_KMAX - LC3_KMIN)) * r6[0];
+                for (int i = 0; i < NL; i++) {
+                    const float v = (1.0f - 0.5f * (float)i / (float)(LC3_KMAX - LC3_KMIN)) * r6[i];
+                    if (v > mx) { mx = v; idx = i; }
+                }
+                L.ism[0] = idx;
+                idx = 0;
+                if (k_to > k_from) {
+                    mx = r6[k_from];
+                    lc3_argmax_seq(r6 + k_from, k_to - k_from, mx, idx);
+                }
+                L.ism[1] = idx;
+            }
+            LC3_SYNC();
+            i1 = L.ism[0];
+            i2 = L.ism[1];
+            LC3_SYNC();
         }
-        L.ism[0] = lag_t1;
-        L.ism[1] = idx + k_from + LC3_KMIN;
+        lag_t1 = i1 + LC3_KMIN;
+        lag_t2 = i2 + k_from + LC3_KMIN;
     }
     LC3_SYNC();
     // compute_normalized_value :445-455 for lag 0, lag_t1, lag_t2: the squares once, one sample per lane, then three lanes
@@ -841,22 +936,13 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     }
     LC3_SYNC();
     if (lane < 3) {
-        const int lag = lane == 0 ? 0 : L.ism[lane - 1];
+        const int lag = lane == 0 ? 0 : (lane == 1 ? lag_t1 : lag_t2);
         const int from = LC3_KMAX - lag;
-        float v = 0.0f;
-        #pragma unroll 1
-        for (int n = from; n < from + len6; n += 8) {
-            float a[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) a[u] = sq[n + u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v += a[u];
-        }
+        const float v = lc3_sum_seq(sq + from, len6, 0.0f);
         L.sm[lane] = v;
     }
     LC3_SYNC();
     if (lane == 0) {
-        const int lag_t1 = L.ism[0], lag_t2 = L.ism[1];
         const float nv0 = L.sm[0], nv1 = L.sm[1], nv2 = L.sm[2];
         float normcorr1 = lc3_maxf(0.0f, r6[lag_t1 - LC3_KMIN] / lc3_sqrtf(nv0 * nv1));
         float normcorr2 = lag_t1 == lag_t2 ? normcorr1 : lc3_maxf(0.0f, r6[lag_t2 - LC3_KMIN] / lc3_sqrtf(nv0 * nv2));
@@ -881,52 +967,84 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         const int nk = (k_max + 4) - (k_min - 4) + 1;  // <= 17
         if (lane < nk) {
             const int k = k_min - 4 + lane;
-            float acc = 0.0f;
-            const float *pa = x12 + LC3_NMEM, *pb = x12 + LC3_NMEM - k;
-            #pragma unroll 1
-            for (int n = 0; n < len12; n += 8) {
-                float a[8], b[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    a[u] = pa[n + u];
-                    b[u] = pb[n + u];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) acc += a[u] * b[u];
-            }
+            const float acc = lc3_dot_seq(x12 + LC3_NMEM, x12 + LC3_NMEM - k, len12, 0.0f);  // len12 is a multiple of 8
             r12[lane] = acc;
         }
     }
     LC3_SYNC();
-    if (lane == 0) {
-        float max_corr = 0.0f;
-        int pitch_int = k_min, pitch_fr = 0;
-        for (int k = k_min - 4; k <= k_max + 4; k++) {
-            float v = r12[k - (k_min - 4)];
-            if (v > max_corr && k >= k_min && k <= k_max) {
-                max_corr = v;
-                pitch_int = k;
+    LC3_STAMP(L, lane, 17);
+    // Integer lag = first maximum above zero of the <= 9 in-range correlations (:303-313), then the fractional part = first
+    // maximum above zero of up to seven interpolated values (:315-345, interpolate :457-469).  Both scans run wave-parallel
+    // (lc3_wave_argmax_first; lane j holds correlation j, then candidate j whose nine taps it adds up in the reference's order)
+    // instead of 17 + 7 x 9 steps on one lane.  A NaN in a scan (never with finite PCM) takes the sequential form below.
+    int pitch_int, pitch_fr;
+    {
+        const int nk = (k_max + 4) - (k_min - 4) + 1;
+        const int k = k_min - 4 + lane, in_k = lane < nk && k >= k_min && k <= k_max;
+        const float v = lane < nk ? r12[lane] : 0.0f;
+        int nan_a, nan_b;
+        const int ia = lc3_wave_argmax_first(v, in_k && v > 0.0f, 0.0f, 0, lane, &nan_a);
+        nan_a = lc3_wave_ballot(in_k && v != v, lane) != 0ull;
+        pitch_int = ia < 0 ? k_min : k_min - 4 + ia;
+        const int rel = pitch_int - (k_min - 4);
+        // candidate j: d = d0 + j * dstep, j < nd
+        int d0 = 0, dstep = 1, nd = 0;
+        if (pitch_int == 32) { d0 = 0; nd = 4; }
+        else if (pitch_int < 127 && pitch_int > 32) { d0 = -3; nd = 7; }
+        else if (pitch_int >= 127 && pitch_int < 157) { d0 = -2; dstep = 2; nd = 3; }
+        const int d = d0 + lane * dstep;
+        float acc = 0.0f;
+        if (lane < nd) {
+#pragma unroll
+            for (int m = -4; m <= 4; m++) {  // nine independent table reads (index clamped, the tap skipped where the reference skips it)
+                const int n = 4 * m - d, in = n > -16 && n < 16;
+                const float t = LC3_LTPF_INTERP_R(in ? n + 15 : 15), r = r12[rel + m];
+                acc = in ? acc + r * t : acc;
             }
         }
-        const int rel = pitch_int - (k_min - 4);
-        if (pitch_int == 32) {
-            float mx = 0.0f;
-            for (int d = 0; d <= 3; d++) {
-                float v = lc3_ltpf_interp(r12, rel, d);
-                if (v > mx) { mx = v; pitch_fr = d; }
+        const int ib = lc3_wave_argmax_first(acc, lane < nd && acc > 0.0f, 0.0f, 0, lane, &nan_b);
+        nan_b = lc3_wave_ballot(lane < nd && acc != acc, lane) != 0ull;
+        pitch_fr = ib < 0 ? 0 : d0 + ib * dstep;
+        if (nan_a | nan_b) {
+            LC3_SYNC();
+            if (lane == 0) {
+                float max_corr = 0.0f;
+                int pitch_int = k_min, pitch_fr = 0;
+                for (int k = k_min - 4; k <= k_max + 4; k++) {
+                    float v = r12[k - (k_min - 4)];
+                    if (v > max_corr && k >= k_min && k <= k_max) {
+                        max_corr = v;
+                        pitch_int = k;
+                    }
+                }
+                const int rel = pitch_int - (k_min - 4);
+                if (pitch_int == 32) {
+                    float mx = 0.0f;
+                    for (int d = 0; d <= 3; d++) {
+                        float v = lc3_ltpf_interp(r12, rel, d);
+                        if (v > mx) { mx = v; pitch_fr = d; }
+                    }
+                } else if (pitch_int < 127 && pitch_int > 32) {
+                    float mx = 0.0f;
+                    for (int d = -3; d <= 3; d++) {
+                        float v = lc3_ltpf_interp(r12, rel, d);
+                        if (v > mx) { mx = v; pitch_fr = d; }
+                    }
+                } else if (pitch_int >= 127 && pitch_int < 157) {
+                    float mx = 0.0f;
+                    for (int d = -2; d <= 2; d += 2) {
+                        float v = lc3_ltpf_interp(r12, rel, d);
+                        if (v > mx) { mx = v; pitch_fr = d; }
+                    }
+                }
+                L.ism[4] = pitch_int;
+                L.ism[5] = pitch_fr;
             }
-        } else if (pitch_int < 127 && pitch_int > 32) {
-            float mx = 0.0f;
-            for (int d = -3; d <= 3; d++) {
-                float v = lc3_ltpf_interp(r12, rel, d);
-                if (v > mx) { mx = v; pitch_fr = d; }
-            }
-        } else if (pitch_int >= 127 && pitch_int < 157) {
-            float mx = 0.0f;
-            for (int d = -2; d <= 2; d += 2) {
-                float v = lc3_ltpf_interp(r12, rel, d);
-                if (v > mx) { mx = v; pitch_fr = d; }
-            }
+
+            LC3_SYNC();
+            pitch_int = L.ism[4];
+            pitch_fr = L.ism[5];
+            LC3_SYNC();
         }
         if (pitch_fr < 0) {
             pitch_int -= 1;
@@ -936,15 +1054,12 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         if (pitch_int < 127) pitch_index = 4 * pitch_int + pitch_fr - 128;
         else if (pitch_int < 157) pitch_index = 2 * pitch_int + pitch_fr / 2 - 126;
         else pitch_index = pitch_int + 283;
-        L.ism[4] = pitch_int;
-        L.ism[5] = pitch_fr;
-        L.ism[6] = pitch_index;
+        if (lane == 0) L.ism[6] = pitch_index;
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 15);
     // activation_bit :365-409 -- interpolated signals in parallel, the three 128-term sums on three lanes
     {
-        const int pitch_int = L.ism[4], pitch_fr = L.ism[5];
         // the products of the three sums are formed here, one sample per lane (a product is the same f32 operation wherever
         // it runs); the three lanes below only add them up in the reference's order
         for (int n = lane; n < len12; n += LC3_WAVE) {
@@ -959,20 +1074,12 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     if (lane < 3) {
         // lane 0: sum dA*dB, lane 1: sum dA*dA, lane 2: sum dB*dB
         const float *pp = S + 128 * lane;
-        float acc = 0.0f;
-        #pragma unroll 1
-        for (int n = 0; n < len12; n += 8) {
-            float a[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) a[u] = pp[n + u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) acc += a[u];
-        }
+        const float acc = lc3_sum_seq(pp, len12, 0.0f);
         L.sm[lane] = acc;
     }
     LC3_SYNC();
     if (lane == 0) {
-        const int pitch_int = L.ism[4], pitch_fr = L.ism[5], pitch_present = L.ism[3];
+        const int pitch_present = L.ism[3];
         int pitch_index = L.ism[6];
         const float num = L.sm[0], nd = L.sm[1], sh = L.sm[2];
         const float den = lc3_sqrtf(nd * sh);
@@ -1059,16 +1166,16 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
     LC3_SYNC();
     const int rate_flag = nbits > (160 + c.fs_ind * 160) ? 512 : 0;
     const int mode_flag = nbits >= (480 + c.fs_ind * 160);
+    lc3_bitcons bc;
     // compute_bit_consumption :265-348, lane-parallel.  Everything here is integer arithmetic, so any evaluation
     // order is exact.  The context of tuple k only depends on the (a, b, level) class tt of tuples k-1 and k-2:
     //   c_k = (c_{k-1} & 15) * 16 + tt_{k-1}  ==  16 * tt_{k-2} + tt_{k-1}          (tt <= 15)
     // so all contexts are known after one pass over the quantised pairs.  Lane l owns tuples 4l .. 4l+3; the running
     // bit estimate a tuple sees is (sum over lower lanes) + (running sum inside the lane).
     {
-        uint8_t *ttab = (uint8_t *)L.fb + 256;         // tt per tuple (<= 200 bytes)
-        uint32_t *part = (uint32_t *)L.sm;             // [0,64) est sums, [64,128) lsb sums, [128,192) hi nz / cand
         const int ntup_all = ne / 2, k0 = 4 * lane;
         uint32_t loc[4];   // a | b << 8 | n_esc << 16 | nonzero << 24 for the lane's tuples
+        int tt[4] = {0, 0, 0, 0};  // (a, b, level) class of the lane's tuples: the context of a tuple is 16 * tt(k-2) + tt(k-1)
         int hi_nz = -1;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -1081,7 +1188,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
                 const int n_esc = m >= 4 ? (32 - __builtin_clz(m)) - 2 : 0;
                 const unsigned af = a >> n_esc, bf = b >> n_esc;
                 const int lev = n_esc < 3 ? n_esc : 3;
-                ttab[k] = (uint8_t)(lev <= 1 ? 1 + (int)(af + bf) * (lev + 1) : 12 + lev);
+                tt[j] = lev <= 1 ? 1 + (int)(af + bf) * (lev + 1) : 12 + lev;
                 const int nz = q0 != 0 || q1 != 0;
                 if (nz) hi_nz = k;
                 loc[j] = af | (bf << 8) | ((uint32_t)n_esc << 16) | ((uint32_t)nz << 24) | ((uint32_t)(a == 1) << 25) |
@@ -1091,6 +1198,8 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
         const int hi_all = lc3_wave_max_i32(hi_nz + 1, lane);  // 1 + index of the last non-zero tuple
         const int lastnz = hi_all < 1 ? 2 : 2 * hi_all;  // `while lastnz > 2 && last pair == 0` (:270-273)
         const int ntup = lastnz / 2;
+        // the two classes before the lane's first tuple come from the lane below (one DPP move each; 0 below lane 0)
+        const int p2 = lc3_wave_shr1_i32(tt[2], lane), p3 = lc3_wave_shr1_i32(tt[3], lane);
         uint32_t est4[4], run = 0, lsb_sum = 0;
         int tctx[4];
         // main symbols first: four independent lookup -> bits chains per lane, straight-line so that they overlap
@@ -1103,7 +1212,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
                 const uint32_t v = loc[j];
                 const unsigned af = v & 0xff, bf = (v >> 8) & 0xff;
                 const int n_esc = (int)((v >> 16) & 0xff);
-                const int cctx = k == 0 ? 0 : (k == 1 ? (int)ttab[0] : 16 * (int)ttab[k - 2] + (int)ttab[k - 1]);
+                const int cctx = 16 * (j == 0 ? p2 : (j == 1 ? p3 : tt[j - 2])) + (j == 0 ? p3 : tt[j - 1]);
                 const int t = cctx + rate_flag + ((2 * k) > ne / 2 ? 256 : 0);
                 tctx[j] = t;
                 const int levf = n_esc < 3 ? n_esc : 3;
@@ -1147,30 +1256,18 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
                 }
             }
         }
-        // the owner of the highest qualifying tuple publishes its running estimate
+        // the owner of the highest qualifying tuple (lane best_k / 4) holds its running estimate; every quantity below is
+        // wave-uniform already (reductions end in scalar registers), so nothing goes through LDS
         const int best_k = lc3_wave_max_i32(cand_k, lane);
-        LC3_SYNC();
-        if (cand_k == best_k && best_k >= 0) part[0] = cand_est;
-        LC3_SYNC();
-        const uint32_t best_est = best_k >= 0 ? part[0] : 0u;
-        LC3_SYNC();
-        if (lane == 0) {
-            L.ism[0] = lastnz;
-            L.ism[1] = best_k < 0 ? 2 : 2 * best_k + 2;
-            L.ism[2] = (int)lc3_ceilf((float)est_total / 2048.0f) + (int)lsb_total;
-            L.ism[3] = (int)lc3_ceilf((float)best_est / 2048.0f);
-            L.ism[4] = (int)lsb_total;
-        }
+        const uint32_t best_est = best_k >= 0 ? (uint32_t)lc3_wave_read_i32((int)cand_est, best_k >> 2, lane) : 0u;
+        bc.lastnz = lastnz;
+        bc.lastnz_trunc = best_k < 0 ? 2 : 2 * best_k + 2;
+        bc.nbits_est = (int)lc3_ceilf((float)est_total / 2048.0f) + (int)lsb_total;
+        bc.nbits_trunc = (int)lc3_ceilf((float)best_est / 2048.0f);
+        bc.nbits_lsb = (int)lsb_total;
     }
-    LC3_SYNC();
-    lc3_bitcons bc;
     bc.rate_flag = rate_flag;
     bc.mode_flag = mode_flag;
-    bc.lastnz = L.ism[0];
-    bc.lastnz_trunc = L.ism[1];
-    bc.nbits_est = L.ism[2];
-    bc.nbits_trunc = L.ism[3];
-    bc.nbits_lsb = L.ism[4];
     LC3_SYNC();
     for (int n = bc.lastnz_trunc + lane; n < bc.lastnz; n += LC3_WAVE) LC3_XQ(L)[n] = 0;  // truncation :249-252
     LC3_SYNC();
@@ -1431,15 +1528,18 @@ LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PAR
             if (k >= nf_start && k < nf_stop && ((nz13 >> j) & win) == 0) relmask |= 1u << j;
         }
     }
+    if (lane < 13) LC3_RESW(L)[lane] = 0u;
     const uint32_t cnt_nz = (uint32_t)__builtin_popcount(nzmask), cnt_rel = (uint32_t)__builtin_popcount(relmask);
     int rank_nz = (int)lc3_wave_exscan_u32(cnt_nz, lane), rank_rel = (int)lc3_wave_exscan_u32(cnt_rel, lane);
     const int tot_nz = (int)lc3_wave_sum_u32(cnt_nz, lane), tot_rel = (int)lc3_wave_sum_u32(cnt_rel, lane);
+    LC3_SYNC();  // the zeroed words before the bits
 #pragma unroll
     for (int j = 0; j < 7; j++) {
         const int k = k0 + j;
         if (k < ne) {
             if (nzmask & (1u << j)) {
-                if (rank_nz < mx) LC3_RESB(L)[rank_nz] = (uint8_t)(sv[j] >= (float)xv[j + 3] * q.gg);  // :50-55
+                if (rank_nz < mx && sv[j] >= (float)xv[j + 3] * q.gg)  // :50-55; the bits of the 13-word mask are set in place (LDS atomic or)
+                    __atomic_fetch_or(&LC3_RESW(L)[rank_nz >> 5], 1u << (rank_nz & 31), __ATOMIC_RELAXED);
                 rank_nz++;
             }
             if (relmask & (1u << j)) compact[rank_rel++] = lc3_absf(sv[j]) / q.gg;
@@ -1485,6 +1585,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_P
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[i] = L.spec[i];
     int nbits_bw;
     const int bw_ind = lc3_enc_bandwidth(LC3_CFG_PASS, LC3_LDS_PASS lane, &nbits_bw);
+    LC3_STAMP(L, lane, 24);
     const int attack = lc3_enc_attack(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes);
     LC3_STAMP(L, lane, 2);
     lc3_enc_sns_front(LC3_CFG_PASS, LC3_LDS_PASS lane, attack);
@@ -1521,6 +1622,8 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_P
 // keeps them in registers (two 16-byte units of spectrum per lane, one flag word on lanes 0..3)
 struct lc3_mid_fetch {
     lc3_i4 u[2];
+    uint32_t bands[2];  // the band of each of the lane's eight lines, one byte per line (c.line_band)
+    float g;            // band gain of band `lane` (the vector quantiser's output)
     int32_t flag;
 };
 template <class CC>
@@ -1530,8 +1633,12 @@ __device__ __forceinline__ void lc3_mid_issue(const CC &c, int lane, const float
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int i = lane + LC3_WAVE * j;
-        if (i < n4) m.u[j] = s4[i];
+        if (i < n4) {
+            m.u[j] = s4[i];
+            m.bands[j] = ((LC3_HBM_CONST(uint32_t))c.line_band)[i];
+        }
     }
+    m.g = lane < c.nb ? ((LC3_HBM_CONST(float))mid)[MP_G + lane] : 0.0f;
     m.flag = lane < 4 ? ((LC3_HBM_CONST(int32_t))mid)[MP_FLAGS + lane] : 0;
 }
 
@@ -1542,21 +1649,42 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PA
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
-    // pick up the frame: spectrum -> LDS (16-byte units), flags
+    // pick up the frame: flags and band gains -> LDS, then the spectrum -> LDS (16-byte units), each line scaled by its band's
+    // gain on the way in (E9 back half: spectral shaping :264-268 with the gains the vector quantiser stage produced)
+    float *gs = (float *)L.fa;  // [64] band gains
+    if (lane < 4) L.ism[lane] = m.flag;
+    if (lane < c.nb) gs[lane] = m.g;
+    LC3_SYNC();
     {
         const int n4 = c.nf / 4;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int i = lane + LC3_WAVE * j;
-            if (i < n4) ((lc3_i4 *)L.spec)[i] = m.u[j];
+            if (i < n4) {
+                const lc3_f4 xin = __builtin_bit_cast(lc3_f4, m.u[j]);
+                float x[4] = {xin.x, xin.y, xin.z, xin.w};
+                float gk[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t b = (m.bands[j] >> (8 * q)) & 0xffu;
+                    gk[q] = gs[b < 64u ? b : 0u];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t b = (m.bands[j] >> (8 * q)) & 0xffu;
+                    x[q] = b < 64u ? x[q] * gk[q] : x[q];
+                }
+                lc3_f4 o;
+                o.x = x[0]; o.y = x[1]; o.z = x[2]; o.w = x[3];
+                ((lc3_f4 *)L.spec)[i] = o;
+            }
         }
-        if (lane < 4) L.ism[lane] = m.flag;
     }
-    LC3_SYNC();
     const int bw_ind = L.ism[MPF_BW], nbits_bw = L.ism[MPF_NBITS_BW], near_nyquist = L.ism[MPF_NEAR_NYQUIST];
     const int nbits_ltpf = L.ism[MPF_NBITS_LTPF];
     LC3_SYNC();
-    lc3_enc_sns_apply(LC3_CFG_PASS, LC3_LDS_PASS lane, mid + MP_G);
+    LC3_STAMP(L, lane, 18);
+    LC3_STAMP(L, lane, 19);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[480 + i] = L.spec[i];
     const lc3_tns_res tns = lc3_enc_tns(LC3_CFG_PASS, LC3_LDS_PASS lane, bw_ind, nbits, near_nyquist);
     LC3_STAMP(L, lane, 4);
@@ -1593,14 +1721,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PA
             plane[EP_N_RES * st] = n_res;
         }
         if (lane < 16) plane[(EP_RCI + lane) * st] = L.ism[16 + lane];
-        if (lane < 13) {  // residual bits as a bit mask
-            uint32_t m = 0;
-            for (int j = 0; j < 32; j++) {
-                const int i = 32 * lane + j;
-                if (i < n_res && LC3_RESB(L)[i]) m |= 1u << j;
-            }
-            plane[(EP_RES + lane) * st] = (int32_t)m;
-        }
+        if (lane < 13) plane[(EP_RES + lane) * st] = (int32_t)LC3_RESW(L)[lane];  // residual bits as a bit mask
         for (int k = lane; k < c.ne / 2; k += LC3_WAVE)
             plane[(EP_XQ + k) * st] = (int32_t)(((uint32_t)(uint16_t)LC3_XQ(L)[2 * k]) | ((uint32_t)(uint16_t)LC3_XQ(L)[2 * k + 1] << 16));
     }

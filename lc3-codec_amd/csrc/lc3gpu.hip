@@ -110,8 +110,9 @@ struct lc3_cfg_48k10 {
     const lc3_cpx *fft_tw, *dct_tw;
     const uint16_t *perm;
     const float *resamp_poly, *line_width;
+    const uint8_t *line_band;
     __device__ __forceinline__ explicit lc3_cfg_48k10(const lc3_cfg &r)
-        : fft_tw(r.fft_tw), dct_tw(r.dct_tw), perm(r.perm), resamp_poly(r.resamp_poly), line_width(r.line_width) {}
+        : fft_tw(r.fft_tw), dct_tw(r.dct_tw), perm(r.perm), resamp_poly(r.resamp_poly), line_width(r.line_width), line_band(r.line_band) {}
     typedef const lc3_cfg_48k10 bind_t;
     static __device__ __forceinline__ lc3_cfg_48k10 bind(const lc3_cfg &r) { return lc3_cfg_48k10(r); }
     // host side: do the constants describe this plan?
@@ -176,10 +177,19 @@ __device__ __forceinline__ float lc3_wave_shr1_f32(float v, int lane) {
     const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     return __builtin_bit_cast(float, r);
 }
+// integer form; lane 0 receives 0
+__device__ __forceinline__ int lc3_wave_shr1_i32(int v, int lane) {
+    (void)lane;
+    return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
 // the value lane `src` holds (src the same on every lane), on every lane
 __device__ __forceinline__ float lc3_wave_read_f32(float v, int src, int lane) {
     (void)lane;
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane(src)));
+}
+__device__ __forceinline__ int lc3_wave_read_i32(int v, int src, int lane) {
+    (void)lane;
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
 }
 __device__ __forceinline__ unsigned long long lc3_wave_ballot(int pred, int lane) {
     (void)lane;
@@ -273,7 +283,8 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_kernel(lc3
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const int nf = c0.nf, z = c0.z;
     lc3_enc_state *gst = states + (size_t)(first_channel + s);
-    lc3_fft_tables_stage(c0);
+    lc3_front_tables_stage(c0);
+    lc3_fft_tables_stage(c0);  // ends with the workgroup barrier
     LC3_PROF_BEGIN(L, lane);
     if (fresh) lc3_enc_state_init(L, lane, gst, valid);
     else lc3_enc_state_load(L, lane, gst);
@@ -576,6 +587,10 @@ int make_config(lc3_cfg &c, int frame_us, int fs_hz) {
 __global__ void lc3_line_width_kernel(float *out, lc3_cfg c) {
     for (int k = threadIdx.x; k < c.ne; k += blockDim.x) out[k] = lc3_line_width_value(c, k);
 }
+// fills the line -> band table of a configuration on the device (lc3_line_band_value)
+__global__ void lc3_line_band_kernel(uint8_t *out, lc3_cfg c) {
+    for (int k = threadIdx.x; k < c.nf; k += blockDim.x) out[k] = (uint8_t)lc3_line_band_value(c, k);
+}
 // fills the polyphase resampler table of a configuration on the device (lc3_resamp_poly_value)
 __global__ void lc3_resamp_poly_kernel(float *out, int p, int lim, int stride) {
     const int n = p * stride;
@@ -612,8 +627,9 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
         const size_t bytes_perm = (sizeof(uint16_t) * (size_t)c.nfft + 15) & ~(size_t)15;
         const size_t bytes_poly = sizeof(float) * (size_t)c.p_up * (size_t)c.resamp_stride;
         const size_t bytes_lw = sizeof(float) * (size_t)c.ne;
+        const size_t bytes_lb = ((size_t)c.nf + 15) & ~(size_t)15;
         char *base = nullptr;
-        HIP_TRY(hipMalloc((void **)&base, 2 * bytes_tw + bytes_perm + bytes_poly + bytes_lw));
+        HIP_TRY(hipMalloc((void **)&base, 2 * bytes_tw + bytes_perm + bytes_poly + bytes_lw + bytes_lb));
         HIP_TRY(hipMemcpy(base, pl.fft_tw.data(), bytes_tw, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(base + bytes_tw, pl.dct_tw.data(), bytes_tw, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(base + 2 * bytes_tw, pl.perm.data(), sizeof(uint16_t) * (size_t)c.nfft, hipMemcpyHostToDevice));
@@ -623,12 +639,16 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(lc3_line_width_kernel, dim3(1), dim3(256), 0, nullptr, lw, c);
         HIP_TRY(hipGetLastError());
+        uint8_t *lb = (uint8_t *)(base + 2 * bytes_tw + bytes_perm + bytes_poly + bytes_lw);
+        hipLaunchKernelGGL(lc3_line_band_kernel, dim3(1), dim3(256), 0, nullptr, lb, c);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(nullptr));
         c.fft_tw = (const lc3_cpx *)base;
         c.dct_tw = (const lc3_cpx *)(base + bytes_tw);
         c.perm = (const uint16_t *)(base + 2 * bytes_tw);
         c.resamp_poly = poly;
         c.line_width = lw;
+        c.line_band = lb;
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lc3_cfg_table), &c, sizeof(c), sizeof(c) * (size_t)slot, hipMemcpyHostToDevice));
         g_cfgs.cfg[dev][slot] = c;
         g_cfgs.ready[dev][slot] = true;

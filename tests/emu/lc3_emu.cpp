@@ -66,11 +66,27 @@ static inline float lc3_wave_shr1_f32(float v, int lane) {
     LC3_SYNC();
     return r;
 }
+static inline int lc3_wave_shr1_i32(int v, int lane) {
+    LC3_SYNC();
+    g_xi[tl_wave][lane] = v;
+    LC3_SYNC();
+    const int r = lane > 0 ? g_xi[tl_wave][lane - 1] : 0;
+    LC3_SYNC();
+    return r;
+}
 static inline float lc3_wave_read_f32(float v, int src, int lane) {
     LC3_SYNC();
     g_xf[tl_wave][lane] = v;
     LC3_SYNC();
     const float r = g_xf[tl_wave][src & 63];
+    LC3_SYNC();
+    return r;
+}
+static inline int lc3_wave_read_i32(int v, int src, int lane) {
+    LC3_SYNC();
+    g_xi[tl_wave][lane] = v;
+    LC3_SYNC();
+    const int r = g_xi[tl_wave][src & 63];
     LC3_SYNC();
     return r;
 }
@@ -208,6 +224,9 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
     std::vector<float> lw((size_t)j.cfg.ne);
     for (int k = 0; k < j.cfg.ne; k++) lw[(size_t)k] = lc3_line_width_value(j.cfg, k);
     j.cfg.line_width = lw.data();
+    std::vector<uint8_t> lb((size_t)j.cfg.nf + 16);
+    for (int k = 0; k < j.cfg.nf; k++) lb[(size_t)k] = (uint8_t)lc3_line_band_value(j.cfg, k);
+    j.cfg.line_band = lb.data();
     j.encode = 1;
     j.n_frames = T;
     j.nbytes = nbytes;

@@ -27,27 +27,37 @@ d_o = torch.zeros((S, T, 480), dtype=torch.int16, device="cuda")
 enc = pkg.Lc3Encoder(S, 10000, 48000)
 dec = pkg.Lc3Decoder(S, 10000, 48000)
 st = torch.cuda.current_stream().cuda_stream
+ENC_ONLY = os.environ.get("LC3_PROF_ENC_ONLY", "0") == "1"  # the encoder then also uses the decoder's stamp ids (finer sections)
 for _ in range(2):
     enc.encode(d_pcm, d_b, 150, T, stream=st)
-    dec.decode(d_b, d_o, 150, T, stream=st)
+    if not ENC_ONLY:
+        dec.decode(d_b, d_o, 150, T, stream=st)
 torch.cuda.synchronize()
 api.prof_read()
 for _ in range(5):
     enc.encode(d_pcm, d_b, 150, T, stream=st)
-    dec.decode(d_b, d_o, 150, T, stream=st)
+    if not ENC_ONLY:
+        dec.decode(d_b, d_o, 150, T, stream=st)
 torch.cuda.synchronize()
 acc = api.prof_read()
-names = {1: "front: mdct+energy", 2: "front: bandwidth+attack", 26: "front: sns pad, smooth, pre-emph, floor, log2",
+names = {22: "front: mdct load, window, fold", 23: "front: mdct dct-iv", 1: "front: mdct scale + band energies", 24: "front: bandwidth", 2: "front: attack",
+         28: "back: load mid plane, shaping, tns autocorrelation", 29: "back: tns levinson + lpc->rc", 30: "back: tns quantisation, orders, bits", 26: "front: sns pad, smooth, pre-emph, floor, log2",
          27: "front: sns grouping, mean, attack smoothing", 3: "front: targets + spectrum -> mid plane",
          12: "front: ltpf shift+resample", 13: "front: ltpf 50 Hz high-pass", 14: "front: ltpf pitch detection",
          15: "front: ltpf lag refinement", 5: "front: ltpf activation, ring store",
-         4: "back: load mid plane, shaping, tns", 9: "back: quant energies+max", 10: "back: quant gain bisection",
+         4: "back: tns lattice", 9: "back: quant energies+max", 10: "back: quant gain bisection",
          11: "back: quant first quantise+bit count", 6: "back: quant adjust + 2nd pass", 7: "back: residual+noise",
          8: "back: plane store",
          17: "dec load reconstructed frame (plane)", 18: "dec plc save/load", 25: "dec imdct: dct-iv",
          19: "dec imdct: window+ola", 20: "dec ltpf", 21: "dec output"}
 frames = 5 * S * T
-enc_ids = [1, 2, 26, 27, 3, 12, 13, 14, 15, 5, 4, 9, 10, 11, 6, 7, 8]
+if ENC_ONLY:
+    names.update({20: "front: mdct scale", 21: "front: mdct x*x/width", 1: "front: mdct band sums", 17: "front: ltpf 17-lag correlations",
+                  15: "front: ltpf lag scans", 18: "back: pick up mid plane", 19: "back: sns shaping", 28: "back: tns autocorrelation"})
+enc_ids = [22, 23, 1, 24, 2, 26, 27, 3, 12, 13, 14, 15, 5, 28, 29, 30, 4, 9, 10, 11, 6, 7, 8]
+if ENC_ONLY:
+    enc_ids = [22, 23, 20, 21, 1, 24, 2, 26, 27, 3, 12, 13, 14, 17, 15, 5, 18, 19, 28, 29, 30, 4, 9, 10, 11, 6, 7, 8]
+    dec_ids = []
 dec_ids = [17, 18, 25, 19, 20, 21]
 for ids, label in ((enc_ids, "encoder analysis kernels (front + back)"), (dec_ids, "decoder synthesis kernel")):
     tot = sum(acc[i] for i in ids)
