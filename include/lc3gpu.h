@@ -15,6 +15,10 @@
  * encoder/modified_dct.rs:109-111) an error code is returned instead.  Corrupt frames are NOT
  * errors: as in the reference (lc3_decoder.rs:138-141) they are concealed (PLC) and counted.
  * Handles are not thread-safe (mirrors `&mut self`); distinct handles may be used concurrently.
+ * A handle is bound to the HIP device that was current when it was created; every call switches to that device for its
+ * duration.  Batch calls are asynchronous on the HIP stream they are given; a handle's launches share its scratch planes, so
+ * a call on another stream than the handle's previous one is ordered after it (an event wait on the GPU, no host
+ * synchronisation).  State load / reset calls wait for the handle's work in flight.
  */
 #ifndef LC3GPU_H_
 #define LC3GPU_H_
@@ -36,6 +40,24 @@ extern "C" {
 
 typedef struct lc3gpu_encoder lc3gpu_encoder;
 typedef struct lc3gpu_decoder lc3gpu_decoder;
+
+/* Buffer layouts of the batch calls (C = the handle's channel count, T = n_frames):
+ *   PLANAR       int16[C][T][nf], uint8[C][T][nbytes], flags uint8[C][T]: what the reference's per-channel calls see after
+ *                the caller has de-interleaved (examples/encode.rs:95-102)
+ *   INTERLEAVED  int16[T][nf][C], uint8[T][C][nbytes], flags uint8[T][C]: the WAV sample order and the .lc3 file order
+ *                (frames in time order, channels inside a frame: examples/encode.rs:105-115, examples/decode.rs:86-112); the
+ *                kernels de-interleave on load and interleave on store */
+#define LC3GPU_LAYOUT_PLANAR 0
+#define LC3GPU_LAYOUT_INTERLEAVED 1
+
+/* One stream of a mixed-configuration handle: the reference builds one Lc3Encoder / Lc3Decoder per configuration
+ * (lc3_encoder.rs:117-124, common/config.rs:42-100) and takes the frame size from the slice length of every call
+ * (lc3_encoder.rs:65); a mixed handle fixes all three per stream so that ONE launch per kernel serves every stream. */
+typedef struct lc3gpu_stream_desc {
+    int fs_hz;    /* 8000 (decoder only), 16000, 24000, 32000, 44100, 48000 */
+    int frame_us; /* 7500 or 10000 */
+    int nbytes;   /* bytes per frame */
+} lc3gpu_stream_desc;
 
 /* library / device */
 int lc3gpu_version(void);
@@ -73,11 +95,25 @@ int lc3gpu_encode(lc3gpu_encoder *enc, const int16_t *d_pcm, uint8_t *d_out, int
 /* same, restricted to channels [first_channel, first_channel + n_channels); buffers hold only those channels */
 int lc3gpu_encode_range(lc3gpu_encoder *enc, int first_channel, int n_channels, const int16_t *d_pcm,
                         uint8_t *d_out, int nbytes, int n_frames, void *hip_stream);
+/* same as lc3gpu_encode with the buffers in `layout` (LC3GPU_LAYOUT_*); interleaved PCM needs 2-byte alignment only */
+int lc3gpu_encode_layout(lc3gpu_encoder *enc, int layout, const int16_t *d_pcm, uint8_t *d_out, int nbytes, int n_frames,
+                         void *hip_stream);
 
-/* per-channel state blobs (checkpoint / CPU cross-checks): size per channel, device->host copy, host->device */
+/* Mixed-configuration encoder: n_streams streams, each with its own rate, frame duration and frame size; 8 kHz streams are
+ * refused (LC3GPU_EUNSUPPORTED, as lc3gpu_encoder_create).  lc3gpu_encode_mixed encodes n_frames frames of every stream
+ * with one launch per kernel.  Ragged DEVICE buffers, streams in descriptor order, each stream planar:
+ *   d_pcm  stream i at element offset n_frames * sum_{j<i} nf_j      (int16[n_frames][nf_i]; 4-byte aligned base)
+ *   d_out  stream i at byte offset    n_frames * sum_{j<i} nbytes_j  (uint8[n_frames][nbytes_i])
+ * The per-frame calls, state blobs and timing work on a mixed handle as on a uniform one (channel index = descriptor
+ * index); lc3gpu_encode / _range / _layout do not (LC3GPU_EINVAL). */
+int lc3gpu_encoder_create_mixed(lc3gpu_encoder **out, int n_streams, const lc3gpu_stream_desc *descs);
+int lc3gpu_encode_mixed(lc3gpu_encoder *enc, const int16_t *d_pcm, uint8_t *d_out, int n_frames, void *hip_stream);
+
+/* per-channel state blobs (checkpoint / CPU cross-checks): size per channel, device->host copy, host->device.
+ * nbytes must equal state_size * num_channels (LC3GPU_ELENGTH otherwise); both calls synchronise the device. */
 size_t lc3gpu_encoder_state_size(const lc3gpu_encoder *enc);
-int lc3gpu_encoder_state_save(lc3gpu_encoder *enc, void *host_dst);
-int lc3gpu_encoder_state_load(lc3gpu_encoder *enc, const void *host_src);
+int lc3gpu_encoder_state_save(lc3gpu_encoder *enc, void *host_dst, size_t nbytes);
+int lc3gpu_encoder_state_load(lc3gpu_encoder *enc, const void *host_src, size_t nbytes);
 
 /* ---- decoder ------------------------------------------------------------------------------------ */
 /* Lc3Decoder::new (lc3_decoder.rs:181-215) */
@@ -98,10 +134,19 @@ int lc3gpu_decode(lc3gpu_decoder *dec, const uint8_t *d_in, const uint8_t *d_bad
                   int n_frames, void *hip_stream);
 int lc3gpu_decode_range(lc3gpu_decoder *dec, int first_channel, int n_channels, const uint8_t *d_in,
                         const uint8_t *d_bad_frame, int16_t *d_pcm, int nbytes, int n_frames, void *hip_stream);
+/* same as lc3gpu_decode with the buffers (and the flag array) in `layout` (LC3GPU_LAYOUT_*) */
+int lc3gpu_decode_layout(lc3gpu_decoder *dec, int layout, const uint8_t *d_in, const uint8_t *d_bad_frame, int16_t *d_pcm,
+                         int nbytes, int n_frames, void *hip_stream);
+
+/* Mixed-configuration decoder (see lc3gpu_encoder_create_mixed; 8 kHz streams are allowed).  Ragged buffers as there:
+ * d_in like the encoder's d_out, d_pcm like its d_pcm; d_bad_frame (optional) uint8[n_streams][n_frames] in descriptor order. */
+int lc3gpu_decoder_create_mixed(lc3gpu_decoder **out, int n_streams, const lc3gpu_stream_desc *descs);
+int lc3gpu_decode_mixed(lc3gpu_decoder *dec, const uint8_t *d_in, const uint8_t *d_bad_frame, int16_t *d_pcm, int n_frames,
+                        void *hip_stream);
 
 size_t lc3gpu_decoder_state_size(const lc3gpu_decoder *dec);
-int lc3gpu_decoder_state_save(lc3gpu_decoder *dec, void *host_dst);
-int lc3gpu_decoder_state_load(lc3gpu_decoder *dec, const void *host_src);
+int lc3gpu_decoder_state_save(lc3gpu_decoder *dec, void *host_dst, size_t nbytes);
+int lc3gpu_decoder_state_load(lc3gpu_decoder *dec, const void *host_src, size_t nbytes);
 /* total number of frames concealed so far over all channels (synchronises the device) */
 int lc3gpu_decoder_plc_events(lc3gpu_decoder *dec, uint64_t *out);
 

@@ -14,8 +14,11 @@ from .api import (  # noqa: F401
     Lc3DecoderError,
     Lc3Encoder,
     Lc3EncoderError,
+    LAYOUT_INTERLEAVED,
+    LAYOUT_PLANAR,
     Lc3GpuError,
     SamplingFrequency,
+    StreamDesc,
     build_native,
     build_tool,
     device_count,

@@ -127,8 +127,11 @@ def load_library():
     L.lc3gpu_encode_range.argtypes = [vp, i, i, vp, vp, i, i, vp]
     L.lc3gpu_encoder_state_size.restype = ctypes.c_size_t
     L.lc3gpu_encoder_state_size.argtypes = [vp]
-    L.lc3gpu_encoder_state_save.argtypes = [vp, vp]
-    L.lc3gpu_encoder_state_load.argtypes = [vp, vp]
+    L.lc3gpu_encoder_state_save.argtypes = [vp, vp, ctypes.c_size_t]
+    L.lc3gpu_encoder_state_load.argtypes = [vp, vp, ctypes.c_size_t]
+    L.lc3gpu_encode_layout.argtypes = [vp, i, vp, vp, i, i, vp]
+    L.lc3gpu_encoder_create_mixed.argtypes = [ctypes.POINTER(vp), i, vp]
+    L.lc3gpu_encode_mixed.argtypes = [vp, vp, vp, i, vp]
     L.lc3gpu_decoder_create.argtypes = [ctypes.POINTER(vp), i, i, i]
     L.lc3gpu_decoder_destroy.argtypes = [vp]
     L.lc3gpu_decoder_reset.argtypes = [vp]
@@ -137,8 +140,11 @@ def load_library():
     L.lc3gpu_decode_range.argtypes = [vp, i, i, vp, vp, vp, i, i, vp]
     L.lc3gpu_decoder_state_size.restype = ctypes.c_size_t
     L.lc3gpu_decoder_state_size.argtypes = [vp]
-    L.lc3gpu_decoder_state_save.argtypes = [vp, vp]
-    L.lc3gpu_decoder_state_load.argtypes = [vp, vp]
+    L.lc3gpu_decoder_state_save.argtypes = [vp, vp, ctypes.c_size_t]
+    L.lc3gpu_decoder_state_load.argtypes = [vp, vp, ctypes.c_size_t]
+    L.lc3gpu_decode_layout.argtypes = [vp, i, vp, vp, vp, i, i, vp]
+    L.lc3gpu_decoder_create_mixed.argtypes = [ctypes.POINTER(vp), i, vp]
+    L.lc3gpu_decode_mixed.argtypes = [vp, vp, vp, vp, i, vp]
     L.lc3gpu_decoder_plc_events.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.lc3gpu_kernel_info.argtypes = [i, vp]
     L.lc3gpu_encoder_timing.argtypes = [vp, i, vp]
@@ -156,7 +162,32 @@ ABI_SYMBOLS = [
     "lc3gpu_decoder_destroy", "lc3gpu_decoder_reset", "lc3gpu_decode_frame", "lc3gpu_decode", "lc3gpu_decode_range",
     "lc3gpu_decoder_state_size", "lc3gpu_decoder_state_save", "lc3gpu_decoder_state_load",
     "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info", "lc3gpu_prof_read", "lc3gpu_encoder_timing", "lc3gpu_decoder_timing",
+    "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
+    "lc3gpu_decode_mixed",
 ]
+
+LAYOUT_PLANAR, LAYOUT_INTERLEAVED = 0, 1
+
+
+class StreamDesc(ctypes.Structure):
+    """lc3gpu_stream_desc: one stream of a mixed-configuration handle"""
+    _fields_ = [("fs_hz", ctypes.c_int), ("frame_us", ctypes.c_int), ("nbytes", ctypes.c_int)]
+
+
+def _desc_array(descs):
+    arr = (StreamDesc * len(descs))()
+    for k, d in enumerate(descs):
+        arr[k].fs_hz, arr[k].frame_us, arr[k].nbytes = int(d[0]), int(d[1]), int(d[2])
+    return arr
+
+
+def _layout(layout):
+    if layout in (LAYOUT_PLANAR, "planar", None):
+        return LAYOUT_PLANAR
+    if layout in (LAYOUT_INTERLEAVED, "interleaved"):
+        return LAYOUT_INTERLEAVED
+    raise ValueError("layout must be 'planar' or 'interleaved'")
+
 
 
 def _strerror(code):
@@ -219,6 +250,28 @@ class Lc3Encoder:
 
     new = classmethod(lambda cls, *a, **k: cls(*a, **k))
 
+    @classmethod
+    def mixed(cls, descs):
+        """one handle for streams of different configurations: descs = [(fs_hz, frame_us, nbytes), ...] (lc3gpu_encoder_create_mixed)"""
+        self = cls.__new__(cls)
+        self._L = load_library()
+        self.descs = [(int(d[0]), int(d[1]), int(d[2])) for d in descs]
+        self.configs = [Lc3Config(d[0], d[1]) for d in self.descs]
+        self.config = None
+        self.num_channels = len(self.descs)
+        h = ctypes.c_void_p()
+        rc = self._L.lc3gpu_encoder_create_mixed(ctypes.byref(h), self.num_channels, _desc_array(self.descs))
+        if rc:
+            raise Lc3EncoderError(rc, "Lc3Encoder::mixed")
+        self._h = h
+        return self
+
+    def encode_mixed(self, d_pcm, d_out, n_frames, stream=None):
+        """ragged DEVICE buffers, streams in descriptor order (include/lc3gpu.h); one launch per kernel"""
+        rc = self._L.lc3gpu_encode_mixed(self._h, _ptr(d_pcm), _ptr(d_out), int(n_frames), _ptr(stream))
+        if rc:
+            raise Lc3EncoderError(rc, "encode_mixed")
+
     def encode_frame(self, channel_index, samples_in, buf_out):
         """encode one frame of one channel; len(buf_out) selects the bitrate (lc3_encoder.rs:65,175-191)"""
         samples_in = np.ascontiguousarray(samples_in, dtype=np.int16)
@@ -239,10 +292,12 @@ class Lc3Encoder:
             raise Lc3EncoderError(rc, "encode_frame_debug")
         return out, dbg
 
-    def encode(self, d_pcm, d_out, nbytes, n_frames, stream=None, first_channel=None, n_channels=None):
-        """batch: DEVICE int16[S][T][nf] -> DEVICE uint8[S][T][nbytes], asynchronous on `stream`"""
+    def encode(self, d_pcm, d_out, nbytes, n_frames, stream=None, first_channel=None, n_channels=None, layout="planar"):
+        """batch: DEVICE int16[S][T][nf] -> DEVICE uint8[S][T][nbytes] (layout "interleaved": int16[T][nf][S] ->
+        uint8[T][S][nbytes]), asynchronous on `stream`"""
         if first_channel is None:
-            rc = self._L.lc3gpu_encode(self._h, _ptr(d_pcm), _ptr(d_out), int(nbytes), int(n_frames), _ptr(stream))
+            rc = self._L.lc3gpu_encode_layout(self._h, _layout(layout), _ptr(d_pcm), _ptr(d_out), int(nbytes), int(n_frames),
+                                              _ptr(stream))
         else:
             rc = self._L.lc3gpu_encode_range(self._h, int(first_channel), int(n_channels), _ptr(d_pcm), _ptr(d_out),
                                              int(nbytes), int(n_frames), _ptr(stream))
@@ -265,15 +320,16 @@ class Lc3Encoder:
     def state_save(self):
         n = self._L.lc3gpu_encoder_state_size(self._h) * self.num_channels
         buf = np.zeros(n, np.uint8)
-        rc = self._L.lc3gpu_encoder_state_save(self._h, _ptr(buf))
+        rc = self._L.lc3gpu_encoder_state_save(self._h, _ptr(buf), buf.size)
         if rc:
             raise Lc3EncoderError(rc, "state_save")
         return buf
 
     def state_load(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
-        assert buf.size == self._L.lc3gpu_encoder_state_size(self._h) * self.num_channels
-        rc = self._L.lc3gpu_encoder_state_load(self._h, _ptr(buf))
+        if buf.size != self._L.lc3gpu_encoder_state_size(self._h) * self.num_channels:
+            raise ValueError("state blob size does not match this handle (state_size * num_channels)")
+        rc = self._L.lc3gpu_encoder_state_load(self._h, _ptr(buf), buf.size)
         if rc:
             raise Lc3EncoderError(rc, "state_load")
 
@@ -313,6 +369,27 @@ class Lc3Decoder:
 
     new = classmethod(lambda cls, *a, **k: cls(*a, **k))
 
+    @classmethod
+    def mixed(cls, descs):
+        """descs = [(fs_hz, frame_us, nbytes), ...] (lc3gpu_decoder_create_mixed)"""
+        self = cls.__new__(cls)
+        self._L = load_library()
+        self.descs = [(int(d[0]), int(d[1]), int(d[2])) for d in descs]
+        self.configs = [Lc3Config(d[0], d[1]) for d in self.descs]
+        self.config = None
+        self.num_channels = len(self.descs)
+        h = ctypes.c_void_p()
+        rc = self._L.lc3gpu_decoder_create_mixed(ctypes.byref(h), self.num_channels, _desc_array(self.descs))
+        if rc:
+            raise Lc3DecoderError(rc, "Lc3Decoder::mixed")
+        self._h = h
+        return self
+
+    def decode_mixed(self, d_in, d_pcm, n_frames, stream=None, d_bad_frame=None):
+        rc = self._L.lc3gpu_decode_mixed(self._h, _ptr(d_in), _ptr(d_bad_frame), _ptr(d_pcm), int(n_frames), _ptr(stream))
+        if rc:
+            raise Lc3DecoderError(rc, "decode_mixed")
+
     def decode_frame(self, num_bits_per_audio_sample, channel_index, buf_in, samples_out):
         """lc3_decoder.rs:217-234; corrupt frames are concealed, not reported (":138-141")"""
         buf_in = np.ascontiguousarray(buf_in, dtype=np.uint8)
@@ -324,11 +401,12 @@ class Lc3Decoder:
             raise Lc3DecoderError(rc, "decode_frame")
 
     def decode(self, d_in, d_pcm, nbytes, n_frames, stream=None, d_bad_frame=None, first_channel=None,
-               n_channels=None):
-        """batch: DEVICE uint8[S][T][nbytes] -> DEVICE int16[S][T][nf], asynchronous on `stream`"""
+               n_channels=None, layout="planar"):
+        """batch: DEVICE uint8[S][T][nbytes] -> DEVICE int16[S][T][nf] (layout "interleaved": uint8[T][S][nbytes] ->
+        int16[T][nf][S]), asynchronous on `stream`"""
         if first_channel is None:
-            rc = self._L.lc3gpu_decode(self._h, _ptr(d_in), _ptr(d_bad_frame), _ptr(d_pcm), int(nbytes), int(n_frames),
-                                       _ptr(stream))
+            rc = self._L.lc3gpu_decode_layout(self._h, _layout(layout), _ptr(d_in), _ptr(d_bad_frame), _ptr(d_pcm), int(nbytes),
+                                              int(n_frames), _ptr(stream))
         else:
             rc = self._L.lc3gpu_decode_range(self._h, int(first_channel), int(n_channels), _ptr(d_in),
                                              _ptr(d_bad_frame), _ptr(d_pcm), int(nbytes), int(n_frames), _ptr(stream))
@@ -358,14 +436,16 @@ class Lc3Decoder:
     def state_save(self):
         n = self._L.lc3gpu_decoder_state_size(self._h) * self.num_channels
         buf = np.zeros(n, np.uint8)
-        rc = self._L.lc3gpu_decoder_state_save(self._h, _ptr(buf))
+        rc = self._L.lc3gpu_decoder_state_save(self._h, _ptr(buf), buf.size)
         if rc:
             raise Lc3DecoderError(rc, "state_save")
         return buf
 
     def state_load(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
-        rc = self._L.lc3gpu_decoder_state_load(self._h, _ptr(buf))
+        if buf.size != self._L.lc3gpu_decoder_state_size(self._h) * self.num_channels:
+            raise ValueError("state blob size does not match this handle (state_size * num_channels)")
+        rc = self._L.lc3gpu_decoder_state_load(self._h, _ptr(buf), buf.size)
         if rc:
             raise Lc3DecoderError(rc, "state_load")
 

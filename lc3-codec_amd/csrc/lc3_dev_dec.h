@@ -389,7 +389,7 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_plc_load(LC3_CFG_PARAM, L
 // ------------------------------------------------------------------------------------------
 LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes,
                                                       int16_t *pcm_out, const lc3_plane_fetch &fetched, lc3_dec_state *g,
-                                                      int valid) {
+                                                      int valid, int stride = 1) {
     LC3_CFG_BIND;
     const int nf = c.nf, nbits = nbytes * 8;
     LC3_STAMP(L, lane, 16);
@@ -430,12 +430,24 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_P
             ow[r] = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
         }
         const int nv = LC3_UNIFORM_I32(valid) ? nf / 2 : 0;
-        LC3_HBM(uint32_t) ob = o32 + lane;
+        if (stride == 1) {
+            LC3_HBM(uint32_t) ob = o32 + lane;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int rem = nv - LC3_WAVE * r;
-            if (rem >= LC3_WAVE) ob[LC3_WAVE * r] = ow[r];
-            else if (lane < rem) ob[LC3_WAVE * r] = ow[r];
+            for (int r = 0; r < 4; r++) {
+                const int rem = nv - LC3_WAVE * r;
+                if (rem >= LC3_WAVE) ob[LC3_WAVE * r] = ow[r];
+                else if (lane < rem) ob[LC3_WAVE * r] = ow[r];
+            }
+        } else {  // interleaved PCM out (examples/decode.rs:93-112 interleaves on the host): sample n at pcm_out[n * stride]
+            LC3_HBM(uint16_t) o16 = (LC3_HBM(uint16_t))pcm_out;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = lane + LC3_WAVE * r;
+                if (i < nv) {
+                    o16[(size_t)(2 * i) * (size_t)stride] = (uint16_t)(ow[r] & 0xffffu);
+                    o16[(size_t)(2 * i + 1) * (size_t)stride] = (uint16_t)(ow[r] >> 16);
+                }
+            }
         }
     }
     LC3_SYNC();

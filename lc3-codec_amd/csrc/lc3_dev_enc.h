@@ -98,18 +98,29 @@ __device__ __forceinline__ void lc3_enc_state_load(lc3_enc_lds &L, int lane, con
 // scalars back to HBM; the MDCT history of the next launch = samples [z, nf) of the last frame of this one
 template <class CC>
 __device__ __forceinline__ void lc3_enc_state_store(const CC &c, lc3_enc_lds &L, int lane, lc3_enc_state *g,
-                                                    const int16_t *last_frame) {
+                                                    const int16_t *last_frame, int stride = 1) {
     LC3_SYNC();
     lc3_wave_copy_out16(&g->sc, &L.st, (int)(sizeof(lc3_enc_scalars) / 16), lane);
     if (last_frame) {
-        LC3_HBM_CONST(uint32_t) src = (LC3_HBM_CONST(uint32_t))(last_frame + c.z);
         uint32_t *dst = (uint32_t *)g->hist;
         const int nw = (c.nf - c.z) / 2;  // <= 150 words
         uint32_t v[3];
+        if (stride == 1) {
+            LC3_HBM_CONST(uint32_t) src = (LC3_HBM_CONST(uint32_t))(last_frame + c.z);
 #pragma unroll
-        for (int u = 0; u < 3; u++) {
-            const int i = lane + LC3_WAVE * u;
-            v[u] = i < nw ? src[i] : 0u;
+            for (int u = 0; u < 3; u++) {
+                const int i = lane + LC3_WAVE * u;
+                v[u] = i < nw ? src[i] : 0u;
+            }
+        } else {  // interleaved input: sample j of the frame sits `stride` elements after sample j - 1
+            LC3_HBM_CONST(uint16_t) src = (LC3_HBM_CONST(uint16_t))last_frame;
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int i = lane + LC3_WAVE * u;
+                v[u] = i < nw ? (uint32_t)src[(size_t)(c.z + 2 * i) * (size_t)stride] |
+                                    ((uint32_t)src[(size_t)(c.z + 2 * i + 1) * (size_t)stride] << 16)
+                              : 0u;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 3; u++) {
@@ -124,8 +135,10 @@ __device__ __forceinline__ void lc3_enc_state_store(const CC &c, lc3_enc_lds &L,
 // ------------------------------------------------------------------------------------------
 // hist: the nf - z samples before this frame (previous frame's tail in the PCM input, or the state blob's copy for the
 // first frame of a launch), 4-byte aligned; nullptr = silence (fresh stream)
+// stride / hstride: distance in elements between consecutive samples of the frame / of the history (1 = planar; the channel
+// count for interleaved PCM; the state blob's copy of the history is always planar)
 LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const int16_t *pcm,
-                                         const int16_t *hist) {
+                                         const int16_t *hist, int stride, int hstride) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int nf = c.nf, z = c.z, h = nf / 2, mid = 3 * h;
@@ -146,15 +159,35 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS
             wv[r][2] = in ? lc3_f(w, k) : 0.0f;
             wv[r][3] = in ? lc3_f(w, nf - 1 - k) : 0.0f;
         }
+        if (stride == 1) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = lane + LC3_WAVE * u;
-            v[u] = i < nf / 2 ? p32[i] : 0u;
+            for (int u = 0; u < 4; u++) {
+                const int i = lane + LC3_WAVE * u;
+                v[u] = i < nf / 2 ? p32[i] : 0u;
+            }
+        } else {  // interleaved PCM (examples/encode.rs:95-102 de-interleaves on the host): two strided 16-bit loads per word
+            LC3_HBM_CONST(uint16_t) p16 = (LC3_HBM_CONST(uint16_t))pcm;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = lane + LC3_WAVE * u;
+                v[u] = i < nf / 2 ? (uint32_t)p16[(size_t)(2 * i) * (size_t)stride] | ((uint32_t)p16[(size_t)(2 * i + 1) * (size_t)stride] << 16) : 0u;
+            }
         }
+        if (hstride == 1) {
 #pragma unroll
-        for (int u = 0; u < 3; u++) {
-            const int i = lane + LC3_WAVE * u;
-            hv[u] = (hist && i < (nf - z) / 2) ? h32[i] : 0u;
+            for (int u = 0; u < 3; u++) {
+                const int i = lane + LC3_WAVE * u;
+                hv[u] = (hist && i < (nf - z) / 2) ? h32[i] : 0u;
+            }
+        } else {
+            LC3_HBM_CONST(uint16_t) h16 = (LC3_HBM_CONST(uint16_t))hist;
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int i = lane + LC3_WAVE * u;
+                hv[u] = (hist && i < (nf - z) / 2)
+                            ? (uint32_t)h16[(size_t)(2 * i) * (size_t)hstride] | ((uint32_t)h16[(size_t)(2 * i + 1) * (size_t)hstride] << 16)
+                            : 0u;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 3; u++) {
@@ -1576,11 +1609,11 @@ LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PAR
 // stores nothing.  dbg (optional): float[1472] stage dumps.
 LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const int16_t *pcm,
                                                       const int16_t *hist, lc3_enc_state *g, float *mid, int32_t *plane,
-                                                      int plane_stride, int nbytes, float *dbg) {
+                                                      int plane_stride, int nbytes, float *dbg, int stride = 1, int hstride = 1) {
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
-    const int near_nyquist = lc3_enc_mdct(LC3_CFG_PASS, LC3_LDS_PASS lane, pcm, hist);
+    const int near_nyquist = lc3_enc_mdct(LC3_CFG_PASS, LC3_LDS_PASS lane, pcm, hist, stride, hstride);
     LC3_STAMP(L, lane, 1);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[i] = L.spec[i];
     int nbits_bw;

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -267,17 +268,71 @@ __device__ unsigned long long lc3_prof_acc[64];  // 0..31 stage sums; 32/33/34 e
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
+// How a launch finds a stream's PCM, frame bytes and bad-frame flags.  Three buffer layouts (stream s, frame t, T frames):
+//   planar       int16[stream][frame][nf], uint8[stream][frame][nbytes], flags[stream][frame]                (default)
+//   interleaved  int16[frame][nf][ilv streams], uint8[frame][ilv][nbytes], flags[frame][ilv]: the WAV / .lc3 file order the
+//                reference's callers convert from and to on the host (examples/encode.rs:95-115, examples/decode.rs:86-112)
+//   ragged       a mixed-configuration handle: stream i's PCM at element T * tab[i].pcm_off1, its bytes at T * tab[i].byte_off1,
+//                its flags at tab[i].flag_idx * T (the streams in the caller's order, each planar)
+struct lc3_stream_io {
+    long long pcm_off1, byte_off1;  // per frame of the batch: sum of nf / of nbytes over the caller's earlier streams
+    int flag_idx, pad;              // the stream's index in the caller's order
+};
+struct lc3_io {
+    int ilv;
+    const lc3_stream_io *tab;  // indexed by the handle's internal stream index (first_channel + s)
+};
+__device__ __forceinline__ const int16_t *lc3_io_pcm(const lc3_io &io, const int16_t *pcm, int nf, int first, int s, int t, int T,
+                                                     int *stride) {
+    *stride = 1;
+    if (io.tab) return pcm + (size_t)T * (size_t)io.tab[first + s].pcm_off1 + (size_t)t * (size_t)nf;
+    if (io.ilv) {
+        *stride = io.ilv;
+        return pcm + (size_t)t * (size_t)nf * (size_t)io.ilv + (size_t)s;
+    }
+    return pcm + ((size_t)s * (size_t)T + (size_t)t) * (size_t)nf;
+}
+__device__ __forceinline__ size_t lc3_io_byte_off(const lc3_io &io, int nbytes, int first, size_t s, size_t t, int T) {
+    if (io.tab) return (size_t)T * (size_t)io.tab[(size_t)first + s].byte_off1 + t * (size_t)nbytes;
+    if (io.ilv) return (t * (size_t)io.ilv + s) * (size_t)nbytes;
+    return (s * (size_t)T + t) * (size_t)nbytes;
+}
+__device__ __forceinline__ size_t lc3_io_flag_idx(const lc3_io &io, int first, size_t s, size_t t, int T) {
+    if (io.tab) return (size_t)io.tab[(size_t)first + s].flag_idx * (size_t)T + t;
+    if (io.ilv) return t * (size_t)io.ilv + s;
+    return s * (size_t)T + t;
+}
+
+// A mixed-configuration handle keeps its streams sorted by configuration; a "group" is one run of streams of equal
+// (rate, duration, frame bytes).  Every kernel of a mixed batch is ONE launch: a workgroup finds its group from its index.
+#define LC3_MAX_GROUPS 24
+struct lc3_group {
+    int slot, fixed;              // configuration slot; 1 = the compile-time view (48 kHz / 10 ms) applies
+    int first_stream, n_streams;  // [first_stream, first_stream + n_streams) in the handle's internal order
+    int wg_stream, wg_frame;      // the group's first workgroup in a stream-kernel / frame-kernel launch
+    int nbytes, ne, nb, pad;
+    long long frame_base;         // first plane column of the group
+};
+struct lc3_groups {
+    int n, pad;
+    lc3_group g[LC3_MAX_GROUPS];
+};
+__device__ __forceinline__ int lc3_find_group(const lc3_groups &G, unsigned wg, int frame_kernel) {
+    int gi = 0;
+    while (gi + 1 < G.n && wg >= (unsigned)(frame_kernel ? G.g[gi + 1].wg_frame : G.g[gi + 1].wg_stream)) gi++;
+    return __builtin_amdgcn_readfirstlane(gi);
+}
+
 // Analysis, front half: one wave per stream (four streams per workgroup): MDCT, band energies, bandwidth, attack,
 // SNS targets, LTPF analysis.  Leaves the mid-plane column (spectrum, targets, flags) and the first packer-plane words.
 template <class CV>
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_kernel(lc3_cfg_slot<CV> cfg, lc3_enc_state *states,
-                                                                             int first_channel, int n_streams,
-                                                                             const int16_t *pcm, float *mid, int32_t *planes,
-                                                                             int nbytes, int n_frames, int fresh, float *dbg) {
+__device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigned wg, lc3_enc_state *states, int first_channel,
+                                                   int n_streams, const int16_t *pcm, float *mid, int32_t *planes, int nbytes,
+                                                   int n_frames, int fresh, float *dbg, lc3_io io) {
     const int lane = threadIdx.x & 63, wave = LC3_WAVE_ID();
     lc3_enc_lds &L = lc3_enc_wg[wave];
     // stream index inside this launch; the waves past the end of the launch shadow the last stream and store nothing
-    const int s_raw = blockIdx.x * LC3_WG_WAVES + wave;
+    const int s_raw = (int)wg * LC3_WG_WAVES + wave;
     const int valid = s_raw < n_streams;
     const int s = valid ? s_raw : n_streams - 1;
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
@@ -292,23 +347,48 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_kernel(lc3
         const size_t f = (size_t)s * (size_t)n_frames + (size_t)t;
         int32_t *plane = valid ? LC3_PLANE_COL(planes, f, EP_WORDS) : nullptr;
         float *mcol = valid ? mid + f * (size_t)MP_WORDS : nullptr;
-        const int16_t *frame = pcm + f * (size_t)nf;
+        int stride;
+        const int16_t *frame = lc3_io_pcm(io, pcm, nf, first_channel, s, t, n_frames, &stride);
         // MDCT history: the tail of the previous frame of this launch, else the state blob's copy (silence when fresh)
-        const int16_t *hist = t > 0 ? frame - nf + z : (fresh ? nullptr : gst->hist);
-        lc3_encode_front_wave(cfg, L, lane, frame, hist, gst, mcol, plane, LC3_PLANE_STRIDE, nbytes, valid ? dbg : nullptr);
+        const int16_t *hist = t > 0 ? frame - (size_t)(nf - z) * (size_t)stride : (fresh ? nullptr : gst->hist);
+        lc3_encode_front_wave(cfg, L, lane, frame, hist, gst, mcol, plane, LC3_PLANE_STRIDE, nbytes, valid ? dbg : nullptr, stride,
+                              t > 0 ? stride : 1);
     }
-    if (valid)
-        lc3_enc_state_store(c0, L, lane, gst,
-                            n_frames > 0 ? pcm + ((size_t)s * (size_t)n_frames + (size_t)(n_frames - 1)) * (size_t)nf : nullptr);
+    if (valid) {
+        int stride = 1;
+        const int16_t *last = n_frames > 0 ? lc3_io_pcm(io, pcm, nf, first_channel, s, n_frames - 1, n_frames, &stride) : nullptr;
+        lc3_enc_state_store(c0, L, lane, gst, last, stride);
+    }
     LC3_PROF_END(L, lane, 32);
+}
+template <class CV>
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_kernel(lc3_cfg_slot<CV> cfg, lc3_enc_state *states,
+                                                                             int first_channel, int n_streams,
+                                                                             const int16_t *pcm, float *mid, int32_t *planes,
+                                                                             int nbytes, int n_frames, int fresh, float *dbg,
+                                                                             lc3_io io) {
+    lc3_enc_front_body<CV>(cfg, blockIdx.x, states, first_channel, n_streams, pcm, mid, planes, nbytes, n_frames, fresh, dbg, io);
+}
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_mixed_kernel(lc3_groups G, lc3_enc_state *states,
+                                                                                   const int16_t *pcm, float *mid, int32_t *planes,
+                                                                                   int n_frames, int fresh, lc3_io io) {
+    const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
+    float *m = mid + (size_t)g.frame_base * (size_t)MP_WORDS;
+    int32_t *p = planes + (size_t)g.frame_base * (size_t)EP_WORDS;
+    if (g.fixed)
+        lc3_enc_front_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
+                                          g.n_streams, pcm, m, p, g.nbytes, n_frames, fresh, nullptr, io);
+    else
+        lc3_enc_front_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
+                                        g.n_streams, pcm, m, p, g.nbytes, n_frames, fresh, nullptr, io);
 }
 
 // SNS vector quantiser, one LANE per frame (lc3_dev_enc_vq.h): 16 targets -> indices (packer plane) + 64 band gains.
-__global__ __launch_bounds__(256) void lc3_sns_vq_kernel(int nb, float *mid, int32_t *planes, int n_frames) {
+__device__ __forceinline__ void lc3_sns_vq_body(unsigned wg, int nb, float *mid, int32_t *planes, int n_frames) {
     __shared__ uint32_t s_mpvq[16 * 11];
     for (int i = threadIdx.x; i < 16 * 11; i += blockDim.x) s_mpvq[i] = LC3T_MPVQ_OFFSETS[i / 11][i % 11];
     __syncthreads();
-    const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t f = (size_t)wg * blockDim.x + threadIdx.x;
     if (f < (size_t)n_frames) {
         lc3_vq_ctx v;
         v.mid = mid + f * (size_t)MP_WORDS;
@@ -320,17 +400,24 @@ __global__ __launch_bounds__(256) void lc3_sns_vq_kernel(int nb, float *mid, int
         lc3_sns_vq_frame(v);
     }
 }
+__global__ __launch_bounds__(256) void lc3_sns_vq_kernel(int nb, float *mid, int32_t *planes, int n_frames) {
+    lc3_sns_vq_body(blockIdx.x, nb, mid, planes, n_frames);
+}
+__global__ __launch_bounds__(256) void lc3_sns_vq_mixed_kernel(lc3_groups G, float *mid, int32_t *planes, int n_frames) {
+    const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
+    lc3_sns_vq_body(blockIdx.x - g.wg_frame, g.nb, mid + (size_t)g.frame_base * (size_t)MP_WORDS,
+                    planes + (size_t)g.frame_base * (size_t)EP_WORDS, g.n_streams * n_frames);
+}
 
 // Analysis, back half: one wave per stream: spectral shaping with the quantised gains, TNS, quantiser (stateful),
 // residual bits, noise level.  Completes the packer plane column.
 template <class CV>
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_back_kernel(lc3_cfg_slot<CV> cfg, lc3_enc_state *states,
-                                                                            int first_channel, int n_streams,
-                                                                            const float *mid, int32_t *planes, int nbytes,
-                                                                            int n_frames, float *dbg) {
+__device__ __forceinline__ void lc3_enc_back_body(lc3_cfg_slot<CV> cfg, unsigned wg, lc3_enc_state *states, int first_channel,
+                                                  int n_streams, const float *mid, int32_t *planes, int nbytes, int n_frames,
+                                                  float *dbg) {
     const int lane = threadIdx.x & 63, wave = LC3_WAVE_ID();
     lc3_enc_lds &L = lc3_enc_wg[wave];
-    const int s_raw = blockIdx.x * LC3_WG_WAVES + wave;
+    const int s_raw = (int)wg * LC3_WG_WAVES + wave;
     const int valid = s_raw < n_streams;
     const int s = valid ? s_raw : n_streams - 1;
     lc3_enc_state *gst = states + (size_t)(first_channel + s);
@@ -359,19 +446,41 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_bac
     if (valid) lc3_enc_state_store(c0, L, lane, gst, nullptr);
     LC3_PROF_END(L, lane, 32);
 }
+template <class CV>
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_back_kernel(lc3_cfg_slot<CV> cfg, lc3_enc_state *states,
+                                                                            int first_channel, int n_streams,
+                                                                            const float *mid, int32_t *planes, int nbytes,
+                                                                            int n_frames, float *dbg) {
+    lc3_enc_back_body<CV>(cfg, blockIdx.x, states, first_channel, n_streams, mid, planes, nbytes, n_frames, dbg);
+}
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_back_mixed_kernel(lc3_groups G, lc3_enc_state *states,
+                                                                                                const float *mid, int32_t *planes,
+                                                                                                int n_frames) {
+    const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
+    const float *m = mid + (size_t)g.frame_base * (size_t)MP_WORDS;
+    int32_t *p = planes + (size_t)g.frame_base * (size_t)EP_WORDS;
+    if (g.fixed)
+        lc3_enc_back_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
+                                         g.n_streams, m, p, g.nbytes, n_frames, nullptr);
+    else
+        lc3_enc_back_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
+                                       g.n_streams, m, p, g.nbytes, n_frames, nullptr);
+}
 
 // Bitstream packer, one LANE per frame (lc3_dev_enc_pack.h).  blockDim.x frames per workgroup; context lookup and the
 // packed spectral model in LDS, every lane builds its frame in an LDS staging slot, then the workgroup copies the
-// frames out with coalesced stores.  Dynamic LDS: 4096 + 64*17*4 + 152*4 (TNS models) + blockDim.x * nbytes (rounded up to 4) + 4 (sink).
-__global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *planes, uint8_t *out, int nbytes,
-                                                       int n_frames) {
+// frames out with coalesced stores (planar layout: one contiguous run; other layouts: frame by frame).
+// Dynamic LDS: 4096 + 64*17*4 + 152*4 (TNS models) + blockDim.x * nbytes (rounded up to 4) + 4 (sink).
+#define LC3_PACK_LDS_FIXED (4096 + 64 * 17 * 4 + LC3_TNS_MODEL_WORDS * 4)
+__device__ __forceinline__ void lc3_pack_body(unsigned wg, int ne, const int32_t *planes, uint8_t *out, int nbytes, int n_frames,
+                                              int T, int first_channel, lc3_io io) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_lookup = smem;
     uint32_t *s_cf = (uint32_t *)(smem + 4096);
     uint32_t *s_tns = (uint32_t *)(smem + 4096 + 64 * 17 * 4);
-    uint8_t *s_bytes = smem + 4096 + 64 * 17 * 4 + LC3_TNS_MODEL_WORDS * 4;
+    uint8_t *s_bytes = smem + LC3_PACK_LDS_FIXED;
     const int tid = threadIdx.x, fpb = blockDim.x;
-    const size_t f0 = (size_t)blockIdx.x * (size_t)fpb;
+    const size_t f0 = (size_t)wg * (size_t)fpb;
     const size_t remaining = (size_t)n_frames - f0;
     const int nfr = remaining < (size_t)fpb ? (int)remaining : fpb;
     const int total = nfr * nbytes;
@@ -417,14 +526,22 @@ __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *pl
     pk_t2 = clock64();
 #endif
     __syncthreads();
-    uint8_t *dst = out + f0 * (size_t)nbytes;
-    if ((((uintptr_t)dst) & 3u) == 0) {
-        const uint32_t *b32 = (const uint32_t *)s_bytes;
-        uint32_t *d32 = (uint32_t *)dst;
-        for (int i = tid; i < total / 4; i += fpb) d32[i] = b32[i];
-        for (int i = (total & ~3) + tid; i < total; i += fpb) dst[i] = s_bytes[i];
+    if (io.ilv || io.tab) {  // frame f = s * T + t has its own place: one frame after the other, its bytes spread over the threads
+        for (int j = 0; j < nfr; j++) {
+            const size_t fj = f0 + (size_t)j, s = fj / (size_t)T, t = fj - s * (size_t)T;
+            uint8_t *d = out + lc3_io_byte_off(io, nbytes, first_channel, s, t, T);
+            for (int b = tid; b < nbytes; b += fpb) d[b] = s_bytes[j * nbytes + b];
+        }
     } else {
-        for (int i = tid; i < total; i += fpb) dst[i] = s_bytes[i];
+        uint8_t *dst = out + f0 * (size_t)nbytes;
+        if ((((uintptr_t)dst) & 3u) == 0) {
+            const uint32_t *b32 = (const uint32_t *)s_bytes;
+            uint32_t *d32 = (uint32_t *)dst;
+            for (int i = tid; i < total / 4; i += fpb) d32[i] = b32[i];
+            for (int i = (total & ~3) + tid; i < total; i += fpb) dst[i] = s_bytes[i];
+        } else {
+            for (int i = tid; i < total; i += fpb) dst[i] = s_bytes[i];
+        }
     }
 #ifdef LC3_PROFILE
     if ((tid & 63) == 0 && pk_t1) {  // 48: staging; 49..53: sections of lc3_pack_frame; 54: barrier wait + copy-out; 55: waves
@@ -436,17 +553,25 @@ __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *pl
     }
 #endif
 }
+__global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *planes, uint8_t *out, int nbytes, int n_frames, int T,
+                                                       lc3_io io) {
+    lc3_pack_body(blockIdx.x, ne, planes, out, nbytes, n_frames, T, 0, io);
+}
+__global__ __launch_bounds__(256) void lc3_pack_mixed_kernel(lc3_groups G, const int32_t *planes, uint8_t *out, int T, lc3_io io) {
+    const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
+    lc3_pack_body(blockIdx.x - g.wg_frame, g.ne, planes + (size_t)g.frame_base * (size_t)EP_WORDS, out, g.nbytes, g.n_streams * T, T,
+                  g.first_stream, io);
+}
 
-// Frame parser, one LANE per frame (lc3_dev_dec_parse.h).  256 frames per workgroup; the context lookup, the packed
-// (cum | freq) spectral model and the frames' bytes are staged in LDS with coalesced loads.  blockDim.x frames per
-// workgroup (256, or 128 for frames above 220 bytes so that the staging fits 64 KB of dynamic LDS):
-// 4096 + 64*17*4 + blockDim.x*nbytes bytes.
+// Frame parser, one LANE per frame (lc3_dev_dec_parse.h).  blockDim.x frames per workgroup (256, fewer for long frames so that
+// the staging fits 64 KB of dynamic LDS); the context lookup, the packed (cum | freq) spectral model and the frames' bytes are
+// staged in LDS with coalesced loads.
 // Dynamic LDS: 4096 (context lookup) + 64*20*4 (spectral model, lc3_dcf_word) + 16*11*4 (MPVQ offsets) + 152*4 (TNS models) + 144 (band index table) + 16*4*blockDim.x (scale
 // factors, [n][lane]) + blockDim.x * nbytes (frame bytes).
 #define LC3_PARSE_LDS_FIXED (4096 + 64 * LC3_DCF_ROW_WORDS * 4 + 16 * 11 * 4 + 4 * 152 + 144)
 template <class CV>
-__global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot<CV> cfg, const uint8_t *in, const uint8_t *bad,
-                                                        int32_t *planes, int nbytes, int n_frames) {
+__device__ __forceinline__ void lc3_parse_body(lc3_cfg_slot<CV> cfg, unsigned wg, const uint8_t *in, const uint8_t *bad,
+                                               int32_t *planes, int nbytes, int n_frames, int T, int first_channel, lc3_io io) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const int ne = c0.ne, fs_ind = c0.fs_ind, n_ms_10 = c0.n_ms_10;
@@ -458,7 +583,7 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot<CV> cfg, co
     uint16_t *s_ifs = (uint16_t *)(smem + 4096 + 64 * LC3_DCF_ROW_WORDS * 4 + 16 * 11 * 4 + 4 * 152);  // 65 entries, 144 bytes reserved
     float *s_scf = (float *)(smem + LC3_PARSE_LDS_FIXED);
     uint8_t *s_bytes = smem + LC3_PARSE_LDS_FIXED + 16 * 4 * fpb;
-    const size_t f0 = (size_t)blockIdx.x * (size_t)fpb;
+    const size_t f0 = (size_t)wg * (size_t)fpb;
     {
         for (int i = tid; i < 16 * 11; i += fpb) s_mpvq[i] = LC3T_MPVQ_OFFSETS[i / 11][i % 11];
         for (int i = tid; i < LC3_TNS_MODEL_WORDS; i += fpb) s_tns[i] = lc3_tns_model_word(i);
@@ -471,7 +596,13 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot<CV> cfg, co
         const int nfr = remaining < (size_t)fpb ? (int)remaining : fpb;
         const int total = nfr * nbytes;
         const uint8_t *src = in + f0 * (size_t)nbytes;
-        if ((((uintptr_t)src) & 3u) == 0) {
+        if (io.ilv || io.tab) {  // frame f = s * T + t is fetched from its own place (examples/decode.rs:86-92 for the file order)
+            for (int j = 0; j < nfr; j++) {
+                const size_t fj = f0 + (size_t)j, s = fj / (size_t)T, t = fj - s * (size_t)T;
+                const uint8_t *q = in + lc3_io_byte_off(io, nbytes, first_channel, s, t, T);
+                for (int b = tid; b < nbytes; b += fpb) s_bytes[j * nbytes + b] = q[b];
+            }
+        } else if ((((uintptr_t)src) & 3u) == 0) {
             const uint32_t *s32 = (const uint32_t *)src;
             uint32_t *b32 = (uint32_t *)s_bytes;
             for (int i = tid; i < total / 4; i += fpb) b32[i] = s32[i];
@@ -497,7 +628,8 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot<CV> cfg, co
         for (int i = 0; i < 8; i++) c.pt[i] = 0;
         c.plast = clock64();
 #endif
-        const int rc = (bad && bad[f]) ? -100 : lc3_parse_frame(c, ne, fs_ind, n_ms_10);
+        const size_t fb = lc3_io_flag_idx(io, first_channel, f / (size_t)T, f % (size_t)T, T);  // the flag array follows the frame layout
+        const int rc = (bad && bad[fb]) ? -100 : lc3_parse_frame(c, ne, fs_ind, n_ms_10);
         int ok = rc == 0;
         if (ok) {
             lc3_recon_ctx r;
@@ -515,17 +647,32 @@ __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot<CV> cfg, co
 #endif
     }
 }
+template <class CV>
+__global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot<CV> cfg, const uint8_t *in, const uint8_t *bad,
+                                                        int32_t *planes, int nbytes, int n_frames, int T, lc3_io io) {
+    lc3_parse_body<CV>(cfg, blockIdx.x, in, bad, planes, nbytes, n_frames, T, 0, io);
+}
+__global__ __launch_bounds__(256) void lc3_parse_mixed_kernel(lc3_groups G, const uint8_t *in, const uint8_t *bad, int32_t *planes,
+                                                              int T, lc3_io io) {
+    const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
+    int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
+    if (g.fixed)
+        lc3_parse_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_frame, in, bad, p, g.nbytes,
+                                      g.n_streams * T, T, g.first_stream, io);
+    else
+        lc3_parse_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_frame, in, bad, p, g.nbytes, g.n_streams * T,
+                                    T, g.first_stream, io);
+}
 
 template <class CV>
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_kernel(lc3_cfg_slot<CV> cfg, lc3_dec_state *states,
-                                                                          int first_channel, int n_streams,
-                                                                          const uint8_t *in, const int32_t *planes,
-                                                                          int16_t *pcm, int nbytes, int n_frames, int fresh) {
+__device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned wg, lc3_dec_state *states, int first_channel,
+                                                int n_streams, const int32_t *planes, int16_t *pcm, int nbytes, int n_frames,
+                                                int fresh, lc3_io io) {
     const int lane = threadIdx.x & 63, wave = LC3_WAVE_ID();
     lc3_dec_lds &L = lc3_dec_wg[wave];
-    const int s_raw = blockIdx.x * LC3_WG_WAVES + wave;
+    const int s_raw = (int)wg * LC3_WG_WAVES + wave;
     const int valid = s_raw < n_streams;
-    const int s = valid ? s_raw : n_streams - 1;  // see lc3_enc_front_kernel
+    const int s = valid ? s_raw : n_streams - 1;  // see lc3_enc_front_body
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const int nf = c0.nf;
     lc3_dec_state *gst = states + (size_t)(first_channel + s);
@@ -534,19 +681,39 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_kernel(lc3_cf
     if (fresh) lc3_dec_state_init(L, lane, gst, valid);
     else lc3_dec_state_load(L, lane, gst);
     LC3_PROF_MARK(L, lane, 38);  // state load
-    (void)in;  // the frame bytes were consumed by the lane-per-frame stage
     const size_t fbase = (size_t)s * (size_t)n_frames;
     lc3_plane_fetch cur, nxt;
     if (n_frames > 0) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, fbase, LC3_PLANE_WORDS), cur);
     for (int t = 0; t < n_frames; t++) {
         const size_t f = fbase + (size_t)t;
         if (t + 1 < n_frames) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, f + 1, LC3_PLANE_WORDS), nxt);
-        lc3_decode_frame_wave(cfg, L, lane, nbytes, pcm + f * (size_t)nf, cur, gst, valid);
+        int stride;
+        int16_t *out = (int16_t *)lc3_io_pcm(io, pcm, nf, first_channel, s, t, n_frames, &stride);
+        lc3_decode_frame_wave(cfg, L, lane, nbytes, out, cur, gst, valid, stride);
         cur = nxt;
     }
     LC3_PROF_MARK(L, lane, 39);  // frames (incl. everything between the stage stamps)
     if (valid) lc3_dec_state_store(L, lane, gst);
     LC3_PROF_END(L, lane, 35);
+}
+template <class CV>
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_kernel(lc3_cfg_slot<CV> cfg, lc3_dec_state *states,
+                                                                          int first_channel, int n_streams, const int32_t *planes,
+                                                                          int16_t *pcm, int nbytes, int n_frames, int fresh,
+                                                                          lc3_io io) {
+    lc3_decode_body<CV>(cfg, blockIdx.x, states, first_channel, n_streams, planes, pcm, nbytes, n_frames, fresh, io);
+}
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_mixed_kernel(lc3_groups G, lc3_dec_state *states,
+                                                                                const int32_t *planes, int16_t *pcm, int n_frames,
+                                                                                int fresh, lc3_io io) {
+    const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
+    const int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
+    if (g.fixed)
+        lc3_decode_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
+                                       g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io);
+    else
+        lc3_decode_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams,
+                                     p, pcm, g.nbytes, n_frames, fresh, io);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -570,7 +737,7 @@ struct HostCfg {
     int slot = 0;    // its slot in lc3_cfg_table
     bool fixed = false;  // launch the lc3_cfg_48k10 instantiations (compile-time configuration)
 };
-// launches kern<view>(slot, args...) with the view the handle's configuration allows
+// launches kern<view>(slot, args...) with the view the configuration allows
 #define LC3_LAUNCH_CFG(kern, h, grid, block, lds, stream, ...)                                                                   \
     do {                                                                                                                         \
         if ((h).fixed)                                                                                                           \
@@ -608,6 +775,32 @@ struct CfgRegistry {
 };
 CfgRegistry g_cfgs;
 
+// uploads the tables of one configuration into `base` (owned by the caller until success)
+int cfg_upload(lc3_cfg &c, const lc3_host_plan &pl, char *base, size_t bytes_tw, size_t bytes_perm, size_t bytes_poly, size_t bytes_lw,
+               int slot) {
+    HIP_TRY(hipMemcpy(base, pl.fft_tw.data(), bytes_tw, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + bytes_tw, pl.dct_tw.data(), bytes_tw, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + 2 * bytes_tw, pl.perm.data(), sizeof(uint16_t) * (size_t)c.nfft, hipMemcpyHostToDevice));
+    float *poly = (float *)(base + 2 * bytes_tw + bytes_perm);
+    float *lw = (float *)(base + 2 * bytes_tw + bytes_perm + bytes_poly);
+    uint8_t *lb = (uint8_t *)(base + 2 * bytes_tw + bytes_perm + bytes_poly + bytes_lw);
+    hipLaunchKernelGGL(lc3_resamp_poly_kernel, dim3(1), dim3(256), 0, nullptr, poly, c.p_up, c.resamp_lim, c.resamp_stride);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(lc3_line_width_kernel, dim3(1), dim3(256), 0, nullptr, lw, c);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(lc3_line_band_kernel, dim3(1), dim3(256), 0, nullptr, lb, c);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    c.fft_tw = (const lc3_cpx *)base;
+    c.dct_tw = (const lc3_cpx *)(base + bytes_tw);
+    c.perm = (const uint16_t *)(base + 2 * bytes_tw);
+    c.resamp_poly = poly;
+    c.line_width = lw;
+    c.line_band = lb;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lc3_cfg_table), &c, sizeof(c), sizeof(c) * (size_t)slot, hipMemcpyHostToDevice));
+    return LC3GPU_OK;
+}
+
 int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
     static const int fs_tab[6] = {8000, 16000, 24000, 32000, 44100, 48000};
     int k = -1;
@@ -630,26 +823,11 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
         const size_t bytes_lb = ((size_t)c.nf + 15) & ~(size_t)15;
         char *base = nullptr;
         HIP_TRY(hipMalloc((void **)&base, 2 * bytes_tw + bytes_perm + bytes_poly + bytes_lw + bytes_lb));
-        HIP_TRY(hipMemcpy(base, pl.fft_tw.data(), bytes_tw, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(base + bytes_tw, pl.dct_tw.data(), bytes_tw, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(base + 2 * bytes_tw, pl.perm.data(), sizeof(uint16_t) * (size_t)c.nfft, hipMemcpyHostToDevice));
-        float *poly = (float *)(base + 2 * bytes_tw + bytes_perm);
-        float *lw = (float *)(base + 2 * bytes_tw + bytes_perm + bytes_poly);
-        hipLaunchKernelGGL(lc3_resamp_poly_kernel, dim3(1), dim3(256), 0, nullptr, poly, c.p_up, c.resamp_lim, c.resamp_stride);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(lc3_line_width_kernel, dim3(1), dim3(256), 0, nullptr, lw, c);
-        HIP_TRY(hipGetLastError());
-        uint8_t *lb = (uint8_t *)(base + 2 * bytes_tw + bytes_perm + bytes_poly + bytes_lw);
-        hipLaunchKernelGGL(lc3_line_band_kernel, dim3(1), dim3(256), 0, nullptr, lb, c);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(nullptr));
-        c.fft_tw = (const lc3_cpx *)base;
-        c.dct_tw = (const lc3_cpx *)(base + bytes_tw);
-        c.perm = (const uint16_t *)(base + 2 * bytes_tw);
-        c.resamp_poly = poly;
-        c.line_width = lw;
-        c.line_band = lb;
-        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lc3_cfg_table), &c, sizeof(c), sizeof(c) * (size_t)slot, hipMemcpyHostToDevice));
+        const int rc = cfg_upload(c, pl, base, bytes_tw, bytes_perm, bytes_poly, bytes_lw, slot);
+        if (rc) {
+            (void)hipFree(base);  // nothing published: the slot stays unregistered
+            return rc;
+        }
         g_cfgs.cfg[dev][slot] = c;
         g_cfgs.ready[dev][slot] = true;
     }
@@ -661,64 +839,248 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
     return LC3GPU_OK;
 }
 
-}  // namespace
-
-// optional per-kernel timing with HIP events recorded on the launch stream (bench.py roofline)
+// optional per-kernel timing with HIP events recorded on the launch stream (bench.py roofline).  Events come from a pool
+// that lives as long as the handle: nothing is created inside a timed region once the pool has warmed up.
 struct KernelTimer {
     bool enabled = false;
     int stages = 2;               // kernels per batch call: stages + 1 events per call
-    std::vector<hipEvent_t> ev;
+    std::vector<hipEvent_t> pool;  // every event ever created for this handle
+    size_t used = 0;               // events of the pool holding a recorded mark
     double ms[4] = {0.0, 0.0, 0.0, 0.0};
     long launches = 0;
     void mark(hipStream_t s) {
         if (!enabled) return;
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return;
-        (void)hipEventRecord(e, s);
-        ev.push_back(e);
+        if (used == pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            pool.push_back(e);
+        }
+        (void)hipEventRecord(pool[used++], s);
     }
-    // synchronises; folds the recorded event groups into ms[] and clears them
+    // synchronises; folds the recorded event groups into ms[] and returns the events to the pool
     void collect() {
         const size_t grp = (size_t)stages + 1;
-        for (size_t i = 0; i + grp <= ev.size(); i += grp) {
-            (void)hipEventSynchronize(ev[i + grp - 1]);
+        for (size_t i = 0; i + grp <= used; i += grp) {
+            (void)hipEventSynchronize(pool[i + grp - 1]);
             float d[4] = {0.f, 0.f, 0.f, 0.f};
             bool ok = true;
-            for (int k = 0; k < stages; k++) ok = ok && hipEventElapsedTime(&d[k], ev[i + k], ev[i + k + 1]) == hipSuccess;
+            for (int k = 0; k < stages; k++) ok = ok && hipEventElapsedTime(&d[k], pool[i + k], pool[i + k + 1]) == hipSuccess;
             if (ok) {
                 for (int k = 0; k < stages; k++) ms[k] += d[k];
                 launches += 1;
             }
         }
-        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-        ev.clear();
+        used = 0;
+    }
+    void release() {
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+        used = 0;
     }
 };
 
-struct lc3gpu_encoder {
-    KernelTimer timer;
+// makes the handle's device current for the duration of a call (handles are bound to the device they were created on)
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { ok = false; return; }
+        if (cur != dev) {
+            if (hipSetDevice(dev) != hipSuccess) { ok = false; return; }
+            prev = cur;
+        }
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define LC3_ON_DEVICE(h)                      \
+    DeviceGuard guard_((h)->device);          \
+    if (!guard_.ok) return LC3GPU_EHIP
+
+// one stream of a mixed-configuration handle, in the caller's order
+struct MixedStream {
+    int group = 0, internal = 0;  // its group and its index in the handle's internal (sorted) order
+};
+struct GroupHost {
     HostCfg h;
+    int nbytes = 0, first_stream = 0, n_streams = 0;
+};
+
+// what encoder and decoder handles share: the device binding, the ordering of launches across HIP streams (every launch of a
+// handle uses the handle's plane buffers: a launch on another stream than the previous one first waits for it), the timer,
+// and the description of a mixed-configuration handle
+struct HandleCommon {
+    int device = 0;
+    KernelTimer timer;
+    HostCfg h;  // the configuration of a uniform handle
     int num_channels = 0;
+    bool mixed = false;
+    std::vector<GroupHost> groups;
+    std::vector<MixedStream> streams;      // caller order
+    std::vector<int> caller_of_internal;   // internal index -> caller index
+    lc3_stream_io *d_tab = nullptr;        // per internal stream
+    hipStream_t last_stream = nullptr;
+    hipEvent_t done = nullptr;
+    bool has_work = false;
+
+    int order_begin(hipStream_t s) {
+        if (has_work && s != last_stream) HIP_TRY(hipStreamWaitEvent(s, done, 0));
+        return LC3GPU_OK;
+    }
+    int order_end(hipStream_t s) {
+        HIP_TRY(hipEventRecord(done, s));
+        last_stream = s;
+        has_work = true;
+        return LC3GPU_OK;
+    }
+    // host waits for everything the handle has launched
+    int quiesce() {
+        if (has_work) HIP_TRY(hipEventSynchronize(done));
+        return LC3GPU_OK;
+    }
+    const HostCfg &cfg_of_channel(int ch) const { return mixed ? groups[(size_t)streams[(size_t)ch].group].h : h; }
+    int internal_of_channel(int ch) const { return mixed ? streams[(size_t)ch].internal : ch; }
+    void release_common() {
+        timer.release();
+        if (done) (void)hipEventDestroy(done);
+        if (d_tab) (void)hipFree(d_tab);
+        done = nullptr;
+        d_tab = nullptr;
+    }
+};
+
+// Grows a device buffer in stream order: the new block is allocated and the old one freed on `stream`, which (order_begin)
+// already waits for every earlier launch of the handle -- no device-wide synchronisation in the middle of a pipeline.
+template <class T>
+int grow_async(T *&p, size_t bytes, hipStream_t stream) {
+    static int async_ok = -1;  // does this runtime have the stream-ordered allocator?  decided at the first allocation
+    if (async_ok != 0) {
+        T *n = nullptr;
+        if (hipMallocAsync((void **)&n, bytes, stream) == hipSuccess) {
+            async_ok = 1;
+            if (p) HIP_TRY(hipFreeAsync(p, stream));
+            p = n;
+            return LC3GPU_OK;
+        }
+        (void)hipGetLastError();
+        if (async_ok == 1) { g_last_hip = (int)hipErrorOutOfMemory; return LC3GPU_EHIP; }
+        async_ok = 0;
+    }
+    // no stream-ordered allocator: the conservative path
+    HIP_TRY(hipDeviceSynchronize());
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    HIP_TRY(hipMalloc((void **)&p, bytes));
+    return LC3GPU_OK;
+}
+
+// sorts the streams of a mixed handle by (configuration slot, frame bytes) and builds groups, tables and mappings
+int build_mixed(HandleCommon &hc, int n, const lc3gpu_stream_desc *descs, bool encoder) {
+    if (!descs || n <= 0) return LC3GPU_EINVAL;
+    struct Key { int slot, nbytes, idx; };
+    std::vector<Key> keys((size_t)n);
+    std::vector<lc3_cfg> cfgs((size_t)n);
+    static const int fs_tab[6] = {8000, 16000, 24000, 32000, 44100, 48000};
+    for (int i = 0; i < n; i++) {
+        int rc = make_config(cfgs[(size_t)i], descs[i].frame_us, descs[i].fs_hz);
+        if (rc) return rc;
+        if (encoder && cfgs[(size_t)i].fs_ind == 0 && descs[i].fs_hz == 8000) return LC3GPU_EUNSUPPORTED;  // bandwidth_detector.rs:36-37
+        if (descs[i].nbytes < (encoder ? 20 : 1) || descs[i].nbytes > LC3_MAX_NE) return LC3GPU_ELENGTH;
+        int k = 0;
+        for (int q = 0; q < 6; q++)
+            if (fs_tab[q] == descs[i].fs_hz) k = q;
+        keys[(size_t)i] = {2 * k + (descs[i].frame_us == 10000), descs[i].nbytes, i};
+    }
+    std::vector<Key> sorted = keys;
+    std::stable_sort(sorted.begin(), sorted.end(), [](const Key &a, const Key &b) { return a.slot != b.slot ? a.slot < b.slot : a.nbytes < b.nbytes; });
+    hc.streams.assign((size_t)n, MixedStream());
+    hc.caller_of_internal.assign((size_t)n, 0);
+    hc.groups.clear();
+    for (int j = 0; j < n; j++) {
+        const Key &k = sorted[(size_t)j];
+        if (hc.groups.empty() || hc.groups.back().h.slot != k.slot || hc.groups.back().nbytes != k.nbytes) {
+            if (hc.groups.size() == LC3_MAX_GROUPS) return LC3GPU_EINVAL;
+            GroupHost g;
+            int rc = cfg_acquire(g.h, descs[k.idx].frame_us, descs[k.idx].fs_hz);
+            if (rc) return rc;
+            g.nbytes = k.nbytes;
+            g.first_stream = j;
+            hc.groups.push_back(g);
+        }
+        hc.groups.back().n_streams += 1;
+        hc.streams[(size_t)k.idx].group = (int)hc.groups.size() - 1;
+        hc.streams[(size_t)k.idx].internal = j;
+        hc.caller_of_internal[(size_t)j] = k.idx;
+    }
+    // per-frame prefix offsets in the caller's order
+    std::vector<lc3_stream_io> tab((size_t)n);
+    long long po = 0, bo = 0;
+    for (int i = 0; i < n; i++) {
+        lc3_stream_io &e = tab[(size_t)hc.streams[(size_t)i].internal];
+        e.pcm_off1 = po;
+        e.byte_off1 = bo;
+        e.flag_idx = i;
+        e.pad = 0;
+        po += cfgs[(size_t)i].nf;
+        bo += descs[i].nbytes;
+    }
+    HIP_TRY(hipMalloc((void **)&hc.d_tab, sizeof(lc3_stream_io) * (size_t)n));
+    HIP_TRY(hipMemcpy(hc.d_tab, tab.data(), sizeof(lc3_stream_io) * (size_t)n, hipMemcpyHostToDevice));
+    hc.mixed = true;
+    hc.num_channels = n;
+    return LC3GPU_OK;
+}
+
+// the group table of one mixed launch (T frames per stream, fpb frames per workgroup of the frame kernels)
+void fill_groups(const HandleCommon &hc, int T, unsigned fpb, lc3_groups &G, unsigned &wg_stream, unsigned &wg_frame, size_t &frames,
+                 int &max_nbytes) {
+    G.n = (int)hc.groups.size();
+    G.pad = 0;
+    wg_stream = wg_frame = 0;
+    frames = 0;
+    max_nbytes = 0;
+    for (size_t i = 0; i < hc.groups.size(); i++) {
+        const GroupHost &gh = hc.groups[i];
+        lc3_group &g = G.g[i];
+        g.slot = gh.h.slot;
+        g.fixed = gh.h.fixed;
+        g.first_stream = gh.first_stream;
+        g.n_streams = gh.n_streams;
+        g.wg_stream = (int)wg_stream;
+        g.wg_frame = (int)wg_frame;
+        g.nbytes = gh.nbytes;
+        g.ne = gh.h.c.ne;
+        g.nb = gh.h.c.nb;
+        g.pad = 0;
+        g.frame_base = (long long)frames;
+        wg_stream += (unsigned)((gh.n_streams + LC3_WG_WAVES - 1) / LC3_WG_WAVES);
+        wg_frame += (unsigned)(((size_t)gh.n_streams * (size_t)T + fpb - 1) / fpb);
+        frames += (size_t)gh.n_streams * (size_t)T;
+        if (gh.nbytes > max_nbytes) max_nbytes = gh.nbytes;
+    }
+}
+
+}  // namespace
+
+struct lc3gpu_encoder : HandleCommon {
     lc3_enc_state *d_states = nullptr;
-    bool fresh = true;  // states not yet materialised in HBM: kernels initialise in LDS
     // staging for the single-frame host API
     int16_t *d_pcm1 = nullptr;
     uint8_t *d_out1 = nullptr;
     float *d_dbg = nullptr;
-    std::vector<uint8_t> fresh_mask;  // per channel: 1 = still fresh
+    std::vector<uint8_t> fresh_mask;  // per channel (internal order): 1 = state not yet materialised in HBM
     int32_t *d_planes = nullptr;      // packer planes, EP_WORDS words per frame
     float *d_mid = nullptr;           // mid planes (front half -> vector quantiser -> back half), MP_WORDS words per frame
     size_t planes_frames = 0;
 };
 
-struct lc3gpu_decoder {
-    KernelTimer timer;
-    HostCfg h;
-    int num_channels = 0;
+struct lc3gpu_decoder : HandleCommon {
     lc3_dec_state *d_states = nullptr;
     uint8_t *d_in1 = nullptr;
     int16_t *d_pcm1 = nullptr;
-    int32_t *d_planes = nullptr;   // parsed-frame planes [blocks of 64 frames][LC3_PLANE_WORDS][64]
+    int32_t *d_planes = nullptr;   // parsed-frame planes, LC3_PLANE_WORDS words per frame
     size_t planes_frames = 0;      // capacity in frames (multiple of 64)
 };
 
@@ -731,13 +1093,36 @@ static unsigned lc3_frame_block(unsigned dflt) {
     }
     return (env == 64 || env == 128 || env == 256) ? (unsigned)env : dflt;
 }
+// ... clamped so that the dynamic LDS (fixed part + per-frame part) fits the default 64 KB
+static unsigned lc3_frame_block_fit(size_t lds_fixed, size_t lds_per_frame) {
+    unsigned fpb = lc3_frame_block(256u);
+    while (fpb > 64u && lds_fixed + (size_t)fpb * lds_per_frame + 8 > 65536u) fpb >>= 1;
+    return fpb;
+}
 
-static int encoder_reserve_planes(lc3gpu_encoder *e, size_t frames);
-static int decoder_reserve_planes(lc3gpu_decoder *d, size_t frames);
+static int encoder_reserve_planes(lc3gpu_encoder *e, size_t frames, hipStream_t stream) {
+    const size_t need = (frames + 63) / 64 * 64;
+    if (need <= e->planes_frames) return LC3GPU_OK;
+    e->planes_frames = 0;
+    int rc = grow_async(e->d_planes, need * (size_t)EP_WORDS * sizeof(int32_t), stream);
+    if (rc == LC3GPU_OK) rc = grow_async(e->d_mid, need * (size_t)MP_WORDS * sizeof(float), stream);
+    if (rc) return rc;
+    e->planes_frames = need;
+    return LC3GPU_OK;
+}
+static int decoder_reserve_planes(lc3gpu_decoder *d, size_t frames, hipStream_t stream) {
+    const size_t need = (frames + 63) / 64 * 64;
+    if (need <= d->planes_frames) return LC3GPU_OK;
+    d->planes_frames = 0;
+    int rc = grow_async(d->d_planes, need * (size_t)LC3_PLANE_WORDS * sizeof(int32_t), stream);
+    if (rc) return rc;
+    d->planes_frames = need;
+    return LC3GPU_OK;
+}
 
 extern "C" {
 
-int lc3gpu_version(void) { return 100; }
+int lc3gpu_version(void) { return 200; }
 
 const char *lc3gpu_strerror(int code) {
     switch (code) {
@@ -800,6 +1185,17 @@ int lc3gpu_decoder_working_buffer_lengths(int num_channels, int frame_us, int fs
 }
 
 // ---------------------------------------------------------------------------------------------
+static int encoder_alloc(lc3gpu_encoder *e) {
+    HIP_TRY(hipGetDevice(&e->device));
+    HIP_TRY(hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void **)&e->d_states, sizeof(lc3_enc_state) * (size_t)e->num_channels));
+    HIP_TRY(hipMalloc((void **)&e->d_pcm1, sizeof(int16_t) * LC3_MAX_NF));
+    HIP_TRY(hipMalloc((void **)&e->d_out1, LC3_MAX_NE));
+    HIP_TRY(hipMalloc((void **)&e->d_dbg, sizeof(float) * 1472));
+    e->fresh_mask.assign((size_t)e->num_channels, 1);
+    return encoder_reserve_planes(e, (size_t)e->num_channels, nullptr);
+}
+
 int lc3gpu_encoder_create(lc3gpu_encoder **out, int num_channels, int frame_us, int fs_hz) {
     if (!out || num_channels <= 0) return LC3GPU_EINVAL;
     *out = nullptr;
@@ -813,17 +1209,20 @@ int lc3gpu_encoder_create(lc3gpu_encoder **out, int num_channels, int frame_us, 
     if (!e) return LC3GPU_EINVAL;
     e->num_channels = num_channels;
     rc = cfg_acquire(e->h, frame_us, fs_hz);
+    if (rc == LC3GPU_OK) rc = encoder_alloc(e);
     if (rc) { lc3gpu_encoder_destroy(e); return rc; }
-    if (hipMalloc((void **)&e->d_states, sizeof(lc3_enc_state) * (size_t)num_channels) != hipSuccess ||
-        hipMalloc((void **)&e->d_pcm1, sizeof(int16_t) * LC3_MAX_NF) != hipSuccess ||
-        hipMalloc((void **)&e->d_out1, LC3_MAX_NE) != hipSuccess ||
-        hipMalloc((void **)&e->d_dbg, sizeof(float) * 1472) != hipSuccess) {
-        lc3gpu_encoder_destroy(e);
-        return LC3GPU_EHIP;
-    }
-    e->fresh = true;
-    e->fresh_mask.assign((size_t)num_channels, 1);
-    rc = encoder_reserve_planes(e, (size_t)num_channels);
+    *out = e;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_encoder_create_mixed(lc3gpu_encoder **out, int n_streams, const lc3gpu_stream_desc *descs) {
+    if (!out || n_streams <= 0 || !descs) return LC3GPU_EINVAL;
+    *out = nullptr;
+    if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
+    lc3gpu_encoder *e = new (std::nothrow) lc3gpu_encoder();
+    if (!e) return LC3GPU_EINVAL;
+    int rc = build_mixed(*e, n_streams, descs, true);
+    if (rc == LC3GPU_OK) rc = encoder_alloc(e);
     if (rc) { lc3gpu_encoder_destroy(e); return rc; }
     *out = e;
     return LC3GPU_OK;
@@ -831,104 +1230,173 @@ int lc3gpu_encoder_create(lc3gpu_encoder **out, int num_channels, int frame_us, 
 
 int lc3gpu_encoder_destroy(lc3gpu_encoder *e) {
     if (!e) return LC3GPU_OK;
-    if (e->d_states) (void)hipFree(e->d_states);
-    if (e->d_pcm1) (void)hipFree(e->d_pcm1);
-    if (e->d_out1) (void)hipFree(e->d_out1);
-    if (e->d_dbg) (void)hipFree(e->d_dbg);
-    if (e->d_planes) (void)hipFree(e->d_planes);
-    if (e->d_mid) (void)hipFree(e->d_mid);
+    {
+        DeviceGuard g(e->device);
+        (void)e->quiesce();
+        if (e->d_states) (void)hipFree(e->d_states);
+        if (e->d_pcm1) (void)hipFree(e->d_pcm1);
+        if (e->d_out1) (void)hipFree(e->d_out1);
+        if (e->d_dbg) (void)hipFree(e->d_dbg);
+        if (e->d_planes) (void)hipFree(e->d_planes);
+        if (e->d_mid) (void)hipFree(e->d_mid);
+        e->release_common();
+    }
     delete e;
     return LC3GPU_OK;
 }
 
 int lc3gpu_encoder_reset(lc3gpu_encoder *e) {
     if (!e) return LC3GPU_EINVAL;
-    e->fresh = true;
+    LC3_ON_DEVICE(e);
+    int rc = e->quiesce();  // launches in flight still store their state at the end
+    if (rc) return rc;
     e->fresh_mask.assign((size_t)e->num_channels, 1);
     return LC3GPU_OK;
 }
 
-static int encoder_reserve_planes(lc3gpu_encoder *e, size_t frames) {
-    const size_t need = (frames + 63) / 64 * 64;
-    if (need <= e->planes_frames) return LC3GPU_OK;
-    HIP_TRY(hipDeviceSynchronize());  // growing: earlier launches may still use the old buffer
-    if (e->d_planes) (void)hipFree(e->d_planes);
-    if (e->d_mid) (void)hipFree(e->d_mid);
-    e->d_planes = nullptr;
-    e->d_mid = nullptr;
-    e->planes_frames = 0;
-    HIP_TRY(hipMalloc((void **)&e->d_planes, need * (size_t)EP_WORDS * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void **)&e->d_mid, need * (size_t)MP_WORDS * sizeof(float)));
-    e->planes_frames = need;
+// materialises the state of still-fresh channels [first, first + n) (internal order) with zero-frame launches of the init path
+static int encoder_materialise(lc3gpu_encoder *e, int first, int n, hipStream_t stream) {
+    lc3_io io = {0, nullptr};
+    for (int i = first; i < first + n; i++) {
+        if (!e->fresh_mask[(size_t)i]) continue;
+        const HostCfg &h = e->mixed ? e->groups[(size_t)e->streams[(size_t)e->caller_of_internal[(size_t)i]].group].h : e->h;
+        LC3_LAUNCH_CFG(lc3_enc_front_kernel, h, dim3(1), dim3(64 * LC3_WG_WAVES), 0, stream, e->d_states, i, 1,
+                       (const int16_t *)e->d_pcm1, e->d_mid, e->d_planes, 20, 0, 1, (float *)nullptr, io);
+        HIP_TRY(hipGetLastError());
+        e->fresh_mask[(size_t)i] = 0;
+    }
     return LC3GPU_OK;
 }
 
-static int encode_launch(lc3gpu_encoder *e, int first, int n, const int16_t *d_pcm, uint8_t *d_out, int nbytes,
-                         int n_frames, hipStream_t stream, float *dbg) {
+// one configuration, channels [first, first + n) in internal order; the buffers hold only those channels
+static int encode_launch(lc3gpu_encoder *e, const HostCfg &h, int first, int n, const int16_t *d_pcm, uint8_t *d_out, int nbytes,
+                         int n_frames, int layout, hipStream_t stream, float *dbg) {
     if (!e || !d_pcm || !d_out) return LC3GPU_EINVAL;
     if (first < 0 || n <= 0 || first + n > e->num_channels) return LC3GPU_ECHANNEL;
     if (nbytes < 20 || nbytes > LC3_MAX_NE || n_frames <= 0) return LC3GPU_ELENGTH;
-    if (((uintptr_t)d_pcm & 3u) != 0) return LC3GPU_EINVAL;
+    if (layout != LC3GPU_LAYOUT_PLANAR && layout != LC3GPU_LAYOUT_INTERLEAVED) return LC3GPU_EINVAL;
+    if (layout == LC3GPU_LAYOUT_PLANAR ? ((uintptr_t)d_pcm & 3u) != 0 : ((uintptr_t)d_pcm & 1u) != 0) return LC3GPU_EINVAL;
     const size_t frames = (size_t)n * (size_t)n_frames;
-    int rc = encoder_reserve_planes(e, frames);
+    int rc = e->order_begin(stream);
+    if (rc == LC3GPU_OK) rc = encoder_reserve_planes(e, frames, stream);
     if (rc) return rc;
     // a range is launched "fresh" only if every channel in it is still fresh
     int fresh = 1;
     for (int i = first; i < first + n; i++) fresh &= e->fresh_mask[(size_t)i];
     if (!fresh) {
-        // materialise any still-fresh channel of the range with a zero-frame launch of the init path
-        for (int i = first; i < first + n; i++) {
-            if (e->fresh_mask[(size_t)i]) {
-                LC3_LAUNCH_CFG(lc3_enc_front_kernel, e->h, dim3(1), dim3(64 * LC3_WG_WAVES), 0, stream, e->d_states, i, 1,
-                                   d_pcm, e->d_mid, e->d_planes, nbytes, 0, 1, (float *)nullptr);
-                e->fresh_mask[(size_t)i] = 0;
-            }
-        }
+        rc = encoder_materialise(e, first, n, stream);
+        if (rc) return rc;
     }
+    lc3_io io = {layout == LC3GPU_LAYOUT_INTERLEAVED ? n : 0, nullptr};
     // analysis front half (wave per stream) -> SNS vector quantiser (lane per frame) -> back half (wave per stream) ->
     // bitstream packing (lane per frame)
     const dim3 wg_grid((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), wg_block(64 * LC3_WG_WAVES);
     e->timer.mark(stream);
-    LC3_LAUNCH_CFG(lc3_enc_front_kernel, e->h, wg_grid, wg_block, 0, stream, e->d_states, first, n, d_pcm, e->d_mid,
-                       e->d_planes, nbytes, n_frames, fresh, dbg);
+    LC3_LAUNCH_CFG(lc3_enc_front_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n, d_pcm, e->d_mid,
+                       e->d_planes, nbytes, n_frames, fresh, dbg, io);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
-    hipLaunchKernelGGL(lc3_sns_vq_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, stream, e->h.c.nb, e->d_mid,
+    hipLaunchKernelGGL(lc3_sns_vq_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, stream, h.c.nb, e->d_mid,
                        e->d_planes, (int)frames);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
-    LC3_LAUNCH_CFG(lc3_enc_back_kernel, e->h, wg_grid, wg_block, 0, stream, e->d_states, first, n,
+    LC3_LAUNCH_CFG(lc3_enc_back_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n,
                        (const float *)e->d_mid, e->d_planes, nbytes, n_frames, dbg);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
-    const unsigned fpb = lc3_frame_block(nbytes <= 220 ? 256u : 128u);
-    const size_t lds = 4096 + 64 * 17 * 4 + LC3_TNS_MODEL_WORDS * 4 + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3) + 4;  // + the packer's sink byte
-    hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, e->h.c.ne,
-                       (const int32_t *)e->d_planes, d_out, nbytes, (int)frames);
+    const unsigned fpb = lc3_frame_block_fit(LC3_PACK_LDS_FIXED, (size_t)nbytes);
+    const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3) + 4;  // + the packer's sink byte
+    hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, h.c.ne,
+                       (const int32_t *)e->d_planes, d_out, nbytes, (int)frames, n_frames, io);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
     for (int i = first; i < first + n; i++) e->fresh_mask[(size_t)i] = 0;
-    return LC3GPU_OK;
+    return e->order_end(stream);
+}
+
+int lc3gpu_encode_layout(lc3gpu_encoder *e, int layout, const int16_t *d_pcm, uint8_t *d_out, int nbytes, int n_frames, void *stream) {
+    if (!e || e->mixed) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(e);
+    return encode_launch(e, e->h, 0, e->num_channels, d_pcm, d_out, nbytes, n_frames, layout, (hipStream_t)stream, nullptr);
 }
 
 int lc3gpu_encode(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out, int nbytes, int n_frames, void *stream) {
-    if (!e) return LC3GPU_EINVAL;
-    return encode_launch(e, 0, e->num_channels, d_pcm, d_out, nbytes, n_frames, (hipStream_t)stream, nullptr);
+    return lc3gpu_encode_layout(e, LC3GPU_LAYOUT_PLANAR, d_pcm, d_out, nbytes, n_frames, stream);
 }
 
 int lc3gpu_encode_range(lc3gpu_encoder *e, int first_channel, int n_channels, const int16_t *d_pcm, uint8_t *d_out,
                         int nbytes, int n_frames, void *stream) {
-    return encode_launch(e, first_channel, n_channels, d_pcm, d_out, nbytes, n_frames, (hipStream_t)stream, nullptr);
+    if (!e || e->mixed) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(e);
+    return encode_launch(e, e->h, first_channel, n_channels, d_pcm, d_out, nbytes, n_frames, LC3GPU_LAYOUT_PLANAR, (hipStream_t)stream,
+                         nullptr);
+}
+
+// every stream of a mixed-configuration handle, ONE launch per kernel
+int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out, int n_frames, void *stream_) {
+    if (!e || !e->mixed || !d_pcm || !d_out) return LC3GPU_EINVAL;
+    if (n_frames <= 0) return LC3GPU_ELENGTH;
+    if (((uintptr_t)d_pcm & 3u) != 0) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(e);
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = e->order_begin(stream);
+    if (rc) return rc;
+    lc3_groups G;
+    unsigned wg_stream, wg_frame;
+    size_t frames;
+    int max_nbytes;
+    fill_groups(*e, n_frames, 256u, G, wg_stream, wg_frame, frames, max_nbytes);
+    const unsigned fpb = lc3_frame_block_fit(LC3_PACK_LDS_FIXED, (size_t)max_nbytes);
+    fill_groups(*e, n_frames, fpb, G, wg_stream, wg_frame, frames, max_nbytes);
+    rc = encoder_reserve_planes(e, frames, stream);
+    if (rc) return rc;
+    int fresh = 1;
+    for (uint8_t m : e->fresh_mask) fresh &= m;
+    if (!fresh) {
+        rc = encoder_materialise(e, 0, e->num_channels, stream);
+        if (rc) return rc;
+    }
+    lc3_io io = {0, e->d_tab};
+    e->timer.mark(stream);
+    hipLaunchKernelGGL(lc3_enc_front_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states, d_pcm, e->d_mid,
+                       e->d_planes, n_frames, fresh, io);
+    HIP_TRY(hipGetLastError());
+    e->timer.mark(stream);
+    lc3_groups G256;  // the vector quantiser runs 256 frames per workgroup
+    {
+        unsigned a, b;
+        size_t f;
+        int m;
+        fill_groups(*e, n_frames, 256u, G256, a, b, f, m);
+        hipLaunchKernelGGL(lc3_sns_vq_mixed_kernel, dim3(b), dim3(256), 0, stream, G256, e->d_mid, e->d_planes, n_frames);
+        HIP_TRY(hipGetLastError());
+    }
+    e->timer.mark(stream);
+    hipLaunchKernelGGL(lc3_enc_back_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states,
+                       (const float *)e->d_mid, e->d_planes, n_frames);
+    HIP_TRY(hipGetLastError());
+    e->timer.mark(stream);
+    const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)max_nbytes + 3) & ~(size_t)3) + 4;
+    hipLaunchKernelGGL(lc3_pack_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, (const int32_t *)e->d_planes, d_out, n_frames, io);
+    HIP_TRY(hipGetLastError());
+    e->timer.mark(stream);
+    e->fresh_mask.assign((size_t)e->num_channels, 0);
+    return e->order_end(stream);
 }
 
 static int encode_frame_host(lc3gpu_encoder *e, int channel_index, const int16_t *samples_in, int n_samples,
                              uint8_t *buf_out, int nbytes, float *dbg) {
     if (!e || !samples_in || !buf_out) return LC3GPU_EINVAL;
     if (channel_index < 0 || channel_index >= e->num_channels) return LC3GPU_ECHANNEL;
-    if (n_samples != e->h.c.nf) return LC3GPU_ELENGTH;
+    const HostCfg &h = e->cfg_of_channel(channel_index);
+    if (n_samples != h.c.nf) return LC3GPU_ELENGTH;
     if (nbytes < 20 || nbytes > LC3_MAX_NE) return LC3GPU_ELENGTH;
+    LC3_ON_DEVICE(e);
+    int rc = e->quiesce();  // the staging buffers are reused
+    if (rc) return rc;
     HIP_TRY(hipMemcpy(e->d_pcm1, samples_in, sizeof(int16_t) * (size_t)n_samples, hipMemcpyHostToDevice));
-    int rc = encode_launch(e, channel_index, 1, e->d_pcm1, e->d_out1, nbytes, 1, nullptr, dbg ? e->d_dbg : nullptr);
+    rc = encode_launch(e, h, e->internal_of_channel(channel_index), 1, e->d_pcm1, e->d_out1, nbytes, 1, LC3GPU_LAYOUT_PLANAR, nullptr,
+                       dbg ? e->d_dbg : nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(buf_out, e->d_out1, (size_t)nbytes, hipMemcpyDeviceToHost));
     if (dbg) HIP_TRY(hipMemcpy(dbg, e->d_dbg, sizeof(float) * 1472, hipMemcpyDeviceToHost));
@@ -948,50 +1416,73 @@ int lc3gpu_encode_frame_debug(lc3gpu_encoder *e, const int16_t *samples_in, int 
 
 size_t lc3gpu_encoder_state_size(const lc3gpu_encoder *e) { return e ? sizeof(lc3_enc_state) : 0; }
 
-int lc3gpu_encoder_state_save(lc3gpu_encoder *e, void *host_dst) {
+// blobs travel in the caller's channel order (a mixed handle keeps them sorted by configuration internally)
+int lc3gpu_encoder_state_save(lc3gpu_encoder *e, void *host_dst, size_t nbytes) {
     if (!e || !host_dst) return LC3GPU_EINVAL;
-    // materialise fresh channels first
-    for (int i = 0; i < e->num_channels; i++) {
-        if (e->fresh_mask[(size_t)i]) {
-            LC3_LAUNCH_CFG(lc3_enc_front_kernel, e->h, dim3(1), dim3(64 * LC3_WG_WAVES), 0, nullptr, e->d_states, i, 1,
-                               e->d_pcm1, e->d_mid, e->d_planes, 20, 0, 1, (float *)nullptr);
-            e->fresh_mask[(size_t)i] = 0;
-        }
-    }
+    if (nbytes != sizeof(lc3_enc_state) * (size_t)e->num_channels) return LC3GPU_ELENGTH;
+    LC3_ON_DEVICE(e);
+    int rc = encoder_materialise(e, 0, e->num_channels, nullptr);
+    if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(host_dst, e->d_states, sizeof(lc3_enc_state) * (size_t)e->num_channels, hipMemcpyDeviceToHost));
+    if (!e->mixed) {
+        HIP_TRY(hipMemcpy(host_dst, e->d_states, nbytes, hipMemcpyDeviceToHost));
+        return LC3GPU_OK;
+    }
+    std::vector<lc3_enc_state> tmp((size_t)e->num_channels);
+    HIP_TRY(hipMemcpy(tmp.data(), e->d_states, nbytes, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->num_channels; i++)
+        std::memcpy((char *)host_dst + sizeof(lc3_enc_state) * (size_t)i, &tmp[(size_t)e->streams[(size_t)i].internal], sizeof(lc3_enc_state));
     return LC3GPU_OK;
 }
 
-int lc3gpu_encoder_state_load(lc3gpu_encoder *e, const void *host_src) {
+int lc3gpu_encoder_state_load(lc3gpu_encoder *e, const void *host_src, size_t nbytes) {
     if (!e || !host_src) return LC3GPU_EINVAL;
-    HIP_TRY(hipMemcpy(e->d_states, host_src, sizeof(lc3_enc_state) * (size_t)e->num_channels, hipMemcpyHostToDevice));
+    if (nbytes != sizeof(lc3_enc_state) * (size_t)e->num_channels) return LC3GPU_ELENGTH;
+    LC3_ON_DEVICE(e);
+    HIP_TRY(hipDeviceSynchronize());  // a launch in flight would store its state over the loaded one
+    if (!e->mixed) {
+        HIP_TRY(hipMemcpy(e->d_states, host_src, nbytes, hipMemcpyHostToDevice));
+    } else {
+        std::vector<lc3_enc_state> tmp((size_t)e->num_channels);
+        for (int i = 0; i < e->num_channels; i++)
+            std::memcpy(&tmp[(size_t)e->streams[(size_t)i].internal], (const char *)host_src + sizeof(lc3_enc_state) * (size_t)i, sizeof(lc3_enc_state));
+        HIP_TRY(hipMemcpy(e->d_states, tmp.data(), nbytes, hipMemcpyHostToDevice));
+    }
     e->fresh_mask.assign((size_t)e->num_channels, 0);
     return LC3GPU_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-static int decoder_reserve_planes(lc3gpu_decoder *d, size_t frames) {
-    const size_t need = (frames + 63) / 64 * 64;
-    if (need <= d->planes_frames) return LC3GPU_OK;
-    // growing synchronises: earlier launches may still read the old buffer
+static int decoder_init_states(lc3gpu_decoder *d) {
+    // decoder state is materialised eagerly (fresh = 1, zero frames): PLC counters must survive range launches
+    HIP_TRY(hipDeviceSynchronize());  // nothing of this handle may still be in flight (its state is about to be rewritten)
+    lc3_io io = {0, nullptr};
+    if (!d->mixed) {
+        LC3_LAUNCH_CFG(lc3_decode_kernel, d->h, dim3((unsigned)((d->num_channels + LC3_WG_WAVES - 1) / LC3_WG_WAVES)),
+                       dim3(64 * LC3_WG_WAVES), 0, nullptr, d->d_states, 0, d->num_channels, (const int32_t *)d->d_planes, d->d_pcm1, 20,
+                       0, 1, io);
+        HIP_TRY(hipGetLastError());
+    } else {
+        for (const GroupHost &g : d->groups) {
+            LC3_LAUNCH_CFG(lc3_decode_kernel, g.h, dim3((unsigned)((g.n_streams + LC3_WG_WAVES - 1) / LC3_WG_WAVES)),
+                           dim3(64 * LC3_WG_WAVES), 0, nullptr, d->d_states, g.first_stream, g.n_streams, (const int32_t *)d->d_planes,
+                           d->d_pcm1, 20, 0, 1, io);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     HIP_TRY(hipDeviceSynchronize());
-    if (d->d_planes) (void)hipFree(d->d_planes);
-    d->d_planes = nullptr;
-    d->planes_frames = 0;
-    HIP_TRY(hipMalloc((void **)&d->d_planes, need * (size_t)LC3_PLANE_WORDS * sizeof(int32_t)));
-    d->planes_frames = need;
     return LC3GPU_OK;
 }
 
-static int decoder_init_states(lc3gpu_decoder *d) {
-    // decoder state is materialised eagerly (fresh = 1, zero frames): PLC counters must survive range launches
-    LC3_LAUNCH_CFG(lc3_decode_kernel, d->h, dim3((unsigned)((d->num_channels + LC3_WG_WAVES - 1) / LC3_WG_WAVES)),
-                   dim3(64 * LC3_WG_WAVES), 0, nullptr, d->d_states, 0, d->num_channels,
-                       (const uint8_t *)d->d_in1, (const int32_t *)d->d_planes, d->d_pcm1, 20, 0, 1);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    return LC3GPU_OK;
+static int decoder_alloc(lc3gpu_decoder *d) {
+    HIP_TRY(hipGetDevice(&d->device));
+    HIP_TRY(hipEventCreateWithFlags(&d->done, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void **)&d->d_states, sizeof(lc3_dec_state) * (size_t)d->num_channels));
+    HIP_TRY(hipMalloc((void **)&d->d_in1, LC3_MAX_NE));
+    HIP_TRY(hipMalloc((void **)&d->d_pcm1, sizeof(int16_t) * LC3_MAX_NF));
+    int rc = decoder_reserve_planes(d, (size_t)d->num_channels, nullptr);
+    if (rc == LC3GPU_OK) rc = decoder_init_states(d);
+    return rc;
 }
 
 int lc3gpu_decoder_create(lc3gpu_decoder **out, int num_channels, int frame_us, int fs_hz) {
@@ -1005,15 +1496,20 @@ int lc3gpu_decoder_create(lc3gpu_decoder **out, int num_channels, int frame_us, 
     if (!d) return LC3GPU_EINVAL;
     d->num_channels = num_channels;
     rc = cfg_acquire(d->h, frame_us, fs_hz);
+    if (rc == LC3GPU_OK) rc = decoder_alloc(d);
     if (rc) { lc3gpu_decoder_destroy(d); return rc; }
-    if (hipMalloc((void **)&d->d_states, sizeof(lc3_dec_state) * (size_t)num_channels) != hipSuccess ||
-        hipMalloc((void **)&d->d_in1, LC3_MAX_NE) != hipSuccess ||
-        hipMalloc((void **)&d->d_pcm1, sizeof(int16_t) * LC3_MAX_NF) != hipSuccess) {
-        lc3gpu_decoder_destroy(d);
-        return LC3GPU_EHIP;
-    }
-    rc = decoder_reserve_planes(d, (size_t)num_channels);
-    if (rc == LC3GPU_OK) rc = decoder_init_states(d);
+    *out = d;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_decoder_create_mixed(lc3gpu_decoder **out, int n_streams, const lc3gpu_stream_desc *descs) {
+    if (!out || n_streams <= 0 || !descs) return LC3GPU_EINVAL;
+    *out = nullptr;
+    if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
+    lc3gpu_decoder *d = new (std::nothrow) lc3gpu_decoder();
+    if (!d) return LC3GPU_EINVAL;
+    int rc = build_mixed(*d, n_streams, descs, false);
+    if (rc == LC3GPU_OK) rc = decoder_alloc(d);
     if (rc) { lc3gpu_decoder_destroy(d); return rc; }
     *out = d;
     return LC3GPU_OK;
@@ -1021,56 +1517,102 @@ int lc3gpu_decoder_create(lc3gpu_decoder **out, int num_channels, int frame_us, 
 
 int lc3gpu_decoder_destroy(lc3gpu_decoder *d) {
     if (!d) return LC3GPU_OK;
-    if (d->d_states) (void)hipFree(d->d_states);
-    if (d->d_in1) (void)hipFree(d->d_in1);
-    if (d->d_pcm1) (void)hipFree(d->d_pcm1);
-    if (d->d_planes) (void)hipFree(d->d_planes);
+    {
+        DeviceGuard g(d->device);
+        (void)d->quiesce();
+        if (d->d_states) (void)hipFree(d->d_states);
+        if (d->d_in1) (void)hipFree(d->d_in1);
+        if (d->d_pcm1) (void)hipFree(d->d_pcm1);
+        if (d->d_planes) (void)hipFree(d->d_planes);
+        d->release_common();
+    }
     delete d;
     return LC3GPU_OK;
 }
 
 int lc3gpu_decoder_reset(lc3gpu_decoder *d) {
     if (!d) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(d);
     return decoder_init_states(d);
 }
 
-static int decode_launch(lc3gpu_decoder *d, int first, int n, const uint8_t *d_in, const uint8_t *d_bad, int16_t *d_pcm,
-                         int nbytes, int n_frames, hipStream_t stream) {
+static int decode_launch(lc3gpu_decoder *d, const HostCfg &h, int first, int n, const uint8_t *d_in, const uint8_t *d_bad,
+                         int16_t *d_pcm, int nbytes, int n_frames, int layout, hipStream_t stream) {
     if (!d || !d_in || !d_pcm) return LC3GPU_EINVAL;
     if (first < 0 || n <= 0 || first + n > d->num_channels) return LC3GPU_ECHANNEL;
     if (nbytes < 1 || nbytes > LC3_MAX_NE || n_frames <= 0) return LC3GPU_ELENGTH;
-    if (((uintptr_t)d_pcm & 3u) != 0) return LC3GPU_EINVAL;
+    if (layout != LC3GPU_LAYOUT_PLANAR && layout != LC3GPU_LAYOUT_INTERLEAVED) return LC3GPU_EINVAL;
+    if (layout == LC3GPU_LAYOUT_PLANAR ? ((uintptr_t)d_pcm & 3u) != 0 : ((uintptr_t)d_pcm & 1u) != 0) return LC3GPU_EINVAL;
     // stage 1: parse all n * n_frames frames, one lane each (stateless); stage 2: synthesis, one wave per stream
     const size_t frames = (size_t)n * (size_t)n_frames;
-    int rc = decoder_reserve_planes(d, frames);
+    int rc = d->order_begin(stream);
+    if (rc == LC3GPU_OK) rc = decoder_reserve_planes(d, frames, stream);
     if (rc) return rc;
+    lc3_io io = {layout == LC3GPU_LAYOUT_INTERLEAVED ? n : 0, nullptr};
     // frames per workgroup: as many as fit the default 64 KB of dynamic LDS (tables + 64 B of scale factors and nbytes of
     // frame data per frame)
-    unsigned fpb = lc3_frame_block(256u);
-    while (fpb > 64u && LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes) > 65536u) fpb >>= 1;
+    const unsigned fpb = lc3_frame_block_fit(LC3_PARSE_LDS_FIXED, (size_t)(64 + nbytes));
     const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes);
     d->timer.mark(stream);
-    LC3_LAUNCH_CFG(lc3_parse_kernel, d->h, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream,
-                       d_in, d_bad, d->d_planes, nbytes, (int)frames);
+    LC3_LAUNCH_CFG(lc3_parse_kernel, h, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream,
+                       d_in, d_bad, d->d_planes, nbytes, (int)frames, n_frames, io);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream);
-    LC3_LAUNCH_CFG(lc3_decode_kernel, d->h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0, stream,
-                   d->d_states, first, n, d_in,
-                       (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0);
+    LC3_LAUNCH_CFG(lc3_decode_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0, stream,
+                   d->d_states, first, n, (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0, io);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream);
-    return LC3GPU_OK;
+    return d->order_end(stream);
+}
+
+int lc3gpu_decode_layout(lc3gpu_decoder *d, int layout, const uint8_t *d_in, const uint8_t *d_bad, int16_t *d_pcm, int nbytes,
+                         int n_frames, void *stream) {
+    if (!d || d->mixed) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(d);
+    return decode_launch(d, d->h, 0, d->num_channels, d_in, d_bad, d_pcm, nbytes, n_frames, layout, (hipStream_t)stream);
 }
 
 int lc3gpu_decode(lc3gpu_decoder *d, const uint8_t *d_in, const uint8_t *d_bad, int16_t *d_pcm, int nbytes, int n_frames,
                   void *stream) {
-    if (!d) return LC3GPU_EINVAL;
-    return decode_launch(d, 0, d->num_channels, d_in, d_bad, d_pcm, nbytes, n_frames, (hipStream_t)stream);
+    return lc3gpu_decode_layout(d, LC3GPU_LAYOUT_PLANAR, d_in, d_bad, d_pcm, nbytes, n_frames, stream);
 }
 
 int lc3gpu_decode_range(lc3gpu_decoder *d, int first_channel, int n_channels, const uint8_t *d_in, const uint8_t *d_bad,
                         int16_t *d_pcm, int nbytes, int n_frames, void *stream) {
-    return decode_launch(d, first_channel, n_channels, d_in, d_bad, d_pcm, nbytes, n_frames, (hipStream_t)stream);
+    if (!d || d->mixed) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(d);
+    return decode_launch(d, d->h, first_channel, n_channels, d_in, d_bad, d_pcm, nbytes, n_frames, LC3GPU_LAYOUT_PLANAR,
+                         (hipStream_t)stream);
+}
+
+int lc3gpu_decode_mixed(lc3gpu_decoder *d, const uint8_t *d_in, const uint8_t *d_bad, int16_t *d_pcm, int n_frames, void *stream_) {
+    if (!d || !d->mixed || !d_in || !d_pcm) return LC3GPU_EINVAL;
+    if (n_frames <= 0) return LC3GPU_ELENGTH;
+    if (((uintptr_t)d_pcm & 3u) != 0) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(d);
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = d->order_begin(stream);
+    if (rc) return rc;
+    lc3_groups G;
+    unsigned wg_stream, wg_frame;
+    size_t frames;
+    int max_nbytes;
+    fill_groups(*d, n_frames, 256u, G, wg_stream, wg_frame, frames, max_nbytes);
+    const unsigned fpb = lc3_frame_block_fit(LC3_PARSE_LDS_FIXED, (size_t)(64 + max_nbytes));
+    fill_groups(*d, n_frames, fpb, G, wg_stream, wg_frame, frames, max_nbytes);
+    rc = decoder_reserve_planes(d, frames, stream);
+    if (rc) return rc;
+    lc3_io io = {0, d->d_tab};
+    const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + max_nbytes);
+    d->timer.mark(stream);
+    hipLaunchKernelGGL(lc3_parse_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, d_in, d_bad, d->d_planes, n_frames, io);
+    HIP_TRY(hipGetLastError());
+    d->timer.mark(stream);
+    hipLaunchKernelGGL(lc3_decode_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, d->d_states,
+                       (const int32_t *)d->d_planes, d_pcm, n_frames, 0, io);
+    HIP_TRY(hipGetLastError());
+    d->timer.mark(stream);
+    return d->order_end(stream);
 }
 
 int lc3gpu_decode_frame(lc3gpu_decoder *d, int num_bits_per_audio_sample, int channel_index, const uint8_t *buf_in,
@@ -1078,10 +1620,15 @@ int lc3gpu_decode_frame(lc3gpu_decoder *d, int num_bits_per_audio_sample, int ch
     if (!d || !buf_in || !samples_out) return LC3GPU_EINVAL;
     if (num_bits_per_audio_sample != 16) return LC3GPU_EBITS;  // checked first, as in lc3_decoder.rs:80-82
     if (channel_index < 0 || channel_index >= d->num_channels) return LC3GPU_ECHANNEL;
-    if (n_samples != d->h.c.nf) return LC3GPU_ELENGTH;
+    const HostCfg &h = d->cfg_of_channel(channel_index);
+    if (n_samples != h.c.nf) return LC3GPU_ELENGTH;
     if (nbytes < 1 || nbytes > LC3_MAX_NE) return LC3GPU_ELENGTH;
+    LC3_ON_DEVICE(d);
+    int rc = d->quiesce();  // the staging buffers are reused
+    if (rc) return rc;
     HIP_TRY(hipMemcpy(d->d_in1, buf_in, (size_t)nbytes, hipMemcpyHostToDevice));
-    int rc = decode_launch(d, channel_index, 1, d->d_in1, nullptr, d->d_pcm1, nbytes, 1, nullptr);
+    rc = decode_launch(d, h, d->internal_of_channel(channel_index), 1, d->d_in1, nullptr, d->d_pcm1, nbytes, 1, LC3GPU_LAYOUT_PLANAR,
+                       nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(samples_out, d->d_pcm1, sizeof(int16_t) * (size_t)n_samples, hipMemcpyDeviceToHost));
     return LC3GPU_OK;
@@ -1089,23 +1636,42 @@ int lc3gpu_decode_frame(lc3gpu_decoder *d, int num_bits_per_audio_sample, int ch
 
 size_t lc3gpu_decoder_state_size(const lc3gpu_decoder *d) { return d ? sizeof(lc3_dec_state) : 0; }
 
-int lc3gpu_decoder_state_save(lc3gpu_decoder *d, void *host_dst) {
+int lc3gpu_decoder_state_save(lc3gpu_decoder *d, void *host_dst, size_t nbytes) {
     if (!d || !host_dst) return LC3GPU_EINVAL;
+    if (nbytes != sizeof(lc3_dec_state) * (size_t)d->num_channels) return LC3GPU_ELENGTH;
+    LC3_ON_DEVICE(d);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(host_dst, d->d_states, sizeof(lc3_dec_state) * (size_t)d->num_channels, hipMemcpyDeviceToHost));
+    if (!d->mixed) {
+        HIP_TRY(hipMemcpy(host_dst, d->d_states, nbytes, hipMemcpyDeviceToHost));
+        return LC3GPU_OK;
+    }
+    std::vector<lc3_dec_state> tmp((size_t)d->num_channels);
+    HIP_TRY(hipMemcpy(tmp.data(), d->d_states, nbytes, hipMemcpyDeviceToHost));
+    for (int i = 0; i < d->num_channels; i++)
+        std::memcpy((char *)host_dst + sizeof(lc3_dec_state) * (size_t)i, &tmp[(size_t)d->streams[(size_t)i].internal], sizeof(lc3_dec_state));
     return LC3GPU_OK;
 }
 
-int lc3gpu_decoder_state_load(lc3gpu_decoder *d, const void *host_src) {
+int lc3gpu_decoder_state_load(lc3gpu_decoder *d, const void *host_src, size_t nbytes) {
     if (!d || !host_src) return LC3GPU_EINVAL;
-    HIP_TRY(hipMemcpy(d->d_states, host_src, sizeof(lc3_dec_state) * (size_t)d->num_channels, hipMemcpyHostToDevice));
+    if (nbytes != sizeof(lc3_dec_state) * (size_t)d->num_channels) return LC3GPU_ELENGTH;
+    LC3_ON_DEVICE(d);
+    HIP_TRY(hipDeviceSynchronize());  // a launch in flight would store its state over the loaded one
+    if (!d->mixed) {
+        HIP_TRY(hipMemcpy(d->d_states, host_src, nbytes, hipMemcpyHostToDevice));
+        return LC3GPU_OK;
+    }
+    std::vector<lc3_dec_state> tmp((size_t)d->num_channels);
+    for (int i = 0; i < d->num_channels; i++)
+        std::memcpy(&tmp[(size_t)d->streams[(size_t)i].internal], (const char *)host_src + sizeof(lc3_dec_state) * (size_t)i, sizeof(lc3_dec_state));
+    HIP_TRY(hipMemcpy(d->d_states, tmp.data(), nbytes, hipMemcpyHostToDevice));
     return LC3GPU_OK;
 }
 
 int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
     if (!d || !out) return LC3GPU_EINVAL;
     std::vector<lc3_dec_state> st((size_t)d->num_channels);
-    int rc = lc3gpu_decoder_state_save(d, st.data());
+    int rc = lc3gpu_decoder_state_save(d, st.data(), sizeof(lc3_dec_state) * (size_t)d->num_channels);
     if (rc) return rc;
     uint64_t total = 0;
     for (const auto &s : st) total += (uint64_t)s.core.plc_events;
@@ -1118,6 +1684,7 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
 // encoder: out[5] = {front ms, vector-quantiser ms, back ms, pack ms, launches}
 int lc3gpu_encoder_timing(lc3gpu_encoder *e, int enable, double out[5]) {
     if (!e) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(e);
     e->timer.stages = 4;
     e->timer.collect();
     if (out) {
@@ -1132,6 +1699,7 @@ int lc3gpu_encoder_timing(lc3gpu_encoder *e, int enable, double out[5]) {
 // decoder: out[3] = {parse+reconstruct ms, synthesis ms, launches}
 int lc3gpu_decoder_timing(lc3gpu_decoder *d, int enable, double out[3]) {
     if (!d) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(d);
     d->timer.collect();
     if (out) { out[0] = d->timer.ms[0]; out[1] = d->timer.ms[1]; out[2] = (double)d->timer.launches; }
     d->timer.ms[0] = d->timer.ms[1] = 0.0;
