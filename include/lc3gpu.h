@@ -38,6 +38,16 @@ extern "C" {
 #define LC3GPU_ENODEVICE -6     /* no usable HIP device */
 #define LC3GPU_EUNSUPPORTED -7  /* configuration the reference cannot run (8 kHz encode: bandwidth_detector.rs:36-37) */
 
+/* Opt-in corrections of the reference's deviations from the LC3 specification, one bit each, for interop with
+ * other LC3 codecs.  Default 0: every deviation is reproduced, and only then do the bit-exactness claims against the
+ * reference hold (with a bit set there is no reference behaviour; the CPU oracle implements the same switches). */
+#define LC3GPU_SPEC_8KHZ_ENCODE 1     /* 8 kHz encoders can be created (reference: constructor panics, bandwidth_detector.rs:36-37) */
+#define LC3GPU_SPEC_TNS_SSWB_STOP 2   /* 10 ms, bandwidth index 2: TNS filters lines 12..240 (reference: ..200, temporal_noise_shaping.rs:134-140) */
+#define LC3GPU_SPEC_BW_CUTOFF_DB 4    /* bandwidth cut-off test on 10 log10(eps + ratio) (reference: raw ratio, bandwidth_detector.rs:106-115) */
+#define LC3GPU_SPEC_SNS_LAST_GAIN 8   /* SNS gain search includes the last gain of every shape (reference: spectral_noise_shaping.rs:495-503) */
+#define LC3GPU_SPEC_NBITS_SPEC_OLD 16 /* nbits_spec_old is updated (reference: stays 0, spectral_quantization.rs:59,97-100) */
+#define LC3GPU_SPEC_ALL 31
+
 typedef struct lc3gpu_encoder lc3gpu_encoder;
 typedef struct lc3gpu_decoder lc3gpu_decoder;
 
@@ -77,6 +87,8 @@ int lc3gpu_decoder_working_buffer_lengths(int num_channels, int frame_us, int fs
 /* ---- encoder ------------------------------------------------------------------------------------ */
 /* Lc3Encoder::new (lc3_encoder.rs:117-173): num_channels fresh channels on the current HIP device. */
 int lc3gpu_encoder_create(lc3gpu_encoder **out, int num_channels, int frame_us, int fs_hz);
+/* the same with LC3GPU_SPEC_* corrections switched on (spec_flags = 0: identical to lc3gpu_encoder_create) */
+int lc3gpu_encoder_create_spec(lc3gpu_encoder **out, int num_channels, int frame_us, int fs_hz, int spec_flags);
 int lc3gpu_encoder_destroy(lc3gpu_encoder *enc);
 /* back to the freshly constructed state (all channels) */
 int lc3gpu_encoder_reset(lc3gpu_encoder *enc);
@@ -107,6 +119,7 @@ int lc3gpu_encode_layout(lc3gpu_encoder *enc, int layout, const int16_t *d_pcm, 
  * The per-frame calls, state blobs and timing work on a mixed handle as on a uniform one (channel index = descriptor
  * index); lc3gpu_encode / _range / _layout do not (LC3GPU_EINVAL). */
 int lc3gpu_encoder_create_mixed(lc3gpu_encoder **out, int n_streams, const lc3gpu_stream_desc *descs);
+int lc3gpu_encoder_create_mixed_spec(lc3gpu_encoder **out, int n_streams, const lc3gpu_stream_desc *descs, int spec_flags);
 int lc3gpu_encode_mixed(lc3gpu_encoder *enc, const int16_t *d_pcm, uint8_t *d_out, int n_frames, void *hip_stream);
 
 /* per-channel state blobs (checkpoint / CPU cross-checks): size per channel, device->host copy, host->device.

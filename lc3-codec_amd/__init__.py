@@ -17,6 +17,12 @@ from .api import (  # noqa: F401
     LAYOUT_INTERLEAVED,
     LAYOUT_PLANAR,
     Lc3GpuError,
+    SPEC_8KHZ_ENCODE,
+    SPEC_ALL,
+    SPEC_BW_CUTOFF_DB,
+    SPEC_NBITS_SPEC_OLD,
+    SPEC_SNS_LAST_GAIN,
+    SPEC_TNS_SSWB_STOP,
     SamplingFrequency,
     StreamDesc,
     build_native,

@@ -119,6 +119,8 @@ def load_library():
     L.lc3gpu_encoder_working_buffer_lengths.argtypes = [i, i, i, pi64]
     L.lc3gpu_decoder_working_buffer_lengths.argtypes = [i, i, i, pi64]
     L.lc3gpu_encoder_create.argtypes = [ctypes.POINTER(vp), i, i, i]
+    L.lc3gpu_encoder_create_spec.argtypes = [ctypes.POINTER(vp), i, i, i, i]
+    L.lc3gpu_encoder_create_mixed_spec.argtypes = [ctypes.POINTER(vp), i, vp, i]
     L.lc3gpu_encoder_destroy.argtypes = [vp]
     L.lc3gpu_encoder_reset.argtypes = [vp]
     L.lc3gpu_encode_frame.argtypes = [vp, i, vp, i, vp, i]
@@ -163,8 +165,11 @@ ABI_SYMBOLS = [
     "lc3gpu_decoder_state_size", "lc3gpu_decoder_state_save", "lc3gpu_decoder_state_load",
     "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info", "lc3gpu_prof_read", "lc3gpu_encoder_timing", "lc3gpu_decoder_timing",
     "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
-    "lc3gpu_decode_mixed",
+    "lc3gpu_decode_mixed", "lc3gpu_encoder_create_spec", "lc3gpu_encoder_create_mixed_spec",
 ]
+
+# LC3GPU_SPEC_*: opt-in corrections of the reference's deviations from the LC3 specification (default 0 = reference behaviour)
+SPEC_8KHZ_ENCODE, SPEC_TNS_SSWB_STOP, SPEC_BW_CUTOFF_DB, SPEC_SNS_LAST_GAIN, SPEC_NBITS_SPEC_OLD, SPEC_ALL = 1, 2, 4, 8, 16, 31
 
 LAYOUT_PLANAR, LAYOUT_INTERLEAVED = 0, 1
 
@@ -237,13 +242,13 @@ class Lc3Encoder:
             raise Lc3EncoderError(rc)
         return tuple(int(v) for v in out)
 
-    def __init__(self, num_channels, frame_duration, sampling_frequency):
+    def __init__(self, num_channels, frame_duration, sampling_frequency, spec_flags=0):
         self._L = load_library()
         self.config = Lc3Config(sampling_frequency, frame_duration)
         self.num_channels = int(num_channels)
         h = ctypes.c_void_p()
-        rc = self._L.lc3gpu_encoder_create(ctypes.byref(h), self.num_channels, int(frame_duration),
-                                           int(sampling_frequency))
+        rc = self._L.lc3gpu_encoder_create_spec(ctypes.byref(h), self.num_channels, int(frame_duration),
+                                                int(sampling_frequency), int(spec_flags))
         if rc:
             raise Lc3EncoderError(rc, "Lc3Encoder::new")
         self._h = h
@@ -251,7 +256,7 @@ class Lc3Encoder:
     new = classmethod(lambda cls, *a, **k: cls(*a, **k))
 
     @classmethod
-    def mixed(cls, descs):
+    def mixed(cls, descs, spec_flags=0):
         """one handle for streams of different configurations: descs = [(fs_hz, frame_us, nbytes), ...] (lc3gpu_encoder_create_mixed)"""
         self = cls.__new__(cls)
         self._L = load_library()
@@ -260,7 +265,7 @@ class Lc3Encoder:
         self.config = None
         self.num_channels = len(self.descs)
         h = ctypes.c_void_p()
-        rc = self._L.lc3gpu_encoder_create_mixed(ctypes.byref(h), self.num_channels, _desc_array(self.descs))
+        rc = self._L.lc3gpu_encoder_create_mixed_spec(ctypes.byref(h), self.num_channels, _desc_array(self.descs), int(spec_flags))
         if rc:
             raise Lc3EncoderError(rc, "Lc3Encoder::mixed")
         self._h = h

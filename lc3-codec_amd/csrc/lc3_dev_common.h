@@ -104,6 +104,14 @@
 
 #define LC3_WAVE 64
 
+// Opt-in corrections of the reference's deviations from the LC3 specification, one bit each; 0 = the
+// reference's behaviour, which is what every parity claim is about.  Same values as LC3GPU_SPEC_* (include/lc3gpu.h).
+#define LC3_SPEC_8KHZ_ENCODE 1     // A6: an 8 kHz encoder exists (bandwidth detector returns at once, bandwidth_detector.rs:66-71)
+#define LC3_SPEC_TNS_SSWB_STOP 2   // A5: 10 ms, bandwidth index 2: TNS filter stops at line 240 instead of 200
+#define LC3_SPEC_BW_CUTOFF_DB 4    // A7: cut-off test on 10 log10(eps + E[n-L] / E[n]) (the note at bandwidth_detector.rs:106-107)
+#define LC3_SPEC_SNS_LAST_GAIN 8   // A3: the SNS gain search also tries the last gain of every shape
+#define LC3_SPEC_NBITS_SPEC_OLD 16 // A1: nbits_spec_old follows nbits_spec
+
 // HBM "planes" hand frames between the wave-per-stream and the lane-per-frame kernels.  Frame-major: a frame's
 // words are contiguous, so the wave side moves them with coalesced 256-byte accesses and the lane side walks its
 // own frame sequentially (sectors are merged / re-served by L2).  The lane-major alternative

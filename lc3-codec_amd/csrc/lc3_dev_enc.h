@@ -20,11 +20,11 @@ struct lc3_enc_scalars {
     float mem_pitch;
     int mem_ltpf_active;
     float mem_nc, mem_mem_nc, h50_m1, h50_m2;
-    // quantiser (encoder/spectral_quantization.rs:56-61); nbits_spec_old stays 0
+    // quantiser (encoder/spectral_quantization.rs:56-61); nbits_spec_old stays 0 unless LC3_SPEC_NBITS_SPEC_OLD is set
     int reset_offset_old;
     float nbits_offset_old;
     int nbits_est_old;
-    int pad;
+    int nbits_spec_old;
 };
 struct lc3_enc_state {
     float x12[384];          // LTPF 12.8 kHz ring (encoder/long_term_post_filter.rs:114,227); 10 ms uses all 384
@@ -48,6 +48,8 @@ struct __attribute__((aligned(16))) lc3_enc_lds {
     int16_t t[2 * LC3_MAX_NF];   // MDCT time buffer (ModDiscreteCosTrans::freq); later x6 | xq + residual bits
     float sm[32];            // small scratch (per-stage)
     int ism[64];
+    int spec_flags;          // LC3_SPEC_* of the launch (0 = the reference's behaviour)
+    int pad_;
     unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
 #ifdef LC3_PROFILE
     unsigned long long prof_acc[32];  // diagnostic build: per-wave stage totals, flushed once per launch
@@ -300,6 +302,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_bandwidth(LC3_CFG_PARAM, LC
             int start_bw = c.n_ms_10 ? LC3C_BW_START10[fsi - 1][bw] : LC3C_BW_START75[fsi - 1][bw];
             for (int n = start_bw + 1 - l_bw; n < start_bw; n++) {
                 float cutoff = LC3_EB(L)[n - l_bw] / LC3_EB(L)[n];  // raw ratio, no dB
+                if (L.spec_flags & LC3_SPEC_BW_CUTOFF_DB) cutoff = 10.0f * lc3_log10f(1.1920929e-7f + cutoff);
                 cutoff_max = lc3_maxf(cutoff, cutoff_max);
             }
             result = cutoff_max > (float)LC3C_BW_TC[bw] ? bw : fsi;
@@ -485,6 +488,9 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const lc3_tns_params &tp = c.n_ms_10 ? LC3C_TNS10[p_bw] : LC3C_TNS75[p_bw];
+    // at 10 ms / bandwidth index 2 the reference filters lines 12..200 although its sub-blocks (and the decoder) run to
+    // 240; LC3_SPEC_TNS_SSWB_STOP restores 240
+    const int sswb_stop = (L.spec_flags & LC3_SPEC_TNS_SSWB_STOP) && c.n_ms_10 && p_bw == 2;
     float *S = (float *)L.fa;
     float *sAC = S;        // [2][9][3] partial autocorrelations
     float *sES = S + 64;   // [2][3] sub-block energies
@@ -644,7 +650,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
         for (int f = 0; f < tp.num; f++) {
             const int order = L.ism[8 + f];
             if (order == 0) continue;
-            const int start = tp.start[f], len = tp.stop[f] - tp.start[f];  // len <= 256
+            const int start = tp.start[f], len = (sswb_stop && f == 0 ? 240 : tp.stop[f]) - tp.start[f];  // len <= 256
             const int lastl = (len - 1) & 63, lastj = (len - 1) >> 6;
             float fv[4], bv[4];
 #pragma unroll
@@ -766,10 +772,11 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
             const int i = lane + LC3_WAVE * j;
             v[j] = i < keep12 ? g12[i + len12] : 0.0f;
         }
-#ifndef LC3_RESAMP_POLY_IN_LDS
         const int p_rows = p * c.resamp_stride;
-        for (int i = lane; i < p_rows; i += LC3_WAVE) S[i] = c.resamp_poly[i];
+#ifdef LC3_RESAMP_POLY_IN_LDS
+        if (p_rows > 336)  // 8 kHz only (24 rows): larger than the workgroup's staged copy, fetched per frame as before
 #endif
+            for (int i = lane; i < p_rows; i += LC3_WAVE) S[i] = c.resamp_poly[i];
 #pragma unroll
         for (int j = 0; j < 5; j++) {
             const int i = lane + LC3_WAVE * j;
@@ -794,7 +801,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         const float *xa = W + c.hist + q0 - 2 * lim;  // tap j <-> k = j - lim
         const float *xb = W + c.hist + q1 - 2 * lim;
 #ifdef LC3_RESAMP_POLY_IN_LDS
-        const float *poly = lc3_front_tab.resamp_poly;  // staged once per workgroup
+        const float *poly = p * c.resamp_stride > 336 ? S : lc3_front_tab.resamp_poly;  // staged once per workgroup
 #else
         const float *poly = S;
 #endif
@@ -1324,7 +1331,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
     float nbits_offset;
     if (L.st.reset_offset_old) nbits_offset = 0.0f;
     else {
-        float prev = L.st.nbits_offset_old + 0.0f - (float)L.st.nbits_est_old;
+        float prev = L.st.nbits_offset_old + (float)L.st.nbits_spec_old - (float)L.st.nbits_est_old;  // nbits_spec_old = 0 by default (A1)
         nbits_offset = 0.8f * L.st.nbits_offset_old + 0.2f * lc3_minf(40.0f, lc3_maxf(-40.0f, prev));
     }
     const int nbits_spec_adj = lc3_f2u16((float)nbits_spec + nbits_offset + 0.5f);
@@ -1481,6 +1488,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
     if (lane == 0) {
         L.st.nbits_offset_old = nbits_offset;
         L.st.nbits_est_old = bc.nbits_est;
+        if (L.spec_flags & LC3_SPEC_NBITS_SPEC_OLD) L.st.nbits_spec_old = nbits_spec;
         L.st.reset_offset_old = reset_offset;
     }
     // global_gain_adjustment :350-388 (wave-uniform scalar code)

@@ -28,6 +28,7 @@ struct lc3_vq_ctx {
     int stride;
     const uint32_t *mpvq;    // MPVQ_OFFSETS[16][11]
     int nb;
+    int spec_flags;          // LC3_SPEC_SNS_LAST_GAIN: also try the last gain of every shape (the same for every frame of a launch)
 };
 
 // add_unit_pulse :285-316 (corr_xy / energy_y written through on every probe: SURVEY A2).  Magnitudes and pulse
@@ -230,15 +231,19 @@ __device__ __forceinline__ void lc3_sns_vq_frame(const lc3_vq_ctx &v) {
     LC3_VQ_NORMALIZE(y0, 16)
 #pragma unroll
     for (int n = 0; n < 16; n++) xq_sel[n] = xq[n];  // what a search that never improves on +inf is left with
+    const int last_gain = (v.spec_flags & LC3_SPEC_SNS_LAST_GAIN) != 0;  // off: the reference's search
     LC3_VQ_TRY(0, 0, LC3T_SNS_VQ_REG_ADJ_GAINS_BITS)
+    if (last_gain) LC3_VQ_TRY(0, 1, LC3T_SNS_VQ_REG_ADJ_GAINS_BITS)
     LC3_VQ_NORMALIZE(y1, 10)
     LC3_VQ_TRY(1, 0, LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS)
     LC3_VQ_TRY(1, 1, LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS)
     LC3_VQ_TRY(1, 2, LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS)
+    if (last_gain) LC3_VQ_TRY(1, 3, LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS)
     LC3_VQ_NORMALIZE(y2, 16)
     LC3_VQ_TRY(2, 0, LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS)
     LC3_VQ_TRY(2, 1, LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS)
     LC3_VQ_TRY(2, 2, LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS)
+    if (last_gain) LC3_VQ_TRY(2, 3, LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS)
     LC3_VQ_NORMALIZE(y3, 16)
     LC3_VQ_TRY(3, 0, LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS)
     LC3_VQ_TRY(3, 1, LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS)
@@ -247,6 +252,7 @@ __device__ __forceinline__ void lc3_sns_vq_frame(const lc3_vq_ctx &v) {
     LC3_VQ_TRY(3, 4, LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS)
     LC3_VQ_TRY(3, 5, LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS)
     LC3_VQ_TRY(3, 6, LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS)
+    if (last_gain) LC3_VQ_TRY(3, 7, LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS)
     // mvpq_enum :584-629 of the selected shape
     uint32_t idxa = 0, idxb = 0, joint;
     int ls_inda = 0, ls_indb = 0;

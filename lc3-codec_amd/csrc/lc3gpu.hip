@@ -328,7 +328,7 @@ __device__ __forceinline__ int lc3_find_group(const lc3_groups &G, unsigned wg, 
 template <class CV>
 __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigned wg, lc3_enc_state *states, int first_channel,
                                                    int n_streams, const int16_t *pcm, float *mid, int32_t *planes, int nbytes,
-                                                   int n_frames, int fresh, float *dbg, lc3_io io) {
+                                                   int n_frames, int fresh, float *dbg, lc3_io io, int spec_flags) {
     const int lane = threadIdx.x & 63, wave = LC3_WAVE_ID();
     lc3_enc_lds &L = lc3_enc_wg[wave];
     // stream index inside this launch; the waves past the end of the launch shadow the last stream and store nothing
@@ -341,6 +341,7 @@ __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigne
     lc3_front_tables_stage(c0);
     lc3_fft_tables_stage(c0);  // ends with the workgroup barrier
     LC3_PROF_BEGIN(L, lane);
+    if (lane == 0) L.spec_flags = spec_flags;
     if (fresh) lc3_enc_state_init(L, lane, gst, valid);
     else lc3_enc_state_load(L, lane, gst);
     for (int t = 0; t < n_frames; t++) {
@@ -366,25 +367,26 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_kernel(lc3
                                                                              int first_channel, int n_streams,
                                                                              const int16_t *pcm, float *mid, int32_t *planes,
                                                                              int nbytes, int n_frames, int fresh, float *dbg,
-                                                                             lc3_io io) {
-    lc3_enc_front_body<CV>(cfg, blockIdx.x, states, first_channel, n_streams, pcm, mid, planes, nbytes, n_frames, fresh, dbg, io);
+                                                                             lc3_io io, int spec_flags) {
+    lc3_enc_front_body<CV>(cfg, blockIdx.x, states, first_channel, n_streams, pcm, mid, planes, nbytes, n_frames, fresh, dbg, io,
+                           spec_flags);
 }
 __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_mixed_kernel(lc3_groups G, lc3_enc_state *states,
                                                                                    const int16_t *pcm, float *mid, int32_t *planes,
-                                                                                   int n_frames, int fresh, lc3_io io) {
+                                                                                   int n_frames, int fresh, lc3_io io, int spec_flags) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
     float *m = mid + (size_t)g.frame_base * (size_t)MP_WORDS;
     int32_t *p = planes + (size_t)g.frame_base * (size_t)EP_WORDS;
     if (g.fixed)
         lc3_enc_front_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
-                                          g.n_streams, pcm, m, p, g.nbytes, n_frames, fresh, nullptr, io);
+                                          g.n_streams, pcm, m, p, g.nbytes, n_frames, fresh, nullptr, io, spec_flags);
     else
         lc3_enc_front_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
-                                        g.n_streams, pcm, m, p, g.nbytes, n_frames, fresh, nullptr, io);
+                                        g.n_streams, pcm, m, p, g.nbytes, n_frames, fresh, nullptr, io, spec_flags);
 }
 
 // SNS vector quantiser, one LANE per frame (lc3_dev_enc_vq.h): 16 targets -> indices (packer plane) + 64 band gains.
-__device__ __forceinline__ void lc3_sns_vq_body(unsigned wg, int nb, float *mid, int32_t *planes, int n_frames) {
+__device__ __forceinline__ void lc3_sns_vq_body(unsigned wg, int nb, float *mid, int32_t *planes, int n_frames, int spec_flags) {
     __shared__ uint32_t s_mpvq[16 * 11];
     for (int i = threadIdx.x; i < 16 * 11; i += blockDim.x) s_mpvq[i] = LC3T_MPVQ_OFFSETS[i / 11][i % 11];
     __syncthreads();
@@ -397,16 +399,17 @@ __device__ __forceinline__ void lc3_sns_vq_body(unsigned wg, int nb, float *mid,
         v.stride = LC3_PLANE_STRIDE;
         v.mpvq = s_mpvq;
         v.nb = nb;
+        v.spec_flags = spec_flags;
         lc3_sns_vq_frame(v);
     }
 }
-__global__ __launch_bounds__(256) void lc3_sns_vq_kernel(int nb, float *mid, int32_t *planes, int n_frames) {
-    lc3_sns_vq_body(blockIdx.x, nb, mid, planes, n_frames);
+__global__ __launch_bounds__(256) void lc3_sns_vq_kernel(int nb, float *mid, int32_t *planes, int n_frames, int spec_flags) {
+    lc3_sns_vq_body(blockIdx.x, nb, mid, planes, n_frames, spec_flags);
 }
-__global__ __launch_bounds__(256) void lc3_sns_vq_mixed_kernel(lc3_groups G, float *mid, int32_t *planes, int n_frames) {
+__global__ __launch_bounds__(256) void lc3_sns_vq_mixed_kernel(lc3_groups G, float *mid, int32_t *planes, int n_frames, int spec_flags) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     lc3_sns_vq_body(blockIdx.x - g.wg_frame, g.nb, mid + (size_t)g.frame_base * (size_t)MP_WORDS,
-                    planes + (size_t)g.frame_base * (size_t)EP_WORDS, g.n_streams * n_frames);
+                    planes + (size_t)g.frame_base * (size_t)EP_WORDS, g.n_streams * n_frames, spec_flags);
 }
 
 // Analysis, back half: one wave per stream: spectral shaping with the quantised gains, TNS, quantiser (stateful),
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(256) void lc3_sns_vq_mixed_kernel(lc3_groups G, flo
 template <class CV>
 __device__ __forceinline__ void lc3_enc_back_body(lc3_cfg_slot<CV> cfg, unsigned wg, lc3_enc_state *states, int first_channel,
                                                   int n_streams, const float *mid, int32_t *planes, int nbytes, int n_frames,
-                                                  float *dbg) {
+                                                  float *dbg, int spec_flags) {
     const int lane = threadIdx.x & 63, wave = LC3_WAVE_ID();
     lc3_enc_lds &L = lc3_enc_wg[wave];
     const int s_raw = (int)wg * LC3_WG_WAVES + wave;
@@ -431,6 +434,7 @@ __device__ __forceinline__ void lc3_enc_back_body(lc3_cfg_slot<CV> cfg, unsigned
     }
 #endif
     LC3_PROF_BEGIN(L, lane);
+    if (lane == 0) L.spec_flags = spec_flags;
     lc3_enc_state_load(L, lane, gst);  // the front half has stored (or initialised) the scalars
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const size_t fbase = (size_t)s * (size_t)n_frames;
@@ -450,21 +454,21 @@ template <class CV>
 __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_back_kernel(lc3_cfg_slot<CV> cfg, lc3_enc_state *states,
                                                                             int first_channel, int n_streams,
                                                                             const float *mid, int32_t *planes, int nbytes,
-                                                                            int n_frames, float *dbg) {
-    lc3_enc_back_body<CV>(cfg, blockIdx.x, states, first_channel, n_streams, mid, planes, nbytes, n_frames, dbg);
+                                                                            int n_frames, float *dbg, int spec_flags) {
+    lc3_enc_back_body<CV>(cfg, blockIdx.x, states, first_channel, n_streams, mid, planes, nbytes, n_frames, dbg, spec_flags);
 }
 __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_back_mixed_kernel(lc3_groups G, lc3_enc_state *states,
                                                                                                 const float *mid, int32_t *planes,
-                                                                                                int n_frames) {
+                                                                                                int n_frames, int spec_flags) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
     const float *m = mid + (size_t)g.frame_base * (size_t)MP_WORDS;
     int32_t *p = planes + (size_t)g.frame_base * (size_t)EP_WORDS;
     if (g.fixed)
         lc3_enc_back_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
-                                         g.n_streams, m, p, g.nbytes, n_frames, nullptr);
+                                         g.n_streams, m, p, g.nbytes, n_frames, nullptr, spec_flags);
     else
         lc3_enc_back_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
-                                       g.n_streams, m, p, g.nbytes, n_frames, nullptr);
+                                       g.n_streams, m, p, g.nbytes, n_frames, nullptr, spec_flags);
 }
 
 // Bitstream packer, one LANE per frame (lc3_dev_enc_pack.h).  blockDim.x frames per workgroup; context lookup and the
@@ -977,7 +981,8 @@ int grow_async(T *&p, size_t bytes, hipStream_t stream) {
 }
 
 // sorts the streams of a mixed handle by (configuration slot, frame bytes) and builds groups, tables and mappings
-int build_mixed(HandleCommon &hc, int n, const lc3gpu_stream_desc *descs, bool encoder) {
+// refuse_8k: an encoder without LC3GPU_SPEC_8KHZ_ENCODE; min_bytes: 20 for encoders, 1 for decoders
+int build_mixed(HandleCommon &hc, int n, const lc3gpu_stream_desc *descs, bool refuse_8k, int min_bytes) {
     if (!descs || n <= 0) return LC3GPU_EINVAL;
     struct Key { int slot, nbytes, idx; };
     std::vector<Key> keys((size_t)n);
@@ -986,8 +991,8 @@ int build_mixed(HandleCommon &hc, int n, const lc3gpu_stream_desc *descs, bool e
     for (int i = 0; i < n; i++) {
         int rc = make_config(cfgs[(size_t)i], descs[i].frame_us, descs[i].fs_hz);
         if (rc) return rc;
-        if (encoder && cfgs[(size_t)i].fs_ind == 0 && descs[i].fs_hz == 8000) return LC3GPU_EUNSUPPORTED;  // bandwidth_detector.rs:36-37
-        if (descs[i].nbytes < (encoder ? 20 : 1) || descs[i].nbytes > LC3_MAX_NE) return LC3GPU_ELENGTH;
+        if (refuse_8k && descs[i].fs_hz == 8000) return LC3GPU_EUNSUPPORTED;  // bandwidth_detector.rs:36-37
+        if (descs[i].nbytes < min_bytes || descs[i].nbytes > LC3_MAX_NE) return LC3GPU_ELENGTH;
         int k = 0;
         for (int q = 0; q < 6; q++)
             if (fs_tab[q] == descs[i].fs_hz) k = q;
@@ -1065,6 +1070,7 @@ void fill_groups(const HandleCommon &hc, int T, unsigned fpb, lc3_groups &G, uns
 }  // namespace
 
 struct lc3gpu_encoder : HandleCommon {
+    int spec_flags = 0;  // LC3GPU_SPEC_* (0 = the reference's behaviour)
     lc3_enc_state *d_states = nullptr;
     // staging for the single-frame host API
     int16_t *d_pcm1 = nullptr;
@@ -1197,17 +1203,22 @@ static int encoder_alloc(lc3gpu_encoder *e) {
 }
 
 int lc3gpu_encoder_create(lc3gpu_encoder **out, int num_channels, int frame_us, int fs_hz) {
-    if (!out || num_channels <= 0) return LC3GPU_EINVAL;
+    return lc3gpu_encoder_create_spec(out, num_channels, frame_us, fs_hz, 0);
+}
+
+int lc3gpu_encoder_create_spec(lc3gpu_encoder **out, int num_channels, int frame_us, int fs_hz, int spec_flags) {
+    if (!out || num_channels <= 0 || (spec_flags & ~LC3GPU_SPEC_ALL)) return LC3GPU_EINVAL;
     *out = nullptr;
     lc3_cfg c;
     int rc = make_config(c, frame_us, fs_hz);
     if (rc) return rc;
     // the reference cannot construct an 8 kHz encoder (encoder/bandwidth_detector.rs:36-37 indexes [fs_ind - 1])
-    if (c.fs_ind == 0) return LC3GPU_EUNSUPPORTED;
+    if (c.fs_ind == 0 && !(spec_flags & LC3GPU_SPEC_8KHZ_ENCODE)) return LC3GPU_EUNSUPPORTED;
     if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
     lc3gpu_encoder *e = new (std::nothrow) lc3gpu_encoder();
     if (!e) return LC3GPU_EINVAL;
     e->num_channels = num_channels;
+    e->spec_flags = spec_flags;
     rc = cfg_acquire(e->h, frame_us, fs_hz);
     if (rc == LC3GPU_OK) rc = encoder_alloc(e);
     if (rc) { lc3gpu_encoder_destroy(e); return rc; }
@@ -1216,12 +1227,17 @@ int lc3gpu_encoder_create(lc3gpu_encoder **out, int num_channels, int frame_us, 
 }
 
 int lc3gpu_encoder_create_mixed(lc3gpu_encoder **out, int n_streams, const lc3gpu_stream_desc *descs) {
-    if (!out || n_streams <= 0 || !descs) return LC3GPU_EINVAL;
+    return lc3gpu_encoder_create_mixed_spec(out, n_streams, descs, 0);
+}
+
+int lc3gpu_encoder_create_mixed_spec(lc3gpu_encoder **out, int n_streams, const lc3gpu_stream_desc *descs, int spec_flags) {
+    if (!out || n_streams <= 0 || !descs || (spec_flags & ~LC3GPU_SPEC_ALL)) return LC3GPU_EINVAL;
     *out = nullptr;
     if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
     lc3gpu_encoder *e = new (std::nothrow) lc3gpu_encoder();
     if (!e) return LC3GPU_EINVAL;
-    int rc = build_mixed(*e, n_streams, descs, true);
+    e->spec_flags = spec_flags;
+    int rc = build_mixed(*e, n_streams, descs, !(spec_flags & LC3GPU_SPEC_8KHZ_ENCODE), 20);
     if (rc == LC3GPU_OK) rc = encoder_alloc(e);
     if (rc) { lc3gpu_encoder_destroy(e); return rc; }
     *out = e;
@@ -1261,7 +1277,7 @@ static int encoder_materialise(lc3gpu_encoder *e, int first, int n, hipStream_t 
         if (!e->fresh_mask[(size_t)i]) continue;
         const HostCfg &h = e->mixed ? e->groups[(size_t)e->streams[(size_t)e->caller_of_internal[(size_t)i]].group].h : e->h;
         LC3_LAUNCH_CFG(lc3_enc_front_kernel, h, dim3(1), dim3(64 * LC3_WG_WAVES), 0, stream, e->d_states, i, 1,
-                       (const int16_t *)e->d_pcm1, e->d_mid, e->d_planes, 20, 0, 1, (float *)nullptr, io);
+                       (const int16_t *)e->d_pcm1, e->d_mid, e->d_planes, 20, 0, 1, (float *)nullptr, io, e->spec_flags);
         HIP_TRY(hipGetLastError());
         e->fresh_mask[(size_t)i] = 0;
     }
@@ -1293,15 +1309,15 @@ static int encode_launch(lc3gpu_encoder *e, const HostCfg &h, int first, int n, 
     const dim3 wg_grid((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), wg_block(64 * LC3_WG_WAVES);
     e->timer.mark(stream);
     LC3_LAUNCH_CFG(lc3_enc_front_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n, d_pcm, e->d_mid,
-                       e->d_planes, nbytes, n_frames, fresh, dbg, io);
+                       e->d_planes, nbytes, n_frames, fresh, dbg, io, e->spec_flags);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
     hipLaunchKernelGGL(lc3_sns_vq_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, stream, h.c.nb, e->d_mid,
-                       e->d_planes, (int)frames);
+                       e->d_planes, (int)frames, e->spec_flags);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
     LC3_LAUNCH_CFG(lc3_enc_back_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n,
-                       (const float *)e->d_mid, e->d_planes, nbytes, n_frames, dbg);
+                       (const float *)e->d_mid, e->d_planes, nbytes, n_frames, dbg, e->spec_flags);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
     const unsigned fpb = lc3_frame_block_fit(LC3_PACK_LDS_FIXED, (size_t)nbytes);
@@ -1359,7 +1375,7 @@ int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out,
     lc3_io io = {0, e->d_tab};
     e->timer.mark(stream);
     hipLaunchKernelGGL(lc3_enc_front_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states, d_pcm, e->d_mid,
-                       e->d_planes, n_frames, fresh, io);
+                       e->d_planes, n_frames, fresh, io, e->spec_flags);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
     lc3_groups G256;  // the vector quantiser runs 256 frames per workgroup
@@ -1368,12 +1384,12 @@ int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out,
         size_t f;
         int m;
         fill_groups(*e, n_frames, 256u, G256, a, b, f, m);
-        hipLaunchKernelGGL(lc3_sns_vq_mixed_kernel, dim3(b), dim3(256), 0, stream, G256, e->d_mid, e->d_planes, n_frames);
+        hipLaunchKernelGGL(lc3_sns_vq_mixed_kernel, dim3(b), dim3(256), 0, stream, G256, e->d_mid, e->d_planes, n_frames, e->spec_flags);
         HIP_TRY(hipGetLastError());
     }
     e->timer.mark(stream);
     hipLaunchKernelGGL(lc3_enc_back_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states,
-                       (const float *)e->d_mid, e->d_planes, n_frames);
+                       (const float *)e->d_mid, e->d_planes, n_frames, e->spec_flags);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
     const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)max_nbytes + 3) & ~(size_t)3) + 4;
@@ -1508,7 +1524,7 @@ int lc3gpu_decoder_create_mixed(lc3gpu_decoder **out, int n_streams, const lc3gp
     if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
     lc3gpu_decoder *d = new (std::nothrow) lc3gpu_decoder();
     if (!d) return LC3GPU_EINVAL;
-    int rc = build_mixed(*d, n_streams, descs, false);
+    int rc = build_mixed(*d, n_streams, descs, false, 1);
     if (rc == LC3GPU_OK) rc = decoder_alloc(d);
     if (rc) { lc3gpu_decoder_destroy(d); return rc; }
     *out = d;

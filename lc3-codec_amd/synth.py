@@ -63,3 +63,36 @@ def make_ltpf_pcm(nf, fs_hz, n_frames=14):
     x[1] = tone * gate + rng.uniform(-1.0, 1.0, n) * 3000.0 * (1.0 - gate)
     x[2] = 12000.0 * np.sin(2.0 * np.pi * 150.0 * t) + 5000.0 * np.sin(2.0 * np.pi * 300.0 * t + 0.3)
     return np.clip(np.rint(x), -32768, 32767).astype(np.int16).reshape(3, n_frames, nf)
+
+
+def make_bandlimited_pcm(n_streams, n_frames, nf, fs_hz, cutoff_hz, seed=SEED):
+    """Streams whose content stops below `cutoff_hz` (tones with a random roll-off towards the cut-off, nothing above it):
+    what an up-sampled narrower-band signal looks like to the bandwidth detector (encoder/bandwidth_detector.rs:64-127), so
+    that its cut-off stage, and the TNS band layouts of the lower bandwidth indices, are exercised at a high sampling rate."""
+    n = n_frames * nf
+    t = np.arange(n, dtype=np.float64) / float(fs_hz)
+    out = np.zeros((n_streams, n_frames, nf), np.int16)
+    for i in range(n_streams):
+        rng = np.random.default_rng([seed, 7919, i])
+        k = int(rng.integers(12, 40))
+        f = np.sort(rng.uniform(100.0, cutoff_hz, k))
+        edge = rng.uniform(0.03, 0.6)                       # width of the roll-off below the cut-off, as a fraction of it
+        slope = rng.uniform(5.0, 45.0)                      # dB lost across the roll-off
+        rel = np.clip((f - cutoff_hz * (1.0 - edge)) / (cutoff_hz * edge), 0.0, 1.0)
+        amp = 10.0 ** (-slope * rel / 20.0) * rng.uniform(0.3, 1.0, k)
+        x = np.zeros(n)
+        for fk, ak in zip(f, amp):
+            x += ak * np.sin(2.0 * np.pi * fk * t + rng.uniform(0.0, 2.0 * np.pi))
+        x /= max(1e-9, np.abs(x).max())
+        # band-limited clicks (all partials in phase at t0, a short Gaussian envelope): temporal structure for the TNS stage
+        grid = np.arange(200.0, cutoff_hz * 0.97, 150.0)
+        for t0 in rng.uniform(0.0, n / float(fs_hz), max(1, n_frames // 2)):
+            env = np.exp(-0.5 * ((t - t0) / 0.0015) ** 2)
+            sel = env > 1e-4
+            click = np.zeros(int(sel.sum()))
+            for fk in grid:
+                click += np.cos(2.0 * np.pi * fk * (t[sel] - t0))
+            x[sel] += 2.0 * env[sel] * click / len(grid)
+        x *= 10.0 ** (rng.uniform(-20.0, -6.0) / 20.0) * 32767.0 / max(1e-9, np.abs(x).max())
+        out[i] = np.clip(np.rint(x), -32768, 32767).astype(np.int16).reshape(n_frames, nf)
+    return out

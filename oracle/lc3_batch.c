@@ -8,7 +8,7 @@
 #include <stdlib.h>
 
 typedef struct {
-    int fs_hz, frame_us, nbytes, n_frames, s_begin, s_end, nf, encode, rc;
+    int fs_hz, frame_us, nbytes, n_frames, s_begin, s_end, nf, encode, rc, spec_flags;
     const int16_t *pcm_in;
     uint8_t *bytes_out;
     const uint8_t *bytes_in;
@@ -22,7 +22,7 @@ static void *worker(void *arg) {
         lc3o_encoder *e = (lc3o_encoder *)malloc(sizeof(lc3o_encoder));
         if (!e) { j->rc = -2; return 0; }
         for (s = j->s_begin; s < j->s_end; s++) {
-            if (lc3o_encoder_init(e, j->fs_hz, j->frame_us)) { j->rc = -1; break; }
+            if (lc3o_encoder_init_spec(e, j->fs_hz, j->frame_us, j->spec_flags)) { j->rc = -1; break; }
             for (t = 0; t < j->n_frames; t++) {
                 size_t f = (size_t)s * (size_t)j->n_frames + (size_t)t;
                 lc3o_encode_frame(e, j->pcm_in + f * (size_t)j->nf, j->bytes_out + f * (size_t)j->nbytes, j->nbytes);
@@ -76,7 +76,13 @@ static int run(job proto, int n_streams, int n_threads) {
 
 int lc3o_encode_batch(int fs_hz, int frame_us, int nbytes, int n_streams, int n_frames, const int16_t *pcm,
                       uint8_t *bytes, int n_threads) {
+    return lc3o_encode_batch_spec(fs_hz, frame_us, nbytes, n_streams, n_frames, pcm, bytes, n_threads, 0);
+}
+
+int lc3o_encode_batch_spec(int fs_hz, int frame_us, int nbytes, int n_streams, int n_frames, const int16_t *pcm, uint8_t *bytes,
+                           int n_threads, int spec_flags) {
     job j = {0};
+    j.spec_flags = spec_flags;
     j.fs_hz = fs_hz; j.frame_us = frame_us; j.nbytes = nbytes; j.n_frames = n_frames; j.encode = 1;
     j.pcm_in = pcm; j.bytes_out = bytes;
     return run(j, n_streams, n_threads);

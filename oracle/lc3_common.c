@@ -6,6 +6,7 @@
 
 /* common/config.rs:42-100 */
 int lc3o_config_new(lc3o_config *c, int fs_hz, int frame_us) {
+    c->spec_flags = 0;
     static const int fs_tab[6] = {8000, 16000, 24000, 32000, 44100, 48000};
     static const int ind_tab[6] = {0, 1, 2, 3, 4, 4};
     static const int nf75[6] = {60, 120, 180, 240, 360, 360};

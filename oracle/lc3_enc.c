@@ -133,6 +133,7 @@ lc3o_bw_result lc3o_enc_bandwidth(const lc3o_config *c, const float *e_b) {
         int from = start[bw] + 1 - l_bw, to = start[bw];
         for (n = from; n < to; n++) {
             float cutoff = e_b[n - l_bw] / e_b[n];
+            if (c->spec_flags & LC3O_SPEC_BW_CUTOFF_DB) cutoff = 10.0f * lc3m_log10f(1.1920929e-7f + cutoff);
             cutoff_max = lc3m_maxf(cutoff, cutoff_max);
         }
         r.bandwidth_ind = cutoff_max > (float)TC[bw] ? bw : fsi;
@@ -245,7 +246,8 @@ static void mvpq_enum(uint32_t *index, int32_t *lead_sign_ind, int dim_in, const
 }
 
 /* run_quant :569-581 = sns_quant_stage1 :318-361 + sns_quant_stage2 :363-567 */
-void lc3o_enc_sns_quant(const float *scf, float *scfq, lc3o_sns_result *res) {
+void lc3o_enc_sns_quant(const float *scf, float *scfq, lc3o_sns_result *res) { lc3o_enc_sns_quant_spec(scf, scfq, res, 0); }
+void lc3o_enc_sns_quant_spec(const float *scf, float *scfq, lc3o_sns_result *res, int spec_flags) {
     const float *LFCB = TF(LFCB), *HFCB = TF(HFCB), *D = TF(D);
     float st1[16], r1[16], t2rot[16], abs_x[16];
     int32_t y0[16], y1[16], y2[16], y3[16];
@@ -336,7 +338,8 @@ void lc3o_enc_sns_quant(const float *scf, float *scfq, lc3o_sns_result *res) {
 
     {
         /* gain search excludes the last gain of every shape */
-        static const int g_maxind[4] = {1, 3, 3, 7};
+        static const int g_maxind_ref[4] = {1, 3, 3, 7}, g_maxind_all[4] = {2, 4, 4, 8};
+        const int *g_maxind = (spec_flags & LC3O_SPEC_SNS_LAST_GAIN) ? g_maxind_all : g_maxind_ref;
         const float *gains[4];
         int shape_j = 0, gind = 0;
         float g_sel = 0.0f, d_mse_min = INFINITY;
@@ -475,7 +478,7 @@ lc3o_sns_result lc3o_enc_sns(const lc3o_config *c, float *x, const float *e_b, i
     } else {
         memcpy(scf, ds, sizeof(scf));
     }
-    lc3o_enc_sns_quant(scf, scfq, &res);
+    lc3o_enc_sns_quant_spec(scf, scfq, &res, c->spec_flags);
     /* apply_scale_factor_interpolation :163-183 */
     interp[0] = scfq[0];
     interp[1] = scfq[0];
@@ -527,11 +530,13 @@ lc3o_tns_result lc3o_enc_tns(const lc3o_config *c, float *x_s, int p_bw, int nbi
     static const float LAGW[9] = {1.0f, 0.9980280260203829f, 0.9921354055113971f, 0.9823915844707989f,
                                   0.9689107911912967f, 0.9518498073692735f, 0.9314049334023056f,
                                   0.9078082299969592f, 0.8813231366694713f};
-    const tns_params *tp = c->n_ms_10 ? &TNS10[p_bw] : &TNS75[p_bw];
+    tns_params tp_v = c->n_ms_10 ? TNS10[p_bw] : TNS75[p_bw];
+    const tns_params *tp = &tp_v;
     const float step = (float)3.14159265358979323846 / 17.0f; /* PI as f32 / 17.0 :268 */
     lc3o_tns_result res;
     int f, k, n, s, ne = c->ne;
     memset(&res, 0, sizeof(res));
+    if ((c->spec_flags & LC3O_SPEC_TNS_SSWB_STOP) && c->n_ms_10 && p_bw == 2) tp_v.stop[0] = 240; /* SURVEY A5 corrected */
     res.num_tns_filters = tp->num;
     res.lpc_weighting = c->n_ms_10 ? (nbits < 480) : (nbits < 360);
 
@@ -1012,6 +1017,7 @@ lc3o_quant_result lc3o_enc_quant(const lc3o_config *c, lc3o_quant_state *st, con
     /* save state :97-100 (after the FIRST pass) */
     st->nbits_offset_old = nbits_offset;
     st->nbits_est_old = bc.nbits_est;
+    if (c->spec_flags & LC3O_SPEC_NBITS_SPEC_OLD) st->nbits_spec_old = nbits_spec;
     st->reset_offset_old = reset_offset;
 
     /* global_gain_adjustment :350-388 */
@@ -1330,9 +1336,11 @@ void lc3o_enc_bitstream(const lc3o_config *c, lc3o_bw_result bw, const lc3o_sns_
 }
 
 /* ================================================================= top level (encoder/lc3_encoder.rs) */
-int lc3o_encoder_init(lc3o_encoder *e, int fs_hz, int frame_us) {
+int lc3o_encoder_init(lc3o_encoder *e, int fs_hz, int frame_us) { return lc3o_encoder_init_spec(e, fs_hz, frame_us, 0); }
+int lc3o_encoder_init_spec(lc3o_encoder *e, int fs_hz, int frame_us, int spec_flags) {
     memset(e, 0, sizeof(*e));
     if (lc3o_config_new(&e->cfg, fs_hz, frame_us)) return -1;
+    e->cfg.spec_flags = spec_flags;
     lc3o_dct4_init(&e->dct, e->cfg.nf);
     e->att.attack_pos_last = -1; /* attack_detector.rs:38 */
     lc3o_ltpf_enc_init(&e->cfg, &e->ltpf);

@@ -30,7 +30,15 @@ typedef struct { float r, i; } lc3o_cpx; /* common/complex.rs:4-8 */
 /* common/config.rs:18-100 */
 typedef struct {
     int fs_ind, fs, ne, n_ms_10 /* 1 = TenMs, 0 = SevenPointFiveMs */, nb, nf, z;
+    int spec_flags; /* LC3O_SPEC_*: 0 = every deviation of the reference from the LC3 specification reproduced (the default) */
 } lc3o_config;
+/* Opt-in corrections of the reference's deviations, one bit each; the product mirrors them as LC3GPU_SPEC_*
+ * (include/lc3gpu.h).  With a bit set there is no reference behaviour to compare with: the oracle then only pins the GPU. */
+#define LC3O_SPEC_8KHZ_ENCODE 1     /* A6: an 8 kHz encoder can be built (the bandwidth detector returns at once, :66-71) */
+#define LC3O_SPEC_TNS_SSWB_STOP 2   /* A5: 10 ms, bandwidth index 2: the TNS filter stops at line 240, not 200 */
+#define LC3O_SPEC_BW_CUTOFF_DB 4    /* A7: cut-off test on 10 log10(eps + E[n-L] / E[n]) as the note at bandwidth_detector.rs:106-107 says the specification asks */
+#define LC3O_SPEC_SNS_LAST_GAIN 8   /* A3: the SNS gain search also tries the last gain of every shape */
+#define LC3O_SPEC_NBITS_SPEC_OLD 16 /* A1: nbits_spec_old follows nbits_spec */
 int lc3o_config_new(lc3o_config *c, int fs_hz, int frame_us);
 
 /* common/kissfft.rs + common/dct_iv.rs */
@@ -102,6 +110,7 @@ typedef struct {
 } lc3o_encoder;
 
 int lc3o_encoder_init(lc3o_encoder *e, int fs_hz, int frame_us);
+int lc3o_encoder_init_spec(lc3o_encoder *e, int fs_hz, int frame_us, int spec_flags);
 /* Lc3Encoder::encode_frame, encoder/lc3_encoder.rs:63-112,175-191.  nbytes = buf_out.len() */
 int lc3o_encode_frame(lc3o_encoder *e, const int16_t *pcm, uint8_t *out, int nbytes);
 
@@ -111,6 +120,7 @@ lc3o_bw_result lc3o_enc_bandwidth(const lc3o_config *c, const float *e_b);
 int lc3o_enc_attack(const lc3o_config *c, lc3o_attack_state *st, const int16_t *x_s, int nbytes);
 lc3o_sns_result lc3o_enc_sns(const lc3o_config *c, float *x, const float *e_b, int attack);
 void lc3o_enc_sns_quant(const float *scf, float *scfq, lc3o_sns_result *r);
+void lc3o_enc_sns_quant_spec(const float *scf, float *scfq, lc3o_sns_result *r, int spec_flags);
 lc3o_tns_result lc3o_enc_tns(const lc3o_config *c, float *x, int p_bw, int nbits, int near_nyquist);
 void lc3o_ltpf_enc_init(const lc3o_config *c, lc3o_ltpf_enc_state *st);
 lc3o_ltpf_result lc3o_enc_ltpf(const lc3o_config *c, lc3o_ltpf_enc_state *st, const int16_t *x_s,
@@ -205,6 +215,8 @@ void lc3o_dec_output(const float *x, int16_t *out, int n);
  * streams are independent codec channels; frames of one stream are consecutive in time.
  * pcm: int16[S][T][nf]   bytes: uint8[S][T][nbytes]  (both stream-major)
  * n_threads <= 1 runs in the caller's thread. */
+int lc3o_encode_batch_spec(int fs_hz, int frame_us, int nbytes, int n_streams, int n_frames, const int16_t *pcm, uint8_t *bytes,
+                          int n_threads, int spec_flags);
 int lc3o_encode_batch(int fs_hz, int frame_us, int nbytes, int n_streams, int n_frames, const int16_t *pcm,
                       uint8_t *bytes, int n_threads);
 int lc3o_decode_batch(int fs_hz, int frame_us, int nbytes, int n_streams, int n_frames, const uint8_t *bytes,

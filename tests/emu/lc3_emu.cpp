@@ -119,7 +119,7 @@ struct Job {
     int lane, wave, valid;
     int encode;   // 0 decode, 1 encoder front half, 2 encoder back half
     float *mid;   // mid planes of the whole batch (encoder)
-    int n_frames, nbytes, fresh;
+    int n_frames, nbytes, fresh, spec_flags;
     lc3_enc_lds *EL;  // the workgroup's array of working sets
     lc3_dec_lds *DL;
     lc3_enc_state *est;   // this stream's state blob
@@ -140,6 +140,7 @@ void *lane_main(void *arg) {
     tl_wave = j->wave;
     if (j->encode == 1) {  // body of lc3_enc_front_kernel
         lc3_enc_lds &L = j->EL[j->wave];
+        if (lane == 0) L.spec_flags = j->spec_flags;
         if (j->fresh) lc3_enc_state_init(L, lane, j->est, j->valid);
         else lc3_enc_state_load(L, lane, j->est);
         for (int t = 0; t < j->n_frames; t++) {
@@ -155,6 +156,7 @@ void *lane_main(void *arg) {
             lc3_enc_state_store(j->cfg, L, lane, j->est, j->n_frames > 0 ? j->pcm_in + (size_t)(j->n_frames - 1) * j->cfg.nf : nullptr);
     } else if (j->encode == 2) {  // body of lc3_enc_back_kernel
         lc3_enc_lds &L = j->EL[j->wave];
+        if (lane == 0) L.spec_flags = j->spec_flags;
         lc3_enc_state_load(L, lane, j->est);
         lc3_mid_fetch cur, nxt;
         memset(&cur, 0, sizeof(cur));
@@ -209,9 +211,14 @@ void run_wg(const Job *protos) {
 
 extern "C" {
 // pcm int16[S][T][nf] -> bytes uint8[S][T][nbytes]; every stream starts fresh; dbg optional float[1472] (last frame)
+int lc3emu_encode_spec(int fs_hz, int frame_us, int nbytes, int S, int T, const int16_t *pcm, uint8_t *bytes, float *dbg, int spec_flags);
 int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16_t *pcm, uint8_t *bytes, float *dbg) {
+    return lc3emu_encode_spec(fs_hz, frame_us, nbytes, S, T, pcm, bytes, dbg, 0);
+}
+int lc3emu_encode_spec(int fs_hz, int frame_us, int nbytes, int S, int T, const int16_t *pcm, uint8_t *bytes, float *dbg, int spec_flags) {
     Job j;
     memset(&j, 0, sizeof(j));
+    j.spec_flags = spec_flags;
     lc3_host_plan pl;
     if (lc3_make_config(j.cfg, frame_us, fs_hz) || lc3_make_plan(j.cfg, pl)) return -1;
     j.cfg.fft_tw = pl.fft_tw.data();
@@ -269,6 +276,7 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
                 v.stride = LC3_PLANE_STRIDE;
                 v.mpvq = &LC3T_MPVQ_OFFSETS[0][0];
                 v.nb = j.cfg.nb;
+                v.spec_flags = spec_flags;
                 lc3_sns_vq_frame(v);
             }
         }

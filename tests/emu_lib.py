@@ -40,11 +40,11 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 
 
-def encode(pcm, nbytes, fs_hz=48000, frame_us=10000, dbg=None):
+def encode(pcm, nbytes, fs_hz=48000, frame_us=10000, dbg=None, spec_flags=0):
     pcm = np.ascontiguousarray(pcm, np.int16)
     S, T, _ = pcm.shape
     out = np.zeros((S, T, nbytes), np.uint8)
-    rc = lib().lc3emu_encode(fs_hz, frame_us, nbytes, S, T, _p(pcm), _p(out), _p(dbg))
+    rc = lib().lc3emu_encode_spec(fs_hz, frame_us, nbytes, S, T, _p(pcm), _p(out), _p(dbg), int(spec_flags))
     assert rc == 0
     return out
 

@@ -116,12 +116,13 @@ class Decoder:
             pass
 
 
-def encode_batch(pcm, nbytes, fs_hz=48000, frame_us=10000, threads=1):
-    """pcm int16[S][T][nf] -> uint8[S][T][nbytes]; every stream starts from a fresh encoder."""
+def encode_batch(pcm, nbytes, fs_hz=48000, frame_us=10000, threads=1, spec_flags=0):
+    """pcm int16[S][T][nf] -> uint8[S][T][nbytes]; every stream starts from a fresh encoder.  spec_flags: LC3O_SPEC_* bits
+    (corrections of the reference's deviations from the specification; 0 = the reference's behaviour)."""
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     S, T, nf = pcm.shape
     out = np.zeros((S, T, nbytes), np.uint8)
-    rc = lib().lc3o_encode_batch(fs_hz, frame_us, nbytes, S, T, P(pcm), P(out), threads)
+    rc = lib().lc3o_encode_batch_spec(fs_hz, frame_us, nbytes, S, T, P(pcm), P(out), threads, int(spec_flags))
     assert rc == 0
     return out
 

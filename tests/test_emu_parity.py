@@ -98,3 +98,37 @@ def test_emu_ltpf_transitions(fs, us, nbytes):
     assert all(c > 0 for c in counts[1:]), counts
     assert np.array_equal(E.encode(pcm, nbytes, fs, us), ref)
     assert np.array_equal(E.decode(ref, nf, fs, us), ref_pcm)
+
+
+SPEC_FLAGS = {"8khz": 1, "tns_sswb_stop": 2, "bw_cutoff_db": 4, "sns_last_gain": 8, "nbits_spec_old": 16}
+
+
+@pytest.mark.parametrize("flag", [2, 4, 8, 16, 31])
+def test_emu_spec_conformant_switches(flag):
+    """the opt-in corrections of the reference's deviations (LC3_SPEC_* bits), one at a time and all
+    together, device code vs the oracle with the same switch.  Band-limited input with clicks so that the bandwidth
+    detector's cut-off stage and the SSWB TNS layout are reached; only streams on which the switch changes the oracle's
+    output are run (the switch must bite), plus one on which it does not."""
+    pcm = synth.make_bandlimited_pcm(48, 8, 480, 48000, 11800.0)
+    ref0 = O.encode_batch(pcm, 100)
+    ref1 = O.encode_batch(pcm, 100, spec_flags=flag)
+    differs = np.flatnonzero((ref0 != ref1).any(axis=(1, 2)))
+    assert len(differs) > 0, "the switch changes nothing on this input"
+    same = np.flatnonzero(~(ref0 != ref1).any(axis=(1, 2)))
+    pick = list(differs[:3]) + list(same[:1])
+    got = E.encode(pcm[pick], 100, spec_flags=flag)
+    assert np.array_equal(got, ref1[pick])
+    assert np.array_equal(E.encode(pcm[pick[:1]], 100), ref0[pick[:1]])  # default: the reference's behaviour, unchanged
+
+
+def test_emu_8khz_encode_switch():
+    """LC3_SPEC_8KHZ_ENCODE: the reference cannot build an 8 kHz encoder (bandwidth_detector.rs:36-37); with the switch the
+    encoder follows the early return of BandwidthDetector::run (:66-71).  Device code vs oracle, and the oracle's own decoder
+    must make sense of the stream."""
+    for us, nb, nf in ((10000, 30, 80), (7500, 23, 60)):
+        pcm = synth.make_pcm(4, 6, nf, 8000, seed=9)
+        ref = O.encode_batch(pcm, nb, 8000, us, spec_flags=1)
+        assert np.array_equal(E.encode(pcm, nb, 8000, us, spec_flags=1), ref)
+        dec = O.decode_batch(ref, nf, 8000, us)
+        live = pcm.reshape(4, -1).std(axis=1) > 100
+        assert (dec.reshape(4, -1)[live].std(axis=1) > 50).all()

@@ -603,3 +603,71 @@ def test_runtime_configuration_view_of_the_headline_configuration():
     env = dict(os.environ, LC3GPU_GENERIC="1")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "generic ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---------------------------------------------------------------- spec-conformant switches
+def _gpu_encode_spec(pcm, nbytes, fs, us, flags):
+    torch = torch_mod()
+    S, T, nf = pcm.shape
+    enc = pkg.Lc3Encoder(S, us, fs, spec_flags=flags)
+    d_pcm = torch.from_numpy(np.ascontiguousarray(pcm)).cuda()
+    d_out = torch.zeros((S, T, nbytes), dtype=torch.uint8, device="cuda")
+    enc.encode(d_pcm, d_out, nbytes, T, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy()
+
+
+@pytest.mark.parametrize("fs,nf,nbytes,cutoff", [(48000, 480, 100, 11800.0), (32000, 320, 80, 11500.0), (48000, 480, 150, 7500.0)])
+def test_spec_conformant_switches(fs, nf, nbytes, cutoff):
+    """Every LC3GPU_SPEC_* bit alone and all together against the oracle with the same switch; default (0) unchanged and equal
+    to the reference's behaviour.  Where a switch bites on this input is asserted over the three parameter sets together by
+    test_spec_switches_bite; here each must simply match."""
+    pcm = synth.make_bandlimited_pcm(48, 8, nf, fs, cutoff)
+    ref0 = O.encode_batch(pcm, nbytes, fs, 10000, threads=8)
+    assert np.array_equal(_gpu_encode_spec(pcm, nbytes, fs, 10000, 0), ref0)
+    for flag in (2, 4, 8, 16, 2 | 4 | 8 | 16, 31):
+        ref = O.encode_batch(pcm, nbytes, fs, 10000, threads=8, spec_flags=flag)
+        assert np.array_equal(_gpu_encode_spec(pcm, nbytes, fs, 10000, flag), ref), flag
+
+
+def test_spec_switches_bite():
+    """each switch changes the oracle's output somewhere on the test inputs (otherwise the test above proves nothing)"""
+    hit = {2: 0, 4: 0, 8: 0, 16: 0}
+    for fs, nf, nbytes, cutoff in [(48000, 480, 100, 11800.0), (32000, 320, 80, 11500.0), (48000, 480, 150, 7500.0)]:
+        pcm = synth.make_bandlimited_pcm(48, 8, nf, fs, cutoff)
+        ref0 = O.encode_batch(pcm, nbytes, fs, 10000, threads=8)
+        for flag in hit:
+            hit[flag] += int((O.encode_batch(pcm, nbytes, fs, 10000, threads=8, spec_flags=flag) != ref0).any(axis=2).sum())
+    assert all(v > 0 for v in hit.values()), hit
+
+
+def test_8khz_encode_switch_and_mixed_handle_with_switches():
+    t = torch_mod()
+    with pytest.raises(pkg.Lc3EncoderError) as e:
+        pkg.Lc3Encoder(1, 10000, 8000)
+    assert e.value.code == -7  # default: as the reference, no 8 kHz encoder
+    with pytest.raises(pkg.Lc3EncoderError):
+        pkg.Lc3Encoder(1, 10000, 48000, spec_flags=64)  # unknown bit
+    for us, nb, nf in ((10000, 30, 80), (7500, 23, 60)):
+        pcm = synth.make_pcm(40, 8, nf, 8000, seed=9)
+        ref = O.encode_batch(pcm, nb, 8000, us, threads=8, spec_flags=1)
+        assert np.array_equal(_gpu_encode_spec(pcm, nb, 8000, us, 1), ref)
+        assert np.array_equal(gpu_decode(ref, nf, 8000, us), O.decode_batch(ref, nf, 8000, us, threads=8))
+    # a mixed handle with all switches on, 8 kHz streams included
+    descs = [(8000, 10000, 30), (48000, 10000, 100), (8000, 7500, 23), (32000, 10000, 80)] * 6
+    enc = pkg.Lc3Encoder.mixed(descs, spec_flags=31)
+    T = 5
+    pcms = []
+    for i, (fs, us, nb) in enumerate(descs):
+        nf = pkg.Lc3Config(fs, us).nf
+        pcms.append(synth.make_bandlimited_pcm(1, T, nf, fs, min(11800.0, fs * 0.45), seed=100 + i)[0] if fs > 8000
+                    else synth.make_pcm(1, T, nf, fs, seed=100 + i)[0])
+    d_pcm = t.from_numpy(np.concatenate([p.reshape(-1) for p in pcms])).cuda()
+    d_b = t.zeros(sum(T * d[2] for d in descs), dtype=t.uint8, device="cuda")
+    enc.encode_mixed(d_pcm, d_b, T, stream=t.cuda.current_stream().cuda_stream)
+    got = d_b.cpu().numpy()
+    off = 0
+    for i, (fs, us, nb) in enumerate(descs):
+        ref = O.encode_batch(pcms[i][None], nb, fs, us, spec_flags=31)[0]
+        assert np.array_equal(got[off:off + T * nb].reshape(T, nb), ref), (i, fs, us)
+        off += T * nb
