@@ -33,9 +33,15 @@ public:
         if (rc) throw Error(rc, "calc_working_buffer_lengths");
         return {(size_t)o[0], (size_t)o[1], (size_t)o[2]};
     }
-    Lc3Encoder(size_t num_channels, FrameDuration d, SamplingFrequency f) {
-        int rc = lc3gpu_encoder_create(&h_, (int)num_channels, (int)d, (int)f);
+    // spec_flags: LC3GPU_SPEC_* corrections of the reference's deviations from the specification (0 = the reference's behaviour)
+    Lc3Encoder(size_t num_channels, FrameDuration d, SamplingFrequency f, int spec_flags = 0) {
+        int rc = lc3gpu_encoder_create_spec(&h_, (int)num_channels, (int)d, (int)f, spec_flags);
         if (rc) throw Error(rc, "Lc3Encoder::new");
+    }
+    // one handle for streams of different configurations (one launch per kernel for the whole mixed batch)
+    explicit Lc3Encoder(const std::vector<lc3gpu_stream_desc> &streams, int spec_flags = 0) {
+        int rc = lc3gpu_encoder_create_mixed_spec(&h_, (int)streams.size(), streams.data(), spec_flags);
+        if (rc) throw Error(rc, "Lc3Encoder::mixed");
     }
     ~Lc3Encoder() { lc3gpu_encoder_destroy(h_); }
     Lc3Encoder(const Lc3Encoder &) = delete;
@@ -46,9 +52,15 @@ public:
         if (rc) throw Error(rc, "encode_frame");  // the reference panics here; Err() is impossible (empty enum)
     }
     // batch: device pointers, stream-major, asynchronous on `hip_stream`
-    void encode(const int16_t *d_pcm, uint8_t *d_out, int nbytes, int n_frames, void *hip_stream = nullptr) {
-        int rc = lc3gpu_encode(h_, d_pcm, d_out, nbytes, n_frames, hip_stream);
+    void encode(const int16_t *d_pcm, uint8_t *d_out, int nbytes, int n_frames, void *hip_stream = nullptr,
+                int layout = LC3GPU_LAYOUT_PLANAR) {
+        int rc = lc3gpu_encode_layout(h_, layout, d_pcm, d_out, nbytes, n_frames, hip_stream);
         if (rc) throw Error(rc, "encode");
+    }
+    // mixed handle: ragged buffers in descriptor order (lc3gpu.h)
+    void encode_mixed(const int16_t *d_pcm, uint8_t *d_out, int n_frames, void *hip_stream = nullptr) {
+        int rc = lc3gpu_encode_mixed(h_, d_pcm, d_out, n_frames, hip_stream);
+        if (rc) throw Error(rc, "encode_mixed");
     }
     lc3gpu_encoder *handle() { return h_; }
 
@@ -69,6 +81,10 @@ public:
         int rc = lc3gpu_decoder_create(&h_, (int)num_channels, (int)d, (int)f);
         if (rc) throw Error(rc, "Lc3Decoder::new");
     }
+    explicit Lc3Decoder(const std::vector<lc3gpu_stream_desc> &streams) {
+        int rc = lc3gpu_decoder_create_mixed(&h_, (int)streams.size(), streams.data());
+        if (rc) throw Error(rc, "Lc3Decoder::mixed");
+    }
     ~Lc3Decoder() { lc3gpu_decoder_destroy(h_); }
     Lc3Decoder(const Lc3Decoder &) = delete;
     Lc3Decoder &operator=(const Lc3Decoder &) = delete;
@@ -78,9 +94,14 @@ public:
         if (rc == LC3GPU_EBITS) throw Only16BitsPerAudioSampleSupported(rc, "decode_frame");
         if (rc) throw Error(rc, "decode_frame");
     }
-    void decode(const uint8_t *d_in, int16_t *d_pcm, int nbytes, int n_frames, void *hip_stream = nullptr, const uint8_t *d_bad_frame = nullptr) {
-        int rc = lc3gpu_decode(h_, d_in, d_bad_frame, d_pcm, nbytes, n_frames, hip_stream);
+    void decode(const uint8_t *d_in, int16_t *d_pcm, int nbytes, int n_frames, void *hip_stream = nullptr, const uint8_t *d_bad_frame = nullptr,
+                int layout = LC3GPU_LAYOUT_PLANAR) {
+        int rc = lc3gpu_decode_layout(h_, layout, d_in, d_bad_frame, d_pcm, nbytes, n_frames, hip_stream);
         if (rc) throw Error(rc, "decode");
+    }
+    void decode_mixed(const uint8_t *d_in, int16_t *d_pcm, int n_frames, void *hip_stream = nullptr, const uint8_t *d_bad_frame = nullptr) {
+        int rc = lc3gpu_decode_mixed(h_, d_in, d_bad_frame, d_pcm, n_frames, hip_stream);
+        if (rc) throw Error(rc, "decode_mixed");
     }
     uint64_t plc_events() {
         uint64_t v = 0;

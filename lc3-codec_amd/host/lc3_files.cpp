@@ -61,42 +61,37 @@ FileResult encode_wav_to_lc3(const std::string &wav_file, const std::string &lc3
     rc = lc3gpu_encoder_create(&enc, num_channels, frame_us, fs_hz);
     if (rc) { std::fclose(out); return fail(FileStatus::Codec, "encoder create failed", rc); }
     const size_t T = (size_t)std::max(1, opt.frames_per_launch);
-    std::vector<int16_t> planar(C * T * (size_t)nf);
-    std::vector<uint8_t> bytes(C * T * (size_t)nbytes), frame_out(C * (size_t)nbytes);
+    // The WAV sample order (int16[frame][sample][channel]) and the .lc3 frame order (uint8[frame][channel][nbytes]) ARE the
+    // interleaved layout of the batch call: what examples/encode.rs:95-115 does per frame on the host (de-interleave, one
+    // encode_frame per channel, frames appended channel after channel) happens inside the kernels' loads and stores.
+    std::vector<int16_t> inter(T * (size_t)nf * C);
+    std::vector<uint8_t> bytes(T * C * (size_t)nbytes);
     DeviceBuf d_pcm, d_out;
     FileResult res;
-    if (!d_pcm.alloc(planar.size() * 2) || !d_out.alloc(bytes.size())) {
+    if (!d_pcm.alloc(inter.size() * 2) || !d_out.alloc(bytes.size())) {
         res = fail(FileStatus::Codec, "device allocation failed", LC3GPU_EHIP);
     } else {
         for (size_t f0 = 0; f0 < total_frames && res.status == FileStatus::Ok; f0 += T) {
             const size_t tn = std::min(T, total_frames - f0);
-            // de-interleave: channel ch of frame t at planar[ch][t][i] (examples/encode.rs:97-103)
-            for (size_t t = 0; t < tn; t++) {
-                const size_t cursor = start + (f0 + t) * bytes_per_frame;
-                for (size_t i = 0; i < (size_t)nf; i++)
-                    for (size_t ch = 0; ch < C; ch++) {
-                        const size_t b = cursor + (i * C + ch) * 2;
-                        const int16_t v = b + 1 < in.size() ? (int16_t)rd16(in.data() + b) : (int16_t)0;
-                        planar[(ch * tn + t) * (size_t)nf + i] = v;
-                    }
+            // little-endian samples as they lie in the file; the last partial frame is zero padded (examples/encode.rs:72-95)
+            const size_t cursor = start + f0 * bytes_per_frame, n_samples = tn * (size_t)nf * C;
+            for (size_t i = 0; i < n_samples; i++) {
+                const size_t bpos = cursor + 2 * i;
+                inter[i] = bpos + 1 < in.size() ? (int16_t)rd16(in.data() + bpos) : (int16_t)0;
             }
-            if (hipMemcpy(d_pcm.p, planar.data(), C * tn * (size_t)nf * 2, hipMemcpyHostToDevice) != hipSuccess) {
+            if (hipMemcpy(d_pcm.p, inter.data(), n_samples * 2, hipMemcpyHostToDevice) != hipSuccess) {
                 res = fail(FileStatus::Codec, "upload failed", LC3GPU_EHIP);
                 break;
             }
-            rc = lc3gpu_encode(enc, (const int16_t *)d_pcm.p, (uint8_t *)d_out.p, nbytes, (int)tn, nullptr);
+            rc = lc3gpu_encode_layout(enc, LC3GPU_LAYOUT_INTERLEAVED, (const int16_t *)d_pcm.p, (uint8_t *)d_out.p, nbytes, (int)tn, nullptr);
             if (rc) { res = fail(FileStatus::Codec, "encode failed", rc); break; }
-            if (hipMemcpy(bytes.data(), d_out.p, C * tn * (size_t)nbytes, hipMemcpyDeviceToHost) != hipSuccess) {
+            if (hipMemcpy(bytes.data(), d_out.p, tn * C * (size_t)nbytes, hipMemcpyDeviceToHost) != hipSuccess) {
                 res = fail(FileStatus::Codec, "download failed", LC3GPU_EHIP);
                 break;
             }
-            for (size_t t = 0; t < tn; t++) {
-                for (size_t ch = 0; ch < C; ch++)
-                    std::memcpy(frame_out.data() + ch * (size_t)nbytes, bytes.data() + (ch * tn + t) * (size_t)nbytes, (size_t)nbytes);
-                if (std::fwrite(frame_out.data(), 1, frame_out.size(), out) != frame_out.size()) {
-                    res = fail(FileStatus::Io, "write failed");
-                    break;
-                }
+            if (std::fwrite(bytes.data(), 1, tn * C * (size_t)nbytes, out) != tn * C * (size_t)nbytes) {
+                res = fail(FileStatus::Io, "write failed");
+                break;
             }
             res.frames += tn;
         }
@@ -148,36 +143,31 @@ FileResult decode_lc3_to_wav(const std::string &lc3_file, const std::string &wav
     rc = lc3gpu_decoder_create(&dec, num_channels, frame_us, fs_hz);
     if (rc) { std::fclose(out); return fail(FileStatus::Codec, "decoder create failed", rc); }
     const size_t T = (size_t)std::max(1, opt.frames_per_launch);
-    std::vector<uint8_t> planar(C * T * (size_t)nbytes), frame_out((size_t)nf * C * 2);
-    std::vector<int16_t> pcm(C * T * (size_t)nf);
+    // file order in, WAV order out: the interleaved layout of the batch call (examples/decode.rs:86-117 on the host)
+    std::vector<int16_t> pcm(T * (size_t)nf * C);
+    std::vector<uint8_t> frame_out(T * (size_t)nf * C * 2);
     DeviceBuf d_in, d_pcm;
     FileResult res;
-    if (!d_in.alloc(planar.size()) || !d_pcm.alloc(pcm.size() * 2)) {
+    if (!d_in.alloc(T * C * (size_t)nbytes) || !d_pcm.alloc(pcm.size() * 2)) {
         res = fail(FileStatus::Codec, "device allocation failed", LC3GPU_EHIP);
     } else {
         for (size_t f0 = 0; f0 < total_frames && res.status == FileStatus::Ok; f0 += T) {
             const size_t tn = std::min(T, total_frames - f0);
-            for (size_t t = 0; t < tn; t++)
-                for (size_t ch = 0; ch < C; ch++)
-                    std::memcpy(planar.data() + (ch * tn + t) * (size_t)nbytes, in.data() + ((f0 + t) * C + ch) * (size_t)nbytes, (size_t)nbytes);
-            if (hipMemcpy(d_in.p, planar.data(), C * tn * (size_t)nbytes, hipMemcpyHostToDevice) != hipSuccess) {
+            if (hipMemcpy(d_in.p, in.data() + f0 * C * (size_t)nbytes, tn * C * (size_t)nbytes, hipMemcpyHostToDevice) != hipSuccess) {
                 res = fail(FileStatus::Codec, "upload failed", LC3GPU_EHIP);
                 break;
             }
-            rc = lc3gpu_decode(dec, (const uint8_t *)d_in.p, nullptr, (int16_t *)d_pcm.p, nbytes, (int)tn, nullptr);
+            rc = lc3gpu_decode_layout(dec, LC3GPU_LAYOUT_INTERLEAVED, (const uint8_t *)d_in.p, nullptr, (int16_t *)d_pcm.p, nbytes, (int)tn, nullptr);
             if (rc) { res = fail(FileStatus::Codec, "decode failed", rc); break; }
-            if (hipMemcpy(pcm.data(), d_pcm.p, C * tn * (size_t)nf * 2, hipMemcpyDeviceToHost) != hipSuccess) {
+            const size_t n_samples = tn * (size_t)nf * C;
+            if (hipMemcpy(pcm.data(), d_pcm.p, n_samples * 2, hipMemcpyDeviceToHost) != hipSuccess) {
                 res = fail(FileStatus::Codec, "download failed", LC3GPU_EHIP);
                 break;
             }
-            for (size_t t = 0; t < tn; t++) {  // interleave (examples/decode.rs:113-117), little endian
-                for (size_t i = 0; i < (size_t)nf; i++)
-                    for (size_t ch = 0; ch < C; ch++)
-                        wr16(frame_out.data() + (i * C + ch) * 2, (uint16_t)pcm[(ch * tn + t) * (size_t)nf + i]);
-                if (std::fwrite(frame_out.data(), 1, frame_out.size(), out) != frame_out.size()) {
-                    res = fail(FileStatus::Io, "write failed");
-                    break;
-                }
+            for (size_t i = 0; i < n_samples; i++) wr16(frame_out.data() + 2 * i, (uint16_t)pcm[i]);  // little endian
+            if (std::fwrite(frame_out.data(), 1, n_samples * 2, out) != n_samples * 2) {
+                res = fail(FileStatus::Io, "write failed");
+                break;
             }
             res.frames += tn;
         }
