@@ -342,15 +342,19 @@ __device__ __forceinline__ int lc3_dec_load_frame(const CC &c, lc3_dec_lds &L, i
 // ------------------------------------------------------------------------------------------
 // D9: packet loss concealment (decoder/packet_loss_concealment.rs:49-85).  plc_last_good lives in HBM.
 // ------------------------------------------------------------------------------------------
+// a good frame: the concealment counters restart (save :49-61); the spectrum itself is copied to the state blob only where
+// nothing else holds it -- on the last frame of a launch (lc3_decode_frame_wave)
 template <class CC>
-__device__ __forceinline__ void lc3_dec_plc_save(const CC &c, lc3_dec_lds &L, int lane, lc3_dec_state *g) {
-    for (int k = lane; k < c.ne; k += LC3_WAVE) g->plc_last_good[k] = L.spec[k];
+__device__ __forceinline__ void lc3_dec_plc_save(const CC &c, lc3_dec_lds &L, int lane, lc3_dec_state *g, int to_blob) {
+    if (to_blob)
+        for (int k = lane; k < c.ne; k += LC3_WAVE) g->plc_last_good[k] = L.spec[k];
     if (lane == 0) {
         L.st.plc_num_lost = 0;
         L.st.plc_alpha = 1.0f;
     }
 }
-LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_plc_load(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_dec_state *g) {
+// last_good: the last good frame's spectrum (ne f32): the state blob's copy, or the plane column of an earlier frame of this launch
+LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_plc_load(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const float *last_good) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     // The sign-scrambling LCG seed_k = (16831 + seed_{k-1} * 12821) & 0xFFFF is affine mod 2^16, so lane l can
@@ -369,7 +373,7 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_plc_load(LC3_CFG_PARAM, L
     uint32_t seed = seed0;
     for (int i = 0; i <= lane; i++) seed = (16831u + seed * 12821u) & 0xFFFFu;  // seed_{lane}
     for (int k = lane; k < ne; k += LC3_WAVE) {
-        const float lg = g->plc_last_good[k];
+        const float lg = ((LC3_HBM_CONST(float))last_good)[k];
         L.spec[k] = seed < 0x8000u ? lg * alpha : lg * -alpha;
         if (k == ne - 1) {
             L.st.plc_seed = seed;  // the reference leaves the seed after ne steps
@@ -387,9 +391,10 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_plc_load(LC3_CFG_PARAM, L
 // in: nbytes in HBM; pcm_out: nf samples in HBM (4-byte aligned); plane/stride: the frame's parsed column
 // (lc3_dev_dec_parse.h); g: the stream's state blob in HBM.
 // ------------------------------------------------------------------------------------------
-LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes,
+// plc_src / save_good: see lc3_decode_stream_wave.  Returns 1 for a good frame, 0 for a concealed one.
+LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes,
                                                       int16_t *pcm_out, const lc3_plane_fetch &fetched, lc3_dec_state *g,
-                                                      int valid, int stride = 1) {
+                                                      int valid, int stride, const float *plc_src, int save_good) {
     LC3_CFG_BIND;
     const int nf = c.nf, nbits = nbytes * 8;
     LC3_STAMP(L, lane, 16);
@@ -399,9 +404,9 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_P
     if (ok) {
         ltpf_active = L.ism[SI_LTPF_ACTIVE];
         pitch_index = L.ism[SI_PITCH_INDEX];
-        if (valid) lc3_dec_plc_save(c, L, lane, g);
+        lc3_dec_plc_save(c, L, lane, g, valid && save_good);
     } else {
-        lc3_dec_plc_load(LC3_CFG_PASS, LC3_LDS_PASS lane, g);
+        lc3_dec_plc_load(LC3_CFG_PASS, LC3_LDS_PASS lane, plc_src);
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 18);
@@ -452,4 +457,34 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_frame_wave(LC3_CFG_P
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 21);
+    return ok;
+}
+
+// All frames of one stream of a launch.  Packet-loss concealment needs the spectrum of the last good frame
+// (decoder/packet_loss_concealment.rs:49-85).  Within a launch that spectrum already lies in HBM -- the plane column the
+// lane-per-frame stage wrote for that frame -- so a good frame copies nothing; only the last frame of the launch saves its
+// spectrum to the state blob (or, when that frame is lost, the plane column of the launch's last good frame is copied there).
+// Frame t's samples go to pcm0 + t * frame_step, `stride` elements apart.
+LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_stream_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes, const int32_t *planes,
+                                                       size_t fbase, int n_frames, lc3_dec_state *g, int valid, int16_t *pcm0,
+                                                       size_t frame_step, int stride) {
+    LC3_CFG_BIND;
+    const auto &c0 = c;
+    lc3_plane_fetch cur, nxt;
+    if (n_frames > 0) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, fbase, LC3_PLANE_WORDS), cur);
+    int t_good = -1, last_ok = 1;
+    for (int t = 0; t < n_frames; t++) {
+        const size_t f = fbase + (size_t)t;
+        if (t + 1 < n_frames) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, f + 1, LC3_PLANE_WORDS), nxt);
+        int16_t *out = pcm0 + (size_t)t * frame_step;
+        const float *plc_src = t_good >= 0 ? (const float *)(LC3_PLANE_COL(planes, fbase + (size_t)t_good, LC3_PLANE_WORDS) + LC3_PLANE_X * LC3_PLANE_STRIDE)
+                                           : (const float *)g->plc_last_good;
+        last_ok = lc3_decode_frame_wave(LC3_CFG_PASS, L, lane, nbytes, out, cur, g, valid, stride, plc_src, t == n_frames - 1);
+        if (last_ok) t_good = t;
+        cur = nxt;
+    }
+    if (valid && !last_ok && t_good >= 0) {  // the launch ended in a lost frame: its last good spectrum moves to the state blob
+        LC3_HBM_CONST(float) src = (LC3_HBM_CONST(float))(LC3_PLANE_COL(planes, fbase + (size_t)t_good, LC3_PLANE_WORDS) + LC3_PLANE_X * LC3_PLANE_STRIDE);
+        for (int k = lane; k < c0.ne; k += LC3_WAVE) g->plc_last_good[k] = src[k];
+    }
 }

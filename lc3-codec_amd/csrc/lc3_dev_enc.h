@@ -25,6 +25,9 @@ struct lc3_enc_scalars {
     float nbits_offset_old;
     int nbits_est_old;
     int nbits_spec_old;
+    // the LTPF sample rings of the state blob are circular: logical element i lives at (head + i) mod length, a frame overwrites
+    // only the oldest len12 / len6 slots instead of shifting the whole ring through HBM
+    int ring12_head, ring6_head, pad_[2];
 };
 struct lc3_enc_state {
     float x12[384];          // LTPF 12.8 kHz ring (encoder/long_term_post_filter.rs:114,227); 10 ms uses all 384
@@ -33,7 +36,7 @@ struct lc3_enc_state {
                              // samples of the previous frame
     lc3_enc_scalars sc;
 };
-static_assert(sizeof(lc3_enc_scalars) == 64 && sizeof(lc3_enc_state) % 16 == 0 && offsetof(lc3_enc_state, sc) % 16 == 0,
+static_assert(sizeof(lc3_enc_scalars) == 80 && sizeof(lc3_enc_state) % 16 == 0 && offsetof(lc3_enc_state, sc) % 16 == 0,
               "encoder state blob: 16-byte units");
 
 // LDS working set of one encoder wave: 8 KB (room for five workgroups of four streams per CU; the kernels run four,
@@ -80,7 +83,7 @@ __device__ __forceinline__ void lc3_enc_state_init(lc3_enc_lds &L, int lane, lc3
     // fresh channel (Lc3Encoder::new: zeroed working buffers; attack_detector.rs:31-43;
     // long_term_post_filter.rs:74-90 t_prev = K_MIN)
     int *w = (int *)&L.st;
-    if (lane < 16) w[lane] = 0;
+    if (lane < (int)(sizeof(lc3_enc_scalars) / 4)) w[lane] = 0;
     if (valid) {  // rings and history in HBM
         int *gw = (int *)g;
         for (int i = lane; i < (int)(offsetof(lc3_enc_state, sc) / 4); i += LC3_WAVE) gw[i] = 0;
@@ -712,6 +715,17 @@ __device__ __forceinline__ int lc3_float_order_key(float v) {
     const uint32_t b = lc3_bits(v + 0.0f);  // -0.0 + 0.0 = +0.0
     return (int)(b ^ ((uint32_t)((int32_t)b >> 31) & 0x7fffffffu));
 }
+// the same scan over elements with explicit indices: lane holds (v0, index i0) and (v1, index i1); returns the lowest index that
+// holds the maximum, -1 for an empty scan
+__device__ __forceinline__ int lc3_wave_argmax_first2(float v0, int i0, int in0, float v1, int i1, int in1, int lane, int *any_nan) {
+    const int lowest = -2147483647 - 1, big = 0x3fffffff;
+    const int k0 = in0 ? lc3_float_order_key(v0) : lowest, k1 = in1 ? lc3_float_order_key(v1) : lowest;
+    *any_nan = lc3_wave_ballot((in0 && v0 != v0) || (in1 && v1 != v1), lane) != 0ull;
+    const int m = lc3_wave_max_i32(k0 > k1 ? k0 : k1, lane);
+    const int c0 = in0 && k0 == m ? i0 : big, c1 = in1 && k1 == m ? i1 : big;
+    const int best = -lc3_wave_max_i32(-(c0 < c1 ? c0 : c1), lane);
+    return best == big ? -1 : best;
+}
 __device__ __forceinline__ int lc3_wave_argmax_first(float v0, int in0, float v1, int in1, int lane, int *any_nan) {
     const int lowest = -2147483647 - 1;
     const int k0 = in0 ? lc3_float_order_key(v0) : lowest, k1 = in1 ? lc3_float_order_key(v1) : lowest;
@@ -737,11 +751,41 @@ __device__ __forceinline__ float lc3_ltpf_dot(const float *x12, int n, int d) { 
     return acc;
 }
 
+// Two adjacent outputs of the polyphase resampler (encoder/long_term_post_filter.rs:152-166) from one sliding window of
+// samples: out0 = sum_j xa[j] * ha[j], out1 = sum_j xa[j + d] * hb[j] with d = DLO + far, each sum in tap order.  nt is a
+// multiple of 4; xa[0 .. nt + 11) must be readable.
+template <int DLO>
+__device__ __forceinline__ void lc3_resample_pair(const float *xa, const float *ha, const float *hb, int nt, int far, float &out0,
+                                                  float &out1) {
+    float win[8], nxt[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 8; u++) win[u] = xa[u];
+    float acc0 = 0.0f, acc1 = 0.0f;
+    for (int j = 0; j < nt; j += 4) {
+        const lc3_f4 a = *(const lc3_f4 *)(ha + j), b = *(const lc3_f4 *)(hb + j);
+#pragma unroll
+        for (int u = 0; u < 4; u++) nxt[u] = xa[j + 8 + u];
+        const float ta[4] = {a.x, a.y, a.z, a.w}, tb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            acc0 += win[u] * ta[u];
+            acc1 += (far ? win[u + DLO + 1] : win[u + DLO]) * tb[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            win[u] = win[u + 4];
+            win[u + 4] = nxt[u];
+        }
+    }
+    out0 = acc0;
+    out1 = acc1;
+}
+
 // g: the stream's state blob in HBM, owner of the two sample rings (x12 at 12.8 kHz, x6 at 6.4 kHz); `store` = 0 for
 // the shadow waves of a partial workgroup.  Staging: x12 lives in fa for the duration of the stage, the resampler's
 // polyphase table and later the correlation scratch in fb, x6 in `t` once the resampler has consumed the time buffer.
 LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int near_nyquist,
-                                                    int nbits, lc3_enc_state *g, int store) {
+                                                    int nbits, lc3_enc_state *g, int store, int ltpf_phase) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int len12 = c.len12, len6 = c.len6, p = c.p_up;
@@ -762,7 +806,14 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
 
     // shift_out_old_samples :217-229 happens while the ring is fetched: element i of the staged ring = element i + len12
     // of the stored one.  The polyphase table rides along.
-    const int keep12 = x12_len - len12, keep6 = 178 - len6;  // <= 276, <= 130
+    // The 6.4 kHz ring: LC3_KMAX history samples + the frame's len6 new ones.  (At 7.5 ms the reference's 178-element buffer has
+    // 16 more elements, which are shifted around and overwritten before any use.)
+    const int r6_len = LC3_KMAX + len6;
+    const int keep12 = x12_len - len12, keep6 = LC3_KMAX;  // <= 276, 114
+    // ring heads: where the oldest samples (the slots this frame overwrites) start, and where the ring starts after the shift
+    const int old12 = L.st.ring12_head, old6 = L.st.ring6_head;
+    const int head12 = old12 + len12 >= x12_len ? old12 + len12 - x12_len : old12 + len12;
+    const int head6 = old6 + len6 >= r6_len ? old6 + len6 - r6_len : old6 + len6;
     LC3_HBM_FENCE();
     {
         LC3_HBM_CONST(float) g12 = (LC3_HBM_CONST(float))g->x12;
@@ -770,7 +821,9 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
 #pragma unroll
         for (int j = 0; j < 5; j++) {
             const int i = lane + LC3_WAVE * j;
-            v[j] = i < keep12 ? g12[i + len12] : 0.0f;
+            int ph = head12 + i;  // the ring after this frame's shift starts at the advanced head
+            ph -= ph >= x12_len ? x12_len : 0;
+            v[j] = i < keep12 ? g12[ph] : 0.0f;
         }
         const int p_rows = p * c.resamp_stride;
 #ifdef LC3_RESAMP_POLY_IN_LDS
@@ -795,38 +848,38 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     {
         const int nt = c.resamp_nt, lim = c.resamp_lim;
         float *o12 = x12 + c.delay12 + LC3_NMEM;
-        const int n0 = lane, has1 = lane + LC3_WAVE < len12;
-        const int n1 = has1 ? lane + LC3_WAVE : lane;
+        // Lane l computes the ADJACENT outputs 2l and 2l + 1: their sample windows start d = dlo or dlo + 1 positions apart
+        // (dlo = 15 / p), so one sliding register window of eight samples feeds both -- four new LDS values per four taps of
+        // both outputs instead of eight.
+        const int half = len12 / 2, live = lane < half, lp = live ? lane : half - 1;
+        const int n0 = 2 * lp, n1 = n0 + 1;
         const int q0 = (15 * n0 * c.inv_p) >> 16, q1 = (15 * n1 * c.inv_p) >> 16;  // 15 n / p without integer divisions
         const float *xa = W + c.hist + q0 - 2 * lim;  // tap j <-> k = j - lim
-        const float *xb = W + c.hist + q1 - 2 * lim;
 #ifdef LC3_RESAMP_POLY_IN_LDS
         const float *poly = p * c.resamp_stride > 336 ? S : lc3_front_tab.resamp_poly;  // staged once per workgroup
 #else
         const float *poly = S;
 #endif
         const float *ha = poly + (15 * n0 - q0 * p) * c.resamp_stride, *hb = poly + (15 * n1 - q1 * p) * c.resamp_stride;
-        float acc0 = 0.0f, acc1 = 0.0f;
-        for (int j = 0; j < nt; j += 4) {
-            const lc3_f4 a = *(const lc3_f4 *)(ha + j), b = *(const lc3_f4 *)(hb + j);
-            acc0 += xa[j] * a.x;
-            acc1 += xb[j] * b.x;
-            acc0 += xa[j + 1] * a.y;
-            acc1 += xb[j + 1] * b.y;
-            acc0 += xa[j + 2] * a.z;
-            acc1 += xb[j + 2] * b.z;
-            acc0 += xa[j + 3] * a.w;
-            acc1 += xb[j + 3] * b.w;
-        }
+        float acc0, acc1;
+        const int dlo = LC3_UNIFORM_I32(15 / p), far = (q1 - q0) != dlo;
+        if (dlo == 3) lc3_resample_pair<3>(xa, ha, hb, nt, far, acc0, acc1);       // p = 4 (48 / 44.1 kHz)
+        else if (dlo == 2) lc3_resample_pair<2>(xa, ha, hb, nt, far, acc0, acc1);  // p = 6 (32 kHz)
+        else if (dlo == 1) lc3_resample_pair<1>(xa, ha, hb, nt, far, acc0, acc1);  // p = 8, 12 (24, 16 kHz)
+        else lc3_resample_pair<0>(xa, ha, hb, nt, far, acc0, acc1);                // p = 24 (8 kHz)
         LC3_SYNC();
-        if (n0 < len12) o12[n0] = acc0 * c.resamp_scale;
-        if (has1) o12[n1] = acc1 * c.resamp_scale;
+        if (live) {
+            o12[n0] = acc0 * c.resamp_scale;
+            o12[n1] = acc1 * c.resamp_scale;
+        }
         // the time buffer is consumed: stage the 6.4 kHz ring in its place (shifted by len6 on the way in)
         LC3_HBM_CONST(float) g6 = (LC3_HBM_CONST(float))g->x6;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const int i = lane + LC3_WAVE * j;
-            if (i < keep6) x6[i] = g6[i + len6];
+            int ph = head6 + i;
+            ph -= ph >= r6_len ? r6_len : 0;
+            if (i < keep6) x6[i] = g6[ph];
         }
     }
     // the high-pass memories h[-1], h[-2] as every lane needs them below (read before lane 0 moves them on)
@@ -838,9 +891,11 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     // and the output y[n] = b0 * h[n] + b1 * h[n-1] + b2 * h[n-2].  Only the recursion is serial (and runs across frames):
     // lane 0 walks it, four operations per sample, and leaves h in place of x; the three-tap output is then formed one
     // sample per lane from the stored h -- the same f32 operations in the same order as in the single loop.
-    if (lane == 0) {
-        float *o12 = x12 + c.delay12 + LC3_NMEM;
-        float m1 = hp_m1, m2 = hp_m2;
+    // The recursion has the same length for every stream: the four streams of the workgroup run it together on four lanes of
+    // one wave (LC3_SERIAL_BEGIN: `L` is the lane's stream inside the block), a quarter of the instructions per stream.
+    LC3_SERIAL_BEGIN(lc3_enc_lds, L, lane, ltpf_phase, 1)
+        float *o12 = (float *)L.fa + 64 + c.delay12 + LC3_NMEM;  // this stream's x12 + delay12 + NMEM
+        float m1 = L.st.h50_m1, m2 = L.st.h50_m2;
         #pragma unroll 1
         for (int n0 = 0; n0 < len12; n0 += 8) {  // len12 is a multiple of 8; eight samples per LDS round trip
             float x[8];
@@ -858,7 +913,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         }
         L.st.h50_m1 = m1;
         L.st.h50_m2 = m2;
-    }
+    LC3_SERIAL_END
     LC3_SYNC();
     {
         float *o12 = x12 + c.delay12 + LC3_NMEM;
@@ -890,56 +945,55 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     }
     LC3_SYNC();
     int lag_t1, lag_t2;
-    {   // 98 lags, len6-term sums in order; a lane runs its two lags (lane, lane + 64) side by side, 8 terms per batch
-        const int NL = LC3_KMAX + 1 - LC3_KMIN;
-        const int k0 = lane, has1 = lane + LC3_WAVE < NL, k1 = has1 ? lane + LC3_WAVE : lane;
-        const float *pa = x6 + LC3_KMAX, *pb0 = x6 + (LC3_KMAX - LC3_KMIN - k0), *pb1 = x6 + (LC3_KMAX - LC3_KMIN - k1);
+    {   // 98 lags, len6-term sums in order.  Lane l runs the ADJACENT lags 2l and 2l + 1 side by side: their second operands are
+        // the same samples one position apart (x6[97 - 2l + n] and x6[96 - 2l + n]), so nine LDS values serve eight terms of both
+        // sums, and the first operand (the same samples for every lag) comes as 64-bit broadcasts.
+        const int NL = LC3_KMAX + 1 - LC3_KMIN;  // 98
+        const int lp = lane < NL / 2 ? lane : NL / 2 - 1, live = lane < NL / 2;
+        const int k0 = 2 * lp, k1 = 2 * lp + 1;
+        const float *pa = x6 + LC3_KMAX, *pb = x6 + (LC3_KMAX - LC3_KMIN - 1 - k0);  // pb[n] = operand of lag k1, pb[n + 1] of lag k0
         float acc0 = 0.0f, acc1 = 0.0f;
         {   // the next eight operands of each array are requested before the current eight products are added
-            float a[8], b0[8], b1[8], an[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, b0n[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f},
-                  b1n[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            float a[8], bb[9], an[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, bn[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                a[u] = pa[u];
-                b0[u] = pb0[u];
-                b1[u] = pb1[u];
-            }
+            for (int u = 0; u < 8; u++) a[u] = pa[u];
+#pragma unroll
+            for (int u = 0; u < 9; u++) bb[u] = pb[u];
             #pragma unroll 1
             for (int n = 0; n < len6; n += 8) {
                 if (n + 8 < len6) {
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        an[u] = pa[n + 8 + u];
-                        b0n[u] = pb0[n + 8 + u];
-                        b1n[u] = pb1[n + 8 + u];
-                    }
+                    for (int u = 0; u < 8; u++) an[u] = pa[n + 8 + u];
+#pragma unroll
+                    for (int u = 1; u < 9; u++) bn[u] = pb[n + 8 + u];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    acc0 += a[u] * b0[u];
-                    acc1 += a[u] * b1[u];
+                    acc0 += a[u] * bb[u + 1];
+                    acc1 += a[u] * bb[u];
                 }
+                bn[0] = bb[8];  // the last operand of this block is the first of the next for the odd lag
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    a[u] = an[u];
-                    b0[u] = b0n[u];
-                    b1[u] = b1n[u];
-                }
+                for (int u = 0; u < 8; u++) a[u] = an[u];
+#pragma unroll
+                for (int u = 0; u < 9; u++) bb[u] = bn[u];
             }
         }
-        r6[k0] = acc0;
-        if (has1) r6[k1] = acc1;
+        if (live) {
+            r6[k0] = acc0;
+            r6[k1] = acc1;
+        }
         // index_of_max_value :427-443 twice: over the weighted correlations of all lags (T1) and over the plain ones of the
         // lags around the previous frame's (T2).  The values are still in registers: wave-parallel first-maximum scans
-        // (lc3_wave_argmax_first) instead of 98 + 9 compare steps on one lane.
+        // (lc3_wave_argmax_first2) instead of 98 + 9 compare steps on one lane.
         const float w0 = (1.0f - 0.5f * (float)k0 / (float)(LC3_KMAX - LC3_KMIN)) * acc0;
         const float w1 = (1.0f - 0.5f * (float)k1 / (float)(LC3_KMAX - LC3_KMIN)) * acc1;
         const int t_prev = L.st.t_prev;
         const int k_from = (t_prev - 4 > LC3_KMIN ? t_prev - 4 : LC3_KMIN) - LC3_KMIN;
         const int k_to = (t_prev + 4 < LC3_KMAX ? t_prev + 4 : LC3_KMAX) - LC3_KMIN + 1;
         int nan1, nan2;
-        int i1 = lc3_wave_argmax_first(w0, 1, w1, has1, lane, &nan1);
-        int i2 = lc3_wave_argmax_first(acc0, k0 >= k_from && k0 < k_to, acc1, has1 && k1 >= k_from && k1 < k_to, lane, &nan2);
+        int i1 = lc3_wave_argmax_first2(w0, k0, live, w1, k1, live, lane, &nan1);
+        int i2 = lc3_wave_argmax_first2(acc0, k0, live && k0 >= k_from && k0 < k_to, acc1, k1, live && k1 >= k_from && k1 < k_to, lane, &nan2);
         i2 = i2 < 0 ? 0 : i2 - k_from;
         if (nan1 | nan2) {  // a NaN inside a scan (never with finite PCM): the reference's sequential scans, on lane 0
             LC3_SYNC();
@@ -1155,19 +1209,25 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     res.pitch_present = L.ism[3];
     res.ltpf_active = L.ism[7];
     res.nbits_ltpf = res.pitch_present ? 11 : 1;
-    // the rings go back to the state blob
+    // the new samples go into the oldest slots of the rings in the state blob
     if (store) {
         float *g12 = g->x12, *g6 = g->x6;
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
+        for (int j = 0; j < 2; j++) {
             const int i = lane + LC3_WAVE * j;
-            if (i < x12_len) g12[i] = x12[i];
+            int ph = old12 + i;
+            ph -= ph >= x12_len ? x12_len : 0;
+            if (i < len12) g12[ph] = x12[keep12 + i];
         }
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int i = lane + LC3_WAVE * j;
-            if (i < 178) g6[i] = x6[i];
+        {
+            int ph = old6 + lane;
+            ph -= ph >= r6_len ? r6_len : 0;
+            if (lane < len6) g6[ph] = x6[keep6 + lane];
         }
+    }
+    if (lane == 0) {
+        L.st.ring12_head = head12;
+        L.st.ring6_head = head6;
     }
     LC3_SYNC();
     return res;
@@ -1617,7 +1677,8 @@ LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PAR
 // stores nothing.  dbg (optional): float[1472] stage dumps.
 LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const int16_t *pcm,
                                                       const int16_t *hist, lc3_enc_state *g, float *mid, int32_t *plane,
-                                                      int plane_stride, int nbytes, float *dbg, int stride = 1, int hstride = 1) {
+                                                      int plane_stride, int nbytes, float *dbg, int stride = 1, int hstride = 1,
+                                                      int phase = 0) {
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
@@ -1636,7 +1697,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_P
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 3);
-    const lc3_ltpf_res pf = lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, plane != nullptr);
+    const lc3_ltpf_res pf = lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, plane != nullptr, phase);
     LC3_STAMP(L, lane, 5);
     if (dbg && lane == 0) {
         float *d = dbg + 1440;

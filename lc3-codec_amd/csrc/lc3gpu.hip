@@ -353,7 +353,7 @@ __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigne
         // MDCT history: the tail of the previous frame of this launch, else the state blob's copy (silence when fresh)
         const int16_t *hist = t > 0 ? frame - (size_t)(nf - z) * (size_t)stride : (fresh ? nullptr : gst->hist);
         lc3_encode_front_wave(cfg, L, lane, frame, hist, gst, mcol, plane, LC3_PLANE_STRIDE, nbytes, valid ? dbg : nullptr, stride,
-                              t > 0 ? stride : 1);
+                              t > 0 ? stride : 1, t);
     }
     if (valid) {
         int stride = 1;
@@ -686,16 +686,9 @@ __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned w
     else lc3_dec_state_load(L, lane, gst);
     LC3_PROF_MARK(L, lane, 38);  // state load
     const size_t fbase = (size_t)s * (size_t)n_frames;
-    lc3_plane_fetch cur, nxt;
-    if (n_frames > 0) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, fbase, LC3_PLANE_WORDS), cur);
-    for (int t = 0; t < n_frames; t++) {
-        const size_t f = fbase + (size_t)t;
-        if (t + 1 < n_frames) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, f + 1, LC3_PLANE_WORDS), nxt);
-        int stride;
-        int16_t *out = (int16_t *)lc3_io_pcm(io, pcm, nf, first_channel, s, t, n_frames, &stride);
-        lc3_decode_frame_wave(cfg, L, lane, nbytes, out, cur, gst, valid, stride);
-        cur = nxt;
-    }
+    int stride;
+    int16_t *pcm0 = (int16_t *)lc3_io_pcm(io, pcm, nf, first_channel, s, 0, n_frames, &stride);
+    lc3_decode_stream_wave(cfg, L, lane, nbytes, planes, fbase, n_frames, gst, valid, pcm0, (size_t)nf * (size_t)stride, stride);
     LC3_PROF_MARK(L, lane, 39);  // frames (incl. everything between the stage stamps)
     if (valid) lc3_dec_state_store(L, lane, gst);
     LC3_PROF_END(L, lane, 35);

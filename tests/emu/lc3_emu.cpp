@@ -150,7 +150,7 @@ void *lane_main(void *arg) {
             const int16_t *frame = j->pcm_in + (size_t)t * j->cfg.nf;
             const int16_t *hist = t > 0 ? frame - j->cfg.nf + j->cfg.z : (j->fresh ? nullptr : j->est->hist);
             lc3_encode_front_wave(j->cfg, L, lane, frame, hist, j->est, mcol, plane, LC3_PLANE_STRIDE, j->nbytes,
-                                  j->valid ? j->dbg : nullptr);
+                                  j->valid ? j->dbg : nullptr, 1, 1, t);
         }
         if (j->valid)
             lc3_enc_state_store(j->cfg, L, lane, j->est, j->n_frames > 0 ? j->pcm_in + (size_t)(j->n_frames - 1) * j->cfg.nf : nullptr);
@@ -174,16 +174,7 @@ void *lane_main(void *arg) {
         lc3_dec_lds &L = j->DL[j->wave];
         if (j->fresh) lc3_dec_state_init(L, lane, j->dst, j->valid);
         else lc3_dec_state_load(L, lane, j->dst);
-        lc3_plane_fetch cur, nxt;
-        memset(&cur, 0, sizeof(cur));
-        memset(&nxt, 0, sizeof(nxt));
-        if (j->n_frames > 0) lc3_dec_issue_frame(j->cfg, lane, LC3_PLANE_COL(j->planes, j->frame0, LC3_PLANE_WORDS), cur);
-        for (int t = 0; t < j->n_frames; t++) {
-            const size_t f = j->frame0 + (size_t)t;
-            if (t + 1 < j->n_frames) lc3_dec_issue_frame(j->cfg, lane, LC3_PLANE_COL(j->planes, f + 1, LC3_PLANE_WORDS), nxt);
-            lc3_decode_frame_wave(j->cfg, L, lane, j->nbytes, j->pcm_out + (size_t)t * j->cfg.nf, cur, j->dst, j->valid);
-            cur = nxt;
-        }
+        lc3_decode_stream_wave(j->cfg, L, lane, j->nbytes, j->planes, j->frame0, j->n_frames, j->dst, j->valid, j->pcm_out, (size_t)j->cfg.nf, 1);
         if (j->valid) lc3_dec_state_store(L, lane, j->dst);
     }
     return 0;
