@@ -175,31 +175,19 @@ __device__ __forceinline__ float lc3_maxf(float a, float b) { return (a != a) ? 
 __device__ __forceinline__ float lc3_minf(float a, float b) { return (a != a) ? b : ((b != b) ? a : (b < a ? b : a)); }
 __device__ __forceinline__ float lc3_absf(float a) { return lc3_from_bits(lc3_bits(a) & 0x7fffffffu); }
 
-// Rust `as` casts are saturating with NaN -> 0
+// Rust `as` casts are saturating with NaN -> 0.  Branch-free: NaN replaced by 0, the value clamped in the
+// float domain (both bounds are exact floats), then truncated -- three or four instructions instead of a chain of divergent
+// early returns.
+__device__ __forceinline__ float lc3_nan_to_zero(float x) { return x != x ? 0.0f : x; }
+__device__ __forceinline__ float lc3_clampf(float x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }
 __device__ __forceinline__ int32_t lc3_f2i32(float x) {
-    if (x != x) return 0;
-    if (x >= 2147483648.0f) return 2147483647;
-    if (x <= -2147483648.0f) return (-2147483647 - 1);
-    return (int32_t)x;
+    const float xc = lc3_nan_to_zero(x);
+    const int32_t r = (int32_t)lc3_clampf(xc, -2147483648.0f, 2147483520.0f);  // 2147483520 = the largest float below 2^31
+    return xc >= 2147483648.0f ? 2147483647 : r;
 }
-__device__ __forceinline__ int32_t lc3_f2i16(float x) {
-    if (x != x) return 0;
-    if (x >= 32767.0f) return 32767;
-    if (x <= -32768.0f) return -32768;
-    return (int32_t)x;
-}
-__device__ __forceinline__ int32_t lc3_f2i8(float x) {
-    if (x != x) return 0;
-    if (x >= 127.0f) return 127;
-    if (x <= -128.0f) return -128;
-    return (int32_t)x;
-}
-__device__ __forceinline__ int32_t lc3_f2u16(float x) {
-    if (x != x) return 0;
-    if (x >= 65535.0f) return 65535;
-    if (x <= 0.0f) return 0;
-    return (int32_t)x;
-}
+__device__ __forceinline__ int32_t lc3_f2i16(float x) { return (int32_t)lc3_clampf(lc3_nan_to_zero(x), -32768.0f, 32767.0f); }
+__device__ __forceinline__ int32_t lc3_f2i8(float x) { return (int32_t)lc3_clampf(lc3_nan_to_zero(x), -128.0f, 127.0f); }
+__device__ __forceinline__ int32_t lc3_f2u16(float x) { return (int32_t)lc3_clampf(lc3_nan_to_zero(x), 0.0f, 65535.0f); }
 // The transform tables of the configuration (FFT twiddles, DCT-IV twiddles, leaf gather order).  The device build can
 // redirect them to a copy staged in LDS (lc3gpu.hip: lc3_fft_tab); the default reads the configuration's HBM tables.
 #ifdef LC3_FFT_TABLES_IN_LDS
@@ -375,7 +363,18 @@ __device__ __forceinline__ float lc3_pow10f(float y) {
     return z;
 }
 
-// shared reduction of e_log2f.c / e_log10f.c
+// The codec only ever raises 10 to (gg_ind + gg_off) / 28 (an integer in [-256, 255] over 28: spectral_quantization.rs:239,
+// global_gain.rs:19-20) and to b * g_tilt / 630 (band b < 64, five tilts: spectral_noise_shaping.rs:216-218).  The HIP build
+// tabulates both once per device WITH lc3_pow10f itself (lc3gpu.hip: lc3_pow10_tables_kernel), so a lookup returns the very bits
+// the routine computes; translation units without the tables evaluate the routine.
+#ifndef LC3_POW10_GG
+#define LC3_POW10_GG(k) lc3_pow10f((float)(k) / 28.0f)
+#define LC3_POW10_TILT(fs_ind, b) lc3_pow10f((float)(b) * ((float)LC3C_G_TILT[(fs_ind)] / 630.0f))
+#endif
+
+// shared reduction of e_log2f.c / e_log10f.c.  Branch-free: the main path is evaluated for every input (garbage in, garbage
+// out, no traps) and the special results (zero, negative, infinity / NaN, exactly 1) are selected at the end -- the lanes of a
+// wave hold different values, so early returns would only add exec-mask bookkeeping around the common path.
 struct lc3_logparts {
     float hi, lo;
     int k;
@@ -385,36 +384,30 @@ __device__ __forceinline__ lc3_logparts lc3_log_reduce(float x) {
     const float Lg1 = lc3_from_bits(0x3f2aaaaau), Lg2 = lc3_from_bits(0x3eccce13u);
     const float Lg3 = lc3_from_bits(0x3e91e9eeu), Lg4 = lc3_from_bits(0x3e789e26u);
     lc3_logparts p;
-    p.special = 0;
-    p.lo = 0.0f;
-    uint32_t ix = lc3_bits(x);
-    int k = 0;
-    if (ix < 0x00800000u || (ix >> 31)) {
-        if ((ix << 1) == 0) { p.special = 1; p.hi = -1.0f / (x * x); p.k = 0; return p; }
-        if (ix >> 31) { p.special = 1; p.hi = (x - x) / 0.0f; p.k = 0; return p; }
-        k -= 25;
-        x *= 33554432.0f;
-        ix = lc3_bits(x);
-    } else if (ix >= 0x7f800000u) {
-        p.special = 1; p.hi = x; p.k = 0; return p;
-    } else if (ix == 0x3f800000u) {
-        p.special = 1; p.hi = 0.0f; p.k = 0; return p;
-    }
+    const uint32_t ix0 = lc3_bits(x);
+    const int neg = (int)(ix0 >> 31), zero = (ix0 << 1) == 0, sub = ix0 < 0x00800000u || neg;  // x < 2^-126 (or negative)
+    const int big = !sub && ix0 >= 0x7f800000u, one = !sub && !big && ix0 == 0x3f800000u;
+    // special results, in msun's order of tests
+    const float sp = zero ? -1.0f / (x * x) : (neg ? (x - x) / 0.0f : (big ? x : 0.0f));
+    p.special = zero | neg | big | one;
+    const float xs = sub ? x * 33554432.0f : x;  // subnormal: scale up by 2^25
+    uint32_t ix = lc3_bits(xs);
+    int k = sub ? -25 : 0;
     ix += 0x3f800000u - 0x3f3504f3u;
     k += (int)(ix >> 23) - 0x7f;
     ix = (ix & 0x007fffffu) + 0x3f3504f3u;
-    x = lc3_from_bits(ix);
-    float f = x - 1.0f;
-    float s = f / (2.0f + f);
-    float z = s * s;
-    float w = z * z;
-    float t1 = w * (Lg2 + w * Lg4);
-    float t2 = z * (Lg1 + w * Lg3);
-    float R = t2 + t1;
-    float hfsq = 0.5f * f * f;
+    const float xr = lc3_from_bits(ix);
+    const float f = xr - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float w = z * z;
+    const float t1 = w * (Lg2 + w * Lg4);
+    const float t2 = z * (Lg1 + w * Lg3);
+    const float R = t2 + t1;
+    const float hfsq = 0.5f * f * f;
     float hi = f - hfsq;
     hi = lc3_from_bits(lc3_bits(hi) & 0xfffff000u);
-    p.hi = hi;
+    p.hi = p.special ? sp : hi;
     p.lo = (f - hi) - hfsq + s * (hfsq + R);
     p.k = k;
     return p;
@@ -422,67 +415,51 @@ __device__ __forceinline__ lc3_logparts lc3_log_reduce(float x) {
 // e_log2f.c (encoder/spectral_noise_shaping.rs:232)
 __device__ __forceinline__ float lc3_log2f(float x) {
     const float ivln2hi = lc3_from_bits(0x3fb8b000u), ivln2lo = lc3_from_bits(0xb9389ad4u);
-    lc3_logparts p = lc3_log_reduce(x);
-    if (p.special) return p.hi;
-    return (p.lo + p.hi) * ivln2lo + p.lo * ivln2hi + p.hi * ivln2hi + (float)p.k;
+    const lc3_logparts p = lc3_log_reduce(x);
+    const float r = (p.lo + p.hi) * ivln2lo + p.lo * ivln2hi + p.hi * ivln2hi + (float)p.k;
+    return p.special ? p.hi : r;
 }
 // e_log10f.c (encoder/spectral_quantization.rs:218,393)
 __device__ __forceinline__ float lc3_log10f(float x) {
     const float ivln10hi = lc3_from_bits(0x3ede6000u), ivln10lo = lc3_from_bits(0xb804ead9u);
     const float log10_2hi = lc3_from_bits(0x3e9a2080u), log10_2lo = lc3_from_bits(0x355427dbu);
-    lc3_logparts p = lc3_log_reduce(x);
-    if (p.special) return p.hi;
-    float dk = (float)p.k;
-    return dk * log10_2lo + (p.lo + p.hi) * ivln10lo + p.lo * ivln10hi + p.hi * ivln10hi + dk * log10_2hi;
+    const lc3_logparts p = lc3_log_reduce(x);
+    const float dk = (float)p.k;
+    const float r = dk * log10_2lo + (p.lo + p.hi) * ivln10lo + p.lo * ivln10hi + p.hi * ivln10hi + dk * log10_2hi;
+    return p.special ? p.hi : r;
 }
 
-// s_exp2f.c, TBLSIZE = 16, f64 polynomial (encoder/spectral_noise_shaping.rs:256)
+// s_exp2f.c, TBLSIZE = 16, f64 polynomial (encoder/spectral_noise_shaping.rs:256).  exp2ft[i] = 2^((i-8)/16) as f64 bit
+// patterns; branch-free (the callers run it one frame per lane: divergent early returns and a 16-way switch would be
+// executed by every lane) with the special results selected at the end.
+static __device__ const uint64_t LC3C_EXP2FT[16] = {
+    0x3fe6a09e667f3bcdull, 0x3fe7a11473eb0187ull, 0x3fe8ace5422aa0dbull, 0x3fe9c49182a3f090ull,
+    0x3feae89f995ad3adull, 0x3fec199bdd85529cull, 0x3fed5818dcfba487ull, 0x3feea4afa2a490daull,
+    0x3ff0000000000000ull, 0x3ff0b5586cf9890full, 0x3ff172b83c7d517bull, 0x3ff2387a6e756238ull,
+    0x3ff306fe0a31b715ull, 0x3ff3dea64c123422ull, 0x3ff4bfdad5362a27ull, 0x3ff5ab07dd485429ull};
 __device__ __forceinline__ float lc3_exp2f(float x) {
     const float redux = lc3_from_bits(0x4b400000u) / 16.0f;
     const float P1 = lc3_from_bits(0x3f317218u), P2 = lc3_from_bits(0x3e75fdf0u);
     const float P3 = lc3_from_bits(0x3d6359a4u), P4 = lc3_from_bits(0x3c1d964eu);
-    uint32_t ui = lc3_bits(x), ix = ui & 0x7fffffffu;
-    if (ix > 0x42fc0000u) {
-        if (ix > 0x7f800000u) return x;
-        if (ui >= 0x43000000u && ui < 0x80000000u) return x * lc3_from_bits(0x7f000000u);
-        if (ui >= 0x80000000u) {
-            if (ui >= 0xc3160000u) return 0.0f;
-        }
-    } else if (ix <= 0x33000000u) {
-        return 1.0f + x;
-    }
+    const uint32_t ui = lc3_bits(x), ix = ui & 0x7fffffffu;
+    // main path (meaningful for 2^-25 < |x| <= 126; evaluated for every input)
     float uf = x + redux;
     uint32_t i0 = lc3_bits(uf);
     i0 += 8;
-    uint32_t k = i0 / 16;
-    uint64_t uk = (uint64_t)(0x3ffu + k) << 52;
+    const uint32_t k = i0 / 16;
+    const uint64_t uk = (uint64_t)(0x3ffu + k) << 52;
     i0 &= 15;
     uf -= redux;
-    double z = (double)(x - uf);
-    // exp2ft[i] = 2^((i-8)/16)
-    uint64_t tb;
-    switch (i0) {
-    case 0: tb = 0x3fe6a09e667f3bcdull; break;
-    case 1: tb = 0x3fe7a11473eb0187ull; break;
-    case 2: tb = 0x3fe8ace5422aa0dbull; break;
-    case 3: tb = 0x3fe9c49182a3f090ull; break;
-    case 4: tb = 0x3feae89f995ad3adull; break;
-    case 5: tb = 0x3fec199bdd85529cull; break;
-    case 6: tb = 0x3fed5818dcfba487ull; break;
-    case 7: tb = 0x3feea4afa2a490daull; break;
-    case 8: tb = 0x3ff0000000000000ull; break;
-    case 9: tb = 0x3ff0b5586cf9890full; break;
-    case 10: tb = 0x3ff172b83c7d517bull; break;
-    case 11: tb = 0x3ff2387a6e756238ull; break;
-    case 12: tb = 0x3ff306fe0a31b715ull; break;
-    case 13: tb = 0x3ff3dea64c123422ull; break;
-    case 14: tb = 0x3ff4bfdad5362a27ull; break;
-    default: tb = 0x3ff5ab07dd485429ull; break;
-    }
-    double r = lc3_d_from_bits(tb);
-    double t = r * z;
+    const double z = (double)(x - uf);
+    double r = lc3_d_from_bits(LC3C_EXP2FT[i0]);
+    const double t = r * z;
     r = r + t * ((double)P1 + z * (double)P2) + t * (z * z) * ((double)P3 + z * (double)P4);
-    return (float)(r * lc3_d_from_bits(uk));
+    const float res = (float)(r * lc3_d_from_bits(uk));
+    // the special ranges, in msun's order
+    const int large = ix > 0x42fc0000u;  // |x| > 126
+    const int nan = ix > 0x7f800000u, over = ui >= 0x43000000u && ui < 0x80000000u, under = ui >= 0xc3160000u;
+    const float sp_large = nan ? x : (over ? x * lc3_from_bits(0x7f000000u) : (under ? 0.0f : res));
+    return large ? sp_large : (ix <= 0x33000000u ? 1.0f + x : res);
 }
 
 // e_asinf.c (encoder/temporal_noise_shaping.rs:272)
@@ -532,6 +509,22 @@ __device__ __forceinline__ float lc3_sinf_small(float x) {
     float c = (float)(((1.0 + z * C0) + w * C1) + (w * z) * r);
     return sign ? -c : c;
 }
+
+// Quantised TNS reflection coefficients: sin(step * (rc_i - 8)), rc_i = 0..16, step = PI / 17 -- formed as (PI as f32) / 17.0 by
+// the encoder (encoder/temporal_noise_shaping.rs:268-273) and as (PI / 17.0) as f32 by the decoder
+// (decoder/temporal_noise_shaping.rs:41-44).  The HIP build tabulates both with lc3_sinf_small itself (lc3gpu.hip).
+__device__ __forceinline__ float lc3_tns_sin_enc_value(int ri) {
+    const float step = (float)3.14159265358979323846 / 17.0f;
+    return lc3_sinf_small(step * ((float)ri - 8.0f));
+}
+__device__ __forceinline__ float lc3_tns_sin_dec_value(int ri) {
+    const float step = (float)(3.14159265358979323846 / 17.0);
+    return lc3_sinf_small(step * (float)(ri - 8));
+}
+#ifndef LC3_TNS_SIN_ENC
+#define LC3_TNS_SIN_ENC(ri) lc3_tns_sin_enc_value(ri)
+#define LC3_TNS_SIN_DEC(ri) lc3_tns_sin_dec_value(ri)
+#endif
 
 // fast_math::exp2_raw (fast-math 0.1.1; decoder/spectral_noise_shaping.rs:122)
 __device__ __forceinline__ float lc3_exp2_raw(float x) {

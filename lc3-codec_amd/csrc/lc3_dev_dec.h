@@ -426,7 +426,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
             if (i < nf / 2) {
                 for (int j = 0; j < 2; j++) {
                     const float x = L.spec[2 * i + j];
-                    int32_t tmp = x > 0.0f ? lc3_f2i32(x + 0.5f) : lc3_f2i32(x - 0.5f);
+                    int32_t tmp = lc3_f2i32(x + (x > 0.0f ? 0.5f : -0.5f));  // x - 0.5 == x + (-0.5)
                     tmp = tmp > 32767 ? 32767 : tmp;
                     tmp = tmp < -32768 ? -32768 : tmp;
                     v[j] = tmp;

@@ -565,7 +565,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     {
         const int fs = cfg.fs_ind + 1, q = nbits / (10 * fs);
         const int gg_off = -(q < 115 ? q : 115) - 105 - (5 * fs);
-        gg = lc3_pow10f(((float)gg_ind + (float)gg_off) / 28.0f);
+        gg = LC3_POW10_GG(gg_ind + gg_off);  // 10^(((float)gg_ind + (float)gg_off) / 28)
     }
     // TNS :24-137: all-pole lattice, state shared across both filters
     const int nbands = bw < 3 ? 1 : 2, num_tns = LC3_SIW(SI_NUM_TNS);
@@ -575,13 +575,12 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     const int hi0 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][1] : LC3C_TNSDEC75[bw][1];
     const int lo1 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][2] : LC3C_TNSDEC75[bw][2];
     const int hi1 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][3] : LC3C_TNSDEC75[bw][3];
-    const float step = (float)(3.14159265358979323846 / 17.0);  // (PI / 17.0) as f32 :41
     float st[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, rq[8];
     int order = ord0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int ri = LC3_SIW(AD_RCI + k);
-        rq[k] = ri != 0 ? lc3_sinf_small(step * (float)(ri - 8)) : 0.0f;
+        rq[k] = ri != 0 ? LC3_TNS_SIN_DEC(ri) : 0.0f;  // sin(step * (ri - 8)); SURVEY A12
     }
     // noise filling :18-56
     const int bw_stop = cfg.n_ms_10 ? LC3C_BWSTOP10[bw] : LC3C_BWSTOP75[bw];
@@ -637,7 +636,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const int ri = LC3_SIW(AD_RCI + 8 + q);
-                    rq[q] = ri != 0 ? lc3_sinf_small(step * (float)(ri - 8)) : 0.0f;
+                    rq[q] = ri != 0 ? LC3_TNS_SIN_DEC(ri) : 0.0f;
                 }
             }
             {   // TNS synthesis lattice: stages q < ord_eff are live on this lane for this line.

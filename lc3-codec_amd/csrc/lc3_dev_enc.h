@@ -418,8 +418,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_sns_front(LC3_CFG_PARAM, L
         if (b == 0) v = 0.75f * sP[0] + 0.25f * sP[1];
         else if (b == 63) v = 0.25f * sP[62] + 0.75f * sP[63];
         else v = 0.25f * sP[b - 1] + 0.5f * sP[b] + 0.25f * sP[b + 1];
-        const float exponent = (float)LC3C_G_TILT[c.fs_ind] / 630.0f;
-        v *= lc3_pow10f((float)b * exponent);
+        v *= LC3_POW10_TILT(c.fs_ind, b);  // 10^(b * (g_tilt / 630)), the exponent formed as (float)b * ((float)g_tilt / 630.0f)
         sE[b] = v;
     }
     LC3_SYNC();
@@ -610,7 +609,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
             float q = lc3_asinf(rc_q[lane]) / step;
             int ri = (q >= 0.0f ? lc3_f2i8(q + 0.5f) : lc3_f2i8(-(-q + 0.5f))) + 8;
             rc_i[lane] = ri;
-            rc_q[lane] = lc3_sinf_small(step * ((float)ri - 8.0f));
+            rc_q[lane] = LC3_TNS_SIN_ENC(ri);  // sin(step * ((float)ri - 8.0f))
         } else {
             rc_i[lane] = 8;
             rc_q[lane] = 0.0f;
@@ -1245,7 +1244,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int ne = c.ne;
-    const float gg = lc3_pow10f(((float)gg_ind + (float)gg_off) / 28.0f);
+    const float gg = LC3_POW10_GG(gg_ind + gg_off);  // 10^(((float)gg_ind + (float)gg_off) / 28): the sum of two small integers is exact in f32
     {   // ne <= 400: seven lines per lane, loaded together, divided as seven independent chains, stored together
         float x[7];
 #pragma unroll
@@ -1256,7 +1255,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
         int16_t q[7];
 #pragma unroll
         for (int u = 0; u < 7; u++)
-            q[u] = (int16_t)(x[u] >= 0.0f ? lc3_f2i16(x[u] / gg + 0.375f) : lc3_f2i16(x[u] / gg - 0.375f));
+            q[u] = (int16_t)lc3_f2i16(x[u] / gg + (x[u] >= 0.0f ? 0.375f : -0.375f));  // a - 0.375 == a + (-0.375)
 #pragma unroll
         for (int u = 0; u < 7; u++) {
             const int n = lane + LC3_WAVE * u;

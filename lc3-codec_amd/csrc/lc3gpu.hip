@@ -82,6 +82,17 @@ __shared__ lc3_spec_tables lc3_spec_tab;
 #define LC3_UNIFORM_I32(x) __builtin_amdgcn_readfirstlane((int)(x))
 // product of two values below 2^24 (range-coder steps): the full-rate 24-bit multiplier instead of the quarter-rate v_mul_lo_u32
 #define LC3_MUL24(a, b) __umul24((a), (b))
+// 10^x tables of the two argument families the codec uses (lc3_dev_common.h: LC3_POW10_GG / LC3_POW10_TILT), filled on the device
+// by lc3_pow10f itself when a device's first configuration is registered
+__device__ float lc3_pow10_gg_tab[512];       // [k + 256] = 10^(k / 28), k = gg_ind + gg_off
+__device__ float lc3_pow10_tilt_tab[5 * 64];  // [fs_ind * 64 + b] = 10^(b * (g_tilt[fs_ind] / 630))
+#define LC3_POW10_GG(k) ((unsigned)((k) + 256) < 512u ? lc3_pow10_gg_tab[(k) + 256] : lc3_pow10f((float)(k) / 28.0f))
+#define LC3_POW10_TILT(fs_ind, b) (lc3_pow10_tilt_tab[(fs_ind) * 64 + (b)])
+// the 17 quantised TNS reflection coefficients in the encoder's form of the step (lc3_dev_common.h: LC3_TNS_SIN_*)
+__device__ float lc3_tns_sin_tab[17];
+#define LC3_TNS_SIN_ENC(ri) ((unsigned)(ri) < 17u ? lc3_tns_sin_tab[(ri)] : lc3_tns_sin_enc_value(ri))
+// (the decoder's lane-per-frame parser evaluates the routine: a per-lane table fetch from memory costs it more than the arithmetic)
+#define LC3_TNS_SIN_DEC(ri) lc3_tns_sin_dec_value(ri)
 #include "lc3_dev_common.h"
 // ---- configuration slots ----------------------------------------------------------------------------------------
 // Every (sampling rate, frame duration) pair owns one slot of a __constant__ table; handles register their
@@ -755,6 +766,16 @@ __global__ void lc3_line_width_kernel(float *out, lc3_cfg c) {
 __global__ void lc3_line_band_kernel(uint8_t *out, lc3_cfg c) {
     for (int k = threadIdx.x; k < c.nf; k += blockDim.x) out[k] = (uint8_t)lc3_line_band_value(c, k);
 }
+__global__ void lc3_pow10_tables_kernel() {
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) lc3_pow10_gg_tab[i] = lc3_pow10f((float)(i - 256) / 28.0f);
+    for (int i = threadIdx.x; i < 5 * 64; i += blockDim.x) {
+        const int fsi = i / 64, b = i % 64;
+        lc3_pow10_tilt_tab[i] = lc3_pow10f((float)b * ((float)LC3C_G_TILT[fsi] / 630.0f));
+    }
+    for (int i = threadIdx.x; i < 17; i += blockDim.x) {
+        lc3_tns_sin_tab[i] = lc3_tns_sin_enc_value(i);
+    }
+}
 // fills the polyphase resampler table of a configuration on the device (lc3_resamp_poly_value)
 __global__ void lc3_resamp_poly_kernel(float *out, int p, int lim, int stride) {
     const int n = p * stride;
@@ -767,6 +788,7 @@ __global__ void lc3_resamp_poly_kernel(float *out, int p, int lim, int stride) {
 #define LC3_MAX_DEVICES 64
 struct CfgRegistry {
     std::mutex mu;
+    bool tables[LC3_MAX_DEVICES] = {};  // the device's 10^x tables are filled
     bool ready[LC3_MAX_DEVICES][LC3_CFG_SLOTS] = {};
     lc3_cfg cfg[LC3_MAX_DEVICES][LC3_CFG_SLOTS];
 };
@@ -809,6 +831,12 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
     if (dev < 0 || dev >= LC3_MAX_DEVICES) return LC3GPU_EINVAL;
     const int slot = 2 * k + (frame_us == 10000);
     std::lock_guard<std::mutex> lock(g_cfgs.mu);
+    if (!g_cfgs.tables[dev]) {
+        hipLaunchKernelGGL(lc3_pow10_tables_kernel, dim3(1), dim3(256), 0, nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        g_cfgs.tables[dev] = true;
+    }
     if (!g_cfgs.ready[dev][slot]) {
         lc3_cfg c;
         lc3_host_plan pl;
