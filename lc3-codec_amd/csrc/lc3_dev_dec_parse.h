@@ -604,6 +604,9 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     int band_end = (int)ifs[1];  // first line of the next band (kept in a register: one table read per band, not per line)
     float g_band = lc3_r_band_gain(r, 0, cfg.nb);
     for (int k0 = 0; k0 < ne; k0 += 4) {  // ne is a multiple of 4
+        // residual bits go to the first n_res non-zero lines of a frame (a few dozen lines in): once no lane of the wave has bits
+        // left, the refinement code is skipped for the rest of the pass (a wave-uniform branch)
+        const int res_live = LC3_WAVE_ANY(rank_nz < n_res);
         int32_t xnext[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) xnext[j] = k0 + 12 + j < lastnz ? lc3_px_get(c, LC3_PLANE_X + k0 + 12 + j) : 0;
@@ -614,7 +617,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
             const int k = k0 + j;
             const int32_t xi = xw[j];
             float v = (float)xi;
-            {   // residual_spectrum::decode: the j-th non-zero line takes tail bit tail0 + j while j < n_res
+            if (res_live) {  // residual_spectrum::decode: the j-th non-zero line takes tail bit tail0 + j while j < n_res
                 const int nz = xi != 0, take = nz && rank_nz < n_res;
                 const int pos = tail0 + rank_nz;
                 const int bidx = take ? nbytes - 1 - (pos >> 3) : 0;

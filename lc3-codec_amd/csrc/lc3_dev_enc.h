@@ -602,40 +602,47 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 29);
-    // apply_quantization :267-292 -- one lane per coefficient
+    // apply_quantization :267-292 -- one lane per coefficient; the orders (:275-291: the last index that is not 8, per filter) and
+    // the bit budget (calc_bit_budget :294-311: integer sums, any order is exact) are read off the same 16 lanes by ballot and
+    // wave sums instead of a walk on lane 0 with one table fetch per coefficient
+    int ri_lane = 8;
     if (lane < 16) {
         const float step = (float)3.14159265358979323846 / 17.0f;  // PI as f32 / 17.0 :268
+        float rq_lane = 0.0f;
         if ((lane >> 3) < tp.num) {
-            float q = lc3_asinf(rc_q[lane]) / step;
-            int ri = (q >= 0.0f ? lc3_f2i8(q + 0.5f) : lc3_f2i8(-(-q + 0.5f))) + 8;
-            rc_i[lane] = ri;
-            rc_q[lane] = LC3_TNS_SIN_ENC(ri);  // sin(step * ((float)ri - 8.0f))
-        } else {
-            rc_i[lane] = 8;
-            rc_q[lane] = 0.0f;
+            const float q = lc3_asinf(rc_q[lane]) / step;
+            ri_lane = (q >= 0.0f ? lc3_f2i8(q + 0.5f) : lc3_f2i8(-(-q + 0.5f))) + 8;
+            rq_lane = LC3_TNS_SIN_ENC(ri_lane);  // sin(step * ((float)ri - 8.0f))
         }
+        rc_i[lane] = ri_lane;
+        rc_q[lane] = rq_lane;
     }
-    LC3_SYNC();
-    if (lane == 0) {
-        for (int f = 0; f < 2; f++) {
-            int k = 7;
-            while (k >= 0 && rc_i[f * 8 + k] == 8) k--;
-            L.ism[8 + f] = f < tp.num ? k + 1 : 0;
+    {
+        const unsigned long long live = lc3_wave_ballot(lane < 16 && ri_lane != 8, lane);
+        const uint32_t m0 = (uint32_t)(live & 0xffull), m1 = (uint32_t)((live >> 8) & 0xffull);
+        const int o0 = (0 < tp.num && m0 != 0u) ? 32 - __builtin_clz(m0) : 0;  // 1 + index of the last coefficient that is not 8
+        const int o1 = (1 < tp.num && m1 != 0u) ? 32 - __builtin_clz(m1) : 0;
+        const int ord_f = lane < 8 ? o0 : o1;
+        uint32_t cb = 0;
+        if (lane < 16 && (lane & 7) < ord_f) {
+            const int ric = ri_lane < 0 ? 0 : (ri_lane > 16 ? 16 : ri_lane);
+            cb = LC3T_AC_TNS_COEF_BITS[lane & 7][ric];
         }
-        // calc_bit_budget :294-311
+        const uint32_t cb0 = lc3_wave_sum_u32(lane < 8 ? cb : 0u, lane), cb1 = lc3_wave_sum_u32(lane >= 8 ? cb : 0u, lane);
         int nbits_tns = 0;
-        for (int f = 0; f < tp.num; f++) {
-            int order = L.ism[8 + f];
-            int order_bits = order != 0 ? LC3T_AC_TNS_ORDER_BITS[res.lpc_weighting][order - 1] : 0;
-            int coef_bits = 0;
-            for (int k = 0; k < order; k++) {
-                int ri = rc_i[f * 8 + k];
-                ri = ri < 0 ? 0 : (ri > 16 ? 16 : ri);
-                coef_bits += LC3T_AC_TNS_COEF_BITS[k][ri];
-            }
-            nbits_tns += (int)lc3_ceilf((2048.0f + (float)order_bits + (float)coef_bits) / 2048.0f);
+        if (0 < tp.num) {
+            const int ob = o0 != 0 ? LC3T_AC_TNS_ORDER_BITS[res.lpc_weighting][o0 - 1] : 0;
+            nbits_tns += (int)lc3_ceilf((2048.0f + (float)ob + (float)(int)cb0) / 2048.0f);
         }
-        L.ism[10] = nbits_tns;
+        if (1 < tp.num) {
+            const int ob = o1 != 0 ? LC3T_AC_TNS_ORDER_BITS[res.lpc_weighting][o1 - 1] : 0;
+            nbits_tns += (int)lc3_ceilf((2048.0f + (float)ob + (float)(int)cb1) / 2048.0f);
+        }
+        if (lane == 0) {
+            L.ism[8] = o0;
+            L.ism[9] = o1;
+            L.ism[10] = nbits_tns;
+        }
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 30);

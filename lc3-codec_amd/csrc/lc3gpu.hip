@@ -82,6 +82,7 @@ __shared__ lc3_spec_tables lc3_spec_tab;
 #define LC3_UNIFORM_I32(x) __builtin_amdgcn_readfirstlane((int)(x))
 // product of two values below 2^24 (range-coder steps): the full-rate 24-bit multiplier instead of the quarter-rate v_mul_lo_u32
 #define LC3_MUL24(a, b) __umul24((a), (b))
+#define LC3_WAVE_ANY(pred) (__ballot((pred) != 0) != 0ull)
 // 10^x tables of the two argument families the codec uses (lc3_dev_common.h: LC3_POW10_GG / LC3_POW10_TILT), filled on the device
 // by lc3_pow10f itself when a device's first configuration is registered
 __device__ float lc3_pow10_gg_tab[512];       // [k + 256] = 10^(k / 28), k = gg_ind + gg_off
