@@ -268,11 +268,9 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_mdct(LC3_CFG_PARAM, LC3_LDS
                 if (b < nn_idx) lower += LC3_EB(L)[b];
                 else upper += LC3_EB(L)[b];
             }
-            L.ism[0] = upper > 30.0f * lower;
+            nn = upper > 30.0f * lower;
         }
-        LC3_SYNC();
-        nn = L.ism[0];
-        LC3_SYNC();
+        nn = lc3_wave_bcast0_i32(nn, lane);  // lane 0's result in a scalar register: no LDS round trip
     }
     return nn;
 }
@@ -285,6 +283,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_bandwidth(LC3_CFG_PARAM, LC
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     *nbits_bw = LC3C_NBITS_BW[c.fs_ind];
     if (c.fs_ind == 0) return 0;  // :66-71 (the reference cannot construct an 8 kHz encoder)
+    int result0 = 0;
     if (lane == 0) {
         const int fsi = c.fs_ind;
         int bw = 0;
@@ -310,12 +309,9 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_bandwidth(LC3_CFG_PARAM, LC
             }
             result = cutoff_max > (float)LC3C_BW_TC[bw] ? bw : fsi;
         }
-        L.ism[0] = result;
+        result0 = result;
     }
-    LC3_SYNC();
-    int r = L.ism[0];
-    LC3_SYNC();
-    return r;
+    return lc3_wave_bcast0_i32(result0, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -362,6 +358,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, LC3_L
         en[lane] = lc3_sum_seq(hp + 40 * lane, 40, 0.0f);
     }
     LC3_SYNC();
+    int attack0 = 0;
     if (lane == 0) {
         int attack_position = -1;
         float e_last = L.st.att_energy_last, m_last = L.st.att_max_energy_last;
@@ -372,7 +369,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, LC3_L
             e_last = energy;
             m_last = max_energy;
         }
-        L.ism[0] = attack_position >= 0 || L.st.att_pos_last >= limit;
+        attack0 = attack_position >= 0 || L.st.att_pos_last >= limit;
         L.st.att_energy_last = e_last;
         L.st.att_max_energy_last = m_last;
         L.st.att_pos_last = attack_position;
@@ -380,9 +377,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_attack(LC3_CFG_PARAM, LC3_L
         L.st.att_ds_tm2 = ds[num_ds - 2];
     }
     LC3_SYNC();
-    int r = L.ism[0];
-    LC3_SYNC();
-    return r;
+    return lc3_wave_bcast0_i32(attack0, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -638,11 +633,9 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
             const int ob = o1 != 0 ? LC3T_AC_TNS_ORDER_BITS[res.lpc_weighting][o1 - 1] : 0;
             nbits_tns += (int)lc3_ceilf((2048.0f + (float)ob + (float)(int)cb1) / 2048.0f);
         }
-        if (lane == 0) {
-            L.ism[8] = o0;
-            L.ism[9] = o1;
-            L.ism[10] = nbits_tns;
-        }
+        res.rc_order[0] = o0;
+        res.rc_order[1] = o1;
+        res.nbits_tns = nbits_tns;
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 30);
@@ -657,7 +650,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
     {
         float stv[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // the lattice state, the same on every lane
         for (int f = 0; f < tp.num; f++) {
-            const int order = L.ism[8 + f];
+            const int order = res.rc_order[f];
             if (order == 0) continue;
             const int start = tp.start[f], len = (sswb_stop && f == 0 ? 240 : tp.stop[f]) - tp.start[f];  // len <= 256
             const int lastl = (len - 1) & 63, lastj = (len - 1) >> 6;
@@ -697,10 +690,6 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
             LC3_SYNC();
         }
     }
-    LC3_SYNC();
-    res.rc_order[0] = L.ism[8];
-    res.rc_order[1] = L.ism[9];
-    res.nbits_tns = L.ism[10];
     LC3_SYNC();
     return res;
 }
@@ -1035,18 +1024,17 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         sq[n] = v * v;
     }
     LC3_SYNC();
+    float nv = 0.0f;
     if (lane < 3) {
         const int lag = lane == 0 ? 0 : (lane == 1 ? lag_t1 : lag_t2);
         const int from = LC3_KMAX - lag;
-        const float v = lc3_sum_seq(sq + from, len6, 0.0f);
-        L.sm[lane] = v;
+        nv = lc3_sum_seq(sq + from, len6, 0.0f);
     }
-    LC3_SYNC();
-    if (lane == 0) {
-        const float nv0 = L.sm[0], nv1 = L.sm[1], nv2 = L.sm[2];
+    int t_current, pitch_present;
+    {   // the three sums sit on lanes 0..2: read across the wave, the decision is then the same scalar code on every lane
+        const float nv0 = lc3_wave_read_f32(nv, 0, lane), nv1 = lc3_wave_read_f32(nv, 1, lane), nv2 = lc3_wave_read_f32(nv, 2, lane);
         float normcorr1 = lc3_maxf(0.0f, r6[lag_t1 - LC3_KMIN] / lc3_sqrtf(nv0 * nv1));
         float normcorr2 = lag_t1 == lag_t2 ? normcorr1 : lc3_maxf(0.0f, r6[lag_t2 - LC3_KMIN] / lc3_sqrtf(nv0 * nv2));
-        int t_current, pitch_present;
         if (normcorr2 > 0.85f * normcorr1) {
             t_current = lag_t2;
             pitch_present = normcorr2 > 0.6f;
@@ -1054,13 +1042,9 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
             t_current = lag_t1;
             pitch_present = normcorr1 > 0.6f;
         }
-        L.ism[2] = t_current;
-        L.ism[3] = pitch_present;
     }
-    LC3_SYNC();
     LC3_STAMP(L, lane, 14);
     // pitch_lag_parameter :292-363
-    const int t_current = L.ism[2];
     const int k_min = 2 * t_current - 4 > 32 ? 2 * t_current - 4 : 32;
     const int k_max = 2 * t_current + 4 < 228 ? 2 * t_current + 4 : 228;
     {
@@ -1077,7 +1061,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     // maximum above zero of up to seven interpolated values (:315-345, interpolate :457-469).  Both scans run wave-parallel
     // (lc3_wave_argmax_first; lane j holds correlation j, then candidate j whose nine taps it adds up in the reference's order)
     // instead of 17 + 7 x 9 steps on one lane.  A NaN in a scan (never with finite PCM) takes the sequential form below.
-    int pitch_int, pitch_fr;
+    int pitch_int, pitch_fr, pitch_index_u;
     {
         const int nk = (k_max + 4) - (k_min - 4) + 1;
         const int k = k_min - 4 + lane, in_k = lane < nk && k >= k_min && k <= k_max;
@@ -1154,7 +1138,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         if (pitch_int < 127) pitch_index = 4 * pitch_int + pitch_fr - 128;
         else if (pitch_int < 157) pitch_index = 2 * pitch_int + pitch_fr / 2 - 126;
         else pitch_index = pitch_int + 283;
-        if (lane == 0) L.ism[6] = pitch_index;
+        pitch_index_u = pitch_index;
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 15);
@@ -1171,49 +1155,43 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         }
     }
     LC3_SYNC();
+    float acc3 = 0.0f;
     if (lane < 3) {
         // lane 0: sum dA*dB, lane 1: sum dA*dA, lane 2: sum dB*dB
         const float *pp = S + 128 * lane;
-        const float acc = lc3_sum_seq(pp, len12, 0.0f);
-        L.sm[lane] = acc;
+        acc3 = lc3_sum_seq(pp, len12, 0.0f);
     }
-    LC3_SYNC();
-    if (lane == 0) {
-        const int pitch_present = L.ism[3];
-        int pitch_index = L.ism[6];
-        const float num = L.sm[0], nd = L.sm[1], sh = L.sm[2];
+    int ltpf_active = 0;
+    {
+        const float num = lc3_wave_read_f32(acc3, 0, lane), nd = lc3_wave_read_f32(acc3, 1, lane), sh = lc3_wave_read_f32(acc3, 2, lane);
         const float den = lc3_sqrtf(nd * sh);
         float nc = den > 0.0f ? num / den : 0.0f;
         const float pitch = (float)pitch_int + (float)pitch_fr / 4.0f;
-        int ltpf_active = 0;
         if (gain_ltpf_on && !near_nyquist) {
             const int ma = L.st.mem_ltpf_active;
             ltpf_active = (!ma && (c.n_ms_10 || L.st.mem_mem_nc > 0.94f) && L.st.mem_nc > 0.94f && nc > 0.94f) ||
                           (ma && nc > 0.9f) ||
                           (ma && lc3_absf(pitch - L.st.mem_pitch) < 2.0f && (nc - L.st.mem_nc) > -0.1f && nc > 0.84f);
         }
+        int pitch_index = pitch_index_u;
         if (!pitch_present) {  // :184-214
             pitch_index = 0;
             nc = 0.0f;
         }
-        L.st.t_prev = t_current;
-        L.st.mem_mem_nc = L.st.mem_nc;
-        if (pitch_present) {
-            L.st.mem_pitch = pitch;
-            L.st.mem_ltpf_active = ltpf_active;
-            L.st.mem_nc = nc;
-        } else {
-            L.st.mem_pitch = 0.0f;
-            L.st.mem_ltpf_active = 0;
-            L.st.mem_nc = 0.0f;
+        const float mem_nc_old = L.st.mem_nc;
+        LC3_SYNC();  // every lane has read the memories before lane 0 moves them on
+        if (lane == 0) {
+            L.st.t_prev = t_current;
+            L.st.mem_mem_nc = mem_nc_old;
+            L.st.mem_pitch = pitch_present ? pitch : 0.0f;
+            L.st.mem_ltpf_active = pitch_present ? ltpf_active : 0;
+            L.st.mem_nc = pitch_present ? nc : 0.0f;
         }
-        L.ism[6] = pitch_index;
-        L.ism[7] = ltpf_active;
+        res.pitch_index = pitch_index;
     }
     LC3_SYNC();
-    res.pitch_index = L.ism[6];
-    res.pitch_present = L.ism[3];
-    res.ltpf_active = L.ism[7];
+    res.pitch_present = pitch_present;
+    res.ltpf_active = ltpf_active;
     res.nbits_ltpf = res.pitch_present ? 11 : 1;
     // the new samples go into the oldest slots of the rings in the state blob
     if (store) {
@@ -1438,6 +1416,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
     // evaluated per round: the 1 + 2 + 4 gains the next three steps can possibly visit are known in advance, lane c
     // sums the terms of candidate c (each sum in the reference's order), and the three decisions are then read off.
     // Rounds of 3, 3 and 2 levels replace 8 dependent chains by 3.
+    int gg_min = 0, reset_offset = 0, gg_ind_u = 0;
     {
         int fac = 256, gg_ind = 255;
         float *tvb = (float *)L.fa;  // 7 candidate term arrays of LC3_TVB floats (840 of the 960 floats of fa/fb)
@@ -1529,23 +1508,16 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
             level += depth;
         }
 #undef LC3_TVB
-        if (lane == 0) {
-            // global_gain_limitation :212-228
-            int gg_min = 0;
-            if (x_f_max > 0.0f) gg_min = lc3_f2i16(lc3_ceilf(28.0f * lc3_log10f(x_f_max / (32768.0f - 0.375f)))) - gg_off;
-            int reset_offset = 0;
-            if (gg_ind < gg_min || x_f_max == 0.0f) {
-                reset_offset = 1;
-                gg_ind = gg_min;
-            }
-            L.ism[8] = gg_ind;
-            L.ism[9] = gg_min;
-            L.ism[10] = reset_offset;
+        // global_gain_limitation :212-228 (every input is wave-uniform: the same scalar code on every lane)
+        gg_min = 0;
+        if (x_f_max > 0.0f) gg_min = lc3_f2i16(lc3_ceilf(28.0f * lc3_log10f(x_f_max / (32768.0f - 0.375f)))) - gg_off;
+        if (gg_ind < gg_min || x_f_max == 0.0f) {
+            reset_offset = 1;
+            gg_ind = gg_min;
         }
+        gg_ind_u = gg_ind;
     }
-    LC3_SYNC();
-    int gg_ind = L.ism[8];
-    const int gg_min = L.ism[9], reset_offset = L.ism[10];
+    int gg_ind = gg_ind_u;
     LC3_SYNC();
     LC3_STAMP(L, lane, 10);
     lc3_bitcons bc = lc3_quantize_spectrum(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, gg_off, gg_ind, nbits_spec);
@@ -1592,7 +1564,8 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
 // E18 residual bits (encoder/residual_spectrum.rs:33-62), E19 noise level
 // (encoder/noise_level_estimation.rs:21-55).  Returns n_res via L.ism[0], noise factor via L.ism[1].
 // ------------------------------------------------------------------------------------------
-LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane,
+// returns n_res | noise factor << 16
+LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_residual_noise(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane,
                                                     const lc3_quant_res q, int bw_ind) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
@@ -1653,19 +1626,18 @@ LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_residual_noise(LC3_CFG_PAR
         }
     }
     LC3_SYNC();
-    if (lane == 0) {
-        L.ism[0] = tot_nz < mx ? tot_nz : mx;
-        const float sum = lc3_sum_seq(compact, tot_rel, 0.0f);
-        const float level = tot_rel > 0 ? sum / (float)tot_rel : 0.0f;
-        const float diff = 8.0f - 16.0f * level;
-        int nfac = 0;
-        if (diff >= 0.0f) {
-            const int v = lc3_f2i32(diff + 0.5f);
-            nfac = v < 7 ? v : 7;
-        }
-        L.ism[1] = nfac;
+    float sum0 = 0.0f;
+    if (lane == 0) sum0 = lc3_sum_seq(compact, tot_rel, 0.0f);
+    const float sum = lc3_wave_bcast0_f32(sum0, lane);
+    const float level = tot_rel > 0 ? sum / (float)tot_rel : 0.0f;
+    const float diff = 8.0f - 16.0f * level;
+    int nfac = 0;
+    if (diff >= 0.0f) {
+        const int v = lc3_f2i32(diff + 0.5f);
+        nfac = v < 7 ? v : 7;
     }
     LC3_SYNC();
+    return (nfac << 16) | (tot_nz < mx ? tot_nz : mx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1799,10 +1771,9 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PA
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[960 + i] = L.spec[i];
     const lc3_quant_res spec = lc3_enc_quant(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, nbits_bw, tns.nbits_tns, nbits_ltpf);
     LC3_STAMP(L, lane, 6);
-    lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
+    const int rn = lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
     LC3_STAMP(L, lane, 7);
-    const int n_res = L.ism[0], noise_factor = L.ism[1];
-    LC3_SYNC();
+    const int n_res = rn & 0xffff, noise_factor = rn >> 16;
     if (dbg && lane == 0) {
         float *d = dbg + 1440;
         const int st = plane_stride;

@@ -204,6 +204,15 @@ __device__ __forceinline__ int lc3_wave_read_i32(int v, int src, int lane) {
     (void)lane;
     return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
 }
+// lane 0's value on every lane (all lanes active): a scalar register, no LDS round trip
+__device__ __forceinline__ int lc3_wave_bcast0_i32(int v, int lane) {
+    (void)lane;
+    return __builtin_amdgcn_readlane(v, 0);
+}
+__device__ __forceinline__ float lc3_wave_bcast0_f32(float v, int lane) {
+    (void)lane;
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+}
 __device__ __forceinline__ unsigned long long lc3_wave_ballot(int pred, int lane) {
     (void)lane;
     return __ballot(pred);

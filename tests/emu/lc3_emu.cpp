@@ -90,6 +90,8 @@ static inline int lc3_wave_read_i32(int v, int src, int lane) {
     LC3_SYNC();
     return r;
 }
+static inline int lc3_wave_bcast0_i32(int v, int lane) { return lc3_wave_read_i32(v, 0, lane); }
+static inline float lc3_wave_bcast0_f32(float v, int lane) { return lc3_wave_read_f32(v, 0, lane); }
 static inline unsigned long long lc3_wave_ballot(int pred, int lane) {
     LC3_SYNC();
     g_xi[tl_wave][lane] = pred != 0;
