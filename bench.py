@@ -329,6 +329,11 @@ def run_rank(args):
 
         if emu:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        elif os.environ.get("LC3_BENCH_BACKEND") == "gloo":
+            # test aid for boxes with fewer GPUs than ranks: the ranks share the visible devices and reduce over gloo (RCCL needs
+            # one GPU per rank); everything else -- launcher, sharding, GPU engine -- is the production path
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -397,7 +402,8 @@ def run_rank(args):
     kernel_ms = eng.timing_stop()
 
     # max time over ranks, counters summed over ranks (the only collective of the job)
-    elapsed, total_frames, total_mismatches, _ = D.reduce_report(dist, eng.device, elapsed, frames_per_step * args.steps,
+    red_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else eng.device
+    elapsed, total_frames, total_mismatches, _ = D.reduce_report(dist, red_dev, elapsed, frames_per_step * args.steps,
                                                                   mismatches=mismatches)
     overlapped = eng.overlap_probe(args.steps, args.warmup) if (args.overlap_probe and world == 1) else None
 

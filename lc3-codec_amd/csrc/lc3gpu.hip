@@ -112,34 +112,40 @@ struct lc3_cfg_any {
     typedef const lc3_cfg &bind_t;
     static __device__ __forceinline__ bind_t bind(const lc3_cfg &r) { return r; }
 };
-struct lc3_cfg_48k10 {
-    static constexpr int fs = 48000, fs_ind = 4, nf = 480, ne = 400, nb = 64, z = 180, n_ms_10 = 1, nfft = 240, n_stages = 4;
-    static constexpr int radix[6] = {4, 4, 3, 5, 0, 0}, m[6] = {60, 15, 5, 1, 0, 0}, fstride[6] = {1, 4, 16, 48, 0, 0},
-                         inv_m[6] = {1093, 4370, 13108, 65536, 0, 0};
-    static constexpr int len12 = 128, len6 = 64, delay12 = 24, p_up = 4, hist = 60;
-    static constexpr float resamp_scale = 4.0f;
-    static constexpr int resamp_lim = 30, resamp_nt = 64, resamp_stride = 68, inv_p = 16384;
-    static constexpr int l_den = 12, l_num = 10, num_mem_blocks = 2, norm = 120, s25 = 120;
-    const lc3_cpx *fft_tw, *dct_tw;
-    const uint16_t *perm;
-    const float *resamp_poly, *line_width;
-    const uint8_t *line_band;
-    __device__ __forceinline__ explicit lc3_cfg_48k10(const lc3_cfg &r)
-        : fft_tw(r.fft_tw), dct_tw(r.dct_tw), perm(r.perm), resamp_poly(r.resamp_poly), line_width(r.line_width), line_band(r.line_band) {}
-    typedef const lc3_cfg_48k10 bind_t;
-    static __device__ __forceinline__ lc3_cfg_48k10 bind(const lc3_cfg &r) { return lc3_cfg_48k10(r); }
-    // host side: do the constants describe this plan?
-    static bool matches(const lc3_cfg &r) {
-        bool ok = r.fs == fs && r.fs_ind == fs_ind && r.nf == nf && r.ne == ne && r.nb == nb && r.z == z && r.n_ms_10 == n_ms_10 &&
-                  r.nfft == nfft && r.n_stages == n_stages && r.len12 == len12 && r.len6 == len6 && r.delay12 == delay12 &&
-                  r.p_up == p_up && r.hist == hist && r.resamp_scale == resamp_scale && r.resamp_lim == resamp_lim &&
-                  r.resamp_nt == resamp_nt && r.resamp_stride == resamp_stride && r.inv_p == inv_p && r.l_den == l_den &&
-                  r.l_num == l_num && r.num_mem_blocks == num_mem_blocks && r.norm == norm && r.s25 == s25;
-        for (int i = 0; i < 6; i++)
-            ok = ok && r.radix[i] == radix[i] && r.m[i] == m[i] && r.fstride[i] == fstride[i] && r.inv_m[i] == inv_m[i];
-        return ok;
-    }
-};
+// One struct per view (lc3_cfg_views.h, generated by tools/gen_views.py): the configuration's integers as constants, the
+// device pointers taken from the constant table's slot, and matches() -- host side -- to check the constants against the plan
+// cfg_acquire computes.
+#define LC3_ARR(...) {__VA_ARGS__}
+#define LC3_DEFINE_CFG_VIEW(NAME, FS, FS_IND, NF, NE, NB, Z, N10, NFFT, NST, RADIX, M, FSTRIDE, INV_M, LEN12, LEN6, DELAY12, P_UP, HIST,  \
+                            RSCALE, RLIM, RNT, RSTRIDE, INV_P, L_DEN, L_NUM, NMB, NORM, S25)                                             \
+    struct NAME {                                                                                                                      \
+        static constexpr int fs = FS, fs_ind = FS_IND, nf = NF, ne = NE, nb = NB, z = Z, n_ms_10 = N10, nfft = NFFT, n_stages = NST;    \
+        static constexpr int radix[6] = RADIX, m[6] = M, fstride[6] = FSTRIDE, inv_m[6] = INV_M;                                        \
+        static constexpr int len12 = LEN12, len6 = LEN6, delay12 = DELAY12, p_up = P_UP, hist = HIST;                                   \
+        static constexpr float resamp_scale = RSCALE;                                                                                  \
+        static constexpr int resamp_lim = RLIM, resamp_nt = RNT, resamp_stride = RSTRIDE, inv_p = INV_P;                                \
+        static constexpr int l_den = L_DEN, l_num = L_NUM, num_mem_blocks = NMB, norm = NORM, s25 = S25;                                \
+        const lc3_cpx *fft_tw, *dct_tw;                                                                                                \
+        const uint16_t *perm;                                                                                                          \
+        const float *resamp_poly, *line_width;                                                                                         \
+        const uint8_t *line_band;                                                                                                      \
+        __device__ __forceinline__ explicit NAME(const lc3_cfg &r)                                                                     \
+            : fft_tw(r.fft_tw), dct_tw(r.dct_tw), perm(r.perm), resamp_poly(r.resamp_poly), line_width(r.line_width),                  \
+              line_band(r.line_band) {}                                                                                                \
+        typedef const NAME bind_t;                                                                                                     \
+        static __device__ __forceinline__ NAME bind(const lc3_cfg &r) { return NAME(r); }                                              \
+        static bool matches(const lc3_cfg &r) {                                                                                        \
+            bool ok = r.fs == fs && r.fs_ind == fs_ind && r.nf == nf && r.ne == ne && r.nb == nb && r.z == z && r.n_ms_10 == n_ms_10 && \
+                      r.nfft == nfft && r.n_stages == n_stages && r.len12 == len12 && r.len6 == len6 && r.delay12 == delay12 &&         \
+                      r.p_up == p_up && r.hist == hist && r.resamp_scale == resamp_scale && r.resamp_lim == resamp_lim &&               \
+                      r.resamp_nt == resamp_nt && r.resamp_stride == resamp_stride && r.inv_p == inv_p && r.l_den == l_den &&           \
+                      r.l_num == l_num && r.num_mem_blocks == num_mem_blocks && r.norm == norm && r.s25 == s25;                         \
+            for (int i = 0; i < 6; i++)                                                                                                \
+                ok = ok && r.radix[i] == radix[i] && r.m[i] == m[i] && r.fstride[i] == fstride[i] && r.inv_m[i] == inv_m[i];            \
+            return ok;                                                                                                                 \
+        }                                                                                                                              \
+    };
+#include "lc3_cfg_views.h"
 #undef LC3_CFG_TEMPLATE
 #undef LC3_CFG_PARAM
 #undef LC3_CFG_BIND
@@ -753,15 +759,20 @@ thread_local int g_last_hip = 0;
 struct HostCfg {
     lc3_cfg c;       // host copy (device pointers inside are valid on the device it was registered on)
     int slot = 0;    // its slot in lc3_cfg_table
-    bool fixed = false;  // launch the lc3_cfg_48k10 instantiations (compile-time configuration)
+    int view = 0;    // 0: run-time view (lc3_cfg_any); 1..4: the compile-time view of lc3_cfg_views.h that matches this configuration
 };
 // launches kern<view>(slot, args...) with the view the configuration allows
-#define LC3_LAUNCH_CFG(kern, h, grid, block, lds, stream, ...)                                                                   \
-    do {                                                                                                                         \
-        if ((h).fixed)                                                                                                           \
-            hipLaunchKernelGGL(kern<lc3_cfg_48k10>, grid, block, lds, stream, lc3_cfg_slot<lc3_cfg_48k10>{(h).slot}, __VA_ARGS__); \
-        else                                                                                                                     \
-            hipLaunchKernelGGL(kern<lc3_cfg_any>, grid, block, lds, stream, lc3_cfg_slot<lc3_cfg_any>{(h).slot}, __VA_ARGS__);     \
+#define LC3_LAUNCH_VIEW(kern, V, h, grid, block, lds, stream, ...) \
+    hipLaunchKernelGGL(kern<V>, grid, block, lds, stream, lc3_cfg_slot<V>{(h).slot}, __VA_ARGS__)
+#define LC3_LAUNCH_CFG(kern, h, grid, block, lds, stream, ...)                                                  \
+    do {                                                                                                        \
+        switch ((h).view) {                                                                                     \
+        case 1: LC3_LAUNCH_VIEW(kern, lc3_cfg_48k10, h, grid, block, lds, stream, __VA_ARGS__); break;          \
+        case 2: LC3_LAUNCH_VIEW(kern, lc3_cfg_48k75, h, grid, block, lds, stream, __VA_ARGS__); break;          \
+        case 3: LC3_LAUNCH_VIEW(kern, lc3_cfg_32k10, h, grid, block, lds, stream, __VA_ARGS__); break;          \
+        case 4: LC3_LAUNCH_VIEW(kern, lc3_cfg_16k10, h, grid, block, lds, stream, __VA_ARGS__); break;          \
+        default: LC3_LAUNCH_VIEW(kern, lc3_cfg_any, h, grid, block, lds, stream, __VA_ARGS__); break;           \
+        }                                                                                                       \
     } while (0)
 
 int make_config(lc3_cfg &c, int frame_us, int fs_hz) {
@@ -870,7 +881,13 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
     h.slot = slot;
     // LC3GPU_GENERIC=1 keeps every configuration on the run-time view (test aid: both instantiations must agree)
     static const bool generic_only = std::getenv("LC3GPU_GENERIC") != nullptr && std::atoi(std::getenv("LC3GPU_GENERIC")) != 0;
-    h.fixed = !generic_only && lc3_cfg_48k10::matches(h.c);
+    h.view = 0;
+    if (!generic_only) {
+        if (lc3_cfg_48k10::matches(h.c)) h.view = 1;
+        else if (lc3_cfg_48k75::matches(h.c)) h.view = 2;
+        else if (lc3_cfg_32k10::matches(h.c)) h.view = 3;
+        else if (lc3_cfg_16k10::matches(h.c)) h.view = 4;
+    }
     return LC3GPU_OK;
 }
 
@@ -1081,7 +1098,7 @@ void fill_groups(const HandleCommon &hc, int T, unsigned fpb, lc3_groups &G, uns
         const GroupHost &gh = hc.groups[i];
         lc3_group &g = G.g[i];
         g.slot = gh.h.slot;
-        g.fixed = gh.h.fixed;
+        g.fixed = gh.h.view == 1;  // the mixed kernels carry two bodies: the headline view and the run-time view
         g.first_stream = gh.first_stream;
         g.n_streams = gh.n_streams;
         g.wg_stream = (int)wg_stream;

@@ -583,9 +583,9 @@ def test_state_blob_size_is_checked():
 
 
 def test_runtime_configuration_view_of_the_headline_configuration():
-    """48 kHz / 10 ms normally runs the kernels instantiated with the configuration as compile-time constants
-    (lc3_cfg_48k10); LC3GPU_GENERIC=1 keeps it on the run-time view every other configuration uses.  Both must give the
-    oracle's bytes and PCM (a fresh process: the switch is read once per process)."""
+    """48 kHz / 10 ms, 48 kHz / 7.5 ms, 32 kHz / 10 ms and 16 kHz / 10 ms normally run kernels instantiated with the configuration as
+    compile-time constants (lc3_cfg_views.h); LC3GPU_GENERIC=1 keeps them on the run-time view every other configuration uses.
+    Both must give the oracle's bytes and PCM (a fresh process: the switch is read once per process)."""
     import os
     import subprocess
     import sys
@@ -595,6 +595,8 @@ def test_runtime_configuration_view_of_the_headline_configuration():
         "import test_gpu_parity as t\n"
         "for nb in (150, 60, 300):\n"
         "    t._roundtrip_check(48000, 10000, nb, 96, 6, seed=61)\n"
+        "for fs, us, nb in ((48000, 7500, 113), (32000, 10000, 80), (16000, 10000, 40)):\n"
+        "    t._roundtrip_check(fs, us, nb, 64, 6, seed=62)\n"
         "t.test_corrupt_frames_are_concealed_like_the_reference()\n"
         "t.test_ltpf_transitions(48000, 10000, 40)\n"
         "print('generic ok')\n"
