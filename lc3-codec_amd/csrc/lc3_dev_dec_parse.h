@@ -51,6 +51,7 @@ struct lc3_parse_ctx {
 #define LC3_PSTAMP(c, id)
 #endif
 
+static_assert(LC3_PLANE_STRIDE == 1, "the parser's 64 / 128-bit plane accesses need frame-major planes");
 __device__ __forceinline__ void lc3_px_set(lc3_parse_ctx &c, int word, int32_t v) { c.plane[word * c.stride] = v; }
 __device__ __forceinline__ int32_t lc3_px_get(const lc3_parse_ctx &c, int word) { return c.plane[word * c.stride]; }
 
@@ -369,8 +370,13 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             const int bit1 = lc3_p_bool_sel(c, esc ? want_e : m1 > 0, err);
             const int32_t v0 = bit0 ? -m0 : m0, v1 = bit1 ? -m1 : m1;
             // (an escape step stores its partial values too: the pair's main step overwrites them)
-            lc3_px_set(c, LC3_PLANE_X + 2 * tup, v0);
-            lc3_px_set(c, LC3_PLANE_X + 2 * tup + 1, v1);
+            {   // the pair as one 64-bit store (8-byte aligned: the column, LC3_PLANE_X and 2 * tup are even numbers of words)
+                typedef int32_t lc3_i2 __attribute__((vector_size(8)));
+                lc3_i2 pr;
+                pr[0] = v0;
+                pr[1] = v1;
+                *(lc3_i2 *)(c.plane + (LC3_PLANE_X + 2 * tup) * LC3_PLANE_STRIDE) = pr;
+            }
             if (lsb_mode && !esc) lc3_px_set(c, LC3_PLANE_LEV + tup, lev);  // written by TUPLE index, read by LINE index (:184-195)
             c.nnz += esc ? 0u : (uint32_t)(m0 != 0) + (uint32_t)(m1 != 0);
             c.seed += esc ? 0u : (uint32_t)m0 * (uint32_t)(2 * tup) + (uint32_t)m1 * (uint32_t)(2 * tup + 1);
@@ -593,8 +599,16 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     // k0 .. k0+11 of the current group of four), so that the loads of a group have a whole group's work to land.
     uint32_t nzwin = 0;
     int32_t xw[12];
+    {   // 128-bit loads (the column and LC3_PLANE_X are 16-byte aligned); words at or beyond lastnz are stale and masked
+        struct q4 { int32_t v[4]; };
+        const lc3_i4 *x4 = (const lc3_i4 *)(c.plane + LC3_PLANE_X * LC3_PLANE_STRIDE);
 #pragma unroll
-    for (int j = 0; j < 12; j++) xw[j] = j < lastnz ? lc3_px_get(c, LC3_PLANE_X + j) : 0;  // lastnz <= ne
+        for (int g4 = 0; g4 < 3; g4++) {
+            const q4 w = __builtin_bit_cast(q4, x4[g4]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) xw[4 * g4 + j] = 4 * g4 + j < lastnz ? w.v[j] : 0;  // lastnz <= ne
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if (xw[j] != 0 && j < bw_stop) nzwin |= 1u << (j + 3);
@@ -608,8 +622,13 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
         // left, the refinement code is skipped for the rest of the pass (a wave-uniform branch)
         const int res_live = LC3_WAVE_ANY(rank_nz < n_res);
         int32_t xnext[4];
+        {   // one 128-bit load per group of four lines (up to 11 words past the spectrum: still inside the column)
+            struct q4 { int32_t v[4]; };
+            const q4 w = __builtin_bit_cast(q4, *(const lc3_i4 *)(c.plane + (LC3_PLANE_X + k0 + 12) * LC3_PLANE_STRIDE));
 #pragma unroll
-        for (int j = 0; j < 4; j++) xnext[j] = k0 + 12 + j < lastnz ? lc3_px_get(c, LC3_PLANE_X + k0 + 12 + j) : 0;
+            for (int j = 0; j < 4; j++) xnext[j] = k0 + 12 + j < lastnz ? w.v[j] : 0;
+        }
+        float vout[4];
         // The per-line work is written with selects, not branches: the conditions differ from lane to lane (each lane is
         // another frame), and a divergent branch costs more scalar bookkeeping than the few operations it would skip.
 #pragma unroll
@@ -665,9 +684,14 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
                 g_band = lc3_r_band_gain(r, bi, cfg.nb);
             }
             v *= g_band;
-            lc3_px_set(c, LC3_PLANE_X + k, (int32_t)lc3_bits(v));
+            vout[j] = v;
             // slide the window: drop line k - 3, bring in line k + 4
             nzwin = (nzwin >> 1) | ((xw[j + 4] != 0 && k + 4 < bw_stop) ? 64u : 0u);
+        }
+        {   // the group's four reconstructed lines leave as one 128-bit store
+            lc3_f4 o;
+            o.x = vout[0]; o.y = vout[1]; o.z = vout[2]; o.w = vout[3];
+            *(lc3_f4 *)(c.plane + (LC3_PLANE_X + k0) * LC3_PLANE_STRIDE) = o;
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) xw[j] = xw[j + 4];
