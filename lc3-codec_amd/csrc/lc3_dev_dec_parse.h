@@ -510,9 +510,18 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     const int ne = cfg.ne, nbytes = c.len, nbits = nbytes * 8;
     // the side-information words of the column in one batch of independent loads (a lane of this kernel is
     // latency-bound: a word fetched at its point of use costs a full memory round trip)
-    int32_t siw[SI_WORDS];
+    int32_t siw[LC3_PLANE_X];  // the SI_WORDS words and the padding up to the spectrum, fetched as 128-bit units
+    {
+        struct q4 { int32_t v[4]; };
+        static_assert(SI_WORDS <= LC3_PLANE_X && LC3_PLANE_X % 4 == 0, "side-information region");
+        const lc3_i4 *s4 = (const lc3_i4 *)c.plane;
 #pragma unroll
-    for (int i = 0; i < SI_WORDS; i++) siw[i] = lc3_px_get(c, i);
+        for (int i = 0; i < LC3_PLANE_X / 4; i++) {
+            const q4 w = __builtin_bit_cast(q4, s4[i]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) siw[4 * i + j] = w.v[j];
+        }
+    }
 #define LC3_SIW(word) siw[word]
     const int lsb_mode = LC3_SIW(SI_LSB_MODE), lastnz = LC3_SIW(SI_LASTNZ), gg_ind = LC3_SIW(SI_GG);
     const int tail0 = LC3_SIW(AD_TAIL0), nres_max = LC3_SIW(AD_NRES_MAX), head = LC3_SIW(AD_HEAD);

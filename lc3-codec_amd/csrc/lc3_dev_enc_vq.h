@@ -128,8 +128,14 @@ __device__ __forceinline__ void lc3_vq_enum(const lc3_vq_ctx &v, const int (&y)[
 
 __device__ __forceinline__ void lc3_sns_vq_frame(const lc3_vq_ctx &v) {
     float s[16];
+    {   // the 16 targets as four 128-bit loads (the column and MP_SCF are 16-byte aligned)
+        const lc3_f4 *s4 = (const lc3_f4 *)(v.mid + MP_SCF);
 #pragma unroll
-    for (int n = 0; n < 16; n++) s[n] = v.mid[MP_SCF + n];
+        for (int n = 0; n < 4; n++) {
+            const lc3_f4 w = s4[n];
+            s[4 * n] = w.x; s[4 * n + 1] = w.y; s[4 * n + 2] = w.z; s[4 * n + 3] = w.w;
+        }
+    }
     // stage 1 :318-361: nearest LF / HF codebook entries (first minimum)
     int ind_lf = 0, ind_hf = 0;
     {
@@ -290,8 +296,16 @@ __device__ __forceinline__ void lc3_sns_vq_frame(const lc3_vq_ctx &v) {
     }
     const int diff = 64 - v.nb;
     if (diff == 0) {
+        lc3_f4 *g4 = (lc3_f4 *)v.gains;  // 64 gains as sixteen 128-bit stores
 #pragma unroll
-        for (int b = 0; b < 64; b++) v.gains[b] = lc3_exp2f(-lc3_vq_interp(q, b));
+        for (int b = 0; b < 64; b += 4) {
+            lc3_f4 o;
+            o.x = lc3_exp2f(-lc3_vq_interp(q, b));
+            o.y = lc3_exp2f(-lc3_vq_interp(q, b + 1));
+            o.z = lc3_exp2f(-lc3_vq_interp(q, b + 2));
+            o.w = lc3_exp2f(-lc3_vq_interp(q, b + 3));
+            g4[b / 4] = o;
+        }
     } else {  // :185-201 (encoder form); only 8 kHz has nb < 64 and the reference cannot encode 8 kHz
         float f[64];
 #pragma unroll
