@@ -115,6 +115,25 @@
 #define LC3_SPEC_BW_CUTOFF_DB 4    // A7: cut-off test on 10 log10(eps + E[n-L] / E[n]) (the note at bandwidth_detector.rs:106-107)
 #define LC3_SPEC_SNS_LAST_GAIN 8   // A3: the SNS gain search also tries the last gain of every shape
 #define LC3_SPEC_NBITS_SPEC_OLD 16 // A1: nbits_spec_old follows nbits_spec
+// internal (never part of the ABI's LC3GPU_SPEC_* set; LC3GPU_SEQ_SUMS=1 in the environment at create time): decisions that
+// are normally taken from guarded tree sums always take their sequential-sum path, so that tests can run that path
+#define LC3_SPEC_TEST_SEQ_SUMS 256
+#ifndef LC3_BISECT_GUARD
+#define LC3_BISECT_GUARD 1.0e-4f
+#endif
+// the CPU emulator of the device code (tests/emu) defines these to run the sequential sum next to every guarded
+// decision and to stop when the two disagree
+#ifndef LC3_GUARD_SELFCHECK
+#define LC3_GUARD_SELFCHECK 0
+#define LC3_GUARD_ASSERT(cond) ((void)0)
+#endif
+// x / d for many x and one (wave-uniform) d.  The GPU build (lc3gpu.hip) supplies the hardware's own correctly rounded
+// division sequence with the part that only depends on d done once; here: the plain division.
+#ifndef LC3_UNIFORM_DIV
+struct lc3_divisor { float d; };
+static inline lc3_divisor lc3_divisor_make(float d) { lc3_divisor v = {d}; return v; }
+static inline float lc3_div_by(float x, const lc3_divisor &v) { return x / v.d; }
+#endif
 
 // HBM "planes" hand frames between the wave-per-stream and the lane-per-frame kernels.  Frame-major: a frame's
 // words are contiguous, so the wave side moves them with coalesced 256-byte accesses and the lane side walks its

@@ -60,8 +60,8 @@ struct __attribute__((aligned(16))) lc3_enc_lds {
 };
 #define LC3_EB(L) ((float *)(L).fa + 512)                    // [64] band energies: MDCT stage -> bandwidth, SNS
 #define LC3_SCF(L) ((float *)(L).fa + 144)                   // [16] SNS target scale factors (lc3_enc_sns_front)
-#define LC3_XQ(L) ((L).t)                                    // int16[ne] quantised spectrum (from the quantiser on)
-#define LC3_RESW(L) ((uint32_t *)((uint8_t *)(L).t + 2 * LC3_MAX_NE))  // uint32[13] residual bits, bit j of word j / 32
+#define LC3_XQ(L) ((L).t)                                    // int16[512] quantised spectrum, zero from ne on (from the quantiser on)
+#define LC3_RESW(L) ((uint32_t *)((uint8_t *)(L).t + 1024))  // uint32[13] residual bits, bit j of word j / 32 (behind the 512 padded entries of xq)
 
 LC3_LDS_DECL(lc3_enc_lds, lc3_enc_wg)
 static_assert(offsetof(lc3_enc_lds, fa) % 16 == 0 && offsetof(lc3_enc_lds, spec) % 16 == 0 && offsetof(lc3_enc_lds, t) % 16 == 0,
@@ -1222,62 +1222,54 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
 // ------------------------------------------------------------------------------------------
 struct lc3_bitcons { int rate_flag, lastnz, nbits_lsb, lastnz_trunc, nbits_est, nbits_trunc, mode_flag, lsb_mode; float gg; };
 
-// quantize_spectrum :230-263 + compute_bit_consumption :265-348.
-// Quantisation is lane-parallel; the context-adaptive bit estimate walks tuples in order on lane 0.
+// quantize_spectrum :230-263 + compute_bit_consumption :265-348, lane-parallel: lane l owns lines 8l .. 8l+7, i.e. the
+// four tuples 4l .. 4l+3, from the division to the bit estimate (the quantised values go to LDS only for the later stages).
 LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int nbits,
                                                             int gg_off, int gg_ind, int nbits_spec) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const int ne = c.ne;
     const float gg = LC3_POW10_GG(gg_ind + gg_off);  // 10^(((float)gg_ind + (float)gg_off) / 28): the sum of two small integers is exact in f32
-    {   // ne <= 400: seven lines per lane, loaded together, divided as seven independent chains, stored together
-        float x[7];
-#pragma unroll
-        for (int u = 0; u < 7; u++) {
-            const int n = lane + LC3_WAVE * u;
-            x[u] = n < ne ? L.spec[n] : 0.0f;
-        }
-        int16_t q[7];
-#pragma unroll
-        for (int u = 0; u < 7; u++)
-            q[u] = (int16_t)lc3_f2i16(x[u] / gg + (x[u] >= 0.0f ? 0.375f : -0.375f));  // a - 0.375 == a + (-0.375)
-#pragma unroll
-        for (int u = 0; u < 7; u++) {
-            const int n = lane + LC3_WAVE * u;
-            if (n < ne) LC3_XQ(L)[n] = q[u];
-        }
-    }
-    LC3_SYNC();
     const int rate_flag = nbits > (160 + c.fs_ind * 160) ? 512 : 0;
     const int mode_flag = nbits >= (480 + c.fs_ind * 160);
     lc3_bitcons bc;
-    // compute_bit_consumption :265-348, lane-parallel.  Everything here is integer arithmetic, so any evaluation
+    const int ntup_all = ne / 2, k0 = 4 * lane;
+    int q8[8];
+    {   // eight lines per lane (ne <= 400 < 512: lines at and above ne quantise to 0, the tuple scan below relies on it)
+        const lc3_divisor dv = lc3_divisor_make(gg);
+        const lc3_f4 xa = *(const lc3_f4 *)(L.spec + 8 * lane), xb = *(const lc3_f4 *)(L.spec + 8 * lane + 4);  // past spec: fa (selected away)
+        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float xu = 8 * lane + u < ne ? x[u] : 0.0f;
+            q8[u] = lc3_f2i16(lc3_div_by(xu, dv) + (xu >= 0.0f ? 0.375f : -0.375f));  // a - 0.375 == a + (-0.375)
+        }
+        const lc3_i4 w = {(q8[0] & 0xffff) | (int)((uint32_t)q8[1] << 16), (q8[2] & 0xffff) | (int)((uint32_t)q8[3] << 16),
+                          (q8[4] & 0xffff) | (int)((uint32_t)q8[5] << 16), (q8[6] & 0xffff) | (int)((uint32_t)q8[7] << 16)};  // int16 x 8
+        *(lc3_i4 *)(LC3_XQ(L) + 8 * lane) = w;  // int16[512]: the whole padded array
+    }
+    // compute_bit_consumption :265-348.  Everything here is integer arithmetic, so any evaluation
     // order is exact.  The context of tuple k only depends on the (a, b, level) class tt of tuples k-1 and k-2:
     //   c_k = (c_{k-1} & 15) * 16 + tt_{k-1}  ==  16 * tt_{k-2} + tt_{k-1}          (tt <= 15)
-    // so all contexts are known after one pass over the quantised pairs.  Lane l owns tuples 4l .. 4l+3; the running
+    // so all contexts are known after one pass over the quantised pairs.  The running
     // bit estimate a tuple sees is (sum over lower lanes) + (running sum inside the lane).
     {
-        const int ntup_all = ne / 2, k0 = 4 * lane;
-        uint32_t loc[4];   // a | b << 8 | n_esc << 16 | nonzero << 24 for the lane's tuples
-        int tt[4] = {0, 0, 0, 0};  // (a, b, level) class of the lane's tuples: the context of a tuple is 16 * tt(k-2) + tt(k-1)
+        uint32_t loc[4];   // a | b << 8 | n_esc << 16 | flags for the lane's tuples
+        int tt[4];         // (a, b, level) class of the lane's tuples: the context of a tuple is 16 * tt(k-2) + tt(k-1)
         int hi_nz = -1;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = k0 + j;
-            loc[j] = 0;
-            if (k < ntup_all) {
-                const int q0 = LC3_XQ(L)[2 * k], q1 = LC3_XQ(L)[2 * k + 1];
-                const unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
-                const unsigned m = a > b ? a : b;
-                const int n_esc = m >= 4 ? (32 - __builtin_clz(m)) - 2 : 0;
-                const unsigned af = a >> n_esc, bf = b >> n_esc;
-                const int lev = n_esc < 3 ? n_esc : 3;
-                tt[j] = lev <= 1 ? 1 + (int)(af + bf) * (lev + 1) : 12 + lev;
-                const int nz = q0 != 0 || q1 != 0;
-                if (nz) hi_nz = k;
-                loc[j] = af | (bf << 8) | ((uint32_t)n_esc << 16) | ((uint32_t)nz << 24) | ((uint32_t)(a == 1) << 25) |
-                         ((uint32_t)(b == 1) << 26) | ((uint32_t)(a != 0) << 27) | ((uint32_t)(b != 0) << 28);
-            }
+        for (int j = 0; j < 4; j++) {  // tuples at and above ne / 2 are all-zero: class 1, never counted (k < ntup below)
+            const int q0 = q8[2 * j], q1 = q8[2 * j + 1];
+            const unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
+            const unsigned m = a > b ? a : b;
+            const int n_esc = m >= 4 ? (32 - __builtin_clz(m)) - 2 : 0;
+            const unsigned af = a >> n_esc, bf = b >> n_esc;
+            const int lev = n_esc < 3 ? n_esc : 3;
+            tt[j] = lev <= 1 ? 1 + (int)(af + bf) * (lev + 1) : 12 + lev;
+            const int nz = (q0 | q1) != 0;
+            hi_nz = nz ? k0 + j : hi_nz;
+            loc[j] = af | (bf << 8) | ((uint32_t)n_esc << 16) | ((uint32_t)nz << 24) | ((uint32_t)(a == 1) << 25) |
+                     ((uint32_t)(b == 1) << 26) | ((uint32_t)(a != 0) << 27) | ((uint32_t)(b != 0) << 28);
         }
         const int hi_all = lc3_wave_max_i32(hi_nz + 1, lane);  // 1 + index of the last non-zero tuple
         const int lastnz = hi_all < 1 ? 2 : 2 * hi_all;  // `while lastnz > 2 && last pair == 0` (:270-273)
@@ -1285,60 +1277,59 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
         // the two classes before the lane's first tuple come from the lane below (one DPP move each; 0 below lane 0)
         const int p2 = lc3_wave_shr1_i32(tt[2], lane), p3 = lc3_wave_shr1_i32(tt[3], lane);
         uint32_t est4[4], run = 0, lsb_sum = 0;
-        int tctx[4];
-        // main symbols first: four independent lookup -> bits chains per lane, straight-line so that they overlap
+        int tctx[4], esc_max = 0;
+        // main symbols first: four independent lookup -> bits chains per lane, straight-line so that they overlap; the
+        // lookups of tuples at and above ntup are made too (valid indices) and their result dropped
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int k = k0 + j;
-            est4[j] = 0;
-            tctx[j] = 0;
-            if (k < ntup) {
-                const uint32_t v = loc[j];
-                const unsigned af = v & 0xff, bf = (v >> 8) & 0xff;
-                const int n_esc = (int)((v >> 16) & 0xff);
-                const int cctx = 16 * (j == 0 ? p2 : (j == 1 ? p3 : tt[j - 2])) + (j == 0 ? p3 : tt[j - 1]);
-                const int t = cctx + rate_flag + ((2 * k) > ne / 2 ? 256 : 0);
-                tctx[j] = t;
-                const int levf = n_esc < 3 ? n_esc : 3;
-                const int pki = LC3_SPEC_LOOKUP(t + levf * 1024);
-                uint32_t est = LC3_SPEC_BITS(pki, af + 4 * bf);
-                if (v & (1u << 27)) est += 2048;
-                if (v & (1u << 28)) est += 2048;
-                if (n_esc > 0 && mode_flag) lsb_sum += 2 + ((v >> 25) & 1) + ((v >> 26) & 1);
-                est4[j] = est;
+            const int live = k < ntup;
+            const uint32_t v = loc[j];
+            const unsigned af = v & 0xff, bf = (v >> 8) & 0xff;
+            const int n_esc = (int)((v >> 16) & 0xff);
+            const int cctx = 16 * (j == 0 ? p2 : (j == 1 ? p3 : tt[j - 2])) + (j == 0 ? p3 : tt[j - 1]);
+            const int t = cctx + rate_flag + ((2 * k) > ne / 2 ? 256 : 0);
+            tctx[j] = t;
+            const int levf = n_esc < 3 ? n_esc : 3;
+            const int pki = LC3_SPEC_LOOKUP(t + levf * 1024);
+            uint32_t est = LC3_SPEC_BITS(pki, af + 4 * bf);
+            est += ((v >> 27) & 1u) * 2048u + ((v >> 28) & 1u) * 2048u;
+            if (live && n_esc > 0) {
+                if (mode_flag) lsb_sum += 2 + ((v >> 25) & 1) + ((v >> 26) & 1);
+                esc_max = n_esc > esc_max ? n_esc : esc_max;
             }
+            est4[j] = live ? est : 0u;
         }
-        // escape symbols (magnitudes >= 4 only): one per dropped bit plane (integer sums: any order is exact)
+        // escape symbols (magnitudes >= 4 only): one per dropped bit plane, plane i coded with the table of level min(i, 3):
+        //   sum_{i < n_esc} bits(level min(i, 3)) + 2 sign... = planes 0, 1, 2 one by one + (n_esc - 3) times the plane-3 cost
+        // (integer sums: any order is exact).  A plane no tuple of the wave reaches is skipped (wave-uniform).
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int n_esc = (int)((loc[j] >> 16) & 0xff);
-            if (k0 + j < ntup && n_esc > 0) {
-                uint32_t est = 0;
-#pragma clang loop vectorize(disable)
-                for (int i = 0; i < n_esc; i++) {  // one to a few trips: a vectorised form only adds its set-up
-                    const int pki = LC3_SPEC_LOOKUP(tctx[j] + (i < 3 ? i : 3) * 1024);
-                    est += LC3_SPEC_BITS(pki, 16);
-                    if (!(i == 0 && mode_flag)) est += 2 * 2048;
-                }
-                est4[j] += est;
+        for (int i = 0; i < 4; i++) {
+            if (!LC3_WAVE_ANY(esc_max > i)) break;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int n_esc = (int)((loc[j] >> 16) & 0xff);
+                const int pki = LC3_SPEC_LOOKUP(tctx[j] + i * 1024);
+                uint32_t e = LC3_SPEC_BITS(pki, 16) + ((i == 0 && mode_flag) ? 0u : 2u * 2048u);
+                if (i == 3) e *= (uint32_t)(n_esc > 3 ? n_esc - 3 : 0);
+                est4[j] += (k0 + j < ntup && n_esc > i) ? e : 0u;
             }
-            run += est4[j];
         }
+#pragma unroll
+        for (int j = 0; j < 4; j++) run += est4[j];
         const uint32_t base = lc3_wave_exscan_u32(run, lane);
-        const uint32_t est_total = lc3_wave_sum_u32(run, lane), lsb_total = lc3_wave_sum_u32(lsb_sum, lane);
-        // lastnz_trunc / nbits_trunc: the last non-zero tuple whose running estimate still fits nbits_spec (:327-330)
+        const uint32_t est_total = (uint32_t)lc3_wave_read_i32((int)(base + run), LC3_WAVE - 1, lane);
+        const uint32_t lsb_total = lc3_wave_sum_u32(lsb_sum, lane);
+        // lastnz_trunc / nbits_trunc: the last non-zero tuple whose running estimate still fits nbits_spec (:327-330; the
+        // reference rounds the estimate to f32 before the division, which matters above 2^24)
         int cand_k = -1;
         uint32_t cand_est = 0, acc = base;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int k = k0 + j;
-            if (k < ntup) {
-                acc += est4[j];
-                if ((loc[j] & (1u << 24)) && (int)lc3_ceilf((float)acc / 2048.0f) <= nbits_spec) {
-                    cand_k = k;
-                    cand_est = acc;
-                }
-            }
+            acc += est4[j];
+            const int ok = k0 + j < ntup && (loc[j] & (1u << 24)) && (int)lc3_ceilf((float)acc / 2048.0f) <= nbits_spec;
+            cand_k = ok ? k0 + j : cand_k;
+            cand_est = ok ? acc : cand_est;
         }
         // the owner of the highest qualifying tuple (lane best_k / 4) holds its running estimate; every quantity below is
         // wave-uniform already (reductions end in scalar registers), so nothing goes through LDS
@@ -1350,6 +1341,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
         bc.nbits_trunc = (int)lc3_ceilf((float)best_est / 2048.0f);
         bc.nbits_lsb = (int)lsb_total;
     }
+    (void)ntup_all;
     bc.rate_flag = rate_flag;
     bc.mode_flag = mode_flag;
     LC3_SYNC();
@@ -1411,103 +1403,57 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
     LC3_STAMP(L, lane, 9);
     // global_gain_estimation :174-209 -- 8-step bisection on gg_ind.  Per step the reference walks the group energies
     // from the top: a group below the gain adds a constant only once a group at/above the gain has been seen
-    // ("is_zero"), the others add a linear term; tmp is a sequential f32 sum of ~100 terms, so a step is a chain of ~100
-    // dependent additions that every lane would execute redundantly.  Instead, three levels of the bisection are
-    // evaluated per round: the 1 + 2 + 4 gains the next three steps can possibly visit are known in advance, lane c
-    // sums the terms of candidate c (each sum in the reference's order), and the three decisions are then read off.
-    // Rounds of 3, 3 and 2 levels replace 8 dependent chains by 3.
+    // ("is_zero"), the others add a linear term; tmp is a sequential f32 sum of ~100 terms and the ONLY use of tmp is
+    // the comparison `tmp > thr`.  Every term is >= 0 (3.78, 0, >= 9.8, > 70), so the sequential f32 sum of n <= 100
+    // terms lies within (n - 1) * 2^-24 < 6e-6 (relative) of the exact sum, and so does a tree sum over the wave: when
+    // the tree sum is further than LC3_BISECT_GUARD (1e-4, relative) from the threshold the comparison is decided without
+    // the chain of dependent additions; otherwise (about one step in 10^4) the step repeats the sum in the reference's
+    // order.  LC3_SPEC_TEST_SEQ_SUMS forces that path (tests).
     int gg_min = 0, reset_offset = 0, gg_ind_u = 0;
     {
         int fac = 256, gg_ind = 255;
-        float *tvb = (float *)L.fa;  // 7 candidate term arrays of LC3_TVB floats (840 of the 960 floats of fa/fb)
-#define LC3_TVB 120
-        const int ne4p = ((ne4 + 19) / 20) * 20;  // <= 100; the sum loop reads one 20-float chunk beyond it
+        float *tv = (float *)L.fa;  // the terms of one step in the reference's order (sequential path only)
         const float thr = (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f;
-        for (int level = 0; level < 8;) {
-            const int depth = 8 - level >= 3 ? 3 : 8 - level, nc = (1 << depth) - 1;
-            const int f1 = fac >> 1, f2 = fac >> 2, f3 = fac >> 3;
-            // candidate c: the gain visited at depth d after the decisions encoded in its index (see the walk below)
-            int cand[7];
-            cand[0] = gg_ind - f1;
-            cand[1] = gg_ind - f1 - f2;
-            cand[2] = gg_ind - f2;
-            cand[3] = gg_ind - f1 - f2 - f3;
-            cand[4] = gg_ind - f1 - f3;
-            cand[5] = gg_ind - f2 - f3;
-            cand[6] = gg_ind - f3;
-            int hi[7];
+        const int seq_always = (L.spec_flags & LC3_SPEC_TEST_SEQ_SUMS) != 0;
+        for (int level = 0; level < 8; level++) {
+            fac >>= 1;
+            gg_ind -= fac;
+            const float g = (float)gg_ind + (float)gg_off;
+            // highest group at/above the gain: two ballots (groups 0..63, 64..127)
+            const unsigned long long m0 = lc3_wave_ballot(lane < ne4 && !(e14[0] < g), lane);
+            const unsigned long long m1 = lc3_wave_ballot(lane + LC3_WAVE < ne4 && !(e14[1] < g), lane);
+            const int h = m1 ? 64 + (63 - __builtin_clzll(m1)) : (m0 ? 63 - __builtin_clzll(m0) : -1);
+            float term[2];
 #pragma unroll
-            for (int cidx = 0; cidx < 7; cidx++) {
-                hi[cidx] = -1;
-                if (cidx < nc) {
-                    const float g = (float)cand[cidx] + (float)gg_off;
-                    // highest group at/above the gain: two ballots (groups 0..63, 64..127)
-                    const unsigned long long m0 = lc3_wave_ballot(lane < ne4 && !(e14[0] < g), lane);
-                    const unsigned long long m1 = lc3_wave_ballot(lane + LC3_WAVE < ne4 && !(e14[1] < g), lane);
-                    const int h = m1 ? 64 + (63 - __builtin_clzll(m1)) : (m0 ? 63 - __builtin_clzll(m0) : -1);
-                    hi[cidx] = h;
-                    float *tv_c = tvb + cidx * LC3_TVB;
-                    // terms in the reference's order (groups from the top down) at tv_c[ne4 - 1 - n], zero padded to a
-                    // multiple of twenty (adding +0 at the end of the sum does not change it)
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const int n = lane + LC3_WAVE * q;
-                        if (n < ne4) {
-                            float tv;
-                            if (e14[q] < g) tv = n < h ? 2.7f * 28.0f / 20.0f : 0.0f;
-                            else if (g < (e14[q] - 43.0f * 28.0f / 20.0f)) tv = e28[q] - 2.0f * g - 36.0f * 28.0f / 20.0f;
-                            else tv = e14[q] - g + 7.0f * 28.0f / 20.0f;
-                            tv_c[ne4 - 1 - n] = tv;
-                        } else if (n < ne4p) tv_c[n] = 0.0f;
-                    }
-                }
+            for (int q = 0; q < 2; q++) {
+                const int n = lane + LC3_WAVE * q;
+                float t;
+                if (e14[q] < g) t = n < h ? 2.7f * 28.0f / 20.0f : 0.0f;
+                else if (g < (e14[q] - 43.0f * 28.0f / 20.0f)) t = e28[q] - 2.0f * g - 36.0f * 28.0f / 20.0f;
+                else t = e14[q] - g + 7.0f * 28.0f / 20.0f;
+                term[q] = n < ne4 ? t : 0.0f;
             }
-            LC3_SYNC();
-            // lane c < nc: tmp = sequential f32 sum of candidate c's terms (the other lanes shadow candidate 0); the
-            // terms are fetched 20 at a time, one chunk ahead of the additions.  Every term is >= 0 (3.78, 0, >= 9.8,
-            // > 70), so a running sum never decreases: a lane is decided once it exceeds the threshold, and the walk
-            // stops when every candidate is decided.
-            float tmp = 0.0f;
-            {
-                const lc3_f4 *tv4 = (const lc3_f4 *)(tvb + (lane < nc ? lane : 0) * LC3_TVB);
-                lc3_f4 cur[5], nxt[5];
-#pragma unroll
-                for (int u = 0; u < 5; u++) cur[u] = tv4[u];
-                for (int i = 0; i < ne4p && lc3_wave_ballot(lane < nc && !(tmp > thr), lane) != 0ull; i += 20) {
-#pragma unroll
-                    for (int u = 0; u < 5; u++) nxt[u] = tv4[i / 4 + 5 + u];  // one chunk past the end is scratch space
-#pragma unroll
-                    for (int u = 0; u < 5; u++) {
-                        tmp += cur[u].x;
-                        tmp += cur[u].y;
-                        tmp += cur[u].z;
-                        tmp += cur[u].w;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 5; u++) cur[u] = nxt[u];
-                }
+            const float tsum = lc3_wave_sum_f32_any(term[0] + term[1], lane);
+            int over = -1;
+            if (!seq_always) {
+                if (tsum * (1.0f - LC3_BISECT_GUARD) > thr) over = 1;
+                else if (tsum * (1.0f + LC3_BISECT_GUARD) <= thr) over = 0;
             }
-            const unsigned long long over = lc3_wave_ballot(tmp > thr, lane);  // bit c: candidate c's sum exceeds thr
-            LC3_SYNC();
-            // the walk: `fac >>= 1; gg_ind -= fac; if tmp > thr && hi >= 0 { gg_ind += fac }` per level; the candidate
-            // visited at depth 2 is 1 + P1, at depth 3 it is 3 + 2 P1 + P2
-            int idx = 0, path = 0;
+            if (over < 0 || LC3_GUARD_SELFCHECK) {  // too close to call from a reordered sum: groups from the top down, one sequential f32 sum
 #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                if (d < depth) {
-                    int h = 0;
-#pragma unroll
-                    for (int cidx = 0; cidx < 7; cidx++) h = cidx == idx ? hi[cidx] : h;
-                    const int P = (int)((over >> idx) & 1ull) && h >= 0;
-                    fac >>= 1;
-                    gg_ind -= P ? 0 : fac;
-                    path = 2 * path + P;
-                    idx = (2 << d) - 1 + path;
+                for (int q = 0; q < 2; q++) {
+                    const int n = lane + LC3_WAVE * q;
+                    if (n < ne4) tv[ne4 - 1 - n] = term[q];
                 }
+                LC3_SYNC();
+                const float tmp = lc3_sum_seq(tv, ne4, 0.0f);  // every lane the same sum (broadcast reads)
+                LC3_GUARD_ASSERT(over < 0 || over == (int)(tmp > thr));
+                over = tmp > thr;
+                LC3_SYNC();
             }
-            level += depth;
+            // `fac >>= 1; gg_ind -= fac; if tmp > thr && hi >= 0 { gg_ind += fac }`
+            if (over && h >= 0) gg_ind += fac;
         }
-#undef LC3_TVB
         // global_gain_limitation :212-228 (every input is wave-uniform: the same scalar code on every lane)
         gg_min = 0;
         if (x_f_max > 0.0f) gg_min = lc3_f2i16(lc3_ceilf(28.0f * lc3_log10f(x_f_max / (32768.0f - 0.375f)))) - gg_off;
@@ -1610,9 +1556,10 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_residual_noise(LC3_CFG_PARA
     }
     if (lane < 13) LC3_RESW(L)[lane] = 0u;
     const uint32_t cnt_nz = (uint32_t)__builtin_popcount(nzmask), cnt_rel = (uint32_t)__builtin_popcount(relmask);
-    int rank_nz = (int)lc3_wave_exscan_u32(cnt_nz, lane), rank_rel = (int)lc3_wave_exscan_u32(cnt_rel, lane);
+    int rank_nz = (int)lc3_wave_exscan_u32(cnt_nz, lane);
     const int tot_nz = (int)lc3_wave_sum_u32(cnt_nz, lane), tot_rel = (int)lc3_wave_sum_u32(cnt_rel, lane);
     LC3_SYNC();  // the zeroed words before the bits
+    float part = 0.0f;  // the lane's share of the noise-level sum (tree order: see below)
 #pragma unroll
     for (int j = 0; j < 7; j++) {
         const int k = k0 + j;
@@ -1622,20 +1569,50 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_residual_noise(LC3_CFG_PARA
                     __atomic_fetch_or(&LC3_RESW(L)[rank_nz >> 5], 1u << (rank_nz & 31), __ATOMIC_RELAXED);
                 rank_nz++;
             }
-            if (relmask & (1u << j)) compact[rank_rel++] = lc3_absf(sv[j]) / q.gg;
+            if (relmask & (1u << j)) part += lc3_absf(sv[j]) / q.gg;
         }
     }
-    LC3_SYNC();
-    float sum0 = 0.0f;
-    if (lane == 0) sum0 = lc3_sum_seq(compact, tot_rel, 0.0f);
-    const float sum = lc3_wave_bcast0_f32(sum0, lane);
-    const float level = tot_rel > 0 ? sum / (float)tot_rel : 0.0f;
-    const float diff = 8.0f - 16.0f * level;
-    int nfac = 0;
-    if (diff >= 0.0f) {
-        const int v = lc3_f2i32(diff + 0.5f);
-        nfac = v < 7 ? v : 7;
+    // noise level :44-55: nfac = min(7, trunc(8 - 16 * mean + 0.5)) only depends on which side of the boundaries
+    // 1, 2 .. 7 the value v = 8.5 - 16 * mean falls.  The terms |x| / gg are >= 0, so the reference's sequential f32 sum
+    // of n <= 376 terms is within 375 * 2^-24 (relative) of the exact sum, a tree sum within 16 * 2^-24: the two means
+    // differ by < 2.4e-5 * mean, the two v by < 3.9e-4 * mean + a few ulps of 8.5.  Further than `tol` from a boundary
+    // the tree sum decides; otherwise the sum is repeated in the reference's order.
+    int nfac = 0, decided = 0;
+    {
+        const float tsum = lc3_wave_sum_f32_any(part, lane);
+        const float mean = tot_rel > 0 ? tsum / (float)tot_rel : 0.0f;
+        const float v = 8.5f - 16.0f * mean, tol = 1.0e-5f + 6.0e-4f * mean;
+        if (!(L.spec_flags & LC3_SPEC_TEST_SEQ_SUMS)) {
+            if (v < 1.0f) decided = (1.0f - v) > tol;  // includes every mean > 0.47 and NaN-free large sums
+            else if (v >= 8.0f) decided = 1;
+            else {
+                const float fl = lc3_floorf(v), d_lo = v - fl, d_hi = 1.0f - d_lo;
+                decided = d_lo > tol && (fl >= 7.0f || d_hi > tol);
+                nfac = lc3_f2i32(fl);
+            }
+            if (v >= 8.0f) nfac = 7;
+        }
     }
+    const int nfac_tree = nfac;
+    if (!decided || LC3_GUARD_SELFCHECK) {  // wave-uniform
+        int rank_rel = (int)lc3_wave_exscan_u32(cnt_rel, lane);
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            if (k0 + j < ne && (relmask & (1u << j))) compact[rank_rel++] = lc3_absf(sv[j]) / q.gg;
+        LC3_SYNC();
+        float sum0 = 0.0f;
+        if (lane == 0) sum0 = lc3_sum_seq(compact, tot_rel, 0.0f);
+        const float sum = lc3_wave_bcast0_f32(sum0, lane);
+        const float level = tot_rel > 0 ? sum / (float)tot_rel : 0.0f;
+        const float diff = 8.0f - 16.0f * level;
+        nfac = 0;
+        if (diff >= 0.0f) {
+            const int v = lc3_f2i32(diff + 0.5f);
+            nfac = v < 7 ? v : 7;
+        }
+        LC3_GUARD_ASSERT(!decided || nfac == nfac_tree);
+    }
+    (void)nfac_tree;
     LC3_SYNC();
     return (nfac << 16) | (tot_nz < mx ? tot_nz : mx);
 }

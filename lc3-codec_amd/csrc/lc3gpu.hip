@@ -94,6 +94,28 @@ __device__ float lc3_tns_sin_tab[17];
 #define LC3_TNS_SIN_ENC(ri) ((unsigned)(ri) < 17u ? lc3_tns_sin_tab[(ri)] : lc3_tns_sin_enc_value(ri))
 // (the decoder's lane-per-frame parser evaluates the routine: a per-lane table fetch from memory costs it more than the arithmetic)
 #define LC3_TNS_SIN_DEC(ri) lc3_tns_sin_dec_value(ri)
+// x / d for many x and one d: the compiler's f32 division is v_div_scale x2, v_rcp, two Newton steps on the reciprocal,
+// q = n * r, two residual corrections, v_div_fmas, v_div_fixup; scale and fix-up only act on zero / infinite / NaN operands,
+// a denominator outside 2^+-126, an exponent difference of 96 or more, and numerators below 2^-103 or quotients below 2^-126.
+// With d a finite normal number (the global gain, 1.8e-9 .. 1.5e5) and |x| < 2^60 none of them changes a quotient of at
+// least 2^-100, and the callers (quantiser: trunc(q + 0.375)) do not distinguish smaller ones; what is left is this sequence
+// with the reciprocal refined once per d.
+#define LC3_UNIFORM_DIV 1
+struct lc3_divisor { float d, r; };
+__device__ __forceinline__ lc3_divisor lc3_divisor_make(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    lc3_divisor v = {d, r};
+    return v;
+}
+__device__ __forceinline__ float lc3_div_by(float x, const lc3_divisor &v) {
+    float q = x * v.r;
+    float e = __builtin_fmaf(-v.d, q, x);
+    q = __builtin_fmaf(e, v.r, q);
+    e = __builtin_fmaf(-v.d, q, x);
+    return __builtin_fmaf(e, v.r, q);
+}
 #include "lc3_dev_common.h"
 // ---- configuration slots ----------------------------------------------------------------------------------------
 // Every (sampling rate, frame duration) pair owns one slot of a __constant__ table; handles register their
@@ -188,6 +210,20 @@ __device__ __forceinline__ uint32_t lc3_wave_sum_u32(uint32_t u, int lane) {
     v += LC3_DPP(v, v, LC3_DPP_ROW_MIRROR, 0xf, false);
     return (uint32_t)__builtin_amdgcn_readlane(v, 0) + (uint32_t)__builtin_amdgcn_readlane(v, 16) +
            (uint32_t)__builtin_amdgcn_readlane(v, 32) + (uint32_t)__builtin_amdgcn_readlane(v, 48);
+}
+// f32 sum over the wave in an UNSPECIFIED order (a tree): only for decisions that are guarded against the rounding
+// difference to the reference's sequential sum (see lc3_enc_quant)
+__device__ __forceinline__ float lc3_wave_sum_f32_any(float v, int lane) {
+    (void)lane;
+    int w;
+    w = LC3_DPP(0, __builtin_bit_cast(int, v), LC3_DPP_QUAD_1032, 0xf, false); v += __builtin_bit_cast(float, w);
+    w = LC3_DPP(0, __builtin_bit_cast(int, v), LC3_DPP_QUAD_2301, 0xf, false); v += __builtin_bit_cast(float, w);
+    w = LC3_DPP(0, __builtin_bit_cast(int, v), LC3_DPP_ROW_HALF_MIRROR, 0xf, false); v += __builtin_bit_cast(float, w);
+    w = LC3_DPP(0, __builtin_bit_cast(int, v), LC3_DPP_ROW_MIRROR, 0xf, false); v += __builtin_bit_cast(float, w);
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 // bit l of the result = lane l's predicate (wave-uniform)
 // the value lane - 1 holds (lane 0: unspecified); one DPP move across the whole wave
@@ -1254,6 +1290,12 @@ int lc3gpu_encoder_create(lc3gpu_encoder **out, int num_channels, int frame_us, 
     return lc3gpu_encoder_create_spec(out, num_channels, frame_us, fs_hz, 0);
 }
 
+// test hooks read from the environment when a handle is created (LC3GPU_GENERIC, LC3GPU_SEQ_SUMS)
+static bool lc3_env_flag(const char *name) {
+    const char *v = std::getenv(name);
+    return v != nullptr && std::atoi(v) != 0;
+}
+
 int lc3gpu_encoder_create_spec(lc3gpu_encoder **out, int num_channels, int frame_us, int fs_hz, int spec_flags) {
     if (!out || num_channels <= 0 || (spec_flags & ~LC3GPU_SPEC_ALL)) return LC3GPU_EINVAL;
     *out = nullptr;
@@ -1266,7 +1308,7 @@ int lc3gpu_encoder_create_spec(lc3gpu_encoder **out, int num_channels, int frame
     lc3gpu_encoder *e = new (std::nothrow) lc3gpu_encoder();
     if (!e) return LC3GPU_EINVAL;
     e->num_channels = num_channels;
-    e->spec_flags = spec_flags;
+    e->spec_flags = spec_flags | (lc3_env_flag("LC3GPU_SEQ_SUMS") ? LC3_SPEC_TEST_SEQ_SUMS : 0);
     rc = cfg_acquire(e->h, frame_us, fs_hz);
     if (rc == LC3GPU_OK) rc = encoder_alloc(e);
     if (rc) { lc3gpu_encoder_destroy(e); return rc; }
@@ -1284,7 +1326,7 @@ int lc3gpu_encoder_create_mixed_spec(lc3gpu_encoder **out, int n_streams, const 
     if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
     lc3gpu_encoder *e = new (std::nothrow) lc3gpu_encoder();
     if (!e) return LC3GPU_EINVAL;
-    e->spec_flags = spec_flags;
+    e->spec_flags = spec_flags | (lc3_env_flag("LC3GPU_SEQ_SUMS") ? LC3_SPEC_TEST_SEQ_SUMS : 0);
     int rc = build_mixed(*e, n_streams, descs, !(spec_flags & LC3GPU_SPEC_8KHZ_ENCODE), 20);
     if (rc == LC3GPU_OK) rc = encoder_alloc(e);
     if (rc) { lc3gpu_encoder_destroy(e); return rc; }

@@ -6,6 +6,8 @@
 // placement, LDS aliasing) can be checked against the oracle in this GPU-less container before
 // GPU minutes are spent; it is never shipped or timed.  Build: tests/emu_lib.py.
 #include <pthread.h>
+#include <cstdio>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -36,6 +38,15 @@ static thread_local int tl_wave = 0;
         }                                \
         pthread_barrier_wait(&g_wg_bar); \
     }
+// every decision the device code takes from a guarded tree sum is checked against the sequential sum here
+#define LC3_GUARD_SELFCHECK 1
+#define LC3_GUARD_ASSERT(cond)                                                                         \
+    do {                                                                                               \
+        if (!(cond)) {                                                                                 \
+            fprintf(stderr, "lc3_emu: guarded decision differs from the sequential sum (%s:%d)\n", __FILE__, __LINE__); \
+            abort();                                                                                   \
+        }                                                                                              \
+    } while (0)
 #include "../../lc3-codec_amd/csrc/lc3_dev_common.h"
 // wave-level primitives: the GPU uses DPP / v_readlane; the emulator exchanges through memory
 static int g_xi[LC3_WG_WAVES][64];
@@ -58,6 +69,15 @@ static inline uint32_t lc3_wave_sum_u32(uint32_t v, int lane) {
     return m;
 }
 static float g_xf[LC3_WG_WAVES][64];
+static inline float lc3_wave_sum_f32_any(float v, int lane) {  // order unspecified on the GPU; here: a different tree on purpose
+    LC3_SYNC();
+    g_xf[tl_wave][lane] = v;
+    LC3_SYNC();
+    float m = 0.0f;
+    for (int i = 63; i >= 0; i--) m += g_xf[tl_wave][i];
+    LC3_SYNC();
+    return m;
+}
 static inline float lc3_wave_shr1_f32(float v, int lane) {
     LC3_SYNC();
     g_xf[tl_wave][lane] = v;

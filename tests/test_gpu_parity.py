@@ -607,6 +607,31 @@ def test_runtime_configuration_view_of_the_headline_configuration():
     assert r.returncode == 0 and "generic ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_sequential_sum_path_of_guarded_decisions():
+    """The gain bisection and the noise level only need the SIDE of a threshold their f32 sums fall on: the kernels decide from a
+    tree sum when that is further from the threshold than the rounding of the reference's sequential sum can reach and repeat
+    the sum in the reference's order otherwise (about one decision in 10^4).  LC3GPU_SEQ_SUMS=1 sends every decision down the
+    sequential path; both must give the oracle's bytes (the default path is what every other test runs)."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, 'tests')\n"
+        "import test_gpu_parity as t\n"
+        "for nb in (150, 40, 300):\n"
+        "    t._roundtrip_check(48000, 10000, nb, 96, 6, seed=71)\n"
+        "for fs, us, nb in ((48000, 7500, 113), (24000, 10000, 60), (16000, 7500, 30)):\n"
+        "    t._roundtrip_check(fs, us, nb, 64, 6, seed=72)\n"
+        "t.test_mixed_configuration_batch()\n"
+        "print('seq ok')\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LC3GPU_SEQ_SUMS="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "seq ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ---------------------------------------------------------------- SURVEY section 8 row f3: spec-conformant switches
 def _gpu_encode_spec(pcm, nbytes, fs, us, flags):
     torch = torch_mod()
