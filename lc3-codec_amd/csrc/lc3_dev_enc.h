@@ -544,6 +544,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
     LC3_STAMP(L, lane, 28);
     // Levinson-Durbin :204-232 and the LPC -> reflection conversion :234-265: one lane per filter, the order-8
     // recursions fully unrolled on register arrays.
+    int tns_on = 0;  // lanes 0 / 1: the filter's prediction gain passes :219
     if (lane < 2 && lane < tp.num) {
         const int f = lane;
         float r[9];
@@ -575,6 +576,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
         }
         const float pred_gain = e == 0.0f ? r[0] : r[0] / e;
         if (pred_gain > 1.5f && !near_nyquist) {
+            tns_on = 1;
             float gamma = 1.0f;
             if (res.lpc_weighting > 0 && pred_gain < 2.0f)
                 gamma -= (1.0f - 0.85f) * (2.0f - pred_gain) / (2.0f - 1.5f);
@@ -600,6 +602,20 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
     // apply_quantization :267-292 -- one lane per coefficient; the orders (:275-291: the last index that is not 8, per filter) and
     // the bit budget (calc_bit_budget :294-311: integer sums, any order is exact) are read off the same 16 lanes by ballot and
     // wave sums instead of a walk on lane 0 with one table fetch per coefficient
+    if (lc3_wave_ballot(tns_on, lane) == 0ull) {
+        // no filter of the frame is active (nine frames in ten): every coefficient is 0.0 -> index 8, order 0, and each
+        // filter costs ceil(2048 / 2048) = 1 bit (:294-311)
+        if (lane < 16) {
+            rc_i[lane] = 8;
+            rc_q[lane] = 0.0f;
+        }
+        res.rc_order[0] = 0;
+        res.rc_order[1] = 0;
+        res.nbits_tns = tp.num;
+        LC3_SYNC();
+        LC3_STAMP(L, lane, 30);
+        return res;
+    }
     int ri_lane = 8;
     if (lane < 16) {
         const float step = (float)3.14159265358979323846 / 17.0f;  // PI as f32 / 17.0 :268
@@ -1378,27 +1394,21 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
     }
     // compute_spectral_energy :390-395 -- one lane per 4-line group (two groups per lane, kept in registers together
     // with the two products of the energy that the gain search needs)
-    float e14[2], e28[2];
+    float e14[2], e28[2], amax = 0.0f;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int n = lane + LC3_WAVE * q;
-        float ei = 0.0f;
-        if (n < ne4) {
-            const lc3_f4 x = *(const lc3_f4 *)(L.spec + 4 * n);
-            const float total = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
-            ei = 10.0f * lc3_log10f(1.1920929e-7f + total);
-        }
+        const lc3_f4 x = *(const lc3_f4 *)(L.spec + 4 * (n < ne4 ? n : 0));
+        const float total = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        const float ei = n < ne4 ? 10.0f * lc3_log10f(1.1920929e-7f + total) : 0.0f;
+        const float m = lc3_maxf(lc3_maxf(lc3_absf(x.x), lc3_absf(x.y)), lc3_maxf(lc3_absf(x.z), lc3_absf(x.w)));
+        amax = lc3_maxf(amax, m);  // (a lane past the last group repeats group 0)
         e14[q] = ei * 28.0f / 20.0f;
         e28[q] = 2.0f * ei * 28.0f / 20.0f;
     }
     // global_gain_limitation's max |x| :214-217 (the maximum is order-independent; non-negative floats order like
     // their bit patterns, so the wave maximum is an integer reduction)
-    float x_f_max;
-    {
-        float m = 0.0f;
-        for (int n = lane; n < ne; n += LC3_WAVE) m = lc3_maxf(m, lc3_absf(L.spec[n]));
-        x_f_max = lc3_from_bits((uint32_t)lc3_wave_max_i32((int)lc3_bits(m), lane));
-    }
+    const float x_f_max = lc3_from_bits((uint32_t)lc3_wave_max_i32((int)lc3_bits(amax), lane));
     LC3_SYNC();
     LC3_STAMP(L, lane, 9);
     // global_gain_estimation :174-209 -- 8-step bisection on gg_ind.  Per step the reference walks the group energies
@@ -1517,60 +1527,76 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_residual_noise(LC3_CFG_PARA
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     // Both loops of the reference walk the spectrum in order and act on a SUBSET of the lines (non-zero lines for
     // the residual bits, lines with an all-zero neighbourhood for the noise level); the position of a line inside
-    // its subset is a prefix count.  Lane l owns lines 7l .. 7l+6: it counts, the counts are prefix-summed, and
-    //  - residual bit j (j < nbits_residual_max) is written by the owner of the j-th non-zero line,
-    //  - the noise contributions |x|/gg are compacted in order so that lane 0 can add them up sequentially
-    //    (the f32 sum keeps the reference's order).
+    // its subset is a prefix count.  Lane l owns lines 8l .. 8l+7 (one 16-byte unit of quantised values, two of spectrum);
+    // membership is kept as 8-bit masks, the neighbours' bits come over from the adjacent lanes:
+    //  - residual bit j (j < nbits_residual_max) is set by the owner of the j-th non-zero line,
+    //  - the noise contributions |x| / gg are added up per lane and over the wave (see below).
     const int ne = c.ne;
-    float *compact = (float *)L.fa;          // relevant |x| / gg values, in line order (<= 376)
+    float *compact = (float *)L.fa;          // relevant |x| / gg values, in line order (<= 376; sequential path only)
     const int bw_stop = c.n_ms_10 ? LC3C_BWSTOP10[bw_ind] : LC3C_BWSTOP75[bw_ind];
     const int nf_start = c.n_ms_10 ? 24 : 18, nf_width = c.n_ms_10 ? 3 : 2;
     const int nf_stop = ne < bw_stop ? ne : bw_stop;
     int mx = q.nbits_spec - q.nbits_trunc + 4;  // nbits_residual_max (encoder/residual_spectrum.rs:42-43)
     if (mx < 0) mx = 0;
-    const int k0 = 7 * lane;
-    // the lane's seven lines and three neighbours on either side: thirteen quantised values and spectrum lines fetched
-    // once; bit i of nz13 <-> line k0 - 3 + i is non-zero (lines outside [0, bw_stop) count as zero: the reference's
-    // window is clipped at bw_stop and never reaches below line 0)
-    int16_t xv[13];
-    float sv[7];
-    uint32_t nz13 = 0;
+    const int k0 = 8 * lane;
+    int xv[8];
+    float sv[8];
+    {
+        const lc3_i4 w = *(const lc3_i4 *)(LC3_XQ(L) + k0);  // zero from ne on (lc3_quantize_spectrum)
+        const lc3_f4 sa = *(const lc3_f4 *)(L.spec + k0), sb = *(const lc3_f4 *)(L.spec + k0 + 4);  // past ne: never selected
+        int wi[4];
+        __builtin_memcpy(wi, &w, 16);
 #pragma unroll
-    for (int i = 0; i < 13; i++) {
-        const int k = k0 - 3 + i;
-        xv[i] = (k >= 0 && k < ne) ? LC3_XQ(L)[k] : (int16_t)0;
-        if (xv[i] != 0 && k < bw_stop) nz13 |= 1u << i;
-    }
-#pragma unroll
-    for (int j = 0; j < 7; j++) sv[j] = k0 + j < ne ? L.spec[k0 + j] : 0.0f;
-    uint32_t nzmask = 0, relmask = 0;
-    const uint32_t win = nf_width == 3 ? 0x7Fu : 0x3Eu;  // lines k-3..k+3 or k-2..k+2 relative to bit j
-#pragma unroll
-    for (int j = 0; j < 7; j++) {
-        const int k = k0 + j;
-        if (k < ne) {
-            if (xv[j + 3] != 0) nzmask |= 1u << j;
-            // encoder/noise_level_estimation.rs:35-42: x_q[k - w .. min(bw_stop, k + w + 1)) all zero
-            if (k >= nf_start && k < nf_stop && ((nz13 >> j) & win) == 0) relmask |= 1u << j;
+        for (int i = 0; i < 4; i++) {
+            xv[2 * i] = (int)(int16_t)(wi[i] & 0xffff);
+            xv[2 * i + 1] = wi[i] >> 16;
         }
+        sv[0] = sa.x; sv[1] = sa.y; sv[2] = sa.z; sv[3] = sa.w; sv[4] = sb.x; sv[5] = sb.y; sv[6] = sb.z; sv[7] = sb.w;
     }
+    // bit j of a mask <-> line k0 + j.  lc3_bits_below(n) = the low clamp(n, 0, 8) bits
+#define LC3_BITS_BELOW(n) ((n) <= 0 ? 0u : ((n) >= 8 ? 0xffu : (1u << (n)) - 1u))
+    uint32_t nzmask = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) nzmask |= (uint32_t)(xv[j] != 0) << j;
+    // the noise window only sees lines below bw_stop (the reference clips it there) and none below line 0
+    const uint32_t nzw = nzmask & LC3_BITS_BELOW(bw_stop - k0);
+    const uint32_t prev = (uint32_t)lc3_wave_shr1_i32((int)nzw, lane), next = (uint32_t)lc3_wave_shl1_i32((int)nzw, lane);
+    const uint32_t nz14 = (prev >> 5) | (nzw << 3) | ((next & 7u) << 11);  // bit i <-> line k0 - 3 + i
+    // encoder/noise_level_estimation.rs:35-42: x_q[k - w .. min(bw_stop, k + w + 1)) all zero, k in [nf_start, nf_stop)
+    uint32_t any;
+    if (nf_width == 3) {  // bits j .. j+6
+        const uint32_t a = nz14 | (nz14 >> 1), b = a | (a >> 2);
+        any = b | (b >> 3);
+    } else {              // bits j+1 .. j+5
+        const uint32_t n1 = nz14 >> 1, a = n1 | (n1 >> 1), b = a | (a >> 2);
+        any = b | (n1 >> 4);
+    }
+    const uint32_t relmask = ~any & LC3_BITS_BELOW(nf_stop - k0) & ~LC3_BITS_BELOW(nf_start - k0) & 0xffu;
+#undef LC3_BITS_BELOW
     if (lane < 13) LC3_RESW(L)[lane] = 0u;
     const uint32_t cnt_nz = (uint32_t)__builtin_popcount(nzmask), cnt_rel = (uint32_t)__builtin_popcount(relmask);
-    int rank_nz = (int)lc3_wave_exscan_u32(cnt_nz, lane);
+    const int rank0 = (int)lc3_wave_exscan_u32(cnt_nz, lane);
     const int tot_nz = (int)lc3_wave_sum_u32(cnt_nz, lane), tot_rel = (int)lc3_wave_sum_u32(cnt_rel, lane);
     LC3_SYNC();  // the zeroed words before the bits
     float part = 0.0f;  // the lane's share of the noise-level sum (tree order: see below)
+    {
+        const lc3_divisor dv = lc3_divisor_make(q.gg);  // (quotients below 2^-100 may differ in their last bit: they cannot move a mean)
+        uint32_t local = 0;  // the lane's residual bits: bit p <-> its p-th non-zero line
+        int p = 0;
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-        const int k = k0 + j;
-        if (k < ne) {
-            if (nzmask & (1u << j)) {
-                if (rank_nz < mx && sv[j] >= (float)xv[j + 3] * q.gg)  // :50-55; the bits of the 13-word mask are set in place (LDS atomic or)
-                    __atomic_fetch_or(&LC3_RESW(L)[rank_nz >> 5], 1u << (rank_nz & 31), __ATOMIC_RELAXED);
-                rank_nz++;
-            }
-            if (relmask & (1u << j)) part += lc3_absf(sv[j]) / q.gg;
+        for (int j = 0; j < 8; j++) {
+            const int nz = (int)((nzmask >> j) & 1u);
+            const int bit = nz && rank0 + p < mx && sv[j] >= (float)xv[j] * q.gg;  // :50-55
+            local |= (uint32_t)bit << p;
+            p += nz;
+            const float term = lc3_div_by(lc3_absf(sv[j]), dv);
+            part += ((relmask >> j) & 1u) ? term : 0.0f;
         }
+        // into the 13-word mask in place (LDS atomic or): at most two words per lane
+        const int sh = rank0 & 31;
+        const uint32_t lo = local << sh, hi = sh > 24 ? local >> (32 - sh) : 0u;
+        if (lo) __atomic_fetch_or(&LC3_RESW(L)[rank0 >> 5], lo, __ATOMIC_RELAXED);
+        if (hi) __atomic_fetch_or(&LC3_RESW(L)[(rank0 >> 5) + 1], hi, __ATOMIC_RELAXED);
     }
     // noise level :44-55: nfac = min(7, trunc(8 - 16 * mean + 0.5)) only depends on which side of the boundaries
     // 1, 2 .. 7 the value v = 8.5 - 16 * mean falls.  The terms |x| / gg are >= 0, so the reference's sequential f32 sum
@@ -1594,11 +1620,12 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_residual_noise(LC3_CFG_PARA
         }
     }
     const int nfac_tree = nfac;
-    if (!decided || LC3_GUARD_SELFCHECK) {  // wave-uniform
+    if (!decided || LC3_GUARD_SELFCHECK) {  // wave-uniform: the same terms in line order, one sequential f32 sum
         int rank_rel = (int)lc3_wave_exscan_u32(cnt_rel, lane);
+        const lc3_divisor dv = lc3_divisor_make(q.gg);
 #pragma unroll
-        for (int j = 0; j < 7; j++)
-            if (k0 + j < ne && (relmask & (1u << j))) compact[rank_rel++] = lc3_absf(sv[j]) / q.gg;
+        for (int j = 0; j < 8; j++)
+            if (relmask & (1u << j)) compact[rank_rel++] = lc3_div_by(lc3_absf(sv[j]), dv);
         LC3_SYNC();
         float sum0 = 0.0f;
         if (lane == 0) sum0 = lc3_sum_seq(compact, tot_rel, 0.0f);

@@ -237,6 +237,11 @@ __device__ __forceinline__ int lc3_wave_shr1_i32(int v, int lane) {
     (void)lane;
     return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
+// the value lane + 1 holds; lane 63 receives 0
+__device__ __forceinline__ int lc3_wave_shl1_i32(int v, int lane) {
+    (void)lane;
+    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
 // the value lane `src` holds (src the same on every lane), on every lane
 __device__ __forceinline__ float lc3_wave_read_f32(float v, int src, int lane) {
     (void)lane;

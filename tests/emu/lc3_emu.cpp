@@ -94,6 +94,14 @@ static inline int lc3_wave_shr1_i32(int v, int lane) {
     LC3_SYNC();
     return r;
 }
+static inline int lc3_wave_shl1_i32(int v, int lane) {
+    LC3_SYNC();
+    g_xi[tl_wave][lane] = v;
+    LC3_SYNC();
+    const int r = lane < 63 ? g_xi[tl_wave][lane + 1] : 0;
+    LC3_SYNC();
+    return r;
+}
 static inline float lc3_wave_read_f32(float v, int src, int lane) {
     LC3_SYNC();
     g_xf[tl_wave][lane] = v;
