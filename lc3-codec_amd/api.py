@@ -68,6 +68,7 @@ def build_native(force=False, verbose=False):
            "-fno-fast-math", "-Wno-unused-function", "-Wno-missing-braces", "-o", _LIB, _SRC]
     if _PROFILE:
         cmd.insert(1, "-DLC3_PROFILE")
+    cmd[1:1] = os.environ.get("LC3_HIPCC_EXTRA", "").split()  # compiler experiments
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -94,6 +94,9 @@
 // Pointer to read-only HBM data handed to a stage function: the HIP translation unit marks the address space so that
 // the loads are global_load rather than flat_load.
 // a value the caller knows to be the same on every lane of the wave (the device build moves it to a scalar register)
+#ifndef LC3_KEEP_SCALAR  // lc3gpu.hip: keeps the compiler from merging a value's operation with a neighbour's into a packed one
+#define LC3_KEEP_SCALAR(x) ((void)0)
+#endif
 #ifndef LC3_UNIFORM_I32
 #define LC3_UNIFORM_I32(x) (x)
 #endif
@@ -673,29 +676,38 @@ __device__ __forceinline__ void lc3_wave_copy_out16(void *hbm_dst, const void *l
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lc3_sum_seq(const float *a, int n, float acc) {
     // software-pipelined: the next eight operands are requested before the current eight are added (the additions are one
-    // dependent chain; their operands' LDS latency is then hidden behind it)
-    float x[8], xn[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    // dependent chain; their operands' LDS latency is then hidden behind it).  Two register blocks take turns, so no block is
+    // ever copied.
+    float x[8], y[8];
     const int nb = n & ~7;
+    int i = 0;
     if (nb > 0) {
 #pragma unroll
         for (int u = 0; u < 8; u++) x[u] = a[u];
     }
-    for (int i = 0; i < nb; i += 8) {
-        if (i + 8 < nb) {
+    for (; i + 16 <= nb; i += 16) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) xn[u] = a[i + 8 + u];
-        }
+        for (int u = 0; u < 8; u++) y[u] = a[i + 8 + u];
 #pragma unroll
         for (int u = 0; u < 8; u++) acc += x[u];
+        if (i + 16 < nb) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) x[u] = xn[u];
+            for (int u = 0; u < 8; u++) x[u] = a[i + 16 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += y[u];
     }
-    for (int i = nb; i < n; i++) acc += a[i];
+    if (i < nb) {  // an odd number of blocks: the last one is in x
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += x[u];
+    }
+    for (i = nb; i < n; i++) acc += a[i];
     return acc;
 }
 __device__ __forceinline__ float lc3_dot_seq(const float *a, const float *b, int n, float acc) {
-    float x[8], y[8], xn[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, yn[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float x[8], y[8], xn[8], yn[8];
     const int nb = n & ~7;
+    int i = 0;
     if (nb > 0) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -703,23 +715,29 @@ __device__ __forceinline__ float lc3_dot_seq(const float *a, const float *b, int
             y[u] = b[u];
         }
     }
-    for (int i = 0; i < nb; i += 8) {
-        if (i + 8 < nb) {
+    for (; i + 16 <= nb; i += 16) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                xn[u] = a[i + 8 + u];
-                yn[u] = b[i + 8 + u];
-            }
+        for (int u = 0; u < 8; u++) {
+            xn[u] = a[i + 8 + u];
+            yn[u] = b[i + 8 + u];
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) acc += x[u] * y[u];
+        if (i + 16 < nb) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            x[u] = xn[u];
-            y[u] = yn[u];
+            for (int u = 0; u < 8; u++) {
+                x[u] = a[i + 16 + u];
+                y[u] = b[i + 16 + u];
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += xn[u] * yn[u];
     }
-    for (int i = nb; i < n; i++) acc += a[i] * b[i];
+    if (i < nb) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += x[u] * y[u];
+    }
+    for (i = nb; i < n; i++) acc += a[i] * b[i];
     return acc;
 }
 

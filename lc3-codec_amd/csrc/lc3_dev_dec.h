@@ -79,22 +79,46 @@ __device__ __forceinline__ void lc3_dec_state_store(lc3_dec_lds &L, int lane, lc
 // ------------------------------------------------------------------------------------------
 // D10: IMDCT + window + overlap-add (decoder/modified_dct.rs:76-151); spec -> time samples in spec
 // ------------------------------------------------------------------------------------------
-LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_dec_state *g) {
+// The overlap memory (decoder/modified_dct.rs:30,149; nf - z <= 300 samples): element n belongs to lane n % 64 in every frame, so it
+// stays in five registers per lane over the frames of a launch and touches the state blob only at the launch's ends.
+struct lc3_ola5 { float v[5]; };
+template <class CC>
+__device__ __forceinline__ lc3_ola5 lc3_dec_ola_load(const CC &c, int lane, const lc3_dec_state *g) {
+    LC3_HBM_CONST(float) ola = (LC3_HBM_CONST(float))g->mem_ola;
+    lc3_ola5 m;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int n = lane + LC3_WAVE * r;
+        m.v[r] = n < c.nf - c.z ? ola[n] : 0.0f;
+    }
+    return m;
+}
+// whole rounds of 64 under a wave-uniform condition, one base address with constant offsets
+template <class CC>
+__device__ __forceinline__ void lc3_dec_ola_store(const CC &c, int lane, lc3_dec_state *g, int valid, const lc3_ola5 &m) {
+    const int nv = LC3_UNIFORM_I32(valid) ? c.nf - c.z : 0;
+    LC3_HBM(float) ob = (LC3_HBM(float))g->mem_ola + lane;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int rem = nv - LC3_WAVE * r;
+        if (rem >= LC3_WAVE) ob[LC3_WAVE * r] = m.v[r];
+        else if (lane < rem) ob[LC3_WAVE * r] = m.v[r];
+    }
+}
+// mo: the previous frame's overlap memory; returns the new one
+LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE lc3_ola5 lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_ola5 mo) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     const int nf = c.nf, ne = c.ne, z = c.z, h = nf / 2;
     const uint32_t *w = lc3_window_bits(c);
     float *freq = L.spec;
     float *u = (float *)L.fa;  // DCT-IV output
-    // The overlap memory of the previous frame (HBM; element n belongs to lane n % 64 in every frame, so a lane reads back what
-    // it stored itself) and the window coefficients this lane will need are requested now, as one batch of independent
-    // loads, and used after the transform.
-    LC3_HBM_CONST(float) ola = (LC3_HBM_CONST(float))g->mem_ola;
-    float mo[5], wa[5], wb[5], wc[3];  // nf - z <= 300, z <= 180
+    // the window coefficients this lane will need are requested now, as one batch of independent loads, and used after the
+    // transform
+    float wa[5], wb[5], wc[3];  // nf - z <= 300, z <= 180
 #pragma unroll
     for (int r = 0; r < 5; r++) {
         const int n = lane + LC3_WAVE * r, in = n < nf - z;
-        mo[r] = in ? ola[n] : 0.0f;
         wa[r] = in ? lc3_f(w, 2 * nf - 1 - (z + n)) : 0.0f;
         wb[r] = in ? lc3_f(w, 2 * nf - 1 - (nf + z + n)) : 0.0f;
     }
@@ -111,15 +135,14 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_imdct(LC3_CFG_PARAM, LC3_
     // t_hat_mdct[i] = unfolded(i) * gain * w[2nf - 1 - i] is evaluated where it is consumed (each element is used once)
     const float gain = 1.0f / lc3_sqrtf(2.0f * (float)nf);
 #define LC3_UNFOLD(i) ((i) < h ? u[h + (i)] : ((i) < nf ? -u[nf - 1 - ((i) - h)] : ((i) < 3 * h ? -u[h - 1 - ((i) - nf)] : -u[(i) - 3 * h])))
-    float keep[5];  // the new overlap memory; it replaces the transform output in LDS (u is dead once every lane has read it)
-                    // and goes out to HBM with the PCM in the output stage (lc3_dec_ola_store)
+    lc3_ola5 keep;  // the new overlap memory
 #pragma unroll
     for (int r = 0; r < 5; r++) {
         const int n = lane + LC3_WAVE * r;
-        keep[r] = 0.0f;
+        keep.v[r] = 0.0f;
         if (n < nf - z) {
-            freq[n] = mo[r] + (LC3_UNFOLD(z + n) * gain) * wa[r];
-            keep[r] = (LC3_UNFOLD(nf + z + n) * gain) * wb[r];
+            freq[n] = mo.v[r] + (LC3_UNFOLD(z + n) * gain) * wa[r];
+            keep.v[r] = (LC3_UNFOLD(nf + z + n) * gain) * wb[r];
         }
     }
 #pragma unroll
@@ -129,31 +152,8 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_imdct(LC3_CFG_PARAM, LC3_
     }
 #undef LC3_UNFOLD
     LC3_SYNC();
-#pragma unroll
-    for (int r = 0; r < 5; r++) {
-        const int n = lane + LC3_WAVE * r;
-        if (n < nf - z) u[n] = keep[r];
-    }
-    LC3_SYNC();
+    return keep;
 }
-// the overlap memory left in LDS by lc3_dec_imdct -> the state blob; whole rounds of 64 under a wave-uniform condition,
-// one base address with constant offsets
-template <class CC>
-__device__ __forceinline__ void lc3_dec_ola_store(const CC &c, lc3_dec_lds &L, int lane, lc3_dec_state *g, int valid) {
-    const float *u = (const float *)L.fa;
-    const int nv = LC3_UNIFORM_I32(valid) ? c.nf - c.z : 0;
-    LC3_HBM(float) ob = (LC3_HBM(float))g->mem_ola + lane;
-    float keep[5];
-#pragma unroll
-    for (int r = 0; r < 5; r++) keep[r] = lane < nv - LC3_WAVE * r ? u[lane + LC3_WAVE * r] : 0.0f;
-#pragma unroll
-    for (int r = 0; r < 5; r++) {
-        const int rem = nv - LC3_WAVE * r;
-        if (rem >= LC3_WAVE) ob[LC3_WAVE * r] = keep[r];
-        else if (lane < rem) ob[LC3_WAVE * r] = keep[r];
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // D11: long-term post-filter synthesis (decoder/long_term_post_filter.rs:142-424)
 // ------------------------------------------------------------------------------------------
@@ -394,7 +394,7 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_plc_load(LC3_CFG_PARAM, L
 // plc_src / save_good: see lc3_decode_stream_wave.  Returns 1 for a good frame, 0 for a concealed one.
 LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes,
                                                       int16_t *pcm_out, const lc3_plane_fetch &fetched, lc3_dec_state *g,
-                                                      int valid, int stride, const float *plc_src, int save_good) {
+                                                      int valid, int stride, const float *plc_src, int save_good, lc3_ola5 &ola) {
     LC3_CFG_BIND;
     const int nf = c.nf, nbits = nbytes * 8;
     LC3_STAMP(L, lane, 16);
@@ -410,12 +410,11 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 18);
-    lc3_dec_imdct(LC3_CFG_PASS, LC3_LDS_PASS lane, g);
+    ola = lc3_dec_imdct(LC3_CFG_PASS, LC3_LDS_PASS lane, ola);
     LC3_STAMP(L, lane, 19);
     lc3_dec_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, ltpf_active, pitch_index, nbits);
     LC3_STAMP(L, lane, 20);
     // output_scaling::scale_and_round (decoder/output_scaling.rs:13-25); two samples per 32-bit store
-    lc3_dec_ola_store(c, L, lane, g, valid);
     {
         LC3_HBM(uint32_t) o32 = (LC3_HBM(uint32_t))pcm_out;
         uint32_t ow[4];  // nf / 2 <= 240 words: all four computed, then stored together
@@ -473,16 +472,18 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_stream_wave(LC3_CFG_
     lc3_plane_fetch cur, nxt;
     if (n_frames > 0) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, fbase, LC3_PLANE_WORDS), cur);
     int t_good = -1, last_ok = 1;
+    lc3_ola5 ola = lc3_dec_ola_load(c0, lane, g);
     for (int t = 0; t < n_frames; t++) {
         const size_t f = fbase + (size_t)t;
         if (t + 1 < n_frames) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, f + 1, LC3_PLANE_WORDS), nxt);
         int16_t *out = pcm0 + (size_t)t * frame_step;
         const float *plc_src = t_good >= 0 ? (const float *)(LC3_PLANE_COL(planes, fbase + (size_t)t_good, LC3_PLANE_WORDS) + LC3_PLANE_X * LC3_PLANE_STRIDE)
                                            : (const float *)g->plc_last_good;
-        last_ok = lc3_decode_frame_wave(LC3_CFG_PASS, L, lane, nbytes, out, cur, g, valid, stride, plc_src, t == n_frames - 1);
+        last_ok = lc3_decode_frame_wave(LC3_CFG_PASS, L, lane, nbytes, out, cur, g, valid, stride, plc_src, t == n_frames - 1, ola);
         if (last_ok) t_good = t;
         cur = nxt;
     }
+    lc3_dec_ola_store(c0, lane, g, valid, ola);
     if (valid && !last_ok && t_good >= 0) {  // the launch ended in a lost frame: its last good spectrum moves to the state blob
         LC3_HBM_CONST(float) src = (LC3_HBM_CONST(float))(LC3_PLANE_COL(planes, fbase + (size_t)t_good, LC3_PLANE_WORDS) + LC3_PLANE_X * LC3_PLANE_STRIDE);
         for (int k = lane; k < c0.ne; k += LC3_WAVE) g->plc_last_good[k] = src[k];

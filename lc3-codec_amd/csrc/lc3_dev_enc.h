@@ -781,6 +781,7 @@ __device__ __forceinline__ void lc3_resample_pair(const float *xa, const float *
         for (int u = 0; u < 4; u++) {
             acc0 += win[u] * ta[u];
             acc1 += (far ? win[u + DLO + 1] : win[u + DLO]) * tb[u];
+            LC3_KEEP_SCALAR(acc1);  // (pairing the two sums into packed f32 operations costs more register moves than it saves)
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -964,30 +965,37 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         const int k0 = 2 * lp, k1 = 2 * lp + 1;
         const float *pa = x6 + LC3_KMAX, *pb = x6 + (LC3_KMAX - LC3_KMIN - 1 - k0);  // pb[n] = operand of lag k1, pb[n + 1] of lag k0
         float acc0 = 0.0f, acc1 = 0.0f;
-        {   // the next eight operands of each array are requested before the current eight products are added
-            float a[8], bb[9], an[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, bn[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        {   // the next eight operands of each array are requested before the current eight products are added; two register
+            // blocks take turns (len6 is 64 or 48: a whole number of double blocks)
+            float a[8], bb[9], an[8], bn[9];
 #pragma unroll
             for (int u = 0; u < 8; u++) a[u] = pa[u];
 #pragma unroll
             for (int u = 0; u < 9; u++) bb[u] = pb[u];
-            #pragma unroll 1
-            for (int n = 0; n < len6; n += 8) {
-                if (n + 8 < len6) {
+#pragma unroll  // (a configuration view knows len6: straight-line code, no block is moved between registers)
+            for (int n = 0; n < len6; n += 16) {
 #pragma unroll
-                    for (int u = 0; u < 8; u++) an[u] = pa[n + 8 + u];
+                for (int u = 0; u < 8; u++) an[u] = pa[n + 8 + u];
 #pragma unroll
-                    for (int u = 1; u < 9; u++) bn[u] = pb[n + 8 + u];
-                }
+                for (int u = 1; u < 9; u++) bn[u] = pb[n + 8 + u];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     acc0 += a[u] * bb[u + 1];
                     acc1 += a[u] * bb[u];
                 }
-                bn[0] = bb[8];  // the last operand of this block is the first of the next for the odd lag
+                bn[0] = bb[8];  // the last operand of a block is the first of the next for the odd lag
+                if (n + 16 < len6) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) a[u] = an[u];
+                    for (int u = 0; u < 8; u++) a[u] = pa[n + 16 + u];
 #pragma unroll
-                for (int u = 0; u < 9; u++) bb[u] = bn[u];
+                    for (int u = 1; u < 9; u++) bb[u] = pb[n + 16 + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    acc0 += an[u] * bn[u + 1];
+                    acc1 += an[u] * bn[u];
+                }
+                bb[0] = bn[8];
             }
         }
         if (live) {

@@ -80,6 +80,7 @@ __shared__ lc3_spec_tables lc3_spec_tab;
 #define LC3_HBM_CONST(T) const __attribute__((address_space(1))) T *
 #define LC3_HBM(T) __attribute__((address_space(1))) T *
 #define LC3_UNIFORM_I32(x) __builtin_amdgcn_readfirstlane((int)(x))
+#define LC3_KEEP_SCALAR(x) asm("" : "+v"(x))
 // product of two values below 2^24 (range-coder steps): the full-rate 24-bit multiplier instead of the quarter-rate v_mul_lo_u32
 #define LC3_MUL24(a, b) __umul24((a), (b))
 #define LC3_WAVE_ANY(pred) (__ballot((pred) != 0) != 0ull)
