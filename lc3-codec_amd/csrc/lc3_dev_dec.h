@@ -6,12 +6,14 @@
 #include "lc3_dev_common.h"
 #include "lc3_dev_dec_parse.h"
 
-// The decoder's stage functions are real calls (inlined, the kernel needs 128 VGPRs plus spills and runs 1.5x slower).
-// A call has a price the code is arranged around: the callee waits for every outstanding load and store at its entry and
-// before its return, so stores are issued where a long stretch without a call follows (the output stage), not at the end
-// of a stage function.
+// The decoder's stage functions are real calls, except the IMDCT (everything inlined, the kernel needs 128 VGPRs plus spills
+// and runs 1.3x slower).  A call has a price the code is arranged around: every outstanding load and store is waited for
+// before a call, at the callee's entry and before its return.  So stores are issued where a long stretch without a call
+// follows (the output stage), and the loads of the next frame's plane column -- issued at the top of a frame -- get the inlined
+// IMDCT's worth of work before the first call (the LTPF) drains them (IMDCT as a call: synthesis 0.146 ms, inlined 0.134 ms).
 #ifndef LC3_DEC_STAGE
 #define LC3_DEC_STAGE __noinline__
+#define LC3_DEC_STAGE_HOT __forceinline__
 #endif
 
 // Persistent per-stream decoder state.  `core` is what a wave keeps resident in LDS while it
@@ -106,7 +108,7 @@ __device__ __forceinline__ void lc3_dec_ola_store(const CC &c, int lane, lc3_dec
     }
 }
 // mo: the previous frame's overlap memory; returns the new one
-LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE lc3_ola5 lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_ola5 mo) {
+LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE_HOT lc3_ola5 lc3_dec_imdct(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, const lc3_ola5 mo) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     const int nf = c.nf, ne = c.ne, z = c.z, h = nf / 2;
