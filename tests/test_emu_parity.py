@@ -132,3 +132,15 @@ def test_emu_8khz_encode_switch():
         dec = O.decode_batch(ref, nf, 8000, us)
         live = pcm.reshape(4, -1).std(axis=1) > 100
         assert (dec.reshape(4, -1)[live].std(axis=1) > 50).all()
+
+
+@pytest.mark.parametrize("fs,us,nf,nbytes", [(48000, 10000, 480, 150), (48000, 7500, 360, 40), (16000, 10000, 160, 60)])
+def test_emu_guarded_decisions_and_their_sequential_path(fs, us, nf, nbytes):
+    """The quantiser's gain bisection and noise level are decided from tree sums where those are further from the threshold than
+    the rounding of the reference's sequential sum can reach.  The emulator build runs the sequential sum
+    next to EVERY such decision and aborts the process when the two disagree (LC3_GUARD_SELFCHECK), so simply running frames is
+    the check; flag 256 (LC3_SPEC_TEST_SEQ_SUMS, what LC3GPU_SEQ_SUMS=1 sets on the GPU) forces the sequential path."""
+    pcm = synth.make_pcm(10, 6, nf, fs, first_stream=40)
+    ref = O.encode_batch(pcm, nbytes, fs, us)
+    assert np.array_equal(E.encode(pcm, nbytes, fs, us), ref)
+    assert np.array_equal(E.encode(pcm, nbytes, fs, us, spec_flags=256), ref)
