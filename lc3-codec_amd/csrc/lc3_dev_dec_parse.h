@@ -52,6 +52,7 @@ struct lc3_parse_ctx {
 #endif
 
 static_assert(LC3_PLANE_STRIDE == 1, "the parser's 64 / 128-bit plane accesses need frame-major planes");
+typedef int32_t lc3_i2 __attribute__((vector_size(8)));  // two plane words (a line pair), 8-byte aligned
 __device__ __forceinline__ void lc3_px_set(lc3_parse_ctx &c, int word, int32_t v) { c.plane[word * c.stride] = v; }
 __device__ __forceinline__ int32_t lc3_px_get(const lc3_parse_ctx &c, int word) { return c.plane[word * c.stride]; }
 
@@ -286,21 +287,20 @@ __device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_ac
     return lo;
 }
 
-// read_res_bit (decoder/arithmetic_codec.rs:339-383)
-__device__ __forceinline__ int lc3_p_res_bit(lc3_parse_ctx &c, int idx, int &nbits_res, int &cont) {
+// read_res_bit (decoder/arithmetic_codec.rs:339-383) on a line whose value `xv` is already in a register; the caller stores it back
+__device__ __forceinline__ int lc3_p_res_bit(lc3_parse_ctx &c, int idx, int32_t &xv, int &nbits_res, int &cont) {
     int bit;
     if (nbits_res == 0) { cont = 0; return 0; }
     if (lc3_p_bool(c, bit)) return -1;
     nbits_res -= 1;
     if (bit) {
-        const int32_t xv = lc3_px_get(c, LC3_PLANE_X + idx);
-        if (xv > 0) lc3_px_set(c, LC3_PLANE_X + idx, xv + 1);
-        else if (xv < 0) lc3_px_set(c, LC3_PLANE_X + idx, xv - 1);
+        if (xv > 0) xv += 1;
+        else if (xv < 0) xv -= 1;
         else {
             if (nbits_res == 0) { cont = 0; return 0; }
             if (lc3_p_bool(c, bit)) return -1;
             nbits_res -= 1;
-            lc3_px_set(c, LC3_PLANE_X + idx, bit ? -1 : 1);
+            xv = bit ? -1 : 1;
             c.nnz += 1;
         }
         c.seed += (uint32_t)idx;  // |x| grew by one
@@ -346,6 +346,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
     LC3_PSTAMP(c, 1);
     // decode_spectral_data :211-302
     const int ntup = lastnz / 2;
+    int lev_end = 0;  // 1 + the last pair that was coded with escape levels (lsb_mode's refinement walk has nothing to do beyond it)
     {
         const int rate_flag = nbits > (160 + fs_ind * 160) ? 512 : 0;
         // One symbol per iteration and lane: a lane decodes the escape symbols of its pair (each followed by the pair's next
@@ -371,13 +372,13 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             const int32_t v0 = bit0 ? -m0 : m0, v1 = bit1 ? -m1 : m1;
             // (an escape step stores its partial values too: the pair's main step overwrites them)
             {   // the pair as one 64-bit store (8-byte aligned: the column, LC3_PLANE_X and 2 * tup are even numbers of words)
-                typedef int32_t lc3_i2 __attribute__((vector_size(8)));
                 lc3_i2 pr;
                 pr[0] = v0;
                 pr[1] = v1;
                 *(lc3_i2 *)(c.plane + (LC3_PLANE_X + 2 * tup) * LC3_PLANE_STRIDE) = pr;
             }
             if (lsb_mode && !esc) lc3_px_set(c, LC3_PLANE_LEV + tup, lev);  // written by TUPLE index, read by LINE index (:184-195)
+            lev_end = (!esc && lev > 0) ? tup + 1 : lev_end;
             c.nnz += esc ? 0u : (uint32_t)(m0 != 0) + (uint32_t)(m1 != 0);
             c.seed += esc ? 0u : (uint32_t)m0 * (uint32_t)(2 * tup) + (uint32_t)m1 * (uint32_t)(2 * tup + 1);
             cctx = esc ? cctx : (cctx & 15) * 16 + (lv <= 1 ? 1 + (a + b) * (lv + 1) : 12 + lv);
@@ -403,21 +404,31 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             // save_lev is read by LINE index k = 0, 2, 4 .. but was written by TUPLE index: entries at or beyond the
             // number of tuples were never written (zero in the reference), so the walk ends at ntup.  The levels are
             // fetched eight at a time.
+            // The levels and the line pairs they refine are fetched eight pairs at a time (a lane of this kernel is latency-bound: a
+            // read-modify-write of a plane word per bit cost a memory round trip each).
+            struct q2 { int32_t v[2]; };
             int stop = 0;
-            for (int k0 = 0; k0 < ntup && !stop; k0 += 16) {
+            const int walk_end = lev_end < ntup ? lev_end : ntup;  // entries at and beyond lev_end are 0: skipped without reading a bit
+            for (int k0 = 0; k0 < walk_end && !stop; k0 += 16) {
                 int lv[8];
+                q2 xp[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) lv[j] = k0 + 2 * j < ntup ? lc3_px_get(c, LC3_PLANE_LEV + k0 + 2 * j) : 0;
+                for (int j = 0; j < 8; j++) {
+                    const int k = k0 + 2 * j, in = k < ntup;  // lines k, k + 1 < 2 * ntup <= ne
+                    lv[j] = in ? lc3_px_get(c, LC3_PLANE_LEV + k) : 0;
+                    xp[j] = __builtin_bit_cast(q2, *(const lc3_i2 *)(c.plane + (LC3_PLANE_X + (in ? k : 0)) * LC3_PLANE_STRIDE));
+                }
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     if (!stop && lv[j] > 0) {
                         const int k = k0 + 2 * j;
-                        if (lc3_p_res_bit(c, k, nres, cont)) return -7;
+                        if (lc3_p_res_bit(c, k, xp[j].v[0], nres, cont)) return -7;
                         if (!cont) stop = 1;
                         else {
-                            if (lc3_p_res_bit(c, k + 1, nres, cont)) return -7;
+                            if (lc3_p_res_bit(c, k + 1, xp[j].v[1], nres, cont)) return -7;
                             if (!cont) stop = 1;
                         }
+                        *(lc3_i2 *)(c.plane + (LC3_PLANE_X + k) * LC3_PLANE_STRIDE) = __builtin_bit_cast(lc3_i2, xp[j]);
                     }
                 }
             }
