@@ -632,6 +632,22 @@ def test_sequential_sum_path_of_guarded_decisions():
     assert r.returncode == 0 and "seq ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_stress_parity_tool_small_run():
+    """tools/stress_parity.py (the differential run whose full-size results are profiles/r02_stress_parity*.json: 7.3 M frames per
+    direction over 14 configurations, none differing) at a size that takes seconds"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "--streams", "96", "--frames", "5", "--rounds", "1"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["frames_differing"] == 0 and line["total_frames_each_direction"] == 14 * 96 * 5
+
+
 # ---------------------------------------------------------------- SURVEY section 8 row f3: spec-conformant switches
 def _gpu_encode_spec(pcm, nbytes, fs, us, flags):
     torch = torch_mod()

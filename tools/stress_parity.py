@@ -1,0 +1,98 @@
+"""Differential stress run of the GPU engine against the CPU oracle (test infrastructure: the oracle is only the checker).
+
+    python tools/stress_parity.py [--streams 2048] [--frames 16] [--rounds 2] > gpurun_out/stress_parity.json
+
+For every (sampling rate, frame duration, frame size) of the list below and every round: synthetic PCM of mixed character
+(tonal / noisy / clicks from lc3-codec_amd.synth, plus band-limited, very quiet, clipping and silent streams), encoded by the
+GPU engine and by the oracle (all host threads), the bitstreams compared byte for byte; then the oracle's bytes decoded by
+both and the PCM compared sample for sample.  Exit code 1 on any difference.  The point of the volume: decisions the kernels
+take from guarded tree sums fall back to the sequential sum about once in 10^4 decisions, so millions of
+frames are needed to exercise both sides of every guard on real data."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CASES = [  # fs_hz, frame_us, nbytes
+    (48000, 10000, 150), (48000, 10000, 40), (48000, 10000, 80), (48000, 10000, 300), (48000, 7500, 113), (48000, 7500, 30),
+    (44100, 10000, 100), (32000, 10000, 80), (32000, 7500, 60), (24000, 10000, 60), (24000, 7500, 45), (16000, 10000, 40),
+    (16000, 7500, 30), (16000, 10000, 120),
+]
+
+
+def make_mixed(synth, S, T, nf, fs, rnd):
+    pcm = synth.make_pcm(S, T, nf, fs, first_stream=100000 * (rnd + 1))
+    rng = np.random.default_rng([77, rnd, fs, nf])
+    # a quarter of the streams band-limited (lower bandwidth indices, other TNS layouts)
+    nb = S // 4
+    cut = float(rng.choice([3500.0, 7000.0, 11000.0])) if fs >= 32000 else float(fs) / 4.5
+    pcm[:nb] = synth.make_bandlimited_pcm(nb, T, nf, fs, min(cut, fs / 2.2), seed=synth.SEED + rnd + 1)
+    # very quiet streams (a few LSB: global-gain floor, zero frames) and streams scaled into clipping
+    q = slice(nb, nb + S // 16)
+    pcm[q] = (pcm[q].astype(np.int32) // int(rng.integers(500, 4000))).astype(np.int16)
+    c = slice(nb + S // 16, nb + S // 8)
+    pcm[c] = np.clip(pcm[c].astype(np.int32) * int(rng.integers(3, 9)), -32768, 32767).astype(np.int16)
+    return np.ascontiguousarray(pcm)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=2048)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--rounds", type=int, default=2)
+    a = ap.parse_args()
+    import torch
+
+    import oracle_lib as O
+
+    pkg = importlib.import_module("lc3-codec_amd")
+    synth = importlib.import_module("lc3-codec_amd.synth")
+    threads = os.cpu_count() or 8
+    S, T = a.streams, a.frames
+    st = torch.cuda.current_stream().cuda_stream
+    rows, bad = [], 0
+    t0 = time.time()
+    for fs, us, nbytes in CASES:
+        nf = (fs if fs != 44100 else 48000) * us // 1000000
+        enc = pkg.Lc3Encoder(S, us, fs)
+        dec = pkg.Lc3Decoder(S, us, fs)
+        enc_bad = dec_bad = 0
+        for rnd in range(a.rounds):
+            pcm = make_mixed(synth, S, T, nf, fs, rnd)
+            enc.reset()
+            dec.reset()
+            d_pcm = torch.from_numpy(pcm).cuda()
+            d_out = torch.zeros((S, T, nbytes), dtype=torch.uint8, device="cuda")
+            enc.encode(d_pcm, d_out, nbytes, T, stream=st)
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy()
+            ref = O.encode_batch(pcm, nbytes, fs, us, threads=threads)
+            enc_bad += int((got != ref).any(axis=2).sum())
+            d_in = torch.from_numpy(ref).cuda()
+            d_dec = torch.zeros((S, T, nf), dtype=torch.int16, device="cuda")
+            dec.decode(d_in, d_dec, nbytes, T, stream=st)
+            torch.cuda.synchronize()
+            ref_pcm = O.decode_batch(ref, nf, fs, us, threads=threads)
+            dec_bad += int((d_dec.cpu().numpy() != ref_pcm).any(axis=2).sum())
+        rows.append({"fs_hz": fs, "frame_us": us, "nbytes": nbytes, "frames": S * T * a.rounds, "encode_frames_differing": enc_bad,
+                     "decode_frames_differing": dec_bad})
+        bad += enc_bad + dec_bad
+        print(f"{fs} {us} {nbytes}: {S * T * a.rounds} frames, enc diff {enc_bad}, dec diff {dec_bad}", file=sys.stderr)
+    total = sum(r["frames"] for r in rows)
+    print(json.dumps({"what": "GPU engine vs CPU oracle, byte-exact bitstreams and sample-exact PCM (tools/stress_parity.py)",
+                      "streams": S, "frames_per_stream": T, "rounds": a.rounds, "total_frames_each_direction": total,
+                      "frames_differing": bad, "seconds": round(time.time() - t0, 1), "env_seq_sums": os.environ.get("LC3GPU_SEQ_SUMS"),
+                      "cases": rows}))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
