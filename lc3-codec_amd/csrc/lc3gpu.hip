@@ -1285,8 +1285,9 @@ static int encoder_alloc(lc3gpu_encoder *e) {
     HIP_TRY(hipGetDevice(&e->device));
     HIP_TRY(hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
     HIP_TRY(hipMalloc((void **)&e->d_states, sizeof(lc3_enc_state) * (size_t)e->num_channels));
-    HIP_TRY(hipMalloc((void **)&e->d_pcm1, sizeof(int16_t) * LC3_MAX_NF));
-    HIP_TRY(hipMalloc((void **)&e->d_out1, LC3_MAX_NE));
+    // staging of the *_frame calls: pinned host memory the kernels read / write in place (no copy engine round trips)
+    HIP_TRY(hipHostMalloc((void **)&e->d_pcm1, sizeof(int16_t) * LC3_MAX_NF, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&e->d_out1, LC3_MAX_NE, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void **)&e->d_dbg, sizeof(float) * 1472));
     e->fresh_mask.assign((size_t)e->num_channels, 1);
     return encoder_reserve_planes(e, (size_t)e->num_channels, nullptr);
@@ -1346,8 +1347,8 @@ int lc3gpu_encoder_destroy(lc3gpu_encoder *e) {
         DeviceGuard g(e->device);
         (void)e->quiesce();
         if (e->d_states) (void)hipFree(e->d_states);
-        if (e->d_pcm1) (void)hipFree(e->d_pcm1);
-        if (e->d_out1) (void)hipFree(e->d_out1);
+        if (e->d_pcm1) (void)hipHostFree(e->d_pcm1);
+        if (e->d_out1) (void)hipHostFree(e->d_out1);
         if (e->d_dbg) (void)hipFree(e->d_dbg);
         if (e->d_planes) (void)hipFree(e->d_planes);
         if (e->d_mid) (void)hipFree(e->d_mid);
@@ -1506,11 +1507,12 @@ static int encode_frame_host(lc3gpu_encoder *e, int channel_index, const int16_t
     LC3_ON_DEVICE(e);
     int rc = e->quiesce();  // the staging buffers are reused
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(e->d_pcm1, samples_in, sizeof(int16_t) * (size_t)n_samples, hipMemcpyHostToDevice));
+    std::memcpy(e->d_pcm1, samples_in, sizeof(int16_t) * (size_t)n_samples);
     rc = encode_launch(e, h, e->internal_of_channel(channel_index), 1, e->d_pcm1, e->d_out1, nbytes, 1, LC3GPU_LAYOUT_PLANAR, nullptr,
                        dbg ? e->d_dbg : nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(buf_out, e->d_out1, (size_t)nbytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    std::memcpy(buf_out, e->d_out1, (size_t)nbytes);
     if (dbg) HIP_TRY(hipMemcpy(dbg, e->d_dbg, sizeof(float) * 1472, hipMemcpyDeviceToHost));
     return LC3GPU_OK;
 }
@@ -1590,8 +1592,8 @@ static int decoder_alloc(lc3gpu_decoder *d) {
     HIP_TRY(hipGetDevice(&d->device));
     HIP_TRY(hipEventCreateWithFlags(&d->done, hipEventDisableTiming));
     HIP_TRY(hipMalloc((void **)&d->d_states, sizeof(lc3_dec_state) * (size_t)d->num_channels));
-    HIP_TRY(hipMalloc((void **)&d->d_in1, LC3_MAX_NE));
-    HIP_TRY(hipMalloc((void **)&d->d_pcm1, sizeof(int16_t) * LC3_MAX_NF));
+    HIP_TRY(hipHostMalloc((void **)&d->d_in1, LC3_MAX_NE, hipHostMallocDefault));  // *_frame staging: pinned host memory, used in place
+    HIP_TRY(hipHostMalloc((void **)&d->d_pcm1, sizeof(int16_t) * LC3_MAX_NF, hipHostMallocDefault));
     int rc = decoder_reserve_planes(d, (size_t)d->num_channels, nullptr);
     if (rc == LC3GPU_OK) rc = decoder_init_states(d);
     return rc;
@@ -1633,8 +1635,8 @@ int lc3gpu_decoder_destroy(lc3gpu_decoder *d) {
         DeviceGuard g(d->device);
         (void)d->quiesce();
         if (d->d_states) (void)hipFree(d->d_states);
-        if (d->d_in1) (void)hipFree(d->d_in1);
-        if (d->d_pcm1) (void)hipFree(d->d_pcm1);
+        if (d->d_in1) (void)hipHostFree(d->d_in1);
+        if (d->d_pcm1) (void)hipHostFree(d->d_pcm1);
         if (d->d_planes) (void)hipFree(d->d_planes);
         d->release_common();
     }
@@ -1738,11 +1740,12 @@ int lc3gpu_decode_frame(lc3gpu_decoder *d, int num_bits_per_audio_sample, int ch
     LC3_ON_DEVICE(d);
     int rc = d->quiesce();  // the staging buffers are reused
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(d->d_in1, buf_in, (size_t)nbytes, hipMemcpyHostToDevice));
+    std::memcpy(d->d_in1, buf_in, (size_t)nbytes);
     rc = decode_launch(d, h, d->internal_of_channel(channel_index), 1, d->d_in1, nullptr, d->d_pcm1, nbytes, 1, LC3GPU_LAYOUT_PLANAR,
                        nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(samples_out, d->d_pcm1, sizeof(int16_t) * (size_t)n_samples, hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    std::memcpy(samples_out, d->d_pcm1, sizeof(int16_t) * (size_t)n_samples);
     return LC3GPU_OK;
 }
 
