@@ -218,6 +218,21 @@ __device__ __forceinline__ int lc3_p_bool_sel(lc3_parse_ctx &c, int want, int &e
     c.tnext = lc3_p_tail_byte(c, (c.tail >> 3) + 1);  // consumed at the next wrap, not here
     return want ? bit : 0;
 }
+// two consecutive read_tail_bool (:100-116), each when its `want`: the cursor, its byte window and the bound check advance once.
+// (The bound check is monotone in the bit position, so the last bit read stands for both.)
+__device__ __forceinline__ void lc3_p_bool2_sel(lc3_parse_ctx &c, int w0, int w1, int &err, int &b0, int &b1) {
+    const int n = w0 + w1, bit_index = c.tail & 7;
+    const int byte_last = (c.tail + n - 1) >> 3;
+    const int bad = (c.len - c.head - byte_last + 2 < 0) | (c.len - byte_last - 1 < 0);
+    err |= (n > 0) & bad;
+    const uint32_t win = (c.tcur | (c.tnext << 8)) >> bit_index;
+    b0 = w0 ? (int)(win & 1u) : 0;
+    b1 = w1 ? (int)((win >> w0) & 1u) : 0;
+    const int wrap = bit_index + n >= 8;
+    c.tail += n;
+    c.tcur = wrap ? c.tnext : c.tcur;
+    c.tnext = lc3_p_tail_byte(c, (c.tail >> 3) + 1);  // consumed at the next wrap, not here
+}
 // the two renormalisation steps of ac_decode (:88-95) from the head bytes held in registers
 __device__ __forceinline__ void lc3_p_ac_renorm_sel(lc3_parse_ctx &c, lc3_acdec &st, int &err) {
     const int need0 = st.range < 0x10000u;
@@ -367,8 +382,8 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             // two tail bits: after an escape symbol the pair's next bit plane (when it is transmitted), after the main symbol
             // the signs of the non-zero values
             const int want_e = !lsb_mode || lev > 0;
-            const int bit0 = lc3_p_bool_sel(c, esc ? want_e : m0 > 0, err);
-            const int bit1 = lc3_p_bool_sel(c, esc ? want_e : m1 > 0, err);
+            int bit0, bit1;
+            lc3_p_bool2_sel(c, esc ? want_e : m0 > 0, esc ? want_e : m1 > 0, err, bit0, bit1);
             const int32_t v0 = bit0 ? -m0 : m0, v1 = bit1 ? -m1 : m1;
             // (an escape step stores its partial values too: the pair's main step overwrites them)
             {   // the pair as one 64-bit store (8-byte aligned: the column, LC3_PLANE_X and 2 * tup are even numbers of words)
