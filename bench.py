@@ -335,6 +335,10 @@ def run_rank(args):
             local_rank = local_rank % max(1, torch.cuda.device_count())
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
+            # stdout carries ONE JSON line (rank 0): RCCL's version banner (NCCL_DEBUG=VERSION, set on some boxes) goes to stdout
+            # through C stdio and would surface after it at exit
+            if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+                os.environ["NCCL_DEBUG"] = "WARN"
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
