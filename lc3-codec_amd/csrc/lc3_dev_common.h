@@ -121,6 +121,9 @@
 // internal (never part of the ABI's LC3GPU_SPEC_* set; LC3GPU_SEQ_SUMS=1 in the environment at create time): decisions that
 // are normally taken from guarded tree sums always take their sequential-sum path, so that tests can run that path
 #define LC3_SPEC_TEST_SEQ_SUMS 256
+// per launch, set by the host for launches that do not fill the chip: the analysis kernel prepares the packer's symbols
+// (lc3_enc_symbols).  LC3GPU_PREP_SYMBOLS=0 / 1 in the environment forces it off / on for every launch (tests).
+#define LC3_LAUNCH_PREP_SYMBOLS 512
 #ifndef LC3_BISECT_GUARD
 #define LC3_BISECT_GUARD 1.0e-4f
 #endif

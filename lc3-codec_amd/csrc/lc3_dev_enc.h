@@ -1653,6 +1653,104 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_residual_noise(LC3_CFG_PARA
 }
 
 // ------------------------------------------------------------------------------------------
+// E20, the part that does not depend on the range coder's state: which symbols spectral_data (encoder/bitstream_encoding.rs:246-326)
+// will code, with which model interval, and the bits that follow each of them.  Lane l owns the pairs 4l .. 4l+3 (as in
+// lc3_quantize_spectrum): classes and contexts in parallel, positions by prefix sum, one LC3_SYM_WORD per symbol into the
+// packer plane.  The lane-per-frame packer (lc3_dev_enc_pack.h) then only runs the coder: half the instructions per symbol
+// on its serial path.  Small launches only (LC3_LAUNCH_PREP_SYMBOLS, lc3_dev_enc_pack.h); more than LC3_SYM_CAP symbols (never
+// seen; the bit budget allows it in theory): EP_NSYM = -1 and the packer derives the symbols itself.
+// ------------------------------------------------------------------------------------------
+LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_symbols(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const lc3_quant_res q,
+                                              int32_t *plane, int st) {
+    LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
+    const int ne = c.ne, k0 = 4 * lane, ntup = q.lastnz_trunc / 2, lsb_mode = q.lsb_mode, rate_flag = q.rate_flag;
+    int q8[8];
+    {
+        const lc3_i4 w = *(const lc3_i4 *)(LC3_XQ(L) + 8 * lane);  // zero from lastnz_trunc on
+        int wi[4];
+        __builtin_memcpy(wi, &w, 16);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            q8[2 * i] = (int)(int16_t)(wi[i] & 0xffff);
+            q8[2 * i + 1] = wi[i] >> 16;
+        }
+    }
+    unsigned a4[4], b4[4];
+    int ne4[4], tt[4], cnt = 0, lsbs = 0, esc_max = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int q0 = q8[2 * j], q1 = q8[2 * j + 1], live = k0 + j < ntup;
+        const unsigned a = (unsigned)(q0 < 0 ? -q0 : q0), b = (unsigned)(q1 < 0 ? -q1 : q1);
+        const unsigned m = a > b ? a : b;
+        const int n_esc = m >= 4 ? (32 - __builtin_clz(m)) - 2 : 0;
+        const int lev = n_esc < 3 ? n_esc : 3;
+        tt[j] = lev <= 1 ? 1 + (int)((a >> n_esc) + (b >> n_esc)) * (lev + 1) : 12 + lev;
+        a4[j] = a;
+        b4[j] = b;
+        ne4[j] = live ? n_esc : -1;  // -1: not coded
+        cnt += live ? n_esc + 1 : 0;
+        esc_max = (live && n_esc > esc_max) ? n_esc : esc_max;
+        // the LSB list (:298-312): in lsb_mode an escaped pair leaves its two LSBs, and the sign of a value whose upper part is zero
+        if (live && lsb_mode && n_esc > 0) lsbs += 2 + (int)((a >> 1) == 0u && q0 != 0) + (int)((b >> 1) == 0u && q1 != 0);
+    }
+    const int p2 = lc3_wave_shr1_i32(tt[2], lane), p3 = lc3_wave_shr1_i32(tt[3], lane);
+    const uint32_t base = lc3_wave_exscan_u32((uint32_t)cnt, lane);
+    const int total = lc3_wave_read_i32((int)base + cnt, LC3_WAVE - 1, lane);
+    const int nlsbs = (int)lc3_wave_sum_u32((uint32_t)lsbs, lane);
+    const int fits = total <= LC3_SYM_CAP;
+    if (lane == 0) {
+        plane[EP_NSYM * st] = fits ? total : -1;
+        plane[EP_NLSBS * st] = nlsbs;
+    }
+    if (!fits) return;
+    int pos[4], tctx[4];
+    {
+        int p = (int)base;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
+            pos[j] = p;
+            p += ne4[j] + 1;  // (a pair that is not coded has ne4 = -1)
+            const int cctx = 16 * (j == 0 ? p2 : (j == 1 ? p3 : tt[j - 2])) + (j == 0 ? p3 : tt[j - 1]);
+            tctx[j] = cctx + rate_flag + ((2 * k) > ne / 2 ? 256 : 0);
+        }
+    }
+    // main symbols: the magnitudes above the escaped bit planes, then the signs of the values that are non-zero there
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int n_esc = ne4[j];
+        if (n_esc >= 0) {
+            const int lv = n_esc < 3 ? n_esc : 3;
+            const int pki = LC3_SPEC_LOOKUP(tctx[j] + lv * 1024);
+            const int sym = (int)((a4[j] >> n_esc) + 4u * (b4[j] >> n_esc));
+            const int lsb_here = lsb_mode && n_esc > 0;
+            const unsigned a_l = lsb_here ? a4[j] >> 1 : a4[j], b_l = lsb_here ? b4[j] >> 1 : b4[j];
+            const int s0 = q8[2 * j] <= 0, s1 = q8[2 * j + 1] <= 0;
+            const int nb = (int)(a_l > 0u) + (int)(b_l > 0u);
+            const int bits = a_l > 0u ? (s0 | (s1 << 1)) : s1;
+            plane[(EP_SYM + pos[j] + n_esc) * st] =
+                (int32_t)LC3_SYM_WORD((int)LC3T_AC_SPEC_CUMFREQ[pki][sym], (int)LC3T_AC_SPEC_FREQ[pki][sym], nb, bits);
+        }
+    }
+    // escape symbols, bit plane i of the pairs that have one (a wave-uniform trip count), coded with the table of level min(i, 3);
+    // each is followed by that plane's two bits unless the plane is the LSB plane of an lsb_mode frame (those go to the LSB list)
+    for (int i = 0; LC3_WAVE_ANY(esc_max > i); i++) {
+        const int lv = i < 3 ? i : 3;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (ne4[j] > i) {
+                const int pki = LC3_SPEC_LOOKUP(tctx[j] + lv * 1024);
+                const int nb = (lsb_mode && i == 0) ? 0 : 2;
+                const int bits = (int)((a4[j] >> i) & 1u) | ((int)((b4[j] >> i) & 1u) << 1);
+                plane[(EP_SYM + pos[j] + i) * st] =
+                    (int32_t)LC3_SYM_WORD((int)LC3T_AC_SPEC_CUMFREQ[pki][16], (int)LC3T_AC_SPEC_FREQ[pki][16], nb, bits);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // EncoderChannel::encode (encoder/lc3_encoder.rs:63-112): one frame of one stream on one wave.
 // pcm: nf samples in HBM (4-byte aligned); plane/plane_stride: this frame's column of the packer planes
 // (lc3_dev_enc_pack.h); nbytes selects the bitrate.  dbg (optional): float[3*480] stage dumps.
@@ -1815,6 +1913,8 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PA
         if (lane < 13) plane[(EP_RES + lane) * st] = (int32_t)LC3_RESW(L)[lane];  // residual bits as a bit mask
         for (int k = lane; k < c.ne / 2; k += LC3_WAVE)
             plane[(EP_XQ + k) * st] = (int32_t)(((uint32_t)(uint16_t)LC3_XQ(L)[2 * k]) | ((uint32_t)(uint16_t)LC3_XQ(L)[2 * k + 1] << 16));
+        if (L.spec_flags & LC3_LAUNCH_PREP_SYMBOLS) lc3_enc_symbols(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, plane, st);
+        else if (lane == 0) plane[EP_NSYM * st] = -1;
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 8);

@@ -15,11 +15,22 @@ enum {
     EP_BW = 0, EP_NBITS_BW, EP_LASTNZ_TRUNC, EP_LSB_MODE, EP_GG_IND, EP_NUM_TNS, EP_ORD0, EP_ORD1, EP_LPC_W,
     EP_PITCH_PRESENT, EP_LTPF_ACTIVE, EP_PITCH_INDEX, EP_IND_LF, EP_IND_HF, EP_SHAPE_J, EP_GIND, EP_LS_INDA,
     EP_JOINT, EP_NOISE, EP_RATE_FLAG, EP_N_RES,
+    EP_NSYM,                   // number of prepared spectral symbols in EP_SYM (-1: none, the packer derives them from EP_XQ)
+    EP_NLSBS,                  // with prepared symbols: the number of LSB-list bits the spectral data implies (:298-312)
     EP_RCI,                    // 16 words: TNS coefficient indices
     EP_RES = EP_RCI + 16,      // 13 words: residual bits, bit j of word j / 32
     EP_XQ = EP_RES + 13,       // 200 words: quantised spectrum, x_q[2k] | x_q[2k+1] << 16
-    EP_WORDS = EP_XQ + 200
+    EP_SYM = EP_XQ + 200,      // LC3_SYM_CAP words: the spectral data as the range coder will see it, one word per symbol (below)
+    EP_WORDS = EP_SYM + 448
 };
+// A prepared symbol (lc3_enc_symbols, wave-parallel in the analysis kernel: what spectral_data :246-326 codes does not depend on
+// the coder's state): model interval and the up to two bits that follow it backwards (escape: the pair's next bit plane; main
+// symbol: the signs of its non-zero values).  Only small launches prepare symbols: the analysis kernels of a full batch are
+// VALU-bound and the work costs them more (+0.10 ms per 65 536 frames) than it saves the packer (-0.03 ms); a launch that does
+// not fill the chip has the instruction slots to spare, and its packer -- a lane walking one frame, 0.14 ms whatever the launch
+// size -- takes half as long.
+#define LC3_SYM_CAP 448
+#define LC3_SYM_WORD(cum, freq, nb, bits) ((uint32_t)(cum) | ((uint32_t)(freq) << 10) | ((uint32_t)(nb) << 20) | ((uint32_t)(bits) << 22))
 
 
 struct lc3_pack_ctx {
@@ -271,7 +282,28 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
     LC3_PSTAMP(w, 2);
     // spectral_data :246-326
     int nlsbs = 0;
-    {
+    const int nsym = LC3_EPW(EP_NSYM);
+    if (LC3_WAVE_ANY(nsym >= 0)) {
+        // prepared symbols (small launches): interval, then its bits; the word three symbols ahead is requested every iteration
+        const int n = nsym > 0 ? nsym : 0, last = LC3_SYM_CAP - 1;
+        uint32_t s0 = (uint32_t)lc3_ep_get(w, EP_SYM), s1 = (uint32_t)lc3_ep_get(w, EP_SYM + 1), s2 = (uint32_t)lc3_ep_get(w, EP_SYM + 2),
+                 s3 = (uint32_t)lc3_ep_get(w, EP_SYM + 3);
+        for (int i = 0; LC3_WAVE_ANY(i < n); i++) {
+            if (i < n) {
+                lc3_pk_ac_encode_sel(w, s0 & 0x3ffu, (s0 >> 10) & 0x3ffu);
+                const int nb = (int)((s0 >> 20) & 3u);
+                lc3_pk_bool_backward_sel(w, nb > 0, (int)((s0 >> 22) & 1u));
+                lc3_pk_bool_backward_sel(w, nb > 1, (int)((s0 >> 23) & 1u));
+            }
+            s0 = s1;
+            s1 = s2;
+            s2 = s3;
+            s3 = (uint32_t)lc3_ep_get(w, EP_SYM + (i + 4 < last ? i + 4 : last));
+        }
+        nlsbs = nsym >= 0 ? LC3_EPW(EP_NLSBS) : 0;
+    }
+    if (LC3_WAVE_ANY(nsym < 0) && nsym < 0) {
+
         // One symbol per iteration and lane: every lane walks its own frame's symbol sequence (escape symbols of a pair,
         // then its main symbol) and moves on to its next pair by itself.  With a common pair index the wave spends
         // sum over pairs of (1 + deepest escape level of any lane) iterations, here max over lanes of (sum over pairs of

@@ -144,3 +144,6 @@ def test_emu_guarded_decisions_and_their_sequential_path(fs, us, nf, nbytes):
     ref = O.encode_batch(pcm, nbytes, fs, us)
     assert np.array_equal(E.encode(pcm, nbytes, fs, us), ref)
     assert np.array_equal(E.encode(pcm, nbytes, fs, us, spec_flags=256), ref)
+    # 512 (LC3_LAUNCH_PREP_SYMBOLS, what the host sets for launches that do not fill the chip): the analysis kernel prepares the
+    # packer's symbol words, the packer only runs the range coder over them
+    assert np.array_equal(E.encode(pcm, nbytes, fs, us, spec_flags=512), ref)

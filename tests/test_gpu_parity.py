@@ -632,6 +632,34 @@ def test_sequential_sum_path_of_guarded_decisions():
     assert r.returncode == 0 and "seq ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_prepared_packer_symbols_on_and_off():
+    """Launches of at most 1024 streams have the analysis kernel prepare the packer's symbol words (lc3_enc_symbols), larger ones
+    leave the derivation to the packer.  Both forms on the same launches, small and large (LC3GPU_PREP_SYMBOLS=0 / 1 overrides the
+    size rule), against the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, 'tests')\n"
+        "import test_gpu_parity as t\n"
+        "for nb in (150, 40, 300):\n"
+        "    t._roundtrip_check(48000, 10000, nb, 96, 6, seed=81)\n"
+        "for fs, us, nb in ((48000, 7500, 113), (24000, 10000, 60), (16000, 7500, 30), (32000, 10000, 400)):\n"
+        "    t._roundtrip_check(fs, us, nb, 64, 6, seed=82)\n"
+        "t._roundtrip_check(48000, 10000, 150, 2048, 2, seed=83)\n"
+        "t.test_mixed_configuration_batch()\n"
+        "for nb in (20, 25, 50, 80, 100, 140, 141, 160, 260, 399):\n"
+        "    t.test_bitrate_sweep_48k(nb)\n"
+        "print('prep ok')\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for v in ("0", "1"):
+        env = dict(os.environ, LC3GPU_PREP_SYMBOLS=v)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "prep ok" in r.stdout, v + r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_stress_parity_tool_small_run():
     """tools/stress_parity.py (the differential run whose full-size results are profiles/r02_stress_parity*.json: 7.3 M frames per
     direction over 14 configurations, none differing) at a size that takes seconds"""
