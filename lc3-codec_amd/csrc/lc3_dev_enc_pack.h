@@ -25,7 +25,7 @@ enum {
 };
 // A prepared symbol (lc3_enc_symbols, wave-parallel in the analysis kernel: what spectral_data :246-326 codes does not depend on
 // the coder's state): model interval and the up to two bits that follow it backwards (escape: the pair's next bit plane; main
-// symbol: the signs of its non-zero values).  Only small launches prepare symbols: the analysis kernels of a full batch are
+// symbol: the signs of its non-zero values).  Only launches of up to 16 384 frames prepare symbols: the analysis kernels of a full batch are
 // VALU-bound and the work costs them more (+0.10 ms per 65 536 frames) than it saves the packer (-0.03 ms); a launch that does
 // not fill the chip has the instruction slots to spare, and its packer -- a lane walking one frame, 0.14 ms whatever the launch
 // size -- takes half as long.

@@ -1190,14 +1190,16 @@ static unsigned lc3_frame_block(unsigned dflt) {
     return (env == 64 || env == 128 || env == 256) ? (unsigned)env : dflt;
 }
 // ... clamped so that the dynamic LDS (fixed part + per-frame part) fits the default 64 KB
-// LC3_LAUNCH_PREP_SYMBOLS for launches of at most 1024 streams (256 workgroups: one per compute unit, a quarter of what the analysis
-// kernels need to be VALU-bound), see lc3_dev_enc_pack.h; LC3GPU_PREP_SYMBOLS=0 / 1 forces it off / on (tests)
-static int lc3_prep_symbols_flag(size_t n_streams) {
+// LC3_LAUNCH_PREP_SYMBOLS for launches of at most 16 384 frames (lc3_dev_enc_pack.h): the preparation costs the back half
+// ~24 us per 16 384 frames and saves the packer ~40 us whatever the launch size (measured: 2048 x 1 frames 295 -> 264 us,
+// 16 384 x 1 486 -> 469 us, 16 384 x 4 1090 -> 1139 us for the four encoder kernels); LC3GPU_PREP_SYMBOLS=0 / 1 forces it
+// off / on (tests)
+static int lc3_prep_symbols_flag(size_t n_frames_total) {
     static const int forced = [] {
         const char *e = std::getenv("LC3GPU_PREP_SYMBOLS");
         return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
     }();
-    const bool on = forced >= 0 ? forced != 0 : n_streams <= 1024;
+    const bool on = forced >= 0 ? forced != 0 : n_frames_total <= 16384;
     return on ? LC3_LAUNCH_PREP_SYMBOLS : 0;
 }
 static unsigned lc3_frame_block_fit(size_t lds_fixed, size_t lds_per_frame) {
@@ -1424,7 +1426,7 @@ static int encode_launch(lc3gpu_encoder *e, const HostCfg &h, int first, int n, 
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
     LC3_LAUNCH_CFG(lc3_enc_back_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n,
-                       (const float *)e->d_mid, e->d_planes, nbytes, n_frames, dbg, e->spec_flags | lc3_prep_symbols_flag((size_t)n));
+                       (const float *)e->d_mid, e->d_planes, nbytes, n_frames, dbg, e->spec_flags | lc3_prep_symbols_flag(frames));
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
     const unsigned fpb = lc3_frame_block_fit(LC3_PACK_LDS_FIXED, (size_t)nbytes);
@@ -1496,7 +1498,7 @@ int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out,
     }
     e->timer.mark(stream);
     hipLaunchKernelGGL(lc3_enc_back_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states,
-                       (const float *)e->d_mid, e->d_planes, n_frames, e->spec_flags | lc3_prep_symbols_flag((size_t)e->num_channels));
+                       (const float *)e->d_mid, e->d_planes, n_frames, e->spec_flags | lc3_prep_symbols_flag((size_t)e->num_channels * (size_t)n_frames));
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream);
     const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)max_nbytes + 3) & ~(size_t)3) + 4;

@@ -633,7 +633,7 @@ def test_sequential_sum_path_of_guarded_decisions():
 
 
 def test_prepared_packer_symbols_on_and_off():
-    """Launches of at most 1024 streams have the analysis kernel prepare the packer's symbol words (lc3_enc_symbols), larger ones
+    """Launches of at most 16 384 frames have the analysis kernel prepare the packer's symbol words (lc3_enc_symbols), larger ones
     leave the derivation to the packer.  Both forms on the same launches, small and large (LC3GPU_PREP_SYMBOLS=0 / 1 overrides the
     size rule), against the oracle."""
     import os
