@@ -317,28 +317,243 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_L
 // it works on frame t, so the memory latency hides behind a frame's worth of work.
 struct lc3_plane_fetch { lc3_i4 u[2]; };
 template <class CC>
-__device__ __forceinline__ void lc3_dec_issue_frame(const CC &c, int lane, const int32_t *plane, lc3_plane_fetch &m) {
+__device__ __forceinline__ void lc3_dec_issue_frame(const CC &c, int lane, const int32_t *plane, lc3_plane_fetch &m, int late = 0) {
     LC3_HBM_CONST(lc3_i4) p4 = (LC3_HBM_CONST(lc3_i4))((LC3_HBM_CONST(int32_t))plane + LC3_PLANE_SI);
-    const int n4 = (LC3_PLANE_X - LC3_PLANE_SI) / 4 + c.ne / 4;
+    const int n4 = (LC3_PLANE_X - LC3_PLANE_SI) / 4 + c.ne / 4;  // <= 112
+    // late reconstruction: the residual bit mask (16 words at LC3_PLANE_LEV = unit 112) rides along on four otherwise idle lanes
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int i = lane + LC3_WAVE * u;
-        if (i < n4) m.u[u] = p4[i];
+        if (i < n4 || (late && i >= LC3_PLANE_LEV / 4 && i < LC3_PLANE_LEV / 4 + 4)) m.u[u] = p4[i];
     }
 }
 template <class CC>
-__device__ __forceinline__ int lc3_dec_load_frame(const CC &c, lc3_dec_lds &L, int lane, const lc3_plane_fetch &m) {
+__device__ __forceinline__ int lc3_dec_load_frame(const CC &c, lc3_dec_lds &L, int lane, const lc3_plane_fetch &m, int late = 0) {
     const int n_si4 = (LC3_PLANE_X - LC3_PLANE_SI) / 4, n4 = n_si4 + c.ne / 4;
+    static_assert(LC3_PLANE_X == 48 && LC3_PLANE_LEV == 448, "ism[48 .. 64) takes the residual bit mask of a late reconstruction");
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int i = lane + LC3_WAVE * u;
         if (i < n_si4) ((lc3_i4 *)L.ism)[i] = m.u[u];
         else if (i < n4) ((lc3_i4 *)L.spec)[i - n_si4] = m.u[u];
+        else if (late && i >= LC3_PLANE_LEV / 4 && i < LC3_PLANE_LEV / 4 + 4) ((lc3_i4 *)L.ism)[n_si4 + i - LC3_PLANE_LEV / 4] = m.u[u];
     }
     LC3_SYNC();
     const int ok = L.ism[AD_OK];
     LC3_SYNC();
     return ok;
+}
+
+// ------------------------------------------------------------------------------------------
+// D4-D8 for launches of a few frames, with the 64 lanes of the stream's wave instead of one lane of the parse kernel
+// (lc3_reconstruct_frame, lc3_dev_dec_parse.h, is the same arithmetic line by line: int -> f32, residual bit or noise value,
+// global gain, TNS synthesis, band gain).  Lane l owns lines 8l .. 8l+7; what the reference carries from line to line becomes
+// a prefix count: the rank of a non-zero line among the non-zero lines picks its residual bit, the rank of a noise-filled line
+// among the filled ones picks its LCG state (the LCG is affine mod 2^16: f^n in log n steps).  Only the TNS lattice stays a
+// walk over the lines (lane 0, frames with an active filter).
+// In: L.ism = side information + residual bit mask (ism[48..)), L.spec = the parsed integers.  Out: L.spec = shaped spectrum.
+// ------------------------------------------------------------------------------------------
+LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_reconstruct_wave(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int nbytes) {
+    LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
+    const int ne = c.ne, nbits = nbytes * 8;
+    const int lastnz = L.ism[SI_LASTNZ], gg_ind = L.ism[SI_GG], n_res = L.ism[AD_NRES], bw = L.ism[SI_BW];
+    const uint32_t *resw = (const uint32_t *)(L.ism + LC3_PLANE_X);
+    float *sc = (float *)L.fa;  // scratch until the IMDCT: scale factors [0, 16), band gains [16, 80)
+    lc3_recon_ctx r;
+    r.scf = sc;
+    r.sstride = 1;
+    r.mpvq = &LC3T_MPVQ_OFFSETS[0][0];
+    r.ifs = lc3_band_index(c);
+    // spectral_noise_shaping::decode (:21-73): the pulse vector on every lane (wave-uniform inputs), one scale factor per lane
+    {
+        int y[16];
+#pragma unroll
+        for (int n = 0; n < 16; n++) y[n] = 0;
+        const int shape_j = (L.ism[SI_SUB_MSB] << 1) + L.ism[SI_SUB_LSB];
+        const int ls_a = L.ism[SI_LS_A];
+        const uint32_t idx_a = (uint32_t)L.ism[SI_IDX_A];
+        if (shape_j == 0) {
+            lc3_r_deenum(r, 10, 10, ls_a, idx_a, y, 0);
+            lc3_r_deenum(r, 6, 1, L.ism[SI_LS_B], (uint32_t)L.ism[SI_IDX_B], y, 10);
+        } else if (shape_j == 1) lc3_r_deenum(r, 10, 10, ls_a, idx_a, y, 0);
+        else if (shape_j == 2) lc3_r_deenum(r, 16, 8, ls_a, idx_a, y, 0);
+        else lc3_r_deenum(r, 16, 6, ls_a, idx_a, y, 0);
+        float y_norm = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 16; n++) y_norm += (float)y[n] * (float)y[n];
+        y_norm = lc3_sqrtf(y_norm);
+        float gain;
+        const int gi = L.ism[SI_G_IND];
+        if (shape_j == 0) gain = lc3_f(LC3T_SNS_VQ_REG_ADJ_GAINS_BITS, gi & 1);
+        else if (shape_j == 1) gain = lc3_f(LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS, gi & 3);
+        else if (shape_j == 2) gain = lc3_f(LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS, gi & 3);
+        else gain = lc3_f(LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS, gi & 7);
+        if (y_norm != 0.0f) gain /= y_norm;
+        const int ind_lf = L.ism[SI_IND_LF], ind_hf = L.ism[SI_IND_HF];
+        const int n = lane & 15;
+        float factor = 0.0f;
+#pragma unroll
+        for (int col = 0; col < 16; col++) factor += (float)y[col] * lc3_f(&LC3T_D_BITS[n][0], col);
+        const float st1 = n < 8 ? lc3_f(&LC3T_LFCB_BITS[ind_lf][0], n) : lc3_f(&LC3T_HFCB_BITS[ind_hf][0], n - 8);
+        if (lane < 16) sc[n] = st1 + gain * factor;
+    }
+    LC3_SYNC();
+    if (lane < c.nb) sc[16 + lane] = lc3_r_band_gain(r, lane, c.nb);
+    // global gain :15-25
+    float gg;
+    {
+        const int fs = c.fs_ind + 1, q = nbits / (10 * fs);
+        const int gg_off = -(q < 115 ? q : 115) - 105 - (5 * fs);
+        gg = LC3_POW10_GG(gg_ind + gg_off);
+    }
+    // the lane's eight lines (integers; words at and beyond lastnz are stale)
+    const int k0 = 8 * lane;
+    int32_t xi[8];
+    {
+        const lc3_i4 a = ((const lc3_i4 *)L.spec)[2 * lane], b = ((const lc3_i4 *)L.spec)[2 * lane + 1];
+        int32_t w[8];
+        __builtin_memcpy(w, &a, 16);
+        __builtin_memcpy(w + 4, &b, 16);
+#pragma unroll
+        for (int j = 0; j < 8; j++) xi[j] = k0 + j < lastnz ? w[j] : 0;
+    }
+    uint32_t nzmask = 0, absk = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        nzmask |= (uint32_t)(xi[j] != 0) << j;
+        absk += (uint32_t)(xi[j] < 0 ? -xi[j] : xi[j]) * (uint32_t)(k0 + j);
+    }
+    // noise-filling seed :140-145 (a wrapping integer sum: any order) and the zero-frame flag :147-151
+    uint32_t lcg = lc3_wave_sum_u32(absk, lane) & 0xFFFFu;
+    const int x0 = lc3_wave_read_i32(xi[0], 0, lane), x1 = lc3_wave_read_i32(xi[1], 0, lane);
+    const int do_fill = !(lastnz == 2 && x0 == 0 && x1 == 0 && gg_ind == 0);
+    // noise filling :18-56: lines with an all-zero neighbourhood (lines at or beyond bw_stop count as zero, none below line 0)
+    const int bw_stop = c.n_ms_10 ? LC3C_BWSTOP10[bw] : LC3C_BWSTOP75[bw];
+    const int nf_start = c.n_ms_10 ? 24 : 18, nf_width = c.n_ms_10 ? 3 : 2;
+    const int lim = bw_stop < ne ? bw_stop : ne;
+    const float level = (8.0f - (float)L.ism[SI_NF]) / 16.0f;
+#define LC3_BITS_BELOW(n) ((n) <= 0 ? 0u : ((n) >= 8 ? 0xffu : (1u << (n)) - 1u))
+    uint32_t fillmask;
+    {
+        const uint32_t nzw = nzmask & LC3_BITS_BELOW(bw_stop - k0);
+        const uint32_t prev = (uint32_t)lc3_wave_shr1_i32((int)nzw, lane), next = (uint32_t)lc3_wave_shl1_i32((int)nzw, lane);
+        const uint32_t nz14 = (prev >> 5) | (nzw << 3) | ((next & 7u) << 11);  // bit i <-> line k0 - 3 + i
+        uint32_t any;
+        if (nf_width == 3) {  // bits j .. j+6
+            const uint32_t a = nz14 | (nz14 >> 1), b = a | (a >> 2);
+            any = b | (b >> 3);
+        } else {              // bits j+1 .. j+5
+            const uint32_t n1 = nz14 >> 1, a = n1 | (n1 >> 1), b = a | (a >> 2);
+            any = b | (n1 >> 4);
+        }
+        fillmask = do_fill ? (~any & LC3_BITS_BELOW(lim - k0) & ~LC3_BITS_BELOW(nf_start - k0) & 0xffu) : 0u;
+    }
+#undef LC3_BITS_BELOW
+    // the LCG state before the lane's first filled line: f^R(seed), f(x) = 13849 + 31821 x mod 2^16, R = filled lines below
+    {
+        uint32_t R = lc3_wave_exscan_u32((uint32_t)__builtin_popcount(fillmask), lane);
+        uint32_t pa = 31821u, pc = 13849u, A = 1u, C = 0u;  // f^(2^i) = pa x + pc; accumulated map A x + C
+        for (int i = 0; i < 9; i++) {  // R < 512
+            if (R & 1u) {
+                A = (pa * A) & 0xFFFFu;
+                C = (pa * C + pc) & 0xFFFFu;
+            }
+            pc = (pa * pc + pc) & 0xFFFFu;
+            pa = (pa * pa) & 0xFFFFu;
+            R >>= 1;
+        }
+        lcg = (A * lcg + C) & 0xFFFFu;
+    }
+    int rank_nz = (int)lc3_wave_exscan_u32((uint32_t)__builtin_popcount(nzmask), lane);
+    float v8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        float v = (float)xi[j];
+        {   // residual_spectrum::decode: the j-th non-zero line takes residual bit j while j < n_res
+            const int nz = (int)((nzmask >> j) & 1u), take = nz && rank_nz < n_res;
+            const int rr = take ? rank_nz : 0;
+            const int bit = (int)((resw[rr >> 5] >> (rr & 31)) & 1u);
+            const float up = v > 0.0f ? 0.3125f : 0.1875f, dn = v > 0.0f ? 0.1875f : 0.3125f;
+            const float v_adj = bit ? v + up : v - dn;
+            v = take ? v_adj : v;
+            rank_nz += nz;
+        }
+        {
+            const int fill = (int)((fillmask >> j) & 1u);
+            const uint32_t lcg_n = (13849u + lcg * 31821u) & 0xFFFFu;
+            lcg = fill ? lcg_n : lcg;
+            v = fill ? (lcg_n < 0x8000u ? level : -level) : v;
+        }
+        v8[j] = v * gg;
+    }
+    // TNS :24-137
+    const int nbands = bw < 3 ? 1 : 2, num_tns = L.ism[SI_NUM_TNS];
+    const int ord0 = (0 < nbands && 0 < num_tns) ? L.ism[AD_ORD0] : 0;
+    const int ord1 = (1 < nbands && 1 < num_tns) ? L.ism[AD_ORD0 + 1] : 0;
+    LC3_SYNC();  // every lane holds its lines: L.spec may be overwritten
+    if (ord0 > 0 || ord1 > 0) {  // wave-uniform
+        if (k0 < ne) {
+            lc3_f4 o0, o1;
+            o0.x = v8[0]; o0.y = v8[1]; o0.z = v8[2]; o0.w = v8[3];
+            o1.x = v8[4]; o1.y = v8[5]; o1.z = v8[6]; o1.w = v8[7];
+            ((lc3_f4 *)L.spec)[2 * lane] = o0;
+            ((lc3_f4 *)L.spec)[2 * lane + 1] = o1;
+        }
+        LC3_SYNC();
+        if (lane == 0) {  // the all-pole lattice, its state shared across the two filters
+            float st[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            for (int f = 0; f < nbands; f++) {
+                const int order = f == 0 ? ord0 : ord1;
+                if (order == 0) continue;
+                const int lo = c.n_ms_10 ? LC3C_TNSDEC10[bw][2 * f] : LC3C_TNSDEC75[bw][2 * f];
+                const int hi = c.n_ms_10 ? LC3C_TNSDEC10[bw][2 * f + 1] : LC3C_TNSDEC75[bw][2 * f + 1];
+                float rq[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int ri = L.ism[AD_RCI + 8 * f + q];
+                    rq[q] = ri != 0 ? LC3_TNS_SIN_DEC(ri) : 0.0f;  // sin(step * (ri - 8)); SURVEY A12
+                }
+                for (int k = lo; k < hi; k++) {
+                    float t = L.spec[k];
+#pragma unroll
+                    for (int q = 7; q >= 0; q--) {
+                        const float t2 = t - rq[q] * st[q];
+                        t = q < order ? t2 : t;
+                        if (q < 7) {
+                            const float sn = rq[q] * t + st[q];
+                            st[q + 1] = q + 1 < order ? sn : st[q + 1];
+                        }
+                    }
+                    L.spec[k] = t;
+                    st[0] = t;
+                }
+            }
+        }
+        LC3_SYNC();
+        if (k0 < ne) {
+            const lc3_f4 i0 = ((const lc3_f4 *)L.spec)[2 * lane], i1 = ((const lc3_f4 *)L.spec)[2 * lane + 1];
+            v8[0] = i0.x; v8[1] = i0.y; v8[2] = i0.z; v8[3] = i0.w;
+            v8[4] = i1.x; v8[5] = i1.y; v8[6] = i1.z; v8[7] = i1.w;
+        }
+        LC3_SYNC();
+    }
+    // SNS :113-151: the band gain of each line
+    if (k0 < ne) {
+        const uint8_t *lb = c.line_band + k0;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int b = k0 + j < c.nf ? (int)lb[j] : 255;
+            o[j] = v8[j] * sc[16 + (b < 64 ? b : 0)];
+        }
+        lc3_f4 o0, o1;
+        o0.x = o[0]; o0.y = o[1]; o0.z = o[2]; o0.w = o[3];
+        o1.x = o[4]; o1.y = o[5]; o1.z = o[6]; o1.w = o[7];
+        ((lc3_f4 *)L.spec)[2 * lane] = o0;
+        ((lc3_f4 *)L.spec)[2 * lane + 1] = o1;
+    }
+    LC3_SYNC();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -396,11 +611,12 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_plc_load(LC3_CFG_PARAM, L
 // plc_src / save_good: see lc3_decode_stream_wave.  Returns 1 for a good frame, 0 for a concealed one.
 LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes,
                                                       int16_t *pcm_out, const lc3_plane_fetch &fetched, lc3_dec_state *g,
-                                                      int valid, int stride, const float *plc_src, int save_good, lc3_ola5 &ola) {
+                                                      int valid, int stride, const float *plc_src, int save_good, lc3_ola5 &ola, int late = 0) {
     LC3_CFG_BIND;
     const int nf = c.nf, nbits = nbytes * 8;
     LC3_STAMP(L, lane, 16);
-    const int ok = lc3_dec_load_frame(c, L, lane, fetched);
+    const int ok = lc3_dec_load_frame(c, L, lane, fetched, late);
+    if (ok && late) lc3_dec_reconstruct_wave(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes);  // launches of a few frames: D4-D8 here
     LC3_STAMP(L, lane, 17);
     int ltpf_active = 0, pitch_index = 0;
     if (ok) {
@@ -468,25 +684,27 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
 // Frame t's samples go to pcm0 + t * frame_step, `stride` elements apart.
 LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_stream_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes, const int32_t *planes,
                                                        size_t fbase, int n_frames, lc3_dec_state *g, int valid, int16_t *pcm0,
-                                                       size_t frame_step, int stride) {
+                                                       size_t frame_step, int stride, int late = 0) {
     LC3_CFG_BIND;
     const auto &c0 = c;
     lc3_plane_fetch cur, nxt;
-    if (n_frames > 0) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, fbase, LC3_PLANE_WORDS), cur);
+    // late: the plane columns hold integers (lc3_dec_reconstruct_wave): the last good SPECTRUM of the stream is then kept in the
+    // state blob by every good frame
+    if (n_frames > 0) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, fbase, LC3_PLANE_WORDS), cur, late);
     int t_good = -1, last_ok = 1;
     lc3_ola5 ola = lc3_dec_ola_load(c0, lane, g);
     for (int t = 0; t < n_frames; t++) {
         const size_t f = fbase + (size_t)t;
-        if (t + 1 < n_frames) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, f + 1, LC3_PLANE_WORDS), nxt);
+        if (t + 1 < n_frames) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, f + 1, LC3_PLANE_WORDS), nxt, late);
         int16_t *out = pcm0 + (size_t)t * frame_step;
-        const float *plc_src = t_good >= 0 ? (const float *)(LC3_PLANE_COL(planes, fbase + (size_t)t_good, LC3_PLANE_WORDS) + LC3_PLANE_X * LC3_PLANE_STRIDE)
+        const float *plc_src = (t_good >= 0 && !late) ? (const float *)(LC3_PLANE_COL(planes, fbase + (size_t)t_good, LC3_PLANE_WORDS) + LC3_PLANE_X * LC3_PLANE_STRIDE)
                                            : (const float *)g->plc_last_good;
-        last_ok = lc3_decode_frame_wave(LC3_CFG_PASS, L, lane, nbytes, out, cur, g, valid, stride, plc_src, t == n_frames - 1, ola);
+        last_ok = lc3_decode_frame_wave(LC3_CFG_PASS, L, lane, nbytes, out, cur, g, valid, stride, plc_src, late || t == n_frames - 1, ola, late);
         if (last_ok) t_good = t;
         cur = nxt;
     }
     lc3_dec_ola_store(c0, lane, g, valid, ola);
-    if (valid && !last_ok && t_good >= 0) {  // the launch ended in a lost frame: its last good spectrum moves to the state blob
+    if (valid && !last_ok && t_good >= 0 && !late) {  // the launch ended in a lost frame: its last good spectrum moves to the state blob
         LC3_HBM_CONST(float) src = (LC3_HBM_CONST(float))(LC3_PLANE_COL(planes, fbase + (size_t)t_good, LC3_PLANE_WORDS) + LC3_PLANE_X * LC3_PLANE_STRIDE);
         for (int k = lane; k < c0.ne; k += LC3_WAVE) g->plc_last_good[k] = src[k];
     }

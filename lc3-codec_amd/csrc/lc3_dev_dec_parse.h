@@ -531,6 +531,37 @@ __device__ __forceinline__ float lc3_r_band_gain(const lc3_recon_ctx &r, int bi,
     return lc3_exp2_raw(sf);
 }
 
+// Launches of a few frames leave the reconstruction to the synthesis kernel, which does it with the 64 lanes of the stream's wave
+// (lc3_dec_reconstruct_wave, lc3_dev_dec.h): a lane walking the 400 lines of one frame alone takes 0.13 ms whatever the launch
+// size.  What only this kernel can supply is checked / extracted here: the residual-bit count and its bounds (:168-183) and the
+// residual bits themselves, tail bits tail0 .. tail0 + n_res - 1 of the frame, as a bit mask in the (then unused) level words.
+// Returns 1 when the frame is usable.
+__device__ __forceinline__ int lc3_reconstruct_prepare_late(lc3_parse_ctx &c) {
+    const int nbytes = c.len;
+    const int lsb_mode = lc3_px_get(c, SI_LSB_MODE), tail0 = lc3_px_get(c, AD_TAIL0), nres_max = lc3_px_get(c, AD_NRES_MAX),
+              head = lc3_px_get(c, AD_HEAD);
+    int n_res = 0;
+    if (!lsb_mode) {
+        n_res = (int)c.nnz < nres_max ? (int)c.nnz : nres_max;
+        if (n_res > 480) return 0;  // ResidualBoolDataOverflow (Vec<bool, 480>)
+        if (n_res > 0) {
+            const int last_byte = (tail0 + n_res - 1) / 8;
+            if (nbytes - head - last_byte + 2 < 0) return 0;
+            if (nbytes - last_byte - 1 < 0) return 0;
+        }
+        for (int w = 0; 32 * w < n_res; w++) {
+            uint32_t bits = 0;
+            for (int j = 0; j < 32 && 32 * w + j < n_res; j++) {
+                const int pos = tail0 + 32 * w + j;
+                bits |= (((uint32_t)c.bytes[nbytes - 1 - (pos >> 3)] >> (pos & 7)) & 1u) << j;
+            }
+            lc3_px_set(c, LC3_PLANE_LEV + w, (int32_t)bits);
+        }
+    }
+    lc3_px_set(c, AD_NRES, n_res);
+    return 1;
+}
+
 template <class CC>
 __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3_recon_ctx &r, const CC &cfg) {
     const int ne = cfg.ne, nbytes = c.len, nbits = nbytes * 8;

@@ -149,7 +149,7 @@ struct Job {
     int lane, wave, valid;
     int encode;   // 0 decode, 1 encoder front half, 2 encoder back half
     float *mid;   // mid planes of the whole batch (encoder)
-    int n_frames, nbytes, fresh, spec_flags;
+    int n_frames, nbytes, fresh, spec_flags, late;
     lc3_enc_lds *EL;  // the workgroup's array of working sets
     lc3_dec_lds *DL;
     lc3_enc_state *est;   // this stream's state blob
@@ -204,7 +204,7 @@ void *lane_main(void *arg) {
         lc3_dec_lds &L = j->DL[j->wave];
         if (j->fresh) lc3_dec_state_init(L, lane, j->dst, j->valid);
         else lc3_dec_state_load(L, lane, j->dst);
-        lc3_decode_stream_wave(j->cfg, L, lane, j->nbytes, j->planes, j->frame0, j->n_frames, j->dst, j->valid, j->pcm_out, (size_t)j->cfg.nf, 1);
+        lc3_decode_stream_wave(j->cfg, L, lane, j->nbytes, j->planes, j->frame0, j->n_frames, j->dst, j->valid, j->pcm_out, (size_t)j->cfg.nf, 1, j->late);
         if (j->valid) lc3_dec_state_store(L, lane, j->dst);
     }
     return 0;
@@ -328,8 +328,15 @@ int lc3emu_encode_spec(int fs_hz, int frame_us, int nbytes, int S, int T, const 
     }
     return 0;
 }
+int lc3emu_decode_late(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8_t *bytes, const uint8_t *bad, int16_t *pcm,
+                       int late);
 int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8_t *bytes, const uint8_t *bad,
                   int16_t *pcm) {
+    return lc3emu_decode_late(fs_hz, frame_us, nbytes, S, T, bytes, bad, pcm, 0);
+}
+// late = 1: the reconstruction runs in the synthesis stage (what the library does for launches of a few frames)
+int lc3emu_decode_late(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8_t *bytes, const uint8_t *bad, int16_t *pcm,
+                       int late) {
     Job j;
     memset(&j, 0, sizeof(j));
     lc3_host_plan pl;
@@ -337,6 +344,10 @@ int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8
     j.cfg.fft_tw = pl.fft_tw.data();
     j.cfg.dct_tw = pl.dct_tw.data();
     j.cfg.perm = pl.perm.data();
+    std::vector<uint8_t> lb((size_t)j.cfg.nf);
+    for (int k = 0; k < j.cfg.nf; k++) lb[(size_t)k] = (uint8_t)lc3_line_band_value(j.cfg, k);
+    j.cfg.line_band = lb.data();
+    j.late = late;
     j.encode = 0;
     j.n_frames = T;
     j.nbytes = nbytes;
@@ -361,7 +372,8 @@ int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8
         c.tail = 0;
         int rc = (bad && bad[f]) ? -100 : lc3_parse_frame(c, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10);
         int ok = rc == 0;
-        if (ok) {  // the same lane rebuilds the spectrum (lc3_parse_kernel)
+        if (ok && late) ok = lc3_reconstruct_prepare_late(c);
+        else if (ok) {  // the same lane rebuilds the spectrum (lc3_parse_kernel)
             float scf[16];
             lc3_recon_ctx r;
             r.scf = scf;

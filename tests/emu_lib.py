@@ -49,12 +49,12 @@ def encode(pcm, nbytes, fs_hz=48000, frame_us=10000, dbg=None, spec_flags=0):
     return out
 
 
-def decode(data, nf, fs_hz=48000, frame_us=10000, bad=None):
+def decode(data, nf, fs_hz=48000, frame_us=10000, bad=None, late=0):
     data = np.ascontiguousarray(data, np.uint8)
     S, T, nbytes = data.shape
     out = np.zeros((S, T, nf), np.int16)
     if bad is not None:
         bad = np.ascontiguousarray(bad, np.uint8)
-    rc = lib().lc3emu_decode(fs_hz, frame_us, nbytes, S, T, _p(data), _p(bad), _p(out))
+    rc = lib().lc3emu_decode_late(fs_hz, frame_us, nbytes, S, T, _p(data), _p(bad), _p(out), int(late))
     assert rc == 0
     return out

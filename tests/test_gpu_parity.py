@@ -676,6 +676,38 @@ def test_stress_parity_tool_small_run():
     assert line["frames_differing"] == 0 and line["total_frames_each_direction"] == 14 * 96 * 5
 
 
+def test_late_reconstruction_on_and_off():
+    """Launches of at most 16 384 frames rebuild the spectrum in the synthesis kernel with the wave's 64 lanes
+    (lc3_dec_reconstruct_wave), larger ones in the parse kernel with one lane per frame (lc3_reconstruct_frame).  Both forms on
+    the same launches (LC3GPU_LATE_RECON=0 / 1 overrides the size rule): clean, corrupted, flagged and garbage streams."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, 'tests')\n"
+        "import test_gpu_parity as t\n"
+        "for nb in (150, 40, 300, 20, 400):\n"
+        "    t._roundtrip_check(48000, 10000, nb, 96, 6, seed=91)\n"
+        "for fs, us, nb in ((48000, 7500, 113), (24000, 10000, 60), (16000, 7500, 30), (32000, 10000, 80), (44100, 10000, 100)):\n"
+        "    t._roundtrip_check(fs, us, nb, 64, 6, seed=92)\n"
+        "t._roundtrip_check(48000, 10000, 150, 2048, 2, seed=93)\n"
+        "t.test_corrupt_frames_are_concealed_like_the_reference()\n"
+        "t.test_bad_frame_flag_forces_concealment()\n"
+        "t.test_random_garbage_streams()\n"
+        "t.test_mixed_configuration_batch()\n"
+        "t.test_mixed_batch_bad_frames_and_plc_counter()\n"
+        "t.test_ltpf_transitions(48000, 10000, 40)\n"
+        "t.test_ltpf_transitions(16000, 10000, 40)\n"
+        "print('late ok')\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for v in ("0", "1"):
+        env = dict(os.environ, LC3GPU_LATE_RECON=v)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "late ok" in r.stdout, v + r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ---------------------------------------------------------------- SURVEY section 8 row f3: spec-conformant switches
 def _gpu_encode_spec(pcm, nbytes, fs, us, flags):
     torch = torch_mod()
