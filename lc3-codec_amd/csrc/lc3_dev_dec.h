@@ -344,6 +344,53 @@ __device__ __forceinline__ int lc3_dec_load_frame(const CC &c, lc3_dec_lds &L, i
     return ok;
 }
 
+// TNS synthesis (decoder/temporal_noise_shaping.rs:60-137) of lines [lo, hi) in place with a filter of ORDER stages:
+//   t = x - rc[ORDER-1] * st[ORDER-1];  q = ORDER-2 .. 0: t -= rc[q] * st[q]; st[q+1] = rc[q] * t + st[q];  x = st[0] = t
+// four lines per LDS round trip (the ranges are multiples of four lines long and start at a multiple of four, except 7.5 ms
+// frames whose start 9 is handled line by line)
+template <int ORDER>
+__device__ __forceinline__ void lc3_dec_tns_lattice(float *x, int lo, int hi, const float (&rq)[8], float (&st)[8]) {
+    int k = lo;
+    for (; k < hi && (k & 3) != 0; k++) {
+        float t = x[k];
+#pragma unroll
+        for (int q = ORDER - 1; q >= 0; q--) {
+            t = t - rq[q] * st[q];
+            if (q < ORDER - 1) st[q + 1] = rq[q] * t + st[q];
+        }
+        x[k] = t;
+        st[0] = t;
+    }
+    for (; k + 4 <= hi; k += 4) {
+        const lc3_f4 in = *(const lc3_f4 *)(x + k);
+        float v[4] = {in.x, in.y, in.z, in.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float t = v[u];
+#pragma unroll
+            for (int q = ORDER - 1; q >= 0; q--) {
+                t = t - rq[q] * st[q];
+                if (q < ORDER - 1) st[q + 1] = rq[q] * t + st[q];
+            }
+            v[u] = t;
+            st[0] = t;
+        }
+        lc3_f4 o;
+        o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+        *(lc3_f4 *)(x + k) = o;
+    }
+    for (; k < hi; k++) {
+        float t = x[k];
+#pragma unroll
+        for (int q = ORDER - 1; q >= 0; q--) {
+            t = t - rq[q] * st[q];
+            if (q < ORDER - 1) st[q + 1] = rq[q] * t + st[q];
+        }
+        x[k] = t;
+        st[0] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // D4-D8 for launches of a few frames, with the 64 lanes of the stream's wave instead of one lane of the parse kernel
 // (lc3_reconstruct_frame, lc3_dev_dec_parse.h, is the same arithmetic line by line: int -> f32, residual bit or noise value,
@@ -514,19 +561,16 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_reconstruct_wave(LC3_CFG_
                     const int ri = L.ism[AD_RCI + 8 * f + q];
                     rq[q] = ri != 0 ? LC3_TNS_SIN_DEC(ri) : 0.0f;  // sin(step * (ri - 8)); SURVEY A12
                 }
-                for (int k = lo; k < hi; k++) {
-                    float t = L.spec[k];
-#pragma unroll
-                    for (int q = 7; q >= 0; q--) {
-                        const float t2 = t - rq[q] * st[q];
-                        t = q < order ? t2 : t;
-                        if (q < 7) {
-                            const float sn = rq[q] * t + st[q];
-                            st[q + 1] = q + 1 < order ? sn : st[q + 1];
-                        }
-                    }
-                    L.spec[k] = t;
-                    st[0] = t;
+                // the order is the same for every line of a filter: one straight-line body per order (no per-stage selects)
+                switch (order) {
+                case 1: lc3_dec_tns_lattice<1>(L.spec, lo, hi, rq, st); break;
+                case 2: lc3_dec_tns_lattice<2>(L.spec, lo, hi, rq, st); break;
+                case 3: lc3_dec_tns_lattice<3>(L.spec, lo, hi, rq, st); break;
+                case 4: lc3_dec_tns_lattice<4>(L.spec, lo, hi, rq, st); break;
+                case 5: lc3_dec_tns_lattice<5>(L.spec, lo, hi, rq, st); break;
+                case 6: lc3_dec_tns_lattice<6>(L.spec, lo, hi, rq, st); break;
+                case 7: lc3_dec_tns_lattice<7>(L.spec, lo, hi, rq, st); break;
+                default: lc3_dec_tns_lattice<8>(L.spec, lo, hi, rq, st); break;
                 }
             }
         }

@@ -738,10 +738,12 @@ __global__ __launch_bounds__(256) void lc3_parse_mixed_kernel(lc3_groups G, cons
                                     T, g.first_stream, io, late);
 }
 
-template <class CV>
+// LATE: the launch reconstructs the spectrum here (lc3_dec_reconstruct_wave) -- a compile-time switch, so that the kernels of full
+// batches carry none of it
+template <class CV, int LATE>
 __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned wg, lc3_dec_state *states, int first_channel,
                                                 int n_streams, const int32_t *planes, int16_t *pcm, int nbytes, int n_frames,
-                                                int fresh, lc3_io io, int late) {
+                                                int fresh, lc3_io io) {
     const int lane = threadIdx.x & 63, wave = LC3_WAVE_ID();
     lc3_dec_lds &L = lc3_dec_wg[wave];
     const int s_raw = (int)wg * LC3_WG_WAVES + wave;
@@ -758,7 +760,7 @@ __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned w
     const size_t fbase = (size_t)s * (size_t)n_frames;
     int stride;
     int16_t *pcm0 = (int16_t *)lc3_io_pcm(io, pcm, nf, first_channel, s, 0, n_frames, &stride);
-    lc3_decode_stream_wave(cfg, L, lane, nbytes, planes, fbase, n_frames, gst, valid, pcm0, (size_t)nf * (size_t)stride, stride, late);
+    lc3_decode_stream_wave(cfg, L, lane, nbytes, planes, fbase, n_frames, gst, valid, pcm0, (size_t)nf * (size_t)stride, stride, LATE);
     LC3_PROF_MARK(L, lane, 39);  // frames (incl. everything between the stage stamps)
     if (valid) lc3_dec_state_store(L, lane, gst);
     LC3_PROF_END(L, lane, 35);
@@ -767,20 +769,37 @@ template <class CV>
 __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_kernel(lc3_cfg_slot<CV> cfg, lc3_dec_state *states,
                                                                           int first_channel, int n_streams, const int32_t *planes,
                                                                           int16_t *pcm, int nbytes, int n_frames, int fresh,
-                                                                          lc3_io io, int late) {
-    lc3_decode_body<CV>(cfg, blockIdx.x, states, first_channel, n_streams, planes, pcm, nbytes, n_frames, fresh, io, late);
+                                                                          lc3_io io) {
+    lc3_decode_body<CV, 0>(cfg, blockIdx.x, states, first_channel, n_streams, planes, pcm, nbytes, n_frames, fresh, io);
 }
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_mixed_kernel(lc3_groups G, lc3_dec_state *states,
-                                                                                const int32_t *planes, int16_t *pcm, int n_frames,
-                                                                                int fresh, lc3_io io, int late) {
+template <class CV>
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_late_kernel(lc3_cfg_slot<CV> cfg, lc3_dec_state *states,
+                                                                               int first_channel, int n_streams, const int32_t *planes,
+                                                                               int16_t *pcm, int nbytes, int n_frames, int fresh,
+                                                                               lc3_io io) {
+    lc3_decode_body<CV, 1>(cfg, blockIdx.x, states, first_channel, n_streams, planes, pcm, nbytes, n_frames, fresh, io);
+}
+template <int LATE>
+__device__ __forceinline__ void lc3_decode_mixed_body(const lc3_groups &G, lc3_dec_state *states, const int32_t *planes, int16_t *pcm,
+                                                      int n_frames, int fresh, lc3_io io) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
     const int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
     if (g.fixed)
-        lc3_decode_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
-                                       g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io, late);
+        lc3_decode_body<lc3_cfg_48k10, LATE>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
+                                             g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io);
     else
-        lc3_decode_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams,
-                                     p, pcm, g.nbytes, n_frames, fresh, io, late);
+        lc3_decode_body<lc3_cfg_any, LATE>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
+                                           g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io);
+}
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_mixed_kernel(lc3_groups G, lc3_dec_state *states,
+                                                                                const int32_t *planes, int16_t *pcm, int n_frames,
+                                                                                int fresh, lc3_io io) {
+    lc3_decode_mixed_body<0>(G, states, planes, pcm, n_frames, fresh, io);
+}
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_mixed_late_kernel(lc3_groups G, lc3_dec_state *states,
+                                                                                     const int32_t *planes, int16_t *pcm, int n_frames,
+                                                                                     int fresh, lc3_io io) {
+    lc3_decode_mixed_body<1>(G, states, planes, pcm, n_frames, fresh, io);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1203,14 +1222,17 @@ static int lc3_prep_symbols_flag(size_t n_frames_total) {
     const bool on = forced >= 0 ? forced != 0 : n_frames_total <= 16384;
     return on ? LC3_LAUNCH_PREP_SYMBOLS : 0;
 }
-// Launches of at most this many frames reconstruct the spectrum in the synthesis kernel (lc3_dec_reconstruct_wave) instead of the
-// parse kernel: LC3GPU_LATE_RECON=0 / 1 forces it off / on (tests)
-static int lc3_late_reconstruction(size_t n_frames_total) {
+// Launches of a few frames reconstruct the spectrum in the synthesis kernel (lc3_dec_reconstruct_wave) instead of the parse kernel:
+// the parser then takes 0.22 instead of 0.36 ms whatever the launch size, the synthesis kernel 20 - 35 us more per frame of a
+// stream (its frames run one after the other; the lane-0 TNS lattice of a frame with an active filter is most of it).  Measured
+// (parse + synthesis, us): 1 x 1 frames 301 -> 157, 1024 x 1 361 -> 260, 4096 x 4 402 -> 354, 1024 x 16 428 -> 469.
+// LC3GPU_LATE_RECON=0 / 1 forces it off / on (tests)
+static int lc3_late_reconstruction(size_t n_frames_total, int frames_per_stream) {
     static const int forced = [] {
         const char *e = std::getenv("LC3GPU_LATE_RECON");
         return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
     }();
-    return forced >= 0 ? forced : (n_frames_total <= 16384 ? 1 : 0);
+    return forced >= 0 ? forced : ((n_frames_total <= 16384 && frames_per_stream <= 4) ? 1 : 0);
 }
 static unsigned lc3_frame_block_fit(size_t lds_fixed, size_t lds_per_frame) {
     unsigned fpb = lc3_frame_block(256u);
@@ -1596,13 +1618,13 @@ static int decoder_init_states(lc3gpu_decoder *d) {
     if (!d->mixed) {
         LC3_LAUNCH_CFG(lc3_decode_kernel, d->h, dim3((unsigned)((d->num_channels + LC3_WG_WAVES - 1) / LC3_WG_WAVES)),
                        dim3(64 * LC3_WG_WAVES), 0, nullptr, d->d_states, 0, d->num_channels, (const int32_t *)d->d_planes, d->d_pcm1, 20,
-                       0, 1, io, 0);
+                       0, 1, io);
         HIP_TRY(hipGetLastError());
     } else {
         for (const GroupHost &g : d->groups) {
             LC3_LAUNCH_CFG(lc3_decode_kernel, g.h, dim3((unsigned)((g.n_streams + LC3_WG_WAVES - 1) / LC3_WG_WAVES)),
                            dim3(64 * LC3_WG_WAVES), 0, nullptr, d->d_states, g.first_stream, g.n_streams, (const int32_t *)d->d_planes,
-                           d->d_pcm1, 20, 0, 1, io, 0);
+                           d->d_pcm1, 20, 0, 1, io);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1689,14 +1711,18 @@ static int decode_launch(lc3gpu_decoder *d, const HostCfg &h, int first, int n, 
     // frame data per frame)
     const unsigned fpb = lc3_frame_block_fit(LC3_PARSE_LDS_FIXED, (size_t)(64 + nbytes));
     const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes);
-    const int late = lc3_late_reconstruction(frames);
+    const int late = lc3_late_reconstruction(frames, n_frames);
     d->timer.mark(stream);
     LC3_LAUNCH_CFG(lc3_parse_kernel, h, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream,
                        d_in, d_bad, d->d_planes, nbytes, (int)frames, n_frames, io, late);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream);
-    LC3_LAUNCH_CFG(lc3_decode_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0, stream,
-                   d->d_states, first, n, (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0, io, late);
+    if (late)
+        LC3_LAUNCH_CFG(lc3_decode_late_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0,
+                       stream, d->d_states, first, n, (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0, io);
+    else
+        LC3_LAUNCH_CFG(lc3_decode_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0, stream,
+                       d->d_states, first, n, (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0, io);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream);
     return d->order_end(stream);
@@ -1742,12 +1768,16 @@ int lc3gpu_decode_mixed(lc3gpu_decoder *d, const uint8_t *d_in, const uint8_t *d
     lc3_io io = {0, d->d_tab};
     const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + max_nbytes);
     d->timer.mark(stream);
-    const int late = lc3_late_reconstruction((size_t)d->num_channels * (size_t)n_frames);
+    const int late = lc3_late_reconstruction((size_t)d->num_channels * (size_t)n_frames, n_frames);
     hipLaunchKernelGGL(lc3_parse_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, d_in, d_bad, d->d_planes, n_frames, io, late);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream);
-    hipLaunchKernelGGL(lc3_decode_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, d->d_states,
-                       (const int32_t *)d->d_planes, d_pcm, n_frames, 0, io, late);
+    if (late)
+        hipLaunchKernelGGL(lc3_decode_mixed_late_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, d->d_states,
+                           (const int32_t *)d->d_planes, d_pcm, n_frames, 0, io);
+    else
+        hipLaunchKernelGGL(lc3_decode_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, d->d_states,
+                           (const int32_t *)d->d_planes, d_pcm, n_frames, 0, io);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream);
     return d->order_end(stream);

@@ -677,7 +677,7 @@ def test_stress_parity_tool_small_run():
 
 
 def test_late_reconstruction_on_and_off():
-    """Launches of at most 16 384 frames rebuild the spectrum in the synthesis kernel with the wave's 64 lanes
+    """Launches of at most 16 384 frames and four frames per stream rebuild the spectrum in the synthesis kernel with the wave's 64 lanes
     (lc3_dec_reconstruct_wave), larger ones in the parse kernel with one lane per frame (lc3_reconstruct_frame).  Both forms on
     the same launches (LC3GPU_LATE_RECON=0 / 1 overrides the size rule): clean, corrupted, flagged and garbage streams."""
     import os
