@@ -237,18 +237,18 @@ class GpuEngine:
             h.timing(True)
 
     def timing_stop(self):
-        ef = ev = eb = ep = en = dp = ds = dn = 0.0
+        ef = ev = eb = ep = en = dp = dr = dt = ds = dn = 0.0
         for h in self.encs:
             a, v, b, p_, n = h.timing(False)
             ef, ev, eb, ep, en = ef + a, ev + v, eb + b, ep + p_, en + n
         for h in self.decs:
-            a, b, n = h.timing(False)
-            dp, ds, dn = dp + a, ds + b, dn + n
+            a, r, t, b, n = h.timing_kernels(False)
+            dp, dr, dt, ds, dn = dp + a, dr + r, dt + t, ds + b, dn + n
         en, dn = en / self.NP, dn / self.NP  # launches per step = NP per kernel: scale to "per step"
         km = {"lc3_enc_front_kernel": ef / max(en, 1), "lc3_sns_vq_kernel": ev / max(en, 1),
               "lc3_enc_back_kernel": eb / max(en, 1), "lc3_pack_kernel": ep / max(en, 1)}
         if self.decs:
-            km.update({"lc3_parse_kernel": dp / max(dn, 1), "lc3_decode_kernel": ds / max(dn, 1)})
+            km.update({"lc3_parse_kernel": dp / max(dn, 1), "lc3_recon_kernel": dr / max(dn, 1), "lc3_tns_kernel": dt / max(dn, 1), "lc3_decode_kernel": ds / max(dn, 1)})
         return km
 
     def overlap_probe(self, steps, warmup):
@@ -423,7 +423,7 @@ def run_rank(args):
             # algorithmic bytes (their traffic is the planes between kernels).  The analysis of a frame is three kernels
             # (front half, quantiser, back half): ONE unit for the roofline, with the frame's PCM as its algorithmic bytes.
             alg_bytes = {"lc3_enc_front_kernel": 2 * NF, "lc3_sns_vq_kernel": 0, "lc3_enc_back_kernel": 0,
-                         "lc3_pack_kernel": NBYTES, "lc3_parse_kernel": NBYTES, "lc3_decode_kernel": 2 * NF}
+                         "lc3_pack_kernel": NBYTES, "lc3_parse_kernel": NBYTES, "lc3_recon_kernel": 0, "lc3_tns_kernel": 0, "lc3_decode_kernel": 2 * NF}
             groups = {"analysis (lc3_enc_front_kernel + lc3_sns_vq_kernel + lc3_enc_back_kernel)":
                       ["lc3_enc_front_kernel", "lc3_sns_vq_kernel", "lc3_enc_back_kernel"]}
             for k in kernel_ms:

@@ -170,12 +170,15 @@ int lc3gpu_encode_frame_debug(lc3gpu_encoder *enc, const int16_t *samples_in, in
                               int nbytes, float *dbg);
 /* per-kernel timing of the batch calls with HIP events recorded on the launch stream.  An encoder batch call runs four
  * kernels: analysis front half (wave per stream), SNS vector quantiser (lane per frame), analysis back half (wave per
- * stream), bitstream packing (lane per frame); a decoder batch call two: frame parsing + spectrum reconstruction (lane
- * per frame), synthesis (wave per stream).  `enable` switches recording on/off; the call synchronises and returns the
+ * stream), bitstream packing (lane per frame); a decoder batch call two or four: frame parsing (lane per frame), spectrum
+ * reconstruction (full batches: two kernels of its own, wave per frame and -- for the TNS lattice -- lane per frame; small
+ * launches: inside the synthesis kernel), synthesis (wave per stream).  `enable` switches recording on/off; the call synchronises and returns the
  * per-kernel milliseconds accumulated since the previous call followed by the number of batch calls:
- * encoder out[5] = {front, vq, back, pack, calls}, decoder out[3] = {parse, synthesis, calls}. */
+ * encoder out[5] = {front, vq, back, pack, calls}, decoder out[3] = {parse + reconstruction, synthesis, calls},
+ * lc3gpu_decoder_timing_kernels out[5] = {parse, reconstruction kernel, TNS kernel (both 0 where the launch has none), synthesis, calls}. */
 int lc3gpu_encoder_timing(lc3gpu_encoder *enc, int enable, double out[5]);
 int lc3gpu_decoder_timing(lc3gpu_decoder *dec, int enable, double out[3]);
+int lc3gpu_decoder_timing_kernels(lc3gpu_decoder *dec, int enable, double out[5]);
 /* diagnostic build (liblc3gpu_prof.so, -DLC3_PROFILE) only: per-stage shader-clock cycle sums since the last call.
  * slots 1..9 = encoder stages (mdct, bw+attack, sns, tns, ltpf, quant, residual+noise, bitstream, store),
  * slots 17..25 = decoder stages (names in tools/stage_profile.py); 32/33/34 = encoder whole-wave time sum / max / waves,

@@ -17,7 +17,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 # LC3GPU_PROFILE=1 selects the diagnostic build with in-kernel stage stamps (never used for timing claims)
 _PROFILE = os.environ.get("LC3GPU_PROFILE", "0") == "1"
-_LIB = os.path.join(_HERE, "lib", "liblc3gpu_prof.so" if _PROFILE else "liblc3gpu.so")
+# LC3GPU_LIB=<file name under lib/> selects another build of the same sources (compiler / tuning experiments, e.g. one made with
+# LC3_HIPCC_EXTRA="-DLC3_RECON_WAVES=6"); the default is the one build() produces
+_LIB = os.path.join(_HERE, "lib", os.environ.get("LC3GPU_LIB") or ("liblc3gpu_prof.so" if _PROFILE else "liblc3gpu.so"))
 _SRC = os.path.join(_HERE, "csrc", "lc3gpu.hip")
 
 class Lc3GpuError(RuntimeError):
@@ -152,6 +154,7 @@ def load_library():
     L.lc3gpu_kernel_info.argtypes = [i, vp]
     L.lc3gpu_encoder_timing.argtypes = [vp, i, vp]
     L.lc3gpu_decoder_timing.argtypes = [vp, i, vp]
+    L.lc3gpu_decoder_timing_kernels.argtypes = [vp, i, vp]
     _lib = L
     return L
 
@@ -165,7 +168,7 @@ ABI_SYMBOLS = [
     "lc3gpu_decoder_destroy", "lc3gpu_decoder_reset", "lc3gpu_decode_frame", "lc3gpu_decode", "lc3gpu_decode_range",
     "lc3gpu_decoder_state_size", "lc3gpu_decoder_state_save", "lc3gpu_decoder_state_load",
     "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info", "lc3gpu_prof_read", "lc3gpu_encoder_timing", "lc3gpu_decoder_timing",
-    "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
+    "lc3gpu_decoder_timing_kernels", "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
     "lc3gpu_decode_mixed", "lc3gpu_encoder_create_spec", "lc3gpu_encoder_create_mixed_spec",
 ]
 
@@ -426,6 +429,14 @@ class Lc3Decoder:
         if rc:
             raise Lc3DecoderError(rc, "timing")
         return float(out[0]), float(out[1]), int(out[2])
+
+    def timing_kernels(self, enable=True):
+        """-> (parse ms, reconstruction-kernel ms, TNS-kernel ms, synthesis ms, batch calls) since the last call; (re)arms recording"""
+        out = (ctypes.c_double * 5)()
+        rc = self._L.lc3gpu_decoder_timing_kernels(self._h, int(bool(enable)), out)
+        if rc:
+            raise Lc3DecoderError(rc, "timing")
+        return float(out[0]), float(out[1]), float(out[2]), float(out[3]), int(out[4])
 
     def reset(self):
         rc = self._L.lc3gpu_decoder_reset(self._h)

@@ -110,6 +110,10 @@
 #ifndef LC3_WAVE_ANY
 #define LC3_WAVE_ANY(pred) ((pred) != 0)
 #endif
+// the largest value any lane of the (lane-per-frame) wave holds, wave-uniform.  Translation units that run frames one at a time: the lane's own.
+#ifndef LC3_LANEWAVE_MAX
+#define LC3_LANEWAVE_MAX(v) (v)
+#endif
 
 // Opt-in corrections of the reference's deviations from the LC3 specification, one bit each; 0 = the
 // reference's behaviour, which is what every parity claim is about.  Same values as LC3GPU_SPEC_* (include/lc3gpu.h).

@@ -27,7 +27,7 @@ enum {
     SI_BW = 0, SI_LASTNZ, SI_LSB_MODE, SI_GG, SI_NUM_TNS, SI_ORD0, SI_ORD1, SI_IND_LF, SI_IND_HF, SI_LS_A, SI_LS_B,
     SI_IDX_A, SI_IDX_B, SI_SUB_LSB, SI_SUB_MSB, SI_G_IND, SI_PITCH_PRESENT, SI_LTPF_ACTIVE, SI_PITCH_INDEX, SI_NF,
     AD_ORD0, AD_ORD1, AD_NRES, AD_SEED, AD_ZERO, AD_OK, AD_RCI /* 16 entries */, AD_TAIL0 = AD_RCI + 16, AD_NRES_MAX,
-    AD_HEAD, SI_WORDS
+    AD_HEAD, AD_Y /* 3 words: the SNS pulse vector, 16 x 5 bits (lc3_parse_pulses) */, SI_WORDS = AD_Y + 3
 };
 
 struct lc3_parse_ctx {
@@ -303,6 +303,7 @@ __device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_ac
 }
 
 // read_res_bit (decoder/arithmetic_codec.rs:339-383) on a line whose value `xv` is already in a register; the caller stores it back
+template <int COUNT>
 __device__ __forceinline__ int lc3_p_res_bit(lc3_parse_ctx &c, int idx, int32_t &xv, int &nbits_res, int &cont) {
     int bit;
     if (nbits_res == 0) { cont = 0; return 0; }
@@ -316,9 +317,9 @@ __device__ __forceinline__ int lc3_p_res_bit(lc3_parse_ctx &c, int idx, int32_t 
             if (lc3_p_bool(c, bit)) return -1;
             nbits_res -= 1;
             xv = bit ? -1 : 1;
-            c.nnz += 1;
+            if (COUNT) c.nnz += 1;
         }
-        c.seed += (uint32_t)idx;  // |x| grew by one
+        if (COUNT) c.seed += (uint32_t)idx;  // |x| grew by one
     }
     cont = 1;
     return 0;
@@ -326,6 +327,9 @@ __device__ __forceinline__ int lc3_p_res_bit(lc3_parse_ctx &c, int idx, int32_t 
 
 // read_frame: side info + arithmetic_codec::decode up to (not including) the non-lsb residual bits, the noise seed
 // and the zero-frame flag, which the synthesis kernel derives lane-parallel from x.  Returns 0 when the frame parsed.
+// COUNT: keep the running count of non-zero lines and the noise-filling seed (the reconstruction kernels of a full batch derive both
+// from the integers, wave-parallel: the symbol loop then carries ten operations less per symbol, two of them quarter-rate multiplies).
+template <int COUNT = 1>
 __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_ind, int n_ms_10) {
     int lastnz = 0, lsb_mode = 0, num_tns = 0, ord[2];
     c.nnz = 0;
@@ -394,8 +398,10 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             }
             if (lsb_mode && !esc) lc3_px_set(c, LC3_PLANE_LEV + tup, lev);  // written by TUPLE index, read by LINE index (:184-195)
             lev_end = (!esc && lev > 0) ? tup + 1 : lev_end;
-            c.nnz += esc ? 0u : (uint32_t)(m0 != 0) + (uint32_t)(m1 != 0);
-            c.seed += esc ? 0u : (uint32_t)m0 * (uint32_t)(2 * tup) + (uint32_t)m1 * (uint32_t)(2 * tup + 1);
+            if (COUNT) {
+                c.nnz += esc ? 0u : (uint32_t)(m0 != 0) + (uint32_t)(m1 != 0);
+                c.seed += esc ? 0u : (uint32_t)m0 * (uint32_t)(2 * tup) + (uint32_t)m1 * (uint32_t)(2 * tup + 1);
+            }
             cctx = esc ? cctx : (cctx & 15) * 16 + (lv <= 1 ? 1 + (a + b) * (lv + 1) : 12 + lv);
             xk = esc ? xk + (int32_t)((uint32_t)bit0 << lev) : 0;
             xk1 = esc ? xk1 + (int32_t)((uint32_t)bit1 << lev) : 0;
@@ -437,10 +443,10 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
                 for (int j = 0; j < 8; j++) {
                     if (!stop && lv[j] > 0) {
                         const int k = k0 + 2 * j;
-                        if (lc3_p_res_bit(c, k, xp[j].v[0], nres, cont)) return -7;
+                        if (lc3_p_res_bit<COUNT>(c, k, xp[j].v[0], nres, cont)) return -7;
                         if (!cont) stop = 1;
                         else {
-                            if (lc3_p_res_bit(c, k + 1, xp[j].v[1], nres, cont)) return -7;
+                            if (lc3_p_res_bit<COUNT>(c, k + 1, xp[j].v[1], nres, cont)) return -7;
                             if (!cont) stop = 1;
                         }
                         *(lc3_i2 *)(c.plane + (LC3_PLANE_X + k) * LC3_PLANE_STRIDE) = __builtin_bit_cast(lc3_i2, xp[j]);
@@ -549,17 +555,133 @@ __device__ __forceinline__ int lc3_reconstruct_prepare_late(lc3_parse_ctx &c) {
             if (nbytes - head - last_byte + 2 < 0) return 0;
             if (nbytes - last_byte - 1 < 0) return 0;
         }
-        for (int w = 0; 32 * w < n_res; w++) {
-            uint32_t bits = 0;
-            for (int j = 0; j < 32 && 32 * w + j < n_res; j++) {
-                const int pos = tail0 + 32 * w + j;
-                bits |= (((uint32_t)c.bytes[nbytes - 1 - (pos >> 3)] >> (pos & 7)) & 1u) << j;
+        for (int w = 0; 32 * w < n_res; w++) {  // 32 tail bits at a time: five bytes, shifted (bits beyond n_res are never looked at)
+            const int pos = tail0 + 32 * w, bi = pos >> 3;
+            unsigned long long v = 0;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int idx = nbytes - 1 - bi - i;
+                v |= (unsigned long long)(idx >= 0 ? c.bytes[idx] : (uint8_t)0) << (8 * i);
             }
-            lc3_px_set(c, LC3_PLANE_LEV + w, (int32_t)bits);
+            lc3_px_set(c, LC3_PLANE_LEV + w, (int32_t)(uint32_t)(v >> (pos & 7)));
         }
     }
     lc3_px_set(c, AD_NRES, n_res);
     return 1;
+}
+
+// For the wave-per-frame reconstruction kernel (lc3_dev_dec_recon.h) the parser also de-enumerates the SNS pulse vector
+// (decoder/spectral_noise_shaping.rs:21-59,155-235): serial integer work, a few hundred operations on a lane that has just walked
+// ~300 symbols, against a chain of wave-uniform scalar steps in every one of the 65 536 waves there.  16 values in -10 .. 10, five
+// bits each, six to a word.
+__device__ __forceinline__ void lc3_parse_pulses(lc3_parse_ctx &c, const lc3_recon_ctx &r) {
+    int y[16];
+#pragma unroll
+    for (int n = 0; n < 16; n++) y[n] = 0;
+    const int shape_j = (lc3_px_get(c, SI_SUB_MSB) << 1) + lc3_px_get(c, SI_SUB_LSB);
+    const int ls_a = lc3_px_get(c, SI_LS_A), ls_b = lc3_px_get(c, SI_LS_B);
+    const uint32_t idx_a = (uint32_t)lc3_px_get(c, SI_IDX_A), idx_b = (uint32_t)lc3_px_get(c, SI_IDX_B);
+    if (shape_j == 0) {
+        lc3_r_deenum(r, 10, 10, ls_a, idx_a, y, 0);
+        lc3_r_deenum(r, 6, 1, ls_b, idx_b, y, 10);
+    } else if (shape_j == 1) lc3_r_deenum(r, 10, 10, ls_a, idx_a, y, 0);
+    else if (shape_j == 2) lc3_r_deenum(r, 16, 8, ls_a, idx_a, y, 0);
+    else lc3_r_deenum(r, 16, 6, ls_a, idx_a, y, 0);
+    uint32_t w[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int n = 0; n < 16; n++) w[n / 6] |= ((uint32_t)y[n] & 31u) << (5 * (n % 6));
+#pragma unroll
+    for (int i = 0; i < 3; i++) lc3_px_set(c, AD_Y + i, (int32_t)w[i]);
+}
+// element n of the packed pulse vector (words w0..w2 = AD_Y .. AD_Y + 2)
+__device__ __forceinline__ int lc3_pulse_unpack(uint32_t w0, uint32_t w1, uint32_t w2, int n) {
+    const uint32_t w = n < 6 ? w0 : (n < 12 ? w1 : w2);
+    const uint32_t f = (w >> (5 * (n % 6))) & 31u;
+    return (int)(f ^ 16u) - 16;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// TNS synthesis lattice (decoder/temporal_noise_shaping.rs:60-137) of four consecutive lines k0 .. k0+3 (k0 wave-uniform) of ONE LANE's
+// frame, in place in v.  The lane's first filter covers [lo0, lo1) with the coefficients in rq, its second one -- coefficients rq1,
+// taken over at line lo1 together with the reset of the lattice memory beyond ord0 -- covers [lo1, hi) (lo1 = hi: one filter; lo0 = hi:
+// none).  Per line:   t = x - rc[7] * st[7];  q = 6 .. 0: t -= rc[q] * st[q]; st[q+1] = rc[q] * t + st[q];  x = st[0] = t
+// always over all eight stages, without per-stage selects: the coefficients are ZERO beyond a filter's order, a stage with rc = 0
+// subtracts rc * st = +-0 from t, which leaves t as it is (t is never -0: the inputs are converted integers, +-level and their
+// products with positive gains, and a difference of equal values is +0), and what such stages write into the lattice memory beyond
+// the order is discarded where it could be read (the reset at lo1 restores the zeros the reference still has there).
+// The bounds are per lane (they follow the frame's bandwidth): lanes whose range the group lies inside take the wavefront form, lanes
+// it straddles a boundary of walk it line by line, both under the execution mask; a group no lane's range touches costs a few compares.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lc3_tns_take_second(int ord0, float (&rq)[8], const float (&rq1)[8], float (&st)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        rq[q] = rq1[q];
+        st[q] = q >= ord0 ? 0.0f : st[q];
+    }
+}
+__device__ __forceinline__ void lc3_tns_lattice4(int k0, int lo0, int lo1, int hi, int ord0, float (&rq)[8], const float (&rq1)[8],
+                                                 float (&st)[8], float (&v)[4]) {
+    if (k0 == lo1 && lo1 < hi) lc3_tns_take_second(ord0, rq, rq1, st);  // the group starts the second filter
+    const int inside = (k0 >= lo0 && k0 + 3 < lo1) || (k0 >= lo1 && k0 + 3 < hi);
+    if (inside) {
+        // The four lines as a skewed wavefront: line j runs its stage q at step (7 - q) + 2 j.  Stage q of a line reads st[q] as the line
+        // before left it (written by that line's stage q - 1, one step earlier) and writes st[q + 1], which the line before has read two
+        // steps earlier: the order of every read and write of the lattice memory is that of the line-by-line walk, with up to four
+        // independent operations in flight instead of one chain of dependent ones.
+#pragma unroll
+        for (int step = 0; step < 8 + 2 * 3; step++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int q = 7 - (step - 2 * j);
+                if (q >= 0 && q <= 7) {
+                    v[j] = v[j] - rq[q] * st[q];
+                    LC3_KEEP_SCALAR(v[j]);  // (paired into packed-f32 operations the chain gains moves and hazard nops)
+                    if (q < 7) {
+                        st[q + 1] = rq[q] * v[j] + st[q];
+                        LC3_KEEP_SCALAR(st[q + 1]);
+                    }
+                    if (q == 0) st[0] = v[j];
+                }
+            }
+        }
+    } else if (k0 + 3 >= lo0 && k0 < hi) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
+            if (k == lo1 && j > 0 && lo1 < hi) lc3_tns_take_second(ord0, rq, rq1, st);  // (j == 0: done above)
+            if (k >= lo0 && k < hi) {
+                float t = v[j];
+#pragma unroll
+                for (int q = 7; q >= 0; q--) {
+                    t = t - rq[q] * st[q];
+                    if (q < 7) st[q + 1] = rq[q] * t + st[q];
+                }
+                st[0] = t;
+                v[j] = t;
+            }
+        }
+    }
+}
+
+// Hand-over to the reconstruction kernels of a full batch (lc3_dev_dec_recon.h), which count the non-zero lines themselves: the tail
+// bits that may turn out to be residual bits -- at most one per line below lastnz, at most AD_NRES_MAX, at most 480 -- as a bit mask in
+// the level words; the count and its bound checks (:168-183) happen there.
+__device__ __forceinline__ void lc3_reconstruct_prepare_wave(lc3_parse_ctx &c) {
+    const int nbytes = c.len;
+    const int lsb_mode = lc3_px_get(c, SI_LSB_MODE), tail0 = lc3_px_get(c, AD_TAIL0), nres_max = lc3_px_get(c, AD_NRES_MAX),
+              lastnz = lc3_px_get(c, SI_LASTNZ);
+    int n = nres_max < lastnz ? nres_max : lastnz;
+    n = lsb_mode ? 0 : (n < 480 ? n : 480);
+    for (int w = 0; 32 * w < n; w++) {  // 32 tail bits at a time: five bytes, shifted (a byte beyond the frame's start reads as 0)
+        const int pos = tail0 + 32 * w, bi = pos >> 3;
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int idx = nbytes - 1 - bi - i;
+            v |= (unsigned long long)(idx >= 0 ? c.bytes[idx] : (uint8_t)0) << (8 * i);
+        }
+        lc3_px_set(c, LC3_PLANE_LEV + w, (int32_t)(uint32_t)(v >> (pos & 7)));
+    }
 }
 
 template <class CC>
@@ -647,13 +769,17 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     const int hi0 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][1] : LC3C_TNSDEC75[bw][1];
     const int lo1 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][2] : LC3C_TNSDEC75[bw][2];
     const int hi1 = cfg.n_ms_10 ? LC3C_TNSDEC10[bw][3] : LC3C_TNSDEC75[bw][3];
-    float st[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, rq[8];
-    int order = ord0;
+    // the two filters' coefficients, zero beyond the order (lc3_tns_lattice4); this lane's line ranges, empty without an active filter
+    float st[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, rq[8], rq1[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const int ri = LC3_SIW(AD_RCI + k);
-        rq[k] = ri != 0 ? LC3_TNS_SIN_DEC(ri) : 0.0f;  // sin(step * (ri - 8)); SURVEY A12
+        const int r0 = LC3_SIW(AD_RCI + k), r1 = LC3_SIW(AD_RCI + 8 + k);
+        rq[k] = (r0 != 0 && k < ord0) ? LC3_TNS_SIN_DEC(r0) : 0.0f;  // sin(step * (ri - 8)); SURVEY A12
+        rq1[k] = (r1 != 0 && k < ord1) ? LC3_TNS_SIN_DEC(r1) : 0.0f;
     }
+    const int tns_on = ord0 > 0 || ord1 > 0;
+    const int t_lo0 = tns_on ? lo0 : 0, t_hi = tns_on ? (nbands == 2 ? hi1 : hi0) : 0, t_lo1 = tns_on ? (nbands == 2 ? lo1 : hi0) : 0;
+    const int tns_wave = LC3_WAVE_ANY(tns_on);  // no lane of the wave has a filter: the lattice is skipped altogether
     // noise filling :18-56
     const int bw_stop = cfg.n_ms_10 ? LC3C_BWSTOP10[bw] : LC3C_BWSTOP75[bw];
     const int nf_start = cfg.n_ms_10 ? 24 : 18, nf_width = cfg.n_ms_10 ? 3 : 2;
@@ -718,41 +844,20 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
                 lcg = fill ? lcg_n : lcg;
                 v = fill ? (lcg_n < 0x8000u ? level : -level) : v;
             }
-            v *= gg;
-            if (k == lo1 && nbands == 2) {  // second filter: its coefficients, the lattice memory carries over
-                order = ord1;
+            vout[j] = v * gg;
+            // slide the window: drop line k - 3, bring in line k + 4
+            nzwin = (nzwin >> 1) | ((xw[j + 4] != 0 && k + 4 < bw_stop) ? 64u : 0u);
+        }
+        if (tns_wave) lc3_tns_lattice4(k0, t_lo0, t_lo1, t_hi, ord0, rq, rq1, st, vout);  // TNS synthesis, the group's four lines together
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int ri = LC3_SIW(AD_RCI + 8 + q);
-                    rq[q] = ri != 0 ? LC3_TNS_SIN_DEC(ri) : 0.0f;
-                }
-            }
-            {   // TNS synthesis lattice: stages q < ord_eff are live on this lane for this line.
-                // t = x - rc[order-1]*st[order-1]; then q = order-2 .. 0: t -= rc[q]*st[q]; st[q+1] = rc[q]*t + st[q]
-                const int in_range = (k >= lo0 && k < hi0) || (nbands == 2 && k >= lo1 && k < hi1);
-                const int ord_eff = in_range ? order : 0;
-                float t = v;
-#pragma unroll
-                for (int q = 7; q >= 0; q--) {
-                    const float t2 = t - rq[q] * st[q];
-                    t = q < ord_eff ? t2 : t;
-                    if (q < 7) {
-                        const float sn = rq[q] * t + st[q];
-                        st[q + 1] = q + 1 < ord_eff ? sn : st[q + 1];
-                    }
-                }
-                v = t;
-                st[0] = ord_eff > 0 ? t : st[0];
-            }
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
             while (k >= band_end) {  // band of line k (bands are contiguous and non-empty below ne)
                 bi++;
                 band_end = (int)ifs[bi + 1];
                 g_band = lc3_r_band_gain(r, bi, cfg.nb);
             }
-            v *= g_band;
-            vout[j] = v;
-            // slide the window: drop line k - 3, bring in line k + 4
-            nzwin = (nzwin >> 1) | ((xw[j + 4] != 0 && k + 4 < bw_stop) ? 64u : 0u);
+            vout[j] *= g_band;
         }
         {   // the group's four reconstructed lines leave as one 128-bit store
             lc3_f4 o;

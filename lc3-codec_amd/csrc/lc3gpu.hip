@@ -84,6 +84,7 @@ __shared__ lc3_spec_tables lc3_spec_tab;
 // product of two values below 2^24 (range-coder steps): the full-rate 24-bit multiplier instead of the quarter-rate v_mul_lo_u32
 #define LC3_MUL24(a, b) __umul24((a), (b))
 #define LC3_WAVE_ANY(pred) (__ballot((pred) != 0) != 0ull)
+#define LC3_LANEWAVE_MAX(v) lc3_wave_max_i32((v), 0)
 // 10^x tables of the two argument families the codec uses (lc3_dev_common.h: LC3_POW10_GG / LC3_POW10_TILT), filled on the device
 // by lc3_pow10f itself when a device's first configuration is registered
 __device__ float lc3_pow10_gg_tab[512];       // [k + 256] = 10^(k / 28), k = gg_ind + gg_off
@@ -331,6 +332,7 @@ __device__ unsigned long long lc3_prof_acc[64];  // 0..31 stage sums; 32/33/34 e
 #define LC3_PROF_MARK(L, lane, slot)
 #endif
 #include "lc3_dev_dec.h"
+#include "lc3_dev_dec_recon.h"
 #include "lc3_dev_enc.h"
 #include "lc3_host_plan.h"
 
@@ -702,10 +704,21 @@ __device__ __forceinline__ void lc3_parse_body(lc3_cfg_slot<CV> cfg, unsigned wg
         c.plast = clock64();
 #endif
         const size_t fb = lc3_io_flag_idx(io, first_channel, f / (size_t)T, f % (size_t)T, T);  // the flag array follows the frame layout
-        const int rc = (bad && bad[fb]) ? -100 : lc3_parse_frame(c, ne, fs_ind, n_ms_10);
+        int rc;
+        if (late == 2) rc = (bad && bad[fb]) ? -100 : lc3_parse_frame<0>(c, ne, fs_ind, n_ms_10);  // (late is launch-uniform)
+        else rc = (bad && bad[fb]) ? -100 : lc3_parse_frame<1>(c, ne, fs_ind, n_ms_10);
         int ok = rc == 0;
-        if (ok && late) ok = lc3_reconstruct_prepare_late(c);  // launches of a few frames: D4-D8 in the synthesis kernel
-        else if (ok) {
+        if (ok && late == 2) {  // D4-D8 in the reconstruction kernels of a full batch
+            lc3_recon_ctx r;
+            r.scf = nullptr;
+            r.sstride = 0;
+            r.mpvq = s_mpvq;
+            r.ifs = nullptr;
+            lc3_reconstruct_prepare_wave(c);
+            lc3_parse_pulses(c, r);
+        } else if (ok && late) {  // D4-D8 in the synthesis kernel (launches of a few frames)
+            ok = lc3_reconstruct_prepare_late(c);
+        } else if (ok) {
             lc3_recon_ctx r;
             r.scf = s_scf + tid;
             r.sstride = fpb;
@@ -736,6 +749,80 @@ __global__ __launch_bounds__(256) void lc3_parse_mixed_kernel(lc3_groups G, cons
     else
         lc3_parse_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_frame, in, bad, p, g.nbytes, g.n_streams * T,
                                     T, g.first_stream, io, late);
+}
+
+// Spectrum reconstruction D4-D8 of a full batch (lc3_dev_dec_recon.h), between the parser and the synthesis kernel:
+//   lc3_recon_kernel  one WAVE per frame: residual bits, noise filling, gain, scale factors, band gains.  Frames are independent; a
+//                     workgroup (LC3_WG_WAVES waves) stages the tables once and walks frames wg * 4 + wave, + 4 * gridDim.x, ...;
+//   lc3_tns_kernel    one LANE per frame: the TNS lattice and the band gains of the filter range, for the frames that have a filter.
+#ifndef LC3_RECON_WAVES
+#define LC3_RECON_WAVES 8  // waves per SIMD the register allocation aims at
+#endif
+__shared__ lc3_recon_tables lc3_recon_tab;
+__shared__ lc3_recon_wave lc3_recon_wv[LC3_WG_WAVES];
+template <class CV>
+__device__ __forceinline__ void lc3_recon_body(lc3_cfg_slot<CV> cfg, unsigned wg, unsigned n_wg, int32_t *planes, int nbytes, size_t n_frames) {
+    const int lane = threadIdx.x & 63, wave = LC3_WAVE_ID();
+    typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
+    lc3_recon_tables_stage(c0, lc3_recon_tab, (int)threadIdx.x, 64 * LC3_WG_WAVES);
+    __syncthreads();
+    for (size_t f = (size_t)wg * LC3_WG_WAVES + (size_t)wave; f < n_frames; f += (size_t)n_wg * LC3_WG_WAVES)
+        lc3_recon_frame_direct(c0, lc3_recon_tab, lc3_recon_wv[wave], lane, LC3_PLANE_COL(planes, f, LC3_PLANE_WORDS), nbytes);
+}
+template <class CV>
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_RECON_WAVES) void lc3_recon_kernel(lc3_cfg_slot<CV> cfg, int32_t *planes, int nbytes, int n_frames) {
+    lc3_recon_body<CV>(cfg, blockIdx.x, gridDim.x, planes, nbytes, (size_t)n_frames);
+}
+// mixed batch: one frame per wave, G's frame-kernel workgroup numbers computed for LC3_WG_WAVES frames per workgroup
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_RECON_WAVES) void lc3_recon_mixed_kernel(lc3_groups G, int32_t *planes, int T) {
+    const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
+    int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
+    const unsigned wg = blockIdx.x - g.wg_frame;
+    const size_t nfr = (size_t)g.n_streams * (size_t)T, left = nfr - (size_t)wg * LC3_WG_WAVES;  // this workgroup's four frames only
+    if (g.fixed)
+        lc3_recon_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, 0, 1, p + (size_t)wg * LC3_WG_WAVES * (size_t)LC3_PLANE_WORDS, g.nbytes,
+                                      left < LC3_WG_WAVES ? left : LC3_WG_WAVES);
+    else
+        lc3_recon_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, 0, 1, p + (size_t)wg * LC3_WG_WAVES * (size_t)LC3_PLANE_WORDS, g.nbytes,
+                                    left < LC3_WG_WAVES ? left : LC3_WG_WAVES);
+}
+// LC3_TNS_FPB frames per workgroup, one wave per 64 of them: 16 KB of (dynamic) LDS per wave for its frames' band gains, band-major.
+// Four waves per workgroup so that the 1 024 waves of a full batch land one per SIMD (single-wave workgroups are packed several to a CU).
+#define LC3_TNS_FPB 256
+#define LC3_TNS_LDS (LC3_TNS_FPB * 64 * 4 + 20 * 4 + LC3_MAX_NF)
+template <class CV>
+__device__ __forceinline__ void lc3_tns_body(lc3_cfg_slot<CV> cfg, unsigned wg, int32_t *planes, size_t n_frames) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float *s_gains = (float *)smem;
+    float *s_sin = (float *)(smem + LC3_TNS_FPB * 64 * 4);
+    uint32_t *s_lb = (uint32_t *)(smem + LC3_TNS_FPB * 64 * 4 + 20 * 4);
+    const int tid = threadIdx.x;
+    typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
+    if (tid < 17) s_sin[tid] = lc3_tns_sin_dec_value(tid);
+    for (int i = tid; i < LC3_MAX_NF / 4; i += LC3_TNS_FPB) s_lb[i] = lc3_line_band_word(c0, i);
+    __syncthreads();
+    const size_t f = (size_t)wg * LC3_TNS_FPB + (size_t)tid;
+    const int valid = f < n_frames;
+    lc3_tns_lane_ctx x;
+    x.col = LC3_PLANE_COL(planes, valid ? f : 0, LC3_PLANE_WORDS);
+    x.gains = s_gains + (tid >> 6) * (64 * 64) + (tid & 63);
+    x.gstride = 64;
+    x.sin_tab = s_sin;
+    x.line_band = s_lb;
+    lc3_tns_lane_frame(c0, x, valid);
+}
+template <class CV>
+__global__ __launch_bounds__(LC3_TNS_FPB) void lc3_tns_kernel(lc3_cfg_slot<CV> cfg, int32_t *planes, int n_frames) {
+    lc3_tns_body<CV>(cfg, blockIdx.x, planes, (size_t)n_frames);
+}
+// G: frame-kernel workgroup numbers computed for LC3_TNS_FPB frames per workgroup
+__global__ __launch_bounds__(LC3_TNS_FPB) void lc3_tns_mixed_kernel(lc3_groups G, int32_t *planes, int T) {
+    const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
+    int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
+    if (g.fixed)
+        lc3_tns_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_frame, p, (size_t)g.n_streams * (size_t)T);
+    else
+        lc3_tns_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_frame, p, (size_t)g.n_streams * (size_t)T);
 }
 
 // LATE: the launch reconstructs the spectrum here (lc3_dec_reconstruct_wave) -- a compile-time switch, so that the kernels of full
@@ -955,40 +1042,57 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
 
 // optional per-kernel timing with HIP events recorded on the launch stream (bench.py roofline).  Events come from a pool
 // that lives as long as the handle: nothing is created inside a timed region once the pool has warmed up.
+// after a kernel launch inside a batch call: on failure the marks of this call are forgotten (the timer's intervals stay aligned) and
+// what was already enqueued is still recorded as the handle's work in flight, so that a later call or quiesce() orders behind it
+#define LC3_LAUNCH_CHECK(h, stream, t0)               \
+    do {                                              \
+        hipError_t e_ = hipGetLastError();            \
+        if (e_ != hipSuccess) {                       \
+            g_last_hip = (int)e_;                     \
+            (h)->timer.rollback(t0);                  \
+            (void)(h)->order_end(stream);             \
+            return LC3GPU_EHIP;                       \
+        }                                             \
+    } while (0)
 struct KernelTimer {
     bool enabled = false;
-    int stages = 2;               // kernels per batch call: stages + 1 events per call
     std::vector<hipEvent_t> pool;  // every event ever created for this handle
+    std::vector<int8_t> slot;      // per recorded mark: the ms[] slot of the interval that ENDS at it, -1 for the first mark of a call
     size_t used = 0;               // events of the pool holding a recorded mark
     double ms[4] = {0.0, 0.0, 0.0, 0.0};
     long launches = 0;
-    void mark(hipStream_t s) {
+    // first mark of a batch call: begin(stream); after every kernel: mark(stream, slot of that kernel)
+    void begin(hipStream_t s) { mark(s, -1); }
+    void mark(hipStream_t s, int sl) {
         if (!enabled) return;
         if (used == pool.size()) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return;
             pool.push_back(e);
+            slot.push_back(0);
         }
+        slot[used] = (int8_t)sl;
         (void)hipEventRecord(pool[used++], s);
     }
-    // synchronises; folds the recorded event groups into ms[] and returns the events to the pool
+    // a call failed after its first mark: forget the marks it recorded (the events stay in the pool)
+    void rollback(size_t to) { if (to <= used) used = to; }
+    // synchronises; folds the recorded intervals into ms[] and returns the events to the pool
     void collect() {
-        const size_t grp = (size_t)stages + 1;
-        for (size_t i = 0; i + grp <= used; i += grp) {
-            (void)hipEventSynchronize(pool[i + grp - 1]);
-            float d[4] = {0.f, 0.f, 0.f, 0.f};
-            bool ok = true;
-            for (int k = 0; k < stages; k++) ok = ok && hipEventElapsedTime(&d[k], pool[i + k], pool[i + k + 1]) == hipSuccess;
-            if (ok) {
-                for (int k = 0; k < stages; k++) ms[k] += d[k];
+        if (used) (void)hipEventSynchronize(pool[used - 1]);
+        for (size_t i = 0; i < used; i++) {
+            if (slot[i] < 0) {
                 launches += 1;
+                continue;
             }
+            float d = 0.f;
+            if (i > 0 && hipEventElapsedTime(&d, pool[i - 1], pool[i]) == hipSuccess) ms[slot[i]] += d;
         }
         used = 0;
     }
     void release() {
         for (hipEvent_t e : pool) (void)hipEventDestroy(e);
         pool.clear();
+        slot.clear();
         used = 0;
     }
 };
@@ -1222,17 +1326,59 @@ static int lc3_prep_symbols_flag(size_t n_frames_total) {
     const bool on = forced >= 0 ? forced != 0 : n_frames_total <= 16384;
     return on ? LC3_LAUNCH_PREP_SYMBOLS : 0;
 }
-// Launches of a few frames reconstruct the spectrum in the synthesis kernel (lc3_dec_reconstruct_wave) instead of the parse kernel:
-// the parser then takes 0.22 instead of 0.36 ms whatever the launch size, the synthesis kernel 20 - 35 us more per frame of a
-// stream (its frames run one after the other; the lane-0 TNS lattice of a frame with an active filter is most of it).  Measured
-// (parse + synthesis, us): 1 x 1 frames 301 -> 157, 1024 x 1 361 -> 260, 4096 x 4 402 -> 354, 1024 x 16 428 -> 469.
-// LC3GPU_LATE_RECON=0 / 1 forces it off / on (tests)
-static int lc3_late_reconstruction(size_t n_frames_total, int frames_per_stream) {
+// Where the spectrum of a parsed frame is reconstructed (D4-D8).  Three forms, the same arithmetic line by line:
+//   LC3_RECON_LANE  in the parse kernel, by the lane that parsed the frame (lc3_reconstruct_frame): full batches.  One pass over the
+//                   lines with the TNS lattice as a four-line wavefront (lc3_tns_lattice4);
+//   LC3_RECON_LATE  in the synthesis kernel, by the stream's wave (lc3_dec_reconstruct_wave): launches of a few frames, where a lane
+//                   walking its frame alone is what the caller waits for (measured, parse + synthesis, us: 1 x 1 frames 301 -> 157,
+//                   1024 x 1 361 -> 260, 4096 x 4 402 -> 354, 1024 x 16 428 -> 469);
+//   LC3_RECON_WAVE  two kernels of its own between parser and synthesis (lc3_dev_dec_recon.h): one WAVE per frame for what is parallel
+//                   over a frame's lines, then one LANE per frame for the TNS lattice.  Built in round 3 to take the line-parallel
+//                   work out of the one-wave-per-SIMD parser; measured on the 65 536-frame batch (ms): parser 0.220 + wave-per-frame
+//                   0.093 + lattice 0.070 = 0.383 against 0.339 for LC3_RECON_LANE -- the two extra trips of every spectrum through
+//                   HBM cost more than the occupancy gains.  Kept selectable and tested, not the default.
+// LC3GPU_RECON=lane|late|wave forces a form for every launch (tests); LC3GPU_LATE_RECON=0 / 1 is the older spelling of lane / late.
+enum { LC3_RECON_LANE = 0, LC3_RECON_LATE = 1, LC3_RECON_WAVE = 2 };
+static int lc3_recon_mode(size_t n_frames_total, int frames_per_stream) {
     static const int forced = [] {
+        const char *m = std::getenv("LC3GPU_RECON");
+        if (m) {
+            if (!std::strcmp(m, "lane")) return (int)LC3_RECON_LANE;
+            if (!std::strcmp(m, "late")) return (int)LC3_RECON_LATE;
+            if (!std::strcmp(m, "wave")) return (int)LC3_RECON_WAVE;
+        }
         const char *e = std::getenv("LC3GPU_LATE_RECON");
-        return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
+        return e ? (std::atoi(e) != 0 ? (int)LC3_RECON_LATE : (int)LC3_RECON_LANE) : -1;
     }();
-    return forced >= 0 ? forced : ((n_frames_total <= 16384 && frames_per_stream <= 4) ? 1 : 0);
+    if (forced >= 0) return forced;
+    return (n_frames_total <= 16384 && frames_per_stream <= 4) ? LC3_RECON_LATE : LC3_RECON_LANE;
+}
+// the TNS kernels use more than the default 64 KB of dynamic LDS: opt in once per device (every instantiation)
+static int lc3_tns_lds_optin() {
+    static bool done[LC3_MAX_DEVICES] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= LC3_MAX_DEVICES) return LC3GPU_EINVAL;
+    if (done[dev]) return LC3GPU_OK;
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_kernel<lc3_cfg_any>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_kernel<lc3_cfg_48k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_kernel<lc3_cfg_48k75>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_kernel<lc3_cfg_32k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_kernel<lc3_cfg_16k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
+    done[dev] = true;
+    return LC3GPU_OK;
+}
+// workgroups of the reconstruction kernel: eight per CU (LC3GPU_RECON_GRID overrides: tuning aid)
+static size_t lc3_recon_grid() {
+    static const size_t n = [] {
+        const char *e = std::getenv("LC3GPU_RECON_GRID");
+        if (e && std::atoi(e) > 0) return (size_t)std::atoi(e);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return (size_t)(cus > 0 ? cus : 256) * 8;
+    }();
+    return n;
 }
 static unsigned lc3_frame_block_fit(size_t lds_fixed, size_t lds_per_frame) {
     unsigned fpb = lc3_frame_block(256u);
@@ -1448,25 +1594,26 @@ static int encode_launch(lc3gpu_encoder *e, const HostCfg &h, int first, int n, 
     // analysis front half (wave per stream) -> SNS vector quantiser (lane per frame) -> back half (wave per stream) ->
     // bitstream packing (lane per frame)
     const dim3 wg_grid((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), wg_block(64 * LC3_WG_WAVES);
-    e->timer.mark(stream);
+    const size_t t0 = e->timer.used;
+    e->timer.begin(stream);
     LC3_LAUNCH_CFG(lc3_enc_front_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n, d_pcm, e->d_mid,
                        e->d_planes, nbytes, n_frames, fresh, dbg, io, e->spec_flags);
-    HIP_TRY(hipGetLastError());
-    e->timer.mark(stream);
+    LC3_LAUNCH_CHECK(e, stream, t0);
+    e->timer.mark(stream, 0);
     hipLaunchKernelGGL(lc3_sns_vq_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, stream, h.c.nb, e->d_mid,
                        e->d_planes, (int)frames, e->spec_flags);
-    HIP_TRY(hipGetLastError());
-    e->timer.mark(stream);
+    LC3_LAUNCH_CHECK(e, stream, t0);
+    e->timer.mark(stream, 1);
     LC3_LAUNCH_CFG(lc3_enc_back_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n,
                        (const float *)e->d_mid, e->d_planes, nbytes, n_frames, dbg, e->spec_flags | lc3_prep_symbols_flag(frames));
-    HIP_TRY(hipGetLastError());
-    e->timer.mark(stream);
+    LC3_LAUNCH_CHECK(e, stream, t0);
+    e->timer.mark(stream, 2);
     const unsigned fpb = lc3_frame_block_fit(LC3_PACK_LDS_FIXED, (size_t)nbytes);
     const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3) + 4;  // + the packer's sink byte
     hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, h.c.ne,
                        (const int32_t *)e->d_planes, d_out, nbytes, (int)frames, n_frames, io);
-    HIP_TRY(hipGetLastError());
-    e->timer.mark(stream);
+    LC3_LAUNCH_CHECK(e, stream, t0);
+    e->timer.mark(stream, 3);
     for (int i = first; i < first + n; i++) e->fresh_mask[(size_t)i] = 0;
     return e->order_end(stream);
 }
@@ -1514,11 +1661,12 @@ int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out,
         if (rc) return rc;
     }
     lc3_io io = {0, e->d_tab};
-    e->timer.mark(stream);
+    const size_t t0 = e->timer.used;
+    e->timer.begin(stream);
     hipLaunchKernelGGL(lc3_enc_front_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states, d_pcm, e->d_mid,
                        e->d_planes, n_frames, fresh, io, e->spec_flags);
-    HIP_TRY(hipGetLastError());
-    e->timer.mark(stream);
+    LC3_LAUNCH_CHECK(e, stream, t0);
+    e->timer.mark(stream, 0);
     lc3_groups G256;  // the vector quantiser runs 256 frames per workgroup
     {
         unsigned a, b;
@@ -1526,17 +1674,17 @@ int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out,
         int m;
         fill_groups(*e, n_frames, 256u, G256, a, b, f, m);
         hipLaunchKernelGGL(lc3_sns_vq_mixed_kernel, dim3(b), dim3(256), 0, stream, G256, e->d_mid, e->d_planes, n_frames, e->spec_flags);
-        HIP_TRY(hipGetLastError());
+        LC3_LAUNCH_CHECK(e, stream, t0);
     }
-    e->timer.mark(stream);
+    e->timer.mark(stream, 1);
     hipLaunchKernelGGL(lc3_enc_back_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states,
                        (const float *)e->d_mid, e->d_planes, n_frames, e->spec_flags | lc3_prep_symbols_flag((size_t)e->num_channels * (size_t)n_frames));
-    HIP_TRY(hipGetLastError());
-    e->timer.mark(stream);
+    LC3_LAUNCH_CHECK(e, stream, t0);
+    e->timer.mark(stream, 2);
     const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)max_nbytes + 3) & ~(size_t)3) + 4;
     hipLaunchKernelGGL(lc3_pack_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, (const int32_t *)e->d_planes, d_out, n_frames, io);
-    HIP_TRY(hipGetLastError());
-    e->timer.mark(stream);
+    LC3_LAUNCH_CHECK(e, stream, t0);
+    e->timer.mark(stream, 3);
     e->fresh_mask.assign((size_t)e->num_channels, 0);
     return e->order_end(stream);
 }
@@ -1711,20 +1859,35 @@ static int decode_launch(lc3gpu_decoder *d, const HostCfg &h, int first, int n, 
     // frame data per frame)
     const unsigned fpb = lc3_frame_block_fit(LC3_PARSE_LDS_FIXED, (size_t)(64 + nbytes));
     const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes);
-    const int late = lc3_late_reconstruction(frames, n_frames);
-    d->timer.mark(stream);
+    const int mode = lc3_recon_mode(frames, n_frames);
+    if (mode == LC3_RECON_WAVE && (rc = lc3_tns_lds_optin()) != LC3GPU_OK) return rc;
+    const size_t t0 = d->timer.used;
+    d->timer.begin(stream);
     LC3_LAUNCH_CFG(lc3_parse_kernel, h, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream,
-                       d_in, d_bad, d->d_planes, nbytes, (int)frames, n_frames, io, late);
-    HIP_TRY(hipGetLastError());
-    d->timer.mark(stream);
-    if (late)
+                       d_in, d_bad, d->d_planes, nbytes, (int)frames, n_frames, io, mode);
+    LC3_LAUNCH_CHECK(d, stream, t0);
+    d->timer.mark(stream, 0);
+    if (mode == LC3_RECON_WAVE) {
+        const size_t wgs = (frames + LC3_WG_WAVES - 1) / LC3_WG_WAVES;
+        LC3_LAUNCH_CFG(lc3_recon_kernel, h, dim3((unsigned)(wgs < lc3_recon_grid() ? wgs : lc3_recon_grid())), dim3(64 * LC3_WG_WAVES), 0, stream,
+                       d->d_planes, nbytes, (int)frames);
+        LC3_LAUNCH_CHECK(d, stream, t0);
+        d->timer.mark(stream, 1);
+    }
+    if (mode == LC3_RECON_WAVE) {
+        LC3_LAUNCH_CFG(lc3_tns_kernel, h, dim3((unsigned)((frames + LC3_TNS_FPB - 1) / LC3_TNS_FPB)), dim3(LC3_TNS_FPB), LC3_TNS_LDS, stream,
+                       d->d_planes, (int)frames);
+        LC3_LAUNCH_CHECK(d, stream, t0);
+        d->timer.mark(stream, 2);
+    }
+    if (mode == LC3_RECON_LATE)
         LC3_LAUNCH_CFG(lc3_decode_late_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0,
                        stream, d->d_states, first, n, (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0, io);
     else
         LC3_LAUNCH_CFG(lc3_decode_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0, stream,
                        d->d_states, first, n, (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0, io);
-    HIP_TRY(hipGetLastError());
-    d->timer.mark(stream);
+    LC3_LAUNCH_CHECK(d, stream, t0);
+    d->timer.mark(stream, 3);
     return d->order_end(stream);
 }
 
@@ -1767,19 +1930,37 @@ int lc3gpu_decode_mixed(lc3gpu_decoder *d, const uint8_t *d_in, const uint8_t *d
     if (rc) return rc;
     lc3_io io = {0, d->d_tab};
     const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + max_nbytes);
-    d->timer.mark(stream);
-    const int late = lc3_late_reconstruction((size_t)d->num_channels * (size_t)n_frames, n_frames);
-    hipLaunchKernelGGL(lc3_parse_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, d_in, d_bad, d->d_planes, n_frames, io, late);
-    HIP_TRY(hipGetLastError());
-    d->timer.mark(stream);
-    if (late)
+    const int mode = lc3_recon_mode((size_t)d->num_channels * (size_t)n_frames, n_frames);
+    if (mode == LC3_RECON_WAVE && (rc = lc3_tns_lds_optin()) != LC3GPU_OK) return rc;
+    const size_t t0 = d->timer.used;
+    d->timer.begin(stream);
+    hipLaunchKernelGGL(lc3_parse_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, d_in, d_bad, d->d_planes, n_frames, io, mode);
+    LC3_LAUNCH_CHECK(d, stream, t0);
+    d->timer.mark(stream, 0);
+    lc3_groups Gx;  // the group table for other numbers of frames per workgroup
+    unsigned gx_a, gx_b;
+    size_t gx_f;
+    int gx_m;
+    if (mode == LC3_RECON_WAVE) {
+        fill_groups(*d, n_frames, (unsigned)LC3_WG_WAVES, Gx, gx_a, gx_b, gx_f, gx_m);
+        hipLaunchKernelGGL(lc3_recon_mixed_kernel, dim3(gx_b), dim3(64 * LC3_WG_WAVES), 0, stream, Gx, d->d_planes, n_frames);
+        LC3_LAUNCH_CHECK(d, stream, t0);
+        d->timer.mark(stream, 1);
+    }
+    if (mode == LC3_RECON_WAVE) {
+        fill_groups(*d, n_frames, (unsigned)LC3_TNS_FPB, Gx, gx_a, gx_b, gx_f, gx_m);
+        hipLaunchKernelGGL(lc3_tns_mixed_kernel, dim3(gx_b), dim3(LC3_TNS_FPB), LC3_TNS_LDS, stream, Gx, d->d_planes, n_frames);
+        LC3_LAUNCH_CHECK(d, stream, t0);
+        d->timer.mark(stream, 2);
+    }
+    if (mode == LC3_RECON_LATE)
         hipLaunchKernelGGL(lc3_decode_mixed_late_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, d->d_states,
                            (const int32_t *)d->d_planes, d_pcm, n_frames, 0, io);
     else
         hipLaunchKernelGGL(lc3_decode_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, d->d_states,
                            (const int32_t *)d->d_planes, d_pcm, n_frames, 0, io);
-    HIP_TRY(hipGetLastError());
-    d->timer.mark(stream);
+    LC3_LAUNCH_CHECK(d, stream, t0);
+    d->timer.mark(stream, 3);
     return d->order_end(stream);
 }
 
@@ -1854,7 +2035,6 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
 int lc3gpu_encoder_timing(lc3gpu_encoder *e, int enable, double out[5]) {
     if (!e) return LC3GPU_EINVAL;
     LC3_ON_DEVICE(e);
-    e->timer.stages = 4;
     e->timer.collect();
     if (out) {
         for (int k = 0; k < 4; k++) out[k] = e->timer.ms[k];
@@ -1865,15 +2045,33 @@ int lc3gpu_encoder_timing(lc3gpu_encoder *e, int enable, double out[5]) {
     e->timer.enabled = enable != 0;
     return LC3GPU_OK;
 }
-// decoder: out[3] = {parse+reconstruct ms, synthesis ms, launches}
-int lc3gpu_decoder_timing(lc3gpu_decoder *d, int enable, double out[3]) {
+// decoder: out[3] = {parse + reconstruction ms, synthesis ms, launches}
+static int decoder_timing_read(lc3gpu_decoder *d, int enable, double ms[4], double *launches) {
     if (!d) return LC3GPU_EINVAL;
     LC3_ON_DEVICE(d);
     d->timer.collect();
-    if (out) { out[0] = d->timer.ms[0]; out[1] = d->timer.ms[1]; out[2] = (double)d->timer.launches; }
-    d->timer.ms[0] = d->timer.ms[1] = 0.0;
+    for (int k = 0; k < 4; k++) {
+        ms[k] = d->timer.ms[k];
+        d->timer.ms[k] = 0.0;
+    }
+    *launches = (double)d->timer.launches;
     d->timer.launches = 0;
     d->timer.enabled = enable != 0;
+    return LC3GPU_OK;
+}
+int lc3gpu_decoder_timing(lc3gpu_decoder *d, int enable, double out[3]) {
+    double ms[4], n;
+    const int rc = decoder_timing_read(d, enable, ms, &n);
+    if (rc) return rc;
+    if (out) { out[0] = ms[0] + ms[1] + ms[2]; out[1] = ms[3]; out[2] = n; }
+    return LC3GPU_OK;
+}
+// the same kernel by kernel: out[5] = {parse ms, reconstruction kernel ms, TNS kernel ms, synthesis ms, launches}
+int lc3gpu_decoder_timing_kernels(lc3gpu_decoder *d, int enable, double out[5]) {
+    double ms[4], n;
+    const int rc = decoder_timing_read(d, enable, ms, &n);
+    if (rc) return rc;
+    if (out) { out[0] = ms[0]; out[1] = ms[1]; out[2] = ms[2]; out[3] = ms[3]; out[4] = n; }
     return LC3GPU_OK;
 }
 

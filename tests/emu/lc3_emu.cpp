@@ -140,6 +140,7 @@ static inline uint32_t lc3_wave_exscan_u32(uint32_t v, int lane) {
 }
 
 #include "../../lc3-codec_amd/csrc/lc3_dev_dec.h"
+#include "../../lc3-codec_amd/csrc/lc3_dev_dec_recon.h"
 #include "../../lc3-codec_amd/csrc/lc3_dev_enc.h"
 #include "../../lc3-codec_amd/csrc/lc3_host_plan.h"
 
@@ -152,6 +153,8 @@ struct Job {
     int n_frames, nbytes, fresh, spec_flags, late;
     lc3_enc_lds *EL;  // the workgroup's array of working sets
     lc3_dec_lds *DL;
+    lc3_recon_tables *RT;  // wave-per-frame reconstruction: the workgroup's tables and the waves' scratch
+    lc3_recon_wave *RW;
     lc3_enc_state *est;   // this stream's state blob
     lc3_dec_state *dst;
     const int16_t *pcm_in;
@@ -200,6 +203,9 @@ void *lane_main(void *arg) {
             cur = nxt;
         }
         if (j->valid) lc3_enc_state_store(j->cfg, L, lane, j->est, nullptr);
+    } else if (j->encode == 3) {  // body of lc3_recon_kernel: one wave per frame
+        if (j->valid)
+            lc3_recon_frame_direct(j->cfg, *j->RT, j->RW[j->wave], lane, LC3_PLANE_COL((int32_t *)j->planes, j->frame0, LC3_PLANE_WORDS), j->nbytes);
     } else {
         lc3_dec_lds &L = j->DL[j->wave];
         if (j->fresh) lc3_dec_state_init(L, lane, j->dst, j->valid);
@@ -334,7 +340,8 @@ int lc3emu_decode(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8
                   int16_t *pcm) {
     return lc3emu_decode_late(fs_hz, frame_us, nbytes, S, T, bytes, bad, pcm, 0);
 }
-// late = 1: the reconstruction runs in the synthesis stage (what the library does for launches of a few frames)
+// late = 1: the reconstruction runs in the synthesis stage (what the library does for launches of a few frames); late = 2: in the
+// wave-per-frame reconstruction kernel between parser and synthesis (full batches)
 int lc3emu_decode_late(int fs_hz, int frame_us, int nbytes, int S, int T, const uint8_t *bytes, const uint8_t *bad, int16_t *pcm,
                        int late) {
     Job j;
@@ -370,10 +377,21 @@ int lc3emu_decode_late(int fs_hz, int frame_us, int nbytes, int S, int T, const 
         c.stride = LC3_PLANE_STRIDE;
         c.head = 0;
         c.tail = 0;
-        int rc = (bad && bad[f]) ? -100 : lc3_parse_frame(c, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10);
+        int rc;
+        if (late == 2) rc = (bad && bad[f]) ? -100 : lc3_parse_frame<0>(c, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10);
+        else rc = (bad && bad[f]) ? -100 : lc3_parse_frame<1>(c, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10);
         int ok = rc == 0;
-        if (ok && late) ok = lc3_reconstruct_prepare_late(c);
-        else if (ok) {  // the same lane rebuilds the spectrum (lc3_parse_kernel)
+        if (ok && late == 2) {  // the reconstruction kernels take the pulse vector de-enumerated and count the residual bits themselves
+            lc3_recon_ctx r;
+            r.scf = nullptr;
+            r.sstride = 0;
+            r.mpvq = &LC3T_MPVQ_OFFSETS[0][0];
+            r.ifs = nullptr;
+            lc3_reconstruct_prepare_wave(c);
+            lc3_parse_pulses(c, r);
+        } else if (ok && late) {
+            ok = lc3_reconstruct_prepare_late(c);
+        } else if (ok) {  // the same lane rebuilds the spectrum (lc3_parse_kernel)
             float scf[16];
             lc3_recon_ctx r;
             r.scf = scf;
@@ -389,6 +407,39 @@ int lc3emu_decode_late(int fs_hz, int frame_us, int nbytes, int S, int T, const 
     lc3_dec_state *st = (lc3_dec_state *)aligned_alloc(16, LC3_WG_WAVES * sizeof(lc3_dec_state));
     j.DL = L;
     j.planes = planes.data();
+    if (late == 2) {  // stage 1b: the wave-per-frame reconstruction kernel (lc3_recon_kernel), LC3_WG_WAVES frames per workgroup
+        static lc3_recon_tables rt;
+        static lc3_recon_wave rw[LC3_WG_WAVES];
+        lc3_recon_tables_stage(j.cfg, rt, 0, 1);
+        j.RT = &rt;
+        j.RW = rw;
+        for (size_t f0 = 0; f0 < frames; f0 += LC3_WG_WAVES) {
+            Job protos[LC3_WG_WAVES];
+            memset(rw, 0xFF, sizeof(rw));  // LDS is not zeroed on the GPU
+            for (int w = 0; w < LC3_WG_WAVES; w++) {
+                protos[w] = j;
+                protos[w].encode = 3;
+                protos[w].valid = f0 + (size_t)w < frames;
+                protos[w].frame0 = f0 + (size_t)w;
+            }
+            run_wg(protos);
+        }
+        // stage 1c: the lane-per-frame TNS pass (lc3_tns_kernel) -- on the GPU 64 frames per wave, here a plain loop
+        static float gains[64], sin_tab[17];
+        static uint32_t lb[LC3_MAX_NF / 4];
+        for (int i = 0; i < 17; i++) sin_tab[i] = lc3_tns_sin_dec_value(i);
+        for (int i = 0; i < LC3_MAX_NF / 4; i++) lb[i] = lc3_line_band_word(j.cfg, i);
+        for (size_t f = 0; f < frames; f++) {
+            lc3_tns_lane_ctx x;
+            x.col = LC3_PLANE_COL(planes.data(), f, LC3_PLANE_WORDS);
+            x.gains = gains;
+            x.gstride = 1;
+            x.sin_tab = sin_tab;
+            x.line_band = lb;
+            lc3_tns_lane_frame(j.cfg, x, 1);
+        }
+        j.late = 0;  // the synthesis stage finds f32 spectra
+    }
     for (int s0 = 0; s0 < S; s0 += LC3_WG_WAVES) {
         Job protos[LC3_WG_WAVES];
         memset(L, 0xFF, LC3_WG_WAVES * sizeof(lc3_dec_lds));  // (see lc3emu_encode)

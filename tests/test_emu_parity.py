@@ -149,37 +149,39 @@ def test_emu_guarded_decisions_and_their_sequential_path(fs, us, nf, nbytes):
     assert np.array_equal(E.encode(pcm, nbytes, fs, us, spec_flags=512), ref)
 
 
-def test_emu_late_reconstruction():
+@pytest.mark.parametrize("late", [1, 2])
+def test_emu_late_reconstruction(late):
     """Launches of a few frames reconstruct the spectrum (residual bits, noise filling, gain, TNS, band gains) with the 64 lanes of
     the stream's wave in the synthesis stage instead of one lane of the parser (lc3_dec_reconstruct_wave): the same PCM as the
     oracle on clean streams of every kind, on corrupted and flagged frames (concealment then reads the state blob's copy of the
-    last good spectrum), on garbage, and through the LTPF transitions."""
+    last good spectrum), on garbage, and through the LTPF transitions.  late = 2: the same wave-parallel reconstruction as the
+    wave-per-FRAME kernel of full batches (lc3_recon_kernel) between parser and synthesis."""
     for fs, us, nf, nb in [(48000, 10000, 480, 150), (48000, 7500, 360, 113), (32000, 10000, 320, 40), (24000, 7500, 180, 60),
                            (16000, 10000, 160, 120), (8000, 10000, 80, 30), (48000, 10000, 480, 20), (48000, 10000, 480, 400)]:
         pcm = synth.make_pcm(8, 6, nf, fs, first_stream=300)
         data = O.encode_batch(pcm, nb, fs, us, spec_flags=1 if fs == 8000 else 0)
-        assert np.array_equal(E.decode(data, nf, fs, us, late=1), O.decode_batch(data, nf, fs, us)), (fs, us, nb)
+        assert np.array_equal(E.decode(data, nf, fs, us, late=late), O.decode_batch(data, nf, fs, us)), (fs, us, nb)
     pcm = synth.make_pcm(3, 8, 480, 48000, seed=3)
     data = O.encode_batch(pcm, 150).copy()
     data[0, 2, -1] |= 7
     data[0, 3, -1] |= 7
     data[1, 4] = np.random.default_rng(1).integers(0, 256, 150, dtype=np.uint8)
     data[2, 7, -1] |= 7  # a launch that ends in a lost frame
-    assert np.array_equal(E.decode(data, 480, late=1), O.decode_batch(data, 480))
+    assert np.array_equal(E.decode(data, 480, late=late), O.decode_batch(data, 480))
     bad = np.zeros((3, 8), np.uint8)
     bad[2, 1] = bad[0, 0] = 1
     corrupt = O.encode_batch(pcm, 150).copy()
     corrupt[2, 1, -1] |= 7
     corrupt[0, 0, -1] |= 7
-    assert np.array_equal(E.decode(O.encode_batch(pcm, 150), 480, bad=bad, late=1), O.decode_batch(corrupt, 480))
+    assert np.array_equal(E.decode(O.encode_batch(pcm, 150), 480, bad=bad, late=late), O.decode_batch(corrupt, 480))
     rng = np.random.default_rng(23)
     for nbytes in (20, 40, 150, 400):
         g = rng.integers(0, 256, (12, 4, nbytes), dtype=np.uint8)
-        assert np.array_equal(E.decode(g, 480, late=1), O.decode_batch(g, 480)), nbytes
+        assert np.array_equal(E.decode(g, 480, late=late), O.decode_batch(g, 480)), nbytes
     for fs, nf, nb in ((48000, 480, 40), (16000, 160, 40)):
         lp = synth.make_ltpf_pcm(nf, fs)
         d = O.encode_batch(lp, nb, fs, 10000)
-        assert np.array_equal(E.decode(d, nf, fs, 10000, late=1), O.decode_batch(d, nf, fs, 10000))
+        assert np.array_equal(E.decode(d, nf, fs, 10000, late=late), O.decode_batch(d, nf, fs, 10000))
     bl = synth.make_bandlimited_pcm(8, 6, 480, 48000, 7000.0)  # lower bandwidth indices: other TNS / noise-filling limits
     d = O.encode_batch(bl, 100)
-    assert np.array_equal(E.decode(d, 480, late=1), O.decode_batch(d, 480))
+    assert np.array_equal(E.decode(d, 480, late=late), O.decode_batch(d, 480))

@@ -678,8 +678,9 @@ def test_stress_parity_tool_small_run():
 
 def test_late_reconstruction_on_and_off():
     """Launches of at most 16 384 frames and four frames per stream rebuild the spectrum in the synthesis kernel with the wave's 64 lanes
-    (lc3_dec_reconstruct_wave), larger ones in the parse kernel with one lane per frame (lc3_reconstruct_frame).  Both forms on
-    the same launches (LC3GPU_LATE_RECON=0 / 1 overrides the size rule): clean, corrupted, flagged and garbage streams."""
+    (lc3_dec_reconstruct_wave), larger ones in a wave-per-frame kernel of its own (lc3_recon_kernel); the round-1/2 form (one lane per
+    frame inside the parse kernel, lc3_reconstruct_frame) stays selectable.  All three forms on the same launches
+    (LC3GPU_RECON=lane|late|wave overrides the size rule): clean, corrupted, flagged and garbage streams."""
     import os
     import subprocess
     import sys
@@ -702,8 +703,9 @@ def test_late_reconstruction_on_and_off():
         "print('late ok')\n"
     )
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for v in ("0", "1"):
-        env = dict(os.environ, LC3GPU_LATE_RECON=v)
+    for v in ("lane", "late", "wave"):
+        env = dict(os.environ, LC3GPU_RECON=v)
+        env.pop("LC3GPU_LATE_RECON", None)
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "late ok" in r.stdout, v + r.stdout[-2000:] + r.stderr[-2000:]
 
