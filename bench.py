@@ -120,44 +120,72 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(mode, budget_1t=6.0, budget_all=12.0):
-    """Time the CPU oracle (a C port of the reference; the reference itself is Rust and cannot be built on the box) on a
-    bounded sample of the bench workload: every stream keeps ONE encoder / decoder object for all its frames (init
-    amortised over 512 frames), one stream per thread at a time.  Two legs: 1 thread, and every host core."""
+def granted_cpus():
+    """-> (threads this process may run on, how that was determined).  os.cpu_count() is the machine; what the job is granted is
+    the affinity mask capped by the cgroup CPU quota (cpu.max / cfs_quota_us)."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    n = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return n, {"os_cpu_count": os.cpu_count(), "sched_getaffinity": aff, "cgroup_cpu_quota": quota}
+
+
+def cpu_baseline(mode, seconds=2.5):
+    """Time the CPU oracle (a C port of the reference; the reference itself is Rust and cannot be built on the box) on a bounded
+    sample of the bench workload.  One C call per leg (oracle/lc3_batch.c::lc3o_timed_run): N threads, each with ONE persistent
+    encoder / decoder object, code 128-frame streams of the bench generator's PCM for `seconds`; thread creation, allocation and
+    initialisation lie outside the timed region.  Legs: 1, 2, 4, ... threads up to what the job is granted (affinity mask capped by
+    the cgroup quota -- not os.cpu_count())."""
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
     synth = importlib.import_module("lc3-codec_amd.synth")
-    cores = os.cpu_count() or 1
-    T = 512
+    granted, how = granted_cpus()
+    T = 128
     base = synth.make_pcm(64, 8, NF, FS)                 # 64 distinct streams of the bench generator ...
-    pcm64 = np.tile(base, (1, T // 8, 1))                # ... 512 consecutive frames each
-
-    def leg(threads, budget):
-        S = max(threads, 2) if threads > 1 else 2
-        sample = np.ascontiguousarray(np.tile(pcm64, ((S + 63) // 64, 1, 1))[:S])
-        done, t0 = 0, time.perf_counter()
-        while True:
-            b = O.encode_batch(sample, NBYTES, FS, US, threads=threads)
-            if mode == "roundtrip":
-                O.decode_batch(b, NF, FS, US, threads=threads)
-            done += S * T
-            dt = time.perf_counter() - t0
-            if dt >= budget:
-                return done / dt, done, dt, S
-
-    v1, n1, d1, s1 = leg(1, budget_1t)
-    va, na, da, sa = leg(cores, budget_all)
+    pcm = np.ascontiguousarray(np.tile(base, (1, T // 8, 1)))  # ... 128 consecutive frames each
+    legs, n = [], 1
+    while n < granted:
+        legs.append(n)
+        n *= 2
+    legs.append(granted)
+    scaling = []
+    for th in legs:
+        frames, dt = O.timed_run(pcm, NBYTES, FS, US, threads=th, roundtrip=(mode == "roundtrip"), seconds=seconds)
+        scaling.append({"threads": th, "value": frames / dt, "frames": int(frames), "seconds": dt})
+    v1, va = scaling[0], scaling[-1]
     what = "encode+decode" if mode == "roundtrip" else "encode"
+    eff = va["value"] / (v1["value"] * va["threads"])
+    note = None
+    if eff < 0.5:
+        note = (f"all-threads / 1-thread = {va['value'] / v1['value']:.1f}x on {va['threads']} threads (efficiency {eff:.2f}): the threads are "
+                "SMT siblings / share memory bandwidth and boost clocks; see `scaling` for where it flattens")
     return {
-        "value": va, "unit": "frames/s", "cores": cores, "kind": "port",
-        "threads_1": {"value": v1, "unit": "frames/s", "cores": 1,
-                      "sample": f"{n1} frames ({s1} streams x {T} consecutive frames, repeated), {what}, {d1:.1f} s"},
-        "nproc": cores, "cpu_model": _cpu_model(),
-        "sample": f"{na} frames ({sa} streams x {T} consecutive frames per pass, one persistent codec object per stream, "
-                  f"repeated) of the bench generator's PCM, {what}, {cores} host threads, {da:.1f} s",
+        "value": va["value"], "unit": "frames/s", "cores": va["threads"], "kind": "port",
+        "threads_1": {"value": v1["value"], "unit": "frames/s", "cores": 1,
+                      "sample": f"{v1['frames']} frames, {what}, {v1['seconds']:.1f} s"},
+        "scaling": scaling, "parallel_efficiency": eff, "granted": how, "cpu_model": _cpu_model(),
+        "sample": f"{va['frames']} frames of the bench generator's PCM (64 distinct streams x {T} consecutive frames, one persistent "
+                  f"codec object per thread, a stream per pass), {what}, {va['threads']} host threads, {va['seconds']:.1f} s; "
+                  "threads, buffers and codec objects are created before the clock starts",
+        "note": note,
     }
 
 
@@ -174,6 +202,24 @@ def kernel_source_sha():
         with open(p, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
+
+
+def load_ceiling():
+    """the measured issue ceiling and copy bandwidth (tools/valu_ceiling.hip -> profiles/r03_valu_ceiling.json): cycles per wave64
+    vector instruction of the codec's instruction mix on one SIMD, by waves per SIMD, and the device copy rate"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_valu_ceiling.json")) as f:
+            j = json.load(f)
+        mix = {r["waves_per_simd"]: r["cycles_per_wave_instr"] for r in j["valu"] if r["instruction"].startswith("mix")}
+        return {"cycles_per_instr_by_waves_per_simd": mix, "copy_GBs": j["copy"]["GBs_read_plus_write"],
+                "source": "profiles/r03_valu_ceiling.json (tools/valu_ceiling.hip on an MI355X of this pool)"}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+# resident waves per SIMD of each kernel on the 65 536-frame batch (lane-per-frame kernels: 1 024 waves on 1 024 SIMDs)
+WAVES_PER_SIMD = {"lc3_enc_front_kernel": 4, "lc3_sns_vq_kernel": 1, "lc3_enc_back_kernel": 4, "lc3_pack_kernel": 1,
+                  "lc3_parse_kernel": 1, "lc3_recon_kernel": 8, "lc3_tns_kernel": 1, "lc3_decode_kernel": 4}
 
 
 def load_pmc():
@@ -211,6 +257,7 @@ class GpuEngine:
         self.encs = mk(pkg.Lc3Encoder)
         self.decs = mk(pkg.Lc3Decoder) if mode == "roundtrip" else []
         self.hs = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(NP - 1)]
+        self.marks = []
 
     device = "cuda"
 
@@ -224,6 +271,17 @@ class GpuEngine:
 
     def sync(self):
         self.torch.cuda.synchronize()
+
+    def step_mark(self):
+        """an event on the launch stream (single-stream runs only): consecutive marks bracket one step"""
+        if self.NP == 1:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record(self.hs[0])
+            self.marks.append(e)
+
+    def step_times_ms(self):
+        m, self.marks = self.marks, []
+        return [m[i].elapsed_time(m[i + 1]) for i in range(len(m) - 1)]
 
     def reset(self):
         for h in self.encs + self.decs:
@@ -297,6 +355,12 @@ class EmuEngine:
 
     def sync(self):
         pass
+
+    def step_mark(self):
+        pass
+
+    def step_times_ms(self):
+        return []
 
     def reset(self):
         pass
@@ -393,17 +457,21 @@ def run_rank(args):
         dist.barrier()
     eng.sync()
 
-    # timed region: exactly K steps; per-kernel durations from HIP events the C ABI records on the launch stream
+    # timed region: exactly K steps; per-kernel durations from HIP events the C ABI records on the launch stream, and one event
+    # after every step for the per-step minimum / median
     eng.timing_start()
+    eng.step_mark()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.step()
+        eng.step_mark()
     eng.sync()
     if dist is not None:
         dist.barrier()
     eng.sync()
     elapsed = time.perf_counter() - t0
     kernel_ms = eng.timing_stop()
+    step_ms = sorted(eng.step_times_ms())
 
     # max time over ranks, counters summed over ranks (the only collective of the job)
     red_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else eng.device
@@ -436,31 +504,40 @@ def run_rank(args):
             # counters of the committed PMC passes, scaled to this run's frames per launch; withheld (null) unless the file
             # was measured on exactly these kernel sources
             pj, pmc_note = load_pmc()
-            traffic = valu_issue = valu_pipe = lane_frac = None
+            traffic = valu_frac = lane_frac = valu_insts = None
+            ceil = load_ceiling()
             if pj is not None:
                 scale = frames_per_step / pj["frames_per_launch"]
                 kk = pj["kernels"]
-                traffic = sum(kk[k]["fetch_size_kb"] + kk[k]["write_size_kb"] for k in groups[dom]) * 1024.0 * scale
-                insts = sum(kk[k]["sq_insts_valu"] for k in kernel_ms) * scale
-                thread_cyc = sum(kk[k]["sq_thread_cycles_valu"] for k in kernel_ms) * scale
-                cycles = sum(kernel_ms.values()) * 1e-3 * CLOCK_MHZ * 1e6
-                valu_issue = insts * 4.0 / (N_SIMD * cycles)   # one wave's issue cost: 4 cycles per VALU instruction
-                valu_pipe = insts * 2.0 / (N_SIMD * cycles)    # SIMD-32 pipe: 2 cycles per wave64 VALU instruction
-                lane_frac = thread_cyc / (insts * 64.0)
+                live = [k for k in kernel_ms if k in kk and kernel_ms[k] > 0.002]  # kernels this run launched
+                traffic = sum(kk[k]["fetch_size_kb"] + kk[k]["write_size_kb"] for k in groups[dom] if k in kk) * 1024.0 * scale
+                valu_insts = {k: kk[k]["sq_insts_valu"] * scale for k in live}
+                thread_cyc = sum(kk[k]["sq_thread_cycles_valu"] for k in live) * scale
+                lane_frac = thread_cyc / (sum(valu_insts.values()) * 64.0)
+                if ceil is not None:
+                    # cycles the step's vector instructions need at the MEASURED issue rate of this instruction mix (by the kernel's
+                    # resident waves per SIMD) over the SIMD-cycles the step's kernels had (at the maximum clock: a lower bound)
+                    cpi = ceil["cycles_per_instr_by_waves_per_simd"]
+                    need = sum(valu_insts[k] * cpi[min(cpi, key=lambda w: abs(w - WAVES_PER_SIMD.get(k, 4)))] for k in live)
+                    have = N_SIMD * sum(kernel_ms[k] for k in live) * 1e-3 * CLOCK_MHZ * 1e6
+                    valu_frac = need / have
                 pmc_note = pj.get("source")
             roof = {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "measured_copy_GBs": ceil["copy_GBs"] if ceil else None,
                 "algorithmic_bytes_per_frame": alg,
                 "roundtrip_algorithmic_bytes_per_frame": ALG_BYTES_ENC + (ALG_BYTES_DEC if mode == "roundtrip" else 0),
                 "roundtrip_achieved_GBs": value * (ALG_BYTES_ENC + (ALG_BYTES_DEC if mode == "roundtrip" else 0)) / 1e9 / world,
-                "valu_issue_frac": valu_issue, "valu_pipe_frac": valu_pipe, "active_lane_frac": lane_frac,
+                "valu_frac": valu_frac, "active_lane_frac": lane_frac, "valu_insts_per_step": valu_insts, "valu_ceiling": ceil,
                 "pmc": pmc_note,
                 "note": "instruction/latency-bound, not HBM-bound (SURVEY 8d honesty note): ~60 flop per algorithmic byte. "
-                        "traffic = FETCH_SIZE + WRITE_SIZE of the dominant unit per launch; valu_issue_frac = sum SQ_INSTS_VALU x 4 / "
-                        "(1024 SIMDs x cycles of the step's kernels at 2.4 GHz), valu_pipe_frac the same at the SIMD-32 rate of 2 "
-                        "cycles per instruction; active_lane_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU); all from the "
-                        "committed rocprofv3 PMC passes (profiles/pmc_latest.json), null when they were taken on other sources",
+                        "traffic = FETCH_SIZE + WRITE_SIZE of the dominant unit per launch; measured_copy_GBs = what a 16-byte-per-lane copy "
+                        "kernel reaches on this chip (read + write), beside the 8 TB/s vendor figure `frac` divides by; valu_frac = sum over "
+                        "the step's kernels of SQ_INSTS_VALU x (measured cycles per wave instruction of the codec's instruction mix at that "
+                        "kernel's waves per SIMD) / (1024 SIMDs x the kernels' cycles at 2.4 GHz); active_lane_frac = SQ_THREAD_CYCLES_VALU / "
+                        "(64 x SQ_INSTS_VALU); counters from the committed rocprofv3 PMC passes (profiles/pmc_latest.json), null when they "
+                        "were taken on other kernel sources",
             }
         if mode == "roundtrip":
             workload = (f"{frames_per_step}-frame batch mono 48 kHz / 10 ms / 150-byte frames, encode+decode (BASELINE configs[1]); "
@@ -472,7 +549,9 @@ def run_rank(args):
             metric = "LC3 frames/sec (encode) @48kHz/10ms"
         line = {
             "metric": metric, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_min": step_ms[0] if step_ms else None, "ms_per_step_median": step_ms[len(step_ms) // 2] if step_ms else None,
+            "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": workload, "mode": mode, "streams_per_gpu": S, "frames_per_stream_per_step": T,

@@ -6,6 +6,8 @@
 #include "lc3_oracle.h"
 #include <pthread.h>
 #include <stdlib.h>
+#include <string.h>
+#include <time.h>
 
 typedef struct {
     int fs_hz, frame_us, nbytes, n_frames, s_begin, s_end, nf, encode, rc, spec_flags;
@@ -94,4 +96,98 @@ int lc3o_decode_batch(int fs_hz, int frame_us, int nbytes, int n_streams, int n_
     j.fs_hz = fs_hz; j.frame_us = frame_us; j.nbytes = nbytes; j.n_frames = n_frames; j.encode = 0;
     j.bytes_in = bytes; j.pcm_out = pcm;
     return run(j, n_streams, n_threads);
+}
+
+/* ---- bench.py's cpu_baseline leg --------------------------------------------------------------------------------------------
+ * n_threads host threads, each with ONE persistent encoder (and decoder, when roundtrip) coding its own stream of n_frames
+ * consecutive frames, again and again, until `seconds` have passed.  Threads are created, allocate and initialise their codec
+ * objects and buffers, and meet at a barrier BEFORE the clock starts: no allocation and no thread creation inside the timed
+ * region.  pcm: int16[n_distinct][n_frames][nf]; thread t codes streams t, t + 1, ... (mod n_distinct), one per pass.
+ * Out: total frames coded (an encode+decode pair counts once) and the time from the barrier to the last thread's finish. */
+typedef struct {
+    int fs_hz, frame_us, nbytes, n_frames, nf, roundtrip, rc, first, n_distinct;
+    const int16_t *pcm;
+    double seconds, frames, t_end;
+    pthread_barrier_t *bar;
+    double *t_start;
+} tjob;
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *timed_worker(void *arg) {
+    tjob *j = (tjob *)arg;
+    lc3o_encoder *e = (lc3o_encoder *)malloc(sizeof(lc3o_encoder));
+    lc3o_decoder *d = (lc3o_decoder *)malloc(sizeof(lc3o_decoder));
+    uint8_t *bytes = (uint8_t *)malloc((size_t)j->nbytes);
+    int16_t *out = (int16_t *)malloc(sizeof(int16_t) * (size_t)j->nf);
+    int t;
+    double t0, deadline;
+    if (!e || !d || !bytes || !out || lc3o_encoder_init_spec(e, j->fs_hz, j->frame_us, 0) || lc3o_decoder_init(d, j->fs_hz, j->frame_us))
+        j->rc = -1;
+    memset(bytes, 0, (size_t)j->nbytes);
+    pthread_barrier_wait(j->bar);
+    t0 = now_s();
+    if (j->t_start) *j->t_start = t0;
+    deadline = t0 + j->seconds;
+    if (!j->rc) {
+        int pass = 0;
+        do {  /* one pass = one stream from its first frame (fresh codec objects: ~1 frame's worth of work per n_frames) */
+            const int16_t *x = j->pcm + (size_t)((j->first + pass) % j->n_distinct) * (size_t)j->n_frames * (size_t)j->nf;
+            if (pass > 0 && (lc3o_encoder_init_spec(e, j->fs_hz, j->frame_us, 0) || lc3o_decoder_init(d, j->fs_hz, j->frame_us))) { j->rc = -1; break; }
+            for (t = 0; t < j->n_frames; t++) {
+                lc3o_encode_frame(e, x + (size_t)t * (size_t)j->nf, bytes, j->nbytes);
+                if (j->roundtrip) lc3o_decode_frame(d, 16, bytes, j->nbytes, out);
+            }
+            j->frames += (double)j->n_frames;
+            pass++;
+        } while (now_s() < deadline);
+    }
+    j->t_end = now_s();
+    free(e);
+    free(d);
+    free(bytes);
+    free(out);
+    return 0;
+}
+
+int lc3o_timed_run(int fs_hz, int frame_us, int nbytes, int n_frames, const int16_t *pcm, int n_distinct, int n_threads, int roundtrip,
+                   double seconds, double *frames_out, double *elapsed_out) {
+    lc3o_config c;
+    pthread_barrier_t bar;
+    pthread_t *th;
+    tjob *jobs;
+    double t_start = 0.0, t_end = 0.0, frames = 0.0;
+    int i, rc = 0;
+    if (n_threads < 1 || n_distinct < 1 || n_frames < 1 || lc3o_config_new(&c, fs_hz, frame_us)) return -1;
+    th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    jobs = (tjob *)calloc((size_t)n_threads, sizeof(tjob));
+    if (!th || !jobs) return -2;
+    pthread_barrier_init(&bar, 0, (unsigned)n_threads);
+    for (i = 0; i < n_threads; i++) {
+        tjob *j = &jobs[i];
+        j->fs_hz = fs_hz; j->frame_us = frame_us; j->nbytes = nbytes; j->n_frames = n_frames; j->nf = c.nf; j->roundtrip = roundtrip;
+        j->pcm = pcm;
+        j->first = i % n_distinct;
+        j->n_distinct = n_distinct;
+        j->seconds = seconds;
+        j->bar = &bar;
+        j->t_start = i == 0 ? &t_start : 0;
+        if (pthread_create(&th[i], 0, timed_worker, j)) { rc = -3; n_threads = i; break; }
+    }
+    for (i = 0; i < n_threads; i++) {
+        pthread_join(th[i], 0);
+        if (jobs[i].rc) rc = jobs[i].rc;
+        frames += jobs[i].frames;
+        if (jobs[i].t_end > t_end) t_end = jobs[i].t_end;
+    }
+    pthread_barrier_destroy(&bar);
+    free(th);
+    free(jobs);
+    if (frames_out) *frames_out = frames;
+    if (elapsed_out) *elapsed_out = t_end - t_start;
+    return rc;
 }

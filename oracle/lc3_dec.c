@@ -10,6 +10,7 @@
 
 /* test-coverage statistic: how often each LTPF transition case (1..5) ran; not thread-safe, informational */
 long lc3o_ltpf_trans_count[6];
+int lc3o_ltpf_trans_counting = 0; /* tests switch the coverage statistic on (oracle_lib.ltpf_transition_counts); off, decode threads share no counter */
 #define TF(name) ((const float *)(const void *)LC3T_##name##_BITS)
 
 const float *lc3o_mdct_window(const lc3o_config *c);
@@ -617,7 +618,7 @@ void lc3o_dec_ltpf(const lc3o_config *c, lc3o_ltpf_dec_state *st, const lc3o_ltp
     else if (!info->is_active && st->ltpf_active_prev) trans = 3;
     else if (pitch_int == st->p_int_mem && pitch_frac == st->p_fr_mem) trans = 4;
     else trans = 5;
-    lc3o_ltpf_trans_count[trans]++; /* test coverage statistic (which LTPF transitions the test inputs reach) */
+    if (lc3o_ltpf_trans_counting) lc3o_ltpf_trans_count[trans]++; /* test coverage statistic (which LTPF transitions the test inputs reach) */
 
     switch (trans) {
     case 1:

@@ -221,6 +221,11 @@ int lc3o_encode_batch(int fs_hz, int frame_us, int nbytes, int n_streams, int n_
                       uint8_t *bytes, int n_threads);
 int lc3o_decode_batch(int fs_hz, int frame_us, int nbytes, int n_streams, int n_frames, const uint8_t *bytes,
                       int16_t *pcm, int n_threads);
+/* bench.py's cpu_baseline leg (lc3_batch.c): n_threads threads with persistent codec objects code for `seconds`; nothing is
+ * allocated and no thread is created inside the timed region */
+int lc3o_timed_run(int fs_hz, int frame_us, int nbytes, int n_frames, const int16_t *pcm, int n_distinct, int n_threads, int roundtrip,
+                   double seconds, double *frames_out, double *elapsed_out);
+extern int lc3o_ltpf_trans_counting;
 /* buffer lengths the reference API reports (lc3_encoder.rs:194-209, lc3_decoder.rs:236-244) */
 void lc3o_encoder_working_buffer_lengths(int num_channels, int fs_hz, int frame_us, int64_t out[3]);
 void lc3o_decoder_working_buffer_lengths(int num_channels, int fs_hz, int frame_us, int64_t out[2]);

@@ -140,8 +140,26 @@ def ltpf_transition_counts(reset=False):
     """How often each decoder LTPF transition case (index 1..5) ran inside the oracle since the last reset."""
     import ctypes
     cnt = (ctypes.c_long * 6).in_dll(lib(), "lc3o_ltpf_trans_count")
+    ctypes.c_int.in_dll(lib(), "lc3o_ltpf_trans_counting").value = 1  # the statistic is off until a test asks for it
     out = [int(v) for v in cnt]
     if reset:
         for i in range(6):
             cnt[i] = 0
     return out
+
+
+def timed_run(pcm, nbytes, fs_hz=48000, frame_us=10000, threads=1, roundtrip=True, seconds=5.0):
+    """bench.py's cpu_baseline leg: `threads` host threads, each with ONE persistent encoder (and decoder) that codes its own stream
+    of consecutive frames (pcm[t % S], cycled) for `seconds`; thread start-up, allocation and initialisation lie outside the timed
+    region.  -> (frames coded, elapsed seconds)"""
+    pcm = np.ascontiguousarray(pcm, np.int16)
+    S, T, nf = pcm.shape
+    frames = ctypes.c_double(0.0)
+    elapsed = ctypes.c_double(0.0)
+    f = lib().lc3o_timed_run
+    f.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_double, ctypes.POINTER(ctypes.c_double),
+                                                                                 ctypes.POINTER(ctypes.c_double)]
+    rc = f(fs_hz, frame_us, nbytes, T, P(pcm), S, int(threads), int(bool(roundtrip)), float(seconds), ctypes.byref(frames),
+           ctypes.byref(elapsed))
+    assert rc == 0, rc
+    return frames.value, elapsed.value
