@@ -74,36 +74,59 @@ def _free_port():
     return p
 
 
-def launch_ranks(n, argv):
-    """Start n ranks of this script (one per GPU), relay rank 0's JSON line; -> process exit code."""
+def launch_ranks(n, argv, limit_s=None):
+    """Start n ranks of this script (one per GPU) as FRESH child processes, relay rank 0's JSON line; -> process exit code.
+    All children are watched while they run: as soon as one exits non-zero (a rank without a GPU, an import error, a crash after
+    the rendezvous) the remaining children -- exactly the processes started here -- are terminated and the launcher returns 1;
+    otherwise rank 0 would sit in a collective until the backend's timeout.  An overall wall-clock limit covers hangs."""
+    import tempfile
+
     port = _free_port()
+    limit_s = float(os.environ.get("LC3_BENCH_LIMIT_S", "1800")) if limit_s is None else limit_s
     procs = []
+    out0 = tempfile.TemporaryFile()  # rank 0's stdout (a file, not a pipe: nobody has to drain it while we poll)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), LC3_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120.0
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()  # exactly the child we started
-            p.wait()
-        rc = rc or p.returncode
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    deadline, rc, why = time.time() + limit_s, 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = 1, "rank %d exited with code %d" % bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            rc, why = 1, "wall-clock limit of %.0f s reached" % limit_s
+            break
+        time.sleep(0.05)
+    if rc:
+        for p in procs:  # the children this launcher started, nothing else
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        sys.stderr.write("bench.py: %s; the other ranks were stopped\n" % why)
+        return 1
+    out0.seek(0)
     line = None
-    for ln in out.decode(errors="replace").splitlines():
+    for ln in out0.read().decode(errors="replace").splitlines():
         if ln.startswith("{"):
             line = ln
     if line is None:
-        rc = rc or 1
         sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
-    else:
-        print(line, flush=True)
-    return int(rc != 0)
+        return 1
+    print(line, flush=True)
+    return 0
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -406,6 +429,11 @@ def run_rank(args):
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    if dist is not None and os.environ.get("LC3_BENCH_TEST_DIE_RANK") == str(rank):
+        # test hook (tests/test_dist_gloo.py): this rank dies after the rendezvous; the launcher must stop the others, which are
+        # about to wait for it in a collective
+        dist.barrier()
+        os._exit(17)
     synth = importlib.import_module("lc3-codec_amd.synth")
     D = importlib.import_module("lc3-codec_amd.dist")
     mode = args.mode

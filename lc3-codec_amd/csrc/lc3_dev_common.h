@@ -100,6 +100,12 @@
 #ifndef LC3_UNIFORM_I32
 #define LC3_UNIFORM_I32(x) (x)
 #endif
+#ifndef LC3_KEEP_PER_FRAME  // lc3gpu.hip: an opaque barrier that keeps what is computed from x inside the loop it is written in
+#define LC3_KEEP_PER_FRAME(x) ((void)0)
+#endif
+#ifndef LC3_UNIFORM_PTR
+#define LC3_UNIFORM_PTR(T, p) ((T)(p))
+#endif
 #ifndef LC3_HBM_CONST
 #define LC3_HBM_CONST(T) const T *
 #define LC3_HBM(T) T *

@@ -112,22 +112,26 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE_HOT lc3_ola5 lc3_dec_imdct(LC3_CFG_PAR
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     const int nf = c.nf, ne = c.ne, z = c.z, h = nf / 2;
-    const uint32_t *w = lc3_window_bits(c);
+    LC3_HBM_CONST(uint32_t) w = LC3_UNIFORM_PTR(LC3_HBM_CONST(uint32_t), lc3_window_bits(c));  // scalar base: the hoisted per-lane addresses are one register each
     float *freq = L.spec;
     float *u = (float *)L.fa;  // DCT-IV output
     // the window coefficients this lane will need are requested now, as one batch of independent loads, and used after the
     // transform
     float wa[5], wb[5], wc[3];  // nf - z <= 300, z <= 180
+    // (the table offsets are formed here, frame by frame, from an opaque copy of the lane number: formed once ahead of the frame loop
+    // they were thirteen live registers, some of them spilled, and every reload from scratch drained the wave's memory queue)
+    int lane_w = lane;
+    LC3_KEEP_PER_FRAME(lane_w);
 #pragma unroll
     for (int r = 0; r < 5; r++) {
-        const int n = lane + LC3_WAVE * r, in = n < nf - z;
-        wa[r] = in ? lc3_f(w, 2 * nf - 1 - (z + n)) : 0.0f;
-        wb[r] = in ? lc3_f(w, 2 * nf - 1 - (nf + z + n)) : 0.0f;
+        const int n = lane_w + LC3_WAVE * r, in = n < nf - z;
+        wa[r] = in ? lc3_from_bits(w[2 * nf - 1 - (z + n)]) : 0.0f;
+        wb[r] = in ? lc3_from_bits(w[2 * nf - 1 - (nf + z + n)]) : 0.0f;
     }
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        const int n = lane + LC3_WAVE * r;
-        wc[r] = n < z ? lc3_f(w, 2 * nf - 1 - (nf + n)) : 0.0f;
+        const int n = lane_w + LC3_WAVE * r;
+        wc[r] = n < z ? lc3_from_bits(w[2 * nf - 1 - (nf + n)]) : 0.0f;
     }
     for (int n = ne + lane; n < nf; n += LC3_WAVE) freq[n] = 0.0f;
     LC3_SYNC();
@@ -627,8 +631,15 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_recon_frame_wave(LC3_CFG_PA
 // nothing else holds it -- on the last frame of a launch (lc3_decode_frame_wave)
 template <class CC>
 __device__ __forceinline__ void lc3_dec_plc_save(const CC &c, lc3_dec_lds &L, int lane, lc3_dec_state *g, int to_blob) {
-    if (to_blob)
-        for (int k = lane; k < c.ne; k += LC3_WAVE) g->plc_last_good[k] = L.spec[k];
+    if (to_blob) {  // ne <= 400: seven rounds, all LDS reads ahead of the stores
+        float v[7];
+#pragma unroll
+        for (int r = 0; r < 7; r++) v[r] = L.spec[lane + LC3_WAVE * r < LC3_MAX_NE ? lane + LC3_WAVE * r : 0];
+        LC3_HBM(float) dst = (LC3_HBM(float))g->plc_last_good + lane;
+#pragma unroll
+        for (int r = 0; r < 7; r++)
+            if (lane + LC3_WAVE * r < c.ne) dst[LC3_WAVE * r] = v[r];
+    }
     if (lane == 0) {
         L.st.plc_num_lost = 0;
         L.st.plc_alpha = 1.0f;
@@ -665,6 +676,22 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_plc_load(LC3_CFG_PARAM, L
         seed = (a64 * seed + c64) & 0xFFFFu;
     }
     LC3_SYNC();
+}
+
+// The interleaved output path as a call: inlined, its eight per-lane addresses were computed ahead of the frame loop and spilled
+// (the planar path, which every full batch takes, paid for them with scratch traffic and a full memory wait at each reload).
+__device__ LC3_DEC_STAGE void lc3_dec_store_strided(int16_t *pcm_out, int stride, int lane, int nv, uint32_t w0, uint32_t w1, uint32_t w2,
+                                                    uint32_t w3) {
+    LC3_HBM(uint16_t) o16 = (LC3_HBM(uint16_t))pcm_out;
+    const uint32_t ow[4] = {w0, w1, w2, w3};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int i = lane + LC3_WAVE * r;
+        if (i < nv) {
+            o16[(size_t)(2 * i) * (size_t)stride] = (uint16_t)(ow[r] & 0xffffu);
+            o16[(size_t)(2 * i + 1) * (size_t)stride] = (uint16_t)(ow[r] >> 16);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -725,15 +752,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
                 else if (lane < rem) ob[LC3_WAVE * r] = ow[r];
             }
         } else {  // interleaved PCM out (examples/decode.rs:93-112 interleaves on the host): sample n at pcm_out[n * stride]
-            LC3_HBM(uint16_t) o16 = (LC3_HBM(uint16_t))pcm_out;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int i = lane + LC3_WAVE * r;
-                if (i < nv) {
-                    o16[(size_t)(2 * i) * (size_t)stride] = (uint16_t)(ow[r] & 0xffffu);
-                    o16[(size_t)(2 * i + 1) * (size_t)stride] = (uint16_t)(ow[r] >> 16);
-                }
-            }
+            lc3_dec_store_strided(pcm_out, stride, lane, nv, ow[0], ow[1], ow[2], ow[3]);
         }
     }
     LC3_SYNC();

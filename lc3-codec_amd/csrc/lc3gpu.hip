@@ -80,7 +80,12 @@ __shared__ lc3_spec_tables lc3_spec_tab;
 #define LC3_HBM_CONST(T) const __attribute__((address_space(1))) T *
 #define LC3_HBM(T) __attribute__((address_space(1))) T *
 #define LC3_UNIFORM_I32(x) __builtin_amdgcn_readfirstlane((int)(x))
+// a pointer the caller knows to be wave-uniform, in scalar registers: loads through it take the (scalar base + 32-bit lane offset) form
+#define LC3_UNIFORM_PTR(T, p)                                                                                             \
+    ((T)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)(uintptr_t)(p) >> 32)) << 32) | \
+         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(p))))
 #define LC3_KEEP_SCALAR(x) asm("" : "+v"(x))
+#define LC3_KEEP_PER_FRAME(x) asm volatile("" : "+v"(x))
 // product of two values below 2^24 (range-coder steps): the full-rate 24-bit multiplier instead of the quarter-rate v_mul_lo_u32
 #define LC3_MUL24(a, b) __umul24((a), (b))
 #define LC3_WAVE_ANY(pred) (__ballot((pred) != 0) != 0ull)

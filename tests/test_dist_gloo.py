@@ -130,3 +130,18 @@ def test_bench_encode_mode_shards_the_batch():
 def test_bench_launcher_reports_a_failing_rank():
     rc, line = _run_bench("--gpus", "2", "--mode", "encode", "--frames-total", "3", "--frames", "2")
     assert rc != 0 and line is None
+
+
+def test_bench_launcher_stops_the_others_when_one_rank_dies_after_the_rendezvous():
+    """exactly one rank exits (code 17) after init_process_group + a barrier; rank 0 would wait in the next collective until the
+    backend's timeout: the launcher sees the dead child, terminates the children it started and returns non-zero quickly"""
+    import subprocess
+    import time
+
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--engine", "emu", "--steps", "1", "--warmup", "0", "--gpus", "2"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, LC3_BENCH_TEST_DIE_RANK="1"))
+    assert p.returncode != 0
+    assert "rank 1 exited with code 17" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert time.time() - t0 < 120.0

@@ -776,3 +776,40 @@ def test_8khz_encode_switch_and_mixed_handle_with_switches():
         ref = O.encode_batch(pcms[i][None], nb, fs, us, spec_flags=31)[0]
         assert np.array_equal(got[off:off + T * nb].reshape(T, nb), ref), (i, fs, us)
         off += T * nb
+
+
+# ---------------------------------------------------------------- the production launcher on the GPU
+def _bench_line(extra, env_extra, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", *extra], capture_output=True, text=True,
+                       timeout=timeout, env=dict(os.environ, **env_extra))
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_two_ranks_through_the_launcher_share_the_gpu():
+    """`bench.py --gpus 2` on a one-GPU box: the production launcher (fresh child processes, rendezvous on 127.0.0.1), the stream
+    sharding, the GPU engine and the final reduction together; the ranks share the visible device and reduce over gloo (RCCL needs
+    one GPU per rank -- LC3_BENCH_BACKEND=gloo is the only thing that differs from the driver's multi-GPU invocation)."""
+    p, line = _bench_line(["--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "2048"], {"LC3_BENCH_BACKEND": "gloo"})
+    assert p.returncode == 0 and line is not None, p.stderr[-2000:]
+    assert line["n_gpus"] == 2 and "world size 2 (gloo)" in line["config"]["parallelism"] and line["config"]["engine"] == "gpu"
+    assert line["scaling"] == "weak" and line["config"]["frames_per_step_per_gpu"] == 2048 * 4
+    assert line["parity"]["bitstream_exact"] and line["parity"]["pcm_max_abs_diff"] == 0 and line["parity_mismatches_all_ranks"] == 0
+    assert abs(line["value"] - 2 * 2048 * 4 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]  # frames of BOTH ranks / max time
+    assert line["kernel_ms"]["lc3_enc_front_kernel"] > 0.0
+
+
+def test_launcher_stops_the_gpu_ranks_when_one_dies():
+    import time
+
+    t0 = time.time()
+    p, line = _bench_line(["--gpus", "2", "--steps", "2", "--warmup", "0", "--streams", "256"],
+                          {"LC3_BENCH_BACKEND": "gloo", "LC3_BENCH_TEST_DIE_RANK": "1"})
+    assert p.returncode != 0 and line is None and "rank 1 exited with code 17" in p.stderr
+    assert time.time() - t0 < 300.0

@@ -57,9 +57,10 @@ if ENC_ONLY:
 enc_ids = [22, 23, 1, 24, 2, 26, 27, 3, 12, 13, 14, 15, 5, 28, 29, 30, 4, 9, 10, 11, 6, 7, 8]
 if ENC_ONLY:
     enc_ids = [22, 23, 20, 21, 1, 24, 2, 26, 27, 3, 12, 13, 14, 17, 15, 5, 18, 19, 28, 29, 30, 4, 9, 10, 11, 6, 7, 8]
-    dec_ids = []
-dec_ids = [17, 18, 25, 19, 20, 21]
+dec_ids = [] if ENC_ONLY else [17, 18, 25, 19, 20, 21]  # (with LC3_PROF_ENC_ONLY the decoder's ids are encoder sub-stages, listed above)
 for ids, label in ((enc_ids, "encoder analysis kernels (front + back)"), (dec_ids, "decoder synthesis kernel")):
+    if not ids:
+        continue
     tot = sum(acc[i] for i in ids)
     print(f"{label}: {tot / frames:.0f} wave-cycles per frame (sum over stages, S={S} T={T})")
     for i in ids:
