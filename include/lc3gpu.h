@@ -168,6 +168,33 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *dec, uint64_t *out);
  * dbg float[1472] = spectrum after MDCT [0,480), after SNS [480,960), after TNS [960,1440), scalars [1440,1472) */
 int lc3gpu_encode_frame_debug(lc3gpu_encoder *enc, const int16_t *samples_in, int n_samples, uint8_t *buf_out,
                               int nbytes, float *dbg);
+/* decode one frame of channel 0 (uniform handles) from host bytes like lc3gpu_decode_frame and also return stage dumps, so that a
+ * decoder stage can be checked on its own (the reference tests every one: decoder/arithmetic_codec.rs:415-474,
+ * residual_spectrum.rs:47-107, noise_filling.rs:65-146, temporal_noise_shaping.rs:147-238, spectral_noise_shaping.rs:244-350,
+ * modified_dct.rs:174-329, long_term_post_filter.rs:504-1199).  dbg float[LC3GPU_DBG_FLOATS], NaN where a form has no such value:
+ *   [LC3GPU_DBG_INT, +ne)    integers after the range decoder            [LC3GPU_DBG_GAIN, +ne)  after residual bits, noise filling, global gain
+ *   [LC3GPU_DBG_TNS, +ne)    after the TNS filter                        [LC3GPU_DBG_SPEC, +ne)  after the SNS band gains (input of the IMDCT)
+ *   [LC3GPU_DBG_IMDCT, +nf)  after IMDCT, window, overlap-add            [LC3GPU_DBG_LTPF, +nf)  after the long-term post-filter
+ * recon_form selects which of the library's three forms of the spectrum reconstruction runs: LC3GPU_RECON_LANE (in the parse
+ * kernel, what full batches use), LC3GPU_RECON_LATE (in the synthesis kernel, what lc3gpu_decode_frame and small launches use),
+ * LC3GPU_RECON_WAVE (the wave-per-frame kernels; no GAIN / TNS dumps). */
+#define LC3GPU_DBG_INT 0
+#define LC3GPU_DBG_SPEC 400
+#define LC3GPU_DBG_IMDCT 800
+#define LC3GPU_DBG_LTPF 1280
+#define LC3GPU_DBG_GAIN 1760
+#define LC3GPU_DBG_TNS 2160
+#define LC3GPU_DBG_FLOATS 2560
+#define LC3GPU_RECON_LANE 0
+#define LC3GPU_RECON_LATE 1
+#define LC3GPU_RECON_WAVE 2
+int lc3gpu_decode_frame_debug(lc3gpu_decoder *dec, int recon_form, const uint8_t *buf_in, int nbytes, int16_t *samples_out, int n_samples,
+                              float *dbg);
+/* the synthesis half alone on channel 0: `in` is a reconstructed spectrum (time_in = 0, n_in = ne: IMDCT -> LTPF -> PCM) or the
+ * time samples that enter the long-term post-filter (time_in = 1, n_in = nf: LTPF -> PCM), with the frame's post-filter side
+ * information and its size (nbits = 8 * nbytes selects the filter gain).  dbg as above (IMDCT and LTPF dumps). */
+int lc3gpu_decoder_synth_debug(lc3gpu_decoder *dec, int time_in, const float *in, int n_in, int ltpf_active, int pitch_index, int nbytes,
+                               int16_t *samples_out, int n_samples, float *dbg);
 /* per-kernel timing of the batch calls with HIP events recorded on the launch stream.  An encoder batch call runs four
  * kernels: analysis front half (wave per stream), SNS vector quantiser (lane per frame), analysis back half (wave per
  * stream), bitstream packing (lane per frame); a decoder batch call two or four: frame parsing (lane per frame), spectrum

@@ -155,6 +155,8 @@ def load_library():
     L.lc3gpu_encoder_timing.argtypes = [vp, i, vp]
     L.lc3gpu_decoder_timing.argtypes = [vp, i, vp]
     L.lc3gpu_decoder_timing_kernels.argtypes = [vp, i, vp]
+    L.lc3gpu_decode_frame_debug.argtypes = [vp, i, vp, i, vp, i, vp]
+    L.lc3gpu_decoder_synth_debug.argtypes = [vp, i, vp, i, i, i, i, vp, i, vp]
     _lib = L
     return L
 
@@ -168,7 +170,7 @@ ABI_SYMBOLS = [
     "lc3gpu_decoder_destroy", "lc3gpu_decoder_reset", "lc3gpu_decode_frame", "lc3gpu_decode", "lc3gpu_decode_range",
     "lc3gpu_decoder_state_size", "lc3gpu_decoder_state_save", "lc3gpu_decoder_state_load",
     "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info", "lc3gpu_prof_read", "lc3gpu_encoder_timing", "lc3gpu_decoder_timing",
-    "lc3gpu_decoder_timing_kernels", "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
+    "lc3gpu_decoder_timing_kernels", "lc3gpu_decode_frame_debug", "lc3gpu_decoder_synth_debug", "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
     "lc3gpu_decode_mixed", "lc3gpu_encoder_create_spec", "lc3gpu_encoder_create_mixed_spec",
 ]
 
@@ -176,6 +178,9 @@ ABI_SYMBOLS = [
 SPEC_8KHZ_ENCODE, SPEC_TNS_SSWB_STOP, SPEC_BW_CUTOFF_DB, SPEC_SNS_LAST_GAIN, SPEC_NBITS_SPEC_OLD, SPEC_ALL = 1, 2, 4, 8, 16, 31
 
 LAYOUT_PLANAR, LAYOUT_INTERLEAVED = 0, 1
+# stage dumps of Lc3Decoder.decode_frame_debug / synth_debug (LC3GPU_DBG_*)
+DBG_INT, DBG_SPEC, DBG_IMDCT, DBG_LTPF, DBG_GAIN, DBG_TNS, DBG_FLOATS = 0, 400, 800, 1280, 1760, 2160, 2560
+RECON_LANE, RECON_LATE, RECON_WAVE = 0, 1, 2
 
 
 class StreamDesc(ctypes.Structure):
@@ -429,6 +434,28 @@ class Lc3Decoder:
         if rc:
             raise Lc3DecoderError(rc, "timing")
         return float(out[0]), float(out[1]), int(out[2])
+
+    def decode_frame_debug(self, buf_in, recon_form=1):
+        """one frame of channel 0 with stage dumps -> (pcm int16[nf], dbg float32[DBG_FLOATS]); recon_form 0 lane, 1 late, 2 wave"""
+        buf_in = np.ascontiguousarray(buf_in, np.uint8)
+        out = np.zeros(self.config.nf, np.int16)
+        dbg = np.zeros(DBG_FLOATS, np.float32)
+        rc = self._L.lc3gpu_decode_frame_debug(self._h, int(recon_form), _ptr(buf_in), int(buf_in.size), _ptr(out), int(out.size), _ptr(dbg))
+        if rc:
+            raise Lc3DecoderError(rc, "decode_frame_debug")
+        return out, dbg
+
+    def synth_debug(self, data, ltpf_active, pitch_index, nbytes, time_in=False):
+        """the synthesis half alone on channel 0: a spectrum (ne floats) or, with time_in, the post-filter's input samples (nf floats)
+        -> (pcm int16[nf], dbg float32[DBG_FLOATS])"""
+        data = np.ascontiguousarray(data, np.float32)
+        out = np.zeros(self.config.nf, np.int16)
+        dbg = np.zeros(DBG_FLOATS, np.float32)
+        rc = self._L.lc3gpu_decoder_synth_debug(self._h, int(bool(time_in)), _ptr(data), int(data.size), int(ltpf_active), int(pitch_index),
+                                                int(nbytes), _ptr(out), int(out.size), _ptr(dbg))
+        if rc:
+            raise Lc3DecoderError(rc, "synth_debug")
+        return out, dbg
 
     def timing_kernels(self, enable=True):
         """-> (parse ms, reconstruction-kernel ms, TNS-kernel ms, synthesis ms, batch calls) since the last call; (re)arms recording"""

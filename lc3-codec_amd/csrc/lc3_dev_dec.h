@@ -404,7 +404,7 @@ __device__ __forceinline__ void lc3_dec_tns_lattice(float *x, int lo, int hi, co
 // walk over the lines (lane 0, frames with an active filter).
 // In: L.ism = side information + residual bit mask (ism[48..)), L.spec = the parsed integers.  Out: L.spec = shaped spectrum.
 // ------------------------------------------------------------------------------------------
-LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_reconstruct_wave(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int nbytes) {
+LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_reconstruct_wave(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int nbytes, float *dbg = nullptr) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     const int ne = c.ne, nbits = nbytes * 8;
@@ -538,6 +538,11 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_reconstruct_wave(LC3_CFG_
         }
         v8[j] = v * gg;
     }
+    if (dbg && k0 < ne)
+        for (int j = 0; j < 8; j++) {
+            dbg[LC3_DBG_INT + k0 + j] = (float)xi[j];
+            dbg[LC3_DBG_GAIN + k0 + j] = v8[j];
+        }
     // TNS :24-137
     const int nbands = bw < 3 ? 1 : 2, num_tns = L.ism[SI_NUM_TNS];
     const int ord0 = (0 < nbands && 0 < num_tns) ? L.ism[AD_ORD0] : 0;
@@ -586,6 +591,8 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_reconstruct_wave(LC3_CFG_
         }
         LC3_SYNC();
     }
+    if (dbg && k0 < ne)
+        for (int j = 0; j < 8; j++) dbg[LC3_DBG_TNS + k0 + j] = v8[j];
     // SNS :113-151: the band gain of each line
     if (k0 < ne) {
         const uint8_t *lb = c.line_band + k0;
@@ -702,12 +709,20 @@ __device__ LC3_DEC_STAGE void lc3_dec_store_strided(int16_t *pcm_out, int stride
 // plc_src / save_good: see lc3_decode_stream_wave.  Returns 1 for a good frame, 0 for a concealed one.
 LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes,
                                                       int16_t *pcm_out, const lc3_plane_fetch &fetched, lc3_dec_state *g,
-                                                      int valid, int stride, const float *plc_src, int save_good, lc3_ola5 &ola, int late = 0) {
+                                                      int valid, int stride, const float *plc_src, int save_good, lc3_ola5 &ola, int late = 0,
+                                                      float *dbg = nullptr, int dbg_flags = 0) {
     LC3_CFG_BIND;
     const int nf = c.nf, nbits = nbytes * 8;
     LC3_STAMP(L, lane, 16);
     const int ok = lc3_dec_load_frame(c, L, lane, fetched, late);
-    if (ok && late) lc3_dec_reconstruct_wave(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes);  // launches of a few frames: D4-D8 here
+    if (ok && late) lc3_dec_reconstruct_wave(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes, (dbg_flags & LC3_DBG_DUMP) ? dbg : nullptr);  // launches of a few frames: D4-D8 here
+    if (dbg_flags & (LC3_DBG_SPEC_IN | LC3_DBG_DUMP)) {  // diagnostic entry points: the spectrum comes from / goes to the caller's buffer
+        for (int k = lane; k < c.ne; k += LC3_WAVE) {
+            if (dbg_flags & LC3_DBG_SPEC_IN) L.spec[k] = dbg[LC3_DBG_SPEC + k];
+            else if (ok) dbg[LC3_DBG_SPEC + k] = L.spec[k];
+        }
+        LC3_SYNC();
+    }
     LC3_STAMP(L, lane, 17);
     int ltpf_active = 0, pitch_index = 0;
     if (ok) {
@@ -721,7 +736,17 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
     LC3_STAMP(L, lane, 18);
     ola = lc3_dec_imdct(LC3_CFG_PASS, LC3_LDS_PASS lane, ola);
     LC3_STAMP(L, lane, 19);
+    if (dbg_flags & (LC3_DBG_TIME_IN | LC3_DBG_DUMP)) {
+        for (int n = lane; n < nf; n += LC3_WAVE) {
+            if (dbg_flags & LC3_DBG_TIME_IN) L.spec[n] = dbg[LC3_DBG_IMDCT + n];  // (the filter is fed directly)
+            else dbg[LC3_DBG_IMDCT + n] = L.spec[n];
+        }
+        LC3_SYNC();
+    }
     lc3_dec_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, ltpf_active, pitch_index, nbits);
+    if (dbg_flags & LC3_DBG_DUMP) {
+        for (int n = lane; n < nf; n += LC3_WAVE) dbg[LC3_DBG_LTPF + n] = L.spec[n];
+    }
     LC3_STAMP(L, lane, 20);
     // output_scaling::scale_and_round (decoder/output_scaling.rs:13-25); two samples per 32-bit store
     {
@@ -767,7 +792,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
 // Frame t's samples go to pcm0 + t * frame_step, `stride` elements apart.
 LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_stream_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes, const int32_t *planes,
                                                        size_t fbase, int n_frames, lc3_dec_state *g, int valid, int16_t *pcm0,
-                                                       size_t frame_step, int stride, int late = 0) {
+                                                       size_t frame_step, int stride, int late = 0, float *dbg = nullptr, int dbg_flags = 0) {
     LC3_CFG_BIND;
     const auto &c0 = c;
     lc3_plane_fetch cur, nxt;
@@ -782,7 +807,8 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_stream_wave(LC3_CFG_
         int16_t *out = pcm0 + (size_t)t * frame_step;
         const float *plc_src = (t_good >= 0 && !late) ? (const float *)(LC3_PLANE_COL(planes, fbase + (size_t)t_good, LC3_PLANE_WORDS) + LC3_PLANE_X * LC3_PLANE_STRIDE)
                                            : (const float *)g->plc_last_good;
-        last_ok = lc3_decode_frame_wave(LC3_CFG_PASS, L, lane, nbytes, out, cur, g, valid, stride, plc_src, late || t == n_frames - 1, ola, late);
+        last_ok = lc3_decode_frame_wave(LC3_CFG_PASS, L, lane, nbytes, out, cur, g, valid, stride, plc_src, late || t == n_frames - 1, ola, late,
+                                        dbg, valid ? dbg_flags : 0);
         if (last_ok) t_good = t;
         cur = nxt;
     }

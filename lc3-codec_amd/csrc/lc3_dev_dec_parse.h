@@ -30,7 +30,20 @@ enum {
     AD_HEAD, AD_Y /* 3 words: the SNS pulse vector, 16 x 5 bits (lc3_parse_pulses) */, SI_WORDS = AD_Y + 3
 };
 
+// Stage dumps of the decoder's diagnostic entry points (lc3gpu_decode_frame_debug, include/lc3gpu.h): float offsets
+enum {
+    LC3_DBG_INT = 0,        // [400] the integers after the range decoder (values, as floats)
+    LC3_DBG_SPEC = 400,     // [400] the spectrum after reconstruction (input of the inverse transform)
+    LC3_DBG_IMDCT = 800,    // [480] time samples after IMDCT, window and overlap-add
+    LC3_DBG_LTPF = 1280,    // [480] time samples after the long-term post-filter
+    LC3_DBG_GAIN = 1760,    // [400] after residual bits, noise filling and global gain (input of the TNS filter)
+    LC3_DBG_TNS = 2160,     // [400] after the TNS filter (input of the SNS band gains)
+    LC3_DBG_FLOATS = 2560
+};
+enum { LC3_DBG_DUMP = 1, LC3_DBG_SPEC_IN = 2, LC3_DBG_TIME_IN = 4 };  // what the synthesis kernel does with the buffer
+
 struct lc3_parse_ctx {
+    float *dbg;              // stage dumps (diagnostic entry point, one frame) or null
     const uint8_t *bytes;    // this frame's bytes
     int len;
     const uint8_t *lookup;   // AC_SPEC_LOOKUP[4096]
@@ -848,7 +861,11 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
             // slide the window: drop line k - 3, bring in line k + 4
             nzwin = (nzwin >> 1) | ((xw[j + 4] != 0 && k + 4 < bw_stop) ? 64u : 0u);
         }
+        if (c.dbg)
+            for (int j = 0; j < 4; j++) c.dbg[LC3_DBG_GAIN + k0 + j] = vout[j];
         if (tns_wave) lc3_tns_lattice4(k0, t_lo0, t_lo1, t_hi, ord0, rq, rq1, st, vout);  // TNS synthesis, the group's four lines together
+        if (c.dbg)
+            for (int j = 0; j < 4; j++) c.dbg[LC3_DBG_TNS + k0 + j] = vout[j];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int k = k0 + j;

@@ -651,7 +651,8 @@ __global__ __launch_bounds__(256) void lc3_pack_mixed_kernel(lc3_groups G, const
 #define LC3_PARSE_LDS_FIXED (4096 + 64 * LC3_DCF_ROW_WORDS * 4 + 16 * 11 * 4 + 4 * 152 + 144)
 template <class CV>
 __device__ __forceinline__ void lc3_parse_body(lc3_cfg_slot<CV> cfg, unsigned wg, const uint8_t *in, const uint8_t *bad,
-                                               int32_t *planes, int nbytes, int n_frames, int T, int first_channel, lc3_io io, int late) {
+                                               int32_t *planes, int nbytes, int n_frames, int T, int first_channel, lc3_io io, int late,
+                                               float *dbg = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const int ne = c0.ne, fs_ind = c0.fs_ind, n_ms_10 = c0.n_ms_10;
@@ -695,6 +696,7 @@ __device__ __forceinline__ void lc3_parse_body(lc3_cfg_slot<CV> cfg, unsigned wg
     const size_t f = f0 + (size_t)tid;
     if (f < (size_t)n_frames) {
         lc3_parse_ctx c;
+        c.dbg = f == 0 ? dbg : nullptr;
         c.bytes = s_bytes + tid * nbytes;
         c.len = nbytes;
         c.lookup = s_lookup;
@@ -743,6 +745,12 @@ template <class CV>
 __global__ __launch_bounds__(256) void lc3_parse_kernel(lc3_cfg_slot<CV> cfg, const uint8_t *in, const uint8_t *bad,
                                                         int32_t *planes, int nbytes, int n_frames, int T, lc3_io io, int late) {
     lc3_parse_body<CV>(cfg, blockIdx.x, in, bad, planes, nbytes, n_frames, T, 0, io, late);
+}
+template <class CV>
+__global__ __launch_bounds__(256) void lc3_parse_debug_kernel(lc3_cfg_slot<CV> cfg, const uint8_t *in, int32_t *planes, int nbytes, int late,
+                                                              float *dbg) {
+    lc3_io io = {0, nullptr};
+    lc3_parse_body<CV>(cfg, 0, in, nullptr, planes, nbytes, 1, 1, 0, io, late, dbg);
 }
 __global__ __launch_bounds__(256) void lc3_parse_mixed_kernel(lc3_groups G, const uint8_t *in, const uint8_t *bad, int32_t *planes,
                                                               int T, lc3_io io, int late) {
@@ -835,7 +843,7 @@ __global__ __launch_bounds__(LC3_TNS_FPB) void lc3_tns_mixed_kernel(lc3_groups G
 template <class CV, int LATE>
 __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned wg, lc3_dec_state *states, int first_channel,
                                                 int n_streams, const int32_t *planes, int16_t *pcm, int nbytes, int n_frames,
-                                                int fresh, lc3_io io) {
+                                                int fresh, lc3_io io, float *dbg = nullptr, int dbg_flags = 0) {
     const int lane = threadIdx.x & 63, wave = LC3_WAVE_ID();
     lc3_dec_lds &L = lc3_dec_wg[wave];
     const int s_raw = (int)wg * LC3_WG_WAVES + wave;
@@ -852,7 +860,8 @@ __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned w
     const size_t fbase = (size_t)s * (size_t)n_frames;
     int stride;
     int16_t *pcm0 = (int16_t *)lc3_io_pcm(io, pcm, nf, first_channel, s, 0, n_frames, &stride);
-    lc3_decode_stream_wave(cfg, L, lane, nbytes, planes, fbase, n_frames, gst, valid, pcm0, (size_t)nf * (size_t)stride, stride, LATE);
+    lc3_decode_stream_wave(cfg, L, lane, nbytes, planes, fbase, n_frames, gst, valid, pcm0, (size_t)nf * (size_t)stride, stride, LATE, dbg,
+                           dbg_flags);
     LC3_PROF_MARK(L, lane, 39);  // frames (incl. everything between the stage stamps)
     if (valid) lc3_dec_state_store(L, lane, gst);
     LC3_PROF_END(L, lane, 35);
@@ -870,6 +879,15 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_late_kernel(l
                                                                                int16_t *pcm, int nbytes, int n_frames, int fresh,
                                                                                lc3_io io) {
     lc3_decode_body<CV, 1>(cfg, blockIdx.x, states, first_channel, n_streams, planes, pcm, nbytes, n_frames, fresh, io);
+}
+// the diagnostic entry points' instantiation (lc3gpu_decode_frame_debug, lc3gpu_decoder_synth_debug): one stream, stage dumps
+template <class CV>
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_debug_kernel(lc3_cfg_slot<CV> cfg, lc3_dec_state *states, int channel,
+                                                                                const int32_t *planes, int16_t *pcm, int nbytes, int late,
+                                                                                float *dbg, int dbg_flags) {
+    lc3_io io = {0, nullptr};
+    if (late) lc3_decode_body<CV, 1>(cfg, 0, states, channel, 1, planes, pcm, nbytes, 1, 0, io, dbg, dbg_flags);
+    else lc3_decode_body<CV, 0>(cfg, 0, states, channel, 1, planes, pcm, nbytes, 1, 0, io, dbg, dbg_flags);
 }
 template <int LATE>
 __device__ __forceinline__ void lc3_decode_mixed_body(const lc3_groups &G, lc3_dec_state *states, const int32_t *planes, int16_t *pcm,
@@ -1307,6 +1325,7 @@ struct lc3gpu_decoder : HandleCommon {
     int16_t *d_pcm1 = nullptr;
     int32_t *d_planes = nullptr;   // parsed-frame planes, LC3_PLANE_WORDS words per frame
     size_t planes_frames = 0;      // capacity in frames (multiple of 64)
+    float *d_dbg = nullptr;        // stage dumps of the diagnostic entry points (LC3_DBG_FLOATS), allocated at first use
 };
 
 // frames per workgroup of the lane-per-frame kernels (= threads per workgroup).  LC3GPU_FPB overrides (tuning aid).
@@ -1835,6 +1854,7 @@ int lc3gpu_decoder_destroy(lc3gpu_decoder *d) {
         if (d->d_in1) (void)hipHostFree(d->d_in1);
         if (d->d_pcm1) (void)hipHostFree(d->d_pcm1);
         if (d->d_planes) (void)hipFree(d->d_planes);
+        if (d->d_dbg) (void)hipFree(d->d_dbg);
         d->release_common();
     }
     delete d;
@@ -1986,6 +2006,91 @@ int lc3gpu_decode_frame(lc3gpu_decoder *d, int num_bits_per_audio_sample, int ch
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(nullptr));
     std::memcpy(samples_out, d->d_pcm1, sizeof(int16_t) * (size_t)n_samples);
+    return LC3GPU_OK;
+}
+
+// ---- diagnostic entry points: one frame of channel 0 of a uniform handle with stage dumps (LC3_DBG_*, lc3_dev_dec_parse.h) ----
+static int decoder_debug_begin(lc3gpu_decoder *d, const float *fill) {
+    if (!d->d_dbg) HIP_TRY(hipMalloc((void **)&d->d_dbg, sizeof(float) * LC3_DBG_FLOATS));
+    std::vector<float> nanv((size_t)LC3_DBG_FLOATS, std::nanf(""));
+    (void)fill;
+    HIP_TRY(hipMemcpy(d->d_dbg, nanv.data(), sizeof(float) * LC3_DBG_FLOATS, hipMemcpyHostToDevice));
+    return LC3GPU_OK;
+}
+
+int lc3gpu_decode_frame_debug(lc3gpu_decoder *d, int recon_form, const uint8_t *buf_in, int nbytes, int16_t *samples_out, int n_samples,
+                              float *dbg) {
+    if (!d || d->mixed || !buf_in || !samples_out || !dbg) return LC3GPU_EINVAL;
+    if (recon_form != LC3_RECON_LANE && recon_form != LC3_RECON_LATE && recon_form != LC3_RECON_WAVE) return LC3GPU_EINVAL;
+    const HostCfg &h = d->h;
+    if (n_samples != h.c.nf) return LC3GPU_ELENGTH;
+    if (nbytes < 1 || nbytes > LC3_MAX_NE) return LC3GPU_ELENGTH;
+    LC3_ON_DEVICE(d);
+    int rc = d->quiesce();
+    if (rc == LC3GPU_OK) rc = decoder_reserve_planes(d, 1, nullptr);
+    if (rc == LC3GPU_OK) rc = decoder_debug_begin(d, nullptr);
+    if (rc == LC3GPU_OK && recon_form == LC3_RECON_WAVE) rc = lc3_tns_lds_optin();
+    if (rc) return rc;
+    std::memcpy(d->d_in1, buf_in, (size_t)nbytes);
+    const unsigned fpb = lc3_frame_block_fit(LC3_PARSE_LDS_FIXED, (size_t)(64 + nbytes));
+    const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes);
+    std::vector<int32_t> col((size_t)LC3_PLANE_WORDS);
+    // the integers: parsing is stateless, so the frame is first parsed in the form that leaves them in the plane
+    LC3_LAUNCH_CFG(lc3_parse_debug_kernel, h, dim3(1), dim3(fpb), lds, nullptr, (const uint8_t *)d->d_in1, d->d_planes, nbytes, 1, (float *)nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(col.data(), d->d_planes, sizeof(int32_t) * LC3_PLANE_WORDS, hipMemcpyDeviceToHost));
+    const int parsed = col[AD_OK] != 0, lastnz = col[SI_LASTNZ];
+    if (recon_form != LC3_RECON_LATE) {  // the form under test rebuilds the plane column
+        LC3_LAUNCH_CFG(lc3_parse_debug_kernel, h, dim3(1), dim3(fpb), lds, nullptr, (const uint8_t *)d->d_in1, d->d_planes, nbytes, recon_form,
+                       recon_form == LC3_RECON_LANE ? d->d_dbg : (float *)nullptr);
+        HIP_TRY(hipGetLastError());
+        if (recon_form == LC3_RECON_WAVE) {
+            LC3_LAUNCH_CFG(lc3_recon_kernel, h, dim3(1), dim3(64 * LC3_WG_WAVES), 0, nullptr, d->d_planes, nbytes, 1);
+            HIP_TRY(hipGetLastError());
+            LC3_LAUNCH_CFG(lc3_tns_kernel, h, dim3(1), dim3(LC3_TNS_FPB), LC3_TNS_LDS, nullptr, d->d_planes, 1);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    LC3_LAUNCH_CFG(lc3_decode_debug_kernel, h, dim3(1), dim3(64 * LC3_WG_WAVES), 0, nullptr, d->d_states, 0, (const int32_t *)d->d_planes, d->d_pcm1,
+                   nbytes, recon_form == LC3_RECON_LATE ? 1 : 0, d->d_dbg, (int)LC3_DBG_DUMP);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    std::memcpy(samples_out, d->d_pcm1, sizeof(int16_t) * (size_t)n_samples);
+    HIP_TRY(hipMemcpy(dbg, d->d_dbg, sizeof(float) * LC3_DBG_FLOATS, hipMemcpyDeviceToHost));
+    if (parsed)  // (the late form dumps them itself; the others take them from the first parse)
+        for (int k = 0; k < h.c.ne; k++) dbg[LC3_DBG_INT + k] = k < lastnz ? (float)col[LC3_PLANE_X + k] : 0.0f;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_decoder_synth_debug(lc3gpu_decoder *d, int time_in, const float *in, int n_in, int ltpf_active, int pitch_index, int nbytes,
+                               int16_t *samples_out, int n_samples, float *dbg) {
+    if (!d || d->mixed || !in || !samples_out || !dbg) return LC3GPU_EINVAL;
+    const HostCfg &h = d->h;
+    if (n_samples != h.c.nf || n_in != (time_in ? h.c.nf : h.c.ne)) return LC3GPU_ELENGTH;
+    if (nbytes < 1 || nbytes > LC3_MAX_NE) return LC3GPU_ELENGTH;
+    LC3_ON_DEVICE(d);
+    int rc = d->quiesce();
+    if (rc == LC3GPU_OK) rc = decoder_reserve_planes(d, 1, nullptr);
+    if (rc == LC3GPU_OK) rc = decoder_debug_begin(d, nullptr);
+    if (rc) return rc;
+    // a plane column that says: good frame, this long-term post-filter side information; the spectrum / the samples come from the buffer
+    std::vector<int32_t> col((size_t)LC3_PLANE_WORDS, 0);
+    col[AD_OK] = 1;
+    col[SI_PITCH_PRESENT] = 1;
+    col[SI_LTPF_ACTIVE] = ltpf_active != 0;
+    col[SI_PITCH_INDEX] = pitch_index;
+    HIP_TRY(hipMemcpy(d->d_planes, col.data(), sizeof(int32_t) * LC3_PLANE_WORDS, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d->d_dbg + (time_in ? LC3_DBG_IMDCT : LC3_DBG_SPEC), in, sizeof(float) * (size_t)n_in, hipMemcpyHostToDevice));
+    if (time_in) {  // the transform runs on silence
+        std::vector<float> z((size_t)h.c.ne, 0.0f);
+        HIP_TRY(hipMemcpy(d->d_dbg + LC3_DBG_SPEC, z.data(), sizeof(float) * z.size(), hipMemcpyHostToDevice));
+    }
+    LC3_LAUNCH_CFG(lc3_decode_debug_kernel, h, dim3(1), dim3(64 * LC3_WG_WAVES), 0, nullptr, d->d_states, 0, (const int32_t *)d->d_planes, d->d_pcm1,
+                   nbytes, 0, d->d_dbg, (int)(LC3_DBG_SPEC_IN | LC3_DBG_DUMP | (time_in ? LC3_DBG_TIME_IN : 0)));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    std::memcpy(samples_out, d->d_pcm1, sizeof(int16_t) * (size_t)n_samples);
+    HIP_TRY(hipMemcpy(dbg, d->d_dbg, sizeof(float) * LC3_DBG_FLOATS, hipMemcpyDeviceToHost));
     return LC3GPU_OK;
 }
 

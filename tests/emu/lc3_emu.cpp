@@ -368,6 +368,7 @@ int lc3emu_decode_late(int fs_hz, int frame_us, int nbytes, int S, int T, const 
     for (int i = 0; i < LC3_TNS_MODEL_WORDS; i++) tns[(size_t)i] = lc3_tns_model_word(i);
     for (size_t f = 0; f < frames; f++) {
         lc3_parse_ctx c;
+        c.dbg = nullptr;
         c.tns = tns.data();
         c.bytes = bytes + f * (size_t)nbytes;
         c.len = nbytes;

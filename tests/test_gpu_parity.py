@@ -813,3 +813,69 @@ def test_launcher_stops_the_gpu_ranks_when_one_dies():
                           {"LC3_BENCH_BACKEND": "gloo", "LC3_BENCH_TEST_DIE_RANK": "1"})
     assert p.returncode != 0 and line is None and "rank 1 exited with code 17" in p.stderr
     assert time.time() - t0 < 300.0
+
+
+# ---------------------------------------------------------------- decoder stages on the device against the reference's stage goldens
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("form", [0, 1, 2])  # lane (full batches), late (single frames / small launches), wave (wave-per-frame kernels)
+def test_decoder_stage_dumps_match_reference_goldens(form):
+    """lc3gpu_decode_frame_debug on the reference's end-to-end decode KAT frame (decoder/lc3_decoder.rs:374-425): the same frame
+    the reference's per-stage tests were dumped from, so every stage of the HIP path is compared with the reference's OWN vector for
+    it, bit for bit: integers after the range decoder (noise_filling.rs:65-146 `spec_lines_int`), after residual bits + noise
+    filling + global gain (the input of temporal_noise_shaping.rs:147-238), after TNS (its `spec_lines_expected` = the input of
+    spectral_noise_shaping.rs:244-350), after SNS (its `spec_lines_expected`), PCM (`samples_out_expected`); IMDCT / LTPF outputs
+    against the oracle's stage functions on the same frame."""
+    from test_oracle_kats import f32, kat
+
+    t = "decoder/lc3_decoder.rs::lc3_decode_channel"
+    buf = np.array(kat(t, "buf_in"), np.uint8)
+    dec = pkg.Lc3Decoder(1, US, FS)
+    pcm, dbg = dec.decode_frame_debug(buf, recon_form=form)
+    assert pcm.tolist() == kat(t, "samples_out_expected")
+    ints = np.array(kat("decoder/noise_filling.rs::decode_noise_filling", "spec_lines_int", 0, np.int32))
+    assert np.array_equal(dbg[0:400], ints.astype(np.float32)), "integers after the range decoder"
+    sns_out = f32("decoder/spectral_noise_shaping.rs::spectral_noise_shaping_decode", "spec_lines_expected")
+    assert np.array_equal(_bits(dbg[400:800]), _bits(sns_out)), "spectrum after SNS"
+    if form != 2:  # the wave-per-frame kernels hand the TNS range over between two kernels: no separate dumps
+        tns_in = f32("decoder/temporal_noise_shaping.rs::decode_test", "spec_lines")
+        tns_out = f32("decoder/temporal_noise_shaping.rs::decode_test", "spec_lines_expected")
+        assert np.array_equal(_bits(dbg[1760:2160]), _bits(tns_in)), "after residual bits, noise filling, global gain"
+        assert np.array_equal(_bits(dbg[2160:2560]), _bits(tns_out)), "after TNS"
+    # IMDCT and LTPF of this frame: the oracle's stage functions fed with the reference's SNS output
+    import ctypes
+
+    od = O.Decoder()
+    freq = np.zeros(480, np.float32)
+    O.lib().lc3o_kat_imdct(od.h, O.P(sns_out), O.P(freq))
+    assert np.array_equal(_bits(dbg[800:1280]), _bits(freq)), "IMDCT output"
+    si = np.zeros(20, np.int64)
+    tail = ctypes.c_int()
+    assert O.lib().lc3o_kat_side_info(O.P(buf), 150, 4, 400, O.P(si), ctypes.byref(tail)) == 0
+    O.lib().lc3o_kat_dec_ltpf(od.h, int(si[17]), int(si[16]), int(si[18]), 1200, O.P(freq))
+    assert np.array_equal(_bits(dbg[1280:1760]), _bits(freq)), "LTPF output"
+
+
+def test_synthesis_stages_match_reference_goldens():
+    """lc3gpu_decoder_synth_debug: the IMDCT fed with the reference's two spectra (decoder/modified_dct.rs:174-329) and the
+    long-term post-filter fed with the reference's six frames that walk its transition cases 1, 1, 2, 5, 4, 3
+    (decoder/long_term_post_filter.rs:504-1199), each against the reference's expected output, bit for bit"""
+    from test_oracle_kats import f32
+
+    t = "decoder/modified_dct.rs::modified_dct_decode"
+    dec = pkg.Lc3Decoder(1, US, FS)
+    dec.synth_debug(f32(t, "x_hat", 0), 0, 0, 150)
+    _, dbg = dec.synth_debug(f32(t, "x_hat", 1), 0, 0, 150)
+    assert np.array_equal(_bits(dbg[800:1280]), _bits(f32(t, "freq_buf_expected"))), "IMDCT after two frames"
+    t = "decoder/long_term_post_filter.rs::long_term_post_filter_full_cycle"
+    dec = pkg.Lc3Decoder(1, US, FS)
+    infos = [(0, 134), (0, 132), (1, 134), (1, 136), (1, 136), (0, 132)]
+    for i, (active, idx) in enumerate(infos):
+        pcm, dbg = dec.synth_debug(f32(t, "freq_samples", i), active, idx, 40, time_in=True)  # nbits = 320 as in the reference's test
+        exp = f32(t, "freq_samples_expected", i)
+        assert np.array_equal(_bits(dbg[1280:1760]), _bits(exp)), f"LTPF frame {i}"
+        ref_pcm = np.zeros(480, np.int16)
+        O.lib().lc3o_dec_output(O.P(exp), O.P(ref_pcm), 480)
+        assert np.array_equal(pcm, ref_pcm), f"output scaling frame {i}"
