@@ -195,6 +195,11 @@ int lc3gpu_decode_frame_debug(lc3gpu_decoder *dec, int recon_form, const uint8_t
  * information and its size (nbits = 8 * nbytes selects the filter gain).  dbg as above (IMDCT and LTPF dumps). */
 int lc3gpu_decoder_synth_debug(lc3gpu_decoder *dec, int time_in, const float *in, int n_in, int ltpf_active, int pitch_index, int nbytes,
                                int16_t *samples_out, int n_samples, float *dbg);
+/* tests only: the float routines the codec's bit-exactness rests on, evaluated on the device as the kernels compile them.
+ * which: 0 x / d by the quantiser's reciprocal sequence, 1 x / d by the compiler's IEEE division, 2 log2f, 3 log10f, 4 exp2f, 5 asinf,
+ * 6 fast-math exp2_raw, 7 10^x, 8 sinf (|x| small), 9 the device-filled tables (n = 866: 512 gains 10^(k/28), k = -256..255, 320 tilt
+ * factors, 17 + 17 TNS sines).  x, d, out: HOST arrays of n floats (d only for 0 and 1, neither for 9). */
+int lc3gpu_selftest_math(int which, const float *x, const float *d, int n, float *out);
 /* per-kernel timing of the batch calls with HIP events recorded on the launch stream.  An encoder batch call runs four
  * kernels: analysis front half (wave per stream), SNS vector quantiser (lane per frame), analysis back half (wave per
  * stream), bitstream packing (lane per frame); a decoder batch call two or four: frame parsing (lane per frame), spectrum

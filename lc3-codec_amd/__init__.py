@@ -30,5 +30,6 @@ from .api import (  # noqa: F401
     device_count,
     library_path,
     load_library,
+    selftest_math,
     tool_path,
 )

@@ -157,6 +157,7 @@ def load_library():
     L.lc3gpu_decoder_timing_kernels.argtypes = [vp, i, vp]
     L.lc3gpu_decode_frame_debug.argtypes = [vp, i, vp, i, vp, i, vp]
     L.lc3gpu_decoder_synth_debug.argtypes = [vp, i, vp, i, i, i, i, vp, i, vp]
+    L.lc3gpu_selftest_math.argtypes = [i, vp, vp, i, vp]
     _lib = L
     return L
 
@@ -170,7 +171,7 @@ ABI_SYMBOLS = [
     "lc3gpu_decoder_destroy", "lc3gpu_decoder_reset", "lc3gpu_decode_frame", "lc3gpu_decode", "lc3gpu_decode_range",
     "lc3gpu_decoder_state_size", "lc3gpu_decoder_state_save", "lc3gpu_decoder_state_load",
     "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info", "lc3gpu_prof_read", "lc3gpu_encoder_timing", "lc3gpu_decoder_timing",
-    "lc3gpu_decoder_timing_kernels", "lc3gpu_decode_frame_debug", "lc3gpu_decoder_synth_debug", "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
+    "lc3gpu_decoder_timing_kernels", "lc3gpu_decode_frame_debug", "lc3gpu_decoder_synth_debug", "lc3gpu_selftest_math", "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
     "lc3gpu_decode_mixed", "lc3gpu_encoder_create_spec", "lc3gpu_encoder_create_mixed_spec",
 ]
 
@@ -209,6 +210,21 @@ def _strerror(code):
         return load_library().lc3gpu_strerror(int(code)).decode()
     except Exception:
         return "?"
+
+
+def selftest_math(which, x=None, d=None, n=None):
+    """tests only: a float routine evaluated on the device (lc3gpu_selftest_math) -> float32[n]"""
+    L = load_library()
+    if x is not None:
+        x = np.ascontiguousarray(x, np.float32)
+        n = x.size
+    if d is not None:
+        d = np.ascontiguousarray(d, np.float32)
+    out = np.zeros(int(n), np.float32)
+    rc = L.lc3gpu_selftest_math(int(which), _ptr(x), _ptr(d), int(n), _ptr(out))
+    if rc:
+        raise Lc3GpuError(rc, "selftest_math")
+    return out
 
 
 def device_count():

@@ -104,9 +104,11 @@ __device__ float lc3_tns_sin_tab[17];
 // x / d for many x and one d: the compiler's f32 division is v_div_scale x2, v_rcp, two Newton steps on the reciprocal,
 // q = n * r, two residual corrections, v_div_fmas, v_div_fixup; scale and fix-up only act on zero / infinite / NaN operands,
 // a denominator outside 2^+-126, an exponent difference of 96 or more, and numerators below 2^-103 or quotients below 2^-126.
-// With d a finite normal number (the global gain, 1.8e-9 .. 1.5e5) and |x| < 2^60 none of them changes a quotient of at
-// least 2^-100, and the callers (quantiser: trunc(q + 0.375)) do not distinguish smaller ones; what is left is this sequence
-// with the reciprocal refined once per d.
+// With d a finite normal number (the global gain, 1.8e-9 .. 1.5e5) and |x| < 2^60 only the last two can occur, and a numerator
+// below 2^-103 gives a quotient below 2^-74, which the callers (quantiser: trunc(q + 0.375)) cannot tell from 0 either way; what
+// is left is this sequence with the reciprocal refined once per d.  Measured on the device over 2^24 random pairs of that range
+// (tests/test_gpu_parity.py::test_device_math_on_the_device): bit-identical to the IEEE quotient for every |x| >= 2^-103, one
+// unit in the last place off for 0.13 % of the numerators below 2^-110.
 #define LC3_UNIFORM_DIV 1
 struct lc3_divisor { float d, r; };
 __device__ __forceinline__ lc3_divisor lc3_divisor_make(float d) {
@@ -2182,6 +2184,61 @@ int lc3gpu_decoder_timing_kernels(lc3gpu_decoder *d, int enable, double out[5]) 
     const int rc = decoder_timing_read(d, enable, ms, &n);
     if (rc) return rc;
     if (out) { out[0] = ms[0]; out[1] = ms[1]; out[2] = ms[2]; out[3] = ms[3]; out[4] = n; }
+    return LC3GPU_OK;
+}
+
+// Device arithmetic self-test (tests only): evaluates, ON THE DEVICE and as the kernels compile them, the float routines the codec's
+// bit-exactness rests on.  which: 0 lc3_div_by(x, d) (the quantiser's division by a wave-uniform gain), 1 x / d (hipcc's IEEE division),
+// 2 log2f, 3 log10f, 4 exp2f, 5 asinf, 6 exp2_raw, 7 10^x, 8 sinf on the TNS argument range, 9 the device-filled tables (out: 512
+// gains 10^(k/28), 320 tilt factors, 17 encoder TNS sines, 17 decoder TNS sines = 866 values; x, d ignored).  Host pointers.
+__global__ void lc3_math_test_kernel(int which, const float *x, const float *d, int n, float *out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float r = 0.0f;
+        switch (which) {
+        case 0: { const lc3_divisor v = lc3_divisor_make(d[i]); r = lc3_div_by(x[i], v); } break;
+        case 1: r = x[i] / d[i]; break;
+        case 2: r = lc3_log2f(x[i]); break;
+        case 3: r = lc3_log10f(x[i]); break;
+        case 4: r = lc3_exp2f(x[i]); break;
+        case 5: r = lc3_asinf(x[i]); break;
+        case 6: r = lc3_exp2_raw(x[i]); break;
+        case 7: r = lc3_pow10f(x[i]); break;
+        case 8: r = lc3_sinf_small(x[i]); break;
+        default:
+            if (i < 512) r = LC3_POW10_GG(i - 256);
+            else if (i < 832) r = LC3_POW10_TILT((i - 512) / 64, (i - 512) % 64);
+            else if (i < 849) r = LC3_TNS_SIN_ENC(i - 832);
+            else r = LC3_TNS_SIN_DEC(i - 849);
+        }
+        out[i] = r;
+    }
+}
+int lc3gpu_selftest_math(int which, const float *x, const float *d, int n, float *out) {
+    if (which < 0 || which > 9 || n <= 0 || !out || (which < 9 && !x) || (which < 2 && !d)) return LC3GPU_EINVAL;
+    if (which == 9 && n != 866) return LC3GPU_ELENGTH;
+    if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
+    HostCfg h;
+    int rc = cfg_acquire(h, 10000, 48000);  // fills the device tables
+    if (rc) return rc;
+    float *dx = nullptr, *dd = nullptr, *dout = nullptr;
+    const size_t bytes = sizeof(float) * (size_t)n;
+    hipError_t e = hipMalloc((void **)&dx, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&dd, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&dout, bytes);
+    if (e == hipSuccess && x) e = hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && d) e = hipMemcpy(dd, d, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(lc3_math_test_kernel, dim3(1024), dim3(256), 0, nullptr, which, (const float *)dx, (const float *)dd, n, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(dx);
+    (void)hipFree(dd);
+    (void)hipFree(dout);
+    if (e != hipSuccess) {
+        g_last_hip = (int)e;
+        return LC3GPU_EHIP;
+    }
     return LC3GPU_OK;
 }
 

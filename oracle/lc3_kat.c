@@ -194,3 +194,21 @@ void lc3o_kat_dec_ltpf(void *dec, int is_active, int pitch_present, int pitch_in
     lc3o_dec_ltpf(&d->cfg, &d->ltpf, &info, nbits, freq);
 }
 float lc3o_kat_powf(float x, float y) { return lc3m_powf(x, y); }
+
+/* vectorised float routines for the device-math test (tests/test_gpu_parity.py::test_device_math_on_the_device):
+ * which = 2 log2f, 3 log10f, 4 exp2f, 5 asinf, 6 exp2_raw, 7 powf(10, x), 8 sinf */
+void lc3o_kat_math(int which, const float *x, int n, float *out) {
+    int i;
+    for (i = 0; i < n; i++) {
+        switch (which) {
+        case 2: out[i] = lc3m_log2f(x[i]); break;
+        case 3: out[i] = lc3m_log10f(x[i]); break;
+        case 4: out[i] = lc3m_exp2f(x[i]); break;
+        case 5: out[i] = lc3m_asinf(x[i]); break;
+        case 6: out[i] = lc3m_exp2_raw(x[i]); break;
+        case 7: out[i] = lc3m_powf(10.0f, x[i]); break;
+        case 8: out[i] = lc3m_sinf(x[i]); break;
+        default: out[i] = 0.0f;
+        }
+    }
+}

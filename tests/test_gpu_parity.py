@@ -879,3 +879,71 @@ def test_synthesis_stages_match_reference_goldens():
         ref_pcm = np.zeros(480, np.int16)
         O.lib().lc3o_dec_output(O.P(exp), O.P(ref_pcm), 480)
         assert np.array_equal(pcm, ref_pcm), f"output scaling frame {i}"
+
+
+# ---------------------------------------------------------------- the device's float routines, evaluated on the device
+def test_device_math_on_the_device():
+    """What frame parity only covers transitively, checked value by value ON the GPU (lc3gpu_selftest_math): the quantiser's division
+    by a wave-uniform gain (`lc3_div_by`: the compiler's own f32 division sequence with the reciprocal refined once per gain -- the CPU
+    emulator compiles the plain `x / d` instead) against IEEE division on 2^24 random (x, d) pairs over the quantiser's operating range
+    and its stated edge (|x| < 2^60, d in [1.8e-9, 1.5e5]: bit-identical from |x| = 2^-103 up); hipcc's code for the restated msun routines (log2f, log10f, exp2f, asinf,
+    powf(10, .), sinf) and fast-math's exp2_raw against the oracle's C routines, bit for bit; and the tables the device fills with
+    those routines at start-up (gains 10^(k/28), tilt factors, TNS sines) against the oracle evaluating the same expressions."""
+    import ctypes
+
+    rng = np.random.default_rng(20240317)
+    n = 1 << 24
+    # x: signed, log-uniform magnitude over 2^-126 .. 2^60, with exact zeros, quantiser-typical values and huge ones mixed in
+    mag = np.exp2(rng.uniform(-126.0, 60.0, n)).astype(np.float32)
+    x = (mag * rng.choice(np.array([-1.0, 1.0], np.float32), n)).astype(np.float32)
+    x[:: 1 << 10] = 0.0
+    x[1:: 1 << 10] = (rng.uniform(-40000.0, 40000.0, x[1:: 1 << 10].size)).astype(np.float32)
+    d = np.exp(rng.uniform(np.log(1.8e-9), np.log(1.5e5), n)).astype(np.float32)
+    d[: 1 << 12] = np.float32(1.8e-9)
+    d[1 << 12: 1 << 13] = np.float32(1.5e5)
+    got = pkg.selftest_math(0, x, d)
+    ieee_dev = pkg.selftest_math(1, x, d)
+    with np.errstate(all="ignore"):
+        ieee = (x / d).astype(np.float32)  # numpy's f32 division is the correctly rounded IEEE quotient
+    assert np.array_equal(ieee_dev.view(np.uint32), ieee.view(np.uint32)), "hipcc's f32 division is not the IEEE quotient"
+    big = np.abs(x) >= np.float32(2.0 ** -103)  # below: the hardware sequence would pre-scale the numerator; the quotient is < 2^-74
+    assert np.array_equal(got.view(np.uint32)[big], ieee.view(np.uint32)[big]), "lc3_div_by differs from IEEE division on a numerator >= 2^-103"
+    # there the callers (trunc(q + 0.375), spectral_quantization.rs:239-262) cannot tell the quotients apart: both are tiny and within an ulp
+    assert np.all(np.abs(got[~big]) < np.float32(2.0 ** -73))
+    assert np.abs(got.view(np.int32)[~big].astype(np.int64) - ieee.view(np.int32)[~big].astype(np.int64)).max() <= 1
+    assert np.array_equal(np.trunc(got + np.float32(0.375)), np.trunc(ieee + np.float32(0.375)))
+
+    def oracle(which, v):
+        out = np.zeros(v.size, np.float32)
+        O.lib().lc3o_kat_math(int(which), O.P(v), int(v.size), O.P(out))
+        return out
+
+    m = 1 << 20
+    eps = np.float32(1.1920929e-7)
+    cases = {
+        2: (eps + np.exp(rng.uniform(np.log(1e-9), np.log(1e13), m))).astype(np.float32),           # log2f(eps + band energy)
+        3: np.exp(rng.uniform(np.log(1e-9), np.log(1e13), m)).astype(np.float32),                   # log10f
+        4: rng.uniform(-70.0, 70.0, m).astype(np.float32),                                          # exp2f(-scale factor)
+        5: np.concatenate([rng.uniform(-1.0, 1.0, m - 5), [-1.0, 1.0, 0.0, 0.5, -0.5]]).astype(np.float32),  # asinf(reflection coefficient)
+        6: rng.uniform(-40.0, 40.0, m).astype(np.float32),                                          # exp2_raw(scale factor)
+        7: rng.uniform(-12.0, 12.0, m).astype(np.float32),                                          # 10^x
+        8: rng.uniform(-1.6, 1.6, m).astype(np.float32),                                            # sin(k pi / 17), |k| <= 8
+    }
+    for which, v in cases.items():
+        v[:4] = np.array([1.0, 2.0, 0.5, 1e-7], np.float32) if which in (2, 3) else v[:4]
+        a, b = pkg.selftest_math(which, v), oracle(which, v)
+        same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert same.all(), (which, int((~same).sum()), v[~same][:4], a[~same][:4], b[~same][:4])
+    # device-filled tables
+    tab = pkg.selftest_math(9, n=866)
+    k = np.arange(-256, 256, dtype=np.float32)
+    assert np.array_equal(tab[:512].view(np.uint32), oracle(7, (k / np.float32(28.0)).astype(np.float32)).view(np.uint32)), "10^(k/28) table"
+    g_tilt = np.array([14, 18, 22, 26, 30], np.float32)
+    b = np.arange(64, dtype=np.float32)
+    tilt_arg = (b[None, :] * (g_tilt[:, None] / np.float32(630.0)).astype(np.float32)).astype(np.float32).reshape(-1)
+    assert np.array_equal(tab[512:832].view(np.uint32), oracle(7, tilt_arg).view(np.uint32)), "tilt table"
+    ri = np.arange(17, dtype=np.float32)
+    step_enc = np.float32(np.float32(np.pi) / np.float32(17.0))        # (PI as f32) / 17.0   encoder/temporal_noise_shaping.rs:268-273
+    step_dec = np.float32(np.pi / 17.0)                                # (PI / 17.0) as f32   decoder/temporal_noise_shaping.rs:41-44
+    assert np.array_equal(tab[832:849].view(np.uint32), oracle(8, (step_enc * (ri - np.float32(8.0))).astype(np.float32)).view(np.uint32)), "encoder TNS sines"
+    assert np.array_equal(tab[849:866].view(np.uint32), oracle(8, (step_dec * (ri - np.float32(8.0))).astype(np.float32)).view(np.uint32)), "decoder TNS sines"
