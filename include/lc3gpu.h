@@ -123,7 +123,10 @@ int lc3gpu_encoder_create_mixed_spec(lc3gpu_encoder **out, int n_streams, const 
 int lc3gpu_encode_mixed(lc3gpu_encoder *enc, const int16_t *d_pcm, uint8_t *d_out, int n_frames, void *hip_stream);
 
 /* per-channel state blobs (checkpoint / CPU cross-checks): size per channel, device->host copy, host->device.
- * nbytes must equal state_size * num_channels (LC3GPU_ELENGTH otherwise); both calls synchronise the device. */
+ * nbytes must equal state_size * num_channels (LC3GPU_ELENGTH otherwise); both calls synchronise the device.  A channel's blob
+ * starts with a 16-byte header {magic "LC3E" / "LC3D", layout version, payload size, fs_hz, frame duration, spec_flags}: loading
+ * a blob saved by a handle of another configuration, another stream-descriptor order, the other side or another library version
+ * returns LC3GPU_EINVAL instead of decoding garbage. */
 size_t lc3gpu_encoder_state_size(const lc3gpu_encoder *enc);
 int lc3gpu_encoder_state_save(lc3gpu_encoder *enc, void *host_dst, size_t nbytes);
 int lc3gpu_encoder_state_load(lc3gpu_encoder *enc, const void *host_src, size_t nbytes);

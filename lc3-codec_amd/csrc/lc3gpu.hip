@@ -1432,9 +1432,66 @@ static int decoder_reserve_planes(lc3gpu_decoder *d, size_t frames, hipStream_t 
     return LC3GPU_OK;
 }
 
+// ---- state blobs (checkpoint / CPU cross-checks).  Per channel, in the caller's channel order: a 16-byte header that says what
+// the payload is (which side, layout version, payload size, the channel's configuration and switches) followed by the state struct.
+// A blob from a handle of another configuration, another descriptor order, the other side or another layout version is refused
+// (LC3GPU_EINVAL) instead of being taken as state.
+struct lc3_state_header {
+    uint32_t magic;       // 'LC3E' / 'LC3D'
+    uint16_t version;     // layout version of the state structs (LC3_STATE_VERSION)
+    uint16_t payload16;   // payload bytes / 16
+    uint32_t fs_hz;
+    uint16_t frame_us10;  // frame duration in units of 100 us (75 / 100)
+    uint16_t spec_flags;  // LC3GPU_SPEC_* of an encoder channel, 0 for decoders
+};
+static_assert(sizeof(lc3_state_header) == 16, "state blob header");
+#define LC3_STATE_VERSION 3
+#define LC3_STATE_MAGIC_ENC 0x4533434cu  // "LC3E"
+#define LC3_STATE_MAGIC_DEC 0x4433434cu  // "LC3D"
+static lc3_state_header lc3_state_header_of(const HandleCommon &hc, int channel, uint32_t magic, size_t payload, int spec_flags) {
+    const HostCfg &h = hc.cfg_of_channel(channel);
+    lc3_state_header hd;
+    hd.magic = magic;
+    hd.version = LC3_STATE_VERSION;
+    hd.payload16 = (uint16_t)(payload / 16);
+    hd.fs_hz = (uint32_t)h.c.fs;
+    hd.frame_us10 = (uint16_t)(h.c.n_ms_10 ? 100 : 75);
+    hd.spec_flags = (uint16_t)spec_flags;
+    return hd;
+}
+// device states (internal order) -> blobs (caller order), and back after the headers have been checked
+template <class ST>
+static int state_blobs_save(HandleCommon &hc, const ST *d_states, uint32_t magic, int spec_flags, void *host_dst, size_t nbytes) {
+    const size_t per = sizeof(lc3_state_header) + sizeof(ST);
+    if (nbytes != per * (size_t)hc.num_channels) return LC3GPU_ELENGTH;
+    std::vector<ST> tmp((size_t)hc.num_channels);
+    HIP_TRY(hipMemcpy(tmp.data(), d_states, sizeof(ST) * tmp.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < hc.num_channels; i++) {
+        char *dst = (char *)host_dst + per * (size_t)i;
+        const lc3_state_header hd = lc3_state_header_of(hc, i, magic, sizeof(ST), spec_flags);
+        std::memcpy(dst, &hd, sizeof(hd));
+        std::memcpy(dst + sizeof(hd), &tmp[(size_t)hc.internal_of_channel(i)], sizeof(ST));
+    }
+    return LC3GPU_OK;
+}
+template <class ST>
+static int state_blobs_load(HandleCommon &hc, ST *d_states, uint32_t magic, int spec_flags, const void *host_src, size_t nbytes) {
+    const size_t per = sizeof(lc3_state_header) + sizeof(ST);
+    if (nbytes != per * (size_t)hc.num_channels) return LC3GPU_ELENGTH;
+    std::vector<ST> tmp((size_t)hc.num_channels);
+    for (int i = 0; i < hc.num_channels; i++) {
+        const char *src = (const char *)host_src + per * (size_t)i;
+        const lc3_state_header want = lc3_state_header_of(hc, i, magic, sizeof(ST), spec_flags);
+        if (std::memcmp(src, &want, sizeof(want)) != 0) return LC3GPU_EINVAL;  // another configuration / order / side / version
+        std::memcpy(&tmp[(size_t)hc.internal_of_channel(i)], src + sizeof(want), sizeof(ST));
+    }
+    HIP_TRY(hipMemcpy(d_states, tmp.data(), sizeof(ST) * tmp.size(), hipMemcpyHostToDevice));
+    return LC3GPU_OK;
+}
+
 extern "C" {
 
-int lc3gpu_version(void) { return 200; }
+int lc3gpu_version(void) { return 300; }
 
 const char *lc3gpu_strerror(int code) {
     switch (code) {
@@ -1746,40 +1803,25 @@ int lc3gpu_encode_frame_debug(lc3gpu_encoder *e, const int16_t *samples_in, int 
     return encode_frame_host(e, 0, samples_in, n_samples, buf_out, nbytes, dbg);
 }
 
-size_t lc3gpu_encoder_state_size(const lc3gpu_encoder *e) { return e ? sizeof(lc3_enc_state) : 0; }
+size_t lc3gpu_encoder_state_size(const lc3gpu_encoder *e) { return e ? sizeof(lc3_state_header) + sizeof(lc3_enc_state) : 0; }
 
-// blobs travel in the caller's channel order (a mixed handle keeps them sorted by configuration internally)
 int lc3gpu_encoder_state_save(lc3gpu_encoder *e, void *host_dst, size_t nbytes) {
     if (!e || !host_dst) return LC3GPU_EINVAL;
-    if (nbytes != sizeof(lc3_enc_state) * (size_t)e->num_channels) return LC3GPU_ELENGTH;
+    if (nbytes != lc3gpu_encoder_state_size(e) * (size_t)e->num_channels) return LC3GPU_ELENGTH;
     LC3_ON_DEVICE(e);
     int rc = encoder_materialise(e, 0, e->num_channels, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    if (!e->mixed) {
-        HIP_TRY(hipMemcpy(host_dst, e->d_states, nbytes, hipMemcpyDeviceToHost));
-        return LC3GPU_OK;
-    }
-    std::vector<lc3_enc_state> tmp((size_t)e->num_channels);
-    HIP_TRY(hipMemcpy(tmp.data(), e->d_states, nbytes, hipMemcpyDeviceToHost));
-    for (int i = 0; i < e->num_channels; i++)
-        std::memcpy((char *)host_dst + sizeof(lc3_enc_state) * (size_t)i, &tmp[(size_t)e->streams[(size_t)i].internal], sizeof(lc3_enc_state));
-    return LC3GPU_OK;
+    return state_blobs_save(*e, e->d_states, LC3_STATE_MAGIC_ENC, e->spec_flags & LC3GPU_SPEC_ALL, host_dst, nbytes);
 }
 
 int lc3gpu_encoder_state_load(lc3gpu_encoder *e, const void *host_src, size_t nbytes) {
     if (!e || !host_src) return LC3GPU_EINVAL;
-    if (nbytes != sizeof(lc3_enc_state) * (size_t)e->num_channels) return LC3GPU_ELENGTH;
+    if (nbytes != lc3gpu_encoder_state_size(e) * (size_t)e->num_channels) return LC3GPU_ELENGTH;
     LC3_ON_DEVICE(e);
     HIP_TRY(hipDeviceSynchronize());  // a launch in flight would store its state over the loaded one
-    if (!e->mixed) {
-        HIP_TRY(hipMemcpy(e->d_states, host_src, nbytes, hipMemcpyHostToDevice));
-    } else {
-        std::vector<lc3_enc_state> tmp((size_t)e->num_channels);
-        for (int i = 0; i < e->num_channels; i++)
-            std::memcpy(&tmp[(size_t)e->streams[(size_t)i].internal], (const char *)host_src + sizeof(lc3_enc_state) * (size_t)i, sizeof(lc3_enc_state));
-        HIP_TRY(hipMemcpy(e->d_states, tmp.data(), nbytes, hipMemcpyHostToDevice));
-    }
+    int rc = state_blobs_load(*e, e->d_states, LC3_STATE_MAGIC_ENC, e->spec_flags & LC3GPU_SPEC_ALL, host_src, nbytes);
+    if (rc) return rc;
     e->fresh_mask.assign((size_t)e->num_channels, 0);
     return LC3GPU_OK;
 }
@@ -2096,47 +2138,32 @@ int lc3gpu_decoder_synth_debug(lc3gpu_decoder *d, int time_in, const float *in, 
     return LC3GPU_OK;
 }
 
-size_t lc3gpu_decoder_state_size(const lc3gpu_decoder *d) { return d ? sizeof(lc3_dec_state) : 0; }
+size_t lc3gpu_decoder_state_size(const lc3gpu_decoder *d) { return d ? sizeof(lc3_state_header) + sizeof(lc3_dec_state) : 0; }
 
 int lc3gpu_decoder_state_save(lc3gpu_decoder *d, void *host_dst, size_t nbytes) {
     if (!d || !host_dst) return LC3GPU_EINVAL;
-    if (nbytes != sizeof(lc3_dec_state) * (size_t)d->num_channels) return LC3GPU_ELENGTH;
+    if (nbytes != lc3gpu_decoder_state_size(d) * (size_t)d->num_channels) return LC3GPU_ELENGTH;
     LC3_ON_DEVICE(d);
     HIP_TRY(hipDeviceSynchronize());
-    if (!d->mixed) {
-        HIP_TRY(hipMemcpy(host_dst, d->d_states, nbytes, hipMemcpyDeviceToHost));
-        return LC3GPU_OK;
-    }
-    std::vector<lc3_dec_state> tmp((size_t)d->num_channels);
-    HIP_TRY(hipMemcpy(tmp.data(), d->d_states, nbytes, hipMemcpyDeviceToHost));
-    for (int i = 0; i < d->num_channels; i++)
-        std::memcpy((char *)host_dst + sizeof(lc3_dec_state) * (size_t)i, &tmp[(size_t)d->streams[(size_t)i].internal], sizeof(lc3_dec_state));
-    return LC3GPU_OK;
+    return state_blobs_save(*d, d->d_states, LC3_STATE_MAGIC_DEC, 0, host_dst, nbytes);
 }
 
 int lc3gpu_decoder_state_load(lc3gpu_decoder *d, const void *host_src, size_t nbytes) {
     if (!d || !host_src) return LC3GPU_EINVAL;
-    if (nbytes != sizeof(lc3_dec_state) * (size_t)d->num_channels) return LC3GPU_ELENGTH;
+    if (nbytes != lc3gpu_decoder_state_size(d) * (size_t)d->num_channels) return LC3GPU_ELENGTH;
     LC3_ON_DEVICE(d);
     HIP_TRY(hipDeviceSynchronize());  // a launch in flight would store its state over the loaded one
-    if (!d->mixed) {
-        HIP_TRY(hipMemcpy(d->d_states, host_src, nbytes, hipMemcpyHostToDevice));
-        return LC3GPU_OK;
-    }
-    std::vector<lc3_dec_state> tmp((size_t)d->num_channels);
-    for (int i = 0; i < d->num_channels; i++)
-        std::memcpy(&tmp[(size_t)d->streams[(size_t)i].internal], (const char *)host_src + sizeof(lc3_dec_state) * (size_t)i, sizeof(lc3_dec_state));
-    HIP_TRY(hipMemcpy(d->d_states, tmp.data(), nbytes, hipMemcpyHostToDevice));
-    return LC3GPU_OK;
+    return state_blobs_load(*d, d->d_states, LC3_STATE_MAGIC_DEC, 0, host_src, nbytes);
 }
 
 int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
     if (!d || !out) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(d);
+    HIP_TRY(hipDeviceSynchronize());
     std::vector<lc3_dec_state> st((size_t)d->num_channels);
-    int rc = lc3gpu_decoder_state_save(d, st.data(), sizeof(lc3_dec_state) * (size_t)d->num_channels);
-    if (rc) return rc;
+    HIP_TRY(hipMemcpy(st.data(), d->d_states, sizeof(lc3_dec_state) * st.size(), hipMemcpyDeviceToHost));
     uint64_t total = 0;
-    for (const auto &s : st) total += (uint64_t)s.core.plc_events;
+    for (const auto &x : st) total += (uint64_t)x.core.plc_events;
     *out = total;
     return LC3GPU_OK;
 }

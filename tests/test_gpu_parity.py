@@ -582,6 +582,31 @@ def test_state_blob_size_is_checked():
     assert L.lc3gpu_decoder_state_load(dec._h, small_d.ctypes.data_as(ctypes.c_void_p), small_d.size) == -3
 
 
+def test_state_blobs_say_what_they_are():
+    """a channel's blob carries a header (side, layout version, payload size, rate, frame duration, switches): a blob of equal SIZE from a
+    handle of another configuration, from a mixed handle with another descriptor order, from an encoder with other switches, or with a
+    damaged header is refused (LC3GPU_EINVAL = -1) instead of being taken as state; a matching one loads and continues bit-exactly"""
+    e48, e32 = pkg.Lc3Encoder(2, US, FS), pkg.Lc3Encoder(2, 10000, 32000)
+    d48, d48_75 = pkg.Lc3Decoder(2, US, FS), pkg.Lc3Decoder(2, 7500, 48000)
+    be, bd = e48.state_save(), d48.state_save()
+    assert be[:4].tobytes() == b"LC3E" and bd[:4].tobytes() == b"LC3D"
+    for handle, blob, err in ((e32, be, pkg.Lc3EncoderError), (d48_75, bd, pkg.Lc3DecoderError),
+                              (pkg.Lc3Encoder(2, US, FS, spec_flags=2), be, pkg.Lc3EncoderError)):
+        with pytest.raises(err) as ex:
+            handle.state_load(blob)
+        assert ex.value.code == -1
+    bad = be.copy()
+    bad[4] ^= 1  # layout version
+    with pytest.raises(pkg.Lc3EncoderError):
+        e48.state_load(bad)
+    e48.state_load(be)  # the matching blob is fine
+    a = pkg.Lc3Encoder.mixed([(48000, 10000, 100), (32000, 10000, 80)])
+    b = pkg.Lc3Encoder.mixed([(32000, 10000, 80), (48000, 10000, 100)])
+    with pytest.raises(pkg.Lc3EncoderError):
+        b.state_load(a.state_save())
+    a.state_load(a.state_save())
+
+
 def test_runtime_configuration_view_of_the_headline_configuration():
     """48 kHz / 10 ms, 48 kHz / 7.5 ms, 32 kHz / 10 ms and 16 kHz / 10 ms normally run kernels instantiated with the configuration as
     compile-time constants (lc3_cfg_views.h); LC3GPU_GENERIC=1 keeps them on the run-time view every other configuration uses.
@@ -660,20 +685,27 @@ def test_prepared_packer_symbols_on_and_off():
         assert r.returncode == 0 and "prep ok" in r.stdout, v + r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_stress_parity_tool_small_run():
-    """tools/stress_parity.py (the differential run whose full-size results are profiles/r02_stress_parity*.json: 7.3 M frames per
-    direction over 14 configurations, none differing) at a size that takes seconds"""
+def test_stress_parity_tool_one_million_frames():
+    """tools/stress_parity.py at volume inside the suite: 14 configurations x 2048 streams x 18 frames x 2 rounds = 1 032 192 frames per
+    direction, every bitstream byte and every PCM sample compared with the oracle (which runs on the host threads the job is granted);
+    one frame in 48 of the decode direction is damaged first (bit flips, random bytes, bad-frame flags), so concealment, the parser's
+    error paths and the frames that follow a lost one are part of the volume.  (The guarded decisions of the quantiser fall back to
+    their sequential sum about once in 10^4 decisions: it takes this many frames to see both sides of every guard on real data.)"""
     import json
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "--streams", "96", "--frames", "5", "--rounds", "1"],
-                       cwd=root, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "--streams", "2048", "--frames", "18", "--rounds", "2"],
+                       cwd=root, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["frames_differing"] == 0 and line["total_frames_each_direction"] == 14 * 96 * 5
+    assert line["frames_differing"] == 0 and line["total_frames_each_direction"] == 14 * 2048 * 18 * 2 >= 1000000
+    assert line["frames_damaged"] > 10000
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "stress_parity_suite.json"), "w") as f:
+        f.write(r.stdout.strip().splitlines()[-1] + "\n")
 
 
 def test_late_reconstruction_on_and_off():

@@ -5,7 +5,8 @@
 For every (sampling rate, frame duration, frame size) of the list below and every round: synthetic PCM of mixed character
 (tonal / noisy / clicks from lc3-codec_amd.synth, plus band-limited, very quiet, clipping and silent streams), encoded by the
 GPU engine and by the oracle (all host threads), the bitstreams compared byte for byte; then the oracle's bytes decoded by
-both and the PCM compared sample for sample.  Exit code 1 on any difference.  The point of the volume: decisions the kernels
+both -- a share of the frames damaged first (bit flips, random bytes, bad-frame flags: concealment and error paths) -- and the PCM
+compared sample for sample.  Exit code 1 on any difference.  The point of the volume: decisions the kernels
 take from guarded tree sums fall back to the sequential sum about once in 10^4 decisions, so millions of
 frames are needed to exercise both sides of every guard on real data."""
 import argparse
@@ -48,6 +49,9 @@ def main():
     ap.add_argument("--streams", type=int, default=2048)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--corrupt", type=float, default=1.0 / 48.0,
+                    help="share of the frames the decode direction damages (random bit flips, whole frames of random bytes and, at 48 kHz, "
+                         "frames flagged bad through the external indicator): concealment, error paths and the frames after them")
     a = ap.parse_args()
     import torch
 
@@ -55,7 +59,11 @@ def main():
 
     pkg = importlib.import_module("lc3-codec_amd")
     synth = importlib.import_module("lc3-codec_amd.synth")
-    threads = os.cpu_count() or 8
+    try:
+        from bench import granted_cpus
+        threads = granted_cpus()[0]  # what the job may run on (cgroup quota), not the machine's core count
+    except Exception:
+        threads = os.cpu_count() or 8
     S, T = a.streams, a.frames
     st = torch.cuda.current_stream().cuda_stream
     rows, bad = [], 0
@@ -64,7 +72,7 @@ def main():
         nf = (fs if fs != 44100 else 48000) * us // 1000000
         enc = pkg.Lc3Encoder(S, us, fs)
         dec = pkg.Lc3Decoder(S, us, fs)
-        enc_bad = dec_bad = 0
+        enc_bad = dec_bad = damaged = 0
         for rnd in range(a.rounds):
             pcm = make_mixed(synth, S, T, nf, fs, rnd)
             enc.reset()
@@ -76,20 +84,39 @@ def main():
             got = d_out.cpu().numpy()
             ref = O.encode_batch(pcm, nbytes, fs, us, threads=threads)
             enc_bad += int((got != ref).any(axis=2).sum())
-            d_in = torch.from_numpy(ref).cuda()
+            # decode direction: the oracle's bytes, a share of them damaged -- the same bytes for both decoders, except for frames
+            # handed to the GPU intact but FLAGGED bad, which the oracle receives with an out-of-range bandwidth index instead
+            # (48 kHz: three bandwidth bits, 7 > 4; side_info_reader.rs:43-50), so that both conceal them
+            crng = np.random.default_rng([91, rnd, fs, us, nbytes])
+            data, flags = ref.copy(), np.zeros((S, T), np.uint8)
+            kind = crng.random((S, T))
+            flips = kind < a.corrupt / 3.0
+            for s_i, t_i in zip(*np.nonzero(flips)):
+                for _ in range(int(crng.integers(1, 4))):
+                    data[s_i, t_i, int(crng.integers(0, nbytes))] ^= np.uint8(1 << int(crng.integers(0, 8)))
+            garbage = (kind >= a.corrupt / 3.0) & (kind < 2.0 * a.corrupt / 3.0)
+            data[garbage] = crng.integers(0, 256, (int(garbage.sum()), nbytes), dtype=np.uint8)
+            for_oracle = data
+            if fs == 48000:
+                flags = ((kind >= 2.0 * a.corrupt / 3.0) & (kind < a.corrupt)).astype(np.uint8)
+                for_oracle = data.copy()
+                for_oracle[flags.astype(bool), -1] |= np.uint8(7)
+            damaged += int(flips.sum() + garbage.sum() + flags.sum())
+            d_in = torch.from_numpy(data).cuda()
+            d_flags = torch.from_numpy(flags).cuda()
             d_dec = torch.zeros((S, T, nf), dtype=torch.int16, device="cuda")
-            dec.decode(d_in, d_dec, nbytes, T, stream=st)
+            dec.decode(d_in, d_dec, nbytes, T, stream=st, d_bad_frame=d_flags)
             torch.cuda.synchronize()
-            ref_pcm = O.decode_batch(ref, nf, fs, us, threads=threads)
+            ref_pcm = O.decode_batch(for_oracle, nf, fs, us, threads=threads)
             dec_bad += int((d_dec.cpu().numpy() != ref_pcm).any(axis=2).sum())
         rows.append({"fs_hz": fs, "frame_us": us, "nbytes": nbytes, "frames": S * T * a.rounds, "encode_frames_differing": enc_bad,
-                     "decode_frames_differing": dec_bad})
+                     "decode_frames_differing": dec_bad, "decode_frames_damaged": damaged})
         bad += enc_bad + dec_bad
         print(f"{fs} {us} {nbytes}: {S * T * a.rounds} frames, enc diff {enc_bad}, dec diff {dec_bad}", file=sys.stderr)
     total = sum(r["frames"] for r in rows)
     print(json.dumps({"what": "GPU engine vs CPU oracle, byte-exact bitstreams and sample-exact PCM (tools/stress_parity.py)",
                       "streams": S, "frames_per_stream": T, "rounds": a.rounds, "total_frames_each_direction": total,
-                      "frames_differing": bad, "seconds": round(time.time() - t0, 1), "env_seq_sums": os.environ.get("LC3GPU_SEQ_SUMS"),
+                      "frames_differing": bad, "corrupt_share": a.corrupt, "frames_damaged": sum(r["decode_frames_damaged"] for r in rows), "host_threads": threads, "seconds": round(time.time() - t0, 1), "env_seq_sums": os.environ.get("LC3GPU_SEQ_SUMS"),
                       "cases": rows}))
     return 1 if bad else 0
 
