@@ -381,11 +381,23 @@ __device__ __forceinline__ size_t lc3_io_flag_idx(const lc3_io &io, int first, s
     return s * (size_t)T + t;
 }
 
+// runs BODY<view>(slot{g.slot}, args...) with the group's configuration view (a mixed batch is BASELINE config 4's whole point: its
+// 48 kHz / 7.5 ms, 32 kHz and 16 kHz groups get the compile-time views the uniform handles of those configurations get)
+#define LC3_GROUP_VIEW(BODY, g, ...)                                                        \
+    do {                                                                                    \
+        switch ((g).fixed) {                                                                \
+        case 1: BODY<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{(g).slot}, __VA_ARGS__); break; \
+        case 2: BODY<lc3_cfg_48k75>(lc3_cfg_slot<lc3_cfg_48k75>{(g).slot}, __VA_ARGS__); break; \
+        case 3: BODY<lc3_cfg_32k10>(lc3_cfg_slot<lc3_cfg_32k10>{(g).slot}, __VA_ARGS__); break; \
+        case 4: BODY<lc3_cfg_16k10>(lc3_cfg_slot<lc3_cfg_16k10>{(g).slot}, __VA_ARGS__); break; \
+        default: BODY<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{(g).slot}, __VA_ARGS__); break;    \
+        }                                                                                   \
+    } while (0)
 // A mixed-configuration handle keeps its streams sorted by configuration; a "group" is one run of streams of equal
 // (rate, duration, frame bytes).  Every kernel of a mixed batch is ONE launch: a workgroup finds its group from its index.
 #define LC3_MAX_GROUPS 24
 struct lc3_group {
-    int slot, fixed;              // configuration slot; 1 = the compile-time view (48 kHz / 10 ms) applies
+    int slot, fixed;              // configuration slot; the compile-time view that applies (lc3_cfg_views.h: 1..4), 0 = the run-time view
     int first_stream, n_streams;  // [first_stream, first_stream + n_streams) in the handle's internal order
     int wg_stream, wg_frame;      // the group's first workgroup in a stream-kernel / frame-kernel launch
     int nbytes, ne, nb, pad;
@@ -455,12 +467,8 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_mixed_kern
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
     float *m = mid + (size_t)g.frame_base * (size_t)MP_WORDS;
     int32_t *p = planes + (size_t)g.frame_base * (size_t)EP_WORDS;
-    if (g.fixed)
-        lc3_enc_front_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
-                                          g.n_streams, pcm, m, p, g.nbytes, n_frames, fresh, nullptr, io, spec_flags);
-    else
-        lc3_enc_front_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
-                                        g.n_streams, pcm, m, p, g.nbytes, n_frames, fresh, nullptr, io, spec_flags);
+    LC3_GROUP_VIEW(lc3_enc_front_body, g, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, pcm, m, p, g.nbytes, n_frames, fresh,
+                   (float *)nullptr, io, spec_flags);
 }
 
 // SNS vector quantiser, one LANE per frame (lc3_dev_enc_vq.h): 16 targets -> indices (packer plane) + 64 band gains.
@@ -541,12 +549,8 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_bac
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
     const float *m = mid + (size_t)g.frame_base * (size_t)MP_WORDS;
     int32_t *p = planes + (size_t)g.frame_base * (size_t)EP_WORDS;
-    if (g.fixed)
-        lc3_enc_back_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
-                                         g.n_streams, m, p, g.nbytes, n_frames, nullptr, spec_flags);
-    else
-        lc3_enc_back_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
-                                       g.n_streams, m, p, g.nbytes, n_frames, nullptr, spec_flags);
+    LC3_GROUP_VIEW(lc3_enc_back_body, g, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, m, p, g.nbytes, n_frames, (float *)nullptr,
+                   spec_flags);
 }
 
 // Bitstream packer, one LANE per frame (lc3_dev_enc_pack.h).  blockDim.x frames per workgroup; context lookup and the
@@ -758,12 +762,7 @@ __global__ __launch_bounds__(256) void lc3_parse_mixed_kernel(lc3_groups G, cons
                                                               int T, lc3_io io, int late) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
-    if (g.fixed)
-        lc3_parse_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_frame, in, bad, p, g.nbytes,
-                                      g.n_streams * T, T, g.first_stream, io, late);
-    else
-        lc3_parse_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_frame, in, bad, p, g.nbytes, g.n_streams * T,
-                                    T, g.first_stream, io, late);
+    LC3_GROUP_VIEW(lc3_parse_body, g, blockIdx.x - g.wg_frame, in, bad, p, g.nbytes, g.n_streams * T, T, g.first_stream, io, late);
 }
 
 // Spectrum reconstruction D4-D8 of a full batch (lc3_dev_dec_recon.h), between the parser and the synthesis kernel:
@@ -794,12 +793,8 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_RECON_WAVES) void lc3_recon_
     int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
     const unsigned wg = blockIdx.x - g.wg_frame;
     const size_t nfr = (size_t)g.n_streams * (size_t)T, left = nfr - (size_t)wg * LC3_WG_WAVES;  // this workgroup's four frames only
-    if (g.fixed)
-        lc3_recon_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, 0, 1, p + (size_t)wg * LC3_WG_WAVES * (size_t)LC3_PLANE_WORDS, g.nbytes,
-                                      left < LC3_WG_WAVES ? left : LC3_WG_WAVES);
-    else
-        lc3_recon_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, 0, 1, p + (size_t)wg * LC3_WG_WAVES * (size_t)LC3_PLANE_WORDS, g.nbytes,
-                                    left < LC3_WG_WAVES ? left : LC3_WG_WAVES);
+    LC3_GROUP_VIEW(lc3_recon_body, g, 0u, 1u, p + (size_t)wg * LC3_WG_WAVES * (size_t)LC3_PLANE_WORDS, g.nbytes,
+                   left < LC3_WG_WAVES ? left : (size_t)LC3_WG_WAVES);
 }
 // LC3_TNS_FPB frames per workgroup, one wave per 64 of them: 16 KB of (dynamic) LDS per wave for its frames' band gains, band-major.
 // Four waves per workgroup so that the 1 024 waves of a full batch land one per SIMD (single-wave workgroups are packed several to a CU).
@@ -834,10 +829,7 @@ __global__ __launch_bounds__(LC3_TNS_FPB) void lc3_tns_kernel(lc3_cfg_slot<CV> c
 __global__ __launch_bounds__(LC3_TNS_FPB) void lc3_tns_mixed_kernel(lc3_groups G, int32_t *planes, int T) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
-    if (g.fixed)
-        lc3_tns_body<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_frame, p, (size_t)g.n_streams * (size_t)T);
-    else
-        lc3_tns_body<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_frame, p, (size_t)g.n_streams * (size_t)T);
+    LC3_GROUP_VIEW(lc3_tns_body, g, blockIdx.x - g.wg_frame, p, (size_t)g.n_streams * (size_t)T);
 }
 
 // LATE: the launch reconstructs the spectrum here (lc3_dec_reconstruct_wave) -- a compile-time switch, so that the kernels of full
@@ -896,12 +888,13 @@ __device__ __forceinline__ void lc3_decode_mixed_body(const lc3_groups &G, lc3_d
                                                       int n_frames, int fresh, lc3_io io) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
     const int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
-    if (g.fixed)
-        lc3_decode_body<lc3_cfg_48k10, LATE>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
-                                             g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io);
-    else
-        lc3_decode_body<lc3_cfg_any, LATE>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream,
-                                           g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io);
+    switch (g.fixed) {
+    case 1: lc3_decode_body<lc3_cfg_48k10, LATE>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io); break;
+    case 2: lc3_decode_body<lc3_cfg_48k75, LATE>(lc3_cfg_slot<lc3_cfg_48k75>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io); break;
+    case 3: lc3_decode_body<lc3_cfg_32k10, LATE>(lc3_cfg_slot<lc3_cfg_32k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io); break;
+    case 4: lc3_decode_body<lc3_cfg_16k10, LATE>(lc3_cfg_slot<lc3_cfg_16k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io); break;
+    default: lc3_decode_body<lc3_cfg_any, LATE>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io); break;
+    }
 }
 __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_mixed_kernel(lc3_groups G, lc3_dec_state *states,
                                                                                 const int32_t *planes, int16_t *pcm, int n_frames,
@@ -1289,7 +1282,7 @@ void fill_groups(const HandleCommon &hc, int T, unsigned fpb, lc3_groups &G, uns
         const GroupHost &gh = hc.groups[i];
         lc3_group &g = G.g[i];
         g.slot = gh.h.slot;
-        g.fixed = gh.h.view == 1;  // the mixed kernels carry two bodies: the headline view and the run-time view
+        g.fixed = gh.h.view;  // the mixed kernels carry one body per configuration view
         g.first_stream = gh.first_stream;
         g.n_streams = gh.n_streams;
         g.wg_stream = (int)wg_stream;

@@ -979,3 +979,45 @@ def test_device_math_on_the_device():
     step_dec = np.float32(np.pi / 17.0)                                # (PI / 17.0) as f32   decoder/temporal_noise_shaping.rs:41-44
     assert np.array_equal(tab[832:849].view(np.uint32), oracle(8, (step_enc * (ri - np.float32(8.0))).astype(np.float32)).view(np.uint32)), "encoder TNS sines"
     assert np.array_equal(tab[849:866].view(np.uint32), oracle(8, (step_dec * (ri - np.float32(8.0))).astype(np.float32)).view(np.uint32)), "decoder TNS sines"
+
+
+def test_one_handle_alternates_reconstruction_forms_with_lost_frames_at_launch_edges():
+    """ONE decoder handle whose launches alternate between two frames per stream (spectrum rebuilt in the synthesis kernel, the last
+    good spectrum written to the state blob by every good frame) and eight (rebuilt in the parse kernel, the last good spectrum taken
+    from the launch's own plane columns and copied to the blob only at the launch's end), with corrupt and flagged frames as the
+    first and the last frame of launches, so that concealment crosses every kind of hand-over: the PCM of the whole 30-frame run
+    must be the oracle's."""
+    torch = torch_mod()
+    S, chunks = 48, [2, 8, 2, 8, 2, 8]
+    T = sum(chunks)
+    pcm = synth.make_pcm(S, T, 480, 48000, seed=1234)
+    data = O.encode_batch(pcm, 150, threads=8).copy()
+    flags = np.zeros((S, T), np.uint8)
+    edges, t0 = [], 0
+    for n in chunks:
+        edges += [t0, t0 + n - 1]
+        t0 += n
+    rng = np.random.default_rng(5)
+    for s in range(S):
+        lost = rng.choice(edges, size=4, replace=False)
+        for t in lost[:2]:
+            data[s, t, -1] |= 7          # bandwidth index out of range: the parser rejects the frame
+        for t in lost[2:]:
+            flags[s, t] = 1              # external bad-frame indicator on an intact frame
+    for_oracle = data.copy()
+    for_oracle[flags.astype(bool), -1] |= 7
+    ref = O.decode_batch(for_oracle, 480, threads=8)
+    dec = pkg.Lc3Decoder(S, US, FS)
+    st = torch.cuda.current_stream().cuda_stream
+    got, t0 = [], 0
+    for n in chunks:
+        d_in = torch.from_numpy(np.ascontiguousarray(data[:, t0:t0 + n])).cuda()
+        d_fl = torch.from_numpy(np.ascontiguousarray(flags[:, t0:t0 + n])).cuda()
+        d_out = torch.zeros((S, n, 480), dtype=torch.int16, device="cuda")
+        dec.decode(d_in, d_out, 150, n, stream=st, d_bad_frame=d_fl)
+        torch.cuda.synchronize()
+        got.append(d_out.cpu().numpy())
+        t0 += n
+    got = np.concatenate(got, axis=1)
+    assert np.array_equal(got, ref), np.argwhere((got != ref).any(axis=2))[:8]
+    assert dec.plc_events() == 4 * S
