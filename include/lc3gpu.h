@@ -32,7 +32,9 @@ extern "C" {
 #define LC3GPU_OK 0
 #define LC3GPU_EINVAL -1        /* bad argument (unsupported fs / duration, null pointer, size mismatch) */
 #define LC3GPU_ECHANNEL -2      /* channel index out of range (reference: panic, lc3_encoder.rs:185-189) */
-#define LC3GPU_ELENGTH -3       /* samples / buffer length mismatch (reference: assert_eq! panic) */
+#define LC3GPU_ELENGTH -3       /* samples / buffer length mismatch (reference: assert_eq! panic); also: a frame size outside
+                                   20 ... 400 bytes on the encoder (1 ... 400 on the decoder) -- a deliberate deviation: the reference's
+                                   encode_frame takes any buf_out.len() (src/encoder/lc3_encoder.rs:65), LC3 defines this range */
 #define LC3GPU_EBITS -4         /* Lc3DecoderError::Only16BitsPerAudioSampleSupported (lc3_decoder.rs:80-82) */
 #define LC3GPU_EHIP -5          /* HIP runtime error; see lc3gpu_last_hip_error() */
 #define LC3GPU_ENODEVICE -6     /* no usable HIP device */
