@@ -389,6 +389,41 @@ class GpuEngine:
         res["pipelined"] = {"hip_streams": 2, "value": S * T * steps / pel, "unit": "frames/s", "ms_per_step": pel / steps * 1e3,
                             "note": "the full batch, encoder of step k+1 on one HIP stream under the decoder of step k on another "
                                     "(two byte buffers); informational, not `value`"}
+        del enc, dec
+        # both together: two half batches, each with its encoder on one stream and its decoder on another (four streams).  The
+        # lane-per-frame kernels of a 65 536-frame launch are ONE wave per SIMD and leave half of its issue slots idle (DESIGN
+        # section 6): whatever runs beside them on another stream gets those
+        H, SH = 2, S // 2
+        he = [pkg.Lc3Encoder(SH, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(H)]
+        hd = [pkg.Lc3Decoder(SH, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(H)]
+        hs_e = [torch.cuda.Stream() for _ in range(H)]
+        hs_d = [torch.cuda.Stream() for _ in range(H)]
+        h_enc = [[torch.cuda.Event() for _ in range(H)] for _ in range(2)]
+        h_dec = [[torch.cuda.Event() for _ in range(H)] for _ in range(2)]
+
+        def hstep(k):
+            b = k & 1
+            for p in range(H):
+                lo, hi = p * SH, (p + 1) * SH
+                if k >= 2:
+                    hs_e[p].wait_event(h_dec[b][p])
+                he[p].encode(self.d_pcm[lo:hi], bufs[b][lo:hi], NBYTES, T, stream=hs_e[p].cuda_stream)
+                h_enc[b][p].record(hs_e[p])
+                hs_d[p].wait_event(h_enc[b][p])
+                hd[p].decode(bufs[b][lo:hi], self.d_out[lo:hi], NBYTES, T, stream=hs_d[p].cuda_stream)
+                h_dec[b][p].record(hs_d[p])
+
+        for k in range(2 * ((warmup + 1) // 2)):
+            hstep(k)
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        for k in range(steps):
+            hstep(k + 2)
+        torch.cuda.synchronize()
+        hel = time.perf_counter() - h0
+        res["pipelined_halves"] = {"hip_streams": 4, "value": S * T * steps / hel, "unit": "frames/s", "ms_per_step": hel / steps * 1e3,
+                                   "note": "two half batches, each with its encoder on one HIP stream and its decoder on another (the decoder of "
+                                           "step k under the encoder of step k+1); informational, not `value`"}
         return res
 
 

@@ -532,7 +532,7 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_reconstruct_wave(LC3_CFG_
         }
         {
             const int fill = (int)((fillmask >> j) & 1u);
-            const uint32_t lcg_n = (13849u + lcg * 31821u) & 0xFFFFu;
+            const uint32_t lcg_n = (13849u + LC3_MUL24(lcg, 31821u)) & 0xFFFFu;
             lcg = fill ? lcg_n : lcg;
             v = fill ? (lcg_n < 0x8000u ? level : -level) : v;
         }

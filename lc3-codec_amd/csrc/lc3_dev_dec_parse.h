@@ -853,7 +853,7 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
             }
             {   // noise filling: next LCG state and a +-level line where the neighbourhood is empty
                 const int fill = do_fill && k >= nf_start && k < lim && (nzwin & winmask) == 0;
-                const uint32_t lcg_n = (13849u + lcg * 31821u) & 0xFFFFu;
+                const uint32_t lcg_n = (13849u + LC3_MUL24(lcg, 31821u)) & 0xFFFFu;
                 lcg = fill ? lcg_n : lcg;
                 v = fill ? (lcg_n < 0x8000u ? level : -level) : v;
             }

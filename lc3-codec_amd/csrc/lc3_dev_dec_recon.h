@@ -250,7 +250,7 @@ __device__ __forceinline__ void lc3_recon_frame_direct(const CC &c, const lc3_re
         }
         {
             const int fill = (int)((fillmask >> j) & 1u);
-            const uint32_t lcg_n = (13849u + lcg * 31821u) & 0xFFFFu;
+            const uint32_t lcg_n = (13849u + LC3_MUL24(lcg, 31821u)) & 0xFFFFu;
             lcg = fill ? lcg_n : lcg;
             v = fill ? (lcg_n < 0x8000u ? level : -level) : v;
         }

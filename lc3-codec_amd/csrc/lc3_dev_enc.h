@@ -1660,22 +1660,10 @@ LC3_CFG_TEMPLATE __device__ __noinline__ int lc3_enc_residual_noise(LC3_CFG_PARA
 // on its serial path.  Small launches only (LC3_LAUNCH_PREP_SYMBOLS, lc3_dev_enc_pack.h); more than LC3_SYM_CAP symbols (never
 // seen; the bit budget allows it in theory): EP_NSYM = -1 and the packer derives the symbols itself.
 // ------------------------------------------------------------------------------------------
-LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_symbols(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const lc3_quant_res q,
-                                              int32_t *plane, int st) {
-    LC3_CFG_BIND;
-    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
-    const int ne = c.ne, k0 = 4 * lane, ntup = q.lastnz_trunc / 2, lsb_mode = q.lsb_mode, rate_flag = q.rate_flag;
-    int q8[8];
-    {
-        const lc3_i4 w = *(const lc3_i4 *)(LC3_XQ(L) + 8 * lane);  // zero from lastnz_trunc on
-        int wi[4];
-        __builtin_memcpy(wi, &w, 16);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            q8[2 * i] = (int)(int16_t)(wi[i] & 0xffff);
-            q8[2 * i + 1] = wi[i] >> 16;
-        }
-    }
+// q8: the lane's eight quantised values (pairs 4 lane .. 4 lane + 3; zero from lastnz_trunc on and beyond ne)
+__device__ __forceinline__ void lc3_enc_symbols_core(int ne, int lane, const int (&q8)[8], int lastnz_trunc, int lsb_mode, int rate_flag,
+                                                     int32_t *plane, int st) {
+    const int k0 = 4 * lane, ntup = lastnz_trunc / 2;
     unsigned a4[4], b4[4];
     int ne4[4], tt[4], cnt = 0, lsbs = 0, esc_max = 0;
 #pragma unroll
@@ -1748,6 +1736,41 @@ LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_symbols(LC3_CFG_PARAM, LC3
             }
         }
     }
+}
+// the eight values of a lane from four packed words (x_q[2k] | x_q[2k+1] << 16)
+__device__ __forceinline__ void lc3_enc_symbols_unpack(const int (&wi)[4], int (&q8)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        q8[2 * i] = (int)(int16_t)(wi[i] & 0xffff);
+        q8[2 * i + 1] = wi[i] >> 16;
+    }
+}
+// ... inside the analysis kernel's back half, from the quantised spectrum in LDS
+LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_symbols(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, const lc3_quant_res q,
+                                              int32_t *plane, int st) {
+    LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
+    const lc3_i4 w = *(const lc3_i4 *)(LC3_XQ(L) + 8 * lane);  // zero from lastnz_trunc on
+    int wi[4], q8[8];
+    __builtin_memcpy(wi, &w, 16);
+    lc3_enc_symbols_unpack(wi, q8);
+    lc3_enc_symbols_core(c.ne, lane, q8, q.lastnz_trunc, q.lsb_mode, q.rate_flag, plane, st);
+}
+// ... as a stage of its own between the back half and the packer, one WAVE per frame, from the frame's plane column (frame-major
+// planes: the lane's four words are one 16-byte unit of the column; EP_XQ and EP_WORDS are multiples of four words)
+__device__ __forceinline__ void lc3_enc_symbols_frame(int ne, int lane, int32_t *plane) {
+    static_assert(EP_XQ % 4 == 0 && EP_WORDS % 4 == 0 && LC3_PLANE_STRIDE == 1, "16-byte units of the packer plane");
+    const int lastnz_trunc = LC3_UNIFORM_I32(plane[EP_LASTNZ_TRUNC]), lsb_mode = LC3_UNIFORM_I32(plane[EP_LSB_MODE]),
+              rate_flag = LC3_UNIFORM_I32(plane[EP_RATE_FLAG]);
+    int wi[4] = {0, 0, 0, 0}, q8[8];
+    if (4 * lane < 200) {
+        const lc3_i4 w = *(const lc3_i4 *)(plane + EP_XQ + 4 * lane);
+        __builtin_memcpy(wi, &w, 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) wi[i] = 4 * lane + i < ne / 2 ? wi[i] : 0;  // words beyond the configuration's pairs are stale
+    lc3_enc_symbols_unpack(wi, q8);
+    lc3_enc_symbols_core(ne, lane, q8, lastnz_trunc, lsb_mode, rate_flag, plane, 1);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -396,7 +396,7 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
     // ac_enc_finish :354-395
     {
         int bits = 1;
-        while ((w.range >> (24 - bits)) == 0) bits++;
+        while (bits < 24 && (w.range >> (24 - bits)) == 0) bits++;  // (range >= 64 here; the bound only keeps a damaged plane from spinning)
         uint32_t mask = 0x00ffffffu >> bits;
         uint32_t val = w.low + mask;
         const uint32_t over1 = val >> 24;

@@ -649,6 +649,23 @@ __global__ __launch_bounds__(256) void lc3_pack_mixed_kernel(lc3_groups G, const
                   g.first_stream, io);
 }
 
+// The packer's symbols as a stage of its own (lc3_enc_symbols_frame, lc3_dev_enc.h): one WAVE per frame.  A workgroup stages the
+// context lookup table once (lc3_spec_tab) and walks frames wg * 4 + wave, + 4 * gridDim.x, ...; eight waves per SIMD.  Selectable
+// (LC3GPU_PREP_SYMBOLS=2); measured against the two other forms in DESIGN.md section 6.
+template <class CV>
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 8) void lc3_symbols_kernel(lc3_cfg_slot<CV> cfg, int32_t *planes, int n_frames) {
+    typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
+    {
+        const uint32_t *sl = (const uint32_t *)LC3T_AC_SPEC_LOOKUP;
+        uint32_t *dl = (uint32_t *)lc3_spec_tab.lookup;
+        for (int i = (int)threadIdx.x; i < 1024; i += 64 * LC3_WG_WAVES) dl[i] = sl[i];
+    }
+    __syncthreads();
+    const int lane = (int)(threadIdx.x & 63);
+    for (size_t f = (size_t)blockIdx.x * LC3_WG_WAVES + (size_t)LC3_WAVE_ID(); f < (size_t)n_frames; f += (size_t)gridDim.x * LC3_WG_WAVES)
+        lc3_enc_symbols_frame(c0.ne, lane, LC3_UNIFORM_PTR(int32_t *, LC3_PLANE_COL(planes, f, EP_WORDS)));
+}
+
 // Frame parser, one LANE per frame (lc3_dev_dec_parse.h).  blockDim.x frames per workgroup (256, fewer for long frames so that
 // the staging fits 64 KB of dynamic LDS); the context lookup, the packed (cum | freq) spectral model and the frames' bytes are
 // staged in LDS with coalesced loads.
@@ -1337,13 +1354,18 @@ static unsigned lc3_frame_block(unsigned dflt) {
 // ~24 us per 16 384 frames and saves the packer ~40 us whatever the launch size (measured: 2048 x 1 frames 295 -> 264 us,
 // 16 384 x 1 486 -> 469 us, 16 384 x 4 1090 -> 1139 us for the four encoder kernels); LC3GPU_PREP_SYMBOLS=0 / 1 forces it
 // off / on (tests)
-static int lc3_prep_symbols_flag(size_t n_frames_total) {
+// LC3GPU_PREP_SYMBOLS=2: the preparation as a kernel of its own between the back half and the packer (lc3_symbols_kernel; uniform
+// handles), built to measure the third form
+static int lc3_prep_symbols_mode(size_t n_frames_total) {  // 0: the packer derives its symbols, 1: back half, 2: lc3_symbols_kernel
     static const int forced = [] {
         const char *e = std::getenv("LC3GPU_PREP_SYMBOLS");
-        return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
+        return e ? (std::atoi(e) == 2 ? 2 : (std::atoi(e) != 0 ? 1 : 0)) : -1;
     }();
-    const bool on = forced >= 0 ? forced != 0 : n_frames_total <= 16384;
-    return on ? LC3_LAUNCH_PREP_SYMBOLS : 0;
+    return forced >= 0 ? forced : (n_frames_total <= 16384 ? 1 : 0);
+}
+static int lc3_prep_symbols_flag(size_t n_frames_total, bool mixed = false) {
+    const int m = lc3_prep_symbols_mode(n_frames_total);
+    return (m == 1 || (m == 2 && mixed)) ? LC3_LAUNCH_PREP_SYMBOLS : 0;
 }
 // Where the spectrum of a parsed frame is reconstructed (D4-D8).  Three forms, the same arithmetic line by line:
 //   LC3_RECON_LANE  in the parse kernel, by the lane that parsed the frame (lc3_reconstruct_frame): full batches.  One pass over the
@@ -1684,6 +1706,12 @@ static int encode_launch(lc3gpu_encoder *e, const HostCfg &h, int first, int n, 
                        (const float *)e->d_mid, e->d_planes, nbytes, n_frames, dbg, e->spec_flags | lc3_prep_symbols_flag(frames));
     LC3_LAUNCH_CHECK(e, stream, t0);
     e->timer.mark(stream, 2);
+    if (lc3_prep_symbols_mode(frames) == 2) {  // (timed together with the packer)
+        const size_t wgs = (frames + LC3_WG_WAVES - 1) / LC3_WG_WAVES;
+        LC3_LAUNCH_CFG(lc3_symbols_kernel, h, dim3((unsigned)(wgs < lc3_recon_grid() ? wgs : lc3_recon_grid())), dim3(64 * LC3_WG_WAVES), 0, stream,
+                       e->d_planes, (int)frames);
+        LC3_LAUNCH_CHECK(e, stream, t0);
+    }
     const unsigned fpb = lc3_frame_block_fit(LC3_PACK_LDS_FIXED, (size_t)nbytes);
     const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3) + 4;  // + the packer's sink byte
     hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, h.c.ne,
@@ -1754,7 +1782,7 @@ int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out,
     }
     e->timer.mark(stream, 1);
     hipLaunchKernelGGL(lc3_enc_back_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states,
-                       (const float *)e->d_mid, e->d_planes, n_frames, e->spec_flags | lc3_prep_symbols_flag((size_t)e->num_channels * (size_t)n_frames));
+                       (const float *)e->d_mid, e->d_planes, n_frames, e->spec_flags | lc3_prep_symbols_flag((size_t)e->num_channels * (size_t)n_frames, true));
     LC3_LAUNCH_CHECK(e, stream, t0);
     e->timer.mark(stream, 2);
     const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)max_nbytes + 3) & ~(size_t)3) + 4;

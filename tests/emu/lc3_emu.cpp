@@ -203,6 +203,8 @@ void *lane_main(void *arg) {
             cur = nxt;
         }
         if (j->valid) lc3_enc_state_store(j->cfg, L, lane, j->est, nullptr);
+    } else if (j->encode == 4) {  // body of lc3_symbols_kernel: one wave per frame
+        if (j->valid) lc3_enc_symbols_frame(j->cfg.ne, lane, LC3_PLANE_COL(j->enc_planes, j->frame0, EP_WORDS));
     } else if (j->encode == 3) {  // body of lc3_recon_kernel: one wave per frame
         if (j->valid)
             lc3_recon_frame_direct(j->cfg, *j->RT, j->RW[j->wave], lane, LC3_PLANE_COL((int32_t *)j->planes, j->frame0, LC3_PLANE_WORDS), j->nbytes);
@@ -245,6 +247,8 @@ int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16
 int lc3emu_encode_spec(int fs_hz, int frame_us, int nbytes, int S, int T, const int16_t *pcm, uint8_t *bytes, float *dbg, int spec_flags) {
     Job j;
     memset(&j, 0, sizeof(j));
+    const int symbols_stage = (spec_flags & 1024) != 0;  // emulator only: the packer's symbols from lc3_symbols_kernel (LC3GPU_PREP_SYMBOLS=2)
+    spec_flags &= ~1024;
     j.spec_flags = spec_flags;
     lc3_host_plan pl;
     if (lc3_make_config(j.cfg, frame_us, fs_hz) || lc3_make_plan(j.cfg, pl)) return -1;
@@ -306,6 +310,18 @@ int lc3emu_encode_spec(int fs_hz, int frame_us, int nbytes, int S, int T, const 
                 v.spec_flags = spec_flags;
                 lc3_sns_vq_frame(v);
             }
+        }
+    }
+    if (symbols_stage) {
+        for (size_t f0 = 0; f0 < frames; f0 += LC3_WG_WAVES) {
+            Job protos[LC3_WG_WAVES];
+            for (int w = 0; w < LC3_WG_WAVES; w++) {
+                protos[w] = j;
+                protos[w].encode = 4;
+                protos[w].valid = f0 + (size_t)w < frames;
+                protos[w].frame0 = protos[w].valid ? f0 + (size_t)w : frames - 1;
+            }
+            run_wg(protos);
         }
     }
     free(L);

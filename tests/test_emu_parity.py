@@ -147,6 +147,9 @@ def test_emu_guarded_decisions_and_their_sequential_path(fs, us, nf, nbytes):
     # 512 (LC3_LAUNCH_PREP_SYMBOLS, what the host sets for launches that do not fill the chip): the analysis kernel prepares the
     # packer's symbol words, the packer only runs the range coder over them
     assert np.array_equal(E.encode(pcm, nbytes, fs, us, spec_flags=512), ref)
+    # 1024 (emulator only): the same symbol words from the wave-per-frame stage between back half and packer (lc3_symbols_kernel,
+    # LC3GPU_PREP_SYMBOLS=2 on the GPU)
+    assert np.array_equal(E.encode(pcm, nbytes, fs, us, spec_flags=1024), ref)
 
 
 @pytest.mark.parametrize("late", [1, 2])

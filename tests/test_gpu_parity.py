@@ -659,8 +659,9 @@ def test_sequential_sum_path_of_guarded_decisions():
 
 def test_prepared_packer_symbols_on_and_off():
     """Launches of at most 16 384 frames have the analysis kernel prepare the packer's symbol words (lc3_enc_symbols), larger ones
-    leave the derivation to the packer.  Both forms on the same launches, small and large (LC3GPU_PREP_SYMBOLS=0 / 1 overrides the
-    size rule), against the oracle."""
+    leave the derivation to the packer; the third form, the preparation as a wave-per-frame kernel of its own between back half and
+    packer (lc3_symbols_kernel, LC3GPU_PREP_SYMBOLS=2), is selectable.  All three forms on the same launches, small and large
+    (LC3GPU_PREP_SYMBOLS=0 / 1 / 2 overrides the size rule), against the oracle."""
     import os
     import subprocess
     import sys
@@ -679,7 +680,7 @@ def test_prepared_packer_symbols_on_and_off():
         "print('prep ok')\n"
     )
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for v in ("0", "1"):
+    for v in ("0", "1", "2"):
         env = dict(os.environ, LC3GPU_PREP_SYMBOLS=v)
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "prep ok" in r.stdout, v + r.stdout[-2000:] + r.stderr[-2000:]
