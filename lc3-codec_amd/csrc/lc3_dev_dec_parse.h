@@ -246,7 +246,13 @@ __device__ __forceinline__ void lc3_p_bool2_sel(lc3_parse_ctx &c, int w0, int w1
     c.tcur = wrap ? c.tnext : c.tcur;
     c.tnext = lc3_p_tail_byte(c, (c.tail >> 3) + 1);  // consumed at the next wrap, not here
 }
-// the two renormalisation steps of ac_decode (:88-95) from the head bytes held in registers
+// the two renormalisation steps of ac_decode (:88-95) from the head bytes held in registers; REFILL = 0 leaves the request for the
+// next two head bytes to the caller (lc3_p_head_refill)
+__device__ __forceinline__ void lc3_p_head_refill(lc3_parse_ctx &c) {
+    c.hb0 = lc3_p_head_byte(c, c.head);
+    c.hb1 = lc3_p_head_byte(c, c.head + 1);
+}
+template <int REFILL = 1>
 __device__ __forceinline__ void lc3_p_ac_renorm_sel(lc3_parse_ctx &c, lc3_acdec &st, int &err) {
     const int need0 = st.range < 0x10000u;
     err |= need0 & (c.head >= c.len);  // read_head_byte :42-50
@@ -259,8 +265,7 @@ __device__ __forceinline__ void lc3_p_ac_renorm_sel(lc3_parse_ctx &c, lc3_acdec 
         st.range <<= 8;
         c.head += 1;
     }
-    c.hb0 = lc3_p_head_byte(c, c.head);
-    c.hb1 = lc3_p_head_byte(c, c.head + 1);
+    if (REFILL) lc3_p_head_refill(c);
 }
 // ac_decode (decoder/arithmetic_codec.rs:67-97) over a packed (cum | freq << 16) model row with symbols 0..HI: the
 // reference scans from the top for the largest j with low >= tmp * cum[j] (:81-84; cum is non-decreasing, cum[0] = 0),
@@ -311,7 +316,7 @@ __device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_ac
     const int lo = ge16 ? 16 : 4 * g + n;
     st.low -= LC3_MUL24(tmp, sv & 0xffffu);
     st.range = LC3_MUL24(tmp, sv >> 16);
-    lc3_p_ac_renorm_sel(c, st, err);
+    lc3_p_ac_renorm_sel<0>(c, st, err);  // the caller requests the next head bytes (after it has consumed its tail bits)
     return lo;
 }
 
@@ -392,6 +397,9 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
         while (tup < ntup) {
             const int t = cctx + rate_flag + ((tup * 2) > (ne / 2) ? 256 : 0);
             const int lv = lev < 3 ? lev : 3;
+            // (LDS returns in order and a use of a prefetched byte waits for everything in flight: the two head bytes and the tail byte
+            // the next iteration may need are requested together at the end of this one, behind its last use of such a byte -- the next
+            // symbol's context read, which has to be waited for anyway, then covers them)
             if (lev < 14) sym = lc3_p_ac_decode_spec_sel(c, st, c.cf + (int)c.lookup[t + lv * 1024] * LC3_DCF_ROW_WORDS, err);
             const int esc = sym >= 16 && lev < 14;
             const int a = sym & 3, b = sym >> 2;
@@ -401,6 +409,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             const int want_e = !lsb_mode || lev > 0;
             int bit0, bit1;
             lc3_p_bool2_sel(c, esc ? want_e : m0 > 0, esc ? want_e : m1 > 0, err, bit0, bit1);
+            lc3_p_head_refill(c);
             const int32_t v0 = bit0 ? -m0 : m0, v1 = bit1 ? -m1 : m1;
             // (an escape step stores its partial values too: the pair's main step overwrites them)
             {   // the pair as one 64-bit store (8-byte aligned: the column, LC3_PLANE_X and 2 * tup are even numbers of words)
@@ -415,7 +424,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
                 c.nnz += esc ? 0u : (uint32_t)(m0 != 0) + (uint32_t)(m1 != 0);
                 c.seed += esc ? 0u : (uint32_t)m0 * (uint32_t)(2 * tup) + (uint32_t)m1 * (uint32_t)(2 * tup + 1);
             }
-            cctx = esc ? cctx : (cctx & 15) * 16 + (lv <= 1 ? 1 + (a + b) * (lv + 1) : 12 + lv);
+            cctx = esc ? cctx : (cctx & 15) * 16 + (lv <= 1 ? 1 + ((a + b) << lv) : 12 + lv);  // (a + b) * (lv + 1) for lv = 0, 1
             xk = esc ? xk + (int32_t)((uint32_t)bit0 << lev) : 0;
             xk1 = esc ? xk1 + (int32_t)((uint32_t)bit1 << lev) : 0;
             tup += !esc;

@@ -1289,7 +1289,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
             const int n_esc = m >= 4 ? (32 - __builtin_clz(m)) - 2 : 0;
             const unsigned af = a >> n_esc, bf = b >> n_esc;
             const int lev = n_esc < 3 ? n_esc : 3;
-            tt[j] = lev <= 1 ? 1 + (int)(af + bf) * (lev + 1) : 12 + lev;
+            tt[j] = lev <= 1 ? 1 + (int)((af + bf) << lev) : 12 + lev;  // (a + b) * (lev + 1) for lev = 0, 1
             const int nz = (q0 | q1) != 0;
             hi_nz = nz ? k0 + j : hi_nz;
             loc[j] = af | (bf << 8) | ((uint32_t)n_esc << 16) | ((uint32_t)nz << 24) | ((uint32_t)(a == 1) << 25) |
@@ -1673,7 +1673,7 @@ __device__ __forceinline__ void lc3_enc_symbols_core(int ne, int lane, const int
         const unsigned m = a > b ? a : b;
         const int n_esc = m >= 4 ? (32 - __builtin_clz(m)) - 2 : 0;
         const int lev = n_esc < 3 ? n_esc : 3;
-        tt[j] = lev <= 1 ? 1 + (int)((a >> n_esc) + (b >> n_esc)) * (lev + 1) : 12 + lev;
+        tt[j] = lev <= 1 ? 1 + (int)(((a >> n_esc) + (b >> n_esc)) << lev) : 12 + lev;
         a4[j] = a;
         b4[j] = b;
         ne4[j] = live ? n_esc : -1;  // -1: not coded

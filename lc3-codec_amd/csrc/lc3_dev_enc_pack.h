@@ -75,6 +75,28 @@ __device__ __forceinline__ void lc3_pk_bool_backward_sel(lc3_pack_ctx &w, int wa
     if (wrap & (w.bp > w.bp_side)) w.side_acc = w.bp_side >= 0 ? (uint32_t)w.buf[w.bp_side] : 0u;  // rare: the writers crossed
 }
 __device__ __forceinline__ void lc3_pk_bool_backward(lc3_pack_ctx &w, int bit) { lc3_pk_bool_backward_sel(w, 1, bit); }
+// Two consecutive write_bool_backward (:27-40), each when its `want`: the bits form one field (the first written one lowest) that is
+// placed with a single multiplication by the mask; the mirrored byte is written through once.  At most one of the two bits can
+// complete the byte; when it is the first one (mask 0x80, both wanted) the second bit opens the byte the writer moves on to.
+__device__ __forceinline__ void lc3_pk_bool2_backward_sel(lc3_pack_ctx &w, int want0, int bit0, int want1, int bit1) {
+    const uint32_t m = (uint32_t)w.mask_side;                           // 1 .. 0x80
+    const uint32_t fm = (uint32_t)want0 + (uint32_t)want1 + (uint32_t)(want0 & want1);  // field of 0, 1 or 2 bits: 0, 1, 3
+    const uint32_t v = want0 ? ((uint32_t)bit0 | ((uint32_t)bit1 << 1)) : (uint32_t)bit1;
+    const uint32_t field = LC3_MUL24(fm, m), val = LC3_MUL24(v & fm, m);  // up to bit 8
+    const uint32_t acc = (w.side_acc & ~field) | val;
+    const int wrap = (int)((field >> 7) & 1u), spill = (int)(field >> 8);  // a bit landed on mask 0x80 / one bit lies beyond it
+    const int at = w.bp_side;
+    w.bp_side -= wrap;
+    w.mask_side = wrap ? 1 + spill : (int)(m * (fm + 1u));              // m << number of bits (fm + 1 = 1, 2, 4)
+    uint32_t next = 0u;                                                 // the byte the writer moves on to: zero ...
+    // ... unless the writers crossed (rare).  The read comes BEFORE this call's stores: what follows a conditional LDS read waits for
+    // every LDS operation in flight, and a store issued just before it would cost a full round trip on every call.
+    if (wrap & (w.bp > w.bp_side)) next = w.bp_side >= 0 ? (uint32_t)w.buf[w.bp_side] : 0u;
+    next = spill ? ((next & ~1u) | (acc >> 8)) : next;
+    *(at >= 0 ? w.buf + at : w.sink) = (uint8_t)acc;                    // (without a wanted bit this rewrites the byte with its own value)
+    *((spill && w.bp_side >= 0) ? w.buf + w.bp_side : w.sink) = (uint8_t)next;
+    w.side_acc = wrap ? next : acc;
+}
 // write_uint_backward (:19-25): nbits (<= 32) bits of val, least significant first -- the reference's bit-by-bit loop done a
 // byte at a time: the bits that land in the mirrored byte replace its field (set or cleared, as write_bool_backward does),
 // the byte is written through, and a completed byte moves the cursor on.
@@ -292,8 +314,7 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
             if (i < n) {
                 lc3_pk_ac_encode_sel(w, s0 & 0x3ffu, (s0 >> 10) & 0x3ffu);
                 const int nb = (int)((s0 >> 20) & 3u);
-                lc3_pk_bool_backward_sel(w, nb > 0, (int)((s0 >> 22) & 1u));
-                lc3_pk_bool_backward_sel(w, nb > 1, (int)((s0 >> 23) & 1u));
+                lc3_pk_bool2_backward_sel(w, nb > 0, (int)((s0 >> 22) & 1u), nb > 1, (int)((s0 >> 23) & 1u));
             }
             s0 = s1;
             s1 = s2;
@@ -320,7 +341,7 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
             // `cur`: an escape symbol (and two LSBs), or the pair's main symbol (and its signs).  Where the lane will be
             // after it, and that symbol's model row:
             const int adv = !cur.esc;
-            const int n_cctx = adv ? (cctx & 15) * 16 + (cur.lv <= 1 ? 1 + (int)(cur.a + cur.b) * (cur.lv + 1) : 12 + cur.lv) : cctx;
+            const int n_cctx = adv ? (cctx & 15) * 16 + (cur.lv <= 1 ? 1 + (int)((cur.a + cur.b) << cur.lv) : 12 + cur.lv) : cctx;
             const int n_lev = adv ? 0 : lev + 1, n_tup = tup + adv;
             const uint32_t n_xw = adv ? x1 : xw;
             const lc3_pk_sym nxt = lc3_pk_symbol(n_xw, n_lev, n_cctx, n_tup, rate_flag, ne);
@@ -330,8 +351,8 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
             const int lsb_here = lsb_mode && lev > 0;
             const unsigned a_l = lsb_here ? cur.a0 >> 1 : cur.a0, b_l = lsb_here ? cur.b0 >> 1 : cur.b0;
             const int want_e = !(lsb_mode && lev == 0);
-            lc3_pk_bool_backward_sel(w, cur.esc ? want_e : a_l > 0u, cur.esc ? (cur.a & 1u) == 1u : cur.q0 <= 0);
-            lc3_pk_bool_backward_sel(w, cur.esc ? want_e : b_l > 0u, cur.esc ? (cur.b & 1u) == 1u : cur.q1 <= 0);
+            lc3_pk_bool2_backward_sel(w, cur.esc ? want_e : a_l > 0u, cur.esc ? (cur.a & 1u) == 1u : cur.q0 <= 0,
+                                      cur.esc ? want_e : b_l > 0u, cur.esc ? (cur.b & 1u) == 1u : cur.q1 <= 0);
             // the LSB list itself is regenerated below when it is written
             nlsbs += (!cur.esc && lsb_here) ? 2 + (a_l == 0u && cur.q0 != 0) + (b_l == 0u && cur.q1 != 0) : 0;
             sv = w.cf[rown * 17 + (nxt.esc ? 16 : (int)(nxt.a + 4u * nxt.b))];
