@@ -87,7 +87,8 @@ __device__ __forceinline__ void lc3_pk_bool2_backward_sel(lc3_pack_ctx &w, int w
     const int wrap = (int)((field >> 7) & 1u), spill = (int)(field >> 8);  // a bit landed on mask 0x80 / one bit lies beyond it
     const int at = w.bp_side;
     w.bp_side -= wrap;
-    w.mask_side = wrap ? 1 + spill : (int)(m * (fm + 1u));              // m << number of bits (fm + 1 = 1, 2, 4)
+    const int moved = (int)(m << (want0 + want1));                      // (a plain shift: as a product this came out as a 64-bit multiply-add in a branch)
+    w.mask_side = wrap ? 1 + spill : moved;
     uint32_t next = 0u;                                                 // the byte the writer moves on to: zero ...
     // ... unless the writers crossed (rare).  The read comes BEFORE this call's stores: what follows a conditional LDS read waits for
     // every LDS operation in flight, and a store issued just before it would cost a full round trip on every call.
