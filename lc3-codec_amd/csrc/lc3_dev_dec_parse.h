@@ -299,10 +299,10 @@ __device__ __forceinline__ uint32_t lc3_dcf_word(int i) {
     const int j = w < 17 ? w : 4 * (w - 16);
     return (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[p][j] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[p][j] << 16);
 }
-__device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_acdec &st, const uint32_t *row, int &err) {
+// pv: words 16..19 of the row (symbols 16, 4, 8, 12), fetched by the caller one symbol ahead
+__device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_acdec &st, const uint32_t *row, const lc3_i4 pv, int &err) {
     const uint32_t tmp = st.range >> 10, limit = tmp << 10;
     err |= st.low >= limit;
-    const lc3_i4 pv = ((const lc3_i4 *)row)[4];  // symbols 16, 4, 8, 12
     const int ge16 = st.low >= LC3_MUL24(tmp, (uint32_t)pv[0] & 0xffffu);
     const int g = (int)(st.low >= LC3_MUL24(tmp, (uint32_t)pv[1] & 0xffffu)) + (int)(st.low >= LC3_MUL24(tmp, (uint32_t)pv[2] & 0xffffu)) +
                   (int)(st.low >= LC3_MUL24(tmp, (uint32_t)pv[3] & 0xffffu));
@@ -392,24 +392,32 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
         // to max over lanes of (sum over pairs of 1 + level), 1.45x fewer on the benchmark's frames.
         // Reference loop per pair: `while lev < 14 { decode; if sym < 16 break; [two LSBs]; lev += 1 }` -- a pair that reaches
         // level 14 ends without another symbol and keeps the escape symbol (16).
+        // The model row of a symbol follows from the symbol before it (context) through two dependent LDS reads (context -> row index,
+        // row -> its words 16..19) and a third one picks the group of four: the first two are made one symbol AHEAD, as soon as the
+        // current symbol is known, and land while the lane consumes the tail bits and stores the pair -- one exposed LDS round trip
+        // per symbol instead of three.
         int cctx = 0, err = 0, tup = 0, lev = 0;
         int32_t xk = 0, xk1 = 0;
+        const int hi_from = ne / 2;  // pairs with 2 * tup > ne / 2 use the upper half of the contexts
+        const uint32_t *row = c.cf + (int)c.lookup[rate_flag + (0 > hi_from ? 256 : 0)] * LC3_DCF_ROW_WORDS;
+        lc3_i4 pv = ((const lc3_i4 *)row)[4];
         while (tup < ntup) {
-            const int t = cctx + rate_flag + ((tup * 2) > (ne / 2) ? 256 : 0);
-            const int lv = lev < 3 ? lev : 3;
-            // (LDS returns in order and a use of a prefetched byte waits for everything in flight: the two head bytes and the tail byte
-            // the next iteration may need are requested together at the end of this one, behind its last use of such a byte -- the next
-            // symbol's context read, which has to be waited for anyway, then covers them)
-            if (lev < 14) sym = lc3_p_ac_decode_spec_sel(c, st, c.cf + (int)c.lookup[t + lv * 1024] * LC3_DCF_ROW_WORDS, err);
+            if (lev < 14) sym = lc3_p_ac_decode_spec_sel(c, st, row, pv, err);
             const int esc = sym >= 16 && lev < 14;
             const int a = sym & 3, b = sym >> 2;
+            const int lv = lev < 3 ? lev : 3;
             const int32_t m0 = xk + (int32_t)((uint32_t)a << lev), m1 = xk1 + (int32_t)((uint32_t)b << lev);  // if this is the main symbol
             // two tail bits: after an escape symbol the pair's next bit plane (when it is transmitted), after the main symbol
             // the signs of the non-zero values
             const int want_e = !lsb_mode || lev > 0;
             int bit0, bit1;
             lc3_p_bool2_sel(c, esc ? want_e : m0 > 0, esc ? want_e : m1 > 0, err, bit0, bit1);
-            lc3_p_head_refill(c);
+            // where the lane goes next, and that symbol's row index (requested behind the last use of a prefetched byte: LDS returns
+            // in order, and such a use waits for everything in flight)
+            const int n_cctx = esc ? cctx : (cctx & 15) * 16 + (lv <= 1 ? 1 + ((a + b) << lv) : 12 + lv);  // (a + b) * (lv + 1) for lv = 0, 1
+            const int n_tup = tup + !esc, n_lev = esc ? lev + 1 : 0;
+            const int n_lv = n_lev < 3 ? n_lev : 3;
+            const int n_row = (int)c.lookup[n_cctx + rate_flag + ((n_tup * 2) > hi_from ? 256 : 0) + n_lv * 1024];
             const int32_t v0 = bit0 ? -m0 : m0, v1 = bit1 ? -m1 : m1;
             // (an escape step stores its partial values too: the pair's main step overwrites them)
             {   // the pair as one 64-bit store (8-byte aligned: the column, LC3_PLANE_X and 2 * tup are even numbers of words)
@@ -420,15 +428,19 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             }
             if (lsb_mode && !esc) lc3_px_set(c, LC3_PLANE_LEV + tup, lev);  // written by TUPLE index, read by LINE index (:184-195)
             lev_end = (!esc && lev > 0) ? tup + 1 : lev_end;
+            row = c.cf + n_row * LC3_DCF_ROW_WORDS;
+            pv = ((const lc3_i4 *)row)[4];
+            lc3_p_head_refill(c);
+            asm volatile("" ::: "memory");  // (keeps the three requests HERE: left alone, the row read sinks into the next iteration's `lev < 14` block)
             if (COUNT) {
                 c.nnz += esc ? 0u : (uint32_t)(m0 != 0) + (uint32_t)(m1 != 0);
                 c.seed += esc ? 0u : (uint32_t)m0 * (uint32_t)(2 * tup) + (uint32_t)m1 * (uint32_t)(2 * tup + 1);
             }
-            cctx = esc ? cctx : (cctx & 15) * 16 + (lv <= 1 ? 1 + ((a + b) << lv) : 12 + lv);  // (a + b) * (lv + 1) for lv = 0, 1
+            cctx = n_cctx;
             xk = esc ? xk + (int32_t)((uint32_t)bit0 << lev) : 0;
             xk1 = esc ? xk1 + (int32_t)((uint32_t)bit1 << lev) : 0;
-            tup += !esc;
-            lev = esc ? lev + 1 : 0;
+            tup = n_tup;
+            lev = n_lev;
         }
         if (err) return -4;
     }
