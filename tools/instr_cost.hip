@@ -1,0 +1,168 @@
+// What single instructions and short idioms cost a wave of the lane-per-frame kernels (one wave per SIMD) and of the wave-per-stream
+// kernels (four): shader-clock cycles per instruction, measured as 2000 rounds of an unrolled block between two s_memtime stamps.
+// The lane-per-frame kernels are issue-bound (filler instructions cost their full time), so their time is the sum
+// of these numbers -- this table says which idiom to write.
+// Stand-alone: hipcc --offload-arch=gfx950 -O3 -o instr_cost tools/instr_cost.hip && ./instr_cost > profiles/r03_instr_cost.json
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(e)                                                                      \
+    do {                                                                              \
+        hipError_t r_ = (e);                                                          \
+        if (r_ != hipSuccess) {                                                       \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(r_)); \
+            exit(1);                                                                  \
+        }                                                                             \
+    } while (0)
+
+#define REP8(x) x x x x x x x x
+#define OPERANDS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "v"(lds) : "vcc", "s20", "s21", "s22", "s23", "memory"
+// eight copies of an idiom on eight independent registers, eight times: 64 idioms per block
+#define BLOCK(S0, S1, S2, S3, S4, S5, S6, S7) REP8(asm volatile(S0 S1 S2 S3 S4 S5 S6 S7 OPERANDS);)
+#define EACH(OP) BLOCK(OP(0), OP(1), OP(2), OP(3), OP(4), OP(5), OP(6), OP(7))
+
+#define KERNEL(NAME, PRE, BODY)                                                                             \
+    __global__ void NAME(unsigned long long *cycles, unsigned *sink, int iters) {                           \
+        __shared__ unsigned lds_buf[1024];                                                                  \
+        lds_buf[threadIdx.x & 1023] = threadIdx.x;                                                          \
+        unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        const unsigned k = 37u, lds = (threadIdx.x & 63) * 4;  /* one bank per lane */                                             \
+        __syncthreads();                                                                                    \
+        PRE;                                                                                                \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
+        for (int i = 0; i < iters; i++) { BODY }                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 0" ::: "memory");                                        \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
+        if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0; \
+        if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + lds_buf[5] == 12345678u) sink[0] = a0;                  \
+    }
+#define NOPRE ((void)0)
+#define SETMASKS asm volatile("s_mov_b64 vcc, 0x5555\n s_mov_b64 s[20:21], 0x3333\n s_mov_b64 s[22:23], 0x0f0f" ::: "vcc", "s20", "s21", "s22", "s23")
+
+// ---- selects and compares
+#define I_CND_VCC(i) "v_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n"
+#define I_CND_E64_VCC(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\n"
+#define I_CND_E64_S(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[20:21]\n"
+#define I_CMP_VCC(i) "v_cmp_lt_u32_e32 vcc, %" #i ", %8\n"
+#define I_CMP_S(i) "v_cmp_lt_u32_e64 s[20:21], %" #i ", %8\n"
+#define I_SEL_VCC(i) "v_cmp_lt_u32_e32 vcc, %8, %" #i "\n v_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n"
+#define I_SEL_S(i) "v_cmp_lt_u32_e64 s[20:21], %8, %" #i "\n s_nop 1\n v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[20:21]\n"
+#define I_SEL_S2(i) "v_cmp_lt_u32_e64 s[20:21], %8, %" #i "\n v_cmp_lt_u32_e64 s[22:23], %" #i ", %8\n v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[20:21]\n"
+#define I_SEL_ARITH(i) "v_sub_u32 %" #i ", %" #i ", %8\n v_ashrrev_i32 %" #i ", 31, %" #i "\n v_bfi_b32 %" #i ", %" #i ", %8, %9\n"
+#define I_SEL_MINMAX(i) "v_min_u32 %" #i ", %" #i ", %8\n"
+KERNEL(k_cnd_vcc, SETMASKS, EACH(I_CND_VCC))
+KERNEL(k_cnd_e64_vcc, SETMASKS, EACH(I_CND_E64_VCC))
+KERNEL(k_cnd_e64_s, SETMASKS, EACH(I_CND_E64_S))
+KERNEL(k_cmp_vcc, NOPRE, EACH(I_CMP_VCC))
+KERNEL(k_cmp_s, NOPRE, EACH(I_CMP_S))
+KERNEL(k_sel_vcc, NOPRE, EACH(I_SEL_VCC))
+KERNEL(k_sel_s, NOPRE, EACH(I_SEL_S))
+KERNEL(k_sel_s2, NOPRE, EACH(I_SEL_S2))
+KERNEL(k_sel_arith, NOPRE, EACH(I_SEL_ARITH))
+KERNEL(k_min, NOPRE, EACH(I_SEL_MINMAX))
+// ---- plain integer operations
+#define I_ADD(i) "v_add_u32 %" #i ", %" #i ", %8\n"
+#define I_ADD3(i) "v_add3_u32 %" #i ", %" #i ", %8, %9\n"
+#define I_LSHLADD(i) "v_lshl_add_u32 %" #i ", %" #i ", 2, %8\n"
+#define I_BFI(i) "v_bfi_b32 %" #i ", %" #i ", %8, %9\n"
+#define I_BFE(i) "v_bfe_i32 %" #i ", %" #i ", 3, 1\n"
+#define I_ASHR(i) "v_ashrrev_i32 %" #i ", 31, %" #i "\n"
+#define I_ANDOR(i) "v_and_or_b32 %" #i ", %" #i ", %8, %9\n"
+#define I_MAD24(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %9\n"
+#define I_MUL24_SDWA(i) "v_mul_u32_u24_sdwa %" #i ", %" #i ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n"
+#define I_ADDC(i) "v_addc_co_u32_e64 %" #i ", s[22:23], %" #i ", %8, s[20:21]\n"
+#define I_MOV(i) "v_mov_b32 %" #i ", %8\n"
+KERNEL(k_add, NOPRE, EACH(I_ADD))
+KERNEL(k_add3, NOPRE, EACH(I_ADD3))
+KERNEL(k_lshladd, NOPRE, EACH(I_LSHLADD))
+KERNEL(k_bfi, NOPRE, EACH(I_BFI))
+KERNEL(k_bfe, NOPRE, EACH(I_BFE))
+KERNEL(k_ashr, NOPRE, EACH(I_ASHR))
+KERNEL(k_andor, NOPRE, EACH(I_ANDOR))
+KERNEL(k_mad24, NOPRE, EACH(I_MAD24))
+KERNEL(k_mul24_sdwa, NOPRE, EACH(I_MUL24_SDWA))
+KERNEL(k_addc, SETMASKS, EACH(I_ADDC))
+KERNEL(k_mov, NOPRE, EACH(I_MOV))
+// ---- scalar side: mask logic, a not-taken branch, an exec-masked region, wait states
+#define I_SNOP(i) "s_nop 1\n"
+KERNEL(k_snop, NOPRE, EACH(I_SNOP))
+// eight v_add each followed by a branch that is never taken (exec is never zero)
+#define I_ADD_BR(i) "v_add_u32 %" #i ", %" #i ", %8\n s_cbranch_execz 1f\n1:\n"
+KERNEL(k_add_branch, NOPRE, EACH(I_ADD_BR))
+// ---- LDS: eight reads in flight then one wait (throughput), a read waited for at once (round trip), byte stores
+#define I_DSR32(i) "ds_read_b32 %" #i ", %9\n"
+#define I_DSR128W(i) "ds_read_b32 %" #i ", %9\n s_waitcnt lgkmcnt(0)\n"
+#define I_DSW8(i) "ds_write_b8 %9, %" #i "\n"
+KERNEL(k_dsr32, NOPRE, BLOCK(I_DSR32(0), I_DSR32(1), I_DSR32(2), I_DSR32(3), I_DSR32(4), I_DSR32(5), I_DSR32(6), I_DSR32(7) "s_waitcnt lgkmcnt(0)\n"))
+KERNEL(k_dsr32_wait, NOPRE, EACH(I_DSR128W))
+KERNEL(k_dsw8, NOPRE, EACH(I_DSW8))
+// a dependent LDS read: the address is the value just read (round-trip latency of a pointer chase)
+#define I_DSCHASE(i) "ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0xffc, %0\n"
+KERNEL(k_dschase, a0 = lds, EACH(I_DSCHASE))
+
+typedef void (*kern_t)(unsigned long long *, unsigned *, int);
+struct Case { const char *name; kern_t k; int instrs_per_idiom; const char *what; };
+
+int main() {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount, iters = 2000;
+    unsigned long long *d_cycles;
+    unsigned *d_sink;
+    CHECK(hipMalloc(&d_cycles, sizeof(unsigned long long) * (size_t)cus * 32));
+    CHECK(hipMalloc(&d_sink, 64));
+    const Case cases[] = {
+        {"v_cndmask_b32_e32 (vcc)", k_cnd_vcc, 1, "select on vcc, VOP2 encoding"},
+        {"v_cndmask_b32_e64 (vcc)", k_cnd_e64_vcc, 1, "select on vcc, VOP3 encoding"},
+        {"v_cndmask_b32_e64 (s[20:21])", k_cnd_e64_s, 1, "select on an SGPR pair"},
+        {"v_cmp_lt_u32_e32 -> vcc", k_cmp_vcc, 1, "compare writing vcc"},
+        {"v_cmp_lt_u32_e64 -> s[20:21]", k_cmp_s, 1, "compare writing an SGPR pair"},
+        {"v_cmp_e32 + v_cndmask_e32 through vcc", k_sel_vcc, 2, "a select: two instructions"},
+        {"v_cmp_e64 + s_nop 1 + v_cndmask_e64 through s[20:21]", k_sel_s, 3, "a select as the compiler emits it: three instructions"},
+        {"v_cmp_e64 + v_cmp_e64 + v_cndmask_e64", k_sel_s2, 3, "a select with another compare in the wait-state slot"},
+        {"v_sub + v_ashrrev 31 + v_bfi", k_sel_arith, 3, "a select without a mask register: three instructions"},
+        {"v_min_u32", k_min, 1, ""},
+        {"v_add_u32", k_add, 1, ""}, {"v_add3_u32", k_add3, 1, ""}, {"v_lshl_add_u32", k_lshladd, 1, ""}, {"v_bfi_b32", k_bfi, 1, ""},
+        {"v_bfe_i32", k_bfe, 1, ""}, {"v_ashrrev_i32", k_ashr, 1, ""}, {"v_and_or_b32", k_andor, 1, ""}, {"v_mad_u32_u24", k_mad24, 1, ""},
+        {"v_mul_u32_u24_sdwa", k_mul24_sdwa, 1, ""}, {"v_addc_co_u32_e64", k_addc, 1, ""}, {"v_mov_b32", k_mov, 1, ""},
+        {"s_nop 1", k_snop, 1, ""},
+        {"v_add_u32 + s_cbranch_execz (not taken)", k_add_branch, 2, ""},
+        {"ds_read_b32 x8 then one wait", k_dsr32, 8, "eight reads in flight; per read"},
+        {"ds_read_b32 + s_waitcnt", k_dsr32_wait, 1, "round trip of one read"},
+        {"ds_write_b8", k_dsw8, 1, ""},
+        {"ds_read_b32 pointer chase", k_dschase, 1, "read, wait, mask: dependent round trip"},
+    };
+    printf("{\n  \"device\": \"%s\", \"gcn_arch\": \"%s\", \"compute_units\": %d,\n", prop.name, prop.gcnArchName, cus);
+    printf("  \"method\": \"one workgroup of 4W waves per CU; %d rounds of 64 idioms on eight independent registers between two s_memtime stamps; cycles per idiom = cycles of the slowest wave / (W x idioms)\",\n", iters);
+    printf("  \"idioms\": [\n");
+    bool first = true;
+    for (const Case &c : cases) {
+        double per[2] = {0, 0};
+        int wi = 0;
+        for (int W : {1, 4}) {
+            const int threads = 64 * 4 * W;
+            const int grid = cus, waves = grid * (threads / 64);
+            for (int rep = 0; rep < 3; rep++) {
+                hipLaunchKernelGGL(c.k, dim3(grid), dim3(threads), 0, nullptr, d_cycles, d_sink, iters);
+                CHECK(hipGetLastError());
+                CHECK(hipDeviceSynchronize());
+            }
+            std::vector<unsigned long long> h((size_t)waves);
+            CHECK(hipMemcpy(h.data(), d_cycles, sizeof(unsigned long long) * (size_t)waves, hipMemcpyDeviceToHost));
+            std::sort(h.begin(), h.end());
+            const double idioms = 64.0 * iters;
+            per[wi++] = (double)h.back() / (W * idioms);
+        }
+        const double n = 1.0;
+        printf("%s    {\"idiom\": \"%s\", \"instructions\": %d, \"cycles_lone_wave\": %.2f, \"cycles_per_wave_at_4_per_simd\": %.2f, \"note\": \"%s\"}",
+               first ? "" : ",\n", c.name, c.instrs_per_idiom, per[0] / n, per[1] / n, c.what);
+        first = false;
+    }
+    printf("\n  ]\n}\n");
+    return 0;
+}
