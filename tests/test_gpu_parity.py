@@ -373,6 +373,54 @@ def test_channel_ranges_on_separate_hip_streams():
     assert np.array_equal(out_p, ref_p)
 
 
+def test_pipelined_half_batches_on_four_hip_streams():
+    """The stream arrangement INTEGRATION.md recommends for throughput (bench.py's `overlapped.pipelined_halves`): the batch as two
+    handle pairs, each with its encoder on one HIP stream and its decoder on another, the decoder of step k under the encoder of
+    step k + 1 (two byte buffers taking turns, events between producer and consumer), state carried over the steps.  Nothing is
+    waited for on the host until the end; every frame of every step against the oracle's streaming run."""
+    t = torch_mod()
+    S, T, K, nf, nb = 2048, 4, 6, 480, 150
+    pcm = synth.make_pcm(S, T * K, nf, 48000, seed=29)
+    ref_b = O.encode_batch(pcm, nb)
+    ref_p = O.decode_batch(ref_b, nf)
+    H = S // 2
+    d_pcm = t.from_numpy(pcm).cuda()
+    encs = [pkg.Lc3Encoder(H, 10000, 48000) for _ in range(2)]
+    decs = [pkg.Lc3Decoder(H, 10000, 48000) for _ in range(2)]
+    es = [t.cuda.Stream() for _ in range(2)]
+    ds = [t.cuda.Stream() for _ in range(2)]
+    bufs = [t.zeros((S, T, nb), dtype=t.uint8, device="cuda") for _ in range(2)]
+    keep_b = t.zeros((K, S, T, nb), dtype=t.uint8, device="cuda")  # a copy of every step's bytes, made on the decoder's stream
+    out_p = t.zeros((K, S, T, nf), dtype=t.int16, device="cuda")
+    enc_done = [[t.cuda.Event() for _ in range(2)] for _ in range(2)]
+    dec_done = [[t.cuda.Event() for _ in range(2)] for _ in range(2)]
+    t.cuda.synchronize()
+    for k in range(K):
+        b = k & 1
+        step_pcm = d_pcm[:, k * T:(k + 1) * T].contiguous()  # (made on the current stream)
+        ready = t.cuda.Event()
+        ready.record()
+        for p in range(2):
+            lo, hi = p * H, (p + 1) * H
+            es[p].wait_event(ready)
+            if k >= 2:
+                es[p].wait_event(dec_done[b][p])  # the buffer's previous reader
+            encs[p].encode(step_pcm[lo:hi], bufs[b][lo:hi], nb, T, stream=es[p].cuda_stream)
+            enc_done[b][p].record(es[p])
+            ds[p].wait_event(enc_done[b][p])
+            decs[p].decode(bufs[b][lo:hi], out_p[k, lo:hi], nb, T, stream=ds[p].cuda_stream)
+            with t.cuda.stream(ds[p]):
+                keep_b[k, lo:hi].copy_(bufs[b][lo:hi], non_blocking=True)
+            dec_done[b][p].record(ds[p])
+        step_pcm.record_stream(es[0])
+        step_pcm.record_stream(es[1])
+    t.cuda.synchronize()
+    got_b = keep_b.cpu().numpy().transpose(1, 0, 2, 3).reshape(S, K * T, nb)
+    got_p = out_p.cpu().numpy().transpose(1, 0, 2, 3).reshape(S, K * T, nf)
+    assert np.array_equal(got_b, ref_b)
+    assert np.array_equal(got_p, ref_p)
+
+
 MIXED = [  # BASELINE config 4: (fs, frame_us, bytes per frame); 8 kHz is decode-only (no reference encoder)
     (16000, 10000, 40), (24000, 10000, 60), (32000, 10000, 80), (44100, 10000, 110), (48000, 10000, 150),
     (16000, 7500, 30), (24000, 7500, 45), (32000, 7500, 60), (44100, 7500, 83), (48000, 7500, 113),
