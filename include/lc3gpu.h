@@ -209,8 +209,10 @@ int lc3gpu_selftest_math(int which, const float *x, const float *d, int n, float
  * kernels: analysis front half (wave per stream), SNS vector quantiser (lane per frame), analysis back half (wave per
  * stream), bitstream packing (lane per frame); a decoder batch call two or four: frame parsing (lane per frame), spectrum
  * reconstruction (full batches: two kernels of its own, wave per frame and -- for the TNS lattice -- lane per frame; small
- * launches: inside the synthesis kernel), synthesis (wave per stream).  `enable` switches recording on/off; the call synchronises and returns the
- * per-kernel milliseconds accumulated since the previous call followed by the number of batch calls:
+ * launches: inside the synthesis kernel), synthesis (wave per stream).  `enable` = 0 switches recording off, 1 on for every batch call,
+ * n > 1 on for every n-th batch call from now on (an event after every kernel costs the stream a few microseconds: sampling keeps a
+ * long timed run undisturbed); the call synchronises and returns the per-kernel milliseconds accumulated since the previous call
+ * followed by the number of batch calls that were timed:
  * encoder out[5] = {front, vq, back, pack, calls}, decoder out[3] = {parse + reconstruction, synthesis, calls},
  * lc3gpu_decoder_timing_kernels out[5] = {parse, reconstruction kernel, TNS kernel (both 0 where the launch has none), synthesis, calls}. */
 int lc3gpu_encoder_timing(lc3gpu_encoder *enc, int enable, double out[5]);

@@ -335,9 +335,9 @@ class Lc3Encoder:
             raise Lc3EncoderError(rc, "encode")
 
     def timing(self, enable=True):
-        """-> (front ms, vector-quantiser ms, back ms, pack ms, batch calls) since the last call; (re)arms recording"""
+        """-> (front ms, vector-quantiser ms, back ms, pack ms, batch calls) since the last call; (re)arms recording (enable = n > 1: every n-th batch call)"""
         out = (ctypes.c_double * 5)()
-        rc = self._L.lc3gpu_encoder_timing(self._h, int(bool(enable)), out)
+        rc = self._L.lc3gpu_encoder_timing(self._h, int(enable), out)
         if rc:
             raise Lc3EncoderError(rc, "timing")
         return float(out[0]), float(out[1]), float(out[2]), float(out[3]), int(out[4])
@@ -444,9 +444,9 @@ class Lc3Decoder:
             raise Lc3DecoderError(rc, "decode")
 
     def timing(self, enable=True):
-        """-> (parse-kernel ms, synthesis-kernel ms, batch calls) since the last call; (re)arms recording"""
+        """-> (parse-kernel ms, synthesis-kernel ms, batch calls) since the last call; (re)arms recording (enable = n > 1: every n-th batch call)"""
         out = (ctypes.c_double * 3)()
-        rc = self._L.lc3gpu_decoder_timing(self._h, int(bool(enable)), out)
+        rc = self._L.lc3gpu_decoder_timing(self._h, int(enable), out)
         if rc:
             raise Lc3DecoderError(rc, "timing")
         return float(out[0]), float(out[1]), int(out[2])
@@ -474,9 +474,9 @@ class Lc3Decoder:
         return out, dbg
 
     def timing_kernels(self, enable=True):
-        """-> (parse ms, reconstruction-kernel ms, TNS-kernel ms, synthesis ms, batch calls) since the last call; (re)arms recording"""
+        """-> (parse ms, reconstruction-kernel ms, TNS-kernel ms, synthesis ms, batch calls) since the last call; (re)arms recording (enable = n > 1: every n-th batch call)"""
         out = (ctypes.c_double * 5)()
-        rc = self._L.lc3gpu_decoder_timing_kernels(self._h, int(bool(enable)), out)
+        rc = self._L.lc3gpu_decoder_timing_kernels(self._h, int(enable), out)
         if rc:
             raise Lc3DecoderError(rc, "timing")
         return float(out[0]), float(out[1]), float(out[2]), float(out[3]), int(out[4])

@@ -1096,10 +1096,22 @@ struct KernelTimer {
     size_t used = 0;               // events of the pool holding a recorded mark
     double ms[4] = {0.0, 0.0, 0.0, 0.0};
     long launches = 0;
+    int period = 1;                // every period-th batch call is timed (an event after every kernel costs the stream ~4 us each)
+    long calls = 0;
+    bool active = false;           // the current call is one of them
     // first mark of a batch call: begin(stream); after every kernel: mark(stream, slot of that kernel)
-    void begin(hipStream_t s) { mark(s, -1); }
+    void begin(hipStream_t s) {
+        active = enabled && (calls++ % (long)period) == 0;
+        mark(s, -1);
+    }
+    void set(int enable) {
+        enabled = enable != 0;
+        period = enable > 1 ? enable : 1;
+        calls = 0;
+        active = false;
+    }
     void mark(hipStream_t s, int sl) {
-        if (!enabled) return;
+        if (!active) return;
         if (used == pool.size()) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return;
@@ -2202,7 +2214,7 @@ int lc3gpu_encoder_timing(lc3gpu_encoder *e, int enable, double out[5]) {
     }
     for (int k = 0; k < 4; k++) e->timer.ms[k] = 0.0;
     e->timer.launches = 0;
-    e->timer.enabled = enable != 0;
+    e->timer.set(enable);
     return LC3GPU_OK;
 }
 // decoder: out[3] = {parse + reconstruction ms, synthesis ms, launches}
@@ -2216,7 +2228,7 @@ static int decoder_timing_read(lc3gpu_decoder *d, int enable, double ms[4], doub
     }
     *launches = (double)d->timer.launches;
     d->timer.launches = 0;
-    d->timer.enabled = enable != 0;
+    d->timer.set(enable);
     return LC3GPU_OK;
 }
 int lc3gpu_decoder_timing(lc3gpu_decoder *d, int enable, double out[3]) {

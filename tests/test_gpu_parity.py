@@ -373,6 +373,30 @@ def test_channel_ranges_on_separate_hip_streams():
     assert np.array_equal(out_p, ref_p)
 
 
+def test_kernel_timer_counts_every_nth_call():
+    """lc3gpu_*_timing: per-kernel HIP events on every batch call (enable = 1) or on every n-th one (enable = n), the count of timed
+    calls and plausible durations; recording off leaves nothing behind."""
+    t = torch_mod()
+    S, T, nf, nb = 256, 2, 480, 150
+    d_pcm = t.from_numpy(synth.make_pcm(S, T, nf, 48000, seed=5)).cuda()
+    d_b = t.zeros((S, T, nb), dtype=t.uint8, device="cuda")
+    d_p = t.zeros((S, T, nf), dtype=t.int16, device="cuda")
+    enc = pkg.Lc3Encoder(S, 10000, 48000)
+    dec = pkg.Lc3Decoder(S, 10000, 48000)
+    for every, calls, want in ((1, 5, 5), (3, 7, 3), (4, 4, 1)):
+        enc.timing(every)
+        dec.timing_kernels(every)
+        for _ in range(calls):
+            enc.encode(d_pcm, d_b, nb, T)
+            dec.decode(d_b, d_p, nb, T)
+        e = enc.timing(0)
+        d = dec.timing_kernels(0)
+        assert e[4] == want and d[4] == want, (every, e, d)
+        assert all(0.0 < x < 50.0 for x in e[:4]) and d[0] > 0.0 and d[3] > 0.0, (e, d)
+    enc.encode(d_pcm, d_b, nb, T)
+    assert enc.timing(0)[4] == 0
+
+
 def test_pipelined_half_batches_on_four_hip_streams():
     """The stream arrangement INTEGRATION.md recommends for throughput (bench.py's `overlapped.pipelined_halves`): the batch as two
     handle pairs, each with its encoder on one HIP stream and its decoder on another, the decoder of step k under the encoder of
