@@ -1190,19 +1190,31 @@ struct HandleCommon {
     hipEvent_t done = nullptr;
     bool has_work = false;
 
+    // A handle's launches share its scratch planes and its state blobs: a call on another stream than the previous one waits for
+    // everything queued on that stream so far.  The event is recorded only then (on the previous stream, when the streams differ): a
+    // caller that stays on one stream pays no event per call (~3 us of stream time each).  Should the previous stream have been
+    // destroyed in the meantime, its work is waited for device-wide.
     int order_begin(hipStream_t s) {
-        if (has_work && s != last_stream) HIP_TRY(hipStreamWaitEvent(s, done, 0));
+        if (has_work && s != last_stream) {
+            if (hipEventRecord(done, last_stream) == hipSuccess) HIP_TRY(hipStreamWaitEvent(s, done, 0));
+            else {
+                (void)hipGetLastError();
+                HIP_TRY(hipDeviceSynchronize());
+            }
+        }
         return LC3GPU_OK;
     }
     int order_end(hipStream_t s) {
-        HIP_TRY(hipEventRecord(done, s));
         last_stream = s;
         has_work = true;
         return LC3GPU_OK;
     }
     // host waits for everything the handle has launched
     int quiesce() {
-        if (has_work) HIP_TRY(hipEventSynchronize(done));
+        if (has_work && hipStreamSynchronize(last_stream) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipDeviceSynchronize());
+        }
         return LC3GPU_OK;
     }
     const HostCfg &cfg_of_channel(int ch) const { return mixed ? groups[(size_t)streams[(size_t)ch].group].h : h; }
