@@ -231,13 +231,14 @@ __device__ __forceinline__ int lc3_p_bool_sel(lc3_parse_ctx &c, int want, int &e
     c.tnext = lc3_p_tail_byte(c, (c.tail >> 3) + 1);  // consumed at the next wrap, not here
     return want ? bit : 0;
 }
-// two consecutive read_tail_bool (:100-116), each when its `want`: the cursor, its byte window and the bound check advance once.
-// (The bound check is monotone in the bit position, so the last bit read stands for both.)
-__device__ __forceinline__ void lc3_p_bool2_sel(lc3_parse_ctx &c, int w0, int w1, int &err, int &b0, int &b1) {
+// two consecutive read_tail_bool (:100-116), each when its `want`: the cursor and its byte window advance once.  The reference's bound
+// checks (a bit's byte must lie inside the frame and not more than two bytes below the head cursor, :100-108) are monotone: the cursors
+// only move on, so the last bit that was read stands for all of them.  `slack` keeps len + 2 - head - (byte of the last bit read) as of
+// the last call that read a bit; the caller tests it, and the byte of the final cursor against the frame, once after its loop.
+__device__ __forceinline__ void lc3_p_bool2_sel(lc3_parse_ctx &c, int w0, int w1, int &slack, int &b0, int &b1) {
     const int n = w0 + w1, bit_index = c.tail & 7;
     const int byte_last = (c.tail + n - 1) >> 3;
-    const int bad = (c.len - c.head - byte_last + 2 < 0) | (c.len - byte_last - 1 < 0);
-    err |= (n > 0) & bad;
+    slack = n > 0 ? c.len + 2 - c.head - byte_last : slack;
     const uint32_t win = (c.tcur | (c.tnext << 8)) >> bit_index;
     b0 = w0 ? (int)(win & 1u) : 0;
     b1 = w1 ? (int)((win >> w0) & 1u) : 0;
@@ -252,15 +253,17 @@ __device__ __forceinline__ void lc3_p_head_refill(lc3_parse_ctx &c) {
     c.hb0 = lc3_p_head_byte(c, c.head);
     c.hb1 = lc3_p_head_byte(c, c.head + 1);
 }
-template <int REFILL = 1>
+// CHECK = 0: the caller tests the head cursor against the frame once after its loop (read_head_byte :42-50 fails when the cursor is at or
+// beyond the end; the cursor moves by one per byte read, so "some byte was read beyond the end" is "the cursor ended beyond the end + 0")
+template <int REFILL = 1, int CHECK = 1>
 __device__ __forceinline__ void lc3_p_ac_renorm_sel(lc3_parse_ctx &c, lc3_acdec &st, int &err) {
     const int need0 = st.range < 0x10000u;
-    err |= need0 & (c.head >= c.len);  // read_head_byte :42-50
+    if (CHECK) err |= need0 & (c.head >= c.len);  // read_head_byte :42-50
     st.low = need0 ? ((st.low << 8) & 0x00ffffffu) + c.hb0 : st.low;
     st.range = need0 ? st.range << 8 : st.range;
     c.head += need0;
     if (st.range < 0x10000u) {  // a second byte only after a symbol of probability below 2^-8: usually no lane of the wave
-        err |= c.head >= c.len;
+        if (CHECK) err |= c.head >= c.len;
         st.low = ((st.low << 8) & 0x00ffffffu) + c.hb1;
         st.range <<= 8;
         c.head += 1;
@@ -316,7 +319,7 @@ __device__ __forceinline__ int lc3_p_ac_decode_spec_sel(lc3_parse_ctx &c, lc3_ac
     const int lo = ge16 ? 16 : 4 * g + n;
     st.low -= LC3_MUL24(tmp, sv & 0xffffu);
     st.range = LC3_MUL24(tmp, sv >> 16);
-    lc3_p_ac_renorm_sel<0>(c, st, err);  // the caller requests the next head bytes (after it has consumed its tail bits)
+    lc3_p_ac_renorm_sel<0, 0>(c, st, err);  // the caller requests the next head bytes (after it has consumed its tail bits) and checks the cursor
     return lo;
 }
 
@@ -396,7 +399,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
         // row -> its words 16..19) and a third one picks the group of four: the first two are made one symbol AHEAD, as soon as the
         // current symbol is known, and land while the lane consumes the tail bits and stores the pair -- one exposed LDS round trip
         // per symbol instead of three.
-        int cctx = 0, err = 0, tup = 0, lev = 0;
+        int cctx = 0, err = 0, tup = 0, lev = 0, slack = 0x7fffffff;
         int32_t xk = 0, xk1 = 0;
         const int hi_from = ne / 2;  // pairs with 2 * tup > ne / 2 use the upper half of the contexts
         const uint32_t *row = c.cf + (int)c.lookup[rate_flag + (0 > hi_from ? 256 : 0)] * LC3_DCF_ROW_WORDS;
@@ -411,7 +414,7 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             // the signs of the non-zero values
             const int want_e = !lsb_mode || lev > 0;
             int bit0, bit1;
-            lc3_p_bool2_sel(c, esc ? want_e : m0 > 0, esc ? want_e : m1 > 0, err, bit0, bit1);
+            lc3_p_bool2_sel(c, esc ? want_e : m0 > 0, esc ? want_e : m1 > 0, slack, bit0, bit1);
             // where the lane goes next, and that symbol's row index (requested behind the last use of a prefetched byte: LDS returns
             // in order, and such a use waits for everything in flight)
             const int n_cctx = esc ? cctx : (cctx & 15) * 16 + (lv <= 1 ? 1 + ((a + b) << lv) : 12 + lv);  // (a + b) * (lv + 1) for lv = 0, 1
@@ -442,6 +445,9 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
             tup = n_tup;
             lev = n_lev;
         }
+        // the loop's deferred bound checks: a head byte read at or beyond the end of the frame, a tail bit more than two bytes below the
+        // head cursor as of its read, a tail bit before the start of the frame
+        err |= (c.head > c.len) | (slack < 0) | (c.len - ((c.tail - 1) >> 3) - 1 < 0);
         if (err) return -4;
     }
     LC3_PSTAMP(c, 2);
