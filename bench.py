@@ -56,9 +56,15 @@ def parse_args(argv=None):
                     help="split the rank's streams over this many codec handle pairs, each on its own HIP stream "
                          "(default 1: one stream, clean per-kernel timing)")
     ap.add_argument("--no-overlap-probe", action="store_true",
-                    help="skip the informational legs that repeat the steps with the work arranged for overlap -- the batch split over "
-                         "four handle pairs on four HIP streams, and encoder / decoder on two HIP streams one step apart (reported as "
-                         "`overlapped`, never `value`)")
+                    help="skip timing the OTHER arrangement (see --arrangement) after the timed region")
+    ap.add_argument("--arrangement", choices=("single", "pipelined"), default="single",
+                    help="how the timed steps are queued: `single` = encode then decode of the same batch on ONE HIP stream (every call waits for "
+                         "the one before it); `pipelined` = the recommended caller pattern (INTEGRATION.md): the encoder handle on one HIP stream, the "
+                         "decoder handle on another, two byte buffers and events, so that the decoder works on step k while the encoder runs step k + 1. "
+                         "The other arrangement is timed too and reported beside `value`")
+    ap.add_argument("--sustain-seconds", type=float, default=2.5,
+                    help="length of the sustained leg: back-to-back steps for this long, frames/s and the shader clock read by a one-wave probe kernel "
+                         "beside them (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--engine", choices=("gpu", "emu"), default="gpu", help=argparse.SUPPRESS)
@@ -283,25 +289,55 @@ class GpuEngine:
         self.decs = mk(pkg.Lc3Decoder) if mode == "roundtrip" else []
         self.hs = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(NP - 1)]
         self.marks = []
+        # the pipelined arrangement (roundtrip, one handle pair): encoder stream, decoder stream, two byte buffers
+        self.arrangement = "single"
+        self.k = 0
+        if mode == "roundtrip" and NP == 1:
+            self.s_enc, self.s_dec = torch.cuda.current_stream(), torch.cuda.Stream()
+            self.bufs = [self.d_bytes, torch.zeros_like(self.d_bytes)]
+            self.enc_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self.dec_done = [torch.cuda.Event(), torch.cuda.Event()]
 
     device = "cuda"
+    carries_state = True
+
+    def set_arrangement(self, name):
+        """`single` or `pipelined`; call between synchronised phases only"""
+        assert name == "single" or (self.mode == "roundtrip" and self.NP == 1)
+        self.sync()
+        self.arrangement, self.k = name, 0
 
     def step(self):
+        if self.arrangement == "pipelined":
+            # step k: the encoder writes buffer k & 1 on its stream as soon as the decoder of step k - 2 has read it; the decoder follows
+            # on ITS stream as soon as the bytes are there -- and meanwhile the encoder is already on step k + 1
+            k, b = self.k, self.k & 1
+            if k >= 2:
+                self.s_enc.wait_event(self.dec_done[b])
+            self.encs[0].encode(self.d_pcm, self.bufs[b], NBYTES, self.T, stream=self.s_enc.cuda_stream)
+            self.enc_done[b].record(self.s_enc)
+            self.s_dec.wait_event(self.enc_done[b])
+            self.decs[0].decode(self.bufs[b], self.d_out, NBYTES, self.T, stream=self.s_dec.cuda_stream)
+            self.dec_done[b].record(self.s_dec)
+            self.k += 1
+            return
         for p in range(self.NP):
             st = self.hs[p].cuda_stream
             lo, hi = p * self.SP, (p + 1) * self.SP
             self.encs[p].encode(self.d_pcm[lo:hi], self.d_bytes[lo:hi], NBYTES, self.T, stream=st)
             if self.decs:
                 self.decs[p].decode(self.d_bytes[lo:hi], self.d_out[lo:hi], NBYTES, self.T, stream=st)
+        self.k += 1
 
     def sync(self):
         self.torch.cuda.synchronize()
 
     def step_mark(self):
-        """an event on the launch stream (single-stream runs only): consecutive marks bracket one step"""
+        """an event behind the step just queued (single-stream runs: on the launch stream; pipelined: behind its decoder): consecutive
+        marks bracket one step"""
         if self.NP == 1:
             e = self.torch.cuda.Event(enable_timing=True)
-            e.record(self.hs[0])
+            e.record(self.s_dec if self.arrangement == "pipelined" else self.hs[0])
             self.marks.append(e)
 
     def step_times_ms(self):
@@ -309,11 +345,18 @@ class GpuEngine:
         return [m[i].elapsed_time(m[i + 1]) for i in range(len(m) - 1)]
 
     def reset(self):
+        self.sync()
         for h in self.encs + self.decs:
             h.reset()
+        self.k = 0
+
+    def last_bytes(self, k):
+        """the first k streams' frame bytes of the most recent step"""
+        buf = self.bufs[(self.k - 1) & 1] if self.arrangement == "pipelined" else self.d_bytes
+        return buf[:k].cpu().numpy()
 
     def results(self, k):
-        return (self.d_bytes[:k].cpu().numpy(), self.d_out[:k].cpu().numpy() if self.d_out is not None else None)
+        return (self.last_bytes(k), self.d_out[:k].cpu().numpy() if self.d_out is not None else None)
 
     def timing_start(self, every=1):
         for h in self.encs + self.decs:
@@ -334,104 +377,77 @@ class GpuEngine:
             km.update({"lc3_parse_kernel": dp / max(dn, 1), "lc3_recon_kernel": dr / max(dn, 1), "lc3_tns_kernel": dt / max(dn, 1), "lc3_decode_kernel": ds / max(dn, 1)})
         return km
 
-    def overlap_probe(self, steps, warmup):
-        torch, pkg, S, T = self.torch, self.pkg, self.S, self.T
-        if self.NP != 1 or S % 4 or self.mode != "roundtrip":
-            return None
-        Q, SQ = 4, S // 4
-        qe = [pkg.Lc3Encoder(SQ, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(Q)]
-        qd = [pkg.Lc3Decoder(SQ, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(Q)]
-        qs = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(Q - 1)]
-
-        def qstep():
-            for p in range(Q):
-                lo, hi = p * SQ, (p + 1) * SQ
-                qe[p].encode(self.d_pcm[lo:hi], self.d_bytes[lo:hi], NBYTES, T, stream=qs[p].cuda_stream)
-                qd[p].decode(self.d_bytes[lo:hi], self.d_out[lo:hi], NBYTES, T, stream=qs[p].cuda_stream)
-
+    def timed_steps(self, steps, warmup, dist=None, kernel_events=0, marks=False):
+        """`warmup` untimed steps, then exactly `steps` steps between two synchronisation points -> (seconds, per-kernel ms or None,
+        sorted per-step ms)"""
         for _ in range(warmup):
-            qstep()
-        torch.cuda.synchronize()
-        q0 = time.perf_counter()
+            self.step()
+        self.sync()
+        if dist is not None:
+            dist.barrier()
+        self.sync()
+        if kernel_events:
+            self.timing_start(kernel_events)
+        if marks:
+            self.step_mark()
+        t0 = time.perf_counter()
         for _ in range(steps):
-            qstep()
-        torch.cuda.synchronize()
-        qel = time.perf_counter() - q0
-        res = {"hip_streams": Q, "value": S * T * steps / qel, "unit": "frames/s", "ms_per_step": qel / steps * 1e3,
-               "note": "same batch as four independent quarter batches on four HIP streams; informational, not `value`"}
-        del qe, qd
-        # the caller's software pipeline: the encoder of step k + 1 runs (stream A) while the decoder works on step k's bytes (stream B);
-        # two byte buffers take turns, events order decoder k behind encoder k and encoder k + 2 behind decoder k
-        enc = pkg.Lc3Encoder(S, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000)
-        dec = pkg.Lc3Decoder(S, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000)
-        sa, sb = torch.cuda.current_stream(), torch.cuda.Stream()
-        bufs = [self.d_bytes, torch.zeros_like(self.d_bytes)]
-        enc_done = [torch.cuda.Event(), torch.cuda.Event()]
-        dec_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self.step()
+            if marks:
+                self.step_mark()
+        self.sync()
+        if dist is not None:
+            dist.barrier()
+        self.sync()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = self.timing_stop() if kernel_events else None
+        return elapsed, kernel_ms, sorted(self.step_times_ms())
 
-        def pstep(k):
-            b = k & 1
-            if k >= 2:
-                sa.wait_event(dec_done[b])  # the buffer's previous reader
-            enc.encode(self.d_pcm, bufs[b], NBYTES, T, stream=sa.cuda_stream)
-            enc_done[b].record(sa)
-            sb.wait_event(enc_done[b])
-            dec.decode(bufs[b], self.d_out, NBYTES, T, stream=sb.cuda_stream)
-            dec_done[b].record(sb)
-
-        for k in range(2 * ((warmup + 1) // 2)):
-            pstep(k)
-        torch.cuda.synchronize()
-        p0 = time.perf_counter()
-        for k in range(steps):
-            pstep(k + 2)
-        torch.cuda.synchronize()
-        pel = time.perf_counter() - p0
-        res["pipelined"] = {"hip_streams": 2, "value": S * T * steps / pel, "unit": "frames/s", "ms_per_step": pel / steps * 1e3,
-                            "note": "the full batch, encoder of step k+1 on one HIP stream under the decoder of step k on another "
-                                    "(two byte buffers); informational, not `value`"}
-        del enc, dec
-        # both together: two half batches, each with its encoder on one stream and its decoder on another (four streams).  The
-        # lane-per-frame kernels of a 65 536-frame launch are ONE wave per SIMD and leave half of its issue slots idle (DESIGN
-        # section 6): whatever runs beside them on another stream gets those
-        H, SH = 2, S // 2
-        he = [pkg.Lc3Encoder(SH, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(H)]
-        hd = [pkg.Lc3Decoder(SH, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(H)]
-        hs_e = [torch.cuda.Stream() for _ in range(H)]
-        hs_d = [torch.cuda.Stream() for _ in range(H)]
-        h_enc = [[torch.cuda.Event() for _ in range(H)] for _ in range(2)]
-        h_dec = [[torch.cuda.Event() for _ in range(H)] for _ in range(2)]
-
-        def hstep(k):
-            b = k & 1
-            for p in range(H):
-                lo, hi = p * SH, (p + 1) * SH
-                if k >= 2:
-                    hs_e[p].wait_event(h_dec[b][p])
-                he[p].encode(self.d_pcm[lo:hi], bufs[b][lo:hi], NBYTES, T, stream=hs_e[p].cuda_stream)
-                h_enc[b][p].record(hs_e[p])
-                hs_d[p].wait_event(h_enc[b][p])
-                hd[p].decode(bufs[b][lo:hi], self.d_out[lo:hi], NBYTES, T, stream=hs_d[p].cuda_stream)
-                h_dec[b][p].record(hs_d[p])
-
-        for k in range(2 * ((warmup + 1) // 2)):
-            hstep(k)
-        torch.cuda.synchronize()
-        h0 = time.perf_counter()
-        for k in range(steps):
-            hstep(k + 2)
-        torch.cuda.synchronize()
-        hel = time.perf_counter() - h0
-        res["pipelined_halves"] = {"hip_streams": 4, "value": S * T * steps / hel, "unit": "frames/s", "ms_per_step": hel / steps * 1e3,
-                                   "note": "two half batches, each with its encoder on one HIP stream and its decoder on another (the decoder of "
-                                           "step k under the encoder of step k+1); informational, not `value`"}
-        return res
+    def sustained(self, seconds):
+        """back-to-back steps of the current arrangement for at least `seconds`; beside them, on a stream of its own, a one-wave probe
+        kernel (lc3gpu_clock_probe) reads the shader clock every few steps: delta(s_memtime) / delta(s_memrealtime) x 100 MHz"""
+        torch, pkg = self.torch, self.pkg
+        n_slots, every, depth = 256, 16, 48
+        slots = torch.zeros((n_slots, 3), dtype=torch.int64, device="cuda")
+        s_probe = torch.cuda.Stream()
+        fences = []
+        self.sync()
+        t0 = time.perf_counter()
+        steps = probes = 0
+        while True:
+            self.step()
+            steps += 1
+            if steps % every == 0:
+                if probes < n_slots:
+                    pkg.clock_probe(slots[probes], stream=s_probe.cuda_stream, spin=50000)
+                    probes += 1
+                e = torch.cuda.Event()
+                e.record(self.s_dec if self.arrangement == "pipelined" else self.hs[0])
+                fences.append(e)
+                if len(fences) > depth // every:
+                    fences.pop(0).synchronize()  # the host stays at most `depth` steps ahead of the chip
+                if time.perf_counter() - t0 >= seconds:
+                    break
+        self.sync()
+        el = time.perf_counter() - t0
+        v = slots[:probes].cpu().numpy()
+        mhz = sorted(100.0 * float(c) / float(r) for c, r, _ in v if r > 0)
+        skip = len(mhz) // 4  # the first probes run while the clock is still ramping: the figures are of the later three quarters
+        late = sorted(100.0 * float(c) / float(r) for c, r, _ in v[skip:] if r > 0)
+        return {"seconds": el, "steps": steps, "value": self.S * self.T * steps / el, "unit": "frames/s", "ms_per_step": el / steps * 1e3,
+                "arrangement": self.arrangement,
+                "shader_clock_MHz": {"median": late[len(late) // 2] if late else None, "min": late[0] if late else None,
+                                     "max": late[-1] if late else None, "probes": len(late),
+                                     "how": "one-wave kernel on a HIP stream of its own beside the steps: delta(s_memtime) / delta(s_memrealtime) "
+                                            "x 100 MHz over ~0.1 ms, every 16th step; first quarter of the probes dropped"}}
 
 
 class EmuEngine:
     """tests only: the device headers under the CPU wave emulator (tests/emu), host arrays, fresh state every step"""
 
     device = "cpu"
+    arrangement = "single"
+    carries_state = False  # (every step starts from fresh state)
 
     def __init__(self, args, pcm_host, S, T, mode, local_rank):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -448,11 +464,8 @@ class EmuEngine:
     def sync(self):
         pass
 
-    def step_mark(self):
-        pass
-
-    def step_times_ms(self):
-        return []
+    def set_arrangement(self, name):
+        assert name == "single"
 
     def reset(self):
         pass
@@ -460,13 +473,19 @@ class EmuEngine:
     def results(self, k):
         return self.bytes[:k], (self.out[:k] if self.out is not None else None)
 
-    def timing_start(self, every=1):
-        pass
+    def timed_steps(self, steps, warmup, dist=None, kernel_events=0, marks=False):
+        for _ in range(warmup):
+            self.step()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        if dist is not None:
+            dist.barrier()
+        return time.perf_counter() - t0, None, []
 
-    def timing_stop(self):
-        return None
-
-    def overlap_probe(self, steps, warmup):
+    def sustained(self, seconds):
         return None
 
 
@@ -479,7 +498,11 @@ def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     emu = args.engine == "emu"
     dist = None
-    if world > 1:
+    rccl_version = None
+    # LC3_BENCH_RCCL=1: the RCCL path of an N-GPU run (library load, communicator, barrier, all_reduce on device tensors) with ONE rank on
+    # the one GPU a box of this pool has -- entered before anything else touches the device, as the ranks of an 8-GPU run do
+    rccl_single = world == 1 and not emu and os.environ.get("LC3_BENCH_RCCL") == "1"
+    if world > 1 or rccl_single:
         import torch
         import torch.distributed as dist
 
@@ -496,7 +519,15 @@ def run_rank(args):
             if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
                 os.environ["NCCL_DEBUG"] = "WARN"
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            if rccl_single:
+                dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                                        device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001 -- informational only
+                rccl_version = None
 
     if dist is not None and os.environ.get("LC3_BENCH_TEST_DIE_RANK") == str(rank):
         # test hook (tests/test_dist_gloo.py): this rank dies after the rendezvous; the launcher must stop the others, which are
@@ -519,63 +550,75 @@ def run_rank(args):
         S, first_stream, scaling = hi - lo, lo, "strong"
     frames_per_step = S * T
 
-    # synthetic input: up to 1024 distinct streams per rank (the generator is host-side numpy), tiled to S streams
-    n_distinct = min(S, 1024)
+    # synthetic input: every stream of the headline batch is its own (16 384 distinct streams per rank; the lane-per-frame kernels take
+    # as long as the longest frame of a wave, so tiled copies would under-sample that tail); larger batches tile 16 384 (the host-side
+    # generator takes ~4 s for them)
+    n_distinct = min(S, 16384)
     base = synth.make_pcm(n_distinct, T, NF, FS, first_stream=first_stream)
     pcm_host = np.ascontiguousarray(np.tile(base, ((S + n_distinct - 1) // n_distinct, 1, 1))[:S])
     eng = (EmuEngine if emu else GpuEngine)(args, pcm_host, S, T, mode, local_rank)
+    can_pipeline = (not emu) and mode == "roundtrip" and max(1, args.hip_streams) == 1
+    main_arr = args.arrangement if can_pipeline else "single"
 
-    # parity gate on the first step (fresh state): engine bitstream / PCM vs the CPU oracle on a sample, every rank
-    parity, mismatches = None, 0
-    if not args.no_parity:
+    # parity gate, on the arrangement that is timed: two steps from fresh state queued back to back (the second one carries state, and
+    # in the pipelined arrangement both byte buffers and all four events are in play), the SECOND step's bitstream and PCM against the
+    # CPU oracle on a sample of the streams, every rank; the oracle runs on this rank's share of the host threads the job is granted
+    def gate(arr):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
 
+        eng.set_arrangement(arr)
+        eng.reset()
+        eng.step()
         eng.step()
         eng.sync()
         k = min(n_distinct, 256 if rank == 0 else 32)
-        thr = os.cpu_count() or 1
-        ref_b = O.encode_batch(pcm_host[:k], NBYTES, FS, US, threads=thr)
+        thr = max(1, granted_cpus()[0] // max(1, world))
+        two = np.ascontiguousarray(np.concatenate([pcm_host[:k], pcm_host[:k]], axis=1))  # every step codes the same T frames
+        ref_b = O.encode_batch(two, NBYTES, FS, US, threads=thr)
         got_b, got_p = eng.results(k)
-        bad_b = int((got_b != ref_b).any(axis=2).sum())
-        parity = {"frames_checked": int(k * T), "bitstream_exact": bad_b == 0}
-        mismatches = bad_b
+        second = slice(T, 2 * T) if eng.carries_state else slice(0, T)
+        bad_b = int((got_b != ref_b[:, second]).any(axis=2).sum())
+        par = {"arrangement": arr, "frames_checked": int(k * T), "which": "second of two steps from fresh state (state carried)",
+               "bitstream_exact": bad_b == 0, "oracle_threads": thr}
+        mism = bad_b
         if mode == "roundtrip":
             ref_p = O.decode_batch(ref_b, NF, FS, US, threads=thr)
-            diff = np.abs(got_p.astype(np.int32) - ref_p.astype(np.int32))
-            parity["pcm_max_abs_diff"] = int(diff.max())
-            mismatches += int((diff.max(axis=2) > 1).sum())
+            diff = np.abs(got_p.astype(np.int32) - ref_p[:, second].astype(np.int32))
+            par["pcm_max_abs_diff"] = int(diff.max())
+            mism += int((diff.max(axis=2) > 1).sum())
         eng.reset()
+        return par, mism
 
-    for _ in range(args.warmup):
-        eng.step()
-    eng.sync()
-    if dist is not None:
-        dist.barrier()
-    eng.sync()
+    parity, mismatches = None, 0
+    if not args.no_parity:
+        parity, mismatches = gate(main_arr)
 
-    # timed region: exactly K steps; per-kernel durations from HIP events the C ABI records on the launch stream on every fourth
-    # step (an event after every kernel of every step costs the stream 0.034 ms per step, 2 % of it), and one event after every
-    # step for the per-step minimum / median
-    eng.timing_start(KERNEL_EVENTS_EVERY)
-    eng.step_mark()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step()
-        eng.step_mark()
-    eng.sync()
-    if dist is not None:
-        dist.barrier()
-    eng.sync()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = eng.timing_stop()
-    step_ms = sorted(eng.step_times_ms())
+    # timed region: exactly K steps; per-kernel durations from HIP events the C ABI records on the launch streams on every fourth
+    # step (an event after every kernel of every step costs the streams ~0.03 ms per step), and one event after every step for the
+    # per-step minimum / median
+    eng.set_arrangement(main_arr)
+    elapsed, kernel_ms, step_ms = eng.timed_steps(args.steps, args.warmup, dist=dist, kernel_events=KERNEL_EVENTS_EVERY, marks=True)
 
     # max time over ranks, counters summed over ranks (the only collective of the job)
     red_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else eng.device
     elapsed, total_frames, total_mismatches, _ = D.reduce_report(dist, red_dev, elapsed, frames_per_step * args.steps,
-                                                                  mismatches=mismatches)
-    overlapped = eng.overlap_probe(args.steps, args.warmup) if (not args.no_overlap_probe and world == 1) else None
+                                                                  mismatches=mismatches, force=rccl_single)
+    # the other arrangement (same K steps, its own parity gate) and the sustained leg of the main one: single rank only
+    other, sustained = None, None
+    if world == 1 and not emu:
+        if can_pipeline and not args.no_overlap_probe:
+            arr2 = "pipelined" if main_arr == "single" else "single"
+            par2, mism2 = gate(arr2) if not args.no_parity else (None, 0)
+            eng.set_arrangement(arr2)
+            el2, _, st2 = eng.timed_steps(args.steps, args.warmup, marks=True)
+            other = {"arrangement": arr2, "value": frames_per_step * args.steps / el2, "unit": "frames/s", "ms_per_step": el2 / args.steps * 1e3,
+                     "ms_per_step_median": st2[len(st2) // 2] if st2 else None, "parity": par2, "parity_mismatches": mism2,
+                     "hip_streams": 2 if arr2 == "pipelined" else 1}
+            total_mismatches += mism2
+        if args.sustain_seconds > 0:
+            eng.set_arrangement(main_arr)
+            sustained = eng.sustained(args.sustain_seconds)
 
     if rank == 0:
         cpu = None
@@ -588,6 +631,8 @@ def run_rank(args):
             # parser reads nbytes, the synthesis kernel writes 2*nf; the vector quantiser and the back half touch no
             # algorithmic bytes (their traffic is the planes between kernels).  The analysis of a frame is three kernels
             # (front half, quantiser, back half): ONE unit for the roofline, with the frame's PCM as its algorithmic bytes.
+            # kernel_ms[k] = that kernel's launch durations summed over one step (a call of a full batch runs as two half launches
+            # side by side on the handle's internal streams: the sum over both, as `rocprofv3 --kernel-trace --stats` totals them)
             alg_bytes = {"lc3_enc_front_kernel": 2 * NF, "lc3_sns_vq_kernel": 0, "lc3_enc_back_kernel": 0,
                          "lc3_pack_kernel": NBYTES, "lc3_parse_kernel": NBYTES, "lc3_recon_kernel": 0, "lc3_tns_kernel": 0, "lc3_decode_kernel": 2 * NF}
             groups = {"analysis (lc3_enc_front_kernel + lc3_sns_vq_kernel + lc3_enc_back_kernel)":
@@ -602,13 +647,15 @@ def run_rank(args):
             # counters of the committed PMC passes, scaled to this run's frames per launch; withheld (null) unless the file
             # was measured on exactly these kernel sources
             pj, pmc_note = load_pmc()
-            traffic = valu_frac = lane_frac = valu_insts = None
+            traffic = traffic_step = valu_frac = lane_frac = valu_insts = None
             ceil = load_ceiling()
             if pj is not None:
                 scale = frames_per_step / pj["frames_per_launch"]
                 kk = pj["kernels"]
                 live = [k for k in kernel_ms if k in kk and kernel_ms[k] > 0.002]  # kernels this run launched
-                traffic = sum(kk[k]["fetch_size_kb"] + kk[k]["write_size_kb"] for k in groups[dom] if k in kk) * 1024.0 * scale
+                hbm = lambda k: (kk[k].get("fetch_size_kb_corrected", kk[k]["fetch_size_kb"]) + kk[k]["write_size_kb"]) * 1024.0 * scale
+                traffic = sum(hbm(k) for k in groups[dom] if k in kk)
+                traffic_step = sum(hbm(k) for k in live)
                 valu_insts = {k: kk[k]["sq_insts_valu"] * scale for k in live}
                 thread_cyc = sum(kk[k]["sq_thread_cycles_valu"] for k in live) * scale
                 lane_frac = thread_cyc / (sum(valu_insts.values()) * 64.0)
@@ -622,7 +669,7 @@ def run_rank(args):
                 pmc_note = pj.get("source")
             roof = {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_whole_step": traffic_step,
                 "measured_copy_GBs": ceil["copy_GBs"] if ceil else None,
                 "algorithmic_bytes_per_frame": alg,
                 "roundtrip_algorithmic_bytes_per_frame": ALG_BYTES_ENC + (ALG_BYTES_DEC if mode == "roundtrip" else 0),
@@ -630,21 +677,25 @@ def run_rank(args):
                 "valu_frac": valu_frac, "active_lane_frac": lane_frac, "valu_insts_per_step": valu_insts, "valu_ceiling": ceil,
                 "pmc": pmc_note,
                 "note": "instruction/latency-bound, not HBM-bound (SURVEY 8d honesty note): ~60 flop per algorithmic byte. "
-                        "traffic = FETCH_SIZE + WRITE_SIZE of the dominant unit per launch; measured_copy_GBs = what a 16-byte-per-lane copy "
-                        "kernel reaches on this chip (read + write), beside the 8 TB/s vendor figure `frac` divides by; valu_frac = sum over "
-                        "the step's kernels of SQ_INSTS_VALU x (measured cycles per wave instruction of the codec's instruction mix at that "
-                        "kernel's waves per SIMD) / (1024 SIMDs x the kernels' cycles at 2.4 GHz); active_lane_frac = SQ_THREAD_CYCLES_VALU / "
+                        "achieved = algorithmic bytes of the dominant unit / the sum of its kernels' launch durations in a step (HIP events on the "
+                        "launch streams; a full batch runs as two half launches side by side, whose durations are summed as rocprofv3 totals them); "
+                        "traffic = FETCH_SIZE + WRITE_SIZE of the dominant unit per step in BYTES (FETCH_SIZE doubled for the kernels whose reads are "
+                        "16-byte-per-lane coalesced, MI355X_MICROARCH.md), traffic_whole_step the same over every kernel of the step; measured_copy_GBs = "
+                        "what a 16-byte-per-lane copy kernel reaches on this chip (read + write), beside the 8 TB/s vendor figure `frac` divides by; "
+                        "valu_frac = sum over the step's kernels of SQ_INSTS_VALU x (measured cycles per wave instruction of the codec's instruction mix at "
+                        "that kernel's waves per SIMD) / (1024 SIMDs x the kernels' cycles at 2.4 GHz); active_lane_frac = SQ_THREAD_CYCLES_VALU / "
                         "(64 x SQ_INSTS_VALU); counters from the committed rocprofv3 PMC passes (profiles/pmc_latest.json), null when they "
                         "were taken on other kernel sources",
             }
         if mode == "roundtrip":
             workload = (f"{frames_per_step}-frame batch mono 48 kHz / 10 ms / 150-byte frames, encode+decode (BASELINE configs[1]); "
-                        f"{n_distinct} distinct synthetic streams tiled to {S}")
+                        f"{n_distinct} distinct synthetic streams" + (f" tiled to {S}" if n_distinct < S else ""))
             metric = "LC3 frames/sec (encode+decode) @48kHz/10ms"
         else:
             workload = (f"{total_streams * T}-frame batch mono 48 kHz / 10 ms / 150-byte frames, encode only, streams sharded over "
-                        f"{world} GPU(s) (BASELINE configs[2]); {n_distinct} distinct synthetic streams per rank tiled to {S}")
+                        f"{world} GPU(s) (BASELINE configs[2]); {n_distinct} distinct synthetic streams per rank" + (f" tiled to {S}" if n_distinct < S else ""))
             metric = "LC3 frames/sec (encode) @48kHz/10ms"
+        hip_streams = 2 if main_arr == "pipelined" else max(1, args.hip_streams)
         line = {
             "metric": metric, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -655,12 +706,19 @@ def run_rank(args):
                 "workload": workload, "mode": mode, "streams_per_gpu": S, "frames_per_stream_per_step": T,
                 "frames_per_step_per_gpu": frames_per_step, "nbytes": NBYTES, "state": "carried across steps (streaming)",
                 "parallelism": f"streams sharded over {world} GPU(s), no data-path collective; "
-                               + (f"torch.distributed world size {dist.get_world_size()} ({dist.get_backend()})" if dist is not None
-                                  else "single process"),
-                "hip_streams": max(1, args.hip_streams), "engine": args.engine,
+                               + (f"torch.distributed world size {dist.get_world_size()} ({dist.get_backend()}"
+                                  + (f", RCCL {rccl_version}" if rccl_version else "") + ")" if dist is not None else "single process"),
+                "hip_streams": hip_streams, "arrangement": main_arr,
+                "arrangement_note": ("`single`: lc3gpu_encode then lc3gpu_decode of the same batch on ONE caller stream, every call behind the one before "
+                                     "it; `pipelined`: the encoder handle on one caller stream, the decoder handle on another, two byte buffers and "
+                                     "events (INTEGRATION.md, recommended caller pattern).  Inside either, a call of >= 32 768 frames runs as two halves "
+                                     "on the handle's two internal HIP streams (LC3GPU_SPLIT=0 switches that off)"),
+                "engine": args.engine,
             },
-            "kernel_ms": kernel_ms, "kernel_ms_from": f"HIP events around every kernel on every {KERNEL_EVENTS_EVERY}th step of the timed region",
-            "roofline": roof, "cpu_baseline": cpu, "overlapped": overlapped,
+            "kernel_ms": kernel_ms,
+            "kernel_ms_from": f"HIP events around every kernel on every {KERNEL_EVENTS_EVERY}th step of the timed region, on the streams the kernels are "
+                              "launched on; per step, summed over a kernel's launches",
+            "roofline": roof, "cpu_baseline": cpu, "other_arrangement": other, "sustained": sustained,
             "parity": parity, "parity_mismatches_all_ranks": total_mismatches,
         }
         print(json.dumps(line), flush=True)

@@ -169,8 +169,20 @@ int lc3gpu_decoder_state_load(lc3gpu_decoder *dec, const void *host_src, size_t 
 int lc3gpu_decoder_plc_events(lc3gpu_decoder *dec, uint64_t *out);
 
 /* ---- diagnostics -------------------------------------------------------------------------------- */
-/* encode one frame of channel 0 from host PCM and also return stage dumps:
- * dbg float[1472] = spectrum after MDCT [0,480), after SNS [480,960), after TNS [960,1440), scalars [1440,1472) */
+/* encode one frame of channel 0 from host PCM (the frame IS a frame of that channel: its state advances) and also return stage dumps,
+ * so that an encoder stage can be checked against the reference's own stage vectors (encoder/modified_dct.rs:191-337,
+ * attack_detector.rs:138-180, spectral_noise_shaping.rs:658-801, temporal_noise_shaping.rs:359-471, long_term_post_filter.rs:479-843,
+ * spectral_quantization.rs:404-480, noise_level_estimation.rs:65-137):
+ * dbg float[LC3GPU_ENC_DBG_FLOATS] = spectrum after MDCT [0,480), after SNS [480,960), after TNS [960,1440); scalars from
+ * LC3GPU_ENC_DBG_SCALARS: +0 bandwidth index, +1 attack flag, +2 ind_lf, +3 ind_hf, +4 shape_j, +5 gind, +6 / +7 TNS orders, +8 nbits_tns,
+ * +9 pitch_index, +10 pitch_present, +11 ltpf_active, +12 gg_ind, +13 lastnz_trunc, +14 nbits_lsb, +15 lsb_mode, +16 residual bits,
+ * +17 noise factor, +18 global gain, +19 nbits_spec, +20 nbits_trunc, +21 near-Nyquist flag, +22 ls_inda, +23 / +24 index_joint_j low /
+ * high 16 bits; the 64 band energies from LC3GPU_ENC_DBG_EB; the attack detector's state after the frame from LC3GPU_ENC_DBG_ATTACK
+ * (energy_last, max_energy_last, attack_pos_last, downsampled sample t-1, t-2) */
+#define LC3GPU_ENC_DBG_SCALARS 1440
+#define LC3GPU_ENC_DBG_EB 1472
+#define LC3GPU_ENC_DBG_ATTACK 1536
+#define LC3GPU_ENC_DBG_FLOATS 1600
 int lc3gpu_encode_frame_debug(lc3gpu_encoder *enc, const int16_t *samples_in, int n_samples, uint8_t *buf_out,
                               int nbytes, float *dbg);
 /* decode one frame of channel 0 (uniform handles) from host bytes like lc3gpu_decode_frame and also return stage dumps, so that a
@@ -197,7 +209,9 @@ int lc3gpu_decode_frame_debug(lc3gpu_decoder *dec, int recon_form, const uint8_t
                               float *dbg);
 /* the synthesis half alone on channel 0: `in` is a reconstructed spectrum (time_in = 0, n_in = ne: IMDCT -> LTPF -> PCM) or the
  * time samples that enter the long-term post-filter (time_in = 1, n_in = nf: LTPF -> PCM), with the frame's post-filter side
- * information and its size (nbits = 8 * nbytes selects the filter gain).  dbg as above (IMDCT and LTPF dumps). */
+ * information and its size (nbits = 8 * nbytes selects the filter gain; pitch_index 0 .. 511 as in the bitstream, LC3GPU_EINVAL otherwise).
+ * dbg as above (IMDCT and LTPF dumps).  Like lc3gpu_decode_frame_debug this ADVANCES channel 0's state (overlap memory, post-filter
+ * memories): a diagnostic call is a frame of that channel. */
 int lc3gpu_decoder_synth_debug(lc3gpu_decoder *dec, int time_in, const float *in, int n_in, int ltpf_active, int pitch_index, int nbytes,
                                int16_t *samples_out, int n_samples, float *dbg);
 /* tests only: the float routines the codec's bit-exactness rests on, evaluated on the device as the kernels compile them.
@@ -207,9 +221,11 @@ int lc3gpu_decoder_synth_debug(lc3gpu_decoder *dec, int time_in, const float *in
 int lc3gpu_selftest_math(int which, const float *x, const float *d, int n, float *out);
 /* per-kernel timing of the batch calls with HIP events recorded on the launch stream.  An encoder batch call runs four
  * kernels: analysis front half (wave per stream), SNS vector quantiser (lane per frame), analysis back half (wave per
- * stream), bitstream packing (lane per frame); a decoder batch call two or four: frame parsing (lane per frame), spectrum
- * reconstruction (full batches: two kernels of its own, wave per frame and -- for the TNS lattice -- lane per frame; small
- * launches: inside the synthesis kernel), synthesis (wave per stream).  `enable` = 0 switches recording off, 1 on for every batch call,
+ * stream), bitstream packing (lane per frame); a decoder batch call two: frame parsing with the spectrum reconstruction on the
+ * lane that parsed the frame (full batches; launches of a few frames reconstruct inside the synthesis kernel instead), synthesis
+ * (wave per stream) -- or four when LC3GPU_RECON=wave selects the measured-but-not-default form with two reconstruction kernels of
+ * their own (wave per frame and, for the TNS lattice, lane per frame).  A call of at least 32 768 frames runs as two halves of its
+ * streams on two internal HIP streams (LC3GPU_SPLIT=0 switches that off): a kernel's figure is then the sum over both launches.  `enable` = 0 switches recording off, 1 on for every batch call,
  * n > 1 on for every n-th batch call from now on (an event after every kernel costs the stream a few microseconds: sampling keeps a
  * long timed run undisturbed); the call synchronises and returns the per-kernel milliseconds accumulated since the previous call
  * followed by the number of batch calls that were timed:
@@ -226,6 +242,10 @@ int lc3gpu_decoder_timing_kernels(lc3gpu_decoder *dec, int enable, double out[5]
  * (staging, side info, TNS data, spectral data, residual bits, finish, barrier wait + copy-out), 55 = its waves.
  * LC3GPU_EUNSUPPORTED in the normal build. */
 int lc3gpu_prof_read(unsigned long long out[64]);
+/* measurement aid (bench.py's sustained leg): one wave on `stream` stamps the shader-cycle counter and the constant 100 MHz counter around
+ * `spin` dependent vector additions; asynchronous, d_out (DEVICE memory, 3 x uint64) <- {shader cycles, 100 MHz ticks, unused}.  The clock the
+ * chip runs at while the probe is in flight = 100 MHz x cycles / ticks (launch it on a stream beside the codec's). */
+int lc3gpu_clock_probe(void *stream, unsigned long long *d_out, int spin);
 /* kernel resource report: out = {lds_bytes, vgprs, sgprs, scratch_bytes, max_threads} for 0 = encoder, 1 = decoder */
 int lc3gpu_kernel_info(int which, int out[5]);
 

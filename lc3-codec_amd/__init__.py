@@ -27,6 +27,7 @@ from .api import (  # noqa: F401
     StreamDesc,
     build_native,
     build_tool,
+    clock_probe,
     device_count,
     library_path,
     load_library,

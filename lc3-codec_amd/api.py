@@ -158,6 +158,7 @@ def load_library():
     L.lc3gpu_decode_frame_debug.argtypes = [vp, i, vp, i, vp, i, vp]
     L.lc3gpu_decoder_synth_debug.argtypes = [vp, i, vp, i, i, i, i, vp, i, vp]
     L.lc3gpu_selftest_math.argtypes = [i, vp, vp, i, vp]
+    L.lc3gpu_clock_probe.argtypes = [vp, vp, i]
     _lib = L
     return L
 
@@ -172,7 +173,7 @@ ABI_SYMBOLS = [
     "lc3gpu_decoder_state_size", "lc3gpu_decoder_state_save", "lc3gpu_decoder_state_load",
     "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info", "lc3gpu_prof_read", "lc3gpu_encoder_timing", "lc3gpu_decoder_timing",
     "lc3gpu_decoder_timing_kernels", "lc3gpu_decode_frame_debug", "lc3gpu_decoder_synth_debug", "lc3gpu_selftest_math", "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
-    "lc3gpu_decode_mixed", "lc3gpu_encoder_create_spec", "lc3gpu_encoder_create_mixed_spec",
+    "lc3gpu_decode_mixed", "lc3gpu_encoder_create_spec", "lc3gpu_encoder_create_mixed_spec", "lc3gpu_clock_probe",
 ]
 
 # LC3GPU_SPEC_*: opt-in corrections of the reference's deviations from the LC3 specification (default 0 = reference behaviour)
@@ -182,6 +183,8 @@ LAYOUT_PLANAR, LAYOUT_INTERLEAVED = 0, 1
 # stage dumps of Lc3Decoder.decode_frame_debug / synth_debug (LC3GPU_DBG_*)
 DBG_INT, DBG_SPEC, DBG_IMDCT, DBG_LTPF, DBG_GAIN, DBG_TNS, DBG_FLOATS = 0, 400, 800, 1280, 1760, 2160, 2560
 RECON_LANE, RECON_LATE, RECON_WAVE = 0, 1, 2
+# stage dumps of Lc3Encoder.encode_frame_debug (LC3GPU_ENC_DBG_*)
+ENC_DBG_SCALARS, ENC_DBG_EB, ENC_DBG_ATTACK, ENC_DBG_FLOATS = 1440, 1472, 1536, 1600
 
 
 class StreamDesc(ctypes.Structure):
@@ -225,6 +228,14 @@ def selftest_math(which, x=None, d=None, n=None):
     if rc:
         raise Lc3GpuError(rc, "selftest_math")
     return out
+
+
+def clock_probe(d_out, stream=None, spin=50000):
+    """measurement aid: a one-wave kernel on `stream` leaves {shader cycles, 100 MHz ticks} of its spin in d_out (device uint64[3]);
+    asynchronous.  clock = 100 MHz x cycles / ticks"""
+    rc = load_library().lc3gpu_clock_probe(_ptr(stream), _ptr(d_out), int(spin))
+    if rc:
+        raise Lc3GpuError(rc, "clock_probe")
 
 
 def device_count():
@@ -315,7 +326,7 @@ class Lc3Encoder:
     def encode_frame_debug(self, samples_in, nbytes):
         samples_in = np.ascontiguousarray(samples_in, dtype=np.int16)
         out = np.zeros(nbytes, np.uint8)
-        dbg = np.zeros(1472, np.float32)
+        dbg = np.zeros(ENC_DBG_FLOATS, np.float32)
         rc = self._L.lc3gpu_encode_frame_debug(self._h, _ptr(samples_in), int(samples_in.size), _ptr(out), nbytes,
                                                _ptr(dbg))
         if rc:

@@ -611,26 +611,6 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_reconstruct_wave(LC3_CFG_
     LC3_SYNC();
 }
 
-// D4-D8 of ONE parsed frame by ONE wave: the body of the wave-per-FRAME kernel lc3_recon_kernel (lc3gpu.hip).  Full batches
-// run the reconstruction there, between the lane-per-frame parser (which then stops after the range decoder, as for a late
-// reconstruction) and the wave-per-stream synthesis kernel: the work is stateless from frame to frame (decoder/residual_spectrum.rs:13-39,
-// noise_filling.rs:18-56, global_gain.rs:15-25, temporal_noise_shaping.rs:24-74, spectral_noise_shaping.rs:21-151), so every frame of
-// the launch is an independent wave and the chip runs them at full occupancy instead of one lane per frame at one wave per SIMD.
-// col: the frame's plane column; in: side information, integers, residual bit mask (lc3_reconstruct_prepare_late); out: the shaped
-// f32 spectrum in place of the integers.  A frame the parser rejected (AD_OK = 0) is left alone: the synthesis kernel conceals it.
-LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_recon_frame_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int32_t *col, int nbytes) {
-    LC3_CFG_BIND;
-    lc3_plane_fetch m;
-    lc3_dec_issue_frame(c, lane, col, m, 1);
-    const int ok = lc3_dec_load_frame(c, L, lane, m, 1);
-    if (ok) {  // wave-uniform
-        lc3_dec_reconstruct_wave(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes);
-        lc3_f4 *dst = (lc3_f4 *)(col + LC3_PLANE_X);
-        for (int i = lane; i < c.ne / 4; i += LC3_WAVE) dst[i] = ((const lc3_f4 *)L.spec)[i];
-    }
-    LC3_SYNC();
-}
-
 // ------------------------------------------------------------------------------------------
 // D9: packet loss concealment (decoder/packet_loss_concealment.rs:49-85).  plc_last_good lives in HBM.
 // ------------------------------------------------------------------------------------------

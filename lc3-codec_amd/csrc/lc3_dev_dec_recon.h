@@ -1,11 +1,13 @@
-// LC3 batched decoder for MI355X -- spectrum reconstruction D4-D8 of a full batch: kernels lc3_recon_kernel (ONE WAVE PER FRAME) and
-// lc3_tns_kernel (ONE LANE PER FRAME), lc3gpu.hip.
+// LC3 batched decoder for MI355X -- spectrum reconstruction D4-D8 as kernels of its own: lc3_recon_kernel (ONE WAVE PER FRAME) and
+// lc3_tns_kernel (ONE LANE PER FRAME), lc3gpu.hip.  OPT-IN (LC3GPU_RECON=wave), not the default: measured against the reconstruction
+// on the parser's lane (lc3_reconstruct_frame, the default of full batches) it loses, 0.383 vs 0.339 ms per 65 536 frames (DESIGN
+// section 6); it is kept selectable and tested beside the other two forms.
 //
 // What DecoderChannel::decode does between the range decoder and the inverse transform (reference decoder/lc3_decoder.rs:99-133):
 // residual_spectrum::decode (decoder/residual_spectrum.rs:13-39), noise_filling::apply_noise_filling (decoder/noise_filling.rs:18-56),
 // global_gain::apply_global_gain (decoder/global_gain.rs:15-25), temporal_noise_shaping::apply_temporal_noise_shaping
 // (decoder/temporal_noise_shaping.rs:24-137) and spectral_noise_shaping::decode (decoder/spectral_noise_shaping.rs:21-235) carries
-// nothing from frame to frame.  In a full batch the lane-per-frame parser (lc3_dev_dec_parse.h) therefore stops after the range
+// nothing from frame to frame.  In this form the lane-per-frame parser (lc3_dev_dec_parse.h) stops after the range
 // decoder and the rest is split by the nature of the work:
 //   * everything that is parallel over the LINES of a frame runs one wave per frame at full occupancy (lc3_recon_frame_direct): residual
 //     bits, noise filling, global gain, scale factors, band gains.  Lane l owns lines 8l .. 8l+7; what the reference carries from line

@@ -58,6 +58,9 @@ struct __attribute__((aligned(16))) lc3_enc_lds {
     unsigned long long prof_acc[32];  // diagnostic build: per-wave stage totals, flushed once per launch
 #endif
 };
+#define LC3_ENC_DBG_EB 1472      // [64] band energies
+#define LC3_ENC_DBG_ATTACK 1536  // [5] attack detector state: energy_last, max_energy_last, attack_pos_last, downsampled t-1, t-2
+#define LC3_ENC_DBG_FLOATS 1600
 #define LC3_EB(L) ((float *)(L).fa + 512)                    // [64] band energies: MDCT stage -> bandwidth, SNS
 #define LC3_SCF(L) ((float *)(L).fa + 144)                   // [16] SNS target scale factors (lc3_enc_sns_front)
 #define LC3_XQ(L) ((L).t)                                    // int16[512] quantised spectrum, zero from ne on (from the quantiser on)
@@ -1785,7 +1788,7 @@ __device__ __forceinline__ void lc3_enc_symbols_frame(int ne, int lane, int32_t 
 //   back : E9b, E11, E17-E19  spectral shaping with the quantised gains, TNS, quantiser, residual bits, noise level
 //          -> the rest of the packer plane column
 // hist: see lc3_enc_mdct; g: the stream's state blob (LTPF rings); mid/plane == nullptr marks a shadow wave that
-// stores nothing.  dbg (optional): float[1472] stage dumps.
+// stores nothing.  dbg (optional): float[LC3_ENC_DBG_FLOATS] stage dumps (include/lc3gpu.h, lc3gpu_encode_frame_debug).
 LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const int16_t *pcm,
                                                       const int16_t *hist, lc3_enc_state *g, float *mid, int32_t *plane,
                                                       int plane_stride, int nbytes, float *dbg, int stride = 1, int hstride = 1,
@@ -1796,6 +1799,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_P
     const int near_nyquist = lc3_enc_mdct(LC3_CFG_PASS, LC3_LDS_PASS lane, pcm, hist, stride, hstride);
     LC3_STAMP(L, lane, 1);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[i] = L.spec[i];
+    if (dbg && lane < c.nb) dbg[LC3_ENC_DBG_EB + lane] = LC3_EB(L)[lane];  // the band energies (modified_dct.rs:140-152)
     int nbits_bw;
     const int bw_ind = lc3_enc_bandwidth(LC3_CFG_PASS, LC3_LDS_PASS lane, &nbits_bw);
     LC3_STAMP(L, lane, 24);
@@ -1814,6 +1818,10 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_P
         float *d = dbg + 1440;
         d[0] = (float)bw_ind; d[1] = (float)attack; d[9] = (float)pf.pitch_index; d[10] = (float)pf.pitch_present;
         d[11] = (float)pf.ltpf_active; d[21] = (float)near_nyquist;
+        // the attack detector's state after this frame (attack_detector.rs:17-21)
+        float *a = dbg + LC3_ENC_DBG_ATTACK;
+        a[0] = L.st.att_energy_last; a[1] = L.st.att_max_energy_last; a[2] = (float)L.st.att_pos_last;
+        a[3] = (float)L.st.att_ds_tm1; a[4] = (float)L.st.att_ds_tm2;
     }
     if (plane && mid && lane == 0) {
         const int st = plane_stride;
@@ -1916,6 +1924,8 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PA
         d[12] = (float)spec.gg_ind; d[13] = (float)spec.lastnz_trunc;
         d[14] = (float)spec.nbits_lsb; d[15] = (float)spec.lsb_mode; d[16] = (float)n_res; d[17] = (float)noise_factor;
         d[18] = spec.gg; d[19] = (float)spec.nbits_spec; d[20] = (float)spec.nbits_trunc;
+        const uint32_t joint = (uint32_t)plane[EP_JOINT * st];  // (up to 25 bits: as two exact halves)
+        d[22] = (float)plane[EP_LS_INDA * st]; d[23] = (float)(joint & 0xffffu); d[24] = (float)(joint >> 16);
     }
     // E20/E21 run as a separate lane-per-frame stage (lc3_dev_enc_pack.h): leave this frame's plane column in HBM
     if (store) {

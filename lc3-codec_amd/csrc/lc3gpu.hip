@@ -1092,16 +1092,27 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
 struct KernelTimer {
     bool enabled = false;
     std::vector<hipEvent_t> pool;  // every event ever created for this handle
-    std::vector<int8_t> slot;      // per recorded mark: the ms[] slot of the interval that ENDS at it, -1 for the first mark of a call
+    std::vector<int8_t> slot;      // per recorded mark: the ms[] slot of the interval that ENDS at it, -1 for the first mark of a chain
+    std::vector<int32_t> prev;     // per recorded mark: the mark its interval STARTS at (the one before it on the same HIP stream), -1: none
     size_t used = 0;               // events of the pool holding a recorded mark
+    size_t call_start = 0;         // `used` when the current call began
+    int last[3] = {-1, -1, -1};    // per chain of the current call (0: the caller's stream, 1 / 2: the handle's internal streams): its latest mark
     double ms[4] = {0.0, 0.0, 0.0, 0.0};
-    long launches = 0;
+    long launches = 0;             // batch calls that were timed
     int period = 1;                // every period-th batch call is timed (an event after every kernel costs the stream ~4 us each)
     long calls = 0;
     bool active = false;           // the current call is one of them
-    // first mark of a batch call: begin(stream); after every kernel: mark(stream, slot of that kernel)
-    void begin(hipStream_t s) {
+    // a batch call: arm(); then per HIP stream it launches on (chain), mark(stream, -1, chain) before its first kernel there and
+    // mark(stream, slot of that kernel, chain) after every kernel.  begin(stream) = arm + the first mark of chain 0.
+    bool arm() {
         active = enabled && (calls++ % (long)period) == 0;
+        call_start = used;
+        last[0] = last[1] = last[2] = -1;
+        if (active) launches += 1;
+        return active;
+    }
+    void begin(hipStream_t s) {
+        arm();
         mark(s, -1);
     }
     void set(int enable) {
@@ -1110,36 +1121,48 @@ struct KernelTimer {
         calls = 0;
         active = false;
     }
-    void mark(hipStream_t s, int sl) {
+    void mark(hipStream_t s, int sl, int chain = 0) {
         if (!active) return;
         if (used == pool.size()) {
             hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return;
+            if (hipEventCreate(&e) != hipSuccess) {  // no event: this call is not timed at all (a dropped mark would charge the
+                (void)hipGetLastError();             // next interval, spanning two kernels, to the wrong slot)
+                rollback(call_start);
+                return;
+            }
             pool.push_back(e);
             slot.push_back(0);
+            prev.push_back(-1);
         }
         slot[used] = (int8_t)sl;
+        prev[used] = sl < 0 ? -1 : last[chain];
+        last[chain] = (int)used;
         (void)hipEventRecord(pool[used++], s);
     }
     // a call failed after its first mark: forget the marks it recorded (the events stay in the pool)
-    void rollback(size_t to) { if (to <= used) used = to; }
+    void rollback(size_t to) {
+        if (to > used) return;
+        if (active) launches -= 1;
+        active = false;
+        used = to;
+    }
     // synchronises; folds the recorded intervals into ms[] and returns the events to the pool
     void collect() {
-        if (used) (void)hipEventSynchronize(pool[used - 1]);
+        for (size_t i = used; i-- > 0;) (void)hipEventSynchronize(pool[i]);
         for (size_t i = 0; i < used; i++) {
-            if (slot[i] < 0) {
-                launches += 1;
-                continue;
-            }
+            if (slot[i] < 0 || prev[i] < 0) continue;
             float d = 0.f;
-            if (i > 0 && hipEventElapsedTime(&d, pool[i - 1], pool[i]) == hipSuccess) ms[slot[i]] += d;
+            if (hipEventElapsedTime(&d, pool[(size_t)prev[i]], pool[i]) == hipSuccess) ms[slot[i]] += d;
         }
         used = 0;
+        call_start = 0;
+        active = false;
     }
     void release() {
         for (hipEvent_t e : pool) (void)hipEventDestroy(e);
         pool.clear();
         slot.clear();
+        prev.clear();
         used = 0;
     }
 };
@@ -1189,32 +1212,67 @@ struct HandleCommon {
     hipStream_t last_stream = nullptr;
     hipEvent_t done = nullptr;
     bool has_work = false;
+    // The split path (lc3_split_parts): a batch call of a full batch runs as two halves of its streams on two internal HIP streams,
+    // forked from and joined to the caller's stream by events, so that the lane-per-frame kernels of one half (one wave per SIMD, a
+    // third of its issue slots idle) run beside the wave-per-stream kernels of the other.
+    hipStream_t sub[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_stage = nullptr, ev_join[2] = {nullptr, nullptr};
+    bool last_split = false;  // the handle's latest work ended on the internal streams (ev_join), not on last_stream (done)
 
     // A handle's launches share its scratch planes and its state blobs: a call on another stream than the previous one waits for
-    // everything queued on that stream so far.  The event is recorded only then (on the previous stream, when the streams differ): a
-    // caller that stays on one stream pays no event per call (~3 us of stream time each).  Should the previous stream have been
-    // destroyed in the meantime, its work is waited for device-wide.
+    // everything the handle has queued so far.  What stands for "so far" is an event the HANDLE owns, recorded when the work was
+    // queued (`done` on the caller's stream, or the two join events of the split path): the caller's stream of an earlier call is never
+    // touched again, it may have been destroyed or its address reused since.
     int order_begin(hipStream_t s) {
         if (has_work && s != last_stream) {
-            if (hipEventRecord(done, last_stream) == hipSuccess) HIP_TRY(hipStreamWaitEvent(s, done, 0));
-            else {
-                (void)hipGetLastError();
-                HIP_TRY(hipDeviceSynchronize());
-            }
+            if (last_split) {
+                HIP_TRY(hipStreamWaitEvent(s, ev_join[0], 0));
+                HIP_TRY(hipStreamWaitEvent(s, ev_join[1], 0));
+            } else HIP_TRY(hipStreamWaitEvent(s, done, 0));
         }
         return LC3GPU_OK;
     }
-    int order_end(hipStream_t s) {
+    int order_end(hipStream_t s, bool split = false) {
+        if (!split) HIP_TRY(hipEventRecord(done, s));  // (the split path has recorded its join events)
         last_stream = s;
+        last_split = split;
         has_work = true;
         return LC3GPU_OK;
     }
     // host waits for everything the handle has launched
     int quiesce() {
-        if (has_work && hipStreamSynchronize(last_stream) != hipSuccess) {
-            (void)hipGetLastError();
-            HIP_TRY(hipDeviceSynchronize());
+        if (!has_work) return LC3GPU_OK;
+        if (last_split) {
+            HIP_TRY(hipEventSynchronize(ev_join[0]));
+            HIP_TRY(hipEventSynchronize(ev_join[1]));
+        } else HIP_TRY(hipEventSynchronize(done));
+        return LC3GPU_OK;
+    }
+    // the internal streams and events of the split path, created at its first use
+    int ensure_split() {
+        if (sub[0]) return LC3GPU_OK;
+        hipStream_t a = nullptr, b = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipStreamDestroy(a);
+            g_last_hip = (int)hipGetLastError();
+            return LC3GPU_EHIP;
         }
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int i = 0; i < 4; i++)
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+                g_last_hip = (int)hipGetLastError();
+                for (int j = 0; j < i; j++) (void)hipEventDestroy(ev[j]);
+                (void)hipStreamDestroy(a);
+                (void)hipStreamDestroy(b);
+                return LC3GPU_EHIP;
+            }
+        sub[0] = a;
+        sub[1] = b;
+        ev_fork = ev[0];
+        ev_stage = ev[1];
+        ev_join[0] = ev[2];
+        ev_join[1] = ev[3];
         return LC3GPU_OK;
     }
     const HostCfg &cfg_of_channel(int ch) const { return mixed ? groups[(size_t)streams[(size_t)ch].group].h : h; }
@@ -1223,7 +1281,12 @@ struct HandleCommon {
         timer.release();
         if (done) (void)hipEventDestroy(done);
         if (d_tab) (void)hipFree(d_tab);
-        done = nullptr;
+        for (hipEvent_t ev : {ev_fork, ev_stage, ev_join[0], ev_join[1]})
+            if (ev) (void)hipEventDestroy(ev);
+        for (hipStream_t st : sub)
+            if (st) (void)hipStreamDestroy(st);
+        done = ev_fork = ev_stage = ev_join[0] = ev_join[1] = nullptr;
+        sub[0] = sub[1] = nullptr;
         d_tab = nullptr;
     }
 };
@@ -1421,6 +1484,8 @@ static int lc3_recon_mode(size_t n_frames_total, int frames_per_stream) {
 // the TNS kernels use more than the default 64 KB of dynamic LDS: opt in once per device (every instantiation)
 static int lc3_tns_lds_optin() {
     static bool done[LC3_MAX_DEVICES] = {};
+    static std::mutex mu;  // handles of different host threads may reach this at the same time
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= LC3_MAX_DEVICES) return LC3GPU_EINVAL;
@@ -1600,7 +1665,7 @@ static int encoder_alloc(lc3gpu_encoder *e) {
     // staging of the *_frame calls: pinned host memory the kernels read / write in place (no copy engine round trips)
     HIP_TRY(hipHostMalloc((void **)&e->d_pcm1, sizeof(int16_t) * LC3_MAX_NF, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&e->d_out1, LC3_MAX_NE, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&e->d_dbg, sizeof(float) * 1472));
+    HIP_TRY(hipMalloc((void **)&e->d_dbg, sizeof(float) * LC3_ENC_DBG_FLOATS));
     e->fresh_mask.assign((size_t)e->num_channels, 1);
     return encoder_reserve_planes(e, (size_t)e->num_channels, nullptr);
 }
@@ -1693,6 +1758,74 @@ static int encoder_materialise(lc3gpu_encoder *e, int first, int n, hipStream_t 
     return LC3GPU_OK;
 }
 
+// How a batch call of a uniform handle is split over the handle's two internal HIP streams.  A launch of 65 536 frames gives every SIMD
+// exactly ONE wave of the lane-per-frame kernels (vector quantiser, packer, parser), and a lone wave leaves a third of the SIMD's issue
+// slots idle; run as two halves, the lane-per-frame kernels of one half share the chip with the wave-per-stream
+// kernels of the other.  -> number of parts (1 or 2).  LC3GPU_SPLIT=0 never splits, LC3GPU_SPLIT=1 splits every launch of at least 16
+// streams (tests), default: launches of at least 32 768 frames.
+static int lc3_split_parts(size_t frames, int n_streams) {
+    static const int forced = [] {
+        const char *e = std::getenv("LC3GPU_SPLIT");
+        return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
+    }();
+    if (n_streams < 4 * LC3_WG_WAVES || forced == 0) return 1;
+    return (forced == 1 || frames >= 32768) ? 2 : 1;
+}
+// first stream of the second half: whole workgroups of the stream kernels, whole waves of the frame kernels where the launch allows
+static int lc3_split_point(int n_streams, int n_frames) {
+    int a = n_streams / 2;
+    const int unit = (a >= 64 && ((size_t)a * (size_t)n_frames) >= 4096) ? 64 : LC3_WG_WAVES;
+    a = (a + unit - 1) / unit * unit;
+    return a < n_streams ? a : n_streams / 2 / LC3_WG_WAVES * LC3_WG_WAVES;
+}
+// where the second half's first kernel is held back to (LC3GPU_SPLIT_STAGGER, tuning aid): 0 nothing, 1 (default) until the first
+// half's first kernel has finished -- both halves' wave-per-stream kernels side by side would only share the chip between them
+static int lc3_split_stagger() {
+    static const int v = [] {
+        const char *e = std::getenv("LC3GPU_SPLIT_STAGGER");
+        return e ? std::atoi(e) : 1;
+    }();
+    return v;
+}
+
+// the four encoder kernels of channels [first, first + n) (internal order) on `stream`; the buffers and planes are those of this range.
+// chain: the timer's chain of this stream.  after_front: recorded behind the front half when not null
+static int encode_kernels(lc3gpu_encoder *e, const HostCfg &h, int first, int n, const int16_t *d_pcm, uint8_t *d_out, float *mid,
+                          int32_t *planes, int nbytes, int n_frames, int fresh, lc3_io io, hipStream_t stream, int chain,
+                          hipEvent_t after_front, float *dbg, size_t frames_of_call) {
+    const size_t frames = (size_t)n * (size_t)n_frames;
+    // analysis front half (wave per stream) -> SNS vector quantiser (lane per frame) -> back half (wave per stream) ->
+    // bitstream packing (lane per frame)
+    const dim3 wg_grid((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), wg_block(64 * LC3_WG_WAVES);
+    e->timer.mark(stream, -1, chain);
+    LC3_LAUNCH_CFG(lc3_enc_front_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n, d_pcm, mid, planes, nbytes, n_frames, fresh,
+                   dbg, io, e->spec_flags);
+    HIP_TRY(hipGetLastError());
+    e->timer.mark(stream, 0, chain);
+    if (after_front) HIP_TRY(hipEventRecord(after_front, stream));
+    hipLaunchKernelGGL(lc3_sns_vq_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, stream, h.c.nb, mid, planes, (int)frames,
+                       e->spec_flags);
+    HIP_TRY(hipGetLastError());
+    e->timer.mark(stream, 1, chain);
+    LC3_LAUNCH_CFG(lc3_enc_back_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n, (const float *)mid, planes, nbytes, n_frames,
+                   dbg, e->spec_flags | lc3_prep_symbols_flag(frames_of_call));
+    HIP_TRY(hipGetLastError());
+    e->timer.mark(stream, 2, chain);
+    if (lc3_prep_symbols_mode(frames_of_call) == 2) {  // (timed together with the packer)
+        const size_t wgs = (frames + LC3_WG_WAVES - 1) / LC3_WG_WAVES;
+        LC3_LAUNCH_CFG(lc3_symbols_kernel, h, dim3((unsigned)(wgs < lc3_recon_grid() ? wgs : lc3_recon_grid())), dim3(64 * LC3_WG_WAVES), 0, stream,
+                       planes, (int)frames);
+        HIP_TRY(hipGetLastError());
+    }
+    const unsigned fpb = lc3_frame_block_fit(LC3_PACK_LDS_FIXED, (size_t)nbytes);
+    const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3) + 4;  // + the packer's sink byte
+    hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, h.c.ne, (const int32_t *)planes,
+                       d_out, nbytes, (int)frames, n_frames, io);
+    HIP_TRY(hipGetLastError());
+    e->timer.mark(stream, 3, chain);
+    return LC3GPU_OK;
+}
+
 // one configuration, channels [first, first + n) in internal order; the buffers hold only those channels
 static int encode_launch(lc3gpu_encoder *e, const HostCfg &h, int first, int n, const int16_t *d_pcm, uint8_t *d_out, int nbytes,
                          int n_frames, int layout, hipStream_t stream, float *dbg) {
@@ -1702,8 +1835,15 @@ static int encode_launch(lc3gpu_encoder *e, const HostCfg &h, int first, int n, 
     if (layout != LC3GPU_LAYOUT_PLANAR && layout != LC3GPU_LAYOUT_INTERLEAVED) return LC3GPU_EINVAL;
     if (layout == LC3GPU_LAYOUT_PLANAR ? ((uintptr_t)d_pcm & 3u) != 0 : ((uintptr_t)d_pcm & 1u) != 0) return LC3GPU_EINVAL;
     const size_t frames = (size_t)n * (size_t)n_frames;
+    const int nf = h.c.nf;
+    int parts = dbg ? 1 : lc3_split_parts(frames, n);
+    const int na = parts == 2 ? lc3_split_point(n, n_frames) : n;
+    // planar PCM is read as 32-bit words: the second half starts na * n_frames * nf samples in (nf is even), its bytes are copied out as
+    // words when aligned and as bytes otherwise
+    if (parts == 2 && (na <= 0 || na >= n)) parts = 1;
     int rc = e->order_begin(stream);
     if (rc == LC3GPU_OK) rc = encoder_reserve_planes(e, frames, stream);
+    if (rc == LC3GPU_OK && parts == 2) rc = e->ensure_split();
     if (rc) return rc;
     // a range is launched "fresh" only if every channel in it is still fresh
     int fresh = 1;
@@ -1713,37 +1853,47 @@ static int encode_launch(lc3gpu_encoder *e, const HostCfg &h, int first, int n, 
         if (rc) return rc;
     }
     lc3_io io = {layout == LC3GPU_LAYOUT_INTERLEAVED ? n : 0, nullptr};
-    // analysis front half (wave per stream) -> SNS vector quantiser (lane per frame) -> back half (wave per stream) ->
-    // bitstream packing (lane per frame)
-    const dim3 wg_grid((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), wg_block(64 * LC3_WG_WAVES);
     const size_t t0 = e->timer.used;
-    e->timer.begin(stream);
-    LC3_LAUNCH_CFG(lc3_enc_front_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n, d_pcm, e->d_mid,
-                       e->d_planes, nbytes, n_frames, fresh, dbg, io, e->spec_flags);
-    LC3_LAUNCH_CHECK(e, stream, t0);
-    e->timer.mark(stream, 0);
-    hipLaunchKernelGGL(lc3_sns_vq_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, stream, h.c.nb, e->d_mid,
-                       e->d_planes, (int)frames, e->spec_flags);
-    LC3_LAUNCH_CHECK(e, stream, t0);
-    e->timer.mark(stream, 1);
-    LC3_LAUNCH_CFG(lc3_enc_back_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n,
-                       (const float *)e->d_mid, e->d_planes, nbytes, n_frames, dbg, e->spec_flags | lc3_prep_symbols_flag(frames));
-    LC3_LAUNCH_CHECK(e, stream, t0);
-    e->timer.mark(stream, 2);
-    if (lc3_prep_symbols_mode(frames) == 2) {  // (timed together with the packer)
-        const size_t wgs = (frames + LC3_WG_WAVES - 1) / LC3_WG_WAVES;
-        LC3_LAUNCH_CFG(lc3_symbols_kernel, h, dim3((unsigned)(wgs < lc3_recon_grid() ? wgs : lc3_recon_grid())), dim3(64 * LC3_WG_WAVES), 0, stream,
-                       e->d_planes, (int)frames);
-        LC3_LAUNCH_CHECK(e, stream, t0);
+    e->timer.arm();
+    if (parts == 1) {
+        rc = encode_kernels(e, h, first, n, d_pcm, d_out, e->d_mid, e->d_planes, nbytes, n_frames, fresh, io, stream, 0, nullptr, dbg, frames);
+    } else {
+        // two halves [first, first + na) and [first + na, first + n) on the handle's streams: fork behind everything the caller's stream
+        // holds so far, join back into it
+        rc = LC3GPU_OK;
+        if (hipEventRecord(e->ev_fork, stream) != hipSuccess || hipStreamWaitEvent(e->sub[0], e->ev_fork, 0) != hipSuccess ||
+            hipStreamWaitEvent(e->sub[1], e->ev_fork, 0) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError();
+            rc = LC3GPU_EHIP;
+        }
+        const size_t fa = (size_t)na * (size_t)n_frames;
+        const bool ilv = layout == LC3GPU_LAYOUT_INTERLEAVED;
+        const int stagger = lc3_split_stagger();
+        if (rc == LC3GPU_OK)
+            rc = encode_kernels(e, h, first, na, d_pcm, d_out, e->d_mid, e->d_planes, nbytes, n_frames, fresh, io, e->sub[0], 1,
+                                stagger == 1 ? e->ev_stage : nullptr, nullptr, frames);
+        if (rc == LC3GPU_OK && stagger == 1 && hipStreamWaitEvent(e->sub[1], e->ev_stage, 0) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError();
+            rc = LC3GPU_EHIP;
+        }
+        if (rc == LC3GPU_OK)
+            rc = encode_kernels(e, h, first + na, n - na, ilv ? d_pcm + na : d_pcm + fa * (size_t)nf, ilv ? d_out + (size_t)na * (size_t)nbytes : d_out + fa * (size_t)nbytes,
+                                e->d_mid + fa * (size_t)MP_WORDS, e->d_planes + fa * (size_t)EP_WORDS, nbytes, n_frames, fresh, io, e->sub[1], 2,
+                                nullptr, nullptr, frames);
+        // whatever was queued, the caller's stream (and the handle's next call) orders behind it
+        for (int i = 0; i < 2; i++)
+            if (hipEventRecord(e->ev_join[i], e->sub[i]) != hipSuccess || hipStreamWaitEvent(stream, e->ev_join[i], 0) != hipSuccess) {
+                g_last_hip = (int)hipGetLastError();
+                if (rc == LC3GPU_OK) rc = LC3GPU_EHIP;
+            }
     }
-    const unsigned fpb = lc3_frame_block_fit(LC3_PACK_LDS_FIXED, (size_t)nbytes);
-    const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3) + 4;  // + the packer's sink byte
-    hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, h.c.ne,
-                       (const int32_t *)e->d_planes, d_out, nbytes, (int)frames, n_frames, io);
-    LC3_LAUNCH_CHECK(e, stream, t0);
-    e->timer.mark(stream, 3);
+    if (rc) {
+        e->timer.rollback(t0);
+        (void)e->order_end(stream, parts == 2);
+        return rc;
+    }
     for (int i = first; i < first + n; i++) e->fresh_mask[(size_t)i] = 0;
-    return e->order_end(stream);
+    return e->order_end(stream, parts == 2);
 }
 
 int lc3gpu_encode_layout(lc3gpu_encoder *e, int layout, const int16_t *d_pcm, uint8_t *d_out, int nbytes, int n_frames, void *stream) {
@@ -1833,7 +1983,7 @@ static int encode_frame_host(lc3gpu_encoder *e, int channel_index, const int16_t
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(nullptr));
     std::memcpy(buf_out, e->d_out1, (size_t)nbytes);
-    if (dbg) HIP_TRY(hipMemcpy(dbg, e->d_dbg, sizeof(float) * 1472, hipMemcpyDeviceToHost));
+    if (dbg) HIP_TRY(hipMemcpy(dbg, e->d_dbg, sizeof(float) * LC3_ENC_DBG_FLOATS, hipMemcpyDeviceToHost));
     return LC3GPU_OK;
 }
 
@@ -1956,6 +2106,42 @@ int lc3gpu_decoder_reset(lc3gpu_decoder *d) {
     return decoder_init_states(d);
 }
 
+// the decoder kernels of channels [first, first + n) (internal order) on `stream`; buffers, flags and planes are those of this range
+static int decode_kernels(lc3gpu_decoder *d, const HostCfg &h, int first, int n, const uint8_t *d_in, const uint8_t *d_bad, int16_t *d_pcm,
+                          int32_t *planes, int nbytes, int n_frames, lc3_io io, int mode, hipStream_t stream, int chain) {
+    // stage 1: parse all n * n_frames frames, one lane each (stateless); stage 2: synthesis, one wave per stream
+    const size_t frames = (size_t)n * (size_t)n_frames;
+    // frames per workgroup: as many as fit the default 64 KB of dynamic LDS (tables + 64 B of scale factors and nbytes of
+    // frame data per frame)
+    const unsigned fpb = lc3_frame_block_fit(LC3_PARSE_LDS_FIXED, (size_t)(64 + nbytes));
+    const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes);
+    d->timer.mark(stream, -1, chain);
+    LC3_LAUNCH_CFG(lc3_parse_kernel, h, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, d_in, d_bad, planes, nbytes,
+                   (int)frames, n_frames, io, mode);
+    HIP_TRY(hipGetLastError());
+    d->timer.mark(stream, 0, chain);
+    if (mode == LC3_RECON_WAVE) {
+        const size_t wgs = (frames + LC3_WG_WAVES - 1) / LC3_WG_WAVES;
+        LC3_LAUNCH_CFG(lc3_recon_kernel, h, dim3((unsigned)(wgs < lc3_recon_grid() ? wgs : lc3_recon_grid())), dim3(64 * LC3_WG_WAVES), 0, stream,
+                       planes, nbytes, (int)frames);
+        HIP_TRY(hipGetLastError());
+        d->timer.mark(stream, 1, chain);
+        LC3_LAUNCH_CFG(lc3_tns_kernel, h, dim3((unsigned)((frames + LC3_TNS_FPB - 1) / LC3_TNS_FPB)), dim3(LC3_TNS_FPB), LC3_TNS_LDS, stream,
+                       planes, (int)frames);
+        HIP_TRY(hipGetLastError());
+        d->timer.mark(stream, 2, chain);
+    }
+    if (mode == LC3_RECON_LATE)
+        LC3_LAUNCH_CFG(lc3_decode_late_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0,
+                       stream, d->d_states, first, n, (const int32_t *)planes, d_pcm, nbytes, n_frames, 0, io);
+    else
+        LC3_LAUNCH_CFG(lc3_decode_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0, stream,
+                       d->d_states, first, n, (const int32_t *)planes, d_pcm, nbytes, n_frames, 0, io);
+    HIP_TRY(hipGetLastError());
+    d->timer.mark(stream, 3, chain);
+    return LC3GPU_OK;
+}
+
 static int decode_launch(lc3gpu_decoder *d, const HostCfg &h, int first, int n, const uint8_t *d_in, const uint8_t *d_bad,
                          int16_t *d_pcm, int nbytes, int n_frames, int layout, hipStream_t stream) {
     if (!d || !d_in || !d_pcm) return LC3GPU_EINVAL;
@@ -1963,46 +2149,49 @@ static int decode_launch(lc3gpu_decoder *d, const HostCfg &h, int first, int n, 
     if (nbytes < 1 || nbytes > LC3_MAX_NE || n_frames <= 0) return LC3GPU_ELENGTH;
     if (layout != LC3GPU_LAYOUT_PLANAR && layout != LC3GPU_LAYOUT_INTERLEAVED) return LC3GPU_EINVAL;
     if (layout == LC3GPU_LAYOUT_PLANAR ? ((uintptr_t)d_pcm & 3u) != 0 : ((uintptr_t)d_pcm & 1u) != 0) return LC3GPU_EINVAL;
-    // stage 1: parse all n * n_frames frames, one lane each (stateless); stage 2: synthesis, one wave per stream
     const size_t frames = (size_t)n * (size_t)n_frames;
+    const int nf = h.c.nf;
+    int parts = lc3_split_parts(frames, n);
+    const int na = parts == 2 ? lc3_split_point(n, n_frames) : n;
+    if (parts == 2 && (na <= 0 || na >= n)) parts = 1;
     int rc = d->order_begin(stream);
     if (rc == LC3GPU_OK) rc = decoder_reserve_planes(d, frames, stream);
+    if (rc == LC3GPU_OK && parts == 2) rc = d->ensure_split();
     if (rc) return rc;
     lc3_io io = {layout == LC3GPU_LAYOUT_INTERLEAVED ? n : 0, nullptr};
-    // frames per workgroup: as many as fit the default 64 KB of dynamic LDS (tables + 64 B of scale factors and nbytes of
-    // frame data per frame)
-    const unsigned fpb = lc3_frame_block_fit(LC3_PARSE_LDS_FIXED, (size_t)(64 + nbytes));
-    const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes);
     const int mode = lc3_recon_mode(frames, n_frames);
     if (mode == LC3_RECON_WAVE && (rc = lc3_tns_lds_optin()) != LC3GPU_OK) return rc;
     const size_t t0 = d->timer.used;
-    d->timer.begin(stream);
-    LC3_LAUNCH_CFG(lc3_parse_kernel, h, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream,
-                       d_in, d_bad, d->d_planes, nbytes, (int)frames, n_frames, io, mode);
-    LC3_LAUNCH_CHECK(d, stream, t0);
-    d->timer.mark(stream, 0);
-    if (mode == LC3_RECON_WAVE) {
-        const size_t wgs = (frames + LC3_WG_WAVES - 1) / LC3_WG_WAVES;
-        LC3_LAUNCH_CFG(lc3_recon_kernel, h, dim3((unsigned)(wgs < lc3_recon_grid() ? wgs : lc3_recon_grid())), dim3(64 * LC3_WG_WAVES), 0, stream,
-                       d->d_planes, nbytes, (int)frames);
-        LC3_LAUNCH_CHECK(d, stream, t0);
-        d->timer.mark(stream, 1);
+    d->timer.arm();
+    if (parts == 1) {
+        rc = decode_kernels(d, h, first, n, d_in, d_bad, d_pcm, d->d_planes, nbytes, n_frames, io, mode, stream, 0);
+    } else {
+        rc = LC3GPU_OK;
+        if (hipEventRecord(d->ev_fork, stream) != hipSuccess || hipStreamWaitEvent(d->sub[0], d->ev_fork, 0) != hipSuccess ||
+            hipStreamWaitEvent(d->sub[1], d->ev_fork, 0) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError();
+            rc = LC3GPU_EHIP;
+        }
+        const size_t fa = (size_t)na * (size_t)n_frames;
+        const bool ilv = layout == LC3GPU_LAYOUT_INTERLEAVED;
+        if (rc == LC3GPU_OK)
+            rc = decode_kernels(d, h, first, na, d_in, d_bad, d_pcm, d->d_planes, nbytes, n_frames, io, mode, d->sub[0], 1);
+        if (rc == LC3GPU_OK)
+            rc = decode_kernels(d, h, first + na, n - na, ilv ? d_in + (size_t)na * (size_t)nbytes : d_in + fa * (size_t)nbytes,
+                                d_bad ? (ilv ? d_bad + na : d_bad + fa) : nullptr, ilv ? d_pcm + na : d_pcm + fa * (size_t)nf,
+                                d->d_planes + fa * (size_t)LC3_PLANE_WORDS, nbytes, n_frames, io, mode, d->sub[1], 2);
+        for (int i = 0; i < 2; i++)
+            if (hipEventRecord(d->ev_join[i], d->sub[i]) != hipSuccess || hipStreamWaitEvent(stream, d->ev_join[i], 0) != hipSuccess) {
+                g_last_hip = (int)hipGetLastError();
+                if (rc == LC3GPU_OK) rc = LC3GPU_EHIP;
+            }
     }
-    if (mode == LC3_RECON_WAVE) {
-        LC3_LAUNCH_CFG(lc3_tns_kernel, h, dim3((unsigned)((frames + LC3_TNS_FPB - 1) / LC3_TNS_FPB)), dim3(LC3_TNS_FPB), LC3_TNS_LDS, stream,
-                       d->d_planes, (int)frames);
-        LC3_LAUNCH_CHECK(d, stream, t0);
-        d->timer.mark(stream, 2);
+    if (rc) {
+        d->timer.rollback(t0);
+        (void)d->order_end(stream, parts == 2);
+        return rc;
     }
-    if (mode == LC3_RECON_LATE)
-        LC3_LAUNCH_CFG(lc3_decode_late_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0,
-                       stream, d->d_states, first, n, (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0, io);
-    else
-        LC3_LAUNCH_CFG(lc3_decode_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0, stream,
-                       d->d_states, first, n, (const int32_t *)d->d_planes, d_pcm, nbytes, n_frames, 0, io);
-    LC3_LAUNCH_CHECK(d, stream, t0);
-    d->timer.mark(stream, 3);
-    return d->order_end(stream);
+    return d->order_end(stream, parts == 2);
 }
 
 int lc3gpu_decode_layout(lc3gpu_decoder *d, int layout, const uint8_t *d_in, const uint8_t *d_bad, int16_t *d_pcm, int nbytes,
@@ -2157,6 +2346,7 @@ int lc3gpu_decoder_synth_debug(lc3gpu_decoder *d, int time_in, const float *in, 
     const HostCfg &h = d->h;
     if (n_samples != h.c.nf || n_in != (time_in ? h.c.nf : h.c.ne)) return LC3GPU_ELENGTH;
     if (nbytes < 1 || nbytes > LC3_MAX_NE) return LC3GPU_ELENGTH;
+    if (pitch_index < 0 || pitch_index > 511) return LC3GPU_EINVAL;  // nine bits in the bitstream (side_info_reader.rs:106-129): the post-filter derives lags and table rows from it
     LC3_ON_DEVICE(d);
     int rc = d->quiesce();
     if (rc == LC3GPU_OK) rc = decoder_reserve_planes(d, 1, nullptr);
@@ -2311,6 +2501,32 @@ int lc3gpu_selftest_math(int which, const float *x, const float *d, int n, float
         g_last_hip = (int)e;
         return LC3GPU_EHIP;
     }
+    return LC3GPU_OK;
+}
+
+// Measurement aid: the shader clock the chip is running at right now.  One wave stamps the shader-cycle counter (s_memtime) and the
+// constant 100 MHz counter (s_memrealtime), spins through `spin` dependent vector additions and stamps both again; the clock is
+// delta(s_memtime) / delta(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back, item 6).  Launched on a stream of its own
+// beside the codec's kernels it reads the clock THEY run at (one wave of one SIMD: it takes nothing measurable from them).
+__global__ void lc3_clock_probe_kernel(unsigned long long *out, int spin) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned v = threadIdx.x;
+    for (int i = 0; i < spin; i++) {
+        v += 0x9e3779b9u;
+        asm volatile("" : "+v"(v));
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+    if (v == 0x12345u && spin < 0) out[2] = v;  // (keeps the loop)
+}
+// asynchronous on `stream`: d_out (DEVICE, 2 x uint64) <- {shader cycles, 100 MHz ticks} over the probe's spin (~0.1 ms at spin = 50 000)
+int lc3gpu_clock_probe(void *stream, unsigned long long *d_out, int spin) {
+    if (!d_out || spin <= 0) return LC3GPU_EINVAL;
+    hipLaunchKernelGGL(lc3_clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_out, spin);
+    HIP_TRY(hipGetLastError());
     return LC3GPU_OK;
 }
 

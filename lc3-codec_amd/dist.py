@@ -17,9 +17,11 @@ def shard_range(total_streams, world, rank):
     return lo, hi
 
 
-def reduce_report(dist, device, elapsed_s, frames, mismatches=0, plc_events=0):
-    """-> (max elapsed over ranks, total frames, total mismatches, total plc events); dist may be None (1 rank)"""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def reduce_report(dist, device, elapsed_s, frames, mismatches=0, plc_events=0, force=False):
+    """-> (max elapsed over ranks, total frames, total mismatches, total plc events); dist may be None (1 rank).
+    force: run the two all_reduce calls even in a group of one rank (the RCCL bring-up check: library load, communicator, reduction
+    on device tensors -- tests/test_gpu_parity.py::test_rccl_world_size_one, bench.py with LC3_BENCH_RCCL=1)"""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return float(elapsed_s), int(frames), int(mismatches), int(plc_events)
     import torch
 

@@ -5,6 +5,7 @@
  * examples/encode.rs:105-115).  Streams are distributed over host threads. */
 #include "lc3_oracle.h"
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -105,11 +106,14 @@ int lc3o_decode_batch(int fs_hz, int frame_us, int nbytes, int n_streams, int n_
  * region.  pcm: int16[n_distinct][n_frames][nf]; thread t codes streams t, t + 1, ... (mod n_distinct), one per pass.
  * Out: total frames coded (an encode+decode pair counts once) and the time from the barrier to the last thread's finish. */
 typedef struct {
+    volatile int ready;  /* workers that have allocated and initialised */
+    volatile int go;     /* 0: wait, 1: run, -1: a worker could not be created -- leave without working */
+} start_gate;
+typedef struct {
     int fs_hz, frame_us, nbytes, n_frames, nf, roundtrip, rc, first, n_distinct;
     const int16_t *pcm;
-    double seconds, frames, t_end;
-    pthread_barrier_t *bar;
-    double *t_start;
+    double seconds, frames, t_start, t_end;
+    start_gate *gate;
 } tjob;
 
 static double now_s(void) {
@@ -128,12 +132,15 @@ static void *timed_worker(void *arg) {
     double t0, deadline;
     if (!e || !d || !bytes || !out || lc3o_encoder_init_spec(e, j->fs_hz, j->frame_us, 0) || lc3o_decoder_init(d, j->fs_hz, j->frame_us))
         j->rc = -1;
-    memset(bytes, 0, (size_t)j->nbytes);
-    pthread_barrier_wait(j->bar);
+    if (bytes) memset(bytes, 0, (size_t)j->nbytes);
+    /* the start gate: counts the threads that really exist (a pthread barrier sized for the planned number would hang the others if one
+     * could not be created) */
+    __atomic_add_fetch(&j->gate->ready, 1, __ATOMIC_SEQ_CST);
+    while (__atomic_load_n(&j->gate->go, __ATOMIC_SEQ_CST) == 0) sched_yield();
     t0 = now_s();
-    if (j->t_start) *j->t_start = t0;
+    j->t_start = t0;
     deadline = t0 + j->seconds;
-    if (!j->rc) {
+    if (!j->rc && __atomic_load_n(&j->gate->go, __ATOMIC_SEQ_CST) > 0) {
         int pass = 0;
         do {  /* one pass = one stream from its first frame (fresh codec objects: ~1 frame's worth of work per n_frames) */
             const int16_t *x = j->pcm + (size_t)((j->first + pass) % j->n_distinct) * (size_t)j->n_frames * (size_t)j->nf;
@@ -157,7 +164,7 @@ static void *timed_worker(void *arg) {
 int lc3o_timed_run(int fs_hz, int frame_us, int nbytes, int n_frames, const int16_t *pcm, int n_distinct, int n_threads, int roundtrip,
                    double seconds, double *frames_out, double *elapsed_out) {
     lc3o_config c;
-    pthread_barrier_t bar;
+    start_gate gate = {0, 0};
     pthread_t *th;
     tjob *jobs;
     double t_start = 0.0, t_end = 0.0, frames = 0.0;
@@ -165,8 +172,11 @@ int lc3o_timed_run(int fs_hz, int frame_us, int nbytes, int n_frames, const int1
     if (n_threads < 1 || n_distinct < 1 || n_frames < 1 || lc3o_config_new(&c, fs_hz, frame_us)) return -1;
     th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
     jobs = (tjob *)calloc((size_t)n_threads, sizeof(tjob));
-    if (!th || !jobs) return -2;
-    pthread_barrier_init(&bar, 0, (unsigned)n_threads);
+    if (!th || !jobs) {
+        free(th);
+        free(jobs);
+        return -2;
+    }
     for (i = 0; i < n_threads; i++) {
         tjob *j = &jobs[i];
         j->fs_hz = fs_hz; j->frame_us = frame_us; j->nbytes = nbytes; j->n_frames = n_frames; j->nf = c.nf; j->roundtrip = roundtrip;
@@ -174,17 +184,19 @@ int lc3o_timed_run(int fs_hz, int frame_us, int nbytes, int n_frames, const int1
         j->first = i % n_distinct;
         j->n_distinct = n_distinct;
         j->seconds = seconds;
-        j->bar = &bar;
-        j->t_start = i == 0 ? &t_start : 0;
+        j->gate = &gate;
         if (pthread_create(&th[i], 0, timed_worker, j)) { rc = -3; n_threads = i; break; }
     }
+    /* every thread that exists has allocated and initialised: open the gate (the clock starts in the workers) */
+    while (__atomic_load_n(&gate.ready, __ATOMIC_SEQ_CST) < n_threads) sched_yield();
+    __atomic_store_n(&gate.go, rc ? -1 : 1, __ATOMIC_SEQ_CST);
     for (i = 0; i < n_threads; i++) {
         pthread_join(th[i], 0);
         if (jobs[i].rc) rc = jobs[i].rc;
         frames += jobs[i].frames;
+        if (i == 0 || jobs[i].t_start < t_start) t_start = jobs[i].t_start;
         if (jobs[i].t_end > t_end) t_end = jobs[i].t_end;
     }
-    pthread_barrier_destroy(&bar);
     free(th);
     free(jobs);
     if (frames_out) *frames_out = frames;

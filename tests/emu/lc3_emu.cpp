@@ -239,7 +239,7 @@ void run_wg(const Job *protos) {
 }  // namespace
 
 extern "C" {
-// pcm int16[S][T][nf] -> bytes uint8[S][T][nbytes]; every stream starts fresh; dbg optional float[1472] (last frame)
+// pcm int16[S][T][nf] -> bytes uint8[S][T][nbytes]; every stream starts fresh; dbg optional float[LC3_ENC_DBG_FLOATS = 1600] (last frame)
 int lc3emu_encode_spec(int fs_hz, int frame_us, int nbytes, int S, int T, const int16_t *pcm, uint8_t *bytes, float *dbg, int spec_flags);
 int lc3emu_encode(int fs_hz, int frame_us, int nbytes, int S, int T, const int16_t *pcm, uint8_t *bytes, float *dbg) {
     return lc3emu_encode_spec(fs_hz, frame_us, nbytes, S, T, pcm, bytes, dbg, 0);

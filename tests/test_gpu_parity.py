@@ -81,6 +81,58 @@ def test_kat_stage_dumps():
     assert out.tolist() == O.kat(t, "buf_out_expected")
 
 
+def test_encoder_stage_dumps_match_reference_goldens():
+    """The encoder's stages ON THE DEVICE against the reference's own stage vectors (lc3gpu_encode_frame_debug), beyond the three
+    spectra of test_kat_stage_dumps.  The end-to-end KAT frame is the frame several of the reference's per-stage tests were dumped
+    from: its band energies are sns_run's / bandwidth_detector_run's `e_b`, it is attack_detector_run's and long_term_post_filter_run's
+    `x_s`, its quantised spectrum is noise_level_estimation_run's `x_q`.  modified_dct_encode and long_term_post_filter_active bring
+    their own frames (two, eight): they run through fresh encoders frame by frame."""
+    import ctypes
+
+    D = pkg.api
+    S0 = D.ENC_DBG_SCALARS
+    enc = pkg.Lc3Encoder(1, US, FS)
+    t = "encoder/lc3_encoder.rs::lc3_encode_channel"
+    out, dbg = enc.encode_frame_debug(O.kat(t, "samples_in", 0, np.int16), 150)
+    assert out.tolist() == O.kat(t, "buf_out_expected")
+    eb = dbg[D.ENC_DBG_EB:D.ENC_DBG_EB + 64]
+    assert np.array_equal(eb, O.kat("encoder/spectral_noise_shaping.rs::sns_run", "e_b", 0, np.float32)), "band energies"
+    assert np.array_equal(eb, O.kat("encoder/bandwidth_detector.rs::bandwidth_detector_run", "e_b", 0, np.float32))
+    assert dbg[S0 + 0] == 4  # bandwidth_detector.rs:137-155 -> (4, 3)
+    # attack_detector.rs:138-180: the flag and every state field
+    att = dbg[D.ENC_DBG_ATTACK:D.ENC_DBG_ATTACK + 5]
+    assert dbg[S0 + 1] == 1 and att[0] == np.float32(549861.5) and att[1] == np.float32(905588.875) and att[2:].tolist() == [0.0, 4846.0, 5210.0], att
+    # spectral_noise_shaping.rs:780-801: ind_lf 8, ind_hf 17, shape_j 3, gind 0, index_joint_j 15253432 (ls_inda 0)
+    joint = int(dbg[S0 + 23]) | (int(dbg[S0 + 24]) << 16)
+    assert dbg[S0 + 2:S0 + 6].tolist() == [8.0, 17.0, 3.0, 0.0] and dbg[S0 + 22] == 0 and joint == 15253432, (dbg[S0 + 2:S0 + 6], joint)
+    # long_term_post_filter.rs:479-520: nbits_ltpf 11 <=> pitch_present, ltpf_active false, pitch_index 0
+    assert (dbg[S0 + 9], dbg[S0 + 10], dbg[S0 + 11]) == (0, 1, 0)
+    # noise_level_estimation.rs:65-137 (p_bw 4, gg 24.709114) -> 6; spectral_quantization.rs:474: gg = 0x41C5AC44
+    assert dbg[S0 + 17] == 6 and dbg[S0 + 18].view(np.uint32) == 0x41C5AC44
+    # modified_dct.rs:191-337: the SECOND frame's spectrum and band energies (the time buffer carries the first), near-Nyquist flag false
+    t = "encoder/modified_dct.rs::modified_dct_encode"
+    enc = pkg.Lc3Encoder(1, US, FS)
+    enc.encode_frame_debug(O.kat(t, "samples_in", 0, np.int16), 150)
+    _, dbg = enc.encode_frame_debug(O.kat(t, "samples_in", 1, np.int16), 150)
+    assert np.array_equal(dbg[0:480], O.kat(t, "output_expected", 0, np.float32)), "MDCT spectrum of the second frame"
+    assert np.array_equal(dbg[D.ENC_DBG_EB:D.ENC_DBG_EB + 64], O.kat(t, "energy_bands_expected", 0, np.float32)), "its band energies"
+    assert dbg[S0 + 21] == 0
+    # long_term_post_filter.rs:523-843: eight consecutive frames at nbits = 400 (50-byte frames); (ltpf_active, pitch_present, pitch_index)
+    # per frame :566-842 -- from the stage dump AND from the frame's bytes, read back with the oracle's side-information reader
+    t = "encoder/long_term_post_filter.rs::long_term_post_filter_active"
+    want = [(0, 0, 0), (0, 0, 0), (0, 1, 180), (0, 1, 184), (0, 1, 477), (0, 1, 478), (1, 1, 478), (1, 1, 478)]
+    enc = pkg.Lc3Encoder(1, US, FS)
+    oenc = O.Encoder()
+    for i, w in enumerate(want):
+        x = O.kat(t, "x_s", i, np.int16)
+        out, dbg = enc.encode_frame_debug(x, 50)
+        assert (int(dbg[S0 + 11]), int(dbg[S0 + 10]), int(dbg[S0 + 9])) == w, (i, dbg[S0 + 9:S0 + 12])
+        si, tail = np.zeros(20, np.int64), ctypes.c_int(0)
+        assert O.lib().lc3o_kat_side_info(O.P(out), 50, 4, 400, O.P(si), ctypes.byref(tail)) == 0
+        assert (int(si[17]), int(si[16]), int(si[18])) == w, (i, si[16:19])
+        assert np.array_equal(out, oenc.encode_frame(x, 50)), i
+
+
 # ---------------------------------------------------------------- batch parity vs the oracle
 def _roundtrip_check(fs, us, nbytes, S, T, seed=synth.SEED):
     cfg = pkg.Lc3Config(fs, us)
@@ -758,6 +810,108 @@ def test_prepared_packer_symbols_on_and_off():
         assert r.returncode == 0 and "prep ok" in r.stdout, v + r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def _split_suite():
+    """what test_split_calls_on_and_off runs in a child process with LC3GPU_SPLIT=1 (every batch call of at least 16 streams runs as two
+    halves on the handle's internal HIP streams) and with LC3GPU_SPLIT=0 (never): every result against the oracle"""
+    t = torch_mod()
+    # odd stream counts (the halves are whole workgroups of four streams / whole waves of 64), several configurations
+    for S in (16, 17, 19, 23, 130, 257):
+        _roundtrip_check(48000, 10000, 150, S, 3, seed=301 + S)
+    for fs, us, nb in ((48000, 7500, 113), (32000, 10000, 80), (16000, 7500, 30), (24000, 10000, 60)):
+        _roundtrip_check(fs, us, nb, 37, 4, seed=302)
+    # state carried across split launches, then across a launch of a size that does not split, through save / load and a reset
+    S, T = 41, 6
+    pcm = synth.make_pcm(S, T, 480, 48000, seed=303)
+    ref = O.encode_batch(pcm, 150)
+    ref_pcm = O.decode_batch(ref, 480)
+    enc, dec = pkg.Lc3Encoder(S, US, FS), pkg.Lc3Decoder(S, US, FS)
+    got = [gpu_encode(pcm[:, a:b], 150, enc=enc) for a, b in ((0, 2), (2, 3), (3, 6))]
+    assert np.array_equal(np.concatenate(got, axis=1), ref)
+    blob = enc.state_save()
+    enc.reset()
+    assert np.array_equal(gpu_encode(pcm[:, :2], 150, enc=enc), ref[:, :2])
+    enc.state_load(blob)
+    gotp = [gpu_decode(ref[:, a:b], 480, dec=dec) for a, b in ((0, 1), (1, 4), (4, 6))]
+    assert np.array_equal(np.concatenate(gotp, axis=1), ref_pcm)
+    # channel ranges of the same handles (ranges of at least 16 streams split again), state still the handle's
+    enc2, dec2 = pkg.Lc3Encoder(S, US, FS), pkg.Lc3Decoder(S, US, FS)
+    d_pcm = t.from_numpy(pcm).cuda()
+    d_b = t.zeros((S, T, 150), dtype=t.uint8, device="cuda")
+    d_p = t.zeros((S, T, 480), dtype=t.int16, device="cuda")
+    for lo, n in ((0, 20), (20, 21)):
+        enc2.encode(d_pcm[lo:lo + n], d_b[lo:lo + n], 150, T, first_channel=lo, n_channels=n)
+        dec2.decode(d_b[lo:lo + n], d_p[lo:lo + n], 150, T, first_channel=lo, n_channels=n)
+    t.cuda.synchronize()
+    assert np.array_equal(d_b.cpu().numpy(), ref) and np.array_equal(d_p.cpu().numpy(), ref_pcm)
+    # damaged frames and bad-frame flags on both sides of the split point, also at the edges of launches; the PLC counter
+    S, T = 36, 8
+    pcm = synth.make_pcm(S, T, 480, 48000, seed=304)
+    data = O.encode_batch(pcm, 150).copy()
+    rng = np.random.default_rng(304)
+    bad = np.zeros((S, T), np.uint8)
+    for s in range(S):
+        for tt in rng.choice(T, 2, replace=False):
+            if s % 3 == 0:
+                data[s, tt] = rng.integers(0, 256, 150, dtype=np.uint8)
+            elif s % 3 == 1:
+                bad[s, tt] = 1
+            else:
+                data[s, tt, -1] |= 7
+    corrupt = data.copy()
+    corrupt[bad.astype(bool), -1] |= 7
+    refp = O.decode_batch(corrupt, 480)
+    dec3 = pkg.Lc3Decoder(S, US, FS)
+    gp = [gpu_decode(data[:, a:b], 480, dec=dec3, bad=bad[:, a:b]) for a, b in ((0, 3), (3, 4), (4, 8))]
+    assert np.array_equal(np.concatenate(gp, axis=1), refp)
+    assert dec3.plc_events() >= 2 * (S // 3)
+    # the interleaved layout (the halves are column ranges of the same buffers)
+    test_interleaved_layout(32000, 10000, 81, 70, 3)
+    test_interleaved_layout(48000, 10000, 150, 18, 4)
+    # calls of one handle on different HIP streams, the per-kernel timer
+    test_launches_on_different_hip_streams_are_ordered()
+    test_kernel_timer_counts_every_nth_call()
+    test_channel_ranges_on_separate_hip_streams()
+    print("split ok")
+
+
+def test_split_calls_on_and_off():
+    """A batch call of a full batch (at least 32 768 frames) runs as two halves of its streams on the handle's two internal HIP streams,
+    forked from and joined to the caller's stream by events (lc3_split_parts, lc3gpu.hip); LC3GPU_SPLIT=1 forces that for every call of
+    at least 16 streams, LC3GPU_SPLIT=0 switches it off.  Both ways through state carry, state blobs, ranges, damaged frames at launch
+    edges, odd stream counts, the interleaved layout, cross-stream ordering and the timer, against the oracle; and the split and the
+    unsplit form of the SAME full-size launch byte for byte (test_full_size_batch_properties has the default form against the oracle)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, 'tests')\nimport test_gpu_parity as t\nt._split_suite()\n"
+    for v in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, LC3GPU_SPLIT=v), capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0 and "split ok" in r.stdout, v + r.stdout[-2000:] + r.stderr[-2000:]
+    # the same full-size launches (two consecutive calls: state, and a damaged frame per 97 in the second) in both forms
+    code2 = (
+        "import sys, hashlib; sys.path.insert(0, 'tests')\n"
+        "import numpy as np, test_gpu_parity as t\n"
+        "S, T = 8192 + 4, 4\n"
+        "pcm = np.tile(t.synth.make_pcm(683, 2 * T, 480, 48000, seed=305), (13, 1, 1))[:S]\n"
+        "enc, dec = t.pkg.Lc3Encoder(S, t.US, t.FS), t.pkg.Lc3Decoder(S, t.US, t.FS)\n"
+        "h = hashlib.sha256()\n"
+        "for k in range(2):\n"
+        "    b = t.gpu_encode(pcm[:, k * T:(k + 1) * T], 150, enc=enc)\n"
+        "    if k: b.reshape(-1, 150)[::97, -1] |= 7\n"
+        "    p = t.gpu_decode(b, 480, dec=dec)\n"
+        "    h.update(b.tobytes()); h.update(p.tobytes())\n"
+        "print('digest', h.hexdigest(), dec.plc_events())\n"
+    )
+    digests = []
+    for v in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code2], cwd=root, env=dict(os.environ, LC3GPU_SPLIT=v), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "digest" in r.stdout, v + r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append(r.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1], digests
+
+
 def test_stress_parity_tool_one_million_frames():
     """tools/stress_parity.py at volume inside the suite: 14 configurations x 2048 streams x 18 frames x 2 rounds = 1 032 192 frames per
     direction, every bitstream byte and every PCM sample compared with the oracle (which runs on the host threads the job is granted);
@@ -918,6 +1072,35 @@ def test_launcher_stops_the_gpu_ranks_when_one_dies():
                           {"LC3_BENCH_BACKEND": "gloo", "LC3_BENCH_TEST_DIE_RANK": "1"})
     assert p.returncode != 0 and line is None and "rank 1 exited with code 17" in p.stderr
     assert time.time() - t0 < 300.0
+
+
+def test_rccl_world_size_one():
+    """RCCL itself on the hardware: the pool hands out one GPU per call, so the N-GPU path's library load, communicator creation, barrier
+    and the all_reduce of the report counters on DEVICE tensors (lc3-codec_amd/dist.py::reduce_report) run here as a group of ONE rank --
+    in a fresh child process that initialises the `nccl` backend before any other GPU call, exactly where a rank of the driver's 8-GPU
+    run does (bench.py, LC3_BENCH_RCCL=1).  The line says which backend reduced it and the RCCL version."""
+    p, line = _bench_line(["--steps", "3", "--warmup", "1", "--streams", "1024", "--no-overlap-probe", "--sustain-seconds", "0"],
+                          {"LC3_BENCH_RCCL": "1"})
+    assert p.returncode == 0 and line is not None, p.stderr[-2000:]
+    par = line["config"]["parallelism"]
+    assert "world size 1 (nccl" in par and "RCCL" in par, par
+    assert line["n_gpus"] == 1 and line["parity"]["bitstream_exact"] and line["parity_mismatches_all_ranks"] == 0
+    assert abs(line["value"] - 1024 * 4 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+
+
+def test_both_caller_arrangements_pass_their_parity_gate():
+    """bench.py times two ways of queueing the same steps -- encode then decode on ONE caller stream, and the recommended pattern
+    (INTEGRATION.md): encoder handle on one stream, decoder handle on another, two byte buffers, events -- and runs its parity gate on
+    each (two steps from fresh state, the second against the oracle).  Here on a batch that takes the split path inside the calls."""
+    p, line = _bench_line(["--steps", "4", "--warmup", "1", "--streams", "8192", "--sustain-seconds", "0.3", "--arrangement", "pipelined"], {})
+    assert p.returncode == 0 and line is not None, p.stderr[-2000:]
+    assert line["config"]["arrangement"] == "pipelined" and line["config"]["hip_streams"] == 2
+    assert line["parity"]["arrangement"] == "pipelined" and line["parity"]["bitstream_exact"] and line["parity"]["pcm_max_abs_diff"] == 0
+    o = line["other_arrangement"]
+    assert o["arrangement"] == "single" and o["parity"]["bitstream_exact"] and o["parity"]["pcm_max_abs_diff"] == 0
+    assert line["parity_mismatches_all_ranks"] == 0
+    s = line["sustained"]
+    assert s["steps"] > 0 and s["shader_clock_MHz"]["probes"] > 0 and 500.0 < s["shader_clock_MHz"]["median"] < 3000.0, s
 
 
 # ---------------------------------------------------------------- decoder stages on the device against the reference's stage goldens

@@ -10,7 +10,7 @@ OUT=gpurun_out
 mkdir -p $OUT/$TAG
 export TMPDIR=/tmp
 ROOT=$(pwd)
-BENCH="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-overlap-probe"
+BENCH="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-overlap-probe --sustain-seconds 0"
 python3 bench.py --no-cpu-baseline > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/$TAG/trace -o trace --output-format csv -- $BENCH > $ROOT/$OUT/$TAG/trace.log 2>&1 )
 find $OUT/$TAG/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv

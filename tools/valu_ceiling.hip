@@ -3,10 +3,13 @@
 //      (f32 add / mul, v_cndmask, DPP row moves, v_readlane, i32 add / shift), as independent streams (eight accumulators per
 //      wave) and as one dependent chain, at 1, 2, 4 and 8 waves per SIMD;
 //   2. the device-to-device copy bandwidth a plain 16-byte-per-lane kernel reaches (SURVEY 8d's "measured device-copy bandwidth").
-// Stand-alone: hipcc --offload-arch=gfx950 -O3 -o valu_ceiling tools/valu_ceiling.hip && ./valu_ceiling > profiles/r03_valu_ceiling.json
-// Every kernel runs `iters` rounds of an unrolled block of 64 instructions between two s_memtime stamps (shader-clock cycles) on
-// lane 0 of each wave; a launch is one workgroup of 4 W waves per CU (W per SIMD).  Reported: wave-instructions per SIMD per cycle
-// = W * instructions of one wave / (cycles of the slowest wave: a SIMD serves its waves oldest first), and its reciprocal.
+// Stand-alone: hipcc --offload-arch=gfx950 -O3 -o valu_ceiling tools/valu_ceiling.hip && ./valu_ceiling > profiles/r04_valu_ceiling.json
+// Every kernel runs `iters` rounds of an unrolled block of 1 024 instructions (16 x 64) between two s_memtime stamps (shader-clock
+// cycles) on lane 0 of each wave; a launch is one workgroup of 4 W waves per CU (W per SIMD).  The loop's own cost -- counter, compare,
+// taken branch: measured with an empty body, ~50 cycles per round for a lone wave -- is 1 % of a round of 1 024 instructions and is
+// subtracted (round 3 ran 64 instructions per round and did not: its figures were up to 19 % high).  Reported: wave-instructions per
+// SIMD per cycle = W * instructions of one wave / (cycles of the slowest wave: a SIMD serves its waves oldest first), its reciprocal,
+// and the shader clock the kernel ran at (delta s_memtime / delta s_memrealtime x 100 MHz, median over the waves).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -24,14 +27,17 @@
         }                                                                             \
     } while (0)
 
-// eight independent streams x 8 = 64 instructions per block; the asm is volatile and touches only its own operands
-#define REP8(x) x x x x x x x x
+// eight independent streams x 128 = 1 024 instructions per block, ONE asm statement (between two asm statements the compiler pads with
+// an s_nop); the asm is volatile and touches only its own operands
+#define REP8(x) x
+#define R128 ".rept 128\n"
+#define ENDR ".endr\n"
 #define BLOCK_INDEP(OP)                                                                                                   \
-    REP8(asm volatile(OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)                                                    \
+    REP8(asm volatile(R128 OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) ENDR                                                  \
                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)                   \
                       : "v"(k) : "vcc");)
 #define BLOCK_CHAIN(OP)                                                                                                   \
-    REP8(asm volatile(OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0)                                                    \
+    REP8(asm volatile(R128 OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) ENDR                                                  \
                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)                   \
                       : "v"(k) : "vcc");)
 #define OP_FADD(i) "v_add_f32 %" #i ", %" #i ", %8\n"
@@ -46,31 +52,37 @@
 // the mix: per eight instructions 2 f32 add, 2 f32 mul, 2 selects, 1 DPP move, 1 integer add (the analysis kernels' VALU histogram)
 #define OP_MIX(i) "v_add_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_cndmask_b32 %2, %2, %8, vcc\n v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n" \
                   "v_add_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_cndmask_b32 %6, %6, %8, vcc\n v_add_u32 %7, %7, %8\n"
-#define BLOCK_MIX REP8(asm volatile(OP_MIX(0) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc");)
+#define BLOCK_MIX REP8(asm volatile(R128 OP_MIX(0) ENDR : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc");)
 // v_readlane writes a scalar register: eight different ones per group
 #define BLOCK_READLANE                                                                                                      \
-    REP8(asm volatile("v_readlane_b32 s20, %0, 1\n v_readlane_b32 s21, %1, 2\n v_readlane_b32 s22, %2, 3\n v_readlane_b32 s23, %3, 4\n" \
-                      "v_readlane_b32 s24, %4, 5\n v_readlane_b32 s25, %5, 6\n v_readlane_b32 s26, %6, 7\n v_readlane_b32 s27, %7, 8\n" \
+    REP8(asm volatile(R128 "v_readlane_b32 s20, %0, 1\n v_readlane_b32 s21, %1, 2\n v_readlane_b32 s22, %2, 3\n v_readlane_b32 s23, %3, 4\n" \
+                      "v_readlane_b32 s24, %4, 5\n v_readlane_b32 s25, %5, 6\n v_readlane_b32 s26, %6, 7\n v_readlane_b32 s27, %7, 8\n" ENDR \
                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)                      \
                       : "v"(k) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");)
 
+#define REP16(x) x x x x x x x x x x x x x x x x
 #define KERNEL(NAME, BODY)                                                                                  \
     __global__ void NAME(unsigned long long *cycles, float *sink, int iters) {                              \
         float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
         const float k = 1.0001f;                                                                            \
         __syncthreads();                                                                                    \
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
-        for (int i = 0; i < iters; i++) { BODY }                                                            \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();  \
+        _Pragma("unroll 1") for (int i = 0; i < iters; i++) { BODY }                                 \
         asm volatile("s_nop 0" ::: "memory");                                                               \
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
-        if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0; \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();  \
+        if ((threadIdx.x & 63) == 0) {                                                                      \
+            const size_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                           \
+            cycles[2 * w] = t1 - t0;                                                                        \
+            cycles[2 * w + 1] = r1 - r0;                                                                    \
+        }                                                                                                   \
         if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678f) sink[0] = a0;                              \
     }
+KERNEL(k_empty, asm volatile("" ::: "memory");)
 KERNEL(k_fadd, BLOCK_INDEP(OP_FADD))
 KERNEL(k_fmul, BLOCK_INDEP(OP_FMUL))
 KERNEL(k_cndmask, BLOCK_INDEP(OP_CNDMASK))
 #define BLOCK_CNDMASK_S                                                                                                   \
-    REP8(asm volatile(OP_CNDMASK_S(0) OP_CNDMASK_S(1) OP_CNDMASK_S(2) OP_CNDMASK_S(3) OP_CNDMASK_S(4) OP_CNDMASK_S(5) OP_CNDMASK_S(6) OP_CNDMASK_S(7) \
+    REP8(asm volatile(R128 OP_CNDMASK_S(0) OP_CNDMASK_S(1) OP_CNDMASK_S(2) OP_CNDMASK_S(3) OP_CNDMASK_S(4) OP_CNDMASK_S(5) OP_CNDMASK_S(6) OP_CNDMASK_S(7) ENDR \
                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)                   \
                       : "v"(k) : "s20", "s21");)
 KERNEL(k_cndmask_s, asm volatile("s_mov_b64 s[20:21], 0x5555" ::: "s20", "s21"); BLOCK_CNDMASK_S)
@@ -95,11 +107,11 @@ int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-    const int iters = 2000;            // x 64 instructions per wave
-    const double instr = 64.0 * iters;
+    const int iters = 128;             // x 1 024 instructions per wave
+    const double instr = 1024.0 * iters;
     unsigned long long *d_cycles;
     float *d_sink;
-    CHECK(hipMalloc(&d_cycles, sizeof(unsigned long long) * (size_t)cus * 32));
+    CHECK(hipMalloc(&d_cycles, sizeof(unsigned long long) * (size_t)cus * 32 * 2));
     CHECK(hipMalloc(&d_sink, 64));
     const Case cases[] = {
         {"v_add_f32", k_fadd, "8 independent streams"}, {"v_mul_f32", k_fmul, "8 independent streams"},
@@ -112,7 +124,23 @@ int main() {
     };
     printf("{\n  \"device\": \"%s\", \"gcn_arch\": \"%s\", \"compute_units\": %d, \"clock_khz_reported\": %d,\n", prop.name, prop.gcnArchName, cus,
            prop.clockRate);
-    printf("  \"method\": \"one workgroup of 4W waves per CU, %d x 64 instructions per wave between two s_memtime stamps; wave_instr_per_simd_cycle = W * instructions / cycles of the slowest wave\",\n", iters);
+    printf("  \"method\": \"one workgroup of 4W waves per CU, %d x 1024 instructions per wave between two s_memtime stamps, the empty loop's cycles subtracted; wave_instr_per_simd_cycle = W * instructions / cycles of the slowest wave; clock = 100 MHz x delta s_memtime / delta s_memrealtime, median over the waves\",\n", iters);
+    // the loop's own cost per round, by waves per SIMD (empty body)
+    double overhead[9] = {0};
+    for (int W : {1, 2, 4, 8}) {
+        const int threads = 64 * 4 * W, wg_threads = threads > 1024 ? 1024 : threads, grid = cus * (threads / wg_threads), waves = grid * (wg_threads / 64);
+        for (int rep = 0; rep < 3; rep++) {
+            hipLaunchKernelGGL(k_empty, dim3(grid), dim3(wg_threads), 0, nullptr, d_cycles, d_sink, iters * 16);  // (16 x the rounds: a measurable run)
+            CHECK(hipGetLastError());
+            CHECK(hipDeviceSynchronize());
+        }
+        std::vector<unsigned long long> h((size_t)waves * 2);
+        CHECK(hipMemcpy(h.data(), d_cycles, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+        unsigned long long mx = 0;
+        for (int w = 0; w < waves; w++) mx = std::max(mx, h[2 * (size_t)w]);
+        overhead[W] = (double)mx / (iters * 16.0);  // per round of the loop
+    }
+    printf("  \"loop_overhead_cycles_per_round\": {\"1\": %.1f, \"2\": %.1f, \"4\": %.1f, \"8\": %.1f},\n", overhead[1], overhead[2], overhead[4], overhead[8]);
     printf("  \"valu\": [\n");
     bool first = true;
     for (const Case &c : cases) {
@@ -129,14 +157,21 @@ int main() {
                 CHECK(hipGetLastError());
                 CHECK(hipDeviceSynchronize());
             }
-            std::vector<unsigned long long> h((size_t)waves);
-            CHECK(hipMemcpy(h.data(), d_cycles, sizeof(unsigned long long) * (size_t)waves, hipMemcpyDeviceToHost));
+            std::vector<unsigned long long> hh((size_t)waves * 2), h((size_t)waves);
+            CHECK(hipMemcpy(hh.data(), d_cycles, sizeof(unsigned long long) * hh.size(), hipMemcpyDeviceToHost));
+            std::vector<double> mhz((size_t)waves);
+            for (int w = 0; w < waves; w++) {
+                h[(size_t)w] = hh[2 * (size_t)w];
+                mhz[(size_t)w] = hh[2 * (size_t)w + 1] ? 100.0 * (double)hh[2 * (size_t)w] / (double)hh[2 * (size_t)w + 1] : 0.0;
+            }
             std::sort(h.begin(), h.end());
-            const double med = (double)h[h.size() / 2], mx = (double)h.back();
+            std::sort(mhz.begin(), mhz.end());
+            const double raw_mx = (double)h.back();
+            const double med = (double)h[h.size() / 2] - overhead[W] * iters, mx = raw_mx - overhead[W] * iters;
             // the waves of a SIMD are served oldest first: the last one to finish marks the time the SIMD needed for all W streams
             printf("%s    {\"instruction\": \"%s\", \"streams\": \"%s\", \"waves_per_simd\": %d, \"wave_instr_per_simd_cycle\": %.4f, "
-                   "\"cycles_per_wave_instr\": %.3f, \"median_wave_cycles\": %.0f, \"max_wave_cycles\": %.0f}",
-                   first ? "" : ",\n", c.name, c.what, W, W * instr / mx, mx / (W * instr), med, mx);
+                   "\"cycles_per_wave_instr\": %.3f, \"median_wave_cycles\": %.0f, \"max_wave_cycles\": %.0f, \"max_wave_cycles_with_loop\": %.0f, \"clock_MHz\": %.0f}",
+                   first ? "" : ",\n", c.name, c.what, W, W * instr / mx, mx / (W * instr), med, mx, raw_mx, mhz[mhz.size() / 2]);
             first = false;
         }
     }
