@@ -57,7 +57,7 @@ def parse_args(argv=None):
                          "(default 1: one stream, clean per-kernel timing)")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip timing the OTHER arrangement (see --arrangement) after the timed region")
-    ap.add_argument("--arrangement", choices=("single", "pipelined"), default="single",
+    ap.add_argument("--arrangement", choices=("single", "pipelined"), default="pipelined",
                     help="how the timed steps are queued: `single` = encode then decode of the same batch on ONE HIP stream (every call waits for "
                          "the one before it); `pipelined` = the recommended caller pattern (INTEGRATION.md): the encoder handle on one HIP stream, the "
                          "decoder handle on another, two byte buffers and events, so that the decoder works on step k while the encoder runs step k + 1. "
@@ -236,14 +236,14 @@ def kernel_source_sha():
 
 
 def load_ceiling():
-    """the measured issue ceiling and copy bandwidth (tools/valu_ceiling.hip -> profiles/r03_valu_ceiling.json): cycles per wave64
+    """the measured issue ceiling and copy bandwidth (tools/valu_ceiling.hip -> profiles/r04_valu_ceiling.json): cycles per wave64
     vector instruction of the codec's instruction mix on one SIMD, by waves per SIMD, and the device copy rate"""
     try:
         with open(os.path.join(ROOT, "profiles", "r03_valu_ceiling.json")) as f:
             j = json.load(f)
         mix = {r["waves_per_simd"]: r["cycles_per_wave_instr"] for r in j["valu"] if r["instruction"].startswith("mix")}
         return {"cycles_per_instr_by_waves_per_simd": mix, "copy_GBs": j["copy"]["GBs_read_plus_write"],
-                "source": "profiles/r03_valu_ceiling.json (tools/valu_ceiling.hip on an MI355X of this pool)"}
+                "source": "profiles/r04_valu_ceiling.json (tools/valu_ceiling.hip on an MI355X of this pool)"}
     except (OSError, ValueError, KeyError):
         return None
 
@@ -499,6 +499,7 @@ def run_rank(args):
     emu = args.engine == "emu"
     dist = None
     rccl_version = None
+    json_out = sys.stdout
     # LC3_BENCH_RCCL=1: the RCCL path of an N-GPU run (library load, communicator, barrier, all_reduce on device tensors) with ONE rank on
     # the one GPU a box of this pool has -- entered before anything else touches the device, as the ranks of an 8-GPU run do
     rccl_single = world == 1 and not emu and os.environ.get("LC3_BENCH_RCCL") == "1"
@@ -514,10 +515,12 @@ def run_rank(args):
             local_rank = local_rank % max(1, torch.cuda.device_count())
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
-            # stdout carries ONE JSON line (rank 0): RCCL's version banner (NCCL_DEBUG=VERSION, set on some boxes) goes to stdout
-            # through C stdio and would surface after it at exit
-            if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-                os.environ["NCCL_DEBUG"] = "WARN"
+            # stdout carries ONE JSON line (rank 0).  RCCL writes its version banner (NCCL_DEBUG=VERSION, set on some boxes) and its
+            # warnings to file descriptor 1 through C stdio, at times of its own choosing: from here on descriptor 1 IS stderr for
+            # everybody, and the JSON line goes to a duplicate of the original stdout
+            sys.stdout.flush()
+            json_out = os.fdopen(os.dup(1), "w")
+            os.dup2(2, 1)
             torch.cuda.set_device(local_rank)
             if rccl_single:
                 dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
@@ -611,9 +614,9 @@ def run_rank(args):
             arr2 = "pipelined" if main_arr == "single" else "single"
             par2, mism2 = gate(arr2) if not args.no_parity else (None, 0)
             eng.set_arrangement(arr2)
-            el2, _, st2 = eng.timed_steps(args.steps, args.warmup, marks=True)
+            el2, km2, st2 = eng.timed_steps(args.steps, args.warmup, kernel_events=KERNEL_EVENTS_EVERY, marks=True)
             other = {"arrangement": arr2, "value": frames_per_step * args.steps / el2, "unit": "frames/s", "ms_per_step": el2 / args.steps * 1e3,
-                     "ms_per_step_median": st2[len(st2) // 2] if st2 else None, "parity": par2, "parity_mismatches": mism2,
+                     "ms_per_step_median": st2[len(st2) // 2] if st2 else None, "kernel_ms": km2, "parity": par2, "parity_mismatches": mism2,
                      "hip_streams": 2 if arr2 == "pipelined" else 1}
             total_mismatches += mism2
         if args.sustain_seconds > 0:
@@ -711,17 +714,19 @@ def run_rank(args):
                 "hip_streams": hip_streams, "arrangement": main_arr,
                 "arrangement_note": ("`single`: lc3gpu_encode then lc3gpu_decode of the same batch on ONE caller stream, every call behind the one before "
                                      "it; `pipelined`: the encoder handle on one caller stream, the decoder handle on another, two byte buffers and "
-                                     "events (INTEGRATION.md, recommended caller pattern).  Inside either, a call of >= 32 768 frames runs as two halves "
-                                     "on the handle's two internal HIP streams (LC3GPU_SPLIT=0 switches that off)"),
+                                     "events (INTEGRATION.md, recommended caller pattern): the decoder works on step k while the encoder runs step k + 1.  "
+                                     "`value` is the arrangement named here; the other one is timed in the same run (`other_arrangement`)"),
                 "engine": args.engine,
             },
             "kernel_ms": kernel_ms,
             "kernel_ms_from": f"HIP events around every kernel on every {KERNEL_EVENTS_EVERY}th step of the timed region, on the streams the kernels are "
                               "launched on; per step, summed over a kernel's launches",
-            "roofline": roof, "cpu_baseline": cpu, "other_arrangement": other, "sustained": sustained,
+            "roofline": roof, "cpu_baseline": cpu, "other_arrangement": other,
+            "value_single_stream": (value if main_arr == "single" else (other["value"] if other and other["arrangement"] == "single" else None)),
+            "sustained": sustained,
             "parity": parity, "parity_mismatches_all_ranks": total_mismatches,
         }
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
     return 0

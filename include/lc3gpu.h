@@ -224,8 +224,8 @@ int lc3gpu_selftest_math(int which, const float *x, const float *d, int n, float
  * stream), bitstream packing (lane per frame); a decoder batch call two: frame parsing with the spectrum reconstruction on the
  * lane that parsed the frame (full batches; launches of a few frames reconstruct inside the synthesis kernel instead), synthesis
  * (wave per stream) -- or four when LC3GPU_RECON=wave selects the measured-but-not-default form with two reconstruction kernels of
- * their own (wave per frame and, for the TNS lattice, lane per frame).  A call of at least 32 768 frames runs as two halves of its
- * streams on two internal HIP streams (LC3GPU_SPLIT=0 switches that off): a kernel's figure is then the sum over both launches.  `enable` = 0 switches recording off, 1 on for every batch call,
+ * their own (wave per frame and, for the TNS lattice, lane per frame).  With LC3GPU_SPLIT=1 (opt-in; measured slower) a call runs as
+ * two halves of its streams on two internal HIP streams: a kernel's figure is then the sum over both launches.  `enable` = 0 switches recording off, 1 on for every batch call,
  * n > 1 on for every n-th batch call from now on (an event after every kernel costs the stream a few microseconds: sampling keeps a
  * long timed run undisturbed); the call synchronises and returns the per-kernel milliseconds accumulated since the previous call
  * followed by the number of batch calls that were timed:

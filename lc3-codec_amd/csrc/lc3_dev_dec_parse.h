@@ -101,9 +101,12 @@ __device__ __forceinline__ int lc3_p_bool(lc3_parse_ctx &c, int &bit) {
 #define LC3_PT(nb, dst) do { if (lc3_p_tail(c, (nb), (dst))) return -1; } while (0)
 #define LC3_PB(dst) do { if (lc3_p_bool(c, (dst))) return -1; } while (0)
 
-// side_info_reader::read (decoder/side_info_reader.rs:29-200)
+// side_info_reader::read (decoder/side_info_reader.rs:29-200).  WR = 0: parse only, nothing goes to the plane (the producer wave of a
+// producer / consumer pair needs the flags, its consumer writes the words)
+template <int WR = 1>
 __device__ __forceinline__ int lc3_parse_side_info(lc3_parse_ctx &c, int fs_ind, int ne, int &lastnz_out, int &lsb_mode_out,
                                                    int &num_tns_out, int ord[2]) {
+#define lc3_px_set(c_, w_, v_) do { if (WR) (lc3_px_set)(c_, w_, v_); } while (0)
     uint32_t v;
     int b, p_bw = 0, lastnz_bits = 0;
     const int nbits_bw = LC3C_NBITS_BW[fs_ind];
@@ -196,6 +199,7 @@ __device__ __forceinline__ int lc3_parse_side_info(lc3_parse_ctx &c, int fs_ind,
     lastnz_out = lastnz;
     num_tns_out = num_tns;
     return 0;
+#undef lc3_px_set
 }
 
 // ---- range decoder and bit reader, written with selects.  Every lane is another frame, so a branch on frame data diverges
@@ -346,6 +350,59 @@ __device__ __forceinline__ int lc3_p_res_bit(lc3_parse_ctx &c, int idx, int32_t 
     return 0;
 }
 
+// What follows the spectral data in arithmetic_codec::decode: the number of residual bits (calc_num_residual_bits :385-405) and, in
+// LSB mode, the refinement of the integers in place (decode_residual_bits :184-206).  range: the range decoder's final range; ntup:
+// pairs decoded; lev_end: 1 + the last pair that was coded with escape levels
+template <int COUNT>
+__device__ __forceinline__ int lc3_parse_finish(lc3_parse_ctx &c, uint32_t range, int nbits, int ntup, int lev_end, int lsb_mode, int ne) {
+    // lines lastnz .. ne-1 are zero (:131-133): not stored, lc3_reconstruct_frame substitutes zeros when it reads them
+    // calc_num_residual_bits :385-405
+    {
+        const int nbits_side = c.tail - 8;
+        const int nbits_ari = (c.head + 1 - 3) * 8 + 25 - lc3_ilog2(range);
+        if (nbits < nbits_side + nbits_ari) return -6;  // NegativeResidualNumBits
+        int nres = nbits - nbits_side - nbits_ari, cont;
+        lc3_px_set(c, AD_TAIL0, c.tail);
+        lc3_px_set(c, AD_NRES_MAX, nres);
+        lc3_px_set(c, AD_HEAD, c.head);
+        if (lsb_mode) {  // decode_residual_bits :184-206: refines the integers in place
+            // save_lev is read by LINE index k = 0, 2, 4 .. but was written by TUPLE index: entries at or beyond the
+            // number of tuples were never written (zero in the reference), so the walk ends at ntup.  The levels are
+            // fetched eight at a time.
+            // The levels and the line pairs they refine are fetched eight pairs at a time (a lane of this kernel is latency-bound: a
+            // read-modify-write of a plane word per bit cost a memory round trip each).
+            struct q2 { int32_t v[2]; };
+            int stop = 0;
+            const int walk_end = lev_end < ntup ? lev_end : ntup;  // entries at and beyond lev_end are 0: skipped without reading a bit
+            for (int k0 = 0; k0 < walk_end && !stop; k0 += 16) {
+                int lv[8];
+                q2 xp[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = k0 + 2 * j, in = k < ntup;  // lines k, k + 1 < 2 * ntup <= ne
+                    lv[j] = in ? lc3_px_get(c, LC3_PLANE_LEV + k) : 0;
+                    xp[j] = __builtin_bit_cast(q2, *(const lc3_i2 *)(c.plane + (LC3_PLANE_X + (in ? k : 0)) * LC3_PLANE_STRIDE));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (!stop && lv[j] > 0) {
+                        const int k = k0 + 2 * j;
+                        if (lc3_p_res_bit<COUNT>(c, k, xp[j].v[0], nres, cont)) return -7;
+                        if (!cont) stop = 1;
+                        else {
+                            if (lc3_p_res_bit<COUNT>(c, k + 1, xp[j].v[1], nres, cont)) return -7;
+                            if (!cont) stop = 1;
+                        }
+                        *(lc3_i2 *)(c.plane + (LC3_PLANE_X + k) * LC3_PLANE_STRIDE) = __builtin_bit_cast(lc3_i2, xp[j]);
+                    }
+                }
+            }
+        }
+    }
+    LC3_PSTAMP(c, 3);
+    return 0;
+}
+
 // read_frame: side info + arithmetic_codec::decode up to (not including) the non-lsb residual bits, the noise seed
 // and the zero-frame flag, which the synthesis kernel derives lane-parallel from x.  Returns 0 when the frame parsed.
 // COUNT: keep the running count of non-zero lines and the noise-filling seed (the reconstruction kernels of a full batch derive both
@@ -451,52 +508,216 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
         if (err) return -4;
     }
     LC3_PSTAMP(c, 2);
-    // lines lastnz .. ne-1 are zero (:131-133): not stored, lc3_reconstruct_frame substitutes zeros when it reads them
-    // calc_num_residual_bits :385-405
+    return lc3_parse_finish<COUNT>(c, st.range, nbits, ntup, lev_end, lsb_mode, ne);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The spectral data of a frame decoded by a PRODUCER / CONSUMER pair of waves (full batches: lc3_parse_pc_kernel, lc3gpu.hip).
+//
+// A 65 536-frame launch gives every SIMD one wave of this kernel, a lone wave issues one instruction per four cycles whatever the
+// instruction, and the symbol loop above is a chain of ~165 of them per symbol with three dependent LDS round trips.  Only part of
+// that chain is the range decoder's recurrence: (low, range, context) -> symbol -> next context and model row.  The rest -- the
+// pair's magnitudes, the tail bits that follow a symbol (bit planes of an escape, signs), the pair's store, the escape levels, the
+// running count of non-zero lines and the noise-filling seed -- only CONSUMES symbols.  So the frames of a wave are walked by two
+// waves: the producer runs the recurrence and leaves one word per symbol (the symbol and the head bytes its renormalisation took)
+// in a ring in LDS; the consumer, on the same SIMD where the hardware places it there, replays the symbols a few iterations behind
+// and does everything else, in the issue slots and LDS waits the producer leaves.  Same arithmetic, same order of every read of the
+// frame and every store to the plane per frame; the iteration count is the wave's (every lane of both waves steps once per
+// iteration, a lane that has finished its frame idles), so ring entry i of lane l is that lane's i-th symbol in both.
+// The producer publishes its iteration count every LC3_PC_CHUNK iterations (stores of one wave reach LDS in order: the count
+// follows the entries it covers) and waits when the consumer falls a ring behind; the consumer publishes what it has taken.
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef LC3_PC_STORE   // (the GPU build defines these over LDS with the compiler kept from reordering around them; these are the emulator's)
+#define LC3_PC_STORE(p, v) (*(volatile int *)(p) = (v))
+#define LC3_PC_LOAD(p) (*(volatile const int *)(p))
+#define LC3_PC_PAUSE() ((void)0)
+#define LC3_PC_RELEASE() ((void)0)
+#define LC3_PC_ACQUIRE() ((void)0)
+#endif
+#define LC3_PC_CHUNK 4
+#define LC3_PC_DONE 0x40000000
+#define LC3_PC_SPIN_LIMIT (1 << 24)  // polls before a wave gives up on its partner (never reached unless the partner died)
+struct lc3_pc_link {
+    uint32_t *ring;   // this lane's entries: entry i at ring[(i & mask) * stride]
+    int mask, stride;
+    int *p_count;     // wave-level words: -1 until the producer has left its start values, then the iterations it has published, | LC3_PC_DONE at its end
+    int *c_count;     // iterations the consumer has taken
+    uint32_t *fin;    // this lane's hand-over words fin[j * fstride], j = 0 .. 3: head cursor after the TNS data, final range, final head cursor, error flag
+    int fstride;
+};
+
+// the producer: side information (flags only), range decoder start, TNS data, then the symbols
+__device__ __forceinline__ void lc3_pc_produce(lc3_parse_ctx &c, const lc3_pc_link &k, int ne, int fs_ind, int n_ms_10, int rc_in) {
+    int lastnz = 0, lsb_mode = 0, num_tns = 0, ord[2] = {0, 0};
+    int dead = rc_in != 0;
+    if (!dead) dead = lc3_parse_side_info<0>(c, fs_ind, ne, lastnz, lsb_mode, num_tns, ord) != 0;
+    const int nbits = c.len * 8;
+    lc3_acdec st;
+    st.low = 0;
+    st.range = 0x00ffffffu;
+    // ac_dec_init :57-65
+    if (!dead && !(c.head + 2 < c.len)) dead = 1;
+    if (!dead) {
+        st.low = ((uint32_t)c.bytes[c.head] << 16) | ((uint32_t)c.bytes[c.head + 1] << 8) | (uint32_t)c.bytes[c.head + 2];
+        c.head += 3;
+        lc3_p_prime(c);
+        // decode_tns_data :304-337
+        const int wt = nbits < (n_ms_10 ? 480 : 360);
+        for (int q = 0; q < 16; q++) lc3_px_set(c, AD_RCI + q, 0);
+        for (int f = 0; f < 2; f++) {
+            int order = ord[f];
+            if (f < num_tns && order > 0) {
+                int err = 0;
+                order = lc3_p_ac_decode_sel<7, 3>(c, st, c.tns + wt * 8, err) + 1;
+                for (int q = 0; q < order; q++) lc3_px_set(c, AD_RCI + f * 8 + q, lc3_p_ac_decode_sel<16, 5>(c, st, c.tns + 16 + q * 17, err));
+                if (err) dead = 1;
+            }
+            lc3_px_set(c, AD_ORD0 + f, order);
+        }
+    }
+    // start values for the consumer, then the first publication
+    k.fin[0] = (uint32_t)c.head;
+    k.fin[3 * k.fstride] = (uint32_t)dead;
+    LC3_PC_STORE(k.p_count, 0);
+    // decode_spectral_data :211-302 -- the recurrence only (see lc3_parse_frame for the whole of it)
+    const int ntup = dead ? 0 : lastnz / 2;
+    int err = 0, it = 0;
     {
-        const int nbits_side = c.tail - 8;
-        const int nbits_ari = (c.head + 1 - 3) * 8 + 25 - lc3_ilog2(st.range);
-        if (nbits < nbits_side + nbits_ari) return -6;  // NegativeResidualNumBits
-        int nres = nbits - nbits_side - nbits_ari, cont;
-        lc3_px_set(c, AD_TAIL0, c.tail);
-        lc3_px_set(c, AD_NRES_MAX, nres);
-        lc3_px_set(c, AD_HEAD, c.head);
-        if (lsb_mode) {  // decode_residual_bits :184-206: refines the integers in place
-            // save_lev is read by LINE index k = 0, 2, 4 .. but was written by TUPLE index: entries at or beyond the
-            // number of tuples were never written (zero in the reference), so the walk ends at ntup.  The levels are
-            // fetched eight at a time.
-            // The levels and the line pairs they refine are fetched eight pairs at a time (a lane of this kernel is latency-bound: a
-            // read-modify-write of a plane word per bit cost a memory round trip each).
-            struct q2 { int32_t v[2]; };
-            int stop = 0;
-            const int walk_end = lev_end < ntup ? lev_end : ntup;  // entries at and beyond lev_end are 0: skipped without reading a bit
-            for (int k0 = 0; k0 < walk_end && !stop; k0 += 16) {
-                int lv[8];
-                q2 xp[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int k = k0 + 2 * j, in = k < ntup;  // lines k, k + 1 < 2 * ntup <= ne
-                    lv[j] = in ? lc3_px_get(c, LC3_PLANE_LEV + k) : 0;
-                    xp[j] = __builtin_bit_cast(q2, *(const lc3_i2 *)(c.plane + (LC3_PLANE_X + (in ? k : 0)) * LC3_PLANE_STRIDE));
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    if (!stop && lv[j] > 0) {
-                        const int k = k0 + 2 * j;
-                        if (lc3_p_res_bit<COUNT>(c, k, xp[j].v[0], nres, cont)) return -7;
-                        if (!cont) stop = 1;
-                        else {
-                            if (lc3_p_res_bit<COUNT>(c, k + 1, xp[j].v[1], nres, cont)) return -7;
-                            if (!cont) stop = 1;
-                        }
-                        *(lc3_i2 *)(c.plane + (LC3_PLANE_X + k) * LC3_PLANE_STRIDE) = __builtin_bit_cast(lc3_i2, xp[j]);
+        const int rate_flag = nbits > (160 + fs_ind * 160) ? 512 : 0;
+        const int hi_from = ne / 2;
+        int cctx = 0, tup = 0, lev = 0, sym = 0;
+        const uint32_t *row = c.cf + (int)c.lookup[rate_flag + (0 > hi_from ? 256 : 0)] * LC3_DCF_ROW_WORDS;
+        lc3_i4 pv = ((const lc3_i4 *)row)[4];
+        int c_seen = 0, spins = 0;
+        while (LC3_WAVE_ANY(tup < ntup)) {
+            if (tup < ntup) {
+                const int head0 = c.head;
+                if (lev < 14) sym = lc3_p_ac_decode_spec_sel(c, st, row, pv, err);
+                const int esc = sym >= 16 && lev < 14;
+                k.ring[(it & k.mask) * k.stride] = (uint32_t)sym | ((uint32_t)(c.head - head0) << 5);
+                const int a = sym & 3, b = sym >> 2;
+                const int lv = lev < 3 ? lev : 3;
+                const int n_cctx = esc ? cctx : (cctx & 15) * 16 + (lv <= 1 ? 1 + ((a + b) << lv) : 12 + lv);
+                const int n_tup = tup + !esc, n_lev = esc ? lev + 1 : 0;
+                const int n_lv = n_lev < 3 ? n_lev : 3;
+                const int n_row = (int)c.lookup[n_cctx + rate_flag + ((n_tup * 2) > hi_from ? 256 : 0) + n_lv * 1024];
+                row = c.cf + n_row * LC3_DCF_ROW_WORDS;
+                pv = ((const lc3_i4 *)row)[4];
+                lc3_p_head_refill(c);
+                cctx = n_cctx;
+                tup = n_tup;
+                lev = n_lev;
+            }
+            it++;
+            if ((it & (LC3_PC_CHUNK - 1)) == 0) {
+                LC3_PC_STORE(k.p_count, it);
+                // the next chunk's entries must not land on entries the consumer has not taken yet
+                while (it + LC3_PC_CHUNK - c_seen > k.mask + 1 && spins < LC3_PC_SPIN_LIMIT) {
+                    c_seen = LC3_PC_LOAD(k.c_count);
+                    if (it + LC3_PC_CHUNK - c_seen > k.mask + 1) {
+                        LC3_PC_PAUSE();
+                        spins++;
                     }
                 }
             }
         }
+        err |= spins >= LC3_PC_SPIN_LIMIT;
     }
-    LC3_PSTAMP(c, 3);
-    return 0;
+    k.fin[k.fstride] = st.range;
+    k.fin[2 * k.fstride] = (uint32_t)c.head;
+    k.fin[3 * k.fstride] = (uint32_t)(dead | (err != 0));
+    LC3_PC_RELEASE();  // the TNS words in the plane and the hand-over words are out before ...
+    LC3_PC_STORE(k.p_count, it | LC3_PC_DONE);
+}
+
+// the consumer: side information (to the plane), then everything of decode_spectral_data that only consumes symbols, then the rest of
+// arithmetic_codec::decode (lc3_parse_finish).  Returns 0 when the frame parsed (as lc3_parse_frame<COUNT>)
+template <int COUNT>
+__device__ __forceinline__ int lc3_pc_consume(lc3_parse_ctx &c, const lc3_pc_link &k, int ne, int fs_ind, int rc_in) {
+    int lastnz = 0, lsb_mode = 0, num_tns = 0, ord[2] = {0, 0};
+    c.nnz = 0;
+    c.seed = 0;
+    int rc = rc_in;
+    if (rc == 0) rc = lc3_parse_side_info<1>(c, fs_ind, ne, lastnz, lsb_mode, num_tns, ord);
+    const int nbits = c.len * 8;
+    // the producer's start values
+    int spins = 0, pc;
+    while ((pc = LC3_PC_LOAD(k.p_count)) < 0 && spins < LC3_PC_SPIN_LIMIT) {
+        LC3_PC_PAUSE();
+        spins++;
+    }
+    c.head = (int)k.fin[0];
+    const int dead = rc != 0 || k.fin[3 * k.fstride] != 0u;  // (the producer's own start can fail: ac_dec_init, the TNS data)
+    const int ntup = dead ? 0 : lastnz / 2;
+    int lev_end = 0, err = 0, it = 0;
+    {
+        int tup = 0, lev = 0, slack = 0x7fffffff, limit = 0;
+        int32_t xk = 0, xk1 = 0;
+        c.tcur = lc3_p_tail_byte(c, c.tail >> 3);
+        c.tnext = lc3_p_tail_byte(c, (c.tail >> 3) + 1);
+        while (LC3_WAVE_ANY(tup < ntup)) {
+            if (it == limit) {  // (wave-uniform) wait for the next chunk
+                while ((((pc = LC3_PC_LOAD(k.p_count)) & (LC3_PC_DONE - 1)) <= it) && !(pc & LC3_PC_DONE) && spins < LC3_PC_SPIN_LIMIT) {
+                    LC3_PC_PAUSE();
+                    spins++;
+                }
+                limit = pc & (LC3_PC_DONE - 1);
+                if (limit <= it) {  // the producer ended (or never answered) short of this wave's count: cannot happen while both walk the same frames
+                    err = 1;
+                    break;
+                }
+            }
+            if (tup < ntup) {
+                const uint32_t w = k.ring[(it & k.mask) * k.stride];
+                const int sym = (int)(w & 31u);
+                c.head += (int)(w >> 5);
+                const int esc = sym >= 16 && lev < 14;
+                const int a = sym & 3, b = sym >> 2;
+                const int32_t m0 = xk + (int32_t)((uint32_t)a << lev), m1 = xk1 + (int32_t)((uint32_t)b << lev);  // if this is the main symbol
+                // two tail bits: after an escape symbol the pair's next bit plane (when it is transmitted), after the main symbol
+                // the signs of the non-zero values
+                const int want_e = !lsb_mode || lev > 0;
+                int bit0, bit1;
+                lc3_p_bool2_sel(c, esc ? want_e : m0 > 0, esc ? want_e : m1 > 0, slack, bit0, bit1);
+                const int32_t v0 = bit0 ? -m0 : m0, v1 = bit1 ? -m1 : m1;
+                {   // (an escape step stores its partial values too: the pair's main step overwrites them)
+                    lc3_i2 pr;
+                    pr[0] = v0;
+                    pr[1] = v1;
+                    *(lc3_i2 *)(c.plane + (LC3_PLANE_X + 2 * tup) * LC3_PLANE_STRIDE) = pr;
+                }
+                if (lsb_mode && !esc) lc3_px_set(c, LC3_PLANE_LEV + tup, lev);  // written by TUPLE index, read by LINE index (:184-195)
+                lev_end = (!esc && lev > 0) ? tup + 1 : lev_end;
+                if (COUNT) {
+                    c.nnz += esc ? 0u : (uint32_t)(m0 != 0) + (uint32_t)(m1 != 0);
+                    // sum |x_k| * k mod 2^16 (:140-145): (m0 + m1) * 2 tup + m1, the factors below 2^17 and 2^9
+                    c.seed += esc ? 0u : LC3_MUL24((uint32_t)(m0 + m1), (uint32_t)(2 * tup)) + (uint32_t)m1;
+                }
+                xk = esc ? xk + (int32_t)((uint32_t)bit0 << lev) : 0;
+                xk1 = esc ? xk1 + (int32_t)((uint32_t)bit1 << lev) : 0;
+                tup += !esc;
+                lev = esc ? lev + 1 : 0;
+            }
+            it++;
+            if ((it & (LC3_PC_CHUNK - 1)) == 0) LC3_PC_STORE(k.c_count, it);
+        }
+        // the loop's deferred bound checks (see lc3_parse_frame)
+        err |= (slack < 0) | (c.len - ((c.tail - 1) >> 3) - 1 < 0);
+    }
+    LC3_PC_STORE(k.c_count, LC3_PC_DONE - 1);  // (a producer waiting for ring space after an abandoned loop goes on)
+    // the producer's end values
+    while (!((pc = LC3_PC_LOAD(k.p_count)) & LC3_PC_DONE) && spins < LC3_PC_SPIN_LIMIT) {
+        LC3_PC_PAUSE();
+        spins++;
+    }
+    LC3_PC_ACQUIRE();
+    const uint32_t range = k.fin[k.fstride];
+    c.head = (int)k.fin[2 * k.fstride];
+    err |= (int)k.fin[3 * k.fstride] | (spins >= LC3_PC_SPIN_LIMIT) | (c.head > c.len);
+    if (rc) return rc;
+    if (dead) return -2;
+    if (err) return -4;
+    return lc3_parse_finish<COUNT>(c, range, nbits, ntup, lev_end, lsb_mode, ne);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

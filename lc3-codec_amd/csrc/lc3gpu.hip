@@ -89,6 +89,27 @@ __shared__ lc3_spec_tables lc3_spec_tab;
 // product of two values below 2^24 (range-coder steps): the full-rate 24-bit multiplier instead of the quarter-rate v_mul_lo_u32
 #define LC3_MUL24(a, b) __umul24((a), (b))
 #define LC3_WAVE_ANY(pred) (__ballot((pred) != 0) != 0ull)
+// the producer / consumer link of the parser (lc3_dev_dec_parse.h): words in LDS read and written by two waves of a workgroup.  A wave's
+// LDS operations execute in issue order; what these add is that the compiler keeps its own order around them
+// (LDS address space spelled out: through a generic pointer these become flat accesses with system-scope cache bits; the loaded value is
+// the same in every lane -- one word per wave pair -- and is handed on in a scalar register, so the loops it controls stay wave-uniform)
+#define LC3_PC_WORD(p) ((volatile __attribute__((address_space(3))) int *)(p))
+static __device__ __forceinline__ int lc3_pc_load_(const int *p) {
+    asm volatile("" ::: "memory");
+    const int v = *LC3_PC_WORD(p);
+    asm volatile("" ::: "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+#define LC3_PC_STORE(p, v)                 \
+    do {                                   \
+        asm volatile("" ::: "memory");     \
+        *LC3_PC_WORD(p) = (v);             \
+        asm volatile("" ::: "memory");     \
+    } while (0)
+#define LC3_PC_LOAD(p) lc3_pc_load_((const int *)(p))
+#define LC3_PC_PAUSE() __builtin_amdgcn_s_sleep(2)
+#define LC3_PC_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#define LC3_PC_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
 #define LC3_LANEWAVE_MAX(v) lc3_wave_max_i32((v), 0)
 // 10^x tables of the two argument families the codec uses (lc3_dev_common.h: LC3_POW10_GG / LC3_POW10_TILT), filled on the device
 // by lc3_pow10f itself when a device's first configuration is registered
@@ -780,6 +801,117 @@ __global__ __launch_bounds__(256) void lc3_parse_mixed_kernel(lc3_groups G, cons
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
     LC3_GROUP_VIEW(lc3_parse_body, g, blockIdx.x - g.wg_frame, in, bad, p, g.nbytes, g.n_streams * T, T, g.first_stream, io, late);
+}
+
+// The parser of a full batch as PRODUCER / CONSUMER wave pairs (lc3_pc_produce / lc3_pc_consume, lc3_dev_dec_parse.h): a workgroup of
+// 2 x fpb threads parses fpb frames; wave w of its first half runs the range decoder's recurrence for 64 frames, wave w of the second half
+// (the same SIMD where the hardware deals a workgroup's waves round the SIMDs) everything else of those frames, the spectrum
+// reconstruction included.  Dynamic LDS: as lc3_parse_kernel + per pair of waves 4 x 64 hand-over words and two counters
+// (lc3_parse_pc_lds).  The ring of a pair -- LC3_PC_RING = 16 entries per lane -- lies in the pair's own scale-factor columns
+// ([16][frames of the workgroup] floats), which only the consumer's reconstruction uses, after the symbols.
+#define LC3_PC_RING 16
+static __host__ __device__ inline size_t lc3_parse_pc_lds(unsigned fpb, int nbytes) {
+    const size_t base = (LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes) + 15) & ~(size_t)15;
+    return base + (size_t)(fpb / 64) * (4 * 64 * 4) + 64;
+}
+template <class CV>
+__device__ __forceinline__ void lc3_parse_pc_body(lc3_cfg_slot<CV> cfg, unsigned wg, const uint8_t *in, const uint8_t *bad, int32_t *planes,
+                                                  int nbytes, int n_frames, int T, int first_channel, lc3_io io) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
+    const int ne = c0.ne, fs_ind = c0.fs_ind, n_ms_10 = c0.n_ms_10;
+    const int tid = threadIdx.x, nt = blockDim.x, fpb = nt >> 1;
+    const int role = tid >= fpb;      // 0: producer, 1: consumer
+    const int ft = tid - role * fpb;  // the frame's slot in the workgroup
+    const int pair = ft >> 6, lane = tid & 63, npairs = fpb >> 6;
+    uint8_t *s_lookup = smem;
+    uint32_t *s_cf = (uint32_t *)(smem + 4096);
+    uint32_t *s_mpvq = (uint32_t *)(smem + 4096 + 64 * LC3_DCF_ROW_WORDS * 4);
+    uint32_t *s_tns = (uint32_t *)(smem + 4096 + 64 * LC3_DCF_ROW_WORDS * 4 + 16 * 11 * 4);
+    uint16_t *s_ifs = (uint16_t *)(smem + 4096 + 64 * LC3_DCF_ROW_WORDS * 4 + 16 * 11 * 4 + 4 * 152);
+    float *s_scf = (float *)(smem + LC3_PARSE_LDS_FIXED);
+    uint8_t *s_bytes = smem + LC3_PARSE_LDS_FIXED + 16 * 4 * fpb;
+    uint32_t *s_fin = (uint32_t *)(smem + ((LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes) + 15) & ~(size_t)15));
+    int *s_cnt = (int *)(s_fin + npairs * 4 * 64);
+    const size_t f0 = (size_t)wg * (size_t)fpb;
+    {
+        if (tid < npairs) {
+            s_cnt[2 * tid] = -1;
+            s_cnt[2 * tid + 1] = 0;
+        }
+        for (int i = tid; i < 16 * 11; i += nt) s_mpvq[i] = LC3T_MPVQ_OFFSETS[i / 11][i % 11];
+        for (int i = tid; i < LC3_TNS_MODEL_WORDS; i += nt) s_tns[i] = lc3_tns_model_word(i);
+        for (int i = tid; i <= c0.nb; i += nt) s_ifs[i] = lc3_band_index(c0)[i];
+        const uint32_t *lk32 = (const uint32_t *)LC3T_AC_SPEC_LOOKUP;
+        uint32_t *d32 = (uint32_t *)s_lookup;
+        for (int i = tid; i < 1024; i += nt) d32[i] = lk32[i];
+        for (int i = tid; i < 64 * LC3_DCF_ROW_WORDS; i += nt) s_cf[i] = lc3_dcf_word(i);
+        const size_t remaining = (size_t)n_frames - f0;
+        const int nfr = remaining < (size_t)fpb ? (int)remaining : fpb;
+        const int total = nfr * nbytes;
+        const uint8_t *src = in + f0 * (size_t)nbytes;
+        if (io.ilv || io.tab) {  // frame f = s * T + t is fetched from its own place (examples/decode.rs:86-92 for the file order)
+            for (int j = 0; j < nfr; j++) {
+                const size_t fj = f0 + (size_t)j, s = fj / (size_t)T, t = fj - s * (size_t)T;
+                const uint8_t *q = in + lc3_io_byte_off(io, nbytes, first_channel, s, t, T);
+                for (int b = tid; b < nbytes; b += nt) s_bytes[j * nbytes + b] = q[b];
+            }
+        } else if ((((uintptr_t)src) & 3u) == 0) {
+            const uint32_t *s32 = (const uint32_t *)src;
+            uint32_t *b32 = (uint32_t *)s_bytes;
+            for (int i = tid; i < total / 4; i += nt) b32[i] = s32[i];
+            for (int i = (total & ~3) + tid; i < total; i += nt) s_bytes[i] = src[i];
+        } else {
+            for (int i = tid; i < total; i += nt) s_bytes[i] = src[i];
+        }
+    }
+    __syncthreads();
+    if (f0 + (size_t)pair * 64 >= (size_t)n_frames) return;  // (wave-uniform) a pair of waves past the end of the launch
+    const size_t f = f0 + (size_t)ft;
+    const int valid = f < (size_t)n_frames;
+    lc3_parse_ctx c;
+    c.dbg = nullptr;
+    c.bytes = s_bytes + (valid ? ft : 0) * nbytes;
+    c.len = nbytes;
+    c.lookup = s_lookup;
+    c.cf = s_cf;
+    c.tns = s_tns;
+    c.plane = LC3_PLANE_COL(planes, valid ? f : f0, LC3_PLANE_WORDS);  // (a lane past the end parses nothing and stores nothing)
+    c.stride = LC3_PLANE_STRIDE;
+    c.head = 0;
+    c.tail = 0;
+    lc3_pc_link k;
+    k.ring = (uint32_t *)s_scf + ft;  // entry i of this lane at [i][ft]: the lane's 16 scale-factor slots
+    k.mask = LC3_PC_RING - 1;
+    k.stride = fpb;
+    k.fstride = 64;
+    k.p_count = s_cnt + 2 * pair;
+    k.c_count = s_cnt + 2 * pair + 1;
+    k.fin = s_fin + pair * (4 * 64) + lane;
+    int rc_in = -100;
+    if (valid) {
+        const size_t fb = lc3_io_flag_idx(io, first_channel, f / (size_t)T, f % (size_t)T, T);  // the flag array follows the frame layout
+        rc_in = (bad && bad[fb]) ? -100 : 0;
+    }
+    if (role == 0) {
+        lc3_pc_produce(c, k, ne, fs_ind, n_ms_10, rc_in);
+        return;
+    }
+    int ok = lc3_pc_consume<1>(c, k, ne, fs_ind, rc_in) == 0;
+    if (ok) {
+        lc3_recon_ctx r;
+        r.scf = s_scf + ft;
+        r.sstride = fpb;
+        r.mpvq = s_mpvq;
+        r.ifs = s_ifs;
+        ok = lc3_reconstruct_frame(c, r, c0);
+    }
+    if (valid) lc3_px_set(c, AD_OK, ok);
+}
+template <class CV>
+__global__ __launch_bounds__(512) void lc3_parse_pc_kernel(lc3_cfg_slot<CV> cfg, const uint8_t *in, const uint8_t *bad, int32_t *planes,
+                                                           int nbytes, int n_frames, int T, lc3_io io) {
+    lc3_parse_pc_body<CV>(cfg, blockIdx.x, in, bad, planes, nbytes, n_frames, T, 0, io);
 }
 
 // Spectrum reconstruction D4-D8 of a full batch (lc3_dev_dec_recon.h), between the parser and the synthesis kernel:
@@ -1481,6 +1613,38 @@ static int lc3_recon_mode(size_t n_frames_total, int frames_per_stream) {
     if (forced >= 0) return forced;
     return (n_frames_total <= 16384 && frames_per_stream <= 4) ? LC3_RECON_LATE : LC3_RECON_LANE;
 }
+// The producer / consumer parser (lc3_parse_pc_kernel): the form of full batches unless LC3GPU_PARSE_PC=0.  Its ring buffers take the
+// workgroup beyond the default 64 KB of dynamic LDS: opt in once per device (every instantiation); frames per workgroup as many as fit
+// the 160 KB of a CU
+#define LC3_PC_LDS_MAX (160 * 1024)
+static bool lc3_parse_pc_enabled() {
+    static const bool on = [] {
+        const char *e = std::getenv("LC3GPU_PARSE_PC");
+        return !(e && std::atoi(e) == 0);
+    }();
+    return on;
+}
+static int lc3_parse_pc_optin() {
+    static bool done[LC3_MAX_DEVICES] = {};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= LC3_MAX_DEVICES) return LC3GPU_EINVAL;
+    if (done[dev]) return LC3GPU_OK;
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_any>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_48k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_48k75>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_32k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_16k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
+    done[dev] = true;
+    return LC3GPU_OK;
+}
+static unsigned lc3_parse_pc_fpb(int nbytes) {
+    unsigned fpb = lc3_frame_block(256u);
+    while (fpb > 64u && lc3_parse_pc_lds(fpb, nbytes) > (size_t)LC3_PC_LDS_MAX) fpb >>= 1;
+    return fpb;
+}
 // the TNS kernels use more than the default 64 KB of dynamic LDS: opt in once per device (every instantiation)
 static int lc3_tns_lds_optin() {
     static bool done[LC3_MAX_DEVICES] = {};
@@ -1758,18 +1922,25 @@ static int encoder_materialise(lc3gpu_encoder *e, int first, int n, hipStream_t 
     return LC3GPU_OK;
 }
 
-// How a batch call of a uniform handle is split over the handle's two internal HIP streams.  A launch of 65 536 frames gives every SIMD
-// exactly ONE wave of the lane-per-frame kernels (vector quantiser, packer, parser), and a lone wave leaves a third of the SIMD's issue
-// slots idle; run as two halves, the lane-per-frame kernels of one half share the chip with the wave-per-stream
-// kernels of the other.  -> number of parts (1 or 2).  LC3GPU_SPLIT=0 never splits, LC3GPU_SPLIT=1 splits every launch of at least 16
-// streams (tests), default: launches of at least 32 768 frames.
+// A batch call of a uniform handle as two halves of its streams on the handle's two internal HIP streams, forked from and joined to
+// the caller's stream by events (OPT-IN: LC3GPU_SPLIT=1, every launch of at least 16 streams).  The idea (round-3 review): a launch of
+// 65 536 frames gives every SIMD exactly ONE wave of the lane-per-frame kernels (vector quantiser, packer, parser), a lone wave leaves
+// part of the SIMD's issue slots idle, and as two halves the lane-per-frame kernels of one half could share the chip with the
+// wave-per-stream kernels of the other.  Built, byte-identical to the unsplit form in every test -- and measured slower on the
+// 65 536-frame batch, 32.4 M frames/s against 43.3 M (gpurun_out/r04_exp_arr.txt -> profiles/r04_split_experiment.txt): a lane-per-frame
+// kernel takes as long for half the frames (it is the latency of one wave walking its 64 frames), so the two halves' quantiser, packer
+// and parser add up where they do not run at the same moment, and every call pays a fork and a join across HIP streams (~35 us per
+// call on this platform, tools/exp_hops.py).  Inside ONE call there is nothing to put beside the last packer / the parsers (DESIGN
+// section 6); what does pay is the caller running the encoder handle and the decoder handle on two streams (bench.py --arrangement
+// pipelined).  -> number of parts (1 or 2).
 static int lc3_split_parts(size_t frames, int n_streams) {
     static const int forced = [] {
         const char *e = std::getenv("LC3GPU_SPLIT");
         return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
     }();
-    if (n_streams < 4 * LC3_WG_WAVES || forced == 0) return 1;
-    return (forced == 1 || frames >= 32768) ? 2 : 1;
+    (void)frames;
+    if (n_streams < 4 * LC3_WG_WAVES) return 1;
+    return forced == 1 ? 2 : 1;
 }
 // first stream of the second half: whole workgroups of the stream kernels, whole waves of the frame kernels where the launch allows
 static int lc3_split_point(int n_streams, int n_frames) {
@@ -2116,8 +2287,15 @@ static int decode_kernels(lc3gpu_decoder *d, const HostCfg &h, int first, int n,
     const unsigned fpb = lc3_frame_block_fit(LC3_PARSE_LDS_FIXED, (size_t)(64 + nbytes));
     const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes);
     d->timer.mark(stream, -1, chain);
-    LC3_LAUNCH_CFG(lc3_parse_kernel, h, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, d_in, d_bad, planes, nbytes,
-                   (int)frames, n_frames, io, mode);
+    if (mode == LC3_RECON_LANE && lc3_parse_pc_enabled()) {
+        int rc = lc3_parse_pc_optin();
+        if (rc) return rc;
+        const unsigned pfpb = lc3_parse_pc_fpb(nbytes);
+        LC3_LAUNCH_CFG(lc3_parse_pc_kernel, h, dim3((unsigned)((frames + pfpb - 1) / pfpb)), dim3(2 * pfpb), lc3_parse_pc_lds(pfpb, nbytes), stream,
+                       d_in, d_bad, planes, nbytes, (int)frames, n_frames, io);
+    } else
+        LC3_LAUNCH_CFG(lc3_parse_kernel, h, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, d_in, d_bad, planes, nbytes,
+                       (int)frames, n_frames, io, mode);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream, 0, chain);
     if (mode == LC3_RECON_WAVE) {

@@ -370,7 +370,7 @@ int lc3emu_decode_late(int fs_hz, int frame_us, int nbytes, int S, int T, const 
     std::vector<uint8_t> lb((size_t)j.cfg.nf);
     for (int k = 0; k < j.cfg.nf; k++) lb[(size_t)k] = (uint8_t)lc3_line_band_value(j.cfg, k);
     j.cfg.line_band = lb.data();
-    j.late = late;
+    j.late = late == 3 ? 0 : late;  // (3: the parser's producer / consumer form; the synthesis stage finds f32 spectra as with 0)
     j.encode = 0;
     j.n_frames = T;
     j.nbytes = nbytes;
@@ -395,7 +395,25 @@ int lc3emu_decode_late(int fs_hz, int frame_us, int nbytes, int S, int T, const 
         c.head = 0;
         c.tail = 0;
         int rc;
-        if (late == 2) rc = (bad && bad[f]) ? -100 : lc3_parse_frame<0>(c, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10);
+        if (late == 3) {
+            // the producer / consumer form of full batches (lc3_parse_pc_kernel): here the producer walks the frame to its end with a
+            // ring that holds every symbol of a frame, then the consumer replays it (one lane, no concurrency: the link's waits never wait)
+            static uint32_t ring[4096];
+            uint32_t fin[4] = {0, 0, 0, 0};
+            int p_count = -1, c_count = 0;
+            lc3_pc_link k;
+            k.ring = ring;
+            k.mask = 4095;
+            k.stride = 1;
+            k.fstride = 1;
+            k.p_count = &p_count;
+            k.c_count = &c_count;
+            k.fin = fin;
+            const int rc_in = (bad && bad[f]) ? -100 : 0;
+            lc3_parse_ctx cp = c;  // (its own cursors)
+            lc3_pc_produce(cp, k, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10, rc_in);
+            rc = lc3_pc_consume<1>(c, k, j.cfg.ne, j.cfg.fs_ind, rc_in);
+        } else if (late == 2) rc = (bad && bad[f]) ? -100 : lc3_parse_frame<0>(c, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10);
         else rc = (bad && bad[f]) ? -100 : lc3_parse_frame<1>(c, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10);
         int ok = rc == 0;
         if (ok && late == 2) {  // the reconstruction kernels take the pulse vector de-enumerated and count the residual bits themselves
@@ -406,7 +424,7 @@ int lc3emu_decode_late(int fs_hz, int frame_us, int nbytes, int S, int T, const 
             r.ifs = nullptr;
             lc3_reconstruct_prepare_wave(c);
             lc3_parse_pulses(c, r);
-        } else if (ok && late) {
+        } else if (ok && late && late != 3) {
             ok = lc3_reconstruct_prepare_late(c);
         } else if (ok) {  // the same lane rebuilds the spectrum (lc3_parse_kernel)
             float scf[16];

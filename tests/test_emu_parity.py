@@ -152,13 +152,15 @@ def test_emu_guarded_decisions_and_their_sequential_path(fs, us, nf, nbytes):
     assert np.array_equal(E.encode(pcm, nbytes, fs, us, spec_flags=1024), ref)
 
 
-@pytest.mark.parametrize("late", [1, 2])
+@pytest.mark.parametrize("late", [1, 2, 3])
 def test_emu_late_reconstruction(late):
     """Launches of a few frames reconstruct the spectrum (residual bits, noise filling, gain, TNS, band gains) with the 64 lanes of
     the stream's wave in the synthesis stage instead of one lane of the parser (lc3_dec_reconstruct_wave): the same PCM as the
     oracle on clean streams of every kind, on corrupted and flagged frames (concealment then reads the state blob's copy of the
     last good spectrum), on garbage, and through the LTPF transitions.  late = 2: the same wave-parallel reconstruction as the
-    wave-per-FRAME kernel of full batches (lc3_recon_kernel) between parser and synthesis."""
+    wave-per-FRAME kernel of full batches (lc3_recon_kernel) between parser and synthesis.  late = 3: the parser's producer / consumer
+    form of full batches (lc3_pc_produce / lc3_pc_consume: the range decoder's recurrence on one wave, everything that only consumes
+    symbols on another), with the reconstruction on the consumer's lane."""
     for fs, us, nf, nb in [(48000, 10000, 480, 150), (48000, 7500, 360, 113), (32000, 10000, 320, 40), (24000, 7500, 180, 60),
                            (16000, 10000, 160, 120), (8000, 10000, 80, 30), (48000, 10000, 480, 20), (48000, 10000, 480, 400)]:
         pcm = synth.make_pcm(8, 6, nf, fs, first_stream=300)

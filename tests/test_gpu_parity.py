@@ -875,11 +875,11 @@ def _split_suite():
 
 
 def test_split_calls_on_and_off():
-    """A batch call of a full batch (at least 32 768 frames) runs as two halves of its streams on the handle's two internal HIP streams,
-    forked from and joined to the caller's stream by events (lc3_split_parts, lc3gpu.hip); LC3GPU_SPLIT=1 forces that for every call of
-    at least 16 streams, LC3GPU_SPLIT=0 switches it off.  Both ways through state carry, state blobs, ranges, damaged frames at launch
-    edges, odd stream counts, the interleaved layout, cross-stream ordering and the timer, against the oracle; and the split and the
-    unsplit form of the SAME full-size launch byte for byte (test_full_size_batch_properties has the default form against the oracle)."""
+    """LC3GPU_SPLIT=1 (opt-in: measured slower than one launch per kernel, lc3_split_parts in lc3gpu.hip) runs every batch call of at
+    least 16 streams as two halves of its streams on the handle's two internal HIP streams, forked from and joined to the caller's stream
+    by events; LC3GPU_SPLIT=0 / unset never does.  Both ways through state carry, state blobs, ranges, damaged frames at launch edges, odd
+    stream counts, the interleaved layout, cross-stream ordering and the timer, against the oracle; and the split and the unsplit form
+    of the SAME full-size launches byte for byte."""
     import os
     import subprocess
     import sys
@@ -962,11 +962,12 @@ def test_late_reconstruction_on_and_off():
         "print('late ok')\n"
     )
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for v in ("lane", "late", "wave"):
-        env = dict(os.environ, LC3GPU_RECON=v)
+    # (lane form: the parser as producer / consumer wave pairs, the default of full batches, and as one wave per 64 frames)
+    for v, pc in (("lane", "1"), ("lane", "0"), ("late", "1"), ("wave", "1")):
+        env = dict(os.environ, LC3GPU_RECON=v, LC3GPU_PARSE_PC=pc)
         env.pop("LC3GPU_LATE_RECON", None)
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and "late ok" in r.stdout, v + r.stdout[-2000:] + r.stderr[-2000:]
+        assert r.returncode == 0 and "late ok" in r.stdout, v + pc + r.stdout[-2000:] + r.stderr[-2000:]
 
 
 # ---------------------------------------------------------------- spec-conformant switches

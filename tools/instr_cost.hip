@@ -1,8 +1,10 @@
 // What single instructions and short idioms cost a wave of the lane-per-frame kernels (one wave per SIMD) and of the wave-per-stream
-// kernels (four): shader-clock cycles per instruction, measured as 2000 rounds of an unrolled block between two s_memtime stamps.
+// kernels (four): shader-clock cycles per instruction, measured as 500 rounds of an unrolled block of 256 idioms (ONE asm statement: the
+// compiler pads between two of them with an s_nop; the loop's own ~32 cycles per round are under 3 % of the cheapest block and are
+// subtracted) between two s_memtime stamps.
 // The lane-per-frame kernels are issue-bound (filler instructions cost their full time), so their time is the sum
 // of these numbers -- this table says which idiom to write.
-// Stand-alone: hipcc --offload-arch=gfx950 -O3 -o instr_cost tools/instr_cost.hip && ./instr_cost > profiles/r03_instr_cost.json
+// Stand-alone: hipcc --offload-arch=gfx950 -O3 -o instr_cost tools/instr_cost.hip && ./instr_cost > profiles/r04_instr_cost.json
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -19,10 +21,10 @@
         }                                                                             \
     } while (0)
 
-#define REP8(x) x x x x x x x x
+#define REP8(x) x
 #define OPERANDS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "v"(lds) : "vcc", "s20", "s21", "s22", "s23", "memory"
-// eight copies of an idiom on eight independent registers, eight times: 64 idioms per block
-#define BLOCK(S0, S1, S2, S3, S4, S5, S6, S7) REP8(asm volatile(S0 S1 S2 S3 S4 S5 S6 S7 OPERANDS);)
+// eight copies of an idiom on eight independent registers, 32 times: 256 idioms per block
+#define BLOCK(S0, S1, S2, S3, S4, S5, S6, S7) REP8(asm volatile(".rept 32\n" S0 S1 S2 S3 S4 S5 S6 S7 ".endr\n" OPERANDS);)
 #define EACH(OP) BLOCK(OP(0), OP(1), OP(2), OP(3), OP(4), OP(5), OP(6), OP(7))
 
 #define KERNEL(NAME, PRE, BODY)                                                                             \
@@ -34,7 +36,7 @@
         __syncthreads();                                                                                    \
         PRE;                                                                                                \
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
-        for (int i = 0; i < iters; i++) { BODY }                                                            \
+        _Pragma("unroll 1") for (int i = 0; i < iters; i++) { BODY }                                        \
         asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 0" ::: "memory");                                        \
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
         if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0; \
@@ -54,6 +56,18 @@
 #define I_SEL_S2(i) "v_cmp_lt_u32_e64 s[20:21], %8, %" #i "\n v_cmp_lt_u32_e64 s[22:23], %" #i ", %8\n v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[20:21]\n"
 #define I_SEL_ARITH(i) "v_sub_u32 %" #i ", %" #i ", %8\n v_ashrrev_i32 %" #i ", 31, %" #i "\n v_bfi_b32 %" #i ", %" #i ", %8, %9\n"
 #define I_SEL_MINMAX(i) "v_min_u32 %" #i ", %" #i ", %8\n"
+// a VOP2 select on vcc in its surroundings: right behind the compare that wrote vcc; the second select on the same compare; a select on
+// a vcc written long ago, between other instructions
+#define I_SEL_VCC2(i) "v_cmp_lt_u32_e32 vcc, %8, %" #i "\n v_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n v_cndmask_b32_e32 %" #i ", %" #i ", %9, vcc\n"
+#define I_SEL_VCC_GAP(i) "v_cmp_lt_u32_e32 vcc, %8, %" #i "\n v_add_u32 %" #i ", %" #i ", %8\n v_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n"
+#define I_CND_VCC_ADD(i) "v_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n v_add_u32 %" #i ", %" #i ", %8\n"
+#define I_SEL_S_NONOP(i) "v_cmp_lt_u32_e64 s[20:21], %8, %" #i "\n v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[20:21]\n"
+#define I_SEL_S_2(i) "v_cmp_lt_u32_e64 s[20:21], %8, %" #i "\n v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[20:21]\n v_cndmask_b32_e64 %" #i ", %" #i ", %9, s[20:21]\n"
+KERNEL(k_sel_vcc2, NOPRE, EACH(I_SEL_VCC2))
+KERNEL(k_sel_vcc_gap, NOPRE, EACH(I_SEL_VCC_GAP))
+KERNEL(k_cnd_vcc_add, SETMASKS, EACH(I_CND_VCC_ADD))
+KERNEL(k_sel_s_nonop, NOPRE, EACH(I_SEL_S_NONOP))
+KERNEL(k_sel_s_2, NOPRE, EACH(I_SEL_S_2))
 KERNEL(k_cnd_vcc, SETMASKS, EACH(I_CND_VCC))
 KERNEL(k_cnd_e64_vcc, SETMASKS, EACH(I_CND_E64_VCC))
 KERNEL(k_cnd_e64_s, SETMASKS, EACH(I_CND_E64_S))
@@ -111,7 +125,7 @@ int main() {
     setvbuf(stdout, nullptr, _IOLBF, 0);
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
-    const int cus = prop.multiProcessorCount, iters = 2000;
+    const int cus = prop.multiProcessorCount, iters = 500;
     unsigned long long *d_cycles;
     unsigned *d_sink;
     CHECK(hipMalloc(&d_cycles, sizeof(unsigned long long) * (size_t)cus * 32));
@@ -124,6 +138,11 @@ int main() {
         {"v_cmp_lt_u32_e64 -> s[20:21]", k_cmp_s, 1, "compare writing an SGPR pair"},
         {"v_cmp_e32 + v_cndmask_e32 through vcc", k_sel_vcc, 2, "a select: two instructions"},
         {"v_cmp_e64 + s_nop 1 + v_cndmask_e64 through s[20:21]", k_sel_s, 3, "a select as the compiler emits it: three instructions"},
+        {"v_cmp_e64 + v_cndmask_e64 through s[20:21], no s_nop", k_sel_s_nonop, 2, "the same without the compiler's wait states (the hardware interlocks)"},
+        {"v_cmp_e64 + 2 x v_cndmask_e64 through s[20:21], no s_nop", k_sel_s_2, 3, "one compare, two selects"},
+        {"v_cmp_e32 + 2 x v_cndmask_e32 through vcc", k_sel_vcc2, 3, "one compare, two selects on vcc"},
+        {"v_cmp_e32 + v_add_u32 + v_cndmask_e32 through vcc", k_sel_vcc_gap, 3, "an instruction between the compare and its select"},
+        {"v_cndmask_b32_e32 (vcc) + v_add_u32", k_cnd_vcc_add, 2, "selects on a vcc written long ago, between other instructions"},
         {"v_cmp_e64 + v_cmp_e64 + v_cndmask_e64", k_sel_s2, 3, "a select with another compare in the wait-state slot"},
         {"v_sub + v_ashrrev 31 + v_bfi", k_sel_arith, 3, "a select without a mask register: three instructions"},
         {"v_min_u32", k_min, 1, ""},
@@ -138,7 +157,7 @@ int main() {
         {"ds_read_b32 pointer chase", k_dschase, 1, "read, wait, mask: dependent round trip"},
     };
     printf("{\n  \"device\": \"%s\", \"gcn_arch\": \"%s\", \"compute_units\": %d,\n", prop.name, prop.gcnArchName, cus);
-    printf("  \"method\": \"one workgroup of 4W waves per CU; %d rounds of 64 idioms on eight independent registers between two s_memtime stamps; cycles per idiom = cycles of the slowest wave / (W x idioms)\",\n", iters);
+    printf("  \"method\": \"one workgroup of 4W waves per CU; %d rounds of 256 idioms (one asm statement) on eight independent registers between two s_memtime stamps, 32 cycles per round of loop overhead subtracted; cycles per idiom = cycles of the slowest wave / (W x idioms)\",\n", iters);
     printf("  \"idioms\": [\n");
     bool first = true;
     for (const Case &c : cases) {
@@ -155,8 +174,8 @@ int main() {
             std::vector<unsigned long long> h((size_t)waves);
             CHECK(hipMemcpy(h.data(), d_cycles, sizeof(unsigned long long) * (size_t)waves, hipMemcpyDeviceToHost));
             std::sort(h.begin(), h.end());
-            const double idioms = 64.0 * iters;
-            per[wi++] = (double)h.back() / (W * idioms);
+            const double idioms = 256.0 * iters;
+            per[wi++] = ((double)h.back() - 32.0 * iters) / (W * idioms);
         }
         const double n = 1.0;
         printf("%s    {\"idiom\": \"%s\", \"instructions\": %d, \"cycles_lone_wave\": %.2f, \"cycles_per_wave_at_4_per_simd\": %.2f, \"note\": \"%s\"}",

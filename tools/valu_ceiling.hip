@@ -50,9 +50,11 @@
 #define OP_MUL24(i) "v_mul_u32_u24 %" #i ", %" #i ", %8\n"
 #define OP_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
 // the mix: per eight instructions 2 f32 add, 2 f32 mul, 2 selects, 1 DPP move, 1 integer add (the analysis kernels' VALU histogram)
-#define OP_MIX(i) "v_add_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_cndmask_b32 %2, %2, %8, vcc\n v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n" \
-                  "v_add_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_cndmask_b32 %6, %6, %8, vcc\n v_add_u32 %7, %7, %8\n"
-#define BLOCK_MIX REP8(asm volatile(R128 OP_MIX(0) ENDR : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc");)
+// (the selects in the SGPR-pair form the kernels' selects mostly have; a VOP2 select on vcc that does not directly follow the compare that
+// wrote vcc is a case of its own, rows "v_cndmask_b32 (vcc)": 22.8 cycles)
+#define OP_MIX(i) "v_add_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n" \
+                  "v_add_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_cndmask_b32_e64 %6, %6, %8, s[20:21]\n v_add_u32 %7, %7, %8\n"
+#define BLOCK_MIX REP8(asm volatile(R128 OP_MIX(0) ENDR : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "s20", "s21");)
 // v_readlane writes a scalar register: eight different ones per group
 #define BLOCK_READLANE                                                                                                      \
     REP8(asm volatile(R128 "v_readlane_b32 s20, %0, 1\n v_readlane_b32 s21, %1, 2\n v_readlane_b32 s22, %2, 3\n v_readlane_b32 s23, %3, 4\n" \
@@ -92,7 +94,7 @@ KERNEL(k_shift, BLOCK_INDEP(OP_SHIFT))
 KERNEL(k_mul24, BLOCK_INDEP(OP_MUL24))
 KERNEL(k_mullo, BLOCK_INDEP(OP_MULLO))
 KERNEL(k_readlane, BLOCK_READLANE)
-KERNEL(k_mix, BLOCK_MIX)
+KERNEL(k_mix, asm volatile("s_mov_b64 s[20:21], 0x5555" ::: "s20", "s21"); BLOCK_MIX)
 KERNEL(k_fadd_chain, BLOCK_CHAIN(OP_FADD))
 KERNEL(k_cndmask_chain, BLOCK_CHAIN(OP_CNDMASK))
 
@@ -119,7 +121,7 @@ int main() {
         {"v_add_u32", k_iadd, "8 independent streams"}, {"v_lshlrev_b32", k_shift, "8 independent streams"},
         {"v_mul_u32_u24", k_mul24, "8 independent streams"}, {"v_mul_lo_u32", k_mullo, "8 independent streams"},
         {"v_readlane_b32", k_readlane, "8 independent streams"},
-        {"mix (2 add, 2 mul, 2 cndmask, 1 dpp, 1 iadd per 8)", k_mix, "8 independent streams"},
+        {"mix (2 add, 2 mul, 2 cndmask_e64, 1 dpp, 1 iadd per 8)", k_mix, "8 independent streams"},
         {"v_add_f32 dependent chain", k_fadd_chain, "1 chain"}, {"v_cndmask_b32 dependent chain", k_cndmask_chain, "1 chain"},
     };
     printf("{\n  \"device\": \"%s\", \"gcn_arch\": \"%s\", \"compute_units\": %d, \"clock_khz_reported\": %d,\n", prop.name, prop.gcnArchName, cus,
