@@ -288,6 +288,30 @@ __device__ __forceinline__ float lc3_sqrtf(float x) { return __builtin_sqrtf(x);
 __device__ __forceinline__ float lc3_floorf(float x) { return __builtin_floorf(x); }
 __device__ __forceinline__ float lc3_ceilf(float x) { return __builtin_ceilf(x); }
 
+// ---- the link between the two waves of a producer / consumer pair (parser: lc3_dev_dec_parse.h, packer: lc3_dev_enc_pack.h): a
+// ring of one word per lane and iteration in LDS and two wave-level counters.  The iteration count is the wave's -- every lane of both
+// waves steps once per iteration, a lane without work idles -- so ring entry i of lane l means the same to both.  The producer
+// publishes its count every LC3_PC_CHUNK iterations (a wave's LDS stores execute in order: the count follows the entries it covers)
+// and waits when the consumer falls a ring behind; the consumer publishes what it has taken.
+#ifndef LC3_PC_STORE   // (the GPU build defines these over LDS with the compiler kept from reordering around them; these are the emulator's)
+#define LC3_PC_STORE(p, v) (*(volatile int *)(p) = (v))
+#define LC3_PC_LOAD(p) (*(volatile const int *)(p))
+#define LC3_PC_PAUSE() ((void)0)
+#define LC3_PC_RELEASE() ((void)0)
+#define LC3_PC_ACQUIRE() ((void)0)
+#endif
+#define LC3_PC_CHUNK 4
+#define LC3_PC_DONE 0x40000000
+#define LC3_PC_SPIN_LIMIT (1 << 24)  // polls before a wave gives up on its partner (never reached unless the partner died)
+struct lc3_pc_link {
+    uint32_t *ring;   // this lane's entries: entry i at ring[(i & mask) * stride]
+    int mask, stride;
+    int *p_count;     // wave-level words: -1 until the producer has left its start values, then the iterations it has published, | LC3_PC_DONE at its end
+    int *c_count;     // iterations the consumer has taken
+    uint32_t *fin;    // this lane's hand-over words fin[j * fstride], j = 0 .. 3: head cursor after the TNS data, final range, final head cursor, error flag
+    int fstride;
+};
+
 // range decoder state (decoder/arithmetic_codec.rs:22-26)
 struct lc3_acdec { uint32_t low, range; };
 

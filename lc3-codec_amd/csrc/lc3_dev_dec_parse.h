@@ -527,25 +527,6 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
 // The producer publishes its iteration count every LC3_PC_CHUNK iterations (stores of one wave reach LDS in order: the count
 // follows the entries it covers) and waits when the consumer falls a ring behind; the consumer publishes what it has taken.
 // ------------------------------------------------------------------------------------------------------------------
-#ifndef LC3_PC_STORE   // (the GPU build defines these over LDS with the compiler kept from reordering around them; these are the emulator's)
-#define LC3_PC_STORE(p, v) (*(volatile int *)(p) = (v))
-#define LC3_PC_LOAD(p) (*(volatile const int *)(p))
-#define LC3_PC_PAUSE() ((void)0)
-#define LC3_PC_RELEASE() ((void)0)
-#define LC3_PC_ACQUIRE() ((void)0)
-#endif
-#define LC3_PC_CHUNK 4
-#define LC3_PC_DONE 0x40000000
-#define LC3_PC_SPIN_LIMIT (1 << 24)  // polls before a wave gives up on its partner (never reached unless the partner died)
-struct lc3_pc_link {
-    uint32_t *ring;   // this lane's entries: entry i at ring[(i & mask) * stride]
-    int mask, stride;
-    int *p_count;     // wave-level words: -1 until the producer has left its start values, then the iterations it has published, | LC3_PC_DONE at its end
-    int *c_count;     // iterations the consumer has taken
-    uint32_t *fin;    // this lane's hand-over words fin[j * fstride], j = 0 .. 3: head cursor after the TNS data, final range, final head cursor, error flag
-    int fstride;
-};
-
 // the producer: side information (flags only), range decoder start, TNS data, then the symbols
 __device__ __forceinline__ void lc3_pc_produce(lc3_parse_ctx &c, const lc3_pc_link &k, int ne, int fs_ind, int n_ms_10, int rc_in) {
     int lastnz = 0, lsb_mode = 0, num_tns = 0, ord[2] = {0, 0};

@@ -221,22 +221,27 @@ __device__ __forceinline__ lc3_pk_sym lc3_pk_symbol(uint32_t xw, int lev, int cc
     return s;
 }
 
-// BitstreamEncoding::encode :77-136; the buffer must be zero-filled (init :138-144)
-__device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
+// the column's scalar words, TNS indices and residual bit words
+struct lc3_pack_head {
+    int32_t sw[EP_RES];
+    uint32_t rw[13];  // residual bit words (used when the frame is not in LSB mode)
+};
+#define LC3_EPW(word) h.sw[word]
+// the 21 scalar words and the 16 TNS indices of the column: one batch of independent loads (a lane of this kernel
+// is latency-bound; every plane word fetched at its point of use would cost a full memory round trip)
+__device__ __forceinline__ void lc3_pack_load_head(const lc3_pack_ctx &w, lc3_pack_head &h) {
+#pragma unroll
+    for (int i = 0; i < EP_RES; i++) h.sw[i] = lc3_ep_get(w, i);
+#pragma unroll
+    for (int i = 0; i < 13; i++) h.rw[i] = (uint32_t)lc3_ep_get(w, EP_RES + i);
+}
+// BitstreamEncoding::encode :77-136 up to the spectral data: side information, ac_enc_init, tns_data
+__device__ __forceinline__ void lc3_pack_begin(lc3_pack_ctx &w, int ne, const lc3_pack_head &h) {
     w.nbits = w.nbytes * 8;
     w.bp = 0;
     w.bp_side = w.nbytes - 1;
     w.mask_side = 1;
     w.side_acc = 0;
-    // the 21 scalar words and the 16 TNS indices of the column: one batch of independent loads (a lane of this kernel
-    // is latency-bound; every plane word fetched at its point of use would cost a full memory round trip)
-    int32_t sw[EP_RES];
-    uint32_t rw[13];  // residual bit words (used when the frame is not in LSB mode)
-#pragma unroll
-    for (int i = 0; i < EP_RES; i++) sw[i] = lc3_ep_get(w, i);
-#pragma unroll
-    for (int i = 0; i < 13; i++) rw[i] = (uint32_t)lc3_ep_get(w, EP_RES + i);
-#define LC3_EPW(word) sw[word]
     const int lsb_mode = LC3_EPW(EP_LSB_MODE), lastnz_trunc = LC3_EPW(EP_LASTNZ_TRUNC);
     const int num_tns = LC3_EPW(EP_NUM_TNS), rate_flag = LC3_EPW(EP_RATE_FLAG);
     const int ord0 = LC3_EPW(EP_ORD0), ord1 = LC3_EPW(EP_ORD1);
@@ -294,7 +299,7 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
                     int ri = 0;
 #pragma unroll
                     for (int q = 0; q < 16; q++)
-                        if (q == k + 8 * f) ri = sw[EP_RCI + q];
+                        if (q == k + 8 * f) ri = h.sw[EP_RCI + q];
                     ri = ri < 0 ? 0 : (ri > 16 ? 16 : ri);
                     const uint32_t sc = w.tns[16 + k * 17 + ri];
                     lc3_pk_ac_encode(w, sc & 0xffffu, sc >> 16);
@@ -302,71 +307,11 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
             }
         }
     }
-    LC3_PSTAMP(w, 2);
-    // spectral_data :246-326
-    int nlsbs = 0;
-    const int nsym = LC3_EPW(EP_NSYM);
-    if (LC3_WAVE_ANY(nsym >= 0)) {
-        // prepared symbols (small launches): interval, then its bits; the word three symbols ahead is requested every iteration
-        const int n = nsym > 0 ? nsym : 0, last = LC3_SYM_CAP - 1;
-        uint32_t s0 = (uint32_t)lc3_ep_get(w, EP_SYM), s1 = (uint32_t)lc3_ep_get(w, EP_SYM + 1), s2 = (uint32_t)lc3_ep_get(w, EP_SYM + 2),
-                 s3 = (uint32_t)lc3_ep_get(w, EP_SYM + 3);
-        for (int i = 0; LC3_WAVE_ANY(i < n); i++) {
-            if (i < n) {
-                lc3_pk_ac_encode_sel(w, s0 & 0x3ffu, (s0 >> 10) & 0x3ffu);
-                const int nb = (int)((s0 >> 20) & 3u);
-                lc3_pk_bool2_backward_sel(w, nb > 0, (int)((s0 >> 22) & 1u), nb > 1, (int)((s0 >> 23) & 1u));
-            }
-            s0 = s1;
-            s1 = s2;
-            s2 = s3;
-            s3 = (uint32_t)lc3_ep_get(w, EP_SYM + (i + 4 < last ? i + 4 : last));
-        }
-        nlsbs = nsym >= 0 ? LC3_EPW(EP_NLSBS) : 0;
-    }
-    if (LC3_WAVE_ANY(nsym < 0) && nsym < 0) {
-
-        // One symbol per iteration and lane: every lane walks its own frame's symbol sequence (escape symbols of a pair,
-        // then its main symbol) and moves on to its next pair by itself.  With a common pair index the wave spends
-        // sum over pairs of (1 + deepest escape level of any lane) iterations, here max over lanes of (sum over pairs of
-        // 1 + level): 1.45x fewer on the benchmark's frames.  The pair after next-but-one is requested every iteration.
-        const int ntup = lastnz_trunc / 2, last = ne / 2 - 1;
-        int tup = 0, lev = 0, cctx = 0;
-        uint32_t xw = (uint32_t)lc3_ep_get(w, EP_XQ), x1 = (uint32_t)lc3_ep_get(w, EP_XQ + (1 < last ? 1 : last)),
-                 x2 = (uint32_t)lc3_ep_get(w, EP_XQ + (2 < last ? 2 : last)), x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (3 < last ? 3 : last));
-        // The symbols depend on the quantised values only, not on the coder's state (:262-296): what the coming iteration
-        // encodes (and its model word) is worked out during the iteration before it and carried over.
-        lc3_pk_sym cur = lc3_pk_symbol(xw, 0, 0, 0, rate_flag, ne);
-        uint32_t sv = w.cf[(int)w.lookup[cur.idx] * 17 + (cur.esc ? 16 : (int)(cur.a + 4u * cur.b))];
-        while (tup < ntup) {
-            // `cur`: an escape symbol (and two LSBs), or the pair's main symbol (and its signs).  Where the lane will be
-            // after it, and that symbol's model row:
-            const int adv = !cur.esc;
-            const int n_cctx = adv ? (cctx & 15) * 16 + (cur.lv <= 1 ? 1 + (int)((cur.a + cur.b) << cur.lv) : 12 + cur.lv) : cctx;
-            const int n_lev = adv ? 0 : lev + 1, n_tup = tup + adv;
-            const uint32_t n_xw = adv ? x1 : xw;
-            const lc3_pk_sym nxt = lc3_pk_symbol(n_xw, n_lev, n_cctx, n_tup, rate_flag, ne);
-            const int rown = (int)w.lookup[nxt.idx];
-            // this symbol
-            lc3_pk_ac_encode_sel(w, sv & 0xffffu, sv >> 16);
-            const int lsb_here = lsb_mode && lev > 0;
-            const unsigned a_l = lsb_here ? cur.a0 >> 1 : cur.a0, b_l = lsb_here ? cur.b0 >> 1 : cur.b0;
-            const int want_e = !(lsb_mode && lev == 0);
-            lc3_pk_bool2_backward_sel(w, cur.esc ? want_e : a_l > 0u, cur.esc ? (cur.a & 1u) == 1u : cur.q0 <= 0,
-                                      cur.esc ? want_e : b_l > 0u, cur.esc ? (cur.b & 1u) == 1u : cur.q1 <= 0);
-            // the LSB list itself is regenerated below when it is written
-            nlsbs += (!cur.esc && lsb_here) ? 2 + (a_l == 0u && cur.q0 != 0) + (b_l == 0u && cur.q1 != 0) : 0;
-            sv = w.cf[rown * 17 + (nxt.esc ? 16 : (int)(nxt.a + 4u * nxt.b))];
-            cur = nxt;
-            cctx = n_cctx;
-            lev = n_lev;
-            tup = n_tup;
-            xw = n_xw;
-            x1 = adv ? x2 : x1;
-            x2 = adv ? x3 : x2;
-            x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (tup + 3 < last ? tup + 3 : last));  // the same word again unless the lane advanced
-        }
-    }
+}
+// ... and behind it: residual_data_and_finalization :328-352, ac_enc_finish :354-395.  nlsbs: the number of LSB-list bits the spectral
+// data implies (:298-312)
+__device__ __forceinline__ void lc3_pack_end(lc3_pack_ctx &w, int ne, const lc3_pack_head &h, int nlsbs) {
+    const int lsb_mode = LC3_EPW(EP_LSB_MODE), lastnz_trunc = LC3_EPW(EP_LASTNZ_TRUNC);
     LC3_PSTAMP(w, 3);
     // residual_data_and_finalization :328-352
     {
@@ -382,7 +327,7 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
 #pragma unroll
             for (int i = 0; i < 13; i++) {  // the words were fetched with the column's scalars
                 const int k = 32 * i;
-                if (k < n_enc) lc3_pk_uint_backward(w, rw[i], n_enc - k < 32 ? n_enc - k : 32);
+                if (k < n_enc) lc3_pk_uint_backward(w, h.rw[i], n_enc - k < 32 ? n_enc - k : 32);
             }
         } else {
             // lsbs[0 .. nlsbs) in the order spectral_data pushed them (:298-312), regenerated on the fly; the pairs are
@@ -451,5 +396,173 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
         }
     }
     LC3_PSTAMP(w, 5);
+}
+
+// BitstreamEncoding::encode :77-136; the buffer must be zero-filled (init :138-144)
+__device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
+    lc3_pack_head h;
+    lc3_pack_load_head(w, h);
+    lc3_pack_begin(w, ne, h);
+    const int lsb_mode = LC3_EPW(EP_LSB_MODE), lastnz_trunc = LC3_EPW(EP_LASTNZ_TRUNC), rate_flag = LC3_EPW(EP_RATE_FLAG);
+    LC3_PSTAMP(w, 2);
+    // spectral_data :246-326
+    int nlsbs = 0;
+    const int nsym = LC3_EPW(EP_NSYM);
+    if (LC3_WAVE_ANY(nsym >= 0)) {
+        // prepared symbols (small launches): interval, then its bits; the word three symbols ahead is requested every iteration
+        const int n = nsym > 0 ? nsym : 0, last = LC3_SYM_CAP - 1;
+        uint32_t s0 = (uint32_t)lc3_ep_get(w, EP_SYM), s1 = (uint32_t)lc3_ep_get(w, EP_SYM + 1), s2 = (uint32_t)lc3_ep_get(w, EP_SYM + 2),
+                 s3 = (uint32_t)lc3_ep_get(w, EP_SYM + 3);
+        for (int i = 0; LC3_WAVE_ANY(i < n); i++) {
+            if (i < n) {
+                lc3_pk_ac_encode_sel(w, s0 & 0x3ffu, (s0 >> 10) & 0x3ffu);
+                const int nb = (int)((s0 >> 20) & 3u);
+                lc3_pk_bool2_backward_sel(w, nb > 0, (int)((s0 >> 22) & 1u), nb > 1, (int)((s0 >> 23) & 1u));
+            }
+            s0 = s1;
+            s1 = s2;
+            s2 = s3;
+            s3 = (uint32_t)lc3_ep_get(w, EP_SYM + (i + 4 < last ? i + 4 : last));
+        }
+        nlsbs = nsym >= 0 ? LC3_EPW(EP_NLSBS) : 0;
+    }
+    if (LC3_WAVE_ANY(nsym < 0) && nsym < 0) {
+
+        // One symbol per iteration and lane: every lane walks its own frame's symbol sequence (escape symbols of a pair,
+        // then its main symbol) and moves on to its next pair by itself.  With a common pair index the wave spends
+        // sum over pairs of (1 + deepest escape level of any lane) iterations, here max over lanes of (sum over pairs of
+        // 1 + level): 1.45x fewer on the benchmark's frames.  The pair after next-but-one is requested every iteration.
+        const int ntup = lastnz_trunc / 2, last = ne / 2 - 1;
+        int tup = 0, lev = 0, cctx = 0;
+        uint32_t xw = (uint32_t)lc3_ep_get(w, EP_XQ), x1 = (uint32_t)lc3_ep_get(w, EP_XQ + (1 < last ? 1 : last)),
+                 x2 = (uint32_t)lc3_ep_get(w, EP_XQ + (2 < last ? 2 : last)), x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (3 < last ? 3 : last));
+        // The symbols depend on the quantised values only, not on the coder's state (:262-296): what the coming iteration
+        // encodes (and its model word) is worked out during the iteration before it and carried over.
+        lc3_pk_sym cur = lc3_pk_symbol(xw, 0, 0, 0, rate_flag, ne);
+        uint32_t sv = w.cf[(int)w.lookup[cur.idx] * 17 + (cur.esc ? 16 : (int)(cur.a + 4u * cur.b))];
+        while (tup < ntup) {
+            // `cur`: an escape symbol (and two LSBs), or the pair's main symbol (and its signs).  Where the lane will be
+            // after it, and that symbol's model row:
+            const int adv = !cur.esc;
+            const int n_cctx = adv ? (cctx & 15) * 16 + (cur.lv <= 1 ? 1 + (int)((cur.a + cur.b) << cur.lv) : 12 + cur.lv) : cctx;
+            const int n_lev = adv ? 0 : lev + 1, n_tup = tup + adv;
+            const uint32_t n_xw = adv ? x1 : xw;
+            const lc3_pk_sym nxt = lc3_pk_symbol(n_xw, n_lev, n_cctx, n_tup, rate_flag, ne);
+            const int rown = (int)w.lookup[nxt.idx];
+            // this symbol
+            lc3_pk_ac_encode_sel(w, sv & 0xffffu, sv >> 16);
+            const int lsb_here = lsb_mode && lev > 0;
+            const unsigned a_l = lsb_here ? cur.a0 >> 1 : cur.a0, b_l = lsb_here ? cur.b0 >> 1 : cur.b0;
+            const int want_e = !(lsb_mode && lev == 0);
+            lc3_pk_bool2_backward_sel(w, cur.esc ? want_e : a_l > 0u, cur.esc ? (cur.a & 1u) == 1u : cur.q0 <= 0,
+                                      cur.esc ? want_e : b_l > 0u, cur.esc ? (cur.b & 1u) == 1u : cur.q1 <= 0);
+            // the LSB list itself is regenerated below when it is written
+            nlsbs += (!cur.esc && lsb_here) ? 2 + (a_l == 0u && cur.q0 != 0) + (b_l == 0u && cur.q1 != 0) : 0;
+            sv = w.cf[rown * 17 + (nxt.esc ? 16 : (int)(nxt.a + 4u * nxt.b))];
+            cur = nxt;
+            cctx = n_cctx;
+            lev = n_lev;
+            tup = n_tup;
+            xw = n_xw;
+            x1 = adv ? x2 : x1;
+            x2 = adv ? x3 : x2;
+            x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (tup + 3 < last ? tup + 3 : last));  // the same word again unless the lane advanced
+        }
+    }
+    lc3_pack_end(w, ne, h, nlsbs);
+}
 #undef LC3_EPW
+
+// ------------------------------------------------------------------------------------------------------------------
+// The packer of a full batch as a PRODUCER / CONSUMER pair of waves (lc3_pack_pc_kernel, lc3gpu.hip; the link: lc3_dev_common.h).
+// What spectral_data (:246-326) codes does not depend on the coder's state: the producer walks the frame's quantised pairs and
+// leaves one word per symbol -- the model interval and the up to two bits that follow it backwards (the format of the prepared
+// symbols, LC3_SYM_WORD, plus a "this lane has a symbol" bit) -- in the ring; the consumer owns the frame: side information, range
+// coder and both writers, in the reference's order of writes.  A lone wave of the one-wave form issues ~190 instructions per symbol at
+// one per four cycles; here two waves of one SIMD share them.
+// ------------------------------------------------------------------------------------------------------------------
+#define LC3_PK_SYM_VALID 0x80000000u
+// fin words of the link: [0] the number of LSB-list bits (:298-312)
+__device__ __forceinline__ void lc3_pack_produce(const lc3_pack_ctx &w, const lc3_pc_link &k, int ne, int valid) {
+    const int lsb_mode = lc3_ep_get(w, EP_LSB_MODE), lastnz_trunc = lc3_ep_get(w, EP_LASTNZ_TRUNC), rate_flag = lc3_ep_get(w, EP_RATE_FLAG);
+    const int ntup = valid ? lastnz_trunc / 2 : 0, last = ne / 2 - 1;
+    int tup = 0, lev = 0, cctx = 0, nlsbs = 0, it = 0, c_seen = 0, spins = 0;
+    uint32_t xw = (uint32_t)lc3_ep_get(w, EP_XQ), x1 = (uint32_t)lc3_ep_get(w, EP_XQ + (1 < last ? 1 : last)),
+             x2 = (uint32_t)lc3_ep_get(w, EP_XQ + (2 < last ? 2 : last)), x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (3 < last ? 3 : last));
+    lc3_pk_sym cur = lc3_pk_symbol(xw, 0, 0, 0, rate_flag, ne);
+    uint32_t sv = w.cf[(int)w.lookup[cur.idx] * 17 + (cur.esc ? 16 : (int)(cur.a + 4u * cur.b))];
+    LC3_PC_STORE(k.p_count, 0);
+    while (LC3_WAVE_ANY(tup < ntup)) {
+        uint32_t word = 0u;
+        if (tup < ntup) {
+            // where the lane will be after this symbol, and that symbol's model row (see lc3_pack_frame)
+            const int adv = !cur.esc;
+            const int n_cctx = adv ? (cctx & 15) * 16 + (cur.lv <= 1 ? 1 + (int)((cur.a + cur.b) << cur.lv) : 12 + cur.lv) : cctx;
+            const int n_lev = adv ? 0 : lev + 1, n_tup = tup + adv;
+            const uint32_t n_xw = adv ? x1 : xw;
+            const lc3_pk_sym nxt = lc3_pk_symbol(n_xw, n_lev, n_cctx, n_tup, rate_flag, ne);
+            const int rown = (int)w.lookup[nxt.idx];
+            // this symbol: interval, then the bits that follow it (escape: the pair's next bit plane; main symbol: the signs)
+            const int lsb_here = lsb_mode && lev > 0;
+            const unsigned a_l = lsb_here ? cur.a0 >> 1 : cur.a0, b_l = lsb_here ? cur.b0 >> 1 : cur.b0;
+            const int want_e = !(lsb_mode && lev == 0);
+            const int w0 = cur.esc ? want_e : a_l > 0u, w1 = cur.esc ? want_e : b_l > 0u;
+            const uint32_t b0 = cur.esc ? (cur.a & 1u) : (uint32_t)(cur.q0 <= 0), b1 = cur.esc ? (cur.b & 1u) : (uint32_t)(cur.q1 <= 0);
+            const uint32_t bits = w0 ? (b0 | (b1 << 1)) : b1;  // the first wanted bit lowest
+            word = LC3_PK_SYM_VALID | LC3_SYM_WORD(sv & 0xffffu, sv >> 16, w0 + w1, bits & 3u);
+            // (the LSB list itself is regenerated by lc3_pack_end when it is written)
+            nlsbs += (!cur.esc && lsb_here) ? 2 + (a_l == 0u && cur.q0 != 0) + (b_l == 0u && cur.q1 != 0) : 0;
+            sv = w.cf[rown * 17 + (nxt.esc ? 16 : (int)(nxt.a + 4u * nxt.b))];
+            cur = nxt;
+            cctx = n_cctx;
+            lev = n_lev;
+            tup = n_tup;
+            xw = n_xw;
+            x1 = adv ? x2 : x1;
+            x2 = adv ? x3 : x2;
+            x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (tup + 3 < last ? tup + 3 : last));  // the same word again unless the lane advanced
+        }
+        k.ring[(it & k.mask) * k.stride] = word;  // every lane: a lane that has finished its frame says so
+        it++;
+        if ((it & (LC3_PC_CHUNK - 1)) == 0) {
+            LC3_PC_STORE(k.p_count, it);
+            while (it + LC3_PC_CHUNK - c_seen > k.mask + 1 && spins < LC3_PC_SPIN_LIMIT) {
+                c_seen = LC3_PC_LOAD(k.c_count);
+                if (it + LC3_PC_CHUNK - c_seen > k.mask + 1) {
+                    LC3_PC_PAUSE();
+                    spins++;
+                }
+            }
+        }
+    }
+    k.fin[0] = (uint32_t)nlsbs;
+    LC3_PC_STORE(k.p_count, it | LC3_PC_DONE);
+}
+
+__device__ __forceinline__ void lc3_pack_consume(lc3_pack_ctx &w, const lc3_pc_link &k, int ne, int valid) {
+    lc3_pack_head h;
+    lc3_pack_load_head(w, h);
+    if (valid) lc3_pack_begin(w, ne, h);
+    int it = 0, limit = 0, spins = 0, pc = 0;
+    while (true) {
+        if (it == limit) {  // (wave-uniform) the next chunk, or the end
+            while ((((pc = LC3_PC_LOAD(k.p_count)) & (LC3_PC_DONE - 1)) <= it || pc < 0) && !(pc >= 0 && (pc & LC3_PC_DONE)) && spins < LC3_PC_SPIN_LIMIT) {
+                LC3_PC_PAUSE();
+                spins++;
+            }
+            limit = pc < 0 ? 0 : (pc & (LC3_PC_DONE - 1));
+            if (limit <= it) break;  // the producer has finished (or never answered)
+        }
+        const uint32_t s0 = k.ring[(it & k.mask) * k.stride];
+        if (s0 & LC3_PK_SYM_VALID) {
+            lc3_pk_ac_encode_sel(w, s0 & 0x3ffu, (s0 >> 10) & 0x3ffu);
+            const int nb = (int)((s0 >> 20) & 3u);
+            lc3_pk_bool2_backward_sel(w, nb > 0, (int)((s0 >> 22) & 1u), nb > 1, (int)((s0 >> 23) & 1u));
+        }
+        it++;
+        if ((it & (LC3_PC_CHUNK - 1)) == 0) LC3_PC_STORE(k.c_count, it);
+    }
+    LC3_PC_STORE(k.c_count, LC3_PC_DONE - 1);
+    const int nlsbs = (int)k.fin[0];
+    if (valid) lc3_pack_end(w, ne, h, nlsbs);
 }

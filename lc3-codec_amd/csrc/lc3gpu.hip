@@ -670,6 +670,98 @@ __global__ __launch_bounds__(256) void lc3_pack_mixed_kernel(lc3_groups G, const
                   g.first_stream, io);
 }
 
+// The packer of a full batch as PRODUCER / CONSUMER wave pairs (lc3_pack_produce / lc3_pack_consume, lc3_dev_enc_pack.h): a workgroup of
+// 2 x fpb threads packs fpb frames; wave w of its first half derives the symbol words of 64 frames, wave w of the second half (the same
+// SIMD where the hardware deals a workgroup's waves round the SIMDs) owns their writers and range coders.  Dynamic LDS: as lc3_pack_kernel +
+// per pair of waves a ring of LC3_PKPC_RING x 64 words, 64 hand-over words and two counters (lc3_pack_pc_lds).  All 2 x fpb threads copy
+// the frames out.
+#define LC3_PKPC_RING 16
+static __host__ __device__ inline size_t lc3_pack_pc_lds(unsigned fpb, int nbytes) {
+    const size_t base = (LC3_PACK_LDS_FIXED + (size_t)fpb * (size_t)nbytes + 4 + 15) & ~(size_t)15;  // ... + the packer's sink byte
+    return base + (size_t)(fpb / 64) * (LC3_PKPC_RING * 64 * 4 + 64 * 4) + 64;
+}
+__device__ __forceinline__ void lc3_pack_pc_body(unsigned wg, int ne, const int32_t *planes, uint8_t *out, int nbytes, int n_frames, int T,
+                                                 int first_channel, lc3_io io) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *s_lookup = smem;
+    uint32_t *s_cf = (uint32_t *)(smem + 4096);
+    uint32_t *s_tns = (uint32_t *)(smem + 4096 + 64 * 17 * 4);
+    uint8_t *s_bytes = smem + LC3_PACK_LDS_FIXED;
+    const int tid = threadIdx.x, nt = blockDim.x, fpb = nt >> 1;
+    const int role = tid >= fpb;      // 0: producer, 1: consumer
+    const int ft = tid - role * fpb;  // the frame's slot in the workgroup
+    const int pair = ft >> 6, lane = tid & 63, npairs = fpb >> 6;
+    uint32_t *s_ring = (uint32_t *)(smem + ((LC3_PACK_LDS_FIXED + (size_t)fpb * (size_t)nbytes + 4 + 15) & ~(size_t)15));
+    uint32_t *s_fin = s_ring + npairs * LC3_PKPC_RING * 64;
+    int *s_cnt = (int *)(s_fin + npairs * 64);
+    const size_t f0 = (size_t)wg * (size_t)fpb;
+    const size_t remaining = (size_t)n_frames - f0;
+    const int nfr = remaining < (size_t)fpb ? (int)remaining : fpb;
+    const int total = nfr * nbytes;
+    {
+        if (tid < npairs) {
+            s_cnt[2 * tid] = -1;
+            s_cnt[2 * tid + 1] = 0;
+        }
+        const uint32_t *lk32 = (const uint32_t *)LC3T_AC_SPEC_LOOKUP;
+        uint32_t *d32 = (uint32_t *)s_lookup;
+        for (int i = tid; i < 1024; i += nt) d32[i] = lk32[i];
+        for (int i = tid; i < 64 * 17; i += nt) {
+            const int p = i / 17, j = i - 17 * p;
+            s_cf[i] = (uint32_t)(int)LC3T_AC_SPEC_CUMFREQ[p][j] | ((uint32_t)(int)LC3T_AC_SPEC_FREQ[p][j] << 16);
+        }
+        for (int i = tid; i < LC3_TNS_MODEL_WORDS; i += nt) s_tns[i] = lc3_tns_model_word(i);
+        uint32_t *b32 = (uint32_t *)s_bytes;  // init :138-144: frames start zero-filled
+        for (int i = tid; i < (total + 3) / 4; i += nt) b32[i] = 0;
+    }
+    __syncthreads();
+    if (f0 + (size_t)pair * 64 < (size_t)n_frames) {  // (wave-uniform) a pair of waves past the end of the launch has nothing to do
+        const size_t f = f0 + (size_t)ft;
+        const int valid = f < (size_t)n_frames;
+        lc3_pack_ctx c;
+        c.buf = s_bytes + (valid ? ft : 0) * nbytes;
+        c.sink = s_bytes + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3);
+        c.nbytes = nbytes;
+        c.lookup = s_lookup;
+        c.cf = s_cf;
+        c.tns = s_tns;
+        c.plane = LC3_PLANE_COL(planes, valid ? f : f0, EP_WORDS);  // (a lane past the end reads a column that exists and writes nothing)
+        c.stride = LC3_PLANE_STRIDE;
+        lc3_pc_link k;
+        k.ring = s_ring + pair * (LC3_PKPC_RING * 64) + lane;
+        k.mask = LC3_PKPC_RING - 1;
+        k.stride = 64;
+        k.fstride = 64;
+        k.p_count = s_cnt + 2 * pair;
+        k.c_count = s_cnt + 2 * pair + 1;
+        k.fin = s_fin + pair * 64 + lane;
+        if (role == 0) lc3_pack_produce(c, k, ne, valid);
+        else lc3_pack_consume(c, k, ne, valid);
+    }
+    __syncthreads();
+    if (io.ilv || io.tab) {  // frame f = s * T + t has its own place: one frame after the other, its bytes spread over the threads
+        for (int j = 0; j < nfr; j++) {
+            const size_t fj = f0 + (size_t)j, s = fj / (size_t)T, t = fj - s * (size_t)T;
+            uint8_t *d = out + lc3_io_byte_off(io, nbytes, first_channel, s, t, T);
+            for (int b = tid; b < nbytes; b += nt) d[b] = s_bytes[j * nbytes + b];
+        }
+    } else {
+        uint8_t *dst = out + f0 * (size_t)nbytes;
+        if ((((uintptr_t)dst) & 3u) == 0) {
+            const uint32_t *b32 = (const uint32_t *)s_bytes;
+            uint32_t *d32 = (uint32_t *)dst;
+            for (int i = tid; i < total / 4; i += nt) d32[i] = b32[i];
+            for (int i = (total & ~3) + tid; i < total; i += nt) dst[i] = s_bytes[i];
+        } else {
+            for (int i = tid; i < total; i += nt) dst[i] = s_bytes[i];
+        }
+    }
+}
+__global__ __launch_bounds__(512) void lc3_pack_pc_kernel(int ne, const int32_t *planes, uint8_t *out, int nbytes, int n_frames, int T,
+                                                          lc3_io io) {
+    lc3_pack_pc_body(blockIdx.x, ne, planes, out, nbytes, n_frames, T, 0, io);
+}
+
 // The packer's symbols as a stage of its own (lc3_enc_symbols_frame, lc3_dev_enc.h): one WAVE per frame.  A workgroup stages the
 // context lookup table once (lc3_spec_tab) and walks frames wg * 4 + wave, + 4 * gridDim.x, ...; eight waves per SIMD.  Selectable
 // (LC3GPU_PREP_SYMBOLS=2); measured against the two other forms in DESIGN.md section 6.
@@ -1613,6 +1705,32 @@ static int lc3_recon_mode(size_t n_frames_total, int frames_per_stream) {
     if (forced >= 0) return forced;
     return (n_frames_total <= 16384 && frames_per_stream <= 4) ? LC3_RECON_LATE : LC3_RECON_LANE;
 }
+// The producer / consumer packer (lc3_pack_pc_kernel): the form of full batches (where the packer derives its symbols itself) unless
+// LC3GPU_PACK_PC=0; its ring buffers take the workgroup just beyond the default 64 KB of dynamic LDS
+static bool lc3_pack_pc_enabled() {
+    static const bool on = [] {
+        const char *e = std::getenv("LC3GPU_PACK_PC");
+        return !(e && std::atoi(e) == 0);
+    }();
+    return on;
+}
+static int lc3_pack_pc_optin() {
+    static bool done[LC3_MAX_DEVICES] = {};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= LC3_MAX_DEVICES) return LC3GPU_EINVAL;
+    if (done[dev]) return LC3GPU_OK;
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_pack_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done[dev] = true;
+    return LC3GPU_OK;
+}
+static unsigned lc3_pack_pc_fpb(int nbytes) {
+    unsigned fpb = lc3_frame_block(256u);
+    while (fpb > 64u && lc3_pack_pc_lds(fpb, nbytes) > (size_t)(160 * 1024)) fpb >>= 1;
+    return fpb;
+}
 // The producer / consumer parser (lc3_parse_pc_kernel): the form of full batches unless LC3GPU_PARSE_PC=0.  Its ring buffers take the
 // workgroup beyond the default 64 KB of dynamic LDS: opt in once per device (every instantiation); frames per workgroup as many as fit
 // the 160 KB of a CU
@@ -1988,10 +2106,18 @@ static int encode_kernels(lc3gpu_encoder *e, const HostCfg &h, int first, int n,
                        planes, (int)frames);
         HIP_TRY(hipGetLastError());
     }
-    const unsigned fpb = lc3_frame_block_fit(LC3_PACK_LDS_FIXED, (size_t)nbytes);
-    const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3) + 4;  // + the packer's sink byte
-    hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, h.c.ne, (const int32_t *)planes,
-                       d_out, nbytes, (int)frames, n_frames, io);
+    if (lc3_prep_symbols_mode(frames_of_call) == 0 && lc3_pack_pc_enabled()) {
+        int rc = lc3_pack_pc_optin();
+        if (rc) return rc;
+        const unsigned pfpb = lc3_pack_pc_fpb(nbytes);
+        hipLaunchKernelGGL(lc3_pack_pc_kernel, dim3((unsigned)((frames + pfpb - 1) / pfpb)), dim3(2 * pfpb), lc3_pack_pc_lds(pfpb, nbytes), stream,
+                           h.c.ne, (const int32_t *)planes, d_out, nbytes, (int)frames, n_frames, io);
+    } else {
+        const unsigned fpb = lc3_frame_block_fit(LC3_PACK_LDS_FIXED, (size_t)nbytes);
+        const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3) + 4;  // + the packer's sink byte
+        hipLaunchKernelGGL(lc3_pack_kernel, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, h.c.ne, (const int32_t *)planes,
+                           d_out, nbytes, (int)frames, n_frames, io);
+    }
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream, 3, chain);
     return LC3GPU_OK;

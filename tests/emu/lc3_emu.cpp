@@ -248,7 +248,8 @@ int lc3emu_encode_spec(int fs_hz, int frame_us, int nbytes, int S, int T, const 
     Job j;
     memset(&j, 0, sizeof(j));
     const int symbols_stage = (spec_flags & 1024) != 0;  // emulator only: the packer's symbols from lc3_symbols_kernel (LC3GPU_PREP_SYMBOLS=2)
-    spec_flags &= ~1024;
+    const int pack_pc = (spec_flags & 2048) != 0;        // emulator only: the packer's producer / consumer form (full batches on the GPU)
+    spec_flags &= ~(1024 | 2048);
     j.spec_flags = spec_flags;
     lc3_host_plan pl;
     if (lc3_make_config(j.cfg, frame_us, fs_hz) || lc3_make_plan(j.cfg, pl)) return -1;
@@ -346,7 +347,23 @@ int lc3emu_encode_spec(int fs_hz, int frame_us, int nbytes, int S, int T, const 
         c.cf = cf.data();
         c.plane = LC3_PLANE_COL(planes.data(), f, EP_WORDS);
         c.stride = LC3_PLANE_STRIDE;
-        lc3_pack_frame(c, j.cfg.ne);
+        if (pack_pc) {
+            // (emulator only) the producer / consumer form of full batches (lc3_pack_pc_kernel): the producer derives every symbol word of
+            // the frame into a ring that holds them all, then the consumer codes them (one lane, no concurrency: the waits never wait)
+            static uint32_t ring[4096];
+            uint32_t fin[4] = {0, 0, 0, 0};
+            int p_count = -1, c_count = 0;
+            lc3_pc_link k;
+            k.ring = ring;
+            k.mask = 4095;
+            k.stride = 1;
+            k.fstride = 1;
+            k.p_count = &p_count;
+            k.c_count = &c_count;
+            k.fin = fin;
+            lc3_pack_produce(c, k, j.cfg.ne, 1);
+            lc3_pack_consume(c, k, j.cfg.ne, 1);
+        } else lc3_pack_frame(c, j.cfg.ne);
     }
     return 0;
 }

@@ -150,6 +150,12 @@ def test_emu_guarded_decisions_and_their_sequential_path(fs, us, nf, nbytes):
     # 1024 (emulator only): the same symbol words from the wave-per-frame stage between back half and packer (lc3_symbols_kernel,
     # LC3GPU_PREP_SYMBOLS=2 on the GPU)
     assert np.array_equal(E.encode(pcm, nbytes, fs, us, spec_flags=1024), ref)
+    # 2048 (emulator only): the packer of full batches as a producer / consumer pair (lc3_pack_produce / lc3_pack_consume): symbol words
+    # derived by one wave, range coder and writers on another
+    assert np.array_equal(E.encode(pcm, nbytes, fs, us, spec_flags=2048), ref)
+    hard = synth.make_pcm(6, 4, nf, fs, seed=77) // 2 + synth.make_bandlimited_pcm(6, 4, nf, fs, fs / 6.0, seed=5) // 2
+    for nb in (20, nbytes, 400 if us == 10000 else 300):  # LSB mode at the low end, long escape chains at the high end
+        assert np.array_equal(E.encode(hard, nb, fs, us, spec_flags=2048), O.encode_batch(hard, nb, fs, us)), nb
 
 
 @pytest.mark.parametrize("late", [1, 2, 3])

@@ -804,10 +804,12 @@ def test_prepared_packer_symbols_on_and_off():
         "print('prep ok')\n"
     )
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for v in ("0", "1", "2"):
-        env = dict(os.environ, LC3GPU_PREP_SYMBOLS=v)
+    # (form 0, the packer deriving its symbols itself: as producer / consumer wave pairs -- the default of full batches -- and as one wave
+    # per 64 frames)
+    for v, pc in (("0", "1"), ("0", "0"), ("1", "1"), ("2", "1")):
+        env = dict(os.environ, LC3GPU_PREP_SYMBOLS=v, LC3GPU_PACK_PC=pc)
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and "prep ok" in r.stdout, v + r.stdout[-2000:] + r.stderr[-2000:]
+        assert r.returncode == 0 and "prep ok" in r.stdout, v + pc + r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def _split_suite():
