@@ -248,9 +248,9 @@ def load_ceiling():
         return None
 
 
-# resident waves per SIMD of each kernel on the 65 536-frame batch (lane-per-frame kernels: 1 024 waves on 1 024 SIMDs)
-WAVES_PER_SIMD = {"lc3_enc_front_kernel": 4, "lc3_sns_vq_kernel": 1, "lc3_enc_back_kernel": 4, "lc3_pack_kernel": 1,
-                  "lc3_parse_kernel": 1, "lc3_recon_kernel": 8, "lc3_tns_kernel": 1, "lc3_decode_kernel": 4}
+# resident waves per SIMD of each kernel on the 65 536-frame batch (lane-per-frame kernels: 1 024 waves on 1 024 SIMDs, or 1 024 wave PAIRS)
+WAVES_PER_SIMD = {"lc3_enc_front_kernel": 4, "lc3_sns_vq_kernel": 1, "lc3_enc_back_kernel": 4, "lc3_pack_kernel": 2,
+                  "lc3_parse_kernel": 2, "lc3_recon_kernel": 8, "lc3_tns_kernel": 1, "lc3_decode_kernel": 4}  # (packer / parser: producer + consumer wave)
 
 
 def load_pmc():

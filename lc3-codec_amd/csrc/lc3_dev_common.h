@@ -902,142 +902,152 @@ __device__ __forceinline__ lc3_cpx lc3_cmul(lc3_cpx a, lc3_cpx b) {  // common/c
 __device__ __forceinline__ lc3_cpx lc3_cadd(lc3_cpx a, lc3_cpx b) { lc3_cpx r; r.r = a.r + b.r; r.i = a.i + b.i; return r; }
 __device__ __forceinline__ lc3_cpx lc3_csub(lc3_cpx a, lc3_cpx b) { lc3_cpx r; r.r = a.r - b.r; r.i = a.i - b.i; return r; }
 
-// one butterfly of radix p at element i of the sub-transform based at f[0]
-__device__ __forceinline__ void lc3_bfly(lc3_cpx *f, const lc3_cpx *tw, int p, int fstride, int m, int i) {
+// one butterfly of radix p: x[k] = element i + k m of the sub-transform (k < p) -> y[k], the reference's expression trees term by term
+__device__ __forceinline__ void lc3_bfly_vals(const lc3_cpx *tw, int p, int fstride, int m, int i, const lc3_cpx (&x)[5], lc3_cpx (&y)[5]) {
     if (p == 4) {  // kissfft.rs:143-175
-        int m2 = 2 * m, m3 = 3 * m;
-        lc3_cpx s0 = lc3_cmul(f[i + m], tw[i * fstride]);
-        lc3_cpx s1 = lc3_cmul(f[i + m2], tw[i * fstride * 2]);
-        lc3_cpx s2 = lc3_cmul(f[i + m3], tw[i * fstride * 3]);
-        lc3_cpx f0 = f[i];
+        lc3_cpx s0 = lc3_cmul(x[1], tw[i * fstride]);
+        lc3_cpx s1 = lc3_cmul(x[2], tw[i * fstride * 2]);
+        lc3_cpx s2 = lc3_cmul(x[3], tw[i * fstride * 3]);
+        lc3_cpx f0 = x[0];
         lc3_cpx s5 = lc3_csub(f0, s1);
         f0 = lc3_cadd(f0, s1);
         lc3_cpx s3 = lc3_cadd(s0, s2);
         lc3_cpx s4 = lc3_csub(s0, s2);
-        f[i + m2] = lc3_csub(f0, s3);
-        f[i] = lc3_cadd(f0, s3);
-        lc3_cpx a, b;
-        a.r = s5.r + s4.i;
-        a.i = s5.i - s4.r;
-        b.r = s5.r - s4.i;
-        b.i = s5.i + s4.r;
-        f[i + m] = a;
-        f[i + m3] = b;
+        y[2] = lc3_csub(f0, s3);
+        y[0] = lc3_cadd(f0, s3);
+        y[1].r = s5.r + s4.i;
+        y[1].i = s5.i - s4.r;
+        y[3].r = s5.r - s4.i;
+        y[3].i = s5.i + s4.r;
     } else if (p == 2) {  // :133-141
-        lc3_cpx t = lc3_cmul(f[m + i], tw[i * fstride]);
-        lc3_cpx f0 = f[i];
-        f[m + i] = lc3_csub(f0, t);
-        f[i] = lc3_cadd(f0, t);
+        lc3_cpx t = lc3_cmul(x[1], tw[i * fstride]);
+        y[1] = lc3_csub(x[0], t);
+        y[0] = lc3_cadd(x[0], t);
     } else if (p == 3) {  // :177-205
-        int m2 = 2 * m;
         lc3_cpx epi3 = tw[fstride * m];
-        lc3_cpx s1 = lc3_cmul(f[i + m], tw[i * fstride]);
-        lc3_cpx s2 = lc3_cmul(f[i + m2], tw[i * fstride * 2]);
+        lc3_cpx s1 = lc3_cmul(x[1], tw[i * fstride]);
+        lc3_cpx s2 = lc3_cmul(x[2], tw[i * fstride * 2]);
         lc3_cpx s3 = lc3_cadd(s1, s2);
         lc3_cpx s0 = lc3_csub(s1, s2);
-        lc3_cpx fi = f[i];
+        lc3_cpx fi = x[0];
         lc3_cpx fm;
         fm.r = fi.r - (s3.r * 0.5f);
         fm.i = fi.i - (s3.i * 0.5f);
         s0.r *= epi3.i;
         s0.i *= epi3.i;
-        f[i] = lc3_cadd(fi, s3);
-        lc3_cpx a, b;
-        a.r = fm.r + s0.i;
-        a.i = fm.i - s0.r;
-        b.r = fm.r - s0.i;
-        b.i = fm.i + s0.r;
-        f[i + m2] = a;
-        f[i + m] = b;
+        y[0] = lc3_cadd(fi, s3);
+        y[2].r = fm.r + s0.i;
+        y[2].i = fm.i - s0.r;
+        y[1].r = fm.r - s0.i;
+        y[1].i = fm.i + s0.r;
     } else {  // p == 5, :207-256
         lc3_cpx ya = tw[fstride * m], yb = tw[fstride * 2 * m];
-        int m2 = 2 * m, m3 = 3 * m, m4 = 4 * m;
-        lc3_cpx s0 = f[i];
-        lc3_cpx s1 = lc3_cmul(f[i + m], tw[i * fstride]);
-        lc3_cpx s2 = lc3_cmul(f[i + m2], tw[i * 2 * fstride]);
-        lc3_cpx s3 = lc3_cmul(f[i + m3], tw[i * 3 * fstride]);
-        lc3_cpx s4 = lc3_cmul(f[i + m4], tw[i * 4 * fstride]);
+        lc3_cpx s0 = x[0];
+        lc3_cpx s1 = lc3_cmul(x[1], tw[i * fstride]);
+        lc3_cpx s2 = lc3_cmul(x[2], tw[i * 2 * fstride]);
+        lc3_cpx s3 = lc3_cmul(x[3], tw[i * 3 * fstride]);
+        lc3_cpx s4 = lc3_cmul(x[4], tw[i * 4 * fstride]);
         lc3_cpx s7 = lc3_cadd(s1, s4), s10 = lc3_csub(s1, s4), s8 = lc3_cadd(s2, s3), s9 = lc3_csub(s2, s3);
-        lc3_cpx o0, s5, s6, s11, s12;
-        o0.r = s0.r + (s7.r + s8.r);
-        o0.i = s0.i + (s7.i + s8.i);
-        f[i] = o0;
+        lc3_cpx s5, s6, s11, s12;
+        y[0].r = s0.r + (s7.r + s8.r);
+        y[0].i = s0.i + (s7.i + s8.i);
         s5.r = s0.r + (s7.r * ya.r) + (s8.r * yb.r);
         s5.i = s0.i + (s7.i * ya.r) + (s8.i * yb.r);
         s6.r = (s10.i * ya.i) + (s9.i * yb.i);
         s6.i = -(s10.r * ya.i) - (s9.r * yb.i);
-        f[i + m] = lc3_csub(s5, s6);
-        f[i + m4] = lc3_cadd(s5, s6);
+        y[1] = lc3_csub(s5, s6);
+        y[4] = lc3_cadd(s5, s6);
         s11.r = s0.r + (s7.r * yb.r) + (s8.r * ya.r);
         s11.i = s0.i + (s7.i * yb.r) + (s8.i * ya.r);
         s12.r = -(s10.i * yb.i) + (s9.i * ya.i);
         s12.i = (s10.r * yb.i) - (s9.r * ya.i);
-        f[i + m2] = lc3_cadd(s11, s12);
-        f[i + m3] = lc3_csub(s11, s12);
+        y[2] = lc3_cadd(s11, s12);
+        y[3] = lc3_csub(s11, s12);
     }
 }
+// ... in place at element i of the sub-transform based at f[0]
+__device__ __forceinline__ void lc3_bfly(lc3_cpx *f, const lc3_cpx *tw, int p, int fstride, int m, int i) {
+    lc3_cpx x[5], y[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        if (k < p) x[k] = f[i + k * m];
+    lc3_bfly_vals(tw, p, fstride, m, i, x, y);
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        if (k < p) f[i + k * m] = y[k];
+}
 
-// DiscreteCosTransformIv::run (common/dct_iv.rs:49-67) on buf[0..nf) (LDS), scratch fa/fb (LDS, nf/2 each)
-template <class CC>
-__device__ __forceinline__ void lc3_dct4_wave(const CC &c, int lane, float *buf, lc3_cpx *fa, lc3_cpx *fb) {
+// DiscreteCosTransformIv::run (common/dct_iv.rs:49-67): in[0..nf) -> out[0..nf) through the complex work array wk[0..nf/2) (all LDS).
+// `in` is consumed; wk may be `in` itself (IN_PLACE: the work array takes the input's place) or a third buffer; out may be `in` when wk
+// is a third buffer.  Same operations in the same order as the reference, with two of its passes over the array folded away:
+//   * the pre-twiddle (:53-56) and the leaf gather of kf_work (kissfft.rs:101-108) happen in the loads of the innermost butterfly
+//     stage (m = 1: butterfly u takes the leaves p u .. p u + p - 1; at most 48 butterflies in every configuration, so one pass: every
+//     lane has read its leaves before any lane writes, which is what lets the work array overlay the input);
+//   * the post-twiddle (:62-66) happens in the stores of the outermost stage (blk = 0: butterfly i produces elements i + k m).
+template <int IN_PLACE, class CC>
+__device__ __forceinline__ void lc3_dct4_core(const CC &c, int lane, float *in, lc3_cpx *wk, float *out) {
     const int nf = c.nf, cnt = c.nfft;
-    // pre-twiddle :53-56
-    for (int n = lane; n < cnt; n += LC3_WAVE) {
-        lc3_cpx x;
-        x.r = buf[2 * n];
-        x.i = buf[nf - 2 * n - 1];
-        fa[n] = lc3_cmul(LC3_DCT_TW(c)[n], x);
+    {   // innermost stage with the pre-twiddle and the gather in its loads
+        const int s = c.n_stages - 1;
+        const int p = c.radix[s], fstride = c.fstride[s], nb = cnt / p;  // m = 1
+        lc3_cpx x[5], y[5];
+        if (lane < nb) {
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (k < p) {
+                    const int n = (int)LC3_FFT_PERM(c)[lane * p + k];
+                    lc3_cpx v;
+                    v.r = in[2 * n];
+                    v.i = in[nf - 2 * n - 1];
+                    x[k] = lc3_cmul(LC3_DCT_TW(c)[n], v);
+                }
+            lc3_bfly_vals(LC3_FFT_TW(c), p, fstride, 1, 0, x, y);
+        }
+        if (IN_PLACE) LC3_SYNC();
+        if (lane < nb) {
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (k < p) wk[lane * p + k] = y[k];
+        }
+        LC3_SYNC();
     }
-    LC3_SYNC();
-    // leaf gather of kf_work (kissfft.rs:101-108)
-    for (int o = lane; o < cnt; o += LC3_WAVE) fb[o] = fa[LC3_FFT_PERM(c)[o]];
-    LC3_SYNC();
-    // butterfly stages, innermost first
-    for (int s = c.n_stages - 1; s >= 0; s--) {
+    for (int s = c.n_stages - 2; s >= 1; s--) {  // the stages between
         const int p = c.radix[s], m = c.m[s], fstride = c.fstride[s];
         const int nb = cnt / p;
         for (int u = lane; u < nb; u += LC3_WAVE) {
             const int blk = (u * c.inv_m[s]) >> 16, i = u - blk * m;  // u / m without an integer division
-            lc3_bfly(fb + blk * p * m, LC3_FFT_TW(c), p, fstride, m, i);
+            lc3_bfly(wk + blk * p * m, LC3_FFT_TW(c), p, fstride, m, i);
         }
         LC3_SYNC();
     }
-    // post-twiddle :62-66
-    for (int n = lane; n < cnt; n += LC3_WAVE) {
-        lc3_cpx y = lc3_cmul(LC3_DCT_TW(c)[n], fb[n]);
-        buf[2 * n] = y.r * 2.0f;
-        buf[nf - 2 * n - 1] = -y.i * 2.0f;
+    {   // outermost stage with the post-twiddle in its stores
+        const int p = c.radix[0], m = c.m[0], fstride = c.fstride[0];  // blk = 0
+        for (int i = lane; i < m; i += LC3_WAVE) {
+            lc3_cpx x[5], y[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (k < p) x[k] = wk[i + k * m];
+            lc3_bfly_vals(LC3_FFT_TW(c), p, fstride, m, i, x, y);
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (k < p) {
+                    const int n = i + k * m;
+                    const lc3_cpx t = lc3_cmul(LC3_DCT_TW(c)[n], y[k]);
+                    out[2 * n] = t.r * 2.0f;
+                    out[nf - 2 * n - 1] = -t.i * 2.0f;
+                }
+        }
+        LC3_SYNC();
     }
-    LC3_SYNC();
 }
-// The same transform with two buffers instead of three: a[0..nf) -> b[0..nf), a is destroyed (it serves as the complex work
-// array once the pre-twiddle has consumed it).  Same operations in the same order as lc3_dct4_wave.
+// on buf[0..nf) in place, scratch fb (nf/2 complex; fa is no longer needed)
+template <class CC>
+__device__ __forceinline__ void lc3_dct4_wave(const CC &c, int lane, float *buf, lc3_cpx *fa, lc3_cpx *fb) {
+    (void)fa;
+    lc3_dct4_core<0>(c, lane, buf, fb, buf);
+}
+// a[0..nf) -> b[0..nf) with two buffers: a is destroyed (it serves as the complex work array once the innermost stage has read it)
 template <class CC>
 __device__ __forceinline__ void lc3_dct4_wave_ab(const CC &c, int lane, float *a, float *b) {
-    const int nf = c.nf, cnt = c.nfft;
-    lc3_cpx *ca = (lc3_cpx *)a, *cb = (lc3_cpx *)b;
-    for (int n = lane; n < cnt; n += LC3_WAVE) {  // pre-twiddle :53-56
-        lc3_cpx x;
-        x.r = a[2 * n];
-        x.i = a[nf - 2 * n - 1];
-        cb[n] = lc3_cmul(LC3_DCT_TW(c)[n], x);
-    }
-    LC3_SYNC();
-    for (int o = lane; o < cnt; o += LC3_WAVE) ca[o] = cb[LC3_FFT_PERM(c)[o]];  // leaf gather of kf_work (kissfft.rs:101-108)
-    LC3_SYNC();
-    for (int s = c.n_stages - 1; s >= 0; s--) {  // butterfly stages, innermost first
-        const int p = c.radix[s], m = c.m[s], fstride = c.fstride[s];
-        const int nb = cnt / p;
-        for (int u = lane; u < nb; u += LC3_WAVE) {
-            const int blk = (u * c.inv_m[s]) >> 16, i = u - blk * m;
-            lc3_bfly(ca + blk * p * m, LC3_FFT_TW(c), p, fstride, m, i);
-        }
-        LC3_SYNC();
-    }
-    for (int n = lane; n < cnt; n += LC3_WAVE) {  // post-twiddle :62-66
-        lc3_cpx y = lc3_cmul(LC3_DCT_TW(c)[n], ca[n]);
-        b[2 * n] = y.r * 2.0f;
-        b[nf - 2 * n - 1] = -y.i * 2.0f;
-    }
-    LC3_SYNC();
+    lc3_dct4_core<1>(c, lane, a, (lc3_cpx *)a, b);
 }

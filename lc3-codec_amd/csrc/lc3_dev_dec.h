@@ -12,6 +12,12 @@
 // follows (the output stage), and the loads of the next frame's plane column -- issued at the top of a frame -- get the inlined
 // IMDCT's worth of work before the first call (the LTPF) drains them (IMDCT as a call: synthesis 0.146 ms, inlined 0.134 ms).
 #ifndef LC3_DEC_STAGE
+// LC3_DEC_KO: timing experiments only (knock-out builds, LC3_HIPCC_EXTRA=-DLC3_DEC_KO=n: the output is garbage): 1 no load / store of the
+// state blob's core part, 2 no overlap-memory load / store, 4 no copy of the last good spectrum, 8 no inverse transform, 16 no post-filter,
+// 32 no PCM stores, 64 no plane loads
+#ifndef LC3_DEC_KO
+#define LC3_DEC_KO 0
+#endif
 #define LC3_DEC_STAGE __noinline__
 #define LC3_DEC_STAGE_HOT __forceinline__
 #endif
@@ -91,14 +97,14 @@ __device__ __forceinline__ lc3_ola5 lc3_dec_ola_load(const CC &c, int lane, cons
 #pragma unroll
     for (int r = 0; r < 5; r++) {
         const int n = lane + LC3_WAVE * r;
-        m.v[r] = n < c.nf - c.z ? ola[n] : 0.0f;
+        m.v[r] = (n < c.nf - c.z && !(LC3_DEC_KO & 2)) ? ola[n] : 0.0f;
     }
     return m;
 }
 // whole rounds of 64 under a wave-uniform condition, one base address with constant offsets
 template <class CC>
 __device__ __forceinline__ void lc3_dec_ola_store(const CC &c, int lane, lc3_dec_state *g, int valid, const lc3_ola5 &m) {
-    const int nv = LC3_UNIFORM_I32(valid) ? c.nf - c.z : 0;
+    const int nv = (LC3_UNIFORM_I32(valid) && !(LC3_DEC_KO & 2)) ? c.nf - c.z : 0;
     LC3_HBM(float) ob = (LC3_HBM(float))g->mem_ola + lane;
 #pragma unroll
     for (int r = 0; r < 5; r++) {
@@ -235,36 +241,41 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_L
     else trans = 5;
     const int p_int_mem = L.st.p_int_mem;
     LC3_SYNC();
-    // compute_filter_coeffs :192-242 (lane 0) and the copy of the frame into the input ring (all lanes)
-    if (lane == 0) {
-        for (int k = 0; k < ncn; k++) cnm[k] = L.st.c_num[k];
-        for (int k = 0; k < ncd; k++) cdm[k] = L.st.c_den[k];
-        if (!is_active) {
-            for (int k = 0; k < ncn; k++) L.st.c_num[k] = 0.0f;
-            for (int k = 0; k < ncd; k++) L.st.c_den[k] = 0.0f;
-        } else {
-            int t_nbits = nbits;
-            if (!c.n_ms_10) t_nbits = (int)((double)nbits * 10.0 / 7.5 + 0.5);
-            const int sf = c.fs_ind * 80;
-            float gain;
-            int gain_ind;
-            if (t_nbits < 320 + sf) { gain = 0.4f; gain_ind = 0; }
-            else if (t_nbits < 400 + sf) { gain = 0.35f; gain_ind = 1; }
-            else if (t_nbits < 480 + sf) { gain = 0.3f; gain_ind = 2; }
-            else if (t_nbits < 560 + sf) { gain = 0.25f; gain_ind = 3; }
-            else { gain = 0.0f; gain_ind = 0; }
-            const uint32_t *tnum, *tden;
-            int tn, td;
-            switch (c.fs) {
-            case 8000: tnum = &LC3T_TAB_LTPF_NUM_8000_BITS[gain_ind][0]; tn = 3; tden = &LC3T_TAB_LTPF_DEN_8000_BITS[pitch_frac][0]; td = 5; break;
-            case 16000: tnum = &LC3T_TAB_LTPF_NUM_16000_BITS[gain_ind][0]; tn = 3; tden = &LC3T_TAB_LTPF_DEN_16000_BITS[pitch_frac][0]; td = 5; break;
-            case 24000: tnum = &LC3T_TAB_LTPF_NUM_24000_BITS[gain_ind][0]; tn = 5; tden = &LC3T_TAB_LTPF_DEN_24000_BITS[pitch_frac][0]; td = 7; break;
-            case 32000: tnum = &LC3T_TAB_LTPF_NUM_32000_BITS[gain_ind][0]; tn = 7; tden = &LC3T_TAB_LTPF_DEN_32000_BITS[pitch_frac][0]; td = 9; break;
-            default: tnum = &LC3T_TAB_LTPF_NUM_48000_BITS[gain_ind][0]; tn = 11; tden = &LC3T_TAB_LTPF_DEN_48000_BITS[pitch_frac][0]; td = 13; break;
-            }
-            for (int k = 0; k < ncn && k < tn; k++) L.st.c_num[k] = 0.85f * gain * lc3_f(tnum, k);  // zip truncation: A9
-            for (int k = 0; k < ncd && k < td; k++) L.st.c_den[k] = gain * lc3_f(tden, k);
+    // compute_filter_coeffs :192-242.  The previous frame's coefficients (c_num_mem / c_den_mem) are only read when that frame's filter
+    // was on (transitions 3 and 5); a filter that stays off (transition 1: every frame of a stream at the higher bitrates) finds the
+    // zeros it would write already there -- they were written when the filter went off, or at initialisation -- and touches nothing
+    if (prev_active) {
+        if (lane < ncn) cnm[lane] = L.st.c_num[lane];
+        if (lane < ncd) cdm[lane] = L.st.c_den[lane];
+    }
+    LC3_SYNC();
+    if (!is_active) {
+        if (prev_active) {
+            if (lane < ncn) L.st.c_num[lane] = 0.0f;
+            if (lane < ncd) L.st.c_den[lane] = 0.0f;
         }
+    } else if (lane == 0) {
+        int t_nbits = nbits;
+        if (!c.n_ms_10) t_nbits = (int)((double)nbits * 10.0 / 7.5 + 0.5);
+        const int sf = c.fs_ind * 80;
+        float gain;
+        int gain_ind;
+        if (t_nbits < 320 + sf) { gain = 0.4f; gain_ind = 0; }
+        else if (t_nbits < 400 + sf) { gain = 0.35f; gain_ind = 1; }
+        else if (t_nbits < 480 + sf) { gain = 0.3f; gain_ind = 2; }
+        else if (t_nbits < 560 + sf) { gain = 0.25f; gain_ind = 3; }
+        else { gain = 0.0f; gain_ind = 0; }
+        const uint32_t *tnum, *tden;
+        int tn, td;
+        switch (c.fs) {
+        case 8000: tnum = &LC3T_TAB_LTPF_NUM_8000_BITS[gain_ind][0]; tn = 3; tden = &LC3T_TAB_LTPF_DEN_8000_BITS[pitch_frac][0]; td = 5; break;
+        case 16000: tnum = &LC3T_TAB_LTPF_NUM_16000_BITS[gain_ind][0]; tn = 3; tden = &LC3T_TAB_LTPF_DEN_16000_BITS[pitch_frac][0]; td = 5; break;
+        case 24000: tnum = &LC3T_TAB_LTPF_NUM_24000_BITS[gain_ind][0]; tn = 5; tden = &LC3T_TAB_LTPF_DEN_24000_BITS[pitch_frac][0]; td = 7; break;
+        case 32000: tnum = &LC3T_TAB_LTPF_NUM_32000_BITS[gain_ind][0]; tn = 7; tden = &LC3T_TAB_LTPF_DEN_32000_BITS[pitch_frac][0]; td = 9; break;
+        default: tnum = &LC3T_TAB_LTPF_NUM_48000_BITS[gain_ind][0]; tn = 11; tden = &LC3T_TAB_LTPF_DEN_48000_BITS[pitch_frac][0]; td = 13; break;
+        }
+        for (int k = 0; k < ncn && k < tn; k++) L.st.c_num[k] = 0.85f * gain * lc3_f(tnum, k);  // zip truncation: A9
+        for (int k = 0; k < ncd && k < td; k++) L.st.c_den[k] = gain * lc3_f(tden, k);
     }
     LC3_SYNC();
     // The IIR recursion feeds back x_hat delayed by at least pitch_int - l_den/2 samples, so that many consecutive
@@ -328,6 +339,7 @@ __device__ __forceinline__ void lc3_dec_issue_frame(const CC &c, int lane, const
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int i = lane + LC3_WAVE * u;
+        if ((LC3_DEC_KO & 64) && i >= (LC3_PLANE_X - LC3_PLANE_SI) / 4) continue;  // (timing experiment: side information only)
         if (i < n4 || (late && i >= LC3_PLANE_LEV / 4 && i < LC3_PLANE_LEV / 4 + 4)) m.u[u] = p4[i];
     }
 }
@@ -708,13 +720,13 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
     if (ok) {
         ltpf_active = L.ism[SI_LTPF_ACTIVE];
         pitch_index = L.ism[SI_PITCH_INDEX];
-        lc3_dec_plc_save(c, L, lane, g, valid && save_good);
+        lc3_dec_plc_save(c, L, lane, g, valid && save_good && !(LC3_DEC_KO & 4));
     } else {
         lc3_dec_plc_load(LC3_CFG_PASS, LC3_LDS_PASS lane, plc_src);
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 18);
-    ola = lc3_dec_imdct(LC3_CFG_PASS, LC3_LDS_PASS lane, ola);
+    if (!(LC3_DEC_KO & 8)) ola = lc3_dec_imdct(LC3_CFG_PASS, LC3_LDS_PASS lane, ola);
     LC3_STAMP(L, lane, 19);
     if (dbg_flags & (LC3_DBG_TIME_IN | LC3_DBG_DUMP)) {
         for (int n = lane; n < nf; n += LC3_WAVE) {
@@ -723,7 +735,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
         }
         LC3_SYNC();
     }
-    lc3_dec_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, ltpf_active, pitch_index, nbits);
+    if (!(LC3_DEC_KO & 16)) lc3_dec_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, ltpf_active, pitch_index, nbits);
     if (dbg_flags & LC3_DBG_DUMP) {
         for (int n = lane; n < nf; n += LC3_WAVE) dbg[LC3_DBG_LTPF + n] = L.spec[n];
     }
@@ -747,7 +759,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
             }
             ow[r] = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
         }
-        const int nv = LC3_UNIFORM_I32(valid) ? nf / 2 : 0;
+        const int nv = (LC3_UNIFORM_I32(valid) && !(LC3_DEC_KO & 32)) ? nf / 2 : 0;
         if (stride == 1) {
             LC3_HBM(uint32_t) ob = o32 + lane;
 #pragma unroll

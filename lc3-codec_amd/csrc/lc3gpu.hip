@@ -1090,7 +1090,7 @@ __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned w
     lc3_fft_tables_stage(c0);
     LC3_PROF_BEGIN(L, lane);
     if (fresh) lc3_dec_state_init(L, lane, gst, valid);
-    else lc3_dec_state_load(L, lane, gst);
+    else if (!(LC3_DEC_KO & 1)) lc3_dec_state_load(L, lane, gst);
     LC3_PROF_MARK(L, lane, 38);  // state load
     const size_t fbase = (size_t)s * (size_t)n_frames;
     int stride;
@@ -1098,7 +1098,7 @@ __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned w
     lc3_decode_stream_wave(cfg, L, lane, nbytes, planes, fbase, n_frames, gst, valid, pcm0, (size_t)nf * (size_t)stride, stride, LATE, dbg,
                            dbg_flags);
     LC3_PROF_MARK(L, lane, 39);  // frames (incl. everything between the stage stamps)
-    if (valid) lc3_dec_state_store(L, lane, gst);
+    if (valid && !(LC3_DEC_KO & 1)) lc3_dec_state_store(L, lane, gst);
     LC3_PROF_END(L, lane, 35);
 }
 template <class CV>

@@ -20,6 +20,14 @@ KEYS = {"FETCH_SIZE": "fetch_size_kb", "WRITE_SIZE": "write_size_kb", "SQ_INSTS_
         "SQ_LDS_IDX_ACTIVE": "sq_lds_idx_active"}
 
 
+# the producer / consumer forms of the two lane-per-frame kernels report under the names bench.py's timer slots carry
+ALIAS = {"lc3_parse_pc_kernel": "lc3_parse_kernel", "lc3_pack_pc_kernel": "lc3_pack_kernel"}
+# kernels whose HBM reads are 16-byte-per-lane coalesced copies (planes, state blobs, PCM of the wave-per-stream kernels):
+# gfx950's FETCH_SIZE counts such a read at half its size (MI355X_MICROARCH.md, HBM / rocprofv3 section), so the corrected figure doubles
+# it -- an upper bound, not every read of these kernels is that wide.  The lane-per-frame kernels read their own column per lane: raw
+WIDE_READS = ("lc3_enc_front_kernel", "lc3_enc_back_kernel", "lc3_decode_kernel")
+
+
 def main():
     src, committed = sys.argv[1], sys.argv[2]
     frames = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
@@ -28,10 +36,16 @@ def main():
         for row in csv.DictReader(f):
             key = KEYS.get(row["counter"])
             if key:
-                kernels.setdefault(row["kernel"].split("<")[0], {})[key] = float(row["mean_per_launch"])  # drop the <view>
+                name = row["kernel"].split("<")[0]  # drop the <view>
+                kernels.setdefault(ALIAS.get(name, name), {})[key] = float(row["mean_per_launch"])
+    for name, k in kernels.items():
+        if "fetch_size_kb" in k:
+            k["fetch_size_kb_corrected"] = k["fetch_size_kb"] * (2.0 if name in WIDE_READS else 1.0)
     out = {
-        "source": "profiles/%s (rocprofv3 --pmc, separate passes, mean per launch of %d frames; FETCH_SIZE / WRITE_SIZE in KB, raw: "
-                  "FETCH_SIZE not doubled, the accesses are not wide streaming reads, MI355X_MICROARCH.md HBM section)" % (committed, frames),
+        "source": "profiles/%s (rocprofv3 --pmc, separate passes, mean per launch of %d frames; FETCH_SIZE / WRITE_SIZE in KB (1024 bytes); "
+                  "fetch_size_kb_corrected = FETCH_SIZE x 2 for the wave-per-stream kernels, whose reads are 16-byte-per-lane coalesced and "
+                  "counted at half their size on gfx950 (MI355X_MICROARCH.md, HBM section), raw for the lane-per-frame kernels; lc3_parse_kernel / "
+                  "lc3_pack_kernel are the producer / consumer kernels lc3_parse_pc_kernel / lc3_pack_pc_kernel)" % (committed, frames),
         "kernel_source_sha256": kernel_source_sha(),
         "frames_per_launch": frames,
         "kernels": dict(sorted(kernels.items())),

@@ -12,8 +12,13 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 BENCH="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-overlap-probe --sustain-seconds 0"
 python3 bench.py --no-cpu-baseline > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+# the default command (caller arrangement `pipelined`: the encoder's and the decoder's kernels share the chip, durations include that) ...
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/$TAG/trace -o trace --output-format csv -- $BENCH > $ROOT/$OUT/$TAG/trace.log 2>&1 )
 find $OUT/$TAG/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
+# ... and the same steps on ONE caller stream: every kernel alone on the chip
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/$TAG/trace1 -o trace --output-format csv -- $BENCH --arrangement single > $ROOT/$OUT/$TAG/trace1.log 2>&1 )
+find $OUT/$TAG/trace1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats_single.csv
+BENCH="$BENCH --arrangement single"   # counters: per launch, the kernels serialised by the profiler anyway
 i=0
 for CTRS in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_THREAD_CYCLES_VALU" \
             "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" \
@@ -23,6 +28,6 @@ for CTRS in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VME
     ( cd /tmp && rocprofv3 --pmc $CTRS -d $ROOT/$OUT/$TAG/pmc$i -o pmc --output-format csv -- $BENCH > $ROOT/$OUT/$TAG/pmc$i.log 2>&1 )
 done
 python3 tools/pmc_summary.py $OUT/$TAG > $OUT/${TAG}_pmc_summary.csv
-rm -rf $OUT/$TAG/trace/*/*.db 2>/dev/null
+rm -rf $OUT/$TAG/trace/*/*.db $OUT/$TAG/trace1/*/*.db 2>/dev/null
 du -sh $OUT/$TAG | tail -1
 head -3 $OUT/${TAG}_kernel_stats.csv
