@@ -239,7 +239,7 @@ def load_ceiling():
     """the measured issue ceiling and copy bandwidth (tools/valu_ceiling.hip -> profiles/r04_valu_ceiling.json): cycles per wave64
     vector instruction of the codec's instruction mix on one SIMD, by waves per SIMD, and the device copy rate"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_valu_ceiling.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_valu_ceiling.json")) as f:
             j = json.load(f)
         mix = {r["waves_per_simd"]: r["cycles_per_wave_instr"] for r in j["valu"] if r["instruction"].startswith("mix")}
         return {"cycles_per_instr_by_waves_per_simd": mix, "copy_GBs": j["copy"]["GBs_read_plus_write"],
@@ -667,7 +667,9 @@ def run_rank(args):
                     # resident waves per SIMD) over the SIMD-cycles the step's kernels had (at the maximum clock: a lower bound)
                     cpi = ceil["cycles_per_instr_by_waves_per_simd"]
                     need = sum(valu_insts[k] * cpi[min(cpi, key=lambda w: abs(w - WAVES_PER_SIMD.get(k, 4)))] for k in live)
-                    have = N_SIMD * sum(kernel_ms[k] for k in live) * 1e-3 * CLOCK_MHZ * 1e6
+                    # ... over the SIMD-cycles of a step's wall time (in the pipelined arrangement the kernels of the two handles run
+                    # side by side: their durations add up to more than the step)
+                    have = N_SIMD * (elapsed / args.steps) * CLOCK_MHZ * 1e6
                     valu_frac = need / have
                 pmc_note = pj.get("source")
             roof = {
@@ -686,7 +688,8 @@ def run_rank(args):
                         "16-byte-per-lane coalesced, MI355X_MICROARCH.md), traffic_whole_step the same over every kernel of the step; measured_copy_GBs = "
                         "what a 16-byte-per-lane copy kernel reaches on this chip (read + write), beside the 8 TB/s vendor figure `frac` divides by; "
                         "valu_frac = sum over the step's kernels of SQ_INSTS_VALU x (measured cycles per wave instruction of the codec's instruction mix at "
-                        "that kernel's waves per SIMD) / (1024 SIMDs x the kernels' cycles at 2.4 GHz); active_lane_frac = SQ_THREAD_CYCLES_VALU / "
+                        "that kernel's waves per SIMD; 4.0 at every occupancy for this mix, 2.0 for plain f32 / i32 arithmetic alone) / (1024 SIMDs x the step's wall time at "
+                        "2.4 GHz); active_lane_frac = SQ_THREAD_CYCLES_VALU / "
                         "(64 x SQ_INSTS_VALU); counters from the committed rocprofv3 PMC passes (profiles/pmc_latest.json), null when they "
                         "were taken on other kernel sources",
             }

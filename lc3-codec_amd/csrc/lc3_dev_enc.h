@@ -58,6 +58,12 @@ struct __attribute__((aligned(16))) lc3_enc_lds {
     unsigned long long prof_acc[32];  // diagnostic build: per-wave stage totals, flushed once per launch
 #endif
 };
+// LC3_ENC_KO: timing experiments only (knock-out builds, LC3_HIPCC_EXTRA=-DLC3_ENC_KO=n: the output is garbage): 1 no MDCT, 2 no bandwidth
+// detector, 4 no attack detector, 8 no SNS targets, 16 no LTPF analysis, 32 no high-pass recursion, 64 no 98-lag correlations, 128 no
+// resampler sums, 256 no TNS, 512 no quantiser, 1024 no residual / noise stage
+#ifndef LC3_ENC_KO
+#define LC3_ENC_KO 0
+#endif
 #define LC3_ENC_DBG_EB 1472      // [64] band energies
 #define LC3_ENC_DBG_ATTACK 1536  // [5] attack detector state: energy_last, max_energy_last, attack_pos_last, downsampled t-1, t-2
 #define LC3_ENC_DBG_FLOATS 1600
@@ -876,9 +882,10 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         const float *poly = S;
 #endif
         const float *ha = poly + (15 * n0 - q0 * p) * c.resamp_stride, *hb = poly + (15 * n1 - q1 * p) * c.resamp_stride;
-        float acc0, acc1;
+        float acc0 = 0.0f, acc1 = 0.0f;
         const int dlo = LC3_UNIFORM_I32(15 / p), far = (q1 - q0) != dlo;
-        if (dlo == 3) lc3_resample_pair<3>(xa, ha, hb, nt, far, acc0, acc1);       // p = 4 (48 / 44.1 kHz)
+        if (LC3_ENC_KO & 128) acc0 = xa[0];
+        else if (dlo == 3) lc3_resample_pair<3>(xa, ha, hb, nt, far, acc0, acc1);       // p = 4 (48 / 44.1 kHz)
         else if (dlo == 2) lc3_resample_pair<2>(xa, ha, hb, nt, far, acc0, acc1);  // p = 6 (32 kHz)
         else if (dlo == 1) lc3_resample_pair<1>(xa, ha, hb, nt, far, acc0, acc1);  // p = 8, 12 (24, 16 kHz)
         else lc3_resample_pair<0>(xa, ha, hb, nt, far, acc0, acc1);                // p = 24 (8 kHz)
@@ -912,7 +919,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         float *o12 = (float *)L.fa + 64 + c.delay12 + LC3_NMEM;  // this stream's x12 + delay12 + NMEM
         float m1 = L.st.h50_m1, m2 = L.st.h50_m2;
         #pragma unroll 1
-        for (int n0 = 0; n0 < len12; n0 += 8) {  // len12 is a multiple of 8; eight samples per LDS round trip
+        for (int n0 = 0; n0 < ((LC3_ENC_KO & 32) ? 0 : len12); n0 += 8) {  // len12 is a multiple of 8; eight samples per LDS round trip
             float x[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) x[u] = o12[n0 + u];
@@ -976,7 +983,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
 #pragma unroll
             for (int u = 0; u < 9; u++) bb[u] = pb[u];
 #pragma unroll  // (a configuration view knows len6: straight-line code, no block is moved between registers)
-            for (int n = 0; n < len6; n += 16) {
+            for (int n = 0; n < ((LC3_ENC_KO & 64) ? 0 : len6); n += 16) {
 #pragma unroll
                 for (int u = 0; u < 8; u++) an[u] = pa[n + 8 + u];
 #pragma unroll
@@ -1796,23 +1803,24 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_P
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
-    const int near_nyquist = lc3_enc_mdct(LC3_CFG_PASS, LC3_LDS_PASS lane, pcm, hist, stride, hstride);
+    const int near_nyquist = (LC3_ENC_KO & 1) ? 0 : lc3_enc_mdct(LC3_CFG_PASS, LC3_LDS_PASS lane, pcm, hist, stride, hstride);
     LC3_STAMP(L, lane, 1);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[i] = L.spec[i];
     if (dbg && lane < c.nb) dbg[LC3_ENC_DBG_EB + lane] = LC3_EB(L)[lane];  // the band energies (modified_dct.rs:140-152)
-    int nbits_bw;
-    const int bw_ind = lc3_enc_bandwidth(LC3_CFG_PASS, LC3_LDS_PASS lane, &nbits_bw);
+    int nbits_bw = 3;
+    const int bw_ind = (LC3_ENC_KO & 2) ? 4 : lc3_enc_bandwidth(LC3_CFG_PASS, LC3_LDS_PASS lane, &nbits_bw);
     LC3_STAMP(L, lane, 24);
-    const int attack = lc3_enc_attack(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes);
+    const int attack = (LC3_ENC_KO & 4) ? 0 : lc3_enc_attack(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes);
     LC3_STAMP(L, lane, 2);
-    lc3_enc_sns_front(LC3_CFG_PASS, LC3_LDS_PASS lane, attack);
+    if (!(LC3_ENC_KO & 8)) lc3_enc_sns_front(LC3_CFG_PASS, LC3_LDS_PASS lane, attack);
     if (mid) {  // targets and spectrum leave LDS before the LTPF stage reuses fa/fb
         if (lane < 16) mid[MP_SCF + lane] = LC3_SCF(L)[lane];
         lc3_wave_copy_out16(mid + MP_SPEC, L.spec, c.nf / 4, lane);
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 3);
-    const lc3_ltpf_res pf = lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, plane != nullptr, phase);
+    lc3_ltpf_res pf = {0, 0, 0, 1};
+    if (!(LC3_ENC_KO & 16)) pf = lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, plane != nullptr, phase);
     LC3_STAMP(L, lane, 5);
     if (dbg && lane == 0) {
         float *d = dbg + 1440;
@@ -1907,12 +1915,16 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PA
     LC3_STAMP(L, lane, 18);
     LC3_STAMP(L, lane, 19);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[480 + i] = L.spec[i];
-    const lc3_tns_res tns = lc3_enc_tns(LC3_CFG_PASS, LC3_LDS_PASS lane, bw_ind, nbits, near_nyquist);
+    lc3_tns_res tns = {};
+    if (LC3_ENC_KO & 256) tns.nbits_tns = 2, tns.num_tns_filters = 2;
+    else tns = lc3_enc_tns(LC3_CFG_PASS, LC3_LDS_PASS lane, bw_ind, nbits, near_nyquist);
     LC3_STAMP(L, lane, 4);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[960 + i] = L.spec[i];
-    const lc3_quant_res spec = lc3_enc_quant(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, nbits_bw, tns.nbits_tns, nbits_ltpf);
+    lc3_quant_res spec = {};
+    if (LC3_ENC_KO & 512) spec.lastnz_trunc = 2, spec.gg = 1.0f;
+    else spec = lc3_enc_quant(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, nbits_bw, tns.nbits_tns, nbits_ltpf);
     LC3_STAMP(L, lane, 6);
-    const int rn = lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
+    const int rn = (LC3_ENC_KO & 1024) ? 0 : lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
     LC3_STAMP(L, lane, 7);
     const int n_res = rn & 0xffff, noise_factor = rn >> 16;
     if (dbg && lane == 0) {
