@@ -46,6 +46,12 @@
 #ifndef LC3_BACK_WAVES
 #define LC3_BACK_WAVES 4
 #endif
+#ifndef LC3_FRONT_WAVES
+#define LC3_FRONT_WAVES 4  // waves per SIMD the register allocation of the front half aims at (tuning experiments)
+#endif
+#ifndef LC3_SYNTH_WAVES
+#define LC3_SYNTH_WAVES 4
+#endif
 #ifndef LC3_SPEC_IN_LDS
 #define LC3_SPEC_IN_LDS 1
 #endif
@@ -473,8 +479,14 @@ __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigne
     }
     LC3_PROF_END(L, lane, 32);
 }
+// waves per SIMD the front half's register allocation aims at, by configuration view: within 128 registers (four waves) the 48 kHz / 7.5 ms
+// view spilled 47 of them (176 bytes of scratch per lane, front half 0.599 ms per 65 536 frames); with the budget of three waves it
+// spills none and takes 0.462 ms -- it still fits four (LDS allows no more).  The other views fit 128 registers as they are (the
+// run-time view gets slower with the larger budget: 0.641 -> 0.733 ms)
+template <class CV> struct lc3_front_waves { static constexpr int value = LC3_FRONT_WAVES; };
+template <> struct lc3_front_waves<lc3_cfg_48k75> { static constexpr int value = 3; };
 template <class CV>
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_kernel(lc3_cfg_slot<CV> cfg, lc3_enc_state *states,
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, lc3_front_waves<CV>::value) void lc3_enc_front_kernel(lc3_cfg_slot<CV> cfg, lc3_enc_state *states,
                                                                              int first_channel, int n_streams,
                                                                              const int16_t *pcm, float *mid, int32_t *planes,
                                                                              int nbytes, int n_frames, int fresh, float *dbg,
@@ -482,7 +494,7 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_kernel(lc3
     lc3_enc_front_body<CV>(cfg, blockIdx.x, states, first_channel, n_streams, pcm, mid, planes, nbytes, n_frames, fresh, dbg, io,
                            spec_flags);
 }
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_enc_front_mixed_kernel(lc3_groups G, lc3_enc_state *states,
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_FRONT_WAVES) void lc3_enc_front_mixed_kernel(lc3_groups G, lc3_enc_state *states,
                                                                                    const int16_t *pcm, float *mid, int32_t *planes,
                                                                                    int n_frames, int fresh, lc3_io io, int spec_flags) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
@@ -1102,7 +1114,7 @@ __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned w
     LC3_PROF_END(L, lane, 35);
 }
 template <class CV>
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_kernel(lc3_cfg_slot<CV> cfg, lc3_dec_state *states,
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_SYNTH_WAVES) void lc3_decode_kernel(lc3_cfg_slot<CV> cfg, lc3_dec_state *states,
                                                                           int first_channel, int n_streams, const int32_t *planes,
                                                                           int16_t *pcm, int nbytes, int n_frames, int fresh,
                                                                           lc3_io io) {
@@ -1705,6 +1717,15 @@ static int lc3_recon_mode(size_t n_frames_total, int frames_per_stream) {
     if (forced >= 0) return forced;
     return (n_frames_total <= 16384 && frames_per_stream <= 4) ? LC3_RECON_LATE : LC3_RECON_LANE;
 }
+// tuning aid: extra dynamic LDS (bytes) a wave-per-stream kernel is launched with, which lowers how many of its workgroups a CU holds
+// (LC3GPU_LDS_PAD_FRONT / _BACK / _SYNTH); 0 = none
+static size_t lc3_lds_pad(int which) {
+    static const size_t pad[3] = {
+        (size_t)(std::getenv("LC3GPU_LDS_PAD_FRONT") ? std::atoi(std::getenv("LC3GPU_LDS_PAD_FRONT")) : 0),
+        (size_t)(std::getenv("LC3GPU_LDS_PAD_BACK") ? std::atoi(std::getenv("LC3GPU_LDS_PAD_BACK")) : 0),
+        (size_t)(std::getenv("LC3GPU_LDS_PAD_SYNTH") ? std::atoi(std::getenv("LC3GPU_LDS_PAD_SYNTH")) : 0)};
+    return pad[which];
+}
 // The producer / consumer packer (lc3_pack_pc_kernel): the form of full batches (where the packer derives its symbols itself) unless
 // LC3GPU_PACK_PC=0; its ring buffers take the workgroup just beyond the default 64 KB of dynamic LDS
 static bool lc3_pack_pc_enabled() {
@@ -2087,7 +2108,7 @@ static int encode_kernels(lc3gpu_encoder *e, const HostCfg &h, int first, int n,
     // bitstream packing (lane per frame)
     const dim3 wg_grid((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), wg_block(64 * LC3_WG_WAVES);
     e->timer.mark(stream, -1, chain);
-    LC3_LAUNCH_CFG(lc3_enc_front_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n, d_pcm, mid, planes, nbytes, n_frames, fresh,
+    LC3_LAUNCH_CFG(lc3_enc_front_kernel, h, wg_grid, wg_block, lc3_lds_pad(0), stream, e->d_states, first, n, d_pcm, mid, planes, nbytes, n_frames, fresh,
                    dbg, io, e->spec_flags);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream, 0, chain);
@@ -2096,7 +2117,7 @@ static int encode_kernels(lc3gpu_encoder *e, const HostCfg &h, int first, int n,
                        e->spec_flags);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream, 1, chain);
-    LC3_LAUNCH_CFG(lc3_enc_back_kernel, h, wg_grid, wg_block, 0, stream, e->d_states, first, n, (const float *)mid, planes, nbytes, n_frames,
+    LC3_LAUNCH_CFG(lc3_enc_back_kernel, h, wg_grid, wg_block, lc3_lds_pad(1), stream, e->d_states, first, n, (const float *)mid, planes, nbytes, n_frames,
                    dbg, e->spec_flags | lc3_prep_symbols_flag(frames_of_call));
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream, 2, chain);
@@ -2439,7 +2460,7 @@ static int decode_kernels(lc3gpu_decoder *d, const HostCfg &h, int first, int n,
         LC3_LAUNCH_CFG(lc3_decode_late_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0,
                        stream, d->d_states, first, n, (const int32_t *)planes, d_pcm, nbytes, n_frames, 0, io);
     else
-        LC3_LAUNCH_CFG(lc3_decode_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0, stream,
+        LC3_LAUNCH_CFG(lc3_decode_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), lc3_lds_pad(2), stream,
                        d->d_states, first, n, (const int32_t *)planes, d_pcm, nbytes, n_frames, 0, io);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream, 3, chain);

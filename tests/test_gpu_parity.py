@@ -812,6 +812,51 @@ def test_prepared_packer_symbols_on_and_off():
         assert r.returncode == 0 and "prep ok" in r.stdout, v + pc + r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_producer_consumer_kernels_at_every_size():
+    """Full batches parse and pack with producer / consumer wave pairs (lc3_parse_pc_kernel, lc3_pack_pc_kernel); launches of up to 16 384
+    frames normally take the small-launch forms.  LC3GPU_RECON=lane + LC3GPU_PREP_SYMBOLS=0 put EVERY launch on the pair kernels: partial
+    waves and workgroups, one-frame launches, the interleaved layout, channel ranges, state carry, damaged and flagged frames, garbage,
+    every rate and duration, the smallest and the largest frames (fewer frames per workgroup), and 64 / 128 frames per workgroup
+    (LC3GPU_FPB: a pair's waves then sit on different SIMDs)."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, 'tests')\n"
+        "import test_gpu_parity as t\n"
+        "for S in (1, 2, 3, 5, 63, 64, 65, 127, 129, 300):\n"
+        "    t._roundtrip_check(48000, 10000, 150, S, 3, seed=401 + S)\n"
+        "for nb in (20, 25, 40, 100, 200, 300, 400):\n"
+        "    t._roundtrip_check(48000, 10000, nb, 70, 5, seed=402)\n"
+        "for fs, us, nb in ((48000, 7500, 113), (44100, 10000, 110), (32000, 7500, 60), (24000, 10000, 60), (16000, 7500, 30), (16000, 10000, 40)):\n"
+        "    t._roundtrip_check(fs, us, nb, 96, 5, seed=403)\n"
+        "t.test_decode_8khz(10000, 30)\n"
+        "t.test_decode_8khz(7500, 23)\n"
+        "t.test_interleaved_layout(48000, 10000, 150, 2, 9)\n"
+        "t.test_interleaved_layout(32000, 10000, 81, 70, 3)\n"
+        "t.test_interleaved_layout(16000, 10000, 40, 5, 4)\n"
+        "t.test_channel_ranges_on_separate_hip_streams()\n"
+        "t.test_state_carry_across_launches()\n"
+        "t.test_state_save_load_and_reset()\n"
+        "t.test_variable_bitrate_per_call()\n"
+        "t.test_corrupt_frames_are_concealed_like_the_reference()\n"
+        "t.test_random_garbage_streams()\n"
+        "t.test_bad_frame_flag_forces_concealment()\n"
+        "t.test_cold_start_many_streams()\n"
+        "t.test_long_stream_state_carry()\n"
+        "t.test_ltpf_transitions(48000, 10000, 60)\n"
+        "t.test_kat_encode_frame(); t.test_kat_decode_frame()\n"
+        "print('pairs ok')\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for fpb in ("256", "128", "64"):
+        env = dict(os.environ, LC3GPU_RECON="lane", LC3GPU_PREP_SYMBOLS="0", LC3GPU_PARSE_PC="1", LC3GPU_PACK_PC="1", LC3GPU_FPB=fpb)
+        env.pop("LC3GPU_LATE_RECON", None)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0 and "pairs ok" in r.stdout, fpb + r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def _split_suite():
     """what test_split_calls_on_and_off runs in a child process with LC3GPU_SPLIT=1 (every batch call of at least 16 streams runs as two
     halves on the handle's internal HIP streams) and with LC3GPU_SPLIT=0 (never): every result against the oracle"""
