@@ -570,35 +570,39 @@ __device__ __forceinline__ void lc3_pc_produce(lc3_parse_ctx &c, const lc3_pc_li
         const uint32_t *row = c.cf + (int)c.lookup[rate_flag + (0 > hi_from ? 256 : 0)] * LC3_DCF_ROW_WORDS;
         lc3_i4 pv = ((const lc3_i4 *)row)[4];
         int c_seen = 0, spins = 0;
+        // A chunk of LC3_PC_CHUNK iterations at a time, straight-line (the loop-carried values of a lane then move between
+        // registers once per chunk, not once per symbol); a lane that has finished its frame idles, and the count that is published
+        // is always whole chunks: behind the last symbol of the wave the consumer finds every lane idle as well
         while (LC3_WAVE_ANY(tup < ntup)) {
-            if (tup < ntup) {
-                const int head0 = c.head;
-                if (lev < 14) sym = lc3_p_ac_decode_spec_sel(c, st, row, pv, err);
-                const int esc = sym >= 16 && lev < 14;
-                k.ring[(it & k.mask) * k.stride] = (uint32_t)sym | ((uint32_t)(c.head - head0) << 5);
-                const int a = sym & 3, b = sym >> 2;
-                const int lv = lev < 3 ? lev : 3;
-                const int n_cctx = esc ? cctx : (cctx & 15) * 16 + (lv <= 1 ? 1 + ((a + b) << lv) : 12 + lv);
-                const int n_tup = tup + !esc, n_lev = esc ? lev + 1 : 0;
-                const int n_lv = n_lev < 3 ? n_lev : 3;
-                const int n_row = (int)c.lookup[n_cctx + rate_flag + ((n_tup * 2) > hi_from ? 256 : 0) + n_lv * 1024];
-                row = c.cf + n_row * LC3_DCF_ROW_WORDS;
-                pv = ((const lc3_i4 *)row)[4];
-                lc3_p_head_refill(c);
-                cctx = n_cctx;
-                tup = n_tup;
-                lev = n_lev;
+#pragma unroll
+            for (int u = 0; u < LC3_PC_CHUNK; u++) {
+                if (tup < ntup) {
+                    const int head0 = c.head;
+                    if (lev < 14) sym = lc3_p_ac_decode_spec_sel(c, st, row, pv, err);
+                    const int esc = sym >= 16 && lev < 14;
+                    k.ring[((it + u) & k.mask) * k.stride] = (uint32_t)sym | ((uint32_t)(c.head - head0) << 5);
+                    const int a = sym & 3, b = sym >> 2;
+                    const int lv = lev < 3 ? lev : 3;
+                    const int n_cctx = esc ? cctx : (cctx & 15) * 16 + (lv <= 1 ? 1 + ((a + b) << lv) : 12 + lv);
+                    const int n_tup = tup + !esc, n_lev = esc ? lev + 1 : 0;
+                    const int n_lv = n_lev < 3 ? n_lev : 3;
+                    const int n_row = (int)c.lookup[n_cctx + rate_flag + ((n_tup * 2) > hi_from ? 256 : 0) + n_lv * 1024];
+                    row = c.cf + n_row * LC3_DCF_ROW_WORDS;
+                    pv = ((const lc3_i4 *)row)[4];
+                    lc3_p_head_refill(c);
+                    cctx = n_cctx;
+                    tup = n_tup;
+                    lev = n_lev;
+                }
             }
-            it++;
-            if ((it & (LC3_PC_CHUNK - 1)) == 0) {
-                LC3_PC_STORE(k.p_count, it);
-                // the next chunk's entries must not land on entries the consumer has not taken yet
-                while (it + LC3_PC_CHUNK - c_seen > k.mask + 1 && spins < LC3_PC_SPIN_LIMIT) {
-                    c_seen = LC3_PC_LOAD(k.c_count);
-                    if (it + LC3_PC_CHUNK - c_seen > k.mask + 1) {
-                        LC3_PC_PAUSE();
-                        spins++;
-                    }
+            it += LC3_PC_CHUNK;
+            LC3_PC_STORE(k.p_count, it);
+            // the next chunk's entries must not land on entries the consumer has not taken yet
+            while (it + LC3_PC_CHUNK - c_seen > k.mask + 1 && spins < LC3_PC_SPIN_LIMIT) {
+                c_seen = LC3_PC_LOAD(k.c_count);
+                if (it + LC3_PC_CHUNK - c_seen > k.mask + 1) {
+                    LC3_PC_PAUSE();
+                    spins++;
                 }
             }
         }
@@ -632,56 +636,56 @@ __device__ __forceinline__ int lc3_pc_consume(lc3_parse_ctx &c, const lc3_pc_lin
     const int ntup = dead ? 0 : lastnz / 2;
     int lev_end = 0, err = 0, it = 0;
     {
-        int tup = 0, lev = 0, slack = 0x7fffffff, limit = 0;
+        int tup = 0, lev = 0, slack = 0x7fffffff;
         int32_t xk = 0, xk1 = 0;
         c.tcur = lc3_p_tail_byte(c, c.tail >> 3);
         c.tnext = lc3_p_tail_byte(c, (c.tail >> 3) + 1);
-        while (LC3_WAVE_ANY(tup < ntup)) {
-            if (it == limit) {  // (wave-uniform) wait for the next chunk
-                while ((((pc = LC3_PC_LOAD(k.p_count)) & (LC3_PC_DONE - 1)) <= it) && !(pc & LC3_PC_DONE) && spins < LC3_PC_SPIN_LIMIT) {
-                    LC3_PC_PAUSE();
-                    spins++;
-                }
-                limit = pc & (LC3_PC_DONE - 1);
-                if (limit <= it) {  // the producer ended (or never answered) short of this wave's count: cannot happen while both walk the same frames
-                    err = 1;
-                    break;
+        // whole chunks of LC3_PC_CHUNK iterations, straight-line (see the producer); the producer's count is whole chunks, the wave's last
+        // one padded with iterations in which every lane idles
+        for (;;) {
+            while ((((pc = LC3_PC_LOAD(k.p_count)) & (LC3_PC_DONE - 1)) <= it) && !(pc & LC3_PC_DONE) && spins < LC3_PC_SPIN_LIMIT) {
+                LC3_PC_PAUSE();
+                spins++;
+            }
+            if ((pc & (LC3_PC_DONE - 1)) <= it) break;  // the producer has ended (or never answered)
+#pragma unroll
+            for (int u = 0; u < LC3_PC_CHUNK; u++) {
+                if (tup < ntup) {
+                    const uint32_t w = k.ring[((it + u) & k.mask) * k.stride];
+                    const int sym = (int)(w & 31u);
+                    c.head += (int)(w >> 5);
+                    const int esc = sym >= 16 && lev < 14;
+                    const int a = sym & 3, b = sym >> 2;
+                    const int32_t m0 = xk + (int32_t)((uint32_t)a << lev), m1 = xk1 + (int32_t)((uint32_t)b << lev);  // if this is the main symbol
+                    // two tail bits: after an escape symbol the pair's next bit plane (when it is transmitted), after the main symbol
+                    // the signs of the non-zero values
+                    const int want_e = !lsb_mode || lev > 0;
+                    int bit0, bit1;
+                    lc3_p_bool2_sel(c, esc ? want_e : m0 > 0, esc ? want_e : m1 > 0, slack, bit0, bit1);
+                    const int32_t v0 = bit0 ? -m0 : m0, v1 = bit1 ? -m1 : m1;
+                    {   // (an escape step stores its partial values too: the pair's main step overwrites them)
+                        lc3_i2 pr;
+                        pr[0] = v0;
+                        pr[1] = v1;
+                        *(lc3_i2 *)(c.plane + (LC3_PLANE_X + 2 * tup) * LC3_PLANE_STRIDE) = pr;
+                    }
+                    if (lsb_mode && !esc) lc3_px_set(c, LC3_PLANE_LEV + tup, lev);  // written by TUPLE index, read by LINE index (:184-195)
+                    lev_end = (!esc && lev > 0) ? tup + 1 : lev_end;
+                    if (COUNT) {
+                        c.nnz += esc ? 0u : (uint32_t)(m0 != 0) + (uint32_t)(m1 != 0);
+                        // sum |x_k| * k mod 2^16 (:140-145): (m0 + m1) * 2 tup + m1, the factors below 2^17 and 2^9
+                        c.seed += esc ? 0u : LC3_MUL24((uint32_t)(m0 + m1), (uint32_t)(2 * tup)) + (uint32_t)m1;
+                    }
+                    xk = esc ? xk + (int32_t)((uint32_t)bit0 << lev) : 0;
+                    xk1 = esc ? xk1 + (int32_t)((uint32_t)bit1 << lev) : 0;
+                    tup += !esc;
+                    lev = esc ? lev + 1 : 0;
                 }
             }
-            if (tup < ntup) {
-                const uint32_t w = k.ring[(it & k.mask) * k.stride];
-                const int sym = (int)(w & 31u);
-                c.head += (int)(w >> 5);
-                const int esc = sym >= 16 && lev < 14;
-                const int a = sym & 3, b = sym >> 2;
-                const int32_t m0 = xk + (int32_t)((uint32_t)a << lev), m1 = xk1 + (int32_t)((uint32_t)b << lev);  // if this is the main symbol
-                // two tail bits: after an escape symbol the pair's next bit plane (when it is transmitted), after the main symbol
-                // the signs of the non-zero values
-                const int want_e = !lsb_mode || lev > 0;
-                int bit0, bit1;
-                lc3_p_bool2_sel(c, esc ? want_e : m0 > 0, esc ? want_e : m1 > 0, slack, bit0, bit1);
-                const int32_t v0 = bit0 ? -m0 : m0, v1 = bit1 ? -m1 : m1;
-                {   // (an escape step stores its partial values too: the pair's main step overwrites them)
-                    lc3_i2 pr;
-                    pr[0] = v0;
-                    pr[1] = v1;
-                    *(lc3_i2 *)(c.plane + (LC3_PLANE_X + 2 * tup) * LC3_PLANE_STRIDE) = pr;
-                }
-                if (lsb_mode && !esc) lc3_px_set(c, LC3_PLANE_LEV + tup, lev);  // written by TUPLE index, read by LINE index (:184-195)
-                lev_end = (!esc && lev > 0) ? tup + 1 : lev_end;
-                if (COUNT) {
-                    c.nnz += esc ? 0u : (uint32_t)(m0 != 0) + (uint32_t)(m1 != 0);
-                    // sum |x_k| * k mod 2^16 (:140-145): (m0 + m1) * 2 tup + m1, the factors below 2^17 and 2^9
-                    c.seed += esc ? 0u : LC3_MUL24((uint32_t)(m0 + m1), (uint32_t)(2 * tup)) + (uint32_t)m1;
-                }
-                xk = esc ? xk + (int32_t)((uint32_t)bit0 << lev) : 0;
-                xk1 = esc ? xk1 + (int32_t)((uint32_t)bit1 << lev) : 0;
-                tup += !esc;
-                lev = esc ? lev + 1 : 0;
-            }
-            it++;
-            if ((it & (LC3_PC_CHUNK - 1)) == 0) LC3_PC_STORE(k.c_count, it);
+            it += LC3_PC_CHUNK;
+            LC3_PC_STORE(k.c_count, it);
         }
+        err |= LC3_WAVE_ANY(tup < ntup) && tup < ntup;  // the producer ended short of this lane's frame: cannot happen while both walk the same frames
         // the loop's deferred bound checks (see lc3_parse_frame)
         err |= (slack < 0) | (c.len - ((c.tail - 1) >> 3) - 1 < 0);
     }

@@ -492,46 +492,48 @@ __device__ __forceinline__ void lc3_pack_produce(const lc3_pack_ctx &w, const lc
     lc3_pk_sym cur = lc3_pk_symbol(xw, 0, 0, 0, rate_flag, ne);
     uint32_t sv = w.cf[(int)w.lookup[cur.idx] * 17 + (cur.esc ? 16 : (int)(cur.a + 4u * cur.b))];
     LC3_PC_STORE(k.p_count, 0);
+    // whole chunks of LC3_PC_CHUNK iterations, straight-line (see lc3_pc_produce, lc3_dev_dec_parse.h)
     while (LC3_WAVE_ANY(tup < ntup)) {
-        uint32_t word = 0u;
-        if (tup < ntup) {
-            // where the lane will be after this symbol, and that symbol's model row (see lc3_pack_frame)
-            const int adv = !cur.esc;
-            const int n_cctx = adv ? (cctx & 15) * 16 + (cur.lv <= 1 ? 1 + (int)((cur.a + cur.b) << cur.lv) : 12 + cur.lv) : cctx;
-            const int n_lev = adv ? 0 : lev + 1, n_tup = tup + adv;
-            const uint32_t n_xw = adv ? x1 : xw;
-            const lc3_pk_sym nxt = lc3_pk_symbol(n_xw, n_lev, n_cctx, n_tup, rate_flag, ne);
-            const int rown = (int)w.lookup[nxt.idx];
-            // this symbol: interval, then the bits that follow it (escape: the pair's next bit plane; main symbol: the signs)
-            const int lsb_here = lsb_mode && lev > 0;
-            const unsigned a_l = lsb_here ? cur.a0 >> 1 : cur.a0, b_l = lsb_here ? cur.b0 >> 1 : cur.b0;
-            const int want_e = !(lsb_mode && lev == 0);
-            const int w0 = cur.esc ? want_e : a_l > 0u, w1 = cur.esc ? want_e : b_l > 0u;
-            const uint32_t b0 = cur.esc ? (cur.a & 1u) : (uint32_t)(cur.q0 <= 0), b1 = cur.esc ? (cur.b & 1u) : (uint32_t)(cur.q1 <= 0);
-            const uint32_t bits = w0 ? (b0 | (b1 << 1)) : b1;  // the first wanted bit lowest
-            word = LC3_PK_SYM_VALID | LC3_SYM_WORD(sv & 0xffffu, sv >> 16, w0 + w1, bits & 3u);
-            // (the LSB list itself is regenerated by lc3_pack_end when it is written)
-            nlsbs += (!cur.esc && lsb_here) ? 2 + (a_l == 0u && cur.q0 != 0) + (b_l == 0u && cur.q1 != 0) : 0;
-            sv = w.cf[rown * 17 + (nxt.esc ? 16 : (int)(nxt.a + 4u * nxt.b))];
-            cur = nxt;
-            cctx = n_cctx;
-            lev = n_lev;
-            tup = n_tup;
-            xw = n_xw;
-            x1 = adv ? x2 : x1;
-            x2 = adv ? x3 : x2;
-            x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (tup + 3 < last ? tup + 3 : last));  // the same word again unless the lane advanced
+#pragma unroll
+        for (int u = 0; u < LC3_PC_CHUNK; u++) {
+            uint32_t word = 0u;
+            if (tup < ntup) {
+                // where the lane will be after this symbol, and that symbol's model row (see lc3_pack_frame)
+                const int adv = !cur.esc;
+                const int n_cctx = adv ? (cctx & 15) * 16 + (cur.lv <= 1 ? 1 + (int)((cur.a + cur.b) << cur.lv) : 12 + cur.lv) : cctx;
+                const int n_lev = adv ? 0 : lev + 1, n_tup = tup + adv;
+                const uint32_t n_xw = adv ? x1 : xw;
+                const lc3_pk_sym nxt = lc3_pk_symbol(n_xw, n_lev, n_cctx, n_tup, rate_flag, ne);
+                const int rown = (int)w.lookup[nxt.idx];
+                // this symbol: interval, then the bits that follow it (escape: the pair's next bit plane; main symbol: the signs)
+                const int lsb_here = lsb_mode && lev > 0;
+                const unsigned a_l = lsb_here ? cur.a0 >> 1 : cur.a0, b_l = lsb_here ? cur.b0 >> 1 : cur.b0;
+                const int want_e = !(lsb_mode && lev == 0);
+                const int w0 = cur.esc ? want_e : a_l > 0u, w1 = cur.esc ? want_e : b_l > 0u;
+                const uint32_t b0 = cur.esc ? (cur.a & 1u) : (uint32_t)(cur.q0 <= 0), b1 = cur.esc ? (cur.b & 1u) : (uint32_t)(cur.q1 <= 0);
+                const uint32_t bits = w0 ? (b0 | (b1 << 1)) : b1;  // the first wanted bit lowest
+                word = LC3_PK_SYM_VALID | LC3_SYM_WORD(sv & 0xffffu, sv >> 16, w0 + w1, bits & 3u);
+                // (the LSB list itself is regenerated by lc3_pack_end when it is written)
+                nlsbs += (!cur.esc && lsb_here) ? 2 + (a_l == 0u && cur.q0 != 0) + (b_l == 0u && cur.q1 != 0) : 0;
+                sv = w.cf[rown * 17 + (nxt.esc ? 16 : (int)(nxt.a + 4u * nxt.b))];
+                cur = nxt;
+                cctx = n_cctx;
+                lev = n_lev;
+                tup = n_tup;
+                xw = n_xw;
+                x1 = adv ? x2 : x1;
+                x2 = adv ? x3 : x2;
+                x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (tup + 3 < last ? tup + 3 : last));  // the same word again unless the lane advanced
+            }
+            k.ring[((it + u) & k.mask) * k.stride] = word;  // every lane: a lane that has finished its frame says so
         }
-        k.ring[(it & k.mask) * k.stride] = word;  // every lane: a lane that has finished its frame says so
-        it++;
-        if ((it & (LC3_PC_CHUNK - 1)) == 0) {
-            LC3_PC_STORE(k.p_count, it);
-            while (it + LC3_PC_CHUNK - c_seen > k.mask + 1 && spins < LC3_PC_SPIN_LIMIT) {
-                c_seen = LC3_PC_LOAD(k.c_count);
-                if (it + LC3_PC_CHUNK - c_seen > k.mask + 1) {
-                    LC3_PC_PAUSE();
-                    spins++;
-                }
+        it += LC3_PC_CHUNK;
+        LC3_PC_STORE(k.p_count, it);
+        while (it + LC3_PC_CHUNK - c_seen > k.mask + 1 && spins < LC3_PC_SPIN_LIMIT) {
+            c_seen = LC3_PC_LOAD(k.c_count);
+            if (it + LC3_PC_CHUNK - c_seen > k.mask + 1) {
+                LC3_PC_PAUSE();
+                spins++;
             }
         }
     }
@@ -543,24 +545,24 @@ __device__ __forceinline__ void lc3_pack_consume(lc3_pack_ctx &w, const lc3_pc_l
     lc3_pack_head h;
     lc3_pack_load_head(w, h);
     if (valid) lc3_pack_begin(w, ne, h);
-    int it = 0, limit = 0, spins = 0, pc = 0;
-    while (true) {
-        if (it == limit) {  // (wave-uniform) the next chunk, or the end
-            while ((((pc = LC3_PC_LOAD(k.p_count)) & (LC3_PC_DONE - 1)) <= it || pc < 0) && !(pc >= 0 && (pc & LC3_PC_DONE)) && spins < LC3_PC_SPIN_LIMIT) {
-                LC3_PC_PAUSE();
-                spins++;
+    int it = 0, spins = 0, pc = 0;
+    for (;;) {  // whole chunks; the producer's count is whole chunks
+        while ((((pc = LC3_PC_LOAD(k.p_count)) & (LC3_PC_DONE - 1)) <= it || pc < 0) && !(pc >= 0 && (pc & LC3_PC_DONE)) && spins < LC3_PC_SPIN_LIMIT) {
+            LC3_PC_PAUSE();
+            spins++;
+        }
+        if (pc < 0 || (pc & (LC3_PC_DONE - 1)) <= it) break;  // the producer has finished (or never answered)
+#pragma unroll
+        for (int u = 0; u < LC3_PC_CHUNK; u++) {
+            const uint32_t s0 = k.ring[((it + u) & k.mask) * k.stride];
+            if (s0 & LC3_PK_SYM_VALID) {
+                lc3_pk_ac_encode_sel(w, s0 & 0x3ffu, (s0 >> 10) & 0x3ffu);
+                const int nb = (int)((s0 >> 20) & 3u);
+                lc3_pk_bool2_backward_sel(w, nb > 0, (int)((s0 >> 22) & 1u), nb > 1, (int)((s0 >> 23) & 1u));
             }
-            limit = pc < 0 ? 0 : (pc & (LC3_PC_DONE - 1));
-            if (limit <= it) break;  // the producer has finished (or never answered)
         }
-        const uint32_t s0 = k.ring[(it & k.mask) * k.stride];
-        if (s0 & LC3_PK_SYM_VALID) {
-            lc3_pk_ac_encode_sel(w, s0 & 0x3ffu, (s0 >> 10) & 0x3ffu);
-            const int nb = (int)((s0 >> 20) & 3u);
-            lc3_pk_bool2_backward_sel(w, nb > 0, (int)((s0 >> 22) & 1u), nb > 1, (int)((s0 >> 23) & 1u));
-        }
-        it++;
-        if ((it & (LC3_PC_CHUNK - 1)) == 0) LC3_PC_STORE(k.c_count, it);
+        it += LC3_PC_CHUNK;
+        LC3_PC_STORE(k.c_count, it);
     }
     LC3_PC_STORE(k.c_count, LC3_PC_DONE - 1);
     const int nlsbs = (int)k.fin[0];
