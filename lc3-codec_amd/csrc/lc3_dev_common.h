@@ -300,7 +300,9 @@ __device__ __forceinline__ float lc3_ceilf(float x) { return __builtin_ceilf(x);
 #define LC3_PC_RELEASE() ((void)0)
 #define LC3_PC_ACQUIRE() ((void)0)
 #endif
-#define LC3_PC_CHUNK 4
+#ifndef LC3_PC_CHUNK
+#define LC3_PC_CHUNK 8
+#endif
 #define LC3_PC_DONE 0x40000000
 #define LC3_PC_SPIN_LIMIT (1 << 24)  // polls before a wave gives up on its partner (never reached unless the partner died)
 struct lc3_pc_link {

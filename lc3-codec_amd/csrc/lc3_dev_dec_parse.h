@@ -103,9 +103,14 @@ __device__ __forceinline__ int lc3_p_bool(lc3_parse_ctx &c, int &bit) {
 
 // side_info_reader::read (decoder/side_info_reader.rs:29-200).  WR = 0: parse only, nothing goes to the plane (the producer wave of a
 // producer / consumer pair needs the flags, its consumer writes the words)
+// the SNS vector quantiser's side information (read_sns_vq :131-200), as the scale-factor computation takes it
+struct lc3_sns_side {
+    int ind_lf, ind_hf, sub_msb, sub_lsb, g_ind, ls_a, ls_b;
+    uint32_t idx_a, idx_b;
+};
 template <int WR = 1>
 __device__ __forceinline__ int lc3_parse_side_info(lc3_parse_ctx &c, int fs_ind, int ne, int &lastnz_out, int &lsb_mode_out,
-                                                   int &num_tns_out, int ord[2]) {
+                                                   int &num_tns_out, int ord[2], lc3_sns_side *sns = nullptr) {
 #define lc3_px_set(c_, w_, v_) do { if (WR) (lc3_px_set)(c_, w_, v_); } while (0)
     uint32_t v;
     int b, p_bw = 0, lastnz_bits = 0;
@@ -141,8 +146,10 @@ __device__ __forceinline__ int lc3_parse_side_info(lc3_parse_ctx &c, int fs_ind,
     // read_sns_vq :131-200
     LC3_PT(5, v);
     lc3_px_set(c, SI_IND_LF, (int)v);
+    const int lc3_sns_ind_lf_ = (int)v;
     LC3_PT(5, v);
     lc3_px_set(c, SI_IND_HF, (int)v);
+    const int lc3_sns_ind_hf_ = (int)v;
     LC3_PB(b);
     const int submode_msb = b;
     if (submode_msb == 0) LC3_PT(1, v);
@@ -150,6 +157,7 @@ __device__ __forceinline__ int lc3_parse_side_info(lc3_parse_ctx &c, int fs_ind,
     int g_ind = (int)v;
     LC3_PB(b);
     lc3_px_set(c, SI_LS_A, b);
+    const int lc3_sns_ls_a_ = b;
     int submode_lsb = 0, ls_indb = 0;
     uint32_t idx_a, idx_b = 0;
     if (submode_msb == 0) {
@@ -183,6 +191,17 @@ __device__ __forceinline__ int lc3_parse_side_info(lc3_parse_ctx &c, int fs_ind,
     lc3_px_set(c, SI_SUB_LSB, submode_lsb);
     lc3_px_set(c, SI_SUB_MSB, submode_msb);
     lc3_px_set(c, SI_G_IND, g_ind);
+    if (sns) {
+        sns->ind_lf = lc3_sns_ind_lf_;
+        sns->ind_hf = lc3_sns_ind_hf_;
+        sns->sub_msb = submode_msb;
+        sns->sub_lsb = submode_lsb;
+        sns->g_ind = g_ind;
+        sns->ls_a = lc3_sns_ls_a_;
+        sns->ls_b = ls_indb;
+        sns->idx_a = idx_a;
+        sns->idx_b = idx_b;
+    }
     // read_long_term_post_filter_info :106-129
     int ltpf_active = 0, pitch_index = 0;
     if (pitch_present) {
@@ -511,6 +530,100 @@ __device__ __forceinline__ int lc3_parse_frame(lc3_parse_ctx &c, int ne, int fs_
     return lc3_parse_finish<COUNT>(c, st.range, nbits, ntup, lev_end, lsb_mode, ne);
 }
 
+// the reconstruction context and the scale factors (used by the consumer wave below and by lc3_reconstruct_frame further down)
+struct lc3_recon_ctx {
+    float *scf;            // 16 scale factors of this lane, element n at scf[n * sstride] (LDS, dynamically indexed)
+    int sstride;
+    const uint32_t *mpvq;  // MPVQ_OFFSETS[16][11] (LDS copy)
+    const uint16_t *ifs;   // band index table of the configuration, nb + 1 entries (LDS copy: read at every band boundary of
+                           // the line loop, and a table word fetched from HBM there waits for every outstanding plane access)
+};
+
+// mpvq_deenum (decoder/spectral_noise_shaping.rs:155-235) writing the pulses into scf slots as floats is not possible
+// (they are needed as integers first), so the pulses live in a 16-entry register array filled by static unrolling.
+__device__ __forceinline__ void lc3_r_deenum(const lc3_recon_ctx &r, int dim_in, int k_val_in, int ls_ind, uint32_t mpvq_ind,
+                                             int (&vec)[16], int base) {
+    int leading_sign = ls_ind == 0 ? 1 : -1, k_max_local = k_val_in, done = 0;
+    uint32_t ind = mpvq_ind;
+#pragma unroll
+    for (int pos = 0; pos < 16; pos++) {
+        if (pos < dim_in && !done) {
+            const uint32_t *h_row = r.mpvq + (dim_in - 1 - pos) * 11;
+            if (ind != 0) {
+                int k_acc = k_max_local;
+                uint32_t ul_diff = 0;
+                int wrap = ind < h_row[k_acc];
+                if (!wrap) ul_diff = ind - h_row[k_acc];
+                while (wrap) {
+                    k_acc -= 1;
+                    wrap = ind < h_row[k_acc];
+                    if (!wrap) ul_diff = ind - h_row[k_acc];
+                }
+                ind = ul_diff;
+                const int k_delta = k_max_local - k_acc;
+                if (k_delta != 0) {
+                    vec[base + pos] = leading_sign < 0 ? -k_delta : k_delta;
+                    leading_sign = (ind & 1u) ? -1 : 1;
+                    ind >>= 1;
+                    k_max_local -= k_delta;
+                }
+            } else {
+                vec[base + pos] = leading_sign < 0 ? -k_max_local : k_max_local;
+                done = 1;
+            }
+        }
+    }
+}
+
+
+// spectral_noise_shaping::decode: the 16 scale factors scf[n] = codebook + gain * (y . D) (:21-73).  TO_REGS = 0: into the lane's LDS
+// slots r.scf; 1: into out[16] (registers: fully unrolled)
+template <int TO_REGS>
+__device__ __forceinline__ void lc3_recon_scf(const lc3_recon_ctx &r, const lc3_sns_side &sv, float *out) {
+    int y[16];
+#pragma unroll
+    for (int n = 0; n < 16; n++) y[n] = 0;
+    const int shape_j = (sv.sub_msb << 1) + sv.sub_lsb;
+    const int ls_a = sv.ls_a;
+    const uint32_t idx_a = sv.idx_a;
+    if (shape_j == 0) {
+        lc3_r_deenum(r, 10, 10, ls_a, idx_a, y, 0);
+        lc3_r_deenum(r, 6, 1, sv.ls_b, sv.idx_b, y, 10);
+    } else if (shape_j == 1) lc3_r_deenum(r, 10, 10, ls_a, idx_a, y, 0);
+    else if (shape_j == 2) lc3_r_deenum(r, 16, 8, ls_a, idx_a, y, 0);
+    else lc3_r_deenum(r, 16, 6, ls_a, idx_a, y, 0);
+    float y_norm = 0.0f;
+#pragma unroll
+    for (int n = 0; n < 16; n++) y_norm += (float)y[n] * (float)y[n];
+    y_norm = lc3_sqrtf(y_norm);
+    float gain;
+    const int gi = sv.g_ind;
+    if (shape_j == 0) gain = lc3_f(LC3T_SNS_VQ_REG_ADJ_GAINS_BITS, gi & 1);
+    else if (shape_j == 1) gain = lc3_f(LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS, gi & 3);
+    else if (shape_j == 2) gain = lc3_f(LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS, gi & 3);
+    else gain = lc3_f(LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS, gi & 7);
+    if (y_norm != 0.0f) gain /= y_norm;
+    const int ind_lf = sv.ind_lf, ind_hf = sv.ind_hf;
+    if (TO_REGS) {
+#pragma unroll
+        for (int n = 0; n < 16; n++) {
+            float factor = 0.0f;
+#pragma unroll
+            for (int col = 0; col < 16; col++) factor += (float)y[col] * lc3_f(&LC3T_D_BITS[n][0], col);
+            const float st1 = n < 8 ? lc3_f(&LC3T_LFCB_BITS[ind_lf][0], n) : lc3_f(&LC3T_HFCB_BITS[ind_hf][0], n - 8);
+            out[n] = st1 + gain * factor;
+        }
+    } else {
+        for (int n = 0; n < 16; n++) {
+            float factor = 0.0f;
+#pragma unroll
+            for (int col = 0; col < 16; col++) factor += (float)y[col] * lc3_f(&LC3T_D_BITS[n][0], col);
+            const float st1 = n < 8 ? lc3_f(&LC3T_LFCB_BITS[ind_lf][0], n) : lc3_f(&LC3T_HFCB_BITS[ind_hf][0], n - 8);
+            r.scf[n * r.sstride] = st1 + gain * factor;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // The spectral data of a frame decoded by a PRODUCER / CONSUMER pair of waves (full batches: lc3_parse_pc_kernel, lc3gpu.hip).
 //
@@ -617,13 +730,22 @@ __device__ __forceinline__ void lc3_pc_produce(lc3_parse_ctx &c, const lc3_pc_li
 
 // the consumer: side information (to the plane), then everything of decode_spectral_data that only consumes symbols, then the rest of
 // arithmetic_codec::decode (lc3_parse_finish).  Returns 0 when the frame parsed (as lc3_parse_frame<COUNT>)
+// r / scf_out (optional): the reconstruction context and 16 registers for the frame's scale factors, which only need the side
+// information: computed here while the producer is still at its start (the ring lies in the lane's scale-factor slots in LDS, so
+// they stay in registers until the symbols are through)
 template <int COUNT>
-__device__ __forceinline__ int lc3_pc_consume(lc3_parse_ctx &c, const lc3_pc_link &k, int ne, int fs_ind, int rc_in) {
+__device__ __forceinline__ int lc3_pc_consume(lc3_parse_ctx &c, const lc3_pc_link &k, int ne, int fs_ind, int rc_in,
+                                              const lc3_recon_ctx *r = nullptr, float *scf_out = nullptr) {
     int lastnz = 0, lsb_mode = 0, num_tns = 0, ord[2] = {0, 0};
     c.nnz = 0;
     c.seed = 0;
     int rc = rc_in;
-    if (rc == 0) rc = lc3_parse_side_info<1>(c, fs_ind, ne, lastnz, lsb_mode, num_tns, ord);
+    lc3_sns_side sns = {0, 0, 0, 0, 0, 0, 0, 0u, 0u};
+    if (rc == 0) rc = lc3_parse_side_info<1>(c, fs_ind, ne, lastnz, lsb_mode, num_tns, ord, &sns);
+    if (scf_out) {
+        if (rc != 0) sns = lc3_sns_side{0, 0, 0, 0, 0, 0, 0, 0u, 0u};  // (a frame that does not parse: any valid indices)
+        lc3_recon_scf<1>(*r, sns, scf_out);
+    }
     const int nbits = c.len * 8;
     // the producer's start values
     int spins = 0, pc;
@@ -717,50 +839,6 @@ __device__ __forceinline__ int lc3_pc_consume(lc3_parse_ctx &c, const lc3_pc_lin
 // reference's, in the reference's order.
 // Returns 1 (and sets AD_OK) when the frame is usable, 0 -> the synthesis kernel conceals it.
 // ------------------------------------------------------------------------------------------------------------------
-struct lc3_recon_ctx {
-    float *scf;            // 16 scale factors of this lane, element n at scf[n * sstride] (LDS, dynamically indexed)
-    int sstride;
-    const uint32_t *mpvq;  // MPVQ_OFFSETS[16][11] (LDS copy)
-    const uint16_t *ifs;   // band index table of the configuration, nb + 1 entries (LDS copy: read at every band boundary of
-                           // the line loop, and a table word fetched from HBM there waits for every outstanding plane access)
-};
-
-// mpvq_deenum (decoder/spectral_noise_shaping.rs:155-235) writing the pulses into scf slots as floats is not possible
-// (they are needed as integers first), so the pulses live in a 16-entry register array filled by static unrolling.
-__device__ __forceinline__ void lc3_r_deenum(const lc3_recon_ctx &r, int dim_in, int k_val_in, int ls_ind, uint32_t mpvq_ind,
-                                             int (&vec)[16], int base) {
-    int leading_sign = ls_ind == 0 ? 1 : -1, k_max_local = k_val_in, done = 0;
-    uint32_t ind = mpvq_ind;
-#pragma unroll
-    for (int pos = 0; pos < 16; pos++) {
-        if (pos < dim_in && !done) {
-            const uint32_t *h_row = r.mpvq + (dim_in - 1 - pos) * 11;
-            if (ind != 0) {
-                int k_acc = k_max_local;
-                uint32_t ul_diff = 0;
-                int wrap = ind < h_row[k_acc];
-                if (!wrap) ul_diff = ind - h_row[k_acc];
-                while (wrap) {
-                    k_acc -= 1;
-                    wrap = ind < h_row[k_acc];
-                    if (!wrap) ul_diff = ind - h_row[k_acc];
-                }
-                ind = ul_diff;
-                const int k_delta = k_max_local - k_acc;
-                if (k_delta != 0) {
-                    vec[base + pos] = leading_sign < 0 ? -k_delta : k_delta;
-                    leading_sign = (ind & 1u) ? -1 : 1;
-                    ind >>= 1;
-                    k_max_local -= k_delta;
-                }
-            } else {
-                vec[base + pos] = leading_sign < 0 ? -k_max_local : k_max_local;
-                done = 1;
-            }
-        }
-    }
-}
-
 // interpolated scale factor of band slot b (0..63) before the nb < 64 folding (:75-98)
 __device__ __forceinline__ float lc3_r_sfi(const lc3_recon_ctx &r, int b) {
     if (b < 2) return r.scf[0];
@@ -931,7 +1009,7 @@ __device__ __forceinline__ void lc3_reconstruct_prepare_wave(lc3_parse_ctx &c) {
 }
 
 template <class CC>
-__device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3_recon_ctx &r, const CC &cfg) {
+__device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3_recon_ctx &r, const CC &cfg, const float *scf_pre = nullptr) {
     const int ne = cfg.ne, nbytes = c.len, nbits = nbytes * 8;
     // the side-information words of the column in one batch of independent loads (a lane of this kernel is
     // latency-bound: a word fetched at its point of use costs a full memory round trip)
@@ -966,39 +1044,17 @@ __device__ __forceinline__ int lc3_reconstruct_frame(lc3_parse_ctx &c, const lc3
     const int x0 = lc3_px_get(c, LC3_PLANE_X), x1 = lc3_px_get(c, LC3_PLANE_X + 1);  // lastnz >= 2: both were stored
     const int do_fill = !(lastnz == 2 && x0 == 0 && x1 == 0 && gg_ind == 0);  // zero frame :147-151
     uint32_t lcg = c.seed & 0xFFFFu;
-    // spectral_noise_shaping::decode: scale factors scf[16] = codebook + gain * (y . D) (:21-73)
-    {
-        int y[16];
+    // spectral_noise_shaping::decode: scale factors scf[16] = codebook + gain * (y . D) (:21-73) -- or the values the caller has
+    // computed already (the consumer wave of a producer / consumer pair does, while it waits for the first symbols)
+    if (scf_pre) {
 #pragma unroll
-        for (int n = 0; n < 16; n++) y[n] = 0;
-        const int shape_j = (LC3_SIW(SI_SUB_MSB) << 1) + LC3_SIW(SI_SUB_LSB);
-        const int ls_a = LC3_SIW(SI_LS_A);
-        const uint32_t idx_a = (uint32_t)LC3_SIW(SI_IDX_A);
-        if (shape_j == 0) {
-            lc3_r_deenum(r, 10, 10, ls_a, idx_a, y, 0);
-            lc3_r_deenum(r, 6, 1, LC3_SIW(SI_LS_B), (uint32_t)LC3_SIW(SI_IDX_B), y, 10);
-        } else if (shape_j == 1) lc3_r_deenum(r, 10, 10, ls_a, idx_a, y, 0);
-        else if (shape_j == 2) lc3_r_deenum(r, 16, 8, ls_a, idx_a, y, 0);
-        else lc3_r_deenum(r, 16, 6, ls_a, idx_a, y, 0);
-        float y_norm = 0.0f;
-#pragma unroll
-        for (int n = 0; n < 16; n++) y_norm += (float)y[n] * (float)y[n];
-        y_norm = lc3_sqrtf(y_norm);
-        float gain;
-        const int gi = LC3_SIW(SI_G_IND);
-        if (shape_j == 0) gain = lc3_f(LC3T_SNS_VQ_REG_ADJ_GAINS_BITS, gi & 1);
-        else if (shape_j == 1) gain = lc3_f(LC3T_SNS_VQ_REG_LF_ADJ_GAINS_BITS, gi & 3);
-        else if (shape_j == 2) gain = lc3_f(LC3T_SNS_VQ_NEAR_ADJ_GAINS_BITS, gi & 3);
-        else gain = lc3_f(LC3T_SNS_VQ_FAR_ADJ_GAINS_BITS, gi & 7);
-        if (y_norm != 0.0f) gain /= y_norm;
-        const int ind_lf = LC3_SIW(SI_IND_LF), ind_hf = LC3_SIW(SI_IND_HF);
-        for (int n = 0; n < 16; n++) {
-            float factor = 0.0f;
-#pragma unroll
-            for (int col = 0; col < 16; col++) factor += (float)y[col] * lc3_f(&LC3T_D_BITS[n][0], col);
-            const float st1 = n < 8 ? lc3_f(&LC3T_LFCB_BITS[ind_lf][0], n) : lc3_f(&LC3T_HFCB_BITS[ind_hf][0], n - 8);
-            r.scf[n * r.sstride] = st1 + gain * factor;
-        }
+        for (int n = 0; n < 16; n++) r.scf[n * r.sstride] = scf_pre[n];
+    } else {
+        lc3_sns_side sv;
+        sv.ind_lf = LC3_SIW(SI_IND_LF); sv.ind_hf = LC3_SIW(SI_IND_HF); sv.sub_msb = LC3_SIW(SI_SUB_MSB); sv.sub_lsb = LC3_SIW(SI_SUB_LSB);
+        sv.g_ind = LC3_SIW(SI_G_IND); sv.ls_a = LC3_SIW(SI_LS_A); sv.ls_b = LC3_SIW(SI_LS_B);
+        sv.idx_a = (uint32_t)LC3_SIW(SI_IDX_A); sv.idx_b = (uint32_t)LC3_SIW(SI_IDX_B);
+        lc3_recon_scf<0>(r, sv, nullptr);
     }
     // global gain :15-25
     float gg;

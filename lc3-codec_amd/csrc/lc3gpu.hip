@@ -1001,15 +1001,14 @@ __device__ __forceinline__ void lc3_parse_pc_body(lc3_cfg_slot<CV> cfg, unsigned
         lc3_pc_produce(c, k, ne, fs_ind, n_ms_10, rc_in);
         return;
     }
-    int ok = lc3_pc_consume<1>(c, k, ne, fs_ind, rc_in) == 0;
-    if (ok) {
-        lc3_recon_ctx r;
-        r.scf = s_scf + ft;
-        r.sstride = fpb;
-        r.mpvq = s_mpvq;
-        r.ifs = s_ifs;
-        ok = lc3_reconstruct_frame(c, r, c0);
-    }
+    lc3_recon_ctx r;
+    r.scf = s_scf + ft;
+    r.sstride = fpb;
+    r.mpvq = s_mpvq;
+    r.ifs = s_ifs;
+    float scf[16];
+    int ok = lc3_pc_consume<1>(c, k, ne, fs_ind, rc_in, &r, scf) == 0;
+    if (ok) ok = lc3_reconstruct_frame(c, r, c0, scf);
     if (valid) lc3_px_set(c, AD_OK, ok);
 }
 template <class CV>

@@ -412,6 +412,8 @@ int lc3emu_decode_late(int fs_hz, int frame_us, int nbytes, int S, int T, const 
         c.head = 0;
         c.tail = 0;
         int rc;
+        float pc_scf[16], pc_scf_regs[16];
+        const float *pc_pre = nullptr;
         if (late == 3) {
             // the producer / consumer form of full batches (lc3_parse_pc_kernel): here the producer walks the frame to its end with a
             // ring that holds every symbol of a frame, then the consumer replays it (one lane, no concurrency: the link's waits never wait)
@@ -429,7 +431,13 @@ int lc3emu_decode_late(int fs_hz, int frame_us, int nbytes, int S, int T, const 
             const int rc_in = (bad && bad[f]) ? -100 : 0;
             lc3_parse_ctx cp = c;  // (its own cursors)
             lc3_pc_produce(cp, k, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10, rc_in);
-            rc = lc3_pc_consume<1>(c, k, j.cfg.ne, j.cfg.fs_ind, rc_in);
+            lc3_recon_ctx rr;
+            rr.scf = pc_scf;
+            rr.sstride = 1;
+            rr.mpvq = &LC3T_MPVQ_OFFSETS[0][0];
+            rr.ifs = lc3_band_index(j.cfg);
+            rc = lc3_pc_consume<1>(c, k, j.cfg.ne, j.cfg.fs_ind, rc_in, &rr, pc_scf_regs);
+            pc_pre = pc_scf_regs;
         } else if (late == 2) rc = (bad && bad[f]) ? -100 : lc3_parse_frame<0>(c, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10);
         else rc = (bad && bad[f]) ? -100 : lc3_parse_frame<1>(c, j.cfg.ne, j.cfg.fs_ind, j.cfg.n_ms_10);
         int ok = rc == 0;
@@ -450,7 +458,7 @@ int lc3emu_decode_late(int fs_hz, int frame_us, int nbytes, int S, int T, const 
             r.sstride = 1;
             r.mpvq = &LC3T_MPVQ_OFFSETS[0][0];
             r.ifs = lc3_band_index(j.cfg);
-            ok = lc3_reconstruct_frame(c, r, j.cfg);
+            ok = lc3_reconstruct_frame(c, r, j.cfg, pc_pre);
         }
         lc3_px_set(c, AD_OK, ok);
     }
