@@ -57,7 +57,7 @@ def parse_args(argv=None):
                          "(default 1: one stream, clean per-kernel timing)")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip timing the OTHER arrangement (see --arrangement) after the timed region")
-    ap.add_argument("--arrangement", choices=("single", "pipelined"), default="pipelined",
+    ap.add_argument("--arrangement", choices=("single", "pipelined", "staggered"), default="pipelined",
                     help="how the timed steps are queued: `single` = encode then decode of the same batch on ONE HIP stream (every call waits for "
                          "the one before it); `pipelined` = the recommended caller pattern (INTEGRATION.md): the encoder handle on one HIP stream, the "
                          "decoder handle on another, two byte buffers and events, so that the decoder works on step k while the encoder runs step k + 1. "
@@ -292,11 +292,16 @@ class GpuEngine:
         # the pipelined arrangement (roundtrip, one handle pair): encoder stream, decoder stream, two byte buffers
         self.arrangement = "single"
         self.k = 0
+        self.pending = None
         if mode == "roundtrip" and NP == 1:
             self.s_enc, self.s_dec = torch.cuda.current_stream(), torch.cuda.Stream()
-            self.bufs = [self.d_bytes, torch.zeros_like(self.d_bytes)]
-            self.enc_done = [torch.cuda.Event(), torch.cuda.Event()]
-            self.dec_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self.bufs = [self.d_bytes, torch.zeros_like(self.d_bytes), torch.zeros_like(self.d_bytes)]
+            self.enc_done = [torch.cuda.Event() for _ in range(3)]
+            self.dec_done = [torch.cuda.Event() for _ in range(3)]
+            # the staggered arrangement: the encoder records this event behind its back half (lc3gpu_encoder_stage_event), the decoder's
+            # stream waits for it
+            self.ev_back = torch.cuda.Event()
+            self.ev_back.record(self.s_enc)  # (torch creates the HIP event at its first record)
 
     device = "cuda"
     carries_state = True
@@ -306,8 +311,34 @@ class GpuEngine:
         assert name == "single" or (self.mode == "roundtrip" and self.NP == 1)
         self.sync()
         self.arrangement, self.k = name, 0
+        if self.mode == "roundtrip" and self.NP == 1:
+            self.encs[0].stage_event(self.pkg.ENC_STAGE_BACK, self.ev_back if name == "staggered" else None)
+
+    def _decode_pending(self, beside_packer):
+        k = self.pending
+        b = k % 3
+        if beside_packer:
+            self.s_dec.wait_event(self.ev_back)  # as recorded inside the encoder call of step k + 1, queued just before
+        self.s_dec.wait_event(self.enc_done[b])
+        self.decs[0].decode(self.bufs[b], self.d_out, NBYTES, self.T, stream=self.s_dec.cuda_stream)
+        self.dec_done[b].record(self.s_dec)
+        self.pending = None
 
     def step(self):
+        if self.arrangement == "staggered":
+            # like `pipelined`, one step further apart: step k's encoder call is queued, then the decoder of step k - 1 -- behind the point
+            # where step k's encoder has only its packer left.  The parser (a lane per frame: a quarter of the chip's workgroup slots) then
+            # runs beside the packer (likewise) and not beside the encoder's front half, which needs every slot; three byte buffers
+            k, b = self.k, self.k % 3
+            if k >= 3:
+                self.s_enc.wait_event(self.dec_done[b])
+            self.encs[0].encode(self.d_pcm, self.bufs[b], NBYTES, self.T, stream=self.s_enc.cuda_stream)
+            self.enc_done[b].record(self.s_enc)
+            if self.pending is not None:
+                self._decode_pending(True)
+            self.pending = k
+            self.k += 1
+            return
         if self.arrangement == "pipelined":
             # step k: the encoder writes buffer k & 1 on its stream as soon as the decoder of step k - 2 has read it; the decoder follows
             # on ITS stream as soon as the bytes are there -- and meanwhile the encoder is already on step k + 1
@@ -330,6 +361,8 @@ class GpuEngine:
         self.k += 1
 
     def sync(self):
+        if self.pending is not None:  # staggered: the last step's decoder call
+            self._decode_pending(False)
         self.torch.cuda.synchronize()
 
     def step_mark(self):
@@ -337,7 +370,7 @@ class GpuEngine:
         marks bracket one step"""
         if self.NP == 1:
             e = self.torch.cuda.Event(enable_timing=True)
-            e.record(self.s_dec if self.arrangement == "pipelined" else self.hs[0])
+            e.record(self.s_dec if self.arrangement != "single" else self.hs[0])
             self.marks.append(e)
 
     def step_times_ms(self):
@@ -352,7 +385,7 @@ class GpuEngine:
 
     def last_bytes(self, k):
         """the first k streams' frame bytes of the most recent step"""
-        buf = self.bufs[(self.k - 1) & 1] if self.arrangement == "pipelined" else self.d_bytes
+        buf = {"pipelined": self.bufs[(self.k - 1) & 1], "staggered": self.bufs[(self.k - 1) % 3]}.get(self.arrangement, self.d_bytes)
         return buf[:k].cpu().numpy()
 
     def results(self, k):
@@ -422,7 +455,7 @@ class GpuEngine:
                     pkg.clock_probe(slots[probes], stream=s_probe.cuda_stream, spin=50000)
                     probes += 1
                 e = torch.cuda.Event()
-                e.record(self.s_dec if self.arrangement == "pipelined" else self.hs[0])
+                e.record(self.s_dec if self.arrangement != "single" else self.hs[0])
                 fences.append(e)
                 if len(fences) > depth // every:
                     fences.pop(0).synchronize()  # the host stays at most `depth` steps ahead of the chip
@@ -608,17 +641,18 @@ def run_rank(args):
     elapsed, total_frames, total_mismatches, _ = D.reduce_report(dist, red_dev, elapsed, frames_per_step * args.steps,
                                                                   mismatches=mismatches, force=rccl_single)
     # the other arrangement (same K steps, its own parity gate) and the sustained leg of the main one: single rank only
-    other, sustained = None, None
+    other, others, sustained = None, [], None
     if world == 1 and not emu:
         if can_pipeline and not args.no_overlap_probe:
-            arr2 = "pipelined" if main_arr == "single" else "single"
-            par2, mism2 = gate(arr2) if not args.no_parity else (None, 0)
-            eng.set_arrangement(arr2)
-            el2, km2, st2 = eng.timed_steps(args.steps, args.warmup, kernel_events=KERNEL_EVENTS_EVERY, marks=True)
-            other = {"arrangement": arr2, "value": frames_per_step * args.steps / el2, "unit": "frames/s", "ms_per_step": el2 / args.steps * 1e3,
-                     "ms_per_step_median": st2[len(st2) // 2] if st2 else None, "kernel_ms": km2, "parity": par2, "parity_mismatches": mism2,
-                     "hip_streams": 2 if arr2 == "pipelined" else 1}
-            total_mismatches += mism2
+            for arr2 in [a for a in ("single", "pipelined", "staggered") if a != main_arr]:
+                par2, mism2 = gate(arr2) if not args.no_parity else (None, 0)
+                eng.set_arrangement(arr2)
+                el2, km2, st2 = eng.timed_steps(args.steps, args.warmup, kernel_events=KERNEL_EVENTS_EVERY, marks=True)
+                others.append({"arrangement": arr2, "value": frames_per_step * args.steps / el2, "unit": "frames/s", "ms_per_step": el2 / args.steps * 1e3,
+                               "ms_per_step_median": st2[len(st2) // 2] if st2 else None, "kernel_ms": km2, "parity": par2, "parity_mismatches": mism2,
+                               "hip_streams": 1 if arr2 == "single" else 2})
+                total_mismatches += mism2
+            other = others[0]  # (the one-stream arrangement unless that is the timed one)
         if args.sustain_seconds > 0:
             eng.set_arrangement(main_arr)
             sustained = eng.sustained(args.sustain_seconds)
@@ -701,7 +735,7 @@ def run_rank(args):
             workload = (f"{total_streams * T}-frame batch mono 48 kHz / 10 ms / 150-byte frames, encode only, streams sharded over "
                         f"{world} GPU(s) (BASELINE configs[2]); {n_distinct} distinct synthetic streams per rank" + (f" tiled to {S}" if n_distinct < S else ""))
             metric = "LC3 frames/sec (encode) @48kHz/10ms"
-        hip_streams = 2 if main_arr == "pipelined" else max(1, args.hip_streams)
+        hip_streams = 2 if main_arr != "single" else max(1, args.hip_streams)
         line = {
             "metric": metric, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -717,14 +751,16 @@ def run_rank(args):
                 "hip_streams": hip_streams, "arrangement": main_arr,
                 "arrangement_note": ("`single`: lc3gpu_encode then lc3gpu_decode of the same batch on ONE caller stream, every call behind the one before "
                                      "it; `pipelined`: the encoder handle on one caller stream, the decoder handle on another, two byte buffers and "
-                                     "events (INTEGRATION.md, recommended caller pattern): the decoder works on step k while the encoder runs step k + 1.  "
+                                     "events (INTEGRATION.md, recommended caller pattern): the decoder works on step k while the encoder runs step k + 1; "
+                                     "`staggered`: the same with three byte buffers and the decoder call of step k queued behind the point where the "
+                                     "encoder call of step k + 1 has only its packer left (lc3gpu_encoder_stage_event): parser beside packer.  "
                                      "`value` is the arrangement named here; the other one is timed in the same run (`other_arrangement`)"),
                 "engine": args.engine,
             },
             "kernel_ms": kernel_ms,
             "kernel_ms_from": f"HIP events around every kernel on every {KERNEL_EVENTS_EVERY}th step of the timed region, on the streams the kernels are "
                               "launched on; per step, summed over a kernel's launches",
-            "roofline": roof, "cpu_baseline": cpu, "other_arrangement": other,
+            "roofline": roof, "cpu_baseline": cpu, "other_arrangement": other, "other_arrangements": others,
             "value_single_stream": (value if main_arr == "single" else (other["value"] if other and other["arrangement"] == "single" else None)),
             "sustained": sustained,
             "parity": parity, "parity_mismatches_all_ranks": total_mismatches,

@@ -234,6 +234,21 @@ int lc3gpu_selftest_math(int which, const float *x, const float *d, int n, float
 int lc3gpu_encoder_timing(lc3gpu_encoder *enc, int enable, double out[5]);
 int lc3gpu_decoder_timing(lc3gpu_decoder *dec, int enable, double out[3]);
 int lc3gpu_decoder_timing_kernels(lc3gpu_decoder *dec, int enable, double out[5]);
+/* Stage events (an extension without a counterpart in the reference: its caller loop, examples/encode.rs:97-115 / examples/decode.rs:93-112,
+ * has no stages to observe).  `hip_event` is a hipEvent_t of the CALLER (NULL clears the slot); from then on every batch call of the handle
+ * records it on the call's stream right behind the kernel(s) of the stage, so that a caller who runs several handles on several HIP streams
+ * can make another stream wait (hipStreamWaitEvent) for a chosen point INSIDE this handle's call -- e.g. start a decoder's parser when the
+ * encoder's back half has ended, beside the encoder's packer (both leave most of the chip's workgroup slots free) instead of beside its
+ * front half (which fills them): bench.py's `staggered` arrangement, INTEGRATION.md section 4.  The event completes no earlier than the
+ * stage; a call that runs as two halves (LC3GPU_SPLIT=1) records every stage event at its end.  The event must stay valid while it is
+ * set.  LC3GPU_EINVAL for an unknown stage. */
+#define LC3GPU_MAX_STAGES 4
+#define LC3GPU_ENC_STAGE_FRONT 0 /* analysis front half done */
+#define LC3GPU_ENC_STAGE_VQ 1    /* ... and the SNS vector quantiser */
+#define LC3GPU_ENC_STAGE_BACK 2  /* ... and the back half: only the packer is left */
+#define LC3GPU_DEC_STAGE_PARSE 0 /* frames parsed and spectra rebuilt: only the synthesis kernel is left */
+int lc3gpu_encoder_stage_event(lc3gpu_encoder *enc, int stage, void *hip_event);
+int lc3gpu_decoder_stage_event(lc3gpu_decoder *dec, int stage, void *hip_event);
 /* diagnostic build (liblc3gpu_prof.so, -DLC3_PROFILE) only: per-stage shader-clock cycle sums since the last call.
  * slots 1..9 = encoder stages (mdct, bw+attack, sns, tns, ltpf, quant, residual+noise, bitstream, store),
  * slots 17..25 = decoder stages (names in tools/stage_profile.py); 32/33/34 = encoder whole-wave time sum / max / waves,

@@ -8,6 +8,10 @@ CPU fallback: constructing a codec without the native library or without a GPU
 raises.  The directory name contains '-', import it with
 importlib.import_module("lc3-codec_amd")."""
 from .api import (  # noqa: F401
+    DEC_STAGE_PARSE,
+    ENC_STAGE_BACK,
+    ENC_STAGE_FRONT,
+    ENC_STAGE_VQ,
     FrameDuration,
     Lc3Config,
     Lc3Decoder,

@@ -159,6 +159,8 @@ def load_library():
     L.lc3gpu_decoder_synth_debug.argtypes = [vp, i, vp, i, i, i, i, vp, i, vp]
     L.lc3gpu_selftest_math.argtypes = [i, vp, vp, i, vp]
     L.lc3gpu_clock_probe.argtypes = [vp, vp, i]
+    L.lc3gpu_encoder_stage_event.argtypes = [vp, i, vp]
+    L.lc3gpu_decoder_stage_event.argtypes = [vp, i, vp]
     _lib = L
     return L
 
@@ -174,12 +176,26 @@ ABI_SYMBOLS = [
     "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info", "lc3gpu_prof_read", "lc3gpu_encoder_timing", "lc3gpu_decoder_timing",
     "lc3gpu_decoder_timing_kernels", "lc3gpu_decode_frame_debug", "lc3gpu_decoder_synth_debug", "lc3gpu_selftest_math", "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
     "lc3gpu_decode_mixed", "lc3gpu_encoder_create_spec", "lc3gpu_encoder_create_mixed_spec", "lc3gpu_clock_probe",
+    "lc3gpu_encoder_stage_event", "lc3gpu_decoder_stage_event",
 ]
 
 # LC3GPU_SPEC_*: opt-in corrections of the reference's deviations from the LC3 specification (default 0 = reference behaviour)
 SPEC_8KHZ_ENCODE, SPEC_TNS_SSWB_STOP, SPEC_BW_CUTOFF_DB, SPEC_SNS_LAST_GAIN, SPEC_NBITS_SPEC_OLD, SPEC_ALL = 1, 2, 4, 8, 16, 31
 
 LAYOUT_PLANAR, LAYOUT_INTERLEAVED = 0, 1
+# stage events (LC3GPU_ENC_STAGE_* / LC3GPU_DEC_STAGE_*)
+ENC_STAGE_FRONT, ENC_STAGE_VQ, ENC_STAGE_BACK, DEC_STAGE_PARSE = 0, 1, 2, 0
+
+
+def _event_handle(event):
+    """a hipEvent_t as an integer: None, an integer, or an object with `cuda_event` (torch.cuda.Event -- record it once before passing it:
+    torch creates the HIP event lazily)"""
+    if event is None:
+        return None
+    h = getattr(event, "cuda_event", event)
+    if not h:
+        raise ValueError("the event has no HIP handle yet (torch.cuda.Event: record it once first)")
+    return ctypes.c_void_p(int(h))
 # stage dumps of Lc3Decoder.decode_frame_debug / synth_debug (LC3GPU_DBG_*)
 DBG_INT, DBG_SPEC, DBG_IMDCT, DBG_LTPF, DBG_GAIN, DBG_TNS, DBG_FLOATS = 0, 400, 800, 1280, 1760, 2160, 2560
 RECON_LANE, RECON_LATE, RECON_WAVE = 0, 1, 2
@@ -345,6 +361,14 @@ class Lc3Encoder:
         if rc:
             raise Lc3EncoderError(rc, "encode")
 
+    def stage_event(self, stage, event):
+        """every batch call from now on records `event` (the caller's; None clears) behind the kernels of `stage` (ENC_STAGE_*)"""
+        rc = self._L.lc3gpu_encoder_stage_event(self._h, int(stage), _event_handle(event))
+        if rc:
+            raise Lc3EncoderError(rc, "stage_event")
+        self._stage_events = getattr(self, "_stage_events", {})
+        self._stage_events[int(stage)] = event  # keeps the event alive while it is set
+
     def timing(self, enable=True):
         """-> (front ms, vector-quantiser ms, back ms, pack ms, batch calls) since the last call; (re)arms recording (enable = n > 1: every n-th batch call)"""
         out = (ctypes.c_double * 5)()
@@ -453,6 +477,14 @@ class Lc3Decoder:
                                              _ptr(d_bad_frame), _ptr(d_pcm), int(nbytes), int(n_frames), _ptr(stream))
         if rc:
             raise Lc3DecoderError(rc, "decode")
+
+    def stage_event(self, stage, event):
+        """every batch call from now on records `event` (the caller's; None clears) behind the kernels of `stage` (DEC_STAGE_PARSE)"""
+        rc = self._L.lc3gpu_decoder_stage_event(self._h, int(stage), _event_handle(event))
+        if rc:
+            raise Lc3DecoderError(rc, "stage_event")
+        self._stage_events = getattr(self, "_stage_events", {})
+        self._stage_events[int(stage)] = event
 
     def timing(self, enable=True):
         """-> (parse-kernel ms, synthesis-kernel ms, batch calls) since the last call; (re)arms recording (enable = n > 1: every n-th batch call)"""

@@ -76,6 +76,9 @@
         LC3_SYNC();    \
     }
 #endif
+#ifndef LC3_SERIAL_WIDE_BEGIN  // the same for K up to 64 lanes per stream (the HIP kernels spread 4 K lanes over more than one wave)
+#define LC3_SERIAL_WIDE_BEGIN(T, L, lane, phase, K) LC3_SERIAL_BEGIN(T, L, lane, phase, K)
+#endif
 
 // The same bracket without the gathering: lanes 0..K-1 of the stream's own wave run the block (for serial work whose
 // duration differs a lot from stream to stream, where waiting for the slowest stream of the workgroup costs more than

@@ -1057,16 +1057,20 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         const float v = x6[n];
         sq[n] = v * v;
     }
-    LC3_SYNC();
-    float nv = 0.0f;
-    if (lane < 3) {
-        const int lag = lane == 0 ? 0 : (lane == 1 ? lag_t1 : lag_t2);
-        const int from = LC3_KMAX - lag;
-        nv = lc3_sum_seq(sq + from, len6, 0.0f);
+    // The three sums are serial and equally long for every stream: the four streams of the workgroup run them on twelve lanes of one wave
+    // (LC3_SERIAL_BEGIN: inside, `L` is the lane's stream; what the block needs travels through the stream's LDS)
+    if (lane == 0) {
+        L.ism[8] = lag_t1;
+        L.ism[9] = lag_t2;
     }
+    LC3_SERIAL_BEGIN(lc3_enc_lds, L, lane, ltpf_phase + 1, 3)
+        const float *sq_ = (const float *)L.fb + 224;
+        const int lag = sub == 0 ? 0 : L.ism[8 + sub - 1];
+        L.sm[8 + sub] = lc3_sum_seq(sq_ + (LC3_KMAX - lag), len6, 0.0f);
+    LC3_SERIAL_END
     int t_current, pitch_present;
-    {   // the three sums sit on lanes 0..2: read across the wave, the decision is then the same scalar code on every lane
-        const float nv0 = lc3_wave_read_f32(nv, 0, lane), nv1 = lc3_wave_read_f32(nv, 1, lane), nv2 = lc3_wave_read_f32(nv, 2, lane);
+    {   // the decision is then the same scalar code on every lane
+        const float nv0 = L.sm[8], nv1 = L.sm[9], nv2 = L.sm[10];
         float normcorr1 = lc3_maxf(0.0f, r6[lag_t1 - LC3_KMIN] / lc3_sqrtf(nv0 * nv1));
         float normcorr2 = lag_t1 == lag_t2 ? normcorr1 : lc3_maxf(0.0f, r6[lag_t2 - LC3_KMIN] / lc3_sqrtf(nv0 * nv2));
         if (normcorr2 > 0.85f * normcorr1) {
@@ -1081,15 +1085,18 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     // pitch_lag_parameter :292-363
     const int k_min = 2 * t_current - 4 > 32 ? 2 * t_current - 4 : 32;
     const int k_max = 2 * t_current + 4 < 228 ? 2 * t_current + 4 : 228;
-    {
-        const int nk = (k_max + 4) - (k_min - 4) + 1;  // <= 17
-        if (lane < nk) {
-            const int k = k_min - 4 + lane;
-            const float acc = lc3_dot_seq(x12 + LC3_NMEM, x12 + LC3_NMEM - k, len12, 0.0f);  // len12 is a multiple of 8
-            r12[lane] = acc;
-        }
+    // <= 17 correlations of len12 terms each, a lane per lag: the workgroup's 4 x 17 lanes on one wave and four lanes of the next
+    if (lane == 0) {
+        L.ism[10] = k_min - 4;
+        L.ism[11] = (k_max + 4) - (k_min - 4) + 1;  // <= 17
     }
-    LC3_SYNC();
+    LC3_SERIAL_WIDE_BEGIN(lc3_enc_lds, L, lane, ltpf_phase + 2, 17)
+        if (sub < L.ism[11]) {
+            const float *x12_ = (const float *)L.fa + 64;
+            const int k = L.ism[10] + sub;
+            ((float *)L.fb)[200 + sub] = lc3_dot_seq(x12_ + LC3_NMEM, x12_ + LC3_NMEM - k, len12, 0.0f);  // len12 is a multiple of 8
+        }
+    LC3_SERIAL_END
     LC3_STAMP(L, lane, 17);
     // Integer lag = first maximum above zero of the <= 9 in-range correlations (:303-313), then the fractional part = first
     // maximum above zero of up to seven interpolated values (:315-345, interpolate :457-469).  Both scans run wave-parallel
@@ -1188,16 +1195,13 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
             S[256 + n] = b * b;
         }
     }
-    LC3_SYNC();
-    float acc3 = 0.0f;
-    if (lane < 3) {
-        // lane 0: sum dA*dB, lane 1: sum dA*dA, lane 2: sum dB*dB
-        const float *pp = S + 128 * lane;
-        acc3 = lc3_sum_seq(pp, len12, 0.0f);
-    }
+    // sub 0: sum dA*dB, 1: sum dA*dA, 2: sum dB*dB -- twelve lanes of one wave for the workgroup's four streams
+    LC3_SERIAL_BEGIN(lc3_enc_lds, L, lane, ltpf_phase + 3, 3)
+        L.sm[12 + sub] = lc3_sum_seq((const float *)L.fb + 128 * sub, len12, 0.0f);
+    LC3_SERIAL_END
     int ltpf_active = 0;
     {
-        const float num = lc3_wave_read_f32(acc3, 0, lane), nd = lc3_wave_read_f32(acc3, 1, lane), sh = lc3_wave_read_f32(acc3, 2, lane);
+        const float num = L.sm[12], nd = L.sm[13], sh = L.sm[14];
         const float den = lc3_sqrtf(nd * sh);
         float nc = den > 0.0f ? num / den : 0.0f;
         const float pitch = (float)pitch_int + (float)pitch_fr / 4.0f;

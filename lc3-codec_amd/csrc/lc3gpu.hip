@@ -52,6 +52,13 @@
 #ifndef LC3_SYNTH_WAVES
 #define LC3_SYNTH_WAVES 4
 #endif
+// Wave priority of the lane-per-frame kernels (s_setprio 0..3).  Their waves walk one dependent chain per lane and leave most issue
+// slots empty; beside another handle's wave-per-stream kernels (the two-stream arrangement) a raised priority lets them keep their own
+// pace -- and leave the compute unit sooner -- while the other kernel's waves take the slots in between.
+#ifndef LC3_LANE_PRIO
+#define LC3_LANE_PRIO 0
+#endif
+#define LC3_LANE_KERNEL_BEGIN() do { if (LC3_LANE_PRIO) __builtin_amdgcn_s_setprio(LC3_LANE_PRIO); } while (0)
 #ifndef LC3_SPEC_IN_LDS
 #define LC3_SPEC_IN_LDS 1
 #endif
@@ -83,6 +90,17 @@ __shared__ lc3_spec_tables lc3_spec_tab;
         }              \
         __syncthreads(); \
     }
+// The same for blocks of up to 64 lanes per stream (K x streams beyond one wave): virtual lane v = lane + 64 j runs on the j-th wave after
+// wave `phase`, stream v / K, sub = v % K.  (K = 17: wave `phase` carries 64 of the workgroup's 68 lanes, the next one 4.)
+#define LC3_SERIAL_WIDE_BEGIN(T, L, lane, phase, K)                                                           \
+    {                                                                                                         \
+        T *lc3_wg_base_ = &(L) - LC3_WAVE_ID();                                                               \
+        __syncthreads();                                                                                      \
+        const int lc3_v_ = (lane) + 64 * ((LC3_WAVE_ID() + LC3_WG_WAVES - ((phase) % LC3_WG_WAVES)) % LC3_WG_WAVES); \
+        if (lc3_v_ < LC3_WG_WAVES * (K)) {                                                                    \
+            T &L = lc3_wg_base_[lc3_v_ / (K)];                                                                \
+            const int sub = lc3_v_ % (K);                                                                     \
+            (void)sub;
 #define LC3_HBM_CONST(T) const __attribute__((address_space(1))) T *
 #define LC3_HBM(T) __attribute__((address_space(1))) T *
 #define LC3_UNIFORM_I32(x) __builtin_amdgcn_readfirstlane((int)(x))
@@ -506,6 +524,7 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_FRONT_WAVES) void lc3_enc_fr
 
 // SNS vector quantiser, one LANE per frame (lc3_dev_enc_vq.h): 16 targets -> indices (packer plane) + 64 band gains.
 __device__ __forceinline__ void lc3_sns_vq_body(unsigned wg, int nb, float *mid, int32_t *planes, int n_frames, int spec_flags) {
+    LC3_LANE_KERNEL_BEGIN();
     __shared__ uint32_t s_mpvq[16 * 11];
     for (int i = threadIdx.x; i < 16 * 11; i += blockDim.x) s_mpvq[i] = LC3T_MPVQ_OFFSETS[i / 11][i % 11];
     __syncthreads();
@@ -593,6 +612,7 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_bac
 #define LC3_PACK_LDS_FIXED (4096 + 64 * 17 * 4 + LC3_TNS_MODEL_WORDS * 4)
 __device__ __forceinline__ void lc3_pack_body(unsigned wg, int ne, const int32_t *planes, uint8_t *out, int nbytes, int n_frames,
                                               int T, int first_channel, lc3_io io) {
+    LC3_LANE_KERNEL_BEGIN();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_lookup = smem;
     uint32_t *s_cf = (uint32_t *)(smem + 4096);
@@ -694,6 +714,7 @@ static __host__ __device__ inline size_t lc3_pack_pc_lds(unsigned fpb, int nbyte
 }
 __device__ __forceinline__ void lc3_pack_pc_body(unsigned wg, int ne, const int32_t *planes, uint8_t *out, int nbytes, int n_frames, int T,
                                                  int first_channel, lc3_io io) {
+    LC3_LANE_KERNEL_BEGIN();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_lookup = smem;
     uint32_t *s_cf = (uint32_t *)(smem + 4096);
@@ -801,6 +822,7 @@ template <class CV>
 __device__ __forceinline__ void lc3_parse_body(lc3_cfg_slot<CV> cfg, unsigned wg, const uint8_t *in, const uint8_t *bad,
                                                int32_t *planes, int nbytes, int n_frames, int T, int first_channel, lc3_io io, int late,
                                                float *dbg = nullptr) {
+    LC3_LANE_KERNEL_BEGIN();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const int ne = c0.ne, fs_ind = c0.fs_ind, n_ms_10 = c0.n_ms_10;
@@ -921,6 +943,7 @@ static __host__ __device__ inline size_t lc3_parse_pc_lds(unsigned fpb, int nbyt
 template <class CV>
 __device__ __forceinline__ void lc3_parse_pc_body(lc3_cfg_slot<CV> cfg, unsigned wg, const uint8_t *in, const uint8_t *bad, int32_t *planes,
                                                   int nbytes, int n_frames, int T, int first_channel, lc3_io io) {
+    LC3_LANE_KERNEL_BEGIN();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const int ne = c0.ne, fs_ind = c0.fs_ind, n_ms_10 = c0.n_ms_10;
@@ -1324,6 +1347,16 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
             return LC3GPU_EHIP;                       \
         }                                             \
     } while (0)
+// a stage event of the caller behind the kernel just queued (mixed handles; the uniform ones: encode_kernels / decode_kernels)
+#define LC3_STAGE_RECORD(h, stage, stream, t0)        \
+    do {                                              \
+        const int rc_ = (h)->stage_record(stage, stream); \
+        if (rc_) {                                    \
+            (h)->timer.rollback(t0);                  \
+            (void)(h)->order_end(stream);             \
+            return rc_;                               \
+        }                                             \
+    } while (0)
 struct KernelTimer {
     bool enabled = false;
     std::vector<hipEvent_t> pool;  // every event ever created for this handle
@@ -1453,6 +1486,25 @@ struct HandleCommon {
     hipStream_t sub[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_stage = nullptr, ev_join[2] = {nullptr, nullptr};
     bool last_split = false;  // the handle's latest work ended on the internal streams (ev_join), not on last_stream (done)
+    // Stage events (lc3gpu_*_stage_event): events of the CALLER, recorded behind a stage's kernel(s) of every batch call, so that a caller
+    // with several handles on several HIP streams can start another handle's work beside a chosen part of this one's
+    hipEvent_t stage_ev[LC3GPU_MAX_STAGES] = {};
+    int stage_record(int stage, hipStream_t s) {  // (chain 0 only: the split path records every stage at its join)
+        if (stage_ev[stage]) HIP_TRY(hipEventRecord(stage_ev[stage], s));
+        return LC3GPU_OK;
+    }
+    int stage_record_all(hipStream_t s) {
+        for (int i = 0; i < LC3GPU_MAX_STAGES; i++) {
+            const int rc = stage_record(i, s);
+            if (rc) return rc;
+        }
+        return LC3GPU_OK;
+    }
+    int stage_set(int stage, void *ev) {
+        if (stage < 0 || stage >= LC3GPU_MAX_STAGES) return LC3GPU_EINVAL;
+        stage_ev[stage] = (hipEvent_t)ev;
+        return LC3GPU_OK;
+    }
 
     // A handle's launches share its scratch planes and its state blobs: a call on another stream than the previous one waits for
     // everything the handle has queued so far.  What stands for "so far" is an event the HANDLE owns, recorded when the work was
@@ -1746,8 +1798,13 @@ static int lc3_pack_pc_optin() {
     done[dev] = true;
     return LC3GPU_OK;
 }
+// Frames per workgroup of the pair kernels: 128 (four waves, one per SIMD; ~40 KB of LDS at 150-byte frames).  Such a workgroup takes
+// the place of exactly ONE workgroup of a wave-per-stream kernel (40 KB, a wave per SIMD) when another handle's call runs beside it on
+// another HIP stream; with 256 frames (70 KB, two waves per SIMD) it displaced two for as long as it ran.  Measured: two-stream
+// arrangement 48.9 -> 50.3 M frames/s, one stream 46.0 -> 45.9 M (parse 0.281 -> 0.287, pack 0.163 -> 0.159 ms alone;
+// profiles/r04_pair_workgroup_size.txt)
 static unsigned lc3_pack_pc_fpb(int nbytes) {
-    unsigned fpb = lc3_frame_block(256u);
+    unsigned fpb = lc3_frame_block(128u);
     while (fpb > 64u && lc3_pack_pc_lds(fpb, nbytes) > (size_t)(160 * 1024)) fpb >>= 1;
     return fpb;
 }
@@ -1779,7 +1836,7 @@ static int lc3_parse_pc_optin() {
     return LC3GPU_OK;
 }
 static unsigned lc3_parse_pc_fpb(int nbytes) {
-    unsigned fpb = lc3_frame_block(256u);
+    unsigned fpb = lc3_frame_block(128u);  // (see lc3_pack_pc_fpb)
     while (fpb > 64u && lc3_parse_pc_lds(fpb, nbytes) > (size_t)LC3_PC_LDS_MAX) fpb >>= 1;
     return fpb;
 }
@@ -2106,20 +2163,24 @@ static int encode_kernels(lc3gpu_encoder *e, const HostCfg &h, int first, int n,
     // analysis front half (wave per stream) -> SNS vector quantiser (lane per frame) -> back half (wave per stream) ->
     // bitstream packing (lane per frame)
     const dim3 wg_grid((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), wg_block(64 * LC3_WG_WAVES);
+    int rc_stage = 0;
     e->timer.mark(stream, -1, chain);
     LC3_LAUNCH_CFG(lc3_enc_front_kernel, h, wg_grid, wg_block, lc3_lds_pad(0), stream, e->d_states, first, n, d_pcm, mid, planes, nbytes, n_frames, fresh,
                    dbg, io, e->spec_flags);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream, 0, chain);
     if (after_front) HIP_TRY(hipEventRecord(after_front, stream));
+    if (chain == 0 && (rc_stage = e->stage_record(LC3GPU_ENC_STAGE_FRONT, stream)) != 0) return rc_stage;
     hipLaunchKernelGGL(lc3_sns_vq_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, stream, h.c.nb, mid, planes, (int)frames,
                        e->spec_flags);
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream, 1, chain);
+    if (chain == 0 && (rc_stage = e->stage_record(LC3GPU_ENC_STAGE_VQ, stream)) != 0) return rc_stage;
     LC3_LAUNCH_CFG(lc3_enc_back_kernel, h, wg_grid, wg_block, lc3_lds_pad(1), stream, e->d_states, first, n, (const float *)mid, planes, nbytes, n_frames,
                    dbg, e->spec_flags | lc3_prep_symbols_flag(frames_of_call));
     HIP_TRY(hipGetLastError());
     e->timer.mark(stream, 2, chain);
+    if (chain == 0 && (rc_stage = e->stage_record(LC3GPU_ENC_STAGE_BACK, stream)) != 0) return rc_stage;
     if (lc3_prep_symbols_mode(frames_of_call) == 2) {  // (timed together with the packer)
         const size_t wgs = (frames + LC3_WG_WAVES - 1) / LC3_WG_WAVES;
         LC3_LAUNCH_CFG(lc3_symbols_kernel, h, dim3((unsigned)(wgs < lc3_recon_grid() ? wgs : lc3_recon_grid())), dim3(64 * LC3_WG_WAVES), 0, stream,
@@ -2203,6 +2264,7 @@ static int encode_launch(lc3gpu_encoder *e, const HostCfg &h, int first, int n, 
                 g_last_hip = (int)hipGetLastError();
                 if (rc == LC3GPU_OK) rc = LC3GPU_EHIP;
             }
+        if (rc == LC3GPU_OK) rc = e->stage_record_all(stream);
     }
     if (rc) {
         e->timer.rollback(t0);
@@ -2262,6 +2324,7 @@ int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out,
                        e->d_planes, n_frames, fresh, io, e->spec_flags);
     LC3_LAUNCH_CHECK(e, stream, t0);
     e->timer.mark(stream, 0);
+    LC3_STAGE_RECORD(e, LC3GPU_ENC_STAGE_FRONT, stream, t0);
     lc3_groups G256;  // the vector quantiser runs 256 frames per workgroup
     {
         unsigned a, b;
@@ -2272,10 +2335,12 @@ int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out,
         LC3_LAUNCH_CHECK(e, stream, t0);
     }
     e->timer.mark(stream, 1);
+    LC3_STAGE_RECORD(e, LC3GPU_ENC_STAGE_VQ, stream, t0);
     hipLaunchKernelGGL(lc3_enc_back_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states,
                        (const float *)e->d_mid, e->d_planes, n_frames, e->spec_flags | lc3_prep_symbols_flag((size_t)e->num_channels * (size_t)n_frames, true));
     LC3_LAUNCH_CHECK(e, stream, t0);
     e->timer.mark(stream, 2);
+    LC3_STAGE_RECORD(e, LC3GPU_ENC_STAGE_BACK, stream, t0);
     const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)max_nbytes + 3) & ~(size_t)3) + 4;
     hipLaunchKernelGGL(lc3_pack_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, (const int32_t *)e->d_planes, d_out, n_frames, io);
     LC3_LAUNCH_CHECK(e, stream, t0);
@@ -2455,6 +2520,10 @@ static int decode_kernels(lc3gpu_decoder *d, const HostCfg &h, int first, int n,
         HIP_TRY(hipGetLastError());
         d->timer.mark(stream, 2, chain);
     }
+    if (chain == 0) {
+        const int rc_stage = d->stage_record(LC3GPU_DEC_STAGE_PARSE, stream);
+        if (rc_stage) return rc_stage;
+    }
     if (mode == LC3_RECON_LATE)
         LC3_LAUNCH_CFG(lc3_decode_late_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0,
                        stream, d->d_states, first, n, (const int32_t *)planes, d_pcm, nbytes, n_frames, 0, io);
@@ -2509,6 +2578,7 @@ static int decode_launch(lc3gpu_decoder *d, const HostCfg &h, int first, int n, 
                 g_last_hip = (int)hipGetLastError();
                 if (rc == LC3GPU_OK) rc = LC3GPU_EHIP;
             }
+        if (rc == LC3GPU_OK) rc = d->stage_record_all(stream);
     }
     if (rc) {
         d->timer.rollback(t0);
@@ -2580,6 +2650,7 @@ int lc3gpu_decode_mixed(lc3gpu_decoder *d, const uint8_t *d_in, const uint8_t *d
         LC3_LAUNCH_CHECK(d, stream, t0);
         d->timer.mark(stream, 2);
     }
+    LC3_STAGE_RECORD(d, LC3GPU_DEC_STAGE_PARSE, stream, t0);
     if (mode == LC3_RECON_LATE)
         hipLaunchKernelGGL(lc3_decode_mixed_late_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, d->d_states,
                            (const int32_t *)d->d_planes, d_pcm, n_frames, 0, io);
@@ -2847,6 +2918,15 @@ __global__ void lc3_clock_probe_kernel(unsigned long long *out, int spin) {
     if (v == 0x12345u && spin < 0) out[2] = v;  // (keeps the loop)
 }
 // asynchronous on `stream`: d_out (DEVICE, 2 x uint64) <- {shader cycles, 100 MHz ticks} over the probe's spin (~0.1 ms at spin = 50 000)
+int lc3gpu_encoder_stage_event(lc3gpu_encoder *e, int stage, void *hip_event) {
+    if (!e || stage > LC3GPU_ENC_STAGE_BACK) return LC3GPU_EINVAL;
+    return e->stage_set(stage, hip_event);
+}
+int lc3gpu_decoder_stage_event(lc3gpu_decoder *d, int stage, void *hip_event) {
+    if (!d || stage > LC3GPU_DEC_STAGE_PARSE) return LC3GPU_EINVAL;
+    return d->stage_set(stage, hip_event);
+}
+
 int lc3gpu_clock_probe(void *stream, unsigned long long *d_out, int spin) {
     if (!d_out || spin <= 0) return LC3GPU_EINVAL;
     hipLaunchKernelGGL(lc3_clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_out, spin);

@@ -38,6 +38,16 @@ static thread_local int tl_wave = 0;
         }                                \
         pthread_barrier_wait(&g_wg_bar); \
     }
+// (K x streams beyond one wave: virtual lane v = lane + 64 j on the j-th wave after wave `phase`, as in lc3gpu.hip)
+#define LC3_SERIAL_WIDE_BEGIN(T, L, lane, phase, K)                                                               \
+    {                                                                                                             \
+        T *lc3_wg_base_ = &(L) - tl_wave;                                                                         \
+        pthread_barrier_wait(&g_wg_bar);                                                                          \
+        const int lc3_v_ = (lane) + 64 * ((tl_wave + LC3_WG_WAVES - ((phase) % LC3_WG_WAVES)) % LC3_WG_WAVES);    \
+        if (lc3_v_ < LC3_WG_WAVES * (K)) {                                                                        \
+            T &L = lc3_wg_base_[lc3_v_ / (K)];                                                                    \
+            const int sub = lc3_v_ % (K);                                                                         \
+            (void)sub;
 // every decision the device code takes from a guarded tree sum is checked against the sequential sum here
 #define LC3_GUARD_SELFCHECK 1
 #define LC3_GUARD_ASSERT(cond)                                                                         \

@@ -148,6 +148,33 @@ def _roundtrip_check(fs, us, nbytes, S, T, seed=synth.SEED):
     assert diff == 0, f"PCM not exact: max |diff| = {diff}"
 
 
+
+def _mixed_bandwidth_check(nbytes=150, S=80, T=6, seed=95):
+    """A 48 kHz batch whose neighbouring streams stop at different cut-offs (3.5 / 7.5 / 11.5 / 15.5 kHz / full band), so that the lanes of
+    one lane-per-frame wave (a wave holds 64 / T streams' frames) carry different bandwidth indices and TNS band layouts: the per-lane
+    divergent paths of lc3_tns_lattice4 / lc3_tns_lane_frame.  Both directions against the oracle; returns the bandwidth indices met."""
+    cuts = (3500.0, 7500.0, 11500.0, 15500.0, None)
+    parts = [synth.make_bandlimited_pcm(S, T, 480, 48000, c, seed=seed + i) if c else synth.make_pcm(S, T, 480, 48000, seed=seed + i)
+             for i, c in enumerate(cuts)]
+    pcm = np.empty((S, T, 480), np.int16)
+    for s in range(S):
+        pcm[s] = parts[s % len(cuts)][s]
+    ref_bytes = O.encode_batch(pcm, nbytes, 48000, 10000, threads=8)
+    got_bytes = gpu_encode(pcm, nbytes, 48000, 10000)
+    assert np.array_equal(got_bytes, ref_bytes)
+    ref_pcm = O.decode_batch(ref_bytes, 480, 48000, 10000, threads=8)
+    got_pcm = gpu_decode(ref_bytes, 480, 48000, 10000)
+    assert np.array_equal(got_pcm, ref_pcm)
+    # the bandwidth index is the last byte's low three bits at 48 kHz (write_bandwidth: bitstream_encoding.rs, read side side_info.rs)
+    return sorted(set((ref_bytes[:, :, -1] & 7).reshape(-1).tolist()))
+
+
+def test_lanes_of_a_wave_with_different_bandwidths():
+    """default forms; the forced forms run the same check in test_late_reconstruction_on_and_off"""
+    seen = _mixed_bandwidth_check()
+    assert len(seen) >= 4, seen
+
+
 def test_batch_48k_10ms_150B():  # BASELINE config shape, 2048 frames with carried state
     _roundtrip_check(48000, 10000, 150, 256, 8)
 
@@ -1006,6 +1033,8 @@ def test_late_reconstruction_on_and_off():
         "t.test_mixed_batch_bad_frames_and_plc_counter()\n"
         "t.test_ltpf_transitions(48000, 10000, 40)\n"
         "t.test_ltpf_transitions(16000, 10000, 40)\n"
+        "assert len(t._mixed_bandwidth_check()) >= 4\n"
+        "assert len(t._mixed_bandwidth_check(nbytes=60, S=70, T=3, seed=96)) >= 3\n"
         "print('late ok')\n"
     )
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1136,7 +1165,7 @@ def test_rccl_world_size_one():
     assert abs(line["value"] - 1024 * 4 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
 
 
-def test_both_caller_arrangements_pass_their_parity_gate():
+def test_every_caller_arrangement_passes_its_parity_gate():
     """bench.py times two ways of queueing the same steps -- encode then decode on ONE caller stream, and the recommended pattern
     (INTEGRATION.md): encoder handle on one stream, decoder handle on another, two byte buffers, events -- and runs its parity gate on
     each (two steps from fresh state, the second against the oracle).  Here on a batch that takes the split path inside the calls."""
@@ -1146,9 +1175,73 @@ def test_both_caller_arrangements_pass_their_parity_gate():
     assert line["parity"]["arrangement"] == "pipelined" and line["parity"]["bitstream_exact"] and line["parity"]["pcm_max_abs_diff"] == 0
     o = line["other_arrangement"]
     assert o["arrangement"] == "single" and o["parity"]["bitstream_exact"] and o["parity"]["pcm_max_abs_diff"] == 0
+    # ... and the third one: like `pipelined`, the decoder call queued behind the encoder's LC3GPU_ENC_STAGE_BACK event of the NEXT step
+    g = [a for a in line["other_arrangements"] if a["arrangement"] == "staggered"]
+    assert len(g) == 1 and g[0]["parity"]["bitstream_exact"] and g[0]["parity"]["pcm_max_abs_diff"] == 0 and g[0]["hip_streams"] == 2
     assert line["parity_mismatches_all_ranks"] == 0
     s = line["sustained"]
     assert s["steps"] > 0 and s["shader_clock_MHz"]["probes"] > 0 and 500.0 < s["shader_clock_MHz"]["median"] < 3000.0, s
+
+
+def test_stage_events_order_another_stream_inside_a_call():
+    """lc3gpu_encoder_stage_event / lc3gpu_decoder_stage_event: the caller's event is recorded behind the stage's kernels of every batch
+    call.  A second stream that waits for the encoder's BACK event and then overwrites the PCM input must not disturb the call (the
+    front half -- the only reader of the PCM -- has ended by then); the decoder's PARSE event likewise guards its byte input.  Unknown
+    stages are rejected; a cleared slot records nothing."""
+    t = torch_mod()
+    S, T = 256, 4
+    pcm = synth.make_pcm(S, T, 480, 48000, seed=77)
+    ref = O.encode_batch(pcm, 150)
+    ref_pcm = O.decode_batch(ref, 480)
+    enc, dec = pkg.Lc3Encoder(S, US, FS), pkg.Lc3Decoder(S, US, FS)
+    s0, s1 = t.cuda.Stream(), t.cuda.Stream()
+    ev_f, ev_b, ev_p = t.cuda.Event(), t.cuda.Event(), t.cuda.Event()
+    with pytest.raises(ValueError):
+        enc.stage_event(pkg.ENC_STAGE_BACK, ev_b)  # torch has not created the HIP event yet
+    for e in (ev_f, ev_b, ev_p):
+        e.record(s0)
+    with pytest.raises(pkg.Lc3EncoderError):
+        enc.stage_event(3, ev_b)
+    with pytest.raises(pkg.Lc3DecoderError):
+        dec.stage_event(1, ev_p)
+    enc.stage_event(pkg.ENC_STAGE_FRONT, ev_f)
+    enc.stage_event(pkg.ENC_STAGE_BACK, ev_b)
+    dec.stage_event(pkg.DEC_STAGE_PARSE, ev_p)
+    d_pcm = t.from_numpy(pcm).cuda()
+    d_bytes = t.zeros((S, T, 150), dtype=t.uint8, device="cuda")
+    d_out = t.zeros((S, T, 480), dtype=t.int16, device="cuda")
+    t.cuda.synchronize()
+    for rep in range(3):
+        d_pcm.copy_(t.from_numpy(pcm))
+        t.cuda.synchronize()
+        enc.reset()
+        dec.reset()
+        enc.encode(d_pcm, d_bytes, 150, T, stream=s0.cuda_stream)
+        s1.wait_event(ev_f if rep == 1 else ev_b)
+        with t.cuda.stream(s1):
+            d_pcm.zero_()                      # legal once the front half is through
+        s0.synchronize()
+        s1.synchronize()
+        assert np.array_equal(d_bytes.cpu().numpy(), ref), rep
+        d_in = d_bytes.clone()
+        t.cuda.synchronize()
+        dec.decode(d_in, d_out, 150, T, stream=s0.cuda_stream)
+        s1.wait_event(ev_p)
+        with t.cuda.stream(s1):
+            d_in.fill_(255)                    # legal once the parser is through
+        s0.synchronize()
+        s1.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), ref_pcm), rep
+    assert ev_f.query() and ev_b.query() and ev_p.query()
+    # cleared: the events are not touched again
+    enc.stage_event(pkg.ENC_STAGE_FRONT, None)
+    enc.stage_event(pkg.ENC_STAGE_BACK, None)
+    dec.stage_event(pkg.DEC_STAGE_PARSE, None)
+    d_pcm.copy_(t.from_numpy(pcm))
+    enc.reset()
+    enc.encode(d_pcm, d_bytes, 150, T, stream=s0.cuda_stream)
+    s0.synchronize()
+    assert np.array_equal(d_bytes.cpu().numpy(), ref)
 
 
 # ---------------------------------------------------------------- decoder stages on the device against the reference's stage goldens
