@@ -294,7 +294,10 @@ class GpuEngine:
         self.k = 0
         self.pending = None
         if mode == "roundtrip" and NP == 1:
-            self.s_enc, self.s_dec = torch.cuda.current_stream(), torch.cuda.Stream()
+            # (LC3_BENCH_PRIO=enc|dec: that handle's stream gets the higher HIP stream priority -- a measurement aid)
+            prio = os.environ.get("LC3_BENCH_PRIO", "")
+            self.s_enc = torch.cuda.Stream(priority=-1) if prio == "enc" else torch.cuda.current_stream()
+            self.s_dec = torch.cuda.Stream(priority=-1 if prio == "dec" else 0)
             self.bufs = [self.d_bytes, torch.zeros_like(self.d_bytes), torch.zeros_like(self.d_bytes)]
             self.enc_done = [torch.cuda.Event() for _ in range(3)]
             self.dec_done = [torch.cuda.Event() for _ in range(3)]

@@ -1254,6 +1254,11 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     LC3_SYNC();
     return res;
 }
+// the same as a function of its own (a kernel that carries several configuration views: lc3_enc_front_mixed_kernel)
+LC3_CFG_TEMPLATE __device__ __noinline__ lc3_ltpf_res lc3_enc_ltpf_call(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int near_nyquist,
+                                                                   int nbits, lc3_enc_state *g, int store, int ltpf_phase) {
+    return lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, store, ltpf_phase);
+}
 
 // ------------------------------------------------------------------------------------------
 // E17: spectral quantisation (encoder/spectral_quantization.rs:75-395)
@@ -1803,7 +1808,7 @@ __device__ __forceinline__ void lc3_enc_symbols_frame(int ne, int lane, int32_t 
 LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const int16_t *pcm,
                                                       const int16_t *hist, lc3_enc_state *g, float *mid, int32_t *plane,
                                                       int plane_stride, int nbytes, float *dbg, int stride = 1, int hstride = 1,
-                                                      int phase = 0) {
+                                                      int phase = 0, int outline_ltpf = 0) {
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
@@ -1824,7 +1829,9 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_P
     LC3_SYNC();
     LC3_STAMP(L, lane, 3);
     lc3_ltpf_res pf = {0, 0, 0, 1};
-    if (!(LC3_ENC_KO & 16)) pf = lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, plane != nullptr, phase);
+    if (LC3_ENC_KO & 16) {
+    } else if (outline_ltpf) pf = lc3_enc_ltpf_call(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, plane != nullptr, phase);
+    else pf = lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, plane != nullptr, phase);
     LC3_STAMP(L, lane, 5);
     if (dbg && lane == 0) {
         float *d = dbg + 1440;

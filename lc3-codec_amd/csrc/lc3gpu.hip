@@ -49,6 +49,9 @@
 #ifndef LC3_FRONT_WAVES
 #define LC3_FRONT_WAVES 4  // waves per SIMD the register allocation of the front half aims at (tuning experiments)
 #endif
+#ifndef LC3_FRONT_WAVES_75
+#define LC3_FRONT_WAVES_75 3  // ... of the 48 kHz / 7.5 ms view (168 registers: no spills; at 4 it spills 47)
+#endif
 #ifndef LC3_SYNTH_WAVES
 #define LC3_SYNTH_WAVES 4
 #endif
@@ -460,7 +463,9 @@ __device__ __forceinline__ int lc3_find_group(const lc3_groups &G, unsigned wg, 
 
 // Analysis, front half: one wave per stream (four streams per workgroup): MDCT, band energies, bandwidth, attack,
 // SNS targets, LTPF analysis.  Leaves the mid-plane column (spectrum, targets, flags) and the first packer-plane words.
-template <class CV>
+// (OUTLINE_LTPF: the LTPF stage as a function of its own -- the mixed kernel, which carries a body per configuration view and spilled 69
+// registers with all of them inlined; the uniform kernels keep it inline: 48 kHz / 7.5 ms 0.473 -> 0.625 ms with the call's register saves)
+template <class CV, int OUTLINE_LTPF = 0>
 __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigned wg, lc3_enc_state *states, int first_channel,
                                                    int n_streams, const int16_t *pcm, float *mid, int32_t *planes, int nbytes,
                                                    int n_frames, int fresh, float *dbg, lc3_io io, int spec_flags) {
@@ -488,7 +493,7 @@ __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigne
         // MDCT history: the tail of the previous frame of this launch, else the state blob's copy (silence when fresh)
         const int16_t *hist = t > 0 ? frame - (size_t)(nf - z) * (size_t)stride : (fresh ? nullptr : gst->hist);
         lc3_encode_front_wave(cfg, L, lane, frame, hist, gst, mcol, plane, LC3_PLANE_STRIDE, nbytes, valid ? dbg : nullptr, stride,
-                              t > 0 ? stride : 1, t);
+                              t > 0 ? stride : 1, t, OUTLINE_LTPF);
     }
     if (valid) {
         int stride = 1;
@@ -502,7 +507,7 @@ __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigne
 // spills none and takes 0.462 ms -- it still fits four (LDS allows no more).  The other views fit 128 registers as they are (the
 // run-time view gets slower with the larger budget: 0.641 -> 0.733 ms)
 template <class CV> struct lc3_front_waves { static constexpr int value = LC3_FRONT_WAVES; };
-template <> struct lc3_front_waves<lc3_cfg_48k75> { static constexpr int value = 3; };
+template <> struct lc3_front_waves<lc3_cfg_48k75> { static constexpr int value = LC3_FRONT_WAVES_75; };
 template <class CV>
 __global__ __launch_bounds__(64 * LC3_WG_WAVES, lc3_front_waves<CV>::value) void lc3_enc_front_kernel(lc3_cfg_slot<CV> cfg, lc3_enc_state *states,
                                                                              int first_channel, int n_streams,
@@ -512,13 +517,19 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, lc3_front_waves<CV>::value) void
     lc3_enc_front_body<CV>(cfg, blockIdx.x, states, first_channel, n_streams, pcm, mid, planes, nbytes, n_frames, fresh, dbg, io,
                            spec_flags);
 }
+template <class CV>
+__device__ __forceinline__ void lc3_enc_front_body_mixed(lc3_cfg_slot<CV> cfg, unsigned wg, lc3_enc_state *states, int first_channel,
+                                                         int n_streams, const int16_t *pcm, float *mid, int32_t *planes, int nbytes,
+                                                         int n_frames, int fresh, float *dbg, lc3_io io, int spec_flags) {
+    lc3_enc_front_body<CV, 1>(cfg, wg, states, first_channel, n_streams, pcm, mid, planes, nbytes, n_frames, fresh, dbg, io, spec_flags);
+}
 __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_FRONT_WAVES) void lc3_enc_front_mixed_kernel(lc3_groups G, lc3_enc_state *states,
                                                                                    const int16_t *pcm, float *mid, int32_t *planes,
                                                                                    int n_frames, int fresh, lc3_io io, int spec_flags) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
     float *m = mid + (size_t)g.frame_base * (size_t)MP_WORDS;
     int32_t *p = planes + (size_t)g.frame_base * (size_t)EP_WORDS;
-    LC3_GROUP_VIEW(lc3_enc_front_body, g, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, pcm, m, p, g.nbytes, n_frames, fresh,
+    LC3_GROUP_VIEW(lc3_enc_front_body_mixed, g, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, pcm, m, p, g.nbytes, n_frames, fresh,
                    (float *)nullptr, io, spec_flags);
 }
 
@@ -794,6 +805,11 @@ __global__ __launch_bounds__(512) void lc3_pack_pc_kernel(int ne, const int32_t 
                                                           lc3_io io) {
     lc3_pack_pc_body(blockIdx.x, ne, planes, out, nbytes, n_frames, T, 0, io);
 }
+__global__ __launch_bounds__(512) void lc3_pack_pc_mixed_kernel(lc3_groups G, const int32_t *planes, uint8_t *out, int T, lc3_io io) {
+    const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
+    lc3_pack_pc_body(blockIdx.x - g.wg_frame, g.ne, planes + (size_t)g.frame_base * (size_t)EP_WORDS, out, g.nbytes, g.n_streams * T, T,
+                     g.first_stream, io);
+}
 
 // The packer's symbols as a stage of its own (lc3_enc_symbols_frame, lc3_dev_enc.h): one WAVE per frame.  A workgroup stages the
 // context lookup table once (lc3_spec_tab) and walks frames wg * 4 + wave, + 4 * gridDim.x, ...; eight waves per SIMD.  Selectable
@@ -1039,13 +1055,19 @@ __global__ __launch_bounds__(512) void lc3_parse_pc_kernel(lc3_cfg_slot<CV> cfg,
                                                            int nbytes, int n_frames, int T, lc3_io io) {
     lc3_parse_pc_body<CV>(cfg, blockIdx.x, in, bad, planes, nbytes, n_frames, T, 0, io);
 }
+__global__ __launch_bounds__(512) void lc3_parse_pc_mixed_kernel(lc3_groups G, const uint8_t *in, const uint8_t *bad, int32_t *planes, int T,
+                                                                 lc3_io io) {
+    const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
+    int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
+    LC3_GROUP_VIEW(lc3_parse_pc_body, g, blockIdx.x - g.wg_frame, in, bad, p, g.nbytes, g.n_streams * T, T, g.first_stream, io);
+}
 
 // Spectrum reconstruction D4-D8 of a full batch (lc3_dev_dec_recon.h), between the parser and the synthesis kernel:
 //   lc3_recon_kernel  one WAVE per frame: residual bits, noise filling, gain, scale factors, band gains.  Frames are independent; a
 //                     workgroup (LC3_WG_WAVES waves) stages the tables once and walks frames wg * 4 + wave, + 4 * gridDim.x, ...;
 //   lc3_tns_kernel    one LANE per frame: the TNS lattice and the band gains of the filter range, for the frames that have a filter.
 #ifndef LC3_RECON_WAVES
-#define LC3_RECON_WAVES 8  // waves per SIMD the register allocation aims at
+#define LC3_RECON_WAVES 6  // waves per SIMD the register allocation aims at (80 registers: 5 spilled; at 8 waves 16 were, and the kernel was slower)
 #endif
 __shared__ lc3_recon_tables lc3_recon_tab;
 __shared__ lc3_recon_wave lc3_recon_wv[LC3_WG_WAVES];
@@ -1795,6 +1817,7 @@ static int lc3_pack_pc_optin() {
     if (dev < 0 || dev >= LC3_MAX_DEVICES) return LC3GPU_EINVAL;
     if (done[dev]) return LC3GPU_OK;
     HIP_TRY(hipFuncSetAttribute((const void *)lc3_pack_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_pack_pc_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done[dev] = true;
     return LC3GPU_OK;
 }
@@ -1827,6 +1850,7 @@ static int lc3_parse_pc_optin() {
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= LC3_MAX_DEVICES) return LC3GPU_EINVAL;
     if (done[dev]) return LC3GPU_OK;
+    HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_any>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_48k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_48k75>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
@@ -2341,8 +2365,25 @@ int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out,
     LC3_LAUNCH_CHECK(e, stream, t0);
     e->timer.mark(stream, 2);
     LC3_STAGE_RECORD(e, LC3GPU_ENC_STAGE_BACK, stream, t0);
-    const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)max_nbytes + 3) & ~(size_t)3) + 4;
-    hipLaunchKernelGGL(lc3_pack_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, (const int32_t *)e->d_planes, d_out, n_frames, io);
+    if (lc3_prep_symbols_mode((size_t)e->num_channels * (size_t)n_frames) == 0 && lc3_pack_pc_enabled()) {
+        // full batches: the producer / consumer pairs (as lc3gpu_encode does), a group table of their own number of frames per workgroup
+        if ((rc = lc3_pack_pc_optin()) != LC3GPU_OK) {
+            e->timer.rollback(t0);
+            (void)e->order_end(stream);
+            return rc;
+        }
+        const unsigned pfpb = lc3_pack_pc_fpb(max_nbytes);
+        lc3_groups Gp;
+        unsigned a, b;
+        size_t f;
+        int m;
+        fill_groups(*e, n_frames, pfpb, Gp, a, b, f, m);
+        hipLaunchKernelGGL(lc3_pack_pc_mixed_kernel, dim3(b), dim3(2 * pfpb), lc3_pack_pc_lds(pfpb, max_nbytes), stream, Gp, (const int32_t *)e->d_planes,
+                           d_out, n_frames, io);
+    } else {
+        const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)max_nbytes + 3) & ~(size_t)3) + 4;
+        hipLaunchKernelGGL(lc3_pack_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, (const int32_t *)e->d_planes, d_out, n_frames, io);
+    }
     LC3_LAUNCH_CHECK(e, stream, t0);
     e->timer.mark(stream, 3);
     e->fresh_mask.assign((size_t)e->num_channels, 0);
@@ -2631,7 +2672,22 @@ int lc3gpu_decode_mixed(lc3gpu_decoder *d, const uint8_t *d_in, const uint8_t *d
     if (mode == LC3_RECON_WAVE && (rc = lc3_tns_lds_optin()) != LC3GPU_OK) return rc;
     const size_t t0 = d->timer.used;
     d->timer.begin(stream);
-    hipLaunchKernelGGL(lc3_parse_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, d_in, d_bad, d->d_planes, n_frames, io, mode);
+    if (mode == LC3_RECON_LANE && lc3_parse_pc_enabled()) {  // full batches: the producer / consumer pairs (as lc3gpu_decode does)
+        if ((rc = lc3_parse_pc_optin()) != LC3GPU_OK) {
+            d->timer.rollback(t0);
+            (void)d->order_end(stream);
+            return rc;
+        }
+        const unsigned pfpb = lc3_parse_pc_fpb(max_nbytes);
+        lc3_groups Gp;
+        unsigned a, b;
+        size_t f;
+        int m;
+        fill_groups(*d, n_frames, pfpb, Gp, a, b, f, m);
+        hipLaunchKernelGGL(lc3_parse_pc_mixed_kernel, dim3(b), dim3(2 * pfpb), lc3_parse_pc_lds(pfpb, max_nbytes), stream, Gp, d_in, d_bad, d->d_planes,
+                           n_frames, io);
+    } else
+        hipLaunchKernelGGL(lc3_parse_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, d_in, d_bad, d->d_planes, n_frames, io, mode);
     LC3_LAUNCH_CHECK(d, stream, t0);
     d->timer.mark(stream, 0);
     lc3_groups Gx;  // the group table for other numbers of frames per workgroup
