@@ -59,6 +59,8 @@ struct __attribute__((aligned(16))) lc3_enc_lds {
 #endif
 };
 // LC3_ENC_KO: timing experiments only (knock-out builds, LC3_HIPCC_EXTRA=-DLC3_ENC_KO=n: the output is garbage): 1 no MDCT, 2 no bandwidth
+// (inside the LTPF stage also: 2048 no 17-lag correlations, 4096 no activation products, 8192 no float copy of the resampler's window, 16384 no
+// squares / normalised values, 32768 no activation sums)
 // detector, 4 no attack detector, 8 no SNS targets, 16 no LTPF analysis, 32 no high-pass recursion, 64 no 98-lag correlations, 128 no
 // resampler sums, 256 no TNS, 512 no quantiser, 1024 no residual / noise stage
 #ifndef LC3_ENC_KO
@@ -859,7 +861,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         // x_s_extended as f32, converted once (every sample is a tap operand of several outputs)
         const int16_t *xs16 = L.t + (c.nf - c.z) - c.hist;
         // (the zero-padded taps of a row may reach up to three samples past the window: those operands must be finite)
-        for (int i = lane; i < c.hist + c.nf + 4; i += LC3_WAVE) W[i] = i < c.hist + c.nf ? (float)xs16[i] : 0.0f;
+        for (int i = lane; i < ((LC3_ENC_KO & 8192) ? 0 : c.hist + c.nf + 4); i += LC3_WAVE) W[i] = i < c.hist + c.nf ? (float)xs16[i] : 0.0f;
         LC3_SYNC();
     }
     // resampling :152-166 -- one lane per 12.8 kHz output, taps accumulated in the reference's order (k ascending).
@@ -1053,7 +1055,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     // compute_normalized_value :445-455 for lag 0, lag_t1, lag_t2: the squares once, one sample per lane, then three lanes
     // add 64 of them each in the reference's order
     float *sq = S + 224;  // 178 floats
-    for (int n = lane; n < LC3_KMAX + len6; n += LC3_WAVE) {
+    for (int n = lane; n < ((LC3_ENC_KO & 16384) ? 0 : LC3_KMAX + len6); n += LC3_WAVE) {
         const float v = x6[n];
         sq[n] = v * v;
     }
@@ -1066,7 +1068,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     LC3_SERIAL_BEGIN(lc3_enc_lds, L, lane, ltpf_phase + 1, 3)
         const float *sq_ = (const float *)L.fb + 224;
         const int lag = sub == 0 ? 0 : L.ism[8 + sub - 1];
-        L.sm[8 + sub] = lc3_sum_seq(sq_ + (LC3_KMAX - lag), len6, 0.0f);
+        L.sm[8 + sub] = lc3_sum_seq(sq_ + (LC3_KMAX - lag), (LC3_ENC_KO & 16384) ? 0 : len6, 0.0f);
     LC3_SERIAL_END
     int t_current, pitch_present;
     {   // the decision is then the same scalar code on every lane
@@ -1091,7 +1093,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         L.ism[11] = (k_max + 4) - (k_min - 4) + 1;  // <= 17
     }
     LC3_SERIAL_WIDE_BEGIN(lc3_enc_lds, L, lane, ltpf_phase + 2, 17)
-        if (sub < L.ism[11]) {
+        if (!(LC3_ENC_KO & 2048) && sub < L.ism[11]) {
             const float *x12_ = (const float *)L.fa + 64;
             const int k = L.ism[10] + sub;
             ((float *)L.fb)[200 + sub] = lc3_dot_seq(x12_ + LC3_NMEM, x12_ + LC3_NMEM - k, len12, 0.0f);  // len12 is a multiple of 8
@@ -1187,7 +1189,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     {
         // the products of the three sums are formed here, one sample per lane (a product is the same f32 operation wherever
         // it runs); the three lanes below only add them up in the reference's order
-        for (int n = lane; n < len12; n += LC3_WAVE) {
+        for (int n = lane; n < ((LC3_ENC_KO & 4096) ? 0 : len12); n += LC3_WAVE) {
             const float a = lc3_ltpf_dot(x12, n, 0);
             const float b = lc3_ltpf_dot(x12, n - pitch_int, pitch_fr);
             S[n] = a * b;
@@ -1197,7 +1199,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     }
     // sub 0: sum dA*dB, 1: sum dA*dA, 2: sum dB*dB -- twelve lanes of one wave for the workgroup's four streams
     LC3_SERIAL_BEGIN(lc3_enc_lds, L, lane, ltpf_phase + 3, 3)
-        L.sm[12 + sub] = lc3_sum_seq((const float *)L.fb + 128 * sub, len12, 0.0f);
+        L.sm[12 + sub] = lc3_sum_seq((const float *)L.fb + 128 * sub, (LC3_ENC_KO & 32768) ? 0 : len12, 0.0f);
     LC3_SERIAL_END
     int ltpf_active = 0;
     {
