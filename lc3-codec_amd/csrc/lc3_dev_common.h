@@ -1045,14 +1045,17 @@ __device__ __forceinline__ void lc3_dct4_core(const CC &c, int lane, float *in, 
         LC3_SYNC();
     }
 }
+#ifndef LC3_DCT4_CORE  // (lc3gpu.hip: the run-time configuration view picks a compile-time plan by frame length)
+#define LC3_DCT4_CORE(IN_PLACE, c, lane, in, wk, out) lc3_dct4_core<IN_PLACE>(c, lane, in, wk, out)
+#endif
 // on buf[0..nf) in place, scratch fb (nf/2 complex; fa is no longer needed)
 template <class CC>
 __device__ __forceinline__ void lc3_dct4_wave(const CC &c, int lane, float *buf, lc3_cpx *fa, lc3_cpx *fb) {
     (void)fa;
-    lc3_dct4_core<0>(c, lane, buf, fb, buf);
+    LC3_DCT4_CORE(0, c, lane, buf, fb, buf);
 }
 // a[0..nf) -> b[0..nf) with two buffers: a is destroyed (it serves as the complex work array once the innermost stage has read it)
 template <class CC>
 __device__ __forceinline__ void lc3_dct4_wave_ab(const CC &c, int lane, float *a, float *b) {
-    lc3_dct4_core<1>(c, lane, a, (lc3_cpx *)a, b);
+    LC3_DCT4_CORE(1, c, lane, a, (lc3_cpx *)a, b);
 }

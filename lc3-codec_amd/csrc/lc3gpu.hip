@@ -173,6 +173,7 @@ __device__ __forceinline__ float lc3_div_by(float x, const lc3_divisor &v) {
     e = __builtin_fmaf(-v.d, q, x);
     return __builtin_fmaf(e, v.r, q);
 }
+#define LC3_DCT4_CORE(IN_PLACE, c, lane, in, wk, out) lc3_dct4_select<IN_PLACE>(c, lane, in, wk, out)
 #include "lc3_dev_common.h"
 // ---- configuration slots ----------------------------------------------------------------------------------------
 // Every (sampling rate, frame duration) pair owns one slot of a __constant__ table; handles register their
@@ -224,7 +225,35 @@ struct lc3_cfg_any {
             return ok;                                                                                                                 \
         }                                                                                                                              \
     };
+// an FFT / DCT-IV plan by frame length (lc3_cfg_views.h): the integers lc3_dct4_core reads of a configuration, as constants
+#define LC3_DEFINE_FFT_PLAN(NAME, NF, NFFT, NST, RADIX, M, FSTRIDE, INV_M)                         \
+    struct NAME {                                                                                 \
+        static constexpr int nf = NF, nfft = NFFT, n_stages = NST;                                \
+        static constexpr int radix[6] = RADIX, m[6] = M, fstride[6] = FSTRIDE, inv_m[6] = INV_M;  \
+    };
 #include "lc3_cfg_views.h"
+// The DCT-IV of a wave (lc3_dct4_wave / lc3_dct4_wave_ab, lc3_dev_common.h).  A compile-time configuration view IS its plan.  The run-time
+// view picks the plan of its frame length -- with the radices, strides and loop bounds as run-time values the transform took 0.130 ms
+// against 0.034 ms in the synthesis kernel and 0.193 against 0.106 ms in the front half (48 kHz sizes, profiles/r04_knockout_generic.txt)
+template <int IN_PLACE, class CC>
+__device__ __forceinline__ void lc3_dct4_select(const CC &c, int lane, float *in, lc3_cpx *wk, float *out) {
+    lc3_dct4_core<IN_PLACE>(c, lane, in, wk, out);
+}
+template <int IN_PLACE>
+__device__ __forceinline__ void lc3_dct4_select(const lc3_cfg &c, int lane, float *in, lc3_cpx *wk, float *out) {
+    switch (c.nf) {
+    case 480: lc3_dct4_core<IN_PLACE>(lc3_fft_plan_480(), lane, in, wk, out); break;
+    case 360: lc3_dct4_core<IN_PLACE>(lc3_fft_plan_360(), lane, in, wk, out); break;
+    case 320: lc3_dct4_core<IN_PLACE>(lc3_fft_plan_320(), lane, in, wk, out); break;
+    case 240: lc3_dct4_core<IN_PLACE>(lc3_fft_plan_240(), lane, in, wk, out); break;
+    case 180: lc3_dct4_core<IN_PLACE>(lc3_fft_plan_180(), lane, in, wk, out); break;
+    case 160: lc3_dct4_core<IN_PLACE>(lc3_fft_plan_160(), lane, in, wk, out); break;
+    case 120: lc3_dct4_core<IN_PLACE>(lc3_fft_plan_120(), lane, in, wk, out); break;
+    case 80: lc3_dct4_core<IN_PLACE>(lc3_fft_plan_80(), lane, in, wk, out); break;
+    case 60: lc3_dct4_core<IN_PLACE>(lc3_fft_plan_60(), lane, in, wk, out); break;
+    default: lc3_dct4_core<IN_PLACE>(c, lane, in, wk, out); break;
+    }
+}
 #undef LC3_CFG_TEMPLATE
 #undef LC3_CFG_PARAM
 #undef LC3_CFG_BIND
