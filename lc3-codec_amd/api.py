@@ -59,18 +59,63 @@ def library_path():
     return _LIB
 
 
+def _translation_units():
+    """(kind, index) of every translation unit of the multi-unit build (csrc/lc3gpu.hip, "translation units"): the main unit (0: host
+    side + the whole-source module's device code), the encoder kernels (1) and the decoder kernels (3) of every configuration view beyond
+    the base ones, one unit per mixed-configuration kernel (2)"""
+    import re
+
+    with open(os.path.join(_HERE, "csrc", "lc3_cfg_views.h")) as f:
+        text = f.read()
+    n_all = int(re.search(r"#define LC3_N_VIEWS_ALL (\d+)", text).group(1))
+    n_base = int(re.search(r"#define LC3_N_VIEWS_BASE (\d+)", text).group(1))
+    return [(0, 0)] + [(k, v) for v in range(n_base + 1, n_all + 1) for k in (1, 3)] + [(2, k) for k in range(8)]
+
+
 def build_native(force=False, verbose=False):
-    """Compile csrc/lc3gpu.hip for gfx950 into lib/liblc3gpu.so (hipcc cross-compiles without a GPU)."""
+    """Compile csrc/lc3gpu.hip for gfx950 into lib/liblc3gpu.so (hipcc cross-compiles without a GPU).  The default library is built from
+    several translation units of the same source side by side (device code generation is serial inside one unit; LC3_BUILD_JOBS, default
+    the CPUs this process may use) and carries a compile-time view of every standard configuration; LC3_SINGLE_TU=1, the diagnostic build
+    (LC3GPU_PROFILE=1) and builds with LC3_HIPCC_EXTRA compile it whole, with the four views of the round-1..4 library."""
     srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
     srcs += [os.path.join(_ROOT, "include", "lc3gpu.h"), os.path.join(_ROOT, "tables", "lc3_tables.h")]
     if not force and os.path.exists(_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(_LIB) for s in srcs):
         return _LIB
     os.makedirs(os.path.dirname(_LIB), exist_ok=True)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-fno-fast-math", "-Wno-unused-function", "-Wno-missing-braces", "-o", _LIB, _SRC]
-    if _PROFILE:
-        cmd.insert(1, "-DLC3_PROFILE")
-    cmd[1:1] = os.environ.get("LC3_HIPCC_EXTRA", "").split()  # compiler experiments
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function",
+             "-Wno-missing-braces"]
+    extra = os.environ.get("LC3_HIPCC_EXTRA", "").split()  # compiler experiments
+    single = _PROFILE or bool(extra) or os.environ.get("LC3_SINGLE_TU", "0") == "1"
+    if single:
+        cmd = ["hipcc"] + extra + (["-DLC3_PROFILE"] if _PROFILE else []) + flags + ["-shared", "-o", _LIB, _SRC]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return _LIB
+    from concurrent.futures import ThreadPoolExecutor
+
+    objdir = os.path.join(os.path.dirname(_LIB), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    units = _translation_units()
+
+    def compile_unit(u):
+        obj = os.path.join(objdir, "lc3gpu_%d_%d.o" % u)
+        cmd = ["hipcc", "-DLC3_TU_KIND=%d" % u[0], "-DLC3_TU_INDEX=%d" % u[1]] + flags + ["-c", "-o", obj, _SRC]
+        subprocess.check_call(cmd)
+        return obj
+
+    try:
+        jobs = len(os.sched_getaffinity(0))
+    except AttributeError:
+        jobs = os.cpu_count() or 1
+    jobs = max(1, int(os.environ.get("LC3_BUILD_JOBS", jobs)))
+    if verbose:
+        print("hipcc -DLC3_TU_KIND=k -DLC3_TU_INDEX=i %s -c %s   x %d translation units, %d at a time" % (" ".join(flags), _SRC, len(units), jobs))
+    # (the main unit and the mixed-kernel units are the long ones: first)
+    order = sorted(units, key=lambda u: (u[0] != 0, u[0] != 2))
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(compile_unit, order))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", _LIB] + sorted(objs)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -20,6 +20,52 @@
 
 #include "../../include/lc3gpu.h"
 
+// ---- translation units ------------------------------------------------------------------------------------------------------------
+// The library is this one source compiled either whole (no LC3_TU_KIND: the four configuration views of LC3_FOR_EACH_VIEW_BASE; the
+// diagnostic and the experiment builds) or as parts, side by side (lc3-codec_amd/api.py; device code generation for ~250 kernel bodies is
+// what a build spends its time on, and it is serial inside one unit):
+//   -DLC3_TU_KIND=0                     the MAIN unit: the host side and, as device code, exactly what the whole-source build holds --
+//                                       the kernels of the four base views and of the run-time view, the mixed kernels with those bodies
+//   -DLC3_TU_KIND=1 -DLC3_TU_INDEX=v    the three encoder kernels of one of the other views (lc3_cfg_views.h, v = 5 ..)
+//   -DLC3_TU_KIND=3 -DLC3_TU_INDEX=v    its eight decoder kernels
+//   -DLC3_TU_KIND=2 -DLC3_TU_INDEX=k    the k-th of the eight mixed-configuration kernels with a body for EVERY view (these are the ones a
+//                                       multi-unit library launches: <name>_all; the main unit's stay unused)
+// Why the main unit repeats the whole-source module instead of holding only what nobody else does: the front half of the headline
+// configuration sits at the edge of its 128 registers, and on which side it lands depends on what else its module holds (117 registers
+// and no spill there; 128 and 47 spilled in a unit of its own, 0.448 -> 0.481 ms; profiles/r04_translation_units.txt).
+// Every unit but the main one has its own copy of the constant table and of the device-filled tables (`static` there):
+// lc3_tu_register_<kind>_<index> fills them, the main unit calls every unit's.
+#ifdef LC3_TU_KIND
+#define LC3_MULTI_TU 1
+#ifndef LC3_TU_INDEX
+#define LC3_TU_INDEX 0
+#endif
+#else
+#define LC3_MULTI_TU 0
+#define LC3_TU_KIND 0
+#define LC3_TU_INDEX 0
+#endif
+#if LC3_TU_KIND == 0
+#define LC3_TU_STATIC
+#else
+#define LC3_TU_STATIC static
+#endif
+#define LC3_IN_HOST_TU (LC3_TU_KIND == 0)
+#define LC3_IN_MIXED_TU(k) (LC3_TU_KIND == 0 || (LC3_TU_KIND == 2 && LC3_TU_INDEX == (k)))
+// a mixed kernel's name: in its own unit <name>_all (a body per view), in the main unit the plain name (base views); what the host launches
+#if LC3_TU_KIND == 2
+#define LC3_MIXED_KERNEL(name) name##_all
+#else
+#define LC3_MIXED_KERNEL(name) name
+#endif
+#if LC3_MULTI_TU
+#define LC3_MIXED_LAUNCH(name) name##_all
+#else
+#define LC3_MIXED_LAUNCH(name) name
+#endif
+#define LC3_CAT_(a, b) a##b
+#define LC3_CAT(a, b) LC3_CAT_(a, b)
+
 // A workgroup is LC3_WG_WAVES wavefronts, one stream each.  LC3_SYNC orders the LDS traffic of ONE wave (its lanes
 // exchange data through the stream's LDS working set): the hardware executes a wave's LDS instructions in order, so
 // only the compiler has to be kept from moving accesses across the point.  LC3_SERIAL_BEGIN/END bracket code that is
@@ -140,12 +186,12 @@ static __device__ __forceinline__ int lc3_pc_load_(const int *p) {
 #define LC3_LANEWAVE_MAX(v) lc3_wave_max_i32((v), 0)
 // 10^x tables of the two argument families the codec uses (lc3_dev_common.h: LC3_POW10_GG / LC3_POW10_TILT), filled on the device
 // by lc3_pow10f itself when a device's first configuration is registered
-__device__ float lc3_pow10_gg_tab[512];       // [k + 256] = 10^(k / 28), k = gg_ind + gg_off
-__device__ float lc3_pow10_tilt_tab[5 * 64];  // [fs_ind * 64 + b] = 10^(b * (g_tilt[fs_ind] / 630))
+LC3_TU_STATIC __device__ float lc3_pow10_gg_tab[512];       // [k + 256] = 10^(k / 28), k = gg_ind + gg_off
+LC3_TU_STATIC __device__ float lc3_pow10_tilt_tab[5 * 64];  // [fs_ind * 64 + b] = 10^(b * (g_tilt[fs_ind] / 630))
 #define LC3_POW10_GG(k) ((unsigned)((k) + 256) < 512u ? lc3_pow10_gg_tab[(k) + 256] : lc3_pow10f((float)(k) / 28.0f))
 #define LC3_POW10_TILT(fs_ind, b) (lc3_pow10_tilt_tab[(fs_ind) * 64 + (b)])
 // the 17 quantised TNS reflection coefficients in the encoder's form of the step (lc3_dev_common.h: LC3_TNS_SIN_*)
-__device__ float lc3_tns_sin_tab[17];
+LC3_TU_STATIC __device__ float lc3_tns_sin_tab[17];
 #define LC3_TNS_SIN_ENC(ri) ((unsigned)(ri) < 17u ? lc3_tns_sin_tab[(ri)] : lc3_tns_sin_enc_value(ri))
 // (the decoder's lane-per-frame parser evaluates the routine: a per-lane table fetch from memory costs it more than the arithmetic)
 #define LC3_TNS_SIN_DEC(ri) lc3_tns_sin_dec_value(ri)
@@ -174,6 +220,9 @@ __device__ __forceinline__ float lc3_div_by(float x, const lc3_divisor &v) {
     return __builtin_fmaf(e, v.r, q);
 }
 #define LC3_DCT4_CORE(IN_PLACE, c, lane, in, wk, out) lc3_dct4_select<IN_PLACE>(c, lane, in, wk, out)
+struct lc3_cpx;
+template <int IN_PLACE, class CC>
+__device__ __forceinline__ void lc3_dct4_select(const CC &c, int lane, float *in, lc3_cpx *wk, float *out);
 #include "lc3_dev_common.h"
 // ---- configuration slots ----------------------------------------------------------------------------------------
 // Every (sampling rate, frame duration) pair owns one slot of a __constant__ table; handles register their
@@ -181,7 +230,7 @@ __device__ __forceinline__ float lc3_div_by(float x, const lc3_divisor &v) {
 // bind `c` to the slot through a wave-uniform index: every field is then a scalar (s_load) read that no LDS or HBM
 // store can alias, instead of a load from a by-value copy of the struct in scratch.
 #define LC3_CFG_SLOTS 12
-__constant__ lc3_cfg lc3_cfg_table[LC3_CFG_SLOTS];
+LC3_TU_STATIC __constant__ lc3_cfg lc3_cfg_table[LC3_CFG_SLOTS];
 // Configuration views.  A kernel (and every stage function under it) is instantiated once per view: lc3_cfg_any binds
 // `c` to the slot's entry of the constant table; lc3_cfg_48k10 -- the configuration the headline benchmark runs -- carries
 // the integers of that configuration as compile-time constants (loop bounds, index arithmetic and the FFT plan fold at
@@ -232,6 +281,22 @@ struct lc3_cfg_any {
         static constexpr int radix[6] = RADIX, m[6] = M, fstride[6] = FSTRIDE, inv_m[6] = INV_M;  \
     };
 #include "lc3_cfg_views.h"
+// LC3_FOR_EACH_VIEW / LC3_LAUNCH_CASES: the views the HOST knows (every view in a multi-unit library); LC3_VIEW_CASES: the bodies a mixed
+// kernel of THIS unit carries
+#if LC3_MULTI_TU
+#define LC3_FOR_EACH_VIEW(X) LC3_FOR_EACH_VIEW_ALL(X)
+#define LC3_LAUNCH_CASES LC3_LAUNCH_CASES_ALL
+#define LC3_N_VIEWS LC3_N_VIEWS_ALL
+#else
+#define LC3_FOR_EACH_VIEW(X) LC3_FOR_EACH_VIEW_BASE(X)
+#define LC3_LAUNCH_CASES LC3_LAUNCH_CASES_BASE
+#define LC3_N_VIEWS LC3_N_VIEWS_BASE
+#endif
+#if LC3_TU_KIND == 2
+#define LC3_VIEW_CASES LC3_VIEW_CASES_ALL
+#else
+#define LC3_VIEW_CASES LC3_VIEW_CASES_BASE
+#endif
 // The DCT-IV of a wave (lc3_dct4_wave / lc3_dct4_wave_ab, lc3_dev_common.h).  A compile-time configuration view IS its plan.  The run-time
 // view picks the plan of its frame length -- with the radices, strides and loop bounds as run-time values the transform took 0.130 ms
 // against 0.034 ms in the synthesis kernel and 0.193 against 0.106 ms in the front half (48 kHz sizes, profiles/r04_knockout_generic.txt)
@@ -368,7 +433,7 @@ __device__ __forceinline__ uint32_t lc3_wave_exscan_u32(uint32_t u, int lane) {
 // stage stamps into a per-wave table in LDS (stamp i accumulates the time since the previous stamp into slot i);
 // the table is flushed to a global one with one atomic per slot at the end of the launch, so the stamps do not put
 // memory traffic inside the stages.  Never timed as a whole; read its SHARES (cdna_hip_programming.md section 7).
-__device__ unsigned long long lc3_prof_acc[64];  // 0..31 stage sums; 32/33/34 enc wave time sum/max/count, 35/36/37 dec; 40..47 parse kernel; 48..55 pack kernel
+LC3_TU_STATIC __device__ unsigned long long lc3_prof_acc[64];  // 0..31 stage sums; 32/33/34 enc wave time sum/max/count, 35/36/37 dec; 40..47 parse kernel; 48..55 pack kernel
 #undef LC3_STAMP
 #define LC3_STAMP(L, lane, id)                                                     \
     do {                                                                           \
@@ -460,15 +525,12 @@ __device__ __forceinline__ size_t lc3_io_flag_idx(const lc3_io &io, int first, s
 
 // runs BODY<view>(slot{g.slot}, args...) with the group's configuration view (a mixed batch is BASELINE config 4's whole point: its
 // 48 kHz / 7.5 ms, 32 kHz and 16 kHz groups get the compile-time views the uniform handles of those configurations get)
-#define LC3_GROUP_VIEW(BODY, g, ...)                                                        \
-    do {                                                                                    \
-        switch ((g).fixed) {                                                                \
-        case 1: BODY<lc3_cfg_48k10>(lc3_cfg_slot<lc3_cfg_48k10>{(g).slot}, __VA_ARGS__); break; \
-        case 2: BODY<lc3_cfg_48k75>(lc3_cfg_slot<lc3_cfg_48k75>{(g).slot}, __VA_ARGS__); break; \
-        case 3: BODY<lc3_cfg_32k10>(lc3_cfg_slot<lc3_cfg_32k10>{(g).slot}, __VA_ARGS__); break; \
-        case 4: BODY<lc3_cfg_16k10>(lc3_cfg_slot<lc3_cfg_16k10>{(g).slot}, __VA_ARGS__); break; \
-        default: BODY<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{(g).slot}, __VA_ARGS__); break;    \
-        }                                                                                   \
+#define LC3_GROUP_VIEW(BODY, g, ...)                                                         \
+    do {                                                                                     \
+        switch ((g).fixed) {                                                                 \
+            LC3_VIEW_CASES(BODY, (g).slot, __VA_ARGS__)                                      \
+        default: BODY<lc3_cfg_any>(lc3_cfg_slot<lc3_cfg_any>{(g).slot}, __VA_ARGS__); break; \
+        }                                                                                    \
     } while (0)
 // A mixed-configuration handle keeps its streams sorted by configuration; a "group" is one run of streams of equal
 // (rate, duration, frame bytes).  Every kernel of a mixed batch is ONE launch: a workgroup finds its group from its index.
@@ -492,9 +554,18 @@ __device__ __forceinline__ int lc3_find_group(const lc3_groups &G, unsigned wg, 
 
 // Analysis, front half: one wave per stream (four streams per workgroup): MDCT, band energies, bandwidth, attack,
 // SNS targets, LTPF analysis.  Leaves the mid-plane column (spectrum, targets, flags) and the first packer-plane words.
-// (OUTLINE_LTPF: the LTPF stage as a function of its own -- the mixed kernel, which carries a body per configuration view and spilled 69
-// registers with all of them inlined; the uniform kernels keep it inline: 48 kHz / 7.5 ms 0.473 -> 0.625 ms with the call's register saves)
-template <class CV, int OUTLINE_LTPF = 0>
+// (OUTLINE_LTPF: the LTPF stage as a function of its own, i.e. a register allocation of its own.  With the stage inlined the kernel sits at
+// the edge of its 128 registers, and on which side it lands depends on what ELSE the module holds: 117 registers and no spill in the whole-
+// source module (= the main unit), 128 and 37 - 47 spilled for every view in a translation unit of its own, from nearly the same IR.  The
+// main unit keeps the inlined form it was tuned in; in the other units the 10 ms views outline it (103 - 120 registers, no spill); the
+// 7.5 ms views keep it inline with a larger budget, lc3_front_waves -- their LTPF stage saves and restores ~50 registers per call when
+// outlined, 0.473 -> 0.625 ms.  The mixed kernels, a body per view, outline all.  profiles/r04_translation_units.txt)
+#if LC3_TU_KIND == 0
+template <class CV> struct lc3_front_outline { static constexpr int value = 0; };  // (the whole-source module as tuned: inline, 117 registers)
+#else
+template <class CV> struct lc3_front_outline { static constexpr int value = CV::n_ms_10 ? 1 : 0; };
+#endif
+template <class CV, int OUTLINE_LTPF = lc3_front_outline<CV>::value>
 __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigned wg, lc3_enc_state *states, int first_channel,
                                                    int n_streams, const int16_t *pcm, float *mid, int32_t *planes, int nbytes,
                                                    int n_frames, int fresh, float *dbg, lc3_io io, int spec_flags) {
@@ -535,8 +606,8 @@ __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigne
 // view spilled 47 of them (176 bytes of scratch per lane, front half 0.599 ms per 65 536 frames); with the budget of three waves it
 // spills none and takes 0.462 ms -- it still fits four (LDS allows no more).  The other views fit 128 registers as they are (the
 // run-time view gets slower with the larger budget: 0.641 -> 0.733 ms)
-template <class CV> struct lc3_front_waves { static constexpr int value = LC3_FRONT_WAVES; };
-template <> struct lc3_front_waves<lc3_cfg_48k75> { static constexpr int value = LC3_FRONT_WAVES_75; };
+template <class CV> struct lc3_front_waves { static constexpr int value = CV::n_ms_10 ? LC3_FRONT_WAVES : LC3_FRONT_WAVES_75; };
+template <> struct lc3_front_waves<lc3_cfg_any> { static constexpr int value = LC3_FRONT_WAVES; };
 template <class CV>
 __global__ __launch_bounds__(64 * LC3_WG_WAVES, lc3_front_waves<CV>::value) void lc3_enc_front_kernel(lc3_cfg_slot<CV> cfg, lc3_enc_state *states,
                                                                              int first_channel, int n_streams,
@@ -552,7 +623,8 @@ __device__ __forceinline__ void lc3_enc_front_body_mixed(lc3_cfg_slot<CV> cfg, u
                                                          int n_frames, int fresh, float *dbg, lc3_io io, int spec_flags) {
     lc3_enc_front_body<CV, 1>(cfg, wg, states, first_channel, n_streams, pcm, mid, planes, nbytes, n_frames, fresh, dbg, io, spec_flags);
 }
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_FRONT_WAVES) void lc3_enc_front_mixed_kernel(lc3_groups G, lc3_enc_state *states,
+#if LC3_IN_MIXED_TU(0)
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_FRONT_WAVES) void LC3_MIXED_KERNEL(lc3_enc_front_mixed_kernel)(lc3_groups G, lc3_enc_state *states,
                                                                                    const int16_t *pcm, float *mid, int32_t *planes,
                                                                                    int n_frames, int fresh, lc3_io io, int spec_flags) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
@@ -561,6 +633,12 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_FRONT_WAVES) void lc3_enc_fr
     LC3_GROUP_VIEW(lc3_enc_front_body_mixed, g, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, pcm, m, p, g.nbytes, n_frames, fresh,
                    (float *)nullptr, io, spec_flags);
 }
+#endif
+#if LC3_MULTI_TU && LC3_TU_KIND == 0
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_FRONT_WAVES) void lc3_enc_front_mixed_kernel_all(lc3_groups G, lc3_enc_state *states,
+                                                                                   const int16_t *pcm, float *mid, int32_t *planes,
+                                                                                   int n_frames, int fresh, lc3_io io, int spec_flags);
+#endif
 
 // SNS vector quantiser, one LANE per frame (lc3_dev_enc_vq.h): 16 targets -> indices (packer plane) + 64 band gains.
 __device__ __forceinline__ void lc3_sns_vq_body(unsigned wg, int nb, float *mid, int32_t *planes, int n_frames, int spec_flags) {
@@ -581,14 +659,18 @@ __device__ __forceinline__ void lc3_sns_vq_body(unsigned wg, int nb, float *mid,
         lc3_sns_vq_frame(v);
     }
 }
+#if LC3_IN_HOST_TU
 __global__ __launch_bounds__(256) void lc3_sns_vq_kernel(int nb, float *mid, int32_t *planes, int n_frames, int spec_flags) {
     lc3_sns_vq_body(blockIdx.x, nb, mid, planes, n_frames, spec_flags);
 }
+#endif
+#if LC3_IN_HOST_TU
 __global__ __launch_bounds__(256) void lc3_sns_vq_mixed_kernel(lc3_groups G, float *mid, int32_t *planes, int n_frames, int spec_flags) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     lc3_sns_vq_body(blockIdx.x - g.wg_frame, g.nb, mid + (size_t)g.frame_base * (size_t)MP_WORDS,
                     planes + (size_t)g.frame_base * (size_t)EP_WORDS, g.n_streams * n_frames, spec_flags);
 }
+#endif
 
 // Analysis, back half: one wave per stream: spectral shaping with the quantised gains, TNS, quantiser (stateful),
 // residual bits, noise level.  Completes the packer plane column.
@@ -635,7 +717,8 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_bac
                                                                             int n_frames, float *dbg, int spec_flags) {
     lc3_enc_back_body<CV>(cfg, blockIdx.x, states, first_channel, n_streams, mid, planes, nbytes, n_frames, dbg, spec_flags);
 }
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_back_mixed_kernel(lc3_groups G, lc3_enc_state *states,
+#if LC3_IN_MIXED_TU(1)
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void LC3_MIXED_KERNEL(lc3_enc_back_mixed_kernel)(lc3_groups G, lc3_enc_state *states,
                                                                                                 const float *mid, int32_t *planes,
                                                                                                 int n_frames, int spec_flags) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
@@ -644,6 +727,12 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_bac
     LC3_GROUP_VIEW(lc3_enc_back_body, g, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, m, p, g.nbytes, n_frames, (float *)nullptr,
                    spec_flags);
 }
+#endif
+#if LC3_MULTI_TU && LC3_TU_KIND == 0
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_BACK_WAVES) void lc3_enc_back_mixed_kernel_all(lc3_groups G, lc3_enc_state *states,
+                                                                                                const float *mid, int32_t *planes,
+                                                                                                int n_frames, int spec_flags);
+#endif
 
 // Bitstream packer, one LANE per frame (lc3_dev_enc_pack.h).  blockDim.x frames per workgroup; context lookup and the
 // packed spectral model in LDS, every lane builds its frame in an LDS staging slot, then the workgroup copies the
@@ -732,15 +821,19 @@ __device__ __forceinline__ void lc3_pack_body(unsigned wg, int ne, const int32_t
     }
 #endif
 }
+#if LC3_IN_HOST_TU
 __global__ __launch_bounds__(256) void lc3_pack_kernel(int ne, const int32_t *planes, uint8_t *out, int nbytes, int n_frames, int T,
                                                        lc3_io io) {
     lc3_pack_body(blockIdx.x, ne, planes, out, nbytes, n_frames, T, 0, io);
 }
+#endif
+#if LC3_IN_HOST_TU
 __global__ __launch_bounds__(256) void lc3_pack_mixed_kernel(lc3_groups G, const int32_t *planes, uint8_t *out, int T, lc3_io io) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     lc3_pack_body(blockIdx.x - g.wg_frame, g.ne, planes + (size_t)g.frame_base * (size_t)EP_WORDS, out, g.nbytes, g.n_streams * T, T,
                   g.first_stream, io);
 }
+#endif
 
 // The packer of a full batch as PRODUCER / CONSUMER wave pairs (lc3_pack_produce / lc3_pack_consume, lc3_dev_enc_pack.h): a workgroup of
 // 2 x fpb threads packs fpb frames; wave w of its first half derives the symbol words of 64 frames, wave w of the second half (the same
@@ -830,15 +923,19 @@ __device__ __forceinline__ void lc3_pack_pc_body(unsigned wg, int ne, const int3
         }
     }
 }
+#if LC3_IN_HOST_TU
 __global__ __launch_bounds__(512) void lc3_pack_pc_kernel(int ne, const int32_t *planes, uint8_t *out, int nbytes, int n_frames, int T,
                                                           lc3_io io) {
     lc3_pack_pc_body(blockIdx.x, ne, planes, out, nbytes, n_frames, T, 0, io);
 }
+#endif
+#if LC3_IN_HOST_TU
 __global__ __launch_bounds__(512) void lc3_pack_pc_mixed_kernel(lc3_groups G, const int32_t *planes, uint8_t *out, int T, lc3_io io) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     lc3_pack_pc_body(blockIdx.x - g.wg_frame, g.ne, planes + (size_t)g.frame_base * (size_t)EP_WORDS, out, g.nbytes, g.n_streams * T, T,
                      g.first_stream, io);
 }
+#endif
 
 // The packer's symbols as a stage of its own (lc3_enc_symbols_frame, lc3_dev_enc.h): one WAVE per frame.  A workgroup stages the
 // context lookup table once (lc3_spec_tab) and walks frames wg * 4 + wave, + 4 * gridDim.x, ...; eight waves per SIMD.  Selectable
@@ -967,12 +1064,18 @@ __global__ __launch_bounds__(256) void lc3_parse_debug_kernel(lc3_cfg_slot<CV> c
     lc3_io io = {0, nullptr};
     lc3_parse_body<CV>(cfg, 0, in, nullptr, planes, nbytes, 1, 1, 0, io, late, dbg);
 }
-__global__ __launch_bounds__(256) void lc3_parse_mixed_kernel(lc3_groups G, const uint8_t *in, const uint8_t *bad, int32_t *planes,
+#if LC3_IN_MIXED_TU(2)
+__global__ __launch_bounds__(256) void LC3_MIXED_KERNEL(lc3_parse_mixed_kernel)(lc3_groups G, const uint8_t *in, const uint8_t *bad, int32_t *planes,
                                                               int T, lc3_io io, int late) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
     LC3_GROUP_VIEW(lc3_parse_body, g, blockIdx.x - g.wg_frame, in, bad, p, g.nbytes, g.n_streams * T, T, g.first_stream, io, late);
 }
+#endif
+#if LC3_MULTI_TU && LC3_TU_KIND == 0
+__global__ __launch_bounds__(256) void lc3_parse_mixed_kernel_all(lc3_groups G, const uint8_t *in, const uint8_t *bad, int32_t *planes,
+                                                              int T, lc3_io io, int late);
+#endif
 
 // The parser of a full batch as PRODUCER / CONSUMER wave pairs (lc3_pc_produce / lc3_pc_consume, lc3_dev_dec_parse.h): a workgroup of
 // 2 x fpb threads parses fpb frames; wave w of its first half runs the range decoder's recurrence for 64 frames, wave w of the second half
@@ -1084,12 +1187,18 @@ __global__ __launch_bounds__(512) void lc3_parse_pc_kernel(lc3_cfg_slot<CV> cfg,
                                                            int nbytes, int n_frames, int T, lc3_io io) {
     lc3_parse_pc_body<CV>(cfg, blockIdx.x, in, bad, planes, nbytes, n_frames, T, 0, io);
 }
-__global__ __launch_bounds__(512) void lc3_parse_pc_mixed_kernel(lc3_groups G, const uint8_t *in, const uint8_t *bad, int32_t *planes, int T,
+#if LC3_IN_MIXED_TU(3)
+__global__ __launch_bounds__(512) void LC3_MIXED_KERNEL(lc3_parse_pc_mixed_kernel)(lc3_groups G, const uint8_t *in, const uint8_t *bad, int32_t *planes, int T,
                                                                  lc3_io io) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
     LC3_GROUP_VIEW(lc3_parse_pc_body, g, blockIdx.x - g.wg_frame, in, bad, p, g.nbytes, g.n_streams * T, T, g.first_stream, io);
 }
+#endif
+#if LC3_MULTI_TU && LC3_TU_KIND == 0
+__global__ __launch_bounds__(512) void lc3_parse_pc_mixed_kernel_all(lc3_groups G, const uint8_t *in, const uint8_t *bad, int32_t *planes, int T,
+                                                                 lc3_io io);
+#endif
 
 // Spectrum reconstruction D4-D8 of a full batch (lc3_dev_dec_recon.h), between the parser and the synthesis kernel:
 //   lc3_recon_kernel  one WAVE per frame: residual bits, noise filling, gain, scale factors, band gains.  Frames are independent; a
@@ -1114,7 +1223,8 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_RECON_WAVES) void lc3_recon_
     lc3_recon_body<CV>(cfg, blockIdx.x, gridDim.x, planes, nbytes, (size_t)n_frames);
 }
 // mixed batch: one frame per wave, G's frame-kernel workgroup numbers computed for LC3_WG_WAVES frames per workgroup
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_RECON_WAVES) void lc3_recon_mixed_kernel(lc3_groups G, int32_t *planes, int T) {
+#if LC3_IN_MIXED_TU(4)
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_RECON_WAVES) void LC3_MIXED_KERNEL(lc3_recon_mixed_kernel)(lc3_groups G, int32_t *planes, int T) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
     const unsigned wg = blockIdx.x - g.wg_frame;
@@ -1122,6 +1232,10 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_RECON_WAVES) void lc3_recon_
     LC3_GROUP_VIEW(lc3_recon_body, g, 0u, 1u, p + (size_t)wg * LC3_WG_WAVES * (size_t)LC3_PLANE_WORDS, g.nbytes,
                    left < LC3_WG_WAVES ? left : (size_t)LC3_WG_WAVES);
 }
+#endif
+#if LC3_MULTI_TU && LC3_TU_KIND == 0
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, LC3_RECON_WAVES) void lc3_recon_mixed_kernel_all(lc3_groups G, int32_t *planes, int T);
+#endif
 // LC3_TNS_FPB frames per workgroup, one wave per 64 of them: 16 KB of (dynamic) LDS per wave for its frames' band gains, band-major.
 // Four waves per workgroup so that the 1 024 waves of a full batch land one per SIMD (single-wave workgroups are packed several to a CU).
 #define LC3_TNS_FPB 256
@@ -1152,11 +1266,16 @@ __global__ __launch_bounds__(LC3_TNS_FPB) void lc3_tns_kernel(lc3_cfg_slot<CV> c
     lc3_tns_body<CV>(cfg, blockIdx.x, planes, (size_t)n_frames);
 }
 // G: frame-kernel workgroup numbers computed for LC3_TNS_FPB frames per workgroup
-__global__ __launch_bounds__(LC3_TNS_FPB) void lc3_tns_mixed_kernel(lc3_groups G, int32_t *planes, int T) {
+#if LC3_IN_MIXED_TU(5)
+__global__ __launch_bounds__(LC3_TNS_FPB) void LC3_MIXED_KERNEL(lc3_tns_mixed_kernel)(lc3_groups G, int32_t *planes, int T) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
     LC3_GROUP_VIEW(lc3_tns_body, g, blockIdx.x - g.wg_frame, p, (size_t)g.n_streams * (size_t)T);
 }
+#endif
+#if LC3_MULTI_TU && LC3_TU_KIND == 0
+__global__ __launch_bounds__(LC3_TNS_FPB) void lc3_tns_mixed_kernel_all(lc3_groups G, int32_t *planes, int T);
+#endif
 
 // LATE: the launch reconstructs the spectrum here (lc3_dec_reconstruct_wave) -- a compile-time switch, so that the kernels of full
 // batches carry none of it
@@ -1209,30 +1328,140 @@ __global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_debug_kernel(
     if (late) lc3_decode_body<CV, 1>(cfg, 0, states, channel, 1, planes, pcm, nbytes, 1, 0, io, dbg, dbg_flags);
     else lc3_decode_body<CV, 0>(cfg, 0, states, channel, 1, planes, pcm, nbytes, 1, 0, io, dbg, dbg_flags);
 }
+template <class CV>
+__device__ __forceinline__ void lc3_decode_body_now(lc3_cfg_slot<CV> cfg, unsigned wg, lc3_dec_state *states, int first_channel, int n_streams,
+                                                    const int32_t *planes, int16_t *pcm, int nbytes, int n_frames, int fresh, lc3_io io) {
+    lc3_decode_body<CV, 0>(cfg, wg, states, first_channel, n_streams, planes, pcm, nbytes, n_frames, fresh, io);
+}
+template <class CV>
+__device__ __forceinline__ void lc3_decode_body_late(lc3_cfg_slot<CV> cfg, unsigned wg, lc3_dec_state *states, int first_channel, int n_streams,
+                                                     const int32_t *planes, int16_t *pcm, int nbytes, int n_frames, int fresh, lc3_io io) {
+    lc3_decode_body<CV, 1>(cfg, wg, states, first_channel, n_streams, planes, pcm, nbytes, n_frames, fresh, io);
+}
 template <int LATE>
 __device__ __forceinline__ void lc3_decode_mixed_body(const lc3_groups &G, lc3_dec_state *states, const int32_t *planes, int16_t *pcm,
                                                       int n_frames, int fresh, lc3_io io) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 0)];
     const int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
-    switch (g.fixed) {
-    case 1: lc3_decode_body<lc3_cfg_48k10, LATE>(lc3_cfg_slot<lc3_cfg_48k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io); break;
-    case 2: lc3_decode_body<lc3_cfg_48k75, LATE>(lc3_cfg_slot<lc3_cfg_48k75>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io); break;
-    case 3: lc3_decode_body<lc3_cfg_32k10, LATE>(lc3_cfg_slot<lc3_cfg_32k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io); break;
-    case 4: lc3_decode_body<lc3_cfg_16k10, LATE>(lc3_cfg_slot<lc3_cfg_16k10>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io); break;
-    default: lc3_decode_body<lc3_cfg_any, LATE>(lc3_cfg_slot<lc3_cfg_any>{g.slot}, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io); break;
-    }
+    if (LATE) LC3_GROUP_VIEW(lc3_decode_body_late, g, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io);
+    else LC3_GROUP_VIEW(lc3_decode_body_now, g, blockIdx.x - g.wg_stream, states, g.first_stream, g.n_streams, p, pcm, g.nbytes, n_frames, fresh, io);
 }
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_mixed_kernel(lc3_groups G, lc3_dec_state *states,
+#if LC3_IN_MIXED_TU(6)
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void LC3_MIXED_KERNEL(lc3_decode_mixed_kernel)(lc3_groups G, lc3_dec_state *states,
                                                                                 const int32_t *planes, int16_t *pcm, int n_frames,
                                                                                 int fresh, lc3_io io) {
     lc3_decode_mixed_body<0>(G, states, planes, pcm, n_frames, fresh, io);
 }
-__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_mixed_late_kernel(lc3_groups G, lc3_dec_state *states,
+#endif
+#if LC3_MULTI_TU && LC3_TU_KIND == 0
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_mixed_kernel_all(lc3_groups G, lc3_dec_state *states,
+                                                                                const int32_t *planes, int16_t *pcm, int n_frames,
+                                                                                int fresh, lc3_io io);
+#endif
+#if LC3_IN_MIXED_TU(7)
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void LC3_MIXED_KERNEL(lc3_decode_mixed_late_kernel)(lc3_groups G, lc3_dec_state *states,
                                                                                      const int32_t *planes, int16_t *pcm, int n_frames,
                                                                                      int fresh, lc3_io io) {
     lc3_decode_mixed_body<1>(G, states, planes, pcm, n_frames, fresh, io);
 }
+#endif
+#if LC3_MULTI_TU && LC3_TU_KIND == 0
+__global__ __launch_bounds__(64 * LC3_WG_WAVES, 4) void lc3_decode_mixed_late_kernel_all(lc3_groups G, lc3_dec_state *states,
+                                                                                     const int32_t *planes, int16_t *pcm, int n_frames,
+                                                                                     int fresh, lc3_io io);
+#endif
 
+// ---------------------------------------------------------------------------------------------
+// per translation unit: the unit's kernels, its copy of the tables
+// ---------------------------------------------------------------------------------------------
+template <int I> struct lc3_view_by_index { typedef lc3_cfg_any type; };
+#define LC3_X(i, V) template <> struct lc3_view_by_index<i> { typedef V type; };
+LC3_FOR_EACH_VIEW_ALL(LC3_X)
+#undef LC3_X
+#if LC3_MULTI_TU
+// the kernels of a configuration view -- three of the encoder, eight of the decoder --: T = `extern` declares them (the host unit), T
+// empty instantiates them (the view's units; encoder and decoder apart: besides halving the longest unit, what else a module holds
+// changes how the compiler lays out LDS for the stage functions, and with all eleven in one module the front half came out with 47
+// spilled registers)
+#define LC3_VIEW_ENC_KERNELS(T, CV)                                                                                                          \
+    T template __global__ void lc3_enc_front_kernel<CV>(lc3_cfg_slot<CV>, lc3_enc_state *, int, int, const int16_t *, float *, int32_t *, int, int, \
+                                                        int, float *, lc3_io, int);                                                           \
+    T template __global__ void lc3_enc_back_kernel<CV>(lc3_cfg_slot<CV>, lc3_enc_state *, int, int, const float *, int32_t *, int, int, float *, int); \
+    T template __global__ void lc3_symbols_kernel<CV>(lc3_cfg_slot<CV>, int32_t *, int);
+#define LC3_VIEW_DEC_KERNELS(T, CV)                                                                                                          \
+    T template __global__ void lc3_parse_kernel<CV>(lc3_cfg_slot<CV>, const uint8_t *, const uint8_t *, int32_t *, int, int, int, lc3_io, int);  \
+    T template __global__ void lc3_parse_debug_kernel<CV>(lc3_cfg_slot<CV>, const uint8_t *, int32_t *, int, int, float *);                    \
+    T template __global__ void lc3_parse_pc_kernel<CV>(lc3_cfg_slot<CV>, const uint8_t *, const uint8_t *, int32_t *, int, int, int, lc3_io);   \
+    T template __global__ void lc3_recon_kernel<CV>(lc3_cfg_slot<CV>, int32_t *, int, int);                                                    \
+    T template __global__ void lc3_tns_kernel<CV>(lc3_cfg_slot<CV>, int32_t *, int);                                                           \
+    T template __global__ void lc3_decode_kernel<CV>(lc3_cfg_slot<CV>, lc3_dec_state *, int, int, const int32_t *, int16_t *, int, int, int, lc3_io); \
+    T template __global__ void lc3_decode_late_kernel<CV>(lc3_cfg_slot<CV>, lc3_dec_state *, int, int, const int32_t *, int16_t *, int, int, int, \
+                                                          lc3_io);                                                                            \
+    T template __global__ void lc3_decode_debug_kernel<CV>(lc3_cfg_slot<CV>, lc3_dec_state *, int, const int32_t *, int16_t *, int, int, float *, int);
+#if LC3_TU_KIND == 0
+#define LC3_X(i, V) LC3_VIEW_ENC_KERNELS(extern, V) LC3_VIEW_DEC_KERNELS(extern, V)
+LC3_FOR_EACH_VIEW_EXTRA(LC3_X)
+#undef LC3_X
+#elif LC3_TU_KIND == 1
+typedef lc3_view_by_index<LC3_TU_INDEX>::type lc3_tu_view;
+LC3_VIEW_ENC_KERNELS(, lc3_tu_view)
+#elif LC3_TU_KIND == 3
+typedef lc3_view_by_index<LC3_TU_INDEX>::type lc3_tu_view;
+LC3_VIEW_DEC_KERNELS(, lc3_tu_view)
+#endif
+#endif
+namespace {
+__global__ void lc3_pow10_tables_kernel() {
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) lc3_pow10_gg_tab[i] = lc3_pow10f((float)(i - 256) / 28.0f);
+    for (int i = threadIdx.x; i < 5 * 64; i += blockDim.x) {
+        const int fsi = i / 64, b = i % 64;
+        lc3_pow10_tilt_tab[i] = lc3_pow10f((float)b * ((float)LC3C_G_TILT[fsi] / 630.0f));
+    }
+    for (int i = threadIdx.x; i < 17; i += blockDim.x) {
+        lc3_tns_sin_tab[i] = lc3_tns_sin_enc_value(i);
+    }
+}
+}  // namespace
+// this unit's copy of the tables: slot >= 0 publishes a configuration in its constant table, fill_tables runs its table-filling kernel
+// (once per device).  Returns a hipError_t as int (0 = success).
+#define LC3_TU_REGISTER_NAME(kind, index) LC3_CAT(LC3_CAT(lc3_tu_register_, kind), LC3_CAT(_, index))
+extern "C" __attribute__((visibility("hidden"))) int LC3_TU_REGISTER_NAME(LC3_TU_KIND, LC3_TU_INDEX)(int slot, const lc3_cfg *c, int fill_tables) {
+    if (fill_tables) {
+        hipLaunchKernelGGL(lc3_pow10_tables_kernel, dim3(1), dim3(256), 0, nullptr);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (slot >= 0 && c) {
+        const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(lc3_cfg_table), c, sizeof(*c), sizeof(*c) * (size_t)slot, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+typedef int (*lc3_tu_register_fn)(int, const lc3_cfg *, int);
+#if LC3_MULTI_TU && LC3_TU_KIND == 0
+#define LC3_X(i, V)                                                                                              \
+    extern "C" __attribute__((visibility("hidden"))) int LC3_TU_REGISTER_NAME(1, i)(int, const lc3_cfg *, int); \
+    extern "C" __attribute__((visibility("hidden"))) int LC3_TU_REGISTER_NAME(3, i)(int, const lc3_cfg *, int);
+LC3_FOR_EACH_VIEW_EXTRA(LC3_X)
+#undef LC3_X
+#define LC3_FOR_EACH_MIXED_TU(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define LC3_X(k) extern "C" __attribute__((visibility("hidden"))) int LC3_TU_REGISTER_NAME(2, k)(int, const lc3_cfg *, int);
+LC3_FOR_EACH_MIXED_TU(LC3_X)
+#undef LC3_X
+static const lc3_tu_register_fn lc3_tu_registers[] = {lc3_tu_register_0_0,
+#define LC3_X(i, V) LC3_TU_REGISTER_NAME(1, i), LC3_TU_REGISTER_NAME(3, i),
+                                                       LC3_FOR_EACH_VIEW_EXTRA(LC3_X)
+#undef LC3_X
+#define LC3_X(k) LC3_TU_REGISTER_NAME(2, k),
+                                                           LC3_FOR_EACH_MIXED_TU(LC3_X)
+#undef LC3_X
+};
+#elif LC3_TU_KIND == 0
+static const lc3_tu_register_fn lc3_tu_registers[] = {lc3_tu_register_0_0};
+#endif
+
+#if LC3_IN_HOST_TU  // ============================================================================================== the host side
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1257,15 +1486,12 @@ struct HostCfg {
 // launches kern<view>(slot, args...) with the view the configuration allows
 #define LC3_LAUNCH_VIEW(kern, V, h, grid, block, lds, stream, ...) \
     hipLaunchKernelGGL(kern<V>, grid, block, lds, stream, lc3_cfg_slot<V>{(h).slot}, __VA_ARGS__)
-#define LC3_LAUNCH_CFG(kern, h, grid, block, lds, stream, ...)                                                  \
-    do {                                                                                                        \
-        switch ((h).view) {                                                                                     \
-        case 1: LC3_LAUNCH_VIEW(kern, lc3_cfg_48k10, h, grid, block, lds, stream, __VA_ARGS__); break;          \
-        case 2: LC3_LAUNCH_VIEW(kern, lc3_cfg_48k75, h, grid, block, lds, stream, __VA_ARGS__); break;          \
-        case 3: LC3_LAUNCH_VIEW(kern, lc3_cfg_32k10, h, grid, block, lds, stream, __VA_ARGS__); break;          \
-        case 4: LC3_LAUNCH_VIEW(kern, lc3_cfg_16k10, h, grid, block, lds, stream, __VA_ARGS__); break;          \
-        default: LC3_LAUNCH_VIEW(kern, lc3_cfg_any, h, grid, block, lds, stream, __VA_ARGS__); break;           \
-        }                                                                                                       \
+#define LC3_LAUNCH_CFG(kern, h, grid, block, lds, stream, ...)                                       \
+    do {                                                                                             \
+        switch ((h).view) {                                                                          \
+            LC3_LAUNCH_CASES(kern, h, grid, block, lds, stream, __VA_ARGS__)                         \
+        default: LC3_LAUNCH_VIEW(kern, lc3_cfg_any, h, grid, block, lds, stream, __VA_ARGS__); break; \
+        }                                                                                            \
     } while (0)
 
 int make_config(lc3_cfg &c, int frame_us, int fs_hz) {
@@ -1279,16 +1505,6 @@ __global__ void lc3_line_width_kernel(float *out, lc3_cfg c) {
 // fills the line -> band table of a configuration on the device (lc3_line_band_value)
 __global__ void lc3_line_band_kernel(uint8_t *out, lc3_cfg c) {
     for (int k = threadIdx.x; k < c.nf; k += blockDim.x) out[k] = (uint8_t)lc3_line_band_value(c, k);
-}
-__global__ void lc3_pow10_tables_kernel() {
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) lc3_pow10_gg_tab[i] = lc3_pow10f((float)(i - 256) / 28.0f);
-    for (int i = threadIdx.x; i < 5 * 64; i += blockDim.x) {
-        const int fsi = i / 64, b = i % 64;
-        lc3_pow10_tilt_tab[i] = lc3_pow10f((float)b * ((float)LC3C_G_TILT[fsi] / 630.0f));
-    }
-    for (int i = threadIdx.x; i < 17; i += blockDim.x) {
-        lc3_tns_sin_tab[i] = lc3_tns_sin_enc_value(i);
-    }
 }
 // fills the polyphase resampler table of a configuration on the device (lc3_resamp_poly_value)
 __global__ void lc3_resamp_poly_kernel(float *out, int p, int lim, int stride) {
@@ -1330,7 +1546,7 @@ int cfg_upload(lc3_cfg &c, const lc3_host_plan &pl, char *base, size_t bytes_tw,
     c.resamp_poly = poly;
     c.line_width = lw;
     c.line_band = lb;
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lc3_cfg_table), &c, sizeof(c), sizeof(c) * (size_t)slot, hipMemcpyHostToDevice));
+    for (lc3_tu_register_fn reg : lc3_tu_registers) HIP_TRY((hipError_t)reg(slot, &c, 0));  // every translation unit's constant table
     return LC3GPU_OK;
 }
 
@@ -1346,9 +1562,7 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
     const int slot = 2 * k + (frame_us == 10000);
     std::lock_guard<std::mutex> lock(g_cfgs.mu);
     if (!g_cfgs.tables[dev]) {
-        hipLaunchKernelGGL(lc3_pow10_tables_kernel, dim3(1), dim3(256), 0, nullptr);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(nullptr));
+        for (lc3_tu_register_fn reg : lc3_tu_registers) HIP_TRY((hipError_t)reg(-1, nullptr, 1));  // every translation unit's tables
         g_cfgs.tables[dev] = true;
     }
     if (!g_cfgs.ready[dev][slot]) {
@@ -1376,10 +1590,9 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
     static const bool generic_only = std::getenv("LC3GPU_GENERIC") != nullptr && std::atoi(std::getenv("LC3GPU_GENERIC")) != 0;
     h.view = 0;
     if (!generic_only) {
-        if (lc3_cfg_48k10::matches(h.c)) h.view = 1;
-        else if (lc3_cfg_48k75::matches(h.c)) h.view = 2;
-        else if (lc3_cfg_32k10::matches(h.c)) h.view = 3;
-        else if (lc3_cfg_16k10::matches(h.c)) h.view = 4;
+#define LC3_X(i, V) if (h.view == 0 && V::matches(h.c)) h.view = i;
+        LC3_FOR_EACH_VIEW(LC3_X)
+#undef LC3_X
     }
     return LC3GPU_OK;
 }
@@ -1879,12 +2092,11 @@ static int lc3_parse_pc_optin() {
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= LC3_MAX_DEVICES) return LC3GPU_EINVAL;
     if (done[dev]) return LC3GPU_OK;
-    HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)LC3_MIXED_LAUNCH(lc3_parse_pc_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_any>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
-    HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_48k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
-    HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_48k75>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
-    HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_32k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
-    HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<lc3_cfg_16k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
+#define LC3_X(i, V) HIP_TRY(hipFuncSetAttribute((const void *)lc3_parse_pc_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_PC_LDS_MAX));
+    LC3_FOR_EACH_VIEW(LC3_X)
+#undef LC3_X
     done[dev] = true;
     return LC3GPU_OK;
 }
@@ -1903,11 +2115,10 @@ static int lc3_tns_lds_optin() {
     if (dev < 0 || dev >= LC3_MAX_DEVICES) return LC3GPU_EINVAL;
     if (done[dev]) return LC3GPU_OK;
     HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_kernel<lc3_cfg_any>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
-    HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_kernel<lc3_cfg_48k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
-    HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_kernel<lc3_cfg_48k75>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
-    HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_kernel<lc3_cfg_32k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
-    HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_kernel<lc3_cfg_16k10>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
-    HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
+#define LC3_X(i, V) HIP_TRY(hipFuncSetAttribute((const void *)lc3_tns_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
+    LC3_FOR_EACH_VIEW(LC3_X)
+#undef LC3_X
+    HIP_TRY(hipFuncSetAttribute((const void *)LC3_MIXED_LAUNCH(lc3_tns_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LC3_TNS_LDS));
     done[dev] = true;
     return LC3GPU_OK;
 }
@@ -2373,7 +2584,7 @@ int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out,
     lc3_io io = {0, e->d_tab};
     const size_t t0 = e->timer.used;
     e->timer.begin(stream);
-    hipLaunchKernelGGL(lc3_enc_front_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states, d_pcm, e->d_mid,
+    hipLaunchKernelGGL(LC3_MIXED_LAUNCH(lc3_enc_front_mixed_kernel), dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states, d_pcm, e->d_mid,
                        e->d_planes, n_frames, fresh, io, e->spec_flags);
     LC3_LAUNCH_CHECK(e, stream, t0);
     e->timer.mark(stream, 0);
@@ -2389,7 +2600,7 @@ int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out,
     }
     e->timer.mark(stream, 1);
     LC3_STAGE_RECORD(e, LC3GPU_ENC_STAGE_VQ, stream, t0);
-    hipLaunchKernelGGL(lc3_enc_back_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states,
+    hipLaunchKernelGGL(LC3_MIXED_LAUNCH(lc3_enc_back_mixed_kernel), dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, e->d_states,
                        (const float *)e->d_mid, e->d_planes, n_frames, e->spec_flags | lc3_prep_symbols_flag((size_t)e->num_channels * (size_t)n_frames, true));
     LC3_LAUNCH_CHECK(e, stream, t0);
     e->timer.mark(stream, 2);
@@ -2713,10 +2924,10 @@ int lc3gpu_decode_mixed(lc3gpu_decoder *d, const uint8_t *d_in, const uint8_t *d
         size_t f;
         int m;
         fill_groups(*d, n_frames, pfpb, Gp, a, b, f, m);
-        hipLaunchKernelGGL(lc3_parse_pc_mixed_kernel, dim3(b), dim3(2 * pfpb), lc3_parse_pc_lds(pfpb, max_nbytes), stream, Gp, d_in, d_bad, d->d_planes,
+        hipLaunchKernelGGL(LC3_MIXED_LAUNCH(lc3_parse_pc_mixed_kernel), dim3(b), dim3(2 * pfpb), lc3_parse_pc_lds(pfpb, max_nbytes), stream, Gp, d_in, d_bad, d->d_planes,
                            n_frames, io);
     } else
-        hipLaunchKernelGGL(lc3_parse_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, d_in, d_bad, d->d_planes, n_frames, io, mode);
+        hipLaunchKernelGGL(LC3_MIXED_LAUNCH(lc3_parse_mixed_kernel), dim3(wg_frame), dim3(fpb), lds, stream, G, d_in, d_bad, d->d_planes, n_frames, io, mode);
     LC3_LAUNCH_CHECK(d, stream, t0);
     d->timer.mark(stream, 0);
     lc3_groups Gx;  // the group table for other numbers of frames per workgroup
@@ -2725,22 +2936,22 @@ int lc3gpu_decode_mixed(lc3gpu_decoder *d, const uint8_t *d_in, const uint8_t *d
     int gx_m;
     if (mode == LC3_RECON_WAVE) {
         fill_groups(*d, n_frames, (unsigned)LC3_WG_WAVES, Gx, gx_a, gx_b, gx_f, gx_m);
-        hipLaunchKernelGGL(lc3_recon_mixed_kernel, dim3(gx_b), dim3(64 * LC3_WG_WAVES), 0, stream, Gx, d->d_planes, n_frames);
+        hipLaunchKernelGGL(LC3_MIXED_LAUNCH(lc3_recon_mixed_kernel), dim3(gx_b), dim3(64 * LC3_WG_WAVES), 0, stream, Gx, d->d_planes, n_frames);
         LC3_LAUNCH_CHECK(d, stream, t0);
         d->timer.mark(stream, 1);
     }
     if (mode == LC3_RECON_WAVE) {
         fill_groups(*d, n_frames, (unsigned)LC3_TNS_FPB, Gx, gx_a, gx_b, gx_f, gx_m);
-        hipLaunchKernelGGL(lc3_tns_mixed_kernel, dim3(gx_b), dim3(LC3_TNS_FPB), LC3_TNS_LDS, stream, Gx, d->d_planes, n_frames);
+        hipLaunchKernelGGL(LC3_MIXED_LAUNCH(lc3_tns_mixed_kernel), dim3(gx_b), dim3(LC3_TNS_FPB), LC3_TNS_LDS, stream, Gx, d->d_planes, n_frames);
         LC3_LAUNCH_CHECK(d, stream, t0);
         d->timer.mark(stream, 2);
     }
     LC3_STAGE_RECORD(d, LC3GPU_DEC_STAGE_PARSE, stream, t0);
     if (mode == LC3_RECON_LATE)
-        hipLaunchKernelGGL(lc3_decode_mixed_late_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, d->d_states,
+        hipLaunchKernelGGL(LC3_MIXED_LAUNCH(lc3_decode_mixed_late_kernel), dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, d->d_states,
                            (const int32_t *)d->d_planes, d_pcm, n_frames, 0, io);
     else
-        hipLaunchKernelGGL(lc3_decode_mixed_kernel, dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, d->d_states,
+        hipLaunchKernelGGL(LC3_MIXED_LAUNCH(lc3_decode_mixed_kernel), dim3(wg_stream), dim3(64 * LC3_WG_WAVES), 0, stream, G, d->d_states,
                            (const int32_t *)d->d_planes, d_pcm, n_frames, 0, io);
     LC3_LAUNCH_CHECK(d, stream, t0);
     d->timer.mark(stream, 3);
@@ -3052,3 +3263,4 @@ int lc3gpu_kernel_info(int which, int out[5]) {
 }
 
 }  // extern "C"
+#endif  // LC3_IN_HOST_TU
