@@ -759,9 +759,10 @@ def test_state_blobs_say_what_they_are():
 
 
 def test_runtime_configuration_view_of_the_headline_configuration():
-    """48 kHz / 10 ms, 48 kHz / 7.5 ms, 32 kHz / 10 ms and 16 kHz / 10 ms normally run kernels instantiated with the configuration as
-    compile-time constants (lc3_cfg_views.h); LC3GPU_GENERIC=1 keeps them on the run-time view every other configuration uses.
-    Both must give the oracle's bytes and PCM (a fresh process: the switch is read once per process)."""
+    """Every standard configuration normally runs kernels instantiated with the configuration as compile-time constants
+    (lc3_cfg_views.h: twelve views in the multi-unit library, four in a whole-source build); LC3GPU_GENERIC=1 keeps a process on the
+    run-time view, the fall-back for whatever has no view.  Both must give the oracle's bytes and PCM (a fresh process: the switch is
+    read once per process) -- here every frame length the run-time view's transforms pick a plan for, a mixed batch and the 8 kHz decoder."""
     import os
     import subprocess
     import sys
@@ -771,8 +772,12 @@ def test_runtime_configuration_view_of_the_headline_configuration():
         "import test_gpu_parity as t\n"
         "for nb in (150, 60, 300):\n"
         "    t._roundtrip_check(48000, 10000, nb, 96, 6, seed=61)\n"
-        "for fs, us, nb in ((48000, 7500, 113), (32000, 10000, 80), (16000, 10000, 40)):\n"
+        "for fs, us, nb in ((48000, 7500, 113), (32000, 10000, 80), (16000, 10000, 40), (44100, 10000, 110), (24000, 10000, 60),\n"
+        "                   (32000, 7500, 61), (24000, 7500, 45), (16000, 7500, 30), (44100, 7500, 83)):\n"
         "    t._roundtrip_check(fs, us, nb, 64, 6, seed=62)\n"
+        "t.test_decode_8khz(10000, 30)\n"
+        "t.test_decode_8khz(7500, 23)\n"
+        "t.test_mixed_configuration_batch()\n"
         "t.test_corrupt_frames_are_concealed_like_the_reference()\n"
         "t.test_ltpf_transitions(48000, 10000, 40)\n"
         "print('generic ok')\n"
