@@ -388,7 +388,12 @@ class GpuEngine:
 
     def last_bytes(self, k):
         """the first k streams' frame bytes of the most recent step"""
-        buf = {"pipelined": self.bufs[(self.k - 1) & 1], "staggered": self.bufs[(self.k - 1) % 3]}.get(self.arrangement, self.d_bytes)
+        if self.arrangement == "pipelined":
+            buf = self.bufs[(self.k - 1) & 1]
+        elif self.arrangement == "staggered":
+            buf = self.bufs[(self.k - 1) % 3]
+        else:
+            buf = self.d_bytes
         return buf[:k].cpu().numpy()
 
     def results(self, k):

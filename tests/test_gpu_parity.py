@@ -1133,6 +1133,16 @@ def _bench_line(extra, env_extra, timeout=900):
     return p, (json.loads(lines[-1]) if lines else None)
 
 
+def test_bench_encode_only_mode():
+    """`bench.py --mode encode` (BASELINE config 3 at a small size): one handle, one caller stream, no decoder and no second byte buffer;
+    its parity gate compares the bitstream only"""
+    p, line = _bench_line(["--mode", "encode", "--frames-total", "16384", "--steps", "3", "--warmup", "1", "--sustain-seconds", "0.2"], {})
+    assert p.returncode == 0 and line is not None, p.stderr[-2000:]
+    assert "encode" in line["metric"] and line["config"]["mode"] == "encode" and line["config"]["arrangement"] == "single"
+    assert line["parity"]["bitstream_exact"] and line["parity_mismatches_all_ranks"] == 0 and line["other_arrangements"] == []
+    assert line["kernel_ms"]["lc3_pack_kernel"] > 0.0 and line["sustained"]["steps"] > 0
+
+
 def test_two_ranks_through_the_launcher_share_the_gpu():
     """`bench.py --gpus 2` on a one-GPU box: the production launcher (fresh child processes, rendezvous on 127.0.0.1), the stream
     sharding, the GPU engine and the final reduction together; the ranks share the visible device and reduce over gloo (RCCL needs
