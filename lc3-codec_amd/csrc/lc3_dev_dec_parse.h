@@ -733,6 +733,9 @@ __device__ __forceinline__ void lc3_pc_produce(lc3_parse_ctx &c, const lc3_pc_li
 // r / scf_out (optional): the reconstruction context and 16 registers for the frame's scale factors, which only need the side
 // information: computed here while the producer is still at its start (the ring lies in the lane's scale-factor slots in LDS, so
 // they stay in registers until the symbols are through)
+#ifndef LC3_PCPARSE_KO
+#define LC3_PCPARSE_KO 0  // timing experiments only: 2 = a consumer that only follows the producer through the symbols (profiles/r04_parse_halves.txt)
+#endif
 template <int COUNT>
 __device__ __forceinline__ int lc3_pc_consume(lc3_parse_ctx &c, const lc3_pc_link &k, int ne, int fs_ind, int rc_in,
                                               const lc3_recon_ctx *r = nullptr, float *scf_out = nullptr) {
@@ -772,8 +775,19 @@ __device__ __forceinline__ int lc3_pc_consume(lc3_parse_ctx &c, const lc3_pc_lin
             if ((pc & (LC3_PC_DONE - 1)) <= it) break;  // the producer has ended (or never answered)
 #pragma unroll
             for (int u = 0; u < LC3_PC_CHUNK; u++) {
+#if LC3_PCPARSE_KO == 2  // timing experiment: a consumer that only follows the producer (the output is garbage)
                 if (tup < ntup) {
                     const uint32_t w = k.ring[((it + u) & k.mask) * k.stride];
+                    const int esc = (int)(w & 31u) >= 16 && lev < 14;
+                    tup += !esc;
+                    lev = esc ? lev + 1 : 0;
+                }
+                if (false) {
+                    const uint32_t w = 0;
+#else
+                if (tup < ntup) {
+                    const uint32_t w = k.ring[((it + u) & k.mask) * k.stride];
+#endif
                     const int sym = (int)(w & 31u);
                     c.head += (int)(w >> 5);
                     const int esc = sym >= 16 && lev < 14;
