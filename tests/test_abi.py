@@ -90,3 +90,31 @@ def test_product_does_not_touch_the_oracle():
                     f"{f} mentions the oracle"
     out = os.popen(f"ldd {pkg.library_path()}").read()
     assert "oracle" not in out
+
+
+def test_translation_units_match_the_generated_views():
+    """the multi-unit build's list of units (api._translation_units) against lc3_cfg_views.h: the main unit, an encoder and a decoder unit
+    for every view beyond the base ones, eight mixed-kernel units; the generated header is what tools/gen_views.py writes"""
+    import re
+    import subprocess
+    import sys
+
+    api = importlib.import_module("lc3-codec_amd.api")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "lc3-codec_amd", "csrc", "lc3_cfg_views.h")
+    text = open(hdr).read()
+    n_all = int(re.search(r"#define LC3_N_VIEWS_ALL (\d+)", text).group(1))
+    n_base = int(re.search(r"#define LC3_N_VIEWS_BASE (\d+)", text).group(1))
+    assert (n_all, n_base) == (12, 4)  # 8 / 16 / 24 / 32 / 44.1 / 48 kHz x 7.5 / 10 ms; the whole-source build's four
+    assert len(re.findall(r"^LC3_DEFINE_CFG_VIEW\(", text, re.M)) == n_all and len(re.findall(r"^LC3_DEFINE_FFT_PLAN\(", text, re.M)) == 9
+    units = api._translation_units()
+    assert units[0] == (0, 0) and len(units) == 1 + 2 * (n_all - n_base) + 8
+    assert sorted(u[1] for u in units if u[0] == 1) == list(range(n_base + 1, n_all + 1)) == sorted(u[1] for u in units if u[0] == 3)
+    assert sorted(u[1] for u in units if u[0] == 2) == list(range(8))
+    # the header is reproducible from the generator
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "views.h")
+        subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_views.py"), out])
+        assert open(out, "rb").read() == open(hdr, "rb").read()

@@ -879,6 +879,8 @@ def test_producer_consumer_kernels_at_every_size():
         "t.test_long_stream_state_carry()\n"
         "t.test_ltpf_transitions(48000, 10000, 60)\n"
         "t.test_kat_encode_frame(); t.test_kat_decode_frame()\n"
+        "t.test_mixed_configuration_batch()\n"          # the pair kernels of mixed handles (a body per configuration view)
+        "t.test_mixed_batch_bad_frames_and_plc_counter()\n"
         "print('pairs ok')\n"
     )
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
