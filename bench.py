@@ -56,12 +56,13 @@ def parse_args(argv=None):
                     help="split the rank's streams over this many codec handle pairs, each on its own HIP stream "
                          "(default 1: one stream, clean per-kernel timing)")
     ap.add_argument("--no-overlap-probe", action="store_true",
-                    help="skip timing the OTHER arrangement (see --arrangement) after the timed region")
+                    help="skip timing the OTHER arrangements (see --arrangement) after the timed region")
     ap.add_argument("--arrangement", choices=("single", "pipelined", "staggered"), default="pipelined",
                     help="how the timed steps are queued: `single` = encode then decode of the same batch on ONE HIP stream (every call waits for "
                          "the one before it); `pipelined` = the recommended caller pattern (INTEGRATION.md): the encoder handle on one HIP stream, the "
-                         "decoder handle on another, two byte buffers and events, so that the decoder works on step k while the encoder runs step k + 1. "
-                         "The other arrangement is timed too and reported beside `value`")
+                         "decoder handle on another, two byte buffers and events, so that the decoder works on step k while the encoder runs step k + 1; "
+                         "`staggered` = the same with three buffers and the decoder call queued behind the encoder's LC3GPU_ENC_STAGE_BACK event of the "
+                         "next step (lc3gpu_encoder_stage_event).  The other arrangements are timed too and reported beside `value`")
     ap.add_argument("--sustain-seconds", type=float, default=2.5,
                     help="length of the sustained leg: back-to-back steps for this long, frames/s and the shader clock read by a one-wave probe kernel "
                          "beside them (0 = skip)")
