@@ -677,8 +677,8 @@ def run_rank(args):
             # parser reads nbytes, the synthesis kernel writes 2*nf; the vector quantiser and the back half touch no
             # algorithmic bytes (their traffic is the planes between kernels).  The analysis of a frame is three kernels
             # (front half, quantiser, back half): ONE unit for the roofline, with the frame's PCM as its algorithmic bytes.
-            # kernel_ms[k] = that kernel's launch durations summed over one step (a call of a full batch runs as two half launches
-            # side by side on the handle's internal streams: the sum over both, as `rocprofv3 --kernel-trace --stats` totals them)
+            # kernel_ms[k] = that kernel's launch durations summed over one step (one launch per kernel and step by default; with the
+            # opt-in split of a call, LC3GPU_SPLIT=1, the sum over its part launches, as `rocprofv3 --kernel-trace --stats` totals them)
             alg_bytes = {"lc3_enc_front_kernel": 2 * NF, "lc3_sns_vq_kernel": 0, "lc3_enc_back_kernel": 0,
                          "lc3_pack_kernel": NBYTES, "lc3_parse_kernel": NBYTES, "lc3_recon_kernel": 0, "lc3_tns_kernel": 0, "lc3_decode_kernel": 2 * NF}
             groups = {"analysis (lc3_enc_front_kernel + lc3_sns_vq_kernel + lc3_enc_back_kernel)":
@@ -726,7 +726,7 @@ def run_rank(args):
                 "pmc": pmc_note,
                 "note": "instruction/latency-bound, not HBM-bound (SURVEY 8d honesty note): ~60 flop per algorithmic byte. "
                         "achieved = algorithmic bytes of the dominant unit / the sum of its kernels' launch durations in a step (HIP events on the "
-                        "launch streams; a full batch runs as two half launches side by side, whose durations are summed as rocprofv3 totals them); "
+                        "launch streams; one launch per kernel and step); "
                         "traffic = FETCH_SIZE + WRITE_SIZE of the dominant unit per step in BYTES (FETCH_SIZE doubled for the kernels whose reads are "
                         "16-byte-per-lane coalesced, MI355X_MICROARCH.md), traffic_whole_step the same over every kernel of the step; measured_copy_GBs = "
                         "what a 16-byte-per-lane copy kernel reaches on this chip (read + write), beside the 8 TB/s vendor figure `frac` divides by; "
@@ -777,7 +777,9 @@ def run_rank(args):
         print(json.dumps(line), file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    return 0
+    # a run whose parity gate found a difference is a FAILED run: the line above says so (`parity_mismatches_all_ranks`), and so does
+    # the exit code of every rank (the count is reduced over the ranks), so that a driver looking at `rc` never books its `value`
+    return 3 if total_mismatches > 0 else 0
 
 
 def main():

@@ -167,6 +167,13 @@ int lc3gpu_decoder_state_save(lc3gpu_decoder *dec, void *host_dst, size_t nbytes
 int lc3gpu_decoder_state_load(lc3gpu_decoder *dec, const void *host_src, size_t nbytes);
 /* total number of frames concealed so far over all channels (synchronises the device) */
 int lc3gpu_decoder_plc_events(lc3gpu_decoder *dec, uint64_t *out);
+/* Full batches run the bit packer and the bitstream parser as producer / consumer pairs of wavefronts.  A half that waits 2^24 polls for
+ * its partner gives up (a partner that died: never seen): a parser pair then conceals its frames as the reference conceals a frame whose
+ * read_frame failed (decoder/lc3_decoder.rs:138-141; they count as PLC events too), a packer pair leaves its frames ZERO-FILLED -- the
+ * reference has no such case (`Lc3EncoderError` is empty, encoder/lc3_encoder.rs:29-30), so it is made visible here: *out = the number of
+ * pair halves that ever gave up on this handle (sticky; 0 in every run so far).  Waits for the handle's work in flight. */
+int lc3gpu_encoder_pair_timeouts(lc3gpu_encoder *enc, uint64_t *out);
+int lc3gpu_decoder_pair_timeouts(lc3gpu_decoder *dec, uint64_t *out);
 
 /* ---- diagnostics -------------------------------------------------------------------------------- */
 /* encode one frame of channel 0 from host PCM (the frame IS a frame of that channel: its state advances) and also return stage dumps,
@@ -261,7 +268,10 @@ int lc3gpu_prof_read(unsigned long long out[64]);
  * `spin` dependent vector additions; asynchronous, d_out (DEVICE memory, 3 x uint64) <- {shader cycles, 100 MHz ticks, unused}.  The clock the
  * chip runs at while the probe is in flight = 100 MHz x cycles / ticks (launch it on a stream beside the codec's). */
 int lc3gpu_clock_probe(void *stream, unsigned long long *d_out, int spin);
-/* kernel resource report: out = {lds_bytes, vgprs, sgprs, scratch_bytes, max_threads} for 0 = encoder, 1 = decoder */
+/* kernel resource report as the loaded code object has it: out = {static lds_bytes, vgprs, 0, scratch_bytes, max_threads} for the six kernels
+ * a full batch of the headline configuration launches: which = 0 analysis front half, 1 SNS vector quantiser, 2 analysis back half,
+ * 3 packer (pair form), 4 parser (pair form), 5 synthesis.  (tests/test_kernel_resources.py reads the same, and the spill counts, from the
+ * built library's metadata without a GPU and holds them to the register budgets the kernels are tuned for.) */
 int lc3gpu_kernel_info(int which, int out[5]);
 
 #ifdef __cplusplus

@@ -62,6 +62,12 @@ public:
         int rc = lc3gpu_encode_mixed(h_, d_pcm, d_out, n_frames, hip_stream);
         if (rc) throw Error(rc, "encode_mixed");
     }
+    uint64_t pair_timeouts() {
+        uint64_t v = 0;
+        int rc = lc3gpu_encoder_pair_timeouts(h_, &v);
+        if (rc) throw Error(rc, "pair_timeouts");
+        return v;
+    }
     lc3gpu_encoder *handle() { return h_; }
 
 private:
@@ -107,6 +113,12 @@ public:
         uint64_t v = 0;
         int rc = lc3gpu_decoder_plc_events(h_, &v);
         if (rc) throw Error(rc, "plc_events");
+        return v;
+    }
+    uint64_t pair_timeouts() {
+        uint64_t v = 0;
+        int rc = lc3gpu_decoder_pair_timeouts(h_, &v);
+        if (rc) throw Error(rc, "pair_timeouts");
         return v;
     }
     lc3gpu_decoder *handle() { return h_; }

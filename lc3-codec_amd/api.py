@@ -72,53 +72,93 @@ def _translation_units():
     return [(0, 0)] + [(k, v) for v in range(n_base + 1, n_all + 1) for k in (1, 3)] + [(2, k) for k in range(8)]
 
 
+def _build_signature(single, extra, extra_main, units):
+    """what a built library depends on beside the sources' mtimes (advisor, round 4: switching LC3_SINGLE_TU / LC3_HIPCC_EXTRA used to leave
+    a library of the other flavour in place)"""
+    return "single=%d extra=%s extra_main=%s units=%s profile=%d\n" % (single, " ".join(extra), " ".join(extra_main),
+                                                                      ",".join("%d_%d" % u for u in units), _PROFILE)
+
+
 def build_native(force=False, verbose=False):
     """Compile csrc/lc3gpu.hip for gfx950 into lib/liblc3gpu.so (hipcc cross-compiles without a GPU).  The default library is built from
     several translation units of the same source side by side (device code generation is serial inside one unit; LC3_BUILD_JOBS, default
     the CPUs this process may use) and carries a compile-time view of every standard configuration; LC3_SINGLE_TU=1, the diagnostic build
-    (LC3GPU_PROFILE=1) and builds with LC3_HIPCC_EXTRA compile it whole, with the four views of the round-1..4 library."""
+    (LC3GPU_PROFILE=1) and builds with LC3_HIPCC_EXTRA compile it whole, with the four views of the round-1..4 library.
+    LC3_HIPCC_EXTRA_MAIN="-D..." (timing experiments on the headline kernels): the multi-unit build with those flags on the MAIN unit only;
+    the other units' objects are the production ones.  A library remembers the switches it was built with (<lib>.stamp) and is rebuilt
+    when they differ; experiment builds need their own file name (LC3GPU_LIB) so that they never replace the default library."""
     srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
     srcs += [os.path.join(_ROOT, "include", "lc3gpu.h"), os.path.join(_ROOT, "tables", "lc3_tables.h")]
-    if not force and os.path.exists(_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(_LIB) for s in srcs):
+    extra = os.environ.get("LC3_HIPCC_EXTRA", "").split()  # compiler experiments
+    extra_main = os.environ.get("LC3_HIPCC_EXTRA_MAIN", "").split()
+    if (extra or extra_main) and not os.environ.get("LC3GPU_LIB"):
+        raise RuntimeError("LC3_HIPCC_EXTRA / LC3_HIPCC_EXTRA_MAIN builds are experiments: name their library with LC3GPU_LIB=liblc3gpu_<what>.so")
+    single = _PROFILE or bool(extra) or os.environ.get("LC3_SINGLE_TU", "0") == "1"
+    units = [] if single else _translation_units()
+    sig = _build_signature(single, extra, extra_main, units)
+    stamp = _LIB + ".stamp"
+    try:
+        with open(stamp) as f:
+            same = f.read() == sig
+    except OSError:
+        same = False
+    if not force and same and os.path.exists(_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(_LIB) for s in srcs):
         return _LIB
     os.makedirs(os.path.dirname(_LIB), exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function",
              "-Wno-missing-braces"]
-    extra = os.environ.get("LC3_HIPCC_EXTRA", "").split()  # compiler experiments
-    single = _PROFILE or bool(extra) or os.environ.get("LC3_SINGLE_TU", "0") == "1"
     if single:
         cmd = ["hipcc"] + extra + (["-DLC3_PROFILE"] if _PROFILE else []) + flags + ["-shared", "-o", _LIB, _SRC]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(sig)
         return _LIB
     from concurrent.futures import ThreadPoolExecutor
 
     objdir = os.path.join(os.path.dirname(_LIB), "obj")
     os.makedirs(objdir, exist_ok=True)
-    units = _translation_units()
+    tag = os.path.splitext(os.path.basename(_LIB))[0]
+
+    def unit_obj(u):  # an experiment's main unit gets an object of its own; every other object is shared with the production build
+        return os.path.join(objdir, ("%s_0_0.o" % tag) if (extra_main and u == (0, 0)) else "lc3gpu_%d_%d.o" % u)
 
     def compile_unit(u):
-        obj = os.path.join(objdir, "lc3gpu_%d_%d.o" % u)
-        cmd = ["hipcc", "-DLC3_TU_KIND=%d" % u[0], "-DLC3_TU_INDEX=%d" % u[1]] + flags + ["-c", "-o", obj, _SRC]
-        subprocess.check_call(cmd)
+        obj, tmp = unit_obj(u), unit_obj(u) + ".tmp%d" % os.getpid()
+        cmd = ["hipcc", "-DLC3_TU_KIND=%d" % u[0], "-DLC3_TU_INDEX=%d" % u[1]] + (extra_main if u == (0, 0) else []) + flags + ["-c", "-o", tmp, _SRC]
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, obj)  # (a unit that fails leaves no partial object behind)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
         return obj
+
+    def fresh(u):
+        o = unit_obj(u)
+        return os.path.exists(o) and all(os.path.getmtime(s) <= os.path.getmtime(o) for s in srcs)
 
     try:
         jobs = len(os.sched_getaffinity(0))
     except AttributeError:
         jobs = os.cpu_count() or 1
     jobs = max(1, int(os.environ.get("LC3_BUILD_JOBS", jobs)))
-    if verbose:
-        print("hipcc -DLC3_TU_KIND=k -DLC3_TU_INDEX=i %s -c %s   x %d translation units, %d at a time" % (" ".join(flags), _SRC, len(units), jobs))
-    # (the main unit and the mixed-kernel units are the long ones: first)
+    # (the main unit and the mixed-kernel units are the long ones: first).  Objects newer than every source are kept unless forced; an
+    # experiment build never recompiles the shared ones it finds up to date
     order = sorted(units, key=lambda u: (u[0] != 0, u[0] != 2))
+    todo = [u for u in order if (force and (not extra_main or u == (0, 0))) or not fresh(u)]
+    if verbose:
+        print("hipcc -DLC3_TU_KIND=k -DLC3_TU_INDEX=i %s -c %s   x %d of %d translation units, %d at a time" % (
+            " ".join(flags), _SRC, len(todo), len(units), jobs))
     with ThreadPoolExecutor(max_workers=jobs) as pool:
-        objs = list(pool.map(compile_unit, order))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", _LIB] + sorted(objs)
+        list(pool.map(compile_unit, todo))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", _LIB] + sorted(unit_obj(u) for u in units)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(sig)
     return _LIB
 
 
@@ -196,6 +236,8 @@ def load_library():
     L.lc3gpu_decoder_create_mixed.argtypes = [ctypes.POINTER(vp), i, vp]
     L.lc3gpu_decode_mixed.argtypes = [vp, vp, vp, vp, i, vp]
     L.lc3gpu_decoder_plc_events.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.lc3gpu_encoder_pair_timeouts.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.lc3gpu_decoder_pair_timeouts.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.lc3gpu_kernel_info.argtypes = [i, vp]
     L.lc3gpu_encoder_timing.argtypes = [vp, i, vp]
     L.lc3gpu_decoder_timing.argtypes = [vp, i, vp]
@@ -221,7 +263,7 @@ ABI_SYMBOLS = [
     "lc3gpu_decoder_plc_events", "lc3gpu_encode_frame_debug", "lc3gpu_kernel_info", "lc3gpu_prof_read", "lc3gpu_encoder_timing", "lc3gpu_decoder_timing",
     "lc3gpu_decoder_timing_kernels", "lc3gpu_decode_frame_debug", "lc3gpu_decoder_synth_debug", "lc3gpu_selftest_math", "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
     "lc3gpu_decode_mixed", "lc3gpu_encoder_create_spec", "lc3gpu_encoder_create_mixed_spec", "lc3gpu_clock_probe",
-    "lc3gpu_encoder_stage_event", "lc3gpu_decoder_stage_event",
+    "lc3gpu_encoder_stage_event", "lc3gpu_decoder_stage_event", "lc3gpu_encoder_pair_timeouts", "lc3gpu_decoder_pair_timeouts",
 ]
 
 # LC3GPU_SPEC_*: opt-in corrections of the reference's deviations from the LC3 specification (default 0 = reference behaviour)
@@ -427,6 +469,14 @@ class Lc3Encoder:
         if rc:
             raise Lc3EncoderError(rc, "reset")
 
+    def pair_timeouts(self):
+        """producer / consumer pair halves of the packer that ever gave up on their partner (include/lc3gpu.h); 0 unless a wave died"""
+        v = ctypes.c_uint64()
+        rc = self._L.lc3gpu_encoder_pair_timeouts(self._h, ctypes.byref(v))
+        if rc:
+            raise Lc3EncoderError(rc, "pair_timeouts")
+        return int(v.value)
+
     def state_save(self):
         n = self._L.lc3gpu_encoder_state_size(self._h) * self.num_channels
         buf = np.zeros(n, np.uint8)
@@ -579,6 +629,14 @@ class Lc3Decoder:
         rc = self._L.lc3gpu_decoder_plc_events(self._h, ctypes.byref(v))
         if rc:
             raise Lc3DecoderError(rc, "plc_events")
+        return int(v.value)
+
+    def pair_timeouts(self):
+        """producer / consumer pair halves of the parser that ever gave up on their partner (include/lc3gpu.h); 0 unless a wave died"""
+        v = ctypes.c_uint64()
+        rc = self._L.lc3gpu_decoder_pair_timeouts(self._h, ctypes.byref(v))
+        if rc:
+            raise Lc3DecoderError(rc, "pair_timeouts")
         return int(v.value)
 
     def state_save(self):

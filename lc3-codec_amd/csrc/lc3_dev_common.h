@@ -20,6 +20,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "lc3_dev_experiments.h"
+
 #define LC3_TABLE_QUAL static __device__ const
 #include "../../tables/lc3_tables.h"
 

@@ -12,12 +12,6 @@
 // follows (the output stage), and the loads of the next frame's plane column -- issued at the top of a frame -- get the inlined
 // IMDCT's worth of work before the first call (the LTPF) drains them (IMDCT as a call: synthesis 0.146 ms, inlined 0.134 ms).
 #ifndef LC3_DEC_STAGE
-// LC3_DEC_KO: timing experiments only (knock-out builds, LC3_HIPCC_EXTRA=-DLC3_DEC_KO=n: the output is garbage): 1 no load / store of the
-// state blob's core part, 2 no overlap-memory load / store, 4 no copy of the last good spectrum, 8 no inverse transform, 16 no post-filter,
-// 32 no PCM stores, 64 no plane loads
-#ifndef LC3_DEC_KO
-#define LC3_DEC_KO 0
-#endif
 #define LC3_DEC_STAGE __noinline__
 #define LC3_DEC_STAGE_HOT __forceinline__
 #endif

@@ -641,7 +641,8 @@ __device__ __forceinline__ void lc3_recon_scf(const lc3_recon_ctx &r, const lc3_
 // follows the entries it covers) and waits when the consumer falls a ring behind; the consumer publishes what it has taken.
 // ------------------------------------------------------------------------------------------------------------------
 // the producer: side information (flags only), range decoder start, TNS data, then the symbols
-__device__ __forceinline__ void lc3_pc_produce(lc3_parse_ctx &c, const lc3_pc_link &k, int ne, int fs_ind, int n_ms_10, int rc_in) {
+// returns non-zero when it gave up waiting for the consumer (LC3_PC_SPIN_LIMIT polls: a partner that died; counted by the kernel)
+__device__ __forceinline__ int lc3_pc_produce(lc3_parse_ctx &c, const lc3_pc_link &k, int ne, int fs_ind, int n_ms_10, int rc_in) {
     int lastnz = 0, lsb_mode = 0, num_tns = 0, ord[2] = {0, 0};
     int dead = rc_in != 0;
     if (!dead) dead = lc3_parse_side_info<0>(c, fs_ind, ne, lastnz, lsb_mode, num_tns, ord) != 0;
@@ -675,7 +676,7 @@ __device__ __forceinline__ void lc3_pc_produce(lc3_parse_ctx &c, const lc3_pc_li
     LC3_PC_STORE(k.p_count, 0);
     // decode_spectral_data :211-302 -- the recurrence only (see lc3_parse_frame for the whole of it)
     const int ntup = dead ? 0 : lastnz / 2;
-    int err = 0, it = 0;
+    int err = 0, it = 0, gave_up = 0;
     {
         const int rate_flag = nbits > (160 + fs_ind * 160) ? 512 : 0;
         const int hi_from = ne / 2;
@@ -719,13 +720,15 @@ __device__ __forceinline__ void lc3_pc_produce(lc3_parse_ctx &c, const lc3_pc_li
                 }
             }
         }
-        err |= spins >= LC3_PC_SPIN_LIMIT;
+        gave_up = spins >= LC3_PC_SPIN_LIMIT;
+        err |= gave_up;
     }
     k.fin[k.fstride] = st.range;
     k.fin[2 * k.fstride] = (uint32_t)c.head;
     k.fin[3 * k.fstride] = (uint32_t)(dead | (err != 0));
     LC3_PC_RELEASE();  // the TNS words in the plane and the hand-over words are out before ...
     LC3_PC_STORE(k.p_count, it | LC3_PC_DONE);
+    return gave_up;
 }
 
 // the consumer: side information (to the plane), then everything of decode_spectral_data that only consumes symbols, then the rest of
@@ -733,12 +736,11 @@ __device__ __forceinline__ void lc3_pc_produce(lc3_parse_ctx &c, const lc3_pc_li
 // r / scf_out (optional): the reconstruction context and 16 registers for the frame's scale factors, which only need the side
 // information: computed here while the producer is still at its start (the ring lies in the lane's scale-factor slots in LDS, so
 // they stay in registers until the symbols are through)
-#ifndef LC3_PCPARSE_KO
-#define LC3_PCPARSE_KO 0  // timing experiments only: 2 = a consumer that only follows the producer through the symbols (profiles/r04_parse_halves.txt)
-#endif
+// timed_out (optional): set when the consumer gave up waiting for the producer (the frame then counts as one that did not parse: it is
+// concealed, and the kernel counts the event -- lc3gpu_decoder_pair_timeouts)
 template <int COUNT>
 __device__ __forceinline__ int lc3_pc_consume(lc3_parse_ctx &c, const lc3_pc_link &k, int ne, int fs_ind, int rc_in,
-                                              const lc3_recon_ctx *r = nullptr, float *scf_out = nullptr) {
+                                              const lc3_recon_ctx *r = nullptr, float *scf_out = nullptr, int *timed_out = nullptr) {
     int lastnz = 0, lsb_mode = 0, num_tns = 0, ord[2] = {0, 0};
     c.nnz = 0;
     c.seed = 0;
@@ -756,8 +758,9 @@ __device__ __forceinline__ int lc3_pc_consume(lc3_parse_ctx &c, const lc3_pc_lin
         LC3_PC_PAUSE();
         spins++;
     }
-    c.head = (int)k.fin[0];
-    const int dead = rc != 0 || k.fin[3 * k.fstride] != 0u;  // (the producer's own start can fail: ac_dec_init, the TNS data)
+    const int never = pc < 0;  // the producer never answered: nothing in the ring or the hand-over words means anything
+    c.head = never ? 0 : (int)k.fin[0];
+    const int dead = rc != 0 || never || k.fin[3 * k.fstride] != 0u;  // (the producer's own start can fail: ac_dec_init, the TNS data)
     const int ntup = dead ? 0 : lastnz / 2;
     int lev_end = 0, err = 0, it = 0;
     {
@@ -767,7 +770,7 @@ __device__ __forceinline__ int lc3_pc_consume(lc3_parse_ctx &c, const lc3_pc_lin
         c.tnext = lc3_p_tail_byte(c, (c.tail >> 3) + 1);
         // whole chunks of LC3_PC_CHUNK iterations, straight-line (see the producer); the producer's count is whole chunks, the wave's last
         // one padded with iterations in which every lane idles
-        for (;;) {
+        for (; !never;) {
             while ((((pc = LC3_PC_LOAD(k.p_count)) & (LC3_PC_DONE - 1)) <= it) && !(pc & LC3_PC_DONE) && spins < LC3_PC_SPIN_LIMIT) {
                 LC3_PC_PAUSE();
                 spins++;
@@ -835,6 +838,7 @@ __device__ __forceinline__ int lc3_pc_consume(lc3_parse_ctx &c, const lc3_pc_lin
     const uint32_t range = k.fin[k.fstride];
     c.head = (int)k.fin[2 * k.fstride];
     err |= (int)k.fin[3 * k.fstride] | (spins >= LC3_PC_SPIN_LIMIT) | (c.head > c.len);
+    if (timed_out) *timed_out = spins >= LC3_PC_SPIN_LIMIT;
     if (rc) return rc;
     if (dead) return -2;
     if (err) return -4;

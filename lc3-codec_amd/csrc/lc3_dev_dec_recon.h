@@ -22,12 +22,6 @@
 // The arithmetic per line is that of lc3_reconstruct_frame / lc3_dec_reconstruct_wave, operation for operation.
 #pragma once
 #include "lc3_dev_dec.h"
-#ifndef LC3_TNS_KO
-#define LC3_TNS_KO 0
-#endif
-#ifndef LC3_RECON_KO
-#define LC3_RECON_KO 0  // timing experiments only: 4 no scale factors / band gains, 8 no line work
-#endif
 
 // per workgroup (4.4 KB)
 struct __attribute__((aligned(16))) lc3_recon_tables {

@@ -58,14 +58,6 @@ struct __attribute__((aligned(16))) lc3_enc_lds {
     unsigned long long prof_acc[32];  // diagnostic build: per-wave stage totals, flushed once per launch
 #endif
 };
-// LC3_ENC_KO: timing experiments only (knock-out builds, LC3_HIPCC_EXTRA=-DLC3_ENC_KO=n: the output is garbage): 1 no MDCT, 2 no bandwidth
-// (inside the LTPF stage also: 2048 no 17-lag correlations, 4096 no activation products, 8192 no float copy of the resampler's window, 16384 no
-// squares / normalised values, 32768 no activation sums)
-// detector, 4 no attack detector, 8 no SNS targets, 16 no LTPF analysis, 32 no high-pass recursion, 64 no 98-lag correlations, 128 no
-// resampler sums, 256 no TNS, 512 no quantiser, 1024 no residual / noise stage
-#ifndef LC3_ENC_KO
-#define LC3_ENC_KO 0
-#endif
 #define LC3_ENC_DBG_EB 1472      // [64] band energies
 #define LC3_ENC_DBG_ATTACK 1536  // [5] attack detector state: energy_last, max_energy_last, attack_pos_last, downsampled t-1, t-2
 #define LC3_ENC_DBG_FLOATS 1600
@@ -513,6 +505,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
     // compute_normalized_autocorrelation :80-115 -- one lane per (filter, lag, sub-block) partial sum, every sum in the
     // reference's order.  The sub-block energy e_s (:88-93) is the lag-0 sum of its sub-block -- the same products added in the
     // same order -- so the lag-0 lanes supply it.  A lane's sum has 50..70 terms: blocks of eight, the last one masked.
+    LC3_ENC_REPEAT(16) {
     if (lane < 54) {
         const int f = lane / 27, r = lane - 27 * f, k = r / 3, s = r - 3 * k;
         float ac = 0.0f;
@@ -552,10 +545,12 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
         sAC[lane] = sAC[lane] / sES[f * 3 + s3];
     }
     LC3_SYNC();
+    }
     LC3_STAMP(L, lane, 28);
     // Levinson-Durbin :204-232 and the LPC -> reflection conversion :234-265: one lane per filter, the order-8
     // recursions fully unrolled on register arrays.
     int tns_on = 0;  // lanes 0 / 1: the filter's prediction gain passes :219
+    LC3_ENC_REPEAT(32)
     if (lane < 2 && lane < tp.num) {
         const int f = lane;
         float r[9];
@@ -1424,6 +1419,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
     // compute_spectral_energy :390-395 -- one lane per 4-line group (two groups per lane, kept in registers together
     // with the two products of the energy that the gain search needs)
     float e14[2], e28[2], amax = 0.0f;
+    LC3_ENC_REPEAT(1)
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int n = lane + LC3_WAVE * q;
@@ -1449,7 +1445,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
     // the chain of dependent additions; otherwise (about one step in 10^4) the step repeats the sum in the reference's
     // order.  LC3_SPEC_TEST_SEQ_SUMS forces that path (tests).
     int gg_min = 0, reset_offset = 0, gg_ind_u = 0;
-    {
+    LC3_ENC_REPEAT(2) {
         int fac = 256, gg_ind = 255;
         float *tv = (float *)L.fa;  // the terms of one step in the reference's order (sequential path only)
         const float thr = (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f;
@@ -1506,6 +1502,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
     LC3_SYNC();
     LC3_STAMP(L, lane, 10);
     lc3_bitcons bc = lc3_quantize_spectrum(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, gg_off, gg_ind, nbits_spec);
+    LC3_ENC_REPEAT_MORE(4) bc = lc3_quantize_spectrum(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, gg_off, gg_ind, nbits_spec);
     LC3_STAMP(L, lane, 11);
     // save state after the FIRST pass :97-100
     if (lane == 0) {
@@ -1532,7 +1529,8 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
             else gg_ind += 2;
             if (gg_ind < gg_min) gg_ind = gg_min;
         }
-        if (origin != gg_ind) bc = lc3_quantize_spectrum(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, gg_off, gg_ind, nbits_spec);
+        if (origin != gg_ind)
+            LC3_ENC_REPEAT(8) bc = lc3_quantize_spectrum(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, gg_off, gg_ind, nbits_spec);
     }
     res.gg_ind = gg_ind;
     res.nbits_spec = nbits_spec;
@@ -1897,7 +1895,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PA
     if (lane < 4) L.ism[lane] = m.flag;
     if (lane < c.nb) gs[lane] = m.g;
     LC3_SYNC();
-    {
+    LC3_ENC_REPEAT(128) {
         const int n4 = c.nf / 4;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
@@ -1937,7 +1935,8 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PA
     if (LC3_ENC_KO & 512) spec.lastnz_trunc = 2, spec.gg = 1.0f;
     else spec = lc3_enc_quant(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, nbits_bw, tns.nbits_tns, nbits_ltpf);
     LC3_STAMP(L, lane, 6);
-    const int rn = (LC3_ENC_KO & 1024) ? 0 : lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
+    int rn = (LC3_ENC_KO & 1024) ? 0 : lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
+    LC3_ENC_REPEAT_MORE(64) rn = lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
     LC3_STAMP(L, lane, 7);
     const int n_res = rn & 0xffff, noise_factor = rn >> 16;
     if (dbg && lane == 0) {

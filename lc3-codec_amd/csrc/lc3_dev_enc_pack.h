@@ -482,11 +482,10 @@ __device__ __forceinline__ void lc3_pack_frame(lc3_pack_ctx &w, int ne) {
 // one per four cycles; here two waves of one SIMD share them.
 // ------------------------------------------------------------------------------------------------------------------
 #define LC3_PK_SYM_VALID 0x80000000u
-#ifndef LC3_PKPC_KO
-#define LC3_PKPC_KO 0  // timing experiments only: 1 = a producer that costs nothing, 2 = a consumer that codes nothing (profiles/r04_pack_halves.txt)
-#endif
 // fin words of the link: [0] the number of LSB-list bits (:298-312)
-__device__ __forceinline__ void lc3_pack_produce(const lc3_pack_ctx &w, const lc3_pc_link &k, int ne, int valid) {
+// Both halves return non-zero when they gave up waiting for their partner (LC3_PC_SPIN_LIMIT polls: a partner that died); the kernel
+// counts those (lc3gpu_encoder_pair_timeouts) and the consumer leaves such a frame ZERO-FILLED rather than half written.
+__device__ __forceinline__ int lc3_pack_produce(const lc3_pack_ctx &w, const lc3_pc_link &k, int ne, int valid) {
     const int lsb_mode = lc3_ep_get(w, EP_LSB_MODE), lastnz_trunc = lc3_ep_get(w, EP_LASTNZ_TRUNC), rate_flag = lc3_ep_get(w, EP_RATE_FLAG);
     const int ntup = valid ? lastnz_trunc / 2 : 0, last = ne / 2 - 1;
     int tup = 0, lev = 0, cctx = 0, nlsbs = 0, it = 0, c_seen = 0, spins = 0;
@@ -549,9 +548,10 @@ __device__ __forceinline__ void lc3_pack_produce(const lc3_pack_ctx &w, const lc
     }
     k.fin[0] = (uint32_t)nlsbs;
     LC3_PC_STORE(k.p_count, it | LC3_PC_DONE);
+    return spins >= LC3_PC_SPIN_LIMIT;
 }
 
-__device__ __forceinline__ void lc3_pack_consume(lc3_pack_ctx &w, const lc3_pc_link &k, int ne, int valid) {
+__device__ __forceinline__ int lc3_pack_consume(lc3_pack_ctx &w, const lc3_pc_link &k, int ne, int valid) {
     lc3_pack_head h;
     lc3_pack_load_head(w, h);
     if (valid) lc3_pack_begin(w, ne, h);
@@ -575,6 +575,10 @@ __device__ __forceinline__ void lc3_pack_consume(lc3_pack_ctx &w, const lc3_pc_l
         LC3_PC_STORE(k.c_count, it);
     }
     LC3_PC_STORE(k.c_count, LC3_PC_DONE - 1);
+    const int timed_out = spins >= LC3_PC_SPIN_LIMIT;  // (the wave's, not the lane's: the counts are per wave)
     const int nlsbs = (int)k.fin[0];
-    if (valid) lc3_pack_end(w, ne, h, nlsbs);
+    if (valid && !timed_out) lc3_pack_end(w, ne, h, nlsbs);
+    if (valid && timed_out)  // the symbols never came: no frame rather than a truncated one
+        for (int i = 0; i < w.nbytes; i++) w.buf[i] = 0;
+    return timed_out;
 }

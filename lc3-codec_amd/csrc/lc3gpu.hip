@@ -159,6 +159,13 @@ __shared__ lc3_spec_tables lc3_spec_tab;
          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(p))))
 #define LC3_KEEP_SCALAR(x) asm("" : "+v"(x))
 #define LC3_KEEP_PER_FRAME(x) asm volatile("" : "+v"(x))
+// repeat builds (lc3_dev_experiments.h): a 2 in a scalar register that the compiler cannot fold
+static __device__ __forceinline__ int lc3_exp_two() {
+    int n = 2;
+    asm volatile("" : "+s"(n) : : "memory");
+    return n;
+}
+#define LC3_EXP_TWO() lc3_exp_two()
 // product of two values below 2^24 (range-coder steps): the full-rate 24-bit multiplier instead of the quarter-rate v_mul_lo_u32
 #define LC3_MUL24(a, b) __umul24((a), (b))
 #define LC3_WAVE_ANY(pred) (__ballot((pred) != 0) != 0ull)
@@ -845,8 +852,9 @@ static __host__ __device__ inline size_t lc3_pack_pc_lds(unsigned fpb, int nbyte
     const size_t base = (LC3_PACK_LDS_FIXED + (size_t)fpb * (size_t)nbytes + 4 + 15) & ~(size_t)15;  // ... + the packer's sink byte
     return base + (size_t)(fpb / 64) * (LC3_PKPC_RING * 64 * 4 + 64 * 4) + 64;
 }
+// pc_timeouts: the handle's sticky count of pair halves that gave up on their partner (lc3gpu_encoder_pair_timeouts)
 __device__ __forceinline__ void lc3_pack_pc_body(unsigned wg, int ne, const int32_t *planes, uint8_t *out, int nbytes, int n_frames, int T,
-                                                 int first_channel, lc3_io io) {
+                                                 int first_channel, lc3_io io, unsigned *pc_timeouts) {
     LC3_LANE_KERNEL_BEGIN();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_lookup = smem;
@@ -901,8 +909,8 @@ __device__ __forceinline__ void lc3_pack_pc_body(unsigned wg, int ne, const int3
         k.p_count = s_cnt + 2 * pair;
         k.c_count = s_cnt + 2 * pair + 1;
         k.fin = s_fin + pair * 64 + lane;
-        if (role == 0) lc3_pack_produce(c, k, ne, valid);
-        else lc3_pack_consume(c, k, ne, valid);
+        const int gave_up = role == 0 ? lc3_pack_produce(c, k, ne, valid) : lc3_pack_consume(c, k, ne, valid);
+        if (gave_up && lane == 0) atomicAdd(pc_timeouts, 1u);  // (per wave: the link's counts are the wave's)
     }
     __syncthreads();
     if (io.ilv || io.tab) {  // frame f = s * T + t has its own place: one frame after the other, its bytes spread over the threads
@@ -925,15 +933,16 @@ __device__ __forceinline__ void lc3_pack_pc_body(unsigned wg, int ne, const int3
 }
 #if LC3_IN_HOST_TU
 __global__ __launch_bounds__(512) void lc3_pack_pc_kernel(int ne, const int32_t *planes, uint8_t *out, int nbytes, int n_frames, int T,
-                                                          lc3_io io) {
-    lc3_pack_pc_body(blockIdx.x, ne, planes, out, nbytes, n_frames, T, 0, io);
+                                                          lc3_io io, unsigned *pc_timeouts) {
+    lc3_pack_pc_body(blockIdx.x, ne, planes, out, nbytes, n_frames, T, 0, io, pc_timeouts);
 }
 #endif
 #if LC3_IN_HOST_TU
-__global__ __launch_bounds__(512) void lc3_pack_pc_mixed_kernel(lc3_groups G, const int32_t *planes, uint8_t *out, int T, lc3_io io) {
+__global__ __launch_bounds__(512) void lc3_pack_pc_mixed_kernel(lc3_groups G, const int32_t *planes, uint8_t *out, int T, lc3_io io,
+                                                                unsigned *pc_timeouts) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     lc3_pack_pc_body(blockIdx.x - g.wg_frame, g.ne, planes + (size_t)g.frame_base * (size_t)EP_WORDS, out, g.nbytes, g.n_streams * T, T,
-                     g.first_stream, io);
+                     g.first_stream, io, pc_timeouts);
 }
 #endif
 
@@ -1090,7 +1099,7 @@ static __host__ __device__ inline size_t lc3_parse_pc_lds(unsigned fpb, int nbyt
 }
 template <class CV>
 __device__ __forceinline__ void lc3_parse_pc_body(lc3_cfg_slot<CV> cfg, unsigned wg, const uint8_t *in, const uint8_t *bad, int32_t *planes,
-                                                  int nbytes, int n_frames, int T, int first_channel, lc3_io io) {
+                                                  int nbytes, int n_frames, int T, int first_channel, lc3_io io, unsigned *pc_timeouts) {
     LC3_LANE_KERNEL_BEGIN();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
@@ -1168,8 +1177,8 @@ __device__ __forceinline__ void lc3_parse_pc_body(lc3_cfg_slot<CV> cfg, unsigned
         const size_t fb = lc3_io_flag_idx(io, first_channel, f / (size_t)T, f % (size_t)T, T);  // the flag array follows the frame layout
         rc_in = (bad && bad[fb]) ? -100 : 0;
     }
-    if (role == 0) {
-        lc3_pc_produce(c, k, ne, fs_ind, n_ms_10, rc_in);
+    if (role == 0) {  // pc_timeouts: the handle's sticky count of pair halves that gave up on their partner (lc3gpu_decoder_pair_timeouts)
+        if (lc3_pc_produce(c, k, ne, fs_ind, n_ms_10, rc_in) && lane == 0) atomicAdd(pc_timeouts, 1u);
         return;
     }
     lc3_recon_ctx r;
@@ -1178,26 +1187,28 @@ __device__ __forceinline__ void lc3_parse_pc_body(lc3_cfg_slot<CV> cfg, unsigned
     r.mpvq = s_mpvq;
     r.ifs = s_ifs;
     float scf[16];
-    int ok = lc3_pc_consume<1>(c, k, ne, fs_ind, rc_in, &r, scf) == 0;
+    int gave_up = 0;
+    int ok = lc3_pc_consume<1>(c, k, ne, fs_ind, rc_in, &r, scf, &gave_up) == 0;
+    if (gave_up && lane == 0) atomicAdd(pc_timeouts, 1u);  // (per wave: the link's counts are the wave's; its frames are concealed)
     if (ok) ok = lc3_reconstruct_frame(c, r, c0, scf);
     if (valid) lc3_px_set(c, AD_OK, ok);
 }
 template <class CV>
 __global__ __launch_bounds__(512) void lc3_parse_pc_kernel(lc3_cfg_slot<CV> cfg, const uint8_t *in, const uint8_t *bad, int32_t *planes,
-                                                           int nbytes, int n_frames, int T, lc3_io io) {
-    lc3_parse_pc_body<CV>(cfg, blockIdx.x, in, bad, planes, nbytes, n_frames, T, 0, io);
+                                                           int nbytes, int n_frames, int T, lc3_io io, unsigned *pc_timeouts) {
+    lc3_parse_pc_body<CV>(cfg, blockIdx.x, in, bad, planes, nbytes, n_frames, T, 0, io, pc_timeouts);
 }
 #if LC3_IN_MIXED_TU(3)
 __global__ __launch_bounds__(512) void LC3_MIXED_KERNEL(lc3_parse_pc_mixed_kernel)(lc3_groups G, const uint8_t *in, const uint8_t *bad, int32_t *planes, int T,
-                                                                 lc3_io io) {
+                                                                 lc3_io io, unsigned *pc_timeouts) {
     const lc3_group &g = G.g[lc3_find_group(G, blockIdx.x, 1)];
     int32_t *p = planes + (size_t)g.frame_base * (size_t)LC3_PLANE_WORDS;
-    LC3_GROUP_VIEW(lc3_parse_pc_body, g, blockIdx.x - g.wg_frame, in, bad, p, g.nbytes, g.n_streams * T, T, g.first_stream, io);
+    LC3_GROUP_VIEW(lc3_parse_pc_body, g, blockIdx.x - g.wg_frame, in, bad, p, g.nbytes, g.n_streams * T, T, g.first_stream, io, pc_timeouts);
 }
 #endif
 #if LC3_MULTI_TU && LC3_TU_KIND == 0
 __global__ __launch_bounds__(512) void lc3_parse_pc_mixed_kernel_all(lc3_groups G, const uint8_t *in, const uint8_t *bad, int32_t *planes, int T,
-                                                                 lc3_io io);
+                                                                 lc3_io io, unsigned *pc_timeouts);
 #endif
 
 // Spectrum reconstruction D4-D8 of a full batch (lc3_dev_dec_recon.h), between the parser and the synthesis kernel:
@@ -1391,7 +1402,7 @@ LC3_FOR_EACH_VIEW_ALL(LC3_X)
 #define LC3_VIEW_DEC_KERNELS(T, CV)                                                                                                          \
     T template __global__ void lc3_parse_kernel<CV>(lc3_cfg_slot<CV>, const uint8_t *, const uint8_t *, int32_t *, int, int, int, lc3_io, int);  \
     T template __global__ void lc3_parse_debug_kernel<CV>(lc3_cfg_slot<CV>, const uint8_t *, int32_t *, int, int, float *);                    \
-    T template __global__ void lc3_parse_pc_kernel<CV>(lc3_cfg_slot<CV>, const uint8_t *, const uint8_t *, int32_t *, int, int, int, lc3_io);   \
+    T template __global__ void lc3_parse_pc_kernel<CV>(lc3_cfg_slot<CV>, const uint8_t *, const uint8_t *, int32_t *, int, int, int, lc3_io, unsigned *);   \
     T template __global__ void lc3_recon_kernel<CV>(lc3_cfg_slot<CV>, int32_t *, int, int);                                                    \
     T template __global__ void lc3_tns_kernel<CV>(lc3_cfg_slot<CV>, int32_t *, int);                                                           \
     T template __global__ void lc3_decode_kernel<CV>(lc3_cfg_slot<CV>, lc3_dec_state *, int, int, const int32_t *, int16_t *, int, int, int, lc3_io); \
@@ -1741,6 +1752,7 @@ struct HandleCommon {
     std::vector<MixedStream> streams;      // caller order
     std::vector<int> caller_of_internal;   // internal index -> caller index
     lc3_stream_io *d_tab = nullptr;        // per internal stream
+    unsigned *d_pc_timeouts = nullptr;     // one word: producer / consumer pair halves that gave up on their partner (sticky; *_pair_timeouts)
     hipStream_t last_stream = nullptr;
     hipEvent_t done = nullptr;
     bool has_work = false;
@@ -1832,6 +1844,8 @@ struct HandleCommon {
         timer.release();
         if (done) (void)hipEventDestroy(done);
         if (d_tab) (void)hipFree(d_tab);
+        if (d_pc_timeouts) (void)hipFree(d_pc_timeouts);
+        d_pc_timeouts = nullptr;
         for (hipEvent_t ev : {ev_fork, ev_stage, ev_join[0], ev_join[1]})
             if (ev) (void)hipEventDestroy(ev);
         for (hipStream_t st : sub)
@@ -2284,6 +2298,8 @@ int lc3gpu_decoder_working_buffer_lengths(int num_channels, int frame_us, int fs
 static int encoder_alloc(lc3gpu_encoder *e) {
     HIP_TRY(hipGetDevice(&e->device));
     HIP_TRY(hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void **)&e->d_pc_timeouts, sizeof(unsigned)));
+    HIP_TRY(hipMemset(e->d_pc_timeouts, 0, sizeof(unsigned)));
     HIP_TRY(hipMalloc((void **)&e->d_states, sizeof(lc3_enc_state) * (size_t)e->num_channels));
     // staging of the *_frame calls: pinned host memory the kernels read / write in place (no copy engine round trips)
     HIP_TRY(hipHostMalloc((void **)&e->d_pcm1, sizeof(int16_t) * LC3_MAX_NF, hipHostMallocDefault));
@@ -2456,7 +2472,7 @@ static int encode_kernels(lc3gpu_encoder *e, const HostCfg &h, int first, int n,
         if (rc) return rc;
         const unsigned pfpb = lc3_pack_pc_fpb(nbytes);
         hipLaunchKernelGGL(lc3_pack_pc_kernel, dim3((unsigned)((frames + pfpb - 1) / pfpb)), dim3(2 * pfpb), lc3_pack_pc_lds(pfpb, nbytes), stream,
-                           h.c.ne, (const int32_t *)planes, d_out, nbytes, (int)frames, n_frames, io);
+                           h.c.ne, (const int32_t *)planes, d_out, nbytes, (int)frames, n_frames, io, e->d_pc_timeouts);
     } else {
         const unsigned fpb = lc3_frame_block_fit(LC3_PACK_LDS_FIXED, (size_t)nbytes);
         const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)nbytes + 3) & ~(size_t)3) + 4;  // + the packer's sink byte
@@ -2619,7 +2635,7 @@ int lc3gpu_encode_mixed(lc3gpu_encoder *e, const int16_t *d_pcm, uint8_t *d_out,
         int m;
         fill_groups(*e, n_frames, pfpb, Gp, a, b, f, m);
         hipLaunchKernelGGL(lc3_pack_pc_mixed_kernel, dim3(b), dim3(2 * pfpb), lc3_pack_pc_lds(pfpb, max_nbytes), stream, Gp, (const int32_t *)e->d_planes,
-                           d_out, n_frames, io);
+                           d_out, n_frames, io, e->d_pc_timeouts);
     } else {
         const size_t lds = LC3_PACK_LDS_FIXED + (((size_t)fpb * (size_t)max_nbytes + 3) & ~(size_t)3) + 4;
         hipLaunchKernelGGL(lc3_pack_mixed_kernel, dim3(wg_frame), dim3(fpb), lds, stream, G, (const int32_t *)e->d_planes, d_out, n_frames, io);
@@ -2709,6 +2725,8 @@ static int decoder_init_states(lc3gpu_decoder *d) {
 static int decoder_alloc(lc3gpu_decoder *d) {
     HIP_TRY(hipGetDevice(&d->device));
     HIP_TRY(hipEventCreateWithFlags(&d->done, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void **)&d->d_pc_timeouts, sizeof(unsigned)));
+    HIP_TRY(hipMemset(d->d_pc_timeouts, 0, sizeof(unsigned)));
     HIP_TRY(hipMalloc((void **)&d->d_states, sizeof(lc3_dec_state) * (size_t)d->num_channels));
     HIP_TRY(hipHostMalloc((void **)&d->d_in1, LC3_MAX_NE, hipHostMallocDefault));  // *_frame staging: pinned host memory, used in place
     HIP_TRY(hipHostMalloc((void **)&d->d_pcm1, sizeof(int16_t) * LC3_MAX_NF, hipHostMallocDefault));
@@ -2784,7 +2802,7 @@ static int decode_kernels(lc3gpu_decoder *d, const HostCfg &h, int first, int n,
         if (rc) return rc;
         const unsigned pfpb = lc3_parse_pc_fpb(nbytes);
         LC3_LAUNCH_CFG(lc3_parse_pc_kernel, h, dim3((unsigned)((frames + pfpb - 1) / pfpb)), dim3(2 * pfpb), lc3_parse_pc_lds(pfpb, nbytes), stream,
-                       d_in, d_bad, planes, nbytes, (int)frames, n_frames, io);
+                       d_in, d_bad, planes, nbytes, (int)frames, n_frames, io, d->d_pc_timeouts);
     } else
         LC3_LAUNCH_CFG(lc3_parse_kernel, h, dim3((unsigned)((frames + fpb - 1) / fpb)), dim3(fpb), lds, stream, d_in, d_bad, planes, nbytes,
                        (int)frames, n_frames, io, mode);
@@ -2925,7 +2943,7 @@ int lc3gpu_decode_mixed(lc3gpu_decoder *d, const uint8_t *d_in, const uint8_t *d
         int m;
         fill_groups(*d, n_frames, pfpb, Gp, a, b, f, m);
         hipLaunchKernelGGL(LC3_MIXED_LAUNCH(lc3_parse_pc_mixed_kernel), dim3(b), dim3(2 * pfpb), lc3_parse_pc_lds(pfpb, max_nbytes), stream, Gp, d_in, d_bad, d->d_planes,
-                           n_frames, io);
+                           n_frames, io, d->d_pc_timeouts);
     } else
         hipLaunchKernelGGL(LC3_MIXED_LAUNCH(lc3_parse_mixed_kernel), dim3(wg_frame), dim3(fpb), lds, stream, G, d_in, d_bad, d->d_planes, n_frames, io, mode);
     LC3_LAUNCH_CHECK(d, stream, t0);
@@ -3094,6 +3112,28 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
     return LC3GPU_OK;
 }
 
+// Producer / consumer pair kernels (full batches): how many pair halves ever gave up waiting for their partner (LC3_PC_SPIN_LIMIT
+// polls -- a partner that died; never seen).  Sticky over the handle's life.  A parser pair that gives up conceals its frames (they
+// also count as PLC events); a packer pair that gives up leaves its frames zero-filled.  Waits for the handle's work in flight.
+static int pair_timeouts_read(HandleCommon &hc, uint64_t *out) {
+    unsigned v = 0;
+    int rc = hc.quiesce();
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(&v, hc.d_pc_timeouts, sizeof v, hipMemcpyDeviceToHost));
+    *out = (uint64_t)v;
+    return LC3GPU_OK;
+}
+int lc3gpu_encoder_pair_timeouts(lc3gpu_encoder *e, uint64_t *out) {
+    if (!e || !out) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(e);
+    return pair_timeouts_read(*e, out);
+}
+int lc3gpu_decoder_pair_timeouts(lc3gpu_decoder *d, uint64_t *out) {
+    if (!d || !out) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(d);
+    return pair_timeouts_read(*d, out);
+}
+
 // per-kernel timing (HIP events on the launch stream).  enable = 1 starts recording every batch launch, reading
 // synchronises and returns the per-kernel totals since the last read.
 // encoder: out[5] = {front ms, vector-quantiser ms, back ms, pack ms, launches}
@@ -3248,8 +3288,12 @@ int lc3gpu_prof_read(unsigned long long out[64]) {
 int lc3gpu_kernel_info(int which, int out[5]) {
     if (!out) return LC3GPU_EINVAL;
     hipFuncAttributes a;
-    hipError_t e = which == 0 ? hipFuncGetAttributes(&a, (const void *)lc3_enc_back_kernel<lc3_cfg_any>)
-                              : hipFuncGetAttributes(&a, (const void *)lc3_decode_kernel<lc3_cfg_any>);
+    // the six kernels a full batch of the headline configuration launches (48 kHz / 10 ms view; the pair forms of packer and parser)
+    const void *fn[6] = {(const void *)lc3_enc_front_kernel<lc3_cfg_48k10>, (const void *)lc3_sns_vq_kernel,
+                         (const void *)lc3_enc_back_kernel<lc3_cfg_48k10>, (const void *)lc3_pack_pc_kernel,
+                         (const void *)lc3_parse_pc_kernel<lc3_cfg_48k10>, (const void *)lc3_decode_kernel<lc3_cfg_48k10>};
+    if (which < 0 || which >= 6) return LC3GPU_EINVAL;
+    hipError_t e = hipFuncGetAttributes(&a, fn[which]);
     if (e != hipSuccess) {
         g_last_hip = (int)e;
         return LC3GPU_EHIP;

@@ -6,6 +6,13 @@
 #include <math.h>
 #include <string.h>
 
+/* path statistic for the measurement notes (tools/quantiser_paths.py): [0] frames through the quantiser, [1] frames whose gain
+ * adjustment changes the gain (spectral_quantization.rs:103-107: a SECOND quantise + bit-count pass), [2] frames with at least one
+ * active TNS filter, [3] lsb_mode frames.  Off unless a tool switches it on; atomic adds (encode threads share the counters) */
+long lc3o_enc_path_count[4];
+int lc3o_enc_path_counting = 0;
+#define LC3O_ENC_COUNT(i) do { if (lc3o_enc_path_counting) __sync_fetch_and_add(&lc3o_enc_path_count[i], 1L); } while (0)
+
 #define LC3_TABLE_QUAL static const
 #include "../tables/lc3_tables.h"
 #define TF(name) ((const float *)(const void *)LC3T_##name##_BITS)
@@ -621,6 +628,7 @@ lc3o_tns_result lc3o_enc_tns(const lc3o_config *c, float *x_s, int p_bw, int nbi
         }
         res.nbits_tns += (int)ceilf((2048.0f + (float)order_bits + (float)coef_bits) / 2048.0f);
     }
+    if (res.rc_order[0] != 0 || res.rc_order[1] != 0) LC3O_ENC_COUNT(2);
     /* apply_filtering :313-340 -- lattice state shared across both filters */
     {
         float st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1041,7 +1049,12 @@ lc3o_quant_result lc3o_enc_quant(const lc3o_config *c, lc3o_quant_state *st, con
             else gg_ind += 2;
             if (gg_ind < gg_min) gg_ind = gg_min;
         }
-        if (origin != gg_ind) bc = quantize_spectrum(c, x_f, x_q, nbits, gg_off, gg_ind, nbits_spec, &gg, &lsb_mode);
+        LC3O_ENC_COUNT(0);
+        if (origin != gg_ind) {
+            LC3O_ENC_COUNT(1);
+            bc = quantize_spectrum(c, x_f, x_q, nbits, gg_off, gg_ind, nbits_spec, &gg, &lsb_mode);
+        }
+        if (lsb_mode) LC3O_ENC_COUNT(3);
     }
     res.gg_ind = gg_ind;
     res.nbits_spec = nbits_spec;

@@ -148,6 +148,18 @@ def ltpf_transition_counts(reset=False):
     return out
 
 
+def encoder_path_counts(reset=False):
+    """[frames through the quantiser, frames that take a second quantise + bit-count pass, frames with an active TNS filter, lsb_mode frames]
+    inside the oracle since the last reset (tools/quantiser_paths.py)."""
+    cnt = (ctypes.c_long * 4).in_dll(lib(), "lc3o_enc_path_count")
+    ctypes.c_int.in_dll(lib(), "lc3o_enc_path_counting").value = 1
+    out = [int(v) for v in cnt]
+    if reset:
+        for i in range(4):
+            cnt[i] = 0
+    return out
+
+
 def timed_run(pcm, nbytes, fs_hz=48000, frame_us=10000, threads=1, roundtrip=True, seconds=5.0):
     """bench.py's cpu_baseline leg: `threads` host threads, each with ONE persistent encoder (and decoder) that codes its own stream
     of consecutive frames (pcm[t % S], cycled) for `seconds`; thread start-up, allocation and initialisation lie outside the timed

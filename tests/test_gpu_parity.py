@@ -34,6 +34,7 @@ def gpu_encode(pcm, nbytes, fs=48000, us=10000, enc=None):
     d_out = torch.zeros((S, T, nbytes), dtype=torch.uint8, device="cuda")
     enc.encode(d_pcm, d_out, nbytes, T, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
+    assert enc.pair_timeouts() == 0, "a packer producer / consumer pair gave up on its partner"
     return d_out.cpu().numpy()
 
 
@@ -46,6 +47,7 @@ def gpu_decode(data, nf, fs=48000, us=10000, dec=None, bad=None):
     d_bad = torch.from_numpy(np.ascontiguousarray(bad)).cuda() if bad is not None else None
     dec.decode(d_in, d_pcm, nbytes, T, stream=torch.cuda.current_stream().cuda_stream, d_bad_frame=d_bad)
     torch.cuda.synchronize()
+    assert dec.pair_timeouts() == 0, "a parser producer / consumer pair gave up on its partner"
     return d_pcm.cpu().numpy()
 
 
@@ -1010,6 +1012,7 @@ def test_stress_parity_tool_one_million_frames():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["frames_differing"] == 0 and line["total_frames_each_direction"] == 14 * 2048 * 18 * 2 >= 1000000
+    assert line["pair_timeouts"] == 0  # no producer / consumer pair ever gave up on its partner
     assert line["frames_damaged"] > 10000
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     with open(os.path.join(root, "gpurun_out", "stress_parity_suite.json"), "w") as f:
@@ -1185,7 +1188,7 @@ def test_rccl_world_size_one():
 def test_every_caller_arrangement_passes_its_parity_gate():
     """bench.py times two ways of queueing the same steps -- encode then decode on ONE caller stream, and the recommended pattern
     (INTEGRATION.md): encoder handle on one stream, decoder handle on another, two byte buffers, events -- and runs its parity gate on
-    each (two steps from fresh state, the second against the oracle).  Here on a batch that takes the split path inside the calls."""
+    each (two steps from fresh state, the second against the oracle).  Here on a 32 768-frame batch (producer / consumer pair kernels)."""
     p, line = _bench_line(["--steps", "4", "--warmup", "1", "--streams", "8192", "--sustain-seconds", "0.3", "--arrangement", "pipelined"], {})
     assert p.returncode == 0 and line is not None, p.stderr[-2000:]
     assert line["config"]["arrangement"] == "pipelined" and line["config"]["hip_streams"] == 2

@@ -1,6 +1,6 @@
 """Differential stress run of the GPU engine against the CPU oracle (test infrastructure: the oracle is only the checker).
 
-    python tools/stress_parity.py [--streams 2048] [--frames 16] [--rounds 2] > gpurun_out/stress_parity.json
+    python tools/stress_parity.py [--streams 2048] [--frames 16] [--rounds 2] [--shapes 16384x4,2048x18] > gpurun_out/stress_parity.json
 
 For every (sampling rate, frame duration, frame size) of the list below and every round: synthetic PCM of mixed character
 (tonal / noisy / clicks from lc3-codec_amd.synth, plus band-limited, very quiet, clipping and silent streams), encoded by the
@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--corrupt", type=float, default=1.0 / 48.0,
                     help="share of the frames the decode direction damages (random bit flips, whole frames of random bytes and, at 48 kHz, "
                          "frames flagged bad through the external indicator): concealment, error paths and the frames after them")
+    ap.add_argument("--shapes", default="",
+                    help="comma-separated launch shapes STREAMSxFRAMES that the rounds cycle through (round r uses shape r mod n), e.g. "
+                         "16384x4,2048x18,4096x16: the 65 536-frame launch the benchmark times among them; default: --streams x --frames")
     a = ap.parse_args()
     import torch
 
@@ -64,16 +67,20 @@ def main():
         threads = granted_cpus()[0]  # what the job may run on (cgroup quota), not the machine's core count
     except Exception:
         threads = os.cpu_count() or 8
-    S, T = a.streams, a.frames
+    shapes = [tuple(int(v) for v in sh.split("x")) for sh in a.shapes.split(",") if sh] or [(a.streams, a.frames)]
     st = torch.cuda.current_stream().cuda_stream
-    rows, bad = [], 0
+    rows, bad, timeouts = [], 0, 0
     t0 = time.time()
     for fs, us, nbytes in CASES:
         nf = (fs if fs != 44100 else 48000) * us // 1000000
-        enc = pkg.Lc3Encoder(S, us, fs)
-        dec = pkg.Lc3Decoder(S, us, fs)
-        enc_bad = dec_bad = damaged = 0
+        handles = {}
+        enc_bad = dec_bad = damaged = frames = 0
         for rnd in range(a.rounds):
+            S, T = shapes[rnd % len(shapes)]
+            if S not in handles:
+                handles[S] = (pkg.Lc3Encoder(S, us, fs), pkg.Lc3Decoder(S, us, fs))
+            enc, dec = handles[S]
+            frames += S * T
             pcm = make_mixed(synth, S, T, nf, fs, rnd)
             enc.reset()
             dec.reset()
@@ -109,16 +116,21 @@ def main():
             torch.cuda.synchronize()
             ref_pcm = O.decode_batch(for_oracle, nf, fs, us, threads=threads)
             dec_bad += int((d_dec.cpu().numpy() != ref_pcm).any(axis=2).sum())
-        rows.append({"fs_hz": fs, "frame_us": us, "nbytes": nbytes, "frames": S * T * a.rounds, "encode_frames_differing": enc_bad,
-                     "decode_frames_differing": dec_bad, "decode_frames_damaged": damaged})
+        # the producer / consumer pair kernels' give-up counters (include/lc3gpu.h): a pair whose partner never answered would have
+        # produced concealed / zero-filled frames -- which the comparison above also catches -- but the counter says WHY
+        case_timeouts = sum(e.pair_timeouts() + d.pair_timeouts() for e, d in handles.values())
+        timeouts += case_timeouts
+        rows.append({"fs_hz": fs, "frame_us": us, "nbytes": nbytes, "frames": frames, "encode_frames_differing": enc_bad,
+                     "decode_frames_differing": dec_bad, "decode_frames_damaged": damaged, "pair_timeouts": case_timeouts})
         bad += enc_bad + dec_bad
-        print(f"{fs} {us} {nbytes}: {S * T * a.rounds} frames, enc diff {enc_bad}, dec diff {dec_bad}", file=sys.stderr)
+        print(f"{fs} {us} {nbytes}: {frames} frames, enc diff {enc_bad}, dec diff {dec_bad}, pair time-outs {case_timeouts}", file=sys.stderr)
+        del handles
     total = sum(r["frames"] for r in rows)
     print(json.dumps({"what": "GPU engine vs CPU oracle, byte-exact bitstreams and sample-exact PCM (tools/stress_parity.py)",
-                      "streams": S, "frames_per_stream": T, "rounds": a.rounds, "total_frames_each_direction": total,
-                      "frames_differing": bad, "corrupt_share": a.corrupt, "frames_damaged": sum(r["decode_frames_damaged"] for r in rows), "host_threads": threads, "seconds": round(time.time() - t0, 1), "env_seq_sums": os.environ.get("LC3GPU_SEQ_SUMS"),
+                      "launch_shapes_streams_x_frames": ["%dx%d" % sh for sh in shapes], "rounds": a.rounds, "total_frames_each_direction": total,
+                      "frames_differing": bad, "pair_timeouts": timeouts, "corrupt_share": a.corrupt, "frames_damaged": sum(r["decode_frames_damaged"] for r in rows), "host_threads": threads, "seconds": round(time.time() - t0, 1), "env_seq_sums": os.environ.get("LC3GPU_SEQ_SUMS"),
                       "cases": rows}))
-    return 1 if bad else 0
+    return 1 if (bad or timeouts) else 0
 
 
 if __name__ == "__main__":
