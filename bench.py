@@ -57,12 +57,13 @@ def parse_args(argv=None):
                          "(default 1: one stream, clean per-kernel timing)")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip timing the OTHER arrangements (see --arrangement) after the timed region")
-    ap.add_argument("--arrangement", choices=("single", "pipelined", "staggered"), default="pipelined",
+    ap.add_argument("--arrangement", choices=("single", "pipelined", "staggered", "quad"), default="pipelined",
                     help="how the timed steps are queued: `single` = encode then decode of the same batch on ONE HIP stream (every call waits for "
                          "the one before it); `pipelined` = the recommended caller pattern (INTEGRATION.md): the encoder handle on one HIP stream, the "
                          "decoder handle on another, two byte buffers and events, so that the decoder works on step k while the encoder runs step k + 1; "
                          "`staggered` = the same with three buffers and the decoder call queued behind the encoder's LC3GPU_ENC_STAGE_BACK event of the "
-                         "next step (lc3gpu_encoder_stage_event).  The other arrangements are timed too and reported beside `value`")
+                         "next step (lc3gpu_encoder_stage_event); `quad` = two halves of the streams, each half `pipelined` by itself with its own handle pair on "
+                         "its own two HIP streams.  The other arrangements are timed too and reported beside `value`")
     ap.add_argument("--sustain-seconds", type=float, default=2.5,
                     help="length of the sustained leg: back-to-back steps for this long, frames/s and the shader clock read by a one-wave probe kernel "
                          "beside them (0 = skip)")
@@ -306,17 +307,36 @@ class GpuEngine:
             # stream waits for it
             self.ev_back = torch.cuda.Event()
             self.ev_back.record(self.s_enc)  # (torch creates the HIP event at its first record)
+            # the `quad` arrangement: the batch as TWO halves of its streams, each half with an encoder handle and a decoder handle of its
+            # own on two HIP streams of its own (four caller streams), each half `pipelined` by itself.  Handles, streams and events
+            # are created when the arrangement is first selected
+            self.quad = None
 
     device = "cuda"
     carries_state = True
 
     def set_arrangement(self, name):
-        """`single` or `pipelined`; call between synchronised phases only"""
+        """`single`, `pipelined`, `staggered` or `quad`; call between synchronised phases only"""
         assert name == "single" or (self.mode == "roundtrip" and self.NP == 1)
         self.sync()
         self.arrangement, self.k = name, 0
         if self.mode == "roundtrip" and self.NP == 1:
             self.encs[0].stage_event(self.pkg.ENC_STAGE_BACK, self.ev_back if name == "staggered" else None)
+        if name == "quad" and self.quad is None:
+            torch, pkg = self.torch, self.pkg
+            assert self.S % 2 == 0
+            h = self.S // 2
+            mk = lambda cls: [cls(h, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(2)]
+            ev = lambda: [[torch.cuda.Event() for _ in range(2)] for _ in range(2)]
+            self.quad = {"half": h, "encs": mk(pkg.Lc3Encoder), "decs": mk(pkg.Lc3Decoder),
+                         "s_enc": [torch.cuda.Stream() for _ in range(2)], "s_dec": [torch.cuda.Stream() for _ in range(2)],
+                         "enc_done": ev(), "dec_done": ev()}
+
+    def _handles(self):
+        """the handles of the current arrangement"""
+        if self.arrangement == "quad":
+            return self.quad["encs"], self.quad["decs"]
+        return self.encs, self.decs
 
     def _decode_pending(self, beside_packer):
         k = self.pending
@@ -341,6 +361,22 @@ class GpuEngine:
             if self.pending is not None:
                 self._decode_pending(True)
             self.pending = k
+            self.k += 1
+            return
+        if self.arrangement == "quad":
+            # two halves of the streams, each `pipelined` by itself on its own encoder stream and decoder stream (the halves never join:
+            # each keeps its own encode -> decode -> encode chain, so four kernels of four calls can meet on the chip at any moment)
+            q, k, b = self.quad, self.k, self.k & 1
+            for g in range(2):
+                lo, hi = g * q["half"], (g + 1) * q["half"]
+                se, sd = q["s_enc"][g], q["s_dec"][g]
+                if k >= 2:
+                    se.wait_event(q["dec_done"][g][b])
+                q["encs"][g].encode(self.d_pcm[lo:hi], self.bufs[b][lo:hi], NBYTES, self.T, stream=se.cuda_stream)
+                q["enc_done"][g][b].record(se)
+                sd.wait_event(q["enc_done"][g][b])
+                q["decs"][g].decode(self.bufs[b][lo:hi], self.d_out[lo:hi], NBYTES, self.T, stream=sd.cuda_stream)
+                q["dec_done"][g][b].record(sd)
             self.k += 1
             return
         if self.arrangement == "pipelined":
@@ -374,8 +410,14 @@ class GpuEngine:
         marks bracket one step"""
         if self.NP == 1:
             e = self.torch.cuda.Event(enable_timing=True)
-            e.record(self.s_dec if self.arrangement != "single" else self.hs[0])
+            e.record(self._last_stream())
             self.marks.append(e)
+
+    def _last_stream(self):
+        """the stream the step's last call was queued on"""
+        if self.arrangement == "quad":
+            return self.quad["s_dec"][1]
+        return self.s_dec if self.arrangement != "single" else self.hs[0]
 
     def step_times_ms(self):
         m, self.marks = self.marks, []
@@ -383,39 +425,49 @@ class GpuEngine:
 
     def reset(self):
         self.sync()
-        for h in self.encs + self.decs:
+        for h in self.encs + self.decs + (self.quad["encs"] + self.quad["decs"] if self.quad else []):
             h.reset()
         self.k = 0
 
+    def sample(self, k):
+        """the k streams the parity gate looks at: the first k -- in the `quad` arrangement the first k / 2 of either half"""
+        if self.arrangement == "quad":
+            h = self.quad["half"]
+            return np.concatenate([np.arange(0, k // 2), np.arange(h, h + k - k // 2)])
+        return np.arange(k)
+
     def last_bytes(self, k):
-        """the first k streams' frame bytes of the most recent step"""
-        if self.arrangement == "pipelined":
+        """the sampled streams' frame bytes of the most recent step"""
+        if self.arrangement in ("pipelined", "quad"):
             buf = self.bufs[(self.k - 1) & 1]
         elif self.arrangement == "staggered":
             buf = self.bufs[(self.k - 1) % 3]
         else:
             buf = self.d_bytes
-        return buf[:k].cpu().numpy()
+        return buf[self.torch.from_numpy(self.sample(k)).cuda()].cpu().numpy()
 
     def results(self, k):
-        return (self.last_bytes(k), self.d_out[:k].cpu().numpy() if self.d_out is not None else None)
+        idx = self.torch.from_numpy(self.sample(k)).cuda()
+        return (self.last_bytes(k), self.d_out[idx].cpu().numpy() if self.d_out is not None else None)
 
     def timing_start(self, every=1):
-        for h in self.encs + self.decs:
+        encs, decs = self._handles()
+        for h in encs + decs:
             h.timing(every)
 
     def timing_stop(self):
         ef = ev = eb = ep = en = dp = dr = dt = ds = dn = 0.0
-        for h in self.encs:
+        encs, decs = self._handles()
+        for h in encs:
             a, v, b, p_, n = h.timing(False)
             ef, ev, eb, ep, en = ef + a, ev + v, eb + b, ep + p_, en + n
-        for h in self.decs:
+        for h in decs:
             a, r, t, b, n = h.timing_kernels(False)
             dp, dr, dt, ds, dn = dp + a, dr + r, dt + t, ds + b, dn + n
-        en, dn = en / self.NP, dn / self.NP  # launches per step = NP per kernel: scale to "per step"
+        en, dn = en / len(encs), dn / max(1, len(decs))  # launches per step = one per handle and kernel: scale to "per step"
         km = {"lc3_enc_front_kernel": ef / max(en, 1), "lc3_sns_vq_kernel": ev / max(en, 1),
               "lc3_enc_back_kernel": eb / max(en, 1), "lc3_pack_kernel": ep / max(en, 1)}
-        if self.decs:
+        if decs:
             km.update({"lc3_parse_kernel": dp / max(dn, 1), "lc3_recon_kernel": dr / max(dn, 1), "lc3_tns_kernel": dt / max(dn, 1), "lc3_decode_kernel": ds / max(dn, 1)})
         return km
 
@@ -464,7 +516,7 @@ class GpuEngine:
                     pkg.clock_probe(slots[probes], stream=s_probe.cuda_stream, spin=50000)
                     probes += 1
                 e = torch.cuda.Event()
-                e.record(self.s_dec if self.arrangement != "single" else self.hs[0])
+                e.record(self._last_stream())
                 fences.append(e)
                 if len(fences) > depth // every:
                     fences.pop(0).synchronize()  # the host stays at most `depth` steps ahead of the chip
@@ -619,7 +671,8 @@ def run_rank(args):
         eng.sync()
         k = min(n_distinct, 256 if rank == 0 else 32)
         thr = max(1, granted_cpus()[0] // max(1, world))
-        two = np.ascontiguousarray(np.concatenate([pcm_host[:k], pcm_host[:k]], axis=1))  # every step codes the same T frames
+        idx = eng.sample(k) if hasattr(eng, "sample") else np.arange(k)  # (`quad`: streams of both halves)
+        two = np.ascontiguousarray(np.concatenate([pcm_host[idx], pcm_host[idx]], axis=1))  # every step codes the same T frames
         ref_b = O.encode_batch(two, NBYTES, FS, US, threads=thr)
         got_b, got_p = eng.results(k)
         second = slice(T, 2 * T) if eng.carries_state else slice(0, T)
@@ -653,13 +706,13 @@ def run_rank(args):
     other, others, sustained = None, [], None
     if world == 1 and not emu:
         if can_pipeline and not args.no_overlap_probe:
-            for arr2 in [a for a in ("single", "pipelined", "staggered") if a != main_arr]:
+            for arr2 in [a for a in ("single", "pipelined", "staggered", "quad") if a != main_arr]:
                 par2, mism2 = gate(arr2) if not args.no_parity else (None, 0)
                 eng.set_arrangement(arr2)
                 el2, km2, st2 = eng.timed_steps(args.steps, args.warmup, kernel_events=KERNEL_EVENTS_EVERY, marks=True)
                 others.append({"arrangement": arr2, "value": frames_per_step * args.steps / el2, "unit": "frames/s", "ms_per_step": el2 / args.steps * 1e3,
                                "ms_per_step_median": st2[len(st2) // 2] if st2 else None, "kernel_ms": km2, "parity": par2, "parity_mismatches": mism2,
-                               "hip_streams": 1 if arr2 == "single" else 2})
+                               "hip_streams": {"single": 1, "quad": 4}.get(arr2, 2)})
                 total_mismatches += mism2
             other = others[0]  # (the one-stream arrangement unless that is the timed one)
         if args.sustain_seconds > 0:
@@ -744,7 +797,7 @@ def run_rank(args):
             workload = (f"{total_streams * T}-frame batch mono 48 kHz / 10 ms / 150-byte frames, encode only, streams sharded over "
                         f"{world} GPU(s) (BASELINE configs[2]); {n_distinct} distinct synthetic streams per rank" + (f" tiled to {S}" if n_distinct < S else ""))
             metric = "LC3 frames/sec (encode) @48kHz/10ms"
-        hip_streams = 2 if main_arr != "single" else max(1, args.hip_streams)
+        hip_streams = {"single": max(1, args.hip_streams), "quad": 4}.get(main_arr, 2)
         line = {
             "metric": metric, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -762,7 +815,9 @@ def run_rank(args):
                                      "it; `pipelined`: the encoder handle on one caller stream, the decoder handle on another, two byte buffers and "
                                      "events (INTEGRATION.md, recommended caller pattern): the decoder works on step k while the encoder runs step k + 1; "
                                      "`staggered`: the same with three byte buffers and the decoder call of step k queued behind the point where the "
-                                     "encoder call of step k + 1 has only its packer left (lc3gpu_encoder_stage_event): parser beside packer.  "
+                                     "encoder call of step k + 1 has only its packer left (lc3gpu_encoder_stage_event): parser beside packer; "
+                                     "`quad`: the batch as two halves of its streams, each half with its own encoder handle and decoder handle on its own two "
+                                     "caller streams (four in all), each half `pipelined` by itself -- the halves never join.  "
                                      "`value` is the arrangement named here; the other one is timed in the same run (`other_arrangement`)"),
                 "engine": args.engine,
             },

@@ -72,11 +72,25 @@ def _translation_units():
     return [(0, 0)] + [(k, v) for v in range(n_base + 1, n_all + 1) for k in (1, 3)] + [(2, k) for k in range(8)]
 
 
-def _build_signature(single, extra, extra_main, units):
-    """what a built library depends on beside the sources' mtimes (advisor, round 4: switching LC3_SINGLE_TU / LC3_HIPCC_EXTRA used to leave
-    a library of the other flavour in place)"""
-    return "single=%d extra=%s extra_main=%s units=%s profile=%d\n" % (single, " ".join(extra), " ".join(extra_main),
-                                                                      ",".join("%d_%d" % u for u in units), _PROFILE)
+def _sources_hash(srcs):
+    """sha256 over the CONTENTS of every source a library is built from.  Freshness is decided by content, not by time stamps: an object
+    whose compile started before an edit and ended after it is newer than the sources and still stale (seen in round 5: a test session's
+    build running while the sources were being edited left exactly that)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted(srcs):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _build_signature(single, extra, extra_main, units, src_hash):
+    """what a built library is a function of: the sources' contents and the build switches (advisor, round 4: switching LC3_SINGLE_TU /
+    LC3_HIPCC_EXTRA used to leave a library of the other flavour in place)"""
+    return "sources=%s single=%d extra=%s extra_main=%s units=%s profile=%d\n" % (
+        src_hash, single, " ".join(extra), " ".join(extra_main), ",".join("%d_%d" % u for u in units), _PROFILE)
 
 
 def build_native(force=False, verbose=False):
@@ -87,22 +101,26 @@ def build_native(force=False, verbose=False):
     LC3_HIPCC_EXTRA_MAIN="-D..." (timing experiments on the headline kernels): the multi-unit build with those flags on the MAIN unit only;
     the other units' objects are the production ones.  A library remembers the switches it was built with (<lib>.stamp) and is rebuilt
     when they differ; experiment builds need their own file name (LC3GPU_LIB) so that they never replace the default library."""
-    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".h", ".hip"))]
     srcs += [os.path.join(_ROOT, "include", "lc3gpu.h"), os.path.join(_ROOT, "tables", "lc3_tables.h")]
+    src_hash = _sources_hash(srcs)  # taken BEFORE anything is compiled: what the objects below are guaranteed to be at least as old as
     extra = os.environ.get("LC3_HIPCC_EXTRA", "").split()  # compiler experiments
     extra_main = os.environ.get("LC3_HIPCC_EXTRA_MAIN", "").split()
     if (extra or extra_main) and not os.environ.get("LC3GPU_LIB"):
         raise RuntimeError("LC3_HIPCC_EXTRA / LC3_HIPCC_EXTRA_MAIN builds are experiments: name their library with LC3GPU_LIB=liblc3gpu_<what>.so")
     single = _PROFILE or bool(extra) or os.environ.get("LC3_SINGLE_TU", "0") == "1"
     units = [] if single else _translation_units()
-    sig = _build_signature(single, extra, extra_main, units)
+    sig = _build_signature(single, extra, extra_main, units, src_hash)
     stamp = _LIB + ".stamp"
-    try:
-        with open(stamp) as f:
-            same = f.read() == sig
-    except OSError:
-        same = False
-    if not force and same and os.path.exists(_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(_LIB) for s in srcs):
+
+    def stamped(path, text):
+        try:
+            with open(path) as f:
+                return f.read() == text
+        except OSError:
+            return False
+
+    if not force and os.path.exists(_LIB) and stamped(stamp, sig):
         return _LIB
     os.makedirs(os.path.dirname(_LIB), exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function",
@@ -130,22 +148,27 @@ def build_native(force=False, verbose=False):
         try:
             subprocess.check_call(cmd)
             os.replace(tmp, obj)  # (a unit that fails leaves no partial object behind)
+            with open(obj + ".stamp", "w") as f:
+                f.write(unit_sig(u))
         finally:
             if os.path.exists(tmp):
                 os.remove(tmp)
         return obj
 
+    def unit_sig(u):
+        return "sources=%s flags=%s\n" % (src_hash, " ".join(extra_main) if u == (0, 0) else "")
+
     def fresh(u):
         o = unit_obj(u)
-        return os.path.exists(o) and all(os.path.getmtime(s) <= os.path.getmtime(o) for s in srcs)
+        return os.path.exists(o) and stamped(o + ".stamp", unit_sig(u))
 
     try:
         jobs = len(os.sched_getaffinity(0))
     except AttributeError:
         jobs = os.cpu_count() or 1
     jobs = max(1, int(os.environ.get("LC3_BUILD_JOBS", jobs)))
-    # (the main unit and the mixed-kernel units are the long ones: first).  Objects newer than every source are kept unless forced; an
-    # experiment build never recompiles the shared ones it finds up to date
+    # (the main unit and the mixed-kernel units are the long ones: first).  Objects stamped with these sources' hash are kept unless forced;
+    # an experiment build never recompiles the shared ones it finds up to date
     order = sorted(units, key=lambda u: (u[0] != 0, u[0] != 2))
     todo = [u for u in order if (force and (not extra_main or u == (0, 0))) or not fresh(u)]
     if verbose:

@@ -91,14 +91,14 @@ __device__ __forceinline__ lc3_ola5 lc3_dec_ola_load(const CC &c, int lane, cons
 #pragma unroll
     for (int r = 0; r < 5; r++) {
         const int n = lane + LC3_WAVE * r;
-        m.v[r] = (n < c.nf - c.z && !(LC3_DEC_KO & 2)) ? ola[n] : 0.0f;
+        m.v[r] = n < c.nf - c.z ? ola[n] : 0.0f;
     }
     return m;
 }
 // whole rounds of 64 under a wave-uniform condition, one base address with constant offsets
 template <class CC>
 __device__ __forceinline__ void lc3_dec_ola_store(const CC &c, int lane, lc3_dec_state *g, int valid, const lc3_ola5 &m) {
-    const int nv = (LC3_UNIFORM_I32(valid) && !(LC3_DEC_KO & 2)) ? c.nf - c.z : 0;
+    const int nv = LC3_UNIFORM_I32(valid) ? c.nf - c.z : 0;
     LC3_HBM(float) ob = (LC3_HBM(float))g->mem_ola + lane;
 #pragma unroll
     for (int r = 0; r < 5; r++) {
@@ -333,7 +333,6 @@ __device__ __forceinline__ void lc3_dec_issue_frame(const CC &c, int lane, const
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int i = lane + LC3_WAVE * u;
-        if ((LC3_DEC_KO & 64) && i >= (LC3_PLANE_X - LC3_PLANE_SI) / 4) continue;  // (timing experiment: side information only)
         if (i < n4 || (late && i >= LC3_PLANE_LEV / 4 && i < LC3_PLANE_LEV / 4 + 4)) m.u[u] = p4[i];
     }
 }
@@ -714,13 +713,13 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
     if (ok) {
         ltpf_active = L.ism[SI_LTPF_ACTIVE];
         pitch_index = L.ism[SI_PITCH_INDEX];
-        lc3_dec_plc_save(c, L, lane, g, valid && save_good && !(LC3_DEC_KO & 4));
+        lc3_dec_plc_save(c, L, lane, g, valid && save_good);
     } else {
         lc3_dec_plc_load(LC3_CFG_PASS, LC3_LDS_PASS lane, plc_src);
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 18);
-    if (!(LC3_DEC_KO & 8)) ola = lc3_dec_imdct(LC3_CFG_PASS, LC3_LDS_PASS lane, ola);
+    ola = lc3_dec_imdct(LC3_CFG_PASS, LC3_LDS_PASS lane, ola);
     LC3_STAMP(L, lane, 19);
     if (dbg_flags & (LC3_DBG_TIME_IN | LC3_DBG_DUMP)) {
         for (int n = lane; n < nf; n += LC3_WAVE) {
@@ -729,7 +728,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
         }
         LC3_SYNC();
     }
-    if (!(LC3_DEC_KO & 16)) lc3_dec_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, ltpf_active, pitch_index, nbits);
+    lc3_dec_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, ltpf_active, pitch_index, nbits);
     if (dbg_flags & LC3_DBG_DUMP) {
         for (int n = lane; n < nf; n += LC3_WAVE) dbg[LC3_DBG_LTPF + n] = L.spec[n];
     }
@@ -753,7 +752,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
             }
             ow[r] = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
         }
-        const int nv = (LC3_UNIFORM_I32(valid) && !(LC3_DEC_KO & 32)) ? nf / 2 : 0;
+        const int nv = LC3_UNIFORM_I32(valid) ? nf / 2 : 0;
         if (stride == 1) {
             LC3_HBM(uint32_t) ob = o32 + lane;
 #pragma unroll

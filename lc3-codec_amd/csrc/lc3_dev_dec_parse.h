@@ -778,19 +778,8 @@ __device__ __forceinline__ int lc3_pc_consume(lc3_parse_ctx &c, const lc3_pc_lin
             if ((pc & (LC3_PC_DONE - 1)) <= it) break;  // the producer has ended (or never answered)
 #pragma unroll
             for (int u = 0; u < LC3_PC_CHUNK; u++) {
-#if LC3_PCPARSE_KO == 2  // timing experiment: a consumer that only follows the producer (the output is garbage)
                 if (tup < ntup) {
                     const uint32_t w = k.ring[((it + u) & k.mask) * k.stride];
-                    const int esc = (int)(w & 31u) >= 16 && lev < 14;
-                    tup += !esc;
-                    lev = esc ? lev + 1 : 0;
-                }
-                if (false) {
-                    const uint32_t w = 0;
-#else
-                if (tup < ntup) {
-                    const uint32_t w = k.ring[((it + u) & k.mask) * k.stride];
-#endif
                     const int sym = (int)(w & 31u);
                     c.head += (int)(w >> 5);
                     const int esc = sym >= 16 && lev < 14;

@@ -107,10 +107,7 @@ __device__ __forceinline__ void lc3_recon_frame_direct(const CC &c, const lc3_re
     const int lastnz = LC3_RSI(SI_LASTNZ), gg_ind = LC3_RSI(SI_GG), bw = LC3_RSI(SI_BW);
     if (lane >= 12 && lane < 16) *(lc3_i4 *)(W.resw + 4 * (lane - 12)) = __builtin_bit_cast(lc3_i4, si);
     // spectral_noise_shaping::decode (:21-73): the pulse vector came de-enumerated from the parser; one scale factor per lane
-    if (LC3_RECON_KO & 4) {
-        W.sc[lane] = 1.0f;
-        W.sc[16 + lane] = 1.0f;
-    } else {
+    {
         const uint32_t yw0 = (uint32_t)LC3_RSI(AD_Y), yw1 = (uint32_t)LC3_RSI(AD_Y + 1), yw2 = (uint32_t)LC3_RSI(AD_Y + 2);
         int y[16];
 #pragma unroll
@@ -149,7 +146,7 @@ __device__ __forceinline__ void lc3_recon_frame_direct(const CC &c, const lc3_re
         r.sstride = 1;
         r.mpvq = nullptr;
         r.ifs = nullptr;
-        if (!(LC3_RECON_KO & 4) && lane < c.nb) {
+        if (lane < c.nb) {
             g_band = lc3_r_band_gain(r, lane, c.nb);
             W.sc[16 + lane] = g_band;
         }
@@ -168,9 +165,6 @@ __device__ __forceinline__ void lc3_recon_frame_direct(const CC &c, const lc3_re
         xi[4 + j] = k0 + 4 + j < lastnz ? xb.v[j] : 0;
     }
     float v8[8];
-#if LC3_RECON_KO & 8
-    for (int j = 0; j < 8; j++) v8[j] = (float)xi[j] * gg;
-#else
     uint32_t nzmask = 0, absk = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -252,7 +246,6 @@ __device__ __forceinline__ void lc3_recon_frame_direct(const CC &c, const lc3_re
         }
         v8[j] = v * gg;
     }
-#endif
     // TNS :24-137: a frame with an active filter keeps its filter range as it is now (lc3_tns_lane_frame finishes it)
     const int nbands = bw < 3 ? 1 : 2, num_tns = LC3_RSI(SI_NUM_TNS);
     const int ord0 = (0 < nbands && 0 < num_tns) ? LC3_RSI(AD_ORD0) : 0;

@@ -58,6 +58,10 @@ struct __attribute__((aligned(16))) lc3_enc_lds {
     unsigned long long prof_acc[32];  // diagnostic build: per-wave stage totals, flushed once per launch
 #endif
 };
+// the TNS stage's Levinson recursions of a workgroup's four streams on one wave (1) or each stream's on its own wave (0: A/B builds)
+#ifndef LC3_TNS_GATHER
+#define LC3_TNS_GATHER 1
+#endif
 #define LC3_ENC_DBG_EB 1472      // [64] band energies
 #define LC3_ENC_DBG_ATTACK 1536  // [5] attack detector state: energy_last, max_energy_last, attack_pos_last, downsampled t-1, t-2
 #define LC3_ENC_DBG_FLOATS 1600
@@ -483,8 +487,9 @@ LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_sns_front(LC3_CFG_PARAM, L
 // E11: temporal noise shaping (encoder/temporal_noise_shaping.rs:40-349)
 // rc_i[16] -> L.ism[16..32), rc_q[16] -> L.sm[16..32)
 // ------------------------------------------------------------------------------------------
+// phase: which wave of the workgroup runs the gathered Levinson block (the frame's number: the waves take turns)
 LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int p_bw, int nbits,
-                                                  int near_nyquist) {
+                                                  int near_nyquist, int phase) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const lc3_tns_params &tp = c.n_ms_10 ? LC3C_TNS10[p_bw] : LC3C_TNS75[p_bw];
@@ -548,11 +553,23 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
     }
     LC3_STAMP(L, lane, 28);
     // Levinson-Durbin :204-232 and the LPC -> reflection conversion :234-265: one lane per filter, the order-8
-    // recursions fully unrolled on register arrays.
-    int tns_on = 0;  // lanes 0 / 1: the filter's prediction gain passes :219
+    // recursions fully unrolled on register arrays.  ~600 instructions on two lanes per stream: the filters of the WORKGROUP's four
+    // streams run side by side on eight lanes of ONE wave (LC3_SERIAL_BEGIN: inside, `L` is the lane's stream and `sub` its filter;
+    // the waves take turns frame by frame), so a stream pays a quarter of them.  What the block needs travels through the stream's
+    // LDS: quotients and energies (above), bandwidth and near-Nyquist flag (the frame's flag words), and its verdict comes back in
+    // L.ism[4 + filter].
+    (void)near_nyquist;
     LC3_ENC_REPEAT(32)
-    if (lane < 2 && lane < tp.num) {
-        const int f = lane;
+#if LC3_TNS_GATHER
+    LC3_SERIAL_BEGIN(lc3_enc_lds, L, lane, phase, 2)
+#else
+    LC3_LOCAL_BEGIN(lane, 2)
+#endif
+        const int f = sub;
+        float *sAC = (float *)L.fa, *sES = sAC + 64, *rc_q = L.sm + 16;
+        const int num_g = (c.n_ms_10 ? LC3C_TNS10[L.ism[MPF_BW]] : LC3C_TNS75[L.ism[MPF_BW]]).num;
+        int on = 0;  // the filter's prediction gain passes :219
+        if (f < num_g) {
         float r[9];
         const float e_prod = (1.0f * sES[f * 3] * sES[f * 3 + 1]) * sES[f * 3 + 2];
 #pragma unroll
@@ -581,8 +598,8 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
             e *= 1.0f - rc * rc;
         }
         const float pred_gain = e == 0.0f ? r[0] : r[0] / e;
-        if (pred_gain > 1.5f && !near_nyquist) {
-            tns_on = 1;
+        if (pred_gain > 1.5f && !L.ism[MPF_NEAR_NYQUIST]) {
+            on = 1;
             float gamma = 1.0f;
             if (res.lpc_weighting > 0 && pred_gain < 2.0f)
                 gamma -= (1.0f - 0.85f) * (2.0f - pred_gain) / (2.0f - 1.5f);
@@ -602,7 +619,14 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
 #pragma unroll
             for (int k = 0; k < 8; k++) rc_q[f * 8 + k] = 0.0f;
         }
-    }
+        }
+        L.ism[4 + f] = on;
+#if LC3_TNS_GATHER
+    LC3_SERIAL_END
+#else
+    LC3_LOCAL_END
+#endif
+    const int tns_on = lane < 2 ? L.ism[4 + lane] : 0;  // lanes 0 / 1: the stream's own two filters
     LC3_SYNC();
     LC3_STAMP(L, lane, 29);
     // apply_quantization :267-292 -- one lane per coefficient; the orders (:275-291: the last index that is not 8, per filter) and
@@ -856,7 +880,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         // x_s_extended as f32, converted once (every sample is a tap operand of several outputs)
         const int16_t *xs16 = L.t + (c.nf - c.z) - c.hist;
         // (the zero-padded taps of a row may reach up to three samples past the window: those operands must be finite)
-        for (int i = lane; i < ((LC3_ENC_KO & 8192) ? 0 : c.hist + c.nf + 4); i += LC3_WAVE) W[i] = i < c.hist + c.nf ? (float)xs16[i] : 0.0f;
+        for (int i = lane; i < c.hist + c.nf + 4; i += LC3_WAVE) W[i] = i < c.hist + c.nf ? (float)xs16[i] : 0.0f;
         LC3_SYNC();
     }
     // resampling :152-166 -- one lane per 12.8 kHz output, taps accumulated in the reference's order (k ascending).
@@ -881,8 +905,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         const float *ha = poly + (15 * n0 - q0 * p) * c.resamp_stride, *hb = poly + (15 * n1 - q1 * p) * c.resamp_stride;
         float acc0 = 0.0f, acc1 = 0.0f;
         const int dlo = LC3_UNIFORM_I32(15 / p), far = (q1 - q0) != dlo;
-        if (LC3_ENC_KO & 128) acc0 = xa[0];
-        else if (dlo == 3) lc3_resample_pair<3>(xa, ha, hb, nt, far, acc0, acc1);       // p = 4 (48 / 44.1 kHz)
+        if (dlo == 3) lc3_resample_pair<3>(xa, ha, hb, nt, far, acc0, acc1);       // p = 4 (48 / 44.1 kHz)
         else if (dlo == 2) lc3_resample_pair<2>(xa, ha, hb, nt, far, acc0, acc1);  // p = 6 (32 kHz)
         else if (dlo == 1) lc3_resample_pair<1>(xa, ha, hb, nt, far, acc0, acc1);  // p = 8, 12 (24, 16 kHz)
         else lc3_resample_pair<0>(xa, ha, hb, nt, far, acc0, acc1);                // p = 24 (8 kHz)
@@ -916,7 +939,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         float *o12 = (float *)L.fa + 64 + c.delay12 + LC3_NMEM;  // this stream's x12 + delay12 + NMEM
         float m1 = L.st.h50_m1, m2 = L.st.h50_m2;
         #pragma unroll 1
-        for (int n0 = 0; n0 < ((LC3_ENC_KO & 32) ? 0 : len12); n0 += 8) {  // len12 is a multiple of 8; eight samples per LDS round trip
+        for (int n0 = 0; n0 < len12; n0 += 8) {  // len12 is a multiple of 8; eight samples per LDS round trip
             float x[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) x[u] = o12[n0 + u];
@@ -980,7 +1003,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
 #pragma unroll
             for (int u = 0; u < 9; u++) bb[u] = pb[u];
 #pragma unroll  // (a configuration view knows len6: straight-line code, no block is moved between registers)
-            for (int n = 0; n < ((LC3_ENC_KO & 64) ? 0 : len6); n += 16) {
+            for (int n = 0; n < len6; n += 16) {
 #pragma unroll
                 for (int u = 0; u < 8; u++) an[u] = pa[n + 8 + u];
 #pragma unroll
@@ -1050,7 +1073,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     // compute_normalized_value :445-455 for lag 0, lag_t1, lag_t2: the squares once, one sample per lane, then three lanes
     // add 64 of them each in the reference's order
     float *sq = S + 224;  // 178 floats
-    for (int n = lane; n < ((LC3_ENC_KO & 16384) ? 0 : LC3_KMAX + len6); n += LC3_WAVE) {
+    for (int n = lane; n < LC3_KMAX + len6; n += LC3_WAVE) {
         const float v = x6[n];
         sq[n] = v * v;
     }
@@ -1063,7 +1086,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     LC3_SERIAL_BEGIN(lc3_enc_lds, L, lane, ltpf_phase + 1, 3)
         const float *sq_ = (const float *)L.fb + 224;
         const int lag = sub == 0 ? 0 : L.ism[8 + sub - 1];
-        L.sm[8 + sub] = lc3_sum_seq(sq_ + (LC3_KMAX - lag), (LC3_ENC_KO & 16384) ? 0 : len6, 0.0f);
+        L.sm[8 + sub] = lc3_sum_seq(sq_ + (LC3_KMAX - lag), len6, 0.0f);
     LC3_SERIAL_END
     int t_current, pitch_present;
     {   // the decision is then the same scalar code on every lane
@@ -1088,7 +1111,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         L.ism[11] = (k_max + 4) - (k_min - 4) + 1;  // <= 17
     }
     LC3_SERIAL_WIDE_BEGIN(lc3_enc_lds, L, lane, ltpf_phase + 2, 17)
-        if (!(LC3_ENC_KO & 2048) && sub < L.ism[11]) {
+        if (sub < L.ism[11]) {
             const float *x12_ = (const float *)L.fa + 64;
             const int k = L.ism[10] + sub;
             ((float *)L.fb)[200 + sub] = lc3_dot_seq(x12_ + LC3_NMEM, x12_ + LC3_NMEM - k, len12, 0.0f);  // len12 is a multiple of 8
@@ -1180,27 +1203,34 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 15);
-    // activation_bit :365-409 -- interpolated signals in parallel, the three 128-term sums on three lanes
-    {
+    // activation_bit :365-409 -- interpolated signals in parallel, the three 128-term sums on three lanes.
+    // The normalised correlation `nc` of a frame has two uses: the activation decision of this frame and of the next two (through
+    // mem_nc / mem_mem_nc), and that decision is `false` whatever nc is while the bit rate keeps the filter off (gain_ltpf_on, :146 --
+    // every frame of the headline configuration).  The bit rate is the launch's, so in such a launch only the nc of its LAST TWO frames can
+    // ever matter (they are what the state blob keeps for a later launch at another rate): the caller marks the other frames (bit 8 of
+    // ltpf_phase) and they skip the 3 x 128 products and sums.  Workgroup-uniform: every wave of the workgroup is at the same frame of the
+    // same launch.
+    const int skip_nc = ((ltpf_phase >> 8) & 1) && !gain_ltpf_on;
+    if (!skip_nc) {
         // the products of the three sums are formed here, one sample per lane (a product is the same f32 operation wherever
         // it runs); the three lanes below only add them up in the reference's order
-        for (int n = lane; n < ((LC3_ENC_KO & 4096) ? 0 : len12); n += LC3_WAVE) {
+        for (int n = lane; n < len12; n += LC3_WAVE) {
             const float a = lc3_ltpf_dot(x12, n, 0);
             const float b = lc3_ltpf_dot(x12, n - pitch_int, pitch_fr);
             S[n] = a * b;
             S[128 + n] = a * a;
             S[256 + n] = b * b;
         }
+        // sub 0: sum dA*dB, 1: sum dA*dA, 2: sum dB*dB -- twelve lanes of one wave for the workgroup's four streams
+        LC3_SERIAL_BEGIN(lc3_enc_lds, L, lane, ltpf_phase + 3, 3)
+            L.sm[12 + sub] = lc3_sum_seq((const float *)L.fb + 128 * sub, len12, 0.0f);
+        LC3_SERIAL_END
     }
-    // sub 0: sum dA*dB, 1: sum dA*dA, 2: sum dB*dB -- twelve lanes of one wave for the workgroup's four streams
-    LC3_SERIAL_BEGIN(lc3_enc_lds, L, lane, ltpf_phase + 3, 3)
-        L.sm[12 + sub] = lc3_sum_seq((const float *)L.fb + 128 * sub, (LC3_ENC_KO & 32768) ? 0 : len12, 0.0f);
-    LC3_SERIAL_END
     int ltpf_active = 0;
     {
-        const float num = L.sm[12], nd = L.sm[13], sh = L.sm[14];
+        const float num = skip_nc ? 0.0f : L.sm[12], nd = skip_nc ? 0.0f : L.sm[13], sh = skip_nc ? 0.0f : L.sm[14];
         const float den = lc3_sqrtf(nd * sh);
-        float nc = den > 0.0f ? num / den : 0.0f;
+        float nc = den > 0.0f ? num / den : 0.0f;  // (a skipped frame: 0, never looked at)
         const float pitch = (float)pitch_int + (float)pitch_fr / 4.0f;
         if (gain_ltpf_on && !near_nyquist) {
             const int ma = L.st.mem_ltpf_active;
@@ -1426,8 +1456,10 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
         const lc3_f4 x = *(const lc3_f4 *)(L.spec + 4 * (n < ne4 ? n : 0));
         const float total = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
         const float ei = n < ne4 ? 10.0f * lc3_log10f(1.1920929e-7f + total) : 0.0f;
-        const float m = lc3_maxf(lc3_maxf(lc3_absf(x.x), lc3_absf(x.y)), lc3_maxf(lc3_absf(x.z), lc3_absf(x.w)));
-        amax = lc3_maxf(amax, m);  // (a lane past the last group repeats group 0)
+        // f32::max of magnitudes: with no negative zero among the operands the hardware maximum (IEEE mode: a NaN operand yields the
+        // other one) returns what Rust's NaN-ignoring max returns, in one instruction instead of two compares and two selects each
+        const float m = __builtin_fmaxf(__builtin_fmaxf(lc3_absf(x.x), lc3_absf(x.y)), __builtin_fmaxf(lc3_absf(x.z), lc3_absf(x.w)));
+        amax = __builtin_fmaxf(amax, m);  // (a lane past the last group repeats group 0)
         e14[q] = ei * 28.0f / 20.0f;
         e28[q] = 2.0f * ei * 28.0f / 20.0f;
     }
@@ -1812,24 +1844,24 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_front_wave(LC3_CFG_P
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
-    const int near_nyquist = (LC3_ENC_KO & 1) ? 0 : lc3_enc_mdct(LC3_CFG_PASS, LC3_LDS_PASS lane, pcm, hist, stride, hstride);
+    const int near_nyquist = LC3_KO(LC3_ENC_KO, 1) ? 0 : lc3_enc_mdct(LC3_CFG_PASS, LC3_LDS_PASS lane, pcm, hist, stride, hstride);
     LC3_STAMP(L, lane, 1);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[i] = L.spec[i];
     if (dbg && lane < c.nb) dbg[LC3_ENC_DBG_EB + lane] = LC3_EB(L)[lane];  // the band energies (modified_dct.rs:140-152)
     int nbits_bw = 3;
-    const int bw_ind = (LC3_ENC_KO & 2) ? 4 : lc3_enc_bandwidth(LC3_CFG_PASS, LC3_LDS_PASS lane, &nbits_bw);
+    const int bw_ind = LC3_KO(LC3_ENC_KO, 2) ? 4 : lc3_enc_bandwidth(LC3_CFG_PASS, LC3_LDS_PASS lane, &nbits_bw);
     LC3_STAMP(L, lane, 24);
-    const int attack = (LC3_ENC_KO & 4) ? 0 : lc3_enc_attack(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes);
+    const int attack = LC3_KO(LC3_ENC_KO, 4) ? 0 : lc3_enc_attack(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes);
     LC3_STAMP(L, lane, 2);
-    if (!(LC3_ENC_KO & 8)) lc3_enc_sns_front(LC3_CFG_PASS, LC3_LDS_PASS lane, attack);
+    if (!LC3_KO(LC3_ENC_KO, 8)) lc3_enc_sns_front(LC3_CFG_PASS, LC3_LDS_PASS lane, attack);
     if (mid) {  // targets and spectrum leave LDS before the LTPF stage reuses fa/fb
         if (lane < 16) mid[MP_SCF + lane] = LC3_SCF(L)[lane];
-        lc3_wave_copy_out16(mid + MP_SPEC, L.spec, c.nf / 4, lane);
+        lc3_wave_copy_out16(mid + MP_SPEC, L.spec, c.ne / 4, lane);  // (the ne lines the later stages use: ne is a multiple of four)
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 3);
     lc3_ltpf_res pf = {0, 0, 0, 1};
-    if (LC3_ENC_KO & 16) {
+    if (LC3_KO(LC3_ENC_KO, 16)) {
     } else if (outline_ltpf) pf = lc3_enc_ltpf_call(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, plane != nullptr, phase);
     else pf = lc3_enc_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, near_nyquist, nbits, g, plane != nullptr, phase);
     LC3_STAMP(L, lane, 5);
@@ -1869,7 +1901,7 @@ struct lc3_mid_fetch {
 template <class CC>
 __device__ __forceinline__ void lc3_mid_issue(const CC &c, int lane, const float *mid, lc3_mid_fetch &m) {
     LC3_HBM_CONST(lc3_i4) s4 = (LC3_HBM_CONST(lc3_i4))(mid + MP_SPEC);
-    const int n4 = c.nf / 4;  // <= 120
+    const int n4 = c.ne / 4;  // <= 100: the lines below ne (the front half stores no others)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int i = lane + LC3_WAVE * j;
@@ -1883,9 +1915,10 @@ __device__ __forceinline__ void lc3_mid_issue(const CC &c, int lane, const float
 }
 
 // m: this frame's mid-plane words, fetched by lc3_mid_issue
+// phase: the frame's number in the launch (which wave of the workgroup runs a block gathered over its streams: they take turns)
 LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const float *mid,
                                                      const lc3_mid_fetch &m, int32_t *plane, int plane_stride, int nbytes,
-                                                     int store, float *dbg) {
+                                                     int store, float *dbg, int phase = 0) {
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
@@ -1896,7 +1929,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PA
     if (lane < c.nb) gs[lane] = m.g;
     LC3_SYNC();
     LC3_ENC_REPEAT(128) {
-        const int n4 = c.nf / 4;
+        const int n4 = c.ne / 4;  // (L.spec from ne on is not written: nothing below reads a line there without selecting it away)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int i = lane + LC3_WAVE * j;
@@ -1927,15 +1960,15 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PA
     LC3_STAMP(L, lane, 19);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[480 + i] = L.spec[i];
     lc3_tns_res tns = {};
-    if (LC3_ENC_KO & 256) tns.nbits_tns = 2, tns.num_tns_filters = 2;
-    else tns = lc3_enc_tns(LC3_CFG_PASS, LC3_LDS_PASS lane, bw_ind, nbits, near_nyquist);
+    if (LC3_KO(LC3_ENC_KO, 256)) tns.nbits_tns = 2, tns.num_tns_filters = 2;
+    else tns = lc3_enc_tns(LC3_CFG_PASS, LC3_LDS_PASS lane, bw_ind, nbits, near_nyquist, phase);
     LC3_STAMP(L, lane, 4);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[960 + i] = L.spec[i];
     lc3_quant_res spec = {};
-    if (LC3_ENC_KO & 512) spec.lastnz_trunc = 2, spec.gg = 1.0f;
+    if (LC3_KO(LC3_ENC_KO, 512)) spec.lastnz_trunc = 2, spec.gg = 1.0f;
     else spec = lc3_enc_quant(LC3_CFG_PASS, LC3_LDS_PASS lane, nbits, nbits_bw, tns.nbits_tns, nbits_ltpf);
     LC3_STAMP(L, lane, 6);
-    int rn = (LC3_ENC_KO & 1024) ? 0 : lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
+    int rn = LC3_KO(LC3_ENC_KO, 1024) ? 0 : lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
     LC3_ENC_REPEAT_MORE(64) rn = lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
     LC3_STAMP(L, lane, 7);
     const int n_res = rn & 0xffff, noise_factor = rn >> 16;

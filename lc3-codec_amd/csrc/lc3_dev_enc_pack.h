@@ -499,12 +499,6 @@ __device__ __forceinline__ int lc3_pack_produce(const lc3_pack_ctx &w, const lc3
 #pragma unroll
         for (int u = 0; u < LC3_PC_CHUNK; u++) {
             uint32_t word = 0u;
-#if LC3_PKPC_KO == 1  // timing experiment: a producer that costs nothing (the output is garbage)
-            if (tup < ntup) {
-                word = LC3_PK_SYM_VALID | LC3_SYM_WORD(100u + (uint32_t)(tup & 7), 50u, 2, (uint32_t)(tup & 3));
-                tup += ((it + u) & 3) != 0;
-            }
-#else
             if (tup < ntup) {
                 // where the lane will be after this symbol, and that symbol's model row (see lc3_pack_frame)
                 const int adv = !cur.esc;
@@ -533,7 +527,6 @@ __device__ __forceinline__ int lc3_pack_produce(const lc3_pack_ctx &w, const lc3
                 x2 = adv ? x3 : x2;
                 x3 = (uint32_t)lc3_ep_get(w, EP_XQ + (tup + 3 < last ? tup + 3 : last));  // the same word again unless the lane advanced
             }
-#endif
             k.ring[((it + u) & k.mask) * k.stride] = word;  // every lane: a lane that has finished its frame says so
         }
         it += LC3_PC_CHUNK;
@@ -565,7 +558,7 @@ __device__ __forceinline__ int lc3_pack_consume(lc3_pack_ctx &w, const lc3_pc_li
 #pragma unroll
         for (int u = 0; u < LC3_PC_CHUNK; u++) {
             const uint32_t s0 = k.ring[((it + u) & k.mask) * k.stride];
-            if ((LC3_PKPC_KO != 2) && (s0 & LC3_PK_SYM_VALID)) {
+            if (s0 & LC3_PK_SYM_VALID) {
                 lc3_pk_ac_encode_sel(w, s0 & 0x3ffu, (s0 >> 10) & 0x3ffu);
                 const int nb = (int)((s0 >> 20) & 3u);
                 lc3_pk_bool2_backward_sel(w, nb > 0, (int)((s0 >> 22) & 1u), nb > 1, (int)((s0 >> 23) & 1u));

@@ -13,10 +13,11 @@
 #pragma once
 
 // ---- encoder, wave-per-stream halves (lc3_dev_enc.h) ----
-// LC3_ENC_KO: 1 no MDCT, 2 no bandwidth detector, 4 no attack detector, 8 no SNS targets, 16 no LTPF analysis, 32 no high-pass recursion,
-//   64 no 98-lag correlations, 128 no resampler sums, 256 no TNS, 512 no quantiser, 1024 no residual / noise stage, 2048 no 17-lag
-//   correlations, 4096 no activation products, 8192 no float copy of the resampler's window, 16384 no squares / normalised values,
-//   32768 no activation sums
+// LC3_ENC_KO (stage level, at the stages' call sites): 1 no MDCT, 2 no bandwidth detector, 4 no attack detector, 8 no SNS targets,
+//   16 no LTPF analysis, 256 no TNS, 512 no quantiser, 1024 no residual / noise stage.
+// (Settled and removed in round 5, their results are in profiles/r04_knockout_*.txt and DESIGN.md: the switches inside the LTPF stage,
+//   the synthesis kernel's LC3_DEC_KO, the wave-per-frame reconstruction's LC3_RECON_KO / LC3_TNS_KO and the "one half only" builds of the
+//   producer / consumer pairs, LC3_PCPARSE_KO / LC3_PKPC_KO, which sat inside the unrolled symbol loops.)
 #ifndef LC3_ENC_KO
 #define LC3_ENC_KO 0
 #endif
@@ -27,37 +28,21 @@
 #ifndef LC3_ENC_DUP
 #define LC3_ENC_DUP 0
 #endif
-// ---- synthesis kernel (lc3_dev_dec.h) ----
-// LC3_DEC_KO: 1 no load / store of the stream state, 2 no overlap memory, 4 no copy of the last good spectrum, 8 no inverse transform,
-//   16 no post-filter, 32 no PCM stores, 64 plane loads: side information only
-#ifndef LC3_DEC_KO
-#define LC3_DEC_KO 0
-#endif
-// ---- wave-per-frame reconstruction (lc3_dev_dec_recon.h) ----
-#ifndef LC3_TNS_KO
-#define LC3_TNS_KO 0
-#endif
-#ifndef LC3_RECON_KO
-#define LC3_RECON_KO 0  // 4 no scale factors / band gains, 8 no line work
-#endif
-// ---- producer / consumer pairs ----
-#ifndef LC3_PCPARSE_KO
-#define LC3_PCPARSE_KO 0  // 2 = a consumer that only follows the producer through the symbols
-#endif
-#ifndef LC3_PKPC_KO
-#define LC3_PKPC_KO 0  // 1 = a producer that costs nothing, 2 = a consumer that codes nothing
-#endif
-
 #define LC3_KO(set, bit) (((set) & (bit)) != 0)
 #ifndef LC3_EXP_TWO  // lc3gpu.hip: a 2 the compiler cannot see through
 #define LC3_EXP_TWO() 2
+#endif
+#ifndef LC3_EXP_CLOBBER
+#define LC3_EXP_CLOBBER() ((void)0)
 #endif
 #define LC3_EXP_REPS(set, bit) ((((set) & (bit)) != 0) ? LC3_EXP_TWO() : 1)
 // in front of a statement: run it once more per set bit.  A production build sees NOTHING here (not even a loop of one trip: the
 // headline kernels sit at the edge of their register budgets and a different statement structure moves the allocation)
 #if LC3_ENC_DUP
-#define LC3_ENC_REPEAT(bit) for (int rep_ = LC3_EXP_REPS(LC3_ENC_DUP, bit); rep_ > 0; rep_--)
-#define LC3_ENC_REPEAT_MORE(bit) for (int rep_ = LC3_EXP_REPS(LC3_ENC_DUP, bit); rep_ > 1; rep_--)  // the statement is a second copy
+// (the memory clobber after every run: what the piece loads is loaded again, what it stores is stored again -- without it the compiler
+// hoists a piece without side effects out of the loop and the repeat costs nothing)
+#define LC3_ENC_REPEAT(bit) for (int rep_ = LC3_EXP_REPS(LC3_ENC_DUP, bit); rep_ > 0; rep_--, LC3_EXP_CLOBBER())
+#define LC3_ENC_REPEAT_MORE(bit) for (int rep_ = LC3_EXP_REPS(LC3_ENC_DUP, bit); rep_ > 1; rep_--, LC3_EXP_CLOBBER())  // the statement is a second copy
 #else
 #define LC3_ENC_REPEAT(bit)
 #define LC3_ENC_REPEAT_MORE(bit) if (false)

@@ -166,6 +166,8 @@ static __device__ __forceinline__ int lc3_exp_two() {
     return n;
 }
 #define LC3_EXP_TWO() lc3_exp_two()
+static __device__ __forceinline__ void lc3_exp_clobber() { asm volatile("" : : : "memory"); }
+#define LC3_EXP_CLOBBER() lc3_exp_clobber()
 // product of two values below 2^24 (range-coder steps): the full-rate 24-bit multiplier instead of the quarter-rate v_mul_lo_u32
 #define LC3_MUL24(a, b) __umul24((a), (b))
 #define LC3_WAVE_ANY(pred) (__ballot((pred) != 0) != 0ull)
@@ -599,8 +601,10 @@ __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigne
         const int16_t *frame = lc3_io_pcm(io, pcm, nf, first_channel, s, t, n_frames, &stride);
         // MDCT history: the tail of the previous frame of this launch, else the state blob's copy (silence when fresh)
         const int16_t *hist = t > 0 ? frame - (size_t)(nf - z) * (size_t)stride : (fresh ? nullptr : gst->hist);
+        // (phase: the frame's number -- the waves of the workgroup take turns at the gathered blocks -- and, bit 8, "not one of the launch's
+        // last two frames": lc3_enc_ltpf skips work whose only use is the state blob's memory of the last two frames)
         lc3_encode_front_wave(cfg, L, lane, frame, hist, gst, mcol, plane, LC3_PLANE_STRIDE, nbytes, valid ? dbg : nullptr, stride,
-                              t > 0 ? stride : 1, t, OUTLINE_LTPF);
+                              t > 0 ? stride : 1, t + (t + 2 < n_frames ? 0x100 : 0), OUTLINE_LTPF);
     }
     if (valid) {
         int stride = 1;
@@ -711,7 +715,7 @@ __device__ __forceinline__ void lc3_enc_back_body(lc3_cfg_slot<CV> cfg, unsigned
         const size_t f = fbase + (size_t)t;
         if (t + 1 < n_frames) lc3_mid_issue(c0, lane, mid + (f + 1) * (size_t)MP_WORDS, nxt);  // lands while frame t is worked on
         lc3_encode_back_wave(cfg, L, lane, mid + f * (size_t)MP_WORDS, cur, LC3_PLANE_COL(planes, f, EP_WORDS), LC3_PLANE_STRIDE,
-                             nbytes, valid, valid ? dbg : nullptr);
+                             nbytes, valid, valid ? dbg : nullptr, t);
         cur = nxt;
     }
     if (valid) lc3_enc_state_store(c0, L, lane, gst, nullptr);
@@ -1305,7 +1309,7 @@ __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned w
     lc3_fft_tables_stage(c0);
     LC3_PROF_BEGIN(L, lane);
     if (fresh) lc3_dec_state_init(L, lane, gst, valid);
-    else if (!(LC3_DEC_KO & 1)) lc3_dec_state_load(L, lane, gst);
+    else lc3_dec_state_load(L, lane, gst);
     LC3_PROF_MARK(L, lane, 38);  // state load
     const size_t fbase = (size_t)s * (size_t)n_frames;
     int stride;
@@ -1313,7 +1317,7 @@ __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned w
     lc3_decode_stream_wave(cfg, L, lane, nbytes, planes, fbase, n_frames, gst, valid, pcm0, (size_t)nf * (size_t)stride, stride, LATE, dbg,
                            dbg_flags);
     LC3_PROF_MARK(L, lane, 39);  // frames (incl. everything between the stage stamps)
-    if (valid && !(LC3_DEC_KO & 1)) lc3_dec_state_store(L, lane, gst);
+    if (valid) lc3_dec_state_store(L, lane, gst);
     LC3_PROF_END(L, lane, 35);
 }
 template <class CV>

@@ -279,6 +279,35 @@ def test_variable_bitrate_per_call():  # nbits = 8 * buf_out.len() may change pe
         assert np.array_equal(gp, wp), f"frame {t} pcm"
 
 
+def test_bit_rate_changes_between_launches_of_several_frames():
+    """The frame size may change from call to call (nbits = 8 * buf_out.len(), lc3_encoder.rs:65), and with it whether the long-term
+    post-filter may switch on (long_term_post_filter.rs:146).  A launch at a rate that keeps the filter off only computes the
+    normalised correlation of its LAST TWO frames (lc3_enc_ltpf: nothing else can reach an output or the state): launches of 1 .. 5
+    frames at alternating rates, state carried, against oracle encoders fed the same frames one by one.  The material keeps the filter
+    switching (steady, gliding and interrupted tones) beside the usual synthetic streams."""
+    lt = synth.make_ltpf_pcm(480, 48000, n_frames=20)
+    pcm = np.concatenate([lt, synth.make_pcm(29, 20, 480, 48000, seed=23)], axis=0)
+    S = pcm.shape[0]
+    plan = [(4, 150), (3, 60), (5, 150), (1, 80), (2, 150), (3, 100), (2, 40)]  # (frames, bytes per frame): 880 bits = 110 bytes is the border
+    assert sum(n for n, _ in plan) == 20
+    enc = pkg.Lc3Encoder(S, US, FS)
+    oracle = [O.Encoder() for _ in range(S)]
+    t0, active = 0, 0
+    for n, nb in plan:
+        got = gpu_encode(pcm[:, t0:t0 + n], nb, enc=enc)
+        for s_i in range(S):
+            for t in range(n):
+                want = oracle[s_i].encode_frame(pcm[s_i, t0 + t], nb)
+                assert np.array_equal(got[s_i, t], want), f"stream {s_i} frame {t0 + t} ({nb} bytes)"
+        if nb < 110:  # ltpf_active is the bit after pitch_present's group: count it through the decoder instead
+            O.ltpf_transition_counts(reset=True)
+            O.decode_batch(got, 480)
+            c = O.ltpf_transition_counts()
+            active += sum(c[2:])
+        t0 += n
+    assert active > 0, "the post-filter never switched on: the test material lost its point"
+
+
 # ---------------------------------------------------------------- corrupt frames / PLC
 def test_corrupt_frames_are_concealed_like_the_reference():  # lc3_decoder.rs:138-141, packet_loss_concealment.rs
     S, T = 6, 12
