@@ -57,20 +57,26 @@ def parse_args(argv=None):
                          "(default 1: one stream, clean per-kernel timing)")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip timing the OTHER arrangements (see --arrangement) after the timed region")
-    ap.add_argument("--arrangement", choices=("single", "pipelined", "staggered", "quad"), default="pipelined",
+    ap.add_argument("--arrangement", type=arrangement_name, default=arrangement_name("quad"),
                     help="how the timed steps are queued: `single` = encode then decode of the same batch on ONE HIP stream (every call waits for "
                          "the one before it); `pipelined` = the recommended caller pattern (INTEGRATION.md): the encoder handle on one HIP stream, the "
                          "decoder handle on another, two byte buffers and events, so that the decoder works on step k while the encoder runs step k + 1; "
                          "`staggered` = the same with three buffers and the decoder call queued behind the encoder's LC3GPU_ENC_STAGE_BACK event of the "
-                         "next step (lc3gpu_encoder_stage_event); `quad` = two halves of the streams, each half `pipelined` by itself with its own handle pair on "
-                         "its own two HIP streams.  The other arrangements are timed too and reported beside `value`")
+                         "next step (lc3gpu_encoder_stage_event); `split:a+b[+c..]` = the streams in as many equal groups as there are numbers, every group with "
+                         "an encoder handle and a decoder handle of its own, on 2 HIP streams (`pipelined` by itself) or on 1 (encode then decode): "
+                         "`quad` = split:2+2, `tri` = split:2+1, `duo` = split:1+1.  The other arrangements are timed too and reported beside `value`")
+    ap.add_argument("--also", type=arrangement_name, action="append", default=None,
+                    help="further arrangements to time after the timed region, beside single / pipelined / staggered (repeatable; default: duo, quad)")
     ap.add_argument("--sustain-seconds", type=float, default=2.5,
                     help="length of the sustained leg: back-to-back steps for this long, frames/s and the shader clock read by a one-wave probe kernel "
                          "beside them (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--engine", choices=("gpu", "emu"), default="gpu", help=argparse.SUPPRESS)
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.also is None:
+        a.also = [arrangement_name("duo"), arrangement_name("quad")]
+    return a
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -237,6 +243,23 @@ def kernel_source_sha():
     return h.hexdigest()
 
 
+SPLIT_ALIASES = {"quad": "split:2+2", "tri": "split:2+1", "duo": "split:1+1"}
+
+
+def arrangement_name(a):
+    """argparse type of --arrangement: single | pipelined | staggered | split:N+N.. (N = 1 or 2 HIP streams of a group) | quad | tri | duo"""
+    a = SPLIT_ALIASES.get(a, a)
+    if a in ("single", "pipelined", "staggered"):
+        return a
+    if a.startswith("split:") and all(x in ("1", "2") for x in a[6:].split("+")) and 2 <= len(a[6:].split("+")) <= 4:
+        return a
+    raise argparse.ArgumentTypeError("arrangement: single, pipelined, staggered, quad, tri, duo or split:a+b[+c[+d]] with a, b .. in {1, 2}")
+
+
+def arrangement_streams(a):
+    return sum(int(x) for x in a[6:].split("+")) if a.startswith("split:") else (1 if a == "single" else 2)
+
+
 def load_ceiling():
     """the measured issue ceiling and copy bandwidth (tools/valu_ceiling.hip -> profiles/r04_valu_ceiling.json): cycles per wave64
     vector instruction of the codec's instruction mix on one SIMD, by waves per SIMD, and the device copy rate"""
@@ -307,10 +330,10 @@ class GpuEngine:
             # stream waits for it
             self.ev_back = torch.cuda.Event()
             self.ev_back.record(self.s_enc)  # (torch creates the HIP event at its first record)
-            # the `quad` arrangement: the batch as TWO halves of its streams, each half with an encoder handle and a decoder handle of its
-            # own on two HIP streams of its own (four caller streams), each half `pipelined` by itself.  Handles, streams and events
-            # are created when the arrangement is first selected
-            self.quad = None
+            # the `split:..` arrangements: the batch as GROUPS of its streams, each group with an encoder handle and a decoder handle of its
+            # own on one or two HIP streams of its own.  Handles, streams and events are created when an arrangement is first selected
+            self.splits = {}
+            self.extra_streams = []  # HIP streams beyond the default one and s_dec, shared by every split arrangement
 
     device = "cuda"
     carries_state = True
@@ -322,20 +345,35 @@ class GpuEngine:
         self.arrangement, self.k = name, 0
         if self.mode == "roundtrip" and self.NP == 1:
             self.encs[0].stage_event(self.pkg.ENC_STAGE_BACK, self.ev_back if name == "staggered" else None)
-        if name == "quad" and self.quad is None:
+        if name.startswith("split:") and name not in self.splits:
+            # The chip has a handful of hardware queues (4 by default, GPU_MAX_HW_QUEUES) and the runtime deals HIP streams onto them; two
+            # streams on one queue run one behind the other, and a stream waiting for an event holds up whatever shares its queue.  So
+            # the arrangements draw their streams from ONE list -- the default stream, the pipelined arrangement's decoder stream, then
+            # streams created as needed -- and `quad` runs on four streams of which only two are new.
             torch, pkg = self.torch, self.pkg
-            assert self.S % 2 == 0
-            h = self.S // 2
-            mk = lambda cls: [cls(h, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000) for _ in range(2)]
-            ev = lambda: [[torch.cuda.Event() for _ in range(2)] for _ in range(2)]
-            self.quad = {"half": h, "encs": mk(pkg.Lc3Encoder), "decs": mk(pkg.Lc3Decoder),
-                         "s_enc": [torch.cuda.Stream() for _ in range(2)], "s_dec": [torch.cuda.Stream() for _ in range(2)],
-                         "enc_done": ev(), "dec_done": ev()}
+            widths = [int(x) for x in name[6:].split("+")]
+            G = len(widths)
+            pool = [self.s_enc, self.s_dec] + self.extra_streams
+            while len(pool) < sum(widths):
+                st = torch.cuda.Stream()
+                self.extra_streams.append(st)
+                pool.append(st)
+            bounds = [((self.S // 4) * g // G) * 4 for g in range(G)] + [self.S]  # groups of whole workgroups (four streams each)
+            groups, nxt = [], 0
+            for g, w in enumerate(widths):
+                lo, hi = bounds[g], bounds[g + 1]
+                mk = lambda cls: cls(hi - lo, pkg.FrameDuration.TenMs, pkg.SamplingFrequency.Hz48000)
+                groups.append({"lo": lo, "hi": hi, "enc": mk(pkg.Lc3Encoder), "dec": mk(pkg.Lc3Decoder), "s_enc": pool[nxt],
+                               "s_dec": pool[nxt + w - 1], "enc_done": [torch.cuda.Event() for _ in range(2)],
+                               "dec_done": [torch.cuda.Event() for _ in range(2)]})
+                nxt += w
+            self.splits[name] = groups
 
     def _handles(self):
         """the handles of the current arrangement"""
-        if self.arrangement == "quad":
-            return self.quad["encs"], self.quad["decs"]
+        if self.arrangement.startswith("split:"):
+            gs = self.splits[self.arrangement]
+            return [g["enc"] for g in gs], [g["dec"] for g in gs]
         return self.encs, self.decs
 
     def _decode_pending(self, beside_packer):
@@ -363,20 +401,24 @@ class GpuEngine:
             self.pending = k
             self.k += 1
             return
-        if self.arrangement == "quad":
-            # two halves of the streams, each `pipelined` by itself on its own encoder stream and decoder stream (the halves never join:
-            # each keeps its own encode -> decode -> encode chain, so four kernels of four calls can meet on the chip at any moment)
-            q, k, b = self.quad, self.k, self.k & 1
-            for g in range(2):
-                lo, hi = g * q["half"], (g + 1) * q["half"]
-                se, sd = q["s_enc"][g], q["s_dec"][g]
+        if self.arrangement.startswith("split:"):
+            # groups of the streams, each with its own handle pair: on two HIP streams `pipelined` by itself (two byte buffers, events), on
+            # one HIP stream encode then decode in stream order.  The groups never join: each keeps its own encode -> decode -> encode
+            # chain, so kernels of several calls can meet on the chip at any moment
+            k, b = self.k, self.k & 1
+            for g in self.splits[self.arrangement]:
+                lo, hi, se, sd = g["lo"], g["hi"], g["s_enc"], g["s_dec"]
+                if se is sd:
+                    g["enc"].encode(self.d_pcm[lo:hi], self.bufs[b][lo:hi], NBYTES, self.T, stream=se.cuda_stream)
+                    g["dec"].decode(self.bufs[b][lo:hi], self.d_out[lo:hi], NBYTES, self.T, stream=se.cuda_stream)
+                    continue
                 if k >= 2:
-                    se.wait_event(q["dec_done"][g][b])
-                q["encs"][g].encode(self.d_pcm[lo:hi], self.bufs[b][lo:hi], NBYTES, self.T, stream=se.cuda_stream)
-                q["enc_done"][g][b].record(se)
-                sd.wait_event(q["enc_done"][g][b])
-                q["decs"][g].decode(self.bufs[b][lo:hi], self.d_out[lo:hi], NBYTES, self.T, stream=sd.cuda_stream)
-                q["dec_done"][g][b].record(sd)
+                    se.wait_event(g["dec_done"][b])
+                g["enc"].encode(self.d_pcm[lo:hi], self.bufs[b][lo:hi], NBYTES, self.T, stream=se.cuda_stream)
+                g["enc_done"][b].record(se)
+                sd.wait_event(g["enc_done"][b])
+                g["dec"].decode(self.bufs[b][lo:hi], self.d_out[lo:hi], NBYTES, self.T, stream=sd.cuda_stream)
+                g["dec_done"][b].record(sd)
             self.k += 1
             return
         if self.arrangement == "pipelined":
@@ -415,8 +457,8 @@ class GpuEngine:
 
     def _last_stream(self):
         """the stream the step's last call was queued on"""
-        if self.arrangement == "quad":
-            return self.quad["s_dec"][1]
+        if self.arrangement.startswith("split:"):
+            return self.splits[self.arrangement][-1]["s_dec"]
         return self.s_dec if self.arrangement != "single" else self.hs[0]
 
     def step_times_ms(self):
@@ -425,20 +467,23 @@ class GpuEngine:
 
     def reset(self):
         self.sync()
-        for h in self.encs + self.decs + (self.quad["encs"] + self.quad["decs"] if self.quad else []):
+        for h in self.encs + self.decs + [g[k] for gs in getattr(self, "splits", {}).values() for g in gs for k in ("enc", "dec")]:
             h.reset()
         self.k = 0
 
     def sample(self, k):
-        """the k streams the parity gate looks at: the first k -- in the `quad` arrangement the first k / 2 of either half"""
-        if self.arrangement == "quad":
-            h = self.quad["half"]
-            return np.concatenate([np.arange(0, k // 2), np.arange(h, h + k - k // 2)])
+        """the k streams the parity gate looks at: the first k -- in a split arrangement the first k / G of every group"""
+        import numpy as np
+
+        if self.arrangement.startswith("split:"):
+            gs = self.splits[self.arrangement]
+            per = max(1, k // len(gs))
+            return np.concatenate([np.arange(g["lo"], min(g["hi"], g["lo"] + per)) for g in gs])
         return np.arange(k)
 
     def last_bytes(self, k):
         """the sampled streams' frame bytes of the most recent step"""
-        if self.arrangement in ("pipelined", "quad"):
+        if self.arrangement == "pipelined" or self.arrangement.startswith("split:"):
             buf = self.bufs[(self.k - 1) & 1]
         elif self.arrangement == "staggered":
             buf = self.bufs[(self.k - 1) % 3]
@@ -671,7 +716,8 @@ def run_rank(args):
         eng.sync()
         k = min(n_distinct, 256 if rank == 0 else 32)
         thr = max(1, granted_cpus()[0] // max(1, world))
-        idx = eng.sample(k) if hasattr(eng, "sample") else np.arange(k)  # (`quad`: streams of both halves)
+        idx = eng.sample(k) if hasattr(eng, "sample") else np.arange(k)  # (split arrangements: streams of every group)
+        k = len(idx)
         two = np.ascontiguousarray(np.concatenate([pcm_host[idx], pcm_host[idx]], axis=1))  # every step codes the same T frames
         ref_b = O.encode_batch(two, NBYTES, FS, US, threads=thr)
         got_b, got_p = eng.results(k)
@@ -706,13 +752,13 @@ def run_rank(args):
     other, others, sustained = None, [], None
     if world == 1 and not emu:
         if can_pipeline and not args.no_overlap_probe:
-            for arr2 in [a for a in ("single", "pipelined", "staggered", "quad") if a != main_arr]:
+            for arr2 in [a for a in ("single", "pipelined", "staggered") + tuple(args.also) if a != main_arr]:
                 par2, mism2 = gate(arr2) if not args.no_parity else (None, 0)
                 eng.set_arrangement(arr2)
                 el2, km2, st2 = eng.timed_steps(args.steps, args.warmup, kernel_events=KERNEL_EVENTS_EVERY, marks=True)
                 others.append({"arrangement": arr2, "value": frames_per_step * args.steps / el2, "unit": "frames/s", "ms_per_step": el2 / args.steps * 1e3,
                                "ms_per_step_median": st2[len(st2) // 2] if st2 else None, "kernel_ms": km2, "parity": par2, "parity_mismatches": mism2,
-                               "hip_streams": {"single": 1, "quad": 4}.get(arr2, 2)})
+                               "hip_streams": arrangement_streams(arr2)})
                 total_mismatches += mism2
             other = others[0]  # (the one-stream arrangement unless that is the timed one)
         if args.sustain_seconds > 0:
@@ -797,7 +843,7 @@ def run_rank(args):
             workload = (f"{total_streams * T}-frame batch mono 48 kHz / 10 ms / 150-byte frames, encode only, streams sharded over "
                         f"{world} GPU(s) (BASELINE configs[2]); {n_distinct} distinct synthetic streams per rank" + (f" tiled to {S}" if n_distinct < S else ""))
             metric = "LC3 frames/sec (encode) @48kHz/10ms"
-        hip_streams = {"single": max(1, args.hip_streams), "quad": 4}.get(main_arr, 2)
+        hip_streams = max(1, args.hip_streams) if main_arr == "single" else arrangement_streams(main_arr)
         line = {
             "metric": metric, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -816,8 +862,8 @@ def run_rank(args):
                                      "events (INTEGRATION.md, recommended caller pattern): the decoder works on step k while the encoder runs step k + 1; "
                                      "`staggered`: the same with three byte buffers and the decoder call of step k queued behind the point where the "
                                      "encoder call of step k + 1 has only its packer left (lc3gpu_encoder_stage_event): parser beside packer; "
-                                     "`quad`: the batch as two halves of its streams, each half with its own encoder handle and decoder handle on its own two "
-                                     "caller streams (four in all), each half `pipelined` by itself -- the halves never join.  "
+                                     "`split:a+b..` (`quad` = 2+2, `tri` = 2+1, `duo` = 1+1): the streams in equal groups, each group with its own encoder handle and "
+                                     "decoder handle on 2 caller streams (`pipelined` by itself) or 1 (encode then decode) -- the groups never join.  "
                                      "`value` is the arrangement named here; the other one is timed in the same run (`other_arrangement`)"),
                 "engine": args.engine,
             },

@@ -58,9 +58,12 @@ struct __attribute__((aligned(16))) lc3_enc_lds {
     unsigned long long prof_acc[32];  // diagnostic build: per-wave stage totals, flushed once per launch
 #endif
 };
-// the TNS stage's Levinson recursions of a workgroup's four streams on one wave (1) or each stream's on its own wave (0: A/B builds)
+// The TNS stage's Levinson recursions: each stream's on its own wave (0), or those of a workgroup's four streams side by side on one wave
+// (1).  Measured in round 5 (profiles/r05_tns_gather_ab.txt): the recursion prices at 0.032 of the back half's 0.365 ms and the gathered form
+// executes a quarter of it per stream -- and is SLOWER, 0.370 against 0.362 ms: its two workgroup barriers per frame tie the four waves
+// together, and a frame then takes as long as the slowest of four streams (half of all frames run the quantiser's second pass).
 #ifndef LC3_TNS_GATHER
-#define LC3_TNS_GATHER 1
+#define LC3_TNS_GATHER 0
 #endif
 #define LC3_ENC_DBG_EB 1472      // [64] band energies
 #define LC3_ENC_DBG_ATTACK 1536  // [5] attack detector state: energy_last, max_energy_last, attack_pos_last, downsampled t-1, t-2
@@ -553,11 +556,10 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
     }
     LC3_STAMP(L, lane, 28);
     // Levinson-Durbin :204-232 and the LPC -> reflection conversion :234-265: one lane per filter, the order-8
-    // recursions fully unrolled on register arrays.  ~600 instructions on two lanes per stream: the filters of the WORKGROUP's four
-    // streams run side by side on eight lanes of ONE wave (LC3_SERIAL_BEGIN: inside, `L` is the lane's stream and `sub` its filter;
-    // the waves take turns frame by frame), so a stream pays a quarter of them.  What the block needs travels through the stream's
-    // LDS: quotients and energies (above), bandwidth and near-Nyquist flag (the frame's flag words), and its verdict comes back in
-    // L.ism[4 + filter].
+    // recursions fully unrolled on register arrays (~300 instructions on two lanes).  Written so that the block can also run GATHERED
+    // over the workgroup -- the filters of its four streams side by side on eight lanes of one wave (LC3_TNS_GATHER, above: measured,
+    // slower) --: what it needs travels through the stream's LDS (quotients and energies, bandwidth and near-Nyquist flag in the
+    // frame's flag words), its verdict comes back in L.ism[4 + filter], and inside `L` is the lane's stream, `sub` its filter.
     (void)near_nyquist;
     LC3_ENC_REPEAT(32)
 #if LC3_TNS_GATHER
@@ -1914,11 +1916,18 @@ __device__ __forceinline__ void lc3_mid_issue(const CC &c, int lane, const float
     m.flag = lane < 4 ? ((LC3_HBM_CONST(int32_t))mid)[MP_FLAGS + lane] : 0;
 }
 
+// The back half of a frame in two parts, so that a kernel can put the NEXT frame's mid-column loads between them: lc3_encode_back_compute
+// ends with the frame's last stage call, lc3_encode_back_store is the longest stretch of a frame without one (a call waits for every load
+// in flight).  lc3_encode_back_wave = both.
+struct lc3_back_res {
+    lc3_tns_res tns;
+    lc3_quant_res spec;
+    int n_res, noise_factor;
+};
 // m: this frame's mid-plane words, fetched by lc3_mid_issue
 // phase: the frame's number in the launch (which wave of the workgroup runs a block gathered over its streams: they take turns)
-LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const float *mid,
-                                                     const lc3_mid_fetch &m, int32_t *plane, int plane_stride, int nbytes,
-                                                     int store, float *dbg, int phase = 0) {
+LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_back_res lc3_encode_back_compute(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const float *mid,
+                                                                const lc3_mid_fetch &m, int nbytes, float *dbg, int phase = 0) {
     LC3_CFG_BIND;
     const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
@@ -1971,7 +1980,20 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PA
     int rn = LC3_KO(LC3_ENC_KO, 1024) ? 0 : lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
     LC3_ENC_REPEAT_MORE(64) rn = lc3_enc_residual_noise(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, bw_ind);
     LC3_STAMP(L, lane, 7);
-    const int n_res = rn & 0xffff, noise_factor = rn >> 16;
+    lc3_back_res out;
+    out.tns = tns;
+    out.spec = spec;
+    out.n_res = rn & 0xffff;
+    out.noise_factor = rn >> 16;
+    (void)mid;
+    return out;
+}
+LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_store(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const lc3_back_res &r,
+                                                      int32_t *plane, int plane_stride, int store, float *dbg) {
+    LC3_CFG_BIND;
+    const lc3_tns_res &tns = r.tns;
+    const lc3_quant_res &spec = r.spec;
+    const int n_res = r.n_res, noise_factor = r.noise_factor;
     if (dbg && lane == 0) {
         float *d = dbg + 1440;
         const int st = plane_stride;
@@ -2001,11 +2023,21 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PA
         }
         if (lane < 16) plane[(EP_RCI + lane) * st] = L.ism[16 + lane];
         if (lane < 13) plane[(EP_RES + lane) * st] = (int32_t)LC3_RESW(L)[lane];  // residual bits as a bit mask
-        for (int k = lane; k < c.ne / 2; k += LC3_WAVE)
-            plane[(EP_XQ + k) * st] = (int32_t)(((uint32_t)(uint16_t)LC3_XQ(L)[2 * k]) | ((uint32_t)(uint16_t)LC3_XQ(L)[2 * k + 1] << 16));
+        // the quantised pairs x_q[2k] | x_q[2k+1] << 16 are the words of the int16 array as they lie in LDS: 16-byte units (frame-major
+        // planes; up to three words beyond ne / 2 go along, inside the column's 200 and zero)
+        if (LC3_PLANE_STRIDE == 1) lc3_wave_copy_out16(plane + EP_XQ, LC3_XQ(L), (c.ne / 2 + 3) / 4, lane);
+        else
+            for (int k = lane; k < c.ne / 2; k += LC3_WAVE)
+                plane[(EP_XQ + k) * st] = (int32_t)(((uint32_t)(uint16_t)LC3_XQ(L)[2 * k]) | ((uint32_t)(uint16_t)LC3_XQ(L)[2 * k + 1] << 16));
         if (L.spec_flags & LC3_LAUNCH_PREP_SYMBOLS) lc3_enc_symbols(LC3_CFG_PASS, LC3_LDS_PASS lane, spec, plane, st);
         else if (lane == 0) plane[EP_NSYM * st] = -1;
     }
     LC3_SYNC();
     LC3_STAMP(L, lane, 8);
+}
+LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const float *mid,
+                                                     const lc3_mid_fetch &m, int32_t *plane, int plane_stride, int nbytes,
+                                                     int store, float *dbg, int phase = 0) {
+    const lc3_back_res r = lc3_encode_back_compute(LC3_CFG_PASS, L, lane, mid, m, nbytes, dbg, phase);
+    lc3_encode_back_store(LC3_CFG_PASS, L, lane, r, plane, plane_stride, store, dbg);
 }

@@ -713,6 +713,8 @@ __device__ __forceinline__ void lc3_enc_back_body(lc3_cfg_slot<CV> cfg, unsigned
     if (n_frames > 0) lc3_mid_issue(c0, lane, mid + fbase * (size_t)MP_WORDS, cur);
     for (int t = 0; t < n_frames; t++) {
         const size_t f = fbase + (size_t)t;
+        // (requested here or behind the frame's last stage call -- lc3_encode_back_compute / _store exist for that --: the same 0.362 ms,
+        // profiles/r05_experiments.txt; a stage call waits for every load in flight either way)
         if (t + 1 < n_frames) lc3_mid_issue(c0, lane, mid + (f + 1) * (size_t)MP_WORDS, nxt);  // lands while frame t is worked on
         lc3_encode_back_wave(cfg, L, lane, mid + f * (size_t)MP_WORDS, cur, LC3_PLANE_COL(planes, f, EP_WORDS), LC3_PLANE_STRIDE,
                              nbytes, valid, valid ? dbg : nullptr, t);
@@ -1565,6 +1567,31 @@ int cfg_upload(lc3_cfg &c, const lc3_host_plan &pl, char *base, size_t bytes_tw,
     return LC3GPU_OK;
 }
 
+// The run-time view's DCT-IV takes a compile-time FFT plan by frame length (lc3_dct4_select): the plan the host computes for a
+// configuration -- whose twiddles and gather order are what gets uploaded -- has to BE that plan, or the transform would read tables
+// laid out for other radices.  Checked when a configuration is first registered; a mismatch refuses the configuration instead of
+// producing wrong output (advisor, round 4).
+template <class P>
+static bool fft_plan_equals(const lc3_cfg &c) {
+    bool ok = c.nfft == P::nfft && c.n_stages == P::n_stages;
+    for (int i = 0; i < 6; i++) ok = ok && c.radix[i] == P::radix[i] && c.m[i] == P::m[i] && c.fstride[i] == P::fstride[i] && c.inv_m[i] == P::inv_m[i];
+    return ok;
+}
+static bool fft_plan_consistent(const lc3_cfg &c) {
+    switch (c.nf) {
+    case 480: return fft_plan_equals<lc3_fft_plan_480>(c);
+    case 360: return fft_plan_equals<lc3_fft_plan_360>(c);
+    case 320: return fft_plan_equals<lc3_fft_plan_320>(c);
+    case 240: return fft_plan_equals<lc3_fft_plan_240>(c);
+    case 180: return fft_plan_equals<lc3_fft_plan_180>(c);
+    case 160: return fft_plan_equals<lc3_fft_plan_160>(c);
+    case 120: return fft_plan_equals<lc3_fft_plan_120>(c);
+    case 80: return fft_plan_equals<lc3_fft_plan_80>(c);
+    case 60: return fft_plan_equals<lc3_fft_plan_60>(c);
+    default: return true;  // (no plan by length: the run-time view reads the configuration's own)
+    }
+}
+
 int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
     static const int fs_tab[6] = {8000, 16000, 24000, 32000, 44100, 48000};
     int k = -1;
@@ -1584,6 +1611,7 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
         lc3_cfg c;
         lc3_host_plan pl;
         if (lc3_make_config(c, frame_us, fs_hz) || lc3_make_plan(c, pl)) return LC3GPU_EINVAL;
+        if (!fft_plan_consistent(c)) return LC3GPU_EUNSUPPORTED;
         const size_t bytes_tw = sizeof(lc3_cpx) * (size_t)c.nfft;
         const size_t bytes_perm = (sizeof(uint16_t) * (size_t)c.nfft + 15) & ~(size_t)15;
         const size_t bytes_poly = sizeof(float) * (size_t)c.p_up * (size_t)c.resamp_stride;
@@ -1757,6 +1785,7 @@ struct HandleCommon {
     std::vector<int> caller_of_internal;   // internal index -> caller index
     lc3_stream_io *d_tab = nullptr;        // per internal stream
     unsigned *d_pc_timeouts = nullptr;     // one word: producer / consumer pair halves that gave up on their partner (sticky; *_pair_timeouts)
+    bool pc_optin_done = false;            // the pair kernels' dynamic-LDS opt-in has been made for this handle's device (no lock per call)
     hipStream_t last_stream = nullptr;
     hipEvent_t done = nullptr;
     bool has_work = false;
@@ -2472,8 +2501,11 @@ static int encode_kernels(lc3gpu_encoder *e, const HostCfg &h, int first, int n,
         HIP_TRY(hipGetLastError());
     }
     if (lc3_prep_symbols_mode(frames_of_call) == 0 && lc3_pack_pc_enabled()) {
-        int rc = lc3_pack_pc_optin();
-        if (rc) return rc;
+        if (!e->pc_optin_done) {  // (once per handle: the opt-in itself takes a process-wide lock)
+            int rc = lc3_pack_pc_optin();
+            if (rc) return rc;
+            e->pc_optin_done = true;
+        }
         const unsigned pfpb = lc3_pack_pc_fpb(nbytes);
         hipLaunchKernelGGL(lc3_pack_pc_kernel, dim3((unsigned)((frames + pfpb - 1) / pfpb)), dim3(2 * pfpb), lc3_pack_pc_lds(pfpb, nbytes), stream,
                            h.c.ne, (const int32_t *)planes, d_out, nbytes, (int)frames, n_frames, io, e->d_pc_timeouts);
@@ -2802,8 +2834,11 @@ static int decode_kernels(lc3gpu_decoder *d, const HostCfg &h, int first, int n,
     const size_t lds = LC3_PARSE_LDS_FIXED + (size_t)fpb * (size_t)(64 + nbytes);
     d->timer.mark(stream, -1, chain);
     if (mode == LC3_RECON_LANE && lc3_parse_pc_enabled()) {
-        int rc = lc3_parse_pc_optin();
-        if (rc) return rc;
+        if (!d->pc_optin_done) {  // (once per handle: the opt-in itself takes a process-wide lock)
+            int rc = lc3_parse_pc_optin();
+            if (rc) return rc;
+            d->pc_optin_done = true;
+        }
         const unsigned pfpb = lc3_parse_pc_fpb(nbytes);
         LC3_LAUNCH_CFG(lc3_parse_pc_kernel, h, dim3((unsigned)((frames + pfpb - 1) / pfpb)), dim3(2 * pfpb), lc3_parse_pc_lds(pfpb, nbytes), stream,
                        d_in, d_bad, planes, nbytes, (int)frames, n_frames, io, d->d_pc_timeouts);
