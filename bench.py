@@ -354,8 +354,10 @@ class GpuEngine:
             widths = [int(x) for x in name[6:].split("+")]
             G = len(widths)
             pool = [self.s_enc, self.s_dec] + self.extra_streams
+            prio = os.environ.get("LC3_BENCH_PRIO", "")  # (measurement aid, as for `pipelined`: enc | dec streams at the higher HIP priority)
             while len(pool) < sum(widths):
-                st = torch.cuda.Stream()
+                role = "enc" if (len(pool) - 2) % 2 == 0 else "dec"  # (quad: the second group's encoder stream, then its decoder stream)
+                st = torch.cuda.Stream(priority=-1 if prio == role else 0)
                 self.extra_streams.append(st)
                 pool.append(st)
             bounds = [((self.S // 4) * g // G) * 4 for g in range(G)] + [self.S]  # groups of whole workgroups (four streams each)
@@ -720,6 +722,9 @@ def run_rank(args):
         k = len(idx)
         two = np.ascontiguousarray(np.concatenate([pcm_host[idx], pcm_host[idx]], axis=1))  # every step codes the same T frames
         ref_b = O.encode_batch(two, NBYTES, FS, US, threads=thr)
+        if os.environ.get("LC3_BENCH_TEST_CORRUPT_GATE") == "1":  # test hook: a gate that MUST fail (the run then has to exit non-zero)
+            ref_b = ref_b.copy()
+            ref_b[0, -1, 0] ^= 1
         got_b, got_p = eng.results(k)
         second = slice(T, 2 * T) if eng.carries_state else slice(0, T)
         bad_b = int((got_b != ref_b[:, second]).any(axis=2).sum())

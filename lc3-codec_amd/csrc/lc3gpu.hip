@@ -104,8 +104,10 @@
 // Wave priority of the lane-per-frame kernels (s_setprio 0..3).  Their waves walk one dependent chain per lane and leave most issue
 // slots empty; beside another handle's wave-per-stream kernels (the two-stream arrangement) a raised priority lets them keep their own
 // pace -- and leave the compute unit sooner -- while the other kernel's waves take the slots in between.
+// Round 4 (one or two caller streams): no difference between 0, 1 and 3.  Round 5, four caller streams (`quad`, bench.py's default): 1 is worth
+// +1.5 % sustained (55.2 -> 56.0 M frames/s; profiles/r05_arrangements.txt), 3 the same.
 #ifndef LC3_LANE_PRIO
-#define LC3_LANE_PRIO 0
+#define LC3_LANE_PRIO 1
 #endif
 #define LC3_LANE_KERNEL_BEGIN() do { if (LC3_LANE_PRIO) __builtin_amdgcn_s_setprio(LC3_LANE_PRIO); } while (0)
 #ifndef LC3_SPEC_IN_LDS

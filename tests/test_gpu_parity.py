@@ -1214,6 +1214,20 @@ def test_rccl_world_size_one():
     assert abs(line["value"] - 1024 * 4 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
 
 
+def test_default_arrangement_is_quad_and_a_mismatch_fails_the_run():
+    """bench.py without flags times the four-stream arrangement, says so in the line, and gates parity on streams of both groups; a
+    run whose gate finds a difference exits non-zero after printing the line (round-4 review: it used to exit 0)."""
+    p, line = _bench_line(["--steps", "3", "--warmup", "1", "--streams", "4096", "--sustain-seconds", "0", "--no-overlap-probe"], {})
+    assert p.returncode == 0 and line is not None, p.stderr[-2000:]
+    assert line["config"]["arrangement"] == "split:2+2" and line["config"]["hip_streams"] == 4
+    assert line["parity"]["arrangement"] == "split:2+2" and line["parity"]["bitstream_exact"] and line["parity"]["pcm_max_abs_diff"] == 0
+    # LC3_BENCH_TEST_CORRUPT_GATE=1: the gate's reference bytes are damaged on purpose -> the line reports mismatches, the exit code is 3
+    p, line = _bench_line(["--steps", "2", "--warmup", "1", "--streams", "1024", "--sustain-seconds", "0", "--no-overlap-probe"],
+                          {"LC3_BENCH_TEST_CORRUPT_GATE": "1"})
+    assert line is not None and line["parity_mismatches_all_ranks"] > 0 and not line["parity"]["bitstream_exact"]
+    assert p.returncode == 3, p.returncode
+
+
 def test_every_caller_arrangement_passes_its_parity_gate():
     """bench.py times two ways of queueing the same steps -- encode then decode on ONE caller stream, and the recommended pattern
     (INTEGRATION.md): encoder handle on one stream, decoder handle on another, two byte buffers, events -- and runs its parity gate on
@@ -1227,6 +1241,12 @@ def test_every_caller_arrangement_passes_its_parity_gate():
     # ... and the third one: like `pipelined`, the decoder call queued behind the encoder's LC3GPU_ENC_STAGE_BACK event of the NEXT step
     g = [a for a in line["other_arrangements"] if a["arrangement"] == "staggered"]
     assert len(g) == 1 and g[0]["parity"]["bitstream_exact"] and g[0]["parity"]["pcm_max_abs_diff"] == 0 and g[0]["hip_streams"] == 2
+    # ... and the split arrangements (round 5): the streams in groups, every group with a handle pair of its own -- on two streams
+    # (`quad` = split:2+2, bench.py's default) or one (`duo` = split:1+1); their gates look at streams of EVERY group
+    for name, n_streams in (("split:2+2", 4), ("split:1+1", 2)):
+        g = [a for a in line["other_arrangements"] if a["arrangement"] == name]
+        assert len(g) == 1 and g[0]["parity"]["bitstream_exact"] and g[0]["parity"]["pcm_max_abs_diff"] == 0, (name, g)
+        assert g[0]["hip_streams"] == n_streams and g[0]["parity"]["frames_checked"] >= 256 * 4 - 8
     assert line["parity_mismatches_all_ranks"] == 0
     s = line["sustained"]
     assert s["steps"] > 0 and s["shader_clock_MHz"]["probes"] > 0 and 500.0 < s["shader_clock_MHz"]["median"] < 3000.0, s
