@@ -483,15 +483,17 @@ class GpuEngine:
             return np.concatenate([np.arange(g["lo"], min(g["hi"], g["lo"] + per)) for g in gs])
         return np.arange(k)
 
+    def last_bytes_all(self):
+        """the byte buffer of the most recent step (device tensor, every stream)"""
+        if self.arrangement == "pipelined" or self.arrangement.startswith("split:"):
+            return self.bufs[(self.k - 1) & 1]
+        if self.arrangement == "staggered":
+            return self.bufs[(self.k - 1) % 3]
+        return self.d_bytes
+
     def last_bytes(self, k):
         """the sampled streams' frame bytes of the most recent step"""
-        if self.arrangement == "pipelined" or self.arrangement.startswith("split:"):
-            buf = self.bufs[(self.k - 1) & 1]
-        elif self.arrangement == "staggered":
-            buf = self.bufs[(self.k - 1) % 3]
-        else:
-            buf = self.d_bytes
-        return buf[self.torch.from_numpy(self.sample(k)).cuda()].cpu().numpy()
+        return self.last_bytes_all()[self.torch.from_numpy(self.sample(k)).cuda()].cpu().numpy()
 
     def results(self, k):
         idx = self.torch.from_numpy(self.sample(k)).cuda()

@@ -1228,6 +1228,44 @@ def test_default_arrangement_is_quad_and_a_mismatch_fails_the_run():
     assert p.returncode == 3, p.returncode
 
 
+def test_every_arrangement_produces_the_single_stream_output():
+    """bench.py's engine, full size (65 536 frames per step): three steps from fresh state in every caller arrangement -- one stream, two
+    streams, three buffers + stage event, two and three groups of streams with handle pairs of their own -- leave the SAME bitstream and
+    the SAME PCM for all 16 384 streams as the one-stream arrangement does (state carried across the steps, every buffer and event of the
+    arrangement in play), and the first 64 streams of that agree with the oracle."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    torch_mod()
+    S, T = 16384, 4
+    args = bench.parse_args(["--no-cpu-baseline"])
+    pcm = synth.make_pcm(S, T, bench.NF, bench.FS)
+    eng = bench.GpuEngine(args, pcm, S, T, "roundtrip", 0)
+    ref = None
+    for arr in ("single", "pipelined", "staggered", "split:2+2", "split:1+1", "split:2+1+1"):
+        eng.set_arrangement(arr)
+        eng.reset()
+        for _ in range(3):
+            eng.step()
+        eng.sync()
+        got = (eng.last_bytes_all().cpu().numpy(), eng.d_out.cpu().numpy())
+        if ref is None:
+            ref = got
+            three = np.ascontiguousarray(np.concatenate([pcm[:64]] * 3, axis=1))
+            want_b = O.encode_batch(three, bench.NBYTES, threads=8)
+            assert np.array_equal(got[0][:64], want_b[:, 2 * T:])
+            assert np.array_equal(got[1][:64], O.decode_batch(want_b, bench.NF, threads=8)[:, 2 * T:])
+        else:
+            assert np.array_equal(got[0], ref[0]), arr + ": bitstream differs from the one-stream arrangement"
+            assert np.array_equal(got[1], ref[1]), arr + ": PCM differs from the one-stream arrangement"
+        for h in sum(eng._handles(), []):
+            assert h.pair_timeouts() == 0
+
+
 def test_every_caller_arrangement_passes_its_parity_gate():
     """bench.py times two ways of queueing the same steps -- encode then decode on ONE caller stream, and the recommended pattern
     (INTEGRATION.md): encoder handle on one stream, decoder handle on another, two byte buffers, events -- and runs its parity gate on
