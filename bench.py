@@ -333,7 +333,6 @@ class GpuEngine:
             # the `split:..` arrangements: the batch as GROUPS of its streams, each group with an encoder handle and a decoder handle of its
             # own on one or two HIP streams of its own.  Handles, streams and events are created when an arrangement is first selected
             self.splits = {}
-            self.extra_streams = []  # HIP streams beyond the default one and s_dec, shared by every split arrangement
 
     device = "cuda"
     carries_state = True
@@ -348,18 +347,32 @@ class GpuEngine:
         if name.startswith("split:") and name not in self.splits:
             # The chip has a handful of hardware queues (4 by default, GPU_MAX_HW_QUEUES) and the runtime deals HIP streams onto them; two
             # streams on one queue run one behind the other, and a stream waiting for an event holds up whatever shares its queue.  So
-            # the arrangements draw their streams from ONE list -- the default stream, the pipelined arrangement's decoder stream, then
-            # streams created as needed -- and `quad` runs on four streams of which only two are new.
+            # the arrangements draw their streams from ONE list per role (created as needed and shared by every split arrangement) ...
             torch, pkg = self.torch, self.pkg
             widths = [int(x) for x in name[6:].split("+")]
             G = len(widths)
-            pool = [self.s_enc, self.s_dec] + self.extra_streams
-            prio = os.environ.get("LC3_BENCH_PRIO", "")  # (measurement aid, as for `pipelined`: enc | dec streams at the higher HIP priority)
-            while len(pool) < sum(widths):
-                role = "enc" if (len(pool) - 2) % 2 == 0 else "dec"  # (quad: the second group's encoder stream, then its decoder stream)
-                st = torch.cuda.Stream(priority=-1 if prio == role else 0)
-                self.extra_streams.append(st)
-                pool.append(st)
+            # ... and the ENCODER streams of the groups run at the higher HIP stream priority (round 5: with the encoder kernels
+            # preferred when queues compete, the front halves -- the longest kernels of the critical encoder chains -- keep their pace and the
+            # latency-bound kernels stretch instead: 55.8 against 54.5 M sustained on the round's final kernels; LC3_BENCH_PRIO=none|dec to
+            # compare).  Streams of another priority live on hardware queues of their own.
+            prio = os.environ.get("LC3_BENCH_PRIO", "enc")
+            if not hasattr(self, "split_streams"):
+                self.split_streams = {"enc": [self.s_enc] if prio != "enc" else [], "dec": [self.s_dec] if prio != "dec" else []}
+
+            def stream_of(role, i):
+                have = self.split_streams[role]
+                while len(have) <= i:
+                    have.append(torch.cuda.Stream(priority=-1 if prio == role else 0))
+                return have[i]
+
+            pool = []
+            n_enc = n_dec = 0
+            for w in widths:
+                pool.append(stream_of("enc", n_enc))
+                n_enc += 1
+                if w == 2:
+                    pool.append(stream_of("dec", n_dec))
+                    n_dec += 1
             bounds = [((self.S // 4) * g // G) * 4 for g in range(G)] + [self.S]  # groups of whole workgroups (four streams each)
             groups, nxt = [], 0
             for g, w in enumerate(widths):

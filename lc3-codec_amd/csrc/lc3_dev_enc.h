@@ -58,13 +58,6 @@ struct __attribute__((aligned(16))) lc3_enc_lds {
     unsigned long long prof_acc[32];  // diagnostic build: per-wave stage totals, flushed once per launch
 #endif
 };
-// The TNS stage's Levinson recursions: each stream's on its own wave (0), or those of a workgroup's four streams side by side on one wave
-// (1).  Measured in round 5 (profiles/r05_tns_gather_ab.txt): the recursion prices at 0.032 of the back half's 0.365 ms and the gathered form
-// executes a quarter of it per stream -- and is SLOWER, 0.370 against 0.362 ms: its two workgroup barriers per frame tie the four waves
-// together, and a frame then takes as long as the slowest of four streams (half of all frames run the quantiser's second pass).
-#ifndef LC3_TNS_GATHER
-#define LC3_TNS_GATHER 0
-#endif
 #define LC3_ENC_DBG_EB 1472      // [64] band energies
 #define LC3_ENC_DBG_ATTACK 1536  // [5] attack detector state: energy_last, max_energy_last, attack_pos_last, downsampled t-1, t-2
 #define LC3_ENC_DBG_FLOATS 1600
@@ -487,29 +480,37 @@ LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_sns_front(LC3_CFG_PARAM, L
 }
 
 // ------------------------------------------------------------------------------------------
-// E11: temporal noise shaping (encoder/temporal_noise_shaping.rs:40-349)
+// E11: temporal noise shaping (encoder/temporal_noise_shaping.rs:40-349), in three parts:
+//   lc3_enc_tns_acf    the 54 partial autocorrelations of a frame and their quotients (needs the shaped spectrum in LDS)      -> a slot
+//   lc3_enc_tns_lev    Levinson-Durbin and the LPC -> reflection conversion of up to LC3_TNS_CHUNK frames' filters side by side   slots -> slots
+//   lc3_enc_tns_apply  coefficient quantisation, bit budget and the MA lattice over the spectrum of one frame                     <- its slot
+// The analysis of a frame does not depend on the frames before it, and the recursions are ~350 instructions on TWO lanes (one per
+// filter) -- 12 % of the back half's instructions (profiles/r05_knockout_back.txt).  The back half therefore analyses the frames of a
+// launch in chunks (lc3_encode_back_stream): autocorrelations of every frame of the chunk first, ONE pass of the recursions for all of
+// them (eight lanes for four frames), then frame by frame everything that carries state.  The price is that a frame's spectrum is
+// picked up twice.  Gathering the recursions over the workgroup's four STREAMS instead was tried first and lost to its two workgroup
+// barriers per frame (profiles/r05_tns_gather_ab.txt); frames of one stream need none.
 // rc_i[16] -> L.ism[16..32), rc_q[16] -> L.sm[16..32)
 // ------------------------------------------------------------------------------------------
-// phase: which wave of the workgroup runs the gathered Levinson block (the frame's number: the waves take turns)
-LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int p_bw, int nbits,
-                                                  int near_nyquist, int phase) {
+#define LC3_TNS_CHUNK 4
+struct lc3_tns_slot {
+    float q[54];   // [2][9][3] partial autocorrelations, each divided by its sub-block's energy
+    float es[6];   // [2][3] sub-block energies
+    int p_bw, near_nyquist, on[2];
+    float rc[16];  // reflection coefficients as the recursions leave them (before quantisation)
+};
+static_assert(sizeof(lc3_tns_slot) * LC3_TNS_CHUNK <= sizeof(((lc3_enc_lds *)0)->fb), "the slots live in fb, which the back half does not use otherwise");
+#define LC3_TNS_SLOT(L, u) (((lc3_tns_slot *)(L).fb)[(u)])
+
+LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_tns_acf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int p_bw, int near_nyquist,
+                                              int slot) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
     const lc3_tns_params &tp = c.n_ms_10 ? LC3C_TNS10[p_bw] : LC3C_TNS75[p_bw];
-    // SURVEY A5: at 10 ms / bandwidth index 2 the reference filters lines 12..200 although its sub-blocks (and the decoder) run to
-    // 240; LC3_SPEC_TNS_SSWB_STOP restores 240
-    const int sswb_stop = (L.spec_flags & LC3_SPEC_TNS_SSWB_STOP) && c.n_ms_10 && p_bw == 2;
-    float *S = (float *)L.fa;
-    float *sAC = S;        // [2][9][3] partial autocorrelations
-    float *sES = S + 64;   // [2][3] sub-block energies
-    int *rc_i = L.ism + 16;
-    float *rc_q = L.sm + 16;
+    lc3_tns_slot &T = LC3_TNS_SLOT(L, slot);
+    float *sAC = T.q, *sES = T.es;
     float *x = L.spec;
     const int ne = c.ne;
-    lc3_tns_res res;
-    res.num_tns_filters = tp.num;
-    res.lpc_weighting = c.n_ms_10 ? (nbits < 480) : (nbits < 360);
-
     // compute_normalized_autocorrelation :80-115 -- one lane per (filter, lag, sub-block) partial sum, every sum in the
     // reference's order.  The sub-block energy e_s (:88-93) is the lag-0 sum of its sub-block -- the same products added in the
     // same order -- so the lag-0 lanes supply it.  A lane's sum has 50..70 terms: blocks of eight, the last one masked.
@@ -545,6 +546,10 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
         sAC[lane] = ac;
         if (k == 0) sES[f * 3 + s] = ac;
     }
+    if (lane == 0) {
+        T.p_bw = p_bw;
+        T.near_nyquist = near_nyquist;
+    }
     LC3_SYNC();
     // the 54 quotients ac_s(k) / e_s (:97-104) on the lanes that hold the partial sums: the Levinson lanes below only add
     // three of them per lag (0 + q0 + q1 + q2 in the reference's order)
@@ -555,21 +560,22 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
     LC3_SYNC();
     }
     LC3_STAMP(L, lane, 28);
-    // Levinson-Durbin :204-232 and the LPC -> reflection conversion :234-265: one lane per filter, the order-8
-    // recursions fully unrolled on register arrays (~300 instructions on two lanes).  Written so that the block can also run GATHERED
-    // over the workgroup -- the filters of its four streams side by side on eight lanes of one wave (LC3_TNS_GATHER, above: measured,
-    // slower) --: what it needs travels through the stream's LDS (quotients and energies, bandwidth and near-Nyquist flag in the
-    // frame's flag words), its verdict comes back in L.ism[4 + filter], and inside `L` is the lane's stream, `sub` its filter.
-    (void)near_nyquist;
+}
+
+// Levinson-Durbin :204-232 and the LPC -> reflection conversion :234-265 for the filters of `n` frames (slots 0 .. n-1): lane 2 u + f runs
+// filter f of slot u, the order-8 recursions fully unrolled on register arrays.  What a lane needs is in its slot; its verdict (the
+// prediction gain passes :219) and the coefficients go back there.
+LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_tns_lev(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int nbits, int n) {
+    LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
+    const int lpc_weighting = c.n_ms_10 ? (nbits < 480) : (nbits < 360);
     LC3_ENC_REPEAT(32)
-#if LC3_TNS_GATHER
-    LC3_SERIAL_BEGIN(lc3_enc_lds, L, lane, phase, 2)
-#else
-    LC3_LOCAL_BEGIN(lane, 2)
-#endif
-        const int f = sub;
-        float *sAC = (float *)L.fa, *sES = sAC + 64, *rc_q = L.sm + 16;
-        const int num_g = (c.n_ms_10 ? LC3C_TNS10[L.ism[MPF_BW]] : LC3C_TNS75[L.ism[MPF_BW]]).num;
+    if (lane < 2 * n) {
+        const int f = lane & 1;
+        lc3_tns_slot &T = LC3_TNS_SLOT(L, lane >> 1);
+        const float *sAC = T.q, *sES = T.es;
+        float *rc_q = T.rc;
+        const int num_g = (c.n_ms_10 ? LC3C_TNS10[T.p_bw] : LC3C_TNS75[T.p_bw]).num;
         int on = 0;  // the filter's prediction gain passes :219
         if (f < num_g) {
         float r[9];
@@ -582,28 +588,28 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
         }
         float a[9], al[9];
 #pragma unroll
-        for (int n = 0; n < 9; n++) a[n] = 0.0f;
+        for (int n_ = 0; n_ < 9; n_++) a[n_] = 0.0f;
         float e = r[0];
         a[0] = 1.0f;
 #pragma unroll
         for (int k = 1; k < 9; k++) {
 #pragma unroll
-            for (int n = 0; n < 9; n++) al[n] = a[n];
+            for (int n_ = 0; n_ < 9; n_++) al[n_] = a[n_];
             float rc = 0.0f;
 #pragma unroll
-            for (int n = 0; n < k; n++) rc -= al[n] * r[k - n];
+            for (int n_ = 0; n_ < k; n_++) rc -= al[n_] * r[k - n_];
             if (e != 0.0f) rc /= e;
             a[0] = 1.0f;
 #pragma unroll
-            for (int n = 1; n < k; n++) a[n] = al[n] + rc * al[k - n];
+            for (int n_ = 1; n_ < k; n_++) a[n_] = al[n_] + rc * al[k - n_];
             a[k] = rc;
             e *= 1.0f - rc * rc;
         }
         const float pred_gain = e == 0.0f ? r[0] : r[0] / e;
-        if (pred_gain > 1.5f && !L.ism[MPF_NEAR_NYQUIST]) {
+        if (pred_gain > 1.5f && !T.near_nyquist) {
             on = 1;
             float gamma = 1.0f;
-            if (res.lpc_weighting > 0 && pred_gain < 2.0f)
+            if (lpc_weighting > 0 && pred_gain < 2.0f)
                 gamma -= (1.0f - 0.85f) * (2.0f - pred_gain) / (2.0f - 1.5f);
 #pragma unroll
             for (int k = 0; k < 9; k++) a[k] *= lc3_powi(gamma, k);
@@ -613,22 +619,40 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns(LC3_CFG_PARAM, 
                 rc_q[f * 8 + k - 1] = rck;
                 const float ee = 1.0f - rck * rck;
 #pragma unroll
-                for (int n = 1; n < k; n++) al[n] = (a[n] - rck * a[k - n]) / ee;
+                for (int n_ = 1; n_ < k; n_++) al[n_] = (a[n_] - rck * a[k - n_]) / ee;
 #pragma unroll
-                for (int n = 1; n < k; n++) a[n] = al[n];
+                for (int n_ = 1; n_ < k; n_++) a[n_] = al[n_];
             }
         } else {
 #pragma unroll
             for (int k = 0; k < 8; k++) rc_q[f * 8 + k] = 0.0f;
         }
+        } else {  // a filter this bandwidth does not have
+#pragma unroll
+            for (int k = 0; k < 8; k++) rc_q[f * 8 + k] = 0.0f;
         }
-        L.ism[4 + f] = on;
-#if LC3_TNS_GATHER
-    LC3_SERIAL_END
-#else
-    LC3_LOCAL_END
-#endif
-    const int tns_on = lane < 2 ? L.ism[4 + lane] : 0;  // lanes 0 / 1: the stream's own two filters
+        T.on[f] = on;
+    }
+    LC3_SYNC();
+}
+
+LC3_CFG_TEMPLATE __device__ __noinline__ lc3_tns_res lc3_enc_tns_apply(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_enc_lds) int lane, int p_bw, int nbits,
+                                                        int slot) {
+    LC3_CFG_BIND;
+    LC3_LDS_BIND(lc3_enc_lds, lc3_enc_wg);
+    const lc3_tns_params &tp = c.n_ms_10 ? LC3C_TNS10[p_bw] : LC3C_TNS75[p_bw];
+    // SURVEY A5: at 10 ms / bandwidth index 2 the reference filters lines 12..200 although its sub-blocks (and the decoder) run to
+    // 240; LC3_SPEC_TNS_SSWB_STOP restores 240
+    const int sswb_stop = (L.spec_flags & LC3_SPEC_TNS_SSWB_STOP) && c.n_ms_10 && p_bw == 2;
+    const lc3_tns_slot &T = LC3_TNS_SLOT(L, slot);
+    int *rc_i = L.ism + 16;
+    float *rc_q = L.sm + 16;
+    float *x = L.spec;
+    lc3_tns_res res;
+    res.num_tns_filters = tp.num;
+    res.lpc_weighting = c.n_ms_10 ? (nbits < 480) : (nbits < 360);
+    if (lane < 16) rc_q[lane] = T.rc[lane];
+    const int tns_on = lane < 2 ? T.on[lane] : 0;  // lanes 0 / 1: the frame's two filters
     LC3_SYNC();
     LC3_STAMP(L, lane, 29);
     // apply_quantization :267-292 -- one lane per coefficient; the orders (:275-291: the last index that is not 8, per filter) and
@@ -1451,6 +1475,9 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
     // compute_spectral_energy :390-395 -- one lane per 4-line group (two groups per lane, kept in registers together
     // with the two products of the energy that the gain search needs)
     float e14[2], e28[2], amax = 0.0f;
+    // (`x * 28.0 / 20.0`: the division by the constant through lc3_div_by -- the hardware's division sequence without the scaling and
+    // fix-up steps that only act on operands these values never are; four divisions per lane and frame)
+    const lc3_divisor by20 = lc3_divisor_make(20.0f);
     LC3_ENC_REPEAT(1)
 #pragma unroll
     for (int q = 0; q < 2; q++) {
@@ -1462,8 +1489,8 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
         // other one) returns what Rust's NaN-ignoring max returns, in one instruction instead of two compares and two selects each
         const float m = __builtin_fmaxf(__builtin_fmaxf(lc3_absf(x.x), lc3_absf(x.y)), __builtin_fmaxf(lc3_absf(x.z), lc3_absf(x.w)));
         amax = __builtin_fmaxf(amax, m);  // (a lane past the last group repeats group 0)
-        e14[q] = ei * 28.0f / 20.0f;
-        e28[q] = 2.0f * ei * 28.0f / 20.0f;
+        e14[q] = lc3_div_by(ei * 28.0f, by20);
+        e28[q] = lc3_div_by(2.0f * ei * 28.0f, by20);
     }
     // global_gain_limitation's max |x| :214-217 (the maximum is order-independent; non-negative floats order like
     // their bit patterns, so the wave maximum is an integer reduction)
@@ -1523,9 +1550,33 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
             // `fac >>= 1; gg_ind -= fac; if tmp > thr && hi >= 0 { gg_ind += fac }`
             if (over && h >= 0) gg_ind += fac;
         }
-        // global_gain_limitation :212-228 (every input is wave-uniform: the same scalar code on every lane)
+        // global_gain_limitation :212-228 (every input is wave-uniform: the same scalar code on every lane).
+        // gg_min = ceil(28 log10(x_f_max / 32767.625)) - gg_off is only ever COMPARED with the gain index -- here, and once more after the
+        // gain adjustment has moved the index down by at most one (:381-383) --, and it costs a division, a log10 and a ceiling on the
+        // vector unit (~75 instructions per frame, on a value that is the same on every lane).  An integer bound from the exponent of
+        // x_f_max decides both comparisons for every frame that is not within a factor of ~2.5 of clipping: for 2^(n-1) <= x < 2^n,
+        //   28 log10(x / 32767.625) < 28 n log10(2) - 28 log10(32767.625) = 8.42884 n - 126.4324,
+        // the routine's value is within 1e-4 of that real number and the ceiling of anything below a - 126.42 is at most ceil(a) - 126:
+        // B = ceil(8.42884 n) - 125 >= the reference's ceiling, with a whole unit to spare.  When gg_ind + gg_off - 1 >= B both
+        // comparisons are false whatever gg_min is; otherwise (and for zero, subnormal or non-finite x_f_max) the reference's expression
+        // is evaluated.  The CPU emulator evaluates it beside EVERY bound and stops if the bound is below it.
         gg_min = 0;
-        if (x_f_max > 0.0f) gg_min = lc3_f2i16(lc3_ceilf(28.0f * lc3_log10f(x_f_max / (32768.0f - 0.375f)))) - gg_off;
+        int gg_min_needed = 1;
+        {
+            const uint32_t xb = lc3_bits(x_f_max);
+            if (xb >= 0x00800000u && xb < 0x7f800000u) {
+                const int n = (int)(xb >> 23) - 126;  // x_f_max < 2^n
+                const int a = n >= 0 ? (8632 * n + 1023) >> 10 : -((8631 * -n) >> 10);  // >= ceil(8.42884 n): 8631 / 1024 < 8.42884 < 8632 / 1024
+                const int bound = a - 125;
+                LC3_GUARD_ASSERT(bound >= lc3_f2i16(lc3_ceilf(28.0f * lc3_log10f(x_f_max / (32768.0f - 0.375f)))));
+                gg_min_needed = !(gg_ind + gg_off - 1 >= bound);
+                gg_min = -100000;  // (stands for "below every index it is compared with")
+            }
+        }
+        if (LC3_UNIFORM_I32(gg_min_needed)) {
+            gg_min = 0;
+            if (x_f_max > 0.0f) gg_min = lc3_f2i16(lc3_ceilf(28.0f * lc3_log10f(x_f_max / (32768.0f - 0.375f)))) - gg_off;
+        }
         if (gg_ind < gg_min || x_f_max == 0.0f) {
             reset_offset = 1;
             gg_ind = gg_min;
@@ -1916,20 +1967,18 @@ __device__ __forceinline__ void lc3_mid_issue(const CC &c, int lane, const float
     m.flag = lane < 4 ? ((LC3_HBM_CONST(int32_t))mid)[MP_FLAGS + lane] : 0;
 }
 
-// The back half of a frame in two parts, so that a kernel can put the NEXT frame's mid-column loads between them: lc3_encode_back_compute
-// ends with the frame's last stage call, lc3_encode_back_store is the longest stretch of a frame without one (a call waits for every load
-// in flight).  lc3_encode_back_wave = both.
+// The back half of a frame in three parts (lc3_encode_back_stream below strings them together):
+//   lc3_encode_back_pickup   the frame's mid-column words (fetched by lc3_mid_issue) -> LDS: flags, band gains, the spectrum shaped by its gains
+//   lc3_encode_back_analyse  TNS filter (from the frame's slot), quantiser, residual bits, noise level -- everything that carries state
+//   lc3_encode_back_store    the packer column: the longest stretch of a frame without a stage call
 struct lc3_back_res {
     lc3_tns_res tns;
     lc3_quant_res spec;
     int n_res, noise_factor;
 };
 // m: this frame's mid-plane words, fetched by lc3_mid_issue
-// phase: the frame's number in the launch (which wave of the workgroup runs a block gathered over its streams: they take turns)
-LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_back_res lc3_encode_back_compute(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const float *mid,
-                                                                const lc3_mid_fetch &m, int nbytes, float *dbg, int phase = 0) {
+LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_pickup(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const lc3_mid_fetch &m) {
     LC3_CFG_BIND;
-    const int nbits = nbytes * 8;
     LC3_STAMP(L, lane, 0);
     // pick up the frame: flags and band gains -> LDS, then the spectrum -> LDS (16-byte units), each line scaled by its band's
     // gain on the way in (E9 back half: spectral shaping :264-268 with the gains the vector quantiser stage produced)
@@ -1962,15 +2011,21 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_back_res lc3_encode_back_compute
             }
         }
     }
-    const int bw_ind = L.ism[MPF_BW], nbits_bw = L.ism[MPF_NBITS_BW], near_nyquist = L.ism[MPF_NEAR_NYQUIST];
-    const int nbits_ltpf = L.ism[MPF_NBITS_LTPF];
     LC3_SYNC();
+}
+// slot: where lc3_enc_tns_lev left this frame's TNS analysis
+LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_back_res lc3_encode_back_analyse(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, int nbytes, int slot,
+                                                                float *dbg) {
+    LC3_CFG_BIND;
+    const int nbits = nbytes * 8;
+    const int bw_ind = L.ism[MPF_BW], nbits_bw = L.ism[MPF_NBITS_BW];
+    const int nbits_ltpf = L.ism[MPF_NBITS_LTPF];
     LC3_STAMP(L, lane, 18);
     LC3_STAMP(L, lane, 19);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[480 + i] = L.spec[i];
     lc3_tns_res tns = {};
     if (LC3_KO(LC3_ENC_KO, 256)) tns.nbits_tns = 2, tns.num_tns_filters = 2;
-    else tns = lc3_enc_tns(LC3_CFG_PASS, LC3_LDS_PASS lane, bw_ind, nbits, near_nyquist, phase);
+    else tns = lc3_enc_tns_apply(LC3_CFG_PASS, LC3_LDS_PASS lane, bw_ind, nbits, slot);
     LC3_STAMP(L, lane, 4);
     if (dbg) for (int i = lane; i < c.nf; i += LC3_WAVE) dbg[960 + i] = L.spec[i];
     lc3_quant_res spec = {};
@@ -1985,7 +2040,6 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_back_res lc3_encode_back_compute
     out.spec = spec;
     out.n_res = rn & 0xffff;
     out.noise_factor = rn >> 16;
-    (void)mid;
     return out;
 }
 LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_store(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const lc3_back_res &r,
@@ -2035,9 +2089,41 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_store(LC3_CFG_P
     LC3_SYNC();
     LC3_STAMP(L, lane, 8);
 }
-LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_wave(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const float *mid,
-                                                     const lc3_mid_fetch &m, int32_t *plane, int plane_stride, int nbytes,
-                                                     int store, float *dbg, int phase = 0) {
-    const lc3_back_res r = lc3_encode_back_compute(LC3_CFG_PASS, L, lane, mid, m, nbytes, dbg, phase);
-    lc3_encode_back_store(LC3_CFG_PASS, L, lane, r, plane, plane_stride, store, dbg);
+// The frames of one stream in one launch (the body of lc3_enc_back_kernel's frame loop; the CPU emulator of the tests runs the same).
+// Frames are analysed in chunks of up to LC3_TNS_CHUNK: first the TNS autocorrelations of every frame of the chunk (pick-up,
+// lc3_enc_tns_acf), then ONE pass of the Levinson recursions for all of them (lc3_enc_tns_lev), then frame by frame -- picked up a
+// second time -- everything that carries state from frame to frame.  A chunk of one frame picks it up once.  The mid column of the NEXT
+// visit is requested before the current one is worked on.
+// mid / planes: the launch's columns; fbase: the stream's first frame; store = 0: a shadow wave that stores nothing
+LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_encode_back_stream(LC3_CFG_PARAM, lc3_enc_lds &L, int lane, const float *mid, int32_t *planes,
+                                                       size_t fbase, int n_frames, int nbytes, int store, float *dbg) {
+    LC3_CFG_BIND;
+    lc3_mid_fetch cur, nxt;
+    if (n_frames > 0) lc3_mid_issue(c, lane, mid + fbase * (size_t)MP_WORDS, cur);
+    nxt = cur;
+    for (int t0 = 0; t0 < n_frames; t0 += LC3_TNS_CHUNK) {
+        const int nc = n_frames - t0 < LC3_TNS_CHUNK ? n_frames - t0 : LC3_TNS_CHUNK;
+        if (nc > 1) {
+            for (int u = 0; u < nc; u++) {
+                const int tn = u + 1 < nc ? t0 + u + 1 : t0;  // next visit: the chunk's next frame, then its first frame again
+                lc3_mid_issue(c, lane, mid + (fbase + (size_t)tn) * (size_t)MP_WORDS, nxt);
+                lc3_encode_back_pickup(LC3_CFG_PASS, L, lane, cur);
+                lc3_enc_tns_acf(LC3_CFG_PASS, LC3_LDS_PASS lane, L.ism[MPF_BW], L.ism[MPF_NEAR_NYQUIST], u);
+                cur = nxt;
+            }
+            lc3_enc_tns_lev(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes * 8, nc);
+        }
+        for (int u = 0; u < nc; u++) {
+            const int t = t0 + u;
+            if (t + 1 < n_frames) lc3_mid_issue(c, lane, mid + (fbase + (size_t)t + 1) * (size_t)MP_WORDS, nxt);  // (the next chunk starts at t0 + nc)
+            lc3_encode_back_pickup(LC3_CFG_PASS, L, lane, cur);
+            if (nc == 1) {
+                lc3_enc_tns_acf(LC3_CFG_PASS, LC3_LDS_PASS lane, L.ism[MPF_BW], L.ism[MPF_NEAR_NYQUIST], 0);
+                lc3_enc_tns_lev(LC3_CFG_PASS, LC3_LDS_PASS lane, nbytes * 8, 1);
+            }
+            const lc3_back_res r = lc3_encode_back_analyse(LC3_CFG_PASS, L, lane, nbytes, u, dbg);
+            lc3_encode_back_store(LC3_CFG_PASS, L, lane, r, LC3_PLANE_COL(planes, fbase + (size_t)t, EP_WORDS), LC3_PLANE_STRIDE, store, dbg);
+            cur = nxt;
+        }
+    }
 }

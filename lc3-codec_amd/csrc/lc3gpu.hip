@@ -711,17 +711,8 @@ __device__ __forceinline__ void lc3_enc_back_body(lc3_cfg_slot<CV> cfg, unsigned
     lc3_enc_state_load(L, lane, gst);  // the front half has stored (or initialised) the scalars
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const size_t fbase = (size_t)s * (size_t)n_frames;
-    lc3_mid_fetch cur, nxt;
-    if (n_frames > 0) lc3_mid_issue(c0, lane, mid + fbase * (size_t)MP_WORDS, cur);
-    for (int t = 0; t < n_frames; t++) {
-        const size_t f = fbase + (size_t)t;
-        // (requested here or behind the frame's last stage call -- lc3_encode_back_compute / _store exist for that --: the same 0.362 ms,
-        // profiles/r05_experiments.txt; a stage call waits for every load in flight either way)
-        if (t + 1 < n_frames) lc3_mid_issue(c0, lane, mid + (f + 1) * (size_t)MP_WORDS, nxt);  // lands while frame t is worked on
-        lc3_encode_back_wave(cfg, L, lane, mid + f * (size_t)MP_WORDS, cur, LC3_PLANE_COL(planes, f, EP_WORDS), LC3_PLANE_STRIDE,
-                             nbytes, valid, valid ? dbg : nullptr, t);
-        cur = nxt;
-    }
+    (void)c0;
+    lc3_encode_back_stream(cfg, L, lane, mid, planes, fbase, n_frames, nbytes, valid, valid ? dbg : nullptr);
     if (valid) lc3_enc_state_store(c0, L, lane, gst, nullptr);
     LC3_PROF_END(L, lane, 32);
 }

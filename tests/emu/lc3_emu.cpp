@@ -201,17 +201,7 @@ void *lane_main(void *arg) {
         lc3_enc_lds &L = j->EL[j->wave];
         if (lane == 0) L.spec_flags = j->spec_flags;
         lc3_enc_state_load(L, lane, j->est);
-        lc3_mid_fetch cur, nxt;
-        memset(&cur, 0, sizeof(cur));
-        memset(&nxt, 0, sizeof(nxt));
-        if (j->n_frames > 0) lc3_mid_issue(j->cfg, lane, j->mid + j->frame0 * (size_t)MP_WORDS, cur);
-        for (int t = 0; t < j->n_frames; t++) {
-            const size_t f = j->frame0 + (size_t)t;
-            if (t + 1 < j->n_frames) lc3_mid_issue(j->cfg, lane, j->mid + (f + 1) * (size_t)MP_WORDS, nxt);
-            lc3_encode_back_wave(j->cfg, L, lane, j->mid + f * (size_t)MP_WORDS, cur, LC3_PLANE_COL(j->enc_planes, f, EP_WORDS),
-                                 LC3_PLANE_STRIDE, j->nbytes, j->valid, j->valid ? j->dbg : nullptr);
-            cur = nxt;
-        }
+        lc3_encode_back_stream(j->cfg, L, lane, j->mid, j->enc_planes, j->frame0, j->n_frames, j->nbytes, j->valid, j->valid ? j->dbg : nullptr);
         if (j->valid) lc3_enc_state_store(j->cfg, L, lane, j->est, nullptr);
     } else if (j->encode == 4) {  // body of lc3_symbols_kernel: one wave per frame
         if (j->valid) lc3_enc_symbols_frame(j->cfg.ne, lane, LC3_PLANE_COL(j->enc_planes, j->frame0, EP_WORDS));

@@ -196,3 +196,37 @@ def test_emu_late_reconstruction(late):
     bl = synth.make_bandlimited_pcm(8, 6, 480, 48000, 7000.0)  # lower bandwidth indices: other TNS / noise-filling limits
     d = O.encode_batch(bl, 100)
     assert np.array_equal(E.decode(d, 480, late=late), O.decode_batch(d, 480))
+
+
+def test_gain_limitation_bound_covers_the_reference_expression():
+    """lc3_enc_quant decides `gg_ind < gg_min` from an integer bound on ceil(28 log10(x_f_max / 32767.625)) taken from the exponent of
+    x_f_max (lc3_dev_enc.h) and evaluates the reference's expression (spectral_quantization.rs:218-221) only when the bound cannot decide.
+    The bound has to be >= the expression for EVERY x_f_max of its binade: checked here with the device's own log10f (compiled for
+    the CPU) on the largest value, the smallest value and 4 000 random values of every binade of normal floats."""
+    rng = np.random.default_rng(5)
+    worst = 1000
+    for n in range(-125, 129):  # 2^(n-1) <= x < 2^n
+        lo = np.float32(2.0) ** np.float32(n - 1)
+        top = np.nextafter(np.float32(2.0) ** np.float32(n) if n < 128 else np.float32(np.inf), np.float32(0), dtype=np.float32)
+        xs = np.concatenate([[lo, top], (lo * (np.float32(1) + rng.random(4000, dtype=np.float32))).astype(np.float32)])
+        xs = xs[(xs >= lo) & (xs <= top)]
+        a = (8632 * n + 1023) >> 10 if n >= 0 else -((8631 * -n) >> 10)
+        bound = a - 125
+        for x in xs:
+            y = np.float32(x) / np.float32(32768.0 - 0.375)
+            v = np.ceil(np.float32(28.0) * np.float32(E.lib().lc3emu_log10f(float(y))))
+            v = min(32767.0, max(-32768.0, float(v)))  # lc3_f2i16
+            assert bound >= v, (n, float(x), bound, v)
+            worst = min(worst, bound - int(v))
+    assert 0 <= worst <= 2, worst  # the bound is tight: it does not give the fast path away
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 5, 9])
+def test_emu_frame_counts_around_the_tns_chunk(T):
+    """The encoder's back half analyses the frames of a launch in chunks of four (lc3_encode_back_stream: TNS autocorrelations of the
+    chunk, one pass of the Levinson recursions for all of its frames, then frame by frame); a chunk of ONE frame takes the short path.
+    Launches of 1, 2, 3, 5 (= 4 + 1) and 9 (= 4 + 4 + 1) frames on material with clicks (active TNS filters) against the oracle."""
+    pcm = synth.make_pcm(6, T, 480, 48000, seed=12)
+    for nbytes in (150, 60):
+        assert np.array_equal(E.encode(pcm, nbytes), O.encode_batch(pcm, nbytes))
+
