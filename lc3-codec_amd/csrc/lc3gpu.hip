@@ -113,13 +113,13 @@
 #ifndef LC3_SPEC_IN_LDS
 #define LC3_SPEC_IN_LDS 1
 #endif
-#if LC3_SPEC_IN_LDS
 // per-workgroup LDS copy of the spectral-model tables used by the analysis kernel's bit estimate (6.1 KB)
 struct lc3_spec_tables {
     uint8_t lookup[4096];
     uint16_t bits[64 * 17];
 };
 __shared__ lc3_spec_tables lc3_spec_tab;
+#if LC3_SPEC_IN_LDS
 #define LC3_SPEC_LOOKUP(i) ((int)lc3_spec_tab.lookup[(i)])
 #define LC3_SPEC_BITS(p, j) ((uint32_t)lc3_spec_tab.bits[(p) * 17 + (j)])
 #endif
