@@ -111,6 +111,13 @@
 #ifndef LC3_UNIFORM_PTR
 #define LC3_UNIFORM_PTR(T, p) ((T)(p))
 #endif
+#ifndef LC3_LDS_BASE
+#define LC3_LDS_BASE(p) (p)  // device build: the LDS address as an opaque base register (lc3gpu.hip); for arrays whose alignment is
+                            // unknown anyway (the compiler forgets what it knew about the pointer)
+#endif
+#ifndef LC3_LDS_BASE_ALIGNED
+#define LC3_LDS_BASE_ALIGNED(p, bytes) (p)
+#endif
 #ifndef LC3_HBM_CONST
 #define LC3_HBM_CONST(T) const T *
 #define LC3_HBM(T) T *
@@ -176,6 +183,7 @@ static inline float lc3_div_by(float x, const lc3_divisor &v) { return x / v.d; 
 
 // four consecutive floats at a 16-byte aligned address (one ds_read_b128 / global_load_dwordx4)
 struct __attribute__((aligned(16))) lc3_f4 { float x, y, z, w; };
+typedef int lc3_i4 __attribute__((vector_size(16)));  // builtin vector: assignable across address spaces
 
 struct lc3_cpx {
     float r, i;
@@ -205,6 +213,9 @@ struct lc3_cfg {
     const float *line_width;
     // band (0..nb-1) each spectral line belongs to, 255 for lines >= ne; nf entries, read four at a time (lc3_line_band_value)
     const uint8_t *line_band;
+    // The tables a wave-per-stream kernel stages in LDS once per workgroup, as ONE image in the LDS layout (lc3_fft_tables, then
+    // lc3_front_tables; written on the device when the configuration is registered): staging is a 16-byte copy instead of six strided loops
+    const void *stage_image;
     // decoder LTPF (decoder/long_term_post_filter.rs:104-134)
     int l_den, l_num, num_mem_blocks, norm, s25;
 };
@@ -256,6 +267,14 @@ __device__ __forceinline__ void lc3_fft_tables_stage(const CC &c) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) lc3_fft_tab.perm[i] = c.perm[i];
     __syncthreads();
 }
+// the same from the configuration's image: 16-byte units, all threads of the workgroup; ends with a workgroup barrier
+static_assert(sizeof(lc3_fft_tables) % 16 == 0, "image: 16-byte units");
+__device__ __forceinline__ void lc3_fft_tables_stage_image(const void *image) {
+    const lc3_i4 *src = (const lc3_i4 *)image;
+    lc3_i4 *dst = (lc3_i4 *)&lc3_fft_tab;
+    for (int i = threadIdx.x; i < (int)(sizeof(lc3_fft_tables) / 16); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
 // Tables only the analysis front half reads, per workgroup: the band width of every spectral line (divisor of the band
 // energies) and the fractional-lag interpolation filter of the LTPF analysis -- every frame re-read them from L2 otherwise
 struct lc3_front_tables {
@@ -274,6 +293,13 @@ __device__ __forceinline__ void lc3_front_tables_stage(const CC &c) {  // all th
     const int p_rows = c.p_up * c.resamp_stride;
     for (int i = threadIdx.x; i < p_rows && i < 336; i += blockDim.x) lc3_front_tab.resamp_poly[i] = c.resamp_poly[i];
 }
+static_assert(sizeof(lc3_front_tables) % 16 == 0, "image: 16-byte units");
+__device__ __forceinline__ void lc3_front_tables_stage_image(const void *image) {  // (before a workgroup barrier, like lc3_front_tables_stage)
+    const lc3_i4 *src = (const lc3_i4 *)((const char *)image + sizeof(lc3_fft_tables));
+    lc3_i4 *dst = (lc3_i4 *)&lc3_front_tab;
+    for (int i = threadIdx.x; i < (int)(sizeof(lc3_front_tables) / 16); i += blockDim.x) dst[i] = src[i];
+}
+#define LC3_STAGE_IMAGE_BYTES (sizeof(lc3_fft_tables) + sizeof(lc3_front_tables))
 #else
 #define LC3_LINE_WIDTH(c, k) ((c).line_width[(k)])
 #define LC3_LTPF_INTERP_R(i) (lc3_f(LC3T_TAB_LTPF_INTERP_R_BITS, (i)))
@@ -678,7 +704,6 @@ static __device__ const int LC3C_TNSDEC75[5][4] = {{9, 60, 0, 0}, {9, 120, 0, 0}
 // Coalesced block copies between HBM and a wave's LDS working set.  n4 = number of 16-byte units; both sides 16-byte
 // aligned.  All of a batch's loads are issued before the first use, so a copy costs one memory latency per 8 KB.
 // ------------------------------------------------------------------------------------------
-typedef int lc3_i4 __attribute__((vector_size(16)));  // builtin vector: assignable across address spaces
 __device__ __forceinline__ void lc3_wave_copy_in16(void *lds_dst, const void *hbm_src, int n4, int lane) {
     lc3_i4 *d = (lc3_i4 *)lds_dst;
     LC3_HBM_CONST(lc3_i4) s = (LC3_HBM_CONST(lc3_i4))hbm_src;

@@ -822,8 +822,9 @@ __device__ __forceinline__ float lc3_ltpf_dot(const float *x12, int n, int d) { 
 // samples: out0 = sum_j xa[j] * ha[j], out1 = sum_j xa[j + d] * hb[j] with d = DLO + far, each sum in tap order.  nt is a
 // multiple of 4; xa[0 .. nt + 11) must be readable.
 template <int DLO>
-__device__ __forceinline__ void lc3_resample_pair(const float *xa, const float *ha, const float *hb, int nt, int far, float &out0,
+__device__ __forceinline__ void lc3_resample_pair(const float *xa_, const float *ha, const float *hb, int nt, int far, float &out0,
                                                   float &out1) {
+    const float *xa = LC3_LDS_BASE(xa_);
     float win[8], nxt[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int u = 0; u < 8; u++) win[u] = xa[u];
@@ -1019,7 +1020,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         const int NL = LC3_KMAX + 1 - LC3_KMIN;  // 98
         const int lp = lane < NL / 2 ? lane : NL / 2 - 1, live = lane < NL / 2;
         const int k0 = 2 * lp, k1 = 2 * lp + 1;
-        const float *pa = x6 + LC3_KMAX, *pb = x6 + (LC3_KMAX - LC3_KMIN - 1 - k0);  // pb[n] = operand of lag k1, pb[n + 1] of lag k0
+        const float *pa = LC3_LDS_BASE_ALIGNED(x6 + LC3_KMAX, 8), *pb = LC3_LDS_BASE_ALIGNED(x6 + (LC3_KMAX - LC3_KMIN - 1 - k0), 8);  // pb[n] = operand of lag k1, pb[n + 1] of lag k0
         float acc0 = 0.0f, acc1 = 0.0f;
         {   // the next eight operands of each array are requested before the current eight products are added; two register
             // blocks take turns (len6 is 64 or 48: a whole number of double blocks)
@@ -1112,7 +1113,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     LC3_SERIAL_BEGIN(lc3_enc_lds, L, lane, ltpf_phase + 1, 3)
         const float *sq_ = (const float *)L.fb + 224;
         const int lag = sub == 0 ? 0 : L.ism[8 + sub - 1];
-        L.sm[8 + sub] = lc3_sum_seq(sq_ + (LC3_KMAX - lag), len6, 0.0f);
+        L.sm[8 + sub] = lc3_sum_seq(LC3_LDS_BASE(sq_ + (LC3_KMAX - lag)), len6, 0.0f);
     LC3_SERIAL_END
     int t_current, pitch_present;
     {   // the decision is then the same scalar code on every lane
@@ -1140,7 +1141,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         if (sub < L.ism[11]) {
             const float *x12_ = (const float *)L.fa + 64;
             const int k = L.ism[10] + sub;
-            ((float *)L.fb)[200 + sub] = lc3_dot_seq(x12_ + LC3_NMEM, x12_ + LC3_NMEM - k, len12, 0.0f);  // len12 is a multiple of 8
+            ((float *)L.fb)[200 + sub] = lc3_dot_seq(x12_ + LC3_NMEM, LC3_LDS_BASE(x12_ + LC3_NMEM - k), len12, 0.0f);  // len12 is a multiple of 8
         }
     LC3_SERIAL_END
     LC3_STAMP(L, lane, 17);

@@ -160,6 +160,24 @@ __shared__ lc3_spec_tables lc3_spec_tab;
     ((T)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)(uintptr_t)(p) >> 32)) << 32) | \
          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(p))))
 #define LC3_KEEP_SCALAR(x) asm("" : "+v"(x))
+// An LDS pointer as a base register the compiler knows nothing about: the accesses p[0], p[1], ... then carry their distance as the
+// instruction's immediate offset.  Without it the compiler folds the array's position inside the working set (a constant beyond the 8-bit
+// offsets of ds_read2_b32) into every access and spends one v_add_u32 per LDS instruction on it.
+static __device__ __forceinline__ const float *lc3_lds_base(const float *p) {
+    unsigned a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
+    asm("" : "+v"(a));
+    return (const float *)(const __attribute__((address_space(3))) float *)(uintptr_t)a;
+}
+#define LC3_LDS_BASE(p) lc3_lds_base(p)
+// ... of a known alignment (the mask is what tells the compiler: it tracks known-zero address bits, not assumptions, through the cast)
+template <unsigned BYTES>
+static __device__ __forceinline__ const float *lc3_lds_base_aligned(const float *p) {
+    unsigned a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
+    asm("" : "+v"(a));
+    a &= ~(BYTES - 1u);
+    return (const float *)(const __attribute__((address_space(3))) float *)(uintptr_t)a;
+}
+#define LC3_LDS_BASE_ALIGNED(p, bytes) lc3_lds_base_aligned<bytes>(p)
 #define LC3_KEEP_PER_FRAME(x) asm volatile("" : "+v"(x))
 // repeat builds (lc3_dev_experiments.h): a 2 in a scalar register that the compiler cannot fold
 static __device__ __forceinline__ int lc3_exp_two() {
@@ -269,9 +287,10 @@ struct lc3_cfg_any {
         const uint16_t *perm;                                                                                                          \
         const float *resamp_poly, *line_width;                                                                                         \
         const uint8_t *line_band;                                                                                                      \
+        const void *stage_image;                                                                                                       \
         __device__ __forceinline__ explicit NAME(const lc3_cfg &r)                                                                     \
             : fft_tw(r.fft_tw), dct_tw(r.dct_tw), perm(r.perm), resamp_poly(r.resamp_poly), line_width(r.line_width),                  \
-              line_band(r.line_band) {}                                                                                                \
+              line_band(r.line_band), stage_image(r.stage_image) {}                                                                    \
         typedef const NAME bind_t;                                                                                                     \
         static __device__ __forceinline__ NAME bind(const lc3_cfg &r) { return NAME(r); }                                              \
         static bool matches(const lc3_cfg &r) {                                                                                        \
@@ -589,8 +608,8 @@ __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigne
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const int nf = c0.nf, z = c0.z;
     lc3_enc_state *gst = states + (size_t)(first_channel + s);
-    lc3_front_tables_stage(c0);
-    lc3_fft_tables_stage(c0);  // ends with the workgroup barrier
+    lc3_front_tables_stage_image(c0.stage_image);
+    lc3_fft_tables_stage_image(c0.stage_image);  // ends with the workgroup barrier
     LC3_PROF_BEGIN(L, lane);
     if (lane == 0) L.spec_flags = spec_flags;
     if (fresh) lc3_enc_state_init(L, lane, gst, valid);
@@ -1301,7 +1320,7 @@ __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned w
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const int nf = c0.nf;
     lc3_dec_state *gst = states + (size_t)(first_channel + s);
-    lc3_fft_tables_stage(c0);
+    lc3_fft_tables_stage_image(c0.stage_image);
     LC3_PROF_BEGIN(L, lane);
     if (fresh) lc3_dec_state_init(L, lane, gst, valid);
     else lc3_dec_state_load(L, lane, gst);
@@ -1516,6 +1535,19 @@ __global__ void lc3_line_width_kernel(float *out, lc3_cfg c) {
 __global__ void lc3_line_band_kernel(uint8_t *out, lc3_cfg c) {
     for (int k = threadIdx.x; k < c.nf; k += blockDim.x) out[k] = (uint8_t)lc3_line_band_value(c, k);
 }
+// Writes a configuration's stage image (lc3_cfg::stage_image): one workgroup stages the tables in LDS exactly as the kernels did before the
+// image existed (lc3_front_tables_stage, lc3_fft_tables_stage over a zeroed array) and copies the two LDS structs out.
+__global__ __launch_bounds__(256) void lc3_stage_image_kernel(uint32_t *image, lc3_cfg c) {
+    uint32_t *lf = (uint32_t *)&lc3_fft_tab, *lt = (uint32_t *)&lc3_front_tab;
+    const int nf_w = (int)(sizeof(lc3_fft_tables) / 4), nt_w = (int)(sizeof(lc3_front_tables) / 4);
+    for (int i = threadIdx.x; i < nf_w; i += blockDim.x) lf[i] = 0u;
+    for (int i = threadIdx.x; i < nt_w; i += blockDim.x) lt[i] = 0u;
+    __syncthreads();
+    lc3_front_tables_stage(c);
+    lc3_fft_tables_stage(c);  // ends with the workgroup barrier
+    for (int i = threadIdx.x; i < nf_w; i += blockDim.x) image[i] = lf[i];
+    for (int i = threadIdx.x; i < nt_w; i += blockDim.x) image[nf_w + i] = lt[i];
+}
 // fills the polyphase resampler table of a configuration on the device (lc3_resamp_poly_value)
 __global__ void lc3_resamp_poly_kernel(float *out, int p, int lim, int stride) {
     const int n = p * stride;
@@ -1536,7 +1568,7 @@ CfgRegistry g_cfgs;
 
 // uploads the tables of one configuration into `base` (owned by the caller until success)
 int cfg_upload(lc3_cfg &c, const lc3_host_plan &pl, char *base, size_t bytes_tw, size_t bytes_perm, size_t bytes_poly, size_t bytes_lw,
-               int slot) {
+               size_t bytes_lb, int slot) {
     HIP_TRY(hipMemcpy(base, pl.fft_tw.data(), bytes_tw, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(base + bytes_tw, pl.dct_tw.data(), bytes_tw, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(base + 2 * bytes_tw, pl.perm.data(), sizeof(uint16_t) * (size_t)c.nfft, hipMemcpyHostToDevice));
@@ -1556,6 +1588,12 @@ int cfg_upload(lc3_cfg &c, const lc3_host_plan &pl, char *base, size_t bytes_tw,
     c.resamp_poly = poly;
     c.line_width = lw;
     c.line_band = lb;
+    uint32_t *image = (uint32_t *)(base + 2 * bytes_tw + bytes_perm + bytes_poly + bytes_lw + bytes_lb);  // 16-byte aligned: every part is
+    c.stage_image = nullptr;
+    hipLaunchKernelGGL(lc3_stage_image_kernel, dim3(1), dim3(256), 0, nullptr, image, c);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    c.stage_image = image;
     for (lc3_tu_register_fn reg : lc3_tu_registers) HIP_TRY((hipError_t)reg(slot, &c, 0));  // every translation unit's constant table
     return LC3GPU_OK;
 }
@@ -1607,12 +1645,12 @@ int cfg_acquire(HostCfg &h, int frame_us, int fs_hz) {
         if (!fft_plan_consistent(c)) return LC3GPU_EUNSUPPORTED;
         const size_t bytes_tw = sizeof(lc3_cpx) * (size_t)c.nfft;
         const size_t bytes_perm = (sizeof(uint16_t) * (size_t)c.nfft + 15) & ~(size_t)15;
-        const size_t bytes_poly = sizeof(float) * (size_t)c.p_up * (size_t)c.resamp_stride;
-        const size_t bytes_lw = sizeof(float) * (size_t)c.ne;
+        const size_t bytes_poly = (sizeof(float) * (size_t)c.p_up * (size_t)c.resamp_stride + 15) & ~(size_t)15;
+        const size_t bytes_lw = (sizeof(float) * (size_t)c.ne + 15) & ~(size_t)15;
         const size_t bytes_lb = ((size_t)c.nf + 15) & ~(size_t)15;
         char *base = nullptr;
-        HIP_TRY(hipMalloc((void **)&base, 2 * bytes_tw + bytes_perm + bytes_poly + bytes_lw + bytes_lb));
-        const int rc = cfg_upload(c, pl, base, bytes_tw, bytes_perm, bytes_poly, bytes_lw, slot);
+        HIP_TRY(hipMalloc((void **)&base, 2 * bytes_tw + bytes_perm + bytes_poly + bytes_lw + bytes_lb + LC3_STAGE_IMAGE_BYTES));
+        const int rc = cfg_upload(c, pl, base, bytes_tw, bytes_perm, bytes_poly, bytes_lw, bytes_lb, slot);
         if (rc) {
             (void)hipFree(base);  // nothing published: the slot stays unregistered
             return rc;
