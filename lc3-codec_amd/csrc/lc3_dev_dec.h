@@ -46,12 +46,22 @@ struct __attribute__((aligned(16))) lc3_dec_lds {
     lc3_cpx fa[LC3_MAX_NF / 2];    // pre-twiddled FFT input -> DCT-IV output
     float sm[32];                  // LTPF: the previous frame's coefficients
     int ism[64];
+    // The LTPF output ring of the state blob is fetched LAZILY (lc3_dec_ring_fill): a launch starts with the ring's LDS copy undefined and
+    // only a frame whose filter is on, or was on in the frame before, pulls in what earlier launches left -- minus the blocks this launch has
+    // written by then.  A stream whose filter stays off (every stream at the higher bit rates) never reads the 4 KB at all, and the launch
+    // stores only the blocks it wrote.
+    int ring_loaded;   // the LDS ring holds everything the state blob held at launch start (or the launch started from a fresh state)
+    int ring_blk0;     // block_start_index at launch start: the first block this launch writes
+    int ring_written;  // blocks written by this launch so far, saturating at num_mem_blocks (a fresh state starts saturated: all is stored)
+    int ring_pad_;
     unsigned long long prof_last;  // diagnostic build: time of the previous stage stamp
 #ifdef LC3_PROFILE
     unsigned long long prof_acc[32];  // diagnostic build: per-wave stage totals, flushed once per launch
 #endif
 };
 LC3_LDS_DECL(lc3_dec_lds, lc3_dec_wg)
+#define LC3_DEC_RING_BYTES ((int)sizeof(((lc3_dec_core *)0)->x_hat_ltpf_mem))
+static_assert(offsetof(lc3_dec_core, x_hat_ltpf_mem) == 0 && LC3_DEC_RING_BYTES % 16 == 0, "the ring leads the core blob, in 16-byte units");
 static_assert(offsetof(lc3_dec_lds, spec) % 16 == 0 && offsetof(lc3_dec_lds, fa) % 16 == 0 && offsetof(lc3_dec_lds, ism) % 16 == 0,
               "128-bit LDS accesses need aligned buffers");
 
@@ -66,16 +76,56 @@ __device__ __forceinline__ void lc3_dec_state_init(lc3_dec_lds &L, int lane, lc3
     if (lane == 0) {
         L.st.plc_seed = 24607;  // packet_loss_concealment.rs:31
         L.st.plc_alpha = 1.0f;
+        L.ring_loaded = 1;  // zeros: a fresh stream's ring
+        L.ring_blk0 = 0;
+        L.ring_written = 1 << 20;  // ... and all of it goes to the state blob at the end of the launch
     }
     LC3_SYNC();
 }
+// everything of the core but the LTPF output ring (see lc3_dec_lds::ring_loaded)
 __device__ __forceinline__ void lc3_dec_state_load(lc3_dec_lds &L, int lane, const lc3_dec_state *g) {
-    lc3_wave_copy_in16(&L.st, &g->core, (int)(sizeof(lc3_dec_core) / 16), lane);
+    lc3_wave_copy_in16((char *)&L.st + LC3_DEC_RING_BYTES, (const char *)&g->core + LC3_DEC_RING_BYTES,
+                       (int)((sizeof(lc3_dec_core) - LC3_DEC_RING_BYTES) / 16), lane);
+    LC3_SYNC();
+    if (lane == 0) {
+        L.ring_loaded = 0;
+        L.ring_blk0 = L.st.block_start_index;
+        L.ring_written = 0;
+    }
     LC3_SYNC();
 }
-__device__ __forceinline__ void lc3_dec_state_store(lc3_dec_lds &L, int lane, lc3_dec_state *g) {
+// The ring's blocks this launch has NOT written, from the state blob (whole 16-byte units: a block is nf floats, nf a multiple of 4).
+template <class CC>
+__device__ __forceinline__ void lc3_dec_ring_fill(const CC &c, lc3_dec_lds &L, int lane, const lc3_dec_state *g) {
+    const int nb = c.num_mem_blocks, u_blk = c.nf / 4, b0 = L.ring_blk0 / c.nf, nw = L.ring_written;
+    LC3_HBM_CONST(lc3_i4) src = (LC3_HBM_CONST(lc3_i4))g->core.x_hat_ltpf_mem;
+    lc3_i4 *dst = (lc3_i4 *)L.st.x_hat_ltpf_mem;
+    for (int b = 0; b < nb; b++) {
+        int age = b - b0;  // block b is the age-th block this launch writes
+        age += age < 0 ? nb : 0;
+        if (age < nw) continue;  // newer here than in the state blob
+        for (int u = lane; u < u_blk; u += LC3_WAVE) dst[b * u_blk + u] = src[b * u_blk + u];
+    }
     LC3_SYNC();
-    lc3_wave_copy_out16(&g->core, &L.st, (int)(sizeof(lc3_dec_core) / 16), lane);
+    if (lane == 0) L.ring_loaded = 1;
+    LC3_SYNC();
+}
+// the scalars and filter memories, and the ring blocks this launch wrote
+template <class CC>
+__device__ __forceinline__ void lc3_dec_state_store(const CC &c, lc3_dec_lds &L, int lane, lc3_dec_state *g) {
+    LC3_SYNC();
+    lc3_wave_copy_out16((char *)&g->core + LC3_DEC_RING_BYTES, (const char *)&L.st + LC3_DEC_RING_BYTES,
+                        (int)((sizeof(lc3_dec_core) - LC3_DEC_RING_BYTES) / 16), lane);
+    const int nb = c.num_mem_blocks, u_blk = c.nf / 4, b0 = L.ring_blk0 / c.nf, nw = L.ring_written;
+    if (nw >= nb) {
+        lc3_wave_copy_out16(g->core.x_hat_ltpf_mem, L.st.x_hat_ltpf_mem, nb * u_blk, lane);
+    } else {
+        for (int j = 0; j < nw; j++) {
+            int b = b0 + j;
+            b -= b >= nb ? nb : 0;
+            lc3_wave_copy_out16(g->core.x_hat_ltpf_mem + b * c.nf, L.st.x_hat_ltpf_mem + b * c.nf, u_blk, lane);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -202,7 +252,7 @@ __device__ __forceinline__ void lc3_ltpf_run(const CC &c, lc3_dec_lds &L, int la
 }
 
 LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_LDS_PARAM(lc3_dec_lds) int lane, int is_active, int pitch_index,
-                                             int nbits) {
+                                             int nbits, const lc3_dec_state *g) {
     LC3_CFG_BIND;
     LC3_LDS_BIND(lc3_dec_lds, lc3_dec_wg);
     const int nf = c.nf, blk = L.st.block_start_index, s25 = c.s25;
@@ -234,7 +284,10 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_L
     else if (pitch_int == L.st.p_int_mem && pitch_frac == L.st.p_fr_mem) trans = 4;
     else trans = 5;
     const int p_int_mem = L.st.p_int_mem;
+    const int ring_missing = !L.ring_loaded;
     LC3_SYNC();
+    // every transition but "off -> off" reads samples the ring held before this frame
+    if (LC3_UNIFORM_I32(trans != 1 && ring_missing)) lc3_dec_ring_fill(c, L, lane, g);
     // compute_filter_coeffs :192-242.  The previous frame's coefficients (c_num_mem / c_den_mem) are only read when that frame's filter
     // was on (transitions 3 and 5); a filter that stays off (transition 1: every frame of a stream at the higher bitrates) finds the
     // zeros it would write already there -- they were written when the filter went off, or at initialisation -- and touches nothing
@@ -310,6 +363,7 @@ LC3_CFG_TEMPLATE __device__ LC3_DEC_STAGE void lc3_dec_ltpf(LC3_CFG_PARAM, LC3_L
         int nb = blk + nf;
         if (nb > (c.num_mem_blocks - 1) * nf) nb = 0;
         L.st.block_start_index = nb;
+        if (L.ring_written < c.num_mem_blocks) L.ring_written += 1;
         L.st.ltpf_active_prev = is_active;
         L.st.p_int_mem = pitch_int;
         L.st.p_fr_mem = pitch_frac;
@@ -728,7 +782,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
         }
         LC3_SYNC();
     }
-    lc3_dec_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, ltpf_active, pitch_index, nbits);
+    lc3_dec_ltpf(LC3_CFG_PASS, LC3_LDS_PASS lane, ltpf_active, pitch_index, nbits, g);
     if (dbg_flags & LC3_DBG_DUMP) {
         for (int n = lane; n < nf; n += LC3_WAVE) dbg[LC3_DBG_LTPF + n] = L.spec[n];
     }

@@ -1331,7 +1331,7 @@ __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned w
     lc3_decode_stream_wave(cfg, L, lane, nbytes, planes, fbase, n_frames, gst, valid, pcm0, (size_t)nf * (size_t)stride, stride, LATE, dbg,
                            dbg_flags);
     LC3_PROF_MARK(L, lane, 39);  // frames (incl. everything between the stage stamps)
-    if (valid) lc3_dec_state_store(L, lane, gst);
+    if (valid) lc3_dec_state_store(c0, L, lane, gst);
     LC3_PROF_END(L, lane, 35);
 }
 template <class CV>

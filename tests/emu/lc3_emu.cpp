@@ -213,7 +213,7 @@ void *lane_main(void *arg) {
         if (j->fresh) lc3_dec_state_init(L, lane, j->dst, j->valid);
         else lc3_dec_state_load(L, lane, j->dst);
         lc3_decode_stream_wave(j->cfg, L, lane, j->nbytes, j->planes, j->frame0, j->n_frames, j->dst, j->valid, j->pcm_out, (size_t)j->cfg.nf, 1, j->late);
-        if (j->valid) lc3_dec_state_store(L, lane, j->dst);
+        if (j->valid) lc3_dec_state_store(j->cfg, L, lane, j->dst);
     }
     return 0;
 }

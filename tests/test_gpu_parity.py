@@ -442,6 +442,39 @@ def test_ltpf_transitions(fs, us, nbytes):
     assert np.array_equal(gpu_decode(ref, nf, fs, us), ref_pcm)
 
 
+@pytest.mark.parametrize("fs,us,nbytes,chunks", [(48000, 10000, 60, [1]), (48000, 10000, 60, [1, 2, 3, 5]), (48000, 7500, 60, [2, 1, 4]),
+                                                 (16000, 7500, 30, [1, 3]), (32000, 10000, 40, [4])])
+def test_ltpf_ring_is_fetched_lazily_and_stored_in_part(fs, us, nbytes, chunks):
+    """The decoder's LTPF output ring (lc3_dec_core::x_hat_ltpf_mem, num_mem_blocks * nf samples) is not read at the start of a launch: the
+    first frame whose filter is on -- or was on in the frame before -- pulls in what earlier launches left, minus the blocks this launch has
+    written by then, and a launch stores only the blocks it wrote (lc3_dec_ring_fill, lc3_dec_state_store).  A stream that walks through
+    all five filter transitions, decoded in launches of 1 .. 5 frames with the state carried in the handle (launches shorter than the ring,
+    as long, longer), at 48 kHz with every seventh frame lost on the way (a concealed frame runs the filter with `off`), against the oracle's one pass."""
+    torch = torch_mod()
+    nf = {48000: 480, 32000: 320, 16000: 160}[fs] * us // 10000
+    pcm = synth.make_ltpf_pcm(nf, fs)
+    S, T, _ = pcm.shape
+    data = O.encode_batch(pcm, nbytes, fs, us)
+    bad = np.zeros((S, T), np.uint8)
+    if fs == 48000:
+        bad[:, 6::7] = 1
+    corrupt = data.copy()
+    corrupt[bad.astype(bool), -1] |= 7  # the oracle's way to a lost frame: an unparsable bandwidth field (3 bits at 48 kHz)
+    O.ltpf_transition_counts(reset=True)
+    ref_pcm = O.decode_batch(corrupt, nf, fs, us)
+    assert all(c > 0 for c in O.ltpf_transition_counts()[1:])
+    dec = pkg.Lc3Decoder(S, us, fs)
+    got = np.zeros_like(ref_pcm)
+    t, i = 0, 0
+    while t < T:
+        n = min(chunks[i % len(chunks)], T - t)
+        i += 1
+        got[:, t:t + n] = gpu_decode(np.ascontiguousarray(data[:, t:t + n]), nf, fs, us, dec=dec, bad=np.ascontiguousarray(bad[:, t:t + n]))
+        t += n
+    assert np.array_equal(got, ref_pcm)
+    dec.close()
+
+
 @pytest.mark.parametrize("nbytes", [20, 25, 50, 79, 80, 81, 99, 100, 139, 140, 141, 160, 200, 260, 320, 399])
 def test_bitrate_sweep_48k(nbytes):
     """Bitrate boundaries at 48 kHz / 10 ms: rate_flag (nbits > 800), lsb mode (nbits >= 1120), attack detector on
