@@ -241,6 +241,10 @@ __device__ __forceinline__ int32_t lc3_f2i32(float x) {
     return xc >= 2147483648.0f ? 2147483647 : r;
 }
 __device__ __forceinline__ int32_t lc3_f2i16(float x) { return (int32_t)lc3_clampf(lc3_nan_to_zero(x), -32768.0f, 32767.0f); }
+// the same cast for an operand the caller knows is not a NaN (a finite value divided by a positive finite one): no NaN test
+__device__ __forceinline__ int32_t lc3_f2i16_no_nan(float x) { return (int32_t)lc3_clampf(x, -32768.0f, 32767.0f); }
+// |mag| with the sign bit of x (x = -0.0 counts as negative: callers add the result to a value for which that makes no difference)
+__device__ __forceinline__ float lc3_with_sign_of(float mag, float x) { return lc3_from_bits((lc3_bits(mag) & 0x7fffffffu) | (lc3_bits(x) & 0x80000000u)); }
 __device__ __forceinline__ int32_t lc3_f2i8(float x) { return (int32_t)lc3_clampf(lc3_nan_to_zero(x), -128.0f, 127.0f); }
 __device__ __forceinline__ int32_t lc3_f2u16(float x) { return (int32_t)lc3_clampf(lc3_nan_to_zero(x), 0.0f, 65535.0f); }
 // The transform tables of the configuration (FFT twiddles, DCT-IV twiddles, leaf gather order).  The device build can

@@ -1339,7 +1339,11 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const float xu = 8 * lane + u < ne ? x[u] : 0.0f;
-            q8[u] = lc3_f2i16(lc3_div_by(xu, dv) + (xu >= 0.0f ? 0.375f : -0.375f));  // a - 0.375 == a + (-0.375)
+            // `(x / gg + (x >= 0 ? 0.375 : -0.375)) as i16`, a - 0.375 == a + (-0.375).  The offset takes x's sign BIT: the one operand
+            // that treats differently, x = -0.0, gives -0.0 - 0.375 -> 0 where the reference has -0.0 + 0.375 -> 0.  The quotient is no
+            // NaN (x is finite: an MDCT of int16 samples, scaled by finite gains; gg = 10^(n / 28) is positive and finite), so the cast's NaN
+            // rule has nothing to act on.
+            q8[u] = lc3_f2i16_no_nan(lc3_div_by(xu, dv) + lc3_with_sign_of(0.375f, xu));
         }
         const lc3_i4 w = {(q8[0] & 0xffff) | (int)((uint32_t)q8[1] << 16), (q8[2] & 0xffff) | (int)((uint32_t)q8[3] << 16),
                           (q8[4] & 0xffff) | (int)((uint32_t)q8[5] << 16), (q8[6] & 0xffff) | (int)((uint32_t)q8[7] << 16)};  // int16 x 8
@@ -1419,12 +1423,16 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_bitcons lc3_quantize_spectrum(LC3_C
         const uint32_t lsb_total = lc3_wave_sum_u32(lsb_sum, lane);
         // lastnz_trunc / nbits_trunc: the last non-zero tuple whose running estimate still fits nbits_spec (:327-330; the
         // reference rounds the estimate to f32 before the division, which matters above 2^24)
+        // `ceil(acc as f32 / 2048) <= nbits_spec` as an integer comparison: below 2^24 the conversion is exact and the two say the same;
+        // from 2^24 on the quotient is >= 8192 > nbits_spec (<= 3200) and acc > 2048 * nbits_spec (< 2^23): both false
         int cand_k = -1;
         uint32_t cand_est = 0, acc = base;
+        const uint32_t fits = nbits_spec < 0 ? 0u : 2048u * (uint32_t)nbits_spec;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             acc += est4[j];
-            const int ok = k0 + j < ntup && (loc[j] & (1u << 24)) && (int)lc3_ceilf((float)acc / 2048.0f) <= nbits_spec;
+            const int ok = k0 + j < ntup && (loc[j] & (1u << 24)) && acc <= fits && nbits_spec >= 0;
+            LC3_GUARD_ASSERT((acc <= fits && nbits_spec >= 0) == ((int)lc3_ceilf((float)acc / 2048.0f) <= nbits_spec));
             cand_k = ok ? k0 + j : cand_k;
             cand_est = ok ? acc : cand_est;
         }
@@ -1510,7 +1518,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ lc3_quant_res lc3_enc_quant(LC3_CFG_PAR
     LC3_ENC_REPEAT(2) {
         int fac = 256, gg_ind = 255;
         float *tv = (float *)L.fa;  // the terms of one step in the reference's order (sequential path only)
-        const float thr = (float)nbits_spec_adj * 1.4f * 28.0f / 20.0f;
+        const float thr = lc3_div_by((float)nbits_spec_adj * 1.4f * 28.0f, by20);
         const int seq_always = (L.spec_flags & LC3_SPEC_TEST_SEQ_SUMS) != 0;
         for (int level = 0; level < 8; level++) {
             fac >>= 1;
