@@ -818,33 +818,32 @@ __device__ __forceinline__ float lc3_ltpf_dot(const float *x12, int n, int d) { 
     return acc;
 }
 
-// Two adjacent outputs of the polyphase resampler (encoder/long_term_post_filter.rs:152-166) from one sliding window of
-// samples: out0 = sum_j xa[j] * ha[j], out1 = sum_j xa[j + d] * hb[j] with d = DLO + far, each sum in tap order.  nt is a
-// multiple of 4; xa[0 .. nt + 11) must be readable.
-template <int DLO>
-__device__ __forceinline__ void lc3_resample_pair(const float *xa_, const float *ha, const float *hb, int nt, int far, float &out0,
-                                                  float &out1) {
+// Two outputs of the polyphase resampler (encoder/long_term_post_filter.rs:152-166) that share their polyphase row: n and n + d with 15 d a multiple of p (d = p / gcd(15, p)) start OFF =
+// 15 d / p samples apart and use the same taps, so one tap fetch and one window of OFF + 8 samples in registers feed both --
+// out0 = sum_j xa[j] * h[j], out1 = sum_j xa[j + OFF] * h[j], each sum in tap order.  nt is a multiple of 4; xa[0 .. nt + OFF) is read.
+template <int OFF>
+__device__ __forceinline__ void lc3_resample_same_row(const float *xa_, const float *h, int nt, float &out0, float &out1) {
     const float *xa = LC3_LDS_BASE(xa_);
-    float win[8], nxt[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float win[OFF + 8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) win[u] = xa[u];
+    for (int u = 0; u < OFF + 4; u++) win[u] = xa[u];
+#pragma unroll
+    for (int u = OFF + 4; u < OFF + 8; u++) win[u] = 0.0f;
     float acc0 = 0.0f, acc1 = 0.0f;
     for (int j = 0; j < nt; j += 4) {
-        const lc3_f4 a = *(const lc3_f4 *)(ha + j), b = *(const lc3_f4 *)(hb + j);
+        const lc3_f4 a = *(const lc3_f4 *)(h + j);
+        if (j + 4 < nt) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) nxt[u] = xa[j + 8 + u];
-        const float ta[4] = {a.x, a.y, a.z, a.w}, tb[4] = {b.x, b.y, b.z, b.w};
+            for (int u = 0; u < 4; u++) win[OFF + 4 + u] = xa[j + OFF + 4 + u];
+        }
+        const float ta[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             acc0 += win[u] * ta[u];
-            acc1 += (far ? win[u + DLO + 1] : win[u + DLO]) * tb[u];
-            LC3_KEEP_SCALAR(acc1);  // (pairing the two sums into packed f32 operations costs more register moves than it saves)
+            acc1 += win[u + OFF] * ta[u];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            win[u] = win[u + 4];
-            win[u + 4] = nxt[u];
-        }
+        for (int u = 0; u < OFF + 4; u++) win[u] = win[u + 4];
     }
     out0 = acc0;
     out1 = acc1;
@@ -917,25 +916,28 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     {
         const int nt = c.resamp_nt, lim = c.resamp_lim;
         float *o12 = x12 + c.delay12 + LC3_NMEM;
-        // Lane l computes the ADJACENT outputs 2l and 2l + 1: their sample windows start d = dlo or dlo + 1 positions apart
-        // (dlo = 15 / p), so one sliding register window of eight samples feeds both -- four new LDS values per four taps of
-        // both outputs instead of eight.
+        // Lane l computes two outputs d = p / gcd(15, p) apart: they use the same polyphase row and start OFF = 15 d / p samples apart
+        // (lc3_resample_same_row).  Blocks of 2 d outputs: lane l takes n0 = 2 d (l / d) + l % d and n0 + d; len12 is a multiple of 2 d.
         const int half = len12 / 2, live = lane < half, lp = live ? lane : half - 1;
-        const int n0 = 2 * lp, n1 = n0 + 1;
-        const int q0 = (15 * n0 * c.inv_p) >> 16, q1 = (15 * n1 * c.inv_p) >> 16;  // 15 n / p without integer divisions
+        const int ds = LC3_UNIFORM_I32(p == 4 ? 2 : (p == 6 ? 1 : (p == 12 ? 2 : 3))), d = 1 << ds;  // p = 4, 6, 8, 12, 24 -> d = 4, 2, 8, 4, 8
+#ifdef LC3_RESAMP_MAP_A
+        const int n0 = ((lp >> ds) << (ds + 1)) + (lp & (d - 1)), n1 = n0 + d;
+#else
+        // (which block a lane takes decides the LDS bank pattern of the sample reads: neighbouring lanes on neighbouring BLOCKS, 2 d outputs
+        // = 7.5 d samples apart, spread over the banks; neighbouring lanes inside one block collide three deep)
+        const int n_blk = half >> ds, blk = lp % n_blk, n0 = (blk << (ds + 1)) + lp / n_blk, n1 = n0 + d;
+#endif
+        const int q0 = (15 * n0 * c.inv_p) >> 16;  // 15 n / p without integer divisions
         const float *xa = W + c.hist + q0 - 2 * lim;  // tap j <-> k = j - lim
 #ifdef LC3_RESAMP_POLY_IN_LDS
         const float *poly = p * c.resamp_stride > 336 ? S : lc3_front_tab.resamp_poly;  // staged once per workgroup
 #else
         const float *poly = S;
 #endif
-        const float *ha = poly + (15 * n0 - q0 * p) * c.resamp_stride, *hb = poly + (15 * n1 - q1 * p) * c.resamp_stride;
+        const float *ha = poly + (15 * n0 - q0 * p) * c.resamp_stride;
         float acc0 = 0.0f, acc1 = 0.0f;
-        const int dlo = LC3_UNIFORM_I32(15 / p), far = (q1 - q0) != dlo;
-        if (dlo == 3) lc3_resample_pair<3>(xa, ha, hb, nt, far, acc0, acc1);       // p = 4 (48 / 44.1 kHz)
-        else if (dlo == 2) lc3_resample_pair<2>(xa, ha, hb, nt, far, acc0, acc1);  // p = 6 (32 kHz)
-        else if (dlo == 1) lc3_resample_pair<1>(xa, ha, hb, nt, far, acc0, acc1);  // p = 8, 12 (24, 16 kHz)
-        else lc3_resample_pair<0>(xa, ha, hb, nt, far, acc0, acc1);                // p = 24 (8 kHz)
+        if (p == 4 || p == 8) lc3_resample_same_row<15>(xa, ha, nt, acc0, acc1);  // 48 / 44.1 kHz, 24 kHz
+        else lc3_resample_same_row<5>(xa, ha, nt, acc0, acc1);                   // 32, 16, 8 kHz
         LC3_SYNC();
         if (live) {
             o12[n0] = acc0 * c.resamp_scale;
