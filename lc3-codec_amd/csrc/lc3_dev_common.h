@@ -253,11 +253,13 @@ __device__ __forceinline__ int32_t lc3_f2u16(float x) { return (int32_t)lc3_clam
 struct lc3_fft_tables {
     lc3_cpx fft_tw[LC3_MAX_NF / 2], dct_tw[LC3_MAX_NF / 2];
     uint16_t perm[LC3_MAX_NF / 2];
+    uint16_t leaf_bfly[64];  // innermost stage: the butterfly whose leaves are l, l + nb, l + 2 nb ... (nb = nfft / radix <= 48 of them)
 };
 __shared__ lc3_fft_tables lc3_fft_tab;  // one copy per workgroup (4.2 KB), filled by lc3_fft_tables_stage
 #define LC3_FFT_TW(c) (lc3_fft_tab.fft_tw)
 #define LC3_DCT_TW(c) (lc3_fft_tab.dct_tw)
 #define LC3_FFT_PERM(c) (lc3_fft_tab.perm)
+#define LC3_FFT_LEAF_BFLY(c, l) ((int)lc3_fft_tab.leaf_bfly[(l)])
 // all threads of the workgroup; ends with a workgroup barrier
 template <class CC>
 __device__ __forceinline__ void lc3_fft_tables_stage(const CC &c) {
@@ -269,6 +271,10 @@ __device__ __forceinline__ void lc3_fft_tables_stage(const CC &c) {
         ld[i] = dt[i];
     }
     for (int i = threadIdx.x; i < n; i += blockDim.x) lc3_fft_tab.perm[i] = c.perm[i];
+    {   // the leaves of the innermost stage's butterfly u are perm[p u + k] = perm[p u] + k nb: invert u -> perm[p u]
+        const int p = c.radix[c.n_stages - 1], nb = n / p;
+        for (int u = threadIdx.x; u < nb; u += blockDim.x) lc3_fft_tab.leaf_bfly[c.perm[u * p]] = (uint16_t)u;
+    }
     __syncthreads();
 }
 // the same from the configuration's image: 16-byte units, all threads of the workgroup; ends with a workgroup barrier
@@ -310,6 +316,16 @@ __device__ __forceinline__ void lc3_front_tables_stage_image(const void *image) 
 #define LC3_FFT_TW(c) ((c).fft_tw)
 #define LC3_DCT_TW(c) ((c).dct_tw)
 #define LC3_FFT_PERM(c) ((c).perm)
+#endif
+#ifndef LC3_FFT_LEAF_BFLY  // (no LDS copy of the tables: found by search -- the CPU emulator's build)
+template <class CC>
+__device__ __forceinline__ int lc3_fft_leaf_bfly_search(const CC &c, int l) {
+    const int p = c.radix[c.n_stages - 1], nb = c.nfft / p;
+    for (int u = 0; u < nb; u++)
+        if ((int)c.perm[u * p] == l) return u;
+    return 0;
+}
+#define LC3_FFT_LEAF_BFLY(c, l) lc3_fft_leaf_bfly_search(c, l)
 #endif
 // a * b for a, b < 2^24 (the device build maps it to the 24-bit multiplier)
 #ifndef LC3_MUL24
@@ -1026,12 +1042,16 @@ __device__ __forceinline__ void lc3_dct4_core(const CC &c, int lane, float *in, 
     {   // innermost stage with the pre-twiddle and the gather in its loads
         const int s = c.n_stages - 1;
         const int p = c.radix[s], fstride = c.fstride[s], nb = cnt / p;  // m = 1
+        // Lane l takes the butterfly whose leaves are l, l + nb, ... (the gather order of kf_work is a digit reversal: the leaves of ONE
+        // butterfly lie nb apart, and every residue l < nb belongs to exactly one): the loads are then contiguous over the lanes instead
+        // of a gather through perm[] that put three lanes on every bank, and the stores (butterfly u -> elements p u ...) go 3 p or so
+        // elements apart.  lc3_fft_tables::leaf_bfly names the butterfly.
         lc3_cpx x[5], y[5];
         if (lane < nb) {
 #pragma unroll
             for (int k = 0; k < 5; k++)
                 if (k < p) {
-                    const int n = (int)LC3_FFT_PERM(c)[lane * p + k];
+                    const int n = lane + k * nb;
                     lc3_cpx v;
                     v.r = in[2 * n];
                     v.i = in[nf - 2 * n - 1];
@@ -1039,19 +1059,25 @@ __device__ __forceinline__ void lc3_dct4_core(const CC &c, int lane, float *in, 
                 }
             lc3_bfly_vals(LC3_FFT_TW(c), p, fstride, 1, 0, x, y);
         }
+        const int u = lane < nb ? LC3_FFT_LEAF_BFLY(c, lane) : 0;  // (a table in LDS, not the array being overlaid)
         if (IN_PLACE) LC3_SYNC();
         if (lane < nb) {
 #pragma unroll
             for (int k = 0; k < 5; k++)
-                if (k < p) wk[lane * p + k] = y[k];
+                if (k < p) wk[u * p + k] = y[k];
         }
         LC3_SYNC();
     }
     for (int s = c.n_stages - 2; s >= 1; s--) {  // the stages between
         const int p = c.radix[s], m = c.m[s], fstride = c.fstride[s];
-        const int nb = cnt / p;
+        const int nb = cnt / p, nblk = nb / m;  // nblk sub-transforms of p m elements, m butterflies each
+        // Which butterfly a lane takes is free (butterflies of a stage touch disjoint elements).  Neighbouring lanes take the SAME butterfly
+        // index i of neighbouring sub-transforms: their elements lie p m apart (15, 45, 10 ... complex numbers: odd or twice odd, so a
+        // pass of sixteen 8-byte accesses spreads over the LDS banks) and they share their twiddles.  With neighbouring lanes on
+        // neighbouring butterflies of one sub-transform, i + k m for several sub-transforms at once, the radix-3 stage of the 240-point
+        // transform ran three deep in bank conflicts (modelled: 256 -> 88 LDS cycles for its two middle stages).
         for (int u = lane; u < nb; u += LC3_WAVE) {
-            const int blk = (u * c.inv_m[s]) >> 16, i = u - blk * m;  // u / m without an integer division
+            const int i = u / nblk, blk = u - i * nblk;  // (compile-time plans: a multiplication and a shift)
             lc3_bfly(wk + blk * p * m, LC3_FFT_TW(c), p, fstride, m, i);
         }
         LC3_SYNC();

@@ -149,12 +149,14 @@ __device__ __forceinline__ lc3_ola5 lc3_dec_ola_load(const CC &c, int lane, cons
 template <class CC>
 __device__ __forceinline__ void lc3_dec_ola_store(const CC &c, int lane, lc3_dec_state *g, int valid, const lc3_ola5 &m) {
     const int nv = LC3_UNIFORM_I32(valid) ? c.nf - c.z : 0;
-    LC3_HBM(float) ob = (LC3_HBM(float))g->mem_ola + lane;
+    int lane_o = lane;  // (an opaque copy: the per-lane address is formed here, after the frame loop, not carried -- spilled -- across it)
+    LC3_KEEP_PER_FRAME(lane_o);
+    LC3_HBM(float) ob = (LC3_HBM(float))g->mem_ola + lane_o;
 #pragma unroll
     for (int r = 0; r < 5; r++) {
         const int rem = nv - LC3_WAVE * r;
         if (rem >= LC3_WAVE) ob[LC3_WAVE * r] = m.v[r];
-        else if (lane < rem) ob[LC3_WAVE * r] = m.v[r];
+        else if (lane_o < rem) ob[LC3_WAVE * r] = m.v[r];
     }
 }
 // mo: the previous frame's overlap memory; returns the new one
@@ -679,8 +681,10 @@ template <class CC>
 __device__ __forceinline__ void lc3_dec_plc_save(const CC &c, lc3_dec_lds &L, int lane, lc3_dec_state *g, int to_blob) {
     if (to_blob) {  // ne <= 400: seven rounds, all LDS reads ahead of the stores
         float v[7];
+        int lane_s = lane;  // (an opaque copy: formed ahead of the frame loop, the last round's clamped address was a register spilled to scratch)
+        LC3_KEEP_PER_FRAME(lane_s);
 #pragma unroll
-        for (int r = 0; r < 7; r++) v[r] = L.spec[lane + LC3_WAVE * r < LC3_MAX_NE ? lane + LC3_WAVE * r : 0];
+        for (int r = 0; r < 7; r++) v[r] = L.spec[lane_s + LC3_WAVE * r < LC3_MAX_NE ? lane_s + LC3_WAVE * r : 0];
         LC3_HBM(float) dst = (LC3_HBM(float))g->plc_last_good + lane;
 #pragma unroll
         for (int r = 0; r < 7; r++)
