@@ -514,9 +514,15 @@ LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_tns_acf(LC3_CFG_PARAM, LC3
     // compute_normalized_autocorrelation :80-115 -- one lane per (filter, lag, sub-block) partial sum, every sum in the
     // reference's order.  The sub-block energy e_s (:88-93) is the lag-0 sum of its sub-block -- the same products added in the
     // same order -- so the lag-0 lanes supply it.  A lane's sum has 50..70 terms: blocks of eight, the last one masked.
+    // Which lane takes which sum is chosen for the LDS banks (every operand is a 4-byte read at its own address): the nine lags of a
+    // sub-block on nine neighbouring lanes (consecutive addresses), three sub-blocks per half-wave, and the two sub-blocks of the upper
+    // filter that start a multiple of 32 lines apart (160 and 320 at 48 kHz) in different half-waves.  Modelled for the full-band
+    // layout: 48 instead of 72 LDS cycles per eight terms (32 if nothing collided).
     LC3_ENC_REPEAT(16) {
-    if (lane < 54) {
-        const int f = lane / 27, r = lane - 27 * f, k = r / 3, s = r - 3 * k;
+    if ((lane & 31) < 27) {
+        const int j = (lane & 31) / 9, k = (lane & 31) - 9 * j;
+        const int blk = lane < 32 ? (j == 2 ? 3 : j) : (j == 0 ? 2 : j + 3);  // f * 3 + s: {0, 1, 3} | {2, 4, 5}
+        const int f = blk >= 3, s = blk - 3 * f;
         float ac = 0.0f;
         if (f < tp.num) {
             const int start = tp.sub_start[f][s], stop = tp.sub_stop[f][s], k_from = start + k;
@@ -543,7 +549,7 @@ LC3_CFG_TEMPLATE __device__ __noinline__ void lc3_enc_tns_acf(LC3_CFG_PARAM, LC3
                 }
             }
         }
-        sAC[lane] = ac;
+        sAC[f * 27 + k * 3 + s] = ac;
         if (k == 0) sES[f * 3 + s] = ac;
     }
     if (lane == 0) {
