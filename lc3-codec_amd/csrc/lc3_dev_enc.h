@@ -1028,40 +1028,63 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         const int NL = LC3_KMAX + 1 - LC3_KMIN;  // 98
         const int lp = lane < NL / 2 ? lane : NL / 2 - 1, live = lane < NL / 2;
         const int k0 = 2 * lp, k1 = 2 * lp + 1;
-        const float *pa = LC3_LDS_BASE_ALIGNED(x6 + LC3_KMAX, 8), *pb = LC3_LDS_BASE_ALIGNED(x6 + (LC3_KMAX - LC3_KMIN - 1 - k0), 8);  // pb[n] = operand of lag k1, pb[n + 1] of lag k0
-        float acc0 = 0.0f, acc1 = 0.0f;
+        // The two sums of a lane advance together as one packed pair: (acc1, acc0) += a[n] * (pb[n], pb[n + 1]) -- the same two f32
+        // multiplications and two additions per term as two scalar chains.  The operand pairs (pb[n], pb[n + 1]) are wanted at BOTH
+        // parities of n; pb is 8-byte aligned (x6 is, k0 is even), so the even ones are aligned 64-bit reads, and the odd ones are read as
+        // aligned pairs too, from a copy of the ring one sample on (x6s[i] = x6[i + 1], in `spec`, dead since the mid column left):
+        // sixteen lanes at a time, two banks each, every bank once.  (Read at odd offsets of x6 itself they came as 4-byte pairs whose
+        // addresses all have one parity: two deep in bank conflicts, and twice -- the compiler fetched every sample once per alignment.)
+        typedef float lc3_v2 __attribute__((vector_size(8)));
+        float *x6s = (float *)L.spec;
+        for (int i = lane; i < LC3_KMAX + len6 - 1; i += LC3_WAVE) x6s[i] = x6[i + 1];
+        LC3_SYNC();
+        const int pbo = LC3_KMAX - LC3_KMIN - 1 - k0;  // pb[n] = x6[pbo + n] = operand of lag k1, pb[n + 1] of lag k0
+        const float *pa = LC3_LDS_BASE_ALIGNED(x6 + LC3_KMAX, 8);
+        const lc3_v2 *pe = (const lc3_v2 *)LC3_LDS_BASE_ALIGNED(x6 + pbo, 8), *po = (const lc3_v2 *)LC3_LDS_BASE_ALIGNED(x6s + pbo, 8);
+        float acc0, acc1;
         {   // the next eight operands of each array are requested before the current eight products are added; two register
             // blocks take turns (len6 is 64 or 48: a whole number of double blocks)
-            float a[8], bb[9], an[8], bn[9];
+            lc3_v2 acc = {0.0f, 0.0f};
+            float a[8], an[8];
+            lc3_v2 be[4], bo[4], ben[4], bon[4];  // be[j] = (pb[n + 2j], pb[n + 2j + 1]), bo[j] = (pb[n + 2j + 1], pb[n + 2j + 2])
 #pragma unroll
             for (int u = 0; u < 8; u++) a[u] = pa[u];
 #pragma unroll
-            for (int u = 0; u < 9; u++) bb[u] = pb[u];
+            for (int j = 0; j < 4; j++) {
+                be[j] = pe[j];
+                bo[j] = po[j];
+            }
 #pragma unroll  // (a configuration view knows len6: straight-line code, no block is moved between registers)
             for (int n = 0; n < len6; n += 16) {
 #pragma unroll
                 for (int u = 0; u < 8; u++) an[u] = pa[n + 8 + u];
 #pragma unroll
-                for (int u = 1; u < 9; u++) bn[u] = pb[n + 8 + u];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    acc0 += a[u] * bb[u + 1];
-                    acc1 += a[u] * bb[u];
+                for (int j = 0; j < 4; j++) {
+                    ben[j] = pe[(n + 8) / 2 + j];
+                    bon[j] = po[(n + 8) / 2 + j];
                 }
-                bn[0] = bb[8];  // the last operand of a block is the first of the next for the odd lag
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    acc = acc + a[2 * j] * be[j];
+                    acc = acc + a[2 * j + 1] * bo[j];
+                }
                 if (n + 16 < len6) {
 #pragma unroll
                     for (int u = 0; u < 8; u++) a[u] = pa[n + 16 + u];
 #pragma unroll
-                    for (int u = 1; u < 9; u++) bb[u] = pb[n + 16 + u];
+                    for (int j = 0; j < 4; j++) {
+                        be[j] = pe[(n + 16) / 2 + j];
+                        bo[j] = po[(n + 16) / 2 + j];
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    acc0 += an[u] * bn[u + 1];
-                    acc1 += an[u] * bn[u];
+                for (int j = 0; j < 4; j++) {
+                    acc = acc + an[2 * j] * ben[j];
+                    acc = acc + an[2 * j + 1] * bon[j];
                 }
-                bb[0] = bn[8];
             }
+            acc1 = acc[0];
+            acc0 = acc[1];
         }
         if (live) {
             r6[k0] = acc0;
