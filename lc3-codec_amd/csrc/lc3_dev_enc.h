@@ -889,8 +889,12 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     const int head12 = old12 + len12 >= x12_len ? old12 + len12 - x12_len : old12 + len12;
     const int head6 = old6 + len6 >= r6_len ? old6 + len6 - r6_len : old6 + len6;
     LC3_HBM_FENCE();
+    // the 6.4 kHz ring is requested together with the 12.8 kHz one (one trip to HBM instead of two); it waits in registers until the
+    // resampler has consumed the time buffer whose place it takes
+    float v6[3];
     {
         LC3_HBM_CONST(float) g12 = (LC3_HBM_CONST(float))g->x12;
+        LC3_HBM_CONST(float) g6 = (LC3_HBM_CONST(float))g->x6;
         float v[5];
 #pragma unroll
         for (int j = 0; j < 5; j++) {
@@ -898,6 +902,13 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
             int ph = head12 + i;  // the ring after this frame's shift starts at the advanced head
             ph -= ph >= x12_len ? x12_len : 0;
             v[j] = i < keep12 ? g12[ph] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = lane + LC3_WAVE * j;
+            int ph = head6 + i;
+            ph -= ph >= r6_len ? r6_len : 0;
+            v6[j] = i < keep6 ? g6[ph] : 0.0f;
         }
         const int p_rows = p * c.resamp_stride;
 #ifdef LC3_RESAMP_POLY_IN_LDS
@@ -950,13 +961,10 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
             o12[n1] = acc1 * c.resamp_scale;
         }
         // the time buffer is consumed: stage the 6.4 kHz ring in its place (shifted by len6 on the way in)
-        LC3_HBM_CONST(float) g6 = (LC3_HBM_CONST(float))g->x6;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const int i = lane + LC3_WAVE * j;
-            int ph = head6 + i;
-            ph -= ph >= r6_len ? r6_len : 0;
-            if (i < keep6) x6[i] = g6[ph];
+            if (i < keep6) x6[i] = v6[j];
         }
     }
     // the high-pass memories h[-1], h[-2] as every lane needs them below (read before lane 0 moves them on)
@@ -1013,6 +1021,20 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         }
     }
     LC3_SYNC();
+    // The frame's new samples go into the oldest slots of the rings in the state blob as soon as they are final -- here for the 12.8 kHz
+    // ring, after the decimation below for the 6.4 kHz one --, not at the end of the stage: a store issued right before the next frame's
+    // first stage call is waited for at that call, with the whole latency of a trip to HBM exposed; issued here it has the rest of the
+    // stage to complete in.
+    if (store) {
+        float *g12 = g->x12;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int i = lane + LC3_WAVE * j;
+            int ph = old12 + i;
+            ph -= ph >= x12_len ? x12_len : 0;
+            if (i < len12) g12[ph] = x12[keep12 + i];
+        }
+    }
     LC3_STAMP(L, lane, 13);
     // pitch_detection :232-290
     for (int n = lane; n < len6; n += LC3_WAVE) {
@@ -1021,6 +1043,12 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
                            0.2353512128364889f * s[3] + 0.1236796411180537f * s[4];
     }
     LC3_SYNC();
+    if (store) {
+        float *g6 = g->x6;
+        int ph = old6 + lane;
+        ph -= ph >= r6_len ? r6_len : 0;
+        if (lane < len6) g6[ph] = x6[keep6 + lane];
+    }
     int lag_t1, lag_t2;
     {   // 98 lags, len6-term sums in order.  Lane l runs the ADJACENT lags 2l and 2l + 1 side by side: their second operands are
         // the same samples one position apart (x6[97 - 2l + n] and x6[96 - 2l + n]), so nine LDS values serve eight terms of both
@@ -1316,22 +1344,6 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
     res.pitch_present = pitch_present;
     res.ltpf_active = ltpf_active;
     res.nbits_ltpf = res.pitch_present ? 11 : 1;
-    // the new samples go into the oldest slots of the rings in the state blob
-    if (store) {
-        float *g12 = g->x12, *g6 = g->x6;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int i = lane + LC3_WAVE * j;
-            int ph = old12 + i;
-            ph -= ph >= x12_len ? x12_len : 0;
-            if (i < len12) g12[ph] = x12[keep12 + i];
-        }
-        {
-            int ph = old6 + lane;
-            ph -= ph >= r6_len ? r6_len : 0;
-            if (lane < len6) g6[ph] = x6[keep6 + lane];
-        }
-    }
     if (lane == 0) {
         L.st.ring12_head = head12;
         L.st.ring6_head = head6;
