@@ -256,10 +256,18 @@ struct lc3_fft_tables {
     uint16_t leaf_bfly[64];  // innermost stage: the butterfly whose leaves are l, l + nb, l + 2 nb ... (nb = nfft / radix <= 48 of them)
 };
 __shared__ lc3_fft_tables lc3_fft_tab;  // one copy per workgroup (4.2 KB), filled by lc3_fft_tables_stage
+#ifdef LC3_TABLES_IN_GLOBAL  // experiment build: the tables read from the configuration's stage image in global memory (no LDS copy)
+#define LC3_FFT_IMG(c) ((const lc3_fft_tables *)(c).stage_image)
+#define LC3_FFT_TW(c) (LC3_FFT_IMG(c)->fft_tw)
+#define LC3_DCT_TW(c) (LC3_FFT_IMG(c)->dct_tw)
+#define LC3_FFT_PERM(c) (LC3_FFT_IMG(c)->perm)
+#define LC3_FFT_LEAF_BFLY(c, l) ((int)LC3_FFT_IMG(c)->leaf_bfly[(l)])
+#else
 #define LC3_FFT_TW(c) (lc3_fft_tab.fft_tw)
 #define LC3_DCT_TW(c) (lc3_fft_tab.dct_tw)
 #define LC3_FFT_PERM(c) (lc3_fft_tab.perm)
 #define LC3_FFT_LEAF_BFLY(c, l) ((int)lc3_fft_tab.leaf_bfly[(l)])
+#endif
 // all threads of the workgroup; ends with a workgroup barrier
 template <class CC>
 __device__ __forceinline__ void lc3_fft_tables_stage(const CC &c) {
@@ -293,8 +301,16 @@ struct lc3_front_tables {
     float resamp_poly[336];  // polyphase rows of the LTPF resampler (lc3_resamp_poly_value), <= 12 rows x 28 floats for an encoder
 };
 __shared__ __attribute__((aligned(16))) lc3_front_tables lc3_front_tab;  // 3.2 KB, filled by lc3_front_tables_stage
+#ifdef LC3_TABLES_IN_GLOBAL
+#define LC3_FRONT_IMG(c) ((const lc3_front_tables *)((const char *)(c).stage_image + sizeof(lc3_fft_tables)))
+#define LC3_LINE_WIDTH(c, k) (LC3_FRONT_IMG(c)->line_width[(k)])
+#define LC3_LTPF_INTERP_R(i) (lc3_f(LC3T_TAB_LTPF_INTERP_R_BITS, (i)))
+#define LC3_RESAMP_POLY(c) (LC3_FRONT_IMG(c)->resamp_poly)
+#else
 #define LC3_LINE_WIDTH(c, k) (lc3_front_tab.line_width[(k)])
 #define LC3_LTPF_INTERP_R(i) (lc3_front_tab.interp_r[(i)])
+#define LC3_RESAMP_POLY(c) (lc3_front_tab.resamp_poly)
+#endif
 #define LC3_RESAMP_POLY_IN_LDS 1
 template <class CC>
 __device__ __forceinline__ void lc3_front_tables_stage(const CC &c) {  // all threads of the workgroup, before a workgroup barrier

@@ -947,7 +947,7 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ lc3_ltpf_res lc3_enc_ltpf(LC3_CFG_PA
         const int q0 = (15 * n0 * c.inv_p) >> 16;  // 15 n / p without integer divisions
         const float *xa = W + c.hist + q0 - 2 * lim;  // tap j <-> k = j - lim
 #ifdef LC3_RESAMP_POLY_IN_LDS
-        const float *poly = p * c.resamp_stride > 336 ? S : lc3_front_tab.resamp_poly;  // staged once per workgroup
+        const float *poly = p * c.resamp_stride > 336 ? S : LC3_RESAMP_POLY(c);  // staged once per workgroup
 #else
         const float *poly = S;
 #endif

@@ -336,6 +336,9 @@ __device__ __forceinline__ void lc3_dct4_select(const CC &c, int lane, float *in
 }
 template <int IN_PLACE>
 __device__ __forceinline__ void lc3_dct4_select(const lc3_cfg &c, int lane, float *in, lc3_cpx *wk, float *out) {
+#ifdef LC3_TABLES_IN_GLOBAL  // (experiment build: the plan structs carry no table pointer; the run-time view runs its run-time plan)
+    lc3_dct4_core<IN_PLACE>(c, lane, in, wk, out);
+#else
     switch (c.nf) {
     case 480: lc3_dct4_core<IN_PLACE>(lc3_fft_plan_480(), lane, in, wk, out); break;
     case 360: lc3_dct4_core<IN_PLACE>(lc3_fft_plan_360(), lane, in, wk, out); break;
@@ -348,6 +351,7 @@ __device__ __forceinline__ void lc3_dct4_select(const lc3_cfg &c, int lane, floa
     case 60: lc3_dct4_core<IN_PLACE>(lc3_fft_plan_60(), lane, in, wk, out); break;
     default: lc3_dct4_core<IN_PLACE>(c, lane, in, wk, out); break;
     }
+#endif
 }
 #undef LC3_CFG_TEMPLATE
 #undef LC3_CFG_PARAM
@@ -608,8 +612,10 @@ __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigne
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const int nf = c0.nf, z = c0.z;
     lc3_enc_state *gst = states + (size_t)(first_channel + s);
+#ifndef LC3_TABLES_IN_GLOBAL
     lc3_front_tables_stage_image(c0.stage_image);
     lc3_fft_tables_stage_image(c0.stage_image);  // ends with the workgroup barrier
+#endif
     LC3_PROF_BEGIN(L, lane);
     if (lane == 0) L.spec_flags = spec_flags;
     if (fresh) lc3_enc_state_init(L, lane, gst, valid);
@@ -1320,7 +1326,9 @@ __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned w
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const int nf = c0.nf;
     lc3_dec_state *gst = states + (size_t)(first_channel + s);
+#ifndef LC3_TABLES_IN_GLOBAL
     lc3_fft_tables_stage_image(c0.stage_image);
+#endif
     LC3_PROF_BEGIN(L, lane);
     if (fresh) lc3_dec_state_init(L, lane, gst, valid);
     else lc3_dec_state_load(L, lane, gst);
