@@ -38,6 +38,7 @@
 // configuration as an argument are templates over its type for the same reason.
 #ifndef LC3_CFG_PARAM
 #define LC3_CFG_TEMPLATE
+#define LC3_CFG_TEMPLATE_AND(...) template <__VA_ARGS__>  // a stage function with template parameters of its own
 #define LC3_CFG_PARAM const lc3_cfg &c
 #define LC3_CFG_BIND
 #define LC3_CFG_PASS c
@@ -291,6 +292,26 @@ __device__ __forceinline__ void lc3_fft_tables_stage_image(const void *image) {
     const lc3_i4 *src = (const lc3_i4 *)image;
     lc3_i4 *dst = (lc3_i4 *)&lc3_fft_tab;
     for (int i = threadIdx.x; i < (int)(sizeof(lc3_fft_tables) / 16); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+// ... in two steps, so that a kernel can have the image, its stream state and its first frame on their way from HBM at the same time (a
+// launch is only four frames long: three or four trips in a row at its start were ~15 % of the synthesis kernel's time).  Workgroups of
+// 256 threads: 270 units = two per thread at most.
+struct lc3_fft_image_regs { lc3_i4 a, b; };
+__device__ __forceinline__ lc3_fft_image_regs lc3_fft_tables_image_issue(const void *image) {
+    LC3_HBM_CONST(lc3_i4) src = (LC3_HBM_CONST(lc3_i4))image;
+    const int n = (int)(sizeof(lc3_fft_tables) / 16), i = (int)threadIdx.x;
+    static_assert(sizeof(lc3_fft_tables) / 16 <= 2 * 64 * 4, "two units per thread of a four-wave workgroup");
+    lc3_fft_image_regs r;
+    r.a = src[i < n ? i : 0];
+    r.b = src[i + 256 < n ? i + 256 : 0];
+    return r;
+}
+__device__ __forceinline__ void lc3_fft_tables_image_commit(const lc3_fft_image_regs &r) {  // ends with a workgroup barrier
+    lc3_i4 *dst = (lc3_i4 *)&lc3_fft_tab;
+    const int n = (int)(sizeof(lc3_fft_tables) / 16), i = (int)threadIdx.x;
+    if (i < n) dst[i] = r.a;
+    if (i + 256 < n) dst[i + 256] = r.b;
     __syncthreads();
 }
 // Tables only the analysis front half reads, per workgroup: the band width of every spectral line (divisor of the band

@@ -94,6 +94,25 @@ __device__ __forceinline__ void lc3_dec_state_load(lc3_dec_lds &L, int lane, con
     }
     LC3_SYNC();
 }
+// the same in two steps (see lc3_fft_tables_image_issue): the 12 units are requested, then -- behind whatever else the caller has requested
+// in between -- written to LDS
+static_assert((sizeof(lc3_dec_core) - LC3_DEC_RING_BYTES) / 16 <= LC3_WAVE, "one unit per lane");
+__device__ __forceinline__ lc3_i4 lc3_dec_state_issue(int lane, const lc3_dec_state *g) {
+    const int n = (int)((sizeof(lc3_dec_core) - LC3_DEC_RING_BYTES) / 16);
+    LC3_HBM_CONST(lc3_i4) src = (LC3_HBM_CONST(lc3_i4))((const char *)&g->core + LC3_DEC_RING_BYTES);
+    return src[lane < n ? lane : 0];
+}
+__device__ __forceinline__ void lc3_dec_state_commit(lc3_dec_lds &L, int lane, const lc3_i4 &v) {
+    const int n = (int)((sizeof(lc3_dec_core) - LC3_DEC_RING_BYTES) / 16);
+    if (lane < n) ((lc3_i4 *)((char *)&L.st + LC3_DEC_RING_BYTES))[lane] = v;
+    LC3_SYNC();
+    if (lane == 0) {
+        L.ring_loaded = 0;
+        L.ring_blk0 = L.st.block_start_index;
+        L.ring_written = 0;
+    }
+    LC3_SYNC();
+}
 // The ring's blocks this launch has NOT written, from the state blob (whole 16-byte units: a block is nf floats, nf a multiple of 4).
 template <class CC>
 __device__ __forceinline__ void lc3_dec_ring_fill(const CC &c, lc3_dec_lds &L, int lane, const lc3_dec_state *g) {
@@ -833,9 +852,15 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ int lc3_decode_frame_wave(LC3_CFG_PA
 // lane-per-frame stage wrote for that frame -- so a good frame copies nothing; only the last frame of the launch saves its
 // spectrum to the state blob (or, when that frame is lost, the plane column of the launch's last good frame is copied there).
 // Frame t's samples go to pcm0 + t * frame_step, `stride` elements apart.
-LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_stream_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes, const int32_t *planes,
+struct lc3_no_prologue { __device__ __forceinline__ void operator()() const {} };
+// prologue: called once, after the first frame's column and the overlap memory have been REQUESTED and before anything is used -- the
+// kernel body writes its tables and the stream state (requested before the call) to LDS there, so that all of a launch's first loads are
+// on their way from HBM together
+LC3_CFG_TEMPLATE_AND(class PROLOGUE = lc3_no_prologue)
+__device__ __forceinline__ void lc3_decode_stream_wave(LC3_CFG_PARAM, lc3_dec_lds &L, int lane, int nbytes, const int32_t *planes,
                                                        size_t fbase, int n_frames, lc3_dec_state *g, int valid, int16_t *pcm0,
-                                                       size_t frame_step, int stride, int late = 0, float *dbg = nullptr, int dbg_flags = 0) {
+                                                       size_t frame_step, int stride, int late = 0, float *dbg = nullptr, int dbg_flags = 0,
+                                                       PROLOGUE prologue = PROLOGUE(), int fresh_in_prologue = 0) {
     LC3_CFG_BIND;
     const auto &c0 = c;
     lc3_plane_fetch cur, nxt;
@@ -844,6 +869,11 @@ LC3_CFG_TEMPLATE __device__ __forceinline__ void lc3_decode_stream_wave(LC3_CFG_
     if (n_frames > 0) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, fbase, LC3_PLANE_WORDS), cur, late);
     int t_good = -1, last_ok = 1;
     lc3_ola5 ola = lc3_dec_ola_load(c0, lane, g);
+    prologue();
+    if (LC3_UNIFORM_I32(fresh_in_prologue)) {  // the prologue has just reset the stream (lc3_dec_state_init): what was requested above is the OLD overlap memory
+#pragma unroll
+        for (int r = 0; r < 5; r++) ola.v[r] = 0.0f;
+    }
     for (int t = 0; t < n_frames; t++) {
         const size_t f = fbase + (size_t)t;
         if (t + 1 < n_frames) lc3_dec_issue_frame(c0, lane, LC3_PLANE_COL(planes, f + 1, LC3_PLANE_WORDS), nxt, late);

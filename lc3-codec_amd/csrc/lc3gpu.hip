@@ -354,10 +354,12 @@ __device__ __forceinline__ void lc3_dct4_select(const lc3_cfg &c, int lane, floa
 #endif
 }
 #undef LC3_CFG_TEMPLATE
+#undef LC3_CFG_TEMPLATE_AND
 #undef LC3_CFG_PARAM
 #undef LC3_CFG_BIND
 #undef LC3_CFG_PASS
 #define LC3_CFG_TEMPLATE template <class CV>
+#define LC3_CFG_TEMPLATE_AND(...) template <class CV, __VA_ARGS__>
 #define LC3_CFG_PARAM lc3_cfg_slot<CV> cslot
 #define LC3_CFG_BIND typename CV::bind_t c = CV::bind(lc3_cfg_table[__builtin_amdgcn_readfirstlane(cslot.id)])
 #define LC3_CFG_PASS cslot
@@ -1326,18 +1328,26 @@ __device__ __forceinline__ void lc3_decode_body(lc3_cfg_slot<CV> cfg, unsigned w
     typename CV::bind_t c0 = CV::bind(lc3_cfg_table[cfg.id]);
     const int nf = c0.nf;
     lc3_dec_state *gst = states + (size_t)(first_channel + s);
+    // the launch's first loads -- table image, stream state, first frame's column, overlap memory -- are all requested before any is used
+    // (lc3_decode_stream_wave's prologue hook)
 #ifndef LC3_TABLES_IN_GLOBAL
-    lc3_fft_tables_stage_image(c0.stage_image);
+    const lc3_fft_image_regs tab_regs = lc3_fft_tables_image_issue(c0.stage_image);
 #endif
     LC3_PROF_BEGIN(L, lane);
-    if (fresh) lc3_dec_state_init(L, lane, gst, valid);
-    else lc3_dec_state_load(L, lane, gst);
-    LC3_PROF_MARK(L, lane, 38);  // state load
+    lc3_i4 st_regs = {0, 0, 0, 0};
+    if (!fresh) st_regs = lc3_dec_state_issue(lane, gst);
     const size_t fbase = (size_t)s * (size_t)n_frames;
     int stride;
     int16_t *pcm0 = (int16_t *)lc3_io_pcm(io, pcm, nf, first_channel, s, 0, n_frames, &stride);
     lc3_decode_stream_wave(cfg, L, lane, nbytes, planes, fbase, n_frames, gst, valid, pcm0, (size_t)nf * (size_t)stride, stride, LATE, dbg,
-                           dbg_flags);
+                           dbg_flags, [&]() {
+#ifndef LC3_TABLES_IN_GLOBAL
+                               lc3_fft_tables_image_commit(tab_regs);
+#endif
+                               if (fresh) lc3_dec_state_init(L, lane, gst, valid);
+                               else lc3_dec_state_commit(L, lane, st_regs);
+                               LC3_PROF_MARK(L, lane, 38);  // state load
+                           }, fresh);
     LC3_PROF_MARK(L, lane, 39);  // frames (incl. everything between the stage stamps)
     if (valid) lc3_dec_state_store(c0, L, lane, gst);
     LC3_PROF_END(L, lane, 35);
