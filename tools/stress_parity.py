@@ -1,6 +1,6 @@
 """Differential stress run of the GPU engine against the CPU oracle (test infrastructure: the oracle is only the checker).
 
-    python tools/stress_parity.py [--streams 2048] [--frames 16] [--rounds 2] [--shapes 16384x4,2048x18] > gpurun_out/stress_parity.json
+    python tools/stress_parity.py [--streams 2048] [--frames 16] [--rounds 2] [--shapes 16384x4,2048x18] [--split 1,2,3,5] > gpurun_out/stress_parity.json
 
 For every (sampling rate, frame duration, frame size) of the list below and every round: synthetic PCM of mixed character
 (tonal / noisy / clicks from lc3-codec_amd.synth, plus band-limited, very quiet, clipping and silent streams), encoded by the
@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--shapes", default="",
                     help="comma-separated launch shapes STREAMSxFRAMES that the rounds cycle through (round r uses shape r mod n), e.g. "
                          "16384x4,2048x18,4096x16: the 65 536-frame launch the benchmark times among them; default: --streams x --frames")
+    ap.add_argument("--split", default="",
+                    help="comma-separated launch lengths (frames) a round's frames are cut into, cycled, the state carried in the handles from "
+                         "launch to launch, e.g. 1,2,3,5: launches shorter than, as long as and longer than the decoder's filter ring")
     a = ap.parse_args()
     import torch
 
@@ -68,6 +71,19 @@ def main():
     except Exception:
         threads = os.cpu_count() or 8
     shapes = [tuple(int(v) for v in sh.split("x")) for sh in a.shapes.split(",") if sh] or [(a.streams, a.frames)]
+    split = [int(v) for v in a.split.split(",") if v]  # launch lengths a round's frames are cut into (cycled); empty: one launch per round
+
+    def launches(T):
+        if not split:
+            return [(0, T)]
+        out, t, i = [], 0, 0
+        while t < T:
+            n = min(split[i % len(split)], T - t)
+            out.append((t, n))
+            t += n
+            i += 1
+        return out
+
     st = torch.cuda.current_stream().cuda_stream
     rows, bad, timeouts = [], 0, 0
     t0 = time.time()
@@ -86,7 +102,13 @@ def main():
             dec.reset()
             d_pcm = torch.from_numpy(pcm).cuda()
             d_out = torch.zeros((S, T, nbytes), dtype=torch.uint8, device="cuda")
-            enc.encode(d_pcm, d_out, nbytes, T, stream=st)
+            for t_i, n_i in launches(T):  # state carried in the handle from launch to launch
+                if n_i == T:
+                    enc.encode(d_pcm, d_out, nbytes, T, stream=st)
+                else:
+                    part = torch.zeros((S, n_i, nbytes), dtype=torch.uint8, device="cuda")
+                    enc.encode(d_pcm[:, t_i:t_i + n_i].contiguous(), part, nbytes, n_i, stream=st)
+                    d_out[:, t_i:t_i + n_i] = part
             torch.cuda.synchronize()
             got = d_out.cpu().numpy()
             ref = O.encode_batch(pcm, nbytes, fs, us, threads=threads)
@@ -112,7 +134,13 @@ def main():
             d_in = torch.from_numpy(data).cuda()
             d_flags = torch.from_numpy(flags).cuda()
             d_dec = torch.zeros((S, T, nf), dtype=torch.int16, device="cuda")
-            dec.decode(d_in, d_dec, nbytes, T, stream=st, d_bad_frame=d_flags)
+            for t_i, n_i in launches(T):
+                if n_i == T:
+                    dec.decode(d_in, d_dec, nbytes, T, stream=st, d_bad_frame=d_flags)
+                else:
+                    part = torch.zeros((S, n_i, nf), dtype=torch.int16, device="cuda")
+                    dec.decode(d_in[:, t_i:t_i + n_i].contiguous(), part, nbytes, n_i, stream=st, d_bad_frame=d_flags[:, t_i:t_i + n_i].contiguous())
+                    d_dec[:, t_i:t_i + n_i] = part
             torch.cuda.synchronize()
             ref_pcm = O.decode_batch(for_oracle, nf, fs, us, threads=threads)
             dec_bad += int((d_dec.cpu().numpy() != ref_pcm).any(axis=2).sum())
@@ -127,7 +155,8 @@ def main():
         del handles
     total = sum(r["frames"] for r in rows)
     print(json.dumps({"what": "GPU engine vs CPU oracle, byte-exact bitstreams and sample-exact PCM (tools/stress_parity.py)",
-                      "launch_shapes_streams_x_frames": ["%dx%d" % sh for sh in shapes], "rounds": a.rounds, "total_frames_each_direction": total,
+                      "launch_shapes_streams_x_frames": ["%dx%d" % sh for sh in shapes], "launch_lengths_within_a_round": split or "one launch per round",
+                      "rounds": a.rounds, "total_frames_each_direction": total,
                       "frames_differing": bad, "pair_timeouts": timeouts, "corrupt_share": a.corrupt, "frames_damaged": sum(r["decode_frames_damaged"] for r in rows), "host_threads": threads, "seconds": round(time.time() - t0, 1), "env_seq_sums": os.environ.get("LC3GPU_SEQ_SUMS"),
                       "cases": rows}))
     return 1 if (bad or timeouts) else 0
