@@ -73,7 +73,9 @@
 // share) runs the block for all streams of the workgroup at once -- lane q*K+sub works on stream q with `L` rebound
 // to that stream's working set -- and a second barrier releases the others.  Everything such a block reads or writes
 // therefore lives in LDS (or is a launch-uniform value); per-stream register values must be staged through L first.
+#ifndef LC3_WG_WAVES
 #define LC3_WG_WAVES 4
+#endif
 #define LC3_SYNC()                                            \
     do {                                                      \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
