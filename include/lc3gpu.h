@@ -39,6 +39,10 @@ extern "C" {
 #define LC3GPU_EHIP -5          /* HIP runtime error; see lc3gpu_last_hip_error() */
 #define LC3GPU_ENODEVICE -6     /* no usable HIP device */
 #define LC3GPU_EUNSUPPORTED -7  /* configuration the reference cannot run (8 kHz encode: bandwidth_detector.rs:36-37) */
+#define LC3GPU_EPAIR -8         /* a producer / consumer wave pair of an EARLIER batch call of this handle gave up on its partner (see
+                                   lc3gpu_*_pair_timeouts): that call's frames are zero-filled (encoder) or concealed (decoder).  Returned
+                                   once, by the first batch call that notices (read from pinned host memory: no synchronisation); the call
+                                   that returns it has launched nothing and may be repeated */
 
 /* Opt-in corrections of the reference's deviations from the LC3 specification, one bit each, for interop with
  * other LC3 codecs.  Default 0: every deviation is reproduced, and only then do the bit-exactness claims against the
@@ -171,9 +175,60 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *dec, uint64_t *out);
  * its partner gives up (a partner that died: never seen): a parser pair then conceals its frames as the reference conceals a frame whose
  * read_frame failed (decoder/lc3_decoder.rs:138-141; they count as PLC events too), a packer pair leaves its frames ZERO-FILLED -- the
  * reference has no such case (`Lc3EncoderError` is empty, encoder/lc3_encoder.rs:29-30), so it is made visible here: *out = the number of
- * pair halves that ever gave up on this handle (sticky; 0 in every run so far).  Waits for the handle's work in flight. */
+ * pair halves that ever gave up on this handle (sticky; 0 in every run so far).  Waits for the handle's work in flight.
+ * A caller need not poll: the handle's next batch call returns LC3GPU_EPAIR (once) when a pair half of an earlier call gave up. */
 int lc3gpu_encoder_pair_timeouts(lc3gpu_encoder *enc, uint64_t *out);
 int lc3gpu_decoder_pair_timeouts(lc3gpu_decoder *dec, uint64_t *out);
+/* tests only: make the device do what a pair half that gives up does (count + host flag), so that the LC3GPU_EPAIR path can be exercised */
+int lc3gpu_encoder_debug_pair_giveup(lc3gpu_encoder *enc);
+int lc3gpu_decoder_debug_pair_giveup(lc3gpu_decoder *dec);
+
+/* ---- host-resident batches ----------------------------------------------------------------------- */
+/* The reference's callers keep PCM and frame bytes in HOST memory and walk them frame by frame, channel by channel
+ * (examples/encode.rs:73-116: read samples, de-interleave, encode_frame per channel, write; examples/decode.rs:60-112 the mirror).
+ * These two calls take such buffers whole -- planar, as the batch calls: pcm int16[num_channels][n_frames][nf], bytes
+ * uint8[num_channels][n_frames][nbytes], bad_frame (optional) uint8[num_channels][n_frames] -- and return when the results are in host
+ * memory: the handle's channels go through the device in ranges, the copies of one range beside the kernels of another (two internal HIP
+ * streams).  State is carried as by the batch calls.  The PCIe link bounds them (960 + 150 bytes per 48 kHz / 10 ms frame each way);
+ * buffers from lc3gpu_host_alloc (pinned) copy at the link's rate, any other host memory through the runtime's staging copies. */
+int lc3gpu_encode_host(lc3gpu_encoder *enc, const int16_t *pcm, uint8_t *out, int nbytes, int n_frames);
+int lc3gpu_decode_host(lc3gpu_decoder *dec, const uint8_t *in, const uint8_t *bad_frame, int16_t *pcm, int nbytes, int n_frames);
+int lc3gpu_host_alloc(void **out, size_t nbytes);
+int lc3gpu_host_free(void *p);
+
+/* ---- pipeline: the caller loop as an object -------------------------------------------------------- */
+/* The reference's caller owns the loop "for every frame, for every channel: encode_frame" (examples/encode.rs:97-115) and its mirror
+ * (examples/decode.rs:93-112).  On the GPU the arrangement of that loop decides a fifth of the throughput (kernels of different calls share
+ * the chip): a pipeline owns the arrangement that measured best -- the channels in `n_groups` groups (0 = the default,
+ * two), every group with an encoder handle on a HIP stream of the higher priority and a decoder handle on a stream of the default
+ * priority, two submissions in flight per group, the groups never joining -- so that a C / Rust caller gets it from three calls.
+ * Buffers: DEVICE pointers, planar like lc3gpu_encode / lc3gpu_decode (int16[num_channels][n_frames][nf], uint8[num_channels][n_frames][nbytes]).
+ * Every call is asynchronous on the pipeline's own streams:
+ *   lc3gpu_pipeline_submit   one round trip: encode d_pcm -> d_bytes, decode d_bytes -> d_pcm_out (the decoder of a group starts when its
+ *                            encoder has finished, and the encoder of the NEXT submission runs beside it).  A submission's encoder waits
+ *                            for the decoders of the two submissions before it only where it would overwrite bytes they still read:
+ *                            alternate two byte buffers and nothing waits.
+ *   lc3gpu_pipeline_encode / lc3gpu_pipeline_decode   the halves alone (d_bad_frame as for lc3gpu_decode, may be NULL)
+ *   lc3gpu_pipeline_wait     the host waits for everything submitted
+ *   lc3gpu_pipeline_join     `hip_stream` (the caller's) waits for everything submitted -- results may be consumed on that stream
+ *   lc3gpu_pipeline_follow   the NEXT submission waits for what `hip_stream` holds now (e.g. the kernel that produces d_pcm)
+ *   lc3gpu_pipeline_group    the channel range and the handles of a group (borrowed: state blobs, PLC / health counters, timing,
+ *                            stage events; never destroy them, never call their batch functions while the pipeline has work in flight)
+ *   lc3gpu_pipeline_reset    waits, then every channel back to the freshly constructed state
+ * Errors as the batch calls (LC3GPU_EPAIR included). */
+typedef struct lc3gpu_pipeline lc3gpu_pipeline;
+int lc3gpu_pipeline_create(lc3gpu_pipeline **out, int num_channels, int frame_us, int fs_hz, int n_groups);
+int lc3gpu_pipeline_destroy(lc3gpu_pipeline *p);
+int lc3gpu_pipeline_reset(lc3gpu_pipeline *p);
+int lc3gpu_pipeline_submit(lc3gpu_pipeline *p, const int16_t *d_pcm, uint8_t *d_bytes, int16_t *d_pcm_out, int nbytes, int n_frames);
+int lc3gpu_pipeline_encode(lc3gpu_pipeline *p, const int16_t *d_pcm, uint8_t *d_bytes, int nbytes, int n_frames);
+int lc3gpu_pipeline_decode(lc3gpu_pipeline *p, const uint8_t *d_bytes, const uint8_t *d_bad_frame, int16_t *d_pcm_out, int nbytes, int n_frames);
+int lc3gpu_pipeline_wait(lc3gpu_pipeline *p);
+int lc3gpu_pipeline_join(lc3gpu_pipeline *p, void *hip_stream);
+int lc3gpu_pipeline_follow(lc3gpu_pipeline *p, void *hip_stream);
+int lc3gpu_pipeline_groups(const lc3gpu_pipeline *p);
+int lc3gpu_pipeline_group(lc3gpu_pipeline *p, int group, int *first_channel, int *n_channels, lc3gpu_encoder **enc, lc3gpu_decoder **dec);
+int lc3gpu_pipeline_last_hip_error(const lc3gpu_pipeline *p);
 
 /* ---- diagnostics -------------------------------------------------------------------------------- */
 /* encode one frame of channel 0 from host PCM (the frame IS a frame of that channel: its state advances) and also return stage dumps,
@@ -269,9 +324,10 @@ int lc3gpu_prof_read(unsigned long long out[64]);
  * chip runs at while the probe is in flight = 100 MHz x cycles / ticks (launch it on a stream beside the codec's). */
 int lc3gpu_clock_probe(void *stream, unsigned long long *d_out, int spin);
 /* kernel resource report as the loaded code object has it: out = {static lds_bytes, vgprs, 0, scratch_bytes, max_threads} for the six kernels
- * a full batch of the headline configuration launches: which = 0 analysis front half, 1 SNS vector quantiser, 2 analysis back half,
- * 3 packer (pair form), 4 parser (pair form), 5 synthesis.  (tests/test_kernel_resources.py reads the same, and the spill counts, from the
- * built library's metadata without a GPU and holds them to the register budgets the kernels are tuned for.) */
+ * a full batch of the headline configuration launches: which = 0 analysis back half, 1 synthesis (the numbers these two had when they
+ * were the only ones), 2 analysis front half, 3 SNS vector quantiser, 4 packer (pair form), 5 parser (pair form); LC3GPU_EINVAL beyond.
+ * (tests/test_kernel_resources.py reads the same, and the spill counts, from the built library's metadata without a GPU and holds them
+ * to the register budgets the kernels are tuned for.) */
 int lc3gpu_kernel_info(int which, int out[5]);
 
 #ifdef __cplusplus

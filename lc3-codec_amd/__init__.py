@@ -21,6 +21,8 @@ from .api import (  # noqa: F401
     LAYOUT_INTERLEAVED,
     LAYOUT_PLANAR,
     Lc3GpuError,
+    Lc3Pipeline,
+    PinnedBuffer,
     SPEC_8KHZ_ENCODE,
     SPEC_ALL,
     SPEC_BW_CUTOFF_DB,

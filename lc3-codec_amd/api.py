@@ -21,6 +21,8 @@ _PROFILE = os.environ.get("LC3GPU_PROFILE", "0") == "1"
 # LC3_HIPCC_EXTRA="-DLC3_RECON_WAVES=6"); the default is the one build() produces
 _LIB = os.path.join(_HERE, "lib", os.environ.get("LC3GPU_LIB") or ("liblc3gpu_prof.so" if _PROFILE else "liblc3gpu.so"))
 _SRC = os.path.join(_HERE, "csrc", "lc3gpu.hip")
+# host-only sources of the library on top of its own C ABI (the pipeline object): plain C++ beside the HIP translation units
+_HOST_SRCS = [os.path.join(_HERE, "csrc", "lc3gpu_pipeline.cpp")]
 
 class Lc3GpuError(RuntimeError):
     def __init__(self, code, what=""):
@@ -101,7 +103,7 @@ def build_native(force=False, verbose=False):
     LC3_HIPCC_EXTRA_MAIN="-D..." (timing experiments on the headline kernels): the multi-unit build with those flags on the MAIN unit only;
     the other units' objects are the production ones.  A library remembers the switches it was built with (<lib>.stamp) and is rebuilt
     when they differ; experiment builds need their own file name (LC3GPU_LIB) so that they never replace the default library."""
-    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".h", ".hip"))]
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".h", ".hip", ".cpp"))]
     srcs += [os.path.join(_ROOT, "include", "lc3gpu.h"), os.path.join(_ROOT, "tables", "lc3_tables.h")]
     src_hash = _sources_hash(srcs)  # taken BEFORE anything is compiled: what the objects below are guaranteed to be at least as old as
     extra = os.environ.get("LC3_HIPCC_EXTRA", "").split()  # compiler experiments
@@ -126,7 +128,7 @@ def build_native(force=False, verbose=False):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function",
              "-Wno-missing-braces"]
     if single:
-        cmd = ["hipcc"] + extra + (["-DLC3_PROFILE"] if _PROFILE else []) + flags + ["-shared", "-o", _LIB, _SRC]
+        cmd = ["hipcc"] + extra + (["-DLC3_PROFILE"] if _PROFILE else []) + flags + ["-shared", "-o", _LIB, _SRC] + _HOST_SRCS
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -176,7 +178,12 @@ def build_native(force=False, verbose=False):
             " ".join(flags), _SRC, len(todo), len(units), jobs))
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         list(pool.map(compile_unit, todo))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", _LIB] + sorted(unit_obj(u) for u in units)
+    host_objs = []
+    for src in _HOST_SRCS:  # (seconds each: always recompiled)
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        subprocess.check_call(["hipcc", "-O2", "-std=c++17", "-fPIC", "-c", "-o", obj, src])
+        host_objs.append(obj)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", _LIB] + sorted(unit_obj(u) for u in units) + host_objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -271,6 +278,24 @@ def load_library():
     L.lc3gpu_clock_probe.argtypes = [vp, vp, i]
     L.lc3gpu_encoder_stage_event.argtypes = [vp, i, vp]
     L.lc3gpu_decoder_stage_event.argtypes = [vp, i, vp]
+    L.lc3gpu_encoder_debug_pair_giveup.argtypes = [vp]
+    L.lc3gpu_decoder_debug_pair_giveup.argtypes = [vp]
+    L.lc3gpu_encode_host.argtypes = [vp, vp, vp, i, i]
+    L.lc3gpu_decode_host.argtypes = [vp, vp, vp, vp, i, i]
+    L.lc3gpu_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
+    L.lc3gpu_host_free.argtypes = [vp]
+    L.lc3gpu_pipeline_create.argtypes = [ctypes.POINTER(vp), i, i, i, i]
+    L.lc3gpu_pipeline_destroy.argtypes = [vp]
+    L.lc3gpu_pipeline_reset.argtypes = [vp]
+    L.lc3gpu_pipeline_submit.argtypes = [vp, vp, vp, vp, i, i]
+    L.lc3gpu_pipeline_encode.argtypes = [vp, vp, vp, i, i]
+    L.lc3gpu_pipeline_decode.argtypes = [vp, vp, vp, vp, i, i]
+    L.lc3gpu_pipeline_wait.argtypes = [vp]
+    L.lc3gpu_pipeline_join.argtypes = [vp, vp]
+    L.lc3gpu_pipeline_follow.argtypes = [vp, vp]
+    L.lc3gpu_pipeline_groups.argtypes = [vp]
+    L.lc3gpu_pipeline_group.argtypes = [vp, i, ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.lc3gpu_pipeline_last_hip_error.argtypes = [vp]
     _lib = L
     return L
 
@@ -287,6 +312,10 @@ ABI_SYMBOLS = [
     "lc3gpu_decoder_timing_kernels", "lc3gpu_decode_frame_debug", "lc3gpu_decoder_synth_debug", "lc3gpu_selftest_math", "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
     "lc3gpu_decode_mixed", "lc3gpu_encoder_create_spec", "lc3gpu_encoder_create_mixed_spec", "lc3gpu_clock_probe",
     "lc3gpu_encoder_stage_event", "lc3gpu_decoder_stage_event", "lc3gpu_encoder_pair_timeouts", "lc3gpu_decoder_pair_timeouts",
+    "lc3gpu_encoder_debug_pair_giveup", "lc3gpu_decoder_debug_pair_giveup", "lc3gpu_encode_host", "lc3gpu_decode_host", "lc3gpu_host_alloc",
+    "lc3gpu_host_free", "lc3gpu_pipeline_create", "lc3gpu_pipeline_destroy", "lc3gpu_pipeline_reset", "lc3gpu_pipeline_submit",
+    "lc3gpu_pipeline_encode", "lc3gpu_pipeline_decode", "lc3gpu_pipeline_wait", "lc3gpu_pipeline_join", "lc3gpu_pipeline_follow",
+    "lc3gpu_pipeline_groups", "lc3gpu_pipeline_group", "lc3gpu_pipeline_last_hip_error",
 ]
 
 # LC3GPU_SPEC_*: opt-in corrections of the reference's deviations from the LC3 specification (default 0 = reference behaviour)
@@ -492,6 +521,18 @@ class Lc3Encoder:
         if rc:
             raise Lc3EncoderError(rc, "reset")
 
+    def encode_host(self, pcm, out, nbytes, n_frames):
+        """HOST int16[S][T][nf] -> HOST uint8[S][T][nbytes] (numpy arrays or raw addresses, e.g. of PinnedBuffer); synchronous (lc3gpu_encode_host)"""
+        rc = self._L.lc3gpu_encode_host(self._h, _ptr(pcm), _ptr(out), int(nbytes), int(n_frames))
+        if rc:
+            raise Lc3EncoderError(rc, "encode_host")
+
+    def debug_pair_giveup(self):
+        """tests only: the device does what a pair half that gives up does (count + host flag)"""
+        rc = self._L.lc3gpu_encoder_debug_pair_giveup(self._h)
+        if rc:
+            raise Lc3EncoderError(rc, "debug_pair_giveup")
+
     def pair_timeouts(self):
         """producer / consumer pair halves of the packer that ever gave up on their partner (include/lc3gpu.h); 0 unless a wave died"""
         v = ctypes.c_uint64()
@@ -516,9 +557,21 @@ class Lc3Encoder:
         if rc:
             raise Lc3EncoderError(rc, "state_load")
 
+    @classmethod
+    def _borrowed(cls, handle, num_channels, frame_duration, sampling_frequency):
+        """a handle somebody else owns (a pipeline's): every method works, close() does not destroy it"""
+        self = cls.__new__(cls)
+        self._L = load_library()
+        self.config = Lc3Config(sampling_frequency, frame_duration)
+        self.num_channels = int(num_channels)
+        self._h = ctypes.c_void_p(handle)
+        self._borrowed_handle = True
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self._L.lc3gpu_encoder_destroy(self._h)
+            if not getattr(self, "_borrowed_handle", False):
+                self._L.lc3gpu_encoder_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -654,6 +707,17 @@ class Lc3Decoder:
             raise Lc3DecoderError(rc, "plc_events")
         return int(v.value)
 
+    def decode_host(self, data, pcm, nbytes, n_frames, bad_frame=None):
+        """HOST uint8[S][T][nbytes] -> HOST int16[S][T][nf]; synchronous (lc3gpu_decode_host)"""
+        rc = self._L.lc3gpu_decode_host(self._h, _ptr(data), _ptr(bad_frame), _ptr(pcm), int(nbytes), int(n_frames))
+        if rc:
+            raise Lc3DecoderError(rc, "decode_host")
+
+    def debug_pair_giveup(self):
+        rc = self._L.lc3gpu_decoder_debug_pair_giveup(self._h)
+        if rc:
+            raise Lc3DecoderError(rc, "debug_pair_giveup")
+
     def pair_timeouts(self):
         """producer / consumer pair halves of the parser that ever gave up on their partner (include/lc3gpu.h); 0 unless a wave died"""
         v = ctypes.c_uint64()
@@ -678,9 +742,102 @@ class Lc3Decoder:
         if rc:
             raise Lc3DecoderError(rc, "state_load")
 
+    _borrowed = Lc3Encoder.__dict__["_borrowed"]
+
     def close(self):
         if getattr(self, "_h", None):
-            self._L.lc3gpu_decoder_destroy(self._h)
+            if not getattr(self, "_borrowed_handle", False):
+                self._L.lc3gpu_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PinnedBuffer:
+    """page-locked host memory from lc3gpu_host_alloc as a numpy array (`.array`): what lc3gpu_encode_host / lc3gpu_decode_host copy at the
+    PCIe link's rate"""
+
+    def __init__(self, shape, dtype):
+        self._L = load_library()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        rc = self._L.lc3gpu_host_alloc(ctypes.byref(p), max(1, n))
+        if rc:
+            raise Lc3GpuError(rc, "host_alloc")
+        self._p = p
+        self.array = np.frombuffer((ctypes.c_uint8 * max(1, n)).from_address(p.value), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._L.lc3gpu_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Lc3Pipeline:
+    """lc3gpu_pipeline: the caller loop (examples/encode.rs:97-115, examples/decode.rs:93-112) in the arrangement that measured best --
+    groups of the channels, each with an encoder handle and a decoder handle of its own on HIP streams of its own"""
+
+    def __init__(self, num_channels, frame_duration, sampling_frequency, n_groups=0):
+        self._L = load_library()
+        self.config = Lc3Config(sampling_frequency, frame_duration)
+        self.num_channels = int(num_channels)
+        h = ctypes.c_void_p()
+        rc = self._L.lc3gpu_pipeline_create(ctypes.byref(h), self.num_channels, int(frame_duration), int(sampling_frequency), int(n_groups))
+        if rc:
+            raise Lc3GpuError(rc, "Lc3Pipeline")
+        self._h = h
+        self.groups = []
+        for g in range(self._L.lc3gpu_pipeline_groups(h)):
+            first, n, e, d = ctypes.c_int(), ctypes.c_int(), ctypes.c_void_p(), ctypes.c_void_p()
+            rc = self._L.lc3gpu_pipeline_group(h, g, ctypes.byref(first), ctypes.byref(n), ctypes.byref(e), ctypes.byref(d))
+            if rc:
+                raise Lc3GpuError(rc, "pipeline_group")
+            self.groups.append({"first": first.value, "n": n.value,
+                                "enc": Lc3Encoder._borrowed(e.value, n.value, frame_duration, sampling_frequency),
+                                "dec": Lc3Decoder._borrowed(d.value, n.value, frame_duration, sampling_frequency)})
+
+    def _check(self, rc, what):
+        if rc:
+            raise Lc3GpuError(rc, what)
+
+    def submit(self, d_pcm, d_bytes, d_pcm_out, nbytes, n_frames):
+        self._check(self._L.lc3gpu_pipeline_submit(self._h, _ptr(d_pcm), _ptr(d_bytes), _ptr(d_pcm_out), int(nbytes), int(n_frames)), "pipeline_submit")
+
+    def encode(self, d_pcm, d_bytes, nbytes, n_frames):
+        self._check(self._L.lc3gpu_pipeline_encode(self._h, _ptr(d_pcm), _ptr(d_bytes), int(nbytes), int(n_frames)), "pipeline_encode")
+
+    def decode(self, d_bytes, d_pcm_out, nbytes, n_frames, d_bad_frame=None):
+        self._check(self._L.lc3gpu_pipeline_decode(self._h, _ptr(d_bytes), _ptr(d_bad_frame), _ptr(d_pcm_out), int(nbytes), int(n_frames)), "pipeline_decode")
+
+    def wait(self):
+        self._check(self._L.lc3gpu_pipeline_wait(self._h), "pipeline_wait")
+
+    def join(self, stream=None):
+        self._check(self._L.lc3gpu_pipeline_join(self._h, _ptr(stream)), "pipeline_join")
+
+    def follow(self, stream=None):
+        self._check(self._L.lc3gpu_pipeline_follow(self._h, _ptr(stream)), "pipeline_follow")
+
+    def reset(self):
+        self._check(self._L.lc3gpu_pipeline_reset(self._h), "pipeline_reset")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for g in self.groups:
+                g["enc"].close()
+                g["dec"].close()
+            self._L.lc3gpu_pipeline_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -295,23 +295,27 @@ __device__ __forceinline__ void lc3_fft_tables_stage_image(const void *image) {
     __syncthreads();
 }
 // ... in two steps, so that a kernel can have the image, its stream state and its first frame on their way from HBM at the same time (a
-// launch is only four frames long: three or four trips in a row at its start were ~15 % of the synthesis kernel's time).  Workgroups of
-// 256 threads: 270 units = two per thread at most.
+// launch is only four frames long: three or four trips in a row at its start were ~15 % of the synthesis kernel's time).  Two units per
+// thread: enough for the 270 units with 64 * LC3_WG_WAVES >= 135 threads (three waves; the production workgroup has four).
+#ifndef LC3_WG_WAVES
+#define LC3_WG_WAVES 4
+#endif
+#define LC3_WG_THREADS (64 * LC3_WG_WAVES)
 struct lc3_fft_image_regs { lc3_i4 a, b; };
 __device__ __forceinline__ lc3_fft_image_regs lc3_fft_tables_image_issue(const void *image) {
     LC3_HBM_CONST(lc3_i4) src = (LC3_HBM_CONST(lc3_i4))image;
     const int n = (int)(sizeof(lc3_fft_tables) / 16), i = (int)threadIdx.x;
-    static_assert(sizeof(lc3_fft_tables) / 16 <= 2 * 64 * 4, "two units per thread of a four-wave workgroup");
+    static_assert(sizeof(lc3_fft_tables) / 16 <= 2 * LC3_WG_THREADS, "two units per thread of the workgroup");
     lc3_fft_image_regs r;
     r.a = src[i < n ? i : 0];
-    r.b = src[i + 256 < n ? i + 256 : 0];
+    r.b = src[i + LC3_WG_THREADS < n ? i + LC3_WG_THREADS : 0];
     return r;
 }
 __device__ __forceinline__ void lc3_fft_tables_image_commit(const lc3_fft_image_regs &r) {  // ends with a workgroup barrier
     lc3_i4 *dst = (lc3_i4 *)&lc3_fft_tab;
     const int n = (int)(sizeof(lc3_fft_tables) / 16), i = (int)threadIdx.x;
     if (i < n) dst[i] = r.a;
-    if (i + 256 < n) dst[i + 256] = r.b;
+    if (i + LC3_WG_THREADS < n) dst[i + LC3_WG_THREADS] = r.b;
     __syncthreads();
 }
 // Tables only the analysis front half reads, per workgroup: the band width of every spectral line (divisor of the band

@@ -632,10 +632,11 @@ __device__ __forceinline__ void lc3_enc_front_body(lc3_cfg_slot<CV> cfg, unsigne
         const int16_t *frame = lc3_io_pcm(io, pcm, nf, first_channel, s, t, n_frames, &stride);
         // MDCT history: the tail of the previous frame of this launch, else the state blob's copy (silence when fresh)
         const int16_t *hist = t > 0 ? frame - (size_t)(nf - z) * (size_t)stride : (fresh ? nullptr : gst->hist);
-        // (phase: the frame's number -- the waves of the workgroup take turns at the gathered blocks -- and, bit 8, "not one of the launch's
-        // last two frames": lc3_enc_ltpf skips work whose only use is the state blob's memory of the last two frames)
+        // (phase: the frame's number modulo the workgroup's waves -- they take turns at the gathered blocks -- and, bit 8, "not one of the
+        // launch's last two frames": lc3_enc_ltpf skips work whose only use is the state blob's memory of the last two frames.  The number is
+        // reduced HERE: a launch may have any number of frames, and frame 256's own bit 8 must not read as the flag)
         lc3_encode_front_wave(cfg, L, lane, frame, hist, gst, mcol, plane, LC3_PLANE_STRIDE, nbytes, valid ? dbg : nullptr, stride,
-                              t > 0 ? stride : 1, t + (t + 2 < n_frames ? 0x100 : 0), OUTLINE_LTPF);
+                              t > 0 ? stride : 1, (t % LC3_WG_WAVES) + (t + 2 < n_frames ? 0x100 : 0), OUTLINE_LTPF);
     }
     if (valid) {
         int stride = 1;
@@ -880,6 +881,17 @@ static __host__ __device__ inline size_t lc3_pack_pc_lds(unsigned fpb, int nbyte
     const size_t base = (LC3_PACK_LDS_FIXED + (size_t)fpb * (size_t)nbytes + 4 + 15) & ~(size_t)15;  // ... + the packer's sink byte
     return base + (size_t)(fpb / 64) * (LC3_PKPC_RING * 64 * 4 + 64 * 4) + 64;
 }
+// A pair half gave up on its partner: count it in the handle's sticky device word (pc[0]; lc3gpu_*_pair_timeouts) and raise the handle's
+// flag in pinned HOST memory (its address sits in pc[2..3]), which the next batch call of the handle reads without any synchronisation
+// and reports as LC3GPU_EPAIR -- a caller that never polls the counter must not ship zero-filled frames as LC3 payload unnoticed.
+__device__ __forceinline__ void lc3_pc_gave_up(unsigned *pc) {
+    atomicAdd(pc, 1u);
+    volatile unsigned *flag = (volatile unsigned *)(((unsigned long long)pc[3] << 32) | (unsigned long long)pc[2]);
+    if (flag) {
+        *flag = 1u;
+        __threadfence_system();
+    }
+}
 // pc_timeouts: the handle's sticky count of pair halves that gave up on their partner (lc3gpu_encoder_pair_timeouts)
 __device__ __forceinline__ void lc3_pack_pc_body(unsigned wg, int ne, const int32_t *planes, uint8_t *out, int nbytes, int n_frames, int T,
                                                  int first_channel, lc3_io io, unsigned *pc_timeouts) {
@@ -938,7 +950,7 @@ __device__ __forceinline__ void lc3_pack_pc_body(unsigned wg, int ne, const int3
         k.c_count = s_cnt + 2 * pair + 1;
         k.fin = s_fin + pair * 64 + lane;
         const int gave_up = role == 0 ? lc3_pack_produce(c, k, ne, valid) : lc3_pack_consume(c, k, ne, valid);
-        if (gave_up && lane == 0) atomicAdd(pc_timeouts, 1u);  // (per wave: the link's counts are the wave's)
+        if (gave_up && lane == 0) lc3_pc_gave_up(pc_timeouts);  // (per wave: the link's counts are the wave's)
     }
     __syncthreads();
     if (io.ilv || io.tab) {  // frame f = s * T + t has its own place: one frame after the other, its bytes spread over the threads
@@ -1206,7 +1218,7 @@ __device__ __forceinline__ void lc3_parse_pc_body(lc3_cfg_slot<CV> cfg, unsigned
         rc_in = (bad && bad[fb]) ? -100 : 0;
     }
     if (role == 0) {  // pc_timeouts: the handle's sticky count of pair halves that gave up on their partner (lc3gpu_decoder_pair_timeouts)
-        if (lc3_pc_produce(c, k, ne, fs_ind, n_ms_10, rc_in) && lane == 0) atomicAdd(pc_timeouts, 1u);
+        if (lc3_pc_produce(c, k, ne, fs_ind, n_ms_10, rc_in) && lane == 0) lc3_pc_gave_up(pc_timeouts);
         return;
     }
     lc3_recon_ctx r;
@@ -1217,7 +1229,7 @@ __device__ __forceinline__ void lc3_parse_pc_body(lc3_cfg_slot<CV> cfg, unsigned
     float scf[16];
     int gave_up = 0;
     int ok = lc3_pc_consume<1>(c, k, ne, fs_ind, rc_in, &r, scf, &gave_up) == 0;
-    if (gave_up && lane == 0) atomicAdd(pc_timeouts, 1u);  // (per wave: the link's counts are the wave's; its frames are concealed)
+    if (gave_up && lane == 0) lc3_pc_gave_up(pc_timeouts);  // (per wave: the link's counts are the wave's; its frames are concealed)
     if (ok) ok = lc3_reconstruct_frame(c, r, c0, scf);
     if (valid) lc3_px_set(c, AD_OK, ok);
 }
@@ -1835,7 +1847,17 @@ struct HandleCommon {
     std::vector<MixedStream> streams;      // caller order
     std::vector<int> caller_of_internal;   // internal index -> caller index
     lc3_stream_io *d_tab = nullptr;        // per internal stream
-    unsigned *d_pc_timeouts = nullptr;     // one word: producer / consumer pair halves that gave up on their partner (sticky; *_pair_timeouts)
+    unsigned *d_pc_timeouts = nullptr;     // [0] producer / consumer pair halves that gave up on their partner (sticky; *_pair_timeouts), [2..3] address of h_pc_flag
+    volatile unsigned *h_pc_flag = nullptr;  // one word of pinned host memory a kernel sets when a pair half gives up (lc3_pc_gave_up)
+    int pc_health_alloc() {
+        HIP_TRY(hipHostMalloc((void **)&h_pc_flag, sizeof(unsigned), hipHostMallocDefault));
+        *h_pc_flag = 0;
+        HIP_TRY(hipMalloc((void **)&d_pc_timeouts, 4 * sizeof(unsigned)));
+        const unsigned long long a = (unsigned long long)(uintptr_t)h_pc_flag;
+        const unsigned init[4] = {0u, 0u, (unsigned)(a & 0xFFFFFFFFull), (unsigned)(a >> 32)};
+        HIP_TRY(hipMemcpy(d_pc_timeouts, init, sizeof init, hipMemcpyHostToDevice));
+        return LC3GPU_OK;
+    }
     bool pc_optin_done = false;            // the pair kernels' dynamic-LDS opt-in has been made for this handle's device (no lock per call)
     hipStream_t last_stream = nullptr;
     hipEvent_t done = nullptr;
@@ -1846,6 +1868,28 @@ struct HandleCommon {
     hipStream_t sub[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_stage = nullptr, ev_join[2] = {nullptr, nullptr};
     bool last_split = false;  // the handle's latest work ended on the internal streams (ev_join), not on last_stream (done)
+    // The host-resident batch path (lc3gpu_encode_host / lc3gpu_decode_host): device staging buffers for two channel ranges in flight, one per
+    // internal stream; while such a call runs the in-call split (which owns the same two streams) is off
+    void *d_stage_in[2] = {nullptr, nullptr}, *d_stage_out[2] = {nullptr, nullptr}, *d_stage_flag[2] = {nullptr, nullptr};
+    size_t stage_in_bytes = 0, stage_out_bytes = 0, stage_flag_bytes = 0;
+    bool in_host_call = false;
+    int stage_reserve(size_t in_bytes, size_t out_bytes, size_t flag_bytes) {
+        auto grow = [](void **buf, size_t &have, size_t want) -> int {
+            if (want <= have) return LC3GPU_OK;
+            for (int i = 0; i < 2; i++) {
+                if (buf[i]) (void)hipFree(buf[i]);
+                buf[i] = nullptr;
+            }
+            have = 0;
+            for (int i = 0; i < 2; i++) HIP_TRY(hipMalloc(&buf[i], want));
+            have = want;
+            return LC3GPU_OK;
+        };
+        int rc = grow(d_stage_in, stage_in_bytes, in_bytes);
+        if (rc == LC3GPU_OK) rc = grow(d_stage_out, stage_out_bytes, out_bytes);
+        if (rc == LC3GPU_OK) rc = grow(d_stage_flag, stage_flag_bytes, flag_bytes);
+        return rc;
+    }
     // Stage events (lc3gpu_*_stage_event): events of the CALLER, recorded behind a stage's kernel(s) of every batch call, so that a caller
     // with several handles on several HIP streams can start another handle's work beside a chosen part of this one's
     hipEvent_t stage_ev[LC3GPU_MAX_STAGES] = {};
@@ -1871,6 +1915,12 @@ struct HandleCommon {
     // queued (`done` on the caller's stream, or the two join events of the split path): the caller's stream of an earlier call is never
     // touched again, it may have been destroyed or its address reused since.
     int order_begin(hipStream_t s) {
+        // a pair half of an EARLIER call gave up (its frames left zero-filled / concealed): said once, by the first call that sees it;
+        // that call launches nothing and may be repeated; the count stays in lc3gpu_*_pair_timeouts
+        if (h_pc_flag && *h_pc_flag) {
+            *h_pc_flag = 0;
+            return LC3GPU_EPAIR;
+        }
         if (has_work && s != last_stream) {
             if (last_split) {
                 HIP_TRY(hipStreamWaitEvent(s, ev_join[0], 0));
@@ -1930,6 +1980,15 @@ struct HandleCommon {
         if (d_tab) (void)hipFree(d_tab);
         if (d_pc_timeouts) (void)hipFree(d_pc_timeouts);
         d_pc_timeouts = nullptr;
+        if (h_pc_flag) (void)hipHostFree((void *)h_pc_flag);
+        h_pc_flag = nullptr;
+        for (int i = 0; i < 2; i++) {
+            for (void **b : {&d_stage_in[i], &d_stage_out[i], &d_stage_flag[i]}) {
+                if (*b) (void)hipFree(*b);
+                *b = nullptr;
+            }
+        }
+        stage_in_bytes = stage_out_bytes = stage_flag_bytes = 0;
         for (hipEvent_t ev : {ev_fork, ev_stage, ev_join[0], ev_join[1]})
             if (ev) (void)hipEventDestroy(ev);
         for (hipStream_t st : sub)
@@ -2328,6 +2387,7 @@ const char *lc3gpu_strerror(int code) {
     case LC3GPU_EHIP: return "HIP runtime error";
     case LC3GPU_ENODEVICE: return "no HIP device";
     case LC3GPU_EUNSUPPORTED: return "configuration not supported by the reference";
+    case LC3GPU_EPAIR: return "a producer / consumer pair of an earlier call gave up: frames of that call are zero-filled (encoder) or concealed (decoder)";
     default: return "unknown error";
     }
 }
@@ -2382,8 +2442,7 @@ int lc3gpu_decoder_working_buffer_lengths(int num_channels, int frame_us, int fs
 static int encoder_alloc(lc3gpu_encoder *e) {
     HIP_TRY(hipGetDevice(&e->device));
     HIP_TRY(hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
-    HIP_TRY(hipMalloc((void **)&e->d_pc_timeouts, sizeof(unsigned)));
-    HIP_TRY(hipMemset(e->d_pc_timeouts, 0, sizeof(unsigned)));
+    { const int rc = e->pc_health_alloc(); if (rc) return rc; }
     HIP_TRY(hipMalloc((void **)&e->d_states, sizeof(lc3_enc_state) * (size_t)e->num_channels));
     // staging of the *_frame calls: pinned host memory the kernels read / write in place (no copy engine round trips)
     HIP_TRY(hipHostMalloc((void **)&e->d_pcm1, sizeof(int16_t) * LC3_MAX_NF, hipHostMallocDefault));
@@ -2581,7 +2640,7 @@ static int encode_launch(lc3gpu_encoder *e, const HostCfg &h, int first, int n, 
     if (layout == LC3GPU_LAYOUT_PLANAR ? ((uintptr_t)d_pcm & 3u) != 0 : ((uintptr_t)d_pcm & 1u) != 0) return LC3GPU_EINVAL;
     const size_t frames = (size_t)n * (size_t)n_frames;
     const int nf = h.c.nf;
-    int parts = dbg ? 1 : lc3_split_parts(frames, n);
+    int parts = (dbg || e->in_host_call) ? 1 : lc3_split_parts(frames, n);
     const int na = parts == 2 ? lc3_split_point(n, n_frames) : n;
     // planar PCM is read as 32-bit words: the second half starts na * n_frames * nf samples in (nf is even), its bytes are copied out as
     // words when aligned and as bytes otherwise
@@ -2791,6 +2850,9 @@ int lc3gpu_encoder_state_load(lc3gpu_encoder *e, const void *host_src, size_t nb
 static int decoder_init_states(lc3gpu_decoder *d) {
     // decoder state is materialised eagerly (fresh = 1, zero frames): PLC counters must survive range launches
     HIP_TRY(hipDeviceSynchronize());  // nothing of this handle may still be in flight (its state is about to be rewritten)
+    // the fresh launch below stores only the part of the post-filter's output ring a launch writes (lc3_dec_state_store): the rest of a
+    // blob must not be whatever hipMalloc handed out (state_save would copy stale device memory to the host, and blobs would differ from run to run)
+    HIP_TRY(hipMemset(d->d_states, 0, sizeof(lc3_dec_state) * (size_t)d->num_channels));
     lc3_io io = {0, nullptr};
     if (!d->mixed) {
         LC3_LAUNCH_CFG(lc3_decode_kernel, d->h, dim3((unsigned)((d->num_channels + LC3_WG_WAVES - 1) / LC3_WG_WAVES)),
@@ -2812,8 +2874,7 @@ static int decoder_init_states(lc3gpu_decoder *d) {
 static int decoder_alloc(lc3gpu_decoder *d) {
     HIP_TRY(hipGetDevice(&d->device));
     HIP_TRY(hipEventCreateWithFlags(&d->done, hipEventDisableTiming));
-    HIP_TRY(hipMalloc((void **)&d->d_pc_timeouts, sizeof(unsigned)));
-    HIP_TRY(hipMemset(d->d_pc_timeouts, 0, sizeof(unsigned)));
+    { const int rc = d->pc_health_alloc(); if (rc) return rc; }
     HIP_TRY(hipMalloc((void **)&d->d_states, sizeof(lc3_dec_state) * (size_t)d->num_channels));
     HIP_TRY(hipHostMalloc((void **)&d->d_in1, LC3_MAX_NE, hipHostMallocDefault));  // *_frame staging: pinned host memory, used in place
     HIP_TRY(hipHostMalloc((void **)&d->d_pcm1, sizeof(int16_t) * LC3_MAX_NF, hipHostMallocDefault));
@@ -2933,7 +2994,7 @@ static int decode_launch(lc3gpu_decoder *d, const HostCfg &h, int first, int n, 
     if (layout == LC3GPU_LAYOUT_PLANAR ? ((uintptr_t)d_pcm & 3u) != 0 : ((uintptr_t)d_pcm & 1u) != 0) return LC3GPU_EINVAL;
     const size_t frames = (size_t)n * (size_t)n_frames;
     const int nf = h.c.nf;
-    int parts = lc3_split_parts(frames, n);
+    int parts = d->in_host_call ? 1 : lc3_split_parts(frames, n);
     const int na = parts == 2 ? lc3_split_point(n, n_frames) : n;
     if (parts == 2 && (na <= 0 || na >= n)) parts = 1;
     int rc = d->order_begin(stream);
@@ -3202,6 +3263,107 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
     return LC3GPU_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Host-resident batches.  The reference's caller holds PCM and frame bytes in host memory and walks them frame by frame
+// (examples/encode.rs:73-116, examples/decode.rs:60-112); lc3gpu_encode_host / lc3gpu_decode_host take such buffers whole: the handle's
+// channels in ranges, range c on internal HIP stream c & 1 as  copy in -> the range's kernels -> copy out,  so that the copies of one range
+// run beside the kernels of another (the kernels of the ranges themselves run one after the other: they share the handle's planes).
+// Synchronous, like the loop they replace.  PCIe bounds them (a 48 kHz / 10 ms frame is 960 + 150 bytes each way); pinned buffers
+// (lc3gpu_host_alloc) copy at the link's rate, pageable ones through the runtime's staging.
+static int host_chunk_channels(int num_channels, int n_frames) {
+    // ranges of whole waves of the lane-per-frame kernels and at least 16 384 frames (where the pair kernels begin), at most eight ranges
+    long long c = (16384 + n_frames - 1) / n_frames;
+    const long long min_c = ((long long)num_channels + 7) / 8;
+    if (c < min_c) c = min_c;
+    c = (c + 63) / 64 * 64;
+    return c >= num_channels ? num_channels : (int)c;
+}
+int lc3gpu_host_alloc(void **out, size_t nbytes) {
+    if (!out || nbytes == 0) return LC3GPU_EINVAL;
+    *out = nullptr;
+    if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
+    HIP_TRY(hipHostMalloc(out, nbytes, hipHostMallocDefault));
+    return LC3GPU_OK;
+}
+int lc3gpu_host_free(void *p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return LC3GPU_OK;
+}
+int lc3gpu_encode_host(lc3gpu_encoder *e, const int16_t *pcm, uint8_t *out, int nbytes, int n_frames) {
+    if (!e || e->mixed || !pcm || !out) return LC3GPU_EINVAL;
+    if (nbytes < 20 || nbytes > LC3_MAX_NE || n_frames <= 0) return LC3GPU_ELENGTH;
+    LC3_ON_DEVICE(e);
+    int rc = e->quiesce();
+    if (rc == LC3GPU_OK) rc = e->ensure_split();
+    if (rc) return rc;
+    const int nf = e->h.c.nf, C = e->num_channels, cc = host_chunk_channels(C, n_frames);
+    const size_t in_row = (size_t)n_frames * (size_t)nf * sizeof(int16_t), out_row = (size_t)n_frames * (size_t)nbytes;
+    rc = e->stage_reserve((size_t)cc * in_row, (size_t)cc * out_row, 0);
+    if (rc) return rc;
+    e->in_host_call = true;
+    int k = 0;
+    for (int first = 0; first < C && rc == LC3GPU_OK; first += cc, k++) {
+        const int n = first + cc <= C ? cc : C - first, b = k & 1;
+        hipStream_t st = e->sub[b];
+        if (hipMemcpyAsync(e->d_stage_in[b], (const char *)pcm + (size_t)first * in_row, (size_t)n * in_row, hipMemcpyHostToDevice, st) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError();
+            rc = LC3GPU_EHIP;
+            break;
+        }
+        rc = encode_launch(e, e->h, first, n, (const int16_t *)e->d_stage_in[b], (uint8_t *)e->d_stage_out[b], nbytes, n_frames, LC3GPU_LAYOUT_PLANAR, st,
+                           nullptr);
+        if (rc == LC3GPU_OK && hipMemcpyAsync(out + (size_t)first * out_row, e->d_stage_out[b], (size_t)n * out_row, hipMemcpyDeviceToHost, st) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError();
+            rc = LC3GPU_EHIP;
+        }
+    }
+    e->in_host_call = false;
+    for (int i = 0; i < 2; i++)
+        if (hipStreamSynchronize(e->sub[i]) != hipSuccess && rc == LC3GPU_OK) {
+            g_last_hip = (int)hipGetLastError();
+            rc = LC3GPU_EHIP;
+        }
+    return rc;
+}
+int lc3gpu_decode_host(lc3gpu_decoder *d, const uint8_t *in, const uint8_t *bad_frame, int16_t *pcm, int nbytes, int n_frames) {
+    if (!d || d->mixed || !in || !pcm) return LC3GPU_EINVAL;
+    if (nbytes < 1 || nbytes > LC3_MAX_NE || n_frames <= 0) return LC3GPU_ELENGTH;
+    LC3_ON_DEVICE(d);
+    int rc = d->quiesce();
+    if (rc == LC3GPU_OK) rc = d->ensure_split();
+    if (rc) return rc;
+    const int nf = d->h.c.nf, C = d->num_channels, cc = host_chunk_channels(C, n_frames);
+    const size_t in_row = (size_t)n_frames * (size_t)nbytes, out_row = (size_t)n_frames * (size_t)nf * sizeof(int16_t);
+    rc = d->stage_reserve((size_t)cc * in_row, (size_t)cc * out_row, bad_frame ? (size_t)cc * (size_t)n_frames : 0);
+    if (rc) return rc;
+    d->in_host_call = true;
+    int k = 0;
+    for (int first = 0; first < C && rc == LC3GPU_OK; first += cc, k++) {
+        const int n = first + cc <= C ? cc : C - first, b = k & 1;
+        hipStream_t st = d->sub[b];
+        if (hipMemcpyAsync(d->d_stage_in[b], in + (size_t)first * in_row, (size_t)n * in_row, hipMemcpyHostToDevice, st) != hipSuccess ||
+            (bad_frame && hipMemcpyAsync(d->d_stage_flag[b], bad_frame + (size_t)first * (size_t)n_frames, (size_t)n * (size_t)n_frames, hipMemcpyHostToDevice,
+                                         st) != hipSuccess)) {
+            g_last_hip = (int)hipGetLastError();
+            rc = LC3GPU_EHIP;
+            break;
+        }
+        rc = decode_launch(d, d->h, first, n, (const uint8_t *)d->d_stage_in[b], bad_frame ? (const uint8_t *)d->d_stage_flag[b] : nullptr,
+                           (int16_t *)d->d_stage_out[b], nbytes, n_frames, LC3GPU_LAYOUT_PLANAR, st);
+        if (rc == LC3GPU_OK && hipMemcpyAsync((char *)pcm + (size_t)first * out_row, d->d_stage_out[b], (size_t)n * out_row, hipMemcpyDeviceToHost, st) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError();
+            rc = LC3GPU_EHIP;
+        }
+    }
+    d->in_host_call = false;
+    for (int i = 0; i < 2; i++)
+        if (hipStreamSynchronize(d->sub[i]) != hipSuccess && rc == LC3GPU_OK) {
+            g_last_hip = (int)hipGetLastError();
+            rc = LC3GPU_EHIP;
+        }
+    return rc;
+}
+
 // Producer / consumer pair kernels (full batches): how many pair halves ever gave up waiting for their partner (LC3_PC_SPIN_LIMIT
 // polls -- a partner that died; never seen).  Sticky over the handle's life.  A parser pair that gives up conceals its frames (they
 // also count as PLC events); a packer pair that gives up leaves its frames zero-filled.  Waits for the handle's work in flight.
@@ -3212,6 +3374,27 @@ static int pair_timeouts_read(HandleCommon &hc, uint64_t *out) {
     HIP_TRY(hipMemcpy(&v, hc.d_pc_timeouts, sizeof v, hipMemcpyDeviceToHost));
     *out = (uint64_t)v;
     return LC3GPU_OK;
+}
+// tests only: what a pair half that gives up does (lc3_pc_gave_up), from a one-lane kernel -- the path from the device to LC3GPU_EPAIR
+// cannot be provoked otherwise (no pair has ever given up)
+__global__ void lc3_pc_gave_up_kernel(unsigned *pc) { lc3_pc_gave_up(pc); }
+static int pair_giveup_inject(HandleCommon &hc) {
+    int rc = hc.quiesce();
+    if (rc) return rc;
+    hipLaunchKernelGGL(lc3_pc_gave_up_kernel, dim3(1), dim3(1), 0, nullptr, hc.d_pc_timeouts);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return LC3GPU_OK;
+}
+int lc3gpu_encoder_debug_pair_giveup(lc3gpu_encoder *e) {
+    if (!e) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(e);
+    return pair_giveup_inject(*e);
+}
+int lc3gpu_decoder_debug_pair_giveup(lc3gpu_decoder *d) {
+    if (!d) return LC3GPU_EINVAL;
+    LC3_ON_DEVICE(d);
+    return pair_giveup_inject(*d);
 }
 int lc3gpu_encoder_pair_timeouts(lc3gpu_encoder *e, uint64_t *out) {
     if (!e || !out) return LC3GPU_EINVAL;
@@ -3378,10 +3561,11 @@ int lc3gpu_prof_read(unsigned long long out[64]) {
 int lc3gpu_kernel_info(int which, int out[5]) {
     if (!out) return LC3GPU_EINVAL;
     hipFuncAttributes a;
-    // the six kernels a full batch of the headline configuration launches (48 kHz / 10 ms view; the pair forms of packer and parser)
-    const void *fn[6] = {(const void *)lc3_enc_front_kernel<lc3_cfg_48k10>, (const void *)lc3_sns_vq_kernel,
-                         (const void *)lc3_enc_back_kernel<lc3_cfg_48k10>, (const void *)lc3_pack_pc_kernel,
-                         (const void *)lc3_parse_pc_kernel<lc3_cfg_48k10>, (const void *)lc3_decode_kernel<lc3_cfg_48k10>};
+    // the six kernels a full batch of the headline configuration launches (48 kHz / 10 ms view; the pair forms of packer and parser).
+    // 0 and 1 keep the meaning they had when there were two kernels (analysis back half, synthesis); the others are appended.
+    const void *fn[6] = {(const void *)lc3_enc_back_kernel<lc3_cfg_48k10>, (const void *)lc3_decode_kernel<lc3_cfg_48k10>,
+                         (const void *)lc3_enc_front_kernel<lc3_cfg_48k10>, (const void *)lc3_sns_vq_kernel,
+                         (const void *)lc3_pack_pc_kernel, (const void *)lc3_parse_pc_kernel<lc3_cfg_48k10>};
     if (which < 0 || which >= 6) return LC3GPU_EINVAL;
     hipError_t e = hipFuncGetAttributes(&a, fn[which]);
     if (e != hipSuccess) {

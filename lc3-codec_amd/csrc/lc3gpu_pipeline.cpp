@@ -1,0 +1,264 @@
+// lc3gpu_pipeline -- the caller loop of the reference, as an object of the library (host code only, on top of the C ABI of lc3gpu.hip).
+//
+// The reference's callers hold the codec objects and walk the frames: examples/encode.rs:97-115 (for every frame, for every channel:
+// encode_frame) and examples/decode.rs:93-112 (the mirror).  On the GPU the fastest arrangement of that loop is not one call after the
+// other on one HIP stream: a lane-per-frame kernel (packer, parser, SNS vector quantiser) leaves most of the chip's workgroup slots
+// free, a wave-per-stream kernel fills them, and kernels of DIFFERENT calls can share the chip.  What measured best (DESIGN section 6,
+// `quad`): the channels in two groups, every group with an encoder handle and a decoder handle of its own, the encoder handle on a
+// HIP stream of the higher priority, the decoder handle on a stream of the default priority, two byte buffers in flight per group, the
+// groups never joining.  Until round 6 that arrangement lived in bench.py; this file makes it a property of the library:
+//
+//   lc3gpu_pipeline_create  -> the handles, streams and events of `n_groups` groups
+//   lc3gpu_pipeline_submit  -> one step of every group: encode d_pcm -> d_bytes on the group's encoder stream, decode d_bytes -> d_pcm_out
+//                              on its decoder stream behind an event; asynchronous
+//   lc3gpu_pipeline_encode / _decode -> the halves alone, the groups side by side
+//   lc3gpu_pipeline_wait / _join / _follow -> the host / a caller's HIP stream waits for the pipeline / the pipeline for a caller's stream
+//
+// Buffers are planar (LC3GPU_LAYOUT_PLANAR): a group's channels are a contiguous slice of every buffer.
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/lc3gpu.h"
+
+namespace {
+struct Group {
+    int first = 0, n = 0;
+    lc3gpu_encoder *enc = nullptr;
+    lc3gpu_decoder *dec = nullptr;
+    hipStream_t s_enc = nullptr, s_dec = nullptr;
+    // the two most recent submissions of this group: behind the encoder's / the decoder's work of each
+    hipEvent_t enc_done[2] = {nullptr, nullptr}, dec_done[2] = {nullptr, nullptr};
+    bool enc_rec[2] = {false, false}, dec_rec[2] = {false, false};
+    // the byte range the decoder of that submission READS and the encoder of a later one may WRITE
+    const uint8_t *bytes_lo[2] = {nullptr, nullptr}, *bytes_hi[2] = {nullptr, nullptr};
+    // the PCM range the decoder of that submission WRITES (a later encoder may read it: a transcoding chain)
+    int last_enc = -1, last_dec = -1;  // slot of the latest encoder / decoder work (for wait / join)
+};
+}  // namespace
+
+struct lc3gpu_pipeline {
+    int device = 0;
+    int num_channels = 0, nf = 0;
+    unsigned long long k = 0;  // submissions so far (slot = k & 1)
+    std::vector<Group> groups;
+    hipEvent_t ev_follow = nullptr;
+    bool follow_pending = false;
+    int last_hip = 0;
+};
+
+namespace {
+struct DeviceGuard {
+    int prev = -1, dev;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+#define PL_HIP(p, call)                      \
+    do {                                     \
+        hipError_t e_ = (call);              \
+        if (e_ != hipSuccess) {              \
+            (p)->last_hip = (int)e_;         \
+            (void)hipGetLastError();         \
+            return LC3GPU_EHIP;              \
+        }                                    \
+    } while (0)
+
+// the pipeline's next work on `s` waits for what lc3gpu_pipeline_follow recorded
+int follow_wait(lc3gpu_pipeline *p, hipStream_t s) {
+    if (p->follow_pending) PL_HIP(p, hipStreamWaitEvent(s, p->ev_follow, 0));
+    return LC3GPU_OK;
+}
+bool overlaps(const uint8_t *a_lo, const uint8_t *a_hi, const uint8_t *b_lo, const uint8_t *b_hi) { return a_lo < b_hi && b_lo < a_hi; }
+}  // namespace
+
+extern "C" {
+
+int lc3gpu_pipeline_destroy(lc3gpu_pipeline *p) {
+    if (!p) return LC3GPU_OK;
+    {
+        DeviceGuard g(p->device);
+        for (Group &q : p->groups) {
+            if (q.s_enc) (void)hipStreamSynchronize(q.s_enc);
+            if (q.s_dec) (void)hipStreamSynchronize(q.s_dec);
+            if (q.enc) (void)lc3gpu_encoder_destroy(q.enc);
+            if (q.dec) (void)lc3gpu_decoder_destroy(q.dec);
+            for (int i = 0; i < 2; i++) {
+                if (q.enc_done[i]) (void)hipEventDestroy(q.enc_done[i]);
+                if (q.dec_done[i]) (void)hipEventDestroy(q.dec_done[i]);
+            }
+            if (q.s_enc) (void)hipStreamDestroy(q.s_enc);
+            if (q.s_dec) (void)hipStreamDestroy(q.s_dec);
+        }
+        if (p->ev_follow) (void)hipEventDestroy(p->ev_follow);
+    }
+    delete p;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_pipeline_create(lc3gpu_pipeline **out, int num_channels, int frame_us, int fs_hz, int n_groups) {
+    if (!out || num_channels <= 0 || n_groups < 0 || n_groups > 8) return LC3GPU_EINVAL;
+    *out = nullptr;
+    int cfg[7];
+    int rc = lc3gpu_config(frame_us, fs_hz, cfg);
+    if (rc) return rc;
+    if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
+    if (n_groups == 0) n_groups = 2;  // what measured best on a full batch (more groups: every group adds its lane-per-frame kernels' latency)
+    // groups of whole workgroups of the wave-per-stream kernels (four channels); fewer groups when there are not enough channels
+    const int quads = (num_channels + 3) / 4;
+    if (n_groups > quads) n_groups = quads;
+    lc3gpu_pipeline *p = new (std::nothrow) lc3gpu_pipeline();
+    if (!p) return LC3GPU_EINVAL;
+    p->num_channels = num_channels;
+    p->nf = cfg[5];
+    if (hipGetDevice(&p->device) != hipSuccess) {
+        delete p;
+        return LC3GPU_EHIP;
+    }
+    // (numerically the greatest priority is the smallest number: -1 high, 0 default, 1 low on this platform.  The decoder streams get the
+    // DEFAULT priority, not the least one -- what the measured arrangement used)
+    int prio_least = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_high);
+    const int prio_low = prio_high < 0 ? 0 : prio_least;
+    p->groups.resize((size_t)n_groups);
+    rc = LC3GPU_OK;
+    for (int g = 0; g < n_groups && rc == LC3GPU_OK; g++) {
+        Group &q = p->groups[(size_t)g];
+        const int lo = (int)((long long)quads * g / n_groups) * 4, hi = g + 1 == n_groups ? num_channels : (int)((long long)quads * (g + 1) / n_groups) * 4;
+        q.first = lo;
+        q.n = hi - lo;
+        // The encoder chain (front half -> vector quantiser -> back half -> packer) is each group's critical path: its stream gets the
+        // higher HIP stream priority.  Streams of another priority also live on hardware queues of their own -- the runtime deals the
+        // streams of one priority onto a handful of queues, and two streams that share a queue run one behind the other.
+        if (hipStreamCreateWithPriority(&q.s_enc, hipStreamNonBlocking, prio_high) != hipSuccess ||
+            hipStreamCreateWithPriority(&q.s_dec, hipStreamNonBlocking, prio_low) != hipSuccess) {
+            rc = LC3GPU_EHIP;
+            break;
+        }
+        for (int i = 0; i < 2 && rc == LC3GPU_OK; i++)
+            if (hipEventCreateWithFlags(&q.enc_done[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&q.dec_done[i], hipEventDisableTiming) != hipSuccess)
+                rc = LC3GPU_EHIP;
+        if (rc == LC3GPU_OK) rc = lc3gpu_encoder_create(&q.enc, q.n, frame_us, fs_hz);
+        if (rc == LC3GPU_OK) rc = lc3gpu_decoder_create(&q.dec, q.n, frame_us, fs_hz);
+    }
+    if (rc == LC3GPU_OK && hipEventCreateWithFlags(&p->ev_follow, hipEventDisableTiming) != hipSuccess) rc = LC3GPU_EHIP;
+    if (rc) {
+        if (rc == LC3GPU_EHIP) (void)hipGetLastError();
+        lc3gpu_pipeline_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_pipeline_groups(const lc3gpu_pipeline *p) { return p ? (int)p->groups.size() : LC3GPU_EINVAL; }
+
+int lc3gpu_pipeline_group(lc3gpu_pipeline *p, int group, int *first_channel, int *n_channels, lc3gpu_encoder **enc, lc3gpu_decoder **dec) {
+    if (!p || group < 0 || group >= (int)p->groups.size()) return LC3GPU_EINVAL;
+    const Group &q = p->groups[(size_t)group];
+    if (first_channel) *first_channel = q.first;
+    if (n_channels) *n_channels = q.n;
+    if (enc) *enc = q.enc;
+    if (dec) *dec = q.dec;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_pipeline_last_hip_error(const lc3gpu_pipeline *p) { return p ? p->last_hip : 0; }
+
+// what = 1 encode, 2 decode, 3 both
+static int pipeline_step(lc3gpu_pipeline *p, int what, const int16_t *d_pcm, uint8_t *d_bytes, const uint8_t *d_bad, int16_t *d_pcm_out, int nbytes,
+                         int n_frames) {
+    if (!p || !d_bytes || ((what & 1) && !d_pcm) || ((what & 2) && !d_pcm_out)) return LC3GPU_EINVAL;
+    if (n_frames <= 0) return LC3GPU_ELENGTH;
+    DeviceGuard dg(p->device);
+    const int b = (int)(p->k & 1ull);
+    int rc = LC3GPU_OK;
+    for (Group &q : p->groups) {
+        const size_t f0 = (size_t)q.first * (size_t)n_frames;
+        uint8_t *bytes = d_bytes + f0 * (size_t)nbytes;
+        const uint8_t *bytes_end = bytes + (size_t)q.n * (size_t)n_frames * (size_t)nbytes;
+        if (what & 1) {
+            // the encoder may not overwrite bytes a decoder of the two submissions in flight still reads (a caller that alternates two byte
+            // buffers never waits here for the submission before this one; a caller with one buffer does)
+            for (int i = 0; i < 2; i++)
+                if (q.dec_rec[i] && overlaps(bytes, bytes_end, q.bytes_lo[i], q.bytes_hi[i])) PL_HIP(p, hipStreamWaitEvent(q.s_enc, q.dec_done[i], 0));
+            if ((rc = follow_wait(p, q.s_enc)) != 0) return rc;
+            rc = lc3gpu_encode(q.enc, d_pcm + f0 * (size_t)p->nf, bytes, nbytes, n_frames, q.s_enc);
+            if (rc) return rc;
+            PL_HIP(p, hipEventRecord(q.enc_done[b], q.s_enc));
+            q.enc_rec[b] = true;
+            q.last_enc = b;
+        }
+        if (what & 2) {
+            if (what & 1) PL_HIP(p, hipStreamWaitEvent(q.s_dec, q.enc_done[b], 0));
+            if ((rc = follow_wait(p, q.s_dec)) != 0) return rc;
+            const uint8_t *bad = d_bad ? d_bad + f0 : nullptr;
+            rc = lc3gpu_decode(q.dec, bytes, bad, d_pcm_out + f0 * (size_t)p->nf, nbytes, n_frames, q.s_dec);
+            if (rc) return rc;
+            PL_HIP(p, hipEventRecord(q.dec_done[b], q.s_dec));
+            q.dec_rec[b] = true;
+            q.bytes_lo[b] = bytes;
+            q.bytes_hi[b] = bytes_end;
+            q.last_dec = b;
+        }
+    }
+    p->follow_pending = false;
+    p->k++;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_pipeline_submit(lc3gpu_pipeline *p, const int16_t *d_pcm, uint8_t *d_bytes, int16_t *d_pcm_out, int nbytes, int n_frames) {
+    return pipeline_step(p, 3, d_pcm, d_bytes, nullptr, d_pcm_out, nbytes, n_frames);
+}
+int lc3gpu_pipeline_encode(lc3gpu_pipeline *p, const int16_t *d_pcm, uint8_t *d_bytes, int nbytes, int n_frames) {
+    return pipeline_step(p, 1, d_pcm, d_bytes, nullptr, nullptr, nbytes, n_frames);
+}
+int lc3gpu_pipeline_decode(lc3gpu_pipeline *p, const uint8_t *d_bytes, const uint8_t *d_bad_frame, int16_t *d_pcm_out, int nbytes, int n_frames) {
+    return pipeline_step(p, 2, nullptr, (uint8_t *)d_bytes, d_bad_frame, d_pcm_out, nbytes, n_frames);
+}
+
+int lc3gpu_pipeline_wait(lc3gpu_pipeline *p) {
+    if (!p) return LC3GPU_EINVAL;
+    DeviceGuard dg(p->device);
+    for (Group &q : p->groups) {
+        if (q.last_enc >= 0) PL_HIP(p, hipEventSynchronize(q.enc_done[q.last_enc]));
+        if (q.last_dec >= 0) PL_HIP(p, hipEventSynchronize(q.dec_done[q.last_dec]));
+    }
+    return LC3GPU_OK;
+}
+
+int lc3gpu_pipeline_join(lc3gpu_pipeline *p, void *hip_stream) {
+    if (!p) return LC3GPU_EINVAL;
+    DeviceGuard dg(p->device);
+    for (Group &q : p->groups) {
+        if (q.last_enc >= 0) PL_HIP(p, hipStreamWaitEvent((hipStream_t)hip_stream, q.enc_done[q.last_enc], 0));
+        if (q.last_dec >= 0) PL_HIP(p, hipStreamWaitEvent((hipStream_t)hip_stream, q.dec_done[q.last_dec], 0));
+    }
+    return LC3GPU_OK;
+}
+
+int lc3gpu_pipeline_follow(lc3gpu_pipeline *p, void *hip_stream) {
+    if (!p) return LC3GPU_EINVAL;
+    DeviceGuard dg(p->device);
+    PL_HIP(p, hipEventRecord(p->ev_follow, (hipStream_t)hip_stream));
+    p->follow_pending = true;
+    return LC3GPU_OK;
+}
+
+int lc3gpu_pipeline_reset(lc3gpu_pipeline *p) {
+    if (!p) return LC3GPU_EINVAL;
+    int rc = lc3gpu_pipeline_wait(p);
+    for (Group &q : p->groups) {
+        if (rc == LC3GPU_OK) rc = lc3gpu_encoder_reset(q.enc);
+        if (rc == LC3GPU_OK) rc = lc3gpu_decoder_reset(q.dec);
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -47,6 +47,42 @@ def make_pcm(n_streams, n_frames, nf, fs_hz, seed=SEED, first_stream=0):
     return out
 
 
+def make_pcm_parallel(n_streams, n_frames, nf, fs_hz, seed=SEED, first_stream=0, workers=None):
+    """make_pcm over `workers` child processes (streams are generated independently from (seed, stream index), so the result is the same
+    array).  The children are fresh interpreters running THIS FILE as a script (numpy only) -- nothing is forked: the caller may hold
+    a GPU context -- and hand their chunk back through a temporary .npy file.  Falls back to the serial generator if a child fails."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    if workers is None:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            workers = os.cpu_count() or 1
+    workers = max(1, min(int(workers), n_streams // 256))
+    if workers <= 1:
+        return make_pcm(n_streams, n_frames, nf, fs_hz, seed=seed, first_stream=first_stream)
+    step = (n_streams + workers - 1) // workers
+    out = np.empty((n_streams, n_frames, nf), np.int16)
+    with tempfile.TemporaryDirectory(prefix="lc3synth") as d:
+        procs = []
+        for k, a in enumerate(range(0, n_streams, step)):
+            n = min(step, n_streams - a)
+            path = os.path.join(d, "c%d.npy" % k)
+            procs.append((a, n, path, subprocess.Popen([sys.executable, os.path.abspath(__file__), str(n), str(n_frames), str(nf), str(fs_hz),
+                                                        str(seed), str(first_stream + a), path])))
+        ok = True
+        for a, n, path, pr in procs:
+            ok = (pr.wait() == 0) and ok
+            if ok:
+                out[a:a + n] = np.load(path)
+    if not ok:
+        return make_pcm(n_streams, n_frames, nf, fs_hz, seed=seed, first_stream=first_stream)
+    return out
+
+
 def make_ltpf_pcm(nf, fs_hz, n_frames=14):
     """Three streams that walk the decoder's long-term post-filter through all five of its frame-to-frame transition
     cases (decoder/long_term_post_filter.rs:142-160): a tone whose pitch glides (filter stays on while its lag changes),
@@ -96,3 +132,10 @@ def make_bandlimited_pcm(n_streams, n_frames, nf, fs_hz, cutoff_hz, seed=SEED):
         x *= 10.0 ** (rng.uniform(-20.0, -6.0) / 20.0) * 32767.0 / max(1e-9, np.abs(x).max())
         out[i] = np.clip(np.rint(x), -32768, 32767).astype(np.int16).reshape(n_frames, nf)
     return out
+
+
+if __name__ == "__main__":  # a worker of make_pcm_parallel: n_streams n_frames nf fs_hz seed first_stream out.npy
+    import sys
+
+    _a = sys.argv[1:]
+    np.save(_a[6], make_pcm(int(_a[0]), int(_a[1]), int(_a[2]), int(_a[3]), seed=int(_a[4]), first_stream=int(_a[5])))

@@ -193,7 +193,7 @@ void *lane_main(void *arg) {
             const int16_t *frame = j->pcm_in + (size_t)t * j->cfg.nf;
             const int16_t *hist = t > 0 ? frame - j->cfg.nf + j->cfg.z : (j->fresh ? nullptr : j->est->hist);
             lc3_encode_front_wave(j->cfg, L, lane, frame, hist, j->est, mcol, plane, LC3_PLANE_STRIDE, j->nbytes,
-                                  j->valid ? j->dbg : nullptr, 1, 1, t + (t + 2 < j->n_frames ? 0x100 : 0));  // (as lc3_enc_front_body)
+                                  j->valid ? j->dbg : nullptr, 1, 1, (t % LC3_WG_WAVES) + (t + 2 < j->n_frames ? 0x100 : 0));  // (as lc3_enc_front_body)
         }
         if (j->valid)
             lc3_enc_state_store(j->cfg, L, lane, j->est, j->n_frames > 0 ? j->pcm_in + (size_t)(j->n_frames - 1) * j->cfg.nf : nullptr);

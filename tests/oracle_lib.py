@@ -36,6 +36,23 @@ def lib():
     return _lib
 
 
+_native = None
+
+
+def lib_native():
+    """the oracle built with -O3 -march=native on THIS host (oracle/Makefile `native`; bench.py's second cpu_baseline leg); None when it
+    cannot be built here"""
+    global _native
+    if _native is None:
+        path = os.path.join(ORACLE_DIR, "liblc3oracle_native.so")
+        try:
+            subprocess.check_call(["make", "-s", "-B", "-C", ORACLE_DIR, "native"])  # -B: a copy built on another host is not this host's
+            _native = ctypes.CDLL(path)
+        except (subprocess.CalledProcessError, OSError):
+            _native = False
+    return _native or None
+
+
 def P(a):
     """pointer to a numpy array's data"""
     return a.ctypes.data_as(ctypes.c_void_p)
@@ -116,22 +133,22 @@ class Decoder:
             pass
 
 
-def encode_batch(pcm, nbytes, fs_hz=48000, frame_us=10000, threads=1, spec_flags=0):
+def encode_batch(pcm, nbytes, fs_hz=48000, frame_us=10000, threads=1, spec_flags=0, library=None):
     """pcm int16[S][T][nf] -> uint8[S][T][nbytes]; every stream starts from a fresh encoder.  spec_flags: LC3O_SPEC_* bits
     (corrections of the reference's deviations from the specification; 0 = the reference's behaviour)."""
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     S, T, nf = pcm.shape
     out = np.zeros((S, T, nbytes), np.uint8)
-    rc = lib().lc3o_encode_batch_spec(fs_hz, frame_us, nbytes, S, T, P(pcm), P(out), threads, int(spec_flags))
+    rc = (library or lib()).lc3o_encode_batch_spec(fs_hz, frame_us, nbytes, S, T, P(pcm), P(out), threads, int(spec_flags))
     assert rc == 0
     return out
 
 
-def decode_batch(data, nf, fs_hz=48000, frame_us=10000, threads=1):
+def decode_batch(data, nf, fs_hz=48000, frame_us=10000, threads=1, library=None):
     data = np.ascontiguousarray(data, dtype=np.uint8)
     S, T, nbytes = data.shape
     out = np.zeros((S, T, nf), np.int16)
-    rc = lib().lc3o_decode_batch(fs_hz, frame_us, nbytes, S, T, P(data), P(out), threads)
+    rc = (library or lib()).lc3o_decode_batch(fs_hz, frame_us, nbytes, S, T, P(data), P(out), threads)
     assert rc == 0
     return out
 
@@ -160,7 +177,7 @@ def encoder_path_counts(reset=False):
     return out
 
 
-def timed_run(pcm, nbytes, fs_hz=48000, frame_us=10000, threads=1, roundtrip=True, seconds=5.0):
+def timed_run(pcm, nbytes, fs_hz=48000, frame_us=10000, threads=1, roundtrip=True, seconds=5.0, library=None):
     """bench.py's cpu_baseline leg: `threads` host threads, each with ONE persistent encoder (and decoder) that codes its own stream
     of consecutive frames (pcm[t % S], cycled) for `seconds`; thread start-up, allocation and initialisation lie outside the timed
     region.  -> (frames coded, elapsed seconds)"""
@@ -168,7 +185,7 @@ def timed_run(pcm, nbytes, fs_hz=48000, frame_us=10000, threads=1, roundtrip=Tru
     S, T, nf = pcm.shape
     frames = ctypes.c_double(0.0)
     elapsed = ctypes.c_double(0.0)
-    f = lib().lc3o_timed_run
+    f = (library or lib()).lc3o_timed_run
     f.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                                                                                  ctypes.POINTER(ctypes.c_double)]
     rc = f(fs_hz, frame_us, nbytes, T, P(pcm), S, int(threads), int(bool(roundtrip)), float(seconds), ctypes.byref(frames),

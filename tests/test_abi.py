@@ -33,6 +33,32 @@ def test_library_exports_every_declared_symbol(L):
     assert sorted(api.ABI_SYMBOLS) == syms
 
 
+def test_rust_binding_binds_every_symbol_with_the_headers_parameter_lists():
+    """bindings/lc3gpu.rs (shipped uncompiled: no Rust toolchain here) is what tools/gen_rust_binding.py writes from include/lc3gpu.h: the
+    extern block names every declared symbol exactly once, with as many parameters as the header's declaration has"""
+    import subprocess
+    import sys
+    import tempfile
+
+    rs_path = os.path.join(ROOT, "bindings", "lc3gpu.rs")
+    rs = open(rs_path).read()
+    block = rs[rs.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    bound = re.findall(r"pub fn (lc3gpu_\w+)\((.*?)\)(?: -> [^;]+)?;", block)
+    assert sorted(n for n, _ in bound) == header_symbols()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lc3gpu.h")).read(), flags=re.S)
+    for name, params in bound:
+        m = re.search(r"\b%s\s*\(([^;{}]*?)\)\s*;" % name, text, flags=re.S)
+        c_params = [q for q in " ".join(m.group(1).split()).split(",") if q.strip() and q.strip() != "void"]
+        assert len([q for q in params.split(",") if q.strip()]) == len(c_params), name
+    for code in ("LC3GPU_EPAIR: i32 = -8", "LC3GPU_EBITS: i32 = -4", "LC3GPU_LAYOUT_INTERLEAVED: i32 = 1"):
+        assert code in rs
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "lc3gpu.rs")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_rust_binding.py"), out])
+        assert open(out).read() == rs, "bindings/lc3gpu.rs is stale: run tools/gen_rust_binding.py"
+
+
 def test_signatures_are_plain_c():
     text = open(os.path.join(ROOT, "include", "lc3gpu.h")).read()
     assert "torch" not in text.lower().replace("no torch", "")
@@ -69,6 +95,7 @@ def test_working_buffer_lengths(L):  # lc3_encoder.rs:194-209, lc3_decoder.rs:23
 def test_error_strings_and_no_fallback(L):
     assert L.lc3gpu_strerror(0) == b"ok"
     assert b"16 bits" in L.lc3gpu_strerror(-4)
+    assert b"pair" in L.lc3gpu_strerror(-8)
     assert L.lc3gpu_version() >= 100
     if pkg.device_count() == 0:
         # no GPU here: constructing a codec must fail loudly, never fall back to a CPU path
@@ -77,6 +104,9 @@ def test_error_strings_and_no_fallback(L):
         assert e.value.code == -6
         with pytest.raises(pkg.Lc3DecoderError):
             pkg.Lc3Decoder(1, 10000, 48000)
+        with pytest.raises(pkg.Lc3GpuError) as e:
+            pkg.Lc3Pipeline(8, 10000, 48000)
+        assert e.value.code == -6
 
 
 def test_product_does_not_touch_the_oracle():

@@ -145,3 +145,32 @@ def test_bench_launcher_stops_the_others_when_one_rank_dies_after_the_rendezvous
     assert "rank 1 exited with code 17" in p.stderr
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert time.time() - t0 < 120.0
+
+
+def test_eight_ranks_through_the_launcher():
+    """the shape of the driver's 8-GPU run without an 8-GPU box: `bench.py --gpus 8` with CPU ranks (the device code under the wave emulator,
+    gloo): eight fresh children, contiguous shards, one reduction; every rank gates the same number of its own streams (the sample does
+    not shrink with N), the oracle's share of a rank's time is reported, and the N > 1 line points at the N = 1 line for `cpu_baseline`"""
+    rc, line = _run_bench("--gpus", "8")
+    assert rc == 0 and line is not None
+    assert line["n_gpus"] == 8 and "world size 8 (gloo)" in line["config"]["parallelism"]
+    assert line["config"]["frames_per_step_per_gpu"] == 8 and line["scaling"] == "weak"
+    assert line["parity"]["bitstream_exact"] and line["parity"]["frames_checked"] == 8 and line["parity_mismatches_all_ranks"] == 0
+    assert line["parity"]["oracle_seconds"] < 30.0
+    assert abs(line["value"] - 8 * 8 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    assert line["cpu_baseline"]["value"] is None and "--gpus 1" in line["cpu_baseline"]["sample"]
+    # strong scaling: 16 streams of 2 frames over 8 ranks, two each
+    rc, line = _run_bench("--gpus", "8", "--mode", "encode", "--frames-total", "32", "--frames", "2")
+    assert rc == 0 and line["n_gpus"] == 8 and line["config"]["streams_per_gpu"] == 2 and line["parity_mismatches_all_ranks"] == 0
+
+
+def test_eight_ranks_one_dies():
+    import subprocess
+    import time
+
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--engine", "emu", "--steps", "1", "--warmup", "0", "--gpus", "8"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, LC3_BENCH_TEST_DIE_RANK="5"))
+    assert p.returncode != 0 and "rank 5 exited with code 17" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert time.time() - t0 < 300.0

@@ -308,7 +308,105 @@ def test_bit_rate_changes_between_launches_of_several_frames():
     assert active > 0, "the post-filter never switched on: the test material lost its point"
 
 
+def test_long_launches_keep_the_post_filter_memories_for_a_later_rate():
+    """Launches of MORE than 256 frames per stream at a rate that keeps the post-filter off, each followed by a launch at a rate that
+    lets it switch on: the first low-rate frames decide `ltpf_active` from mem_nc / mem_mem_nc (long_term_post_filter.rs:365-409), which
+    are the normalised correlations of the long launch's LAST TWO frames -- the only ones it computes.  (The "not one of the last two"
+    mark once shared a word with the frame number and read frame 256's own bit 8 as the mark.)  Steady tones: the filter is on from the
+    first low-rate frame only if both memories are right."""
+    plan = [(258, 150), (3, 60), (300, 150), (3, 60), (2, 150), (2, 60)]
+    T = sum(n for n, _ in plan)
+    lt = synth.make_ltpf_pcm(480, 48000, n_frames=T)
+    pcm = np.concatenate([lt, synth.make_pcm(5, T, 480, 48000, seed=31)], axis=0)
+    S = pcm.shape[0]
+    enc = pkg.Lc3Encoder(S, US, FS)
+    oracle = [O.Encoder() for _ in range(S)]
+    t0, first_frame_active = 0, 0
+    for n, nb in plan:
+        got = gpu_encode(pcm[:, t0:t0 + n], nb, enc=enc)
+        for s_i in range(S):
+            for t in range(n):
+                want = oracle[s_i].encode_frame(pcm[s_i, t0 + t], nb)
+                assert np.array_equal(got[s_i, t], want), f"stream {s_i} frame {t0 + t} ({nb} bytes)"
+        if nb < 110:
+            O.ltpf_transition_counts(reset=True)
+            O.decode_batch(got[:, :1], 480)  # fresh decoders, one frame: a filter that is on shows as a transition out of "off"
+            first_frame_active += sum(O.ltpf_transition_counts()[2:])
+        t0 += n
+    assert first_frame_active > 0, "no stream had the filter on in the first frame after a long launch: the test lost its point"
+
+
 # ---------------------------------------------------------------- corrupt frames / PLC
+def _loss_bursts_check():
+    for fs, us, nbytes in ((48000, 10000, 150), (32000, 7500, 61)):
+        cfg = pkg.Lc3Config(fs, us)
+        S, T = 12, 40
+        pcm = synth.make_pcm(S, T, cfg.nf, fs, seed=37)
+        data = O.encode_batch(pcm, nbytes, fs, us).copy()
+        rng = np.random.default_rng(41)
+        bad = np.zeros((S, T), np.uint8)
+        marked = data.copy()  # what the oracle sees: an externally flagged frame is a frame it cannot parse
+        for s_i in range(S):
+            start = 2 + (s_i * 3) % 11
+            run = 9 + s_i % 5  # 9 .. 13
+            for k in range(run):
+                t = start + k
+                how = (s_i + k) % 3
+                if how == 0:
+                    data[s_i, t, -1] |= 7
+                    marked[s_i, t, -1] |= 7  # invalid bandwidth index -> SideInfoError -> PLC
+                elif how == 1:
+                    bad[s_i, t] = 1
+                    marked[s_i, t, -1] |= 7
+                else:  # garbage that cannot parse either (garbage that happens to parse would end the run)
+                    g = rng.integers(0, 256, nbytes, dtype=np.uint8)
+                    g[-1] |= 7
+                    data[s_i, t] = g
+                    marked[s_i, t] = g
+            # a second, short run later: the fade starts again from the first factor after a good frame
+            for t in range(start + run + 4, min(T, start + run + 7)):
+                bad[s_i, t] = 1
+                marked[s_i, t, -1] |= 7
+        ref = O.decode_batch(marked, cfg.nf, fs, us)
+        cuts = [5, 3, 7, 1, 6, 4, 2, 8, 4]
+        assert sum(cuts) == T
+        dec = pkg.Lc3Decoder(S, us, fs)
+        t0, parts = 0, []
+        for n in cuts:
+            parts.append(gpu_decode(data[:, t0:t0 + n], cfg.nf, fs, us, dec=dec, bad=bad[:, t0:t0 + n]))
+            t0 += n
+        got = np.concatenate(parts, axis=1)
+        d = np.argwhere((got != ref).any(axis=2))
+        assert len(d) == 0, f"{fs}/{us}: {len(d)} frames differ, first {d[0].tolist()}"
+        assert dec.plc_events() >= S * 12
+        assert np.array_equal(gpu_decode(data, cfg.nf, fs, us, bad=bad), ref), f"{fs}/{us}: one launch of {T} frames"
+        # the same runs in a batch large enough for the producer / consumer parser (every stream repeated)
+        rep = 16384 // (S * T) + 1
+        big = gpu_decode(np.tile(data, (rep, 1, 1)), cfg.nf, fs, us, bad=np.tile(bad, (rep, 1)))
+        assert np.array_equal(big, np.tile(ref, (rep, 1, 1))), f"{fs}/{us}: {rep * S} streams"
+    print("bursts ok")
+
+
+def test_loss_bursts_of_nine_to_thirteen_frames_across_launches():
+    """packet_loss_concealment.rs:62-66: from the ninth lost frame of a run on the concealed spectrum fades by 0.85 per frame (0.9 for
+    frames 4 .. 8 of the run).  Runs of 9 .. 13 lost frames -- unparsable side information, garbage and external flags mixed -- that
+    cross launch boundaries (launches of 5, 3, 7, 1, 6, 4 ... frames: `num_lost_frames` and `alpha` travel in the state blob), in the
+    form full batches use (reconstruction on the parser's lane) and the one small launches use (in the synthesis kernel), at 48 kHz /
+    10 ms and at 32 kHz / 7.5 ms; the size rule's own choice as well."""
+    import os
+    import subprocess
+    import sys
+
+    _loss_bursts_check()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, 'tests')\nimport test_gpu_parity as t\nt._loss_bursts_check()\n"
+    for v in ("lane", "late"):
+        env = dict(os.environ, LC3GPU_RECON=v)
+        env.pop("LC3GPU_LATE_RECON", None)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "bursts ok" in r.stdout, v + r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_corrupt_frames_are_concealed_like_the_reference():  # lc3_decoder.rs:138-141, packet_loss_concealment.rs
     S, T = 6, 12
     pcm = synth.make_pcm(S, T, 480, 48000, seed=19)
@@ -345,6 +443,183 @@ def test_bad_frame_flag_forces_concealment():
     ref = O.decode_batch(corrupt, 480)
     got = gpu_decode(data, 480, bad=bad)
     assert np.array_equal(got, ref)
+
+
+def test_a_pair_that_gave_up_is_reported_by_the_next_batch_call():
+    """A packer pair that gives up leaves its frames zero-filled, a parser pair conceals them (include/lc3gpu.h); the caller must not have
+    to poll a counter to learn that: the device raises a flag in pinned host memory and the handle's next batch call returns LC3GPU_EPAIR
+    once, launches nothing, and may be repeated.  No pair has ever given up, so the device side of the path is driven by the injection
+    entry point (the same device function the kernels call)."""
+    pcm = synth.make_pcm(8, 2, 480, 48000, seed=3)
+    ref = O.encode_batch(pcm, 150)
+    enc = pkg.Lc3Encoder(8, US, FS)
+    assert np.array_equal(gpu_encode(pcm[:, :1], 150, enc=enc), ref[:, :1])
+    enc.debug_pair_giveup()
+    with pytest.raises(pkg.Lc3EncoderError) as ei:
+        gpu_encode(pcm[:, 1:], 150, enc=enc)
+    assert ei.value.code == -8
+    torch_mod().cuda.synchronize()
+    assert np.array_equal(gpu_encode_keep_count(pcm[:, 1:], 150, enc), ref[:, 1:])  # the refused call launched nothing: state intact
+    assert enc.pair_timeouts() == 1
+    dec = pkg.Lc3Decoder(8, US, FS)
+    refp = O.decode_batch(ref, 480)
+    dec.debug_pair_giveup()
+    with pytest.raises(pkg.Lc3DecoderError) as ed:
+        gpu_decode(ref, 480, dec=dec)
+    assert ed.value.code == -8
+    torch = torch_mod()
+    d_in = torch.from_numpy(ref).cuda()
+    d_pcm = torch.zeros((8, 2, 480), dtype=torch.int16, device="cuda")
+    dec.decode(d_in, d_pcm, 150, 2, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_pcm.cpu().numpy(), refp) and dec.pair_timeouts() == 1
+
+
+def gpu_encode_keep_count(pcm, nbytes, enc):
+    """gpu_encode without its `pair_timeouts() == 0` assertion"""
+    torch = torch_mod()
+    S, T, nf = pcm.shape
+    d_pcm = torch.from_numpy(np.ascontiguousarray(pcm)).cuda()
+    d_out = torch.zeros((S, T, nbytes), dtype=torch.uint8, device="cuda")
+    enc.encode(d_pcm, d_out, nbytes, T, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy()
+
+
+def test_decoder_state_blobs_are_deterministic():
+    """a decoder launch stores only the part of the post-filter's output ring it wrote: the rest of a blob is zero, not whatever the
+    allocation held -- two handles that decoded the same frames save identical blobs, also after a reset"""
+    pcm = synth.make_pcm(6, 3, 480, 48000, seed=43)
+    data = O.encode_batch(pcm, 150)
+    blobs = []
+    for _ in range(2):
+        junk = torch_mod().full((1 << 22,), 0x5A, dtype=torch_mod().uint8, device="cuda")  # dirty the allocator's memory
+        del junk
+        dec = pkg.Lc3Decoder(6, US, FS)
+        gpu_decode(data[:, :1], 480, dec=dec)
+        dec.reset()
+        gpu_decode(data, 480, dec=dec)
+        blobs.append(dec.state_save())
+    assert np.array_equal(blobs[0], blobs[1])
+
+
+# ---------------------------------------------------------------- host-resident batches, the pipeline object
+def test_host_resident_batch_path():
+    """lc3gpu_encode_host / lc3gpu_decode_host: the caller loops of examples/encode.rs:73-116 / examples/decode.rs:60-112 over HOST buffers,
+    the channels through the device in ranges on two internal HIP streams.  One range and several, pageable and pinned buffers, state
+    carried over two calls, lost-frame flags: against the oracle (a sample) and against the device-pointer calls (everything)."""
+    for S, T in ((300, 5), (20000, 2)):
+        base = synth.make_pcm(min(S, 512), 2 * T, 480, 48000, seed=47)
+        pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1, 1))[:S])
+        enc_h, enc_d = pkg.Lc3Encoder(S, US, FS), pkg.Lc3Encoder(S, US, FS)
+        dec_h, dec_d = pkg.Lc3Decoder(S, US, FS), pkg.Lc3Decoder(S, US, FS)
+        pin_in = pkg.PinnedBuffer((S, T, 480), np.int16)
+        pin_out = pkg.PinnedBuffer((S, T, 150), np.uint8)
+        k = min(S, 96)
+        ref_b = O.encode_batch(pcm[:k], 150, threads=8)
+        ref_p = O.decode_batch(ref_b, 480, threads=8)
+        rng = np.random.default_rng(53)
+        for step in range(2):
+            x = np.ascontiguousarray(pcm[:, step * T:(step + 1) * T])
+            if step == 0:  # pinned buffers first, pageable numpy arrays second
+                pin_in.array[...] = x
+                enc_h.encode_host(pin_in.array, pin_out.array, 150, T)
+                got = pin_out.array.copy()
+            else:
+                got = np.zeros((S, T, 150), np.uint8)
+                enc_h.encode_host(x, got, 150, T)
+            want = gpu_encode(x, 150, enc=enc_d)
+            assert np.array_equal(got, want), (S, T, step)
+            assert np.array_equal(got[:k], ref_b[:, step * T:(step + 1) * T])
+            bad = (rng.random((S, T)) < 0.05).astype(np.uint8)
+            out = np.zeros((S, T, 480), np.int16)
+            dec_h.decode_host(got, out, 150, T, bad_frame=bad if step else None)
+            wantp = gpu_decode(got, 480, dec=dec_d, bad=bad if step else None)
+            assert np.array_equal(out, wantp), (S, T, step)
+            if step == 0:
+                assert np.array_equal(out[:k], ref_p[:, :T])
+        pin_in.close()
+        pin_out.close()
+    with pytest.raises(pkg.Lc3EncoderError):
+        enc_h.encode_host(x, got, 10, T)  # frame size out of range, as the batch calls
+
+
+def test_pipeline_object_equals_the_single_stream_calls():
+    """lc3gpu_pipeline (the `quad` arrangement as a library object): three submissions with two byte buffers alternating, then with ONE
+    byte buffer (every encoder then waits for the decoder before it), equal byte for byte and sample for sample to lc3gpu_encode +
+    lc3gpu_decode of the same frames on one stream, and to the oracle on a sample; the halves alone; join / follow against a caller's
+    stream; reset; the group table."""
+    torch = torch_mod()
+    S, T, steps = 8200, 4, 3  # two groups of 4 100 channels: 16 400 frames each, the pair kernels' size
+    base = synth.make_pcm(1025, T * steps, 480, 48000, seed=59)
+    pcm = np.ascontiguousarray(np.tile(base, (8, 1, 1)))
+    assert pcm.shape[0] == S
+    enc, dec = pkg.Lc3Encoder(S, US, FS), pkg.Lc3Decoder(S, US, FS)
+    want_b, want_p = [], []
+    for k in range(steps):
+        b = gpu_encode(pcm[:, k * T:(k + 1) * T], 150, enc=enc)
+        want_b.append(b)
+        want_p.append(gpu_decode(b, 480, dec=dec))
+    ref_b = O.encode_batch(pcm[:64], 150, threads=8)
+    assert np.array_equal(np.concatenate(want_b, axis=1)[:64], ref_b)
+    pl = pkg.Lc3Pipeline(S, US, FS)
+    assert len(pl.groups) == 2 and [g["first"] for g in pl.groups] == [0, 4100] and sum(g["n"] for g in pl.groups) == S
+    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, k * T:(k + 1) * T])).cuda() for k in range(steps)]
+    for n_buf in (2, 1):
+        d_bytes = [torch.zeros((S, T, 150), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
+        d_out = [torch.zeros((S, T, 480), dtype=torch.int16, device="cuda") for _ in range(steps)]
+        keep = []
+        torch.cuda.synchronize()
+        for k in range(steps):
+            pl.submit(d_in[k], d_bytes[k % n_buf], d_out[k], 150, T)
+            if n_buf == 2 and k == 0:
+                pl.wait()
+                keep.append(d_bytes[0].cpu().numpy())
+        pl.wait()
+        for g in pl.groups:
+            assert g["enc"].pair_timeouts() == 0 and g["dec"].pair_timeouts() == 0
+        for k in range(steps):
+            assert np.array_equal(d_out[k].cpu().numpy(), want_p[k]), (n_buf, k)
+        assert np.array_equal(d_bytes[(steps - 1) % n_buf].cpu().numpy(), want_b[steps - 1])
+        if keep:
+            assert np.array_equal(keep[0], want_b[0])
+        pl.reset()
+    # the halves alone, a caller's stream on both sides: the PCM arrives on `side` (follow), the result is copied on `side` (join)
+    side = torch.cuda.Stream()
+    d_b = torch.zeros((S, T, 150), dtype=torch.uint8, device="cuda")
+    d_o = torch.zeros((S, T, 480), dtype=torch.int16, device="cuda")
+    host_in = torch.from_numpy(np.ascontiguousarray(pcm[:, :T])).pin_memory()
+    d_x = torch.empty((S, T, 480), dtype=torch.int16, device="cuda")
+    with torch.cuda.stream(side):
+        d_x.copy_(host_in, non_blocking=True)
+    pl.follow(side.cuda_stream)
+    pl.encode(d_x, d_b, 150, T)
+    pl.decode(d_b, d_o, 150, T)
+    pl.join(side.cuda_stream)
+    with torch.cuda.stream(side):
+        got_p = d_o.to("cpu", non_blocking=True)
+    side.synchronize()
+    assert np.array_equal(got_p.numpy(), want_p[0]) and np.array_equal(d_b.cpu().numpy(), want_b[0])
+    # a group's handles are the caller's to read: state blobs of the pipeline's first group == those of the plain handles' first channels
+    pl.wait()
+    n0 = pl.groups[0]["n"]
+    enc2 = pkg.Lc3Encoder(n0, US, FS)
+    gpu_encode(pcm[:n0, :T], 150, enc=enc2)
+    assert np.array_equal(pl.groups[0]["enc"].state_save(), enc2.state_save())
+    pl.close()
+    # few channels: fewer groups than asked for, odd counts
+    for S2, G in ((3, 4), (9, 2), (64, 3)):
+        p2 = pkg.Lc3Pipeline(S2, US, FS, n_groups=G)
+        assert sum(g["n"] for g in p2.groups) == S2 and all(g["n"] > 0 for g in p2.groups)
+        x = np.ascontiguousarray(pcm[:S2, :2])
+        d_x2 = torch.from_numpy(x).cuda()
+        d_b2 = torch.zeros((S2, 2, 150), dtype=torch.uint8, device="cuda")
+        d_o2 = torch.zeros((S2, 2, 480), dtype=torch.int16, device="cuda")
+        p2.submit(d_x2, d_b2, d_o2, 150, 2)
+        p2.wait()
+        rb = O.encode_batch(x, 150)
+        assert np.array_equal(d_b2.cpu().numpy(), rb) and np.array_equal(d_o2.cpu().numpy(), O.decode_batch(rb, 480))
+        p2.close()
 
 
 # ---------------------------------------------------------------- API error behaviour
@@ -1058,8 +1333,8 @@ def test_split_calls_on_and_off():
 
 
 def test_stress_parity_tool_one_million_frames():
-    """tools/stress_parity.py at volume inside the suite: 14 configurations x 2048 streams x 18 frames x 2 rounds = 1 032 192 frames per
-    direction, every bitstream byte and every PCM sample compared with the oracle (which runs on the host threads the job is granted);
+    """tools/stress_parity.py at volume inside the suite: (14 configurations in both directions + 3 decode-only 8 kHz ones) x 2048 streams x
+    18 frames x 2 rounds = 1 253 376 frames, every bitstream byte and every PCM sample compared with the oracle (which runs on the host threads the job is granted);
     one frame in 48 of the decode direction is damaged first (bit flips, random bytes, bad-frame flags), so concealment, the parser's
     error paths and the frames that follow a lost one are part of the volume.  (The guarded decisions of the quantiser fall back to
     their sequential sum about once in 10^4 decisions: it takes this many frames to see both sides of every guard on real data.)"""
@@ -1073,7 +1348,9 @@ def test_stress_parity_tool_one_million_frames():
                        cwd=root, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["frames_differing"] == 0 and line["total_frames_each_direction"] == 14 * 2048 * 18 * 2 >= 1000000
+    assert line["frames_differing"] == 0 and line["total_frames_each_direction"] == 17 * 2048 * 18 * 2 >= 1000000
+    k8 = [c for c in line["cases"] if c["fs_hz"] == 8000]
+    assert len(k8) == 3 and all(c["directions"].startswith("decode only") and c["decode_frames_damaged"] > 500 for c in k8)
     assert line["pair_timeouts"] == 0  # no producer / consumer pair ever gave up on its partner
     assert line["frames_damaged"] > 10000
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)

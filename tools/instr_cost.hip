@@ -101,6 +101,110 @@ KERNEL(k_mad24, NOPRE, EACH(I_MAD24))
 KERNEL(k_mul24_sdwa, NOPRE, EACH(I_MUL24_SDWA))
 KERNEL(k_addc, SETMASKS, EACH(I_ADDC))
 KERNEL(k_mov, NOPRE, EACH(I_MOV))
+// ---- f32 arithmetic: VOP2 encodings, the VOP3 forms of the same operations, packed pairs, DPP operands (round 6: what does a flop cost?)
+#define I_ADDF(i) "v_add_f32 %" #i ", %" #i ", %8\n"
+#define I_SUBF(i) "v_sub_f32 %" #i ", %" #i ", %8\n"
+#define I_MULF(i) "v_mul_f32 %" #i ", %" #i ", %8\n"
+#define I_MAXF(i) "v_max_f32 %" #i ", %" #i ", %8\n"
+#define I_FMACF(i) "v_fmac_f32 %" #i ", %8, %9\n"
+#define I_FMAF(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n"
+#define I_ADDF_E64(i) "v_add_f32_e64 %" #i ", %" #i ", %8\n"
+#define I_ADDF_NEG(i) "v_add_f32_e64 %" #i ", -%" #i ", %8\n"
+#define I_MULF_E64(i) "v_mul_f32_e64 %" #i ", %" #i ", %8\n"
+#define I_ADDF_DPP(i) "v_add_f32_dpp %" #i ", %8, %" #i " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define I_MOV_DPP(i) "v_mov_b32_dpp %" #i ", %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define I_CVT_F32_I32(i) "v_cvt_f32_i32 %" #i ", %" #i "\n"
+#define I_RCPF(i) "v_rcp_f32 %" #i ", %" #i "\n"
+#define I_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
+#define I_LSHL(i) "v_lshlrev_b32 %" #i ", 3, %" #i "\n"
+#define I_AND(i) "v_and_b32 %" #i ", %" #i ", %8\n"
+#define I_XOR(i) "v_xor_b32 %" #i ", %" #i ", %8\n"
+#define I_SUBU(i) "v_sub_u32 %" #i ", %" #i ", %8\n"
+#define I_MAXI(i) "v_max_i32 %" #i ", %" #i ", %8\n"
+KERNEL(k_addf, NOPRE, EACH(I_ADDF))
+KERNEL(k_subf, NOPRE, EACH(I_SUBF))
+KERNEL(k_mulf, NOPRE, EACH(I_MULF))
+KERNEL(k_maxf, NOPRE, EACH(I_MAXF))
+KERNEL(k_fmacf, NOPRE, EACH(I_FMACF))
+KERNEL(k_fmaf, NOPRE, EACH(I_FMAF))
+KERNEL(k_addf_e64, NOPRE, EACH(I_ADDF_E64))
+KERNEL(k_addf_neg, NOPRE, EACH(I_ADDF_NEG))
+KERNEL(k_mulf_e64, NOPRE, EACH(I_MULF_E64))
+KERNEL(k_addf_dpp, NOPRE, EACH(I_ADDF_DPP))
+KERNEL(k_mov_dpp, NOPRE, EACH(I_MOV_DPP))
+KERNEL(k_cvt, NOPRE, EACH(I_CVT_F32_I32))
+KERNEL(k_rcp, NOPRE, EACH(I_RCPF))
+KERNEL(k_mullo, NOPRE, EACH(I_MULLO))
+KERNEL(k_lshl, NOPRE, EACH(I_LSHL))
+KERNEL(k_and, NOPRE, EACH(I_AND))
+KERNEL(k_xor, NOPRE, EACH(I_XOR))
+KERNEL(k_subu, NOPRE, EACH(I_SUBU))
+KERNEL(k_maxi, NOPRE, EACH(I_MAXI))
+// packed f32: two IEEE operations per lane and instruction on 64-bit register pairs (un-fused add / mul: bit-exact under -ffp-contract=off)
+typedef float lc3_f2 __attribute__((ext_vector_type(2)));
+#define OPERANDS_PK : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(q), "v"(r) : "memory"
+#define BLOCK_PK(S0, S1, S2, S3, S4, S5, S6, S7) asm volatile(".rept 32\n" S0 S1 S2 S3 S4 S5 S6 S7 ".endr\n" OPERANDS_PK);
+#define EACH_PK(OP) BLOCK_PK(OP(0), OP(1), OP(2), OP(3), OP(4), OP(5), OP(6), OP(7))
+#define KERNEL_PK(NAME, BODY)                                                                               \
+    __global__ void NAME(unsigned long long *cycles, unsigned *sink, int iters) {                           \
+        const float t = (float)threadIdx.x;                                                                 \
+        lc3_f2 p0 = {t, t + 1}, p1 = {t + 2, t + 3}, p2 = {t + 4, t + 5}, p3 = {t + 6, t + 7}, p4 = {t + 8, t + 9}, p5 = {t + 10, t + 11}, \
+               p6 = {t + 12, t + 13}, p7 = {t + 14, t + 15};                                                \
+        const lc3_f2 q = {1.0000001f, 0.9999999f}, r = {1e-9f, -1e-9f};                                     \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
+        _Pragma("unroll 1") for (int i = 0; i < iters; i++) { BODY }                                        \
+        asm volatile("s_nop 0" ::: "memory");                                                               \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
+        if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0; \
+        const lc3_f2 z = p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7;                                             \
+        if (z.x + z.y == 12345.678f) sink[0] = 1;                                                           \
+    }
+#define I_PK_ADD(i) "v_pk_add_f32 %" #i ", %" #i ", %8\n"
+#define I_PK_MUL(i) "v_pk_mul_f32 %" #i ", %" #i ", %8\n"
+#define I_PK_FMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n"
+#define I_PK_ADD_NEG(i) "v_pk_add_f32 %" #i ", %" #i ", %8 neg_lo:[0,1] neg_hi:[1,0]\n"
+#define I_PK_MUL_SWAP(i) "v_pk_mul_f32 %" #i ", %" #i ", %8 op_sel:[0,1] op_sel_hi:[1,0]\n"
+KERNEL_PK(k_pk_add, EACH_PK(I_PK_ADD))
+KERNEL_PK(k_pk_mul, EACH_PK(I_PK_MUL))
+KERNEL_PK(k_pk_fma, EACH_PK(I_PK_FMA))
+KERNEL_PK(k_pk_add_neg, EACH_PK(I_PK_ADD_NEG))
+KERNEL_PK(k_pk_mul_swap, EACH_PK(I_PK_MUL_SWAP))
+// ---- run-length sweep: N plain VOP2 f32 additions (on up to eight independent registers), then ONE instruction of another class, repeated.
+// Which class takes the SIMD out of its two-cycle rate, and how long a pure run has to be before the rate is back
+#define R1 I_ADDF(0)
+#define R2 I_ADDF(0) I_MULF(1)
+#define R3 I_ADDF(0) I_MULF(1) I_ADDF(2)
+#define R4 I_ADDF(0) I_MULF(1) I_ADDF(2) I_MULF(3)
+#define R6 R4 I_ADDF(4) I_MULF(5)
+#define R8 R4 I_ADDF(4) I_MULF(5) I_ADDF(6) I_MULF(7)
+#define R12 R8 R4
+#define R16 R8 R8
+#define R24 R8 R8 R8
+#define R32 R16 R16
+#define X_CND "v_cndmask_b32_e64 %7, %7, %8, s[20:21]\n"
+#define X_DPP "v_mov_b32_dpp %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define X_VOP3 "v_add3_u32 %7, %7, %8, %9\n"
+#define X_CMP "v_cmp_lt_u32_e64 s[20:21], %7, %8\n"
+#define X_LDS "ds_read_b32 %7, %9\n"
+#define X_NONE ""
+#define RUNBLOCK(R, X) asm volatile(".rept 16\n" R X ".endr\n" OPERANDS);
+#define RUN_KERNELS(TAG, X)                        \
+    KERNEL(k_run_##TAG##_1, SETMASKS, RUNBLOCK(R1, X))   \
+    KERNEL(k_run_##TAG##_2, SETMASKS, RUNBLOCK(R2, X))   \
+    KERNEL(k_run_##TAG##_3, SETMASKS, RUNBLOCK(R3, X))   \
+    KERNEL(k_run_##TAG##_4, SETMASKS, RUNBLOCK(R4, X))   \
+    KERNEL(k_run_##TAG##_6, SETMASKS, RUNBLOCK(R6, X))   \
+    KERNEL(k_run_##TAG##_8, SETMASKS, RUNBLOCK(R8, X))   \
+    KERNEL(k_run_##TAG##_12, SETMASKS, RUNBLOCK(R12, X)) \
+    KERNEL(k_run_##TAG##_16, SETMASKS, RUNBLOCK(R16, X)) \
+    KERNEL(k_run_##TAG##_24, SETMASKS, RUNBLOCK(R24, X)) \
+    KERNEL(k_run_##TAG##_32, SETMASKS, RUNBLOCK(R32, X))
+RUN_KERNELS(none, X_NONE)
+RUN_KERNELS(cnd, X_CND)
+RUN_KERNELS(dpp, X_DPP)
+RUN_KERNELS(vop3, X_VOP3)
+RUN_KERNELS(cmp, X_CMP)
+RUN_KERNELS(lds, X_LDS)
 // ---- scalar side: mask logic, a not-taken branch, an exec-masked region, wait states
 #define I_SNOP(i) "s_nop 1\n"
 KERNEL(k_snop, NOPRE, EACH(I_SNOP))
@@ -149,6 +253,18 @@ int main() {
         {"v_add_u32", k_add, 1, ""}, {"v_add3_u32", k_add3, 1, ""}, {"v_lshl_add_u32", k_lshladd, 1, ""}, {"v_bfi_b32", k_bfi, 1, ""},
         {"v_bfe_i32", k_bfe, 1, ""}, {"v_ashrrev_i32", k_ashr, 1, ""}, {"v_and_or_b32", k_andor, 1, ""}, {"v_mad_u32_u24", k_mad24, 1, ""},
         {"v_mul_u32_u24_sdwa", k_mul24_sdwa, 1, ""}, {"v_addc_co_u32_e64", k_addc, 1, ""}, {"v_mov_b32", k_mov, 1, ""},
+        {"v_add_f32", k_addf, 1, "VOP2"}, {"v_sub_f32", k_subf, 1, "VOP2"}, {"v_mul_f32", k_mulf, 1, "VOP2"}, {"v_max_f32", k_maxf, 1, "VOP2"},
+        {"v_fmac_f32", k_fmacf, 1, "VOP2 (fused: not usable where the reference rounds twice)"}, {"v_fma_f32", k_fmaf, 1, "VOP3"},
+        {"v_add_f32_e64", k_addf_e64, 1, "the VOP3 encoding of a plain add"}, {"v_add_f32_e64 with a neg modifier", k_addf_neg, 1, "VOP3 (source modifier)"},
+        {"v_mul_f32_e64", k_mulf_e64, 1, "the VOP3 encoding of a plain multiply"},
+        {"v_add_f32_dpp quad_perm", k_addf_dpp, 1, "a DPP operand on an arithmetic instruction"}, {"v_mov_b32_dpp row_shr", k_mov_dpp, 1, ""},
+        {"v_cvt_f32_i32", k_cvt, 1, "VOP1"}, {"v_rcp_f32", k_rcp, 1, "VOP1, transcendental unit"}, {"v_mul_lo_u32", k_mullo, 1, "VOP3"},
+        {"v_lshlrev_b32", k_lshl, 1, "VOP2"}, {"v_and_b32", k_and, 1, "VOP2"}, {"v_xor_b32", k_xor, 1, "VOP2"}, {"v_sub_u32", k_subu, 1, "VOP2"},
+        {"v_max_i32", k_maxi, 1, "VOP2"},
+        {"v_pk_add_f32", k_pk_add, 1, "two f32 additions per lane"}, {"v_pk_mul_f32", k_pk_mul, 1, "two f32 multiplications per lane"},
+        {"v_pk_fma_f32", k_pk_fma, 1, "two fused multiply-adds per lane"},
+        {"v_pk_add_f32 neg_lo:[0,1] neg_hi:[1,0]", k_pk_add_neg, 1, "add in one half, subtract in the other (a butterfly's re / im)"},
+        {"v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]", k_pk_mul_swap, 1, "second operand's halves swapped (the cross terms of a complex product)"},
         {"s_nop 1", k_snop, 1, ""},
         {"v_add_u32 + s_cbranch_execz (not taken)", k_add_branch, 2, ""},
         {"ds_read_b32 x8 then one wait", k_dsr32, 8, "eight reads in flight; per read"},
@@ -161,9 +277,9 @@ int main() {
     printf("  \"idioms\": [\n");
     bool first = true;
     for (const Case &c : cases) {
-        double per[2] = {0, 0};
+        double per[3] = {0, 0, 0};
         int wi = 0;
-        for (int W : {1, 4}) {
+        for (int W : {1, 2, 4}) {
             const int threads = 64 * 4 * W;
             const int grid = cus, waves = grid * (threads / 64);
             for (int rep = 0; rep < 3; rep++) {
@@ -178,10 +294,41 @@ int main() {
             per[wi++] = ((double)h.back() - 32.0 * iters) / (W * idioms);
         }
         const double n = 1.0;
-        printf("%s    {\"idiom\": \"%s\", \"instructions\": %d, \"cycles_lone_wave\": %.2f, \"cycles_per_wave_at_4_per_simd\": %.2f, \"note\": \"%s\"}",
-               first ? "" : ",\n", c.name, c.instrs_per_idiom, per[0] / n, per[1] / n, c.what);
+        printf("%s    {\"idiom\": \"%s\", \"instructions\": %d, \"cycles_lone_wave\": %.2f, \"cycles_per_wave_at_2_per_simd\": %.2f, \"cycles_per_wave_at_4_per_simd\": %.2f, \"note\": \"%s\"}",
+               first ? "" : ",\n", c.name, c.instrs_per_idiom, per[0] / n, per[1] / n, per[2] / n, c.what);
         first = false;
     }
-    printf("\n  ]\n}\n");
+    printf("\n  ],\n");
+    // run-length sweep
+    struct Run { const char *tag; const char *what; kern_t k[10]; };
+    const int lens[10] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+#define RUNS(TAG) {k_run_##TAG##_1, k_run_##TAG##_2, k_run_##TAG##_3, k_run_##TAG##_4, k_run_##TAG##_6, k_run_##TAG##_8, k_run_##TAG##_12, k_run_##TAG##_16, k_run_##TAG##_24, k_run_##TAG##_32}
+    const Run runs[] = {{"none", "nothing (the pure run)", RUNS(none)}, {"v_cndmask_b32_e64", "a select on an SGPR pair", RUNS(cnd)},
+                        {"v_mov_b32_dpp", "a DPP move", RUNS(dpp)}, {"v_add3_u32", "a three-operand VOP3", RUNS(vop3)},
+                        {"v_cmp_lt_u32_e64", "a compare into an SGPR pair", RUNS(cmp)}, {"ds_read_b32", "an LDS read (not waited for)", RUNS(lds)}};
+    printf("  \"run_length_sweep\": {\"what\": \"N alternating v_add_f32 / v_mul_f32 (VOP2, independent registers) followed by ONE instruction of another class, the block repeated 16 x 500 times; cycles per BLOCK and per instruction by waves per SIMD\", \"rows\": [\n");
+    first = true;
+    for (const Run &r : runs)
+        for (int li = 0; li < 10; li++) {
+            const int n = lens[li], per_block = n + (r.tag[0] == 'n' ? 0 : 1);
+            double cyc[3];
+            int wi = 0;
+            for (int W : {1, 2, 4}) {
+                const int threads = 64 * 4 * W, waves = cus * (threads / 64);
+                for (int rep = 0; rep < 2; rep++) {
+                    hipLaunchKernelGGL(r.k[li], dim3(cus), dim3(threads), 0, nullptr, d_cycles, d_sink, iters);
+                    CHECK(hipGetLastError());
+                    CHECK(hipDeviceSynchronize());
+                }
+                std::vector<unsigned long long> h((size_t)waves);
+                CHECK(hipMemcpy(h.data(), d_cycles, sizeof(unsigned long long) * (size_t)waves, hipMemcpyDeviceToHost));
+                std::sort(h.begin(), h.end());
+                cyc[wi++] = ((double)h.back() - 32.0 * iters) / (W * 16.0 * iters);
+            }
+            printf("%s    {\"other\": \"%s\", \"run\": %d, \"cycles_per_block\": {\"1\": %.2f, \"2\": %.2f, \"4\": %.2f}, \"cycles_per_instruction\": {\"1\": %.2f, \"2\": %.2f, \"4\": %.2f}}",
+                   first ? "" : ",\n", r.tag, n, cyc[0], cyc[1], cyc[2], cyc[0] / per_block, cyc[1] / per_block, cyc[2] / per_block);
+            first = false;
+        }
+    printf("\n  ]}\n}\n");
     return 0;
 }

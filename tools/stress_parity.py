@@ -27,6 +27,9 @@ CASES = [  # fs_hz, frame_us, nbytes
     (44100, 10000, 100), (32000, 10000, 80), (32000, 7500, 60), (24000, 10000, 60), (24000, 7500, 45), (16000, 10000, 40),
     (16000, 7500, 30), (16000, 10000, 120),
 ]
+# 8 kHz: the reference has a decoder and no encoder (the constructor panics, encoder/bandwidth_detector.rs:36-37) -- decode direction only, on
+# streams the ORACLE's encoder produced (its early-return path, bandwidth_detector.rs:66-71), damage included
+DECODE_ONLY = [(8000, 10000, 30), (8000, 7500, 23), (8000, 10000, 60)]
 
 
 def make_mixed(synth, S, T, nf, fs, rnd):
@@ -55,6 +58,7 @@ def main():
     ap.add_argument("--shapes", default="",
                     help="comma-separated launch shapes STREAMSxFRAMES that the rounds cycle through (round r uses shape r mod n), e.g. "
                          "16384x4,2048x18,4096x16: the 65 536-frame launch the benchmark times among them; default: --streams x --frames")
+    ap.add_argument("--only-8khz", action="store_true", help="run the 8 kHz decode-only cases alone")
     ap.add_argument("--split", default="",
                     help="comma-separated launch lengths (frames) a round's frames are cut into, cycled, the state carried in the handles from "
                          "launch to launch, e.g. 1,2,3,5: launches shorter than, as long as and longer than the decoder's filter ring")
@@ -87,32 +91,34 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     rows, bad, timeouts = [], 0, 0
     t0 = time.time()
-    for fs, us, nbytes in CASES:
+    for fs, us, nbytes in ([] if a.only_8khz else CASES) + DECODE_ONLY:
         nf = (fs if fs != 44100 else 48000) * us // 1000000
+        both = (fs, us, nbytes) not in DECODE_ONLY
         handles = {}
         enc_bad = dec_bad = damaged = frames = 0
         for rnd in range(a.rounds):
             S, T = shapes[rnd % len(shapes)]
             if S not in handles:
-                handles[S] = (pkg.Lc3Encoder(S, us, fs), pkg.Lc3Decoder(S, us, fs))
+                handles[S] = (pkg.Lc3Encoder(S, us, fs) if both else None, pkg.Lc3Decoder(S, us, fs))
             enc, dec = handles[S]
             frames += S * T
             pcm = make_mixed(synth, S, T, nf, fs, rnd)
-            enc.reset()
             dec.reset()
-            d_pcm = torch.from_numpy(pcm).cuda()
-            d_out = torch.zeros((S, T, nbytes), dtype=torch.uint8, device="cuda")
-            for t_i, n_i in launches(T):  # state carried in the handle from launch to launch
-                if n_i == T:
-                    enc.encode(d_pcm, d_out, nbytes, T, stream=st)
-                else:
-                    part = torch.zeros((S, n_i, nbytes), dtype=torch.uint8, device="cuda")
-                    enc.encode(d_pcm[:, t_i:t_i + n_i].contiguous(), part, nbytes, n_i, stream=st)
-                    d_out[:, t_i:t_i + n_i] = part
-            torch.cuda.synchronize()
-            got = d_out.cpu().numpy()
             ref = O.encode_batch(pcm, nbytes, fs, us, threads=threads)
-            enc_bad += int((got != ref).any(axis=2).sum())
+            if both:
+                enc.reset()
+                d_pcm = torch.from_numpy(pcm).cuda()
+                d_out = torch.zeros((S, T, nbytes), dtype=torch.uint8, device="cuda")
+                for t_i, n_i in launches(T):  # state carried in the handle from launch to launch
+                    if n_i == T:
+                        enc.encode(d_pcm, d_out, nbytes, T, stream=st)
+                    else:
+                        part = torch.zeros((S, n_i, nbytes), dtype=torch.uint8, device="cuda")
+                        enc.encode(d_pcm[:, t_i:t_i + n_i].contiguous(), part, nbytes, n_i, stream=st)
+                        d_out[:, t_i:t_i + n_i] = part
+                torch.cuda.synchronize()
+                got = d_out.cpu().numpy()
+                enc_bad += int((got != ref).any(axis=2).sum())
             # decode direction: the oracle's bytes, a share of them damaged -- the same bytes for both decoders, except for frames
             # handed to the GPU intact but FLAGGED bad, which the oracle receives with an out-of-range bandwidth index instead
             # (48 kHz: three bandwidth bits, 7 > 4; side_info_reader.rs:43-50), so that both conceal them
@@ -146,9 +152,10 @@ def main():
             dec_bad += int((d_dec.cpu().numpy() != ref_pcm).any(axis=2).sum())
         # the producer / consumer pair kernels' give-up counters (include/lc3gpu.h): a pair whose partner never answered would have
         # produced concealed / zero-filled frames -- which the comparison above also catches -- but the counter says WHY
-        case_timeouts = sum(e.pair_timeouts() + d.pair_timeouts() for e, d in handles.values())
+        case_timeouts = sum((e.pair_timeouts() if e is not None else 0) + d.pair_timeouts() for e, d in handles.values())
         timeouts += case_timeouts
-        rows.append({"fs_hz": fs, "frame_us": us, "nbytes": nbytes, "frames": frames, "encode_frames_differing": enc_bad,
+        rows.append({"fs_hz": fs, "frame_us": us, "nbytes": nbytes, "frames": frames, "directions": "encode + decode" if both else "decode only (oracle-encoded)",
+                     "encode_frames_differing": enc_bad,
                      "decode_frames_differing": dec_bad, "decode_frames_damaged": damaged, "pair_timeouts": case_timeouts})
         bad += enc_bad + dec_bad
         print(f"{fs} {us} {nbytes}: {frames} frames, enc diff {enc_bad}, dec diff {dec_bad}, pair time-outs {case_timeouts}", file=sys.stderr)
