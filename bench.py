@@ -382,7 +382,7 @@ class GpuEngine:
         if name == "pipeline" and not hasattr(self, "pl"):
             # the library's own arrangement (lc3gpu_pipeline_*): handles, streams, priorities and events live behind the C ABI
             self.pl = self.pkg.Lc3Pipeline(self.S, self.pkg.FrameDuration.TenMs, self.pkg.SamplingFrequency.Hz48000)
-            self.s_mark = self.torch.cuda.Stream()  # step marks / fences: a stream of the caller's that joins the pipeline
+
         if self.mode == "roundtrip" and self.NP == 1:
             self.encs[0].stage_event(self.pkg.ENC_STAGE_BACK, self.ev_back if name == "staggered" else None)
         if name.startswith("split:") and name not in self.splits:
@@ -517,14 +517,21 @@ class GpuEngine:
         marks bracket one step"""
         if self.NP == 1:
             e = self.torch.cuda.Event(enable_timing=True)
-            e.record(self._last_stream())
+            self._record(e)
             self.marks.append(e)
 
-    def _last_stream(self):
-        """the stream the step's last call was queued on (the pipeline object: a stream of ours that waits for everything submitted)"""
+    def _record(self, e):
+        """an event behind the step just queued"""
         if self.arrangement == "pipeline":
-            self.pl.join(self.s_mark.cuda_stream)
-            return self.s_mark
+            # lc3gpu_pipeline_mark: on the pipeline's own last stream.  (NOT join + a stream of ours: a fifth stream that waits for events
+            # shares a hardware queue with one of the pipeline's four and holds it up -- measured 52.4 against 58 M frames/s)
+            e.record(self.torch.cuda.current_stream())  # torch creates the HIP event at its first record; re-recorded by the library below
+            self.pl.mark(e)
+        else:
+            e.record(self._last_stream())
+
+    def _last_stream(self):
+        """the stream the step's last call was queued on"""
         if self.arrangement.startswith("split:"):
             return self.splits[self.arrangement][-1]["s_dec"]
         return self.s_dec if self.arrangement != "single" else self.hs[0]
@@ -637,7 +644,7 @@ class GpuEngine:
                     pkg.clock_probe(slots[probes], stream=s_probe.cuda_stream, spin=50000)
                     probes += 1
                 e = torch.cuda.Event()
-                e.record(self._last_stream())
+                self._record(e)
                 fences.append(e)
                 if len(fences) > depth // every:
                     fences.pop(0).synchronize()  # the host stays at most `depth` steps ahead of the chip
@@ -1017,7 +1024,7 @@ def run_rank(args):
         other_modes["tick_carried_65536x1"] = shape_bench(torch, pkg, eng.d_full, pcm_host, 65536, 1, args.steps, args.warmup)
         other_modes["mode_b_streaming_4096x16"] = shape_bench(torch, pkg, eng.d_full, pcm_host, 4096, 16, args.steps, args.warmup)
         sweep = []
-        for T2 in (2, 8, 32):
+        for T2 in (2, 4, 8, 32):
             r = shape_bench(torch, pkg, eng.d_full, pcm_host, 65536 // T2, T2, args.steps, args.warmup, arrangements=("pipeline",))
             sweep.append({"frames_per_stream_per_step": T2, "streams": 65536 // T2, "value": r["value"], "ms_per_step": r["pipeline"]["ms_per_step"],
                           "kernel_ms": r["pipeline"]["kernel_ms"], "parity_mismatches": r["pipeline"].get("parity_mismatches")})

@@ -106,6 +106,8 @@ def build_native(force=False, verbose=False):
     srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".h", ".hip", ".cpp"))]
     srcs += [os.path.join(_ROOT, "include", "lc3gpu.h"), os.path.join(_ROOT, "tables", "lc3_tables.h")]
     src_hash = _sources_hash(srcs)  # taken BEFORE anything is compiled: what the objects below are guaranteed to be at least as old as
+    # (the HIP translation units do not see the host-only sources: an edit there relinks the library without recompiling them)
+    dev_hash = _sources_hash([p_ for p_ in srcs if not p_.endswith(".cpp")])
     extra = os.environ.get("LC3_HIPCC_EXTRA", "").split()  # compiler experiments
     extra_main = os.environ.get("LC3_HIPCC_EXTRA_MAIN", "").split()
     if (extra or extra_main) and not os.environ.get("LC3GPU_LIB"):
@@ -158,7 +160,7 @@ def build_native(force=False, verbose=False):
         return obj
 
     def unit_sig(u):
-        return "sources=%s flags=%s\n" % (src_hash, " ".join(extra_main) if u == (0, 0) else "")
+        return "sources=%s flags=%s\n" % (dev_hash, " ".join(extra_main) if u == (0, 0) else "")
 
     def fresh(u):
         o = unit_obj(u)
@@ -293,6 +295,7 @@ def load_library():
     L.lc3gpu_pipeline_wait.argtypes = [vp]
     L.lc3gpu_pipeline_join.argtypes = [vp, vp]
     L.lc3gpu_pipeline_follow.argtypes = [vp, vp]
+    L.lc3gpu_pipeline_mark.argtypes = [vp, vp]
     L.lc3gpu_pipeline_groups.argtypes = [vp]
     L.lc3gpu_pipeline_group.argtypes = [vp, i, ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.lc3gpu_pipeline_last_hip_error.argtypes = [vp]
@@ -314,7 +317,7 @@ ABI_SYMBOLS = [
     "lc3gpu_encoder_stage_event", "lc3gpu_decoder_stage_event", "lc3gpu_encoder_pair_timeouts", "lc3gpu_decoder_pair_timeouts",
     "lc3gpu_encoder_debug_pair_giveup", "lc3gpu_decoder_debug_pair_giveup", "lc3gpu_encode_host", "lc3gpu_decode_host", "lc3gpu_host_alloc",
     "lc3gpu_host_free", "lc3gpu_pipeline_create", "lc3gpu_pipeline_destroy", "lc3gpu_pipeline_reset", "lc3gpu_pipeline_submit",
-    "lc3gpu_pipeline_encode", "lc3gpu_pipeline_decode", "lc3gpu_pipeline_wait", "lc3gpu_pipeline_join", "lc3gpu_pipeline_follow",
+    "lc3gpu_pipeline_encode", "lc3gpu_pipeline_decode", "lc3gpu_pipeline_wait", "lc3gpu_pipeline_join", "lc3gpu_pipeline_follow", "lc3gpu_pipeline_mark",
     "lc3gpu_pipeline_groups", "lc3gpu_pipeline_group", "lc3gpu_pipeline_last_hip_error",
 ]
 
@@ -828,6 +831,10 @@ class Lc3Pipeline:
 
     def follow(self, stream=None):
         self._check(self._L.lc3gpu_pipeline_follow(self._h, _ptr(stream)), "pipeline_follow")
+
+    def mark(self, event):
+        """records `event` (torch.cuda.Event that has been recorded once, or a hipEvent_t) behind the last group's latest work"""
+        self._check(self._L.lc3gpu_pipeline_mark(self._h, _event_handle(event)), "pipeline_mark")
 
     def reset(self):
         self._check(self._L.lc3gpu_pipeline_reset(self._h), "pipeline_reset")

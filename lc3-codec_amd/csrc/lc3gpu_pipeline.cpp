@@ -243,6 +243,14 @@ int lc3gpu_pipeline_join(lc3gpu_pipeline *p, void *hip_stream) {
     return LC3GPU_OK;
 }
 
+int lc3gpu_pipeline_mark(lc3gpu_pipeline *p, void *hip_event) {
+    if (!p || !hip_event) return LC3GPU_EINVAL;
+    DeviceGuard dg(p->device);
+    const Group &q = p->groups.back();
+    PL_HIP(p, hipEventRecord((hipEvent_t)hip_event, q.last_dec >= 0 ? q.s_dec : q.s_enc));
+    return LC3GPU_OK;
+}
+
 int lc3gpu_pipeline_follow(lc3gpu_pipeline *p, void *hip_stream) {
     if (!p) return LC3GPU_EINVAL;
     DeviceGuard dg(p->device);

@@ -338,7 +338,7 @@ def test_long_launches_keep_the_post_filter_memories_for_a_later_rate():
 
 # ---------------------------------------------------------------- corrupt frames / PLC
 def _loss_bursts_check():
-    for fs, us, nbytes in ((48000, 10000, 150), (32000, 7500, 61)):
+    for fs, us, nbytes in ((48000, 10000, 150), (48000, 7500, 113)):  # (three bandwidth bits: `|= 7` is an out-of-range index)
         cfg = pkg.Lc3Config(fs, us)
         S, T = 12, 40
         pcm = synth.make_pcm(S, T, cfg.nf, fs, seed=37)
@@ -392,7 +392,7 @@ def test_loss_bursts_of_nine_to_thirteen_frames_across_launches():
     frames 4 .. 8 of the run).  Runs of 9 .. 13 lost frames -- unparsable side information, garbage and external flags mixed -- that
     cross launch boundaries (launches of 5, 3, 7, 1, 6, 4 ... frames: `num_lost_frames` and `alpha` travel in the state blob), in the
     form full batches use (reconstruction on the parser's lane) and the one small launches use (in the synthesis kernel), at 48 kHz /
-    10 ms and at 32 kHz / 7.5 ms; the size rule's own choice as well."""
+    10 ms and at 48 kHz / 7.5 ms; the size rule's own choice as well."""
     import os
     import subprocess
     import sys

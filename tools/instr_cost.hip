@@ -22,7 +22,7 @@
     } while (0)
 
 #define REP8(x) x
-#define OPERANDS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "v"(lds) : "vcc", "s20", "s21", "s22", "s23", "memory"
+#define OPERANDS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "v"(lds), "v"(pq) : "vcc", "s20", "s21", "s22", "s23", "s24", "memory"
 // eight copies of an idiom on eight independent registers, 32 times: 256 idioms per block
 #define BLOCK(S0, S1, S2, S3, S4, S5, S6, S7) REP8(asm volatile(".rept 32\n" S0 S1 S2 S3 S4 S5 S6 S7 ".endr\n" OPERANDS);)
 #define EACH(OP) BLOCK(OP(0), OP(1), OP(2), OP(3), OP(4), OP(5), OP(6), OP(7))
@@ -33,6 +33,7 @@
         lds_buf[threadIdx.x & 1023] = threadIdx.x;                                                          \
         unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
         const unsigned k = 37u, lds = (threadIdx.x & 63) * 4;  /* one bank per lane */                                             \
+        const unsigned long long pq = 0x3f8000003f800000ull + threadIdx.x;  /* a register PAIR (%10): packed-f32 operand of the mixes */    \
         __syncthreads();                                                                                    \
         PRE;                                                                                                \
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
@@ -187,7 +188,38 @@ KERNEL_PK(k_pk_mul_swap, EACH_PK(I_PK_MUL_SWAP))
 #define X_CMP "v_cmp_lt_u32_e64 s[20:21], %7, %8\n"
 #define X_LDS "ds_read_b32 %7, %9\n"
 #define X_NONE ""
+// (second batch: what else shares a wave's instruction stream with the arithmetic)
+#define X_DPP_QUAD "v_mov_b32_dpp %7, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define X_DPP_ADD "v_add_f32_dpp %7, %8, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define X_DPP_BC "v_mov_b32_dpp %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define X_DPP_OWN "v_mov_b32_dpp %7, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define X_DPP_WSHR "v_mov_b32_dpp %7, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define X_DPP_NOP "v_mov_b32_dpp %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+#define X_READLANE "v_readlane_b32 s24, %7, 3\n"
+#define X_READFIRST "v_readfirstlane_b32 s24, %7\n"
+#define X_BPERM "ds_bpermute_b32 %7, %9, %8\n"
+#define X_SWIZZLE "ds_swizzle_b32 %7, %8 offset:swizzle(SWAP,1)\n"
+#define X_PERMLANE "v_permlane32_swap_b32 %7, %6\n"
+#define X_SDWA "v_mov_b32_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+#define X_CVT "v_cvt_f32_i32 %7, %7\n"
+#define X_RCP "v_rcp_f32 %7, %7\n"
+#define X_MAXF "v_max_f32 %7, %7, %8\n"
+#define X_LSHL "v_lshlrev_b32 %7, 3, %7\n"
+#define X_PK "v_pk_add_f32 %10, %10, %10\n"
+#define X_PK2 "v_pk_mul_f32 %10, %10, %10\n v_pk_add_f32 %10, %10, %10\n"
+#define X_SALU "s_add_u32 s24, s24, 1\n"
+#define X_SALU4 "s_add_u32 s24, s24, 1\n s_and_b32 s24, s24, 0xff\n s_lshl_b32 s24, s24, 1\n s_cmp_lg_u32 s24, 0\n"
+#define X_WAIT "s_waitcnt lgkmcnt(0)\n"
+#define X_CND_VCC "v_cndmask_b32_e32 %7, %7, %8, vcc\n"
+#define X_MOV "v_mov_b32 %7, %8\n"
+#define R64 R32 R32
+#define R128 R64 R64
 #define RUNBLOCK(R, X) asm volatile(".rept 16\n" R X ".endr\n" OPERANDS);
+#define RUN4_KERNELS(TAG, X)                             \
+    KERNEL(k_r4_##TAG##_2, SETMASKS, RUNBLOCK(R2, X))    \
+    KERNEL(k_r4_##TAG##_8, SETMASKS, RUNBLOCK(R8, X))    \
+    KERNEL(k_r4_##TAG##_32, SETMASKS, RUNBLOCK(R32, X))  \
+    KERNEL(k_r4_##TAG##_128, SETMASKS, RUNBLOCK(R128, X))
 #define RUN_KERNELS(TAG, X)                        \
     KERNEL(k_run_##TAG##_1, SETMASKS, RUNBLOCK(R1, X))   \
     KERNEL(k_run_##TAG##_2, SETMASKS, RUNBLOCK(R2, X))   \
@@ -205,6 +237,30 @@ RUN_KERNELS(dpp, X_DPP)
 RUN_KERNELS(vop3, X_VOP3)
 RUN_KERNELS(cmp, X_CMP)
 RUN_KERNELS(lds, X_LDS)
+RUN4_KERNELS(dppq, X_DPP_QUAD)
+RUN4_KERNELS(dppadd, X_DPP_ADD)
+RUN4_KERNELS(dppbc, X_DPP_BC)
+RUN4_KERNELS(dppown, X_DPP_OWN)
+RUN4_KERNELS(dpp, X_DPP)
+RUN4_KERNELS(dppwshr, X_DPP_WSHR)
+RUN4_KERNELS(dppnop, X_DPP_NOP)
+RUN4_KERNELS(readlane, X_READLANE)
+RUN4_KERNELS(readfirst, X_READFIRST)
+RUN4_KERNELS(bperm, X_BPERM)
+RUN4_KERNELS(swizzle, X_SWIZZLE)
+RUN4_KERNELS(permlane, X_PERMLANE)
+RUN4_KERNELS(sdwa, X_SDWA)
+RUN4_KERNELS(cvt, X_CVT)
+RUN4_KERNELS(rcp, X_RCP)
+RUN4_KERNELS(maxf, X_MAXF)
+RUN4_KERNELS(lshl, X_LSHL)
+RUN4_KERNELS(pk, X_PK)
+RUN4_KERNELS(pk2, X_PK2)
+RUN4_KERNELS(salu, X_SALU)
+RUN4_KERNELS(salu4, X_SALU4)
+RUN4_KERNELS(wait, X_WAIT)
+RUN4_KERNELS(cndvcc, X_CND_VCC)
+RUN4_KERNELS(mov, X_MOV)
 // ---- scalar side: mask logic, a not-taken branch, an exec-masked region, wait states
 #define I_SNOP(i) "s_nop 1\n"
 KERNEL(k_snop, NOPRE, EACH(I_SNOP))
@@ -327,6 +383,43 @@ int main() {
             }
             printf("%s    {\"other\": \"%s\", \"run\": %d, \"cycles_per_block\": {\"1\": %.2f, \"2\": %.2f, \"4\": %.2f}, \"cycles_per_instruction\": {\"1\": %.2f, \"2\": %.2f, \"4\": %.2f}}",
                    first ? "" : ",\n", r.tag, n, cyc[0], cyc[1], cyc[2], cyc[0] / per_block, cyc[1] / per_block, cyc[2] / per_block);
+            first = false;
+        }
+    printf("\n  ]},\n");
+    // second batch: runs of 2 / 8 / 32 / 128 with one (or a few) instructions of many more classes
+    struct Run4 { const char *tag; int extra; kern_t k[4]; };
+    const int lens4[4] = {2, 8, 32, 128};
+#define RUNS4(TAG) {k_r4_##TAG##_2, k_r4_##TAG##_8, k_r4_##TAG##_32, k_r4_##TAG##_128}
+    const Run4 runs4[] = {
+        {"v_mov_b32_dpp row_shr:1 (source never written)", 1, RUNS4(dpp)}, {"v_mov_b32_dpp quad_perm", 1, RUNS4(dppq)}, {"v_add_f32_dpp quad_perm", 1, RUNS4(dppadd)},
+        {"v_mov_b32_dpp row_shr:1 bound_ctrl", 1, RUNS4(dppbc)}, {"v_mov_b32_dpp row_shr:1 of a register the run just wrote", 1, RUNS4(dppown)},
+        {"v_mov_b32_dpp wave_shr:1 (the kernels' neighbour exchange)", 1, RUNS4(dppwshr)}, {"v_mov_b32_dpp row_shr:1 + s_nop 1", 2, RUNS4(dppnop)},
+        {"v_readlane_b32", 1, RUNS4(readlane)}, {"v_readfirstlane_b32", 1, RUNS4(readfirst)}, {"ds_bpermute_b32 (not waited for)", 1, RUNS4(bperm)},
+        {"ds_swizzle_b32 (not waited for)", 1, RUNS4(swizzle)}, {"v_permlane32_swap", 1, RUNS4(permlane)}, {"v_mov_b32_sdwa", 1, RUNS4(sdwa)},
+        {"v_cvt_f32_i32", 1, RUNS4(cvt)}, {"v_rcp_f32", 1, RUNS4(rcp)}, {"v_max_f32", 1, RUNS4(maxf)}, {"v_lshlrev_b32", 1, RUNS4(lshl)},
+        {"v_pk_add_f32", 1, RUNS4(pk)}, {"v_pk_mul_f32 + v_pk_add_f32", 2, RUNS4(pk2)}, {"s_add_u32", 1, RUNS4(salu)}, {"four SALU instructions", 4, RUNS4(salu4)},
+        {"s_waitcnt lgkmcnt(0) (nothing outstanding)", 1, RUNS4(wait)}, {"v_cndmask_b32_e32 on vcc", 1, RUNS4(cndvcc)}, {"v_mov_b32", 1, RUNS4(mov)}};
+    printf("  \"run_length_sweep_2\": {\"what\": \"as above with runs of 2 / 8 / 32 / 128 and more classes of the other instruction(s); cycles per block by waves per SIMD, and beside them what the block would cost at 2 cycles per VOP2 of the run alone (2 N)\", \"rows\": [\n");
+    first = true;
+    for (const Run4 &r : runs4)
+        for (int li = 0; li < 4; li++) {
+            const int n = lens4[li];
+            double cyc[3];
+            int wi = 0;
+            for (int W : {1, 2, 4}) {
+                const int threads = 64 * 4 * W, waves = cus * (threads / 64);
+                for (int rep = 0; rep < 2; rep++) {
+                    hipLaunchKernelGGL(r.k[li], dim3(cus), dim3(threads), 0, nullptr, d_cycles, d_sink, iters);
+                    CHECK(hipGetLastError());
+                    CHECK(hipDeviceSynchronize());
+                }
+                std::vector<unsigned long long> h((size_t)waves);
+                CHECK(hipMemcpy(h.data(), d_cycles, sizeof(unsigned long long) * (size_t)waves, hipMemcpyDeviceToHost));
+                std::sort(h.begin(), h.end());
+                cyc[wi++] = ((double)h.back() - 32.0 * iters) / (W * 16.0 * iters);
+            }
+            printf("%s    {\"other\": \"%s\", \"other_instructions\": %d, \"run\": %d, \"run_alone_at_2_cycles\": %d, \"cycles_per_block\": {\"1\": %.2f, \"2\": %.2f, \"4\": %.2f}}",
+                   first ? "" : ",\n", r.tag, r.extra, n, 2 * n, cyc[0], cyc[1], cyc[2]);
             first = false;
         }
     printf("\n  ]}\n}\n");

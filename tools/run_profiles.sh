@@ -10,10 +10,10 @@ OUT=gpurun_out
 mkdir -p $OUT/$TAG
 export TMPDIR=/tmp
 ROOT=$(pwd)
-BENCH="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-overlap-probe --sustain-seconds 0"
-TRACE="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-overlap-probe --sustain-seconds 0"  # (averages over 25 steps)
+BENCH="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-overlap-probe --no-other-modes --sustain-seconds 0"
+TRACE="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-overlap-probe --no-other-modes --sustain-seconds 0"  # (averages over 25 steps)
 python3 bench.py --no-cpu-baseline > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-# the default command (caller arrangement `quad`: up to four kernels share the chip, durations include that) ...
+# the default command (caller arrangement `pipeline`, the library's object: up to four kernels share the chip, durations include that) ...
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/$TAG/trace -o trace --output-format csv -- $TRACE > $ROOT/$OUT/$TAG/trace.log 2>&1 )
 find $OUT/$TAG/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
 # ... and the same steps on ONE caller stream: every kernel alone on the chip
