@@ -17,6 +17,10 @@
 // Buffers are planar (LC3GPU_LAYOUT_PLANAR): a group's channels are a contiguous slice of every buffer.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -33,6 +37,8 @@ struct Group {
     bool enc_rec[2] = {false, false}, dec_rec[2] = {false, false};
     // the byte range the decoder of that submission READS and the encoder of a later one may WRITE
     const uint8_t *bytes_lo[2] = {nullptr, nullptr}, *bytes_hi[2] = {nullptr, nullptr};
+    // the byte range the encoder of that submission WRITES and a decoder of the same or a later submission may read
+    const uint8_t *ebytes_lo[2] = {nullptr, nullptr}, *ebytes_hi[2] = {nullptr, nullptr};
     // the PCM range the decoder of that submission WRITES (a later encoder may read it: a transcoding chain)
     int last_enc = -1, last_dec = -1;  // slot of the latest encoder / decoder work (for wait / join)
 };
@@ -40,6 +46,7 @@ struct Group {
 
 struct lc3gpu_pipeline {
     int device = 0;
+    bool own_streams = false;  // the streams were created for this pipeline alone (LC3GPU_PIPELINE_OWN_STREAMS=1) and die with it
     int num_channels = 0, nf = 0;
     unsigned long long k = 0;  // submissions so far (slot = k & 1)
     std::vector<Group> groups;
@@ -69,6 +76,47 @@ struct DeviceGuard {
         }                                    \
     } while (0)
 
+// The pipeline streams of a device: created once per process and SHARED by every pipeline object on that device, never destroyed.
+// Why (profiles/r06_pipeline_stream_order.txt): the runtime maps HIP streams onto a few hardware queues per priority class (4 by default),
+// and a stream created when its class is full SHARES the least-used queue -- two chains on one queue run one behind the other.  Measured: the
+// first pipeline of a process 58.9 M frames/s, a second one created beside it (or beside any four live streams) 49.4 M, and it stays there;
+// a third that inherits the queues of a closed first one 59.2 M again.  With one set of streams per device every pipeline is "the first
+// one".  (Pipelines that are busy at the same time then share the streams, i.e. take turns: a process normally has one per device.)
+struct StreamSet {
+    std::vector<hipStream_t> enc, dec;
+};
+std::mutex g_pool_mutex;
+std::map<int, StreamSet> g_pool;
+
+bool env_is(const char *name, const char *value) {
+    const char *e = std::getenv(name);
+    return e && !std::strcmp(e, value);
+}
+// priorities: the encoder streams the greatest the device has; the decoder streams the default one, or (LC3GPU_PIPELINE_DEC_PRIO=low) the
+// least -- a class of hardware queues the application's own default-priority streams never touch
+void stream_priorities(int &prio_enc, int &prio_dec) {
+    int least = 0, greatest = 0;  // (numerically the greatest priority is the smallest number: -1 high, 0 default, 1 low on this platform)
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    prio_enc = greatest;
+    prio_dec = env_is("LC3GPU_PIPELINE_DEC_PRIO", "low") ? least : (greatest < 0 ? 0 : least);
+}
+// stream `g` of a role on the current device, from the shared set (created on demand) or fresh (own = true)
+int role_stream(int device, bool own, bool is_enc, int g, hipStream_t *out) {
+    int prio_enc, prio_dec;
+    stream_priorities(prio_enc, prio_dec);
+    const int prio = is_enc ? prio_enc : prio_dec;
+    if (own) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio) == hipSuccess ? LC3GPU_OK : LC3GPU_EHIP;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    std::vector<hipStream_t> &v = is_enc ? g_pool[device].enc : g_pool[device].dec;
+    while ((int)v.size() <= g) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) return LC3GPU_EHIP;
+        v.push_back(st);
+    }
+    *out = v[(size_t)g];
+    return LC3GPU_OK;
+}
+
 // the pipeline's next work on `s` waits for what lc3gpu_pipeline_follow recorded
 int follow_wait(lc3gpu_pipeline *p, hipStream_t s) {
     if (p->follow_pending) PL_HIP(p, hipStreamWaitEvent(s, p->ev_follow, 0));
@@ -92,8 +140,10 @@ int lc3gpu_pipeline_destroy(lc3gpu_pipeline *p) {
                 if (q.enc_done[i]) (void)hipEventDestroy(q.enc_done[i]);
                 if (q.dec_done[i]) (void)hipEventDestroy(q.dec_done[i]);
             }
-            if (q.s_enc) (void)hipStreamDestroy(q.s_enc);
-            if (q.s_dec) (void)hipStreamDestroy(q.s_dec);
+            if (p->own_streams) {  // (the shared streams of the device stay for the next pipeline)
+                if (q.s_enc) (void)hipStreamDestroy(q.s_enc);
+                if (q.s_dec) (void)hipStreamDestroy(q.s_dec);
+            }
         }
         if (p->ev_follow) (void)hipEventDestroy(p->ev_follow);
     }
@@ -120,11 +170,7 @@ int lc3gpu_pipeline_create(lc3gpu_pipeline **out, int num_channels, int frame_us
         delete p;
         return LC3GPU_EHIP;
     }
-    // (numerically the greatest priority is the smallest number: -1 high, 0 default, 1 low on this platform.  The decoder streams get the
-    // DEFAULT priority, not the least one -- what the measured arrangement used)
-    int prio_least = 0, prio_high = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_high);
-    const int prio_low = prio_high < 0 ? 0 : prio_least;
+    p->own_streams = env_is("LC3GPU_PIPELINE_OWN_STREAMS", "1");
     p->groups.resize((size_t)n_groups);
     rc = LC3GPU_OK;
     for (int g = 0; g < n_groups && rc == LC3GPU_OK; g++) {
@@ -133,10 +179,8 @@ int lc3gpu_pipeline_create(lc3gpu_pipeline **out, int num_channels, int frame_us
         q.first = lo;
         q.n = hi - lo;
         // The encoder chain (front half -> vector quantiser -> back half -> packer) is each group's critical path: its stream gets the
-        // higher HIP stream priority.  Streams of another priority also live on hardware queues of their own -- the runtime deals the
-        // streams of one priority onto a handful of queues, and two streams that share a queue run one behind the other.
-        if (hipStreamCreateWithPriority(&q.s_enc, hipStreamNonBlocking, prio_high) != hipSuccess ||
-            hipStreamCreateWithPriority(&q.s_dec, hipStreamNonBlocking, prio_low) != hipSuccess) {
+        // higher HIP stream priority.  Streams of another priority also live on hardware queues of their own (see StreamSet).
+        if (role_stream(p->device, p->own_streams, true, g, &q.s_enc) != LC3GPU_OK || role_stream(p->device, p->own_streams, false, g, &q.s_dec) != LC3GPU_OK) {
             rc = LC3GPU_EHIP;
             break;
         }
@@ -193,10 +237,14 @@ static int pipeline_step(lc3gpu_pipeline *p, int what, const int16_t *d_pcm, uin
             if (rc) return rc;
             PL_HIP(p, hipEventRecord(q.enc_done[b], q.s_enc));
             q.enc_rec[b] = true;
+            q.ebytes_lo[b] = bytes;
+            q.ebytes_hi[b] = bytes_end;
             q.last_enc = b;
         }
         if (what & 2) {
-            if (what & 1) PL_HIP(p, hipStreamWaitEvent(q.s_dec, q.enc_done[b], 0));
+            // the decoder reads what an encoder in flight writes: this submission's own (a round trip) or an earlier lc3gpu_pipeline_encode's
+            for (int i = 0; i < 2; i++)
+                if (q.enc_rec[i] && overlaps(bytes, bytes_end, q.ebytes_lo[i], q.ebytes_hi[i])) PL_HIP(p, hipStreamWaitEvent(q.s_dec, q.enc_done[i], 0));
             if ((rc = follow_wait(p, q.s_dec)) != 0) return rc;
             const uint8_t *bad = d_bad ? d_bad + f0 : nullptr;
             rc = lc3gpu_decode(q.dec, bytes, bad, d_pcm_out + f0 * (size_t)p->nf, nbytes, n_frames, q.s_dec);
