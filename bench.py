@@ -68,7 +68,7 @@ def parse_args(argv=None):
                          "an encoder handle and a decoder handle of its own, on 2 HIP streams (`pipelined` by itself) or on 1 (encode then decode): "
                          "`quad` = split:2+2, `tri` = split:2+1, `duo` = split:1+1.  The other arrangements are timed too and reported beside `value`")
     ap.add_argument("--also", type=arrangement_name, action="append", default=None,
-                    help="further arrangements to time after the timed region, beside single / pipelined / staggered (repeatable; default: duo, quad)")
+                    help="further arrangements to time after the timed region, beside single / pipelined / staggered (repeatable; default: none)")
     ap.add_argument("--sustain-seconds", type=float, default=2.5,
                     help="length of the sustained leg: back-to-back steps for this long, frames/s and the shader clock read by a one-wave probe kernel "
                          "beside them (0 = skip)")
@@ -83,7 +83,8 @@ def parse_args(argv=None):
     ap.add_argument("--engine", choices=("gpu", "emu"), default="gpu", help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
     if a.also is None:
-        a.also = [arrangement_name("quad")]
+        a.also = []  # (`--also quad`: the hand-built form of `pipeline`; its streams are created AFTER the pipeline's, and a process's second set of
+        #  four streams shares hardware queues -- 52 M where the same arrangement created first measures 58.6: profiles/r06_pipeline_stream_order.txt)
     return a
 
 
@@ -1067,8 +1068,7 @@ def run_rank(args):
             # counters of the committed PMC passes, scaled to this run's frames per launch; withheld (null) unless the file
             # was measured on exactly these kernel sources
             pj, pmc_note = load_pmc()
-            traffic = traffic_step = valu_frac = lane_frac = valu_insts = None
-            ceil = load_ceiling()
+            traffic = traffic_step = valu_frac = valu_frac_vop2 = lane_frac = valu_insts = None
             if pj is not None:
                 scale = frames_per_step / pj["frames_per_launch"]
                 kk = pj["kernels"]
@@ -1079,15 +1079,15 @@ def run_rank(args):
                 valu_insts = {k: kk[k]["sq_insts_valu"] * scale for k in live}
                 thread_cyc = sum(kk[k]["sq_thread_cycles_valu"] for k in live) * scale
                 lane_frac = thread_cyc / (sum(valu_insts.values()) * 64.0)
-                if ceil is not None:
-                    # cycles the step's vector instructions need at the MEASURED issue rate of this instruction mix (by the kernel's
-                    # resident waves per SIMD) over the SIMD-cycles the step's kernels had (at the maximum clock: a lower bound)
-                    cpi = ceil["cycles_per_instr_by_waves_per_simd"]
-                    need = sum(valu_insts[k] * cpi[min(cpi, key=lambda w: abs(w - WAVES_PER_SIMD.get(k, 4)))] for k in live)
-                    # ... over the SIMD-cycles of a step's wall time (in the pipelined arrangement the kernels of the two handles run
-                    # side by side: their durations add up to more than the step)
-                    have = N_SIMD * (elapsed / args.steps) * CLOCK_MHZ * 1e6
-                    valu_frac = need / have
+                # Issue fractions of the step (profiles/r06_instr_cost_findings.txt).  Denominator: the SIMD-cycles of a step's
+                # wall time at the maximum clock.  valu_frac: the hardware's own count of the time its vector ALUs were executing,
+                # SQ_ACTIVE_INST_VALU (quad-cycles per wave, i.e. x 4) -- 4.0 cycles per instruction in every kernel of this codec, which is
+                # what a wave can issue (one instruction per ~4.4 cycles whatever its class).  valu_frac_vop2: the same instructions at the
+                # 2 cycles a SIMD needs for a full-rate instruction (v_add/mul/fma_f32, v_add_u32, ...) when two of its waves can issue.
+                have = N_SIMD * (elapsed / args.steps) * CLOCK_MHZ * 1e6
+                act = sum(kk[k].get("sq_active_inst_valu", kk[k]["sq_insts_valu"]) for k in live) * scale
+                valu_frac = 4.0 * act / have
+                valu_frac_vop2 = 2.0 * sum(valu_insts.values()) / have
                 pmc_note = pj.get("source")
             # the dominant KERNEL alone on the chip (the one-stream arrangement's HIP-event times: nothing shares the chip with it there)
             alone = next((o["kernel_ms"] for o in others if o["arrangement"] == "single" and o.get("kernel_ms")), kernel_ms if main_arr == "single" else None)
@@ -1100,11 +1100,12 @@ def run_rank(args):
                 "frac": achieved / HBM_PEAK_GBS, "frac_dominant_kernel_alone": frac_alone, "achieved_dominant_kernel_alone": achieved_alone,
                 "dominant_kernel_alone": "lc3_enc_front_kernel: 960 algorithmic bytes per frame / its launch duration in the one-stream arrangement",
                 "traffic": traffic, "traffic_whole_step": traffic_step,
-                "measured_copy_GBs": ceil["copy_GBs"] if ceil else None,
+                "measured_copy_GBs": (load_ceiling() or {}).get("copy_GBs"),
                 "algorithmic_bytes_per_frame": alg,
                 "roundtrip_algorithmic_bytes_per_frame": ALG_BYTES_ENC + (ALG_BYTES_DEC if mode == "roundtrip" else 0),
                 "roundtrip_achieved_GBs": value * (ALG_BYTES_ENC + (ALG_BYTES_DEC if mode == "roundtrip" else 0)) / 1e9 / world,
-                "valu_frac": valu_frac, "active_lane_frac": lane_frac, "valu_insts_per_step": valu_insts, "valu_ceiling": ceil,
+                "valu_frac": valu_frac, "valu_frac_vop2": valu_frac_vop2, "active_lane_frac": lane_frac, "valu_insts_per_step": valu_insts,
+                "instruction_cost": "profiles/r06_instr_cost.json (tools/instr_cost.hip), reading in profiles/r06_instr_cost_findings.txt",
                 "pmc": pmc_note,
                 "note": "`bound` says what binds: vector-instruction issue, not HBM (SURVEY 8d honesty note: ~60 flop per algorithmic byte) -- achieved / peak / "
                         "frac are nevertheless the contract's HBM figures (algorithmic bytes over launch duration against 8 TB/s), `frac` with the kernels of "
@@ -1114,9 +1115,10 @@ def run_rank(args):
                         "traffic = FETCH_SIZE + WRITE_SIZE of the dominant unit per step in BYTES (FETCH_SIZE doubled for the kernels whose reads are "
                         "16-byte-per-lane coalesced, MI355X_MICROARCH.md), traffic_whole_step the same over every kernel of the step; measured_copy_GBs = "
                         "what a 16-byte-per-lane copy kernel reaches on this chip (read + write), beside the 8 TB/s vendor figure `frac` divides by; "
-                        "valu_frac = sum over the step's kernels of SQ_INSTS_VALU x (measured cycles per wave instruction of the codec's instruction mix at "
-                        "that kernel's waves per SIMD; 4.0 at every occupancy for this mix, 2.0 for plain f32 / i32 arithmetic alone) / (1024 SIMDs x the step's wall time at "
-                        "2.4 GHz); active_lane_frac = SQ_THREAD_CYCLES_VALU / "
+                        "valu_frac = 4 x sum over the step's kernels of SQ_ACTIVE_INST_VALU (the hardware's count of quad-cycles its waves spent executing vector "
+                        "instructions: 1.00 per instruction in every kernel here) / (1024 SIMDs x the step's wall time at 2.4 GHz); valu_frac_vop2 = 2 x SQ_INSTS_VALU "
+                        "over the same: the step's vector instructions at the 2-cycle rate a SIMD reaches for full-rate instructions with two waves issuing "
+                        "(profiles/r06_instr_cost.json); active_lane_frac = SQ_THREAD_CYCLES_VALU / "
                         "(64 x SQ_INSTS_VALU); counters from the committed rocprofv3 PMC passes (profiles/pmc_latest.json), null when they "
                         "were taken on other kernel sources",
             }

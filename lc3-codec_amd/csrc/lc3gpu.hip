@@ -2133,6 +2133,10 @@ struct lc3gpu_decoder : HandleCommon {
     int32_t *d_planes = nullptr;   // parsed-frame planes, LC3_PLANE_WORDS words per frame
     size_t planes_frames = 0;      // capacity in frames (multiple of 64)
     float *d_dbg = nullptr;        // stage dumps of the diagnostic entry points (LC3_DBG_FLOATS), allocated at first use
+    // lc3gpu_decoder_reset only NOTES that every channel is back to the constructed state: the next batch launch over all channels initialises
+    // the states inside the synthesis kernel (fresh = 1, as the encoder's fresh_mask does); anything else that looks at the state blobs first
+    // (a range or frame call, state_save, plc_events, the diagnostic calls) materialises them with the zero-frame launch (decoder_init_states)
+    bool fresh_pending = false;
 };
 
 // frames per workgroup of the lane-per-frame kernels (= threads per workgroup).  LC3GPU_FPB overrides (tuning aid).
@@ -2850,9 +2854,7 @@ int lc3gpu_encoder_state_load(lc3gpu_encoder *e, const void *host_src, size_t nb
 static int decoder_init_states(lc3gpu_decoder *d) {
     // decoder state is materialised eagerly (fresh = 1, zero frames): PLC counters must survive range launches
     HIP_TRY(hipDeviceSynchronize());  // nothing of this handle may still be in flight (its state is about to be rewritten)
-    // the fresh launch below stores only the part of the post-filter's output ring a launch writes (lc3_dec_state_store): the rest of a
-    // blob must not be whatever hipMalloc handed out (state_save would copy stale device memory to the host, and blobs would differ from run to run)
-    HIP_TRY(hipMemset(d->d_states, 0, sizeof(lc3_dec_state) * (size_t)d->num_channels));
+    d->fresh_pending = false;
     lc3_io io = {0, nullptr};
     if (!d->mixed) {
         LC3_LAUNCH_CFG(lc3_decode_kernel, d->h, dim3((unsigned)((d->num_channels + LC3_WG_WAVES - 1) / LC3_WG_WAVES)),
@@ -2876,6 +2878,10 @@ static int decoder_alloc(lc3gpu_decoder *d) {
     HIP_TRY(hipEventCreateWithFlags(&d->done, hipEventDisableTiming));
     { const int rc = d->pc_health_alloc(); if (rc) return rc; }
     HIP_TRY(hipMalloc((void **)&d->d_states, sizeof(lc3_dec_state) * (size_t)d->num_channels));
+    // A fresh launch stores the part of the post-filter's output ring its configuration uses (lc3_dec_state_store; 960 of the array's 1 080
+    // floats at 48 kHz / 10 ms) and nothing ever writes the rest: zeroed once here, it stays zero -- state_save must not copy whatever
+    // hipMalloc handed out to the host, and two handles that decoded the same frames must save the same blobs
+    HIP_TRY(hipMemset(d->d_states, 0, sizeof(lc3_dec_state) * (size_t)d->num_channels));
     HIP_TRY(hipHostMalloc((void **)&d->d_in1, LC3_MAX_NE, hipHostMallocDefault));  // *_frame staging: pinned host memory, used in place
     HIP_TRY(hipHostMalloc((void **)&d->d_pcm1, sizeof(int16_t) * LC3_MAX_NF, hipHostMallocDefault));
     int rc = decoder_reserve_planes(d, (size_t)d->num_channels, nullptr);
@@ -2932,12 +2938,17 @@ int lc3gpu_decoder_destroy(lc3gpu_decoder *d) {
 int lc3gpu_decoder_reset(lc3gpu_decoder *d) {
     if (!d) return LC3GPU_EINVAL;
     LC3_ON_DEVICE(d);
-    return decoder_init_states(d);
+    int rc = d->quiesce();  // launches in flight still store their state at the end
+    if (rc) return rc;
+    d->fresh_pending = true;
+    return LC3GPU_OK;
 }
+// the state blobs as a reader expects them: a reset that is still only noted is carried out
+static int decoder_materialise(lc3gpu_decoder *d) { return d->fresh_pending ? decoder_init_states(d) : LC3GPU_OK; }
 
 // the decoder kernels of channels [first, first + n) (internal order) on `stream`; buffers, flags and planes are those of this range
 static int decode_kernels(lc3gpu_decoder *d, const HostCfg &h, int first, int n, const uint8_t *d_in, const uint8_t *d_bad, int16_t *d_pcm,
-                          int32_t *planes, int nbytes, int n_frames, lc3_io io, int mode, hipStream_t stream, int chain) {
+                          int32_t *planes, int nbytes, int n_frames, lc3_io io, int mode, hipStream_t stream, int chain, int fresh = 0) {
     // stage 1: parse all n * n_frames frames, one lane each (stateless); stage 2: synthesis, one wave per stream
     const size_t frames = (size_t)n * (size_t)n_frames;
     // frames per workgroup: as many as fit the default 64 KB of dynamic LDS (tables + 64 B of scale factors and nbytes of
@@ -2976,10 +2987,10 @@ static int decode_kernels(lc3gpu_decoder *d, const HostCfg &h, int first, int n,
     }
     if (mode == LC3_RECON_LATE)
         LC3_LAUNCH_CFG(lc3_decode_late_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), 0,
-                       stream, d->d_states, first, n, (const int32_t *)planes, d_pcm, nbytes, n_frames, 0, io);
+                       stream, d->d_states, first, n, (const int32_t *)planes, d_pcm, nbytes, n_frames, fresh, io);
     else
         LC3_LAUNCH_CFG(lc3_decode_kernel, h, dim3((unsigned)((n + LC3_WG_WAVES - 1) / LC3_WG_WAVES)), dim3(64 * LC3_WG_WAVES), lc3_lds_pad(2), stream,
-                       d->d_states, first, n, (const int32_t *)planes, d_pcm, nbytes, n_frames, 0, io);
+                       d->d_states, first, n, (const int32_t *)planes, d_pcm, nbytes, n_frames, fresh, io);
     HIP_TRY(hipGetLastError());
     d->timer.mark(stream, 3, chain);
     return LC3GPU_OK;
@@ -2994,6 +3005,16 @@ static int decode_launch(lc3gpu_decoder *d, const HostCfg &h, int first, int n, 
     if (layout == LC3GPU_LAYOUT_PLANAR ? ((uintptr_t)d_pcm & 3u) != 0 : ((uintptr_t)d_pcm & 1u) != 0) return LC3GPU_EINVAL;
     const size_t frames = (size_t)n * (size_t)n_frames;
     const int nf = h.c.nf;
+    // a reset that is only noted so far: a launch over ALL channels carries it out itself (its synthesis kernel starts from the constructed
+    // state and stores what it leaves); any other launch needs the other channels' blobs initialised first
+    int fresh = 0;
+    if (d->fresh_pending) {
+        if (first == 0 && n == d->num_channels && !d->mixed) fresh = 1;
+        else {
+            const int rc0 = decoder_materialise(d);
+            if (rc0) return rc0;
+        }
+    }
     int parts = d->in_host_call ? 1 : lc3_split_parts(frames, n);
     const int na = parts == 2 ? lc3_split_point(n, n_frames) : n;
     if (parts == 2 && (na <= 0 || na >= n)) parts = 1;
@@ -3007,7 +3028,7 @@ static int decode_launch(lc3gpu_decoder *d, const HostCfg &h, int first, int n, 
     const size_t t0 = d->timer.used;
     d->timer.arm();
     if (parts == 1) {
-        rc = decode_kernels(d, h, first, n, d_in, d_bad, d_pcm, d->d_planes, nbytes, n_frames, io, mode, stream, 0);
+        rc = decode_kernels(d, h, first, n, d_in, d_bad, d_pcm, d->d_planes, nbytes, n_frames, io, mode, stream, 0, fresh);
     } else {
         rc = LC3GPU_OK;
         if (hipEventRecord(d->ev_fork, stream) != hipSuccess || hipStreamWaitEvent(d->sub[0], d->ev_fork, 0) != hipSuccess ||
@@ -3018,11 +3039,11 @@ static int decode_launch(lc3gpu_decoder *d, const HostCfg &h, int first, int n, 
         const size_t fa = (size_t)na * (size_t)n_frames;
         const bool ilv = layout == LC3GPU_LAYOUT_INTERLEAVED;
         if (rc == LC3GPU_OK)
-            rc = decode_kernels(d, h, first, na, d_in, d_bad, d_pcm, d->d_planes, nbytes, n_frames, io, mode, d->sub[0], 1);
+            rc = decode_kernels(d, h, first, na, d_in, d_bad, d_pcm, d->d_planes, nbytes, n_frames, io, mode, d->sub[0], 1, fresh);
         if (rc == LC3GPU_OK)
             rc = decode_kernels(d, h, first + na, n - na, ilv ? d_in + (size_t)na * (size_t)nbytes : d_in + fa * (size_t)nbytes,
                                 d_bad ? (ilv ? d_bad + na : d_bad + fa) : nullptr, ilv ? d_pcm + na : d_pcm + fa * (size_t)nf,
-                                d->d_planes + fa * (size_t)LC3_PLANE_WORDS, nbytes, n_frames, io, mode, d->sub[1], 2);
+                                d->d_planes + fa * (size_t)LC3_PLANE_WORDS, nbytes, n_frames, io, mode, d->sub[1], 2, fresh);
         for (int i = 0; i < 2; i++)
             if (hipEventRecord(d->ev_join[i], d->sub[i]) != hipSuccess || hipStreamWaitEvent(stream, d->ev_join[i], 0) != hipSuccess) {
                 g_last_hip = (int)hipGetLastError();
@@ -3033,8 +3054,10 @@ static int decode_launch(lc3gpu_decoder *d, const HostCfg &h, int first, int n, 
     if (rc) {
         d->timer.rollback(t0);
         (void)d->order_end(stream, parts == 2);
+        if (fresh) (void)decoder_init_states(d);  // (some of the kernels may have run: leave the handle in a defined state)
         return rc;
     }
+    if (fresh) d->fresh_pending = false;
     return d->order_end(stream, parts == 2);
 }
 
@@ -3064,7 +3087,8 @@ int lc3gpu_decode_mixed(lc3gpu_decoder *d, const uint8_t *d_in, const uint8_t *d
     if (((uintptr_t)d_pcm & 3u) != 0) return LC3GPU_EINVAL;
     LC3_ON_DEVICE(d);
     hipStream_t stream = (hipStream_t)stream_;
-    int rc = d->order_begin(stream);
+    int rc = decoder_materialise(d);
+    if (rc == LC3GPU_OK) rc = d->order_begin(stream);
     if (rc) return rc;
     lc3_groups G;
     unsigned wg_stream, wg_frame;
@@ -3165,6 +3189,7 @@ int lc3gpu_decode_frame_debug(lc3gpu_decoder *d, int recon_form, const uint8_t *
     if (nbytes < 1 || nbytes > LC3_MAX_NE) return LC3GPU_ELENGTH;
     LC3_ON_DEVICE(d);
     int rc = d->quiesce();
+    if (rc == LC3GPU_OK) rc = decoder_materialise(d);
     if (rc == LC3GPU_OK) rc = decoder_reserve_planes(d, 1, nullptr);
     if (rc == LC3GPU_OK) rc = decoder_debug_begin(d, nullptr);
     if (rc == LC3GPU_OK && recon_form == LC3_RECON_WAVE) rc = lc3_tns_lds_optin();
@@ -3209,6 +3234,7 @@ int lc3gpu_decoder_synth_debug(lc3gpu_decoder *d, int time_in, const float *in, 
     if (pitch_index < 0 || pitch_index > 511) return LC3GPU_EINVAL;  // nine bits in the bitstream (side_info_reader.rs:106-129): the post-filter derives lags and table rows from it
     LC3_ON_DEVICE(d);
     int rc = d->quiesce();
+    if (rc == LC3GPU_OK) rc = decoder_materialise(d);
     if (rc == LC3GPU_OK) rc = decoder_reserve_planes(d, 1, nullptr);
     if (rc == LC3GPU_OK) rc = decoder_debug_begin(d, nullptr);
     if (rc) return rc;
@@ -3240,6 +3266,7 @@ int lc3gpu_decoder_state_save(lc3gpu_decoder *d, void *host_dst, size_t nbytes) 
     if (nbytes != lc3gpu_decoder_state_size(d) * (size_t)d->num_channels) return LC3GPU_ELENGTH;
     LC3_ON_DEVICE(d);
     HIP_TRY(hipDeviceSynchronize());
+    { const int rc = decoder_materialise(d); if (rc) return rc; }
     return state_blobs_save(*d, d->d_states, LC3_STATE_MAGIC_DEC, 0, host_dst, nbytes);
 }
 
@@ -3248,13 +3275,16 @@ int lc3gpu_decoder_state_load(lc3gpu_decoder *d, const void *host_src, size_t nb
     if (nbytes != lc3gpu_decoder_state_size(d) * (size_t)d->num_channels) return LC3GPU_ELENGTH;
     LC3_ON_DEVICE(d);
     HIP_TRY(hipDeviceSynchronize());  // a launch in flight would store its state over the loaded one
-    return state_blobs_load(*d, d->d_states, LC3_STATE_MAGIC_DEC, 0, host_src, nbytes);
+    const int rc = state_blobs_load(*d, d->d_states, LC3_STATE_MAGIC_DEC, 0, host_src, nbytes);
+    if (rc == LC3GPU_OK) d->fresh_pending = false;  // every channel now has the loaded state
+    return rc;
 }
 
 int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
     if (!d || !out) return LC3GPU_EINVAL;
     LC3_ON_DEVICE(d);
     HIP_TRY(hipDeviceSynchronize());
+    { const int rc = decoder_materialise(d); if (rc) return rc; }
     std::vector<lc3_dec_state> st((size_t)d->num_channels);
     HIP_TRY(hipMemcpy(st.data(), d->d_states, sizeof(lc3_dec_state) * st.size(), hipMemcpyDeviceToHost));
     uint64_t total = 0;

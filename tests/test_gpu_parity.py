@@ -503,6 +503,53 @@ def test_decoder_state_blobs_are_deterministic():
     assert np.array_equal(blobs[0], blobs[1])
 
 
+def test_decoder_reset_paths():
+    """lc3gpu_decoder_reset only notes the reset; whoever touches the states next carries it out: a batch launch over all channels (inside
+    its synthesis kernel), or -- through the zero-frame initialising launch -- a range launch, a frame call, state_save, plc_events.  Each
+    of them after a reset must behave like a fresh handle."""
+    S, T = 12, 5
+    pcm = synth.make_pcm(S, T, 480, 48000, seed=61)
+    data = O.encode_batch(pcm, 150).copy()
+    data[3, 1, -1] |= 7  # one concealed frame: the PLC counter is part of the state
+    ref = O.decode_batch(data, 480)
+    fresh_blob = pkg.Lc3Decoder(S, US, FS).state_save()
+    dec = pkg.Lc3Decoder(S, US, FS)
+    assert np.array_equal(gpu_decode(data, 480, dec=dec), ref) and dec.plc_events() == 1
+    dec.reset()
+    assert dec.plc_events() == 0  # (materialises)
+    assert np.array_equal(gpu_decode(data, 480, dec=dec), ref)
+    dec.reset()
+    assert np.array_equal(dec.state_save(), fresh_blob)  # (materialises)
+    dec.reset()
+    assert np.array_equal(gpu_decode(data, 480, dec=dec), ref) and dec.plc_events() == 1  # the launch itself starts from the constructed state
+    # a range launch right after a reset: the OTHER channels must be fresh afterwards, not stale
+    dec.reset()
+    torch = torch_mod()
+    d_in = torch.from_numpy(np.ascontiguousarray(data[4:8])).cuda()
+    d_pcm = torch.zeros((4, T, 480), dtype=torch.int16, device="cuda")
+    dec.decode(d_in, d_pcm, 150, T, stream=torch.cuda.current_stream().cuda_stream, first_channel=4, n_channels=4)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_pcm.cpu().numpy(), ref[4:8])
+    rest = np.ascontiguousarray(data[:4])
+    d_in2 = torch.from_numpy(rest).cuda()
+    d_pcm2 = torch.zeros((4, T, 480), dtype=torch.int16, device="cuda")
+    dec.decode(d_in2, d_pcm2, 150, T, stream=torch.cuda.current_stream().cuda_stream, first_channel=0, n_channels=4)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_pcm2.cpu().numpy(), ref[:4])
+    # a frame call right after a reset
+    dec.reset()
+    out = np.zeros(480, np.int16)
+    dec.decode_frame(16, 9, data[9, 0], out)
+    assert np.array_equal(out, ref[9, 0])
+    # state_load cancels a pending reset
+    dec2 = pkg.Lc3Decoder(S, US, FS)
+    gpu_decode(data[:, :2], 480, dec=dec2)
+    blob = dec2.state_save()
+    dec.reset()
+    dec.state_load(blob)
+    assert np.array_equal(gpu_decode(data[:, 2:], 480, dec=dec), ref[:, 2:])
+
+
 # ---------------------------------------------------------------- host-resident batches, the pipeline object
 def test_host_resident_batch_path():
     """lc3gpu_encode_host / lc3gpu_decode_host: the caller loops of examples/encode.rs:73-116 / examples/decode.rs:60-112 over HOST buffers,
@@ -1524,13 +1571,16 @@ def test_rccl_world_size_one():
     assert abs(line["value"] - 1024 * 4 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
 
 
-def test_default_arrangement_is_quad_and_a_mismatch_fails_the_run():
-    """bench.py without flags times the four-stream arrangement, says so in the line, and gates parity on streams of both groups; a
-    run whose gate finds a difference exits non-zero after printing the line (round-4 review: it used to exit 0)."""
+def test_default_arrangement_is_the_pipeline_object_and_a_mismatch_fails_the_run():
+    """bench.py without flags times the library's pipeline object (lc3gpu_pipeline_submit: two groups, four HIP streams), says so in the
+    line, walks through the resident frames from step to step, and gates parity on streams of both groups; a run whose gate finds a
+    difference exits non-zero after printing the line (round-4 review: it used to exit 0)."""
     p, line = _bench_line(["--steps", "3", "--warmup", "1", "--streams", "4096", "--sustain-seconds", "0", "--no-overlap-probe"], {})
     assert p.returncode == 0 and line is not None, p.stderr[-2000:]
-    assert line["config"]["arrangement"] == "split:2+2" and line["config"]["hip_streams"] == 4
-    assert line["parity"]["arrangement"] == "split:2+2" and line["parity"]["bitstream_exact"] and line["parity"]["pcm_max_abs_diff"] == 0
+    assert line["config"]["arrangement"] == "pipeline" and line["config"]["hip_streams"] == 4
+    assert line["parity"]["arrangement"] == "pipeline" and line["parity"]["bitstream_exact"] and line["parity"]["pcm_max_abs_diff"] == 0
+    assert line["config"]["resident_frames_per_stream"] == 64 and line["config"]["resident_pcm_bytes_per_gpu"] == 4096 * 64 * 960
+    assert line["roofline"]["bound"] == "valu-issue" and line["parity"]["frames_checked"] >= 1000
     # LC3_BENCH_TEST_CORRUPT_GATE=1: the gate's reference bytes are damaged on purpose -> the line reports mismatches, the exit code is 3
     p, line = _bench_line(["--steps", "2", "--warmup", "1", "--streams", "1024", "--sustain-seconds", "0", "--no-overlap-probe"],
                           {"LC3_BENCH_TEST_CORRUPT_GATE": "1"})
@@ -1556,7 +1606,7 @@ def test_every_arrangement_produces_the_single_stream_output():
     pcm = synth.make_pcm(S, T, bench.NF, bench.FS)
     eng = bench.GpuEngine(args, pcm, S, T, "roundtrip", 0)
     ref = None
-    for arr in ("single", "pipelined", "staggered", "split:2+2", "split:1+1", "split:2+1+1"):
+    for arr in ("single", "pipeline", "pipelined", "staggered", "split:2+2", "split:1+1", "split:2+1+1"):
         eng.set_arrangement(arr)
         eng.reset()
         for _ in range(3):
@@ -1580,7 +1630,8 @@ def test_every_caller_arrangement_passes_its_parity_gate():
     """bench.py times two ways of queueing the same steps -- encode then decode on ONE caller stream, and the recommended pattern
     (INTEGRATION.md): encoder handle on one stream, decoder handle on another, two byte buffers, events -- and runs its parity gate on
     each (two steps from fresh state, the second against the oracle).  Here on a 32 768-frame batch (producer / consumer pair kernels)."""
-    p, line = _bench_line(["--steps", "4", "--warmup", "1", "--streams", "8192", "--sustain-seconds", "0.3", "--arrangement", "pipelined"], {})
+    p, line = _bench_line(["--steps", "4", "--warmup", "1", "--streams", "8192", "--sustain-seconds", "0.3", "--arrangement", "pipelined", "--also", "quad",
+                           "--also", "duo", "--also", "pipeline"], {})
     assert p.returncode == 0 and line is not None, p.stderr[-2000:]
     assert line["config"]["arrangement"] == "pipelined" and line["config"]["hip_streams"] == 2
     assert line["parity"]["arrangement"] == "pipelined" and line["parity"]["bitstream_exact"] and line["parity"]["pcm_max_abs_diff"] == 0
@@ -1590,8 +1641,9 @@ def test_every_caller_arrangement_passes_its_parity_gate():
     g = [a for a in line["other_arrangements"] if a["arrangement"] == "staggered"]
     assert len(g) == 1 and g[0]["parity"]["bitstream_exact"] and g[0]["parity"]["pcm_max_abs_diff"] == 0 and g[0]["hip_streams"] == 2
     # ... and the split arrangements (round 5): the streams in groups, every group with a handle pair of its own -- on two streams
-    # (`quad` = split:2+2, bench.py's default) or one (`duo` = split:1+1); their gates look at streams of EVERY group
-    for name, n_streams in (("split:2+2", 4), ("split:1+1", 2)):
+    # (`quad` = split:2+2, what the library's pipeline object builds inside) or one (`duo` = split:1+1), and the pipeline object itself; their
+    # gates look at streams of EVERY group
+    for name, n_streams in (("split:2+2", 4), ("split:1+1", 2), ("pipeline", 4)):
         g = [a for a in line["other_arrangements"] if a["arrangement"] == name]
         assert len(g) == 1 and g[0]["parity"]["bitstream_exact"] and g[0]["parity"]["pcm_max_abs_diff"] == 0, (name, g)
         assert g[0]["hip_streams"] == n_streams and g[0]["parity"]["frames_checked"] >= 256 * 4 - 8

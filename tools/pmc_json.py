@@ -17,7 +17,8 @@ from bench import kernel_source_sha  # noqa: E402
 KEYS = {"FETCH_SIZE": "fetch_size_kb", "WRITE_SIZE": "write_size_kb", "SQ_INSTS_VALU": "sq_insts_valu",
         "SQ_THREAD_CYCLES_VALU": "sq_thread_cycles_valu", "SQ_INSTS_SALU": "sq_insts_salu", "SQ_WAVE_CYCLES": "sq_wave_cycles",
         "SQ_WAIT_ANY": "sq_wait_any", "SQ_BUSY_CYCLES": "sq_busy_cycles", "SQ_LDS_BANK_CONFLICT": "sq_lds_bank_conflict",
-        "SQ_LDS_IDX_ACTIVE": "sq_lds_idx_active"}
+        "SQ_LDS_IDX_ACTIVE": "sq_lds_idx_active", "SQ_ACTIVE_INST_VALU": "sq_active_inst_valu", "SQ_INSTS_LDS": "sq_insts_lds",
+        "SQ_INSTS_VMEM_RD": "sq_insts_vmem_rd", "SQ_INSTS_VMEM_WR": "sq_insts_vmem_wr", "SQ_INSTS_SMEM": "sq_insts_smem"}
 
 
 # the producer / consumer forms of the two lane-per-frame kernels report under the names bench.py's timer slots carry
