@@ -131,16 +131,25 @@ __shared__ lc3_spec_tables lc3_spec_tab;
 #define LC3_LDS_PARAM(T)
 #define LC3_LDS_PASS
 #define LC3_LDS_BIND(T, arr) T &L = arr[LC3_WAVE_ID()]
+// (LC3_SERIAL_PRIO, experiment: the wave that runs a gathered block does so at a raised wave priority -- three waves of its workgroup wait for
+// it while the SIMD's other workgroups compete with it for issue slots; 0 = off)
+#ifndef LC3_SERIAL_PRIO
+#define LC3_SERIAL_PRIO 0
+#endif
+#define LC3_SERIAL_PRIO_UP() do { if (LC3_SERIAL_PRIO) __builtin_amdgcn_s_setprio(LC3_SERIAL_PRIO); } while (0)
+#define LC3_SERIAL_PRIO_DOWN() do { if (LC3_SERIAL_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 #define LC3_SERIAL_BEGIN(T, L, lane, phase, K)                                               \
     {                                                                                        \
         T *lc3_wg_base_ = &(L) - LC3_WAVE_ID();                                              \
         __syncthreads();                                                                     \
+        if (LC3_WAVE_ID() == ((phase) % LC3_WG_WAVES)) LC3_SERIAL_PRIO_UP();                 \
         if (LC3_WAVE_ID() == ((phase) % LC3_WG_WAVES) && (lane) < LC3_WG_WAVES * (K)) {      \
             T &L = lc3_wg_base_[(lane) / (K)];                                               \
             const int sub = (lane) % (K);                                                    \
             (void)sub;
 #define LC3_SERIAL_END \
         }              \
+        LC3_SERIAL_PRIO_DOWN(); \
         __syncthreads(); \
     }
 // The same for blocks of up to 64 lanes per stream (K x streams beyond one wave): virtual lane v = lane + 64 j runs on the j-th wave after
@@ -150,6 +159,7 @@ __shared__ lc3_spec_tables lc3_spec_tab;
         T *lc3_wg_base_ = &(L) - LC3_WAVE_ID();                                                               \
         __syncthreads();                                                                                      \
         const int lc3_v_ = (lane) + 64 * ((LC3_WAVE_ID() + LC3_WG_WAVES - ((phase) % LC3_WG_WAVES)) % LC3_WG_WAVES); \
+        if (lc3_v_ - (lane) < LC3_WG_WAVES * (K)) LC3_SERIAL_PRIO_UP();                                       \
         if (lc3_v_ < LC3_WG_WAVES * (K)) {                                                                    \
             T &L = lc3_wg_base_[lc3_v_ / (K)];                                                                \
             const int sub = lc3_v_ % (K);                                                                     \

@@ -69,6 +69,21 @@ elif scenario == "memory_first":
     out["p1_after_memory"] = [timed(p1) for _ in range(3)]
     p2 = mk()
     out["p2_beside_p1"] = [timed(p2) for _ in range(2)]
+elif scenario == "host_cost":
+    # host time of one submission (what a rank's CPU core spends per step: 12 kernel launches, 8 event records / waits behind the C ABI)
+    p1 = mk()
+    timed(p1, 20, 5)
+    import statistics
+    per = []
+    for rep in range(5):
+        p1.wait()
+        t0 = time.perf_counter()
+        for k in range(24):  # (short enough that the launch queue never fills and the host never blocks)
+            p1.submit(d_pcm, bufs[k & 1], d_out, NB, T)
+        per.append((time.perf_counter() - t0) / 24 * 1e6)
+        p1.wait()
+    out["host_us_per_submit"] = per
+    out["host_us_per_submit_median"] = statistics.median(per)
 elif scenario == "closed":
     for i in range(4):
         p = mk()
