@@ -131,6 +131,9 @@ __shared__ lc3_spec_tables lc3_spec_tab;
 #define LC3_LDS_PARAM(T)
 #define LC3_LDS_PASS
 #define LC3_LDS_BIND(T, arr) T &L = arr[LC3_WAVE_ID()]
+// (LC3_NO_GATHER, experiment: every wave runs the serial blocks of its own stream on its own lanes -- the definitions of lc3_dev_common.h,
+// no workgroup barriers -- instead of one wave running them for the workgroup's four streams)
+#ifndef LC3_NO_GATHER
 // (LC3_SERIAL_PRIO, experiment: the wave that runs a gathered block does so at a raised wave priority -- three waves of its workgroup wait for
 // it while the SIMD's other workgroups compete with it for issue slots; 0 = off)
 #ifndef LC3_SERIAL_PRIO
@@ -164,6 +167,7 @@ __shared__ lc3_spec_tables lc3_spec_tab;
             T &L = lc3_wg_base_[lc3_v_ / (K)];                                                                \
             const int sub = lc3_v_ % (K);                                                                     \
             (void)sub;
+#endif  // LC3_NO_GATHER
 #define LC3_HBM_CONST(T) const __attribute__((address_space(1))) T *
 #define LC3_HBM(T) __attribute__((address_space(1))) T *
 #define LC3_UNIFORM_I32(x) __builtin_amdgcn_readfirstlane((int)(x))
