@@ -856,7 +856,7 @@ def host_resident_bench(torch, pkg, pcm_host, S, T, reps=3):
             "roundtrip_host_frames_per_s": S * T / (te + td), "encode_ms": te * 1e3, "decode_ms": td * 1e3,
             "pcie_GBs_encode": S * T * (2 * NF + NBYTES) / te / 1e9, "pcie_GBs_decode": S * T * (2 * NF + NBYTES) / td / 1e9,
             "what": "lc3gpu_encode_host then lc3gpu_decode_host (synchronous calls, pinned host buffers from lc3gpu_host_alloc): H2D copy, kernels and "
-                    "D2H copy of channel ranges on two internal HIP streams; best of %d repetitions; NOT `value` (inputs there are resident in HBM)" % reps}
+                    "D2H copy of channel ranges of 32 768 frames on three internal HIP streams (copy-in, kernels, copy-out side by side); best of %d repetitions; NOT `value` (inputs there are resident in HBM)" % reps}
 
 
 # ---------------------------------------------------------------------------------------------------------------

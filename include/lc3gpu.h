@@ -188,8 +188,8 @@ int lc3gpu_decoder_debug_pair_giveup(lc3gpu_decoder *dec);
  * (examples/encode.rs:73-116: read samples, de-interleave, encode_frame per channel, write; examples/decode.rs:60-112 the mirror).
  * These two calls take such buffers whole -- planar, as the batch calls: pcm int16[num_channels][n_frames][nf], bytes
  * uint8[num_channels][n_frames][nbytes], bad_frame (optional) uint8[num_channels][n_frames] -- and return when the results are in host
- * memory: the handle's channels go through the device in ranges, the copies of one range beside the kernels of another (two internal HIP
- * streams).  State is carried as by the batch calls.  The PCIe link bounds them (960 + 150 bytes per 48 kHz / 10 ms frame each way);
+ * memory: the handle's channels go through the device in ranges of >= 32 768 frames, the copy-in of one range, the kernels of another and
+ * the copy-out of a third at the same time (three internal HIP streams).  State is carried as by the batch calls.  The PCIe link bounds them (960 + 150 bytes per 48 kHz / 10 ms frame each way);
  * buffers from lc3gpu_host_alloc (pinned) copy at the link's rate, any other host memory through the runtime's staging copies. */
 int lc3gpu_encode_host(lc3gpu_encoder *enc, const int16_t *pcm, uint8_t *out, int nbytes, int n_frames);
 int lc3gpu_decode_host(lc3gpu_decoder *dec, const uint8_t *in, const uint8_t *bad_frame, int16_t *pcm, int nbytes, int n_frames);

@@ -1887,6 +1887,20 @@ struct HandleCommon {
     void *d_stage_in[2] = {nullptr, nullptr}, *d_stage_out[2] = {nullptr, nullptr}, *d_stage_flag[2] = {nullptr, nullptr};
     size_t stage_in_bytes = 0, stage_out_bytes = 0, stage_flag_bytes = 0;
     bool in_host_call = false;
+    // ... and three internal streams of their own: copies in, kernels, copies out -- each direction's copy engine and the compute queue run
+    // side by side, tied by events per staging buffer (host_lane_*)
+    hipStream_t host_s[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t host_in_done[2] = {nullptr, nullptr}, host_k_done[2] = {nullptr, nullptr}, host_out_done[2] = {nullptr, nullptr};
+    int ensure_host_lane() {
+        if (host_s[0]) return LC3GPU_OK;
+        for (int i = 0; i < 3; i++) HIP_TRY(hipStreamCreateWithFlags(&host_s[i], hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipEventCreateWithFlags(&host_in_done[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&host_k_done[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&host_out_done[i], hipEventDisableTiming));
+        }
+        return LC3GPU_OK;
+    }
     int stage_reserve(size_t in_bytes, size_t out_bytes, size_t flag_bytes) {
         auto grow = [](void **buf, size_t &have, size_t want) -> int {
             if (want <= have) return LC3GPU_OK;
@@ -2003,6 +2017,15 @@ struct HandleCommon {
             }
         }
         stage_in_bytes = stage_out_bytes = stage_flag_bytes = 0;
+        for (int i = 0; i < 3; i++) {
+            if (host_s[i]) (void)hipStreamDestroy(host_s[i]);
+            host_s[i] = nullptr;
+        }
+        for (int i = 0; i < 2; i++)
+            for (hipEvent_t *ev : {&host_in_done[i], &host_k_done[i], &host_out_done[i]}) {
+                if (*ev) (void)hipEventDestroy(*ev);
+                *ev = nullptr;
+            }
         for (hipEvent_t ev : {ev_fork, ev_stage, ev_join[0], ev_join[1]})
             if (ev) (void)hipEventDestroy(ev);
         for (hipStream_t st : sub)
@@ -3310,14 +3333,23 @@ int lc3gpu_decoder_plc_events(lc3gpu_decoder *d, uint64_t *out) {
 // ---------------------------------------------------------------------------------------------
 // Host-resident batches.  The reference's caller holds PCM and frame bytes in host memory and walks them frame by frame
 // (examples/encode.rs:73-116, examples/decode.rs:60-112); lc3gpu_encode_host / lc3gpu_decode_host take such buffers whole: the handle's
-// channels in ranges, range c on internal HIP stream c & 1 as  copy in -> the range's kernels -> copy out,  so that the copies of one range
-// run beside the kernels of another (the kernels of the ranges themselves run one after the other: they share the handle's planes).
+// channels in ranges, each as  copy in -> the range's kernels -> copy out  on three internal HIP streams (one per step: host_lane_run), so
+// that the copy-in of range c + 1, the kernels of range c and the copy-out of range c - 1 run at the same time (the kernels of the ranges
+// themselves run one after the other: they share the handle's planes).
 // Synchronous, like the loop they replace.  PCIe bounds them (a 48 kHz / 10 ms frame is 960 + 150 bytes each way); pinned buffers
 // (lc3gpu_host_alloc) copy at the link's rate, pageable ones through the runtime's staging.
 static int host_chunk_channels(int num_channels, int n_frames) {
-    // ranges of whole waves of the lane-per-frame kernels and at least 16 384 frames (where the pair kernels begin), at most eight ranges
-    long long c = (16384 + n_frames - 1) / n_frames;
-    const long long min_c = ((long long)num_channels + 7) / 8;
+    // Ranges of whole waves of the lane-per-frame kernels and at least 32 768 frames (LC3GPU_HOST_CHUNK_FRAMES overrides: tuning aid), at most
+    // sixteen ranges.  Measured on the 65 536-frame batch, encode / decode in M frames/s: ranges of 8 192 frames 18.7 / 21.4, 16 384: 29.6 / 35.0,
+    // 22 000: 32.2 / 41.4, 32 768: 34.4 / 41.4, one range (no overlap) 27.9 / 37.7 -- a lane-per-frame kernel takes as long for a quarter
+    // of the frames as for all of them, so few large ranges beat many small ones; the link itself moves 56 GB/s each way
+    static const long long target = [] {
+        const char *e = std::getenv("LC3GPU_HOST_CHUNK_FRAMES");
+        const long long v = e ? std::atoll(e) : 0;
+        return v > 0 ? v : 32768ll;
+    }();
+    long long c = (target + n_frames - 1) / n_frames;
+    const long long min_c = ((long long)num_channels + 15) / 16;
     if (c < min_c) c = min_c;
     c = (c + 63) / 64 * 64;
     return c >= num_channels ? num_channels : (int)c;
@@ -3333,79 +3365,105 @@ int lc3gpu_host_free(void *p) {
     if (p) HIP_TRY(hipHostFree(p));
     return LC3GPU_OK;
 }
+// The ranges of a host-resident call: range c uses staging buffers c & 1.  Three internal streams -- copies in, kernels, copies out -- so that
+// the H2D engine, the compute queue and the D2H engine all run at once:
+//   copy-in   waits for the kernels of range c - 2 (they read the buffer it refills), copies, records in_done
+//   kernels   wait for in_done and for the copy-out of range c - 2 (it reads the buffer they refill), run, record k_done
+//   copy-out  waits for k_done, copies, records out_done
+// copy_in / launch / copy_out: what to queue for range (first, n) with buffers b on the given stream; -> LC3GPU_* code
+extern "C++" {
+template <class CopyIn, class Launch, class CopyOut>
+static int host_lane_run(HandleCommon &hc, int C, int cc, CopyIn copy_in, Launch launch, CopyOut copy_out) {
+    int rc = hc.ensure_host_lane();
+    if (rc) return rc;
+    bool k_rec[2] = {false, false}, out_rec[2] = {false, false};
+    hc.in_host_call = true;
+    int k = 0;
+    for (int first = 0; first < C && rc == LC3GPU_OK; first += cc, k++) {
+        const int n = first + cc <= C ? cc : C - first, b = k & 1;
+        hipError_t e = hipSuccess;
+        if (k_rec[b]) e = hipStreamWaitEvent(hc.host_s[0], hc.host_k_done[b], 0);
+        if (e == hipSuccess) e = copy_in(first, n, b, hc.host_s[0]);
+        if (e == hipSuccess) e = hipEventRecord(hc.host_in_done[b], hc.host_s[0]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(hc.host_s[1], hc.host_in_done[b], 0);
+        if (e == hipSuccess && out_rec[b]) e = hipStreamWaitEvent(hc.host_s[1], hc.host_out_done[b], 0);
+        if (e != hipSuccess) {
+            g_last_hip = (int)e;
+            (void)hipGetLastError();
+            rc = LC3GPU_EHIP;
+            break;
+        }
+        rc = launch(first, n, b, hc.host_s[1]);
+        if (rc) break;
+        e = hipEventRecord(hc.host_k_done[b], hc.host_s[1]);
+        k_rec[b] = true;
+        if (e == hipSuccess) e = hipStreamWaitEvent(hc.host_s[2], hc.host_k_done[b], 0);
+        if (e == hipSuccess) e = copy_out(first, n, b, hc.host_s[2]);
+        if (e == hipSuccess) e = hipEventRecord(hc.host_out_done[b], hc.host_s[2]);
+        out_rec[b] = true;
+        if (e != hipSuccess) {
+            g_last_hip = (int)e;
+            (void)hipGetLastError();
+            rc = LC3GPU_EHIP;
+        }
+    }
+    hc.in_host_call = false;
+    for (int i = 0; i < 3; i++)
+        if (hipStreamSynchronize(hc.host_s[i]) != hipSuccess && rc == LC3GPU_OK) {
+            g_last_hip = (int)hipGetLastError();
+            rc = LC3GPU_EHIP;
+        }
+    return rc;
+}
+}  // extern "C++"
 int lc3gpu_encode_host(lc3gpu_encoder *e, const int16_t *pcm, uint8_t *out, int nbytes, int n_frames) {
     if (!e || e->mixed || !pcm || !out) return LC3GPU_EINVAL;
     if (nbytes < 20 || nbytes > LC3_MAX_NE || n_frames <= 0) return LC3GPU_ELENGTH;
     LC3_ON_DEVICE(e);
     int rc = e->quiesce();
-    if (rc == LC3GPU_OK) rc = e->ensure_split();
     if (rc) return rc;
     const int nf = e->h.c.nf, C = e->num_channels, cc = host_chunk_channels(C, n_frames);
     const size_t in_row = (size_t)n_frames * (size_t)nf * sizeof(int16_t), out_row = (size_t)n_frames * (size_t)nbytes;
     rc = e->stage_reserve((size_t)cc * in_row, (size_t)cc * out_row, 0);
     if (rc) return rc;
-    e->in_host_call = true;
-    int k = 0;
-    for (int first = 0; first < C && rc == LC3GPU_OK; first += cc, k++) {
-        const int n = first + cc <= C ? cc : C - first, b = k & 1;
-        hipStream_t st = e->sub[b];
-        if (hipMemcpyAsync(e->d_stage_in[b], (const char *)pcm + (size_t)first * in_row, (size_t)n * in_row, hipMemcpyHostToDevice, st) != hipSuccess) {
-            g_last_hip = (int)hipGetLastError();
-            rc = LC3GPU_EHIP;
-            break;
-        }
-        rc = encode_launch(e, e->h, first, n, (const int16_t *)e->d_stage_in[b], (uint8_t *)e->d_stage_out[b], nbytes, n_frames, LC3GPU_LAYOUT_PLANAR, st,
-                           nullptr);
-        if (rc == LC3GPU_OK && hipMemcpyAsync(out + (size_t)first * out_row, e->d_stage_out[b], (size_t)n * out_row, hipMemcpyDeviceToHost, st) != hipSuccess) {
-            g_last_hip = (int)hipGetLastError();
-            rc = LC3GPU_EHIP;
-        }
-    }
-    e->in_host_call = false;
-    for (int i = 0; i < 2; i++)
-        if (hipStreamSynchronize(e->sub[i]) != hipSuccess && rc == LC3GPU_OK) {
-            g_last_hip = (int)hipGetLastError();
-            rc = LC3GPU_EHIP;
-        }
-    return rc;
+    return host_lane_run(
+        *e, C, cc,
+        [&](int first, int n, int b, hipStream_t st) {
+            return hipMemcpyAsync(e->d_stage_in[b], (const char *)pcm + (size_t)first * in_row, (size_t)n * in_row, hipMemcpyHostToDevice, st);
+        },
+        [&](int first, int n, int b, hipStream_t st) {
+            return encode_launch(e, e->h, first, n, (const int16_t *)e->d_stage_in[b], (uint8_t *)e->d_stage_out[b], nbytes, n_frames,
+                                 LC3GPU_LAYOUT_PLANAR, st, nullptr);
+        },
+        [&](int first, int n, int b, hipStream_t st) {
+            return hipMemcpyAsync(out + (size_t)first * out_row, e->d_stage_out[b], (size_t)n * out_row, hipMemcpyDeviceToHost, st);
+        });
 }
 int lc3gpu_decode_host(lc3gpu_decoder *d, const uint8_t *in, const uint8_t *bad_frame, int16_t *pcm, int nbytes, int n_frames) {
     if (!d || d->mixed || !in || !pcm) return LC3GPU_EINVAL;
     if (nbytes < 1 || nbytes > LC3_MAX_NE || n_frames <= 0) return LC3GPU_ELENGTH;
     LC3_ON_DEVICE(d);
     int rc = d->quiesce();
-    if (rc == LC3GPU_OK) rc = d->ensure_split();
     if (rc) return rc;
     const int nf = d->h.c.nf, C = d->num_channels, cc = host_chunk_channels(C, n_frames);
     const size_t in_row = (size_t)n_frames * (size_t)nbytes, out_row = (size_t)n_frames * (size_t)nf * sizeof(int16_t);
     rc = d->stage_reserve((size_t)cc * in_row, (size_t)cc * out_row, bad_frame ? (size_t)cc * (size_t)n_frames : 0);
     if (rc) return rc;
-    d->in_host_call = true;
-    int k = 0;
-    for (int first = 0; first < C && rc == LC3GPU_OK; first += cc, k++) {
-        const int n = first + cc <= C ? cc : C - first, b = k & 1;
-        hipStream_t st = d->sub[b];
-        if (hipMemcpyAsync(d->d_stage_in[b], in + (size_t)first * in_row, (size_t)n * in_row, hipMemcpyHostToDevice, st) != hipSuccess ||
-            (bad_frame && hipMemcpyAsync(d->d_stage_flag[b], bad_frame + (size_t)first * (size_t)n_frames, (size_t)n * (size_t)n_frames, hipMemcpyHostToDevice,
-                                         st) != hipSuccess)) {
-            g_last_hip = (int)hipGetLastError();
-            rc = LC3GPU_EHIP;
-            break;
-        }
-        rc = decode_launch(d, d->h, first, n, (const uint8_t *)d->d_stage_in[b], bad_frame ? (const uint8_t *)d->d_stage_flag[b] : nullptr,
-                           (int16_t *)d->d_stage_out[b], nbytes, n_frames, LC3GPU_LAYOUT_PLANAR, st);
-        if (rc == LC3GPU_OK && hipMemcpyAsync((char *)pcm + (size_t)first * out_row, d->d_stage_out[b], (size_t)n * out_row, hipMemcpyDeviceToHost, st) != hipSuccess) {
-            g_last_hip = (int)hipGetLastError();
-            rc = LC3GPU_EHIP;
-        }
-    }
-    d->in_host_call = false;
-    for (int i = 0; i < 2; i++)
-        if (hipStreamSynchronize(d->sub[i]) != hipSuccess && rc == LC3GPU_OK) {
-            g_last_hip = (int)hipGetLastError();
-            rc = LC3GPU_EHIP;
-        }
-    return rc;
+    return host_lane_run(
+        *d, C, cc,
+        [&](int first, int n, int b, hipStream_t st) {
+            hipError_t e2 = hipMemcpyAsync(d->d_stage_in[b], in + (size_t)first * in_row, (size_t)n * in_row, hipMemcpyHostToDevice, st);
+            if (e2 == hipSuccess && bad_frame)
+                e2 = hipMemcpyAsync(d->d_stage_flag[b], bad_frame + (size_t)first * (size_t)n_frames, (size_t)n * (size_t)n_frames, hipMemcpyHostToDevice, st);
+            return e2;
+        },
+        [&](int first, int n, int b, hipStream_t st) {
+            return decode_launch(d, d->h, first, n, (const uint8_t *)d->d_stage_in[b], bad_frame ? (const uint8_t *)d->d_stage_flag[b] : nullptr,
+                                 (int16_t *)d->d_stage_out[b], nbytes, n_frames, LC3GPU_LAYOUT_PLANAR, st);
+        },
+        [&](int first, int n, int b, hipStream_t st) {
+            return hipMemcpyAsync((char *)pcm + (size_t)first * out_row, d->d_stage_out[b], (size_t)n * out_row, hipMemcpyDeviceToHost, st);
+        });
 }
 
 // Producer / consumer pair kernels (full batches): how many pair halves ever gave up waiting for their partner (LC3_PC_SPIN_LIMIT
