@@ -41,6 +41,7 @@ struct Group {
     const uint8_t *ebytes_lo[2] = {nullptr, nullptr}, *ebytes_hi[2] = {nullptr, nullptr};
     // the PCM range the decoder of that submission WRITES (a later encoder may read it: a transcoding chain)
     int last_enc = -1, last_dec = -1;  // slot of the latest encoder / decoder work (for wait / join)
+    unsigned long long n_enc = 0, n_dec = 0;  // pieces of work queued per role (a role's slot = its count & 1)
 };
 }  // namespace
 
@@ -48,7 +49,7 @@ struct lc3gpu_pipeline {
     int device = 0;
     bool own_streams = false;  // the streams were created for this pipeline alone (LC3GPU_PIPELINE_OWN_STREAMS=1) and die with it
     int num_channels = 0, nf = 0;
-    unsigned long long k = 0;  // submissions so far (slot = k & 1)
+    unsigned long long k = 0;  // submissions so far
     std::vector<Group> groups;
     hipEvent_t ev_follow = nullptr;
     bool follow_pending = false;
@@ -215,45 +216,66 @@ int lc3gpu_pipeline_group(lc3gpu_pipeline *p, int group, int *first_channel, int
 
 int lc3gpu_pipeline_last_hip_error(const lc3gpu_pipeline *p) { return p ? p->last_hip : 0; }
 
+// Hazards between the two streams of a group.  Each role keeps the records of its two most recent submissions (slot = the role's own
+// count & 1): the byte range it read (decoder) or wrote (encoder) and an event behind its work.  A new piece of work waits for the
+// other role's records it overlaps; records that have been dropped are all OLDER than both live ones, so when nothing live overlaps and
+// something has been dropped, waiting for the older live record orders the work behind every dropped one as well (a caller rotating three
+// byte buffers, halves submitted alone in any order).  In the round trip with two alternating byte buffers this is exactly one wait per
+// role and submission: the encoder of submission k behind the decoder of k - 2, the decoder behind its own encoder.
+static int wait_for_other_role(lc3gpu_pipeline *p, hipStream_t s, const uint8_t *lo, const uint8_t *hi, const hipEvent_t (&ev)[2], const bool (&rec)[2],
+                               const uint8_t *const (&r_lo)[2], const uint8_t *const (&r_hi)[2], unsigned long long count) {
+    if (count == 0) return LC3GPU_OK;
+    const int newer = (int)((count - 1) & 1ull), older = newer ^ 1;
+    bool any = false;
+    for (int i : {newer, older})
+        if (rec[i] && overlaps(lo, hi, r_lo[i], r_hi[i])) {
+            PL_HIP(p, hipStreamWaitEvent(s, ev[i], 0));
+            any = true;
+            if (i == newer) break;  // (the newer record's event is behind the older one's on the same stream)
+        }
+    if (!any && count > 2 && rec[older]) PL_HIP(p, hipStreamWaitEvent(s, ev[older], 0));
+    return LC3GPU_OK;
+}
+
 // what = 1 encode, 2 decode, 3 both
 static int pipeline_step(lc3gpu_pipeline *p, int what, const int16_t *d_pcm, uint8_t *d_bytes, const uint8_t *d_bad, int16_t *d_pcm_out, int nbytes,
                          int n_frames) {
     if (!p || !d_bytes || ((what & 1) && !d_pcm) || ((what & 2) && !d_pcm_out)) return LC3GPU_EINVAL;
     if (n_frames <= 0) return LC3GPU_ELENGTH;
     DeviceGuard dg(p->device);
-    const int b = (int)(p->k & 1ull);
     int rc = LC3GPU_OK;
     for (Group &q : p->groups) {
         const size_t f0 = (size_t)q.first * (size_t)n_frames;
         uint8_t *bytes = d_bytes + f0 * (size_t)nbytes;
         const uint8_t *bytes_end = bytes + (size_t)q.n * (size_t)n_frames * (size_t)nbytes;
         if (what & 1) {
-            // the encoder may not overwrite bytes a decoder of the two submissions in flight still reads (a caller that alternates two byte
-            // buffers never waits here for the submission before this one; a caller with one buffer does)
-            for (int i = 0; i < 2; i++)
-                if (q.dec_rec[i] && overlaps(bytes, bytes_end, q.bytes_lo[i], q.bytes_hi[i])) PL_HIP(p, hipStreamWaitEvent(q.s_enc, q.dec_done[i], 0));
+            // the encoder may not overwrite bytes a decoder still reads
+            if ((rc = wait_for_other_role(p, q.s_enc, bytes, bytes_end, q.dec_done, q.dec_rec, q.bytes_lo, q.bytes_hi, q.n_dec)) != 0) return rc;
             if ((rc = follow_wait(p, q.s_enc)) != 0) return rc;
             rc = lc3gpu_encode(q.enc, d_pcm + f0 * (size_t)p->nf, bytes, nbytes, n_frames, q.s_enc);
             if (rc) return rc;
+            const int b = (int)(q.n_enc & 1ull);
             PL_HIP(p, hipEventRecord(q.enc_done[b], q.s_enc));
             q.enc_rec[b] = true;
             q.ebytes_lo[b] = bytes;
             q.ebytes_hi[b] = bytes_end;
             q.last_enc = b;
+            q.n_enc++;
         }
         if (what & 2) {
             // the decoder reads what an encoder in flight writes: this submission's own (a round trip) or an earlier lc3gpu_pipeline_encode's
-            for (int i = 0; i < 2; i++)
-                if (q.enc_rec[i] && overlaps(bytes, bytes_end, q.ebytes_lo[i], q.ebytes_hi[i])) PL_HIP(p, hipStreamWaitEvent(q.s_dec, q.enc_done[i], 0));
+            if ((rc = wait_for_other_role(p, q.s_dec, bytes, bytes_end, q.enc_done, q.enc_rec, q.ebytes_lo, q.ebytes_hi, q.n_enc)) != 0) return rc;
             if ((rc = follow_wait(p, q.s_dec)) != 0) return rc;
             const uint8_t *bad = d_bad ? d_bad + f0 : nullptr;
             rc = lc3gpu_decode(q.dec, bytes, bad, d_pcm_out + f0 * (size_t)p->nf, nbytes, n_frames, q.s_dec);
             if (rc) return rc;
+            const int b = (int)(q.n_dec & 1ull);
             PL_HIP(p, hipEventRecord(q.dec_done[b], q.s_dec));
             q.dec_rec[b] = true;
             q.bytes_lo[b] = bytes;
             q.bytes_hi[b] = bytes_end;
             q.last_dec = b;
+            q.n_dec++;
         }
     }
     p->follow_pending = false;

@@ -647,8 +647,32 @@ def test_pipeline_object_equals_the_single_stream_calls():
         got_p = d_o.to("cpu", non_blocking=True)
     side.synchronize()
     assert np.array_equal(got_p.numpy(), want_p[0]) and np.array_equal(d_b.cpu().numpy(), want_b[0])
-    # a group's handles are the caller's to read: state blobs of the pipeline's first group == those of the plain handles' first channels
+    # hazards with submissions the pipeline's two slots no longer remember: three byte buffers in rotation over six round trips, then
+    # three encode-only submissions into three buffers followed by their decodes in another order
+    pl.reset()
+    d_b3 = [torch.zeros((S, T, 150), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    d_o6 = [torch.zeros((S, T, 480), dtype=torch.int16, device="cuda") for _ in range(6)]
+    for k in range(6):
+        pl.submit(d_in[k % steps], d_b3[k % 3], d_o6[k], 150, T)
     pl.wait()
+    enc3, dec3 = pkg.Lc3Encoder(S, US, FS), pkg.Lc3Decoder(S, US, FS)
+    for k in range(6):
+        b = gpu_encode(pcm[:, (k % steps) * T:(k % steps + 1) * T], 150, enc=enc3)
+        assert np.array_equal(d_o6[k].cpu().numpy(), gpu_decode(b, 480, dec=dec3)), k
+    pl.reset()
+    for k in range(3):
+        pl.encode(d_in[k], d_b3[k], 150, T)
+    outs = {}
+    for k in (0, 1, 2):  # (decoders carry state: the frames must be decoded in time order; the BUFFERS were filled in three submissions)
+        outs[k] = torch.zeros((S, T, 480), dtype=torch.int16, device="cuda")
+        pl.decode(d_b3[k], outs[k], 150, T)
+    pl.wait()
+    for k in range(3):
+        assert np.array_equal(d_b3[k].cpu().numpy(), want_b[k]) and np.array_equal(outs[k].cpu().numpy(), want_p[k]), k
+    pl.reset()
+    pl.encode(d_in[0], d_b3[0], 150, T)
+    pl.wait()
+    # a group's handles are the caller's to read: state blobs of the pipeline's first group == those of the plain handles' first channels
     n0 = pl.groups[0]["n"]
     enc2 = pkg.Lc3Encoder(n0, US, FS)
     gpu_encode(pcm[:n0, :T], 150, enc=enc2)
