@@ -16,7 +16,7 @@ import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
 v = sorted(r["value"] for r in rows)
 med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
-print(json.dumps({"what": "python bench.py (default arrangement: lc3gpu_pipeline_submit) in %d consecutive fresh processes, 20 timed steps each" % len(v),
+print(json.dumps({"what": "python bench.py (default arrangement: lc3gpu_pipeline_submit) in %d consecutive fresh processes, %d timed steps each" % (len(v), rows[0]["steps"]),
                   "arrangement": rows[0]["config"]["arrangement"], "values_frames_per_s": [r["value"] for r in rows],
                   "parity_mismatches": [r["parity_mismatches_all_ranks"] for r in rows],
                   "min": v[0], "median": med, "max": v[-1], "min_over_median": v[0] / med}))
