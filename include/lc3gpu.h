@@ -96,7 +96,8 @@ int lc3gpu_encoder_create(lc3gpu_encoder **out, int num_channels, int frame_us, 
 /* the same with LC3GPU_SPEC_* corrections switched on (spec_flags = 0: identical to lc3gpu_encoder_create) */
 int lc3gpu_encoder_create_spec(lc3gpu_encoder **out, int num_channels, int frame_us, int fs_hz, int spec_flags);
 int lc3gpu_encoder_destroy(lc3gpu_encoder *enc);
-/* back to the freshly constructed state (all channels) */
+/* back to the freshly constructed state (all channels).  Costs no synchronisation: work in flight completes as it is, the NEXT call starts
+ * every channel from the constructed state (lc3gpu_decoder_reset likewise) */
 int lc3gpu_encoder_reset(lc3gpu_encoder *enc);
 
 /* Lc3Encoder::encode_frame (lc3_encoder.rs:175-191), host buffers.
@@ -218,7 +219,7 @@ int lc3gpu_host_free(void *p);
  *                            after every submission).  The groups are not tied to each other: the mark says nothing about the other groups
  *   lc3gpu_pipeline_group    the channel range and the handles of a group (borrowed: state blobs, PLC / health counters, timing,
  *                            stage events; never destroy them, never call their batch functions while the pipeline has work in flight)
- *   lc3gpu_pipeline_reset    waits, then every channel back to the freshly constructed state
+ *   lc3gpu_pipeline_reset    every channel back to the freshly constructed state from the next submission on (no wait)
  * Errors as the batch calls (LC3GPU_EPAIR included). */
 typedef struct lc3gpu_pipeline lc3gpu_pipeline;
 int lc3gpu_pipeline_create(lc3gpu_pipeline **out, int num_channels, int frame_us, int fs_hz, int n_groups);

@@ -2560,9 +2560,10 @@ int lc3gpu_encoder_destroy(lc3gpu_encoder *e) {
 
 int lc3gpu_encoder_reset(lc3gpu_encoder *e) {
     if (!e) return LC3GPU_EINVAL;
-    LC3_ON_DEVICE(e);
-    int rc = e->quiesce();  // launches in flight still store their state at the end
-    if (rc) return rc;
+    // Nothing to wait for: a launch in flight stores its streams' state at its end, and the next launch of a fresh channel never reads
+    // that -- it starts from the constructed state inside its kernel and stores what IT leaves, behind the earlier store in stream order
+    // (launches on another stream are ordered by order_begin's event; a partial launch materialises the other channels with launches of
+    // its own).  A reset between two batch calls therefore costs no synchronisation ("a new encoder per frame", SURVEY 8d Mode A).
     e->fresh_mask.assign((size_t)e->num_channels, 1);
     return LC3GPU_OK;
 }
@@ -2870,6 +2871,7 @@ int lc3gpu_encoder_state_save(lc3gpu_encoder *e, void *host_dst, size_t nbytes) 
     if (!e || !host_dst) return LC3GPU_EINVAL;
     if (nbytes != lc3gpu_encoder_state_size(e) * (size_t)e->num_channels) return LC3GPU_ELENGTH;
     LC3_ON_DEVICE(e);
+    HIP_TRY(hipDeviceSynchronize());  // (a launch in flight stores its state at its end: the initialising launches below must come after it -- a reset does not wait)
     int rc = encoder_materialise(e, 0, e->num_channels, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -2974,10 +2976,7 @@ int lc3gpu_decoder_destroy(lc3gpu_decoder *d) {
 
 int lc3gpu_decoder_reset(lc3gpu_decoder *d) {
     if (!d) return LC3GPU_EINVAL;
-    LC3_ON_DEVICE(d);
-    int rc = d->quiesce();  // launches in flight still store their state at the end
-    if (rc) return rc;
-    d->fresh_pending = true;
+    d->fresh_pending = true;  // (no wait, for the encoder's reasons: lc3gpu_encoder_reset; whoever reads the blobs first synchronises -- decoder_materialise)
     return LC3GPU_OK;
 }
 // the state blobs as a reader expects them: a reset that is still only noted is carried out

@@ -341,7 +341,7 @@ int lc3gpu_pipeline_follow(lc3gpu_pipeline *p, void *hip_stream) {
 
 int lc3gpu_pipeline_reset(lc3gpu_pipeline *p) {
     if (!p) return LC3GPU_EINVAL;
-    int rc = lc3gpu_pipeline_wait(p);
+    int rc = LC3GPU_OK;  // (asynchronous, as the handles' resets: the next submission starts every channel from the constructed state)
     for (Group &q : p->groups) {
         if (rc == LC3GPU_OK) rc = lc3gpu_encoder_reset(q.enc);
         if (rc == LC3GPU_OK) rc = lc3gpu_decoder_reset(q.dec);
