@@ -39,7 +39,7 @@ ALG_BYTES_DEC = NBYTES + 2 * NF   # frame bytes read + i16 PCM written
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CLOCK_MHZ = 2400.0                # max shader clock (MI355X_MICROARCH.md, chip-level parameters)
 N_SIMD = 1024                     # 256 CUs x 4 SIMDs
-KERNEL_EVENTS_EVERY = 4           # the library's per-kernel HIP events are recorded on every fourth step of the timed region
+KERNEL_EVENTS_EVERY = 10          # the library's per-kernel HIP events are recorded on every tenth step of the timed region (16 records a step: ~2 % of it)
 
 
 def parse_args(argv=None):
@@ -723,7 +723,7 @@ def shape_bench(torch, pkg, d_full, pcm_host, S, T, steps, warmup, cold=False, a
     pieces), step k on frames [T k, T k + T) mod L.  cold: every step starts from FRESH state (reset + encode + decode inside the timed step:
     "a new reference encoder / decoder per frame", /root/reference/src/encoder/lc3_encoder.rs:117-173); otherwise state is carried (a live
     server's tick when T = 1).  Each arrangement with its own parity gate (two steps from fresh state, the second against the oracle on
-    256 streams) and the per-kernel HIP-event times of every fourth step.  -> dict"""
+    256 streams) and the per-kernel HIP-event times of every tenth step.  -> dict"""
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -988,7 +988,7 @@ def run_rank(args):
     if not args.no_parity:
         parity, mismatches = gate(main_arr)
 
-    # timed region: exactly K steps; per-kernel durations from HIP events the C ABI records on the launch streams on every fourth
+    # timed region: exactly K steps; per-kernel durations from HIP events the C ABI records on the launch streams on every tenth
     # step (an event after every kernel of every step costs the streams ~0.03 ms per step), and one event after every step for the
     # per-step minimum / median
     eng.set_arrangement(main_arr)
