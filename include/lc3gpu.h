@@ -184,6 +184,13 @@ int lc3gpu_decoder_pair_timeouts(lc3gpu_decoder *dec, uint64_t *out);
 int lc3gpu_encoder_debug_pair_giveup(lc3gpu_encoder *enc);
 int lc3gpu_decoder_debug_pair_giveup(lc3gpu_decoder *dec);
 
+/* A caller that runs a handle on ONE HIP stream for the handle's whole life (the pipeline object does) can say so: bind = 1 binds the
+ * handle to `hip_stream` -- which must outlive the handle or the binding --, bind = 0 releases it.  A bound handle takes batch calls on
+ * that stream only (LC3GPU_EINVAL otherwise; the *_frame, *_host and diagnostic calls are not for bound handles) and records no event of
+ * its own per call: "the handle's work in flight" is the stream.  Both calls wait for the handle's work in flight. */
+int lc3gpu_encoder_bind_stream(lc3gpu_encoder *enc, void *hip_stream, int bind);
+int lc3gpu_decoder_bind_stream(lc3gpu_decoder *dec, void *hip_stream, int bind);
+
 /* ---- host-resident batches ----------------------------------------------------------------------- */
 /* The reference's callers keep PCM and frame bytes in HOST memory and walk them frame by frame, channel by channel
  * (examples/encode.rs:73-116: read samples, de-interleave, encode_frame per channel, write; examples/decode.rs:60-112 the mirror).

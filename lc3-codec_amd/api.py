@@ -280,6 +280,8 @@ def load_library():
     L.lc3gpu_clock_probe.argtypes = [vp, vp, i]
     L.lc3gpu_encoder_stage_event.argtypes = [vp, i, vp]
     L.lc3gpu_decoder_stage_event.argtypes = [vp, i, vp]
+    L.lc3gpu_encoder_bind_stream.argtypes = [vp, vp, i]
+    L.lc3gpu_decoder_bind_stream.argtypes = [vp, vp, i]
     L.lc3gpu_encoder_debug_pair_giveup.argtypes = [vp]
     L.lc3gpu_decoder_debug_pair_giveup.argtypes = [vp]
     L.lc3gpu_encode_host.argtypes = [vp, vp, vp, i, i]
@@ -315,7 +317,7 @@ ABI_SYMBOLS = [
     "lc3gpu_decoder_timing_kernels", "lc3gpu_decode_frame_debug", "lc3gpu_decoder_synth_debug", "lc3gpu_selftest_math", "lc3gpu_encode_layout", "lc3gpu_decode_layout", "lc3gpu_encoder_create_mixed", "lc3gpu_decoder_create_mixed", "lc3gpu_encode_mixed",
     "lc3gpu_decode_mixed", "lc3gpu_encoder_create_spec", "lc3gpu_encoder_create_mixed_spec", "lc3gpu_clock_probe",
     "lc3gpu_encoder_stage_event", "lc3gpu_decoder_stage_event", "lc3gpu_encoder_pair_timeouts", "lc3gpu_decoder_pair_timeouts",
-    "lc3gpu_encoder_debug_pair_giveup", "lc3gpu_decoder_debug_pair_giveup", "lc3gpu_encode_host", "lc3gpu_decode_host", "lc3gpu_host_alloc",
+    "lc3gpu_encoder_debug_pair_giveup", "lc3gpu_decoder_debug_pair_giveup", "lc3gpu_encoder_bind_stream", "lc3gpu_decoder_bind_stream", "lc3gpu_encode_host", "lc3gpu_decode_host", "lc3gpu_host_alloc",
     "lc3gpu_host_free", "lc3gpu_pipeline_create", "lc3gpu_pipeline_destroy", "lc3gpu_pipeline_reset", "lc3gpu_pipeline_submit",
     "lc3gpu_pipeline_encode", "lc3gpu_pipeline_decode", "lc3gpu_pipeline_wait", "lc3gpu_pipeline_join", "lc3gpu_pipeline_follow", "lc3gpu_pipeline_mark",
     "lc3gpu_pipeline_groups", "lc3gpu_pipeline_group", "lc3gpu_pipeline_last_hip_error",
@@ -530,6 +532,12 @@ class Lc3Encoder:
         if rc:
             raise Lc3EncoderError(rc, "encode_host")
 
+    def bind_stream(self, stream, bind=True):
+        """every later batch call comes on `stream` (which outlives the handle): no per-call event of the handle's own (lc3gpu_encoder_bind_stream)"""
+        rc = self._L.lc3gpu_encoder_bind_stream(self._h, _ptr(stream), int(bool(bind)))
+        if rc:
+            raise Lc3EncoderError(rc, "bind_stream")
+
     def debug_pair_giveup(self):
         """tests only: the device does what a pair half that gives up does (count + host flag)"""
         rc = self._L.lc3gpu_encoder_debug_pair_giveup(self._h)
@@ -715,6 +723,11 @@ class Lc3Decoder:
         rc = self._L.lc3gpu_decode_host(self._h, _ptr(data), _ptr(bad_frame), _ptr(pcm), int(nbytes), int(n_frames))
         if rc:
             raise Lc3DecoderError(rc, "decode_host")
+
+    def bind_stream(self, stream, bind=True):
+        rc = self._L.lc3gpu_decoder_bind_stream(self._h, _ptr(stream), int(bool(bind)))
+        if rc:
+            raise Lc3DecoderError(rc, "bind_stream")
 
     def debug_pair_giveup(self):
         rc = self._L.lc3gpu_decoder_debug_pair_giveup(self._h)

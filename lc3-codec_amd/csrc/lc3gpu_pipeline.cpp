@@ -191,6 +191,9 @@ int lc3gpu_pipeline_create(lc3gpu_pipeline **out, int num_channels, int frame_us
                 rc = LC3GPU_EHIP;
         if (rc == LC3GPU_OK) rc = lc3gpu_encoder_create(&q.enc, q.n, frame_us, fs_hz);
         if (rc == LC3GPU_OK) rc = lc3gpu_decoder_create(&q.dec, q.n, frame_us, fs_hz);
+        // the handles only ever run on the group's two streams, which outlive them: no event of their own per call
+        if (rc == LC3GPU_OK) rc = lc3gpu_encoder_bind_stream(q.enc, q.s_enc, 1);
+        if (rc == LC3GPU_OK) rc = lc3gpu_decoder_bind_stream(q.dec, q.s_dec, 1);
     }
     if (rc == LC3GPU_OK && hipEventCreateWithFlags(&p->ev_follow, hipEventDisableTiming) != hipSuccess) rc = LC3GPU_EHIP;
     if (rc) {

@@ -591,6 +591,51 @@ def test_host_resident_batch_path():
         enc_h.encode_host(x, got, 10, T)  # frame size out of range, as the batch calls
 
 
+def test_handles_bound_to_one_stream():
+    """lc3gpu_*_bind_stream: a handle whose batch calls all come on one stream that outlives it records no event of its own per call (the
+    pipeline object binds its handles).  Bound: same bytes and samples on that stream, state carried, state blobs / counters / reset work
+    (they wait on the stream), a call on another stream is refused; released: any stream again."""
+    torch = torch_mod()
+    S, T = 64, 3
+    pcm = synth.make_pcm(S, 2 * T, 480, 48000, seed=67)
+    ref = O.encode_batch(pcm, 150)
+    refp = O.decode_batch(ref, 480)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    enc, dec = pkg.Lc3Encoder(S, US, FS), pkg.Lc3Decoder(S, US, FS)
+    enc.bind_stream(s1.cuda_stream)
+    dec.bind_stream(s1.cuda_stream)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_b = torch.zeros((S, 2 * T, 150), dtype=torch.uint8, device="cuda")
+    d_o = torch.zeros((S, 2 * T, 480), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    for k in range(2):
+        x = d_pcm[:, k * T:(k + 1) * T].contiguous()
+        b = torch.zeros((S, T, 150), dtype=torch.uint8, device="cuda")
+        o = torch.zeros((S, T, 480), dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        enc.encode(x, b, 150, T, stream=s1.cuda_stream)
+        dec.decode(b, o, 150, T, stream=s1.cuda_stream)
+        if k == 0:
+            blob = enc.state_save()  # (waits for the stream)
+            assert dec.plc_events() == 0
+        s1.synchronize()
+        d_b[:, k * T:(k + 1) * T] = b
+        d_o[:, k * T:(k + 1) * T] = o
+    torch.cuda.synchronize()
+    assert np.array_equal(d_b.cpu().numpy(), ref) and np.array_equal(d_o.cpu().numpy(), refp)
+    enc_ref = pkg.Lc3Encoder(S, US, FS)
+    gpu_encode(pcm[:, :T], 150, enc=enc_ref)
+    assert np.array_equal(blob, enc_ref.state_save())
+    with pytest.raises(pkg.Lc3EncoderError) as ei:
+        enc.encode(d_pcm[:, :T].contiguous(), torch.zeros((S, T, 150), dtype=torch.uint8, device="cuda"), 150, T, stream=s2.cuda_stream)
+    assert ei.value.code == -1
+    enc.bind_stream(None, bind=False)
+    dec.bind_stream(None, bind=False)
+    enc.reset()
+    dec.reset()
+    assert np.array_equal(gpu_encode(pcm, 150, enc=enc), ref) and np.array_equal(gpu_decode(ref, 480, dec=dec), refp)
+
+
 def test_pipeline_object_equals_the_single_stream_calls():
     """lc3gpu_pipeline (the `quad` arrangement as a library object): three submissions with two byte buffers alternating, then with ONE
     byte buffer (every encoder then waits for the decoder before it), equal byte for byte and sample for sample to lc3gpu_encode +
