@@ -5,6 +5,7 @@
 //   lc3gpu-tool wavinfo <file.wav>
 //   lc3gpu-tool frame-timing [fs_hz=48000] [frame_us=10000] [bytes=150] [repeats=200]
 //   lc3gpu-tool buffer-lengths <channels 1|2> <fs_hz> <frame_us>
+//   lc3gpu-tool throughput [channels=16384] [frames_per_submit=4] [submits=200] [bytes=150]
 // The positional arguments are the reference drivers' function parameters (examples/encode.rs:36-44,
 // examples/decode.rs:36-44); the sampling frequency is NOT taken from the WAV header there either.
 #include <cstdio>
@@ -17,8 +18,90 @@
 #include <cmath>
 #include <vector>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/lc3gpu.hpp"
 #include "lc3_files.hpp"
+
+// The headline arrangement from C++, no Python anywhere: what replaces the reference's two caller loops (examples/encode.rs:97-115,
+// examples/decode.rs:93-112) for many channels is three calls -- lc3gpu_pipeline_create / _submit / _wait.  Synthetic PCM (a tone with
+// two harmonics and a little noise per channel, 64 frames resident and walked through), device buffers from hipMalloc, two byte buffers
+// alternating; prints encode + decode frames per second and checks the round trip on the first channel against lc3gpu_encode_frame /
+// lc3gpu_decode_frame of the same frames (the single-frame calls of the reference's API shape).
+static int throughput(int channels, int T, int submits, int nbytes) {
+    using clk = std::chrono::steady_clock;
+    const int nf = 480, R = 64 / T * T;
+    std::vector<int16_t> pcm((size_t)channels * R * nf);
+    unsigned lcg = 12345u;
+    for (int c = 0; c < channels; c++) {
+        const double f0 = 90.0 + 3.1 * (c % 97), amp = 2000.0 + 37.0 * (c % 211);
+        for (int n = 0; n < R * nf; n++) {
+            lcg = lcg * 1664525u + 1013904223u;
+            const double t = n / 48000.0, x = amp * (std::sin(6.283185307179586 * f0 * t) + 0.5 * std::sin(12.566370614359172 * f0 * t + 0.7) +
+                                                      0.33 * std::sin(18.84955592153876 * f0 * t + 1.9)) + ((int)(lcg >> 20) - 2048) * 0.05;
+            pcm[((size_t)c * R) * nf + n] = (int16_t)std::lrint(std::max(-32768.0, std::min(32767.0, x)));
+        }
+    }
+    // rotations: int16[R / T][channels][T][nf]
+    const int n_rot = R / T;
+    std::vector<int16_t> rot(pcm.size());
+    for (int k = 0; k < n_rot; k++)
+        for (int c = 0; c < channels; c++)
+            std::memcpy(&rot[(((size_t)k * channels + c) * T) * nf], &pcm[((size_t)c * R + (size_t)k * T) * nf], sizeof(int16_t) * (size_t)T * nf);
+    int16_t *d_pcm = nullptr, *d_out = nullptr;
+    uint8_t *d_bytes[2] = {nullptr, nullptr};
+    const size_t step_pcm = (size_t)channels * T * nf, step_bytes = (size_t)channels * T * nbytes;
+    if (hipMalloc((void **)&d_pcm, sizeof(int16_t) * rot.size()) != hipSuccess || hipMalloc((void **)&d_out, sizeof(int16_t) * step_pcm) != hipSuccess ||
+        hipMalloc((void **)&d_bytes[0], step_bytes) != hipSuccess || hipMalloc((void **)&d_bytes[1], step_bytes) != hipSuccess) {
+        std::fprintf(stderr, "no device memory\n");
+        return 1;
+    }
+    (void)hipMemcpy(d_pcm, rot.data(), sizeof(int16_t) * rot.size(), hipMemcpyHostToDevice);
+    lc3gpu_pipeline *pl = nullptr;
+    int rc = lc3gpu_pipeline_create(&pl, channels, 10000, 48000, 0);
+    if (rc) { std::fprintf(stderr, "lc3gpu_pipeline_create: %s\n", lc3gpu_strerror(rc)); return 1; }
+    // check: the first submission's channel 0 against the single-frame calls
+    rc = lc3gpu_pipeline_submit(pl, d_pcm, d_bytes[0], d_out, nbytes, T);
+    if (rc == 0) rc = lc3gpu_pipeline_wait(pl);
+    if (rc) { std::fprintf(stderr, "submit: %s\n", lc3gpu_strerror(rc)); return 1; }
+    std::vector<uint8_t> got_b((size_t)T * nbytes), want_b((size_t)nbytes);
+    std::vector<int16_t> got_p((size_t)T * nf), want_p((size_t)nf);
+    (void)hipMemcpy(got_b.data(), d_bytes[0], got_b.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(got_p.data(), d_out, sizeof(int16_t) * got_p.size(), hipMemcpyDeviceToHost);
+    {
+        lc3gpu_encoder *e1 = nullptr;
+        lc3gpu_decoder *d1 = nullptr;
+        if (lc3gpu_encoder_create(&e1, 1, 10000, 48000) || lc3gpu_decoder_create(&d1, 1, 10000, 48000)) return 1;
+        for (int t = 0; t < T; t++) {
+            if (lc3gpu_encode_frame(e1, 0, &pcm[(size_t)t * nf], nf, want_b.data(), nbytes) ||
+                lc3gpu_decode_frame(d1, 16, 0, want_b.data(), nbytes, want_p.data(), nf))
+                return 1;
+            if (std::memcmp(want_b.data(), &got_b[(size_t)t * nbytes], (size_t)nbytes) || std::memcmp(want_p.data(), &got_p[(size_t)t * nf], sizeof(int16_t) * nf)) {
+                std::fprintf(stderr, "pipeline output differs from encode_frame / decode_frame at frame %d\n", t);
+                return 3;
+            }
+        }
+        lc3gpu_encoder_destroy(e1);
+        lc3gpu_decoder_destroy(d1);
+    }
+    for (int k = 1; k < 1 + 8; k++) (void)lc3gpu_pipeline_submit(pl, d_pcm + (size_t)(k % n_rot) * step_pcm, d_bytes[k & 1], d_out, nbytes, T);
+    (void)lc3gpu_pipeline_wait(pl);
+    const auto t0 = clk::now();
+    for (int k = 9; k < 9 + submits; k++) {
+        rc = lc3gpu_pipeline_submit(pl, d_pcm + (size_t)(k % n_rot) * step_pcm, d_bytes[k & 1], d_out, nbytes, T);
+        if (rc) { std::fprintf(stderr, "submit: %s\n", lc3gpu_strerror(rc)); return 1; }
+    }
+    rc = lc3gpu_pipeline_wait(pl);
+    const double sec = std::chrono::duration<double>(clk::now() - t0).count();
+    std::printf("%d channels x %d frames per submission, %d submissions: %.3f ms per submission, %.2f M frames/s encode + decode (lc3gpu_pipeline_submit, %d groups)\n",
+                channels, T, submits, sec / submits * 1e3, (double)channels * T * submits / sec / 1e6, lc3gpu_pipeline_groups(pl));
+    lc3gpu_pipeline_destroy(pl);
+    (void)hipFree(d_pcm);
+    (void)hipFree(d_out);
+    (void)hipFree(d_bytes[0]);
+    (void)hipFree(d_bytes[1]);
+    return rc ? 1 : 0;
+}
 
 // Single-frame timing harness in the shape of the reference's embedded demo (examples/arm/src/main.rs:39-112): one
 // channel, the no_std API shape (channel count as a template argument, Lc3EncoderStatic / Lc3DecoderStatic of
@@ -77,7 +160,8 @@ static int usage() {
                  "       lc3gpu-tool compare <left> <right> [chunk_bytes]\n"
                  "       lc3gpu-tool wavinfo <file.wav>\n"
                  "       lc3gpu-tool frame-timing [fs_hz] [frame_us] [bytes] [repeats]\n"
-                 "       lc3gpu-tool buffer-lengths <channels 1|2> <fs_hz> <frame_us>\n");
+                 "       lc3gpu-tool buffer-lengths <channels 1|2> <fs_hz> <frame_us>\n"
+                 "       lc3gpu-tool throughput [channels] [frames_per_submit] [submits] [bytes]\n");
     return 2;
 }
 
@@ -95,6 +179,9 @@ int main(int argc, char **argv) {
         else std::printf("Completed comparing: no difference\n");
         return rc;
     }
+    if (cmd == "throughput")
+        return throughput(argc > 2 ? std::max(4, std::atoi(argv[2])) : 16384, argc > 3 ? std::max(1, std::min(64, std::atoi(argv[3]))) : 4,
+                          argc > 4 ? std::max(1, std::atoi(argv[4])) : 200, argc > 5 ? std::atoi(argv[5]) : 150);
     if (cmd == "frame-timing")
         return frame_timing(argc > 2 ? std::atoi(argv[2]) : 48000, argc > 3 ? std::atoi(argv[3]) : 10000,
                             argc > 4 ? std::atoi(argv[4]) : 150, argc > 5 ? std::max(1, std::atoi(argv[5])) : 200);

@@ -150,3 +150,18 @@ def test_single_frame_timing_harness(tool):
     assert r.returncode == 0, r.stderr
     assert "Encoded in" in r.stdout and "Decoded in" in r.stdout
     assert "(1900, 1106, 960)" in r.stdout
+
+
+@pytest.mark.gpu
+def test_pipeline_throughput_from_cpp(tool):
+    """`lc3gpu-tool throughput`: the headline arrangement from a C++ caller -- lc3gpu_pipeline_create / _submit / _wait on hipMalloc'ed
+    buffers, no Python in the process.  It checks its first submission against the single-frame calls itself (exit code 3 on a
+    difference); here the rate must be the benchmark's (the pipeline object owns the arrangement, the caller only submits)."""
+    import re
+
+    r = subprocess.run([tool, "throughput", "64", "2", "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([tool, "throughput", "16384", "4", "200"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"([\d.]+) M frames/s", r.stdout)
+    assert m and float(m.group(1)) > 50.0, r.stdout
