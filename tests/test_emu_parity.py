@@ -230,3 +230,33 @@ def test_emu_frame_counts_around_the_tns_chunk(T):
     for nbytes in (150, 60):
         assert np.array_equal(E.encode(pcm, nbytes), O.encode_batch(pcm, nbytes))
 
+
+
+@pytest.mark.parametrize("late", [0, 1])
+def test_emu_loss_bursts_reach_the_second_fade(late):
+    """packet_loss_concealment.rs:62-66: from the ninth lost frame of a run the concealed spectrum fades by 0.85 per frame.  Runs of 13 and 9
+    lost frames (unparsable side information, garbage and external flags mixed) through the device headers under the emulator, in both
+    places the decoder rebuilds the spectrum (parser lane / synthesis wave); the -m gpu suite repeats this across launch boundaries."""
+    S, T = 3, 26
+    pcm = synth.make_pcm(S, T, 480, 48000, seed=71)
+    data = O.encode_batch(pcm, 150).copy()
+    marked = data.copy()
+    bad = np.zeros((S, T), np.uint8)
+    rng = np.random.default_rng(73)
+    for s_i, (start, run) in enumerate(((3, 13), (5, 9), (2, 11))):
+        for k in range(run):
+            t = start + k
+            how = (s_i + k) % 3
+            if how == 0:
+                data[s_i, t, -1] |= 7
+                marked[s_i, t, -1] |= 7
+            elif how == 1:
+                bad[s_i, t] = 1
+                marked[s_i, t, -1] |= 7
+            else:
+                g = rng.integers(0, 256, 150, dtype=np.uint8)
+                g[-1] |= 7
+                data[s_i, t] = g
+                marked[s_i, t] = g
+    ref = O.decode_batch(marked, 480)
+    assert np.array_equal(E.decode(data, 480, bad=bad, late=late), ref)
