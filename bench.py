@@ -369,6 +369,8 @@ class GpuEngine:
             # the `split:..` arrangements: the batch as GROUPS of its streams, each group with an encoder handle and a decoder handle of its
             # own on one or two HIP streams of its own.  Handles, streams and events are created when an arrangement is first selected
             self.splits = {}
+        elif mode == "encode" and NP == 1:
+            self.bufs = [self.d_bytes, torch.zeros_like(self.d_bytes)]  # (the pipeline arrangement's encode-only form: two byte buffers)
 
     device = "cuda"
     carries_state = True
@@ -379,7 +381,7 @@ class GpuEngine:
 
     def set_arrangement(self, name):
         """`pipeline`, `single`, `pipelined`, `staggered` or `split:..`; call between synchronised phases only"""
-        assert name == "single" or (self.mode == "roundtrip" and self.NP == 1)
+        assert name == "single" or (self.mode == "roundtrip" and self.NP == 1) or (name == "pipeline" and self.NP == 1)
         self.sync()
         self.arrangement, self.k = name, 0
         if name == "pipeline" and not hasattr(self, "pl"):
@@ -450,7 +452,10 @@ class GpuEngine:
     def step(self):
         d_pcm = self._pcm()
         if self.arrangement == "pipeline":
-            self.pl.submit(d_pcm, self.bufs[self.k & 1], self.d_out, NBYTES, self.T)
+            if self.mode == "encode":  # (lc3gpu_pipeline_encode: the groups' encoder chains side by side)
+                self.pl.encode(d_pcm, self.bufs[self.k & 1], NBYTES, self.T)
+            else:
+                self.pl.submit(d_pcm, self.bufs[self.k & 1], self.d_out, NBYTES, self.T)
             self.k += 1
             return
         if self.arrangement == "staggered":
@@ -940,6 +945,8 @@ def run_rank(args):
     eng = (EmuEngine if emu else GpuEngine)(args, pcm_host, S, T, mode, local_rank)
     can_pipeline = (not emu) and mode == "roundtrip" and max(1, args.hip_streams) == 1
     main_arr = args.arrangement if can_pipeline else "single"
+    if (not emu) and mode == "encode" and max(1, args.hip_streams) == 1 and args.arrangement == "pipeline":
+        main_arr = "pipeline"  # (encode only: lc3gpu_pipeline_encode, +3 % over one stream; the other arrangements need a decoder)
 
     # parity gate, on the arrangement that is timed: two steps from fresh state queued back to back (the second one carries state, and
     # in the pipelined arrangement both byte buffers and all four events are in play), the SECOND step's bitstream and PCM against the

@@ -1594,11 +1594,16 @@ def _bench_line(extra, env_extra, timeout=900):
 
 
 def test_bench_encode_only_mode():
-    """`bench.py --mode encode` (BASELINE config 3 at a small size): one handle, one caller stream, no decoder and no second byte buffer;
-    its parity gate compares the bitstream only"""
-    p, line = _bench_line(["--mode", "encode", "--frames-total", "16384", "--steps", "3", "--warmup", "1", "--sustain-seconds", "0.2"], {})
+    """`bench.py --mode encode` (BASELINE config 3 at a small size): the pipeline object's encode-only form (lc3gpu_pipeline_encode: the
+    groups' encoder chains side by side, two byte buffers) by default, one handle on one caller stream with `--arrangement single`; the
+    parity gate compares the bitstream only"""
+    p, line = _bench_line(["--mode", "encode", "--frames-total", "16384", "--steps", "3", "--warmup", "1", "--sustain-seconds", "0.2", "--arrangement", "single"], {})
     assert p.returncode == 0 and line is not None, p.stderr[-2000:]
     assert "encode" in line["metric"] and line["config"]["mode"] == "encode" and line["config"]["arrangement"] == "single"
+    assert line["parity"]["bitstream_exact"] and line["parity_mismatches_all_ranks"] == 0 and line["kernel_ms"]["lc3_pack_kernel"] > 0.0
+    p, line = _bench_line(["--mode", "encode", "--frames-total", "65536", "--steps", "3", "--warmup", "1", "--sustain-seconds", "0.2"], {})
+    assert p.returncode == 0 and line is not None, p.stderr[-2000:]
+    assert "encode" in line["metric"] and line["config"]["mode"] == "encode" and line["config"]["arrangement"] == "pipeline"
     assert line["parity"]["bitstream_exact"] and line["parity_mismatches_all_ranks"] == 0 and line["other_arrangements"] == []
     assert line["kernel_ms"]["lc3_pack_kernel"] > 0.0 and line["sustained"]["steps"] > 0
 
