@@ -227,9 +227,18 @@ int lc3gpu_host_free(void *p);
  *   lc3gpu_pipeline_group    the channel range and the handles of a group (borrowed: state blobs, PLC / health counters, timing,
  *                            stage events; never destroy them, never call their batch functions while the pipeline has work in flight)
  *   lc3gpu_pipeline_reset    every channel back to the freshly constructed state from the next submission on (no wait)
- * Errors as the batch calls (LC3GPU_EPAIR included). */
+ * Errors as the batch calls (LC3GPU_EPAIR included).
+ * Mixed configurations (lc3gpu_pipeline_create_mixed, BASELINE config 4 through the pipeline): streams of different rates, durations and frame
+ * sizes, descriptors and ragged buffers as for lc3gpu_*_create_mixed / lc3gpu_encode_mixed (8 kHz streams are refused: a pipeline encodes and
+ * decodes); group g takes the descriptors [group_first[g], group_first[g + 1]) (group_first[0] = 0, ascending, n_groups entries; NULL: equal
+ * shares of the list) -- order the list so that every group holds a share of every configuration.  The *_mixed calls take the place of
+ * submit / encode / decode (LC3GPU_EINVAL for the other kind); everything else is common. */
 typedef struct lc3gpu_pipeline lc3gpu_pipeline;
 int lc3gpu_pipeline_create(lc3gpu_pipeline **out, int num_channels, int frame_us, int fs_hz, int n_groups);
+int lc3gpu_pipeline_create_mixed(lc3gpu_pipeline **out, int n_streams, const lc3gpu_stream_desc *descs, int n_groups, const int *group_first);
+int lc3gpu_pipeline_submit_mixed(lc3gpu_pipeline *p, const int16_t *d_pcm, uint8_t *d_bytes, int16_t *d_pcm_out, int n_frames);
+int lc3gpu_pipeline_encode_mixed(lc3gpu_pipeline *p, const int16_t *d_pcm, uint8_t *d_bytes, int n_frames);
+int lc3gpu_pipeline_decode_mixed(lc3gpu_pipeline *p, const uint8_t *d_bytes, const uint8_t *d_bad_frame, int16_t *d_pcm_out, int n_frames);
 int lc3gpu_pipeline_destroy(lc3gpu_pipeline *p);
 int lc3gpu_pipeline_reset(lc3gpu_pipeline *p);
 int lc3gpu_pipeline_submit(lc3gpu_pipeline *p, const int16_t *d_pcm, uint8_t *d_bytes, int16_t *d_pcm_out, int nbytes, int n_frames);

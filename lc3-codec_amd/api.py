@@ -289,6 +289,10 @@ def load_library():
     L.lc3gpu_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
     L.lc3gpu_host_free.argtypes = [vp]
     L.lc3gpu_pipeline_create.argtypes = [ctypes.POINTER(vp), i, i, i, i]
+    L.lc3gpu_pipeline_create_mixed.argtypes = [ctypes.POINTER(vp), i, vp, i, vp]
+    L.lc3gpu_pipeline_submit_mixed.argtypes = [vp, vp, vp, vp, i]
+    L.lc3gpu_pipeline_encode_mixed.argtypes = [vp, vp, vp, i]
+    L.lc3gpu_pipeline_decode_mixed.argtypes = [vp, vp, vp, vp, i]
     L.lc3gpu_pipeline_destroy.argtypes = [vp]
     L.lc3gpu_pipeline_reset.argtypes = [vp]
     L.lc3gpu_pipeline_submit.argtypes = [vp, vp, vp, vp, i, i]
@@ -318,7 +322,8 @@ ABI_SYMBOLS = [
     "lc3gpu_decode_mixed", "lc3gpu_encoder_create_spec", "lc3gpu_encoder_create_mixed_spec", "lc3gpu_clock_probe",
     "lc3gpu_encoder_stage_event", "lc3gpu_decoder_stage_event", "lc3gpu_encoder_pair_timeouts", "lc3gpu_decoder_pair_timeouts",
     "lc3gpu_encoder_debug_pair_giveup", "lc3gpu_decoder_debug_pair_giveup", "lc3gpu_encoder_bind_stream", "lc3gpu_decoder_bind_stream", "lc3gpu_encode_host", "lc3gpu_decode_host", "lc3gpu_host_alloc",
-    "lc3gpu_host_free", "lc3gpu_pipeline_create", "lc3gpu_pipeline_destroy", "lc3gpu_pipeline_reset", "lc3gpu_pipeline_submit",
+    "lc3gpu_host_free", "lc3gpu_pipeline_create", "lc3gpu_pipeline_create_mixed", "lc3gpu_pipeline_submit_mixed", "lc3gpu_pipeline_encode_mixed",
+    "lc3gpu_pipeline_decode_mixed", "lc3gpu_pipeline_destroy", "lc3gpu_pipeline_reset", "lc3gpu_pipeline_submit",
     "lc3gpu_pipeline_encode", "lc3gpu_pipeline_decode", "lc3gpu_pipeline_wait", "lc3gpu_pipeline_join", "lc3gpu_pipeline_follow", "lc3gpu_pipeline_mark",
     "lc3gpu_pipeline_groups", "lc3gpu_pipeline_group", "lc3gpu_pipeline_last_hip_error",
 ]
@@ -570,10 +575,10 @@ class Lc3Encoder:
 
     @classmethod
     def _borrowed(cls, handle, num_channels, frame_duration, sampling_frequency):
-        """a handle somebody else owns (a pipeline's): every method works, close() does not destroy it"""
+        """a handle somebody else owns (a pipeline's): every method works, close() does not destroy it (frame_duration None: a mixed handle)"""
         self = cls.__new__(cls)
         self._L = load_library()
-        self.config = Lc3Config(sampling_frequency, frame_duration)
+        self.config = Lc3Config(sampling_frequency, frame_duration) if frame_duration is not None else None
         self.num_channels = int(num_channels)
         self._h = ctypes.c_void_p(handle)
         self._borrowed_handle = True
@@ -813,6 +818,38 @@ class Lc3Pipeline:
         if rc:
             raise Lc3GpuError(rc, "Lc3Pipeline")
         self._h = h
+        self._collect_groups(frame_duration, sampling_frequency)
+
+    @classmethod
+    def mixed(cls, descs, n_groups=0, group_first=None):
+        """streams of different configurations, descs = [(fs_hz, frame_us, nbytes), ...]; group g takes descs[group_first[g]:group_first[g + 1]]
+        (None: equal shares of the list); ragged buffers as for Lc3Encoder.mixed (lc3gpu_pipeline_create_mixed)"""
+        self = cls.__new__(cls)
+        self._L = load_library()
+        self.descs = [(int(d[0]), int(d[1]), int(d[2])) for d in descs]
+        self.config = None
+        self.num_channels = len(self.descs)
+        h = ctypes.c_void_p()
+        gf = (ctypes.c_int * len(group_first))(*[int(v) for v in group_first]) if group_first is not None else None
+        rc = self._L.lc3gpu_pipeline_create_mixed(ctypes.byref(h), self.num_channels, _desc_array(self.descs),
+                                                  int(len(group_first) if group_first is not None else n_groups), gf)
+        if rc:
+            raise Lc3GpuError(rc, "Lc3Pipeline.mixed")
+        self._h = h
+        self._collect_groups(None, None)
+        return self
+
+    def submit_mixed(self, d_pcm, d_bytes, d_pcm_out, n_frames):
+        self._check(self._L.lc3gpu_pipeline_submit_mixed(self._h, _ptr(d_pcm), _ptr(d_bytes), _ptr(d_pcm_out), int(n_frames)), "pipeline_submit_mixed")
+
+    def encode_mixed(self, d_pcm, d_bytes, n_frames):
+        self._check(self._L.lc3gpu_pipeline_encode_mixed(self._h, _ptr(d_pcm), _ptr(d_bytes), int(n_frames)), "pipeline_encode_mixed")
+
+    def decode_mixed(self, d_bytes, d_pcm_out, n_frames, d_bad_frame=None):
+        self._check(self._L.lc3gpu_pipeline_decode_mixed(self._h, _ptr(d_bytes), _ptr(d_bad_frame), _ptr(d_pcm_out), int(n_frames)), "pipeline_decode_mixed")
+
+    def _collect_groups(self, frame_duration, sampling_frequency):
+        h = self._h
         self.groups = []
         for g in range(self._L.lc3gpu_pipeline_groups(h)):
             first, n, e, d = ctypes.c_int(), ctypes.c_int(), ctypes.c_void_p(), ctypes.c_void_p()

@@ -42,12 +42,16 @@ struct Group {
     // the PCM range the decoder of that submission WRITES (a later encoder may read it: a transcoding chain)
     int last_enc = -1, last_dec = -1;  // slot of the latest encoder / decoder work (for wait / join)
     unsigned long long n_enc = 0, n_dec = 0;  // pieces of work queued per role (a role's slot = its count & 1)
+    // mixed-configuration pipelines (ragged buffers, streams in descriptor order): per FRAME of a submission, the int16 samples and the
+    // bytes of the streams before this group, and of this group's own streams
+    size_t pcm_before = 0, bytes_before = 0, pcm_own = 0, bytes_own = 0;
 };
 }  // namespace
 
 struct lc3gpu_pipeline {
     int device = 0;
     bool own_streams = false;  // the streams were created for this pipeline alone (LC3GPU_PIPELINE_OWN_STREAMS=1) and die with it
+    bool mixed = false;        // lc3gpu_pipeline_create_mixed: per-stream configurations, ragged buffers
     int num_channels = 0, nf = 0;
     unsigned long long k = 0;  // submissions so far
     std::vector<Group> groups;
@@ -152,6 +156,22 @@ int lc3gpu_pipeline_destroy(lc3gpu_pipeline *p) {
     return LC3GPU_OK;
 }
 
+// streams, events and the binding of a group whose handles exist
+static int group_finish(lc3gpu_pipeline *p, Group &q, int g) {
+    // The encoder chain (front half -> vector quantiser -> back half -> packer) is each group's critical path: its stream gets the
+    // higher HIP stream priority.  Streams of another priority also live on hardware queues of their own (see StreamSet).
+    if (role_stream(p->device, p->own_streams, true, g, &q.s_enc) != LC3GPU_OK || role_stream(p->device, p->own_streams, false, g, &q.s_dec) != LC3GPU_OK)
+        return LC3GPU_EHIP;
+    for (int i = 0; i < 2; i++)
+        if (hipEventCreateWithFlags(&q.enc_done[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&q.dec_done[i], hipEventDisableTiming) != hipSuccess)
+            return LC3GPU_EHIP;
+    // the handles only ever run on the group's two streams, which outlive them: no event of their own per call
+    int rc = lc3gpu_encoder_bind_stream(q.enc, q.s_enc, 1);
+    if (rc == LC3GPU_OK) rc = lc3gpu_decoder_bind_stream(q.dec, q.s_dec, 1);
+    return rc;
+}
+
 int lc3gpu_pipeline_create(lc3gpu_pipeline **out, int num_channels, int frame_us, int fs_hz, int n_groups) {
     if (!out || num_channels <= 0 || n_groups < 0 || n_groups > 8) return LC3GPU_EINVAL;
     *out = nullptr;
@@ -179,21 +199,68 @@ int lc3gpu_pipeline_create(lc3gpu_pipeline **out, int num_channels, int frame_us
         const int lo = (int)((long long)quads * g / n_groups) * 4, hi = g + 1 == n_groups ? num_channels : (int)((long long)quads * (g + 1) / n_groups) * 4;
         q.first = lo;
         q.n = hi - lo;
-        // The encoder chain (front half -> vector quantiser -> back half -> packer) is each group's critical path: its stream gets the
-        // higher HIP stream priority.  Streams of another priority also live on hardware queues of their own (see StreamSet).
-        if (role_stream(p->device, p->own_streams, true, g, &q.s_enc) != LC3GPU_OK || role_stream(p->device, p->own_streams, false, g, &q.s_dec) != LC3GPU_OK) {
-            rc = LC3GPU_EHIP;
-            break;
-        }
-        for (int i = 0; i < 2 && rc == LC3GPU_OK; i++)
-            if (hipEventCreateWithFlags(&q.enc_done[i], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&q.dec_done[i], hipEventDisableTiming) != hipSuccess)
-                rc = LC3GPU_EHIP;
-        if (rc == LC3GPU_OK) rc = lc3gpu_encoder_create(&q.enc, q.n, frame_us, fs_hz);
+        rc = lc3gpu_encoder_create(&q.enc, q.n, frame_us, fs_hz);
         if (rc == LC3GPU_OK) rc = lc3gpu_decoder_create(&q.dec, q.n, frame_us, fs_hz);
-        // the handles only ever run on the group's two streams, which outlive them: no event of their own per call
-        if (rc == LC3GPU_OK) rc = lc3gpu_encoder_bind_stream(q.enc, q.s_enc, 1);
-        if (rc == LC3GPU_OK) rc = lc3gpu_decoder_bind_stream(q.dec, q.s_dec, 1);
+        if (rc == LC3GPU_OK) rc = group_finish(p, q, g);
+    }
+    if (rc == LC3GPU_OK && hipEventCreateWithFlags(&p->ev_follow, hipEventDisableTiming) != hipSuccess) rc = LC3GPU_EHIP;
+    if (rc) {
+        if (rc == LC3GPU_EHIP) (void)hipGetLastError();
+        lc3gpu_pipeline_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return LC3GPU_OK;
+}
+
+// Streams of different configurations in one pipeline (BASELINE config 4 through the pipeline object): the reference would build one
+// Lc3Encoder / Lc3Decoder per configuration (encoder/lc3_encoder.rs:117-124, common/config.rs:42-100) and loop over them; here group g
+// takes the descriptors [group_first[g], group_first[g + 1]) -- the caller chooses the boundaries, e.g. so that every group holds a share
+// of every configuration -- with a mixed encoder handle and a mixed decoder handle of its own.  8 kHz streams are refused as by
+// lc3gpu_encoder_create_mixed (a pipeline encodes AND decodes; decode-only streams belong to a plain decoder handle).
+int lc3gpu_pipeline_create_mixed(lc3gpu_pipeline **out, int n_streams, const lc3gpu_stream_desc *descs, int n_groups, const int *group_first) {
+    if (!out || n_streams <= 0 || !descs || n_groups < 0 || n_groups > 8) return LC3GPU_EINVAL;
+    *out = nullptr;
+    if (lc3gpu_device_count() <= 0) return LC3GPU_ENODEVICE;
+    if (n_groups == 0) n_groups = 2;
+    if (n_groups > n_streams) n_groups = n_streams;
+    std::vector<int> first((size_t)n_groups + 1);
+    for (int g = 0; g <= n_groups; g++) first[(size_t)g] = g == n_groups ? n_streams : (group_first ? group_first[g] : (int)((long long)n_streams * g / n_groups));
+    if (first[0] != 0) return LC3GPU_EINVAL;
+    for (int g = 0; g < n_groups; g++)
+        if (first[(size_t)g + 1] <= first[(size_t)g]) return LC3GPU_EINVAL;
+    lc3gpu_pipeline *p = new (std::nothrow) lc3gpu_pipeline();
+    if (!p) return LC3GPU_EINVAL;
+    p->num_channels = n_streams;
+    p->mixed = true;
+    if (hipGetDevice(&p->device) != hipSuccess) {
+        delete p;
+        return LC3GPU_EHIP;
+    }
+    p->own_streams = env_is("LC3GPU_PIPELINE_OWN_STREAMS", "1");
+    p->groups.resize((size_t)n_groups);
+    int rc = LC3GPU_OK;
+    size_t pcm_run = 0, bytes_run = 0;
+    for (int g = 0; g < n_groups && rc == LC3GPU_OK; g++) {
+        Group &q = p->groups[(size_t)g];
+        q.first = first[(size_t)g];
+        q.n = first[(size_t)g + 1] - q.first;
+        q.pcm_before = pcm_run;
+        q.bytes_before = bytes_run;
+        for (int i = q.first; i < q.first + q.n && rc == LC3GPU_OK; i++) {
+            int cfg[7];
+            rc = lc3gpu_config(descs[i].frame_us, descs[i].fs_hz, cfg);
+            if (rc == LC3GPU_OK && (descs[i].nbytes < 20 || descs[i].nbytes > 400)) rc = LC3GPU_ELENGTH;
+            if (rc == LC3GPU_OK) {
+                q.pcm_own += (size_t)cfg[5];
+                q.bytes_own += (size_t)descs[i].nbytes;
+            }
+        }
+        pcm_run += q.pcm_own;
+        bytes_run += q.bytes_own;
+        if (rc == LC3GPU_OK) rc = lc3gpu_encoder_create_mixed(&q.enc, q.n, descs + q.first);
+        if (rc == LC3GPU_OK) rc = lc3gpu_decoder_create_mixed(&q.dec, q.n, descs + q.first);
+        if (rc == LC3GPU_OK) rc = group_finish(p, q, g);
     }
     if (rc == LC3GPU_OK && hipEventCreateWithFlags(&p->ev_follow, hipEventDisableTiming) != hipSuccess) rc = LC3GPU_EHIP;
     if (rc) {
@@ -255,17 +322,23 @@ static int pipeline_step(lc3gpu_pipeline *p, int what, const int16_t *d_pcm, uin
                          int n_frames) {
     if (!p || !d_bytes || ((what & 1) && !d_pcm) || ((what & 2) && !d_pcm_out)) return LC3GPU_EINVAL;
     if (n_frames <= 0) return LC3GPU_ELENGTH;
+    if (p->mixed != (nbytes < 0)) return LC3GPU_EINVAL;  // (the mixed entry points pass nbytes = -1: frame sizes are the descriptors')
     DeviceGuard dg(p->device);
     int rc = LC3GPU_OK;
     for (Group &q : p->groups) {
+        // the group's slice of every buffer: uniform [channel][frame][..] planar; mixed ragged, streams in descriptor order
         const size_t f0 = (size_t)q.first * (size_t)n_frames;
-        uint8_t *bytes = d_bytes + f0 * (size_t)nbytes;
-        const uint8_t *bytes_end = bytes + (size_t)q.n * (size_t)n_frames * (size_t)nbytes;
+        const size_t pcm_off = p->mixed ? q.pcm_before * (size_t)n_frames : f0 * (size_t)p->nf;
+        const size_t bytes_off = p->mixed ? q.bytes_before * (size_t)n_frames : f0 * (size_t)nbytes;
+        const size_t bytes_len = p->mixed ? q.bytes_own * (size_t)n_frames : (size_t)q.n * (size_t)n_frames * (size_t)nbytes;
+        uint8_t *bytes = d_bytes + bytes_off;
+        const uint8_t *bytes_end = bytes + bytes_len;
         if (what & 1) {
             // the encoder may not overwrite bytes a decoder still reads
             if ((rc = wait_for_other_role(p, q.s_enc, bytes, bytes_end, q.dec_done, q.dec_rec, q.bytes_lo, q.bytes_hi, q.n_dec)) != 0) return rc;
             if ((rc = follow_wait(p, q.s_enc)) != 0) return rc;
-            rc = lc3gpu_encode(q.enc, d_pcm + f0 * (size_t)p->nf, bytes, nbytes, n_frames, q.s_enc);
+            rc = p->mixed ? lc3gpu_encode_mixed(q.enc, d_pcm + pcm_off, bytes, n_frames, q.s_enc)
+                          : lc3gpu_encode(q.enc, d_pcm + pcm_off, bytes, nbytes, n_frames, q.s_enc);
             if (rc) return rc;
             const int b = (int)(q.n_enc & 1ull);
             PL_HIP(p, hipEventRecord(q.enc_done[b], q.s_enc));
@@ -280,7 +353,8 @@ static int pipeline_step(lc3gpu_pipeline *p, int what, const int16_t *d_pcm, uin
             if ((rc = wait_for_other_role(p, q.s_dec, bytes, bytes_end, q.enc_done, q.enc_rec, q.ebytes_lo, q.ebytes_hi, q.n_enc)) != 0) return rc;
             if ((rc = follow_wait(p, q.s_dec)) != 0) return rc;
             const uint8_t *bad = d_bad ? d_bad + f0 : nullptr;
-            rc = lc3gpu_decode(q.dec, bytes, bad, d_pcm_out + f0 * (size_t)p->nf, nbytes, n_frames, q.s_dec);
+            rc = p->mixed ? lc3gpu_decode_mixed(q.dec, bytes, bad, d_pcm_out + pcm_off, n_frames, q.s_dec)
+                          : lc3gpu_decode(q.dec, bytes, bad, d_pcm_out + pcm_off, nbytes, n_frames, q.s_dec);
             if (rc) return rc;
             const int b = (int)(q.n_dec & 1ull);
             PL_HIP(p, hipEventRecord(q.dec_done[b], q.s_dec));
@@ -304,6 +378,16 @@ int lc3gpu_pipeline_encode(lc3gpu_pipeline *p, const int16_t *d_pcm, uint8_t *d_
 }
 int lc3gpu_pipeline_decode(lc3gpu_pipeline *p, const uint8_t *d_bytes, const uint8_t *d_bad_frame, int16_t *d_pcm_out, int nbytes, int n_frames) {
     return pipeline_step(p, 2, nullptr, (uint8_t *)d_bytes, d_bad_frame, d_pcm_out, nbytes, n_frames);
+}
+
+int lc3gpu_pipeline_submit_mixed(lc3gpu_pipeline *p, const int16_t *d_pcm, uint8_t *d_bytes, int16_t *d_pcm_out, int n_frames) {
+    return pipeline_step(p, 3, d_pcm, d_bytes, nullptr, d_pcm_out, -1, n_frames);
+}
+int lc3gpu_pipeline_encode_mixed(lc3gpu_pipeline *p, const int16_t *d_pcm, uint8_t *d_bytes, int n_frames) {
+    return pipeline_step(p, 1, d_pcm, d_bytes, nullptr, nullptr, -1, n_frames);
+}
+int lc3gpu_pipeline_decode_mixed(lc3gpu_pipeline *p, const uint8_t *d_bytes, const uint8_t *d_bad_frame, int16_t *d_pcm_out, int n_frames) {
+    return pipeline_step(p, 2, nullptr, (uint8_t *)d_bytes, d_bad_frame, d_pcm_out, -1, n_frames);
 }
 
 int lc3gpu_pipeline_wait(lc3gpu_pipeline *p) {

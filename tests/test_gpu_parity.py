@@ -1051,6 +1051,51 @@ def test_mixed_configuration_batch():
         enc.encode(d_pcm, d_b, 40, T)  # the uniform batch call is refused on a mixed handle
 
 
+def test_mixed_configuration_pipeline():
+    """lc3gpu_pipeline_create_mixed: the ten encodable configurations of BASELINE config 4 through the pipeline object -- streams of every
+    configuration in every group (the caller's order interleaves them), ragged buffers, two submissions with two byte buffers, state
+    carried -- byte-exact / 0 LSB against the per-configuration oracle; uneven group boundaries given by the caller; 8 kHz refused; the
+    uniform calls refused on a mixed pipeline and the other way round."""
+    t = torch_mod()
+    S, T = 24, 3
+    per_cfg, order = _mixed_setup(S, 2 * T, seed=43)
+    order = [(k, i) for (k, i) in order if MIXED[k][0] != 8000]
+    descs = [MIXED[k] for k, _ in order]
+    for kwargs in ({"n_groups": 2}, {"group_first": [0, 7, 100]}, {"n_groups": 1}):
+        pl = pkg.Lc3Pipeline.mixed(descs, **kwargs)
+        assert sum(g["n"] for g in pl.groups) == len(descs)
+        if "group_first" in kwargs:
+            assert [g["first"] for g in pl.groups] == kwargs["group_first"]
+        d_b = [t.zeros(sum(T * d[2] for d in descs), dtype=t.uint8, device="cuda") for _ in range(2)]
+        for step, t0 in enumerate((0, T)):
+            d_pcm = t.from_numpy(np.concatenate([per_cfg[k]["pcm"][i, t0:t0 + T].reshape(-1) for k, i in order])).cuda()
+            d_out = t.zeros(sum(T * per_cfg[k]["nf"] for k, _ in order), dtype=t.int16, device="cuda")
+            pl.submit_mixed(d_pcm, d_b[step], d_out, T)
+            pl.wait()
+            gb, gp = d_b[step].cpu().numpy(), d_out.cpu().numpy()
+            ob = op = 0
+            for k, i in order:
+                nb_, nf_ = T * MIXED[k][2], T * per_cfg[k]["nf"]
+                assert np.array_equal(gb[ob:ob + nb_].reshape(T, -1), per_cfg[k]["ref_b"][i, t0:t0 + T]), (kwargs, MIXED[k], i, t0)
+                assert np.array_equal(gp[op:op + nf_].reshape(T, -1), per_cfg[k]["ref_p"][i, t0:t0 + T]), (kwargs, MIXED[k], i, t0)
+                ob += nb_
+                op += nf_
+        with pytest.raises(pkg.Lc3GpuError) as e1:
+            pl.submit(d_pcm, d_b[0], d_out, 150, T)
+        assert e1.value.code == -1
+        pl.close()
+    with pytest.raises(pkg.Lc3GpuError) as e8:
+        pkg.Lc3Pipeline.mixed([(48000, 10000, 150), (8000, 10000, 30)])
+    assert e8.value.code == -7
+    with pytest.raises(pkg.Lc3GpuError):
+        pkg.Lc3Pipeline.mixed(descs, group_first=[0, 50, 50])  # an empty group
+    pu = pkg.Lc3Pipeline(8, US, FS)
+    with pytest.raises(pkg.Lc3GpuError) as e2:
+        pu.submit_mixed(d_pcm, d_b[0], d_out, T)
+    assert e2.value.code == -1
+    pu.close()
+
+
 def test_mixed_batch_bad_frames_and_plc_counter():
     """external bad-frame flags on a mixed decoder: the flag array is in the caller's stream order; flagged frames are concealed
     like frames with unparsable side information in the oracle (48 kHz streams: bandwidth index 7 does not exist)"""
